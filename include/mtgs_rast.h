@@ -1,0 +1,136 @@
+/*
+ * mtgs_rast.h -- C ABI of libmtgs_rast.so, the MI355X (gfx950) Gaussian-splatting rasterizer
+ * that sits behind gsplat 1.4.0's Python API for OpenDriveLab/MTGS.
+ *
+ * What each entry point replaces
+ * ------------------------------
+ * MTGS reaches the rasterizer through exactly two Python functions (reference @ 2025-09-12):
+ *   gsplat.rendering.rasterization(...)          mtgs/scene_model/mtgs_scene_graph.py:20-23, :641-662
+ *   gsplat.cuda._wrapper.spherical_harmonics()   mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:15-18, :317
+ *                                                multi_color_gaussian_splatting.py:96, rigid_node.py:248, deformable_node.py:125
+ * gsplat (pinned v1.4.0, requirements.txt:12) lowers those two functions onto a fixed set of
+ * native operators (its `gsplat.cuda._wrapper._make_lazy_cuda_func` table: compute_sh_fwd/bwd,
+ * fully_fused_projection_fwd/bwd, isect_tiles, isect_offset_encode, rasterize_to_pixels_fwd/bwd,
+ * plus cub::DeviceRadixSort inside isect_tiles).  The functions below are that operator table,
+ * one for one, as a plain C ABI: the binding a maintainer would write is in INTEGRATION.md.
+ *
+ * Conventions
+ * -----------
+ *  - Every pointer is a DEVICE pointer into caller-owned memory (PyTorch's allocator in the
+ *    shipped host code).  The library never allocates, frees, retains a pointer or synchronises.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *    All work is enqueued on it; the call returns immediately.
+ *  - Dense row-major fp32 / int32 / int64 arrays, shapes given per argument.  C = cameras,
+ *    N = Gaussians, M = tile/Gaussian intersections, D = colour channels, K = SH bases.
+ *  - Return value: 0 = MTGS_OK, otherwise an MTGS_E* code; mtgs_rast_last_error() returns a
+ *    thread-local message for the last failing call on this thread.
+ *  - Re-entrant: no global mutable state apart from the thread-local error string.
+ *  - Optional pointers are marked "nullable".
+ */
+#ifndef MTGS_RAST_H
+#define MTGS_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTGS_RAST_ABI_VERSION 1
+
+enum {
+    MTGS_OK = 0,
+    MTGS_EINVAL = 1,      /* bad argument (null pointer, negative size, unsupported option) */
+    MTGS_ELAUNCH = 2,     /* hipGetLastError() after a launch reported a failure */
+    MTGS_EWORKSPACE = 3,  /* workspace too small */
+    MTGS_EUNSUPPORTED = 4 /* valid in gsplat, not implemented here (named in the message) */
+};
+
+/* Fixed algorithm constants (gsplat 1.4.0 semantics; see oracle/gsplat_oracle.c for citations) */
+#define MTGS_TILE_SIZE 16
+#define MTGS_ALPHA_MAX 0.999f
+#define MTGS_ALPHA_MIN (1.0f / 255.0f)
+#define MTGS_T_MIN 1e-4f
+#define MTGS_MAX_SH_DEGREE 4
+#define MTGS_MAX_CHANNELS 32 /* blended colour channels per launch (gsplat channel_chunk default) */
+
+int mtgs_rast_version(void);
+const char *mtgs_rast_last_error(void);
+
+/* ---- spherical harmonics: gsplat compute_sh_fwd / compute_sh_bwd ------------------------------
+ * dirs[n,3] (need not be unit), coeffs[n,K,3], masks[n] (nullable, 0 = skip: output/grads zero),
+ * colors[n,3].  degree <= 4 and (degree+1)^2 <= K.  v_dirs nullable (MTGS passes detached dirs). */
+int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
+                const uint8_t *masks, float *colors, void *stream);
+int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
+                const uint8_t *masks, const float *v_colors, float *v_coeffs, float *v_dirs,
+                void *stream);
+
+/* ---- projection: gsplat fully_fused_projection_fwd / _bwd (pinhole, packed=False) -------------
+ * means[N,3] quats[N,4] (wxyz, any norm) scales[N,3] viewmats[C,4,4] (world->cam) Ks[C,3,3].
+ * out: radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3] (a,b,c of the
+ * inverse 2x2 covariance), compensations[C,N] (nullable; antialiased mode).  Culled rows of the
+ * float outputs are written as zeros.
+ * bwd: v_means[N,3] v_quats[N,4] v_scales[N,3] are OVERWRITTEN (summed over cameras);
+ * v_viewmats[C,4,4] nullable, overwritten. */
+int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                     const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                     float near_plane, float far_plane, float radius_clip, int32_t *radii,
+                     float *means2d, float *depths, float *conics, float *compensations,
+                     void *stream);
+int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                     const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                     const int32_t *radii, const float *conics, const float *compensations,
+                     const float *v_means2d, const float *v_depths, const float *v_conics,
+                     const float *v_compensations, float *v_means, float *v_quats, float *v_scales,
+                     float *v_viewmats, void *stream);
+
+/* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
+ * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
+ * mtgs_isect_scan  : cum_tiles[C*N] i64 = inclusive prefix sum; total[1] i64 = M (device).
+ *                    ws from mtgs_scan_workspace_bytes.
+ * mtgs_isect_emit  : isect_ids[M] i64 = cam<<(32+tile_bits) | tile<<32 | bits(depth),
+ *                    flatten_ids[M] i32 = c*N+n, row-major over each Gaussian's tile rectangle. */
+int mtgs_isect_count(int C, int64_t N, const float *means2d, const int32_t *radii, int tile_size,
+                     int tile_w, int tile_h, int32_t *tiles_per_gauss, void *stream);
+int mtgs_scan_workspace_bytes(int64_t n, size_t *bytes);
+int mtgs_isect_scan(int64_t n, const int32_t *tiles_per_gauss, int64_t *cum_tiles, int64_t *total,
+                    void *ws, size_t ws_bytes, void *stream);
+int mtgs_isect_emit(int C, int64_t N, const float *means2d, const int32_t *radii,
+                    const float *depths, const int64_t *cum_tiles, int tile_size, int tile_w,
+                    int tile_h, int64_t *isect_ids, int32_t *flatten_ids, void *stream);
+
+/* ---- radix sort: the cub::DeviceRadixSort::SortPairs call inside gsplat isect_tiles ----------
+ * Stable LSD sort of (i64 key, i32 value) on key bits [0, key_bits).  Output in keys_out/vals_out;
+ * inputs are clobbered (used as the alternate buffer). */
+int mtgs_sort_workspace_bytes(int64_t M, size_t *bytes);
+int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in, int64_t *keys_out,
+                    int32_t *vals_out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- gsplat isect_offset_encode: offsets[C,tile_h,tile_w] i32 = first sorted index per tile --- */
+int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int tile_w, int tile_h,
+                       int32_t *offsets, void *stream);
+
+/* ---- compositing: gsplat rasterize_to_pixels_fwd / _bwd ---------------------------------------
+ * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (nullable).
+ * out: render[C,H,W,D] alphas[C,H,W] last_ids[C,H,W] i32 (index into the sorted list).
+ * bwd: v_means2d[C,N,2] v_conics[C,N,3] v_colors[C,N,D] v_opacities[C,N] and v_means2d_abs
+ * (nullable, absgrad) must be ZERO-FILLED by the caller; gradients are accumulated with atomics. */
+int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
+                   const float *colors, const float *opacities, const float *backgrounds, int width,
+                   int height, int tile_size, int tile_w, int tile_h, const int32_t *offsets,
+                   const int32_t *flatten_ids, int64_t M, float *render, float *alphas,
+                   int32_t *last_ids, void *stream);
+int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
+                   const float *colors, const float *opacities, const float *backgrounds, int width,
+                   int height, int tile_size, int tile_w, int tile_h, const int32_t *offsets,
+                   const int32_t *flatten_ids, int64_t M, const float *alphas,
+                   const int32_t *last_ids, const float *v_render, const float *v_alphas,
+                   float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
+                   float *v_opacities, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTGS_RAST_H */
