@@ -1,0 +1,15 @@
+"""mtgs_amd -- MI355X (gfx950) Gaussian-splatting rasterizer behind gsplat 1.4.0's Python API,
+the hot path of OpenDriveLab/MTGS (rasterization() + spherical_harmonics()).
+
+    from mtgs_amd import rasterization, spherical_harmonics      # or: `import gsplat` (shim package)
+
+Importing this package does not load the HIP library or touch the GPU; the first operator call
+does, and raises if libmtgs_rast.so has not been built (python -m mtgs_amd.build).
+"""
+from .rendering import rasterization
+from .wrapper import (fully_fused_projection, isect_offset_encode, isect_tiles, rasterize_to_pixels,
+                      spherical_harmonics)
+
+__version__ = "0.1.0"
+__all__ = ["rasterization", "spherical_harmonics", "fully_fused_projection", "isect_tiles",
+           "isect_offset_encode", "rasterize_to_pixels"]

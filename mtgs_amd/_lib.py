@@ -1,0 +1,88 @@
+"""ctypes binding of libmtgs_rast.so (include/mtgs_rast.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  Nothing here (or anywhere under mtgs_amd/) touches oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libmtgs_rast.so"
+
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes (restype is int for all but the two introspection calls)
+_SIGNATURES = {
+    "mtgs_sh_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_sh_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_project_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
+                         _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
+                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],
+    "mtgs_isect_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mtgs_isect_emit": [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "mtgs_sort_workspace_bytes": [_i64, C.POINTER(_sz)],
+    "mtgs_sort_pairs": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
+    "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                       _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "mtgs_blend_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
+ABI_VERSION = 1
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the library (does not initialise the GPU).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m mtgs_amd.build` (needs hipcc). "
+            "mtgs_amd has no CPU or PyTorch fallback for the rasterizer.")
+    lib = C.CDLL(str(LIB_PATH))
+    lib.mtgs_rast_version.restype = C.c_int
+    lib.mtgs_rast_last_error.restype = C.c_char_p
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    v = lib.mtgs_rast_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libmtgs_rast.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        msg = load().mtgs_rast_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
+def require_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "mtgs_amd: tensors must live on the HIP device (torch device 'cuda'); got "
+                f"{t.device}. There is no CPU fallback in the product path.")

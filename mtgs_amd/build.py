@@ -1,0 +1,78 @@
+"""Builds mtgs_amd/libmtgs_rast.so (gfx950) from mtgs_amd/csrc/*.hip with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels with the tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "_obj"
+LIB = PKG / "libmtgs_rast.so"
+ARCH = "gfx950"
+
+COMMON_FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+    "-Wall", "-Wno-unused-function", f"-I{PKG.parent / 'include'}",
+]
+# The projection forward must round after every operation (bit-exact tile binning inputs).
+PER_FILE_FLAGS = {"project.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    OBJ.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "mtgs_rast.h", Path(__file__)]
+    jobs = []
+    for src in sources():
+        obj = OBJ / (src.stem + ".o")
+        if force or _stale(obj, [src] + headers):
+            cmd = [hipcc, "-c", str(src), "-o", str(obj)] + COMMON_FLAGS + PER_FILE_FLAGS.get(src.name, [])
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        return r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for warn in ex.map(run, jobs):
+                if verbose and warn:
+                    print(warn, file=sys.stderr)
+    objs = [OBJ / (s.stem + ".o") for s in sources()]
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,414 @@
+// blend.hip -- per-tile front-to-back alpha compositing, forward and backward.
+//
+// Replaces gsplat 1.4.0 rasterize_to_pixels_fwd / rasterize_to_pixels_bwd, the last stage of
+// gsplat.rendering.rasterization (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:641-662).
+//
+// CDNA4 design (not gsplat's 256-thread / 1-pixel-per-thread CUDA layout):
+//  * ONE WAVE PER 16x16 TILE, 4 PIXELS PER LANE (lane l owns column l%16 of rows l/16 + {0,4,8,12}).
+//    A tile is a single wavefront, so there is no workgroup barrier anywhere in the hot loop,
+//    early termination is one ballot, and in the backward the cross-lane reduction of every
+//    per-Gaussian gradient is amortised over 4 pixels per lane and issues ONE set of atomics per
+//    (tile, Gaussian) instead of one per 32-thread warp (8 per tile in the reference layout).
+//  * Per-tile Gaussian chunks are staged through LDS 64 at a time (coalesced flatten_ids read,
+//    gathered attribute rows), then consumed as wave-uniform broadcast ds_read_b128.
+//  * Cross-lane sums use DPP-modified v_add_f32 (6 VALU ops per value, no LDS traffic).
+//  * fp32 atomics are the hardware global_atomic_add_f32 (unsafeAtomicAdd).
+//  * blockIdx -> tile mapping is XCD-aware: workgroup b runs on XCD b%8, so each XCD is given a
+//    contiguous band of tiles and neighbouring tiles (which share Gaussians) share an L2.
+//  * Wide channel counts (D > 8) fall back to 1 pixel per lane / 4 waves per tile.
+//
+// Roofline: the kernels are VALU/LDS bound (about 25 / 70 flops per pixel x Gaussian pair, fwd /
+// bwd) -- MFMA is deliberately unused, there is no dense contraction.  Algorithmic HBM bytes:
+//   fwd: M*(4 + 24 + 4D) gathered attributes + P*(4D + 8) written
+//   bwd: P*(4D + 12) read + M*(4 + 24 + 4D) gathered + N_vis*(24 + 4D (+8 absgrad)) accumulated
+#include "common.hpp"
+
+namespace {
+
+constexpr float kAlphaMax = MTGS_ALPHA_MAX;
+constexpr float kAlphaMin = MTGS_ALPHA_MIN;
+constexpr float kTMin = MTGS_T_MIN;
+
+template <int D>
+struct Rec {  // LDS record per staged Gaussian, in floats: x y a b | c opac col[D] (padded to x4)
+    static constexpr int N = ((6 + D + 3) / 4) * 4;
+};
+
+// XCD-aware block -> tile mapping (speed only; any mapping is correct).
+__device__ __forceinline__ int64_t block_to_tile(int64_t total_tiles) {
+    const int64_t chunk = (total_tiles + 7) / 8;
+    const int64_t b = blockIdx.x;
+    return (b & 7) * chunk + (b >> 3);
+}
+
+template <int D, int NT>
+__device__ __forceinline__ void stage_batch(float *__restrict__ s_rec, int32_t *__restrict__ s_id,
+                                            const int32_t *__restrict__ flatten_ids,
+                                            const float *__restrict__ means2d,
+                                            const float *__restrict__ conics,
+                                            const float *__restrict__ colors,
+                                            const float *__restrict__ opacities, int64_t idx,
+                                            bool in_range) {
+    constexpr int REC = Rec<D>::N;
+    const int tid = threadIdx.x;
+    if (in_range) {
+        const int32_t g = flatten_ids[idx];
+        const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
+        const float ca = conics[(int64_t)g * 3], cb = conics[(int64_t)g * 3 + 1], cc = conics[(int64_t)g * 3 + 2];
+        const float op = opacities[g];
+        float r[REC];
+        r[0] = xy.x; r[1] = xy.y; r[2] = ca; r[3] = cb; r[4] = cc; r[5] = op;
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[6 + k] = colors[(int64_t)g * D + k];
+#pragma unroll
+        for (int k = 6 + D; k < REC; ++k) r[k] = 0.f;
+        float4 *dst = reinterpret_cast<float4 *>(s_rec + tid * REC);
+#pragma unroll
+        for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+        if (s_id) s_id[tid] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D, int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
+    int C, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ backgrounds, int W, int H, int tw, int th,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
+    constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
+    __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
+    const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
+    const int64_t tile = block_to_tile(total_tiles);
+    if (tile >= total_tiles) return;
+    const int cam = (int)(tile / n_tiles);
+    const int t_in = (int)(tile - (int64_t)cam * n_tiles);
+    const int ty = t_in / tw, tx = t_in - ty * tw;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ix = tx * 16 + lx;
+    const float px = (float)ix + 0.5f;
+    int iy[PPL];
+    float py[PPL], T[PPL], acc[PPL][D];
+    int32_t last[PPL];
+    bool done[PPL], inside[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        iy[p] = ty * 16 + ly + p * ROWS;
+        py[p] = (float)iy[p] + 0.5f;
+        inside[p] = ix < W && iy[p] < H;
+        done[p] = !inside[p];
+        T[p] = 1.f;
+        last[p] = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc[p][k] = 0.f;
+    }
+    const int64_t start = offsets[tile];
+    const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
+
+    for (int64_t b0 = start; b0 < end; b0 += NT) {
+        bool all_done = true;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) all_done = all_done && done[p];
+        if (__syncthreads_and(all_done)) break;
+        stage_batch<D, NT>(s_rec, nullptr, flatten_ids, means2d, conics, colors, opacities, b0 + tid, b0 + tid < end);
+        __syncthreads();
+        const int bsz = (int)min((int64_t)NT, end - b0);
+        for (int t = 0; t < bsz; ++t) {
+            const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
+            const float2 r1 = *reinterpret_cast<const float2 *>(s_rec + t * REC + 4);
+            const float dx = r0.x - px;
+            float alpha[PPL];
+            bool valid[PPL], any = false;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                const float dy = r0.y - py[p];
+                const float sigma = 0.5f * (r0.z * dx * dx + r1.x * dy * dy) + r0.w * dx * dy;
+                const float vis = __expf(-sigma);
+                alpha[p] = fminf(kAlphaMax, r1.y * vis);
+                valid[p] = !done[p] && sigma >= 0.f && alpha[p] >= kAlphaMin;
+                any = any || valid[p];
+            }
+            if (!__any(any)) continue;
+            float col[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 6 + k];
+            bool stopped = false;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                if (valid[p]) {
+                    const float next_T = T[p] * (1.f - alpha[p]);
+                    if (next_T <= kTMin) {
+                        done[p] = true;
+                        stopped = true;
+                    } else {
+                        const float w = alpha[p] * T[p];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
+                        last[p] = (int32_t)(b0 + t);
+                        T[p] = next_T;
+                    }
+                }
+            }
+            if (__any(stopped)) {
+                bool ad = true;
+#pragma unroll
+                for (int p = 0; p < PPL; ++p) ad = ad && done[p];
+                if (__all(ad)) break;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        if (inside[p]) {
+            const int64_t pid = ((int64_t)cam * H + iy[p]) * W + ix;
+            alphas[pid] = 1.f - T[p];
+            last_ids[pid] = last[p];
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                render[pid * D + k] = backgrounds ? acc[p][k] + T[p] * backgrounds[cam * D + k] : acc[p][k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D, int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
+    int C, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ backgrounds, int W, int H, int tw, int th,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids,
+    const float *__restrict__ v_render, const float *__restrict__ v_alphas,
+    float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
+    float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
+    __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
+    __shared__ int32_t s_id[NT];
+    __shared__ int32_t s_max[NT / 64];
+    const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
+    const int64_t tile = block_to_tile(total_tiles);
+    if (tile >= total_tiles) return;
+    const int64_t start = offsets[tile];
+    const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
+    if (end <= start) return;
+    const int cam = (int)(tile / n_tiles);
+    const int t_in = (int)(tile - (int64_t)cam * n_tiles);
+    const int ty = t_in / tw, tx = t_in - ty * tw;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4, lane = tid & 63;
+    const int ix = tx * 16 + lx;
+    const float px = (float)ix + 0.5f;
+    float py[PPL], T[PPL], T_final[PPL], buf[PPL][D], vr[PPL][D], va[PPL], bgd[PPL];
+    int32_t bin_final[PPL];
+    int32_t my_max = -1;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        const int iy = ty * 16 + ly + p * ROWS;
+        py[p] = (float)iy + 0.5f;
+        const bool inside = ix < W && iy < H;
+        const int64_t pid = ((int64_t)cam * H + (inside ? iy : 0)) * W + (inside ? ix : 0);
+        T_final[p] = 1.f - alphas[pid];
+        T[p] = T_final[p];
+        va[p] = v_alphas[pid];
+        bin_final[p] = inside ? last_ids[pid] : -1;
+        my_max = max(my_max, bin_final[p]);
+        bgd[p] = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            buf[p][k] = 0.f;
+            vr[p][k] = v_render[pid * D + k];
+            if (backgrounds) bgd[p] += backgrounds[cam * D + k] * vr[p][k];
+        }
+    }
+    // tile-wide newest contributor
+    int32_t wmax = wave_max_i32(my_max);
+    if (NT > 64) {
+        if (lane == 0) s_max[tid >> 6] = wmax;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) wmax = max(wmax, s_max[w]);
+    }
+    const int64_t top = wmax;  // sorted index of the last Gaussian any pixel of the tile used
+    const bool absgrad = v_means2d_abs != nullptr;
+
+    for (int64_t hi = top; hi >= start; hi -= NT) {
+        if (hi != top) __syncthreads();
+        stage_batch<D, NT>(s_rec, s_id, flatten_ids, means2d, conics, colors, opacities, hi - tid, hi - tid >= start);
+        __syncthreads();
+        const int bsz = (int)min((int64_t)NT, hi - start + 1);
+        for (int t = 0; t < bsz; ++t) {
+            const int32_t idx = (int32_t)(hi - t);
+            const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
+            const float2 r1 = *reinterpret_cast<const float2 *>(s_rec + t * REC + 4);
+            const float opac = r1.y;
+            const float dx = r0.x - px;
+            float dy[PPL], vis[PPL], alpha[PPL];
+            bool valid[PPL], any = false;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                dy[p] = r0.y - py[p];
+                const float sigma = 0.5f * (r0.z * dx * dx + r1.x * dy[p] * dy[p]) + r0.w * dx * dy[p];
+                vis[p] = __expf(-sigma);
+                alpha[p] = fminf(kAlphaMax, opac * vis[p]);
+                valid[p] = idx <= bin_final[p] && sigma >= 0.f && alpha[p] >= kAlphaMin;
+                any = any || valid[p];
+            }
+            if (!__any(any)) continue;
+            float col[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 6 + k];
+            float g_xy0 = 0.f, g_xy1 = 0.f, g_ab0 = 0.f, g_ab1 = 0.f, g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_op = 0.f;
+            float g_col[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) g_col[k] = 0.f;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                if (valid[p]) {
+                    const float ra = 1.0f / (1.0f - alpha[p]);
+                    T[p] *= ra;
+                    const float fac = alpha[p] * T[p];
+                    float v_alpha = 0.f;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        g_col[k] += fac * vr[p][k];
+                        v_alpha += (col[k] * T[p] - buf[p][k] * ra) * vr[p][k];
+                        buf[p][k] += col[k] * fac;
+                    }
+                    v_alpha += T_final[p] * ra * va[p];
+                    if (backgrounds) v_alpha += -T_final[p] * ra * bgd[p];
+                    if (opac * vis[p] <= kAlphaMax) {
+                        const float v_sigma = -opac * vis[p] * v_alpha;
+                        g_c0 += 0.5f * v_sigma * dx * dx;
+                        g_c1 += v_sigma * dx * dy[p];
+                        g_c2 += 0.5f * v_sigma * dy[p] * dy[p];
+                        const float vx = v_sigma * (r0.z * dx + r0.w * dy[p]);
+                        const float vy = v_sigma * (r0.w * dx + r1.x * dy[p]);
+                        g_xy0 += vx; g_xy1 += vy;
+                        g_ab0 += fabsf(vx); g_ab1 += fabsf(vy);
+                        g_op += vis[p] * v_alpha;
+                    }
+                }
+            }
+            // wave reduction (DPP), one set of atomics per (wave, Gaussian)
+            g_xy0 = wave_sum_to_lane63(g_xy0);
+            g_xy1 = wave_sum_to_lane63(g_xy1);
+            g_c0 = wave_sum_to_lane63(g_c0);
+            g_c1 = wave_sum_to_lane63(g_c1);
+            g_c2 = wave_sum_to_lane63(g_c2);
+            g_op = wave_sum_to_lane63(g_op);
+#pragma unroll
+            for (int k = 0; k < D; ++k) g_col[k] = wave_sum_to_lane63(g_col[k]);
+            if (absgrad) {
+                g_ab0 = wave_sum_to_lane63(g_ab0);
+                g_ab1 = wave_sum_to_lane63(g_ab1);
+            }
+            if (lane == 63) {
+                const int64_t g = s_id[t];
+                unsafeAtomicAdd(v_means2d + g * 2, g_xy0);
+                unsafeAtomicAdd(v_means2d + g * 2 + 1, g_xy1);
+                if (absgrad) {
+                    unsafeAtomicAdd(v_means2d_abs + g * 2, g_ab0);
+                    unsafeAtomicAdd(v_means2d_abs + g * 2 + 1, g_ab1);
+                }
+                unsafeAtomicAdd(v_conics + g * 3, g_c0);
+                unsafeAtomicAdd(v_conics + g * 3 + 1, g_c1);
+                unsafeAtomicAdd(v_conics + g * 3 + 2, g_c2);
+                unsafeAtomicAdd(v_opacities + g, g_op);
+#pragma unroll
+                for (int k = 0; k < D; ++k) unsafeAtomicAdd(v_colors + g * D + k, g_col[k]);
+            }
+        }
+    }
+}
+
+template <int D, int PPL>
+int launch_fwd(int C, const float *means2d, const float *conics, const float *colors,
+               const float *opacities, const float *backgrounds, int W, int H, int tw, int th,
+               const int32_t *offsets, const int32_t *flatten_ids, int64_t M, float *render,
+               float *alphas, int32_t *last_ids, hipStream_t st) {
+    const int64_t total = (int64_t)C * tw * th;
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    blend_fwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(C, means2d, conics, colors, opacities,
+                                                         backgrounds, W, H, tw, th, offsets,
+                                                         flatten_ids, M, render, alphas, last_ids);
+    return 0;
+}
+
+template <int D, int PPL>
+int launch_bwd(int C, const float *means2d, const float *conics, const float *colors,
+               const float *opacities, const float *backgrounds, int W, int H, int tw, int th,
+               const int32_t *offsets, const int32_t *flatten_ids, int64_t M, const float *alphas,
+               const int32_t *last_ids, const float *v_render, const float *v_alphas,
+               float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
+               float *v_opacities, hipStream_t st) {
+    const int64_t total = (int64_t)C * tw * th;
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    blend_bwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(
+        C, means2d, conics, colors, opacities, backgrounds, W, H, tw, th, offsets, flatten_ids, M,
+        alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
+    return 0;
+}
+
+bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32; }
+
+}  // namespace
+
+#define MTGS_DISPATCH_D(FN, ...)                         \
+    switch (D) {                                         \
+        case 1: FN<1, 4>(__VA_ARGS__); break;            \
+        case 2: FN<2, 4>(__VA_ARGS__); break;            \
+        case 3: FN<3, 4>(__VA_ARGS__); break;            \
+        case 4: FN<4, 4>(__VA_ARGS__); break;            \
+        case 5: FN<5, 4>(__VA_ARGS__); break;            \
+        case 6: FN<6, 4>(__VA_ARGS__); break;            \
+        case 7: FN<7, 4>(__VA_ARGS__); break;            \
+        case 8: FN<8, 4>(__VA_ARGS__); break;            \
+        case 16: FN<16, 1>(__VA_ARGS__); break;          \
+        default: FN<32, 1>(__VA_ARGS__); break;          \
+    }
+
+extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
+                              const float *colors, const float *opacities, const float *backgrounds,
+                              int width, int height, int tile_size, int tile_w, int tile_h,
+                              const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
+                              float *render, float *alphas, int32_t *last_ids, void *stream) {
+    MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_fwd: bad sizes");
+    MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_fwd: tile_size=%d (only 16 is implemented)", tile_size);
+    MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
+                 "mtgs_blend_fwd: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
+    MTGS_REQUIRE(supported_channels(D), MTGS_EUNSUPPORTED,
+                 "mtgs_blend_fwd: D=%d channels (supported: 1..8, 16, 32; pad on the host)", D);
+    if (C == 0) return MTGS_OK;
+    MTGS_REQUIRE(offsets && render && alphas && last_ids && (M == 0 || (means2d && conics && colors && opacities && flatten_ids)),
+                 MTGS_EINVAL, "mtgs_blend_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    MTGS_DISPATCH_D(launch_fwd, C, means2d, conics, colors, opacities, backgrounds, width, height,
+                    tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, st);
+    MTGS_CHECK_LAUNCH("mtgs_blend_fwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
+                              const float *colors, const float *opacities, const float *backgrounds,
+                              int width, int height, int tile_size, int tile_w, int tile_h,
+                              const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
+                              const float *alphas, const int32_t *last_ids, const float *v_render,
+                              const float *v_alphas, float *v_means2d, float *v_means2d_abs,
+                              float *v_conics, float *v_colors, float *v_opacities, void *stream) {
+    MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd: bad sizes");
+    MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_bwd: tile_size=%d (only 16 is implemented)", tile_size);
+    MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
+                 "mtgs_blend_bwd: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
+    MTGS_REQUIRE(supported_channels(D), MTGS_EUNSUPPORTED,
+                 "mtgs_blend_bwd: D=%d channels (supported: 1..8, 16, 32; pad on the host)", D);
+    if (C == 0 || M == 0) return MTGS_OK;
+    MTGS_REQUIRE(means2d && conics && colors && opacities && offsets && flatten_ids && alphas &&
+                     last_ids && v_render && v_alphas && v_means2d && v_conics && v_colors && v_opacities,
+                 MTGS_EINVAL, "mtgs_blend_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, width, height,
+                    tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, v_render, v_alphas,
+                    v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, st);
+    MTGS_CHECK_LAUNCH("mtgs_blend_bwd");
+    return MTGS_OK;
+}

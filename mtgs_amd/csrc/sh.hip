@@ -1,0 +1,296 @@
+// sh.hip -- real spherical harmonics (degree <= 4) colour evaluation, forward and backward.
+//
+// Replaces gsplat 1.4.0 compute_sh_fwd / compute_sh_bwd, reached from MTGS through
+// gsplat.cuda._wrapper.spherical_harmonics (/root/reference/mtgs/scene_model/gaussian_model/
+// vanilla_gaussian_splatting.py:312-318 and siblings).
+//
+// Roofline: HBM.  Algorithmic bytes per Gaussian: fwd 12 (dir) + 12*nb (active coeffs) + 12 (out);
+// bwd 12 + 12 (v_colors) + 12*K (v_coeffs written in full, zeros above the active degree).
+//
+// CDNA4 mapping: coeffs are [n,K,3] AoS, i.e. one Gaussian's coefficients are 12*K contiguous
+// bytes.  One thread per Gaussian reading its own row would make every wave load touch 64
+// different lines; instead a block streams the rows of its 128 Gaussians through LDS with
+// fully-coalesced (float4 when the row is a multiple of 16 B) accesses, and each lane then walks
+// its row in LDS with an ODD row stride (bank = (lane*stride + j) mod 32 -> conflict-free).
+#include "common.hpp"
+
+namespace {
+
+constexpr int SH_BLOCK = 128;
+
+__device__ __forceinline__ void sh_bases_dev(int degree, float x, float y, float z, float *b) {
+    b[0] = 0.2820947917738781f;
+    if (degree < 1) return;
+    b[1] = -0.48860251190292f * y;
+    b[2] = 0.48860251190292f * z;
+    b[3] = -0.48860251190292f * x;
+    if (degree < 2) return;
+    float z2 = z * z;
+    float fTmp0B = -1.092548430592079f * z;
+    float fC1 = x * x - y * y;
+    float fS1 = 2.f * x * y;
+    b[4] = 0.5462742152960395f * fS1;
+    b[5] = fTmp0B * y;
+    b[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    b[7] = fTmp0B * x;
+    b[8] = 0.5462742152960395f * fC1;
+    if (degree < 3) return;
+    float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float fTmp1B = 1.445305721320277f * z;
+    float fC2 = x * fC1 - y * fS1;
+    float fS2 = x * fS1 + y * fC1;
+    b[9] = -0.5900435899266435f * fS2;
+    b[10] = fTmp1B * fS1;
+    b[11] = fTmp0C * y;
+    b[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    b[13] = fTmp0C * x;
+    b[14] = fTmp1B * fC1;
+    b[15] = -0.5900435899266435f * fC2;
+    if (degree < 4) return;
+    float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+    float fTmp2B = -1.770130769779931f * z;
+    float fC3 = x * fC2 - y * fS2;
+    float fS3 = x * fS2 + y * fC2;
+    b[16] = 0.6258357354491763f * fS3;
+    b[17] = fTmp2B * fS2;
+    b[18] = fTmp1C * fS1;
+    b[19] = fTmp0D * y;
+    b[20] = 1.984313483298443f * z * b[12] - 1.006230589874905f * b[6];
+    b[21] = fTmp0D * x;
+    b[22] = fTmp1C * fC1;
+    b[23] = fTmp2B * fC2;
+    b[24] = 0.6258357354491763f * fC3;
+}
+
+// d(basis_k)/d(x,y,z), contracted on the fly with s[k] = <coeffs[k,:], v_color>.
+template <int DEG>
+__device__ __forceinline__ void sh_dir_grad(float x, float y, float z, const float *s, float &vx,
+                                            float &vy, float &vz) {
+    vx = vy = vz = 0.f;
+    if (DEG < 1) return;
+    vy += -0.48860251190292f * s[1];
+    vz += 0.48860251190292f * s[2];
+    vx += -0.48860251190292f * s[3];
+    if (DEG < 2) return;
+    float z2 = z * z;
+    float fTmp0B = -1.092548430592079f * z, fTmp0B_z = -1.092548430592079f;
+    float fC1 = x * x - y * y, fC1_x = 2.f * x, fC1_y = -2.f * y;
+    float fS1 = 2.f * x * y, fS1_x = 2.f * y, fS1_y = 2.f * x;
+    vx += 0.5462742152960395f * fS1_x * s[4]; vy += 0.5462742152960395f * fS1_y * s[4];
+    vy += fTmp0B * s[5]; vz += fTmp0B_z * y * s[5];
+    float pSH6_z = 2.f * 0.9461746957575601f * z;
+    vz += pSH6_z * s[6];
+    vx += fTmp0B * s[7]; vz += fTmp0B_z * x * s[7];
+    vx += 0.5462742152960395f * fC1_x * s[8]; vy += 0.5462742152960395f * fC1_y * s[8];
+    if (DEG < 3) return;
+    float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f, fTmp0C_z = -2.285228997322329f * 2.f * z;
+    float fTmp1B = 1.445305721320277f * z, fTmp1B_z = 1.445305721320277f;
+    float fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
+    float fC2_x = fC1 + x * fC1_x - y * fS1_x, fC2_y = x * fC1_y - fS1 - y * fS1_y;
+    float fS2_x = fS1 + x * fS1_x + y * fC1_x, fS2_y = x * fS1_y + fC1 + y * fC1_y;
+    vx += -0.5900435899266435f * fS2_x * s[9]; vy += -0.5900435899266435f * fS2_y * s[9];
+    vx += fTmp1B * fS1_x * s[10]; vy += fTmp1B * fS1_y * s[10]; vz += fTmp1B_z * fS1 * s[10];
+    vy += fTmp0C * s[11]; vz += fTmp0C_z * y * s[11];
+    float pSH12 = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    float pSH12_z = 3.f * 1.865881662950577f * z2 - 1.119528997770346f;
+    vz += pSH12_z * s[12];
+    vx += fTmp0C * s[13]; vz += fTmp0C_z * x * s[13];
+    vx += fTmp1B * fC1_x * s[14]; vy += fTmp1B * fC1_y * s[14]; vz += fTmp1B_z * fC1 * s[14];
+    vx += -0.5900435899266435f * fC2_x * s[15]; vy += -0.5900435899266435f * fC2_y * s[15];
+    if (DEG < 4) return;
+    float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    float fTmp0D_z = 3.f * -4.683325804901025f * z2 + 2.007139630671868f;
+    float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f, fTmp1C_z = 2.f * 3.31161143515146f * z;
+    float fTmp2B = -1.770130769779931f * z, fTmp2B_z = -1.770130769779931f;
+    float fC3_x = fC2 + x * fC2_x - y * fS2_x, fC3_y = x * fC2_y - fS2 - y * fS2_y;
+    float fS3_x = fS2 + x * fS2_x + y * fC2_x, fS3_y = x * fS2_y + fC2 + y * fC2_y;
+    vx += 0.6258357354491763f * fS3_x * s[16]; vy += 0.6258357354491763f * fS3_y * s[16];
+    vx += fTmp2B * fS2_x * s[17]; vy += fTmp2B * fS2_y * s[17]; vz += fTmp2B_z * fS2 * s[17];
+    vx += fTmp1C * fS1_x * s[18]; vy += fTmp1C * fS1_y * s[18]; vz += fTmp1C_z * fS1 * s[18];
+    vy += fTmp0D * s[19]; vz += fTmp0D_z * y * s[19];
+    vz += (1.984313483298443f * (pSH12 + z * pSH12_z) - 1.006230589874905f * pSH6_z) * s[20];
+    vx += fTmp0D * s[21]; vz += fTmp0D_z * x * s[21];
+    vx += fTmp1C * fC1_x * s[22]; vy += fTmp1C * fC1_y * s[22]; vz += fTmp1C_z * fC1 * s[22];
+    vx += fTmp2B * fC2_x * s[23]; vy += fTmp2B * fC2_y * s[23]; vz += fTmp2B_z * fC2 * s[23];
+    vx += 0.6258357354491763f * fC3_x * s[24]; vy += 0.6258357354491763f * fC3_y * s[24];
+}
+
+// Stream the active part (NB3 floats) of each Gaussian's coefficient row into LDS.
+template <int NB3, int STRIDE>
+__device__ __forceinline__ void stage_coeffs(float *lds, const float *__restrict__ coeffs,
+                                             const uint8_t *__restrict__ masks, int64_t g0, int cnt,
+                                             int K) {
+    const int tid = threadIdx.x;
+    if ((NB3 % 4 == 0) && K * 3 == NB3) {  // rows contiguous and 16-B aligned: float4 stream
+        const float4 *src = reinterpret_cast<const float4 *>(coeffs + g0 * NB3);
+        const int n4 = cnt * (NB3 / 4);
+        for (int i4 = tid; i4 < n4; i4 += SH_BLOCK) {
+            const int g = i4 / (NB3 / 4), j = (i4 % (NB3 / 4)) * 4;
+            if (masks && !masks[g0 + g]) continue;
+            const float4 v = src[i4];
+            float *d = lds + g * STRIDE + j;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        const int total = cnt * NB3;
+        for (int i = tid; i < total; i += SH_BLOCK) {
+            const int g = i / NB3, j = i % NB3;
+            if (masks && !masks[g0 + g]) continue;
+            lds[g * STRIDE + j] = coeffs[(g0 + g) * (int64_t)K * 3 + j];
+        }
+    }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(int64_t n, int K,
+                                                         const float *__restrict__ dirs,
+                                                         const float *__restrict__ coeffs,
+                                                         const uint8_t *__restrict__ masks,
+                                                         float *__restrict__ colors) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3, STRIDE = NB3 | 1;
+    __shared__ float lds[SH_BLOCK * STRIDE];
+    const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
+    const int cnt = (int)min((int64_t)SH_BLOCK, n - g0);
+    stage_coeffs<NB3, STRIDE>(lds, coeffs, masks, g0, cnt, K);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid >= cnt) return;
+    const int64_t g = g0 + tid;
+    float r = 0.f, gg = 0.f, bb = 0.f;
+    if (!masks || masks[g]) {
+        float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+        const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
+        x *= inorm; y *= inorm; z *= inorm;
+        float b[NB];
+        sh_bases_dev(DEG, x, y, z, b);
+        const float *c = lds + tid * STRIDE;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            r += b[k] * c[k * 3];
+            gg += b[k] * c[k * 3 + 1];
+            bb += b[k] * c[k * 3 + 2];
+        }
+    }
+    colors[g * 3] = r; colors[g * 3 + 1] = gg; colors[g * 3 + 2] = bb;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
+                                                         const float *__restrict__ dirs,
+                                                         const float *__restrict__ coeffs,
+                                                         const uint8_t *__restrict__ masks,
+                                                         const float *__restrict__ v_colors,
+                                                         float *__restrict__ v_coeffs,
+                                                         float *__restrict__ v_dirs) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3, STRIDE = NB3 | 1;
+    __shared__ float lds[SH_BLOCK * STRIDE];
+    const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
+    const int cnt = (int)min((int64_t)SH_BLOCK, n - g0);
+    const int tid = threadIdx.x;
+    if (v_dirs) {
+        stage_coeffs<NB3, STRIDE>(lds, coeffs, masks, g0, cnt, K);
+        __syncthreads();
+    }
+    if (tid < cnt) {
+        const int64_t g = g0 + tid;
+        float *row = lds + tid * STRIDE;
+        const bool on = !masks || masks[g];
+        float vdx = 0.f, vdy = 0.f, vdz = 0.f;
+        if (on) {
+            float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+            const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
+            x *= inorm; y *= inorm; z *= inorm;
+            float b[NB];
+            sh_bases_dev(DEG, x, y, z, b);
+            const float v0 = v_colors[g * 3], v1 = v_colors[g * 3 + 1], v2 = v_colors[g * 3 + 2];
+            if (v_dirs) {
+                float s[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    s[k] = (row[k * 3] * v0 + row[k * 3 + 1] * v1) + row[k * 3 + 2] * v2;
+                float vx, vy, vz;
+                sh_dir_grad<DEG>(x, y, z, s, vx, vy, vz);
+                const float dot = (vx * x + vy * y) + vz * z;
+                vdx = (vx - dot * x) * inorm; vdy = (vy - dot * y) * inorm; vdz = (vz - dot * z) * inorm;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                row[k * 3] = b[k] * v0; row[k * 3 + 1] = b[k] * v1; row[k * 3 + 2] = b[k] * v2;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB3; ++j) row[j] = 0.f;
+        }
+        if (v_dirs) { v_dirs[g * 3] = vdx; v_dirs[g * 3 + 1] = vdy; v_dirs[g * 3 + 2] = vdz; }
+    }
+    __syncthreads();
+    // coalesced write of the full [cnt, K*3] block, zeros above the active degree
+    const int K3 = K * 3;
+    float *dst = v_coeffs + g0 * K3;
+    if (K3 % 4 == 0) {
+        const int n4 = cnt * (K3 / 4);
+        for (int i4 = tid; i4 < n4; i4 += SH_BLOCK) {
+            const int g = i4 / (K3 / 4), j = (i4 % (K3 / 4)) * 4;
+            const float *s = lds + g * STRIDE;
+            float4 v;
+            v.x = j < NB3 ? s[j] : 0.f;
+            v.y = j + 1 < NB3 ? s[j + 1] : 0.f;
+            v.z = j + 2 < NB3 ? s[j + 2] : 0.f;
+            v.w = j + 3 < NB3 ? s[j + 3] : 0.f;
+            reinterpret_cast<float4 *>(dst)[i4] = v;
+        }
+    } else {
+        const int total = cnt * K3;
+        for (int i = tid; i < total; i += SH_BLOCK) {
+            const int g = i / K3, j = i % K3;
+            dst[i] = j < NB3 ? lds[g * STRIDE + j] : 0.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
+                           const uint8_t *masks, float *colors, void *stream) {
+    MTGS_REQUIRE(n >= 0 && K > 0, MTGS_EINVAL, "mtgs_sh_fwd: bad sizes n=%lld K=%d", (long long)n, K);
+    MTGS_REQUIRE(degree >= 0 && degree <= MTGS_MAX_SH_DEGREE && (degree + 1) * (degree + 1) <= K,
+                 MTGS_EINVAL, "mtgs_sh_fwd: degree %d needs (degree+1)^2 <= K=%d and degree <= 4", degree, K);
+    if (n == 0) return MTGS_OK;
+    MTGS_REQUIRE(dirs && coeffs && colors, MTGS_EINVAL, "mtgs_sh_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(n, SH_BLOCK);
+    switch (degree) {
+        case 0: sh_fwd_kernel<0><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
+        case 1: sh_fwd_kernel<1><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
+        case 2: sh_fwd_kernel<2><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
+        case 3: sh_fwd_kernel<3><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
+        default: sh_fwd_kernel<4><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
+    }
+    MTGS_CHECK_LAUNCH("mtgs_sh_fwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
+                           const uint8_t *masks, const float *v_colors, float *v_coeffs,
+                           float *v_dirs, void *stream) {
+    MTGS_REQUIRE(n >= 0 && K > 0, MTGS_EINVAL, "mtgs_sh_bwd: bad sizes n=%lld K=%d", (long long)n, K);
+    MTGS_REQUIRE(degree >= 0 && degree <= MTGS_MAX_SH_DEGREE && (degree + 1) * (degree + 1) <= K,
+                 MTGS_EINVAL, "mtgs_sh_bwd: degree %d needs (degree+1)^2 <= K=%d and degree <= 4", degree, K);
+    if (n == 0) return MTGS_OK;
+    MTGS_REQUIRE(dirs && v_colors && v_coeffs && (coeffs || !v_dirs), MTGS_EINVAL, "mtgs_sh_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(n, SH_BLOCK);
+#define MTGS_SH_BWD(DG) \
+    sh_bwd_kernel<DG><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs)
+    switch (degree) {
+        case 0: MTGS_SH_BWD(0); break;
+        case 1: MTGS_SH_BWD(1); break;
+        case 2: MTGS_SH_BWD(2); break;
+        case 3: MTGS_SH_BWD(3); break;
+        default: MTGS_SH_BWD(4); break;
+    }
+#undef MTGS_SH_BWD
+    MTGS_CHECK_LAUNCH("mtgs_sh_bwd");
+    return MTGS_OK;
+}

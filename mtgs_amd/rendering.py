@@ -1,0 +1,163 @@
+"""gsplat.rendering.rasterization (v1.4.0) on MI355X: same signature, argument meaning, return
+values and `meta` keys, for the option set MTGS drives.
+
+Reference call site: /root/reference/mtgs/scene_model/mtgs_scene_graph.py:641-662 (kwargs built at
+:641-659; `info["means2d"].retain_grad()`, `.absgrad`, `info["radii"]` consumed at :663-669 and
+:1170-1178).  Options gsplat accepts that are not implemented here raise NotImplementedError naming
+the option -- they never silently differ.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+from typing_extensions import Literal
+
+from .wrapper import (MAX_CHANNELS, fully_fused_projection, isect_offset_encode, isect_tiles,
+                      rasterize_to_pixels, spherical_harmonics)
+
+
+def rasterization(
+    means: Tensor,  # [N, 3]
+    quats: Tensor,  # [N, 4]
+    scales: Tensor,  # [N, 3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [(C,) N, D] or [(C,) N, K, 3]
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: Literal["RGB", "D", "ED", "RGB+D", "RGB+ED"] = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: Literal["classic", "antialiased"] = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
+    covars: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C).
+
+    Returns (render_colors [C, height, width, X], render_alphas [C, height, width, 1], meta).
+    """
+    meta: Dict = {}
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    assert rasterize_mode in ["classic", "antialiased"], rasterize_mode
+
+    # options of gsplat 1.4.0 that MTGS never enables (mtgs_scene_graph.py:641-659)
+    if packed:
+        raise NotImplementedError("rasterization: packed=True is not implemented (MTGS passes packed=False)")
+    if sparse_grad:
+        raise NotImplementedError("rasterization: sparse_grad=True is not implemented (requires packed=True)")
+    if distributed:
+        raise NotImplementedError("rasterization: distributed=True (Gaussian-sharded) is not implemented; "
+                                  "use view-parallel data parallelism (mtgs_amd.dist)")
+    if camera_model != "pinhole":
+        raise NotImplementedError(f"rasterization: camera_model={camera_model!r} is not implemented")
+    if covars is not None:
+        raise NotImplementedError("rasterization: covars is not implemented (pass quats and scales)")
+    if tile_size != 16:
+        raise NotImplementedError(f"rasterization: tile_size={tile_size} is not implemented (only 16)")
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+
+    if sh_degree is None:
+        # colors are post-activation values [N, D] or [C, N, D]
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (
+            colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
+    else:
+        # colors are SH coefficients [N, K, 3] or [C, N, K, 3]
+        assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
+            colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+
+    # (1) projection
+    radii, means2d, depths, conics, compensations = fully_fused_projection(
+        means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
+        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model)
+    opacities = opacities.repeat(C, 1)  # [C, N]
+    camera_ids, gaussian_ids = None, None
+    if compensations is not None:
+        opacities = opacities * compensations
+
+    meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii,
+                 "means2d": means2d, "depths": depths, "conics": conics, "opacities": opacities})
+
+    # (2) colours [C, N, D]
+    if sh_degree is None:
+        if colors.dim() == 2:
+            colors = colors.expand(C, -1, -1)
+    else:
+        camtoworlds = torch.inverse(viewmats)  # [C, 4, 4]
+        dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+        masks = radii > 0
+        shs = colors.expand(C, -1, -1, -1) if colors.dim() == 3 else colors
+        colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3]
+        colors = torch.clamp_min(colors + 0.5, 0.0)
+
+    # (3) depth channel
+    if render_mode in ["RGB+D", "RGB+ED"]:
+        colors = torch.cat((colors, depths[..., None]), dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
+    elif render_mode in ["D", "ED"]:
+        colors = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
+
+    # (4) tile binning
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height, packed=False, n_cameras=C,
+        camera_ids=camera_ids, gaussian_ids=gaussian_ids)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+
+    meta.update({"tile_width": tile_width, "tile_height": tile_height,
+                 "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids,
+                 "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width,
+                 "height": height, "tile_size": tile_size, "n_cameras": C})
+
+    # (5) compositing, in channel chunks when there are many channels
+    chunk = min(channel_chunk, MAX_CHANNELS)
+    if colors.shape[-1] > chunk:
+        n_chunks = (colors.shape[-1] + chunk - 1) // chunk
+        render_colors, render_alphas = [], []
+        for i in range(n_chunks):
+            colors_chunk = colors[..., i * chunk:(i + 1) * chunk]
+            bg_chunk = backgrounds[..., i * chunk:(i + 1) * chunk] if backgrounds is not None else None
+            rc, ra = rasterize_to_pixels(means2d, conics, colors_chunk, opacities, width, height,
+                                         tile_size, isect_offsets, flatten_ids, backgrounds=bg_chunk,
+                                         packed=False, absgrad=absgrad)
+            render_colors.append(rc)
+            render_alphas.append(ra)
+        render_colors = torch.cat(render_colors, dim=-1)
+        render_alphas = render_alphas[0]
+    else:
+        render_colors, render_alphas = rasterize_to_pixels(
+            means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+            backgrounds=backgrounds, packed=False, absgrad=absgrad)
+
+    # (6) expected depth
+    if render_mode in ["ED", "RGB+ED"]:
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+
+    return render_colors, render_alphas, meta

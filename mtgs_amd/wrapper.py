@@ -1,0 +1,299 @@
+"""Operator layer: the functions of gsplat/cuda/_wrapper.py (v1.4.0) that MTGS's rasterization path
+uses, with the same names, argument meaning and error behaviour, on top of libmtgs_rast.so.
+
+Reference call sites: spherical_harmonics at
+/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:312-318 (also
+multi_color_gaussian_splatting.py:96, rigid_node.py:248, deformable_node.py:125); the other four
+are reached through gsplat.rendering.rasterization (mtgs_scene_graph.py:641-662).
+
+PyTorch is used for device memory, streams and autograd plumbing only; every computation below is
+a HIP kernel launched through the C ABI (include/mtgs_rast.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import call, ptr, require_gpu, stream_of
+
+SUPPORTED_CHANNELS = (1, 2, 3, 4, 5, 6, 7, 8, 16, 32)
+MAX_CHANNELS = 32
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------- SH
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor]):
+        require_gpu(dirs, coeffs, masks)
+        dirs_c, coeffs_c = _f32c(dirs), _f32c(coeffs)
+        K = coeffs_c.shape[-2]
+        n = dirs_c.numel() // 3
+        masks_c = None if masks is None else masks.contiguous().to(torch.uint8)
+        colors = torch.empty(dirs_c.shape, dtype=torch.float32, device=dirs_c.device)
+        call("mtgs_sh_fwd", n, K, degree, ptr(dirs_c), ptr(coeffs_c), ptr(masks_c), ptr(colors),
+             stream_of(dirs_c))
+        ctx.save_for_backward(dirs_c, coeffs_c, masks_c)
+        ctx.degree, ctx.K, ctx.n = degree, K, n
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors: Tensor):
+        dirs, coeffs, masks = ctx.saved_tensors
+        v_colors = _f32c(v_colors)
+        need_dirs = ctx.needs_input_grad[1]
+        v_coeffs = torch.empty_like(coeffs)
+        v_dirs = torch.empty_like(dirs) if need_dirs else None
+        call("mtgs_sh_bwd", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(coeffs), ptr(masks),
+             ptr(v_colors), ptr(v_coeffs), ptr(v_dirs), stream_of(dirs))
+        if not ctx.needs_input_grad[2]:
+            v_coeffs = None
+        return None, v_dirs, v_coeffs, None
+
+
+def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
+                        masks: Optional[Tensor] = None) -> Tensor:
+    """gsplat.cuda._wrapper.spherical_harmonics: dirs[...,3], coeffs[...,K,3], masks[...] -> [...,3]."""
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    assert dirs.shape[:-1] == coeffs.shape[:-2], (dirs.shape, coeffs.shape)
+    assert dirs.shape[-1] == 3, dirs.shape
+    assert coeffs.shape[-1] == 3, coeffs.shape
+    if masks is not None:
+        assert masks.shape == dirs.shape[:-1], masks.shape
+    if degrees_to_use > 4:
+        raise NotImplementedError("spherical_harmonics: degrees_to_use > 4")
+    return _SphericalHarmonics.apply(degrees_to_use, dirs, coeffs, masks)
+
+
+# ------------------------------------------------------------------------------------- projection
+class _FullyFusedProjection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                radius_clip, calc_compensations):
+        require_gpu(means, quats, scales, viewmats, Ks)
+        means, quats, scales, viewmats, Ks = map(_f32c, (means, quats, scales, viewmats, Ks))
+        N, Cn = means.shape[0], viewmats.shape[0]
+        dev = means.device
+        radii = torch.empty((Cn, N), dtype=torch.int32, device=dev)
+        means2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((Cn, N), dtype=torch.float32, device=dev)
+        conics = torch.empty((Cn, N, 3), dtype=torch.float32, device=dev)
+        comps = torch.empty((Cn, N), dtype=torch.float32, device=dev) if calc_compensations else None
+        call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+             width, height, eps2d, near_plane, far_plane, radius_clip, ptr(radii), ptr(means2d),
+             ptr(depths), ptr(conics), ptr(comps), stream_of(means))
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics, comps)
+        ctx.width, ctx.height, ctx.eps2d = width, height, eps2d
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, comps
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_comps):
+        means, quats, scales, viewmats, Ks, radii, conics, comps = ctx.saved_tensors
+        N, Cn = means.shape[0], viewmats.shape[0]
+        dev = means.device
+        zeros = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        v_means2d = zeros(Cn, N, 2) if v_means2d is None else _f32c(v_means2d)
+        v_depths = zeros(Cn, N) if v_depths is None else _f32c(v_depths)
+        v_conics = zeros(Cn, N, 3) if v_conics is None else _f32c(v_conics)
+        v_comps = None if (comps is None or v_comps is None) else _f32c(v_comps)
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_viewmats = torch.empty_like(viewmats) if ctx.needs_input_grad[3] else None
+        call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+             ctx.width, ctx.height, ctx.eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(v_means2d),
+             ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_means), ptr(v_quats), ptr(v_scales),
+             ptr(v_viewmats), stream_of(means))
+        g = ctx.needs_input_grad
+        return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
+                v_viewmats, None, None, None, None, None, None, None, None)
+
+
+def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor],
+                           scales: Optional[Tensor], viewmats: Tensor, Ks: Tensor, width: int,
+                           height: int, eps2d: float = 0.3, near_plane: float = 0.01,
+                           far_plane: float = 1e10, radius_clip: float = 0.0, packed: bool = False,
+                           sparse_grad: bool = False, calc_compensations: bool = False,
+                           camera_model: str = "pinhole"):
+    """gsplat.cuda._wrapper.fully_fused_projection (packed=False, pinhole).
+    Returns (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N] | None)."""
+    Cn, N = viewmats.size(0), means.size(0)
+    assert means.size() == (N, 3), means.size()
+    assert viewmats.size() == (Cn, 4, 4), viewmats.size()
+    assert Ks.size() == (Cn, 3, 3), Ks.size()
+    if covars is not None:
+        raise NotImplementedError("fully_fused_projection: covars (pass quats and scales)")
+    if packed:
+        raise NotImplementedError("fully_fused_projection: packed=True")
+    if sparse_grad:
+        raise NotImplementedError("fully_fused_projection: sparse_grad=True (requires packed=True)")
+    if camera_model != "pinhole":
+        raise NotImplementedError(f"fully_fused_projection: camera_model={camera_model!r}")
+    assert quats is not None and scales is not None, "quats and scales are required"
+    assert quats.size() == (N, 4), quats.size()
+    assert scales.size() == (N, 3), scales.size()
+    return _FullyFusedProjection.apply(means, quats, scales, viewmats, Ks, int(width), int(height),
+                                       float(eps2d), float(near_plane), float(far_plane),
+                                       float(radius_clip), bool(calc_compensations))
+
+
+# ------------------------------------------------------------------------------------- tiles
+def _bit_length(v: int) -> int:
+    return int(v).bit_length()
+
+
+@torch.no_grad()
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                tile_height: int, sort: bool = True, packed: bool = False,
+                n_cameras: Optional[int] = None, camera_ids: Optional[Tensor] = None,
+                gaussian_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """gsplat.cuda._wrapper.isect_tiles (packed=False): (tiles_per_gauss[C,N] i32,
+    isect_ids[M] i64, flatten_ids[M] i32), sorted by (camera, tile, depth) when sort=True."""
+    if packed:
+        raise NotImplementedError("isect_tiles: packed=True")
+    require_gpu(means2d, radii, depths)
+    Cn, N = means2d.shape[:2]
+    assert means2d.shape == (Cn, N, 2), means2d.shape
+    assert radii.shape == (Cn, N), radii.shape
+    assert depths.shape == (Cn, N), depths.shape
+    means2d, depths = _f32c(means2d), _f32c(depths)
+    radii = radii.contiguous()
+    if radii.dtype != torch.int32:
+        radii = radii.to(torch.int32)
+    dev, st = means2d.device, stream_of(means2d)
+    total = Cn * N
+    tiles_per_gauss = torch.empty((Cn, N), dtype=torch.int32, device=dev)
+    call("mtgs_isect_count", Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
+         ptr(tiles_per_gauss), st)
+    ws_bytes = C.c_size_t(0)
+    call("mtgs_scan_workspace_bytes", total, C.byref(ws_bytes))
+    scan_ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
+    cum = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    m_dev = torch.empty(1, dtype=torch.int64, device=dev)
+    call("mtgs_isect_scan", total, ptr(tiles_per_gauss), ptr(cum), ptr(m_dev), ptr(scan_ws),
+         ws_bytes.value, st)
+    M = int(m_dev.item())  # the one host sync of a frame (gsplat does the same)
+    isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        call("mtgs_isect_emit", Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
+             tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids), st)
+        if sort:
+            key_bits = 32 + _bit_length(tile_width * tile_height) + _bit_length(Cn)
+            call("mtgs_sort_workspace_bytes", M, C.byref(ws_bytes))
+            sort_ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
+            ids_sorted = torch.empty_like(isect_ids)
+            flat_sorted = torch.empty_like(flatten_ids)
+            call("mtgs_sort_pairs", M, key_bits, ptr(isect_ids), ptr(flatten_ids), ptr(ids_sorted),
+                 ptr(flat_sorted), ptr(sort_ws), ws_bytes.value, st)
+            isect_ids, flatten_ids = ids_sorted, flat_sorted
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@torch.no_grad()
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    """gsplat.cuda._wrapper.isect_offset_encode -> offsets[C, tile_height, tile_width] i32."""
+    require_gpu(isect_ids)
+    isect_ids = isect_ids.contiguous()
+    offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=torch.int32, device=isect_ids.device)
+    call("mtgs_isect_offsets", isect_ids.numel(), ptr(isect_ids), n_cameras, tile_width, tile_height,
+         ptr(offsets), stream_of(isect_ids))
+    return offsets
+
+
+# ------------------------------------------------------------------------------------- compositing
+class _RasterizeToPixels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size,
+                isect_offsets, flatten_ids, absgrad):
+        require_gpu(means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids)
+        m2d, con, col, opa, bg = map(_f32c, (means2d, conics, colors, opacities, backgrounds))
+        isect_offsets, flatten_ids = isect_offsets.contiguous(), flatten_ids.contiguous()
+        Cn, N, D = col.shape
+        th, tw = isect_offsets.shape[1:]
+        dev = m2d.device
+        render = torch.empty((Cn, height, width, D), dtype=torch.float32, device=dev)
+        alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
+        M = flatten_ids.numel()
+        call("mtgs_blend_fwd", Cn, N, D, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), width,
+             height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), M, ptr(render),
+             ptr(alphas), ptr(last_ids), stream_of(m2d))
+        ctx.save_for_backward(m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids)
+        ctx.dims = (width, height, tile_size, tw, th)
+        ctx.absgrad = absgrad
+        ctx.means2d_ref = means2d  # the tensor MTGS calls .retain_grad() on; .absgrad is set on it
+        return render, alphas
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        width, height, tile_size, tw, th = ctx.dims
+        Cn, N, D = col.shape
+        dev = m2d.device
+        v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
+        v_means2d = torch.zeros_like(m2d)
+        v_conics = torch.zeros_like(con)
+        v_colors = torch.zeros_like(col)
+        v_opacities = torch.zeros_like(opa)
+        v_abs = torch.zeros_like(m2d) if ctx.absgrad else None
+        call("mtgs_blend_bwd", Cn, N, D, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), width,
+             height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), flatten_ids.numel(),
+             ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs),
+             ptr(v_conics), ptr(v_colors), ptr(v_opacities), stream_of(m2d))
+        if ctx.absgrad:
+            ctx.means2d_ref.absgrad = v_abs
+        v_bg = None
+        if bg is not None and ctx.needs_input_grad[4]:
+            v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
+        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None)
+
+
+def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
+                        image_width: int, image_height: int, tile_size: int, isect_offsets: Tensor,
+                        flatten_ids: Tensor, backgrounds: Optional[Tensor] = None,
+                        masks: Optional[Tensor] = None, packed: bool = False,
+                        absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+    """gsplat.cuda._wrapper.rasterize_to_pixels (packed=False) ->
+    (render_colors[C,H,W,D], render_alphas[C,H,W,1])."""
+    if packed:
+        raise NotImplementedError("rasterize_to_pixels: packed=True")
+    if masks is not None:
+        raise NotImplementedError("rasterize_to_pixels: tile masks")
+    if tile_size != 16:
+        raise NotImplementedError(f"rasterize_to_pixels: tile_size={tile_size} (only 16 is implemented)")
+    Cn, N = means2d.shape[:2]
+    assert means2d.shape == (Cn, N, 2), means2d.shape
+    assert conics.shape == (Cn, N, 3), conics.shape
+    assert colors.shape[:2] == (Cn, N), colors.shape
+    assert opacities.shape == (Cn, N), opacities.shape
+    if backgrounds is not None:
+        assert backgrounds.shape == (Cn, colors.shape[-1]), backgrounds.shape
+    th, tw = isect_offsets.shape[1:]
+    assert tw * tile_size >= image_width and th * tile_size >= image_height
+    channels = colors.shape[-1]
+    if channels > MAX_CHANNELS:
+        raise ValueError(f"rasterize_to_pixels: {channels} channels > {MAX_CHANNELS}; chunk on the caller side")
+    pad = next(d for d in SUPPORTED_CHANNELS if d >= channels) - channels
+    if pad:
+        colors = torch.cat([colors, colors.new_zeros(Cn, N, pad)], dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, backgrounds.new_zeros(Cn, pad)], dim=-1)
+    render, alphas = _RasterizeToPixels.apply(means2d, conics, colors, opacities, backgrounds,
+                                              int(image_width), int(image_height), int(tile_size),
+                                              isect_offsets, flatten_ids, bool(absgrad))
+    if pad:
+        render = render[..., :channels]
+    return render, alphas

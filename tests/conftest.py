@@ -1,0 +1,32 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """Builds (if hipcc is present and the .so is stale/missing) and loads libmtgs_rast.so."""
+    from mtgs_amd import _lib, build
+    try:
+        build.build()
+    except RuntimeError:
+        if not _lib.LIB_PATH.exists():
+            raise
+    return _lib.load()

@@ -1,0 +1,231 @@
+"""GPU parity: every stage of the HIP path, called through the C ABI, against the CPU oracle on
+identical inputs.  Integer stages must be bit-exact; float stages within the stated tolerance
+(north star: <= 1e-4 max abs fp32 on RGB / depth / alpha)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import small_scene, to_np
+
+pytestmark = pytest.mark.gpu
+
+RENDER_TOL = 1e-4
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+@pytest.fixture(scope="module")
+def gs(hip_lib):
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import mtgs_amd
+    return mtgs_amd
+
+
+@pytest.mark.parametrize("degree,K", [(0, 1), (0, 16), (1, 16), (2, 16), (3, 16), (4, 25), (2, 9)])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_sh_fwd_bwd(gs, oracle, degree, K, use_mask):
+    g = torch.Generator().manual_seed(degree * 10 + K)
+    n = 1000 + 37
+    dirs = torch.randn(n, 3, generator=g) * 3
+    coeffs = torch.randn(n, K, 3, generator=g)
+    masks = (torch.rand(n, generator=g) > 0.3) if use_mask else None
+    vcol = torch.randn(n, 3, generator=g)
+    ref = oracle.sh_fwd(degree, dirs.numpy(), coeffs.numpy(), None if masks is None else masks.numpy())
+    ref_vc, ref_vd = oracle.sh_bwd(degree, dirs.numpy(), coeffs.numpy(), vcol.numpy(),
+                                   None if masks is None else masks.numpy(), need_v_dirs=True)
+    d, c = dev(dirs).requires_grad_(True), dev(coeffs).requires_grad_(True)
+    out = gs.spherical_harmonics(degree, d, c, masks=None if masks is None else dev(masks))
+    out.backward(dev(vcol))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(c.grad.cpu().numpy(), ref_vc, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(d.grad.cpu().numpy(), ref_vd, atol=5e-6, rtol=1e-4)
+
+
+def test_sh_batched_dims(gs, oracle):
+    g = torch.Generator().manual_seed(0)
+    dirs = torch.randn(2, 50, 3, generator=g)
+    coeffs = torch.randn(2, 50, 16, 3, generator=g)
+    out = gs.spherical_harmonics(3, dev(dirs), dev(coeffs))
+    ref = oracle.sh_fwd(3, dirs.reshape(-1, 3).numpy(), coeffs.reshape(-1, 16, 3).numpy()).reshape(2, 50, 3)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_projection_fwd_bit_exact(gs, oracle, aa):
+    sc, vm, K = small_scene(N=5000, W=200, H=120)
+    vm2 = torch.cat([vm, vm.clone()]); vm2[1, 0, 3] += 0.5
+    K2 = torch.cat([K, K])
+    a = to_np(sc)
+    ref = oracle.project_fwd(a["means"], a["quats"], a["scales"], vm2.numpy(), K2.numpy(), 200, 120,
+                             calc_compensations=aa)
+    out = gs.fully_fused_projection(dev(sc["means"]), None, dev(sc["quats"]), dev(sc["scales"]), dev(vm2),
+                                    dev(K2), 200, 120, calc_compensations=aa)
+    names = ["radii", "means2d", "depths", "conics", "compensations"]
+    assert (ref[0] > 0).sum() > 1000
+    for nm, r, o in zip(names, ref, out):
+        if r is None:
+            assert o is None
+            continue
+        o = o.cpu().numpy()
+        # the forward is compiled without FMA contraction: identical IEEE results are required
+        assert np.array_equal(r.view(np.int32) if r.dtype == np.float32 else r,
+                              o.view(np.int32) if o.dtype == np.float32 else o), f"{nm} not bit-exact"
+
+
+def test_isect_sort_offsets_bit_exact(gs, oracle):
+    sc, vm, K = small_scene(N=4000, W=333, H=211)  # not multiples of 16
+    vm2 = torch.cat([vm, vm.clone()]); vm2[1, 2, 3] += 1.0
+    K2 = torch.cat([K, K])
+    W, H = 333, 211
+    radii, means2d, depths, conics, _ = gs.fully_fused_projection(
+        dev(sc["means"]), None, dev(sc["quats"]), dev(sc["scales"]), dev(vm2), dev(K2), W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = gs.isect_tiles(means2d, radii, depths, 16, tw, th)
+    off = gs.isect_offset_encode(ids, 2, tw, th)
+    r_tpg, r_ids, r_flat = oracle.isect_tiles(means2d.cpu().numpy(), radii.cpu().numpy(), depths.cpu().numpy(), 16, tw, th)
+    r_off = oracle.isect_offset_encode(r_ids, 2, tw, th)
+    assert r_ids.shape[0] > 10000
+    assert np.array_equal(tpg.cpu().numpy(), r_tpg)
+    assert np.array_equal(ids.cpu().numpy(), r_ids)
+    assert np.array_equal(flat.cpu().numpy(), r_flat)
+    assert np.array_equal(off.cpu().numpy(), r_off)
+    # unsorted emission order is also specified (row-major over each rectangle)
+    _, u_ids, u_flat = gs.isect_tiles(means2d, radii, depths, 16, tw, th, sort=False)
+    _, ru_ids, ru_flat = oracle.isect_tiles(means2d.cpu().numpy(), radii.cpu().numpy(), depths.cpu().numpy(), 16, tw, th, sort=False)
+    assert np.array_equal(u_ids.cpu().numpy(), ru_ids) and np.array_equal(u_flat.cpu().numpy(), ru_flat)
+
+
+def test_sort_is_stable_on_masked_bits(gs, oracle):
+    from mtgs_amd import _lib
+    from mtgs_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(7)
+    M = 100003
+    keys = torch.randint(0, 1 << 20, (M,), generator=g, dtype=torch.int64) | (torch.randint(0, 4, (M,), generator=g, dtype=torch.int64) << 40)
+    vals = torch.arange(M, dtype=torch.int32)
+    r_k, r_v = oracle.sort_pairs(keys.numpy(), vals.numpy(), 12)  # only 12 bits significant -> many ties
+    k, v = dev(keys), dev(vals)
+    ko, vo = torch.empty_like(k), torch.empty_like(v)
+    ws = C.c_size_t(0)
+    call("mtgs_sort_workspace_bytes", M, C.byref(ws))
+    w = torch.empty(ws.value, dtype=torch.uint8, device="cuda")
+    call("mtgs_sort_pairs", M, 12, ptr(k), ptr(v), ptr(ko), ptr(vo), ptr(w), ws.value, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(ko.cpu().numpy(), r_k) and np.array_equal(vo.cpu().numpy(), r_v)
+
+
+CONFIGS = [
+    # (render_mode, rasterize_mode, absgrad, D, backgrounds, W, H)
+    ("RGB", "classic", False, 3, False, 100, 70),
+    ("RGB+ED", "antialiased", True, 3, False, 100, 70),   # 3DGS.py-like + MTGS flags
+    ("RGB+ED", "antialiased", True, 6, False, 97, 61),    # MTGS.py: RGB + normals + depth = 7 channels
+    ("RGB+D", "classic", True, 3, True, 64, 48),
+    ("ED", "classic", False, 3, False, 64, 48),
+    ("RGB", "classic", False, 12, True, 50, 40),          # padded to 16 channels, 4 waves per tile
+    ("RGB", "classic", False, 40, False, 40, 30),         # channel chunks
+]
+
+
+@pytest.mark.parametrize("render_mode,rmode,absgrad,D,use_bg,W,H", CONFIGS)
+def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad, D, use_bg, W, H):
+    sc, vm, K = small_scene(N=400, W=W, H=H, D=D)
+    a = to_np(sc)
+    g = torch.Generator().manual_seed(11)
+    n_out = {"RGB": D, "RGB+ED": D + 1, "RGB+D": D + 1, "ED": 1, "D": 1}[render_mode]
+    bg = torch.rand(1, D, generator=g) if use_bg else None
+    Gc = torch.randn(1, H, W, n_out, generator=g)
+    Ga = torch.randn(1, H, W, 1, generator=g)
+    # ---- oracle forward
+    r_render, r_alpha, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"],
+                                                vm.numpy(), K.numpy(), W, H, render_mode=render_mode,
+                                                rasterize_mode=rmode, backgrounds=None if bg is None else bg.numpy())
+    # ---- device forward
+    P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
+    vmd = dev(vm).requires_grad_(True)
+    render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vmd, dev(K),
+                                           W, H, packed=False, render_mode=render_mode, rasterize_mode=rmode,
+                                           absgrad=absgrad, backgrounds=None if bg is None else dev(bg))
+    info["means2d"].retain_grad()
+    assert np.array_equal(info["radii"].cpu().numpy(), m["radii"])
+    assert np.array_equal(info["isect_ids"].cpu().numpy(), m["isect_ids"])
+    assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
+    assert np.array_equal(info["isect_offsets"].cpu().numpy(), m["isect_offsets"])
+    assert np.abs(render.detach().cpu().numpy() - r_render).max() <= RENDER_TOL * max(1.0, np.abs(r_render).max())
+    assert np.abs(alpha.detach().cpu().numpy() - r_alpha).max() <= RENDER_TOL
+    # ---- backward
+    (render * dev(Gc)).sum().add((alpha * dev(Ga)).sum()).backward()
+    Gc_raw, Ga_tot = Gc.numpy().copy(), Ga.numpy().copy()
+    if render_mode in ("ED", "RGB+ED"):
+        al = np.maximum(r_alpha, 1e-10)
+        Gc_raw[..., -1:] = Gc.numpy()[..., -1:] / al
+        Ga_tot = Ga_tot + (-(m["render_raw"][..., -1:] / al ** 2) * Gc.numpy()[..., -1:]) * (r_alpha > 1e-10)
+    v2d, vabs, vcon, vcol, vop = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], m["backgrounds"],
+                                                  W, H, 16, m["isect_offsets"], m["flatten_ids"], r_alpha, m["last_ids"],
+                                                  Gc_raw, Ga_tot)
+    aa = rmode == "antialiased"
+    has_depth = render_mode != "RGB"
+    v_depth = vcol[..., -1].copy() if has_depth else np.zeros_like(vop)
+    v_comp = vop * a["opacities"][None] if aa else None
+    r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3,
+                                                 m["radii"], m["conics"], m["compensations"], v2d, v_depth, vcon, v_comp)
+    r_vo = (vop * (m["compensations"] if aa else 1.0)).sum(0)
+
+    def close(name, got, ref, rel=2e-3):
+        got = got.detach().cpu().numpy()
+        scale = np.abs(ref).max() + 1e-12
+        err = np.abs(got - ref).max()
+        assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+    close("means2d.grad", info["means2d"].grad, v2d)
+    if absgrad:
+        close("means2d.absgrad", info["means2d"].absgrad, vabs)
+        assert (info["means2d"].absgrad >= info["means2d"].grad.abs() - 1e-6).all()
+    close("v_means", P["means"].grad, r_vm)
+    close("v_quats", P["quats"].grad, r_vq)
+    close("v_scales", P["scales"].grad, r_vs)
+    close("v_opacities", P["opacities"].grad, r_vo)
+    close("v_viewmats", vmd.grad[0], r_vvm[0])
+    if render_mode not in ("ED", "D"):
+        close("v_colors", P["colors"].grad, vcol[..., :D].sum(0))
+
+
+def test_rasterization_sh_path(gs, oracle):
+    sc, vm, K = small_scene(N=300, W=80, H=60, sh_degree=3)
+    a = to_np(sc)
+    r_render, r_alpha, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["coeffs"],
+                                                vm.numpy(), K.numpy(), 80, 60, sh_degree=2)
+    render, alpha, info = gs.rasterization(dev(sc["means"]), dev(sc["quats"]), dev(sc["scales"]), dev(sc["opacities"]),
+                                           dev(sc["coeffs"]), dev(vm), dev(K), 80, 60, sh_degree=2, packed=False)
+    assert np.abs(render.cpu().numpy() - r_render).max() <= RENDER_TOL
+    assert np.abs(alpha.cpu().numpy() - r_alpha).max() <= RENDER_TOL
+
+
+def test_empty_and_degenerate_inputs(gs):
+    W, H = 40, 30
+    vm = torch.eye(4)[None].cuda(); K = torch.tensor([[[30.0, 0, 20], [0, 30.0, 15], [0, 0, 1]]]).cuda()
+    # every Gaussian behind the camera -> M = 0, zero image
+    means = torch.tensor([[0.0, 0.0, -5.0], [1.0, 0.0, -2.0]]).cuda().requires_grad_(True)
+    quats = torch.tensor([[1.0, 0, 0, 0]] * 2).cuda(); scales = torch.full((2, 3), 0.1).cuda()
+    opac = torch.full((2,), 0.5).cuda(); cols = torch.rand(2, 3).cuda()
+    render, alpha, info = gs.rasterization(means, quats, scales, opac, cols, vm, K, W, H, packed=False, render_mode="RGB+ED")
+    assert info["flatten_ids"].numel() == 0 and (info["radii"] == 0).all()
+    assert render.abs().max() == 0 and alpha.abs().max() == 0
+    (render.sum() + alpha.sum()).backward()
+    assert means.grad.abs().max() == 0
+    # N = 0
+    z = lambda *s: torch.zeros(*s).cuda()
+    render, alpha, info = gs.rasterization(z(0, 3), z(0, 4), z(0, 3), z(0), z(0, 3), vm, K, W, H, packed=False)
+    assert render.shape == (1, H, W, 3) and render.abs().max() == 0
+
+
+def test_unsupported_options_raise(gs):
+    z = lambda *s: torch.zeros(*s).cuda()
+    args = (z(1, 3), z(1, 4), z(1, 3), z(1), z(1, 3), torch.eye(4)[None].cuda(), torch.eye(3)[None].cuda(), 32, 32)
+    for kw in (dict(packed=True), dict(packed=False, sparse_grad=True), dict(packed=False, distributed=True),
+               dict(packed=False, camera_model="fisheye"), dict(packed=False, tile_size=8),
+               dict(packed=False, covars=z(1, 3, 3))):
+        with pytest.raises(NotImplementedError):
+            gs.rasterization(*args, **kw)
