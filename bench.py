@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered Mpix/s (forward + backward) of the MTGS rasterization hot path at
+2M Gaussians, 1920x1080, on N MI355X GPUs (BASELINE.json `metric`).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one camera per rank, inputs resident in HBM:
+    spherical_harmonics(3, dirs, coeffs[N,16,3])  ->  clamp(rgb + 0.5)              (as MTGS does:
+    rasterization(..., render_mode="RGB+ED", rasterize_mode="antialiased",          vanilla_gaussian_splatting.py:309-322,
+                  absgrad=True, packed=False)                                        mtgs_scene_graph.py:641-662)
+    backward of  L = sum(render * Gc) + sum(alpha * Ga)  with fixed random cotangents, down to the
+    gradients of means / quats / scales / opacities / SH coefficients / viewmat,
+    and, for N > 1, ONE all-reduce of all Gaussian gradients (RCCL over xGMI).
+Each rank renders a different camera (yaw = rank * 45 deg) of the same replicated 2M-Gaussian
+WB-v1 scene, so per-GPU work is fixed as N grows: "scaling": "weak".
+
+Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` describes the
+dominant kernel (compositing backward) with its duration measured live by HIP events on the
+launch stream; `cpu_baseline` times oracle/gsplat_oracle.c (the CPU restatement, "port") on the
+host cores for the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+DOMINANT = "mtgs_blend_bwd"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-gaussians", type=int, default=2_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--variant", choices=["mtgs", "lean"], default="mtgs",
+                    help="mtgs: SH deg 3 + RGB+ED/antialiased/absgrad (what MTGS.py drives); "
+                         "lean: colours given, RGB/classic/no absgrad")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps (0 disables)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_inputs(args, rank, device):
+    from mtgs_amd.synthetic import make_camera, make_scene
+    sh = 3 if args.variant == "mtgs" else None
+    sc = make_scene(args.n_gaussians, seed=args.seed, sh_degree=sh)
+    vm, K = make_camera(args.width, args.height, yaw_deg=45.0 * rank)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    D_out = 4 if args.variant == "mtgs" else 3
+    Gc = torch.randn(1, args.height, args.width, D_out, generator=g)
+    Ga = torch.randn(1, args.height, args.width, 1, generator=g)
+    host = dict(sc, viewmat=vm, K=K, Gc=Gc, Ga=Ga)
+    dev = {k: v.to(device) for k, v in host.items()}
+    return host, dev
+
+
+def make_step(args, dev, world):
+    from mtgs_amd import rasterization, spherical_harmonics
+    from mtgs_amd.dist import FlatGradBucket
+    names = ["means", "quats", "scales", "opacities"] + (["coeffs"] if args.variant == "mtgs" else ["colors"])
+    params = {n: dev[n].requires_grad_(True) for n in names}
+    viewmat = dev["viewmat"].requires_grad_(True)
+    K, Gc, Ga = dev["K"], dev["Gc"], dev["Ga"]
+    cam_pos = torch.inverse(dev["viewmat"].detach())[0, :3, 3]
+    W, H = args.width, args.height
+    all_params = list(params.values()) + [viewmat]
+    bucket = FlatGradBucket(all_params) if world > 1 else None
+    info_box = {"bucket": bucket}
+
+    def step():
+        if bucket is not None:
+            bucket.zero()
+        else:
+            for p in all_params:
+                p.grad = None
+        if args.variant == "mtgs":
+            dirs = params["means"].detach() - cam_pos
+            rgb = torch.clamp(spherical_harmonics(3, dirs, params["coeffs"]) + 0.5, 0.0, 1.0)
+            render, alpha, info = rasterization(
+                means=params["means"], quats=params["quats"], scales=params["scales"],
+                opacities=params["opacities"], colors=rgb, viewmats=viewmat, Ks=K, width=W, height=H,
+                tile_size=16, packed=False, near_plane=0.01, far_plane=1e10, render_mode="RGB+ED",
+                sparse_grad=False, absgrad=True, rasterize_mode="antialiased")
+        else:
+            render, alpha, info = rasterization(
+                means=params["means"], quats=params["quats"], scales=params["scales"],
+                opacities=params["opacities"], colors=params["colors"], viewmats=viewmat, Ks=K,
+                width=W, height=H, tile_size=16, packed=False, render_mode="RGB", absgrad=False,
+                rasterize_mode="classic")
+        info["means2d"].retain_grad()
+        torch.autograd.backward([render, alpha], [Gc, Ga])
+        if bucket is not None:
+            bucket.all_reduce()
+        info_box["info"] = info
+        return render, alpha
+
+    return step, all_params, info_box
+
+
+def cpu_baseline(args, host, steps):
+    """oracle/gsplat_oracle.c (CPU restatement of the same path) on this box's host cores."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    a = {k: v.numpy() for k, v in host.items()}
+    W, H = args.width, args.height
+    mtgs = args.variant == "mtgs"
+    cam_pos = np.linalg.inv(a["viewmat"][0].astype(np.float64))[:3, 3].astype(np.float32)
+
+    def one():
+        if mtgs:
+            dirs = a["means"] - cam_pos
+            rgb = np.clip(orc.sh_fwd(3, dirs, a["coeffs"]) + 0.5, 0.0, 1.0)
+            r, al, m = orc.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], rgb, a["viewmat"],
+                                         a["K"], W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+            alc = np.maximum(al, 1e-10)
+            Gc_raw = a["Gc"].copy()
+            Gc_raw[..., -1:] = a["Gc"][..., -1:] / alc
+            Ga_tot = a["Ga"] - (m["render_raw"][..., -1:] / alc ** 2) * a["Gc"][..., -1:] * (al > 1e-10)
+        else:
+            r, al, m = orc.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"],
+                                         a["viewmat"], a["K"], W, H)
+            Gc_raw, Ga_tot = a["Gc"], a["Ga"]
+        v2d, vabs, vcon, vcol, vop = orc.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H,
+                                                   16, m["isect_offsets"], m["flatten_ids"], al, m["last_ids"],
+                                                   Gc_raw, Ga_tot, absgrad=mtgs)
+        v_depth = vcol[..., -1].copy() if mtgs else np.zeros_like(vop)
+        v_comp = vop * a["opacities"][None] if mtgs else None
+        orc.project_bwd(a["means"], a["quats"], a["scales"], a["viewmat"], a["K"], W, H, 0.3, m["radii"], m["conics"],
+                        m["compensations"], v2d, v_depth, vcon, v_comp)
+        if mtgs:
+            mask = (rgb + 0.0 > 0.0) & (rgb < 1.0)  # clamp VJP
+            orc.sh_bwd(3, dirs, a["coeffs"], vcol[0, :, :3] * mask)
+
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {"value": round(W * H / t / 1e6, 4), "unit": "Mpix/s", "cores": orc.num_threads(),
+            "kind": "port", "ms_per_step": round(t * 1e3, 1),
+            "sample": f"{steps} full step(s) of the same workload ({args.n_gaussians} Gaussians, {W}x{H}, "
+                      f"fwd+bwd, variant {args.variant}) by oracle/gsplat_oracle.c with OpenMP; median"}
+
+
+def main():
+    args = parse_args()
+    from mtgs_amd import _lib, dist as mdist
+    rank, local_rank, world = mdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    device = torch.device("cuda", torch.cuda.current_device())
+    _lib.load()
+    host, dev = build_inputs(args, rank, device)
+    step, all_params, info_box = make_step(args, dev, world)
+    bucket = info_box["bucket"]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    _lib.time_calls([DOMINANT])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = _lib.timed_ms().get(DOMINANT, [])
+    _lib.time_calls(())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = info_box["info"]
+    n_vis = int((info["radii"] > 0).sum().item())
+    M = int(info["flatten_ids"].numel())
+    P = args.width * args.height
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * P / (elapsed / args.steps) / 1e6
+
+    # algorithmic HBM bytes of one compositing-backward launch
+    D = 4 if args.variant == "mtgs" else 3
+    A = 1 if args.variant == "mtgs" else 0
+    bytes_bwd = P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A)
+    k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    achieved = bytes_bwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_blend_bwd.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(args.variant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "rendered Mpix/s (fwd+bwd) @ 2M Gaussians 1920x1080",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: {args.n_gaussians} Gaussians (WB-v1 seed {args.seed}), "
+                        f"{args.width}x{args.height}, 1 camera/GPU, fwd+bwd, variant={args.variant}"
+                        + (" (SH deg 3 K=16 -> RGB+ED, antialiased, absgrad, viewmat grad)" if args.variant == "mtgs"
+                           else " (colours given, RGB, classic)"),
+            "n_gaussians": args.n_gaussians, "width": args.width, "height": args.height,
+            "n_visible": n_vis, "n_intersections": M,
+            "parallelism": f"view-parallel dp{world}, 1 all-reduce of {bucket.nbytes() if bucket else 0} grad bytes/step",
+        },
+        "roofline": {"kernel": "blend_bwd_kernel (mtgs_blend_bwd)", "bound": "hbm",
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
+                     "launches_timed": len(kernel_ms),
+                     "note": "kernel is VALU/LDS/atomic bound, not HBM bound (DESIGN.md section 4)"},
+    }
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

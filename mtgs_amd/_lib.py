@@ -73,8 +73,31 @@ def stream_of(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_timed: dict = {}  # entry-point name -> list of (start_event, end_event); filled when enabled
+
+
+def time_calls(names=()) -> None:
+    """Bracket every call of the named entry points with HIP events on the current stream (the
+    stream the kernels are launched on).  `time_calls(())` disables.  Used by bench.py only."""
+    _timed.clear()
+    for n in names:
+        _timed[n] = []
+
+
+def timed_ms() -> dict:
+    """name -> list of elapsed milliseconds (call torch.cuda.synchronize() first)."""
+    return {n: [s.elapsed_time(e) for s, e in evs] for n, evs in _timed.items()}
+
+
 def call(name: str, *args) -> None:
+    evs = _timed.get(name) if _timed else None
+    if evs is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
     rc = getattr(load(), name)(*args)
+    if evs is not None:
+        e.record()
+        evs.append((s, e))
     if rc != 0:
         msg = load().mtgs_rast_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{name} failed (code {rc}): {msg}")

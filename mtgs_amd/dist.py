@@ -1,0 +1,102 @@
+"""View-parallel data parallelism for multi-traversal training: one process per GPU, replicated
+Gaussians, each rank renders its own camera(s), ONE all-reduce of the Gaussian gradients per step
+over RCCL/xGMI (torch.distributed backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+
+The reference's only collective site is nerfstudio's DDP wrap
+(/root/reference/mtgs/scene_model/custom_pipeline.py:87-89), which cannot survive densification
+(SURVEY.md section 5); its documented multi-GPU mode is scene-per-GPU.  This module is the
+MI355X-native equivalent for the step itself: all parameter gradients live in ONE flat fp32
+buffer (236 B per Gaussian at SH degree 3), so a step issues a single large collective instead
+of per-tensor buckets -- xGMI is point-to-point (7 links per GPU), large messages are what keep
+every link busy.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Initialises torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
+    Returns (rank, local_rank, world_size).  A single process (no env) returns (0, 0, 1)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def camera_for_rank(step: int, rank: int, world: int, n_cameras: int) -> int:
+    """Round-robin view sharding: at step s, rank r renders camera (s*world + r) mod n_cameras."""
+    return (step * world + rank) % n_cameras
+
+
+class FlatGradBucket:
+    """All gradients of `params` as views into one contiguous fp32 buffer.
+
+    `param.grad` is pre-set to a view of the buffer, so autograd accumulates in place and
+    `all_reduce()` is a single collective over the whole buffer (no flatten/unflatten copies)."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.params: List[torch.Tensor] = list(params)
+        assert self.params, "no parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            assert p.device == dev and p.dtype == dt and p.is_leaf and p.requires_grad
+        # 256-byte aligned segments keep every view 16-byte aligned for vector loads
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.views = []
+        for p, o in zip(self.params, offs):
+            v = self.flat[o:o + p.numel()].view_as(p)
+            p.grad = v
+            self.views.append(v)
+
+    def zero(self) -> None:
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):  # re-attach in case someone replaced .grad
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def all_reduce(self, average: bool = False, group=None, async_op: bool = False):
+        """Sum (or mean, to mimic DDP) the gradients over ranks.  No-op in a single process."""
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if average:
+            if async_op:
+                work.wait()
+            self.flat.div_(dist.get_world_size(group))
+        return work
+
+
+def all_reduce_stats(sum_tensors: Iterable[torch.Tensor] = (), max_tensors: Iterable[torch.Tensor] = (),
+                     group=None) -> None:
+    """Densification statistics must be identical on every rank: running
+    grad-norm sums and visibility counts are summed, max screen-space radii are max-reduced
+    (/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:457-474)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in sum_tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    for t in max_tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
