@@ -1,0 +1,59 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/mtgs_rast.h declares,
+and validates arguments on the host before any launch (no compute calls here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def header_symbols():
+    text = (ROOT / "include" / "mtgs_rast.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mtgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_operator_table():
+    syms = header_symbols()
+    for must in ("mtgs_sh_fwd", "mtgs_sh_bwd", "mtgs_project_fwd", "mtgs_project_bwd", "mtgs_isect_count",
+                 "mtgs_isect_scan", "mtgs_isect_emit", "mtgs_sort_pairs", "mtgs_isect_offsets", "mtgs_blend_fwd",
+                 "mtgs_blend_bwd", "mtgs_rast_version", "mtgs_rast_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from mtgs_amd import _lib
+    syms = header_symbols()
+    assert sorted(_lib.EXPORTS) == syms, "python binding table and header disagree"
+    raw = C.CDLL(str(_lib.LIB_PATH))
+    for s in syms:
+        assert hasattr(raw, s), f"{s} not exported by libmtgs_rast.so"
+    assert hip_lib.mtgs_rast_version() == _lib.ABI_VERSION == 1
+
+
+def test_host_side_argument_validation(hip_lib):
+    """Bad arguments are rejected before anything is launched, with a message."""
+    from mtgs_amd import _lib
+    n = C.c_size_t(0)
+    assert hip_lib.mtgs_sort_workspace_bytes(-1, C.byref(n)) == 1
+    assert b"mtgs_sort_workspace_bytes" in hip_lib.mtgs_rast_last_error()
+    assert hip_lib.mtgs_scan_workspace_bytes(1 << 20, C.byref(n)) == 0 and n.value >= 8 * (1 << 20) // 2048
+    # SH degree 5 / K too small
+    assert hip_lib.mtgs_sh_fwd(10, 16, 5, None, None, None, None, None) == 1
+    assert hip_lib.mtgs_sh_fwd(10, 4, 3, None, None, None, None, None) == 1
+    with pytest.raises(RuntimeError, match="degree"):
+        _lib.call("mtgs_sh_fwd", 10, 4, 3, None, None, None, None, None)
+    # null pointers
+    assert hip_lib.mtgs_project_fwd(1, 10, None, None, None, None, None, 64, 64, 0.3, 0.01, 1e10, 0.0,
+                                    None, None, None, None, None, None) == 1
+    # tile size other than 16 and unsupported channel counts are refused by name
+    assert hip_lib.mtgs_blend_fwd(1, 10, 3, None, None, None, None, None, 64, 64, 8, 8, 8, None, None, 0,
+                                  None, None, None, None) == 4
+    assert b"tile_size" in hip_lib.mtgs_rast_last_error()
+    assert hip_lib.mtgs_blend_fwd(1, 10, 9, None, None, None, None, None, 64, 64, 16, 4, 4, None, None, 0,
+                                  None, None, None, None) == 4
+    # empty problems are a no-op success
+    assert hip_lib.mtgs_sh_fwd(0, 16, 3, None, None, None, None, None) == 0
+    assert hip_lib.mtgs_sort_pairs(0, 46, None, None, None, None, None, 0, None) == 0

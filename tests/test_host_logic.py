@@ -1,0 +1,105 @@
+"""Host-side logic that does not need a GPU: the gsplat-compatible surface, loud failure without a
+device, the synthetic generator, and the gradient bucket."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+
+def _args(N=4):
+    z = lambda *s: torch.zeros(*s)
+    return (z(N, 3), z(N, 4), z(N, 3), z(N), z(N, 3), torch.eye(4)[None], torch.eye(3)[None], 32, 32)
+
+
+def test_shim_exposes_the_imports_mtgs_uses():
+    import gsplat
+    from gsplat.cuda._wrapper import spherical_harmonics
+    from gsplat.rendering import rasterization
+    import mtgs_amd
+    assert gsplat.__version__ == "1.4.0"
+    assert rasterization is mtgs_amd.rasterization and spherical_harmonics is mtgs_amd.spherical_harmonics
+    import inspect
+    sig = inspect.signature(rasterization)
+    # the kwargs MTGS passes (mtgs_scene_graph.py:641-659) and gsplat's defaults
+    for name in ("means", "quats", "scales", "opacities", "colors", "viewmats", "Ks", "width", "height", "tile_size",
+                 "packed", "near_plane", "far_plane", "render_mode", "sparse_grad", "absgrad", "rasterize_mode"):
+        assert name in sig.parameters
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert d["near_plane"] == 0.01 and d["far_plane"] == 1e10 and d["eps2d"] == 0.3 and d["radius_clip"] == 0.0
+    assert d["packed"] is True and d["tile_size"] == 16 and d["render_mode"] == "RGB" and d["channel_chunk"] == 32
+
+
+@pytest.mark.parametrize("kw,name", [
+    (dict(packed=True), "packed"), (dict(packed=False, sparse_grad=True), "sparse_grad"),
+    (dict(packed=False, distributed=True), "distributed"), (dict(packed=False, camera_model="ortho"), "camera_model"),
+    (dict(packed=False, tile_size=32), "tile_size"), (dict(packed=False, covars=torch.zeros(4, 3, 3)), "covars")])
+def test_unsupported_options_raise_by_name(kw, name):
+    from mtgs_amd import rasterization
+    with pytest.raises(NotImplementedError, match=name):
+        rasterization(*_args(), **kw)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must fail loudly -- the product path never computes on the host."""
+    from mtgs_amd import rasterization, spherical_harmonics
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rasterization(*_args(), packed=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        spherical_harmonics(0, torch.zeros(4, 3), torch.zeros(4, 1, 3))
+
+
+def test_product_never_imports_the_oracle():
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    for p in list((root / "mtgs_amd").rglob("*.py")) + list((root / "gsplat").rglob("*.py")):
+        src = p.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_shape_checks_mirror_gsplat():
+    from mtgs_amd import rasterization, spherical_harmonics
+    a = list(_args())
+    a[3] = torch.zeros(5)                       # opacities of the wrong length
+    with pytest.raises(AssertionError):
+        rasterization(*a, packed=False)
+    with pytest.raises(AssertionError):          # (deg+1)^2 > K
+        spherical_harmonics(3, torch.zeros(4, 3), torch.zeros(4, 9, 3))
+
+
+def test_wbv1_generator_is_deterministic():
+    from mtgs_amd.synthetic import make_camera, make_scene
+    a, b = make_scene(1000, seed=0, sh_degree=3), make_scene(1000, seed=0, sh_degree=3)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert a["coeffs"].shape == (1000, 16, 3) and a["quats"].norm(dim=-1).sub(1).abs().max() < 1e-6
+    assert a["scales"].min() >= 0.02 - 1e-6 and a["scales"].max() <= 0.2 + 1e-6
+    vm, K = make_camera(1920, 1080, yaw_deg=45.0)
+    assert vm.shape == (1, 4, 4) and K[0, 0, 0] == 0.8 * 1920 and K[0, 0, 2] == 960
+    np.testing.assert_allclose((vm[0, :3, :3] @ vm[0, :3, :3].T).numpy(), np.eye(3), atol=1e-6)
+
+
+def test_mtgs_c2w_to_viewmat_is_the_inverse_with_flipped_axes():
+    from mtgs_amd.synthetic import mtgs_c2w_to_viewmat
+    g = torch.Generator().manual_seed(0)
+    q = torch.nn.functional.normalize(torch.randn(4, generator=g), dim=0)
+    from oracle.torch_ref import quat_to_rotmat
+    c2w = torch.eye(4)
+    c2w[:3, :3] = quat_to_rotmat(q[None])[0]
+    c2w[:3, 3] = torch.tensor([1.0, 2.0, 3.0])
+    vm = mtgs_c2w_to_viewmat(c2w)[0]
+    flip = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0]))
+    np.testing.assert_allclose((vm @ c2w @ flip).numpy(), np.eye(4), atol=1e-5)
+
+
+def test_flat_grad_bucket_single_process():
+    from mtgs_amd.dist import FlatGradBucket
+    a = torch.randn(5, 3, requires_grad=True)
+    b = torch.randn(7, requires_grad=True)
+    bucket = FlatGradBucket([a, b])
+    ((a * 2).sum() + (b * 3).sum()).backward()
+    assert a.grad.data_ptr() == bucket.views[0].data_ptr()
+    assert torch.all(bucket.flat[:15] == 2) and torch.all(bucket.flat[64:71] == 3)
+    bucket.zero()
+    assert bucket.flat.abs().max() == 0 and a.grad.data_ptr() == bucket.views[0].data_ptr()
+    assert bucket.all_reduce() is None          # no process group: no-op
