@@ -7,21 +7,28 @@
 //  * ONE WAVE PER 16x16 TILE, 4 PIXELS PER LANE (lane l owns column l%16 of rows l/16 + {0,4,8,12}).
 //    A tile is a single wavefront, so there is no workgroup barrier anywhere in the hot loop,
 //    early termination is one ballot, and in the backward the cross-lane reduction of every
-//    per-Gaussian gradient is amortised over 4 pixels per lane and issues ONE set of atomics per
-//    (tile, Gaussian) instead of one per 32-thread warp (8 per tile in the reference layout).
-//  * Per-tile Gaussian chunks are staged through LDS 64 at a time (coalesced flatten_ids read,
-//    gathered attribute rows), then consumed as wave-uniform broadcast ds_read_b128.
-//  * Cross-lane sums use DPP-modified v_add_f32 (6 VALU ops per value, no LDS traffic).
-//  * fp32 atomics are the hardware global_atomic_add_f32 (unsafeAtomicAdd).
+//    per-Gaussian gradient is amortised over 4 pixels per lane and issues ONE atomic instruction
+//    per (tile, Gaussian) instead of one set per 32-thread warp (8 per tile in the reference layout).
+//  * Per-tile Gaussian chunks are staged through LDS 64 at a time (coalesced flatten_ids read one
+//    chunk AHEAD, gathered attribute rows), then consumed as wave-uniform broadcast ds_read_b128.
+//  * "Does this Gaussian touch any pixel of the tile" is an OR of the per-pixel compare masks
+//    (SGPR pairs) -- one s_cbranch, no cross-lane traffic.
+//  * Cross-lane sums: all per-Gaussian gradient components are reduced TOGETHER with the transposed
+//    v_permlane16/32_swap + DPP reduction of wave_reduce.hpp (30 VALU ops for 12 values, no LDS),
+//    which leaves value j in the lanes of row j%4 of register j/4: lane 16*(j%4) + j/4 issues the
+//    global_atomic_add_f32 (unsafeAtomicAdd = the hardware fp32 atomic), i.e. ONE atomic
+//    instruction per (tile, Gaussian).
+//  * 1/(1-alpha) is v_rcp_f32 and exp is v_exp_f32 (the reference is built with --use_fast_math).
 //  * blockIdx -> tile mapping is XCD-aware: workgroup b runs on XCD b%8, so each XCD is given a
 //    contiguous band of tiles and neighbouring tiles (which share Gaussians) share an L2.
 //  * Wide channel counts (D > 8) fall back to 1 pixel per lane / 4 waves per tile.
 //
-// Roofline: the kernels are VALU/LDS bound (about 25 / 70 flops per pixel x Gaussian pair, fwd /
-// bwd) -- MFMA is deliberately unused, there is no dense contraction.  Algorithmic HBM bytes:
+// Roofline: the kernels are VALU bound (about 25 / 70 flops per pixel x Gaussian pair, fwd / bwd)
+// -- MFMA is deliberately unused, there is no dense contraction.  Algorithmic HBM bytes:
 //   fwd: M*(4 + 24 + 4D) gathered attributes + P*(4D + 8) written
 //   bwd: P*(4D + 12) read + M*(4 + 24 + 4D) gathered + N_vis*(24 + 4D (+8 absgrad)) accumulated
 #include "common.hpp"
+#include "wave_reduce.hpp"
 
 namespace {
 
@@ -41,32 +48,38 @@ __device__ __forceinline__ int64_t block_to_tile(int64_t total_tiles) {
     return (b & 7) * chunk + (b >> 3);
 }
 
-template <int D, int NT>
-__device__ __forceinline__ void stage_batch(float *__restrict__ s_rec, int32_t *__restrict__ s_id,
-                                            const int32_t *__restrict__ flatten_ids,
-                                            const float *__restrict__ means2d,
-                                            const float *__restrict__ conics,
-                                            const float *__restrict__ colors,
-                                            const float *__restrict__ opacities, int64_t idx,
-                                            bool in_range) {
+// Gather one Gaussian's attributes (row g of the per-camera arrays) into this thread's LDS record.
+template <int D>
+__device__ __forceinline__ void stage_record(float *__restrict__ s_rec, const float *__restrict__ means2d,
+                                             const float *__restrict__ conics,
+                                             const float *__restrict__ colors,
+                                             const float *__restrict__ opacities, int32_t g) {
     constexpr int REC = Rec<D>::N;
-    const int tid = threadIdx.x;
-    if (in_range) {
-        const int32_t g = flatten_ids[idx];
-        const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
-        const float ca = conics[(int64_t)g * 3], cb = conics[(int64_t)g * 3 + 1], cc = conics[(int64_t)g * 3 + 2];
-        const float op = opacities[g];
-        float r[REC];
-        r[0] = xy.x; r[1] = xy.y; r[2] = ca; r[3] = cb; r[4] = cc; r[5] = op;
+    const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
+    const float ca = conics[(int64_t)g * 3], cb = conics[(int64_t)g * 3 + 1], cc = conics[(int64_t)g * 3 + 2];
+    const float op = opacities[g];
+    float r[REC];
+    r[0] = xy.x; r[1] = xy.y; r[2] = ca; r[3] = cb; r[4] = cc; r[5] = op;
 #pragma unroll
-        for (int k = 0; k < D; ++k) r[6 + k] = colors[(int64_t)g * D + k];
+    for (int k = 0; k < D; ++k) r[6 + k] = colors[(int64_t)g * D + k];
 #pragma unroll
-        for (int k = 6 + D; k < REC; ++k) r[k] = 0.f;
-        float4 *dst = reinterpret_cast<float4 *>(s_rec + tid * REC);
+    for (int k = 6 + D; k < REC; ++k) r[k] = 0.f;
+    float4 *dst = reinterpret_cast<float4 *>(s_rec + threadIdx.x * REC);
 #pragma unroll
-        for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
-        if (s_id) s_id[tid] = g;
-    }
+    for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+}
+
+// alpha of one Gaussian at one pixel.  u = a dx + b dy and w = b dx + c dy are kept: the backward
+// needs them for the mean gradient.  sigma = 0.5 (dx u + dy w) == 0.5 (a dx^2 + c dy^2) + b dx dy.
+struct GaussEval { float u, w, sigma, vis, alpha_raw; };
+__device__ __forceinline__ GaussEval eval_gauss(float a, float b, float c, float opac, float dx, float dy) {
+    GaussEval e;
+    e.u = a * dx + b * dy;
+    e.w = b * dx + c * dy;
+    e.sigma = 0.5f * (dx * e.u + dy * e.w);
+    e.vis = __expf(-e.sigma);
+    e.alpha_raw = opac * e.vis;
+    return e;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -106,12 +119,16 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     const int64_t start = offsets[tile];
     const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
 
+    // flatten_ids of the NEXT chunk are fetched while the current chunk is composited
+    int32_t g_next = (start + tid < end) ? flatten_ids[start + tid] : 0;
     for (int64_t b0 = start; b0 < end; b0 += NT) {
         bool all_done = true;
 #pragma unroll
         for (int p = 0; p < PPL; ++p) all_done = all_done && done[p];
         if (__syncthreads_and(all_done)) break;
-        stage_batch<D, NT>(s_rec, nullptr, flatten_ids, means2d, conics, colors, opacities, b0 + tid, b0 + tid < end);
+        const int32_t g_cur = g_next;
+        if (b0 + tid < end) stage_record<D>(s_rec, means2d, conics, colors, opacities, g_cur);
+        if (b0 + NT + tid < end) g_next = flatten_ids[b0 + NT + tid];
         __syncthreads();
         const int bsz = (int)min((int64_t)NT, end - b0);
         for (int t = 0; t < bsz; ++t) {
@@ -119,38 +136,34 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
             const float2 r1 = *reinterpret_cast<const float2 *>(s_rec + t * REC + 4);
             const float dx = r0.x - px;
             float alpha[PPL];
-            bool valid[PPL], any = false;
+            bool valid[PPL];
+            unsigned long long any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                const float dy = r0.y - py[p];
-                const float sigma = 0.5f * (r0.z * dx * dx + r1.x * dy * dy) + r0.w * dx * dy;
-                const float vis = __expf(-sigma);
-                alpha[p] = fminf(kAlphaMax, r1.y * vis);
-                valid[p] = !done[p] && sigma >= 0.f && alpha[p] >= kAlphaMin;
-                any = any || valid[p];
+                const GaussEval e = eval_gauss(r0.z, r0.w, r1.x, r1.y, dx, r0.y - py[p]);
+                alpha[p] = fminf(kAlphaMax, e.alpha_raw);
+                valid[p] = !done[p] && e.sigma >= 0.f && alpha[p] >= kAlphaMin;
+                any |= __ballot(valid[p]);
             }
-            if (!__any(any)) continue;
+            if (any == 0) continue;
             float col[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 6 + k];
-            bool stopped = false;
+            unsigned long long stopped = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                if (valid[p]) {
-                    const float next_T = T[p] * (1.f - alpha[p]);
-                    if (next_T <= kTMin) {
-                        done[p] = true;
-                        stopped = true;
-                    } else {
-                        const float w = alpha[p] * T[p];
+                const float next_T = T[p] * (1.f - alpha[p]);
+                const bool stop = valid[p] && next_T <= kTMin;
+                const bool use = valid[p] && !stop;
+                stopped |= __ballot(stop);
+                done[p] = done[p] || stop;
+                const float w = use ? alpha[p] * T[p] : 0.f;
 #pragma unroll
-                        for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
-                        last[p] = (int32_t)(b0 + t);
-                        T[p] = next_T;
-                    }
-                }
+                for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
+                last[p] = use ? (int32_t)(b0 + t) : last[p];
+                T[p] = use ? next_T : T[p];
             }
-            if (__any(stopped)) {
+            if (stopped) {
                 bool ad = true;
 #pragma unroll
                 for (int p = 0; p < PPL; ++p) ad = ad && done[p];
@@ -172,6 +185,13 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gradient components per Gaussian, in reduction order: xy(2) |xy|(2) conic(3) opacity(1) colour(D)
+template <int D>
+struct GradLayout {
+    static constexpr int NV = 8 + D;
+    static constexpr int NR = (NV + 3) / 4;
+};
+
 template <int D, int PPL>
 __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     int C, const float *__restrict__ means2d, const float *__restrict__ conics,
@@ -183,6 +203,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
     float *__restrict__ v_colors, float *__restrict__ v_opacities) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
+    constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
     __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
     __shared__ int32_t s_id[NT];
     __shared__ int32_t s_max[NT / 64];
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4, lane = tid & 63;
     const int ix = tx * 16 + lx;
     const float px = (float)ix + 0.5f;
-    float py[PPL], T[PPL], T_final[PPL], buf[PPL][D], vr[PPL][D], va[PPL], bgd[PPL];
+    float py[PPL], T[PPL], Tf_va[PPL], buf[PPL][D], vr[PPL][D];
     int32_t bin_final[PPL];
     int32_t my_max = -1;
 #pragma unroll
@@ -207,18 +228,19 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         py[p] = (float)iy + 0.5f;
         const bool inside = ix < W && iy < H;
         const int64_t pid = ((int64_t)cam * H + (inside ? iy : 0)) * W + (inside ? ix : 0);
-        T_final[p] = 1.f - alphas[pid];
-        T[p] = T_final[p];
-        va[p] = v_alphas[pid];
+        const float T_final = 1.f - alphas[pid];
+        T[p] = T_final;
         bin_final[p] = inside ? last_ids[pid] : -1;
         my_max = max(my_max, bin_final[p]);
-        bgd[p] = 0.f;
+        float bgd = 0.f;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             buf[p][k] = 0.f;
             vr[p][k] = v_render[pid * D + k];
-            if (backgrounds) bgd[p] += backgrounds[cam * D + k] * vr[p][k];
+            if (backgrounds) bgd += backgrounds[cam * D + k] * vr[p][k];
         }
+        // d(alpha_out)/d(alpha_i) and the background term share the factor T_final / (1 - alpha_i)
+        Tf_va[p] = T_final * (v_alphas[pid] - bgd);
     }
     // tile-wide newest contributor
     int32_t wmax = wave_max_i32(my_max);
@@ -229,11 +251,31 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         for (int w = 0; w < NT / 64; ++w) wmax = max(wmax, s_max[w]);
     }
     const int64_t top = wmax;  // sorted index of the last Gaussian any pixel of the tile used
-    const bool absgrad = v_means2d_abs != nullptr;
+    if (top < start) return;
 
+    // which gradient component this lane adds to memory after the transposed reduction:
+    // component j = 4*col + row lives in row `row` of register `col`.
+    const int a_col = lane & 15, a_row = lane >> 4;
+    const int j = 4 * a_col + a_row;
+    float *a_base = nullptr;
+    int a_stride = 0;
+    if (a_col < NR && j < NV) {
+        if (j < 2) { a_base = v_means2d + j; a_stride = 2; }
+        else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride = 2; }
+        else if (j < 7) { a_base = v_conics + (j - 4); a_stride = 3; }
+        else if (j < 8) { a_base = v_opacities; a_stride = 1; }
+        else { a_base = v_colors + (j - 8); a_stride = D; }
+    }
+
+    int32_t g_next = (top - tid >= start) ? flatten_ids[top - tid] : 0;
     for (int64_t hi = top; hi >= start; hi -= NT) {
         if (hi != top) __syncthreads();
-        stage_batch<D, NT>(s_rec, s_id, flatten_ids, means2d, conics, colors, opacities, hi - tid, hi - tid >= start);
+        const int32_t g_cur = g_next;
+        if (hi - tid >= start) {
+            stage_record<D>(s_rec, means2d, conics, colors, opacities, g_cur);
+            s_id[tid] = g_cur;
+        }
+        if (hi - NT - tid >= start) g_next = flatten_ids[hi - NT - tid];
         __syncthreads();
         const int bsz = (int)min((int64_t)NT, hi - start + 1);
         for (int t = 0; t < bsz; ++t) {
@@ -242,81 +284,57 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
             const float2 r1 = *reinterpret_cast<const float2 *>(s_rec + t * REC + 4);
             const float opac = r1.y;
             const float dx = r0.x - px;
-            float dy[PPL], vis[PPL], alpha[PPL];
-            bool valid[PPL], any = false;
+            float dy[PPL], alpha[PPL];
+            GaussEval e[PPL];
+            bool valid[PPL];
+            unsigned long long any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 dy[p] = r0.y - py[p];
-                const float sigma = 0.5f * (r0.z * dx * dx + r1.x * dy[p] * dy[p]) + r0.w * dx * dy[p];
-                vis[p] = __expf(-sigma);
-                alpha[p] = fminf(kAlphaMax, opac * vis[p]);
-                valid[p] = idx <= bin_final[p] && sigma >= 0.f && alpha[p] >= kAlphaMin;
-                any = any || valid[p];
+                e[p] = eval_gauss(r0.z, r0.w, r1.x, opac, dx, dy[p]);
+                alpha[p] = fminf(kAlphaMax, e[p].alpha_raw);
+                valid[p] = idx <= bin_final[p] && e[p].sigma >= 0.f && alpha[p] >= kAlphaMin;
+                any |= __ballot(valid[p]);
             }
-            if (!__any(any)) continue;
+            if (any == 0) continue;
             float col[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 6 + k];
-            float g_xy0 = 0.f, g_xy1 = 0.f, g_ab0 = 0.f, g_ab1 = 0.f, g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f, g_op = 0.f;
-            float g_col[D];
+            float gv[4 * NR];
 #pragma unroll
-            for (int k = 0; k < D; ++k) g_col[k] = 0.f;
+            for (int k = 0; k < 4 * NR; ++k) gv[k] = 0.f;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 if (valid[p]) {
-                    const float ra = 1.0f / (1.0f - alpha[p]);
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha[p]);
                     T[p] *= ra;
                     const float fac = alpha[p] * T[p];
-                    float v_alpha = 0.f;
+                    float v_alpha = Tf_va[p] * ra;
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        g_col[k] += fac * vr[p][k];
+                        gv[8 + k] += fac * vr[p][k];
                         v_alpha += (col[k] * T[p] - buf[p][k] * ra) * vr[p][k];
                         buf[p][k] += col[k] * fac;
                     }
-                    v_alpha += T_final[p] * ra * va[p];
-                    if (backgrounds) v_alpha += -T_final[p] * ra * bgd[p];
-                    if (opac * vis[p] <= kAlphaMax) {
-                        const float v_sigma = -opac * vis[p] * v_alpha;
-                        g_c0 += 0.5f * v_sigma * dx * dx;
-                        g_c1 += v_sigma * dx * dy[p];
-                        g_c2 += 0.5f * v_sigma * dy[p] * dy[p];
-                        const float vx = v_sigma * (r0.z * dx + r0.w * dy[p]);
-                        const float vy = v_sigma * (r0.w * dx + r1.x * dy[p]);
-                        g_xy0 += vx; g_xy1 += vy;
-                        g_ab0 += fabsf(vx); g_ab1 += fabsf(vy);
-                        g_op += vis[p] * v_alpha;
+                    if (e[p].alpha_raw <= kAlphaMax) {
+                        const float v_sigma = -e[p].alpha_raw * v_alpha;
+                        const float hs = 0.5f * v_sigma;
+                        gv[4] += hs * dx * dx;
+                        gv[5] += v_sigma * dx * dy[p];
+                        gv[6] += hs * dy[p] * dy[p];
+                        const float vx = v_sigma * e[p].u, vy = v_sigma * e[p].w;
+                        gv[0] += vx; gv[1] += vy;
+                        gv[2] += fabsf(vx); gv[3] += fabsf(vy);
+                        gv[7] += e[p].vis * v_alpha;
                     }
                 }
             }
-            // wave reduction (DPP), one set of atomics per (wave, Gaussian)
-            g_xy0 = wave_sum_to_lane63(g_xy0);
-            g_xy1 = wave_sum_to_lane63(g_xy1);
-            g_c0 = wave_sum_to_lane63(g_c0);
-            g_c1 = wave_sum_to_lane63(g_c1);
-            g_c2 = wave_sum_to_lane63(g_c2);
-            g_op = wave_sum_to_lane63(g_op);
+            float red[NR];
+            wave_reduce_x4<NR>(gv, red);
+            float val = red[0];
 #pragma unroll
-            for (int k = 0; k < D; ++k) g_col[k] = wave_sum_to_lane63(g_col[k]);
-            if (absgrad) {
-                g_ab0 = wave_sum_to_lane63(g_ab0);
-                g_ab1 = wave_sum_to_lane63(g_ab1);
-            }
-            if (lane == 63) {
-                const int64_t g = s_id[t];
-                unsafeAtomicAdd(v_means2d + g * 2, g_xy0);
-                unsafeAtomicAdd(v_means2d + g * 2 + 1, g_xy1);
-                if (absgrad) {
-                    unsafeAtomicAdd(v_means2d_abs + g * 2, g_ab0);
-                    unsafeAtomicAdd(v_means2d_abs + g * 2 + 1, g_ab1);
-                }
-                unsafeAtomicAdd(v_conics + g * 3, g_c0);
-                unsafeAtomicAdd(v_conics + g * 3 + 1, g_c1);
-                unsafeAtomicAdd(v_conics + g * 3 + 2, g_c2);
-                unsafeAtomicAdd(v_opacities + g, g_op);
-#pragma unroll
-                for (int k = 0; k < D; ++k) unsafeAtomicAdd(v_colors + g * D + k, g_col[k]);
-            }
+            for (int i = 1; i < NR; ++i) val = (a_col == i) ? red[i] : val;
+            if (a_base) unsafeAtomicAdd(a_base + (int64_t)s_id[t] * a_stride, val);
         }
     }
 }
