@@ -116,19 +116,25 @@ int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int ti
  * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (nullable).
  * out: render[C,H,W,D] alphas[C,H,W] last_ids[C,H,W] i32 (index into the sorted list).
  * bwd: v_means2d[C,N,2] v_conics[C,N,3] v_colors[C,N,D] v_opacities[C,N] and v_means2d_abs
- * (nullable, absgrad) must be ZERO-FILLED by the caller; gradients are accumulated with atomics. */
+ * (nullable, absgrad) must be ZERO-FILLED by the caller; gradients are accumulated with atomics.
+ * tile_order[C*tile_h*tile_w] (nullable) is a permutation of the tile indices giving the order in
+ * which tiles are dispatched (results do not depend on it); mtgs_tile_schedule fills it with the
+ * tiles sorted by decreasing list length (no gsplat counterpart: a scheduling aid for the
+ * one-wave-per-tile kernels). */
+int mtgs_tile_schedule(int C, int tile_w, int tile_h, const int32_t *offsets, int64_t M,
+                       int32_t *tile_order, void *stream);
 int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *backgrounds, int width,
                    int height, int tile_size, int tile_w, int tile_h, const int32_t *offsets,
                    const int32_t *flatten_ids, int64_t M, float *render, float *alphas,
-                   int32_t *last_ids, void *stream);
+                   int32_t *last_ids, const int32_t *tile_order, void *stream);
 int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *backgrounds, int width,
                    int height, int tile_size, int tile_w, int tile_h, const int32_t *offsets,
                    const int32_t *flatten_ids, int64_t M, const float *alphas,
                    const int32_t *last_ids, const float *v_render, const float *v_alphas,
                    float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
-                   float *v_opacities, void *stream);
+                   float *v_opacities, const int32_t *tile_order, void *stream);
 
 #ifdef __cplusplus
 }

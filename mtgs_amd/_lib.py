@@ -30,10 +30,11 @@ _SIGNATURES = {
     "mtgs_sort_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_sort_pairs": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
+    "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                       _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mtgs_blend_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
 ABI_VERSION = 1

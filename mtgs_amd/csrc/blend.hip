@@ -19,8 +19,8 @@
 //    global_atomic_add_f32 (unsafeAtomicAdd = the hardware fp32 atomic), i.e. ONE atomic
 //    instruction per (tile, Gaussian).
 //  * 1/(1-alpha) is v_rcp_f32 and exp is v_exp_f32 (the reference is built with --use_fast_math).
-//  * blockIdx -> tile mapping is XCD-aware: workgroup b runs on XCD b%8, so each XCD is given a
-//    contiguous band of tiles and neighbouring tiles (which share Gaussians) share an L2.
+//  * Tiles are dispatched longest-list-first (mtgs_tile_schedule): 8160 single-wave workgroups over
+//    1024 SIMDs leave a long tail otherwise.
 //  * Wide channel counts (D > 8) fall back to 1 pixel per lane / 4 waves per tile.
 //
 // Roofline: the kernels are VALU bound (about 25 / 70 flops per pixel x Gaussian pair, fwd / bwd)
@@ -41,11 +41,12 @@ struct Rec {  // LDS record per staged Gaussian, in floats: x y a b | c opac col
     static constexpr int N = ((6 + D + 3) / 4) * 4;
 };
 
-// XCD-aware block -> tile mapping (speed only; any mapping is correct).
-__device__ __forceinline__ int64_t block_to_tile(int64_t total_tiles) {
-    const int64_t chunk = (total_tiles + 7) / 8;
-    const int64_t b = blockIdx.x;
-    return (b & 7) * chunk + (b >> 3);
+// Block -> tile mapping.  `order` (from mtgs_tile_schedule) lists tiles by decreasing work so the
+// hardware dispatcher, which starts workgroups in blockIdx order as slots free up, runs the
+// longest tiles first (LPT scheduling) -- measured: balance matters more than keeping
+// neighbouring tiles on one XCD's L2 (contiguous per-XCD bands were 20 % slower).
+__device__ __forceinline__ int64_t block_to_tile(const int32_t *__restrict__ order) {
+    return order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
 }
 
 // Gather one Gaussian's attributes (row g of the per-camera arrays) into this thread's LDS record.
@@ -89,12 +90,12 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, int W, int H, int tw, int th,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
-    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids) {
+    float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
+    const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
-    const int64_t tile = block_to_tile(total_tiles);
-    if (tile >= total_tiles) return;
+    const int64_t tile = block_to_tile(order);
     const int cam = (int)(tile / n_tiles);
     const int t_in = (int)(tile - (int64_t)cam * n_tiles);
     const int ty = t_in / tw, tx = t_in - ty * tw;
@@ -201,15 +202,15 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     const float *__restrict__ alphas, const int32_t *__restrict__ last_ids,
     const float *__restrict__ v_render, const float *__restrict__ v_alphas,
     float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
-    float *__restrict__ v_colors, float *__restrict__ v_opacities) {
+    float *__restrict__ v_colors, float *__restrict__ v_opacities,
+    const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
     __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
     __shared__ int32_t s_id[NT];
     __shared__ int32_t s_max[NT / 64];
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
-    const int64_t tile = block_to_tile(total_tiles);
-    if (tile >= total_tiles) return;
+    const int64_t tile = block_to_tile(order);
     const int64_t start = offsets[tile];
     const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
     if (end <= start) return;
@@ -343,12 +344,12 @@ template <int D, int PPL>
 int launch_fwd(int C, const float *means2d, const float *conics, const float *colors,
                const float *opacities, const float *backgrounds, int W, int H, int tw, int th,
                const int32_t *offsets, const int32_t *flatten_ids, int64_t M, float *render,
-               float *alphas, int32_t *last_ids, hipStream_t st) {
+               float *alphas, int32_t *last_ids, const int32_t *order, hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
-    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    const unsigned grid = (unsigned)total;
     blend_fwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(C, means2d, conics, colors, opacities,
                                                          backgrounds, W, H, tw, th, offsets,
-                                                         flatten_ids, M, render, alphas, last_ids);
+                                                         flatten_ids, M, render, alphas, last_ids, order);
     return 0;
 }
 
@@ -358,13 +359,47 @@ int launch_bwd(int C, const float *means2d, const float *conics, const float *co
                const int32_t *offsets, const int32_t *flatten_ids, int64_t M, const float *alphas,
                const int32_t *last_ids, const float *v_render, const float *v_alphas,
                float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
-               float *v_opacities, hipStream_t st) {
+               float *v_opacities, const int32_t *order, hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
-    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    const unsigned grid = (unsigned)total;
     blend_bwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(
         C, means2d, conics, colors, opacities, backgrounds, W, H, tw, th, offsets, flatten_ids, M,
-        alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
+        alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, order);
     return 0;
+}
+
+// Counting sort of the tiles by decreasing list length (bucket width 4, single workgroup).
+constexpr int SCHED_THREADS = 1024, SCHED_BUCKETS = 1024;
+__global__ __launch_bounds__(SCHED_THREADS) void tile_schedule_kernel(int total_tiles, const int32_t *__restrict__ offsets,
+                                                                     int64_t M, int32_t *__restrict__ order) {
+    __shared__ int hist[SCHED_BUCKETS];
+    __shared__ int wsum[SCHED_THREADS / 64];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    auto bucket_of = [&](int t) {
+        const int64_t end = (t == total_tiles - 1) ? M : (int64_t)offsets[t + 1];
+        const int len = (int)(end - offsets[t]);
+        return SCHED_BUCKETS - 1 - min(len >> 2, SCHED_BUCKETS - 1);  // descending
+    };
+    for (int t = tid; t < total_tiles; t += SCHED_THREADS) atomicAdd(&hist[bucket_of(t)], 1);
+    __syncthreads();
+    // exclusive scan of hist (one bucket per thread)
+    const int v = hist[tid];
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += up;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    __syncthreads();
+    hist[tid] = base + inc - v;
+    __syncthreads();
+    for (int t = tid; t < total_tiles; t += SCHED_THREADS) order[atomicAdd(&hist[bucket_of(t)], 1)] = t;
 }
 
 bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32; }
@@ -389,7 +424,8 @@ extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, con
                               const float *colors, const float *opacities, const float *backgrounds,
                               int width, int height, int tile_size, int tile_w, int tile_h,
                               const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
-                              float *render, float *alphas, int32_t *last_ids, void *stream) {
+                              float *render, float *alphas, int32_t *last_ids,
+                              const int32_t *tile_order, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_fwd: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_fwd: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
@@ -401,7 +437,7 @@ extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, con
                  MTGS_EINVAL, "mtgs_blend_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     MTGS_DISPATCH_D(launch_fwd, C, means2d, conics, colors, opacities, backgrounds, width, height,
-                    tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, st);
+                    tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_fwd");
     return MTGS_OK;
 }
@@ -412,7 +448,8 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
                               const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
                               const float *alphas, const int32_t *last_ids, const float *v_render,
                               const float *v_alphas, float *v_means2d, float *v_means2d_abs,
-                              float *v_conics, float *v_colors, float *v_opacities, void *stream) {
+                              float *v_conics, float *v_colors, float *v_opacities,
+                              const int32_t *tile_order, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_bwd: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
@@ -426,7 +463,19 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
     hipStream_t st = (hipStream_t)stream;
     MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, width, height,
                     tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, v_render, v_alphas,
-                    v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, st);
+                    v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_bwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_tile_schedule(int C, int tile_w, int tile_h, const int32_t *offsets, int64_t M,
+                                  int32_t *tile_order, void *stream) {
+    MTGS_REQUIRE(C >= 0 && tile_w > 0 && tile_h > 0 && M >= 0, MTGS_EINVAL, "mtgs_tile_schedule: bad sizes");
+    const int64_t total = (int64_t)C * tile_w * tile_h;
+    if (total == 0) return MTGS_OK;
+    MTGS_REQUIRE(total < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_tile_schedule: too many tiles");
+    MTGS_REQUIRE(offsets && tile_order, MTGS_EINVAL, "mtgs_tile_schedule: null pointer");
+    tile_schedule_kernel<<<1, SCHED_THREADS, 0, (hipStream_t)stream>>>((int)total, offsets, M, tile_order);
+    MTGS_CHECK_LAUNCH("mtgs_tile_schedule");
     return MTGS_OK;
 }

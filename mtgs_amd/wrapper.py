@@ -228,10 +228,13 @@ class _RasterizeToPixels(torch.autograd.Function):
         alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
         M = flatten_ids.numel()
+        # longest-list-first dispatch order of the tiles (scheduling aid, does not change results)
+        order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
+        call("mtgs_tile_schedule", Cn, tw, th, ptr(isect_offsets), M, ptr(order), stream_of(m2d))
         call("mtgs_blend_fwd", Cn, N, D, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), width,
              height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), M, ptr(render),
-             ptr(alphas), ptr(last_ids), stream_of(m2d))
-        ctx.save_for_backward(m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids)
+             ptr(alphas), ptr(last_ids), ptr(order), stream_of(m2d))
+        ctx.save_for_backward(m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids, order)
         ctx.dims = (width, height, tile_size, tw, th)
         ctx.absgrad = absgrad
         ctx.means2d_ref = means2d  # the tensor MTGS calls .retain_grad() on; .absgrad is set on it
@@ -239,7 +242,7 @@ class _RasterizeToPixels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alphas):
-        m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids, order = ctx.saved_tensors
         width, height, tile_size, tw, th = ctx.dims
         Cn, N, D = col.shape
         dev = m2d.device
@@ -252,7 +255,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         call("mtgs_blend_bwd", Cn, N, D, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), width,
              height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), flatten_ids.numel(),
              ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs),
-             ptr(v_conics), ptr(v_colors), ptr(v_opacities), stream_of(m2d))
+             ptr(v_conics), ptr(v_colors), ptr(v_opacities), ptr(order), stream_of(m2d))
         if ctx.absgrad:
             ctx.means2d_ref.absgrad = v_abs
         v_bg = None

@@ -84,8 +84,12 @@ def main():
     D = cols.shape[-1]
     render = torch.empty(1, H, W, D, device=dev); alphas = torch.empty(1, H, W, 1, device=dev)
     last = torch.empty(1, H, W, dtype=torch.int32, device=dev)
+    import os
+    order = torch.empty(tw * th, dtype=torch.int32, device=dev)
+    res["tile_schedule"] = timeit(lambda: call("mtgs_tile_schedule", 1, tw, th, ptr(off), M, ptr(order), st), args.reps)
+    optr = None if os.environ.get("NO_ORDER") else ptr(order)
     fwd = lambda: call("mtgs_blend_fwd", 1, N, D, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, W, H, 16, tw, th,
-                       ptr(off), ptr(flat), M, ptr(render), ptr(alphas), ptr(last), st)
+                       ptr(off), ptr(flat), M, ptr(render), ptr(alphas), ptr(last), optr, st)
     res["blend_fwd"] = timeit(fwd, args.reps)
     g = torch.Generator(device="cpu").manual_seed(1)
     vr = torch.randn(1, H, W, D, generator=g).to(dev); va = torch.randn(1, H, W, 1, generator=g).to(dev)
@@ -93,7 +97,7 @@ def main():
     vcon = torch.zeros_like(conics); vcl = torch.zeros_like(cols); vop = torch.zeros_like(opac)
     bwd = lambda: call("mtgs_blend_bwd", 1, N, D, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, W, H, 16, tw, th,
                        ptr(off), ptr(flat), M, ptr(alphas), ptr(last), ptr(vr), ptr(va), ptr(v2d), ptr(vab), ptr(vcon),
-                       ptr(vcl), ptr(vop), st)
+                       ptr(vcl), ptr(vop), optr, st)
     res["blend_bwd"] = timeit(bwd, args.reps)
     vm_ = torch.empty_like(d["means"]); vq = torch.empty_like(d["quats"]); vs = torch.empty_like(d["scales"]); vvm = torch.empty_like(vm)
     vdep = torch.randn_like(depths)

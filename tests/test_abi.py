@@ -19,7 +19,7 @@ def test_header_declares_the_operator_table():
     syms = header_symbols()
     for must in ("mtgs_sh_fwd", "mtgs_sh_bwd", "mtgs_project_fwd", "mtgs_project_bwd", "mtgs_isect_count",
                  "mtgs_isect_scan", "mtgs_isect_emit", "mtgs_sort_pairs", "mtgs_isect_offsets", "mtgs_blend_fwd",
-                 "mtgs_blend_bwd", "mtgs_rast_version", "mtgs_rast_last_error"):
+                 "mtgs_blend_bwd", "mtgs_tile_schedule", "mtgs_rast_version", "mtgs_rast_last_error"):
         assert must in syms
 
 
@@ -50,10 +50,10 @@ def test_host_side_argument_validation(hip_lib):
                                     None, None, None, None, None, None) == 1
     # tile size other than 16 and unsupported channel counts are refused by name
     assert hip_lib.mtgs_blend_fwd(1, 10, 3, None, None, None, None, None, 64, 64, 8, 8, 8, None, None, 0,
-                                  None, None, None, None) == 4
+                                  None, None, None, None, None) == 4
     assert b"tile_size" in hip_lib.mtgs_rast_last_error()
     assert hip_lib.mtgs_blend_fwd(1, 10, 9, None, None, None, None, None, 64, 64, 16, 4, 4, None, None, 0,
-                                  None, None, None, None) == 4
+                                  None, None, None, None, None) == 4
     # empty problems are a no-op success
     assert hip_lib.mtgs_sh_fwd(0, 16, 3, None, None, None, None, None) == 0
     assert hip_lib.mtgs_sort_pairs(0, 46, None, None, None, None, None, 0, None) == 0
