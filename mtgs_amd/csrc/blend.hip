@@ -36,9 +36,12 @@ constexpr float kAlphaMax = MTGS_ALPHA_MAX;
 constexpr float kAlphaMin = MTGS_ALPHA_MIN;
 constexpr float kTMin = MTGS_T_MIN;
 
+// LDS record per staged Gaussian, in floats:  x y a b | c opac s2max idx | col[D] (padded to x4)
+//   a b c   = conic,  s2max = 2 ln(255 opac)  (alpha >= 1/255  <=>  dx u + dy w <= s2max),
+//   idx     = position in the sorted intersection list (int bits).
 template <int D>
-struct Rec {  // LDS record per staged Gaussian, in floats: x y a b | c opac col[D] (padded to x4)
-    static constexpr int N = ((6 + D + 3) / 4) * 4;
+struct Rec {
+    static constexpr int N = ((8 + D + 3) / 4) * 4;
 };
 
 // Block -> tile mapping.  `order` (from mtgs_tile_schedule) lists tiles by decreasing work so the
@@ -49,39 +52,90 @@ __device__ __forceinline__ int64_t block_to_tile(const int32_t *__restrict__ ord
     return order ? (int64_t)order[blockIdx.x] : (int64_t)blockIdx.x;
 }
 
-// Gather one Gaussian's attributes (row g of the per-camera arrays) into this thread's LDS record.
-template <int D>
-__device__ __forceinline__ void stage_record(float *__restrict__ s_rec, const float *__restrict__ means2d,
-                                             const float *__restrict__ conics,
-                                             const float *__restrict__ colors,
-                                             const float *__restrict__ opacities, int32_t g) {
-    constexpr int REC = Rec<D>::N;
-    const float2 xy = reinterpret_cast<const float2 *>(means2d)[g];
-    const float ca = conics[(int64_t)g * 3], cb = conics[(int64_t)g * 3 + 1], cc = conics[(int64_t)g * 3 + 2];
-    const float op = opacities[g];
-    float r[REC];
-    r[0] = xy.x; r[1] = xy.y; r[2] = ca; r[3] = cb; r[4] = cc; r[5] = op;
-#pragma unroll
-    for (int k = 0; k < D; ++k) r[6 + k] = colors[(int64_t)g * D + k];
-#pragma unroll
-    for (int k = 6 + D; k < REC; ++k) r[k] = 0.f;
-    float4 *dst = reinterpret_cast<float4 *>(s_rec + threadIdx.x * REC);
-#pragma unroll
-    for (int k = 0; k < REC / 4; ++k) dst[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+__device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// alpha of one Gaussian at one pixel.  u = a dx + b dy and w = b dx + c dy are kept: the backward
-// needs them for the mean gradient.  sigma = 0.5 (dx u + dy w) == 0.5 (a dx^2 + c dy^2) + b dx dy.
-struct GaussEval { float u, w, sigma, vis, alpha_raw; };
-__device__ __forceinline__ GaussEval eval_gauss(float a, float b, float c, float opac, float dx, float dy) {
+// Stage up to CAND candidates of the tile's sorted list into LDS, DROPPING those that cannot reach
+// alpha >= 1/255 at any pixel centre of the tile, and compacting the survivors in list order
+// (wave ballot + mbcnt prefix).  A candidate is dropped only if the axis-aligned bounding box of its
+// {alpha >= 1/255} ellipse (inflated by a safety margin) misses the tile's pixel centres, so every
+// dropped candidate would have been skipped pixel by pixel anyway: results are unchanged, but the
+// per-pixel loop never sees it.  The binning stage itself keeps gsplat's conservative 3-sigma
+// squares, so isect_ids / flatten_ids / offsets stay bit-identical to the reference.
+//   FWD: candidate k of the batch is sorted index base + k;  BWD: base - k (back to front).
+// Returns the number of survivors (wave-uniform).  Single-wave workgroups only (CULL) -- the
+// 4-waves-per-tile fallback stages one candidate per thread without culling.
+template <int D, int NT, int CAND, bool BWD, bool CULL>
+__device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *__restrict__ s_id,
+                                           const float *__restrict__ means2d,
+                                           const float *__restrict__ conics,
+                                           const float *__restrict__ colors,
+                                           const float *__restrict__ opacities,
+                                           const int32_t (&g)[CAND / NT], int64_t base, int n_cand,
+                                           float tile_x0, float tile_y0) {
+    constexpr int REC = Rec<D>::N;
+    const int tid = threadIdx.x;
+    int count = 0;
+#pragma unroll
+    for (int r = 0; r < CAND / NT; ++r) {
+        const int k = r * NT + tid;
+        const bool in_range = k < n_cand;
+        bool keep = in_range;
+        float2 xy = make_float2(0.f, 0.f);
+        float ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f, s2max = 0.f;
+        if (in_range) {
+            xy = reinterpret_cast<const float2 *>(means2d)[g[r]];
+            ca = conics[(int64_t)g[r] * 3]; cb = conics[(int64_t)g[r] * 3 + 1]; cc = conics[(int64_t)g[r] * 3 + 2];
+            op = opacities[g[r]];
+            // alpha = min(0.999, op e^{-s2/2}) >= 1/255  <=>  s2 <= 2 ln(255 op)
+            s2max = 2.0f * 0.6931471805599453f * __log2f(op * (1.0f / kAlphaMin));
+            if (CULL) {
+                const float det = ca * cc - cb * cb;
+                if (det > 0.f) {
+                    const float s2c = fmaxf(s2max, 0.f) * 1.0001f + 1e-3f;
+                    const float rdet = __builtin_amdgcn_rcpf(det);
+                    const float ex = __builtin_sqrtf(s2c * cc * rdet) * 1.0001f + 1e-3f;
+                    const float ey = __builtin_sqrtf(s2c * ca * rdet) * 1.0001f + 1e-3f;
+                    keep = s2max >= 0.f && xy.x + ex >= tile_x0 + 0.5f && xy.x - ex <= tile_x0 + 15.5f &&
+                           xy.y + ey >= tile_y0 + 0.5f && xy.y - ey <= tile_y0 + 15.5f;
+                }
+            }
+        }
+        int slot = k;
+        if (CULL) {
+            const unsigned long long m = __ballot(keep);
+            slot = count + lanes_below(m);
+            count += __popcll(m);
+        }
+        if (keep) {
+            float rec[REC];
+            rec[0] = xy.x; rec[1] = xy.y; rec[2] = ca; rec[3] = cb; rec[4] = cc; rec[5] = op; rec[6] = s2max;
+            rec[7] = __int_as_float((int32_t)(BWD ? base - k : base + k));
+#pragma unroll
+            for (int c = 0; c < D; ++c) rec[8 + c] = colors[(int64_t)g[r] * D + c];
+#pragma unroll
+            for (int c = 8 + D; c < REC; ++c) rec[c] = 0.f;
+            float4 *dst = reinterpret_cast<float4 *>(s_rec + slot * REC);
+#pragma unroll
+            for (int c = 0; c < REC / 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
+            if (s_id) s_id[slot] = g[r];
+        }
+    }
+    return CULL ? count : n_cand;
+}
+
+// One Gaussian at one pixel.  u = a dx + b dy and w = b dx + c dy (kept: the backward needs them
+// for the mean gradient);  s2 = dx u + dy w = 2 sigma.
+struct GaussEval { float u, w, s2; };
+__device__ __forceinline__ GaussEval eval_gauss(float adx, float bdx, float b, float c, float dx, float dy) {
     GaussEval e;
-    e.u = a * dx + b * dy;
-    e.w = b * dx + c * dy;
-    e.sigma = 0.5f * (dx * e.u + dy * e.w);
-    e.vis = __expf(-e.sigma);
-    e.alpha_raw = opac * e.vis;
+    e.u = adx + b * dy;
+    e.w = bdx + c * dy;
+    e.s2 = dx * e.u + dy * e.w;
     return e;
 }
+constexpr float kHalfLog2e = 0.5f * 1.4426950408889634f;  // exp(-s2/2) = exp2(-s2 * log2(e)/2)
 
 // ------------------------------------------------------------------------------------------------
 template <int D, int PPL>
@@ -93,7 +147,9 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
     const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
-    __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
+    constexpr bool CULL = NT == 64;
+    constexpr int CAND = CULL ? 128 : NT, NR = CAND / NT;
+    __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
     const int64_t tile = block_to_tile(order);
     const int cam = (int)(tile / n_tiles);
@@ -120,48 +176,58 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     const int64_t start = offsets[tile];
     const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
 
-    // flatten_ids of the NEXT chunk are fetched while the current chunk is composited
-    int32_t g_next = (start + tid < end) ? flatten_ids[start + tid] : 0;
-    for (int64_t b0 = start; b0 < end; b0 += NT) {
+    // flatten_ids of the NEXT batch are fetched while the current batch is composited
+    int32_t g_next[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) g_next[r] = (start + r * NT + tid < end) ? flatten_ids[start + r * NT + tid] : 0;
+    for (int64_t b0 = start; b0 < end; b0 += CAND) {
         bool all_done = true;
 #pragma unroll
         for (int p = 0; p < PPL; ++p) all_done = all_done && done[p];
         if (__syncthreads_and(all_done)) break;
-        const int32_t g_cur = g_next;
-        if (b0 + tid < end) stage_record<D>(s_rec, means2d, conics, colors, opacities, g_cur);
-        if (b0 + NT + tid < end) g_next = flatten_ids[b0 + NT + tid];
+        int32_t g_cur[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];
+        const int n_cand = (int)min((int64_t)CAND, end - b0);
+        const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, means2d, conics, colors, opacities,
+                                                              g_cur, b0, n_cand, (float)(tx * 16), (float)(ty * 16));
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (b0 + CAND + r * NT + tid < end) g_next[r] = flatten_ids[b0 + CAND + r * NT + tid];
         __syncthreads();
-        const int bsz = (int)min((int64_t)NT, end - b0);
         for (int t = 0; t < bsz; ++t) {
             const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
-            const float2 r1 = *reinterpret_cast<const float2 *>(s_rec + t * REC + 4);
+            const float4 r1 = *reinterpret_cast<const float4 *>(s_rec + t * REC + 4);
             const float dx = r0.x - px;
-            float alpha[PPL];
+            const float adx = r0.z * dx, bdx = r0.w * dx;
+            float s2[PPL];
             bool valid[PPL];
             unsigned long long any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                const GaussEval e = eval_gauss(r0.z, r0.w, r1.x, r1.y, dx, r0.y - py[p]);
-                alpha[p] = fminf(kAlphaMax, e.alpha_raw);
-                valid[p] = !done[p] && e.sigma >= 0.f && alpha[p] >= kAlphaMin;
+                const GaussEval e = eval_gauss(adx, bdx, r0.w, r1.x, dx, r0.y - py[p]);
+                s2[p] = e.s2;
+                valid[p] = !done[p] && e.s2 >= 0.f && e.s2 <= r1.z;
                 any |= __ballot(valid[p]);
             }
             if (any == 0) continue;
             float col[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 6 + k];
+            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 8 + k];
+            const int32_t idx = __float_as_int(r1.w);
             unsigned long long stopped = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                const float next_T = T[p] * (1.f - alpha[p]);
+                const float alpha = fminf(kAlphaMax, r1.y * __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]));
+                const float next_T = T[p] * (1.f - alpha);
                 const bool stop = valid[p] && next_T <= kTMin;
                 const bool use = valid[p] && !stop;
                 stopped |= __ballot(stop);
                 done[p] = done[p] || stop;
-                const float w = use ? alpha[p] * T[p] : 0.f;
+                const float w = use ? alpha * T[p] : 0.f;
 #pragma unroll
                 for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
-                last[p] = use ? (int32_t)(b0 + t) : last[p];
+                last[p] = use ? idx : last[p];
                 T[p] = use ? next_T : T[p];
             }
             if (stopped) {
@@ -205,9 +271,11 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     float *__restrict__ v_colors, float *__restrict__ v_opacities,
     const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
+    constexpr bool CULL = NT == 64;
+    constexpr int CAND = CULL ? 128 : NT, NRD = CAND / NT;
     constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
-    __shared__ __attribute__((aligned(16))) float s_rec[NT * REC];
-    __shared__ int32_t s_id[NT];
+    __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
+    __shared__ int32_t s_id[CAND];
     __shared__ int32_t s_max[NT / 64];
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
     const int64_t tile = block_to_tile(order);
@@ -268,48 +336,55 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         else { a_base = v_colors + (j - 8); a_stride = D; }
     }
 
-    int32_t g_next = (top - tid >= start) ? flatten_ids[top - tid] : 0;
-    for (int64_t hi = top; hi >= start; hi -= NT) {
+    int32_t g_next[NRD];
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) g_next[r] = (top - r * NT - tid >= start) ? flatten_ids[top - r * NT - tid] : 0;
+    for (int64_t hi = top; hi >= start; hi -= CAND) {
         if (hi != top) __syncthreads();
-        const int32_t g_cur = g_next;
-        if (hi - tid >= start) {
-            stage_record<D>(s_rec, means2d, conics, colors, opacities, g_cur);
-            s_id[tid] = g_cur;
-        }
-        if (hi - NT - tid >= start) g_next = flatten_ids[hi - NT - tid];
+        int32_t g_cur[NRD];
+#pragma unroll
+        for (int r = 0; r < NRD; ++r) g_cur[r] = g_next[r];
+        const int n_cand = (int)min((int64_t)CAND, hi - start + 1);
+        const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, means2d, conics, colors, opacities, g_cur,
+                                                             hi, n_cand, (float)(tx * 16), (float)(ty * 16));
+#pragma unroll
+        for (int r = 0; r < NRD; ++r)
+            if (hi - CAND - r * NT - tid >= start) g_next[r] = flatten_ids[hi - CAND - r * NT - tid];
         __syncthreads();
-        const int bsz = (int)min((int64_t)NT, hi - start + 1);
         for (int t = 0; t < bsz; ++t) {
-            const int32_t idx = (int32_t)(hi - t);
             const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
-            const float2 r1 = *reinterpret_cast<const float2 *>(s_rec + t * REC + 4);
+            const float4 r1 = *reinterpret_cast<const float4 *>(s_rec + t * REC + 4);
+            const int32_t idx = __float_as_int(r1.w);
             const float opac = r1.y;
             const float dx = r0.x - px;
-            float dy[PPL], alpha[PPL];
+            const float adx = r0.z * dx, bdx = r0.w * dx;
+            float dy[PPL];
             GaussEval e[PPL];
             bool valid[PPL];
             unsigned long long any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 dy[p] = r0.y - py[p];
-                e[p] = eval_gauss(r0.z, r0.w, r1.x, opac, dx, dy[p]);
-                alpha[p] = fminf(kAlphaMax, e[p].alpha_raw);
-                valid[p] = idx <= bin_final[p] && e[p].sigma >= 0.f && alpha[p] >= kAlphaMin;
+                e[p] = eval_gauss(adx, bdx, r0.w, r1.x, dx, dy[p]);
+                valid[p] = idx <= bin_final[p] && e[p].s2 >= 0.f && e[p].s2 <= r1.z;
                 any |= __ballot(valid[p]);
             }
             if (any == 0) continue;
             float col[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 6 + k];
+            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 8 + k];
             float gv[4 * NR];
 #pragma unroll
             for (int k = 0; k < 4 * NR; ++k) gv[k] = 0.f;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 if (valid[p]) {
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha[p]);
+                    const float vis = __builtin_amdgcn_exp2f(-kHalfLog2e * e[p].s2);
+                    const float alpha_raw = opac * vis;
+                    const float alpha = fminf(kAlphaMax, alpha_raw);
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[p] *= ra;
-                    const float fac = alpha[p] * T[p];
+                    const float fac = alpha * T[p];
                     float v_alpha = Tf_va[p] * ra;
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
@@ -317,8 +392,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
                         v_alpha += (col[k] * T[p] - buf[p][k] * ra) * vr[p][k];
                         buf[p][k] += col[k] * fac;
                     }
-                    if (e[p].alpha_raw <= kAlphaMax) {
-                        const float v_sigma = -e[p].alpha_raw * v_alpha;
+                    if (alpha_raw <= kAlphaMax) {
+                        const float v_sigma = -alpha_raw * v_alpha;
                         const float hs = 0.5f * v_sigma;
                         gv[4] += hs * dx * dx;
                         gv[5] += v_sigma * dx * dy[p];
@@ -326,7 +401,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
                         const float vx = v_sigma * e[p].u, vy = v_sigma * e[p].w;
                         gv[0] += vx; gv[1] += vy;
                         gv[2] += fabsf(vx); gv[3] += fabsf(vy);
-                        gv[7] += e[p].vis * v_alpha;
+                        gv[7] += vis * v_alpha;
                     }
                 }
             }

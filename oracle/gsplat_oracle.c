@@ -587,11 +587,16 @@ void orc_isect_offsets(int64_t M, const int64_t *ids_sorted, int C, int tw, int 
 }
 
 /* ============================ compositing ==================================================== */
-/* rasterize_to_pixels_fwd.  render[C,H,W,D], alphas[C,H,W], last_ids[C,H,W]. */
+/* rasterize_to_pixels_fwd.  render[C,H,W,D], alphas[C,H,W], last_ids[C,H,W].
+ * critical[C,H,W] (nullable, test aid): 1 where some Gaussian of the pixel's list sits within a
+ * relative 1e-4 of one of the algorithm's two DISCONTINUITIES (alpha == 1/255 skip threshold,
+ * next_T == 1e-4 stop threshold).  There an fp32-rounding-level change of alpha flips a discrete
+ * decision and moves the pixel by up to alpha_min * |colour|, so comparisons against another
+ * fp32 implementation (different exp, FMA contraction) are ill-conditioned at exactly those pixels. */
 void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *backgrounds, int W, int H,
                    int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
-                   int64_t M, float *render, float *alphas, int32_t *last_ids) {
+                   int64_t M, float *render, float *alphas, int32_t *last_ids, uint8_t *critical) {
     (void)N;
     int64_t n_tiles = (int64_t)C * tw * th;
 #pragma omp parallel for schedule(dynamic, 4)
@@ -606,14 +611,18 @@ void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *c
                 float acc[64];
                 for (int k = 0; k < D; ++k) acc[k] = 0.f;
                 int32_t last = 0;
+                uint8_t crit = 0;
                 for (int64_t i = start; i < end; ++i) {
                     int32_t g = flatten_ids[i];
                     float dx = means2d[g * 2] - fxp, dy = means2d[g * 2 + 1] - fyp;
                     float a = conics[g * 3], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
                     float sigma = 0.5f * (a * dx * dx + cc * dy * dy) + b * dx * dy;
                     float alpha = fminf(ALPHA_MAX, opacities[g] * expf(-sigma));
+                    if (fabsf(alpha - ALPHA_MIN) <= 1e-4f * ALPHA_MIN && sigma >= -1e-6f) crit = 1;
+                    if (fabsf(sigma) <= 1e-6f && alpha >= ALPHA_MIN) crit = 1;
                     if (sigma < 0.f || alpha < ALPHA_MIN) continue;
                     float next_T = T * (1.f - alpha);
+                    if (fabsf(next_T - T_MIN) <= 1e-4f * T_MIN) crit = 1;
                     if (next_T <= T_MIN) break;
                     float vis = alpha * T;
                     const float *col = colors + (int64_t)g * D;
@@ -626,6 +635,7 @@ void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *c
                 for (int k = 0; k < D; ++k)
                     render[pid * D + k] = backgrounds ? acc[k] + T * backgrounds[c * D + k] : acc[k];
                 last_ids[pid] = last;
+                if (critical) critical[pid] = crit;
             }
     }
 }

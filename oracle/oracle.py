@@ -172,7 +172,8 @@ def isect_offset_encode(isect_ids, Cc, tw, th):
 
 
 # ---------------------------------------------------------------- compositing
-def blend_fwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, offsets, flatten_ids):
+def blend_fwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, offsets, flatten_ids,
+              want_critical=False):
     means2d, conics, colors, opacities, backgrounds = map(_f, (means2d, conics, colors, opacities, backgrounds))
     Cc, N, D = colors.shape
     th, tw = offsets.shape[1:]
@@ -181,11 +182,14 @@ def blend_fwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, 
     render = np.empty((Cc, H, W, D), np.float32)
     alphas = np.empty((Cc, H, W, 1), np.float32)
     last = np.empty((Cc, H, W), np.int32)
+    crit = np.zeros((Cc, H, W), np.uint8) if want_critical else None
     lib().orc_blend_fwd(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
                         _p(colors, C.c_float), _p(opacities, C.c_float), _p(backgrounds, C.c_float),
                         W, H, tile_size, tw, th, _p(offsets, C.c_int32), _p(flatten_ids, C.c_int32),
                         C.c_int64(flatten_ids.shape[0]), _p(render, C.c_float), _p(alphas, C.c_float),
-                        _p(last, C.c_int32))
+                        _p(last, C.c_int32), _p(crit, C.c_uint8))
+    if want_critical:
+        return render, alphas, last, crit.astype(bool)
     return render, alphas, last
 
 
@@ -249,8 +253,8 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
     tpg, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tw, th)
     offsets = isect_offset_encode(isect_ids, Cc, tw, th)
-    render, alphas, last_ids = blend_fwd(means2d, conics, cols, opac, bg, width, height, tile_size,
-                                         offsets, flatten_ids)
+    render, alphas, last_ids, critical = blend_fwd(means2d, conics, cols, opac, bg, width, height, tile_size,
+                                                   offsets, flatten_ids, want_critical=True)
     render_raw = render
     if render_mode in ("ED", "RGB+ED"):
         render = np.concatenate(
@@ -259,5 +263,5 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
                 tile_width=tw, tile_height=th, tiles_per_gauss=tpg, isect_ids=isect_ids,
                 flatten_ids=flatten_ids, isect_offsets=offsets, width=width, height=height,
                 tile_size=tile_size, n_cameras=Cc, compensations=comps, colors=cols,
-                backgrounds=bg, last_ids=last_ids, render_raw=render_raw)
+                backgrounds=bg, last_ids=last_ids, render_raw=render_raw, critical=critical)
     return render, alphas, meta
