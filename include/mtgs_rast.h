@@ -108,6 +108,30 @@ int mtgs_sort_workspace_bytes(int64_t M, size_t *bytes);
 int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in, int64_t *keys_out,
                     int32_t *vals_out, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- depth-ordered binning: the fast path behind isect_tiles(sort=True) (mtgs_amd/csrc/bin.hip).
+ * Produces the SAME isect_ids / flatten_ids as count+scan+emit+sort_pairs above (bit-identical),
+ * by sorting the visible Gaussians by (camera, depth) first and then stably by tile only.
+ *  mtgs_bin_compact  : vis_keys[<=C*N] i64 = cam<<32 | bits(depth), vis_ids[<=C*N] i32 = c*N+n, in
+ *                      index order; totals[1] i64 (device) = n_vis<<32 | M.  ws: mtgs_scan_workspace_bytes(C*N).
+ *  mtgs_bin_scan     : cum[n_vis] i64 = inclusive sum of tiles_per_gauss[ids_sorted[r]].
+ *  mtgs_bin_emit     : tile_keys[M] u32 = cam*n_tiles + tile, gids[M] i32, in depth order.
+ *  mtgs_sort_pairs_u32 : stable LSD sort of (u32 key, i32 value) on key bits [0, key_bits).
+ *  mtgs_bin_finalize : isect_ids[M] i64 from the sorted (tile key, index) pairs and depths. */
+int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
+                     const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
+                     int64_t *totals, void *ws, size_t ws_bytes, void *stream);
+int mtgs_bin_scan(int64_t n_vis, const int32_t *ids_sorted, const int32_t *tiles_per_gauss,
+                  int64_t *cum, void *ws, size_t ws_bytes, void *stream);
+int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted, int64_t N,
+                  const float *means2d, const int32_t *radii, const int64_t *cum, int tile_size,
+                  int tile_w, int tile_h, uint32_t *tile_keys, int32_t *gids, void *stream);
+int mtgs_sort_u32_workspace_bytes(int64_t M, size_t *bytes);
+int mtgs_sort_pairs_u32(int64_t M, int key_bits, uint32_t *keys_in, int32_t *vals_in,
+                        uint32_t *keys_out, int32_t *vals_out, void *ws, size_t ws_bytes, void *stream);
+int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,
+                      const float *depths, int C, int tile_w, int tile_h, int64_t *isect_ids,
+                      void *stream);
+
 /* ---- gsplat isect_offset_encode: offsets[C,tile_h,tile_w] i32 = first sorted index per tile --- */
 int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int tile_w, int tile_h,
                        int32_t *offsets, void *stream);

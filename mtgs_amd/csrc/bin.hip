@@ -1,0 +1,220 @@
+// bin.hip -- depth-ordered tile binning: the fast path behind gsplat's isect_tiles(sort=True).
+//
+// gsplat 1.4.0 isect_tiles emits one 64-bit key (cam | tile | depth bits) per tile/Gaussian
+// intersection and radix-sorts all M of them on 46 bits: six 8-bit passes over 12-byte pairs
+// (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:641-662 -> gsplat.rendering.rasterization
+// -> isect_tiles).  M is ~13x the number of visible Gaussians, so this path splits the key instead:
+//
+//   1. mtgs_bin_compact   visible Gaussians -> (cam | depth bits, index) in index order, plus the
+//                         two totals the host needs (n_vis and M) from ONE packed int64 scan;
+//   2. mtgs_sort_pairs    stable sort of the n_vis pairs by (cam, depth)          [small]
+//   3. mtgs_bin_scan      prefix sum of tiles_per_gauss in that depth order
+//   4. mtgs_bin_emit      intersections emitted in depth order: (cam*n_tiles + tile, index)
+//   5. mtgs_sort_pairs_u32  stable sort on the tile bits only (13 bits -> 2 passes, 8-byte pairs)
+//   6. mtgs_bin_finalize  rebuilds the 64-bit isect_ids (gsplat's meta output) from the sorted pairs
+//
+// A stable sort by tile of a (depth, index)-ordered sequence is the (tile, depth, index) order, i.e.
+// exactly what the reference's single stable sort of emission-ordered keys produces: isect_ids and
+// flatten_ids are bit-identical (tests/test_gpu_parity.py).  HBM traffic of the sorting drops from
+// 6 x 2 x 12 B x M to 2 x 2 x 8 B x M (+ the small per-Gaussian sort).
+//
+// Roofline: HBM.  Algorithmic bytes: compact C*N*12 in + n_vis*12 out; scan n_vis*8 in + 8 out;
+// emit n_vis*24 in + M*8 out; finalize M*8 in + M*8 (+4 gathered) out.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace {
+
+constexpr int BIN_BLOCK = 256;
+
+struct Rect { int x0, y0, x1, y1; };
+__device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, float ts, int tw, int th) {
+    const float tr = (float)radius / ts, tx = mx / ts, ty = my / ts;
+    Rect r;
+    r.x0 = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tw);
+    r.y0 = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)th);
+    r.x1 = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tw);
+    r.y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)th);
+    return r;
+}
+
+// packed scan value: visible flag in the high word, tile count in the low word
+struct PackedVisTiles {
+    const int32_t *radii, *tpg;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const {
+        return ((int64_t)(radii[i] > 0) << 32) | (int64_t)(uint32_t)tpg[i];
+    }
+};
+struct CompactSink {
+    const int32_t *radii;
+    const float *depths;
+    int64_t N;
+    int64_t *keys;
+    int32_t *ids;
+    // called with the EXCLUSIVE packed prefix of element i
+    __device__ __forceinline__ void operator()(int64_t i, int64_t excl, int64_t /*incl*/) const {
+        if (radii[i] > 0) {
+            const int64_t pos = excl >> 32;
+            keys[pos] = ((i / N) << 32) | (int64_t)__float_as_uint(depths[i]);
+            ids[pos] = (int32_t)i;
+        }
+    }
+};
+struct GatherTiles {
+    const int32_t *ids, *tpg;
+    __device__ __forceinline__ int64_t operator()(int64_t r) const { return tpg[ids[r]]; }
+};
+struct InclusiveSink {
+    int64_t *out;
+    __device__ __forceinline__ void operator()(int64_t r, int64_t /*excl*/, int64_t incl) const { out[r] = incl; }
+};
+
+// One thread per OUTPUT slot (load-balanced search): in depth order the largest footprints (the
+// nearest Gaussians cover the whole image) are adjacent, so a per-Gaussian loop would serialise
+// thousands of stores behind the first wavefronts.  A wave covers 64 consecutive slots: one uniform
+// binary search finds the Gaussian of its first slot, the next 64 prefix sums are held one per lane
+// and each lane locates its own Gaussian with 7 shuffles.  Stores are fully coalesced.
+__global__ __launch_bounds__(BIN_BLOCK) void bin_emit_kernel(
+    int64_t M, int64_t n_vis, const int32_t *__restrict__ ids_sorted, int64_t N,
+    const float *__restrict__ means2d, const int32_t *__restrict__ radii, const int64_t *__restrict__ cum,
+    float ts, int tw, int th, uint32_t *__restrict__ tile_keys, int32_t *__restrict__ gids) {
+    const int64_t i = (int64_t)blockIdx.x * BIN_BLOCK + threadIdx.x;
+    const int lane = lane_id();
+    const int64_t i0 = i - lane;  // first slot of the wave (wave-uniform)
+    if (i0 >= M) return;
+    // r0 = first r with cum[r] > i0   (cum is the inclusive prefix sum, so slot i0 belongs to r0)
+    int64_t lo = 0, hi = n_vis;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cum[mid] > i0) hi = mid; else lo = mid + 1;
+    }
+    const int64_t r0 = lo;
+    // every Gaussian owns >= 1 slot, so the wave's 64 slots touch at most Gaussians r0 .. r0+63
+    const int32_t c = (r0 + lane < n_vis) ? (int32_t)cum[r0 + lane] : 0x7fffffff;
+    int l = 0, h = 64;  // answer in [0, 64]: 65 candidates -> 7 halvings
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        const int mid = min((l + h) >> 1, 63);
+        const int32_t v = __shfl(c, mid, 64);
+        if ((int64_t)v <= i) l = mid + 1; else h = mid;
+    }
+    const int64_t r = r0 + l;
+    // (the shuffle must run with all lanes active: ds_bpermute returns 0 for a disabled source lane)
+    const int32_t prev = __shfl(c, max(l - 1, 0), 64);
+    const int32_t base0 = r0 > 0 ? (int32_t)cum[r0 - 1] : 0;
+    const int32_t excl = l > 0 ? prev : base0;
+    if (i >= M) return;
+    const int32_t idx = ids_sorted[r];
+    const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+    const Rect q = tile_rect(m.x, m.y, radii[idx], ts, tw, th);
+    const int local = (int)(i - excl), bw = q.x1 - q.x0;
+    const int row = local / bw, col = local - row * bw;
+    tile_keys[i] = (uint32_t)(idx / N) * (uint32_t)(tw * th) + (uint32_t)((q.y0 + row) * tw + q.x0 + col);
+    gids[i] = idx;
+}
+
+__global__ __launch_bounds__(BIN_BLOCK) void bin_finalize_kernel(
+    int64_t M, const uint32_t *__restrict__ tile_keys, const int32_t *__restrict__ gids,
+    const float *__restrict__ depths, int n_tiles, int tile_bits, int64_t *__restrict__ isect_ids) {
+    const int64_t i = (int64_t)blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t k = tile_keys[i];
+    const int64_t cam = k / (uint32_t)n_tiles, tile = k % (uint32_t)n_tiles;
+    isect_ids[i] = (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)__float_as_uint(depths[gids[i]]);
+}
+
+inline int bit_length_u32(uint32_t v) {
+    int b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+}  // namespace
+
+extern "C" int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
+                                const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
+                                int64_t *totals, void *ws, size_t ws_bytes, void *stream) {
+    MTGS_REQUIRE(C >= 0 && N >= 0, MTGS_EINVAL, "mtgs_bin_compact: bad sizes");
+    const int64_t total = (int64_t)C * N;
+    hipStream_t st = (hipStream_t)stream;
+    MTGS_REQUIRE(totals, MTGS_EINVAL, "mtgs_bin_compact: null pointer");
+    if (total == 0) {
+        hipError_t e = hipMemsetAsync(totals, 0, sizeof(int64_t), st);
+        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_bin_compact: memset failed");
+        return MTGS_OK;
+    }
+    MTGS_REQUIRE(radii && depths && tiles_per_gauss && vis_keys && vis_ids && ws, MTGS_EINVAL, "mtgs_bin_compact: null pointer");
+    MTGS_REQUIRE(ws_bytes >= mtgs_scan::workspace_bytes(total), MTGS_EWORKSPACE, "mtgs_bin_compact: workspace too small");
+    mtgs_scan::run(total, PackedVisTiles{radii, tiles_per_gauss}, CompactSink{radii, depths, N, vis_keys, vis_ids},
+                   (int64_t *)ws, totals, st);
+    MTGS_CHECK_LAUNCH("mtgs_bin_compact");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_bin_scan(int64_t n_vis, const int32_t *ids_sorted, const int32_t *tiles_per_gauss,
+                             int64_t *cum, void *ws, size_t ws_bytes, void *stream) {
+    MTGS_REQUIRE(n_vis >= 0, MTGS_EINVAL, "mtgs_bin_scan: bad size");
+    if (n_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(ids_sorted && tiles_per_gauss && cum && ws, MTGS_EINVAL, "mtgs_bin_scan: null pointer");
+    MTGS_REQUIRE(ws_bytes >= mtgs_scan::workspace_bytes(n_vis), MTGS_EWORKSPACE, "mtgs_bin_scan: workspace too small");
+    mtgs_scan::run(n_vis, GatherTiles{ids_sorted, tiles_per_gauss}, InclusiveSink{cum}, (int64_t *)ws, nullptr,
+                   (hipStream_t)stream);
+    MTGS_CHECK_LAUNCH("mtgs_bin_scan");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted, int64_t N,
+                             const float *means2d, const int32_t *radii, const int64_t *cum,
+                             int tile_size, int tile_w, int tile_h, uint32_t *tile_keys, int32_t *gids,
+                             void *stream) {
+    MTGS_REQUIRE(M >= 0 && n_vis >= 0 && N >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, MTGS_EINVAL, "mtgs_bin_emit: bad sizes");
+    MTGS_REQUIRE(M < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_bin_emit: M must fit int32");
+    if (n_vis == 0 || M == 0) return MTGS_OK;
+    MTGS_REQUIRE(ids_sorted && means2d && radii && cum, MTGS_EINVAL, "mtgs_bin_emit: null pointer");
+    bin_emit_kernel<<<(unsigned)ceil_div64(M, BIN_BLOCK), BIN_BLOCK, 0, (hipStream_t)stream>>>(
+        M, n_vis, ids_sorted, N, means2d, radii, cum, (float)tile_size, tile_w, tile_h, tile_keys, gids);
+    MTGS_CHECK_LAUNCH("mtgs_bin_emit");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_sort_u32_workspace_bytes(int64_t M, size_t *bytes) {
+    MTGS_REQUIRE(M >= 0 && bytes, MTGS_EINVAL, "mtgs_sort_u32_workspace_bytes: bad arguments");
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                             (const int32_t *)nullptr, (int32_t *)nullptr,
+                                             (size_t)(M > 0 ? M : 1), 0u, 32u, (hipStream_t)0);
+    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_sort_u32_workspace_bytes: %s", hipGetErrorString(e));
+    *bytes = tmp < 16 ? 16 : tmp;
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_sort_pairs_u32(int64_t M, int key_bits, uint32_t *keys_in, int32_t *vals_in,
+                                   uint32_t *keys_out, int32_t *vals_out, void *ws, size_t ws_bytes,
+                                   void *stream) {
+    MTGS_REQUIRE(M >= 0 && key_bits > 0 && key_bits <= 32, MTGS_EINVAL, "mtgs_sort_pairs_u32: bad arguments");
+    if (M == 0) return MTGS_OK;
+    MTGS_REQUIRE(keys_in && vals_in && keys_out && vals_out && ws, MTGS_EINVAL, "mtgs_sort_pairs_u32: null pointer");
+    size_t need = ws_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(ws, need, (const uint32_t *)keys_in, keys_out, (const int32_t *)vals_in,
+                                             vals_out, (size_t)M, 0u, (unsigned)key_bits, (hipStream_t)stream);
+    MTGS_REQUIRE(e == hipSuccess, e == hipErrorInvalidValue ? MTGS_EWORKSPACE : MTGS_ELAUNCH,
+                 "mtgs_sort_pairs_u32: rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,
+                                 const float *depths, int C, int tile_w, int tile_h, int64_t *isect_ids,
+                                 void *stream) {
+    MTGS_REQUIRE(M >= 0 && C >= 0 && tile_w > 0 && tile_h > 0, MTGS_EINVAL, "mtgs_bin_finalize: bad sizes");
+    if (M == 0) return MTGS_OK;
+    MTGS_REQUIRE(tile_keys_sorted && flatten_ids && depths && isect_ids, MTGS_EINVAL, "mtgs_bin_finalize: null pointer");
+    const int n_tiles = tile_w * tile_h;
+    bin_finalize_kernel<<<(unsigned)ceil_div64(M, BIN_BLOCK), BIN_BLOCK, 0, (hipStream_t)stream>>>(
+        M, tile_keys_sorted, flatten_ids, depths, n_tiles, bit_length_u32((uint32_t)n_tiles), isect_ids);
+    MTGS_CHECK_LAUNCH("mtgs_bin_finalize");
+    return MTGS_OK;
+}

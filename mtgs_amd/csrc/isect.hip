@@ -14,6 +14,7 @@
 // LARGE rectangle is emitted by the whole wave (64 consecutive slots per step -> coalesced
 // 8-byte and 4-byte stores).
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace {
 
@@ -47,86 +48,14 @@ __global__ __launch_bounds__(ISECT_BLOCK) void isect_count_kernel(
     tiles_per_gauss[idx] = cnt;
 }
 
-// ---- three-phase inclusive scan int32 -> int64 -------------------------------------------------
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 8;                        // per thread
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;   // 2048 per block
-
-__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t *lds, int64_t &block_total) {
-    // wave inclusive scan with shuffles, then scan of the 4 wave totals
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    int64_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int64_t up = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += up;
-    }
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    int64_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
-        const int64_t t = lds[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    __syncthreads();
-    block_total = tot;
-    return base + inc - v;
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_partials_kernel(int64_t n, const int32_t *__restrict__ in,
-                                                                   int64_t *__restrict__ partials) {
-    __shared__ int64_t lds[SCAN_BLOCK / 64];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    int64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int64_t j = base + (int64_t)i * SCAN_BLOCK + threadIdx.x;
-        if (j < n) s += in[j];
-    }
-    int64_t tot;
-    block_exclusive_scan(s, lds, tot);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
-}
-
-// single block: exclusive scan of the per-block partials in place; total -> *total_out
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_spine_kernel(int64_t nblocks, int64_t *__restrict__ partials,
-                                                                int64_t *__restrict__ total_out) {
-    __shared__ int64_t lds[SCAN_BLOCK / 64];
-    int64_t carry = 0;
-    for (int64_t b0 = 0; b0 < nblocks; b0 += SCAN_BLOCK) {
-        const int64_t j = b0 + threadIdx.x;
-        const int64_t v = j < nblocks ? partials[j] : 0;
-        int64_t tot;
-        const int64_t ex = block_exclusive_scan(v, lds, tot);
-        if (j < nblocks) partials[j] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_final_kernel(int64_t n, const int32_t *__restrict__ in,
-                                                                const int64_t *__restrict__ partials,
-                                                                int64_t *__restrict__ out) {
-    __shared__ int64_t lds[SCAN_BLOCK / 64];
-    // thread owns SCAN_ITEMS consecutive items (blocked arrangement)
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    int32_t v[SCAN_ITEMS];
-    int64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        s += v[i];
-    }
-    int64_t tot;
-    int64_t run = partials[blockIdx.x] + block_exclusive_scan(s, lds, tot);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        run += v[i];
-        if (base + i < n) out[base + i] = run;
-    }
-}
+struct TilesValue {
+    const int32_t *in;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const { return in[i]; }
+};
+struct InclusiveSink {
+    int64_t *out;
+    __device__ __forceinline__ void operator()(int64_t i, int64_t /*excl*/, int64_t incl) const { out[i] = incl; }
+};
 
 // ---- emit ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ISECT_BLOCK) void isect_emit_kernel(
@@ -231,7 +160,7 @@ extern "C" int mtgs_isect_count(int C, int64_t N, const float *means2d, const in
 
 extern "C" int mtgs_scan_workspace_bytes(int64_t n, size_t *bytes) {
     MTGS_REQUIRE(n >= 0 && bytes, MTGS_EINVAL, "mtgs_scan_workspace_bytes: bad arguments");
-    *bytes = (size_t)(ceil_div64(n, SCAN_TILE) + 1) * sizeof(int64_t);
+    *bytes = mtgs_scan::workspace_bytes(n);
     return MTGS_OK;
 }
 
@@ -247,13 +176,9 @@ extern "C" int mtgs_isect_scan(int64_t n, const int32_t *tiles_per_gauss, int64_
         return MTGS_OK;
     }
     MTGS_REQUIRE(tiles_per_gauss && cum_tiles && ws, MTGS_EINVAL, "mtgs_isect_scan: null pointer");
-    const int64_t nblocks = ceil_div64(n, SCAN_TILE);
-    MTGS_REQUIRE(ws_bytes >= (size_t)(nblocks + 1) * sizeof(int64_t), MTGS_EWORKSPACE,
-                 "mtgs_isect_scan: workspace %zu < %zu bytes", ws_bytes, (size_t)(nblocks + 1) * sizeof(int64_t));
-    int64_t *partials = (int64_t *)ws;
-    scan_partials_kernel<<<(unsigned)nblocks, SCAN_BLOCK, 0, st>>>(n, tiles_per_gauss, partials);
-    scan_spine_kernel<<<1, SCAN_BLOCK, 0, st>>>(nblocks, partials, total);
-    scan_final_kernel<<<(unsigned)nblocks, SCAN_BLOCK, 0, st>>>(n, tiles_per_gauss, partials, cum_tiles);
+    MTGS_REQUIRE(ws_bytes >= mtgs_scan::workspace_bytes(n), MTGS_EWORKSPACE,
+                 "mtgs_isect_scan: workspace %zu < %zu bytes", ws_bytes, mtgs_scan::workspace_bytes(n));
+    mtgs_scan::run(n, TilesValue{tiles_per_gauss}, InclusiveSink{cum_tiles}, (int64_t *)ws, total, st);
     MTGS_CHECK_LAUNCH("mtgs_isect_scan");
     return MTGS_OK;
 }

@@ -154,13 +154,22 @@ def _bit_length(v: int) -> int:
     return int(v).bit_length()
 
 
+def _ws(nbytes_fn: str, n: int, dev) -> Tuple[Tensor, int]:
+    nbytes = C.c_size_t(0)
+    call(nbytes_fn, n, C.byref(nbytes))
+    return torch.empty(nbytes.value, dtype=torch.uint8, device=dev), nbytes.value
+
+
 @torch.no_grad()
 def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
                 tile_height: int, sort: bool = True, packed: bool = False,
                 n_cameras: Optional[int] = None, camera_ids: Optional[Tensor] = None,
                 gaussian_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """gsplat.cuda._wrapper.isect_tiles (packed=False): (tiles_per_gauss[C,N] i32,
-    isect_ids[M] i64, flatten_ids[M] i32), sorted by (camera, tile, depth) when sort=True."""
+    isect_ids[M] i64, flatten_ids[M] i32), sorted by (camera, tile, depth) when sort=True.
+
+    sort=True runs the depth-ordered binning of csrc/bin.hip (same outputs, bit for bit, as the
+    emit-then-sort-46-bits formulation, which sort=False + mtgs_sort_pairs still provides)."""
     if packed:
         raise NotImplementedError("isect_tiles: packed=True")
     require_gpu(means2d, radii, depths)
@@ -177,28 +186,49 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     tiles_per_gauss = torch.empty((Cn, N), dtype=torch.int32, device=dev)
     call("mtgs_isect_count", Cn, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
          ptr(tiles_per_gauss), st)
-    ws_bytes = C.c_size_t(0)
-    call("mtgs_scan_workspace_bytes", total, C.byref(ws_bytes))
-    scan_ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
-    cum = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
-    m_dev = torch.empty(1, dtype=torch.int64, device=dev)
-    call("mtgs_isect_scan", total, ptr(tiles_per_gauss), ptr(cum), ptr(m_dev), ptr(scan_ws),
-         ws_bytes.value, st)
-    M = int(m_dev.item())  # the one host sync of a frame (gsplat does the same)
+    scan_ws, scan_bytes = _ws("mtgs_scan_workspace_bytes", total, dev)
+    if not sort:
+        cum = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+        m_dev = torch.empty(1, dtype=torch.int64, device=dev)
+        call("mtgs_isect_scan", total, ptr(tiles_per_gauss), ptr(cum), ptr(m_dev), ptr(scan_ws), scan_bytes, st)
+        M = int(m_dev.item())  # the one host sync of a frame (gsplat does the same)
+        isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
+        flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
+        if M > 0:
+            call("mtgs_isect_emit", Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
+                 tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids), st)
+        return tiles_per_gauss, isect_ids, flatten_ids
+
+    # ---- depth-ordered binning
+    vis_keys = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    vis_ids = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    totals = torch.empty(1, dtype=torch.int64, device=dev)
+    call("mtgs_bin_compact", Cn, N, ptr(radii), ptr(depths), ptr(tiles_per_gauss), ptr(vis_keys),
+         ptr(vis_ids), ptr(totals), ptr(scan_ws), scan_bytes, st)
+    packed_totals = int(totals.item())  # the one host sync of a frame: n_vis and M together
+    n_vis, M = packed_totals >> 32, packed_totals & 0xFFFFFFFF
     isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
-    if M > 0:
-        call("mtgs_isect_emit", Cn, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
-             tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids), st)
-        if sort:
-            key_bits = 32 + _bit_length(tile_width * tile_height) + _bit_length(Cn)
-            call("mtgs_sort_workspace_bytes", M, C.byref(ws_bytes))
-            sort_ws = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
-            ids_sorted = torch.empty_like(isect_ids)
-            flat_sorted = torch.empty_like(flatten_ids)
-            call("mtgs_sort_pairs", M, key_bits, ptr(isect_ids), ptr(flatten_ids), ptr(ids_sorted),
-                 ptr(flat_sorted), ptr(sort_ws), ws_bytes.value, st)
-            isect_ids, flatten_ids = ids_sorted, flat_sorted
+    if M == 0:
+        return tiles_per_gauss, isect_ids, flatten_ids
+    # (camera, depth) order of the visible Gaussians; ties keep index order (stable)
+    keys_s, ids_s = torch.empty(n_vis, dtype=torch.int64, device=dev), torch.empty(n_vis, dtype=torch.int32, device=dev)
+    sort_ws, sort_bytes = _ws("mtgs_sort_workspace_bytes", n_vis, dev)
+    call("mtgs_sort_pairs", n_vis, 32 + _bit_length(Cn), ptr(vis_keys), ptr(vis_ids), ptr(keys_s), ptr(ids_s),
+         ptr(sort_ws), sort_bytes, st)
+    cum = torch.empty(n_vis, dtype=torch.int64, device=dev)
+    call("mtgs_bin_scan", n_vis, ptr(ids_s), ptr(tiles_per_gauss), ptr(cum), ptr(scan_ws), scan_bytes, st)
+    tile_keys = torch.empty(M, dtype=torch.int32, device=dev)
+    gids = torch.empty(M, dtype=torch.int32, device=dev)
+    call("mtgs_bin_emit", M, n_vis, ptr(ids_s), N, ptr(means2d), ptr(radii), ptr(cum), tile_size, tile_width,
+         tile_height, ptr(tile_keys), ptr(gids), st)
+    tile_keys_s = torch.empty_like(tile_keys)
+    sort_ws, sort_bytes = _ws("mtgs_sort_u32_workspace_bytes", M, dev)
+    key_bits = max(1, _bit_length(Cn * tile_width * tile_height - 1))
+    call("mtgs_sort_pairs_u32", M, key_bits, ptr(tile_keys), ptr(gids), ptr(tile_keys_s), ptr(flatten_ids),
+         ptr(sort_ws), sort_bytes, st)
+    call("mtgs_bin_finalize", M, ptr(tile_keys_s), ptr(flatten_ids), ptr(depths), Cn, tile_width, tile_height,
+         ptr(isect_ids), st)
     return tiles_per_gauss, isect_ids, flatten_ids
 
 

@@ -229,3 +229,35 @@ def test_unsupported_options_raise(gs):
                dict(packed=False, covars=z(1, 3, 3))):
         with pytest.raises(NotImplementedError):
             gs.rasterization(*args, **kw)
+
+
+def test_depth_ordered_binning_equals_emit_then_sort(gs, oracle):
+    """isect_tiles(sort=True) runs the depth-ordered binning (csrc/bin.hip); the gsplat formulation
+    (emit in index order, stable 46-bit sort) must give the same arrays bit for bit, including ties
+    in depth (duplicated Gaussians) and several cameras."""
+    import ctypes as C
+    from mtgs_amd._lib import call, ptr
+    sc, vm, K = small_scene(N=3000, W=400, H=300)
+    for k in ("means", "quats", "scales"):
+        sc[k][1500:] = sc[k][:1500]          # exact duplicates -> equal depths, equal tiles
+    vm3 = torch.cat([vm, vm.clone(), vm.clone()]); vm3[1, 0, 3] += 0.4; vm3[2, 2, 3] += 0.8
+    K3 = torch.cat([K, K, K])
+    W, H = 400, 300
+    radii, means2d, depths, conics, _ = gs.fully_fused_projection(
+        dev(sc["means"]), None, dev(sc["quats"]), dev(sc["scales"]), dev(vm3), dev(K3), W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    tpg, ids, flat = gs.isect_tiles(means2d, radii, depths, 16, tw, th)                 # depth-ordered path
+    _, u_ids, u_flat = gs.isect_tiles(means2d, radii, depths, 16, tw, th, sort=False)   # gsplat formulation
+    M = u_ids.numel()
+    assert M > 20000
+    ws = C.c_size_t(0)
+    call("mtgs_sort_workspace_bytes", M, C.byref(ws))
+    w = torch.empty(ws.value, dtype=torch.uint8, device="cuda")
+    ko, vo = torch.empty_like(u_ids), torch.empty_like(u_flat)
+    key_bits = 32 + int(tw * th).bit_length() + int(3).bit_length()
+    call("mtgs_sort_pairs", M, key_bits, ptr(u_ids), ptr(u_flat), ptr(ko), ptr(vo), ptr(w), ws.value,
+         torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(ids, ko) and torch.equal(flat, vo)
+    r_tpg, r_ids, r_flat = oracle.isect_tiles(means2d.cpu().numpy(), radii.cpu().numpy(), depths.cpu().numpy(), 16, tw, th)
+    assert np.array_equal(ids.cpu().numpy(), r_ids) and np.array_equal(flat.cpu().numpy(), r_flat)
+    assert np.array_equal(tpg.cpu().numpy(), r_tpg)
