@@ -103,7 +103,7 @@ int mtgs_isect_emit(int C, int64_t N, const float *means2d, const int32_t *radii
 
 /* ---- radix sort: the cub::DeviceRadixSort::SortPairs call inside gsplat isect_tiles ----------
  * Stable LSD sort of (i64 key, i32 value) on key bits [0, key_bits).  Output in keys_out/vals_out;
- * inputs are clobbered (used as the alternate buffer). */
+ * the inputs are only read (the ping-pong buffer lives in the workspace). */
 int mtgs_sort_workspace_bytes(int64_t M, size_t *bytes);
 int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in, int64_t *keys_out,
                     int32_t *vals_out, void *ws, size_t ws_bytes, void *stream);

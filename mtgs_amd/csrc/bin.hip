@@ -11,6 +11,7 @@
 //   3. mtgs_bin_scan      prefix sum of tiles_per_gauss in that depth order
 //   4. mtgs_bin_emit      intersections emitted in depth order: (cam*n_tiles + tile, index)
 //   5. mtgs_sort_pairs_u32  stable sort on the tile bits only (13 bits -> 2 passes, 8-byte pairs)
+//      (both sorts are the hand-written wave64 radix sort of radix_sort.hpp)
 //   6. mtgs_bin_finalize  rebuilds the 64-bit isect_ids (gsplat's meta output) from the sorted pairs
 //
 // A stable sort by tile of a (depth, index)-ordered sequence is the (tile, depth, index) order, i.e.
@@ -20,11 +21,8 @@
 //
 // Roofline: HBM.  Algorithmic bytes: compact C*N*12 in + n_vis*12 out; scan n_vis*8 in + 8 out;
 // emit n_vis*24 in + M*8 out; finalize M*8 in + M*8 (+4 gathered) out.
-#include <cstring>
-
-#include <rocprim/rocprim.hpp>
-
 #include "common.hpp"
+#include "radix_sort.hpp"
 #include "scan.hpp"
 
 namespace {
@@ -183,12 +181,7 @@ extern "C" int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted
 
 extern "C" int mtgs_sort_u32_workspace_bytes(int64_t M, size_t *bytes) {
     MTGS_REQUIRE(M >= 0 && bytes, MTGS_EINVAL, "mtgs_sort_u32_workspace_bytes: bad arguments");
-    size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                             (const int32_t *)nullptr, (int32_t *)nullptr,
-                                             (size_t)(M > 0 ? M : 1), 0u, 32u, (hipStream_t)0);
-    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_sort_u32_workspace_bytes: %s", hipGetErrorString(e));
-    *bytes = tmp < 16 ? 16 : tmp;
+    *bytes = mtgs_sort::workspace_bytes<uint32_t>(M > 0 ? M : 1);
     return MTGS_OK;
 }
 
@@ -198,12 +191,8 @@ extern "C" int mtgs_sort_pairs_u32(int64_t M, int key_bits, uint32_t *keys_in, i
     MTGS_REQUIRE(M >= 0 && key_bits > 0 && key_bits <= 32, MTGS_EINVAL, "mtgs_sort_pairs_u32: bad arguments");
     if (M == 0) return MTGS_OK;
     MTGS_REQUIRE(keys_in && vals_in && keys_out && vals_out && ws, MTGS_EINVAL, "mtgs_sort_pairs_u32: null pointer");
-    size_t need = ws_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(ws, need, (const uint32_t *)keys_in, keys_out, (const int32_t *)vals_in,
-                                             vals_out, (size_t)M, 0u, (unsigned)key_bits, (hipStream_t)stream);
-    MTGS_REQUIRE(e == hipSuccess, e == hipErrorInvalidValue ? MTGS_EWORKSPACE : MTGS_ELAUNCH,
-                 "mtgs_sort_pairs_u32: rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
-    return MTGS_OK;
+    return mtgs_sort::sort_pairs<uint32_t>(M, key_bits, keys_in, vals_in, keys_out, vals_out, ws, ws_bytes,
+                                           (hipStream_t)stream, "mtgs_sort_pairs_u32");
 }
 
 extern "C" int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,

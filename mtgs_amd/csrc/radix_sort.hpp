@@ -1,0 +1,222 @@
+// radix_sort.hpp -- hand-written stable LSD radix sort of (key, value) pairs for gfx950.
+//
+// Replaces the cub::DeviceRadixSort::SortPairs call of gsplat 1.4.0's isect_tiles.  One pass =
+//   hist    : per-block digit histogram (LDS atomics)            -> g_hist[digit][block]
+//   scan    : one workgroup per digit, exclusive scan over blocks -> g_hist in place, digit totals
+//   reorder : every block re-reads its tile, ranks its keys STABLY and scatters keys + values.
+// Stable ranking inside a block is wave64-native: a wave walks its sub-tile 64 keys at a time; the
+// set of lanes holding the same digit ("peers") is built from RADIX_BITS ballots, the rank is
+// popcount(peers below me) + a wave-private running counter in LDS, and the four waves' sub-tiles
+// are chained by a per-digit prefix over waves.  No inter-workgroup synchronisation inside a launch
+// (nothing to deadlock), no atomics on global memory.
+//
+// Roofline: HBM.  Bytes per pass: hist n*sizeof(K) read; reorder n*(sizeof(K)+4) read + written.
+#pragma once
+#include "common.hpp"
+
+namespace mtgs_sort {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+template <typename K>
+__device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
+    return (unsigned)(key >> shift) & mask;
+}
+
+template <typename K, int ITEMS>
+__global__ __launch_bounds__(THREADS) void hist_kernel(int64_t n, const K *__restrict__ keys, int shift,
+                                                       unsigned mask, int nblocks,
+                                                       uint32_t *__restrict__ g_hist) {
+    __shared__ uint32_t s_hist[RADIX];
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * (THREADS * ITEMS);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t j = base + (int64_t)i * THREADS + tid;
+        if (j < n) atomicAdd(&s_hist[digit_of(keys[j], shift, mask)], 1u);
+    }
+    __syncthreads();
+    g_hist[(int64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
+}
+
+// one workgroup per digit: exclusive scan of g_hist[digit][0..nblocks) in place; total -> totals[digit]
+template <int DUMMY = 0>
+__global__ __launch_bounds__(THREADS) void scan_kernel(int nblocks, uint32_t *__restrict__ g_hist,
+                                                       uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_w[WAVES];
+    uint32_t *row = g_hist + (int64_t)blockIdx.x * nblocks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += THREADS) {
+        const int j = b0 + tid;
+        const uint32_t v = j < nblocks ? row[j] : 0;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t t = s_w[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        if (j < nblocks) row[j] = carry + wbase + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = carry;
+}
+
+template <typename K, int ITEMS>
+__global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__restrict__ keys_in,
+                                                          const int32_t *__restrict__ vals_in,
+                                                          K *__restrict__ keys_out, int32_t *__restrict__ vals_out,
+                                                          int shift, unsigned mask, int bits, int nblocks,
+                                                          const uint32_t *__restrict__ g_hist,
+                                                          const uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_off[WAVES][RADIX];  // phase 1: per-wave digit counts; phase 2+: running global offsets
+    __shared__ uint32_t s_w[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s_off[w][tid] = 0;
+    __syncthreads();
+    // ---- load this wave's sub-tile (order: wave, iteration, lane == increasing index) + count digits
+    const int64_t wbase = (int64_t)blockIdx.x * (THREADS * ITEMS) + (int64_t)wave * (64 * ITEMS);
+    K key[ITEMS];
+    int32_t val[ITEMS];
+    unsigned dig[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t j = wbase + i * 64 + lane;
+        if (j < n) {
+            key[i] = keys_in[j];
+            val[i] = vals_in[j];
+            dig[i] = digit_of(key[i], shift, mask);
+            atomicAdd(&s_off[wave][dig[i]], 1u);
+        } else {
+            key[i] = 0; val[i] = 0; dig[i] = 0;
+        }
+    }
+    __syncthreads();
+    // ---- global base of every digit for this block: (sum of smaller digits) + (same digit, earlier blocks)
+    {
+        const uint32_t tot = totals[tid];
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wb = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+            if (w < wave) wb += s_w[w];
+        uint32_t running = wb + inc - tot + g_hist[(int64_t)tid * nblocks + blockIdx.x];
+        // chain the four waves' sub-tiles
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = s_off[w][tid];
+            s_off[w][tid] = running;
+            running += c;
+        }
+    }
+    __syncthreads();
+    // ---- stable rank + scatter, 64 keys per step
+    uint32_t *my_off = s_off[wave];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t j = wbase + i * 64 + lane;
+        const bool live = j < n;
+        unsigned long long peers = __ballot(live);
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (dig[i] >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t below = (uint32_t)__builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+        uint32_t pos = 0;
+        if (live) pos = my_off[dig[i]] + below;
+        __builtin_amdgcn_wave_barrier();
+        if (live && below == 0) my_off[dig[i]] += (uint32_t)__popcll(peers);  // one lane per distinct digit
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            keys_out[pos] = key[i];
+            vals_out[pos] = val[i];
+        }
+    }
+}
+
+inline int64_t tile_items(int64_t n) { return n <= (1 << 20) ? THREADS * 4 : THREADS * 16; }
+inline int64_t num_blocks(int64_t n) { return ceil_div64(n, tile_items(n)); }
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+// workspace: g_hist[RADIX][nblocks] + totals[RADIX] (uint32), then one (key, value) ping-pong buffer
+template <typename K>
+inline size_t workspace_bytes(int64_t n) {
+    return align256((size_t)(RADIX * (num_blocks(n) + 1)) * sizeof(uint32_t)) + align256((size_t)n * sizeof(K)) +
+           align256((size_t)n * sizeof(int32_t));
+}
+
+// Sorts on key bits [0, key_bits): result in (keys_out, vals_out); the inputs are only read.
+// Passes ping-pong between the output pair and a temporary pair in the workspace, starting on the
+// side that makes the LAST pass land in the output pair.
+template <typename K>
+int sort_pairs(int64_t n, int key_bits, const K *keys_in, const int32_t *vals_in, K *keys_out, int32_t *vals_out,
+               void *ws, size_t ws_bytes, hipStream_t st, const char *who) {
+    if (n == 0) return MTGS_OK;
+    MTGS_REQUIRE(ws_bytes >= workspace_bytes<K>(n), MTGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes,
+                 workspace_bytes<K>(n));
+    MTGS_REQUIRE(n < ((int64_t)1 << 32), MTGS_EINVAL, "%s: n must fit 32 bits", who);
+    const int npass = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
+    const int nblocks = (int)num_blocks(n);
+    const bool small = tile_items(n) == THREADS * 4;
+    char *w = (char *)ws;
+    uint32_t *g_hist = (uint32_t *)w;
+    uint32_t *totals = g_hist + (size_t)RADIX * nblocks;
+    w += align256((size_t)(RADIX * (nblocks + 1)) * sizeof(uint32_t));
+    K *keys_tmp = (K *)w;
+    w += align256((size_t)n * sizeof(K));
+    int32_t *vals_tmp = (int32_t *)w;
+    const K *kin = keys_in;
+    const int32_t *vin = vals_in;
+    bool to_out = (npass % 2) == 1;  // odd: in->out->tmp->out ; even: in->tmp->out
+    int shift = 0;
+    for (int p = 0; p < npass; ++p) {
+        const int bits = (key_bits - shift) < RADIX_BITS ? (key_bits - shift) : RADIX_BITS;
+        const unsigned mask = (1u << bits) - 1u;
+        K *kout = to_out ? keys_out : keys_tmp;
+        int32_t *vout = to_out ? vals_out : vals_tmp;
+        if (small) {
+            hist_kernel<K, 4><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist);
+            scan_kernel<0><<<RADIX, THREADS, 0, st>>>(nblocks, g_hist, totals);
+            reorder_kernel<K, 4><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits, nblocks,
+                                                             g_hist, totals);
+        } else {
+            hist_kernel<K, 16><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist);
+            scan_kernel<0><<<RADIX, THREADS, 0, st>>>(nblocks, g_hist, totals);
+            reorder_kernel<K, 16><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits, nblocks,
+                                                              g_hist, totals);
+        }
+        shift += bits;
+        kin = kout;
+        vin = vout;
+        to_out = !to_out;
+    }
+    hipError_t e = hipGetLastError();
+    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "%s: launch failed: %s", who, hipGetErrorString(e));
+    return MTGS_OK;
+}
+
+}  // namespace mtgs_sort

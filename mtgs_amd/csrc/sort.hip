@@ -5,23 +5,16 @@
 // mtgs_scene_graph.py:641-662).  Keys are cam | tile | fp32-depth-bits, so only
 // 32 + tile_bits + cam_bits bits are significant (46 at 1920x1080, one camera).
 //
-// Round-1 implementation: rocPRIM's device radix sort (the ROCm counterpart of the CUB call the
-// reference makes), restricted to the significant bits.  Roofline: HBM, 2 x 12 B per pair per
-// 8-bit digit pass.  Bit-exact (stable) against oracle/gsplat_oracle.c::orc_sort_pairs.
-#include <cstring>
-
-#include <rocprim/rocprim.hpp>
-
+// Hand-written for gfx950 (radix_sort.hpp): 8-bit digits, hist / scan / reorder per pass, wave64
+// ballot ranking.  Roofline: HBM, 8 B + 2 x 12 B per pair per pass.  Bit-exact (stable) against
+// oracle/gsplat_oracle.c::orc_sort_pairs.  (The default binning path, bin.hip, needs only
+// 32-bit keys and far fewer passes; this entry point is the gsplat-shaped formulation.)
 #include "common.hpp"
+#include "radix_sort.hpp"
 
 extern "C" int mtgs_sort_workspace_bytes(int64_t M, size_t *bytes) {
     MTGS_REQUIRE(M >= 0 && bytes, MTGS_EINVAL, "mtgs_sort_workspace_bytes: bad arguments");
-    size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const int64_t *)nullptr, (int64_t *)nullptr,
-                                             (const int32_t *)nullptr, (int32_t *)nullptr,
-                                             (size_t)(M > 0 ? M : 1), 0u, 64u, (hipStream_t)0);
-    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_sort_workspace_bytes: %s", hipGetErrorString(e));
-    *bytes = tmp < 16 ? 16 : tmp;
+    *bytes = mtgs_sort::workspace_bytes<uint64_t>(M > 0 ? M : 1);
     return MTGS_OK;
 }
 
@@ -32,11 +25,6 @@ extern "C" int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_
                  "mtgs_sort_pairs: bad arguments M=%lld key_bits=%d", (long long)M, key_bits);
     if (M == 0) return MTGS_OK;
     MTGS_REQUIRE(keys_in && vals_in && keys_out && vals_out && ws, MTGS_EINVAL, "mtgs_sort_pairs: null pointer");
-    size_t need = ws_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(ws, need, (const int64_t *)keys_in, keys_out,
-                                             (const int32_t *)vals_in, vals_out, (size_t)M, 0u,
-                                             (unsigned)key_bits, (hipStream_t)stream);
-    MTGS_REQUIRE(e == hipSuccess, e == hipErrorInvalidValue ? MTGS_EWORKSPACE : MTGS_ELAUNCH,
-                 "mtgs_sort_pairs: rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
-    return MTGS_OK;
+    return mtgs_sort::sort_pairs<uint64_t>(M, key_bits, (const uint64_t *)keys_in, vals_in, (uint64_t *)keys_out,
+                                           vals_out, ws, ws_bytes, (hipStream_t)stream, "mtgs_sort_pairs");
 }
