@@ -116,7 +116,9 @@ int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in,
  *  mtgs_bin_scan     : cum[n_vis] i64 = inclusive sum of tiles_per_gauss[ids_sorted[r]].
  *  mtgs_bin_emit     : tile_keys[M] u32 = cam*n_tiles + tile, gids[M] i32, in depth order.
  *  mtgs_sort_pairs_u32 : stable LSD sort of (u32 key, i32 value) on key bits [0, key_bits).
- *  mtgs_bin_finalize : isect_ids[M] i64 from the sorted (tile key, index) pairs and depths. */
+ *  mtgs_bin_sort_tiles : the same sort on the tile bits, with gsplat's isect_ids[M] i64 written by the
+ *                      last pass directly (keys_scratch[M] u32 is a scratch buffer).
+ *  mtgs_bin_finalize : isect_ids[M] i64 from already sorted (tile key, index) pairs and depths. */
 int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
                      const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
                      int64_t *totals, void *ws, size_t ws_bytes, void *stream);
@@ -128,6 +130,10 @@ int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted, int64_t N
 int mtgs_sort_u32_workspace_bytes(int64_t M, size_t *bytes);
 int mtgs_sort_pairs_u32(int64_t M, int key_bits, uint32_t *keys_in, int32_t *vals_in,
                         uint32_t *keys_out, int32_t *vals_out, void *ws, size_t ws_bytes, void *stream);
+int mtgs_bin_sort_tiles(int64_t M, int C, int tile_w, int tile_h, const uint32_t *tile_keys,
+                        const int32_t *gids, const float *depths, uint32_t *keys_scratch,
+                        int32_t *flatten_ids, int64_t *isect_ids, void *ws, size_t ws_bytes,
+                        void *stream);
 int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,
                       const float *depths, int C, int tile_w, int tile_h, int64_t *isect_ids,
                       void *stream);

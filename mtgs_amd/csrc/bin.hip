@@ -71,49 +71,66 @@ struct InclusiveSink {
     __device__ __forceinline__ void operator()(int64_t r, int64_t /*excl*/, int64_t incl) const { out[r] = incl; }
 };
 
-// One thread per OUTPUT slot (load-balanced search): in depth order the largest footprints (the
-// nearest Gaussians cover the whole image) are adjacent, so a per-Gaussian loop would serialise
-// thousands of stores behind the first wavefronts.  A wave covers 64 consecutive slots: one uniform
-// binary search finds the Gaussian of its first slot, the next 64 prefix sums are held one per lane
-// and each lane locates its own Gaussian with 7 shuffles.  Stores are fully coalesced.
+// Load-balanced emission: the work is split by OUTPUT slot, not by Gaussian.  In depth order the
+// largest footprints are adjacent (the nearest Gaussians cover the whole image), so a per-Gaussian
+// loop would serialise thousands of stores behind the first wavefronts.  A block owns 2048
+// consecutive slots: one uniform binary search in the prefix sums finds the Gaussian of its first
+// slot, the next 2048 prefix sums go to LDS, and every slot locates its Gaussian with an 11-step
+// search in LDS (neighbouring lanes read the same words -> broadcasts).  Stores are fully coalesced.
+constexpr int EMIT_ITEMS = 8, EMIT_TILE = BIN_BLOCK * EMIT_ITEMS;
 __global__ __launch_bounds__(BIN_BLOCK) void bin_emit_kernel(
     int64_t M, int64_t n_vis, const int32_t *__restrict__ ids_sorted, int64_t N,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const int64_t *__restrict__ cum,
     float ts, int tw, int th, uint32_t *__restrict__ tile_keys, int32_t *__restrict__ gids) {
-    const int64_t i = (int64_t)blockIdx.x * BIN_BLOCK + threadIdx.x;
-    const int lane = lane_id();
-    const int64_t i0 = i - lane;  // first slot of the wave (wave-uniform)
-    if (i0 >= M) return;
-    // r0 = first r with cum[r] > i0   (cum is the inclusive prefix sum, so slot i0 belongs to r0)
+    __shared__ int32_t s_c[EMIT_TILE];
+    const int tid = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * EMIT_TILE;
+    // r0 = first r with cum[r] > s0   (cum is the inclusive prefix sum, so slot s0 belongs to r0)
     int64_t lo = 0, hi = n_vis;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (cum[mid] > i0) hi = mid; else lo = mid + 1;
+        if (cum[mid] > s0) hi = mid; else lo = mid + 1;
     }
     const int64_t r0 = lo;
-    // every Gaussian owns >= 1 slot, so the wave's 64 slots touch at most Gaussians r0 .. r0+63
-    const int32_t c = (r0 + lane < n_vis) ? (int32_t)cum[r0 + lane] : 0x7fffffff;
-    int l = 0, h = 64;  // answer in [0, 64]: 65 candidates -> 7 halvings
+    // every Gaussian owns >= 1 slot, so the block's slots touch at most Gaussians r0 .. r0+EMIT_TILE-1
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
-        const int mid = min((l + h) >> 1, 63);
-        const int32_t v = __shfl(c, mid, 64);
-        if ((int64_t)v <= i) l = mid + 1; else h = mid;
+    for (int e = 0; e < EMIT_ITEMS; ++e) {
+        const int k = e * BIN_BLOCK + tid;
+        s_c[k] = (r0 + k < n_vis) ? (int32_t)cum[r0 + k] : 0x7fffffff;
     }
-    const int64_t r = r0 + l;
-    // (the shuffle must run with all lanes active: ds_bpermute returns 0 for a disabled source lane)
-    const int32_t prev = __shfl(c, max(l - 1, 0), 64);
     const int32_t base0 = r0 > 0 ? (int32_t)cum[r0 - 1] : 0;
-    const int32_t excl = l > 0 ? prev : base0;
-    if (i >= M) return;
-    const int32_t idx = ids_sorted[r];
-    const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
-    const Rect q = tile_rect(m.x, m.y, radii[idx], ts, tw, th);
-    const int local = (int)(i - excl), bw = q.x1 - q.x0;
-    const int row = local / bw, col = local - row * bw;
-    tile_keys[i] = (uint32_t)(idx / N) * (uint32_t)(tw * th) + (uint32_t)((q.y0 + row) * tw + q.x0 + col);
-    gids[i] = idx;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EMIT_ITEMS; ++e) {
+        const int64_t i = s0 + e * BIN_BLOCK + tid;
+        if (i >= M) break;
+        int l = 0, h = EMIT_TILE - 1;  // first l with s_c[l] > i; it exists and is <= EMIT_TILE-1
+        while (l < h) {
+            const int mid = (l + h) >> 1;
+            if ((int64_t)s_c[mid] <= i) l = mid + 1; else h = mid;
+        }
+        const int32_t excl = l > 0 ? s_c[l - 1] : base0;
+        const int32_t idx = ids_sorted[r0 + l];
+        const float2 m = reinterpret_cast<const float2 *>(means2d)[idx];
+        const Rect q = tile_rect(m.x, m.y, radii[idx], ts, tw, th);
+        const int local = (int)(i - excl), bw = q.x1 - q.x0;
+        const int row = local / bw, col = local - row * bw;
+        tile_keys[i] = (uint32_t)(idx / N) * (uint32_t)(tw * th) + (uint32_t)((q.y0 + row) * tw + q.x0 + col);
+        gids[i] = idx;
+    }
 }
+
+// last-pass epilogue of the tile sort: (tile key, Gaussian index) -> gsplat's 64-bit isect_id
+struct IsectIdEpilogue {
+    static constexpr bool enabled = true;
+    const float *depths;
+    uint32_t n_tiles;
+    int tile_bits;
+    __device__ __forceinline__ int64_t operator()(uint64_t key, int32_t gid) const {
+        const int64_t cam = (uint32_t)key / n_tiles, tile = (uint32_t)key % n_tiles;
+        return (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)__float_as_uint(depths[gid]);
+    }
+};
 
 __global__ __launch_bounds__(BIN_BLOCK) void bin_finalize_kernel(
     int64_t M, const uint32_t *__restrict__ tile_keys, const int32_t *__restrict__ gids,
@@ -173,7 +190,7 @@ extern "C" int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted
     MTGS_REQUIRE(M < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_bin_emit: M must fit int32");
     if (n_vis == 0 || M == 0) return MTGS_OK;
     MTGS_REQUIRE(ids_sorted && means2d && radii && cum, MTGS_EINVAL, "mtgs_bin_emit: null pointer");
-    bin_emit_kernel<<<(unsigned)ceil_div64(M, BIN_BLOCK), BIN_BLOCK, 0, (hipStream_t)stream>>>(
+    bin_emit_kernel<<<(unsigned)ceil_div64(M, EMIT_TILE), BIN_BLOCK, 0, (hipStream_t)stream>>>(
         M, n_vis, ids_sorted, N, means2d, radii, cum, (float)tile_size, tile_w, tile_h, tile_keys, gids);
     MTGS_CHECK_LAUNCH("mtgs_bin_emit");
     return MTGS_OK;
@@ -193,6 +210,21 @@ extern "C" int mtgs_sort_pairs_u32(int64_t M, int key_bits, uint32_t *keys_in, i
     MTGS_REQUIRE(keys_in && vals_in && keys_out && vals_out && ws, MTGS_EINVAL, "mtgs_sort_pairs_u32: null pointer");
     return mtgs_sort::sort_pairs<uint32_t>(M, key_bits, keys_in, vals_in, keys_out, vals_out, ws, ws_bytes,
                                            (hipStream_t)stream, "mtgs_sort_pairs_u32");
+}
+
+extern "C" int mtgs_bin_sort_tiles(int64_t M, int C, int tile_w, int tile_h, const uint32_t *tile_keys,
+                                   const int32_t *gids, const float *depths, uint32_t *keys_scratch,
+                                   int32_t *flatten_ids, int64_t *isect_ids, void *ws, size_t ws_bytes,
+                                   void *stream) {
+    MTGS_REQUIRE(M >= 0 && C > 0 && tile_w > 0 && tile_h > 0, MTGS_EINVAL, "mtgs_bin_sort_tiles: bad sizes");
+    if (M == 0) return MTGS_OK;
+    MTGS_REQUIRE(tile_keys && gids && depths && keys_scratch && flatten_ids && isect_ids && ws, MTGS_EINVAL,
+                 "mtgs_bin_sort_tiles: null pointer");
+    const uint32_t n_tiles = (uint32_t)(tile_w * tile_h);
+    const int key_bits = bit_length_u32((uint32_t)C * n_tiles - 1u) > 0 ? bit_length_u32((uint32_t)C * n_tiles - 1u) : 1;
+    return mtgs_sort::sort_pairs<uint32_t, IsectIdEpilogue>(
+        M, key_bits, tile_keys, gids, keys_scratch, flatten_ids, ws, ws_bytes, (hipStream_t)stream,
+        "mtgs_bin_sort_tiles", IsectIdEpilogue{depths, n_tiles, bit_length_u32(n_tiles)}, isect_ids);
 }
 
 extern "C" int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,

@@ -8,7 +8,8 @@
 // set of lanes holding the same digit ("peers") is built from RADIX_BITS ballots, the rank is
 // popcount(peers below me) + a wave-private running counter in LDS, and the four waves' sub-tiles
 // are chained by a per-digit prefix over waves.  No inter-workgroup synchronisation inside a launch
-// (nothing to deadlock), no atomics on global memory.
+// (nothing to deadlock), no atomics on global memory.  The tile is rebuilt in LDS grouped by digit
+// before it is written, so consecutive lanes store consecutive elements of a digit run (coalesced).
 //
 // Roofline: HBM.  Bytes per pass: hist n*sizeof(K) read; reorder n*(sizeof(K)+4) read + written.
 #pragma once
@@ -77,21 +78,34 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(int nblocks, uint32_t *__
     if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-template <typename K, int ITEMS>
+// Optional epilogue of the LAST pass: instead of the raw key, a 64-bit value derived from
+// (key, value) is written (bin.hip uses it to emit gsplat's isect_ids directly).
+struct NoEpilogue {
+    static constexpr bool enabled = false;
+    __device__ __forceinline__ int64_t operator()(uint64_t, int32_t) const { return 0; }
+};
+
+template <typename K, int ITEMS, class Epi>
 __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__restrict__ keys_in,
                                                           const int32_t *__restrict__ vals_in,
                                                           K *__restrict__ keys_out, int32_t *__restrict__ vals_out,
                                                           int shift, unsigned mask, int bits, int nblocks,
                                                           const uint32_t *__restrict__ g_hist,
-                                                          const uint32_t *__restrict__ totals) {
-    __shared__ uint32_t s_off[WAVES][RADIX];  // phase 1: per-wave digit counts; phase 2+: running global offsets
+                                                          const uint32_t *__restrict__ totals, Epi epi,
+                                                          int64_t *__restrict__ epi_out) {
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ uint32_t s_off[WAVES][RADIX];  // per-wave digit counts, then running LOCAL offsets
+    __shared__ uint32_t s_gbase[RADIX];       // global position of local slot 0 of each digit
     __shared__ uint32_t s_w[WAVES];
+    __shared__ K s_key[TILE];                 // the tile, reordered by digit (stable)
+    __shared__ int32_t s_val[TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s_off[w][tid] = 0;
     __syncthreads();
     // ---- load this wave's sub-tile (order: wave, iteration, lane == increasing index) + count digits
-    const int64_t wbase = (int64_t)blockIdx.x * (THREADS * ITEMS) + (int64_t)wave * (64 * ITEMS);
+    const int64_t tile_base = (int64_t)blockIdx.x * TILE;
+    const int64_t wbase = tile_base + (int64_t)wave * (64 * ITEMS);
     K key[ITEMS];
     int32_t val[ITEMS];
     unsigned dig[ITEMS];
@@ -108,23 +122,37 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__
         }
     }
     __syncthreads();
-    // ---- global base of every digit for this block: (sum of smaller digits) + (same digit, earlier blocks)
+    // ---- per digit (one thread each): count in this block, local exclusive offset, global base
     {
-        const uint32_t tot = totals[tid];
-        uint32_t inc = tot;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) cnt += s_off[w][tid];
+        // exclusive scan of the block's digit counts -> local start of every digit
+        uint32_t inc = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(inc, o, 64);
             if (lane >= o) inc += up;
         }
-        if (lane == 63) s_w[wave] = inc;
+        // exclusive scan of the GLOBAL digit totals
+        const uint32_t tot = totals[tid];
+        uint32_t ginc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(ginc, o, 64);
+            if (lane >= o) ginc += up;
+        }
+        if (lane == 63) { s_w[wave] = inc; s_gbase[wave] = ginc; }  // s_gbase[0..3] used as scratch
         __syncthreads();
-        uint32_t wb = 0;
+        uint32_t lb = 0, gb = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w)
-            if (w < wave) wb += s_w[w];
-        uint32_t running = wb + inc - tot + g_hist[(int64_t)tid * nblocks + blockIdx.x];
-        // chain the four waves' sub-tiles
+            if (w < wave) { lb += s_w[w]; gb += s_gbase[w]; }
+        __syncthreads();
+        const uint32_t local_start = lb + inc - cnt;
+        // global position of the first element of this digit coming from this block
+        s_gbase[tid] = gb + ginc - tot + g_hist[(int64_t)tid * nblocks + blockIdx.x] - local_start;
+        uint32_t running = local_start;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             const uint32_t c = s_off[w][tid];
@@ -133,7 +161,7 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__
         }
     }
     __syncthreads();
-    // ---- stable rank + scatter, 64 keys per step
+    // ---- stable LOCAL rank, 64 keys per step; the tile is rebuilt in LDS grouped by digit
     uint32_t *my_off = s_off[wave];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -153,9 +181,20 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__
         if (live && below == 0) my_off[dig[i]] += (uint32_t)__popcll(peers);  // one lane per distinct digit
         __builtin_amdgcn_wave_barrier();
         if (live) {
-            keys_out[pos] = key[i];
-            vals_out[pos] = val[i];
+            s_key[pos] = key[i];
+            s_val[pos] = val[i];
         }
+    }
+    __syncthreads();
+    // ---- write out: consecutive threads hold consecutive elements of a digit run -> coalesced runs
+    const int count = (int)min((int64_t)TILE, n - tile_base);
+    for (int k = tid; k < count; k += THREADS) {
+        const K kk = s_key[k];
+        const int32_t vv = s_val[k];
+        const uint32_t dst = s_gbase[digit_of(kk, shift, mask)] + (uint32_t)k;
+        if (Epi::enabled) epi_out[dst] = epi((uint64_t)kk, vv);
+        else keys_out[dst] = kk;
+        vals_out[dst] = vv;
     }
 }
 
@@ -172,9 +211,10 @@ inline size_t workspace_bytes(int64_t n) {
 // Sorts on key bits [0, key_bits): result in (keys_out, vals_out); the inputs are only read.
 // Passes ping-pong between the output pair and a temporary pair in the workspace, starting on the
 // side that makes the LAST pass land in the output pair.
-template <typename K>
+template <typename K, class Epi = NoEpilogue>
 int sort_pairs(int64_t n, int key_bits, const K *keys_in, const int32_t *vals_in, K *keys_out, int32_t *vals_out,
-               void *ws, size_t ws_bytes, hipStream_t st, const char *who) {
+               void *ws, size_t ws_bytes, hipStream_t st, const char *who, Epi epi = Epi(),
+               int64_t *epi_out = nullptr) {
     if (n == 0) return MTGS_OK;
     MTGS_REQUIRE(ws_bytes >= workspace_bytes<K>(n), MTGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes,
                  workspace_bytes<K>(n));
@@ -198,16 +238,25 @@ int sort_pairs(int64_t n, int key_bits, const K *keys_in, const int32_t *vals_in
         const unsigned mask = (1u << bits) - 1u;
         K *kout = to_out ? keys_out : keys_tmp;
         int32_t *vout = to_out ? vals_out : vals_tmp;
+        const bool last = p == npass - 1;
         if (small) {
             hist_kernel<K, 4><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist);
             scan_kernel<0><<<RADIX, THREADS, 0, st>>>(nblocks, g_hist, totals);
-            reorder_kernel<K, 4><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits, nblocks,
-                                                             g_hist, totals);
+            if (last && Epi::enabled)
+                reorder_kernel<K, 4, Epi><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
+                                                                      nblocks, g_hist, totals, epi, epi_out);
+            else
+                reorder_kernel<K, 4, NoEpilogue><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
+                                                                             nblocks, g_hist, totals, NoEpilogue(), nullptr);
         } else {
             hist_kernel<K, 16><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist);
             scan_kernel<0><<<RADIX, THREADS, 0, st>>>(nblocks, g_hist, totals);
-            reorder_kernel<K, 16><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits, nblocks,
-                                                              g_hist, totals);
+            if (last && Epi::enabled)
+                reorder_kernel<K, 16, Epi><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
+                                                                       nblocks, g_hist, totals, epi, epi_out);
+            else
+                reorder_kernel<K, 16, NoEpilogue><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
+                                                                              nblocks, g_hist, totals, NoEpilogue(), nullptr);
         }
         shift += bits;
         kin = kout;

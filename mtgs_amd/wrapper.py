@@ -214,7 +214,8 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     # (camera, depth) order of the visible Gaussians; ties keep index order (stable)
     keys_s, ids_s = torch.empty(n_vis, dtype=torch.int64, device=dev), torch.empty(n_vis, dtype=torch.int32, device=dev)
     sort_ws, sort_bytes = _ws("mtgs_sort_workspace_bytes", n_vis, dev)
-    call("mtgs_sort_pairs", n_vis, 32 + _bit_length(Cn), ptr(vis_keys), ptr(vis_ids), ptr(keys_s), ptr(ids_s),
+    depth_key_bits = 32 + (_bit_length(Cn - 1) if Cn > 1 else 0)
+    call("mtgs_sort_pairs", n_vis, depth_key_bits, ptr(vis_keys), ptr(vis_ids), ptr(keys_s), ptr(ids_s),
          ptr(sort_ws), sort_bytes, st)
     cum = torch.empty(n_vis, dtype=torch.int64, device=dev)
     call("mtgs_bin_scan", n_vis, ptr(ids_s), ptr(tiles_per_gauss), ptr(cum), ptr(scan_ws), scan_bytes, st)
@@ -222,13 +223,11 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     gids = torch.empty(M, dtype=torch.int32, device=dev)
     call("mtgs_bin_emit", M, n_vis, ptr(ids_s), N, ptr(means2d), ptr(radii), ptr(cum), tile_size, tile_width,
          tile_height, ptr(tile_keys), ptr(gids), st)
-    tile_keys_s = torch.empty_like(tile_keys)
+    keys_scratch = torch.empty_like(tile_keys)
     sort_ws, sort_bytes = _ws("mtgs_sort_u32_workspace_bytes", M, dev)
-    key_bits = max(1, _bit_length(Cn * tile_width * tile_height - 1))
-    call("mtgs_sort_pairs_u32", M, key_bits, ptr(tile_keys), ptr(gids), ptr(tile_keys_s), ptr(flatten_ids),
-         ptr(sort_ws), sort_bytes, st)
-    call("mtgs_bin_finalize", M, ptr(tile_keys_s), ptr(flatten_ids), ptr(depths), Cn, tile_width, tile_height,
-         ptr(isect_ids), st)
+    # stable sort on the tile bits; the last pass writes gsplat's 64-bit isect_ids directly
+    call("mtgs_bin_sort_tiles", M, Cn, tile_width, tile_height, ptr(tile_keys), ptr(gids), ptr(depths),
+         ptr(keys_scratch), ptr(flatten_ids), ptr(isect_ids), ptr(sort_ws), sort_bytes, st)
     return tiles_per_gauss, isect_ids, flatten_ids
 
 
