@@ -72,19 +72,24 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * out: radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3] (a,b,c of the
  * inverse 2x2 covariance), compensations[C,N] (nullable; antialiased mode).  Culled rows of the
  * float outputs are written as zeros.
+ * Fusion of gsplat's `opacities.repeat(C,1) * compensations` (rendering.py): with opacities[N]
+ * (nullable) given, opac_eff[C,N] = opacities * compensations (or opacities in classic mode) is
+ * written by the forward, and the backward takes v_opac_eff[C,N] (nullable) and writes
+ * v_opacities[N] (nullable), folding v_opac_eff * opacities into the compensation VJP.
  * bwd: v_means[N,3] v_quats[N,4] v_scales[N,3] are OVERWRITTEN (summed over cameras);
  * v_viewmats[C,4,4] nullable, overwritten. */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
-                     float near_plane, float far_plane, float radius_clip, int32_t *radii,
-                     float *means2d, float *depths, float *conics, float *compensations,
-                     void *stream);
+                     float near_plane, float far_plane, float radius_clip, const float *opacities,
+                     int32_t *radii, float *means2d, float *depths, float *conics,
+                     float *compensations, float *opac_eff, void *stream);
 int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      const int32_t *radii, const float *conics, const float *compensations,
-                     const float *v_means2d, const float *v_depths, const float *v_conics,
-                     const float *v_compensations, float *v_means, float *v_quats, float *v_scales,
-                     float *v_viewmats, void *stream);
+                     const float *opacities, const float *v_means2d, const float *v_depths,
+                     const float *v_conics, const float *v_compensations, const float *v_opac_eff,
+                     float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
+                     float *v_opacities, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -144,9 +149,15 @@ int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int ti
 
 /* ---- compositing: gsplat rasterize_to_pixels_fwd / _bwd ---------------------------------------
  * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (nullable).
- * out: render[C,H,W,D] alphas[C,H,W] last_ids[C,H,W] i32 (index into the sorted list).
- * bwd: v_means2d[C,N,2] v_conics[C,N,3] v_colors[C,N,D] v_opacities[C,N] and v_means2d_abs
- * (nullable, absgrad) must be ZERO-FILLED by the caller; gradients are accumulated with atomics.
+ * out: render[C,H,W,DT] alphas[C,H,W] last_ids[C,H,W] i32 (index into the sorted list).
+ * Two fusions of what gsplat's Python does around the operator (rendering.py, "RGB+D"/"RGB+ED"/"D"/"ED"):
+ *   depths[C,N] (nullable): blended as one extra, LAST channel (DT = D + 1) instead of torch.cat;
+ *                           D may then be 0 ("D"/"ED" modes, colors null).  backgrounds stays [C,D].
+ *   ed_normalize          : the last channel is divided by clamp(alpha, min=1e-10) (expected depth).
+ * With depths = NULL and ed_normalize = 0 this is exactly rasterize_to_pixels (DT = D).
+ * bwd: v_means2d[C,N,2] v_conics[C,N,3] v_colors[C,N,D] v_depths[C,N] v_opacities[C,N] and
+ * v_means2d_abs (nullable, absgrad) must be ZERO-FILLED by the caller; gradients are accumulated with
+ * atomics.  render (the forward output) is only read when ed_normalize is set.
  * tile_order[C*tile_h*tile_w] (nullable) is a permutation of the tile indices giving the order in
  * which tiles are dispatched (results do not depend on it); mtgs_tile_schedule fills it with the
  * tiles sorted by decreasing list length (no gsplat counterpart: a scheduling aid for the
@@ -154,16 +165,18 @@ int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int ti
 int mtgs_tile_schedule(int C, int tile_w, int tile_h, const int32_t *offsets, int64_t M,
                        int32_t *tile_order, void *stream);
 int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
-                   const float *colors, const float *opacities, const float *backgrounds, int width,
-                   int height, int tile_size, int tile_w, int tile_h, const int32_t *offsets,
-                   const int32_t *flatten_ids, int64_t M, float *render, float *alphas,
-                   int32_t *last_ids, const int32_t *tile_order, void *stream);
+                   const float *colors, const float *opacities, const float *backgrounds,
+                   const float *depths, int ed_normalize, int width, int height, int tile_size,
+                   int tile_w, int tile_h, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
+                   float *render, float *alphas, int32_t *last_ids, const int32_t *tile_order,
+                   void *stream);
 int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
-                   const float *colors, const float *opacities, const float *backgrounds, int width,
-                   int height, int tile_size, int tile_w, int tile_h, const int32_t *offsets,
-                   const int32_t *flatten_ids, int64_t M, const float *alphas,
-                   const int32_t *last_ids, const float *v_render, const float *v_alphas,
-                   float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
+                   const float *colors, const float *opacities, const float *backgrounds,
+                   const float *depths, int ed_normalize, int width, int height, int tile_size,
+                   int tile_w, int tile_h, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
+                   const float *alphas, const int32_t *last_ids, const float *render,
+                   const float *v_render, const float *v_alphas, float *v_means2d,
+                   float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
                    float *v_opacities, const int32_t *tile_order, void *stream);
 
 #ifdef __cplusplus

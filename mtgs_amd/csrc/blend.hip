@@ -71,6 +71,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                                            const float *__restrict__ means2d,
                                            const float *__restrict__ conics,
                                            const float *__restrict__ colors,
+                                           const float *__restrict__ depths, int DC,
                                            const float *__restrict__ opacities,
                                            const int32_t (&g)[CAND / NT], int64_t base, int n_cand,
                                            float tile_x0, float tile_y0) {
@@ -113,7 +114,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
             rec[0] = xy.x; rec[1] = xy.y; rec[2] = ca; rec[3] = cb; rec[4] = cc; rec[5] = op; rec[6] = s2max;
             rec[7] = __int_as_float((int32_t)(BWD ? base - k : base + k));
 #pragma unroll
-            for (int c = 0; c < D; ++c) rec[8 + c] = colors[(int64_t)g[r] * D + c];
+            for (int c = 0; c < D; ++c) rec[8 + c] = c < DC ? colors[(int64_t)g[r] * DC + c] : depths[g[r]];
 #pragma unroll
             for (int c = 8 + D; c < REC; ++c) rec[c] = 0.f;
             float4 *dst = reinterpret_cast<float4 *>(s_rec + slot * REC);
@@ -142,8 +143,8 @@ template <int D, int PPL>
 __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     int C, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
-    const float *__restrict__ backgrounds, int W, int H, int tw, int th,
-    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
+    const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
+    int tw, int th, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
     const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
@@ -189,8 +190,9 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, end - b0);
-        const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, means2d, conics, colors, opacities,
-                                                              g_cur, b0, n_cand, (float)(tx * 16), (float)(ty * 16));
+        const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, means2d, conics, colors, depths, DC,
+                                                              opacities, g_cur, b0, n_cand, (float)(tx * 16),
+                                                              (float)(ty * 16));
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (b0 + CAND + r * NT + tid < end) g_next[r] = flatten_ids[b0 + CAND + r * NT + tid];
@@ -242,11 +244,16 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     for (int p = 0; p < PPL; ++p) {
         if (inside[p]) {
             const int64_t pid = ((int64_t)cam * H + iy[p]) * W + ix;
-            alphas[pid] = 1.f - T[p];
+            const float alpha_out = 1.f - T[p];
+            alphas[pid] = alpha_out;
             last_ids[pid] = last[p];
 #pragma unroll
-            for (int k = 0; k < D; ++k)
-                render[pid * D + k] = backgrounds ? acc[p][k] + T[p] * backgrounds[cam * D + k] : acc[p][k];
+            for (int k = 0; k < D; ++k) {
+                float v = (backgrounds && k < DC) ? acc[p][k] + T[p] * backgrounds[cam * DC + k] : acc[p][k];
+                // expected depth ("ED"): accumulated depth / clamp(alpha, min=1e-10)  (gsplat rendering.py)
+                if (ed && k == D - 1) v = v / fmaxf(alpha_out, 1e-10f);
+                render[pid * D + k] = v;
+            }
         }
     }
 }
@@ -263,12 +270,12 @@ template <int D, int PPL>
 __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     int C, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
-    const float *__restrict__ backgrounds, int W, int H, int tw, int th,
-    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
-    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids,
+    const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
+    int tw, int th, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
+    const float *__restrict__ alphas, const int32_t *__restrict__ last_ids, const float *__restrict__ render,
     const float *__restrict__ v_render, const float *__restrict__ v_alphas,
     float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
-    float *__restrict__ v_colors, float *__restrict__ v_opacities,
+    float *__restrict__ v_colors, float *__restrict__ v_depths, float *__restrict__ v_opacities,
     const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     constexpr bool CULL = NT == 64;
@@ -297,7 +304,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         py[p] = (float)iy + 0.5f;
         const bool inside = ix < W && iy < H;
         const int64_t pid = ((int64_t)cam * H + (inside ? iy : 0)) * W + (inside ? ix : 0);
-        const float T_final = 1.f - alphas[pid];
+        const float alpha_out = alphas[pid];
+        const float T_final = 1.f - alpha_out;
         T[p] = T_final;
         bin_final[p] = inside ? last_ids[pid] : -1;
         my_max = max(my_max, bin_final[p]);
@@ -306,10 +314,17 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         for (int k = 0; k < D; ++k) {
             buf[p][k] = 0.f;
             vr[p][k] = v_render[pid * D + k];
-            if (backgrounds) bgd += backgrounds[cam * D + k] * vr[p][k];
+            if (backgrounds && k < DC) bgd += backgrounds[cam * DC + k] * vr[p][k];
+        }
+        float va = v_alphas[pid];
+        if (ed) {
+            // VJP of E = A / clamp(alpha, min=1e-10): v_A = v_E / clamp(alpha), v_alpha += -v_E E / alpha
+            const float vE = vr[p][D - 1];
+            vr[p][D - 1] = vE / fmaxf(alpha_out, 1e-10f);
+            if (alpha_out > 1e-10f) va += -vE * render[pid * D + D - 1] / alpha_out;
         }
         // d(alpha_out)/d(alpha_i) and the background term share the factor T_final / (1 - alpha_i)
-        Tf_va[p] = T_final * (v_alphas[pid] - bgd);
+        Tf_va[p] = T_final * (va - bgd);
     }
     // tile-wide newest contributor
     int32_t wmax = wave_max_i32(my_max);
@@ -333,7 +348,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride = 2; }
         else if (j < 7) { a_base = v_conics + (j - 4); a_stride = 3; }
         else if (j < 8) { a_base = v_opacities; a_stride = 1; }
-        else { a_base = v_colors + (j - 8); a_stride = D; }
+        else if (j - 8 < DC) { a_base = v_colors + (j - 8); a_stride = DC; }
+        else { a_base = v_depths; a_stride = 1; }
     }
 
     int32_t g_next[NRD];
@@ -345,8 +361,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < NRD; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, hi - start + 1);
-        const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, means2d, conics, colors, opacities, g_cur,
-                                                             hi, n_cand, (float)(tx * 16), (float)(ty * 16));
+        const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, means2d, conics, colors, depths, DC, opacities,
+                                                             g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16));
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
             if (hi - CAND - r * NT - tid >= start) g_next[r] = flatten_ids[hi - CAND - r * NT - tid];
@@ -417,29 +433,31 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
 
 template <int D, int PPL>
 int launch_fwd(int C, const float *means2d, const float *conics, const float *colors,
-               const float *opacities, const float *backgrounds, int W, int H, int tw, int th,
+               const float *opacities, const float *backgrounds, const float *depths, int DC, int ed, int W,
+               int H, int tw, int th,
                const int32_t *offsets, const int32_t *flatten_ids, int64_t M, float *render,
                float *alphas, int32_t *last_ids, const int32_t *order, hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
     blend_fwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(C, means2d, conics, colors, opacities,
-                                                         backgrounds, W, H, tw, th, offsets,
+                                                         backgrounds, depths, DC, ed, W, H, tw, th, offsets,
                                                          flatten_ids, M, render, alphas, last_ids, order);
     return 0;
 }
 
 template <int D, int PPL>
 int launch_bwd(int C, const float *means2d, const float *conics, const float *colors,
-               const float *opacities, const float *backgrounds, int W, int H, int tw, int th,
-               const int32_t *offsets, const int32_t *flatten_ids, int64_t M, const float *alphas,
-               const int32_t *last_ids, const float *v_render, const float *v_alphas,
-               float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
-               float *v_opacities, const int32_t *order, hipStream_t st) {
+               const float *opacities, const float *backgrounds, const float *depths, int DC, int ed, int W,
+               int H, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
+               const float *alphas, const int32_t *last_ids, const float *render, const float *v_render,
+               const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
+               float *v_depths, float *v_opacities, const int32_t *order, hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
     blend_bwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(
-        C, means2d, conics, colors, opacities, backgrounds, W, H, tw, th, offsets, flatten_ids, M,
-        alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, order);
+        C, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
+        alphas, last_ids, render, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_depths,
+        v_opacities, order);
     return 0;
 }
 
@@ -482,7 +500,7 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 }  // namespace
 
 #define MTGS_DISPATCH_D(FN, ...)                         \
-    switch (D) {                                         \
+    switch (DT) {                                        \
         case 1: FN<1, 4>(__VA_ARGS__); break;            \
         case 2: FN<2, 4>(__VA_ARGS__); break;            \
         case 3: FN<3, 4>(__VA_ARGS__); break;            \
@@ -497,48 +515,54 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 
 extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
                               const float *colors, const float *opacities, const float *backgrounds,
-                              int width, int height, int tile_size, int tile_w, int tile_h,
-                              const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
-                              float *render, float *alphas, int32_t *last_ids,
+                              const float *depths, int ed_normalize, int width, int height, int tile_size,
+                              int tile_w, int tile_h, const int32_t *offsets, const int32_t *flatten_ids,
+                              int64_t M, float *render, float *alphas, int32_t *last_ids,
                               const int32_t *tile_order, void *stream) {
-    MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_fwd: bad sizes");
+    MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_fwd: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_fwd: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
                  "mtgs_blend_fwd: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
-    MTGS_REQUIRE(supported_channels(D), MTGS_EUNSUPPORTED,
-                 "mtgs_blend_fwd: D=%d channels (supported: 1..8, 16, 32; pad on the host)", D);
+    const int DT = D + (depths ? 1 : 0);
+    MTGS_REQUIRE(supported_channels(DT), MTGS_EUNSUPPORTED,
+                 "mtgs_blend_fwd: D=%d channels in total (supported: 1..8, 16, 32; pad on the host)", DT);
+    MTGS_REQUIRE(!ed_normalize || depths, MTGS_EINVAL, "mtgs_blend_fwd: ed_normalize needs depths");
     if (C == 0) return MTGS_OK;
-    MTGS_REQUIRE(offsets && render && alphas && last_ids && (M == 0 || (means2d && conics && colors && opacities && flatten_ids)),
+    MTGS_REQUIRE(offsets && render && alphas && last_ids &&
+                     (M == 0 || (means2d && conics && (colors || D == 0) && opacities && flatten_ids)),
                  MTGS_EINVAL, "mtgs_blend_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    MTGS_DISPATCH_D(launch_fwd, C, means2d, conics, colors, opacities, backgrounds, width, height,
-                    tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, tile_order, st);
+    MTGS_DISPATCH_D(launch_fwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
+                    height, tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_fwd");
     return MTGS_OK;
 }
 
 extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
                               const float *colors, const float *opacities, const float *backgrounds,
-                              int width, int height, int tile_size, int tile_w, int tile_h,
-                              const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
-                              const float *alphas, const int32_t *last_ids, const float *v_render,
-                              const float *v_alphas, float *v_means2d, float *v_means2d_abs,
-                              float *v_conics, float *v_colors, float *v_opacities,
-                              const int32_t *tile_order, void *stream) {
-    MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd: bad sizes");
+                              const float *depths, int ed_normalize, int width, int height, int tile_size,
+                              int tile_w, int tile_h, const int32_t *offsets, const int32_t *flatten_ids,
+                              int64_t M, const float *alphas, const int32_t *last_ids, const float *render,
+                              const float *v_render, const float *v_alphas, float *v_means2d,
+                              float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
+                              float *v_opacities, const int32_t *tile_order, void *stream) {
+    MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_bwd: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
                  "mtgs_blend_bwd: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
-    MTGS_REQUIRE(supported_channels(D), MTGS_EUNSUPPORTED,
-                 "mtgs_blend_bwd: D=%d channels (supported: 1..8, 16, 32; pad on the host)", D);
+    const int DT = D + (depths ? 1 : 0);
+    MTGS_REQUIRE(supported_channels(DT), MTGS_EUNSUPPORTED,
+                 "mtgs_blend_bwd: D=%d channels in total (supported: 1..8, 16, 32; pad on the host)", DT);
+    MTGS_REQUIRE(!ed_normalize || (depths && render), MTGS_EINVAL, "mtgs_blend_bwd: ed_normalize needs depths and render");
     if (C == 0 || M == 0) return MTGS_OK;
-    MTGS_REQUIRE(means2d && conics && colors && opacities && offsets && flatten_ids && alphas &&
-                     last_ids && v_render && v_alphas && v_means2d && v_conics && v_colors && v_opacities,
+    MTGS_REQUIRE(means2d && conics && (colors || D == 0) && opacities && offsets && flatten_ids && alphas &&
+                     last_ids && v_render && v_alphas && v_means2d && v_conics && (v_colors || D == 0) &&
+                     (v_depths || !depths) && v_opacities,
                  MTGS_EINVAL, "mtgs_blend_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, width, height,
-                    tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, v_render, v_alphas,
-                    v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, tile_order, st);
+    MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
+                    height, tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, render, v_render, v_alphas,
+                    v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_bwd");
     return MTGS_OK;
 }

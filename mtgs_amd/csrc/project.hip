@@ -127,8 +127,9 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     int C, int64_t N, const float *__restrict__ means, const float *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ viewmats,
     const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane, float far_plane,
-    float radius_clip, int32_t *__restrict__ radii, float *__restrict__ means2d,
-    float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ compensations) {
+    float radius_clip, const float *__restrict__ opacities, int32_t *__restrict__ radii,
+    float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics,
+    float *__restrict__ compensations, float *__restrict__ opac_eff) {
     const int64_t idx = (int64_t)blockIdx.x * PROJ_BLOCK + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
     const int c = (int)(idx / N);
@@ -172,6 +173,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     depths[idx] = depth;
     conics[idx * 3] = ca; conics[idx * 3 + 1] = cb; conics[idx * 3 + 2] = cc;
     if (compensations) compensations[idx] = comp;
+    // gsplat rendering.py: opacities.repeat(C, 1) [* compensations]
+    if (opac_eff) opac_eff[idx] = r_out > 0 ? (compensations ? opacities[n] * comp : opacities[n]) : 0.f;
 }
 
 // Sum 12 values (v_R, v_t) over the block and add them to v_viewmats with one atomic per value
@@ -203,14 +206,16 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
     const float *__restrict__ scales, const float *__restrict__ viewmats,
     const float *__restrict__ Ks, int W, int H, float eps2d, const int32_t *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ compensations,
-    const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
-    const float *__restrict__ v_conics, const float *__restrict__ v_compensations,
+    const float *__restrict__ opacities, const float *__restrict__ v_means2d,
+    const float *__restrict__ v_depths, const float *__restrict__ v_conics,
+    const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff,
     float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
-    float *__restrict__ v_viewmats) {
+    float *__restrict__ v_viewmats, float *__restrict__ v_opacities) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     const int64_t n = (int64_t)blockIdx.x * PROJ_BLOCK + threadIdx.x;
     const bool live = n < N;
-    float am[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f};
+    float am[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f}, ao = 0.f;
+    const float opac = (live && v_opac_eff) ? opacities[n] : 0.f;
     float m[3] = {0.f, 0.f, 0.f}, sc[3] = {1.f, 1.f, 1.f};
     float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
     bool loaded = false;
@@ -235,8 +240,12 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
             float vcov[4];
             vcov[0] = -(t00 * a + t01 * b); vcov[1] = -(t00 * b + t01 * cc);
             vcov[2] = -(t10 * a + t11 * b); vcov[3] = -(t10 * b + t11 * cc);
-            if (v_compensations) {
-                const float comp = compensations[idx], vcomp = v_compensations[idx];
+            // opac_eff = opacity * compensation: the product rule feeds the compensation VJP
+            if (v_opac_eff) ao += v_opac_eff[idx] * (compensations ? compensations[idx] : 1.f);
+            if (compensations && (v_compensations || v_opac_eff)) {
+                const float comp = compensations[idx];
+                const float vcomp = (v_compensations ? v_compensations[idx] : 0.f) +
+                                    (v_opac_eff ? v_opac_eff[idx] * opac : 0.f);
                 const float det_conic = a * cc - b * b;
                 const float v_sqr = vcomp * 0.5f / (comp + kCompEps);
                 const float omc = 1.f - comp * comp;
@@ -335,6 +344,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
         v_means[n * 3] = am[0]; v_means[n * 3 + 1] = am[1]; v_means[n * 3 + 2] = am[2];
         reinterpret_cast<float4 *>(v_quats)[n] = make_float4(aq[0], aq[1], aq[2], aq[3]);
         v_scales[n * 3] = as[0]; v_scales[n * 3 + 1] = as[1]; v_scales[n * 3 + 2] = as[2];
+        if (v_opacities) v_opacities[n] = ao;
     }
 }
 
@@ -343,8 +353,9 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
 extern "C" int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats,
                                 const float *scales, const float *viewmats, const float *Ks,
                                 int width, int height, float eps2d, float near_plane, float far_plane,
-                                float radius_clip, int32_t *radii, float *means2d, float *depths,
-                                float *conics, float *compensations, void *stream) {
+                                float radius_clip, const float *opacities, int32_t *radii,
+                                float *means2d, float *depths, float *conics, float *compensations,
+                                float *opac_eff, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_fwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     if ((int64_t)C * N == 0) return MTGS_OK;
@@ -352,10 +363,11 @@ extern "C" int mtgs_project_fwd(int C, int64_t N, const float *means, const floa
                  MTGS_EINVAL, "mtgs_project_fwd: null pointer");
     MTGS_REQUIRE((int64_t)C * N < ((int64_t)1 << 31), MTGS_EINVAL,
                  "mtgs_project_fwd: C*N must fit int32 (flatten_ids are int32)");
+    MTGS_REQUIRE(!opac_eff || opacities, MTGS_EINVAL, "mtgs_project_fwd: opac_eff requested without opacities");
     const unsigned grid = (unsigned)ceil_div64((int64_t)C * N, PROJ_BLOCK);
     project_fwd_kernel<<<grid, PROJ_BLOCK, 0, (hipStream_t)stream>>>(
         C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-        radius_clip, radii, means2d, depths, conics, compensations);
+        radius_clip, opacities, radii, means2d, depths, conics, compensations, opac_eff);
     MTGS_CHECK_LAUNCH("mtgs_project_fwd");
     return MTGS_OK;
 }
@@ -363,10 +375,11 @@ extern "C" int mtgs_project_fwd(int C, int64_t N, const float *means, const floa
 extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats,
                                 const float *scales, const float *viewmats, const float *Ks,
                                 int width, int height, float eps2d, const int32_t *radii,
-                                const float *conics, const float *compensations,
+                                const float *conics, const float *compensations, const float *opacities,
                                 const float *v_means2d, const float *v_depths, const float *v_conics,
-                                const float *v_compensations, float *v_means, float *v_quats,
-                                float *v_scales, float *v_viewmats, void *stream) {
+                                const float *v_compensations, const float *v_opac_eff, float *v_means,
+                                float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities,
+                                void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -380,11 +393,14 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                  MTGS_EINVAL, "mtgs_project_bwd: null pointer");
     MTGS_REQUIRE(!v_compensations || compensations, MTGS_EINVAL,
                  "mtgs_project_bwd: v_compensations given without compensations");
+    MTGS_REQUIRE(!v_opac_eff || (opacities && v_opacities), MTGS_EINVAL,
+                 "mtgs_project_bwd: v_opac_eff needs opacities and v_opacities");
     const unsigned grid = (unsigned)ceil_div64(N, PROJ_BLOCK);
     project_bwd_kernel<<<grid, PROJ_BLOCK, 0, st>>>(C, N, means, quats, scales, viewmats, Ks, width,
-                                                    height, eps2d, radii, conics, compensations,
+                                                    height, eps2d, radii, conics, compensations, opacities,
                                                     v_means2d, v_depths, v_conics, v_compensations,
-                                                    v_means, v_quats, v_scales, v_viewmats);
+                                                    v_opac_eff, v_means, v_quats, v_scales, v_viewmats,
+                                                    v_opacities);
     MTGS_CHECK_LAUNCH("mtgs_project_bwd");
     return MTGS_OK;
 }

@@ -15,8 +15,8 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
-from .wrapper import (MAX_CHANNELS, fully_fused_projection, isect_offset_encode, isect_tiles,
-                      rasterize_to_pixels, spherical_harmonics)
+from .wrapper import (MAX_CHANNELS, isect_offset_encode, isect_tiles, projection_with_opacities,
+                      rasterize_to_pixels, rasterize_to_pixels_with_depth, spherical_harmonics)
 
 
 def rasterization(
@@ -87,15 +87,11 @@ def rasterization(
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
 
-    # (1) projection
-    radii, means2d, depths, conics, compensations = fully_fused_projection(
-        means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,
-        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
-        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model)
-    opacities = opacities.repeat(C, 1)  # [C, N]
+    # (1) projection, fused with `opacities.repeat(C, 1) [* compensations]`
+    radii, means2d, depths, conics, compensations, opacities = projection_with_opacities(
+        means, quats, scales, viewmats, Ks, opacities, width, height, eps2d=eps2d, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, calc_compensations=(rasterize_mode == "antialiased"))
     camera_ids, gaussian_ids = None, None
-    if compensations is not None:
-        opacities = opacities * compensations
 
     meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii,
                  "means2d": means2d, "depths": depths, "conics": conics, "opacities": opacities})
@@ -112,17 +108,7 @@ def rasterization(
         colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3]
         colors = torch.clamp_min(colors + 0.5, 0.0)
 
-    # (3) depth channel
-    if render_mode in ["RGB+D", "RGB+ED"]:
-        colors = torch.cat((colors, depths[..., None]), dim=-1)
-        if backgrounds is not None:
-            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
-    elif render_mode in ["D", "ED"]:
-        colors = depths[..., None]
-        if backgrounds is not None:
-            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
-
-    # (4) tile binning
+    # (3) tile binning
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
@@ -135,9 +121,29 @@ def rasterization(
                  "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width,
                  "height": height, "tile_size": tile_size, "n_cameras": C})
 
-    # (5) compositing, in channel chunks when there are many channels
+    # (4) compositing.  The depth channel of the "+D"/"+ED"/"D"/"ED" modes and the expected-depth
+    # normalisation are blended in the same pass (gsplat: torch.cat + rasterize_to_pixels + division).
+    with_depth = render_mode in ["RGB+D", "RGB+ED", "D", "ED"]
+    expected = render_mode in ["ED", "RGB+ED"]
+    if render_mode in ["D", "ED"]:
+        colors, backgrounds = None, None  # gsplat: colors = depths[..., None], backgrounds = zeros
+    n_channels = (0 if colors is None else colors.shape[-1]) + int(with_depth)
     chunk = min(channel_chunk, MAX_CHANNELS)
-    if colors.shape[-1] > chunk:
+    if n_channels <= chunk:
+        if with_depth:
+            render_colors, render_alphas = rasterize_to_pixels_with_depth(
+                means2d, conics, colors, opacities, depths, expected, width, height, tile_size, isect_offsets,
+                flatten_ids, backgrounds=backgrounds, absgrad=absgrad)
+        else:
+            render_colors, render_alphas = rasterize_to_pixels(
+                means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+                backgrounds=backgrounds, packed=False, absgrad=absgrad)
+    else:
+        # many channels: gsplat's own composition, in channel chunks
+        if with_depth:
+            colors = torch.cat((colors, depths[..., None]), dim=-1)
+            if backgrounds is not None:
+                backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
         n_chunks = (colors.shape[-1] + chunk - 1) // chunk
         render_colors, render_alphas = [], []
         for i in range(n_chunks):
@@ -150,14 +156,8 @@ def rasterization(
             render_alphas.append(ra)
         render_colors = torch.cat(render_colors, dim=-1)
         render_alphas = render_alphas[0]
-    else:
-        render_colors, render_alphas = rasterize_to_pixels(
-            means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds, packed=False, absgrad=absgrad)
-
-    # (6) expected depth
-    if render_mode in ["ED", "RGB+ED"]:
-        render_colors = torch.cat(
-            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+        if expected:
+            render_colors = torch.cat(
+                [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
 
     return render_colors, render_alphas, meta

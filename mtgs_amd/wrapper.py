@@ -78,11 +78,14 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 
 # ------------------------------------------------------------------------------------- projection
 class _FullyFusedProjection(torch.autograd.Function):
+    """fully_fused_projection, optionally fused with gsplat's `opacities.repeat(C,1) * compensations`
+    (pass `opacities`; the sixth output is then the effective per-camera opacity)."""
+
     @staticmethod
-    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-                radius_clip, calc_compensations):
-        require_gpu(means, quats, scales, viewmats, Ks)
-        means, quats, scales, viewmats, Ks = map(_f32c, (means, quats, scales, viewmats, Ks))
+    def forward(ctx, means, quats, scales, viewmats, Ks, opacities, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations):
+        require_gpu(means, quats, scales, viewmats, Ks, opacities)
+        means, quats, scales, viewmats, Ks, opacities = map(_f32c, (means, quats, scales, viewmats, Ks, opacities))
         N, Cn = means.shape[0], viewmats.shape[0]
         dev = means.device
         radii = torch.empty((Cn, N), dtype=torch.int32, device=dev)
@@ -90,17 +93,18 @@ class _FullyFusedProjection(torch.autograd.Function):
         depths = torch.empty((Cn, N), dtype=torch.float32, device=dev)
         conics = torch.empty((Cn, N, 3), dtype=torch.float32, device=dev)
         comps = torch.empty((Cn, N), dtype=torch.float32, device=dev) if calc_compensations else None
+        opac_eff = torch.empty((Cn, N), dtype=torch.float32, device=dev) if opacities is not None else None
         call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
-             width, height, eps2d, near_plane, far_plane, radius_clip, ptr(radii), ptr(means2d),
-             ptr(depths), ptr(conics), ptr(comps), stream_of(means))
-        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics, comps)
+             width, height, eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(radii),
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), stream_of(means))
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics, comps, opacities)
         ctx.width, ctx.height, ctx.eps2d = width, height, eps2d
         ctx.mark_non_differentiable(radii)
-        return radii, means2d, depths, conics, comps
+        return radii, means2d, depths, conics, comps, opac_eff
 
     @staticmethod
-    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_comps):
-        means, quats, scales, viewmats, Ks, radii, conics, comps = ctx.saved_tensors
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_comps, v_opac_eff):
+        means, quats, scales, viewmats, Ks, radii, conics, comps, opacities = ctx.saved_tensors
         N, Cn = means.shape[0], viewmats.shape[0]
         dev = means.device
         zeros = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
@@ -108,27 +112,22 @@ class _FullyFusedProjection(torch.autograd.Function):
         v_depths = zeros(Cn, N) if v_depths is None else _f32c(v_depths)
         v_conics = zeros(Cn, N, 3) if v_conics is None else _f32c(v_conics)
         v_comps = None if (comps is None or v_comps is None) else _f32c(v_comps)
+        v_opac_eff = None if (opacities is None or v_opac_eff is None) else _f32c(v_opac_eff)
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
         v_scales = torch.empty_like(scales)
         v_viewmats = torch.empty_like(viewmats) if ctx.needs_input_grad[3] else None
+        v_opacities = torch.empty_like(opacities) if v_opac_eff is not None else None
         call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
-             ctx.width, ctx.height, ctx.eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(v_means2d),
-             ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_means), ptr(v_quats), ptr(v_scales),
-             ptr(v_viewmats), stream_of(means))
+             ctx.width, ctx.height, ctx.eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities),
+             ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
+             ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities), stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
-                v_viewmats, None, None, None, None, None, None, None, None)
+                v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
 
 
-def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor],
-                           scales: Optional[Tensor], viewmats: Tensor, Ks: Tensor, width: int,
-                           height: int, eps2d: float = 0.3, near_plane: float = 0.01,
-                           far_plane: float = 1e10, radius_clip: float = 0.0, packed: bool = False,
-                           sparse_grad: bool = False, calc_compensations: bool = False,
-                           camera_model: str = "pinhole"):
-    """gsplat.cuda._wrapper.fully_fused_projection (packed=False, pinhole).
-    Returns (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N] | None)."""
+def _check_projection_args(means, covars, quats, scales, viewmats, Ks, packed, sparse_grad, camera_model):
     Cn, N = viewmats.size(0), means.size(0)
     assert means.size() == (N, 3), means.size()
     assert viewmats.size() == (Cn, 4, 4), viewmats.size()
@@ -144,7 +143,30 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
     assert quats is not None and scales is not None, "quats and scales are required"
     assert quats.size() == (N, 4), quats.size()
     assert scales.size() == (N, 3), scales.size()
-    return _FullyFusedProjection.apply(means, quats, scales, viewmats, Ks, int(width), int(height),
+
+
+def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor],
+                           scales: Optional[Tensor], viewmats: Tensor, Ks: Tensor, width: int,
+                           height: int, eps2d: float = 0.3, near_plane: float = 0.01,
+                           far_plane: float = 1e10, radius_clip: float = 0.0, packed: bool = False,
+                           sparse_grad: bool = False, calc_compensations: bool = False,
+                           camera_model: str = "pinhole"):
+    """gsplat.cuda._wrapper.fully_fused_projection (packed=False, pinhole).
+    Returns (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N] | None)."""
+    _check_projection_args(means, covars, quats, scales, viewmats, Ks, packed, sparse_grad, camera_model)
+    return _FullyFusedProjection.apply(means, quats, scales, viewmats, Ks, None, int(width), int(height),
+                                       float(eps2d), float(near_plane), float(far_plane),
+                                       float(radius_clip), bool(calc_compensations))[:5]
+
+
+def projection_with_opacities(means, quats, scales, viewmats, Ks, opacities, width, height, eps2d=0.3,
+                              near_plane=0.01, far_plane=1e10, radius_clip=0.0, calc_compensations=False):
+    """fully_fused_projection + `opacities.repeat(C,1) [* compensations]` in one kernel (what
+    gsplat.rendering.rasterization does right after the projection).  Returns the five projection
+    outputs and opacities_eff[C,N]."""
+    _check_projection_args(means, None, quats, scales, viewmats, Ks, False, False, "pinhole")
+    assert opacities.shape == (means.shape[0],), opacities.shape
+    return _FullyFusedProjection.apply(means, quats, scales, viewmats, Ks, opacities, int(width), int(height),
                                        float(eps2d), float(near_plane), float(far_plane),
                                        float(radius_clip), bool(calc_compensations))
 
@@ -244,53 +266,79 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 
 # ------------------------------------------------------------------------------------- compositing
 class _RasterizeToPixels(torch.autograd.Function):
+    """rasterize_to_pixels, optionally fused with the depth channel (`depths` blended as the last
+    channel instead of torch.cat) and the expected-depth normalisation (`ed`) that gsplat's
+    rasterization() applies around it."""
+
     @staticmethod
-    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size,
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, depths, ed, width, height, tile_size,
                 isect_offsets, flatten_ids, absgrad):
-        require_gpu(means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids)
-        m2d, con, col, opa, bg = map(_f32c, (means2d, conics, colors, opacities, backgrounds))
+        require_gpu(means2d, conics, colors, opacities, backgrounds, depths, isect_offsets, flatten_ids)
+        m2d, con, col, opa, bg, dep = map(_f32c, (means2d, conics, colors, opacities, backgrounds, depths))
         isect_offsets, flatten_ids = isect_offsets.contiguous(), flatten_ids.contiguous()
-        Cn, N, D = col.shape
+        Cn, N = m2d.shape[:2]
+        DC = 0 if col is None else col.shape[-1]
+        DT = DC + (1 if dep is not None else 0)
         th, tw = isect_offsets.shape[1:]
         dev = m2d.device
-        render = torch.empty((Cn, height, width, D), dtype=torch.float32, device=dev)
+        render = torch.empty((Cn, height, width, DT), dtype=torch.float32, device=dev)
         alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
         M = flatten_ids.numel()
         # longest-list-first dispatch order of the tiles (scheduling aid, does not change results)
         order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
         call("mtgs_tile_schedule", Cn, tw, th, ptr(isect_offsets), M, ptr(order), stream_of(m2d))
-        call("mtgs_blend_fwd", Cn, N, D, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), width,
-             height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), M, ptr(render),
+        call("mtgs_blend_fwd", Cn, N, DC, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), ptr(dep), int(ed),
+             width, height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), M, ptr(render),
              ptr(alphas), ptr(last_ids), ptr(order), stream_of(m2d))
-        ctx.save_for_backward(m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids, order)
-        ctx.dims = (width, height, tile_size, tw, th)
+        ctx.save_for_backward(m2d, con, col, opa, bg, dep, isect_offsets, flatten_ids, alphas, last_ids, order,
+                              render if ed else None)
+        ctx.dims = (width, height, tile_size, tw, th, DC, bool(ed))
         ctx.absgrad = absgrad
         ctx.means2d_ref = means2d  # the tensor MTGS calls .retain_grad() on; .absgrad is set on it
         return render, alphas
 
     @staticmethod
     def backward(ctx, v_render, v_alphas):
-        m2d, con, col, opa, bg, isect_offsets, flatten_ids, alphas, last_ids, order = ctx.saved_tensors
-        width, height, tile_size, tw, th = ctx.dims
-        Cn, N, D = col.shape
-        dev = m2d.device
+        (m2d, con, col, opa, bg, dep, isect_offsets, flatten_ids, alphas, last_ids, order,
+         render) = ctx.saved_tensors
+        width, height, tile_size, tw, th, DC, ed = ctx.dims
+        Cn, N = m2d.shape[:2]
+        CN = Cn * N
         v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
-        v_means2d = torch.zeros_like(m2d)
-        v_conics = torch.zeros_like(con)
-        v_colors = torch.zeros_like(col)
-        v_opacities = torch.zeros_like(opa)
-        v_abs = torch.zeros_like(m2d) if ctx.absgrad else None
-        call("mtgs_blend_bwd", Cn, N, D, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), width,
-             height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), flatten_ids.numel(),
-             ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs),
-             ptr(v_conics), ptr(v_colors), ptr(v_opacities), ptr(order), stream_of(m2d))
+        # one zero-filled buffer for every atomically accumulated gradient (a single fill kernel)
+        sizes = [2 * CN, 3 * CN, CN, DC * CN, CN if dep is not None else 0, 2 * CN if ctx.absgrad else 0]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=m2d.device)
+        parts = torch.split(flat, sizes)
+        v_means2d, v_conics, v_opacities = parts[0].view(Cn, N, 2), parts[1].view(Cn, N, 3), parts[2].view(Cn, N)
+        v_colors = parts[3].view(Cn, N, DC) if DC else None
+        v_depths = parts[4].view(Cn, N) if dep is not None else None
+        v_abs = parts[5].view(Cn, N, 2) if ctx.absgrad else None
+        call("mtgs_blend_bwd", Cn, N, DC, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), ptr(dep), int(ed),
+             width, height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), flatten_ids.numel(),
+             ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs),
+             ptr(v_conics), ptr(v_colors), ptr(v_depths), ptr(v_opacities), ptr(order), stream_of(m2d))
         if ctx.absgrad:
             ctx.means2d_ref.absgrad = v_abs
         v_bg = None
         if bg is not None and ctx.needs_input_grad[4]:
-            v_bg = (v_render * (1.0 - alphas)).sum(dim=(1, 2))
-        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None)
+            v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
+        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, v_depths, None, None, None, None, None, None, None)
+
+
+def _pad_channels(colors: Optional[Tensor], backgrounds: Optional[Tensor], extra: int):
+    """Zero-pads the colour channels so that colours + `extra` fused channels is a supported count."""
+    channels = 0 if colors is None else colors.shape[-1]
+    total = channels + extra
+    if total > MAX_CHANNELS:
+        raise ValueError(f"rasterize_to_pixels: {total} channels > {MAX_CHANNELS}; chunk on the caller side")
+    pad = next(d for d in SUPPORTED_CHANNELS if d >= total) - total
+    if pad:
+        Cn, N = colors.shape[:2]
+        colors = torch.cat([colors, colors.new_zeros(Cn, N, pad)], dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, backgrounds.new_zeros(Cn, pad)], dim=-1)
+    return colors, backgrounds, channels, pad
 
 
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
@@ -300,6 +348,40 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
                         absgrad: bool = False) -> Tuple[Tensor, Tensor]:
     """gsplat.cuda._wrapper.rasterize_to_pixels (packed=False) ->
     (render_colors[C,H,W,D], render_alphas[C,H,W,1])."""
+    _check_raster_args(means2d, conics, colors, opacities, backgrounds, masks, packed, tile_size, isect_offsets,
+                       image_width, image_height)
+    colors, backgrounds, channels, pad = _pad_channels(colors, backgrounds, 0)
+    render, alphas = _RasterizeToPixels.apply(means2d, conics, colors, opacities, backgrounds, None, False,
+                                              int(image_width), int(image_height), int(tile_size),
+                                              isect_offsets, flatten_ids, bool(absgrad))
+    if pad:
+        render = render[..., :channels]
+    return render, alphas
+
+
+def rasterize_to_pixels_with_depth(means2d: Tensor, conics: Tensor, colors: Optional[Tensor], opacities: Tensor,
+                                   depths: Tensor, expected_depth: bool, image_width: int, image_height: int,
+                                   tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
+                                   backgrounds: Optional[Tensor] = None, absgrad: bool = False):
+    """rasterize_to_pixels with the depth channel of the "RGB+D" / "RGB+ED" / "D" / "ED" render modes
+    blended in the same pass (last output channel; divided by clamp(alpha, 1e-10) for expected depth)
+    -- what gsplat.rendering.rasterization composes from torch.cat + rasterize_to_pixels + a division."""
+    if colors is not None:
+        _check_raster_args(means2d, conics, colors, opacities, backgrounds, None, False, tile_size, isect_offsets,
+                           image_width, image_height)
+        colors, backgrounds, channels, pad = _pad_channels(colors, backgrounds, 1)
+    else:
+        channels, pad, backgrounds = 0, 0, None
+    render, alphas = _RasterizeToPixels.apply(means2d, conics, colors, opacities, backgrounds, depths,
+                                              bool(expected_depth), int(image_width), int(image_height),
+                                              int(tile_size), isect_offsets, flatten_ids, bool(absgrad))
+    if pad:
+        render = torch.cat([render[..., :channels], render[..., -1:]], dim=-1)
+    return render, alphas
+
+
+def _check_raster_args(means2d, conics, colors, opacities, backgrounds, masks, packed, tile_size, isect_offsets,
+                       image_width, image_height):
     if packed:
         raise NotImplementedError("rasterize_to_pixels: packed=True")
     if masks is not None:
@@ -315,17 +397,3 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
         assert backgrounds.shape == (Cn, colors.shape[-1]), backgrounds.shape
     th, tw = isect_offsets.shape[1:]
     assert tw * tile_size >= image_width and th * tile_size >= image_height
-    channels = colors.shape[-1]
-    if channels > MAX_CHANNELS:
-        raise ValueError(f"rasterize_to_pixels: {channels} channels > {MAX_CHANNELS}; chunk on the caller side")
-    pad = next(d for d in SUPPORTED_CHANNELS if d >= channels) - channels
-    if pad:
-        colors = torch.cat([colors, colors.new_zeros(Cn, N, pad)], dim=-1)
-        if backgrounds is not None:
-            backgrounds = torch.cat([backgrounds, backgrounds.new_zeros(Cn, pad)], dim=-1)
-    render, alphas = _RasterizeToPixels.apply(means2d, conics, colors, opacities, backgrounds,
-                                              int(image_width), int(image_height), int(tile_size),
-                                              isect_offsets, flatten_ids, bool(absgrad))
-    if pad:
-        render = render[..., :channels]
-    return render, alphas

@@ -78,32 +78,34 @@ def main():
     opac = d["opacities"][None].contiguous()
     if mtgs:
         opac = (opac * comps).contiguous()
-        cols = torch.cat([colors[None], depths[..., None]], -1).contiguous()
-    else:
-        cols = colors[None].contiguous()
-    D = cols.shape[-1]
+    cols = colors[None].contiguous()
+    DC = cols.shape[-1]
+    dep = depths if mtgs else None
+    D = DC + (1 if mtgs else 0)
+    ed = 1 if mtgs else 0
     render = torch.empty(1, H, W, D, device=dev); alphas = torch.empty(1, H, W, 1, device=dev)
     last = torch.empty(1, H, W, dtype=torch.int32, device=dev)
     import os
     order = torch.empty(tw * th, dtype=torch.int32, device=dev)
     res["tile_schedule"] = timeit(lambda: call("mtgs_tile_schedule", 1, tw, th, ptr(off), M, ptr(order), st), args.reps)
     optr = None if os.environ.get("NO_ORDER") else ptr(order)
-    fwd = lambda: call("mtgs_blend_fwd", 1, N, D, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, W, H, 16, tw, th,
-                       ptr(off), ptr(flat), M, ptr(render), ptr(alphas), ptr(last), optr, st)
+    fwd = lambda: call("mtgs_blend_fwd", 1, N, DC, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, ptr(dep), ed,
+                       W, H, 16, tw, th, ptr(off), ptr(flat), M, ptr(render), ptr(alphas), ptr(last), optr, st)
     res["blend_fwd"] = timeit(fwd, args.reps)
     g = torch.Generator(device="cpu").manual_seed(1)
     vr = torch.randn(1, H, W, D, generator=g).to(dev); va = torch.randn(1, H, W, 1, generator=g).to(dev)
     v2d = torch.zeros_like(means2d); vab = torch.zeros_like(means2d) if mtgs else None
     vcon = torch.zeros_like(conics); vcl = torch.zeros_like(cols); vop = torch.zeros_like(opac)
-    bwd = lambda: call("mtgs_blend_bwd", 1, N, D, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, W, H, 16, tw, th,
-                       ptr(off), ptr(flat), M, ptr(alphas), ptr(last), ptr(vr), ptr(va), ptr(v2d), ptr(vab), ptr(vcon),
-                       ptr(vcl), ptr(vop), optr, st)
+    vdp = torch.zeros_like(depths) if mtgs else None
+    bwd = lambda: call("mtgs_blend_bwd", 1, N, DC, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, ptr(dep), ed,
+                       W, H, 16, tw, th, ptr(off), ptr(flat), M, ptr(alphas), ptr(last), ptr(render), ptr(vr), ptr(va),
+                       ptr(v2d), ptr(vab), ptr(vcon), ptr(vcl), ptr(vdp), ptr(vop), optr, st)
     res["blend_bwd"] = timeit(bwd, args.reps)
     vm_ = torch.empty_like(d["means"]); vq = torch.empty_like(d["quats"]); vs = torch.empty_like(d["scales"]); vvm = torch.empty_like(vm)
-    vdep = torch.randn_like(depths)
+    vdep = torch.randn_like(depths); vopn = torch.empty_like(d["opacities"])
     res["project_bwd"] = timeit(lambda: call("mtgs_project_bwd", 1, N, ptr(d["means"]), ptr(d["quats"]), ptr(d["scales"]), ptr(vm), ptr(K), W, H, 0.3,
-                                              ptr(radii), ptr(conics), ptr(comps), ptr(v2d), ptr(vdep), ptr(vcon), ptr(vop) if mtgs else None,
-                                              ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), st), args.reps)
+                                              ptr(radii), ptr(conics), ptr(comps), ptr(d["opacities"]), ptr(v2d), ptr(vdep), ptr(vcon), None,
+                                              ptr(vop), ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), ptr(vopn), st), args.reps)
     n_vis = int((radii > 0).sum())
     print(f"N={N} {W}x{H} variant={args.variant} n_vis={n_vis} M={M} D={D}")
     tot = 0.0
