@@ -1,0 +1,146 @@
+"""Parity at BASELINE.json's sizes (WB-v1 scenes): the oracle still finishes in seconds on the GPU
+box's host cores, so the HIP path is compared with it DIRECTLY at full size, plus the
+size-independent properties of the domain (sortedness, offsets, alpha range, absgrad >= |grad|,
+determinism of the integer stages, linearity of the backward in the cotangent)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from mtgs_amd.synthetic import make_camera, make_scene
+from tests.util import assert_image_close
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+@pytest.fixture(scope="module")
+def gs(hip_lib):
+    assert torch.cuda.is_available()
+    import mtgs_amd
+    return mtgs_amd
+
+
+def test_config1_100k_640x480_forward(gs, oracle):
+    """BASELINE configs[0]: 100k Gaussians, 640x480, SH degree 0 (colours given), forward only."""
+    N, W, H = 100_000, 640, 480
+    sc = make_scene(N, seed=0)
+    vm, K = make_camera(W, H)
+    a = {k: v.numpy() for k, v in sc.items()}
+    r_ref, a_ref, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], vm.numpy(),
+                                           K.numpy(), W, H)
+    render, alpha, info = gs.rasterization(dev(sc["means"]), dev(sc["quats"]), dev(sc["scales"]), dev(sc["opacities"]),
+                                           dev(sc["colors"]), dev(vm), dev(K), W, H, packed=False)
+    for key in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(info[key].cpu().numpy(), m[key]), key
+    for key in ("means2d", "depths", "conics"):
+        assert np.array_equal(info[key].cpu().numpy(), m[key]), key
+    assert_image_close(render.cpu().numpy(), r_ref, m["critical"], name="render")
+    assert_image_close(alpha.cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0)
+
+
+@pytest.mark.parametrize("N,sh", [(500_000, True), (2_000_000, False)])
+def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
+    """BASELINE configs[1] (500k, SH degree 3) and configs[2] (2M), 1920x1080, MTGS options
+    (RGB+ED, antialiased, absgrad, viewmat gradient), forward + backward, compared directly."""
+    W, H = 1920, 1080
+    sc = make_scene(N, seed=0, sh_degree=3 if sh else None)
+    vm, K = make_camera(W, H)
+    a = {k: v.numpy() for k, v in sc.items()}
+    g = torch.Generator().manual_seed(1)
+    Gc = torch.randn(1, H, W, 4, generator=g)
+    Ga = torch.randn(1, H, W, 1, generator=g)
+    P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
+    vmd = dev(vm).requires_grad_(True)
+    if sh:
+        cam_pos = torch.inverse(vm)[0, :3, 3]
+        dirs = a["means"] - cam_pos.numpy()
+        rgb_ref = np.clip(oracle.sh_fwd(3, dirs, a["coeffs"]) + 0.5, 0.0, 1.0)
+        rgb = torch.clamp(gs.spherical_harmonics(3, P["means"].detach() - dev(cam_pos), P["coeffs"]) + 0.5, 0.0, 1.0)
+        np.testing.assert_allclose(rgb.detach().cpu().numpy(), rgb_ref, atol=5e-6)
+    else:
+        rgb_ref, rgb = a["colors"], P["colors"]
+    r_ref, a_ref, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], rgb_ref, vm.numpy(),
+                                           K.numpy(), W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+    render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vmd, dev(K), W, H,
+                                           packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+    info["means2d"].retain_grad()
+    # ---- integer stages and the projection are bit-exact at full size
+    for key in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(info[key].cpu().numpy(), m[key]), key
+    for key in ("means2d", "depths", "conics"):
+        assert np.array_equal(info[key].detach().cpu().numpy(), m[key]), key
+    # ---- structural properties
+    ids = info["isect_ids"]
+    assert bool((ids[1:] >= ids[:-1]).all()), "isect_ids not sorted"
+    off = info["isect_offsets"].flatten()
+    assert bool((off[1:] >= off[:-1]).all()) and int(off[-1]) <= ids.numel()
+    assert float(alpha.detach().min()) >= 0.0 and float(alpha.detach().max()) < 1.0
+    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render")
+    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0)
+    # ---- backward against the oracle
+    torch.autograd.backward([render, alpha], [dev(Gc), dev(Ga)])
+    Gc_n, Ga_n = Gc.numpy(), Ga.numpy()
+    alc = np.maximum(a_ref, 1e-10)
+    Gc_raw = Gc_n.copy()
+    Gc_raw[..., -1:] = Gc_n[..., -1:] / alc
+    Ga_tot = Ga_n - (m["render_raw"][..., -1:] / alc ** 2) * Gc_n[..., -1:] * (a_ref > 1e-10)
+    v2d, vabs, vcon, vcol, vop = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                  m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw, Ga_tot)
+    r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3,
+                                                 m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
+                                                 vcon, vop * a["opacities"][None])
+
+    def close(name, got, ref, rel=2e-3):
+        got = got.detach().cpu().numpy()
+        err, scale = np.abs(got - ref).max(), np.abs(ref).max()
+        assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+    close("means2d.grad", info["means2d"].grad, v2d)
+    close("means2d.absgrad", info["means2d"].absgrad, vabs)
+    assert bool((info["means2d"].absgrad >= info["means2d"].grad.abs() - 1e-5).all())
+    close("v_means", P["means"].grad, r_vm)
+    close("v_quats", P["quats"].grad, r_vq)
+    close("v_scales", P["scales"].grad, r_vs)
+    close("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0))
+    close("v_viewmats", vmd.grad[0], r_vvm[0])
+    if sh:
+        mask = (rgb_ref > 0.0) & (rgb_ref < 1.0)
+        ref_vc, _ = oracle.sh_bwd(3, dirs, a["coeffs"], vcol[0, :, :3] * mask)
+        close("v_coeffs", P["coeffs"].grad, ref_vc)
+    else:
+        close("v_colors", P["colors"].grad, vcol[0, :, :3])
+
+
+def test_fullsize_properties_linearity_and_determinism(gs):
+    """Size-independent properties at configs[2] size: the backward is linear in the cotangent, the
+    integer stages are deterministic, culled Gaussians get exactly zero gradient."""
+    N, W, H = 2_000_000, 1920, 1080
+    sc = make_scene(N, seed=0)
+    vm, K = make_camera(W, H)
+    P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
+    g = torch.Generator().manual_seed(3)
+    G1, G2 = dev(torch.randn(1, H, W, 3, generator=g)), dev(torch.randn(1, H, W, 3, generator=g))
+
+    def run(Gc):
+        for p in P.values():
+            p.grad = None
+        render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], dev(vm),
+                                               dev(K), W, H, packed=False)
+        torch.autograd.backward([render], [Gc])
+        return {k: p.grad.clone() for k, p in P.items()}, info, render
+
+    g1, info1, r1 = run(G1)
+    g2, info2, r2 = run(G2)
+    g12, _, _ = run(G1 + 2.0 * G2)
+    assert torch.equal(info1["flatten_ids"], info2["flatten_ids"]) and torch.equal(info1["isect_ids"], info2["isect_ids"])
+    assert torch.equal(r1, r2), "forward is not deterministic"
+    for k in P:
+        ref = g1[k] + 2.0 * g2[k]
+        assert float((g12[k] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), k
+    culled = info1["radii"][0] == 0
+    assert float(g1["means"][culled].abs().max()) == 0.0 and float(g1["colors"][culled].abs().max()) == 0.0
