@@ -18,8 +18,11 @@ OBJ = CSRC / "_obj"
 LIB = PKG / "libmtgs_rast.so"
 ARCH = "gfx950"
 
+# -fno-slp-vectorize: on gfx950 v_pk_{fma,mul,add}_f32 issue in two passes (no throughput gain for
+# fp32) but the SLP vectoriser pays v_mov shuffles to pair their operands -- measured -19 % time on
+# the compositing backward without it.
 COMMON_FLAGS = [
-    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", f"-I{PKG.parent / 'include'}",
 ]
 # The projection forward must round after every operation (bit-exact tile binning inputs).
