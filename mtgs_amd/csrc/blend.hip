@@ -21,12 +21,15 @@
 //  * 1/(1-alpha) is v_rcp_f32 and exp is v_exp_f32 (the reference is built with --use_fast_math).
 //  * Tiles are dispatched longest-list-first (mtgs_tile_schedule): 8160 single-wave workgroups over
 //    1024 SIMDs leave a long tail otherwise.
-//  * Wide channel counts (D > 8) fall back to 1 pixel per lane / 4 waves per tile.
+//  * Small images (fewer than ~6000 tiles; MTGS trains at 960x540 = 2040 tiles) cannot fill the chip
+//    with one wave per tile: they run 2 or 4 waves per tile (2 / 1 pixels per lane), same code.
+//    Wide channel counts (D > 8) always use 1 pixel per lane.
 //
 // Roofline: the kernels are VALU bound (about 25 / 70 flops per pixel x Gaussian pair, fwd / bwd)
 // -- MFMA is deliberately unused, there is no dense contraction.  Algorithmic HBM bytes:
 //   fwd: M*(4 + 24 + 4D) gathered attributes + P*(4D + 8) written
 //   bwd: P*(4D + 12) read + M*(4 + 24 + 4D) gathered + N_vis*(24 + 4D (+8 absgrad)) accumulated
+#include <stdlib.h>
 #include "common.hpp"
 #include "wave_reduce.hpp"
 
@@ -64,10 +67,11 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount 
 // per-pixel loop never sees it.  The binning stage itself keeps gsplat's conservative 3-sigma
 // squares, so isect_ids / flatten_ids / offsets stay bit-identical to the reference.
 //   FWD: candidate k of the batch is sorted index base + k;  BWD: base - k (back to front).
-// Returns the number of survivors (wave-uniform).  Single-wave workgroups only (CULL) -- the
-// 4-waves-per-tile fallback stages one candidate per thread without culling.
+// Returns the number of survivors (uniform over the workgroup).  With more than one wave per tile
+// the per-wave ballots are chained through a small LDS array (two workgroup barriers per round).
 template <int D, int NT, int CAND, bool BWD, bool CULL>
 __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *__restrict__ s_id,
+                                           int *__restrict__ s_wc,
                                            const float *__restrict__ means2d,
                                            const float *__restrict__ conics,
                                            const float *__restrict__ colors,
@@ -106,8 +110,24 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
         int slot = k;
         if (CULL) {
             const unsigned long long m = __ballot(keep);
-            slot = count + lanes_below(m);
-            count += __popcll(m);
+            if (NT == 64) {
+                slot = count + lanes_below(m);
+                count += __popcll(m);
+            } else {
+                const int wave = tid >> 6;
+                if ((tid & 63) == 0) s_wc[wave] = __popcll(m);
+                __syncthreads();
+                int below = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) {
+                    const int c = s_wc[w];
+                    if (w < wave) below += c;
+                    total += c;
+                }
+                slot = count + below + lanes_below(m);
+                count += total;
+                __syncthreads();
+            }
         }
         if (keep) {
             float rec[REC];
@@ -148,9 +168,10 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
     const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
-    constexpr bool CULL = NT == 64;
-    constexpr int CAND = CULL ? 128 : NT, NR = CAND / NT;
+    constexpr bool CULL = true;
+    constexpr int CAND = NT == 64 ? 128 : 256, NR = CAND / NT;
     __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
+    __shared__ int s_wc[NT / 64];
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
     const int64_t tile = block_to_tile(order);
     const int cam = (int)(tile / n_tiles);
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, end - b0);
-        const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, means2d, conics, colors, depths, DC,
+        const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, s_wc, means2d, conics, colors, depths, DC,
                                                               opacities, g_cur, b0, n_cand, (float)(tx * 16),
                                                               (float)(ty * 16));
 #pragma unroll
@@ -278,12 +299,13 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     float *__restrict__ v_colors, float *__restrict__ v_depths, float *__restrict__ v_opacities,
     const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
-    constexpr bool CULL = NT == 64;
-    constexpr int CAND = CULL ? 128 : NT, NRD = CAND / NT;
+    constexpr bool CULL = true;
+    constexpr int CAND = NT == 64 ? 128 : 256, NRD = CAND / NT;
     constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
     __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
     __shared__ int32_t s_id[CAND];
     __shared__ int32_t s_max[NT / 64];
+    __shared__ int s_wc[NT / 64];
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
     const int64_t tile = block_to_tile(order);
     const int64_t start = offsets[tile];
@@ -361,7 +383,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < NRD; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, hi - start + 1);
-        const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, means2d, conics, colors, depths, DC, opacities,
+        const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, s_wc, means2d, conics, colors, depths, DC, opacities,
                                                              g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16));
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
@@ -499,18 +521,35 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 
 }  // namespace
 
-#define MTGS_DISPATCH_D(FN, ...)                         \
-    switch (DT) {                                        \
-        case 1: FN<1, 4>(__VA_ARGS__); break;            \
-        case 2: FN<2, 4>(__VA_ARGS__); break;            \
-        case 3: FN<3, 4>(__VA_ARGS__); break;            \
-        case 4: FN<4, 4>(__VA_ARGS__); break;            \
-        case 5: FN<5, 4>(__VA_ARGS__); break;            \
-        case 6: FN<6, 4>(__VA_ARGS__); break;            \
-        case 7: FN<7, 4>(__VA_ARGS__); break;            \
-        case 8: FN<8, 4>(__VA_ARGS__); break;            \
-        case 16: FN<16, 1>(__VA_ARGS__); break;          \
-        default: FN<32, 1>(__VA_ARGS__); break;          \
+// Pixels per lane.  One wave per tile (4 pixels per lane) is the most instruction-efficient
+// mapping, but it needs enough tiles to fill 1024 SIMDs several times over; small images (MTGS
+// trains at 960x540 = 2040 tiles) get 2 or 4 waves per tile instead.  Thresholds from kbench.py.
+static int pick_ppl(int64_t total_tiles, int DT, bool backward) {
+    if (DT > 8) return 1;
+    if (const char *e = getenv("MTGS_PPL")) return atoi(e);  // development knob (scripts/kbench.py sweeps)
+    // measured on MI355X, N = 2M (fwd / bwd us): 8160 tiles 296/597 (4) 323/1010 (2) 359/1682 (1);
+    // 2040 tiles 358/439 (4) 239/430 (2) 196/511 (1); 1200 tiles 524/595 (4) 346/446 (2) 267/419 (1)
+    if (backward) return total_tiles >= 4096 ? 4 : (total_tiles >= 1536 ? 2 : 1);
+    return total_tiles >= 6144 ? 4 : (total_tiles >= 3072 ? 2 : 1);
+}
+
+#define MTGS_DISPATCH_ONE(FN, DD, ...)                                         \
+    if (ppl == 4) FN<DD, 4>(__VA_ARGS__);                                      \
+    else if (ppl == 2) FN<DD, 2>(__VA_ARGS__);                                 \
+    else FN<DD, 1>(__VA_ARGS__);
+
+#define MTGS_DISPATCH_D(FN, ...)                                      \
+    switch (DT) {                                                     \
+        case 1: MTGS_DISPATCH_ONE(FN, 1, __VA_ARGS__) break;          \
+        case 2: MTGS_DISPATCH_ONE(FN, 2, __VA_ARGS__) break;          \
+        case 3: MTGS_DISPATCH_ONE(FN, 3, __VA_ARGS__) break;          \
+        case 4: MTGS_DISPATCH_ONE(FN, 4, __VA_ARGS__) break;          \
+        case 5: MTGS_DISPATCH_ONE(FN, 5, __VA_ARGS__) break;          \
+        case 6: MTGS_DISPATCH_ONE(FN, 6, __VA_ARGS__) break;          \
+        case 7: MTGS_DISPATCH_ONE(FN, 7, __VA_ARGS__) break;          \
+        case 8: MTGS_DISPATCH_ONE(FN, 8, __VA_ARGS__) break;          \
+        case 16: FN<16, 1>(__VA_ARGS__); break;                       \
+        default: FN<32, 1>(__VA_ARGS__); break;                       \
     }
 
 extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
@@ -532,6 +571,7 @@ extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, con
                      (M == 0 || (means2d && conics && (colors || D == 0) && opacities && flatten_ids)),
                  MTGS_EINVAL, "mtgs_blend_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, false);
     MTGS_DISPATCH_D(launch_fwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_fwd");
@@ -560,6 +600,7 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
                      (v_depths || !depths) && v_opacities,
                  MTGS_EINVAL, "mtgs_blend_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
     MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, render, v_render, v_alphas,
                     v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, tile_order, st);
