@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
                 const GaussEval e = eval_gauss(adx, bdx, r0.w, r1.x, dx, r0.y - py[p]);
                 s2[p] = e.s2;
                 valid[p] = !done[p] && e.s2 >= 0.f && e.s2 <= r1.z;
-                any |= __ballot(valid[p]);
+                any |= __builtin_amdgcn_ballot_w64(valid[p]);
             }
             if (any == 0) continue;
             float col[D];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
                 const float next_T = T[p] * (1.f - alpha);
                 const bool stop = valid[p] && next_T <= kTMin;
                 const bool use = valid[p] && !stop;
-                stopped |= __ballot(stop);
+                stopped |= __builtin_amdgcn_ballot_w64(stop);
                 done[p] = done[p] || stop;
                 const float w = use ? alpha * T[p] : 0.f;
 #pragma unroll
@@ -317,7 +317,10 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4, lane = tid & 63;
     const int ix = tx * 16 + lx;
     const float px = (float)ix + 0.5f;
-    float py[PPL], T[PPL], Tf_va[PPL], buf[PPL][D], vr[PPL][D];
+    // Per pixel: T (transmittance behind the current Gaussian), vr = dL/d(out), and the scalar
+    //   Bq = <colour accumulated behind, vr> - T_final * (dL/dalpha_out - <background, vr>)
+    // (the reference keeps the accumulated colour per channel; only its product with vr is ever used).
+    float py[PPL], T[PPL], Bq[PPL], vr[PPL][D];
     int32_t bin_final[PPL];
     int32_t my_max = -1;
 #pragma unroll
@@ -334,7 +337,6 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
         float bgd = 0.f;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            buf[p][k] = 0.f;
             vr[p][k] = v_render[pid * D + k];
             if (backgrounds && k < DC) bgd += backgrounds[cam * DC + k] * vr[p][k];
         }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
             if (alpha_out > 1e-10f) va += -vE * render[pid * D + D - 1] / alpha_out;
         }
         // d(alpha_out)/d(alpha_i) and the background term share the factor T_final / (1 - alpha_i)
-        Tf_va[p] = T_final * (va - bgd);
+        Bq[p] = -T_final * (va - bgd);
     }
     // tile-wide newest contributor
     int32_t wmax = wave_max_i32(my_max);
@@ -399,13 +401,14 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
             float dy[PPL];
             GaussEval e[PPL];
             bool valid[PPL];
-            unsigned long long any = 0;
+            unsigned long long vmask[PPL], any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 dy[p] = r0.y - py[p];
                 e[p] = eval_gauss(adx, bdx, r0.w, r1.x, dx, dy[p]);
                 valid[p] = idx <= bin_final[p] && e[p].s2 >= 0.f && e[p].s2 <= r1.z;
-                any |= __ballot(valid[p]);
+                vmask[p] = __builtin_amdgcn_ballot_w64(valid[p]);
+                any |= vmask[p];
             }
             if (any == 0) continue;
             float col[D];
@@ -414,35 +417,48 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
             float gv[4 * NR];
 #pragma unroll
             for (int k = 0; k < 4 * NR; ++k) gv[k] = 0.f;
+            // sums over this lane's pixels of v_sigma * {1, dy, dy^2}: dx is common to the lane's pixels
+            // (same column), so the conic and mean gradients are recovered from these three numbers
+            float S0 = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                if (valid[p]) {
+                // Wave-uniform branch per pixel slot; inside, invalid lanes run with alpha = 0 (then
+                // 1/(1-alpha) == 1 exactly, fac == 0: T and Bq are unchanged and every contribution is
+                // 0), so there is no exec-mask divergence in the gradient math.
+                if (vmask[p] != 0) {
                     const float vis = __builtin_amdgcn_exp2f(-kHalfLog2e * e[p].s2);
                     const float alpha_raw = opac * vis;
-                    const float alpha = fminf(kAlphaMax, alpha_raw);
+                    const float alpha = valid[p] ? fminf(kAlphaMax, alpha_raw) : 0.f;
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[p] *= ra;
                     const float fac = alpha * T[p];
-                    float v_alpha = Tf_va[p] * ra;
+                    float A = 0.f;  // <colour of this Gaussian, vr>
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
                         gv[8 + k] += fac * vr[p][k];
-                        v_alpha += (col[k] * T[p] - buf[p][k] * ra) * vr[p][k];
-                        buf[p][k] += col[k] * fac;
+                        A += col[k] * vr[p][k];
                     }
-                    if (alpha_raw <= kAlphaMax) {
-                        const float v_sigma = -alpha_raw * v_alpha;
-                        const float hs = 0.5f * v_sigma;
-                        gv[4] += hs * dx * dx;
-                        gv[5] += v_sigma * dx * dy[p];
-                        gv[6] += hs * dy[p] * dy[p];
-                        const float vx = v_sigma * e[p].u, vy = v_sigma * e[p].w;
-                        gv[0] += vx; gv[1] += vy;
-                        gv[2] += fabsf(vx); gv[3] += fabsf(vy);
-                        gv[7] += vis * v_alpha;
-                    }
+                    // dL/dalpha_i = T_i <c_i, vr> - (<behind, vr> - T_final (va - <bg, vr>)) / (1 - alpha_i)
+                    const float v_alpha = A * T[p] - ra * Bq[p];
+                    Bq[p] += fac * A;
+                    // alpha clamped at 0.999 (or lane invalid): no gradient through sigma / opacity
+                    const bool live = valid[p] && alpha_raw <= kAlphaMax;
+                    const float v_sigma = live ? -alpha_raw * v_alpha : 0.f;
+                    const float vsdy = v_sigma * dy[p];
+                    S0 += v_sigma;
+                    S1 += vsdy;
+                    S2 += vsdy * dy[p];
+                    gv[2] += fabsf(v_sigma * e[p].u);
+                    gv[3] += fabsf(v_sigma * e[p].w);
+                    gv[7] += live ? vis * v_alpha : 0.f;
                 }
             }
+            // sum_p v_sigma u_p with u_p = a dx + b dy_p (and w_p = b dx + c dy_p); conic: 1/2 v_sigma d d^T
+            gv[0] = adx * S0 + r0.w * S1;
+            gv[1] = bdx * S0 + r1.x * S1;
+            gv[4] = 0.5f * dx * dx * S0;
+            gv[5] = dx * S1;
+            gv[6] = 0.5f * S2;
             float red[NR];
             wave_reduce_x4<NR>(gv, red);
             float val = red[0];
