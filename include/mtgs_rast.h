@@ -139,6 +139,15 @@ int mtgs_bin_sort_tiles(int64_t M, int C, int tile_w, int tile_h, const uint32_t
                         const int32_t *gids, const float *depths, uint32_t *keys_scratch,
                         int32_t *flatten_ids, int64_t *isect_ids, void *ws, size_t ws_bytes,
                         void *stream);
+/* Everything after the host has read (n_vis, M) from mtgs_bin_compact's totals, in ONE call:
+ * depth sort -> mtgs_bin_scan -> mtgs_bin_emit -> mtgs_bin_sort_tiles -> mtgs_isect_offsets (if offsets
+ * non-null) -> mtgs_tile_schedule (if tile_order non-null).  ws: mtgs_bin_workspace_bytes. */
+int mtgs_bin_workspace_bytes(int64_t n_vis, int64_t M, size_t *bytes);
+int mtgs_bin_build(int C, int64_t N, int64_t n_vis, int64_t M, const float *means2d,
+                   const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss,
+                   const int64_t *vis_keys, const int32_t *vis_ids, int tile_size, int tile_w, int tile_h,
+                   int64_t *isect_ids, int32_t *flatten_ids, int32_t *offsets, int32_t *tile_order,
+                   void *ws, size_t ws_bytes, void *stream);
 int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,
                       const float *depths, int C, int tile_w, int tile_h, int64_t *isect_ids,
                       void *stream);

@@ -35,6 +35,9 @@ _SIGNATURES = {
     "mtgs_sort_u32_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_sort_pairs_u32": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_bin_sort_tiles": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mtgs_bin_workspace_bytes": [_i64, _i64, C.POINTER(_sz)],
+    "mtgs_bin_build": [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                       _vp, _sz, _vp],
     "mtgs_bin_finalize": [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],

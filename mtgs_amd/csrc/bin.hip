@@ -239,3 +239,76 @@ extern "C" int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, co
     MTGS_CHECK_LAUNCH("mtgs_bin_finalize");
     return MTGS_OK;
 }
+
+// ---- one call for everything after the host learns (n_vis, M) ---------------------------------
+// The kernels above are short (5-40 us); launched one ctypes call at a time the host cannot keep the
+// GPU fed and ~60 us of gaps open per frame.  mtgs_bin_build enqueues the whole chain back to back.
+namespace {
+struct BinWorkspace {
+    int64_t *keys_s, *cum;
+    int32_t *ids_s, *gids;
+    uint32_t *tile_keys, *keys_scratch;
+    void *sort_ws;
+    size_t sort_bytes;
+    void *scan_ws;
+    size_t scan_bytes;
+    size_t total;
+};
+inline BinWorkspace carve(char *base, int64_t n_vis, int64_t M) {
+    BinWorkspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += mtgs_sort::align256(bytes); return p; };
+    const int64_t nv = n_vis > 0 ? n_vis : 1, m = M > 0 ? M : 1;
+    w.keys_s = (int64_t *)take((size_t)nv * 8);
+    w.cum = (int64_t *)take((size_t)nv * 8);
+    w.ids_s = (int32_t *)take((size_t)nv * 4);
+    w.tile_keys = (uint32_t *)take((size_t)m * 4);
+    w.gids = (int32_t *)take((size_t)m * 4);
+    w.keys_scratch = (uint32_t *)take((size_t)m * 4);
+    const size_t s1 = mtgs_sort::workspace_bytes<uint64_t>(nv), s2 = mtgs_sort::workspace_bytes<uint32_t>(m);
+    w.sort_bytes = s1 > s2 ? s1 : s2;
+    w.sort_ws = take(w.sort_bytes);
+    w.scan_bytes = mtgs_scan::workspace_bytes(nv);
+    w.scan_ws = take(w.scan_bytes);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int mtgs_bin_workspace_bytes(int64_t n_vis, int64_t M, size_t *bytes) {
+    MTGS_REQUIRE(n_vis >= 0 && M >= 0 && bytes, MTGS_EINVAL, "mtgs_bin_workspace_bytes: bad arguments");
+    *bytes = carve(nullptr, n_vis, M).total;
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_bin_build(int C, int64_t N, int64_t n_vis, int64_t M, const float *means2d,
+                              const int32_t *radii, const float *depths, const int32_t *tiles_per_gauss,
+                              const int64_t *vis_keys, const int32_t *vis_ids, int tile_size, int tile_w,
+                              int tile_h, int64_t *isect_ids, int32_t *flatten_ids, int32_t *offsets,
+                              int32_t *tile_order, void *ws, size_t ws_bytes, void *stream) {
+    MTGS_REQUIRE(C > 0 && N >= 0 && n_vis >= 0 && M >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, MTGS_EINVAL,
+                 "mtgs_bin_build: bad sizes");
+    MTGS_REQUIRE(ws, MTGS_EINVAL, "mtgs_bin_build: null workspace");
+    BinWorkspace w = carve((char *)ws, n_vis, M);
+    MTGS_REQUIRE(ws_bytes >= w.total, MTGS_EWORKSPACE, "mtgs_bin_build: workspace %zu < %zu bytes", ws_bytes, w.total);
+    int rc = MTGS_OK;
+    if (M > 0) {
+        int cam_bits = 0;
+        for (uint32_t v = (uint32_t)(C - 1); v; v >>= 1) ++cam_bits;
+        // the sort reads its inputs only, so vis_keys / vis_ids stay intact
+        rc = mtgs_sort::sort_pairs<uint64_t>(n_vis, 32 + cam_bits, (const uint64_t *)vis_keys, vis_ids,
+                                             (uint64_t *)w.keys_s, w.ids_s, w.sort_ws, w.sort_bytes,
+                                             (hipStream_t)stream, "mtgs_bin_build(depth sort)");
+        if (rc) return rc;
+        if ((rc = mtgs_bin_scan(n_vis, w.ids_s, tiles_per_gauss, w.cum, w.scan_ws, w.scan_bytes, stream))) return rc;
+        if ((rc = mtgs_bin_emit(M, n_vis, w.ids_s, N, means2d, radii, w.cum, tile_size, tile_w, tile_h, w.tile_keys,
+                                w.gids, stream))) return rc;
+        if ((rc = mtgs_bin_sort_tiles(M, C, tile_w, tile_h, w.tile_keys, w.gids, depths, w.keys_scratch, flatten_ids,
+                                      isect_ids, w.sort_ws, w.sort_bytes, stream))) return rc;
+    }
+    if (offsets) {
+        if ((rc = mtgs_isect_offsets(M, isect_ids, C, tile_w, tile_h, offsets, stream))) return rc;
+        if (tile_order && (rc = mtgs_tile_schedule(C, tile_w, tile_h, offsets, M, tile_order, stream))) return rc;
+    }
+    return MTGS_OK;
+}

@@ -31,7 +31,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MTGS_DIST_BACKEND=gloo lets the N > 1 path be exercised with several ranks on ONE GPU
+            backend = os.environ.get("MTGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())

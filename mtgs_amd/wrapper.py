@@ -231,25 +231,20 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     n_vis, M = packed_totals >> 32, packed_totals & 0xFFFFFFFF
     isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
-    if M == 0:
-        return tiles_per_gauss, isect_ids, flatten_ids
-    # (camera, depth) order of the visible Gaussians; ties keep index order (stable)
-    keys_s, ids_s = torch.empty(n_vis, dtype=torch.int64, device=dev), torch.empty(n_vis, dtype=torch.int32, device=dev)
-    sort_ws, sort_bytes = _ws("mtgs_sort_workspace_bytes", n_vis, dev)
-    depth_key_bits = 32 + (_bit_length(Cn - 1) if Cn > 1 else 0)
-    call("mtgs_sort_pairs", n_vis, depth_key_bits, ptr(vis_keys), ptr(vis_ids), ptr(keys_s), ptr(ids_s),
-         ptr(sort_ws), sort_bytes, st)
-    cum = torch.empty(n_vis, dtype=torch.int64, device=dev)
-    call("mtgs_bin_scan", n_vis, ptr(ids_s), ptr(tiles_per_gauss), ptr(cum), ptr(scan_ws), scan_bytes, st)
-    tile_keys = torch.empty(M, dtype=torch.int32, device=dev)
-    gids = torch.empty(M, dtype=torch.int32, device=dev)
-    call("mtgs_bin_emit", M, n_vis, ptr(ids_s), N, ptr(means2d), ptr(radii), ptr(cum), tile_size, tile_width,
-         tile_height, ptr(tile_keys), ptr(gids), st)
-    keys_scratch = torch.empty_like(tile_keys)
-    sort_ws, sort_bytes = _ws("mtgs_sort_u32_workspace_bytes", M, dev)
-    # stable sort on the tile bits; the last pass writes gsplat's 64-bit isect_ids directly
-    call("mtgs_bin_sort_tiles", M, Cn, tile_width, tile_height, ptr(tile_keys), ptr(gids), ptr(depths),
-         ptr(keys_scratch), ptr(flatten_ids), ptr(isect_ids), ptr(sort_ws), sort_bytes, st)
+    # depth sort -> scan -> emit -> tile sort (+ isect_ids) -> offsets -> tile schedule, enqueued by ONE call
+    # so that the host does not starve the GPU between these short kernels.  The offsets and the tile
+    # dispatch order ride along on the returned tensors (picked up by isect_offset_encode /
+    # rasterize_to_pixels instead of being recomputed).
+    offsets = torch.empty((Cn, tile_height, tile_width), dtype=torch.int32, device=dev)
+    order = torch.empty(Cn * tile_height * tile_width, dtype=torch.int32, device=dev)
+    nbytes = C.c_size_t(0)
+    call("mtgs_bin_workspace_bytes", n_vis, M, C.byref(nbytes))
+    bin_ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    call("mtgs_bin_build", Cn, N, n_vis, M, ptr(means2d), ptr(radii), ptr(depths), ptr(tiles_per_gauss),
+         ptr(vis_keys), ptr(vis_ids), tile_size, tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids),
+         ptr(offsets), ptr(order), ptr(bin_ws), nbytes.value, st)
+    offsets._mtgs_tile_order = order
+    isect_ids._mtgs_offsets = offsets
     return tiles_per_gauss, isect_ids, flatten_ids
 
 
@@ -257,6 +252,9 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     """gsplat.cuda._wrapper.isect_offset_encode -> offsets[C, tile_height, tile_width] i32."""
     require_gpu(isect_ids)
+    cached = getattr(isect_ids, "_mtgs_offsets", None)  # computed together with isect_ids by isect_tiles
+    if cached is not None and tuple(cached.shape) == (n_cameras, tile_height, tile_width):
+        return cached
     isect_ids = isect_ids.contiguous()
     offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=torch.int32, device=isect_ids.device)
     call("mtgs_isect_offsets", isect_ids.numel(), ptr(isect_ids), n_cameras, tile_width, tile_height,
@@ -286,8 +284,10 @@ class _RasterizeToPixels(torch.autograd.Function):
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
         M = flatten_ids.numel()
         # longest-list-first dispatch order of the tiles (scheduling aid, does not change results)
-        order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
-        call("mtgs_tile_schedule", Cn, tw, th, ptr(isect_offsets), M, ptr(order), stream_of(m2d))
+        order = getattr(isect_offsets, "_mtgs_tile_order", None)
+        if order is None or order.numel() != Cn * th * tw:
+            order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
+            call("mtgs_tile_schedule", Cn, tw, th, ptr(isect_offsets), M, ptr(order), stream_of(m2d))
         call("mtgs_blend_fwd", Cn, N, DC, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), ptr(dep), int(ed),
              width, height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), M, ptr(render),
              ptr(alphas), ptr(last_ids), ptr(order), stream_of(m2d))
