@@ -116,6 +116,39 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
         close("v_colors", P["colors"].grad, vcol[0, :, :3])
 
 
+@pytest.mark.parametrize("W,H", [(1280, 720), (960, 540), (333, 211)])
+def test_midsize_images_use_more_waves_per_tile(gs, oracle, W, H):
+    """Image sizes that select 2 or 4 waves per tile (fewer than 6144 / 3072 tiles forward, 4096 / 1536
+    backward; MTGS trains at 960x540): same parity bars as the one-wave-per-tile configuration."""
+    N = 200_000
+    sc = make_scene(N, seed=4)
+    vm, K = make_camera(W, H, yaw_deg=30.0)
+    a = {k: v.numpy() for k, v in sc.items()}
+    g = torch.Generator().manual_seed(2)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=g), torch.randn(1, H, W, 1, generator=g)
+    r_ref, a_ref, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], vm.numpy(),
+                                           K.numpy(), W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+    P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
+    render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], dev(vm),
+                                           dev(K), W, H, packed=False, render_mode="RGB+ED",
+                                           rasterize_mode="antialiased", absgrad=True)
+    info["means2d"].retain_grad()
+    assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
+    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render")
+    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0)
+    torch.autograd.backward([render, alpha], [dev(Gc), dev(Ga)])
+    alc = np.maximum(a_ref, 1e-10)
+    Gc_raw = Gc.numpy().copy()
+    Gc_raw[..., -1:] = Gc.numpy()[..., -1:] / alc
+    Ga_tot = Ga.numpy() - (m["render_raw"][..., -1:] / alc ** 2) * Gc.numpy()[..., -1:] * (a_ref > 1e-10)
+    v2d, vabs, vcon, vcol, vop = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                  m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw, Ga_tot)
+    for name, got, ref in (("means2d.grad", info["means2d"].grad, v2d), ("absgrad", info["means2d"].absgrad, vabs),
+                           ("v_colors", P["colors"].grad, vcol[0, :, :3])):
+        err, scale = np.abs(got.detach().cpu().numpy() - ref).max(), np.abs(ref).max()
+        assert err <= 2e-3 * scale, f"{name}: {err:.3e} vs {scale:.3e}"
+
+
 def test_fullsize_properties_linearity_and_determinism(gs):
     """Size-independent properties at configs[2] size: the backward is linear in the cotangent, the
     integer stages are deterministic, culled Gaussians get exactly zero gradient."""
