@@ -66,6 +66,14 @@ def _worker(rank, world, port, out_dir):
     for p, n in zip(params, names):
         p.grad.add_(torch.from_numpy(grads[n]))        # what autograd's accumulation does
     bucket.all_reduce()
+    # the bucket-free variant must give the same sums
+    params2 = [sc[n].clone().requires_grad_(True) for n in names]
+    for p, n in zip(params2, names):
+        p.grad = torch.from_numpy(grads[n]).clone()
+    sent = mdist.all_reduce_grads(params2, direct_bytes=1500)   # colours/means go direct, the rest packed
+    assert sent == sum(p.grad.numel() * 4 for p in params2)
+    for p, q in zip(params, params2):
+        assert torch.equal(p.grad, q.grad)
     t_sum, t_max = torch.from_numpy(s_sum), torch.from_numpy(s_max)
     mdist.all_reduce_stats([t_sum], [t_max])
     np.savez(Path(out_dir) / f"rank{rank}.npz", vis=t_sum.numpy(), maxr=t_max.numpy(),
