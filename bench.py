@@ -51,6 +51,10 @@ def parse_args():
                     help="mtgs: SH deg 3 + RGB+ED/antialiased/absgrad (what MTGS.py drives); "
                          "lean: colours given, RGB/classic/no absgrad")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-oracle steps (0 disables)")
+    ap.add_argument("--dp-exchange", choices=["sparse", "dense"], default="sparse",
+                    help="N > 1: sparse = all-gather of 64-byte rows of the visible Gaussians, SH-coefficient "
+                         "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
+                         "dense = plain all-reduce of every gradient tensor")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -71,7 +75,7 @@ def build_inputs(args, rank, device):
 
 def make_step(args, dev, world):
     from mtgs_amd import rasterization, spherical_harmonics
-    from mtgs_amd.dist import all_reduce_grads
+    from mtgs_amd.dist import SparseGradExchange, all_reduce_grads
     names = ["means", "quats", "scales", "opacities"] + (["coeffs"] if args.variant == "mtgs" else ["colors"])
     params = {n: dev[n].requires_grad_(True) for n in names}
     viewmat = dev["viewmat"].requires_grad_(True)
@@ -80,13 +84,21 @@ def make_step(args, dev, world):
     W, H = args.width, args.height
     all_params = list(params.values()) + [viewmat]
     info_box = {"grad_bytes": 0}
+    sparse = world > 1 and args.dp_exchange == "sparse" and args.variant == "mtgs"
+    exchange = SparseGradExchange(args.n_gaussians, 16, dev["means"].device) if sparse else None
 
     def step():
         for p in all_params:
             p.grad = None
         if args.variant == "mtgs":
             dirs = params["means"].detach() - cam_pos
-            rgb = torch.clamp(spherical_harmonics(3, dirs, params["coeffs"]) + 0.5, 0.0, 1.0)
+            if sparse:
+                # the SH output is the autograd leaf: its gradient (3 floats per Gaussian) is the factor
+                # that is exchanged; every rank rebuilds the summed coefficient gradient from the factors
+                sh_out = spherical_harmonics(3, dirs, params["coeffs"].detach()).requires_grad_(True)
+            else:
+                sh_out = spherical_harmonics(3, dirs, params["coeffs"])
+            rgb = torch.clamp(sh_out + 0.5, 0.0, 1.0)
             render, alpha, info = rasterization(
                 means=params["means"], quats=params["quats"], scales=params["scales"],
                 opacities=params["opacities"], colors=rgb, viewmats=viewmat, Ks=K, width=W, height=H,
@@ -100,7 +112,13 @@ def make_step(args, dev, world):
                 rasterize_mode="classic")
         info["means2d"].retain_grad()
         torch.autograd.backward([render, alpha], [Gc, Ga])
-        if world > 1:  # ONE exchange per step: sum of the Gaussian (and camera) gradients over the ranks
+        if sparse:  # ONE exchange per step: sum of the Gaussian gradients over the ranks (cameras)
+            g = exchange.exchange(info["radii"][0], params["means"].detach(), cam_pos, params["means"].grad,
+                                  params["quats"].grad, params["scales"].grad, params["opacities"].grad, sh_out.grad, 3)
+            for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
+                params[name].grad = t
+            info_box["grad_bytes"] = exchange.last_bytes
+        elif world > 1:
             info_box["grad_bytes"] = all_reduce_grads(all_params)
         info_box["info"] = info
         return render, alpha
@@ -226,7 +244,8 @@ def main():
                            else " (colours given, RGB, classic)"),
             "n_gaussians": args.n_gaussians, "width": args.width, "height": args.height,
             "n_visible": n_vis, "n_intersections": M,
-            "parallelism": f"view-parallel dp{world}, all-reduce of {info_box['grad_bytes']} gradient bytes/step",
+            "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange, "
+                           f"{info_box['grad_bytes']} bytes received per rank per step",
         },
         "roofline": {"kernel": "blend_bwd_kernel (mtgs_blend_bwd)", "bound": "hbm",
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -188,6 +188,19 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
                    float *v_opacities, const int32_t *tile_order, void *stream);
 
+/* ---- view-parallel data parallelism: sparse, factored gradient exchange (mtgs_amd/csrc/dp.hip) ------
+ * No gsplat counterpart.  Rows are 16 floats: v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, spare,
+ * Gaussian index (int bits).  mtgs_dp_pack compacts the rows of the Gaussians with radii > 0 (unordered)
+ * and writes their number to count[1] (device); mtgs_dp_accumulate adds one sender's rows into the dense
+ * gradient tensors, expanding v_rgb through the SH basis evaluated at normalize(mean - cam_pos) into
+ * v_coeffs[N,K,3] (nullable). Indices within one call must be unique (they are: one camera per sender). */
+int mtgs_dp_pack(int64_t N, const int32_t *radii, const float *v_means, const float *v_quats,
+                 const float *v_scales, const float *v_opacities, const float *v_rgb, float *rows,
+                 int64_t capacity, int64_t *count, void *stream);
+int mtgs_dp_accumulate(int64_t n_rows, const float *rows, int64_t N, int K, int degree, const float *means,
+                       const float *cam_pos, float *v_means, float *v_quats, float *v_scales,
+                       float *v_opacities, float *v_coeffs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

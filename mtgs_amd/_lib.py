@@ -40,6 +40,8 @@ _SIGNATURES = {
                        _vp, _sz, _vp],
     "mtgs_bin_finalize": [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
+    "mtgs_dp_pack": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
