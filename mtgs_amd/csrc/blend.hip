@@ -183,13 +183,15 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     int iy[PPL];
     float py[PPL], T[PPL], acc[PPL][D];
     int32_t last[PPL];
-    bool done[PPL], inside[PPL];
+    // A finished pixel (T would drop to <= 1e-4, or outside the image) is marked by py = +inf: its
+    // quadratic form becomes inf/NaN and fails the validity test without a separate flag.
+    bool inside[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
         iy[p] = ty * 16 + ly + p * ROWS;
         py[p] = (float)iy[p] + 0.5f;
         inside[p] = ix < W && iy[p] < H;
-        done[p] = !inside[p];
+        if (!inside[p]) py[p] = INFINITY;
         T[p] = 1.f;
         last[p] = 0;
 #pragma unroll
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     for (int64_t b0 = start; b0 < end; b0 += CAND) {
         bool all_done = true;
 #pragma unroll
-        for (int p = 0; p < PPL; ++p) all_done = all_done && done[p];
+        for (int p = 0; p < PPL; ++p) all_done = all_done && py[p] == INFINITY;
         if (__syncthreads_and(all_done)) break;
         int32_t g_cur[NR];
 #pragma unroll
@@ -225,13 +227,14 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
             const float adx = r0.z * dx, bdx = r0.w * dx;
             float s2[PPL];
             bool valid[PPL];
-            unsigned long long any = 0;
+            unsigned long long vmask[PPL], any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 const GaussEval e = eval_gauss(adx, bdx, r0.w, r1.x, dx, r0.y - py[p]);
                 s2[p] = e.s2;
-                valid[p] = !done[p] && e.s2 >= 0.f && e.s2 <= r1.z;
-                any |= __builtin_amdgcn_ballot_w64(valid[p]);
+                valid[p] = e.s2 >= 0.f && e.s2 <= r1.z;
+                vmask[p] = __builtin_amdgcn_ballot_w64(valid[p]);
+                any |= vmask[p];
             }
             if (any == 0) continue;
             float col[D];
@@ -241,22 +244,24 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
             unsigned long long stopped = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                const float alpha = fminf(kAlphaMax, r1.y * __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]));
-                const float next_T = T[p] * (1.f - alpha);
-                const bool stop = valid[p] && next_T <= kTMin;
-                const bool use = valid[p] && !stop;
-                stopped |= __builtin_amdgcn_ballot_w64(stop);
-                done[p] = done[p] || stop;
-                const float w = use ? alpha * T[p] : 0.f;
+                if (vmask[p] != 0) {  // wave-uniform: skip the strips of the tile this Gaussian does not reach
+                    // invalid lanes run with alpha = 0: T, acc and last are unchanged, and T(1-0) > 1e-4
+                    const float alpha = valid[p] ? fminf(kAlphaMax, r1.y * __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p])) : 0.f;
+                    const float next_T = T[p] * (1.f - alpha);
+                    const bool stop = next_T <= kTMin;
+                    stopped |= __builtin_amdgcn_ballot_w64(stop);
+                    const float w = stop ? 0.f : alpha * T[p];
 #pragma unroll
-                for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
-                last[p] = use ? idx : last[p];
-                T[p] = use ? next_T : T[p];
+                    for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
+                    last[p] = (valid[p] && !stop) ? idx : last[p];
+                    T[p] = stop ? T[p] : next_T;
+                    py[p] = stop ? INFINITY : py[p];
+                }
             }
             if (stopped) {
                 bool ad = true;
 #pragma unroll
-                for (int p = 0; p < PPL; ++p) ad = ad && done[p];
+                for (int p = 0; p < PPL; ++p) ad = ad && py[p] == INFINITY;
                 if (__all(ad)) break;
             }
         }
