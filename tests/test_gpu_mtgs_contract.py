@@ -1,0 +1,157 @@
+"""The consumer contract of the hot path, exercised the way MTGS does it (reference @ 2025-09-12):
+node activations + SH colour (gaussian_model/vanilla_gaussian_splatting.py:296-322), the exact kwargs of
+mtgs_scene_graph.py:641-662 through `gsplat.rendering.rasterization`, the post-raster code of :663-690,
+the densification statistics of :1157-1183 / vanilla :448-474, and a few Adam steps."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class Node(torch.nn.Module):
+    """Parameters and activations of VanillaGaussianSplattingModel (the parts on the hot path)."""
+
+    def __init__(self, n, sh_degree, seed, device):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        k = (sh_degree + 1) ** 2
+        P = lambda t: torch.nn.Parameter(t.to(device))
+        self.means = P((torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([6.0, 2.0, 6.0]) + torch.tensor([0, 0, 9.0]))
+        self.scales = P(torch.log(torch.rand(n, 3, generator=g) * 0.25 + 0.05))
+        self.quats = P(torch.randn(n, 4, generator=g))
+        self.opacities = P(torch.logit(torch.rand(n, 1, generator=g) * 0.7 + 0.2))
+        self.features_dc = P((torch.rand(n, 3, generator=g) - 0.5) / 0.28209479177387814)
+        self.features_rest = P(0.05 * torch.randn(n, k - 1, 3, generator=g))
+        self.sh_degree = sh_degree
+
+    def get_gaussians(self, camera_to_world, step, sh_degree_interval=2):
+        from gsplat.cuda._wrapper import spherical_harmonics          # the import MTGS uses
+        colors = torch.cat((self.features_dc[:, None, :], self.features_rest), dim=1)
+        viewdirs = self.means.detach() - camera_to_world[:3, 3]
+        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        n = min(step // sh_degree_interval, self.sh_degree)
+        rgbs = torch.clamp(spherical_harmonics(n, viewdirs, colors) + 0.5, 0.0, 1.0)
+        return dict(means=self.means, scales=torch.exp(self.scales),
+                    quats=self.quats / self.quats.norm(dim=-1, keepdim=True),
+                    opacities=torch.sigmoid(self.opacities).squeeze(-1), rgbs=rgbs)
+
+
+def get_outputs(nodes, c2w, K, W, H, step, training=True, predict_normals=True):
+    """mtgs_scene_graph.py:547-708, reduced to the hot path and its direct consumers."""
+    from gsplat.rendering import rasterization                        # the import MTGS uses
+    dev = c2w.device
+    parts = [n.get_gaussians(c2w, step) for n in nodes]
+    col = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
+    model_id = torch.cat([torch.full((p["means"].shape[0],), i, device=dev) for i, p in enumerate(parts)])
+    R = c2w[:3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0], device=dev))
+    T = c2w[:3, 3:4]
+    viewmat = torch.eye(4, device=dev)
+    viewmat[:3, :3] = R.T
+    viewmat[:3, 3:4] = -R.T @ T
+    viewmat = viewmat.unsqueeze(0)
+    render_colors = col["rgbs"]
+    if predict_normals:                                               # :636-638 (camera-space normals, 3 more channels)
+        normals = torch.nn.functional.normalize(col["means"] - c2w[:3, 3], dim=-1) @ R
+        render_colors = torch.cat([render_colors, normals], dim=-1)
+    render_mode = "RGB+ED"
+    gsplat_kwargs = dict(means=col["means"], quats=col["quats"], scales=col["scales"], opacities=col["opacities"],
+                         colors=render_colors, viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False,
+                         near_plane=0.01, far_plane=1e10, render_mode=render_mode, sparse_grad=False, absgrad=True,
+                         rasterize_mode="antialiased")
+    render, alpha, info = rasterization(**gsplat_kwargs)
+    if info["radii"].ndim == 3:
+        info["radii"] = (info["radii"][..., 0] * info["radii"][..., 1]).sqrt().int()
+    if training and info["means2d"].requires_grad:
+        info["means2d"].retain_grad()
+    background = torch.zeros(3, device=dev)
+    rgb = torch.clamp(render[..., :3] + (1 - alpha) * background, 0.0, 1.0).squeeze(0)
+    depth_im = render[..., -1:]
+    depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max()).squeeze(0)
+    normals_im = None
+    if predict_normals:
+        normals_im = render[..., 3:6].squeeze(0)
+        normals_im = (normals_im / normals_im.norm(dim=-1, keepdim=True).clamp_min(1e-8) + 1) / 2
+    return dict(rgb=rgb, depth=depth_im, normal=normals_im, accumulation=alpha.squeeze(0), xys=info["means2d"],
+                radii=info["radii"], model_id=model_id, info=info, render=render)
+
+
+def test_mtgs_style_training_steps():
+    dev = torch.device("cuda")
+    W, H = 240, 135                                                    # a 960x540 / 4 training image
+    K = torch.tensor([[[190.0, 0, W / 2], [0, 190.0, H / 2], [0, 0, 1]]], device=dev)
+    c2w = torch.eye(4, device=dev)
+    c2w[:3, :3] = torch.diag(torch.tensor([1.0, -1.0, -1.0]))          # nerfstudio/OpenGL camera looking down -z ... +z world
+    nodes = [Node(1500, 3, 1, dev), Node(700, 3, 2, dev)]               # background node + an object node
+    with torch.no_grad():
+        target = get_outputs([Node(1500, 3, 11, dev), Node(700, 3, 12, dev)], c2w, K, W, H, step=10, training=False)
+    opt = torch.optim.Adam([p for n in nodes for p in n.parameters()], lr=2e-2)
+    xys_grad_norm = torch.zeros(2200, device=dev)
+    vis_counts = torch.ones(2200, device=dev)
+    max_2Dsize = torch.zeros(2200, device=dev)
+    losses = []
+    for step in range(12):                                             # SH degree ramps 0 -> 3 (sh_degree_interval = 2)
+        out = get_outputs(nodes, c2w, K, W, H, step)
+        assert out["render"].shape == (1, H, W, 7) and out["accumulation"].shape == (H, W, 1)
+        loss = (out["rgb"] - target["rgb"]).abs().mean() + 0.1 * (1 / (out["depth"] + 1) - 1 / (target["depth"] + 1)).abs().mean()
+        opt.zero_grad()
+        loss.backward()
+        # ---- update_submodel_statistics (:1157-1183) + after_train (vanilla :448-474)
+        xys, radii = out["xys"], out["radii"]
+        assert xys.grad is not None and xys.absgrad is not None and radii.shape == (1, 2200) and radii.dtype == torch.int32
+        off = 0
+        for i, n in enumerate(nodes):
+            mask = out["model_id"] == i
+            grads = (xys.absgrad[0, mask].detach() * xys.new_tensor([[W, H]]) * 0.5).norm(dim=-1)
+            r = radii[0, mask]
+            visible = (r > 0).flatten()
+            cnt = int(mask.sum())
+            vis_counts[off:off + cnt][visible] += 1
+            xys_grad_norm[off:off + cnt][visible] += grads[visible]
+            max_2Dsize[off:off + cnt][visible] = torch.maximum(max_2Dsize[off:off + cnt][visible], r[visible])
+            off += cnt
+        assert bool((xys.absgrad >= xys.grad.abs() - 1e-6).all())
+        for n in nodes:
+            for name, p in n.named_parameters():
+                assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert float(xys_grad_norm.max()) > 0 and float(max_2Dsize.max()) >= 1
+    # eval path: no grad, same outputs
+    with torch.no_grad():
+        out = get_outputs(nodes, c2w, K, W, H, step=12, training=False)
+    assert torch.isfinite(out["rgb"]).all() and float(out["accumulation"].max()) <= 1.0
+
+
+def test_viewer_style_arbitrary_resolutions_and_threads():
+    """The viewer thread renders at arbitrary sizes (height >= 30, not multiples of 16) under train_lock
+    (custom_viewer/render_state_machine.py:118-203): partial tiles and a second Python thread."""
+    import threading
+    dev = torch.device("cuda")
+    node = Node(3000, 2, 5, dev)
+    c2w = torch.eye(4, device=dev)
+    c2w[:3, :3] = torch.diag(torch.tensor([1.0, -1.0, -1.0]))
+    results, errors = {}, []
+
+    def render(W, H):
+        try:
+            K = torch.tensor([[[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]]], device=dev)
+            with torch.no_grad():
+                out = get_outputs([node], c2w, K, W, H, step=4, training=False, predict_normals=False)
+            results[(W, H)] = (tuple(out["rgb"].shape), bool(torch.isfinite(out["rgb"]).all()), float(out["accumulation"].sum()))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    sizes = [(53, 30), (101, 57), (257, 143), (640, 360)]
+    threads = [threading.Thread(target=render, args=s) for s in sizes]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (W, H) in sizes:
+        shape, finite, acc = results[(W, H)]
+        assert shape == (H, W, 3) and finite and acc > 0
