@@ -99,7 +99,8 @@ def rasterization(
     # (2) colours [C, N, D]
     if sh_degree is None:
         if colors.dim() == 2:
-            colors = colors.expand(C, -1, -1)
+            # (C == 1, MTGS's case: a plain view -- expand()'s backward would launch a reduction over C)
+            colors = colors.unsqueeze(0) if C == 1 else colors.expand(C, -1, -1)
     else:
         camtoworlds = torch.inverse(viewmats)  # [C, 4, 4]
         dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
