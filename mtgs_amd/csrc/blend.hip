@@ -379,13 +379,21 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     const int64_t top = wmax;  // sorted index of the last Gaussian any pixel of the tile used
     if (top < start) return;
 
-    // which gradient component this lane adds to memory after the transposed reduction:
-    // component j = 4*col + row lives in row `row` of register `col`.
+    // After the transposed reduction component jr = 4*col + row lives in row `row` of register `col`.
+    // One wave (or two) per tile: lane 16*row + col issues the atomic for its component right away.
+    // FOUR waves per tile (small images): the reduced values of a whole batch are parked in LDS
+    // (s_grad[wave][entry][16]) and flushed once per batch, so the four waves' sums are formed in LDS and
+    // the global atomics are quartered (measured 392 -> 325 us at 640x480; with 1-2 waves per tile the
+    // extra barrier and LDS traffic cost more than they save).  In the flush, lane L adds component
+    // L % 16 of entry L / 16 (+ 16 per step).
+    constexpr bool BATCH_FLUSH = NV <= 16 && NT == 256;
+    constexpr int NW = NT / 64;
+    __shared__ float s_grad[BATCH_FLUSH ? NW * CAND * 16 : 1];
     const int a_col = lane & 15, a_row = lane >> 4;
-    const int j = 4 * a_col + a_row;
+    const int j = BATCH_FLUSH ? (tid & 15) : 4 * a_col + a_row;
     float *a_base = nullptr;
     int a_stride = 0;
-    if (a_col < NR && j < NV) {
+    if ((BATCH_FLUSH || a_col < NR) && j < NV) {
         if (j < 2) { a_base = v_means2d + j; a_stride = 2; }
         else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride = 2; }
         else if (j < 7) { a_base = v_conics + (j - 4); a_stride = 3; }
@@ -408,6 +416,10 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
             if (hi - CAND - r * NT - tid >= start) g_next[r] = flatten_ids[hi - CAND - r * NT - tid];
+        if (BATCH_FLUSH) {  // zero the batch's gradient slots (entries that touch no pixel never write theirs)
+            float4 *z = reinterpret_cast<float4 *>(s_grad);
+            for (int e = tid; e < NW * bsz * 4; e += NT) z[(e / (bsz * 4)) * (CAND * 4) + e % (bsz * 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __syncthreads();
         for (int t = 0; t < bsz; ++t) {
             const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
@@ -482,7 +494,21 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
             float val = red[0];
 #pragma unroll
             for (int i = 1; i < NR; ++i) val = (a_col == i) ? red[i] : val;
-            if (a_base) unsafeAtomicAdd(a_base + (int64_t)s_id[t] * a_stride, val);
+            if (BATCH_FLUSH) {
+                if (a_col < NR) s_grad[((tid >> 6) * CAND + t) * 16 + 4 * a_col + a_row] = val;
+            } else {
+                if (a_base) unsafeAtomicAdd(a_base + (int64_t)s_id[t] * a_stride, val);
+            }
+        }
+        if (BATCH_FLUSH) {
+            __syncthreads();
+            for (int e = tid; e < bsz * 16; e += NT) {
+                const int t = e >> 4;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += s_grad[(w * CAND + t) * 16 + j];
+                if (a_base && v != 0.f) unsafeAtomicAdd(a_base + (int64_t)s_id[t] * a_stride, v);
+            }
         }
     }
 }
@@ -561,10 +587,11 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 static int pick_ppl(int64_t total_tiles, int DT, bool backward) {
     if (DT > 8) return 1;
     if (const char *e = getenv("MTGS_PPL")) return atoi(e);  // development knob (scripts/kbench.py sweeps)
-    // measured on MI355X, N = 2M (fwd / bwd us): 8160 tiles 296/597 (4) 323/1010 (2) 359/1682 (1);
-    // 2040 tiles 358/439 (4) 239/430 (2) 196/511 (1); 1200 tiles 524/595 (4) 346/446 (2) 267/419 (1)
-    if (backward) return total_tiles >= 4096 ? 4 : (total_tiles >= 1536 ? 2 : 1);
-    return total_tiles >= 6144 ? 4 : (total_tiles >= 3072 ? 2 : 1);
+    // measured on MI355X, N = 2M, after exact culling (us, pixels per lane 4 / 2 / 1):
+    //   fwd: 1200 tiles 405/291/220   2040 tiles 282/202/159   3600 tiles 237/187/169   8160 tiles 230/-/-
+    //   bwd: 1200 tiles 508/407/327   2040 tiles 378/419/420   3600 tiles 358/549/573   8160 tiles 533/-/-
+    if (backward) return total_tiles >= 1536 ? 4 : 1;
+    return total_tiles >= 6144 ? 4 : (total_tiles >= 4608 ? 2 : 1);
 }
 
 #define MTGS_DISPATCH_ONE(FN, DD, ...)                                         \
