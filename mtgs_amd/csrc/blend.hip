@@ -233,9 +233,14 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
         for (int r = 0; r < NR; ++r)
             if (b0 + CAND + r * NT + tid < end) g_next[r] = flatten_ids[b0 + CAND + r * NT + tid];
         __syncthreads();
+        // software pipeline: the record of entry t+1 is read from LDS while entry t is processed
+        float4 n0 = *reinterpret_cast<const float4 *>(s_rec), n1 = *reinterpret_cast<const float4 *>(s_rec + 4);
         for (int t = 0; t < bsz; ++t) {
-            const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
-            const float4 r1 = *reinterpret_cast<const float4 *>(s_rec + t * REC + 4);
+            const float4 r0 = n0, r1 = n1;
+            if (t + 1 < bsz) {
+                n0 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC);
+                n1 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC + 4);
+            }
             const float dx = r0.x - px;
             const float adx = r0.z * dx, bdx = r0.w * dx;
             float s2[PPL];
@@ -421,9 +426,14 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
             for (int e = tid; e < NW * bsz * 4; e += NT) z[(e / (bsz * 4)) * (CAND * 4) + e % (bsz * 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        // software pipeline: the record of entry t+1 is read from LDS while entry t is processed
+        float4 n0 = *reinterpret_cast<const float4 *>(s_rec), n1 = *reinterpret_cast<const float4 *>(s_rec + 4);
         for (int t = 0; t < bsz; ++t) {
-            const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
-            const float4 r1 = *reinterpret_cast<const float4 *>(s_rec + t * REC + 4);
+            const float4 r0 = n0, r1 = n1;
+            if (t + 1 < bsz) {
+                n0 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC);
+                n1 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC + 4);
+            }
             const int32_t idx = __float_as_int(r1.w);
             const float opac = r1.y;
             const float dx = r0.x - px;
