@@ -310,8 +310,10 @@ struct GradLayout {
     static constexpr int NR = (NV + 3) / 4;
 };
 
+// (second launch-bound argument = waves per SIMD the register allocator must leave room for: the
+//  one-wave-per-tile mapping is latency-sensitive, 5 waves/SIMD measured better than 4)
 template <int D, int PPL>
-__global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
+__global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend_bwd_kernel(
     int C, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
