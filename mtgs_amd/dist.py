@@ -174,17 +174,20 @@ class SparseGradExchange:
             counts_h = counts.tolist()            # host sync: buffer sizes for the payload exchange
             cap = max(max(counts_h), 1)
             recv = torch.empty((world * cap, self.ROW), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(recv, self.rows[:cap], group=self.group)     # [cap,16] blocks along dim 0
+            # [cap,16] blocks along dim 0; asynchronous, so that the zero-fill below overlaps the transfer
+            work = dist.all_gather_into_tensor(recv, self.rows[:cap], group=self.group, async_op=True)
             recv = recv.view(world, cap, self.ROW)
             self.last_bytes = world * cap * self.ROW * 4
         else:
             counts_h = [int(self.count.item())]
-            cams, recv = cam_pos[None], self.rows[None]
+            cams, recv, work = cam_pos[None], self.rows[None], None
             self.last_bytes = 0
         # dense, replicated sums: one zero-filled buffer, one accumulate launch per sender
         sizes = [3 * N, 4 * N, 3 * N, N, (3 * K * N if v_rgb is not None else 0)]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         o_means, o_quats, o_scales, o_opac, o_coeffs = torch.split(flat, sizes)
+        if work is not None:
+            work.wait()
         for r in range(world):
             call("mtgs_dp_accumulate", counts_h[r], ptr(recv[r]), N, K, int(sh_degree), ptr(means), ptr(cams[r]),
                  ptr(o_means), ptr(o_quats), ptr(o_scales), ptr(o_opac), ptr(o_coeffs) if v_rgb is not None else None, st)
