@@ -113,8 +113,14 @@ def make_step(args, dev, world):
         info["means2d"].retain_grad()
         torch.autograd.backward([render, alpha], [Gc, Ga])
         if sparse:  # ONE exchange per step: sum of the Gaussian gradients over the ranks (cameras)
+            def local_sh_backward():  # runs while the rows are on the wire
+                sh2 = spherical_harmonics(3, dirs, params["coeffs"])
+                sh2.backward(sh_out.grad)
+                return params["coeffs"].grad
+
             g = exchange.exchange(info["radii"][0], params["means"].detach(), cam_pos, params["means"].grad,
-                                  params["quats"].grad, params["scales"].grad, params["opacities"].grad, sh_out.grad, 3)
+                                  params["quats"].grad, params["scales"].grad, params["opacities"].grad, sh_out.grad, 3,
+                                  local_coeff_grad=local_sh_backward)
             for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
                 params[name].grad = t
             info_box["grad_bytes"] = exchange.last_bytes

@@ -149,50 +149,68 @@ class SparseGradExchange:
 
     def exchange(self, radii: torch.Tensor, means: torch.Tensor, cam_pos: torch.Tensor, v_means: torch.Tensor,
                  v_quats: torch.Tensor, v_scales: torch.Tensor, v_opacities: torch.Tensor,
-                 v_rgb: Optional[torch.Tensor], sh_degree: int):
-        """radii[N] (this rank's camera), means[N,3], cam_pos[3]; local dense gradients v_*; v_rgb[N,3] is
-        the gradient with respect to the SH OUTPUT (before the +0.5 / clamp), or None for no SH part.
+                 v_rgb: Optional[torch.Tensor], sh_degree: int, local_coeff_grad=None):
+        """radii[N] (this rank's camera), means[N,3], cam_pos[3]; this rank's dense gradients v_* (they are
+        UPDATED IN PLACE with the other ranks' rows); v_rgb[N,3] is the gradient with respect to the SH
+        OUTPUT (before the +0.5 / clamp), or None for no SH part.  `local_coeff_grad` is a callable returning
+        this rank's own dense v_coeffs[N,K,3] (the local SH backward); it is invoked while the payload is in
+        flight, so its ~80 us hide behind the transfer.  Without it the coefficient gradient is rebuilt from
+        zeros including the own rows.
         Returns (v_means, v_quats, v_scales, v_opacities, v_coeffs | None): dense sums over all ranks."""
         from ._lib import call, ptr, stream_of
         N, K, dev = self.N, self.K, self.device
         radii = radii.reshape(-1).contiguous()
         assert radii.numel() == N and means.shape == (N, 3)
-        f = lambda t: None if t is None else t.contiguous()
-        v_means, v_quats, v_scales, v_opacities, v_rgb, means = map(f, (v_means, v_quats, v_scales, v_opacities, v_rgb, means))
+        for t in (v_means, v_quats, v_scales, v_opacities):
+            assert t.is_contiguous(), "the local dense gradients are accumulated into in place"
+        v_rgb = None if v_rgb is None else v_rgb.contiguous()
+        means = means.contiguous()
         cam_pos = cam_pos.reshape(3).to(torch.float32).contiguous()
         st = stream_of(means)
-        call("mtgs_dp_pack", N, ptr(radii), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opacities), ptr(v_rgb),
-             ptr(self.rows), N, ptr(self.count), st)
         world = self.world
+        rebuild_own = v_rgb is not None and local_coeff_grad is None
+        work, cams, recv = None, None, None
+        if world > 1 or rebuild_own:
+            call("mtgs_dp_pack", N, ptr(radii), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opacities), ptr(v_rgb),
+                 ptr(self.rows), N, ptr(self.count), st)
         if world > 1:
             # one small collective carries both the row count and the camera position of every rank
             meta = torch.cat([self.count, cam_pos.view(torch.int32).to(torch.int64)])[None]      # [1,4] int64
             metas = torch.empty((world, 4), dtype=torch.int64, device=dev)
             dist.all_gather_into_tensor(metas, meta, group=self.group)
-            counts = metas[:, 0]
             cams = metas[:, 1:4].to(torch.int32).contiguous().view(torch.float32)
-            counts_h = counts.tolist()            # host sync: buffer sizes for the payload exchange
+            counts_h = metas[:, 0].tolist()       # host sync: buffer sizes for the payload exchange
             cap = max(max(counts_h), 1)
             recv = torch.empty((world * cap, self.ROW), dtype=torch.float32, device=dev)
-            # [cap,16] blocks along dim 0; asynchronous, so that the zero-fill below overlaps the transfer
+            # [cap,16] blocks along dim 0; asynchronous, so that the local work below overlaps the transfer
             work = dist.all_gather_into_tensor(recv, self.rows[:cap], group=self.group, async_op=True)
             recv = recv.view(world, cap, self.ROW)
             self.last_bytes = world * cap * self.ROW * 4
         else:
-            counts_h = [int(self.count.item())]
-            cams, recv, work = cam_pos[None], self.rows[None], None
+            counts_h = [int(self.count.item())] if rebuild_own else [0]
             self.last_bytes = 0
-        # dense, replicated sums: one zero-filled buffer, one accumulate launch per sender
-        sizes = [3 * N, 4 * N, 3 * N, N, (3 * K * N if v_rgb is not None else 0)]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        o_means, o_quats, o_scales, o_opac, o_coeffs = torch.split(flat, sizes)
+        # this rank's own coefficient gradient: dense and WRITTEN (not accumulated), so it doubles as the zero-fill
+        v_coeffs = None
+        if v_rgb is not None:
+            if local_coeff_grad is not None:
+                v_coeffs = local_coeff_grad()
+                assert v_coeffs.shape == (N, K, 3) and v_coeffs.is_contiguous()
+            else:
+                # no local SH backward supplied: expand the own rows' v_rgb through the same kernel (its geometry
+                # part goes to a scratch buffer: the own geometry gradients are already in the dense tensors)
+                v_coeffs = torch.zeros((N, K, 3), dtype=torch.float32, device=dev)
+                scratch = torch.zeros(11 * N, dtype=torch.float32, device=dev)
+                s_m, s_q, s_s, s_o = torch.split(scratch, [3 * N, 4 * N, 3 * N, N])
+                call("mtgs_dp_accumulate", counts_h[self.rank if world > 1 else 0], ptr(self.rows), N, K, int(sh_degree),
+                     ptr(means), ptr(cam_pos), ptr(s_m), ptr(s_q), ptr(s_s), ptr(s_o), ptr(v_coeffs), st)
         if work is not None:
             work.wait()
         for r in range(world):
+            if world == 1 or r == self.rank:
+                continue
             call("mtgs_dp_accumulate", counts_h[r], ptr(recv[r]), N, K, int(sh_degree), ptr(means), ptr(cams[r]),
-                 ptr(o_means), ptr(o_quats), ptr(o_scales), ptr(o_opac), ptr(o_coeffs) if v_rgb is not None else None, st)
-        return (o_means.view(N, 3), o_quats.view(N, 4), o_scales.view(N, 3), o_opac.view(N),
-                o_coeffs.view(N, K, 3) if v_rgb is not None else None)
+                 ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opacities), ptr(v_coeffs), st)
+        return v_means, v_quats, v_scales, v_opacities, v_coeffs
 
 
 def all_reduce_stats(sum_tensors: Iterable[torch.Tensor] = (), max_tensors: Iterable[torch.Tensor] = (),

@@ -53,9 +53,16 @@ def _worker(rank, world, port, out_dir):
     for t in dense.values():
         dist.all_reduce(t)
     ex = mdist.SparseGradExchange(N, K, dev)
-    o = ex.exchange(info["radii"][0], P["means"].detach(), cam_pos, P["means"].grad, P["quats"].grad, P["scales"].grad,
-                    P["opacities"].grad, sh_out.grad, 3)
+    loc = {k: P[k].grad.clone() for k in ("means", "quats", "scales", "opacities")}
+    o = ex.exchange(info["radii"][0], P["means"].detach(), cam_pos, loc["means"], loc["quats"], loc["scales"],
+                    loc["opacities"], sh_out.grad, 3)                       # coefficient gradient rebuilt from zeros
     sparse = dict(zip(("means", "quats", "scales", "opacities", "coeffs"), o))
+    loc2 = {k: P[k].grad.clone() for k in ("means", "quats", "scales", "opacities")}
+    own_coeffs = P["coeffs"].grad.clone()                                    # the local SH backward from above
+    o2 = ex.exchange(info["radii"][0], P["means"].detach(), cam_pos, loc2["means"], loc2["quats"], loc2["scales"],
+                     loc2["opacities"], sh_out.grad, 3, local_coeff_grad=lambda: own_coeffs)
+    for a_, b_ in zip(o, o2):
+        assert torch.allclose(a_, b_, atol=1e-5, rtol=1e-5)
     res = {}
     for k in dense:
         scale = float(dense[k].abs().max())
@@ -95,6 +102,7 @@ def test_sparse_exchange_single_process(hip_lib):
     coeffs = torch.zeros(N, K, 3, device=dev, requires_grad=True)
     spherical_harmonics(2, means - cam, coeffs).backward(v_rgb)
     ex = mdist.SparseGradExchange(N, K, dev)
+    ref = [t.clone() for t in (v_means, v_quats, v_scales, v_opac)] + [coeffs.grad]
     o = ex.exchange(radii, means, cam, v_means, v_quats, v_scales, v_opac, v_rgb, 2)
-    for got, ref in zip(o, (v_means, v_quats, v_scales, v_opac, coeffs.grad)):
-        assert torch.allclose(got, ref, atol=1e-6, rtol=1e-5)
+    for got, r in zip(o, ref):
+        assert torch.allclose(got, r, atol=1e-6, rtol=1e-5)
