@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--variant", default="mtgs")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--extra-channels", type=int, default=0, help="extra colour channels (MTGS.py blends 3 normal channels too)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     W, H = args.width, args.height
@@ -79,6 +80,8 @@ def main():
     if mtgs:
         opac = (opac * comps).contiguous()
     cols = colors[None].contiguous()
+    if args.extra_channels:
+        cols = torch.cat([cols, torch.rand(1, N, args.extra_channels, device=dev)], -1).contiguous()
     DC = cols.shape[-1]
     dep = depths if mtgs else None
     D = DC + (1 if mtgs else 0)
