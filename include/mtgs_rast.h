@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 1
+#define MTGS_RAST_ABI_VERSION 2
 
 enum {
     MTGS_OK = 0,
@@ -77,7 +77,10 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * written by the forward, and the backward takes v_opac_eff[C,N] (nullable) and writes
  * v_opacities[N] (nullable), folding v_opac_eff * opacities into the compensation VJP.
  * bwd: v_means[N,3] v_quats[N,4] v_scales[N,3] are OVERWRITTEN (summed over cameras);
- * v_viewmats[C,4,4] nullable, overwritten. */
+ * v_viewmats[C,4,4] nullable, overwritten.
+ * grad_row_strides (HOST pointer, nullable): row strides in floats of the incoming gradients
+ * {v_means2d, v_depths, v_conics, v_compensations, v_opac_eff}; NULL = dense {2,1,3,1,1}.  Lets the
+ * caller hand over views of the interleaved buffer mtgs_blend_bwd accumulated into (see there). */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
@@ -89,7 +92,7 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *opacities, const float *v_means2d, const float *v_depths,
                      const float *v_conics, const float *v_compensations, const float *v_opac_eff,
                      float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
-                     float *v_opacities, void *stream);
+                     float *v_opacities, const int64_t *grad_row_strides, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -167,6 +170,11 @@ int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int ti
  * bwd: v_means2d[C,N,2] v_conics[C,N,3] v_colors[C,N,D] v_depths[C,N] v_opacities[C,N] and
  * v_means2d_abs (nullable, absgrad) must be ZERO-FILLED by the caller; gradients are accumulated with
  * atomics.  render (the forward output) is only read when ed_normalize is set.
+ * grad_row_strides (HOST pointer, nullable): row strides in floats of {v_means2d, v_means2d_abs, v_conics,
+ * v_colors, v_depths, v_opacities}; NULL = the dense gsplat arrays {2,2,3,D,1,1}.  The memory-side fp32
+ * atomics cost one request per 64-byte line an instruction touches, so callers should interleave the six
+ * outputs in ONE buffer of 16-float rows (xy, |xy|, conic, opacity, colour.., depth) and pass views of it:
+ * one line per (tile, Gaussian) instead of six (5x less atomic time on MI355X).
  * tile_order[C*tile_h*tile_w] (nullable) is a permutation of the tile indices giving the order in
  * which tiles are dispatched (results do not depend on it); mtgs_tile_schedule fills it with the
  * tiles sorted by decreasing list length (no gsplat counterpart: a scheduling aid for the
@@ -186,7 +194,8 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    const float *alphas, const int32_t *last_ids, const float *render,
                    const float *v_render, const float *v_alphas, float *v_means2d,
                    float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
-                   float *v_opacities, const int32_t *tile_order, void *stream);
+                   float *v_opacities, const int64_t *grad_row_strides, const int32_t *tile_order,
+                   void *stream);
 
 /* ---- view-parallel data parallelism: sparse, factored gradient exchange (mtgs_amd/csrc/dp.hip) ------
  * No gsplat counterpart.  Rows are 16 floats: v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, spare,

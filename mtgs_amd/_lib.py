@@ -6,14 +6,17 @@ raised.  Nothing here (or anywhere under mtgs_amd/) touches oracle/.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import torch
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libmtgs_rast.so"
+# MTGS_RAST_LIB: development override (A/B builds of the library, scripts/build_variant.py)
+LIB_PATH = Path(os.environ["MTGS_RAST_LIB"]) if os.environ.get("MTGS_RAST_LIB") else _PKG / "libmtgs_rast.so"
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+_i64p = C.POINTER(C.c_int64)  # HOST array (row strides), nullable
 
 # name -> argtypes (restype is int for all but the two introspection calls)
 _SIGNATURES = {
@@ -22,7 +25,7 @@ _SIGNATURES = {
     "mtgs_project_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
-                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp],
     "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_isect_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -46,10 +49,10 @@ _SIGNATURES = {
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mtgs_blend_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
-                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -80,6 +83,11 @@ def load() -> C.CDLL:
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+def host_i64(values):
+    """HOST int64 array argument (None -> NULL)."""
+    return None if values is None else (C.c_int64 * len(values))(*values)
 
 
 def stream_of(t: torch.Tensor):

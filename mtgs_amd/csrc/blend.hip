@@ -96,7 +96,10 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
             op = opacities[g[r]];
             // alpha = min(0.999, op e^{-s2/2}) >= 1/255  <=>  s2 <= 2 ln(255 op)
             s2max = 2.0f * 0.6931471805599453f * __log2f(op * (1.0f / kAlphaMin));
-            if (CULL) {
+            // opacity < 1/255 (or NaN): alpha >= 1/255 is unreachable.  Dropped here unconditionally -- the
+            // per-pixel range test compares bit patterns and relies on s2max >= 0.
+            keep = s2max >= 0.f;
+            if (CULL && keep) {
                 // Exact test: does the ellipse {q(d) = a dx^2 + 2 b dx dy + c dy^2 <= s2max} reach the rectangle
                 // of this tile's pixel centres?  q is convex, so its minimum over the rectangle is 0 if the mean
                 // lies inside, otherwise it is attained on one of the four edges (a clamped 1-D parabola each).
@@ -116,7 +119,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                     };
                     const float qmin = inside ? 0.f : fminf(fminf(edge_x(X0), edge_x(X1)), fminf(edge_y(Y0), edge_y(Y1)));
                     // margin: never drop a candidate the per-pixel test (s2 <= s2max) could still accept
-                    keep = s2max >= 0.f && qmin <= s2max * 1.001f + 1e-2f;
+                    keep = qmin <= s2max * 1.001f + 1e-2f;
                 }
             }
         }
@@ -159,15 +162,60 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
     return CULL ? count : n_cand;
 }
 
-// One Gaussian at one pixel.  u = a dx + b dy and w = b dx + c dy (kept: the backward needs them
-// for the mean gradient);  s2 = dx u + dy w = 2 sigma.
-struct GaussEval { float u, w, s2; };
-__device__ __forceinline__ GaussEval eval_gauss(float adx, float bdx, float b, float c, float dx, float dy) {
-    GaussEval e;
-    e.u = adx + b * dy;
-    e.w = bdx + c * dy;
-    e.s2 = dx * e.u + dy * e.w;
-    return e;
+// One Gaussian at one pixel.  With d = mean - pixel centre and the conic (a, b, c):
+//   s2 = a dx^2 + 2 b dx dy + c dy^2 = 2 sigma,  evaluated as  q0 + dy (2 b dx + c dy),  q0 = a dx^2
+// (dx, q0 and 2 b dx are shared by the pixels of a lane: 3 VALU ops per pixel).  The forward and the backward
+// kernel use the same expression, so they take identical per-pixel decisions.
+__device__ __forceinline__ float eval_s2(float q0, float b2dx, float c, float dy) {
+    return fmaf(dy, fmaf(c, dy, b2dx), q0);
+}
+// "0 <= s2 <= s2max" as ONE unsigned integer compare of the bit patterns: non-negative floats order like their
+// bits, while negative values, NaN and (for finite s2max) +inf all have larger patterns.  Returns the wave's
+// lane mask straight from v_cmp (an SGPR pair; no per-lane boolean is materialised).
+__device__ __forceinline__ unsigned long long in_range_mask(float s2, float s2max) {
+    return __builtin_amdgcn_uicmp(__float_as_uint(s2), __float_as_uint(s2max), 37 /* ICMP_ULE */);
+}
+// Colour row of staged entry t.  The loads are issued by hand (inline asm ds_read_b128) at the top of the
+// entry and waited for right before the any-lane validity branch, so that their LDS latency overlaps the ~20
+// VALU ops of the validity test: left to the compiler they sink behind the branch (or next to the wait) and
+// every entry stalls on LDS.  The compiler's own lgkmcnt bookkeeping stays conservative with an extra
+// in-flight LDS load (the counter only over-counts), and the destination registers are live between the two
+// asm statements, so nothing else is allocated to them while the load is in flight.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_offset(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+#ifndef MTGS_EARLY_COLOR_LOAD
+#define MTGS_EARLY_COLOR_LOAD 1
+#endif
+template <int D, int REC>
+struct ColorRow {
+    static constexpr int NQ = (REC - 8) / 4;
+    f32x4 q[NQ];
+    // `anchor` is a value the validity test depends on (the mean's x): naming it as an in/out operand keeps the
+    // instruction scheduler from moving the load below the test.
+    __device__ __forceinline__ void load(const float *s_rec, int t, float &anchor) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (MTGS_EARLY_COLOR_LOAD)
+                asm volatile("ds_read_b128 %0, %2" : "=v"(q[i]), "+v"(anchor) : "v"(lds_offset(s_rec + t * REC + 8 + 4 * i)));
+            else
+                q[i] = *reinterpret_cast<const f32x4 *>(s_rec + t * REC + 8 + 4 * i);
+        }
+    }
+    __device__ __forceinline__ void wait() {
+        if (MTGS_EARLY_COLOR_LOAD) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[i]));
+        }
+    }
+    __device__ __forceinline__ float operator[](int k) const { return q[k / 4][k % 4]; }
+};
+// base + row * stride_bytes with one v_mad_u64_u32 (32 x 32 + 64 bits)
+__device__ __forceinline__ float *row_address(float *base, uint32_t row, uint32_t stride_bytes) {
+    uint64_t addr, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(addr), "=s"(carry) : "v"(row), "v"(stride_bytes), "v"((uint64_t)base));
+    return reinterpret_cast<float *>(addr);
 }
 constexpr float kHalfLog2e = 0.5f * 1.4426950408889634f;  // exp(-s2/2) = exp2(-s2 * log2(e)/2)
 
@@ -233,45 +281,39 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
         for (int r = 0; r < NR; ++r)
             if (b0 + CAND + r * NT + tid < end) g_next[r] = flatten_ids[b0 + CAND + r * NT + tid];
         __syncthreads();
-        // software pipeline: the record of entry t+1 is read from LDS while entry t is processed
-        float4 n0 = *reinterpret_cast<const float4 *>(s_rec), n1 = *reinterpret_cast<const float4 *>(s_rec + 4);
-        for (int t = 0; t < bsz; ++t) {
-            const float4 r0 = n0, r1 = n1;
-            if (t + 1 < bsz) {
-                n0 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC);
-                n1 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC + 4);
-            }
-            const float dx = r0.x - px;
+        // One staged entry against the lane's pixels; returns true once every pixel of the wave is finished.
+        auto entry = [&](const float4 &r0, const float4 &r1, const int t) -> bool {
+            ColorRow<D, REC> col;
+            float mx = r0.x;
+            col.load(s_rec, t, mx);
+            const float dx = mx - px;
             const float adx = r0.z * dx, bdx = r0.w * dx;
+            const float q0 = adx * dx, b2dx = bdx + bdx;
             float s2[PPL];
-            bool valid[PPL];
             unsigned long long vmask[PPL], any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                const GaussEval e = eval_gauss(adx, bdx, r0.w, r1.x, dx, r0.y - py[p]);
-                s2[p] = e.s2;
-                valid[p] = e.s2 >= 0.f && e.s2 <= r1.z;
-                vmask[p] = __builtin_amdgcn_ballot_w64(valid[p]);
+                s2[p] = eval_s2(q0, b2dx, r1.x, r0.y - py[p]);  // finished pixel: py = +inf -> s2 = +inf / NaN
+                vmask[p] = in_range_mask(s2[p], r1.z);
                 any |= vmask[p];
             }
-            if (any == 0) continue;
-            float col[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 8 + k];
+            col.wait();
+            if (any == 0) return false;
             const int32_t idx = __float_as_int(r1.w);
             unsigned long long stopped = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 if (vmask[p] != 0) {  // wave-uniform: skip the strips of the tile this Gaussian does not reach
                     // invalid lanes run with alpha = 0: T, acc and last are unchanged, and T(1-0) > 1e-4
-                    const float alpha = valid[p] ? fminf(kAlphaMax, r1.y * __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p])) : 0.f;
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask[p]);
+                    const float alpha = valid ? fminf(kAlphaMax, r1.y * __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p])) : 0.f;
                     const float next_T = T[p] * (1.f - alpha);
                     const bool stop = next_T <= kTMin;
                     stopped |= __builtin_amdgcn_ballot_w64(stop);
                     const float w = stop ? 0.f : alpha * T[p];
 #pragma unroll
                     for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
-                    last[p] = (valid[p] && !stop) ? idx : last[p];
+                    last[p] = (valid && !stop) ? idx : last[p];
                     T[p] = stop ? T[p] : next_T;
                     py[p] = stop ? INFINITY : py[p];
                 }
@@ -280,8 +322,20 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
                 bool ad = true;
 #pragma unroll
                 for (int p = 0; p < PPL; ++p) ad = ad && py[p] == INFINITY;
-                if (__all(ad)) break;
+                if (__all(ad)) return true;
             }
+            return false;
+        };
+        // Entries are consumed two per iteration from two alternating register sets (A, B): the record of the
+        // next entry is in flight while the current one is processed, without register copies.
+        auto rec4 = [&](int t, int q) { return *reinterpret_cast<const float4 *>(s_rec + t * REC + 4 * q); };
+        float4 ra0 = rec4(0, 0), ra1 = rec4(0, 1), rb0 = ra0, rb1 = ra1;
+        for (int t = 0; t < bsz; t += 2) {
+            if (t + 1 < bsz) { rb0 = rec4(t + 1, 0); rb1 = rec4(t + 1, 1); }
+            if (entry(ra0, ra1, t)) break;
+            if (t + 1 >= bsz) break;
+            if (t + 2 < bsz) { ra0 = rec4(t + 2, 0); ra1 = rec4(t + 2, 1); }
+            if (entry(rb0, rb1, t + 1)) break;
         }
     }
 #pragma unroll
@@ -303,6 +357,13 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row strides (bytes) of the six gradient outputs.  Dense gsplat arrays by default; the Python layer passes
+// views of ONE interleaved [C,N,16] buffer instead (xy, |xy|, conic, opacity, colour.. in reduction order), so
+// that the 12 lanes of an entry's atomic instruction fall into a single 64-byte line: measured 0.06 ns per
+// (instruction x line) chip-wide, i.e. 638 us for this kernel's ~2M instructions on six dense arrays against
+// 126 us on one line (scripts/dev/atomic_bench.hip) -- the atomics, not VALU, bounded the dense layout.
+struct GradRowBytes { uint32_t means2d, means2d_abs, conics, colors, depths, opacities; };
+
 // Gradient components per Gaussian, in reduction order: xy(2) |xy|(2) conic(3) opacity(1) colour(D)
 template <int D>
 struct GradLayout {
@@ -322,7 +383,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
     const float *__restrict__ v_render, const float *__restrict__ v_alphas,
     float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
     float *__restrict__ v_colors, float *__restrict__ v_depths, float *__restrict__ v_opacities,
-    const int32_t *__restrict__ order) {
+    const GradRowBytes gs, const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     constexpr bool CULL = true;
     constexpr int CAND = NT == 64 ? 128 : 256, NRD = CAND / NT;
@@ -399,14 +460,14 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
     const int a_col = lane & 15, a_row = lane >> 4;
     const int j = BATCH_FLUSH ? (tid & 15) : 4 * a_col + a_row;
     float *a_base = nullptr;
-    int a_stride = 0;
+    uint32_t a_stride_bytes = 0;
     if ((BATCH_FLUSH || a_col < NR) && j < NV) {
-        if (j < 2) { a_base = v_means2d + j; a_stride = 2; }
-        else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride = 2; }
-        else if (j < 7) { a_base = v_conics + (j - 4); a_stride = 3; }
-        else if (j < 8) { a_base = v_opacities; a_stride = 1; }
-        else if (j - 8 < DC) { a_base = v_colors + (j - 8); a_stride = DC; }
-        else { a_base = v_depths; a_stride = 1; }
+        if (j < 2) { a_base = v_means2d + j; a_stride_bytes = gs.means2d; }
+        else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride_bytes = gs.means2d_abs; }
+        else if (j < 7) { a_base = v_conics + (j - 4); a_stride_bytes = gs.conics; }
+        else if (j < 8) { a_base = v_opacities; a_stride_bytes = gs.opacities; }
+        else if (j - 8 < DC) { a_base = v_colors + (j - 8); a_stride_bytes = gs.colors; }
+        else { a_base = v_depths; a_stride_bytes = gs.depths; }
     }
 
     int32_t g_next[NRD];
@@ -428,34 +489,33 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             for (int e = tid; e < NW * bsz * 4; e += NT) z[(e / (bsz * 4)) * (CAND * 4) + e % (bsz * 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        // software pipeline: the record of entry t+1 is read from LDS while entry t is processed
-        float4 n0 = *reinterpret_cast<const float4 *>(s_rec), n1 = *reinterpret_cast<const float4 *>(s_rec + 4);
-        for (int t = 0; t < bsz; ++t) {
-            const float4 r0 = n0, r1 = n1;
-            if (t + 1 < bsz) {
-                n0 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC);
-                n1 = *reinterpret_cast<const float4 *>(s_rec + (t + 1) * REC + 4);
-            }
+        auto entry = [&](const float4 &r0, const float4 &r1, const int t) {
+            ColorRow<D, REC> col;
+            float mx = r0.x;
+            col.load(s_rec, t, mx);
+            int32_t gid;  // Gaussian row for the atomics at the end of the entry, fetched the same way
+            if (MTGS_EARLY_COLOR_LOAD)
+                asm volatile("ds_read_b32 %0, %2" : "=v"(gid), "+v"(mx) : "v"(lds_offset(s_id + t)));
+            else
+                gid = s_id[t];
             const int32_t idx = __float_as_int(r1.w);
             const float opac = r1.y;
-            const float dx = r0.x - px;
+            const float dx = mx - px;
             const float adx = r0.z * dx, bdx = r0.w * dx;
-            float dy[PPL];
-            GaussEval e[PPL];
-            bool valid[PPL];
+            const float q0 = adx * dx, b2dx = bdx + bdx;
+            float dy[PPL], s2[PPL];
             unsigned long long vmask[PPL], any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 dy[p] = r0.y - py[p];
-                e[p] = eval_gauss(adx, bdx, r0.w, r1.x, dx, dy[p]);
-                valid[p] = idx <= bin_final[p] && e[p].s2 >= 0.f && e[p].s2 <= r1.z;
-                vmask[p] = __builtin_amdgcn_ballot_w64(valid[p]);
+                s2[p] = eval_s2(q0, b2dx, r1.x, dy[p]);
+                // contributes to this pixel: not newer than the pixel's last contributor, and alpha >= 1/255
+                vmask[p] = in_range_mask(s2[p], r1.z) & __builtin_amdgcn_sicmp(bin_final[p], idx, 39 /* ICMP_SGE */);
                 any |= vmask[p];
             }
-            if (any == 0) continue;
-            float col[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) col[k] = s_rec[t * REC + 8 + k];
+            col.wait();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gid));
+            if (any == 0) return;
             float gv[4 * NR];
 #pragma unroll
             for (int k = 0; k < 4 * NR; ++k) gv[k] = 0.f;
@@ -464,13 +524,14 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             float S0 = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                // Wave-uniform branch per pixel slot; inside, invalid lanes run with alpha = 0 (then
-                // 1/(1-alpha) == 1 exactly, fac == 0: T and Bq are unchanged and every contribution is
-                // 0), so there is no exec-mask divergence in the gradient math.
+                // Wave-uniform branch per pixel slot; inside, invalid lanes run with vis = 0, hence alpha = 0
+                // (then 1/(1-alpha) == 1 exactly, fac == 0: T and Bq are unchanged and every contribution
+                // is 0), so there is no exec-mask divergence in the gradient math.
                 if (vmask[p] != 0) {
-                    const float vis = __builtin_amdgcn_exp2f(-kHalfLog2e * e[p].s2);
+                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask[p]);
+                    const float vis = valid ? __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]) : 0.f;
                     const float alpha_raw = opac * vis;
-                    const float alpha = valid[p] ? fminf(kAlphaMax, alpha_raw) : 0.f;
+                    const float alpha = fminf(kAlphaMax, alpha_raw);
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[p] *= ra;
                     const float fac = alpha * T[p];
@@ -483,16 +544,16 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
                     // dL/dalpha_i = T_i <c_i, vr> - (<behind, vr> - T_final (va - <bg, vr>)) / (1 - alpha_i)
                     const float v_alpha = A * T[p] - ra * Bq[p];
                     Bq[p] += fac * A;
-                    // alpha clamped at 0.999 (or lane invalid): no gradient through sigma / opacity
-                    const bool live = valid[p] && alpha_raw <= kAlphaMax;
-                    const float v_sigma = live ? -alpha_raw * v_alpha : 0.f;
+                    // alpha clamped at 0.999: no gradient through sigma / opacity (invalid lanes: vis == 0)
+                    const float g = alpha_raw <= kAlphaMax ? v_alpha : 0.f;
+                    const float v_sigma = -alpha_raw * g;
                     const float vsdy = v_sigma * dy[p];
                     S0 += v_sigma;
                     S1 += vsdy;
                     S2 += vsdy * dy[p];
-                    gv[2] += fabsf(v_sigma * e[p].u);
-                    gv[3] += fabsf(v_sigma * e[p].w);
-                    gv[7] += live ? vis * v_alpha : 0.f;
+                    gv[2] += fabsf(v_sigma * fmaf(r0.w, dy[p], adx));   // |v_sigma u|,  u = a dx + b dy
+                    gv[3] += fabsf(v_sigma * fmaf(r1.x, dy[p], bdx));   // |v_sigma w|,  w = b dx + c dy
+                    gv[7] += vis * g;
                 }
             }
             // sum_p v_sigma u_p with u_p = a dx + b dy_p (and w_p = b dx + c dy_p); conic: 1/2 v_sigma d d^T
@@ -502,15 +563,37 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             gv[5] = dx * S1;
             gv[6] = 0.5f * S2;
             float red[NR];
+#if defined(MTGS_EXP_NO_REDUCE)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) red[i] = gv[4 * i] + gv[4 * i + 1] + gv[4 * i + 2] + gv[4 * i + 3];
+#else
             wave_reduce_x4<NR>(gv, red);
+#endif
             float val = red[0];
 #pragma unroll
             for (int i = 1; i < NR; ++i) val = (a_col == i) ? red[i] : val;
             if (BATCH_FLUSH) {
                 if (a_col < NR) s_grad[((tid >> 6) * CAND + t) * 16 + 4 * a_col + a_row] = val;
             } else {
-                if (a_base) unsafeAtomicAdd(a_base + (int64_t)s_id[t] * a_stride, val);
+#if defined(MTGS_EXP_NO_ATOMIC)
+                asm volatile("" ::"v"(val), "v"(gid));
+#elif defined(MTGS_EXP_STORE)
+                if (a_base) *row_address(a_base, (uint32_t)gid, a_stride_bytes) = val;
+#else
+                if (a_base) unsafeAtomicAdd(row_address(a_base, (uint32_t)gid, a_stride_bytes), val);
+#endif
             }
+        };
+        // Entries are consumed two per iteration from two alternating register sets (A, B): the record of the
+        // next entry is in flight while the current one is processed, without register copies.
+        auto rec4 = [&](int t, int q) { return *reinterpret_cast<const float4 *>(s_rec + t * REC + 4 * q); };
+        float4 ra0 = rec4(0, 0), ra1 = rec4(0, 1), rb0 = ra0, rb1 = ra1;
+        for (int t = 0; t < bsz; t += 2) {
+            if (t + 1 < bsz) { rb0 = rec4(t + 1, 0); rb1 = rec4(t + 1, 1); }
+            entry(ra0, ra1, t);
+            if (t + 1 >= bsz) break;
+            if (t + 2 < bsz) { ra0 = rec4(t + 2, 0); ra1 = rec4(t + 2, 1); }
+            entry(rb0, rb1, t + 1);
         }
         if (BATCH_FLUSH) {
             __syncthreads();
@@ -519,7 +602,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += s_grad[(w * CAND + t) * 16 + j];
-                if (a_base && v != 0.f) unsafeAtomicAdd(a_base + (int64_t)s_id[t] * a_stride, v);
+                if (a_base && v != 0.f) unsafeAtomicAdd(row_address(a_base, (uint32_t)s_id[t], a_stride_bytes), v);
             }
         }
     }
@@ -545,13 +628,13 @@ int launch_bwd(int C, const float *means2d, const float *conics, const float *co
                int H, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
                const float *alphas, const int32_t *last_ids, const float *render, const float *v_render,
                const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
-               float *v_depths, float *v_opacities, const int32_t *order, hipStream_t st) {
+               float *v_depths, float *v_opacities, const GradRowBytes gs, const int32_t *order, hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
     blend_bwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(
         C, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
         alphas, last_ids, render, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_depths,
-        v_opacities, order);
+        v_opacities, gs, order);
     return 0;
 }
 
@@ -658,7 +741,8 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
                               int64_t M, const float *alphas, const int32_t *last_ids, const float *render,
                               const float *v_render, const float *v_alphas, float *v_means2d,
                               float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
-                              float *v_opacities, const int32_t *tile_order, void *stream) {
+                              float *v_opacities, const int64_t *grad_row_strides, const int32_t *tile_order,
+                              void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_bwd: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
@@ -673,10 +757,20 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
                      (v_depths || !depths) && v_opacities,
                  MTGS_EINVAL, "mtgs_blend_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    const int64_t dense[6] = {2, 2, 3, D, 1, 1};
+    const int64_t min_w[6] = {2, 2, 3, D, 1, 1};
+    uint32_t sb[6];
+    for (int i = 0; i < 6; ++i) {
+        const int64_t rs = grad_row_strides ? grad_row_strides[i] : dense[i];
+        MTGS_REQUIRE(rs >= min_w[i] && rs < ((int64_t)1 << 30), MTGS_EINVAL,
+                     "mtgs_blend_bwd: grad_row_strides[%d]=%lld (row width %lld)", i, (long long)rs, (long long)min_w[i]);
+        sb[i] = (uint32_t)(rs * 4);
+    }
+    const GradRowBytes gs{sb[0], sb[1], sb[2], sb[3], sb[4], sb[5]};
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
     MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, render, v_render, v_alphas,
-                    v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, tile_order, st);
+                    v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, gs, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_bwd");
     return MTGS_OK;
 }

@@ -30,6 +30,8 @@ __device__ __forceinline__ void block_reduce_viewmat(float (&vals)[12], float *_
         acc[k] += v;
     }
 }
+// row strides (floats) of the incoming gradients: dense gsplat arrays, or views of an interleaved buffer
+struct ProjGradStrides { int64_t means2d, depths, conics, compensations, opac_eff; };
 constexpr int PROJ_MAX_CAMS = 64;  // cameras whose v_viewmat is accumulated in LDS (MTGS: 1)
 
 // One thread per Gaussian, looping over cameras so that v_means / v_quats / v_scales are written
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
     const float *__restrict__ v_depths, const float *__restrict__ v_conics,
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff,
     float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
-    float *__restrict__ v_viewmats, float *__restrict__ v_opacities) {
+    float *__restrict__ v_viewmats, float *__restrict__ v_opacities, const ProjGradStrides gs) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[PROJ_MAX_CAMS * 12];
     __shared__ int s_list[PROJ_BLOCK];
@@ -103,17 +105,18 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
             ProjState s;
             proj_common(m, q, sc, cam, W, H, s);
             const float a = conics[idx * 3], b = conics[idx * 3 + 1], cc = conics[idx * 3 + 2];
-            const float va = v_conics[idx * 3], vb = 0.5f * v_conics[idx * 3 + 1], vc = v_conics[idx * 3 + 2];
+            const float *vcon = v_conics + idx * gs.conics;
+            const float va = vcon[0], vb = 0.5f * vcon[1], vc = vcon[2];
             const float t00 = a * va + b * vb, t01 = a * vb + b * vc, t10 = b * va + cc * vb, t11 = b * vb + cc * vc;
             float vcov[4];
             vcov[0] = -(t00 * a + t01 * b); vcov[1] = -(t00 * b + t01 * cc);
             vcov[2] = -(t10 * a + t11 * b); vcov[3] = -(t10 * b + t11 * cc);
             // opac_eff = opacity * compensation: the product rule feeds the compensation VJP
-            if (v_opac_eff) ao += v_opac_eff[idx] * (compensations ? compensations[idx] : 1.f);
+            if (v_opac_eff) ao += v_opac_eff[idx * gs.opac_eff] * (compensations ? compensations[idx] : 1.f);
             if (compensations && (v_compensations || v_opac_eff)) {
                 const float comp = compensations[idx];
-                const float vcomp = (v_compensations ? v_compensations[idx] : 0.f) +
-                                    (v_opac_eff ? v_opac_eff[idx] * opac : 0.f);
+                const float vcomp = (v_compensations ? v_compensations[idx * gs.compensations] : 0.f) +
+                                    (v_opac_eff ? v_opac_eff[idx * gs.opac_eff] * opac : 0.f);
                 const float det_conic = a * cc - b * b;
                 const float v_sqr = vcomp * 0.5f / (comp + kCompEps);
                 const float omc = 1.f - comp * comp;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
             const float *J = s.J;
             const float x = s.mean_c[0], y = s.mean_c[1];
             const float rz = s.rz, rz2 = s.rz2, rz3 = rz2 * rz, tx = s.tx, ty = s.ty;
-            const float2 vm2 = reinterpret_cast<const float2 *>(v_means2d)[idx];
+            const float2 vm2 = make_float2(v_means2d[idx * gs.means2d], v_means2d[idx * gs.means2d + 1]);
             float G[6], G2[6];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
             if (!s.y_clamped) v_mean_c[1] += -cam.fy * rz2 * vJ[5];
             else v_mean_c[2] += -cam.fy * rz3 * vJ[5] * ty;
             v_mean_c[2] += ((-cam.fx * rz2 * vJ[0] - cam.fy * rz2 * vJ[4]) + 2.f * cam.fx * tx * rz3 * vJ[2]) + 2.f * cam.fy * ty * rz3 * vJ[5];
-            v_mean_c[2] += v_depths[idx];
+            v_mean_c[2] += v_depths[idx * gs.depths];
             const float *R = cam.R;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -241,7 +244,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const float *v_means2d, const float *v_depths, const float *v_conics,
                                 const float *v_compensations, const float *v_opac_eff, float *v_means,
                                 float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities,
-                                void *stream) {
+                                const int64_t *grad_row_strides, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -257,12 +260,20 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                  "mtgs_project_bwd: v_compensations given without compensations");
     MTGS_REQUIRE(!v_opac_eff || (opacities && v_opacities), MTGS_EINVAL,
                  "mtgs_project_bwd: v_opac_eff needs opacities and v_opacities");
+    const int64_t dense[5] = {2, 1, 3, 1, 1};
+    int64_t rs[5];
+    for (int i = 0; i < 5; ++i) {
+        rs[i] = grad_row_strides ? grad_row_strides[i] : dense[i];
+        MTGS_REQUIRE(rs[i] >= dense[i], MTGS_EINVAL, "mtgs_project_bwd: grad_row_strides[%d]=%lld (row width %lld)", i,
+                     (long long)rs[i], (long long)dense[i]);
+    }
+    const ProjGradStrides gs{rs[0], rs[1], rs[2], rs[3], rs[4]};
     const unsigned grid = (unsigned)(ceil_div64(N, PROJ_BLOCK) < 2048 ? ceil_div64(N, PROJ_BLOCK) : 2048);
     project_bwd_kernel<<<grid, PROJ_BLOCK, 0, st>>>(C, N, means, quats, scales, viewmats, Ks, width,
                                                     height, eps2d, radii, conics, compensations, opacities,
                                                     v_means2d, v_depths, v_conics, v_compensations,
                                                     v_opac_eff, v_means, v_quats, v_scales, v_viewmats,
-                                                    v_opacities);
+                                                    v_opacities, gs);
     MTGS_CHECK_LAUNCH("mtgs_project_bwd");
     return MTGS_OK;
 }

@@ -18,7 +18,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import call, ptr, require_gpu, stream_of
+from ._lib import call, host_i64, ptr, require_gpu, stream_of
 
 SUPPORTED_CHANNELS = (1, 2, 3, 4, 5, 6, 7, 8, 16, 32)
 MAX_CHANNELS = 32
@@ -30,6 +30,22 @@ def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32 tensor, got {t.dtype}")
     return t.contiguous()
+
+
+def _strided_rows(t: Optional[Tensor], width: int):
+    """(tensor, row stride in floats) for a [C, N(, width)] gradient whose C*N rows are uniformly strided with
+    unit element stride -- e.g. a view of the interleaved buffer the compositing backward accumulates into;
+    anything else is made contiguous."""
+    if t is None:
+        return None, width
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32 tensor, got {t.dtype}")
+    Cn, N = t.shape[:2]
+    rs = t.stride(1)
+    ok = rs >= width and (t.dim() == 2 or t.stride(2) == 1 or width == 1) and (Cn == 1 or t.stride(0) == N * rs)
+    if N <= 1 or not ok:
+        return t.contiguous(), width
+    return t, rs
 
 
 # ------------------------------------------------------------------------------------- SH
@@ -108,11 +124,12 @@ class _FullyFusedProjection(torch.autograd.Function):
         N, Cn = means.shape[0], viewmats.shape[0]
         dev = means.device
         zeros = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        v_means2d = zeros(Cn, N, 2) if v_means2d is None else _f32c(v_means2d)
-        v_depths = zeros(Cn, N) if v_depths is None else _f32c(v_depths)
-        v_conics = zeros(Cn, N, 3) if v_conics is None else _f32c(v_conics)
-        v_comps = None if (comps is None or v_comps is None) else _f32c(v_comps)
-        v_opac_eff = None if (opacities is None or v_opac_eff is None) else _f32c(v_opac_eff)
+        # incoming gradients may be views of the compositing backward's interleaved buffer: read them in place
+        v_means2d, s_m2d = _strided_rows(zeros(Cn, N, 2) if v_means2d is None else v_means2d, 2)
+        v_depths, s_dep = _strided_rows(zeros(Cn, N) if v_depths is None else v_depths, 1)
+        v_conics, s_con = _strided_rows(zeros(Cn, N, 3) if v_conics is None else v_conics, 3)
+        v_comps, s_cmp = _strided_rows(None if (comps is None or v_comps is None) else v_comps, 1)
+        v_opac_eff, s_opa = _strided_rows(None if (opacities is None or v_opac_eff is None) else v_opac_eff, 1)
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
         v_scales = torch.empty_like(scales)
@@ -121,7 +138,8 @@ class _FullyFusedProjection(torch.autograd.Function):
         call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
              ctx.width, ctx.height, ctx.eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities),
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
-             ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities), stream_of(means))
+             ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
+             host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -306,18 +324,23 @@ class _RasterizeToPixels(torch.autograd.Function):
         Cn, N = m2d.shape[:2]
         CN = Cn * N
         v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
-        # one zero-filled buffer for every atomically accumulated gradient (a single fill kernel)
-        sizes = [2 * CN, 3 * CN, CN, DC * CN, CN if dep is not None else 0, 2 * CN if ctx.absgrad else 0]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=m2d.device)
-        parts = torch.split(flat, sizes)
-        v_means2d, v_conics, v_opacities = parts[0].view(Cn, N, 2), parts[1].view(Cn, N, 3), parts[2].view(Cn, N)
-        v_colors = parts[3].view(Cn, N, DC) if DC else None
-        v_depths = parts[4].view(Cn, N) if dep is not None else None
-        v_abs = parts[5].view(Cn, N, 2) if ctx.absgrad else None
+        # ONE zero-filled, interleaved buffer for every atomically accumulated gradient: rows of RS floats
+        #   [xy 2 | |xy| 2 | conic 3 | opacity 1 | colour DC | depth 1 | pad]   (RS = 16 for <= 8 channels)
+        # so that the 12 atomics of a (tile, Gaussian) entry land in one 64-byte line (5x cheaper than six
+        # dense arrays, include/mtgs_rast.h); the gradients handed to autograd are views of it, which the
+        # projection backward reads in place (_strided_rows).
+        DT = DC + (1 if dep is not None else 0)
+        RS = -(-(8 + DT) // 16) * 16
+        G = torch.zeros((Cn, N, RS), dtype=torch.float32, device=m2d.device)
+        v_means2d, v_abs_buf, v_conics, v_opacities = G[..., 0:2], G[..., 2:4], G[..., 4:7], G[..., 7]
+        v_colors = G[..., 8:8 + DC] if DC else None
+        v_depths = G[..., 8 + DC] if dep is not None else None
+        v_abs = v_abs_buf if ctx.absgrad else None
         call("mtgs_blend_bwd", Cn, N, DC, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), ptr(dep), int(ed),
              width, height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), flatten_ids.numel(),
              ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs),
-             ptr(v_conics), ptr(v_colors), ptr(v_depths), ptr(v_opacities), ptr(order), stream_of(m2d))
+             ptr(v_conics), ptr(v_colors), ptr(v_depths), ptr(v_opacities), host_i64([RS] * 6), ptr(order),
+             stream_of(m2d))
         if ctx.absgrad:
             ctx.means2d_ref.absgrad = v_abs
         v_bg = None

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import _lib, wrapper  # noqa: E402
-from mtgs_amd._lib import call, ptr  # noqa: E402
+from mtgs_amd._lib import call, host_i64, ptr  # noqa: E402
 from mtgs_amd.synthetic import make_camera, make_scene  # noqa: E402
 
 
@@ -97,18 +97,26 @@ def main():
     res["blend_fwd"] = timeit(fwd, args.reps)
     g = torch.Generator(device="cpu").manual_seed(1)
     vr = torch.randn(1, H, W, D, generator=g).to(dev); va = torch.randn(1, H, W, 1, generator=g).to(dev)
-    v2d = torch.zeros_like(means2d); vab = torch.zeros_like(means2d) if mtgs else None
-    vcon = torch.zeros_like(conics); vcl = torch.zeros_like(cols); vop = torch.zeros_like(opac)
-    vdp = torch.zeros_like(depths) if mtgs else None
+    if os.environ.get("DENSE_GRADS"):  # six dense gsplat-style arrays
+        v2d = torch.zeros_like(means2d); vab = torch.zeros_like(means2d) if mtgs else None
+        vcon = torch.zeros_like(conics); vcl = torch.zeros_like(cols); vop = torch.zeros_like(opac)
+        vdp = torch.zeros_like(depths) if mtgs else None
+        gstr, pstr = None, None
+    else:  # views of one interleaved buffer, as mtgs_amd.wrapper passes them
+        RS = -(-(8 + D) // 16) * 16
+        G = torch.zeros(1, N, RS, device=dev)
+        v2d, vab, vcon, vop = G[..., 0:2], (G[..., 2:4] if mtgs else None), G[..., 4:7], G[..., 7]
+        vcl, vdp = G[..., 8:8 + DC], (G[..., 8 + DC] if mtgs else None)
+        gstr, pstr = host_i64([RS] * 6), host_i64([RS, 1, RS, 1, RS])
     bwd = lambda: call("mtgs_blend_bwd", 1, N, DC, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, ptr(dep), ed,
                        W, H, 16, tw, th, ptr(off), ptr(flat), M, ptr(alphas), ptr(last), ptr(render), ptr(vr), ptr(va),
-                       ptr(v2d), ptr(vab), ptr(vcon), ptr(vcl), ptr(vdp), ptr(vop), optr, st)
+                       ptr(v2d), ptr(vab), ptr(vcon), ptr(vcl), ptr(vdp), ptr(vop), gstr, optr, st)
     res["blend_bwd"] = timeit(bwd, args.reps)
     vm_ = torch.empty_like(d["means"]); vq = torch.empty_like(d["quats"]); vs = torch.empty_like(d["scales"]); vvm = torch.empty_like(vm)
     vdep = torch.randn_like(depths); vopn = torch.empty_like(d["opacities"])
     res["project_bwd"] = timeit(lambda: call("mtgs_project_bwd", 1, N, ptr(d["means"]), ptr(d["quats"]), ptr(d["scales"]), ptr(vm), ptr(K), W, H, 0.3,
                                               ptr(radii), ptr(conics), ptr(comps), ptr(d["opacities"]), ptr(v2d), ptr(vdep), ptr(vcon), None,
-                                              ptr(vop), ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), ptr(vopn), st), args.reps)
+                                              ptr(vop), ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), ptr(vopn), pstr, st), args.reps)
     n_vis = int((radii > 0).sum())
     print(f"N={N} {W}x{H} variant={args.variant} n_vis={n_vis} M={M} D={D}")
     tot = 0.0
