@@ -106,3 +106,24 @@ def test_sparse_exchange_single_process(hip_lib):
     o = ex.exchange(radii, means, cam, v_means, v_quats, v_scales, v_opac, v_rgb, 2)
     for got, r in zip(o, ref):
         assert torch.allclose(got, r, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("exchange", ["sparse", "dense"])
+def test_bench_two_ranks_driver_launch(exchange, hip_lib):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
+    rank), with both ranks on the test box's single GPU and gloo in place of RCCL: the whole N > 1 code path
+    (init, exchange, barrier, max-over-ranks timing, ONE JSON line from rank 0) must run."""
+    import json
+    import subprocess
+    env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--n-gaussians", "50000", "--width", "640", "--height", "480", "--dp-exchange", exchange]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert "cpu_baseline" not in out and out["roofline"]["launches_timed"] == 3
+    assert exchange in out["config"]["parallelism"]
