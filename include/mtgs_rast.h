@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 2
+#define MTGS_RAST_ABI_VERSION 3
 
 enum {
     MTGS_OK = 0,
@@ -80,7 +80,18 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * v_viewmats[C,4,4] nullable, overwritten.
  * grad_row_strides (HOST pointer, nullable): row strides in floats of the incoming gradients
  * {v_means2d, v_depths, v_conics, v_compensations, v_opac_eff}; NULL = dense {2,1,3,1,1}.  Lets the
- * caller hand over views of the interleaved buffer mtgs_blend_bwd accumulated into (see there). */
+ * caller hand over views of the interleaved buffer mtgs_blend_bwd accumulated into (see there).
+ * grad_row_index[C*N] i32 (nullable): row of the incoming gradients that belongs to (camera, Gaussian) pair
+ * c*N+n (read for radii > 0 only); NULL = row c*N+n.  With mtgs_bin_compact's vis_rank the caller keeps ONE
+ * compact 64-byte gradient row per VISIBLE Gaussian (19 MB instead of 128 MB at 2M Gaussians: no dense
+ * zero-fill, atomics and re-reads stay in cache).
+ * Dense by-products (all nullable): d_means2d[C,N,2] = the incoming v_means2d rows, d_means2d_abs[C,N,2] =
+ * rows of x_means2d_abs, d_colors[C,N,x_channels] = rows of x_colors (same row index; x_row_strides = HOST
+ * {abs, colors} row strides in floats, NULL = {2, x_channels}), zeros for culled pairs -- the gradients that
+ * leave the rasterizer per Gaussian (retain_grad / absgrad / colours), expanded while their rows are read.
+ * vis_ids[n_vis] i32 + vis_ws[n_vis*12] f32 scratch (both nullable): the visible Gaussians in increasing order
+ * with grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank).  With them (and C == 1) the
+ * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced. */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
@@ -92,7 +103,10 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *opacities, const float *v_means2d, const float *v_depths,
                      const float *v_conics, const float *v_compensations, const float *v_opac_eff,
                      float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
-                     float *v_opacities, const int64_t *grad_row_strides, void *stream);
+                     float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                     const float *x_means2d_abs, const float *x_colors, int x_channels,
+                     const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
+                     const int32_t *vis_ids, int64_t n_vis, float *vis_ws, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -121,6 +135,8 @@ int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in,
  * by sorting the visible Gaussians by (camera, depth) first and then stably by tile only.
  *  mtgs_bin_compact  : vis_keys[<=C*N] i64 = cam<<32 | bits(depth), vis_ids[<=C*N] i32 = c*N+n, in
  *                      index order; totals[1] i64 (device) = n_vis<<32 | M.  ws: mtgs_scan_workspace_bytes(C*N).
+ *                      vis_rank[C*N] i32 (nullable): position of every visible c*N+n in that list (other
+ *                      entries are left untouched) -- the grad_row_index of the two backward kernels.
  *  mtgs_bin_scan     : cum[n_vis] i64 = inclusive sum of tiles_per_gauss[ids_sorted[r]].
  *  mtgs_bin_emit     : tile_keys[M] u32 = cam*n_tiles + tile, gids[M] i32, in depth order.
  *  mtgs_sort_pairs_u32 : stable LSD sort of (u32 key, i32 value) on key bits [0, key_bits).
@@ -129,7 +145,7 @@ int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in,
  *  mtgs_bin_finalize : isect_ids[M] i64 from already sorted (tile key, index) pairs and depths. */
 int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
                      const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
-                     int64_t *totals, void *ws, size_t ws_bytes, void *stream);
+                     int32_t *vis_rank, int64_t *totals, void *ws, size_t ws_bytes, void *stream);
 int mtgs_bin_scan(int64_t n_vis, const int32_t *ids_sorted, const int32_t *tiles_per_gauss,
                   int64_t *cum, void *ws, size_t ws_bytes, void *stream);
 int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted, int64_t N,
@@ -175,6 +191,7 @@ int mtgs_isect_offsets(int64_t M, const int64_t *isect_ids_sorted, int C, int ti
  * atomics cost one request per 64-byte line an instruction touches, so callers should interleave the six
  * outputs in ONE buffer of 16-float rows (xy, |xy|, conic, opacity, colour.., depth) and pass views of it:
  * one line per (tile, Gaussian) instead of six (5x less atomic time on MI355X).
+ * grad_row_index[C*N] i32 (nullable): gradient row of flatten id c*N+n (NULL = c*N+n), see mtgs_project_bwd.
  * tile_order[C*tile_h*tile_w] (nullable) is a permutation of the tile indices giving the order in
  * which tiles are dispatched (results do not depend on it); mtgs_tile_schedule fills it with the
  * tiles sorted by decreasing list length (no gsplat counterpart: a scheduling aid for the
@@ -194,8 +211,8 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    const float *alphas, const int32_t *last_ids, const float *render,
                    const float *v_render, const float *v_alphas, float *v_means2d,
                    float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
-                   float *v_opacities, const int64_t *grad_row_strides, const int32_t *tile_order,
-                   void *stream);
+                   float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                   const int32_t *tile_order, void *stream);
 
 /* ---- view-parallel data parallelism: sparse, factored gradient exchange (mtgs_amd/csrc/dp.hip) ------
  * No gsplat counterpart.  Rows are 16 floats: v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, spare,

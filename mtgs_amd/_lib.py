@@ -25,14 +25,15 @@ _SIGNATURES = {
     "mtgs_project_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
-                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp],
+                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp,
+                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_isect_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_isect_emit": [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mtgs_sort_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_sort_pairs": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "mtgs_bin_compact": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mtgs_bin_compact": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_bin_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_bin_emit": [_i64, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mtgs_sort_u32_workspace_bytes": [_i64, C.POINTER(_sz)],
@@ -49,10 +50,10 @@ _SIGNATURES = {
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mtgs_blend_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
-                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp],
+                       _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -53,12 +53,14 @@ struct CompactSink {
     int64_t N;
     int64_t *keys;
     int32_t *ids;
+    int32_t *rank;  // nullable: rank[i] = position of visible element i in the compacted list
     // called with the EXCLUSIVE packed prefix of element i
     __device__ __forceinline__ void operator()(int64_t i, int64_t excl, int64_t /*incl*/) const {
         if (radii[i] > 0) {
             const int64_t pos = excl >> 32;
             keys[pos] = ((i / N) << 32) | (int64_t)__float_as_uint(depths[i]);
             ids[pos] = (int32_t)i;
+            if (rank) rank[i] = (int32_t)pos;
         }
     }
 };
@@ -152,7 +154,7 @@ inline int bit_length_u32(uint32_t v) {
 
 extern "C" int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
                                 const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
-                                int64_t *totals, void *ws, size_t ws_bytes, void *stream) {
+                                int32_t *vis_rank, int64_t *totals, void *ws, size_t ws_bytes, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0, MTGS_EINVAL, "mtgs_bin_compact: bad sizes");
     const int64_t total = (int64_t)C * N;
     hipStream_t st = (hipStream_t)stream;
@@ -164,7 +166,7 @@ extern "C" int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const fl
     }
     MTGS_REQUIRE(radii && depths && tiles_per_gauss && vis_keys && vis_ids && ws, MTGS_EINVAL, "mtgs_bin_compact: null pointer");
     MTGS_REQUIRE(ws_bytes >= mtgs_scan::workspace_bytes(total), MTGS_EWORKSPACE, "mtgs_bin_compact: workspace too small");
-    mtgs_scan::run(total, PackedVisTiles{radii, tiles_per_gauss}, CompactSink{radii, depths, N, vis_keys, vis_ids},
+    mtgs_scan::run(total, PackedVisTiles{radii, tiles_per_gauss}, CompactSink{radii, depths, N, vis_keys, vis_ids, vis_rank},
                    (int64_t *)ws, totals, st);
     MTGS_CHECK_LAUNCH("mtgs_bin_compact");
     return MTGS_OK;

@@ -78,6 +78,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                                            const float *__restrict__ colors,
                                            const float *__restrict__ depths, int DC,
                                            const float *__restrict__ opacities,
+                                           const int32_t *__restrict__ row_index,
                                            const int32_t (&g)[CAND / NT], int64_t base, int n_cand,
                                            float tile_x0, float tile_y0) {
     constexpr int REC = Rec<D>::N;
@@ -156,7 +157,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
             float4 *dst = reinterpret_cast<float4 *>(s_rec + slot * REC);
 #pragma unroll
             for (int c = 0; c < REC / 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
-            if (s_id) s_id[slot] = g[r];
+            if (s_id) s_id[slot] = row_index ? row_index[g[r]] : g[r];  // gradient row of this Gaussian
         }
     }
     return CULL ? count : n_cand;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
         for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, end - b0);
         const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, s_wc, means2d, conics, colors, depths, DC,
-                                                              opacities, g_cur, b0, n_cand, (float)(tx * 16),
+                                                              opacities, nullptr, g_cur, b0, n_cand, (float)(tx * 16),
                                                               (float)(ty * 16));
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
     const float *__restrict__ v_render, const float *__restrict__ v_alphas,
     float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
     float *__restrict__ v_colors, float *__restrict__ v_depths, float *__restrict__ v_opacities,
-    const GradRowBytes gs, const int32_t *__restrict__ order) {
+    const GradRowBytes gs, const int32_t *__restrict__ row_index, const int32_t *__restrict__ order) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     constexpr bool CULL = true;
     constexpr int CAND = NT == 64 ? 128 : 256, NRD = CAND / NT;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
         for (int r = 0; r < NRD; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, hi - start + 1);
         const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, s_wc, means2d, conics, colors, depths, DC, opacities,
-                                                             g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16));
+                                                             row_index, g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16));
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
             if (hi - CAND - r * NT - tid >= start) g_next[r] = flatten_ids[hi - CAND - r * NT - tid];
@@ -628,13 +629,14 @@ int launch_bwd(int C, const float *means2d, const float *conics, const float *co
                int H, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
                const float *alphas, const int32_t *last_ids, const float *render, const float *v_render,
                const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
-               float *v_depths, float *v_opacities, const GradRowBytes gs, const int32_t *order, hipStream_t st) {
+               float *v_depths, float *v_opacities, const GradRowBytes gs, const int32_t *row_index, const int32_t *order,
+               hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
     blend_bwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(
         C, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
         alphas, last_ids, render, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_depths,
-        v_opacities, gs, order);
+        v_opacities, gs, row_index, order);
     return 0;
 }
 
@@ -741,8 +743,8 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
                               int64_t M, const float *alphas, const int32_t *last_ids, const float *render,
                               const float *v_render, const float *v_alphas, float *v_means2d,
                               float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
-                              float *v_opacities, const int64_t *grad_row_strides, const int32_t *tile_order,
-                              void *stream) {
+                              float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                              const int32_t *tile_order, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && M >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_blend_bwd: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
@@ -770,7 +772,8 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
     MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, render, v_render, v_alphas,
-                    v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, gs, tile_order, st);
+                    v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, gs, grad_row_index, tile_order,
+                    st);
     MTGS_CHECK_LAUNCH("mtgs_blend_bwd");
     return MTGS_OK;
 }

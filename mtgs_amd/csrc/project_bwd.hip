@@ -32,7 +32,132 @@ __device__ __forceinline__ void block_reduce_viewmat(float (&vals)[12], float *_
 }
 // row strides (floats) of the incoming gradients: dense gsplat arrays, or views of an interleaved buffer
 struct ProjGradStrides { int64_t means2d, depths, conics, compensations, opac_eff; };
+// Optional "densify" by-product for callers that keep the compositing backward's gradients in COMPACT rows
+// (one row per visible Gaussian, grad_row_index): the per-Gaussian gradients that leave the rasterizer --
+// v_means2d (for retain_grad), |v_means2d| (absgrad) and v_colors -- are written as dense arrays, zeros for the
+// culled Gaussians, while their rows are in registers / cache anyway.
+struct ProjExpand {
+    const float *abs_src, *col_src;   // row-strided sources (same row index as the gradients); nullable
+    int64_t abs_stride, col_stride;   // in floats
+    int channels;
+    float *means2d, *means2d_abs, *colors;  // dense [C,N,2] [C,N,2] [C,N,channels]; nullable
+};
 constexpr int PROJ_MAX_CAMS = 64;  // cameras whose v_viewmat is accumulated in LDS (MTGS: 1)
+
+// Incoming gradients and saved forward values of ONE (camera, Gaussian) pair
+struct PairIn {
+    float conic[3], v_conic[3];
+    float2 v_mean2d;
+    float v_depth, comp, v_comp, opac, v_opac_eff;
+    bool has_comp, has_vcomp, has_opac;
+};
+// VJP of the projection of one visible (camera, Gaussian) pair: adds to am / aq / as / ao (gradients of
+// mean, quaternion, scale, opacity) and returns v_R (9) | v_t (3) in vRt.
+__device__ __forceinline__ void project_vjp_pair(const float (&m)[3], const float4 q, const float (&sc)[3], const Cam &cam,
+                                                 int W, int H, float eps2d, const PairIn &in, float (&am)[3],
+                                                 float (&aq)[4], float (&as)[3], float &ao, float (&vRt)[12]) {
+    ProjState s;
+    proj_common(m, q, sc, cam, W, H, s);
+    const float va = in.v_conic[0], vb = 0.5f * in.v_conic[1], vc = in.v_conic[2];
+    const float a = in.conic[0], b = in.conic[1], cc = in.conic[2];
+    const float t00 = a * va + b * vb, t01 = a * vb + b * vc, t10 = b * va + cc * vb, t11 = b * vb + cc * vc;
+    float vcov[4];
+    vcov[0] = -(t00 * a + t01 * b); vcov[1] = -(t00 * b + t01 * cc);
+    vcov[2] = -(t10 * a + t11 * b); vcov[3] = -(t10 * b + t11 * cc);
+    // opac_eff = opacity * compensation: the product rule feeds the compensation VJP
+    if (in.has_opac) ao += in.v_opac_eff * (in.has_comp ? in.comp : 1.f);
+    if (in.has_comp && (in.has_vcomp || in.has_opac)) {
+        const float comp = in.comp;
+        const float vcomp = (in.has_vcomp ? in.v_comp : 0.f) + (in.has_opac ? in.v_opac_eff * in.opac : 0.f);
+        const float det_conic = a * cc - b * b;
+        const float v_sqr = vcomp * 0.5f / (comp + kCompEps);
+        const float omc = 1.f - comp * comp;
+        vcov[0] += v_sqr * (omc * a - eps2d * det_conic);
+        vcov[1] += v_sqr * (omc * b);
+        vcov[2] += v_sqr * (omc * b);
+        vcov[3] += v_sqr * (omc * cc - eps2d * det_conic);
+    }
+    const float *J = s.J;
+    const float x = s.mean_c[0], y = s.mean_c[1];
+    const float rz = s.rz, rz2 = s.rz2, rz3 = rz2 * rz, tx = s.tx, ty = s.ty;
+    const float2 vm2 = in.v_mean2d;
+    float G[6], G2[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            G[i * 3 + j] = vcov[i * 2] * J[j] + vcov[i * 2 + 1] * J[3 + j];
+            G2[i * 3 + j] = vcov[i] * J[j] + vcov[2 + i] * J[3 + j];  // vcov^T * J
+        }
+    float v_covar_c[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v_covar_c[i * 3 + j] = J[i] * G[j] + J[3 + i] * G[3 + j];
+    float v_mean_c[3];
+    v_mean_c[0] = cam.fx * rz * vm2.x;
+    v_mean_c[1] = cam.fy * rz * vm2.y;
+    v_mean_c[2] = -(cam.fx * x * vm2.x + cam.fy * y * vm2.y) * rz2;
+    float vJ[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float p = (G[i * 3] * s.covar_c[j * 3] + G[i * 3 + 1] * s.covar_c[j * 3 + 1]) + G[i * 3 + 2] * s.covar_c[j * 3 + 2];
+            const float qq = (G2[i * 3] * s.covar_c[j] + G2[i * 3 + 1] * s.covar_c[3 + j]) + G2[i * 3 + 2] * s.covar_c[6 + j];
+            vJ[i * 3 + j] = p + qq;
+        }
+    if (!s.x_clamped) v_mean_c[0] += -cam.fx * rz2 * vJ[2];
+    else v_mean_c[2] += -cam.fx * rz3 * vJ[2] * tx;
+    if (!s.y_clamped) v_mean_c[1] += -cam.fy * rz2 * vJ[5];
+    else v_mean_c[2] += -cam.fy * rz3 * vJ[5] * ty;
+    v_mean_c[2] += ((-cam.fx * rz2 * vJ[0] - cam.fy * rz2 * vJ[4]) + 2.f * cam.fx * tx * rz3 * vJ[2]) + 2.f * cam.fy * ty * rz3 * vJ[5];
+    v_mean_c[2] += in.v_depth;
+    const float *R = cam.R;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vRt[i * 3 + j] = v_mean_c[i] * m[j];
+        vRt[9 + i] = v_mean_c[i];
+        am[i] += (R[i] * v_mean_c[0] + R[3 + i] * v_mean_c[1]) + R[6 + i] * v_mean_c[2];
+    }
+    float RC[9], RCt[9], tmp[9], tmp2[9], vcT[9];
+    mm3(R, s.covar, RC);
+    mm3_bt(R, s.covar, RCt);
+    mm3(v_covar_c, RCt, tmp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vcT[i * 3 + j] = v_covar_c[j * 3 + i];
+    mm3(vcT, RC, tmp2);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) vRt[i] += tmp[i] + tmp2[i];
+    float v_covar[9];
+    mm3_at(R, v_covar_c, tmp);
+    mm3(tmp, R, v_covar);
+    float sym[9], vM[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sym[i * 3 + j] = v_covar[i * 3 + j] + v_covar[j * 3 + i];
+    mm3(sym, s.Mq, vM);
+    float Gq[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        as[j] += (s.Rq[j] * vM[j] + s.Rq[3 + j] * vM[3 + j]) + s.Rq[6 + j] * vM[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Gq[i * 3 + j] = vM[i * 3 + j] * sc[j];
+    }
+    const float w = s.qn[0], qx = s.qn[1], qy = s.qn[2], qz = s.qn[3];
+    float vqn[4];
+    vqn[0] = 2.f * ((qx * (Gq[7] - Gq[5]) + qy * (Gq[2] - Gq[6])) + qz * (Gq[3] - Gq[1]));
+    vqn[1] = 2.f * (((-2.f * qx * (Gq[4] + Gq[8]) + qy * (Gq[1] + Gq[3])) + qz * (Gq[2] + Gq[6])) + w * (Gq[7] - Gq[5]));
+    vqn[2] = 2.f * (((qx * (Gq[1] + Gq[3]) - 2.f * qy * (Gq[0] + Gq[8])) + qz * (Gq[5] + Gq[7])) + w * (Gq[2] - Gq[6]));
+    vqn[3] = 2.f * (((qx * (Gq[2] + Gq[6]) + qy * (Gq[5] + Gq[7])) - 2.f * qz * (Gq[0] + Gq[4])) + w * (Gq[3] - Gq[1]));
+    const float dot = ((vqn[0] * w + vqn[1] * qx) + vqn[2] * qy) + vqn[3] * qz;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aq[k] += (vqn[k] - dot * s.qn[k]) * s.inv_norm;
+}
 
 // One thread per Gaussian, looping over cameras so that v_means / v_quats / v_scales are written
 // (not accumulated) exactly once.  MTGS always has C = 1.
@@ -45,7 +170,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
     const float *__restrict__ v_depths, const float *__restrict__ v_conics,
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff,
     float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
-    float *__restrict__ v_viewmats, float *__restrict__ v_opacities, const ProjGradStrides gs) {
+    float *__restrict__ v_viewmats, float *__restrict__ v_opacities, const ProjGradStrides gs,
+    const int32_t *__restrict__ row_index, const ProjExpand ex) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[PROJ_MAX_CAMS * 12];
     __shared__ int s_list[PROJ_BLOCK];
@@ -60,7 +186,17 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
     const int64_t n_own = chunk + threadIdx.x;
     bool vis = false;
     if (n_own < N)
-        for (int c = 0; c < C; ++c) vis = vis || radii[(int64_t)c * N + n_own] > 0;
+        for (int c = 0; c < C; ++c) {
+            const int64_t idx = (int64_t)c * N + n_own;
+            const bool v = radii[idx] > 0;
+            vis = vis || v;
+            if (!v) {  // dense by-products of a culled (camera, Gaussian) pair
+                if (ex.means2d) reinterpret_cast<float2 *>(ex.means2d)[idx] = make_float2(0.f, 0.f);
+                if (ex.means2d_abs) reinterpret_cast<float2 *>(ex.means2d_abs)[idx] = make_float2(0.f, 0.f);
+                if (ex.colors)
+                    for (int k = 0; k < ex.channels; ++k) ex.colors[idx * ex.channels + k] = 0.f;
+            }
+        }
     if (n_own < N && !vis) {
         v_means[n_own * 3] = 0.f; v_means[n_own * 3 + 1] = 0.f; v_means[n_own * 3 + 2] = 0.f;
         reinterpret_cast<float4 *>(v_quats)[n_own] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -102,109 +238,25 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
                 loaded = true;
             }
             const Cam cam = load_cam(viewmats + c * 16, Ks + c * 9);
-            ProjState s;
-            proj_common(m, q, sc, cam, W, H, s);
-            const float a = conics[idx * 3], b = conics[idx * 3 + 1], cc = conics[idx * 3 + 2];
-            const float *vcon = v_conics + idx * gs.conics;
-            const float va = vcon[0], vb = 0.5f * vcon[1], vc = vcon[2];
-            const float t00 = a * va + b * vb, t01 = a * vb + b * vc, t10 = b * va + cc * vb, t11 = b * vb + cc * vc;
-            float vcov[4];
-            vcov[0] = -(t00 * a + t01 * b); vcov[1] = -(t00 * b + t01 * cc);
-            vcov[2] = -(t10 * a + t11 * b); vcov[3] = -(t10 * b + t11 * cc);
-            // opac_eff = opacity * compensation: the product rule feeds the compensation VJP
-            if (v_opac_eff) ao += v_opac_eff[idx * gs.opac_eff] * (compensations ? compensations[idx] : 1.f);
-            if (compensations && (v_compensations || v_opac_eff)) {
-                const float comp = compensations[idx];
-                const float vcomp = (v_compensations ? v_compensations[idx * gs.compensations] : 0.f) +
-                                    (v_opac_eff ? v_opac_eff[idx * gs.opac_eff] * opac : 0.f);
-                const float det_conic = a * cc - b * b;
-                const float v_sqr = vcomp * 0.5f / (comp + kCompEps);
-                const float omc = 1.f - comp * comp;
-                vcov[0] += v_sqr * (omc * a - eps2d * det_conic);
-                vcov[1] += v_sqr * (omc * b);
-                vcov[2] += v_sqr * (omc * b);
-                vcov[3] += v_sqr * (omc * cc - eps2d * det_conic);
-            }
-            const float *J = s.J;
-            const float x = s.mean_c[0], y = s.mean_c[1];
-            const float rz = s.rz, rz2 = s.rz2, rz3 = rz2 * rz, tx = s.tx, ty = s.ty;
-            const float2 vm2 = make_float2(v_means2d[idx * gs.means2d], v_means2d[idx * gs.means2d + 1]);
-            float G[6], G2[6];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    G[i * 3 + j] = vcov[i * 2] * J[j] + vcov[i * 2 + 1] * J[3 + j];
-                    G2[i * 3 + j] = vcov[i] * J[j] + vcov[2 + i] * J[3 + j];  // vcov^T * J
-                }
-            float v_covar_c[9];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) v_covar_c[i * 3 + j] = J[i] * G[j] + J[3 + i] * G[3 + j];
-            float v_mean_c[3];
-            v_mean_c[0] = cam.fx * rz * vm2.x;
-            v_mean_c[1] = cam.fy * rz * vm2.y;
-            v_mean_c[2] = -(cam.fx * x * vm2.x + cam.fy * y * vm2.y) * rz2;
-            float vJ[6];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float p = (G[i * 3] * s.covar_c[j * 3] + G[i * 3 + 1] * s.covar_c[j * 3 + 1]) + G[i * 3 + 2] * s.covar_c[j * 3 + 2];
-                    const float qq = (G2[i * 3] * s.covar_c[j] + G2[i * 3 + 1] * s.covar_c[3 + j]) + G2[i * 3 + 2] * s.covar_c[6 + j];
-                    vJ[i * 3 + j] = p + qq;
-                }
-            if (!s.x_clamped) v_mean_c[0] += -cam.fx * rz2 * vJ[2];
-            else v_mean_c[2] += -cam.fx * rz3 * vJ[2] * tx;
-            if (!s.y_clamped) v_mean_c[1] += -cam.fy * rz2 * vJ[5];
-            else v_mean_c[2] += -cam.fy * rz3 * vJ[5] * ty;
-            v_mean_c[2] += ((-cam.fx * rz2 * vJ[0] - cam.fy * rz2 * vJ[4]) + 2.f * cam.fx * tx * rz3 * vJ[2]) + 2.f * cam.fy * ty * rz3 * vJ[5];
-            v_mean_c[2] += v_depths[idx * gs.depths];
-            const float *R = cam.R;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) vRt[i * 3 + j] = v_mean_c[i] * m[j];
-                vRt[9 + i] = v_mean_c[i];
-                am[i] += (R[i] * v_mean_c[0] + R[3 + i] * v_mean_c[1]) + R[6 + i] * v_mean_c[2];
-            }
-            float RC[9], RCt[9], tmp[9], tmp2[9], vcT[9];
-            mm3(R, s.covar, RC);
-            mm3_bt(R, s.covar, RCt);
-            mm3(v_covar_c, RCt, tmp);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) vcT[i * 3 + j] = v_covar_c[j * 3 + i];
-            mm3(vcT, RC, tmp2);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) vRt[i] += tmp[i] + tmp2[i];
-            float v_covar[9];
-            mm3_at(R, v_covar_c, tmp);
-            mm3(tmp, R, v_covar);
-            float sym[9], vM[9];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) sym[i * 3 + j] = v_covar[i * 3 + j] + v_covar[j * 3 + i];
-            mm3(sym, s.Mq, vM);
-            float Gq[9];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                as[j] += (s.Rq[j] * vM[j] + s.Rq[3 + j] * vM[3 + j]) + s.Rq[6 + j] * vM[6 + j];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) Gq[i * 3 + j] = vM[i * 3 + j] * sc[j];
-            }
-            const float w = s.qn[0], qx = s.qn[1], qy = s.qn[2], qz = s.qn[3];
-            float vqn[4];
-            vqn[0] = 2.f * ((qx * (Gq[7] - Gq[5]) + qy * (Gq[2] - Gq[6])) + qz * (Gq[3] - Gq[1]));
-            vqn[1] = 2.f * (((-2.f * qx * (Gq[4] + Gq[8]) + qy * (Gq[1] + Gq[3])) + qz * (Gq[2] + Gq[6])) + w * (Gq[7] - Gq[5]));
-            vqn[2] = 2.f * (((qx * (Gq[1] + Gq[3]) - 2.f * qy * (Gq[0] + Gq[8])) + qz * (Gq[5] + Gq[7])) + w * (Gq[2] - Gq[6]));
-            vqn[3] = 2.f * (((qx * (Gq[2] + Gq[6]) + qy * (Gq[5] + Gq[7])) - 2.f * qz * (Gq[0] + Gq[4])) + w * (Gq[3] - Gq[1]));
-            const float dot = ((vqn[0] * w + vqn[1] * qx) + vqn[2] * qy) + vqn[3] * qz;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) aq[k] += (vqn[k] - dot * s.qn[k]) * s.inv_norm;
+            const int64_t grow = row_index ? (int64_t)row_index[idx] : idx;  // row of the incoming gradients
+            PairIn in;
+            in.conic[0] = conics[idx * 3]; in.conic[1] = conics[idx * 3 + 1]; in.conic[2] = conics[idx * 3 + 2];
+            const float *vcon = v_conics + grow * gs.conics;
+            in.v_conic[0] = vcon[0]; in.v_conic[1] = vcon[1]; in.v_conic[2] = vcon[2];
+            in.v_mean2d = make_float2(v_means2d[grow * gs.means2d], v_means2d[grow * gs.means2d + 1]);
+            in.v_depth = v_depths[grow * gs.depths];
+            in.has_comp = compensations != nullptr; in.has_vcomp = v_compensations != nullptr; in.has_opac = v_opac_eff != nullptr;
+            in.comp = in.has_comp ? compensations[idx] : 1.f;
+            in.v_comp = in.has_vcomp ? v_compensations[grow * gs.compensations] : 0.f;
+            in.opac = opac;
+            in.v_opac_eff = in.has_opac ? v_opac_eff[grow * gs.opac_eff] : 0.f;
+            if (ex.means2d) reinterpret_cast<float2 *>(ex.means2d)[idx] = in.v_mean2d;
+            if (ex.means2d_abs)
+                reinterpret_cast<float2 *>(ex.means2d_abs)[idx] =
+                    make_float2(ex.abs_src[grow * ex.abs_stride], ex.abs_src[grow * ex.abs_stride + 1]);
+            if (ex.colors)
+                for (int k = 0; k < ex.channels; ++k) ex.colors[idx * ex.channels + k] = ex.col_src[grow * ex.col_stride + k];
+            project_vjp_pair(m, q, sc, cam, W, H, eps2d, in, am, aq, as, ao, vRt);
         }
         if (v_viewmats) {
             __syncthreads();
@@ -235,6 +287,125 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
     }
 }
 
+// ---- compact path (C == 1, rows of the incoming gradients indexed by visible rank) ---------------------------
+// The dense kernel above is bound by LATENCY, not bytes: after the in-block compaction one wave per block walks
+// the ~2000-instruction VJP while three wait at the barriers, and every lane issues 13 partial-line stores.  When
+// the caller has the list of visible Gaussians (mtgs_bin_compact's vis_ids / vis_rank) the work splits into
+//   A. project_bwd_vis_kernel    one thread per VISIBLE Gaussian (dense waves, no barrier apart from the viewmat
+//                                sum), results to 48-byte rows of a workspace;
+//   B. project_bwd_expand_kernel a pure streaming pass: every dense output (v_means, v_quats, v_scales,
+//                                v_opacities and the by-products) is staged through LDS and leaves as fully
+//                                coalesced 16-byte stores, zeros for the culled Gaussians included.
+constexpr int VIS_ROW = 12;  // floats per workspace row: v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | pad
+__global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
+    int64_t n_vis, const int32_t *__restrict__ vis_ids, const float *__restrict__ means,
+    const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ viewmats,
+    const float *__restrict__ Ks, int W, int H, float eps2d, const float *__restrict__ conics,
+    const float *__restrict__ compensations, const float *__restrict__ opacities,
+    const float *__restrict__ v_means2d, const float *__restrict__ v_depths, const float *__restrict__ v_conics,
+    const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff, const ProjGradStrides gs,
+    float *__restrict__ ws, float *__restrict__ v_viewmats) {
+    __shared__ float red[(PROJ_BLOCK / 64) * 12];
+    __shared__ float s_acc[12];
+    if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
+    const Cam cam = load_cam(viewmats, Ks);
+    for (int64_t r0 = (int64_t)blockIdx.x * PROJ_BLOCK; r0 < n_vis; r0 += (int64_t)gridDim.x * PROJ_BLOCK) {
+        const int64_t r = r0 + threadIdx.x;
+        float vRt[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) vRt[k] = 0.f;
+        if (r < n_vis) {
+            const int64_t n = vis_ids[r];
+            float m[3], sc[3], am[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f}, ao = 0.f;
+            m[0] = means[n * 3]; m[1] = means[n * 3 + 1]; m[2] = means[n * 3 + 2];
+            const float4 q = reinterpret_cast<const float4 *>(quats)[n];
+            sc[0] = scales[n * 3]; sc[1] = scales[n * 3 + 1]; sc[2] = scales[n * 3 + 2];
+            PairIn in;
+            in.conic[0] = conics[n * 3]; in.conic[1] = conics[n * 3 + 1]; in.conic[2] = conics[n * 3 + 2];
+            const float *vcon = v_conics + r * gs.conics;
+            in.v_conic[0] = vcon[0]; in.v_conic[1] = vcon[1]; in.v_conic[2] = vcon[2];
+            in.v_mean2d = make_float2(v_means2d[r * gs.means2d], v_means2d[r * gs.means2d + 1]);
+            in.v_depth = v_depths[r * gs.depths];
+            in.has_comp = compensations != nullptr; in.has_vcomp = v_compensations != nullptr; in.has_opac = v_opac_eff != nullptr;
+            in.comp = in.has_comp ? compensations[n] : 1.f;
+            in.v_comp = in.has_vcomp ? v_compensations[r * gs.compensations] : 0.f;
+            in.opac = in.has_opac ? opacities[n] : 0.f;
+            in.v_opac_eff = in.has_opac ? v_opac_eff[r * gs.opac_eff] : 0.f;
+            project_vjp_pair(m, q, sc, cam, W, H, eps2d, in, am, aq, as, ao, vRt);
+            float4 *out = reinterpret_cast<float4 *>(ws + r * VIS_ROW);
+            out[0] = make_float4(am[0], am[1], am[2], aq[0]);
+            out[1] = make_float4(aq[1], aq[2], aq[3], as[0]);
+            out[2] = make_float4(as[1], as[2], ao, 0.f);
+        }
+        if (v_viewmats) {
+            __syncthreads();
+            block_reduce_viewmat(vRt, s_acc, red);
+        }
+    }
+    __syncthreads();
+    if (v_viewmats && threadIdx.x < 12) {
+        const int k = threadIdx.x;
+        const float v = s_acc[k];
+        if (v != 0.f) atomicAdd(v_viewmats + (k < 9 ? (k / 3) * 4 + (k % 3) : (k - 9) * 4 + 3), v);
+    }
+}
+
+constexpr int EXP_STAGE_COL = 8;  // colour channels staged through LDS (more: per-lane stores)
+// `count` floats from LDS to consecutive global addresses, whole block, 16-byte stores when aligned
+__device__ __forceinline__ void block_store(float *__restrict__ dst, const float *lds, int count) {
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const int n4 = count >> 2;
+        for (int k = threadIdx.x; k < n4; k += PROJ_BLOCK)
+            reinterpret_cast<float4 *>(dst)[k] = reinterpret_cast<const float4 *>(lds)[k];
+        for (int k = (n4 << 2) + threadIdx.x; k < count; k += PROJ_BLOCK) dst[k] = lds[k];
+    } else {
+        for (int k = threadIdx.x; k < count; k += PROJ_BLOCK) dst[k] = lds[k];
+    }
+}
+__global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
+    int64_t N, const int32_t *__restrict__ radii, const int32_t *__restrict__ row_index,
+    const float *__restrict__ ws, const float *__restrict__ v_means2d, int64_t m2d_stride,
+    float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
+    float *__restrict__ v_opacities, const ProjExpand ex) {
+    __shared__ __attribute__((aligned(16))) float s_vm[PROJ_BLOCK * 3], s_vq[PROJ_BLOCK * 4], s_vs[PROJ_BLOCK * 3], s_vo[PROJ_BLOCK];
+    __shared__ __attribute__((aligned(16))) float s_m2d[PROJ_BLOCK * 2], s_abs[PROJ_BLOCK * 2], s_col[PROJ_BLOCK * EXP_STAGE_COL];
+    const int t = threadIdx.x;
+    const int64_t chunk = (int64_t)blockIdx.x * PROJ_BLOCK;
+    const int n_chunk = (int)min((int64_t)PROJ_BLOCK, N - chunk);
+    const int64_t n = chunk + t;
+    const bool stage_col = ex.colors && ex.channels <= EXP_STAGE_COL;
+    const bool vis = n < N && radii[n] > 0;
+    float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0;
+    float2 xy = make_float2(0.f, 0.f), ab = xy;
+    int64_t r = 0;
+    if (vis) {
+        r = row_index[n];
+        const float4 *row = reinterpret_cast<const float4 *>(ws + r * VIS_ROW);
+        w0 = row[0]; w1 = row[1]; w2 = row[2];
+        if (ex.means2d) xy = make_float2(v_means2d[r * m2d_stride], v_means2d[r * m2d_stride + 1]);
+        if (ex.means2d_abs) ab = make_float2(ex.abs_src[r * ex.abs_stride], ex.abs_src[r * ex.abs_stride + 1]);
+    }
+    s_vm[t * 3] = w0.x; s_vm[t * 3 + 1] = w0.y; s_vm[t * 3 + 2] = w0.z;
+    reinterpret_cast<float4 *>(s_vq)[t] = make_float4(w0.w, w1.x, w1.y, w1.z);
+    s_vs[t * 3] = w1.w; s_vs[t * 3 + 1] = w2.x; s_vs[t * 3 + 2] = w2.y;
+    s_vo[t] = w2.z;
+    reinterpret_cast<float2 *>(s_m2d)[t] = xy;
+    reinterpret_cast<float2 *>(s_abs)[t] = ab;
+    if (stage_col) {
+        for (int k = 0; k < ex.channels; ++k) s_col[t * ex.channels + k] = vis ? ex.col_src[r * ex.col_stride + k] : 0.f;
+    } else if (ex.colors && n < N) {
+        for (int k = 0; k < ex.channels; ++k) ex.colors[n * ex.channels + k] = vis ? ex.col_src[r * ex.col_stride + k] : 0.f;
+    }
+    __syncthreads();
+    block_store(v_means + chunk * 3, s_vm, n_chunk * 3);
+    block_store(v_quats + chunk * 4, s_vq, n_chunk * 4);
+    block_store(v_scales + chunk * 3, s_vs, n_chunk * 3);
+    if (v_opacities) block_store(v_opacities + chunk, s_vo, n_chunk);
+    if (ex.means2d) block_store(ex.means2d + chunk * 2, s_m2d, n_chunk * 2);
+    if (ex.means2d_abs) block_store(ex.means2d_abs + chunk * 2, s_abs, n_chunk * 2);
+    if (stage_col) block_store(ex.colors + chunk * ex.channels, s_col, n_chunk * ex.channels);
+}
+
 }  // namespace
 
 extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats,
@@ -244,7 +415,11 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const float *v_means2d, const float *v_depths, const float *v_conics,
                                 const float *v_compensations, const float *v_opac_eff, float *v_means,
                                 float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities,
-                                const int64_t *grad_row_strides, void *stream) {
+                                const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                                const float *x_means2d_abs, const float *x_colors, int x_channels,
+                                const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
+                                float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
+                                void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -268,12 +443,36 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                      (long long)rs[i], (long long)dense[i]);
     }
     const ProjGradStrides gs{rs[0], rs[1], rs[2], rs[3], rs[4]};
+    MTGS_REQUIRE(x_channels >= 0 && x_channels <= MTGS_MAX_CHANNELS, MTGS_EINVAL, "mtgs_project_bwd: x_channels=%d", x_channels);
+    MTGS_REQUIRE((!d_means2d_abs || x_means2d_abs) && (!d_colors || (x_colors && x_channels > 0)), MTGS_EINVAL,
+                 "mtgs_project_bwd: a dense by-product was requested without its source rows");
+    ProjExpand ex;
+    ex.abs_src = x_means2d_abs; ex.col_src = x_colors;
+    ex.abs_stride = x_row_strides ? x_row_strides[0] : 2;
+    ex.col_stride = x_row_strides ? x_row_strides[1] : x_channels;
+    ex.channels = x_channels;
+    ex.means2d = d_means2d; ex.means2d_abs = d_means2d_abs; ex.colors = d_colors;
+    MTGS_REQUIRE(ex.abs_stride >= 2 && ex.col_stride >= x_channels, MTGS_EINVAL, "mtgs_project_bwd: x_row_strides too small");
+    if (vis_ids && vis_ws && grad_row_index && C == 1) {
+        // compact path: grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank)
+        MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
+        if (n_vis > 0) {
+            const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
+            project_bwd_vis_kernel<<<(unsigned)(blocks < 1024 ? blocks : 1024), PROJ_BLOCK, 0, st>>>(
+                n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
+                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats);
+        }
+        project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
+            N, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);
+        MTGS_CHECK_LAUNCH("mtgs_project_bwd");
+        return MTGS_OK;
+    }
     const unsigned grid = (unsigned)(ceil_div64(N, PROJ_BLOCK) < 2048 ? ceil_div64(N, PROJ_BLOCK) : 2048);
     project_bwd_kernel<<<grid, PROJ_BLOCK, 0, st>>>(C, N, means, quats, scales, viewmats, Ks, width,
                                                     height, eps2d, radii, conics, compensations, opacities,
                                                     v_means2d, v_depths, v_conics, v_compensations,
                                                     v_opac_eff, v_means, v_quats, v_scales, v_viewmats,
-                                                    v_opacities, gs);
+                                                    v_opacities, gs, grad_row_index, ex);
     MTGS_CHECK_LAUNCH("mtgs_project_bwd");
     return MTGS_OK;
 }

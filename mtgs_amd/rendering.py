@@ -15,8 +15,9 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
-from .wrapper import (MAX_CHANNELS, isect_offset_encode, isect_tiles, projection_with_opacities,
-                      rasterize_to_pixels, rasterize_to_pixels_with_depth, spherical_harmonics)
+from .wrapper import (MAX_CHANNELS, SUPPORTED_CHANNELS, fused_rasterization, isect_offset_encode, isect_tiles,
+                      projection_with_opacities, rasterize_to_pixels, rasterize_to_pixels_with_depth,
+                      spherical_harmonics)
 
 
 def rasterization(
@@ -87,11 +88,38 @@ def rasterization(
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
 
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    with_depth = render_mode in ["RGB+D", "RGB+ED", "D", "ED"]
+    expected = render_mode in ["ED", "RGB+ED"]
+    camera_ids, gaussian_ids = None, None
+
+    # Fast path -- everything MTGS drives: colours given per Gaussian, a channel count the compositing kernels
+    # take in one launch.  Projection, binning and compositing run as ONE autograd node (same kernels and
+    # results as the operator-by-operator composition below; see wrapper._FusedRasterization).
+    if sh_degree is None:
+        depth_only = render_mode in ["D", "ED"]
+        n_blend = (0 if depth_only else colors.shape[-1]) + int(with_depth)
+        if n_blend in SUPPORTED_CHANNELS and n_blend <= min(channel_chunk, MAX_CHANNELS):
+            cols = None
+            if not depth_only:
+                cols = colors if colors.dim() == 3 else (colors.unsqueeze(0) if C == 1 else colors.expand(C, -1, -1))
+            render_colors, render_alphas, m = fused_rasterization(
+                means, quats, scales, opacities, cols, viewmats, Ks, None if depth_only else backgrounds, width,
+                height, eps2d, near_plane, far_plane, radius_clip, rasterize_mode == "antialiased", with_depth,
+                expected, absgrad)
+            meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": m["radii"],
+                         "means2d": m["means2d"], "depths": m["depths"], "conics": m["conics"],
+                         "opacities": m["opacities"], "tile_width": tile_width, "tile_height": tile_height,
+                         "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
+                         "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width,
+                         "height": height, "tile_size": tile_size, "n_cameras": C})
+            return render_colors, render_alphas, meta
+
     # (1) projection, fused with `opacities.repeat(C, 1) [* compensations]`
     radii, means2d, depths, conics, compensations, opacities = projection_with_opacities(
         means, quats, scales, viewmats, Ks, opacities, width, height, eps2d=eps2d, near_plane=near_plane,
         far_plane=far_plane, radius_clip=radius_clip, calc_compensations=(rasterize_mode == "antialiased"))
-    camera_ids, gaussian_ids = None, None
 
     meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii,
                  "means2d": means2d, "depths": depths, "conics": conics, "opacities": opacities})
@@ -110,8 +138,6 @@ def rasterization(
         colors = torch.clamp_min(colors + 0.5, 0.0)
 
     # (3) tile binning
-    tile_width = math.ceil(width / float(tile_size))
-    tile_height = math.ceil(height / float(tile_size))
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
         means2d, radii, depths, tile_size, tile_width, tile_height, packed=False, n_cameras=C,
         camera_ids=camera_ids, gaussian_ids=gaussian_ids)
@@ -124,8 +150,6 @@ def rasterization(
 
     # (4) compositing.  The depth channel of the "+D"/"+ED"/"D"/"ED" modes and the expected-depth
     # normalisation are blended in the same pass (gsplat: torch.cat + rasterize_to_pixels + division).
-    with_depth = render_mode in ["RGB+D", "RGB+ED", "D", "ED"]
-    expected = render_mode in ["ED", "RGB+ED"]
     if render_mode in ["D", "ED"]:
         colors, backgrounds = None, None  # gsplat: colors = depths[..., None], backgrounds = zeros
     n_channels = (0 if colors is None else colors.shape[-1]) + int(with_depth)

@@ -139,7 +139,8 @@ class _FullyFusedProjection(torch.autograd.Function):
              ctx.width, ctx.height, ctx.eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities),
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
-             host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), stream_of(means))
+             host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
+             None, 0, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -239,12 +240,23 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                  tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids), st)
         return tiles_per_gauss, isect_ids, flatten_ids
 
-    # ---- depth-ordered binning
+    return _bin_depth_ordered(means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tile_width,
+                              tile_height)[:3]
+
+
+def _bin_depth_ordered(means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tile_width, tile_height,
+                       want_rank: bool = False):
+    """Depth-ordered binning (csrc/bin.hip) after mtgs_isect_count.  Returns (tiles_per_gauss, isect_ids,
+    flatten_ids, offsets, tile_order, vis_ids[n_vis], vis_rank[C*N] | None)."""
+    Cn, N = means2d.shape[:2]
+    dev, st = means2d.device, stream_of(means2d)
+    total = Cn * N
     vis_keys = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
     vis_ids = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    vis_rank = torch.empty(max(total, 1), dtype=torch.int32, device=dev) if want_rank else None
     totals = torch.empty(1, dtype=torch.int64, device=dev)
     call("mtgs_bin_compact", Cn, N, ptr(radii), ptr(depths), ptr(tiles_per_gauss), ptr(vis_keys),
-         ptr(vis_ids), ptr(totals), ptr(scan_ws), scan_bytes, st)
+         ptr(vis_ids), ptr(vis_rank), ptr(totals), ptr(scan_ws), scan_bytes, st)
     packed_totals = int(totals.item())  # the one host sync of a frame: n_vis and M together
     n_vis, M = packed_totals >> 32, packed_totals & 0xFFFFFFFF
     isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
@@ -263,7 +275,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
          ptr(offsets), ptr(order), ptr(bin_ws), nbytes.value, st)
     offsets._mtgs_tile_order = order
     isect_ids._mtgs_offsets = offsets
-    return tiles_per_gauss, isect_ids, flatten_ids
+    return tiles_per_gauss, isect_ids, flatten_ids, offsets, order, vis_ids[:n_vis], vis_rank
 
 
 @torch.no_grad()
@@ -339,7 +351,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         call("mtgs_blend_bwd", Cn, N, DC, ptr(m2d), ptr(con), ptr(col), ptr(opa), ptr(bg), ptr(dep), int(ed),
              width, height, tile_size, tw, th, ptr(isect_offsets), ptr(flatten_ids), flatten_ids.numel(),
              ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs),
-             ptr(v_conics), ptr(v_colors), ptr(v_depths), ptr(v_opacities), host_i64([RS] * 6), ptr(order),
+             ptr(v_conics), ptr(v_colors), ptr(v_depths), ptr(v_opacities), host_i64([RS] * 6), None, ptr(order),
              stream_of(m2d))
         if ctx.absgrad:
             ctx.means2d_ref.absgrad = v_abs
@@ -347,6 +359,165 @@ class _RasterizeToPixels(torch.autograd.Function):
         if bg is not None and ctx.needs_input_grad[4]:
             v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
         return (v_means2d, v_conics, v_colors, v_opacities, v_bg, v_depths, None, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------- fused path
+class _FusedRasterization(torch.autograd.Function):
+    """projection -> tile binning -> compositing as ONE autograd node: what gsplat.rendering.rasterization
+    chains from fully_fused_projection / isect_tiles / rasterize_to_pixels (same kernels, same results).
+
+    Being one node lets the backward keep the compositing gradients in COMPACT rows -- one 64-byte row per
+    VISIBLE Gaussian (mtgs_bin_compact's vis_rank), 19 MB instead of a zero-filled dense 128 MB buffer at 2M
+    Gaussians -- and lets the projection backward emit the gradients that leave the rasterizer (colours,
+    means2d for retain_grad(), |means2d| for absgrad) as dense contiguous tensors while it reads those rows.
+    Outputs: render, alphas, radii, means2d, depths, conics, compensations, opacities_eff, tiles_per_gauss,
+    isect_ids, flatten_ids, isect_offsets  (the tensors of gsplat's `meta`)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
+                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad):
+        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
+        means, quats, scales, opacities, col, viewmats, Ks, bg = map(
+            _f32c, (means, quats, scales, opacities, colors, viewmats, Ks, backgrounds))
+        N, Cn = means.shape[0], viewmats.shape[0]
+        dev, st = means.device, stream_of(means)
+        tile_size = 16
+        tw, th = -(-width // tile_size), -(-height // tile_size)
+        # (1) projection (+ opacity * compensation)
+        radii = torch.empty((Cn, N), dtype=torch.int32, device=dev)
+        means2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((Cn, N), dtype=torch.float32, device=dev)
+        conics = torch.empty((Cn, N, 3), dtype=torch.float32, device=dev)
+        comps = torch.empty((Cn, N), dtype=torch.float32, device=dev) if calc_compensations else None
+        opac_eff = torch.empty((Cn, N), dtype=torch.float32, device=dev)
+        call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+             width, height, eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(radii),
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), st)
+        # (2) tile binning
+        tiles_per_gauss = torch.empty((Cn, N), dtype=torch.int32, device=dev)
+        call("mtgs_isect_count", Cn, N, ptr(means2d), ptr(radii), tile_size, tw, th, ptr(tiles_per_gauss), st)
+        scan_ws, scan_bytes = _ws("mtgs_scan_workspace_bytes", Cn * N, dev)
+        _, isect_ids, flatten_ids, offsets, order, vis_ids, vis_rank = _bin_depth_ordered(
+            means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tw, th, want_rank=True)
+        # (3) compositing
+        DC = 0 if col is None else col.shape[-1]
+        DT = DC + int(with_depth)
+        render = torch.empty((Cn, height, width, DT), dtype=torch.float32, device=dev)
+        alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
+        M = flatten_ids.numel()
+        dep = depths if with_depth else None
+        ed = bool(expected_depth)
+        call("mtgs_blend_fwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
+             width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), M, ptr(render), ptr(alphas),
+             ptr(last_ids), ptr(order), st)
+        ctx.save_for_backward(means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics,
+                              comps, opac_eff, offsets, flatten_ids, alphas, last_ids, order, vis_ids, vis_rank,
+                              render if ed else None)
+        ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
+        ctx.absgrad = bool(absgrad)
+        ctx.set_materialize_grads(False)
+        # classic mode: an empty placeholder keeps the output arity fixed
+        comps_out = comps if comps is not None else torch.empty(0, device=dev)
+        nd = [radii, tiles_per_gauss, isect_ids, flatten_ids, offsets] + ([comps_out] if comps is None else [])
+        ctx.mark_non_differentiable(*nd)
+        return (render, alphas, radii, means2d, depths, conics, comps_out, opac_eff, tiles_per_gauss, isect_ids,
+                flatten_ids, offsets)
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, _r, g_means2d, g_depths, g_conics, g_comps, g_opac, *_ints):
+        (means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics, comps, opac_eff, offsets,
+         flatten_ids, alphas, last_ids, order, vis_ids, vis_rank, render) = ctx.saved_tensors
+        width, height, tile_size, tw, th, DC, with_depth, ed, eps2d = ctx.dims
+        Cn, N = means2d.shape[:2]
+        dev, st = means.device, stream_of(means)
+        n_vis = vis_ids.numel()
+        DT = DC + int(with_depth)
+        dep = depths if with_depth else None
+        # compact gradient rows, one per VISIBLE (camera, Gaussian) pair:
+        #   [xy 2 | |xy| 2 | conic 3 | opacity 1 | colour DC | depth 1 | pad]
+        RS = -(-(8 + DT) // 16) * 16
+        G = torch.zeros((max(n_vis, 1), RS), dtype=torch.float32, device=dev)
+        r_xy, r_abs, r_con, r_opa = G[:, 0:2], G[:, 2:4], G[:, 4:7], G[:, 7]
+        r_col = G[:, 8:8 + DC] if DC else None
+        r_dep = G[:, 8 + DC] if with_depth else None
+        if v_render is not None or v_alphas is not None:
+            if v_render is None:
+                v_render = torch.zeros((Cn, height, width, DT), dtype=torch.float32, device=dev)
+            if v_alphas is None:
+                v_alphas = torch.zeros((Cn, height, width, 1), dtype=torch.float32, device=dev)
+            v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
+            call("mtgs_blend_bwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
+                 width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), flatten_ids.numel(), ptr(alphas),
+                 ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(r_xy),
+                 ptr(r_abs) if ctx.absgrad else None, ptr(r_con), ptr(r_col), ptr(r_dep), ptr(r_opa),
+                 host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
+        # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
+        # added to the visible rows (culled pairs have no gradient path in gsplat either)
+        if n_vis > 0:
+            vi = vis_ids.long()
+            if g_means2d is not None:
+                r_xy += g_means2d.reshape(Cn * N, 2)[vi]
+            if g_conics is not None:
+                r_con += g_conics.reshape(Cn * N, 3)[vi]
+            if g_opac is not None:
+                r_opa += g_opac.reshape(Cn * N)[vi]
+        r_dep_total = r_dep
+        if g_depths is not None and n_vis > 0:
+            r_dep_total = (r_dep if r_dep is not None else 0) + g_depths.reshape(Cn * N)[vi]
+        if r_dep_total is None:
+            r_dep_total = torch.zeros(max(n_vis, 1), dtype=torch.float32, device=dev)
+        r_cmp = None
+        if comps is not None and g_comps is not None and n_vis > 0:
+            r_cmp = g_comps.reshape(Cn * N)[vi].contiguous()
+        need = ctx.needs_input_grad
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_opacities = torch.empty_like(opacities)
+        v_viewmats = torch.empty_like(viewmats) if need[5] else None
+        m2d_out = ctx.means2d_ref() if getattr(ctx, "means2d_ref", None) is not None else None
+        want_m2d = m2d_out is not None and m2d_out.retains_grad
+        d_m2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if want_m2d else None
+        d_abs = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if (ctx.absgrad and m2d_out is not None) else None
+        d_col = torch.empty((Cn, N, DC), dtype=torch.float32, device=dev) if (DC and need[4]) else None
+        vis_ws = torch.empty((max(n_vis, 1), 12), dtype=torch.float32, device=dev)  # scratch of the compact VJP
+        call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
+             eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities), ptr(r_xy), ptr(r_dep_total), ptr(r_con),
+             ptr(r_cmp), ptr(r_opa), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
+             host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs), ptr(r_col), DC,
+             host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws), st)
+        if want_m2d:
+            m2d_out.grad = d_m2d      # what retain_grad() would have kept: the gradient reaching means2d
+        if d_abs is not None:
+            m2d_out.absgrad = d_abs   # gsplat: set in rasterize_to_pixels' backward (mtgs_scene_graph.py:1172)
+        v_bg = None
+        if bg is not None and need[7] and v_render is not None:
+            v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
+        return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
+                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 10
+
+
+def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
+                        near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad):
+    """One-node projection + binning + compositing (see _FusedRasterization).  colors[C,N,D] | None.
+    Returns (render, alphas, dict of gsplat's meta tensors)."""
+    import weakref
+    if colors is not None:
+        total = colors.shape[-1] + int(with_depth)
+        if total not in SUPPORTED_CHANNELS:
+            raise ValueError(f"fused_rasterization: {total} blended channels (supported: {SUPPORTED_CHANNELS})")
+    out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
+                                    int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+                                    bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad))
+    (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
+     offsets) = out
+    if render.grad_fn is not None:  # the backward sets .grad / .absgrad on this very tensor (weak: no cycle)
+        render.grad_fn.means2d_ref = weakref.ref(means2d)
+    return render, alphas, {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+                            "compensations": comps if calc_compensations else None, "opacities": opac_eff,
+                            "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+                            "isect_offsets": offsets}
 
 
 def _pad_channels(colors: Optional[Tensor], backgrounds: Optional[Tensor], extra: int):

@@ -102,21 +102,38 @@ def main():
         vcon = torch.zeros_like(conics); vcl = torch.zeros_like(cols); vop = torch.zeros_like(opac)
         vdp = torch.zeros_like(depths) if mtgs else None
         gstr, pstr = None, None
+        rank = None
     else:  # views of one interleaved buffer, as mtgs_amd.wrapper passes them
         RS = -(-(8 + D) // 16) * 16
-        G = torch.zeros(1, N, RS, device=dev)
+        if os.environ.get("DENSE_ROWS"):   # one row per Gaussian (rasterize_to_pixels' own backward)
+            G, rank = torch.zeros(1, N, RS, device=dev), None
+        else:                              # one row per VISIBLE Gaussian (the fused rasterization node)
+            vis = radii.reshape(-1) > 0
+            rank = (torch.cumsum(vis.int(), 0) - 1).int().contiguous()
+            G = torch.zeros(1, int(vis.sum()), RS, device=dev)
         v2d, vab, vcon, vop = G[..., 0:2], (G[..., 2:4] if mtgs else None), G[..., 4:7], G[..., 7]
         vcl, vdp = G[..., 8:8 + DC], (G[..., 8 + DC] if mtgs else None)
-        gstr, pstr = host_i64([RS] * 6), host_i64([RS, 1, RS, 1, RS])
+        gstr, pstr = host_i64([RS] * 6), host_i64([RS, RS, RS, 1, RS])
     bwd = lambda: call("mtgs_blend_bwd", 1, N, DC, ptr(means2d), ptr(conics), ptr(cols), ptr(opac), None, ptr(dep), ed,
                        W, H, 16, tw, th, ptr(off), ptr(flat), M, ptr(alphas), ptr(last), ptr(render), ptr(vr), ptr(va),
-                       ptr(v2d), ptr(vab), ptr(vcon), ptr(vcl), ptr(vdp), ptr(vop), gstr, optr, st)
+                       ptr(v2d), ptr(vab), ptr(vcon), ptr(vcl), ptr(vdp), ptr(vop), gstr, ptr(rank), optr, st)
     res["blend_bwd"] = timeit(bwd, args.reps)
     vm_ = torch.empty_like(d["means"]); vq = torch.empty_like(d["quats"]); vs = torch.empty_like(d["scales"]); vvm = torch.empty_like(vm)
-    vdep = torch.randn_like(depths); vopn = torch.empty_like(d["opacities"])
+    vdep = torch.randn_like(depths) if (vdp is None or rank is None) else vdp
+    vopn = torch.empty_like(d["opacities"])
+    if rank is None and pstr is not None:
+        pstr = host_i64([RS, 1, RS, 1, RS])
+    dense_out = rank is not None
+    vids = torch.nonzero(radii.reshape(-1) > 0).int().reshape(-1).contiguous() if dense_out else None
+    n_vis_k = vids.numel() if dense_out else 0
+    vws = torch.empty(max(n_vis_k, 1), 12, device=dev) if dense_out else None
+    d2 = torch.empty_like(means2d) if dense_out else None
+    dab = torch.empty_like(means2d) if (dense_out and mtgs) else None
+    dcl = torch.empty_like(cols) if dense_out else None
     res["project_bwd"] = timeit(lambda: call("mtgs_project_bwd", 1, N, ptr(d["means"]), ptr(d["quats"]), ptr(d["scales"]), ptr(vm), ptr(K), W, H, 0.3,
                                               ptr(radii), ptr(conics), ptr(comps), ptr(d["opacities"]), ptr(v2d), ptr(vdep), ptr(vcon), None,
-                                              ptr(vop), ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), ptr(vopn), pstr, st), args.reps)
+                                              ptr(vop), ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), ptr(vopn), pstr, ptr(rank), ptr(vab), ptr(vcl), DC,
+                                              host_i64([RS, RS]) if dense_out else None, ptr(d2), ptr(dab), ptr(dcl), ptr(vids), n_vis_k, ptr(vws), st), args.reps)
     n_vis = int((radii > 0).sum())
     print(f"N={N} {W}x{H} variant={args.variant} n_vis={n_vis} M={M} D={D}")
     tot = 0.0
