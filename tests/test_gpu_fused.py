@@ -1,0 +1,118 @@
+"""The one-node rasterization() (wrapper._FusedRasterization: compact gradient rows per visible Gaussian,
+projection backward with dense by-products) against the operator-by-operator composition of the same HIP
+kernels (projection_with_opacities -> isect_tiles -> rasterize_to_pixels[_with_depth]), which is what
+gsplat.rendering.rasterization chains (reference call site mtgs_scene_graph.py:641-662)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _compose(P, vm, K, W, H, render_mode, rasterize_mode, absgrad, backgrounds=None):
+    from mtgs_amd import wrapper as w
+    Cn = vm.shape[0]
+    radii, means2d, depths, conics, comps, opac = w.projection_with_opacities(
+        P["means"], P["quats"], P["scales"], vm, K, P["opacities"], W, H,
+        calc_compensations=(rasterize_mode == "antialiased"))
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, tw, th)
+    off = w.isect_offset_encode(isect_ids, Cn, tw, th)
+    cols = P["colors"].unsqueeze(0).expand(Cn, -1, -1)
+    if render_mode == "RGB":
+        render, alpha = w.rasterize_to_pixels(means2d, conics, cols, opac, W, H, 16, off, flat, backgrounds=backgrounds,
+                                              absgrad=absgrad)
+    else:
+        render, alpha = w.rasterize_to_pixels_with_depth(means2d, conics, cols, opac, depths, render_mode == "RGB+ED",
+                                                         W, H, 16, off, flat, backgrounds=backgrounds, absgrad=absgrad)
+    return render, alpha, {"means2d": means2d, "depths": depths, "conics": conics, "opacities": opac, "radii": radii,
+                           "flatten_ids": flat}
+
+
+def _scene(N, D, seed, dev):
+    from mtgs_amd.synthetic import make_scene
+    sc = make_scene(N, seed=seed, sh_degree=None, extent=(10.0, 3.0, 10.0))
+    g = torch.Generator().manual_seed(seed + 100)
+    sc["colors"] = torch.rand(N, D, generator=g)
+    return {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+
+
+@pytest.mark.parametrize("cams,D,render_mode,rasterize_mode,absgrad,extra", [
+    (1, 3, "RGB+ED", "antialiased", True, False),   # what MTGS.py drives
+    (1, 3, "RGB", "classic", False, True),          # + losses on info tensors
+    (2, 3, "RGB+ED", "antialiased", True, True),    # several cameras: generic projection backward
+    (1, 6, "RGB+ED", "antialiased", True, False),   # RGB + normals (7 blended channels)
+    (1, 16, "RGB", "classic", True, False),         # wide colours: un-staged by-product stores
+    (1, 15, "RGB+D", "classic", False, False),
+])
+def test_fused_equals_composition(hip_lib, cams, D, render_mode, rasterize_mode, absgrad, extra):
+    from mtgs_amd import rasterization
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    N, W, H = 30_000, 333, 250
+    vms, Ks = zip(*[make_camera(W, H, yaw_deg=30.0 * c) for c in range(cams)])
+    K = torch.cat(Ks).to(dev)
+    g = torch.Generator().manual_seed(5)
+    DT = D + (render_mode != "RGB")
+    Gc, Ga = torch.randn(cams, H, W, DT, generator=g).to(dev), torch.randn(cams, H, W, 1, generator=g).to(dev)
+    bg = torch.rand(cams, D, generator=g).to(dev).requires_grad_(True) if D == 3 else None
+    Gm, Gd = torch.randn(cams, N, 2, generator=g).to(dev), torch.randn(cams, N, generator=g).to(dev)
+    Gq, Go = torch.randn(cams, N, 3, generator=g).to(dev), torch.randn(cams, N, generator=g).to(dev)
+
+    results = []
+    for fused in (True, False):
+        P = _scene(N, D, 3, dev)
+        vm = torch.cat(vms).to(dev).requires_grad_(True)
+        bgi = None if bg is None else bg.detach().clone().requires_grad_(True)
+        if fused:
+            render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K, W, H,
+                                                packed=False, render_mode=render_mode, rasterize_mode=rasterize_mode,
+                                                absgrad=absgrad, backgrounds=bgi)
+        else:
+            render, alpha, info = _compose(P, vm, K, W, H, render_mode, rasterize_mode, absgrad, backgrounds=bgi)
+        info["means2d"].retain_grad()
+        loss = (render * Gc).sum() + (alpha * Ga).sum()
+        if extra:
+            vis = (info["radii"] > 0)
+            loss = loss + (info["means2d"] * Gm * vis[..., None]).sum() + (info["depths"] * Gd * vis).sum() \
+                + (info["conics"] * Gq * vis[..., None]).sum() * 1e-3 + (info["opacities"] * Go * vis).sum()
+        loss.backward()
+        grads = {k: P[k].grad for k in P}
+        grads["viewmat"] = vm.grad
+        if bgi is not None:
+            grads["bg"] = bgi.grad
+        grads["means2d.grad"] = info["means2d"].grad
+        if absgrad:
+            grads["means2d.absgrad"] = info["means2d"].absgrad
+        results.append((render.detach(), alpha.detach(), info, grads))
+    (r1, a1, i1, g1), (r0, a0, i0, g0) = results
+    assert torch.equal(r1, r0) and torch.equal(a1, a0)                      # same kernels, same inputs
+    assert torch.equal(i1["radii"], i0["radii"]) and torch.equal(i1["flatten_ids"], i0["flatten_ids"])
+    assert torch.equal(i1["means2d"].detach(), i0["means2d"].detach())
+    assert set(g1) == set(g0)
+    for k in g0:
+        assert g1[k] is not None and g0[k] is not None, k
+        assert g1[k].shape == g0[k].shape and g1[k].is_contiguous(), k
+        scale = float(g0[k].abs().max())
+        err = float((g1[k] - g0[k]).abs().max())
+        assert scale > 0 and err <= 2e-4 * scale + 1e-6, f"{k}: {err} vs {scale}"   # fp32 atomics in another order
+
+
+def test_fused_no_visible_gaussians(hip_lib):
+    """Every Gaussian behind the camera: zero image, zero gradients, nothing reads a row."""
+    from mtgs_amd import rasterization
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    P = _scene(1000, 3, 1, dev)
+    with torch.no_grad():
+        P["means"][:, 2] = -5.0 - P["means"][:, 2].abs()
+    vm, K = make_camera(64, 48)
+    render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm.to(dev), K.to(dev),
+                                        64, 48, packed=False, render_mode="RGB+ED", absgrad=True)
+    info["means2d"].retain_grad()
+    (render.sum() + alpha.sum()).backward()
+    assert int((info["radii"] > 0).sum()) == 0 and float(render.detach().abs().max()) == 0.0
+    for k in ("means", "quats", "scales", "opacities", "colors"):
+        assert P[k].grad is not None and float(P[k].grad.abs().max()) == 0.0
+    assert float(info["means2d"].grad.abs().max()) == 0.0 and float(info["means2d"].absgrad.abs().max()) == 0.0
