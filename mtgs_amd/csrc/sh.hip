@@ -175,6 +175,96 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(int64_t n, int K,
     colors[g * 3] = r; colors[g * 3 + 1] = gg; colors[g * 3 + 2] = bb;
 }
 
+// ---- K == 16 forward: one 16-lane DPP row per Gaussian, no LDS ---------------------------------
+// MTGS allocates K = 16 coefficients per Gaussian (sh_degree 3) from step 0.  With K = 16, lane (g, k) of a
+// wave = basis k of Gaussian g: the 64 lanes of a load instruction read 64 x 12 B = 768 CONTIGUOUS bytes
+// (4 whole rows), nothing is staged through LDS, there is no barrier, and the sum over k is a 4-step DPP
+// butterfly inside the 16-lane row.  Each lane evaluates only ITS basis function: real SH factor as
+//   b_k = (a0 + a1 z + a2 z^2 + a3 z^3) * s_k,  s_k in {1, x, y, 2xy, x^2-y^2, fS2, fC2}
+// (associated Legendre polynomial in z times the azimuthal factor), with per-lane constants a0..a3.
+// Measured 125 -> see DESIGN.md table (sh_fwd_k16_kernel).
+struct ShLaneConst { float a0, a1, a2, a3; int sel; };
+__device__ __forceinline__ ShLaneConst sh_lane_const(int k) {
+    // sel: 0 = 1, 1 = x, 2 = y, 3 = fS1 (2xy), 4 = fC1 (x^2-y^2), 5 = fS2, 6 = fC2
+    switch (k) {
+        case 0: return {0.2820947917738781f, 0.f, 0.f, 0.f, 0};
+        case 1: return {-0.48860251190292f, 0.f, 0.f, 0.f, 2};
+        case 2: return {0.f, 0.48860251190292f, 0.f, 0.f, 0};
+        case 3: return {-0.48860251190292f, 0.f, 0.f, 0.f, 1};
+        case 4: return {0.5462742152960395f, 0.f, 0.f, 0.f, 3};
+        case 5: return {0.f, -1.092548430592079f, 0.f, 0.f, 2};
+        case 6: return {-0.3153915652525201f, 0.f, 0.9461746957575601f, 0.f, 0};
+        case 7: return {0.f, -1.092548430592079f, 0.f, 0.f, 1};
+        case 8: return {0.5462742152960395f, 0.f, 0.f, 0.f, 4};
+        case 9: return {-0.5900435899266435f, 0.f, 0.f, 0.f, 5};
+        case 10: return {0.f, 1.445305721320277f, 0.f, 0.f, 3};
+        case 11: return {0.4570457994644658f, 0.f, -2.285228997322329f, 0.f, 2};
+        case 12: return {0.f, -1.119528997770346f, 0.f, 1.865881662950577f, 0};
+        case 13: return {0.4570457994644658f, 0.f, -2.285228997322329f, 0.f, 1};
+        case 14: return {0.f, 1.445305721320277f, 0.f, 0.f, 4};
+        default: return {-0.5900435899266435f, 0.f, 0.f, 0.f, 6};
+    }
+}
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return v;
+}
+constexpr int SH16_BLOCK = 256, SH16_UNROLL = 8, SH16_PER_WAVE = 4 * SH16_UNROLL;
+struct F3 { float x, y, z; };
+template <int DEG>
+__global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const float *__restrict__ dirs,
+                                                                const float *__restrict__ coeffs,
+                                                                const uint8_t *__restrict__ masks,
+                                                                float *__restrict__ colors) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
+    const ShLaneConst lc = sh_lane_const(k);
+    const bool active = k < NB;
+    const int64_t wave = (int64_t)blockIdx.x * (SH16_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t g_first = wave * SH16_PER_WAVE + sub;
+    F3 c[SH16_UNROLL], d[SH16_UNROLL];
+    bool on[SH16_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SH16_UNROLL; ++u) {   // all loads of the wave's 32 Gaussians are issued up front
+        const int64_t g = g_first + 4 * u;
+        on[u] = g < n && (!masks || masks[g]);
+        c[u] = F3{0.f, 0.f, 0.f};
+        d[u] = F3{0.f, 0.f, 1.f};
+        if (on[u]) {
+            d[u] = *reinterpret_cast<const F3 *>(dirs + g * 3);
+            if (active) c[u] = *reinterpret_cast<const F3 *>(coeffs + (g * 16 + k) * 3);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SH16_UNROLL; ++u) {
+        const int64_t g = g_first + 4 * u;
+        float x = d[u].x, y = d[u].y, z = d[u].z;
+        const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
+        x *= inorm; y *= inorm; z *= inorm;
+        float sfac = 1.f;
+        if (DEG >= 1) {
+            sfac = lc.sel == 1 ? x : sfac;
+            sfac = lc.sel == 2 ? y : sfac;
+        }
+        if (DEG >= 2) {
+            const float fS1 = 2.f * x * y, fC1 = x * x - y * y;
+            sfac = lc.sel == 3 ? fS1 : sfac;
+            sfac = lc.sel == 4 ? fC1 : sfac;
+            if (DEG >= 3) {
+                sfac = lc.sel == 5 ? x * fS1 + y * fC1 : sfac;
+                sfac = lc.sel == 6 ? x * fC1 - y * fS1 : sfac;
+            }
+        }
+        const float b = (lc.a0 + z * (lc.a1 + z * (lc.a2 + z * lc.a3))) * sfac;
+        const float r = row16_sum(b * c[u].x), gg = row16_sum(b * c[u].y), bb = row16_sum(b * c[u].z);
+        // lanes 0..2 of the row write the three channels: 4 rows -> 48 contiguous bytes per instruction
+        if (k < 3 && g < n) colors[g * 3 + k] = on[u] ? (k == 0 ? r : (k == 1 ? gg : bb)) : 0.f;
+    }
+}
+
 template <int DEG>
 __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
                                                          const float *__restrict__ dirs,
@@ -259,6 +349,17 @@ extern "C" int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, cons
     if (n == 0) return MTGS_OK;
     MTGS_REQUIRE(dirs && coeffs && colors, MTGS_EINVAL, "mtgs_sh_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (K == 16 && degree <= 3) {
+        const unsigned g16 = (unsigned)ceil_div64(n, SH16_PER_WAVE * (SH16_BLOCK / 64));
+        switch (degree) {
+            case 0: sh_fwd_k16_kernel<0><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
+            case 1: sh_fwd_k16_kernel<1><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
+            case 2: sh_fwd_k16_kernel<2><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
+            default: sh_fwd_k16_kernel<3><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
+        }
+        MTGS_CHECK_LAUNCH("mtgs_sh_fwd");
+        return MTGS_OK;
+    }
     const unsigned grid = (unsigned)ceil_div64(n, SH_BLOCK);
     switch (degree) {
         case 0: sh_fwd_kernel<0><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
