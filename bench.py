@@ -112,15 +112,10 @@ def make_step(args, dev, world):
                 rasterize_mode="classic")
         info["means2d"].retain_grad()
         torch.autograd.backward([render, alpha], [Gc, Ga])
-        if sparse:  # ONE exchange per step: sum of the Gaussian gradients over the ranks (cameras)
-            def local_sh_backward():  # runs while the rows are on the wire
-                sh2 = spherical_harmonics(3, dirs, params["coeffs"])
-                sh2.backward(sh_out.grad)
-                return params["coeffs"].grad
-
+        if sparse:  # ONE exchange per step: sum of the Gaussian gradients over the ranks (cameras); the SH
+            # backward of every rank's rows (this rank's included) happens inside the receiver's reduction pass
             g = exchange.exchange(info["radii"][0], params["means"].detach(), cam_pos, params["means"].grad,
-                                  params["quats"].grad, params["scales"].grad, params["opacities"].grad, sh_out.grad, 3,
-                                  local_coeff_grad=local_sh_backward)
+                                  params["quats"].grad, params["scales"].grad, params["opacities"].grad, sh_out.grad, 3)
             for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
                 params[name].grad = t
             info_box["grad_bytes"] = exchange.last_bytes

@@ -227,6 +227,25 @@ int mtgs_dp_accumulate(int64_t n_rows, const float *rows, int64_t N, int K, int 
                        const float *cam_pos, float *v_means, float *v_quats, float *v_scales,
                        float *v_opacities, float *v_coeffs, void *stream);
 
+
+/* Ordered variant + one-pass reduction (what mtgs_amd.dist.SparseGradExchange uses for K <= 16, degree <= 3).
+ * A sender's visibility map: words[ceil(N/64)] u64 (bit n%64 of word n/64 = radii[n] > 0) and prefix[ceil(N/64)] u32
+ * (set bits in the words before).  mtgs_dp_pack_ordered builds both, count[1] i32 (device) = number of rows, and
+ * writes the rows in INDEX order: row(n) = prefix[n/64] + popcount(words[n/64] below bit n%64), so a receiver finds
+ * any Gaussian in any sender's rows from the sender's map alone (block_counts[ceil(N/1024)] u32 is scratch).
+ * mtgs_dp_reduce: W senders' maps (sender r's words at (char*)words + r*map_stride_bytes, prefix likewise), rows
+ * (sender r at rows + r*row_stride floats), cams[W,3]; ONE pass over the N Gaussians sums every sender's rows in
+ * registers (v_rgb expanded through basis(normalize(mean - cam_r))) and WRITES v_means[N,3] v_quats[N,4]
+ * v_scales[N,3] v_opacities[N] v_coeffs[N,K,3] (nullable) -- the sum over senders, zeros where no sender has a row. */
+int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float *v_means, const float *v_quats,
+                         const float *v_scales, const float *v_opacities, const float *v_rgb, uint64_t *words,
+                         uint32_t *prefix, int32_t *count, uint32_t *block_counts, float *rows, int64_t capacity,
+                         void *stream);
+int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                   const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
+                   const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                   float *v_coeffs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_dp_pack": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "mtgs_dp_reduce": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],

@@ -29,7 +29,7 @@ void mtgs_set_error(const char *fmt, ...);
         }                                                                    \
     } while (0)
 
-static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline __host__ __device__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 #ifdef __HIPCC__
 // ---- wave64 cross-lane helpers (DPP; CDNA has row_bcast) ---------------------------------------

@@ -14,6 +14,7 @@
 //
 // Roofline: HBM, read-modify-write of (44 + 12K) bytes per row.
 #include "common.hpp"
+#include "sh_lane.hpp"
 
 namespace {
 
@@ -145,6 +146,199 @@ __global__ __launch_bounds__(256) void dp_pack_kernel(
     }
 }
 
+// ---- ordered exchange + one-pass reduction (the default of mtgs_amd.dist.SparseGradExchange) --------------------
+// A sender describes WHICH Gaussians it has rows for by a visibility map: words[N/64] (bit n%64 of word n/64 =
+// radii[n] > 0) and prefix[N/64] (number of set bits in the words before).  Its rows are packed in index order, so
+// row(n) = prefix[n/64] + popcount(words[n/64] below bit n%64): any receiver can look a Gaussian up in any sender's
+// rows without a per-sender index array.  With that, the receiver's work is ONE streaming pass over the Gaussians
+// (dp_reduce_kernel) that sums every sender's contribution in registers and WRITES the dense gradients once --
+// instead of one read-modify-write pass of (44 + 12 K) bytes per row per sender plus a local SH backward
+// (7 x 55 + 72 us at 8 ranks, 2M Gaussians).
+// Sender, launch 1: visibility words + the number of visible Gaussians per 1024-Gaussian block.
+constexpr int VIS_BLOCK = 1024;  // Gaussians per block = 16 words
+__global__ __launch_bounds__(VIS_BLOCK) void dp_vis_words_kernel(int64_t N, const int32_t *__restrict__ radii,
+                                                                 unsigned long long *__restrict__ words,
+                                                                 uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t s_c[VIS_BLOCK / 64];
+    const int64_t n = (int64_t)blockIdx.x * VIS_BLOCK + threadIdx.x;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(n < N && radii[n] > 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        if (n < N) words[n >> 6] = m;
+        s_c[wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < VIS_BLOCK / 64; ++w) t += s_c[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+// Sender, launch 2: every block sums the counts of the blocks in front of it (a few thousand values), which
+// gives the word prefixes (written for the receivers) and the row of each visible Gaussian; the last block
+// also publishes the total.
+__global__ __launch_bounds__(VIS_BLOCK) void dp_pack_ordered_kernel(
+    int64_t N, const unsigned long long *__restrict__ words, const uint32_t *__restrict__ block_counts,
+    uint32_t *__restrict__ prefix, int32_t *__restrict__ count, const float *__restrict__ v_means,
+    const float *__restrict__ v_quats, const float *__restrict__ v_scales, const float *__restrict__ v_opacities,
+    const float *__restrict__ v_rgb, float *__restrict__ rows, int64_t capacity) {
+    __shared__ uint32_t s_red[VIS_BLOCK / 64];
+    __shared__ uint32_t s_wpre[VIS_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += VIS_BLOCK) part += block_counts[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < VIS_BLOCK / 64; ++w) base += s_red[w];
+    const int64_t n = (int64_t)blockIdx.x * VIS_BLOCK + tid;
+    const int64_t wi = n >> 6;
+    const unsigned long long w = n < N ? words[wi] : 0ull;
+    if (lane == 0) s_wpre[wave] = (uint32_t)__popcll(w);
+    __syncthreads();
+    uint32_t wpre = base, total = base;
+#pragma unroll
+    for (int k = 0; k < VIS_BLOCK / 64; ++k) {
+        if (k < wave) wpre += s_wpre[k];
+        total += s_wpre[k];
+    }
+    if (lane == 0 && n < N) prefix[wi] = wpre;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = (int32_t)total;
+    if (n >= N || !((w >> lane) & 1ull)) return;
+    const int64_t slot = (int64_t)wpre + __popcll(w & ((1ull << lane) - 1ull));
+    if (slot >= capacity) return;
+    float4 *dst = reinterpret_cast<float4 *>(rows + slot * 16);
+    dst[0] = make_float4(v_means[n * 3], v_means[n * 3 + 1], v_means[n * 3 + 2], v_quats[n * 4]);
+    dst[1] = make_float4(v_quats[n * 4 + 1], v_quats[n * 4 + 2], v_quats[n * 4 + 3], v_scales[n * 3]);
+    dst[2] = make_float4(v_scales[n * 3 + 1], v_scales[n * 3 + 2], v_opacities[n], v_rgb ? v_rgb[n * 3] : 0.f);
+    dst[3] = make_float4(v_rgb ? v_rgb[n * 3 + 1] : 0.f, v_rgb ? v_rgb[n * 3 + 2] : 0.f, 0.f, __int_as_float((int)n));
+}
+
+// Receiver: one WAVE per visibility word (64 consecutive Gaussians), so a sender's word and prefix are wave-uniform
+// (held in scalar registers for up to DP_BATCH senders at a time) and the per-Gaussian lookup is a shift and a
+// popcount.  Inside the wave, 16 lanes per Gaussian (4 Gaussians per step, 16 steps): lane k = gradient component k
+// (geometry, k < 11) and SH basis k.  For every sender with the Gaussian's bit set: 64 coalesced bytes of its row,
+// geometry added per lane, basis_k(normalize(mean - cam_sender)) * v_rgb accumulated per lane; then ONE write.
+struct DpSenders {
+    const unsigned long long *words;  // sender r: (char*)words + r * map_stride_bytes
+    const uint32_t *prefix;           //           (char*)prefix + r * map_stride_bytes
+    int64_t map_stride_bytes;
+    const float *rows;                // sender r: rows + r * row_stride (floats)
+    int64_t row_stride;
+    const float *cams;                // [W,3]
+    int W;
+};
+constexpr int DP_MAX_SENDERS = 64;  // one lane per sender computes its row span of a tile
+constexpr int DP_TILE = 32;    // Gaussians per wave (half a visibility word)
+constexpr int DP_MAXSTEP = DP_TILE / 4;
+// ROW-centric inside a Gaussian tile: a wave owns 32 consecutive Gaussians and keeps their 16 x 4 accumulators
+// (lane k: geometry component k | coefficient k x rgb) in LDS.  Rows are packed in index order, so the rows a sender
+// has for the tile are CONTIGUOUS: [prefix + popcount(bits below the tile), + popcount(tile bits)).  The wave walks
+// them four at a time (16 lanes per row: dense lanes, ~5 rows per sender and tile at 15 % visibility), finds the
+// Gaussian from the index stored in the row, evaluates ITS basis function for the sender's camera and adds into the
+// LDS accumulators; the dense gradients are written once at the end.  (A Gaussian-centric loop with a predicate per
+// (Gaussian, sender) pair ran 48 % of its steps with ~30 % of the lanes useful: 512 us at 8 senders.)
+template <int MAXDEG>
+__global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t N, int K, int nb, const float *__restrict__ means,
+                                                        const DpSenders S, float *__restrict__ v_means,
+                                                        float *__restrict__ v_quats, float *__restrict__ v_scales,
+                                                        float *__restrict__ v_opacities, float *__restrict__ v_coeffs) {
+    __shared__ float4 s_acc[4][DP_TILE][16];
+    const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t g0 = tile * DP_TILE;
+    if (g0 >= N) return;
+    const int64_t wi = g0 >> 6;
+    const int half = (int)(tile & 1);
+    ShLaneConst lc = sh_lane_const(k);
+    if (k >= nb) { lc.a0 = 0.f; lc.a1 = 0.f; lc.a2 = 0.f; lc.a3 = 0.f; }
+    float4(*acc)[16] = s_acc[wave];
+#pragma unroll
+    for (int it = 0; it < DP_MAXSTEP; ++it) acc[it * 4 + sub][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the tile's means in LDS: a global gather by the row's index would put a dependent memory round trip into
+    // every step (row -> index -> mean), which is what bounded the kernel (576 us at 8 senders)
+    __shared__ float s_mean[4][DP_TILE * 3];
+    float *tmean = s_mean[wave];
+    if (v_coeffs) {
+        for (int e = lane; e < DP_TILE * 3; e += 64) tmean[e] = g0 * 3 + e < N * 3 ? means[g0 * 3 + e] : 1.f;
+    }
+    const int row_lane0 = (lane & ~15) << 2;  // byte address of lane 0 of this 16-lane row (ds_bpermute)
+    // (first row, number of rows) every sender has for this tile: one lane per sender, one memory round trip
+    __shared__ int2 s_span[4][DP_MAX_SENDERS];
+    if (lane < S.W) {
+        const char *wp = reinterpret_cast<const char *>(S.words) + lane * S.map_stride_bytes + wi * 8;
+        const char *pp = reinterpret_cast<const char *>(S.prefix) + lane * S.map_stride_bytes + wi * 4;
+        const unsigned long long wv = *reinterpret_cast<const unsigned long long *>(wp);
+        const unsigned lo = (unsigned)wv, hi = (unsigned)(wv >> 32);
+        const int start = (int)*reinterpret_cast<const uint32_t *>(pp) + (half ? __builtin_popcount(lo) : 0);
+        s_span[wave][lane] = make_int2(start, __builtin_popcount(half ? hi : lo));
+    }
+    // Software pipeline over the senders: the rows of sender r + 1 are in flight while sender r is accumulated
+    // (all of a sender's row loads are issued before any is used: one memory round trip per sender, overlapped).
+    float nxt[DP_MAXSTEP];
+    int nxt_cnt = 0;
+    auto issue = [&](int r, float (&dst)[DP_MAXSTEP], int &cnt_out) {
+        const int2 sp = s_span[wave][r];
+        const int start = __builtin_amdgcn_readfirstlane(sp.x), cnt = __builtin_amdgcn_readfirstlane(sp.y);
+        cnt_out = cnt;
+        const float *rows_r = S.rows + (int64_t)r * S.row_stride + (int64_t)start * 16;
+#pragma unroll
+        for (int st = 0; st < DP_MAXSTEP; ++st) {
+            const int j = st * 4 + sub;
+            dst[st] = j < cnt ? rows_r[j * 16 + k] : 0.f;
+        }
+    };
+    issue(0, nxt, nxt_cnt);
+    for (int r = 0; r < S.W; ++r) {
+        float cur[DP_MAXSTEP];
+#pragma unroll
+        for (int st = 0; st < DP_MAXSTEP; ++st) cur[st] = nxt[st];
+        const int cnt = nxt_cnt;
+        if (r + 1 < S.W) issue(r + 1, nxt, nxt_cnt);
+        if (cnt == 0) continue;  // wave-uniform: this sender has none of the tile's Gaussians
+        const float cx = S.cams[r * 3], cy = S.cams[r * 3 + 1], cz = S.cams[r * 3 + 2];
+#pragma unroll
+        for (int st = 0; st < DP_MAXSTEP; ++st) {
+            if (st * 4 >= cnt) break;  // wave-uniform
+            const bool on = st * 4 + sub < cnt;
+            const int vi = __float_as_int(cur[st]);
+            const int idx = __builtin_amdgcn_ds_bpermute(row_lane0 + 15 * 4, vi);
+            const int pos = on ? (int)(idx - (int)g0) : 0;
+            float4 a = acc[pos][k];
+            a.x += k < 11 ? cur[st] : 0.f;
+            if (v_coeffs) {
+                const float q0 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 11 * 4, vi));
+                const float q1 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 12 * 4, vi));
+                const float q2 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 13 * 4, vi));
+                float x = tmean[pos * 3] - cx, y = tmean[pos * 3 + 1] - cy, z = tmean[pos * 3 + 2] - cz;
+                const float inorm = __builtin_amdgcn_rsqf((x * x + y * y) + z * z);
+                x *= inorm; y *= inorm; z *= inorm;
+                const float bk = sh_lane_basis<MAXDEG>(lc, x, y, z);
+                a.y += bk * q0; a.z += bk * q1; a.w += bk * q2;
+            }
+            if (on) acc[pos][k] = a;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < DP_MAXSTEP; ++it) {
+        const int64_t n = g0 + it * 4 + sub;
+        if (n >= N) continue;
+        const float4 a = acc[it * 4 + sub][k];
+        if (k < 3) v_means[n * 3 + k] = a.x;
+        else if (k < 7) v_quats[n * 4 + (k - 3)] = a.x;
+        else if (k < 10) v_scales[n * 3 + (k - 7)] = a.x;
+        else if (k == 10) v_opacities[n] = a.x;
+        if (v_coeffs && k < K) {
+            float *dst = v_coeffs + (n * K + k) * 3;
+            dst[0] = a.y; dst[1] = a.z; dst[2] = a.w;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mtgs_dp_pack(int64_t N, const int32_t *radii, const float *v_means, const float *v_quats,
@@ -184,5 +378,60 @@ extern "C" int mtgs_dp_accumulate(int64_t n_rows, const float *rows, int64_t N, 
         dp_accumulate_kernel<32><<<(unsigned)ceil_div64(n_rows * 32, 256), 256, 0, st>>>(
             n_rows, rows, K, nb, means, cam_pos, v_means, v_quats, v_scales, v_opacities, v_coeffs);
     MTGS_CHECK_LAUNCH("mtgs_dp_accumulate");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float *v_means, const float *v_quats,
+                                    const float *v_scales, const float *v_opacities, const float *v_rgb,
+                                    uint64_t *words, uint32_t *prefix, int32_t *count, uint32_t *block_counts,
+                                    float *rows, int64_t capacity, void *stream) {
+    MTGS_REQUIRE(N >= 0 && N < ((int64_t)1 << 31) && capacity >= 0, MTGS_EINVAL, "mtgs_dp_pack_ordered: bad sizes");
+    MTGS_REQUIRE(count, MTGS_EINVAL, "mtgs_dp_pack_ordered: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_dp_pack_ordered: memset failed");
+        return MTGS_OK;
+    }
+    MTGS_REQUIRE(radii && words && prefix && block_counts && v_means && v_quats && v_scales && v_opacities && rows,
+                 MTGS_EINVAL, "mtgs_dp_pack_ordered: null pointer");
+    const unsigned grid = (unsigned)ceil_div64(N, VIS_BLOCK);
+    dp_vis_words_kernel<<<grid, VIS_BLOCK, 0, st>>>(N, radii, (unsigned long long *)words, block_counts);
+    dp_pack_ordered_kernel<<<grid, VIS_BLOCK, 0, st>>>(N, (const unsigned long long *)words, block_counts, prefix, count,
+                                                      v_means, v_quats, v_scales, v_opacities, v_rgb, rows, capacity);
+    MTGS_CHECK_LAUNCH("mtgs_dp_pack_ordered");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                              const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
+                              int64_t row_stride, const float *cams, float *v_means, float *v_quats,
+                              float *v_scales, float *v_opacities, float *v_coeffs, void *stream) {
+    MTGS_REQUIRE(W >= 1 && N >= 0 && map_stride_bytes >= 0 && row_stride >= 0, MTGS_EINVAL, "mtgs_dp_reduce: bad sizes");
+    MTGS_REQUIRE(W <= DP_MAX_SENDERS, MTGS_EUNSUPPORTED, "mtgs_dp_reduce: %d senders (at most %d; use mtgs_dp_accumulate)", W,
+                 DP_MAX_SENDERS);
+    if (N == 0) return MTGS_OK;
+    MTGS_REQUIRE(words && prefix && rows && v_means && v_quats && v_scales && v_opacities, MTGS_EINVAL,
+                 "mtgs_dp_reduce: null pointer");
+    int nb = 0;
+    if (v_coeffs) {
+        MTGS_REQUIRE(means && cams && degree >= 0 && (degree + 1) * (degree + 1) <= K, MTGS_EINVAL,
+                     "mtgs_dp_reduce: bad SH arguments (degree %d, K %d)", degree, K);
+        MTGS_REQUIRE(degree <= 3 && K <= 16, MTGS_EUNSUPPORTED,
+                     "mtgs_dp_reduce: degree %d / K %d (one basis per lane of a 16-lane row: degree <= 3, K <= 16; "
+                     "use mtgs_dp_accumulate)", degree, K);
+        nb = (degree + 1) * (degree + 1);
+    }
+    MTGS_REQUIRE(means, MTGS_EINVAL, "mtgs_dp_reduce: null pointer");
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W};
+    const unsigned grid = (unsigned)ceil_div64(ceil_div64(N, DP_TILE), 4);  // one wave per 32-Gaussian tile
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+        case 0: dp_reduce_kernel<0><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        case 1: dp_reduce_kernel<1><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        case 2: dp_reduce_kernel<2><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        default: dp_reduce_kernel<3><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+    }
+    MTGS_CHECK_LAUNCH("mtgs_dp_reduce");
     return MTGS_OK;
 }

@@ -13,6 +13,7 @@
 // fully-coalesced (float4 when the row is a multiple of 16 B) accesses, and each lane then walks
 // its row in LDS with an ODD row stride (bank = (lane*stride + j) mod 32 -> conflict-free).
 #include "common.hpp"
+#include "sh_lane.hpp"
 
 namespace {
 
@@ -183,28 +184,6 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(int64_t n, int K,
 //   b_k = (a0 + a1 z + a2 z^2 + a3 z^3) * s_k,  s_k in {1, x, y, 2xy, x^2-y^2, fS2, fC2}
 // (associated Legendre polynomial in z times the azimuthal factor), with per-lane constants a0..a3.
 // Measured 125 -> see DESIGN.md table (sh_fwd_k16_kernel).
-struct ShLaneConst { float a0, a1, a2, a3; int sel; };
-__device__ __forceinline__ ShLaneConst sh_lane_const(int k) {
-    // sel: 0 = 1, 1 = x, 2 = y, 3 = fS1 (2xy), 4 = fC1 (x^2-y^2), 5 = fS2, 6 = fC2
-    switch (k) {
-        case 0: return {0.2820947917738781f, 0.f, 0.f, 0.f, 0};
-        case 1: return {-0.48860251190292f, 0.f, 0.f, 0.f, 2};
-        case 2: return {0.f, 0.48860251190292f, 0.f, 0.f, 0};
-        case 3: return {-0.48860251190292f, 0.f, 0.f, 0.f, 1};
-        case 4: return {0.5462742152960395f, 0.f, 0.f, 0.f, 3};
-        case 5: return {0.f, -1.092548430592079f, 0.f, 0.f, 2};
-        case 6: return {-0.3153915652525201f, 0.f, 0.9461746957575601f, 0.f, 0};
-        case 7: return {0.f, -1.092548430592079f, 0.f, 0.f, 1};
-        case 8: return {0.5462742152960395f, 0.f, 0.f, 0.f, 4};
-        case 9: return {-0.5900435899266435f, 0.f, 0.f, 0.f, 5};
-        case 10: return {0.f, 1.445305721320277f, 0.f, 0.f, 3};
-        case 11: return {0.4570457994644658f, 0.f, -2.285228997322329f, 0.f, 2};
-        case 12: return {0.f, -1.119528997770346f, 0.f, 1.865881662950577f, 0};
-        case 13: return {0.4570457994644658f, 0.f, -2.285228997322329f, 0.f, 1};
-        case 14: return {0.f, 1.445305721320277f, 0.f, 0.f, 4};
-        default: return {-0.5900435899266435f, 0.f, 0.f, 0.f, 6};
-    }
-}
 __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -244,21 +223,7 @@ __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const
         float x = d[u].x, y = d[u].y, z = d[u].z;
         const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
         x *= inorm; y *= inorm; z *= inorm;
-        float sfac = 1.f;
-        if (DEG >= 1) {
-            sfac = lc.sel == 1 ? x : sfac;
-            sfac = lc.sel == 2 ? y : sfac;
-        }
-        if (DEG >= 2) {
-            const float fS1 = 2.f * x * y, fC1 = x * x - y * y;
-            sfac = lc.sel == 3 ? fS1 : sfac;
-            sfac = lc.sel == 4 ? fC1 : sfac;
-            if (DEG >= 3) {
-                sfac = lc.sel == 5 ? x * fS1 + y * fC1 : sfac;
-                sfac = lc.sel == 6 ? x * fC1 - y * fS1 : sfac;
-            }
-        }
-        const float b = (lc.a0 + z * (lc.a1 + z * (lc.a2 + z * lc.a3))) * sfac;
+        const float b = sh_lane_basis<DEG>(lc, x, y, z);
         const float r = row16_sum(b * c[u].x), gg = row16_sum(b * c[u].y), bb = row16_sum(b * c[u].z);
         // lanes 0..2 of the row write the three channels: 4 rows -> 48 contiguous bytes per instruction
         if (k < 3 && g < n) colors[g * 3 + k] = on[u] ? (k == 0 ? r : (k == 1 ? gg : bb)) : 0.f;

@@ -131,11 +131,18 @@ class SparseGradExchange:
     A rank renders one camera per step, so only the Gaussians visible in it (~15 % of a road block)
     have a non-zero gradient, and the gradient of the SH coefficients is rank-1 per Gaussian:
     v_coeffs[n,k,:] = basis_k(normalize(mean_n - cam_pos)) * v_rgb[n,:].  Each rank therefore sends
-    64-byte rows {v_mean, v_quat, v_scale, v_opacity, v_rgb, index} of its visible Gaussians plus
-    its camera position (19 MB instead of 472 MB at 2M Gaussians / SH degree 3), the rows are
-    all-gathered (xGMI is point-to-point: bytes are what costs), and every rank rebuilds the SUM of
-    all ranks' dense gradients locally (csrc/dp.hip).  Equal to the dense all-reduce up to fp32
-    summation order.  With a single process it degenerates to a local scatter of the own rows."""
+    64-byte rows {v_mean, v_quat, v_scale, v_opacity, v_rgb, index} of its visible Gaussians, in INDEX
+    order, plus a visibility map (one bit per Gaussian + a popcount prefix per 64) and its camera
+    position: 19 MB + 0.4 MB instead of 472 MB at 2M Gaussians / SH degree 3.  The rows are all-gathered
+    (xGMI is point-to-point: bytes are what costs) and every rank rebuilds the SUM of all ranks' dense
+    gradients in ONE streaming pass over the Gaussians (csrc/dp.hip: mtgs_dp_reduce looks every
+    Gaussian up in every sender's rows through the sender's map, sums in registers, and writes each
+    dense tensor once).  Equal to the dense all-reduce up to fp32 summation order.
+
+    Two collectives per step: a fixed-size one (row count, camera, map) whose counts the host needs
+    to size the second (the rows).  With a single process the exchange degenerates to a local
+    pack + reduce of the own rows.  SH layouts the one-pass kernel does not cover (K > 16 or
+    degree > 3) take the per-sender read-modify-write path (mtgs_dp_pack / mtgs_dp_accumulate)."""
 
     ROW = 16
 
@@ -145,27 +152,65 @@ class SparseGradExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rows = torch.empty((self.N, self.ROW), dtype=torch.float32, device=device)  # send buffer (worst case)
         self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        # meta record of a rank, int32 words: [count, cam x, cam y, cam z | words (u64) ... | prefix (u32) ...]
+        self.n_words = (self.N + 63) // 64
+        self.meta_len = 4 + 3 * self.n_words + (self.n_words & 1)   # even: every rank's u64 words stay 8-byte aligned
+        self.meta = torch.zeros(self.meta_len, dtype=torch.int32, device=device)
+        self.block_counts = torch.empty((self.N + 1023) // 1024 + 1, dtype=torch.int32, device=device)  # pack scratch
         self.last_bytes = 0
+
+    # ---- one-pass path -------------------------------------------------------------------------------
+    def _exchange_ordered(self, radii, means, cam_pos, v_means, v_quats, v_scales, v_opacities, v_rgb, sh_degree):
+        from ._lib import call, ptr, stream_of
+        N, K, dev, world = self.N, self.K, self.device, self.world
+        st = stream_of(means)
+        meta, nw = self.meta, self.n_words
+        words, prefix = meta[4:4 + 2 * nw], meta[4 + 2 * nw:]
+        meta[1:4].copy_(cam_pos.view(torch.int32))
+        call("mtgs_dp_pack_ordered", N, ptr(radii), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opacities),
+             ptr(v_rgb), ptr(words), ptr(prefix), ptr(meta), ptr(self.block_counts), ptr(self.rows), N, st)  # meta[0] = count
+        if world > 1:
+            metas = torch.empty((world, self.meta_len), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(metas, meta[None], group=self.group)
+            counts_h = metas[:, 0].tolist()       # host sync: buffer size for the payload exchange
+            cap = max(max(counts_h), 1)
+            recv = torch.empty((world, cap, self.ROW), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(recv.view(world * cap, self.ROW), self.rows[:cap], group=self.group)
+            self.last_bytes = world * (cap * self.ROW * 4 + self.meta_len * 4)
+        else:
+            metas, recv, cap = meta[None], self.rows, N
+            self.last_bytes = 0
+        cams = metas[:, 1:4].contiguous().view(torch.float32)
+        words_all, prefix_all = metas[:, 4:], metas[:, 4 + 2 * nw:]
+        v_coeffs = torch.empty((N, K, 3), dtype=torch.float32, device=dev) if v_rgb is not None else None
+        # the dense inputs were copied into the rows: they are overwritten with the sums
+        call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all),
+             self.meta_len * 4, ptr(recv), cap * self.ROW, ptr(cams), ptr(v_means), ptr(v_quats), ptr(v_scales),
+             ptr(v_opacities), ptr(v_coeffs), st)
+        return v_means, v_quats, v_scales, v_opacities, v_coeffs
 
     def exchange(self, radii: torch.Tensor, means: torch.Tensor, cam_pos: torch.Tensor, v_means: torch.Tensor,
                  v_quats: torch.Tensor, v_scales: torch.Tensor, v_opacities: torch.Tensor,
                  v_rgb: Optional[torch.Tensor], sh_degree: int, local_coeff_grad=None):
         """radii[N] (this rank's camera), means[N,3], cam_pos[3]; this rank's dense gradients v_* (they are
-        UPDATED IN PLACE with the other ranks' rows); v_rgb[N,3] is the gradient with respect to the SH
-        OUTPUT (before the +0.5 / clamp), or None for no SH part.  `local_coeff_grad` is a callable returning
-        this rank's own dense v_coeffs[N,K,3] (the local SH backward); it is invoked while the payload is in
-        flight, so its ~80 us hide behind the transfer.  Without it the coefficient gradient is rebuilt from
-        zeros including the own rows.
+        OVERWRITTEN with the sums over all ranks); v_rgb[N,3] is the gradient with respect to the SH
+        OUTPUT (before the +0.5 / clamp), or None for no SH part.
+        `local_coeff_grad` is only used by the per-sender fallback path (K > 16 or degree > 3): a callable
+        returning this rank's own dense v_coeffs[N,K,3], invoked while the payload is in flight.
         Returns (v_means, v_quats, v_scales, v_opacities, v_coeffs | None): dense sums over all ranks."""
         from ._lib import call, ptr, stream_of
         N, K, dev = self.N, self.K, self.device
         radii = radii.reshape(-1).contiguous()
         assert radii.numel() == N and means.shape == (N, 3)
         for t in (v_means, v_quats, v_scales, v_opacities):
-            assert t.is_contiguous(), "the local dense gradients are accumulated into in place"
+            assert t.is_contiguous(), "the local dense gradients are overwritten in place"
         v_rgb = None if v_rgb is None else v_rgb.contiguous()
         means = means.contiguous()
         cam_pos = cam_pos.reshape(3).to(torch.float32).contiguous()
+        if self.world <= 64 and (v_rgb is None or (K <= 16 and sh_degree <= 3)):
+            return self._exchange_ordered(radii, means, cam_pos, v_means, v_quats, v_scales, v_opacities, v_rgb,
+                                          sh_degree)
+        # ---- fallback: unordered rows, one read-modify-write pass per remote sender
         st = stream_of(means)
         world = self.world
         rebuild_own = v_rgb is not None and local_coeff_grad is None
