@@ -246,6 +246,30 @@ int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, cons
                    const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                    float *v_coeffs, void *stream);
 
+/* ---- caller side of the path: fused per-node activations ----------------------------
+ * One kernel per direction for what VanillaGaussianSplattingModel.get_gaussians does per step with a dozen PyTorch
+ * launches (mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:299-341; multi_color_gaussian_splatting.py
+ * :77-101 for the per-traversal coefficient sources):
+ *   scales = exp(scales_raw), quats = quats_raw / |quats_raw|, opacities = sigmoid(opacities_raw),
+ *   rgbs = clamp(SH(degree, normalize(means - cam_pos), [features_dc (+ features_dc_add) | features_rest]) + 0.5, 0, 1)
+ *          (use_sh = 0: rgbs = sigmoid(features_dc (+ features_dc_add)), the sh_degree-0 model).
+ * features_dc / features_dc_add (nullable) / features_rest are read in place: row_strides (HOST) = their row strides
+ * in floats {>= 3, >= 3, >= K_rest*3}, so a per-traversal slice of [N,T,..] needs no gather and nothing is concatenated.
+ * K_rest = K - 1 <= 15, degree <= 3.  clamp_mask[N] u8 (bit c: channel c passed the clamp) is saved for the backward.
+ * bwd: gradients with respect to the RAW parameters; g_features_dc[N,3] (also the gradient of features_dc_add) and
+ * g_features_rest[N,K_rest,3] are dense and fully written (zeros above the active degree).  means / cam_pos get no
+ * gradient: MTGS detaches the view directions (vanilla_gaussian_splatting.py:314). */
+int mtgs_node_fwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *scales_raw,
+                  const float *quats_raw, const float *opacities_raw, const float *features_dc,
+                  const float *features_dc_add, const float *features_rest, const int64_t *row_strides,
+                  const float *cam_pos, float *scales, float *quats, float *opacities, float *rgbs,
+                  uint8_t *clamp_mask, void *stream);
+int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *quats_raw,
+                  const float *cam_pos, const float *scales, const float *opacities, const float *rgbs,
+                  const uint8_t *clamp_mask, const float *v_scales, const float *v_quats, const float *v_opacities,
+                  const float *v_rgbs, float *g_scales_raw, float *g_quats_raw, float *g_opacities_raw,
+                  float *g_features_dc, float *g_features_rest, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,271 @@
+// node.hip -- fused per-node activations of an MTGS Gaussian node, forward and backward (SURVEY.md section 8f,
+// rank 1: the caller side of the rasterization path).
+//
+// Restates, in one kernel per direction, what VanillaGaussianSplattingModel.get_gaussians computes every step with
+// ~12 PyTorch launches (/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:299-341;
+// MultiColorGaussianSplattingModel.get_rgbs, multi_color_gaussian_splatting.py:77-101, differs only in WHERE the
+// coefficients come from: features_dc + features_adapters[:, t], features_rest[:, t]):
+//     scales    = exp(scales_raw)                         quats = quats_raw / |quats_raw|
+//     opacities = sigmoid(opacities_raw)
+//     colors    = cat(features_dc[:, None], features_rest)          <- a 384 MB copy at 2M Gaussians, K = 16
+//     dirs      = normalize(means.detach() - cam_pos)
+//     rgbs      = clamp(spherical_harmonics(n, dirs, colors) + 0.5, 0, 1)     (sigmoid(features_dc) when the model
+//                                                                              has sh_degree 0)
+// The fused kernels read features_dc / features_rest in place (row strides given, so a per-traversal slice of
+// [N,T,K-1,3] needs no gather copy) and the backward writes v_features_dc / v_features_rest directly -- no cat, no
+// split, no dirs / clamp temporaries: algorithmic bytes N*(40 + 12 K) + N*44 forward, the same plus N*12 K backward,
+// against ~4x that through the operator chain.
+//
+// Layout (as sh_fwd_k16_kernel): one 16-lane DPP row per Gaussian, lane k = SH basis k; the same lanes also carry the
+// small activations (lanes 0-2 scales, 4-7 quaternion -- an aligned quad, so |q|^2 is two quad_perm adds --, lane 8
+// opacity).  Roofline: HBM.
+#include "common.hpp"
+#include "sh_lane.hpp"
+
+namespace {
+
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lanes of a quad, in every lane
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+struct F3 { float x, y, z; };
+
+struct NodeParams {
+    const float *means, *scales_raw, *quats_raw, *opac_raw;  // [N,3] [N,3] [N,4] [N]
+    const float *dc, *dc_add, *rest;                         // rows of 3, 3 (nullable), Kr*3 floats
+    int64_t dc_stride, dc_add_stride, rest_stride;           // row strides in floats
+    const float *cam_pos;                                    // [3] device
+    int Kr;                                                  // SH bases in `rest` (K - 1)
+    int use_sh;                                              // 0: rgbs = sigmoid(dc [+ dc_add])
+};
+
+// A wave owns 64 consecutive Gaussians and uses TWO lane mappings:
+//   * lane-per-Gaussian for the small activations and for everything that is 3..4 floats per Gaussian
+//     (64 x 12 / 16 / 4 contiguous bytes per instruction -- per-row 4-byte accesses cost one instruction per 4
+//     Gaussians and bounded the first version at 2.7 TB/s);
+//   * the 16-lane-row mapping for the coefficients: in step `it`, row `sub` works on Gaussian 16*sub + it, so the
+//     lane that owns that Gaussian in the first mapping (16*sub + it) sits in the SAME row: results move between the
+//     mappings with a compare + select (row -> lane) or one ds_bpermute per value (lane -> row), never across rows.
+constexpr int NODE_BLOCK = 256, NODE_PER_WAVE = 64, NODE_STEPS = 16;
+struct F4 { float x, y, z, w; };
+
+template <int DEG>
+__global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const NodeParams P, float *__restrict__ scales,
+                                                              float *__restrict__ quats, float *__restrict__ opacities,
+                                                              float *__restrict__ rgbs, uint8_t *__restrict__ clamp_mask) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
+    const ShLaneConst lc = sh_lane_const(k);
+    const bool active = P.use_sh ? (k < NB && k - 1 < P.Kr) : (k == 0);
+    const int64_t g0 = ((int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
+    if (g0 >= N) return;
+    const float camx = P.cam_pos[0], camy = P.cam_pos[1], camz = P.cam_pos[2];
+    // ---- lane-per-Gaussian loads
+    const int64_t gl = g0 + lane;
+    const bool okl = gl < N;
+    F3 sr = F3{0.f, 0.f, 0.f};
+    F4 qr = F4{1.f, 0.f, 0.f, 0.f};
+    float orw = 0.f;
+    if (okl) {
+        sr = *reinterpret_cast<const F3 *>(P.scales_raw + gl * 3);
+        qr = *reinterpret_cast<const F4 *>(P.quats_raw + gl * 4);
+        orw = P.opac_raw[gl];
+    }
+    // ---- coefficient rows, 16 steps of 4 Gaussians, loads issued 8 steps ahead
+    float myr = 0.f, myg = 0.f, myb = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        F3 c[8], m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t g = g0 + sub * 16 + h * 8 + u;
+            c[u] = F3{0.f, 0.f, 0.f}; m[u] = F3{0.f, 0.f, 1.f};
+            if (g < N) {
+                if (P.use_sh) m[u] = *reinterpret_cast<const F3 *>(P.means + g * 3);
+                if (active) {
+                    if (k == 0) {
+                        c[u] = *reinterpret_cast<const F3 *>(P.dc + g * P.dc_stride);
+                        if (P.dc_add) {
+                            const F3 a = *reinterpret_cast<const F3 *>(P.dc_add + g * P.dc_add_stride);
+                            c[u].x += a.x; c[u].y += a.y; c[u].z += a.z;
+                        }
+                    } else {
+                        c[u] = *reinterpret_cast<const F3 *>(P.rest + g * P.rest_stride + (k - 1) * 3);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float r, gg, bb;
+            if (P.use_sh) {
+                float x = m[u].x - camx, y = m[u].y - camy, z = m[u].z - camz;
+                const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
+                x *= inorm; y *= inorm; z *= inorm;
+                const float b = sh_lane_basis<DEG>(lc, x, y, z);
+                r = row16_sum(b * c[u].x); gg = row16_sum(b * c[u].y); bb = row16_sum(b * c[u].z);
+            } else {  // lane 0 of the row holds the coefficients; every lane of the row gets them
+                r = row16_sum(c[u].x); gg = row16_sum(c[u].y); bb = row16_sum(c[u].z);
+            }
+            const bool mine = k == h * 8 + u;  // the lane that owns Gaussian 16*sub + step
+            myr = mine ? r : myr; myg = mine ? gg : myg; myb = mine ? bb : myb;
+        }
+    }
+    if (!okl) return;
+    // ---- lane-per-Gaussian results
+    F3 rgb;
+    if (P.use_sh) {
+        const float x = myr + 0.5f, y = myg + 0.5f, z = myb + 0.5f;
+        rgb = F3{fminf(fmaxf(x, 0.f), 1.f), fminf(fmaxf(y, 0.f), 1.f), fminf(fmaxf(z, 0.f), 1.f)};
+        // torch.clamp passes the gradient where min <= x <= max (inclusive): one bit per channel
+        clamp_mask[gl] = (uint8_t)((x >= 0.f && x <= 1.f) | ((y >= 0.f && y <= 1.f) << 1) | ((z >= 0.f && z <= 1.f) << 2));
+    } else {
+        rgb = F3{1.f / (1.f + expf(-myr)), 1.f / (1.f + expf(-myg)), 1.f / (1.f + expf(-myb))};
+        clamp_mask[gl] = 7;
+    }
+    *reinterpret_cast<F3 *>(rgbs + gl * 3) = rgb;
+    *reinterpret_cast<F3 *>(scales + gl * 3) = F3{expf(sr.x), expf(sr.y), expf(sr.z)};
+    const float qinv = 1.0f / sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
+    *reinterpret_cast<F4 *>(quats + gl * 4) = F4{qr.x * qinv, qr.y * qinv, qr.z * qinv, qr.w * qinv};
+    opacities[gl] = 1.f / (1.f + expf(-orw));
+}
+
+template <int DEG>
+__global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const NodeParams P, const float *__restrict__ scales,
+                                                              const float *__restrict__ opacities,
+                                                              const float *__restrict__ rgbs,
+                                                              const uint8_t *__restrict__ clamp_mask,
+                                                              const float *__restrict__ v_scales,
+                                                              const float *__restrict__ v_quats,
+                                                              const float *__restrict__ v_opacities,
+                                                              const float *__restrict__ v_rgbs, float *__restrict__ g_scales_raw,
+                                                              float *__restrict__ g_quats_raw, float *__restrict__ g_opac_raw,
+                                                              float *__restrict__ g_dc, float *__restrict__ g_rest) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
+    const ShLaneConst lc = sh_lane_const(k);
+    const int64_t g0 = ((int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
+    if (g0 >= N) return;
+    const float camx = P.cam_pos[0], camy = P.cam_pos[1], camz = P.cam_pos[2];
+    // ---- lane-per-Gaussian: activations, and the colour cotangent with the clamp / sigmoid VJP applied
+    const int64_t gl = g0 + lane;
+    const bool okl = gl < N;
+    F3 v = F3{0.f, 0.f, 0.f}, mn = F3{0.f, 0.f, 1.f};
+    if (okl) {
+        v = *reinterpret_cast<const F3 *>(v_rgbs + gl * 3);
+        if (P.use_sh) {
+            const unsigned mk = clamp_mask[gl];
+            v.x = (mk & 1u) ? v.x : 0.f; v.y = (mk & 2u) ? v.y : 0.f; v.z = (mk & 4u) ? v.z : 0.f;
+            mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
+        } else {
+            const F3 y = *reinterpret_cast<const F3 *>(rgbs + gl * 3);
+            v.x *= y.x * (1.f - y.x); v.y *= y.y * (1.f - y.y); v.z *= y.z * (1.f - y.z);
+        }
+        const F3 s = *reinterpret_cast<const F3 *>(scales + gl * 3), vs = *reinterpret_cast<const F3 *>(v_scales + gl * 3);
+        *reinterpret_cast<F3 *>(g_scales_raw + gl * 3) = F3{vs.x * s.x, vs.y * s.y, vs.z * s.z};  // d exp = exp
+        const F4 q = *reinterpret_cast<const F4 *>(P.quats_raw + gl * 4), vq = *reinterpret_cast<const F4 *>(v_quats + gl * 4);
+        const float qinv = 1.0f / sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+        const F4 qn = F4{q.x * qinv, q.y * qinv, q.z * qinv, q.w * qinv};
+        const float dot = ((vq.x * qn.x + vq.y * qn.y) + vq.z * qn.z) + vq.w * qn.w;                // d (q / |q|)
+        *reinterpret_cast<F4 *>(g_quats_raw + gl * 4) =
+            F4{(vq.x - dot * qn.x) * qinv, (vq.y - dot * qn.y) * qinv, (vq.z - dot * qn.z) * qinv, (vq.w - dot * qn.w) * qinv};
+        const float o = opacities[gl];
+        g_opac_raw[gl] = v_opacities[gl] * o * (1.f - o);                                           // d sigmoid
+    }
+    // the basis needs the unit view direction: computed once per Gaussian here, moved to the rows below
+    float dx = mn.x - camx, dy = mn.y - camy, dz = mn.z - camz;
+    const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    dx *= inorm; dy *= inorm; dz *= inorm;
+    // ---- rows: v_coeff[k, :] = basis_k(dir) * v
+    const int row0 = (lane & ~15) << 2;  // byte address of lane 0 of this row (ds_bpermute)
+#pragma unroll
+    for (int it = 0; it < NODE_STEPS; ++it) {
+        const int src = row0 + it * 4;   // the lane that owns Gaussian 16*sub + it
+        const float vx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x)));
+        const float vy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)));
+        const float vz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.z)));
+        float b;
+        if (P.use_sh) {
+            const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dx)));
+            const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
+            const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
+            b = k < NB ? sh_lane_basis<DEG>(lc, x, y, z) : 0.f;
+        } else {
+            b = k == 0 ? 1.f : 0.f;
+        }
+        const int64_t g = g0 + sub * 16 + it;
+        if (g >= N) continue;
+        const F3 o = F3{b * vx, b * vy, b * vz};
+        if (k == 0) *reinterpret_cast<F3 *>(g_dc + g * 3) = o;
+        else if (k - 1 < P.Kr) *reinterpret_cast<F3 *>(g_rest + (g * P.Kr + (k - 1)) * 3) = o;
+    }
+}
+
+}  // namespace
+
+#define MTGS_NODE_DISPATCH(KERNEL, ...)                                                 \
+    switch (degree) {                                                                   \
+        case 0: KERNEL<0><<<grid, NODE_BLOCK, 0, st>>>(__VA_ARGS__); break;             \
+        case 1: KERNEL<1><<<grid, NODE_BLOCK, 0, st>>>(__VA_ARGS__); break;             \
+        case 2: KERNEL<2><<<grid, NODE_BLOCK, 0, st>>>(__VA_ARGS__); break;             \
+        default: KERNEL<3><<<grid, NODE_BLOCK, 0, st>>>(__VA_ARGS__); break;            \
+    }
+
+static int node_check(const char *who, int64_t N, int K_rest, int degree, int use_sh, const int64_t *strides) {
+    MTGS_REQUIRE(N >= 0 && K_rest >= 0, MTGS_EINVAL, "%s: bad sizes", who);
+    MTGS_REQUIRE(degree >= 0 && degree <= 3 && K_rest <= 15, MTGS_EUNSUPPORTED,
+                 "%s: degree %d / %d higher-order bases (one basis per lane of a 16-lane row: degree <= 3, K <= 16)", who,
+                 degree, K_rest);
+    MTGS_REQUIRE(!use_sh || (degree + 1) * (degree + 1) <= K_rest + 1, MTGS_EINVAL,
+                 "%s: degree %d needs (degree+1)^2 <= K = %d", who, degree, K_rest + 1);
+    MTGS_REQUIRE(strides && strides[0] >= 3 && strides[2] >= (int64_t)K_rest * 3, MTGS_EINVAL, "%s: bad row strides", who);
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_node_fwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *scales_raw,
+                             const float *quats_raw, const float *opacities_raw, const float *features_dc,
+                             const float *features_dc_add, const float *features_rest, const int64_t *row_strides,
+                             const float *cam_pos, float *scales, float *quats, float *opacities, float *rgbs,
+                             uint8_t *clamp_mask, void *stream) {
+    if (int rc = node_check("mtgs_node_fwd", N, K_rest, degree, use_sh, row_strides)) return rc;
+    if (N == 0) return MTGS_OK;
+    MTGS_REQUIRE(means && scales_raw && quats_raw && opacities_raw && features_dc && (features_rest || K_rest == 0) && cam_pos &&
+                     scales && quats && opacities && rgbs && clamp_mask,
+                 MTGS_EINVAL, "mtgs_node_fwd: null pointer");
+    const NodeParams P{means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest,
+                       row_strides[0], row_strides[1], row_strides[2], cam_pos, K_rest, use_sh};
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
+    MTGS_NODE_DISPATCH(node_fwd_kernel, N, P, scales, quats, opacities, rgbs, clamp_mask)
+    MTGS_CHECK_LAUNCH("mtgs_node_fwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *quats_raw,
+                             const float *cam_pos, const float *scales, const float *opacities, const float *rgbs,
+                             const uint8_t *clamp_mask, const float *v_scales, const float *v_quats,
+                             const float *v_opacities, const float *v_rgbs, float *g_scales_raw, float *g_quats_raw,
+                             float *g_opacities_raw, float *g_features_dc, float *g_features_rest, void *stream) {
+    const int64_t strides[3] = {3, 3, (int64_t)K_rest * 3};
+    if (int rc = node_check("mtgs_node_bwd", N, K_rest, degree, use_sh, strides)) return rc;
+    if (N == 0) return MTGS_OK;
+    MTGS_REQUIRE(means && quats_raw && cam_pos && scales && opacities && rgbs && clamp_mask && v_scales && v_quats &&
+                     v_opacities && v_rgbs && g_scales_raw && g_quats_raw && g_opacities_raw && g_features_dc &&
+                     (g_features_rest || K_rest == 0),
+                 MTGS_EINVAL, "mtgs_node_bwd: null pointer");
+    const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh};
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
+    MTGS_NODE_DISPATCH(node_bwd_kernel, N, P, scales, opacities, rgbs, clamp_mask, v_scales, v_quats, v_opacities, v_rgbs,
+                       g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc, g_features_rest)
+    MTGS_CHECK_LAUNCH("mtgs_node_bwd");
+    return MTGS_OK;
+}

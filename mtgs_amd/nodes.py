@@ -1,0 +1,107 @@
+"""Fused per-node activations for MTGS Gaussian nodes (the caller side of the
+rasterization path).
+
+`node_gaussians(...)` returns what `VanillaGaussianSplattingModel.get_gaussians` returns
+(/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:299-341: means, exp(scales),
+normalised quats, sigmoid(opacities), rgbs = clamp(SH(n, dirs, cat(features_dc, features_rest)) + 0.5, 0, 1)),
+computed by ONE HIP kernel per direction (csrc/node.hip) instead of ~12 PyTorch launches per direction: the
+coefficients are read where they are (no `torch.cat` copy of [N,16,3], no dirs / clamp temporaries) and the backward
+writes the gradients of features_dc / features_rest directly.  For MultiColorGaussianSplattingModel
+(multi_color_gaussian_splatting.py:77-101) pass `features_dc_add=features_adapters[:, t]` and
+`features_rest=features_rest[:, t]`: strided views are read in place.
+
+No CPU / PyTorch fallback (mtgs_amd._lib raises without the HIP library).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from ._lib import call, host_i64, ptr, require_gpu, stream_of
+
+
+def _rows(t: Optional[Tensor], width: int):
+    """(tensor, row stride in floats) of a [N, ...] tensor whose rows are `width` contiguous floats."""
+    if t is None:
+        return None, width
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32 tensor, got {t.dtype}")
+    N = t.shape[0]
+    inner_ok = t[0].is_contiguous() if N > 0 else True
+    if N > 1 and inner_ok and t.stride(0) >= width:
+        return t, t.stride(0)
+    return t.contiguous(), width
+
+
+class _NodeActivations(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos,
+                degree, use_sh):
+        require_gpu(means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos)
+        N = means.shape[0]
+        Kr = features_rest.shape[-2]
+        means_c, scales_c, quats_c = means.detach().contiguous(), scales_raw.contiguous(), quats_raw.contiguous()
+        opac_c = opacities_raw.reshape(N).contiguous()
+        dc, s_dc = _rows(features_dc, 3)
+        dca, s_dca = _rows(features_dc_add, 3)
+        rest, s_rest = _rows(features_rest, Kr * 3)
+        cam = cam_pos.detach().reshape(3).to(torch.float32).contiguous()
+        dev = means.device
+        scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        opacities = torch.empty((N,), dtype=torch.float32, device=dev)
+        rgbs = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        mask = torch.empty((N,), dtype=torch.uint8, device=dev)
+        call("mtgs_node_fwd", N, Kr, int(degree), int(use_sh), ptr(means_c), ptr(scales_c), ptr(quats_c), ptr(opac_c), ptr(dc),
+             ptr(dca), ptr(rest), host_i64([s_dc, s_dca, s_rest]), ptr(cam), ptr(scales), ptr(quats), ptr(opacities),
+             ptr(rgbs), ptr(mask), stream_of(means))
+        ctx.save_for_backward(means_c, quats_c, cam, scales, opacities, rgbs, mask)
+        ctx.dims = (N, Kr, int(degree), int(use_sh), opacities_raw.shape, features_dc_add is not None)
+        return scales, quats, opacities, rgbs
+
+    @staticmethod
+    def backward(ctx, v_scales, v_quats, v_opacities, v_rgbs):
+        means_c, quats_c, cam, scales, opacities, rgbs, mask = ctx.saved_tensors
+        N, Kr, degree, use_sh, opac_shape, has_add = ctx.dims
+        dev = means_c.device
+        z = lambda g, like: (torch.zeros_like(like) if g is None else g.to(torch.float32).contiguous())
+        v_scales, v_quats = z(v_scales, scales), z(v_quats, torch.empty((N, 4), device=dev))
+        v_opacities, v_rgbs = z(v_opacities, opacities), z(v_rgbs, rgbs)
+        g_scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        g_quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        g_opac = torch.empty((N,), dtype=torch.float32, device=dev)
+        g_dc = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        g_rest = torch.empty((N, Kr, 3), dtype=torch.float32, device=dev)
+        call("mtgs_node_bwd", N, Kr, degree, use_sh, ptr(means_c), ptr(quats_c), ptr(cam), ptr(scales), ptr(opacities),
+             ptr(rgbs), ptr(mask), ptr(v_scales), ptr(v_quats), ptr(v_opacities), ptr(v_rgbs), ptr(g_scales), ptr(g_quats),
+             ptr(g_opac), ptr(g_dc), ptr(g_rest), stream_of(means_c))
+        return (None, g_scales, g_quats, g_opac.reshape(opac_shape), g_dc, g_dc if has_add else None, g_rest, None, None,
+                None)
+
+
+def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, features_dc: Tensor,
+                   features_rest: Tensor, camera_to_worlds: Tensor, sh_degree_to_use: int, model_sh_degree: int,
+                   features_dc_add: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """The dict VanillaGaussianSplattingModel.get_gaussians(camera_to_worlds) returns, from the RAW parameters:
+    means[N,3], scales[N,3] (log), quats[N,4], opacities[N,1] (logits), features_dc[N,3], features_rest[N,K-1,3];
+    `sh_degree_to_use` = min(step // sh_degree_interval, sh_degree), `model_sh_degree` = the model's sh_degree
+    (0 selects rgbs = sigmoid(features_dc), vanilla_gaussian_splatting.py:319-320).  camera_to_worlds[...,3,4]:
+    only its translation is used, as in the reference (:314)."""
+    N = means.shape[0]
+    assert scales.shape == (N, 3) and quats.shape == (N, 4), (scales.shape, quats.shape)
+    assert opacities.numel() == N, opacities.shape
+    assert features_dc.shape == (N, 3), features_dc.shape
+    assert features_rest.dim() == 3 and features_rest.shape[0] == N and features_rest.shape[2] == 3, features_rest.shape
+    if features_dc_add is not None:
+        assert features_dc_add.shape == (N, 3), features_dc_add.shape
+    use_sh = model_sh_degree > 0
+    if use_sh:
+        assert (sh_degree_to_use + 1) ** 2 <= features_rest.shape[1] + 1, (sh_degree_to_use, features_rest.shape)
+    if features_rest.shape[1] > 15 or sh_degree_to_use > 3:
+        raise NotImplementedError("node_gaussians: SH degree > 3 (MTGS configs use <= 3)")
+    cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
+    s, q, o, rgb = _NodeActivations.apply(means, scales, quats, opacities, features_dc, features_dc_add, features_rest,
+                                          cam_pos, int(sh_degree_to_use), bool(use_sh))
+    return {"means": means, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}

@@ -1,0 +1,107 @@
+"""Fused per-node activations (mtgs_amd.nodes.node_gaussians, csrc/node.hip) against the operator chain of
+VanillaGaussianSplattingModel.get_gaussians restated in plain PyTorch
+(/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:299-341; multi-colour sources:
+multi_color_gaussian_splatting.py:77-101), with the SH colour evaluated by the independent fp64 restatement
+oracle/torch_ref.py.  Tolerances: forward 2e-6 absolute (fp32), gradients 1e-5 relative to the tensor's max."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(P, cam_pos, n, model_deg, t=None):
+    """The reference's op chain, fp64, on CPU (torch_ref.spherical_harmonics is the oracle's restatement)."""
+    from oracle import torch_ref
+    means, scales, quats, opac = P["means"], P["scales"], P["quats"], P["opacities"]
+    if t is None:
+        dc, rest = P["features_dc"], P["features_rest"]
+    else:  # MultiColorGaussianSplattingModel.get_pertravel_features
+        dc = P["features_dc"] + P["features_adapters"][:, t, :]
+        rest = P["features_rest"][:, t, :, :]
+    out = {"scales": torch.exp(scales), "quats": quats / quats.norm(dim=-1, keepdim=True),
+           "opacities": torch.sigmoid(opac).squeeze(-1)}
+    colors = torch.cat((dc[:, None, :], rest), dim=1)
+    if model_deg > 0:
+        d = means.detach() - cam_pos
+        d = d / d.norm(dim=-1, keepdim=True)
+        out["rgbs"] = torch.clamp(torch_ref.spherical_harmonics(n, d, colors) + 0.5, 0.0, 1.0)
+    else:
+        out["rgbs"] = torch.sigmoid(colors[:, 0, :])
+    return out
+
+
+def _params(N, K, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = {"means": torch.randn(N, 3, generator=g) * 5, "scales": torch.randn(N, 3, generator=g) - 2,
+         "quats": torch.randn(N, 4, generator=g), "opacities": torch.randn(N, 1, generator=g),
+         "features_dc": torch.randn(N, 3, generator=g) * 0.7}
+    if T:
+        P["features_rest"] = torch.randn(N, T, K - 1, 3, generator=g) * 0.2
+        P["features_adapters"] = torch.randn(N, T, 3, generator=g) * 0.1
+    else:
+        P["features_rest"] = torch.randn(N, K - 1, 3, generator=g) * 0.2
+    return P
+
+
+@pytest.mark.parametrize("N,K,n,model_deg,T", [
+    (4099, 16, 3, 3, 0), (4099, 16, 1, 3, 0), (1000, 16, 0, 3, 0),   # degree ramp 0 -> 3 with K fixed at 16 (MTGS.py:72-73)
+    (777, 9, 2, 2, 0),                                               # WildGaussians-sized coefficients (sh_degree 2)
+    (513, 16, 0, 0, 0),                                              # sh_degree 0 model: rgbs = sigmoid(features_dc)
+    (2050, 16, 3, 3, 3),                                             # multi-colour node, traversal 1 of 3, strided views
+])
+def test_node_gaussians_match_reference_chain(hip_lib, N, K, n, model_deg, T):
+    from mtgs_amd.nodes import node_gaussians
+    dev = torch.device("cuda")
+    P = _params(N, K, T, 11)
+    c2w = torch.eye(4)[None, :3, :].clone()
+    c2w[0, :3, 3] = torch.tensor([0.4, -1.1, 2.3])
+    t = 1 if T else None
+    g = torch.Generator().manual_seed(3)
+    cot = {"scales": torch.randn(N, 3, generator=g), "quats": torch.randn(N, 4, generator=g),
+           "opacities": torch.randn(N, generator=g), "rgbs": torch.randn(N, 3, generator=g)}
+    # reference (fp64, CPU)
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    ref = _reference(R, c2w[0, :3, 3].double(), n, model_deg, t)
+    sum((ref[k] * cot[k].double()).sum() for k in cot).backward()
+    # fused (HIP)
+    D = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
+    if T:
+        out = node_gaussians(D["means"], D["scales"], D["quats"], D["opacities"], D["features_dc"],
+                             D["features_rest"][:, t], c2w.to(dev), n, model_deg,
+                             features_dc_add=D["features_adapters"][:, t])
+    else:
+        out = node_gaussians(D["means"], D["scales"], D["quats"], D["opacities"], D["features_dc"], D["features_rest"],
+                             c2w.to(dev), n, model_deg)
+    assert out["means"] is D["means"]
+    sum((out[k] * cot[k].to(dev)).sum() for k in cot).backward()
+    for k in cot:
+        err = float((out[k].detach().cpu().double() - ref[k].detach()).abs().max())
+        assert err <= 2e-6 * max(1.0, float(ref[k].detach().abs().max())), f"{k}: {err}"
+    for k in P:
+        if k == "means":
+            assert D[k].grad is None and R[k].grad is None  # view directions are detached (vanilla :314)
+            continue
+        gd, gr = D[k].grad, R[k].grad
+        assert gd is not None and gd.shape == gr.shape, k
+        scale = float(gr.abs().max())
+        err = float((gd.cpu().double() - gr).abs().max())
+        assert err <= 1e-5 * scale + 1e-9, f"grad {k}: {err} vs {scale}"
+
+
+def test_node_rgbs_golden_reference_helpers(hip_lib):
+    """A constant-colour Gaussian: features_dc = RGB2SH(rgb), higher orders zero => rgbs == rgb for every view
+    direction.  The expected values come from the reference's own RGB2SH (tests/golden/ref_helpers.npz,
+    generated by tests/golden/make_golden.py from mtgs/scene_model/gaussian_model/utils.py)."""
+    import numpy as np
+    from pathlib import Path
+    from mtgs_amd.nodes import node_gaussians
+    z = np.load(Path(__file__).parent / "golden" / "ref_helpers.npz")
+    rgb, sh = torch.from_numpy(z["rgb"]).float(), torch.from_numpy(z["rgb2sh"]).float()
+    N = rgb.shape[0]
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    out = node_gaussians(torch.randn(N, 3, generator=g).to(dev), torch.zeros(N, 3, device=dev),
+                         torch.randn(N, 4, generator=g).to(dev), torch.zeros(N, 1, device=dev), sh.to(dev),
+                         torch.zeros(N, 15, 3, device=dev), torch.eye(4, device=dev)[None, :3], 3, 3)
+    assert float((out["rgbs"].cpu() - rgb.clamp(0, 1)).abs().max()) <= 2e-6
+    assert float((out["scales"] - 1.0).abs().max()) == 0.0 and float((out["opacities"] - 0.5).abs().max()) == 0.0
