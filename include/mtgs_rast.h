@@ -270,6 +270,14 @@ int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *me
                   const float *v_rgbs, float *g_scales_raw, float *g_quats_raw, float *g_opacities_raw,
                   float *g_features_dc, float *g_features_rest, void *stream);
 
+/* ---- densification statistics of one node in one launch ------------------------------
+ * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous
+ * slice of the collected arrays; pass pointers to the slice) with radii > 0:
+ *   xys_grad_norm += |grad2d * (width, height) * 0.5|,  vis_counts += 1,  max_2dsize = max(max_2dsize, radii).
+ * radii[n] i32, grad2d[n,2] (means2d.absgrad or .grad of the rasterization), the three statistics [n] f32 in place. */
+int mtgs_densify_stats(int64_t n, const int32_t *radii, const float *grad2d, int width, int height,
+                       float *xys_grad_norm, float *vis_counts, float *max_2dsize, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

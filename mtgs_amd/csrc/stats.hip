@@ -1,0 +1,42 @@
+// stats.hip -- densification statistics of one Gaussian node, one launch.
+//
+// Restates MTGSSceneModel.update_submodel_statistics + VanillaGaussianSplattingModel.after_train
+// (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:1157-1183,
+//  /root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:448-474): per step and node
+//     grads = (xys.absgrad[0, mask] * (W, H) * 0.5).norm(dim=-1)        (or xys.grad without absgrad)
+//     vis   = radii[mask] > 0
+//     vis_counts[vis] += 1;  xys_grad_norm[vis] += grads[vis];  max_2Dsize[vis] = max(max_2Dsize[vis], radii[vis])
+// which PyTorch runs as ~12 masked gathers / scatters per node (a rigid-node scene has hundreds of nodes).  A node's
+// Gaussians are a contiguous slice [start, start + n) of the collected arrays (torch.cat in get_gaussians, :408-461).
+//
+// Roofline: HBM; n * 12 B read + 24 B read-modify-write per visible Gaussian.
+#include "common.hpp"
+
+namespace {
+__global__ __launch_bounds__(256) void densify_stats_kernel(int64_t n, const int32_t *__restrict__ radii,
+                                                            const float *__restrict__ grad2d, float half_w, float half_h,
+                                                            float *__restrict__ grad_norm, float *__restrict__ vis_counts,
+                                                            float *__restrict__ max_2dsize) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = radii[i];
+    if (r <= 0) return;
+    const float2 g = reinterpret_cast<const float2 *>(grad2d)[i];
+    const float gx = g.x * half_w, gy = g.y * half_h;
+    grad_norm[i] += sqrtf(gx * gx + gy * gy);
+    vis_counts[i] += 1.f;
+    max_2dsize[i] = fmaxf(max_2dsize[i], (float)r);
+}
+}  // namespace
+
+extern "C" int mtgs_densify_stats(int64_t n, const int32_t *radii, const float *grad2d, int width, int height,
+                                  float *xys_grad_norm, float *vis_counts, float *max_2dsize, void *stream) {
+    MTGS_REQUIRE(n >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_densify_stats: bad sizes");
+    if (n == 0) return MTGS_OK;
+    MTGS_REQUIRE(radii && grad2d && xys_grad_norm && vis_counts && max_2dsize, MTGS_EINVAL, "mtgs_densify_stats: null pointer");
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(grad2d) & 7) == 0, MTGS_EINVAL, "mtgs_densify_stats: grad2d must be 8-byte aligned");
+    densify_stats_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, (hipStream_t)stream>>>(
+        n, radii, grad2d, 0.5f * (float)width, 0.5f * (float)height, xys_grad_norm, vis_counts, max_2dsize);
+    MTGS_CHECK_LAUNCH("mtgs_densify_stats");
+    return MTGS_OK;
+}
