@@ -278,6 +278,20 @@ int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *me
 int mtgs_densify_stats(int64_t n, const int32_t *radii, const float *grad2d, int width, int height,
                        float *xys_grad_norm, float *vis_counts, float *max_2dsize, void *stream);
 
+/* ---- masked SSIM of the loss head, fused ---------------------------------------------
+ * mtgs.utils.ssim.MaskedSSIM(data_range=1.0, size_average=True, channel=3)(gt, pred, mask)  (mtgs/utils/ssim.py:57-190,
+ * mtgs_scene_graph.py:322, :831-841).  gt, pred: [H,W,3] f32 (the rasterizer's layout: no NCHW copies); mask[H,W] u8
+ * (nullable = all ones), cropped by the window margin as the reference does.  11 taps, `win_sigma` (reference: 1.5),
+ * K1 = 0.01, K2 = 0.03.  out[0] = masked mean of the (H-10) x (W-10) x 3 SSIM map, out[1] = number of masked elements.
+ * gmaps[(H-10)*(W-10)*9] (nullable: forward only) receives mask * d ssim / d {mu_pred, E[pred^2], E[gt pred]} per
+ * pixel and channel for the backward; partials: mtgs_ssim_workspace_floats.  Sums in a fixed order (deterministic).
+ * bwd: v_pred[H,W,3] = v_out[0] * d out[0] / d pred  (v_out, fwd_out = DEVICE pointers; gt gets no gradient). */
+int mtgs_ssim_workspace_floats(int width, int height, size_t *n);
+int mtgs_ssim_fwd(int width, int height, const float *gt, const float *pred, const uint8_t *mask, float win_sigma,
+                  float data_range, float K1, float K2, float *gmaps, float *partials, float *out, void *stream);
+int mtgs_ssim_bwd(int width, int height, const float *gt, const float *pred, const float *gmaps, float win_sigma,
+                  const float *v_out, const float *fwd_out, float *v_pred, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

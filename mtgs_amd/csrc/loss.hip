@@ -1,0 +1,208 @@
+// loss.hip -- masked SSIM between the rendered and the ground-truth image, forward and backward, fused
+// (the consumer side of the rasterization path).
+//
+// Restates mtgs.utils.ssim.MaskedSSIM(data_range=1.0, size_average=True, channel=3)(gt, pred, mask)
+// (/root/reference/mtgs/utils/ssim.py:57-108 `_ssim`, :111-190 `ssim`; called from
+// /root/reference/mtgs/scene_model/mtgs_scene_graph.py:322, :831-841): an 11-tap separable Gaussian window
+// (sigma 1.5, 'valid' correlation) gives mu_x, mu_y, E[x^2], E[y^2], E[xy] per pixel and channel,
+//     ssim = ((2 mu_x mu_y + C1) / (mu_x^2 + mu_y^2 + C1)) * ((2 s_xy + C2) / (s_x^2 + s_y^2 + C2)),
+// averaged over the masked elements of the (H-10) x (W-10) map (mask cropped by the window margin).
+// PyTorch runs this as 5 grouped convolutions x 2 passes + ~15 elementwise kernels forward and twice that backward
+// over NCHW copies of the images; here the images stay in the rasterizer's [H,W,3] layout, one kernel computes the
+// five filtered maps in LDS and the per-pixel SSIM together with the three gradient maps the backward needs, and a
+// second kernel applies the transposed window to those maps.  The masked mean is a two-level sum in a fixed order
+// (per-block partials, then one block): deterministic.
+//
+// Roofline: HBM (forward reads 2 x 12 B per pixel and writes 36 B of gradient maps; backward reads 36 + 24, writes 12).
+#include "common.hpp"
+
+namespace {
+
+constexpr int WIN = 11, HALO = WIN - 1, TILE = 16, IN_TILE = TILE + HALO;  // 26
+struct Window { float w[WIN]; };
+
+__device__ __forceinline__ float block_sum_256(float v, float *lds) {
+    v = wave_sum_to_lane63(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// gmaps[(oy * OW + ox) * 9 + c * 3 + {0,1,2}] = mask * d ssim / d {mu_y, E[y^2], E[xy]}   (nullable)
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float *__restrict__ X, const float *__restrict__ Y,
+                                                       const uint8_t *__restrict__ mask, const Window win, float C1, float C2,
+                                                       float *__restrict__ gmaps, float *__restrict__ partials) {
+    __shared__ float sX[IN_TILE][IN_TILE + 1], sY[IN_TILE][IN_TILE + 1];
+    __shared__ float sH[5][IN_TILE][TILE + 1];
+    __shared__ float s_red[4];
+    const int OW = W - HALO, OH = H - HALO;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const int ox = x0 + tx, oy = y0 + ty;
+    const bool valid = ox < OW && oy < OH;
+    // the mask is cropped by the window margin: output (oy, ox) <-> image pixel (oy + 5, ox + 5)
+    const float m = valid ? (mask ? (mask[(int64_t)(oy + HALO / 2) * W + ox + HALO / 2] ? 1.f : 0.f) : 1.f) : 0.f;
+    float sum = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();
+        for (int i = tid; i < IN_TILE * IN_TILE; i += 256) {
+            const int r = i / IN_TILE, q = i - r * IN_TILE;
+            const int gy = y0 + r, gx = x0 + q;
+            const bool in = gy < H && gx < W;
+            const int64_t a = ((int64_t)gy * W + gx) * 3 + c;
+            sX[r][q] = in ? X[a] : 0.f;
+            sY[r][q] = in ? Y[a] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < IN_TILE * TILE; i += 256) {   // horizontal pass: 26 rows x 16 columns
+            const int r = i >> 4, q = i & 15;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const float x = sX[r][q + k], y = sY[r][q + k], w = win.w[k];
+                a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
+            }
+            sH[0][r][q] = a0; sH[1][r][q] = a1; sH[2][r][q] = a2; sH[3][r][q] = a3; sH[4][r][q] = a4;
+        }
+        __syncthreads();
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;   // vertical pass
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float w = win.w[k];
+            mu1 += w * sH[0][ty + k][tx]; mu2 += w * sH[1][ty + k][tx];
+            e11 += w * sH[2][ty + k][tx]; e22 += w * sH[3][ty + k][tx]; e12 += w * sH[4][ty + k][tx];
+        }
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float nA = 2.f * mu12 + C1, dA = mu1_sq + mu2_sq + C1;
+        const float nB = 2.f * s12 + C2, dB = s1 + s2 + C2;
+        const float A = nA / dA, B = nB / dB;
+        sum += m * (A * B);
+        if (gmaps && valid) {
+            // y = the second argument (the prediction).  d/d mu_y, d/d E[y^2], d/d E[xy]:
+            const float dA_dmu2 = (2.f * mu1 - A * 2.f * mu2) / dA;
+            const float dB_dmu2 = (-2.f * mu1 + B * 2.f * mu2) / dB;   // n_B has -2 mu_x, d_B has -2 mu_y
+            const float g_mu = m * (dA_dmu2 * B + A * dB_dmu2);
+            const float g_e22 = m * (A * (-B / dB));
+            const float g_e12 = m * (A * (2.f / dB));
+            float *g = gmaps + ((int64_t)oy * OW + ox) * 9 + c * 3;
+            g[0] = g_mu; g[1] = g_e22; g[2] = g_e12;
+        }
+    }
+    const float bs = block_sum_256(sum, s_red);
+    const float bc = block_sum_256(3.f * m, s_red);
+    if (tid == 0) {
+        const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partials[b * 2] = bs; partials[b * 2 + 1] = bc;
+    }
+}
+
+// out[0] = masked mean, out[1] = number of masked elements (fixed summation order)
+__global__ __launch_bounds__(256) void ssim_finish_kernel(int64_t nblocks, const float *__restrict__ partials,
+                                                          float *__restrict__ out) {
+    __shared__ float s_red[4];
+    float s = 0.f, c = 0.f;
+    for (int64_t b = threadIdx.x; b < nblocks; b += 256) { s += partials[b * 2]; c += partials[b * 2 + 1]; }
+    const float ts = block_sum_256(s, s_red);
+    const float tc = block_sum_256(c, s_red);
+    if (threadIdx.x == 0) { out[0] = ts / tc; out[1] = tc; }
+}
+
+// v_Y[q] = (v_out / count) * sum_p w2d(q - p) * (g_mu[p] + 2 Y[q] g_e22[p] + X[q] g_e12[p])
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float *__restrict__ X, const float *__restrict__ Y,
+                                                       const float *__restrict__ gmaps, const Window win,
+                                                       const float *__restrict__ v_out, const float *__restrict__ fwd_out,
+                                                       float *__restrict__ v_Y) {
+    __shared__ float sG[3][IN_TILE][IN_TILE + 1];
+    __shared__ float sH[3][IN_TILE][TILE + 1];
+    const int OW = W - HALO, OH = H - HALO;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const int px = x0 + tx, py = y0 + ty;
+    const float scale = v_out[0] / fwd_out[1];
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();
+        // pixel (py, px) receives from outputs (py - a, px - b), a, b in [0, 10]: rows y0-10 .. y0+15
+        for (int i = tid; i < IN_TILE * IN_TILE; i += 256) {
+            const int r = i / IN_TILE, q = i - r * IN_TILE;
+            const int gy = y0 - HALO + r, gx = x0 - HALO + q;
+            const bool in = gy >= 0 && gx >= 0 && gy < OH && gx < OW;
+            const float *g = gmaps + ((int64_t)gy * OW + gx) * 9 + c * 3;
+            sG[0][r][q] = in ? g[0] : 0.f; sG[1][r][q] = in ? g[1] : 0.f; sG[2][r][q] = in ? g[2] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < IN_TILE * TILE; i += 256) {   // horizontal: column q <-> tile columns q .. q+10, weight w[10-k]
+            const int r = i >> 4, q = i & 15;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const float w = win.w[HALO - k];
+                a0 += w * sG[0][r][q + k]; a1 += w * sG[1][r][q + k]; a2 += w * sG[2][r][q + k];
+            }
+            sH[0][r][q] = a0; sH[1][r][q] = a1; sH[2][r][q] = a2;
+        }
+        __syncthreads();
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float w = win.w[HALO - k];
+            t0 += w * sH[0][ty + k][tx]; t1 += w * sH[1][ty + k][tx]; t2 += w * sH[2][ty + k][tx];
+        }
+        if (px < W && py < H) {
+            const int64_t a = ((int64_t)py * W + px) * 3 + c;
+            v_Y[a] = scale * (t0 + 2.f * Y[a] * t1 + X[a] * t2);
+        }
+    }
+}
+
+}  // namespace
+
+static Window make_window(float sigma) {
+    Window w;
+    double s = 0.0;
+    for (int i = 0; i < WIN; ++i) {
+        // _fspecial_gauss_1d in float32: coords = arange(size) - size // 2; g = exp(-(coords**2) / (2 sigma**2)); g /= g.sum()
+        const float c = (float)(i - WIN / 2);
+        w.w[i] = expf(-(c * c) / (2.f * sigma * sigma));
+        s += (double)w.w[i];
+    }
+    float fs = 0.f;
+    for (int i = 0; i < WIN; ++i) fs += w.w[i];
+    (void)s;
+    for (int i = 0; i < WIN; ++i) w.w[i] /= fs;
+    return w;
+}
+
+extern "C" int mtgs_ssim_workspace_floats(int width, int height, size_t *n) {
+    MTGS_REQUIRE(width > HALO && height > HALO && n, MTGS_EINVAL, "mtgs_ssim_workspace_floats: image smaller than the 11x11 window");
+    *n = (size_t)ceil_div64(width - HALO, TILE) * (size_t)ceil_div64(height - HALO, TILE) * 2;
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_ssim_fwd(int width, int height, const float *gt, const float *pred, const uint8_t *mask,
+                             float win_sigma, float data_range, float K1, float K2, float *gmaps, float *partials,
+                             float *out, void *stream) {
+    MTGS_REQUIRE(width > HALO && height > HALO, MTGS_EINVAL, "mtgs_ssim_fwd: image %dx%d smaller than the 11x11 window", width, height);
+    MTGS_REQUIRE(gt && pred && partials && out, MTGS_EINVAL, "mtgs_ssim_fwd: null pointer");
+    const Window win = make_window(win_sigma);
+    const float C1 = (K1 * data_range) * (K1 * data_range), C2 = (K2 * data_range) * (K2 * data_range);
+    const dim3 grid((unsigned)ceil_div64(width - HALO, TILE), (unsigned)ceil_div64(height - HALO, TILE));
+    hipStream_t st = (hipStream_t)stream;
+    ssim_fwd_kernel<<<grid, 256, 0, st>>>(height, width, gt, pred, mask, win, C1, C2, gmaps, partials);
+    ssim_finish_kernel<<<1, 256, 0, st>>>((int64_t)grid.x * grid.y, partials, out);
+    MTGS_CHECK_LAUNCH("mtgs_ssim_fwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_ssim_bwd(int width, int height, const float *gt, const float *pred, const float *gmaps,
+                             float win_sigma, const float *v_out, const float *fwd_out, float *v_pred, void *stream) {
+    MTGS_REQUIRE(width > HALO && height > HALO, MTGS_EINVAL, "mtgs_ssim_bwd: image %dx%d smaller than the 11x11 window", width, height);
+    MTGS_REQUIRE(gt && pred && gmaps && v_out && fwd_out && v_pred, MTGS_EINVAL, "mtgs_ssim_bwd: null pointer");
+    const Window win = make_window(win_sigma);
+    const dim3 grid((unsigned)ceil_div64(width, TILE), (unsigned)ceil_div64(height, TILE));
+    ssim_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(height, width, gt, pred, gmaps, win, v_out, fwd_out, v_pred);
+    MTGS_CHECK_LAUNCH("mtgs_ssim_bwd");
+    return MTGS_OK;
+}

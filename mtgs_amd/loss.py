@@ -1,0 +1,65 @@
+"""Loss-head pieces on the consumer side of the rasterization path.
+
+`masked_ssim(gt, pred, mask)` == mtgs.utils.ssim.MaskedSSIM(data_range=1.0, size_average=True, channel=3)(
+gt.permute(2,0,1)[None], pred.permute(2,0,1)[None], mask=mask)  as MTGS calls it
+(/root/reference/mtgs/scene_model/mtgs_scene_graph.py:322, :831-841; /root/reference/mtgs/utils/ssim.py), computed by
+two HIP kernels (csrc/loss.hip) on the [H,W,3] images the rasterizer produces, with the gradient with respect to
+`pred`.  Pinned by golden vectors generated from the reference module itself (tests/golden/make_ssim_golden.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._lib import call, ptr, require_gpu, stream_of
+
+
+class _MaskedSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt, pred, mask, win_sigma, data_range, K1, K2):
+        require_gpu(gt, pred, mask)
+        H, W = pred.shape[:2]
+        gt_c = gt.detach().to(torch.float32).contiguous()
+        pred_c = pred.detach().to(torch.float32).contiguous()
+        mask_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        dev = pred.device
+        n = C.c_size_t(0)
+        call("mtgs_ssim_workspace_floats", W, H, C.byref(n))
+        partials = torch.empty(n.value, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[1]
+        gmaps = torch.empty(((H - 10), (W - 10), 9), dtype=torch.float32, device=dev) if need else None
+        call("mtgs_ssim_fwd", W, H, ptr(gt_c), ptr(pred_c), ptr(mask_c), float(win_sigma), float(data_range), float(K1),
+             float(K2), ptr(gmaps), ptr(partials), ptr(out), stream_of(pred))
+        ctx.save_for_backward(gt_c, pred_c, gmaps, out)
+        ctx.dims = (H, W, float(win_sigma), pred.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, v_out):
+        gt_c, pred_c, gmaps, out = ctx.saved_tensors
+        H, W, win_sigma, dtype = ctx.dims
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        v_pred = torch.empty_like(pred_c)
+        call("mtgs_ssim_bwd", W, H, ptr(gt_c), ptr(pred_c), ptr(gmaps), win_sigma, ptr(v), ptr(out), ptr(v_pred),
+             stream_of(pred_c))
+        return None, v_pred.to(dtype), None, None, None, None, None
+
+
+def masked_ssim(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None, win_sigma: float = 1.5,
+                data_range: float = 1.0, K: Tuple[float, float] = (0.01, 0.03)) -> Tensor:
+    """gt, pred: [H, W, 3]; mask: [H, W, 1] / [H, W] bool or None.  Returns the scalar the reference's MaskedSSIM
+    returns (mean of the SSIM map over the masked elements; the mask is cropped by the 5-pixel window margin).
+    Differentiable with respect to `pred` (the reference's second argument); `gt` gets no gradient."""
+    assert pred.dim() == 3 and pred.shape[2] == 3 and gt.shape == pred.shape, (gt.shape, pred.shape)
+    H, W = pred.shape[:2]
+    if H <= 10 or W <= 10:
+        raise ValueError(f"masked_ssim: image {H}x{W} is smaller than the 11x11 window")
+    if mask is not None:
+        assert mask.numel() == H * W, mask.shape
+    if gt.requires_grad:
+        raise NotImplementedError("masked_ssim: gradient with respect to gt (the first argument) is not implemented")
+    return _MaskedSSIM.apply(gt, pred, mask, win_sigma, data_range, K[0], K[1])
