@@ -51,9 +51,11 @@ struct NodeParams {
 //   * lane-per-Gaussian for the small activations and for everything that is 3..4 floats per Gaussian
 //     (64 x 12 / 16 / 4 contiguous bytes per instruction -- per-row 4-byte accesses cost one instruction per 4
 //     Gaussians and bounded the first version at 2.7 TB/s);
-//   * the 16-lane-row mapping for the coefficients: in step `it`, row `sub` works on Gaussian 16*sub + it, so the
-//     lane that owns that Gaussian in the first mapping (16*sub + it) sits in the SAME row: results move between the
-//     mappings with a compare + select (row -> lane) or one ds_bpermute per value (lane -> row), never across rows.
+//   * the 16-lane-row mapping for the coefficients: in step `it`, row `sub` works on Gaussian 4*it + sub, so one
+//     wave instruction covers 4 CONSECUTIVE Gaussians (720-768 contiguous bytes; with 16*sub + it the four 180-byte
+//     segments were 2.9 KB apart and the forward ran at 3.0 TB/s).  Values move between the mappings with one
+//     ds_bpermute each: lane k of row `sub` keeps the result of step k, i.e. of Gaussian 4k + sub, which the owner
+//     lane l = 4k + sub fetches from lane 16*(l % 4) + l / 4; in the backward row `sub` reads lane 4*it + sub.
 constexpr int NODE_BLOCK = 256, NODE_PER_WAVE = 64, NODE_STEPS = 16;
 struct F4 { float x, y, z, w; };
 
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
         F3 c[8], m[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int64_t g = g0 + sub * 16 + h * 8 + u;
+            const int64_t g = g0 + (h * 8 + u) * 4 + sub;
             c[u] = F3{0.f, 0.f, 0.f}; m[u] = F3{0.f, 0.f, 1.f};
             if (g < N) {
                 if (P.use_sh) m[u] = *reinterpret_cast<const F3 *>(P.means + g * 3);
@@ -115,9 +117,15 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
             } else {  // lane 0 of the row holds the coefficients; every lane of the row gets them
                 r = row16_sum(c[u].x); gg = row16_sum(c[u].y); bb = row16_sum(c[u].z);
             }
-            const bool mine = k == h * 8 + u;  // the lane that owns Gaussian 16*sub + step
+            const bool mine = k == h * 8 + u;  // lane k of the row keeps the result of step k
             myr = mine ? r : myr; myg = mine ? gg : myg; myb = mine ? bb : myb;
         }
+    }
+    {   // the owner of Gaussian l fetches its colour from lane 16 * (l % 4) + l / 4
+        const int src = ((lane & 3) * 16 + (lane >> 2)) << 2;
+        myr = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myr)));
+        myg = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myg)));
+        myb = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myb)));
     }
     if (!okl) return;
     // ---- lane-per-Gaussian results
@@ -185,10 +193,9 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
     const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
     dx *= inorm; dy *= inorm; dz *= inorm;
     // ---- rows: v_coeff[k, :] = basis_k(dir) * v
-    const int row0 = (lane & ~15) << 2;  // byte address of lane 0 of this row (ds_bpermute)
 #pragma unroll
     for (int it = 0; it < NODE_STEPS; ++it) {
-        const int src = row0 + it * 4;   // the lane that owns Gaussian 16*sub + it
+        const int src = (it * 4 + sub) << 2;   // the lane that owns Gaussian 4*it + sub
         const float vx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x)));
         const float vy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)));
         const float vz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.z)));
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
         } else {
             b = k == 0 ? 1.f : 0.f;
         }
-        const int64_t g = g0 + sub * 16 + it;
+        const int64_t g = g0 + it * 4 + sub;
         if (g >= N) continue;
         const F3 o = F3{b * vx, b * vy, b * vz};
         if (k == 0) *reinterpret_cast<F3 *>(g_dc + g * 3) = o;
