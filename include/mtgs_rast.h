@@ -76,6 +76,8 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * (nullable) given, opac_eff[C,N] = opacities * compensations (or opacities in classic mode) is
  * written by the forward, and the backward takes v_opac_eff[C,N] (nullable) and writes
  * v_opacities[N] (nullable), folding v_opac_eff * opacities into the compensation VJP.
+ * tiles_per_gauss[C,N] i32 (nullable, with tile_size / tile_w / tile_h): the count pass of isect_tiles
+ * (mtgs_isect_count) written by the same kernel -- one launch and one pass over means2d / radii less per frame.
  * bwd: v_means[N,3] v_quats[N,4] v_scales[N,3] are OVERWRITTEN (summed over cameras);
  * v_viewmats[C,4,4] nullable, overwritten.
  * grad_row_strides (HOST pointer, nullable): row strides in floats of the incoming gradients
@@ -96,7 +98,8 @@ int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
                      int32_t *radii, float *means2d, float *depths, float *conics,
-                     float *compensations, float *opac_eff, void *stream);
+                     float *compensations, float *opac_eff, int tile_size, int tile_w, int tile_h,
+                     int32_t *tiles_per_gauss, void *stream);
 int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      const int32_t *radii, const float *conics, const float *compensations,

@@ -22,6 +22,7 @@
 // Roofline: HBM.  Algorithmic bytes: compact C*N*12 in + n_vis*12 out; scan n_vis*8 in + 8 out;
 // emit n_vis*24 in + M*8 out; finalize M*8 in + M*8 (+4 gathered) out.
 #include "common.hpp"
+#include "tile_rect.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
 
@@ -29,16 +30,6 @@ namespace {
 
 constexpr int BIN_BLOCK = 256;
 
-struct Rect { int x0, y0, x1, y1; };
-__device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, float ts, int tw, int th) {
-    const float tr = (float)radius / ts, tx = mx / ts, ty = my / ts;
-    Rect r;
-    r.x0 = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tw);
-    r.y0 = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)th);
-    r.x1 = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tw);
-    r.y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)th);
-    return r;
-}
 
 // packed scan value: visible flag in the high word, tile count in the low word
 struct PackedVisTiles {

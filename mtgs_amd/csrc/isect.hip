@@ -14,6 +14,7 @@
 // LARGE rectangle is emitted by the whole wave (64 consecutive slots per step -> coalesced
 // 8-byte and 4-byte stores).
 #include "common.hpp"
+#include "tile_rect.hpp"
 #include "scan.hpp"
 
 namespace {
@@ -21,17 +22,6 @@ namespace {
 constexpr int ISECT_BLOCK = 256;
 constexpr int SMALL_RECT = 8;  // rectangles up to this many tiles are written by their own lane
 
-struct Rect { int x0, y0, x1, y1; };
-
-__device__ __forceinline__ Rect tile_rect(float mx, float my, int32_t radius, float ts, int tw, int th) {
-    const float tr = (float)radius / ts, tx = mx / ts, ty = my / ts;
-    Rect r;
-    r.x0 = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tw);
-    r.y0 = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)th);
-    r.x1 = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tw);
-    r.y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)th);
-    return r;
-}
 
 __global__ __launch_bounds__(ISECT_BLOCK) void isect_count_kernel(
     int64_t total, const float *__restrict__ means2d, const int32_t *__restrict__ radii, float ts,

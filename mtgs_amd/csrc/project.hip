@@ -12,6 +12,7 @@
 // operation in a fixed order, so radii / means2d / depths (the inputs of the integer tile-binning
 // stage, whose results must be bit-exact) have exactly one IEEE-754 value per input.
 #include "project_common.hpp"
+#include "tile_rect.hpp"
 
 namespace {
 
@@ -21,7 +22,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane, float far_plane,
     float radius_clip, const float *__restrict__ opacities, int32_t *__restrict__ radii,
     float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics,
-    float *__restrict__ compensations, float *__restrict__ opac_eff) {
+    float *__restrict__ compensations, float *__restrict__ opac_eff, float tile_size, int tile_w, int tile_h,
+    int32_t *__restrict__ tiles_per_gauss) {
     const int64_t idx = (int64_t)blockIdx.x * PROJ_BLOCK + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
     const int c = (int)(idx / N);
@@ -67,6 +69,14 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     if (compensations) compensations[idx] = comp;
     // gsplat rendering.py: opacities.repeat(C, 1) [* compensations]
     if (opac_eff) opac_eff[idx] = r_out > 0 ? (compensations ? opacities[n] * comp : opacities[n]) : 0.f;
+    if (tiles_per_gauss) {  // gsplat isect_tiles, count pass (what mtgs_isect_count computes from the arrays above)
+        int32_t cnt = 0;
+        if (r_out > 0) {
+            const Rect q = tile_rect(mx, my, r_out, tile_size, tile_w, tile_h);
+            cnt = (q.x1 - q.x0) * (q.y1 - q.y0);
+        }
+        tiles_per_gauss[idx] = cnt;
+    }
 }
 
 }  // namespace
@@ -76,7 +86,8 @@ extern "C" int mtgs_project_fwd(int C, int64_t N, const float *means, const floa
                                 int width, int height, float eps2d, float near_plane, float far_plane,
                                 float radius_clip, const float *opacities, int32_t *radii,
                                 float *means2d, float *depths, float *conics, float *compensations,
-                                float *opac_eff, void *stream) {
+                                float *opac_eff, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss,
+                                void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_fwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     if ((int64_t)C * N == 0) return MTGS_OK;
@@ -85,10 +96,13 @@ extern "C" int mtgs_project_fwd(int C, int64_t N, const float *means, const floa
     MTGS_REQUIRE((int64_t)C * N < ((int64_t)1 << 31), MTGS_EINVAL,
                  "mtgs_project_fwd: C*N must fit int32 (flatten_ids are int32)");
     MTGS_REQUIRE(!opac_eff || opacities, MTGS_EINVAL, "mtgs_project_fwd: opac_eff requested without opacities");
+    MTGS_REQUIRE(!tiles_per_gauss || (tile_size > 0 && tile_w > 0 && tile_h > 0), MTGS_EINVAL,
+                 "mtgs_project_fwd: tiles_per_gauss requested without a tile grid");
     const unsigned grid = (unsigned)ceil_div64((int64_t)C * N, PROJ_BLOCK);
     project_fwd_kernel<<<grid, PROJ_BLOCK, 0, (hipStream_t)stream>>>(
         C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-        radius_clip, opacities, radii, means2d, depths, conics, compensations, opac_eff);
+        radius_clip, opacities, radii, means2d, depths, conics, compensations, opac_eff, (float)tile_size, tile_w, tile_h,
+        tiles_per_gauss);
     MTGS_CHECK_LAUNCH("mtgs_project_fwd");
     return MTGS_OK;
 }

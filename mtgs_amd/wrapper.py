@@ -112,7 +112,7 @@ class _FullyFusedProjection(torch.autograd.Function):
         opac_eff = torch.empty((Cn, N), dtype=torch.float32, device=dev) if opacities is not None else None
         call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
              width, height, eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(radii),
-             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), stream_of(means))
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), 0, 0, 0, None, stream_of(means))
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics, comps, opacities)
         ctx.width, ctx.height, ctx.eps2d = width, height, eps2d
         ctx.mark_non_differentiable(radii)
@@ -390,12 +390,12 @@ class _FusedRasterization(torch.autograd.Function):
         conics = torch.empty((Cn, N, 3), dtype=torch.float32, device=dev)
         comps = torch.empty((Cn, N), dtype=torch.float32, device=dev) if calc_compensations else None
         opac_eff = torch.empty((Cn, N), dtype=torch.float32, device=dev)
+        tiles_per_gauss = torch.empty((Cn, N), dtype=torch.int32, device=dev)
         call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
              width, height, eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(radii),
-             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), st)
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
+             ptr(tiles_per_gauss), st)     # (+ the count pass of isect_tiles)
         # (2) tile binning
-        tiles_per_gauss = torch.empty((Cn, N), dtype=torch.int32, device=dev)
-        call("mtgs_isect_count", Cn, N, ptr(means2d), ptr(radii), tile_size, tw, th, ptr(tiles_per_gauss), st)
         scan_ws, scan_bytes = _ws("mtgs_scan_workspace_bytes", Cn * N, dev)
         _, isect_ids, flatten_ids, offsets, order, vis_ids, vis_rank = _bin_depth_ordered(
             means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tw, th, want_rank=True)

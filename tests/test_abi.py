@@ -47,7 +47,7 @@ def test_host_side_argument_validation(hip_lib):
         _lib.call("mtgs_sh_fwd", 10, 4, 3, None, None, None, None, None)
     # null pointers
     assert hip_lib.mtgs_project_fwd(1, 10, None, None, None, None, None, 64, 64, 0.3, 0.01, 1e10, 0.0,
-                                    None, None, None, None, None, None, None, None) == 1
+                                    None, None, None, None, None, None, None, 0, 0, 0, None, None) == 1
     # tile size other than 16 and unsupported channel counts are refused by name
     assert hip_lib.mtgs_blend_fwd(1, 10, 3, None, None, None, None, None, None, 0, 64, 64, 8, 8, 8, None, None, 0,
                                   None, None, None, None, None) == 4
