@@ -1,0 +1,88 @@
+"""Reading MTGS checkpoints into the tensors the rasterization path consumes.
+
+MTGS's trainer writes `step-%09d.ckpt` = {"step", "pipeline": state_dict, ...}
+(/root/reference/mtgs/scene_model/custom_trainer.py:148-157); the Gaussian nodes live under
+`_model.gaussian_models.<node>.gauss_params.<name>` (MTGSSceneModel.load_state_dict splits the keys at the first dot
+after `gaussian_models.`: /root/reference/mtgs/scene_model/mtgs_scene_graph.py:1185-1203) with
+<name> in {means, scales, quats, features_dc, features_rest, opacities} (+ features_adapters for multi-colour nodes;
+vanilla_gaussian_splatting.py:174-213, multi_color_gaussian_splatting.py:48-71).
+
+`load_gaussian_nodes` returns the raw parameters per node; `collect_gaussians` does what
+MTGSSceneModel.get_gaussians does for the static node types (vanilla / multi-colour: activations through the fused
+node kernels, then one concatenation) so that a released checkpoint can be rendered with `rasterization`.  Rigid /
+deformable nodes (per-frame poses, deformation networks) carry state this module does not interpret: they are listed,
+and `collect_gaussians` refuses them by name instead of rendering them wrongly.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Mapping, Optional, Union
+
+import torch
+from torch import Tensor
+
+GAUSS_PARAM_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities", "features_adapters")
+_PREFIXES = ("_model.gaussian_models.", "gaussian_models.")
+
+
+def load_gaussian_nodes(ckpt: Union[str, Mapping], map_location="cpu") -> Dict[str, Dict[str, Tensor]]:
+    """{node name: {parameter or buffer name: tensor}} from a checkpoint path, a checkpoint dict or a state dict.
+    `gauss_params.<name>` entries are returned under <name>; anything else a node stores (instance_quats,
+    instance_trans, deformation networks ...) keeps its full sub-key."""
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        ckpt = torch.load(ckpt, map_location=map_location, weights_only=False)
+    state = ckpt.get("pipeline", ckpt) if isinstance(ckpt, Mapping) else ckpt
+    nodes: Dict[str, Dict[str, Tensor]] = {}
+    for key, value in state.items():
+        for pre in _PREFIXES:
+            if key.startswith(pre):
+                node, sub = key[len(pre):].split(".", maxsplit=1)       # mtgs_scene_graph.py:1190-1191
+                if sub.startswith("gauss_params."):
+                    sub = sub[len("gauss_params."):]
+                nodes.setdefault(node, {})[sub] = value
+                break
+    if not nodes:
+        raise ValueError("no `gaussian_models.<node>.` entries: not an MTGS checkpoint / state dict")
+    return nodes
+
+
+def node_kind(params: Mapping[str, Tensor]) -> str:
+    """'vanilla' | 'multicolor' | 'dynamic' (anything with per-frame poses or extra modules)."""
+    extra = [k for k in params if k not in GAUSS_PARAM_NAMES]
+    if extra:
+        return "dynamic"
+    return "multicolor" if "features_adapters" in params else "vanilla"
+
+
+def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_worlds: Tensor, sh_degree_to_use: int,
+                      model_sh_degree: int = 3, traversal_index: Optional[int] = None,
+                      node_names: Optional[Iterable[str]] = None, device="cuda") -> Dict[str, Tensor]:
+    """means / scales / quats / opacities / rgbs / model_id of the listed static nodes, activated by
+    mtgs_amd.nodes.node_gaussians and concatenated in order (MTGSSceneModel.get_gaussians,
+    mtgs_scene_graph.py:408-461).  Multi-colour nodes need `traversal_index` (get_pertravel_features,
+    multi_color_gaussian_splatting.py:77-86; None = the shared colour only, as eval_mode 'null')."""
+    from .nodes import node_gaussians
+    out = {k: [] for k in ("means", "scales", "quats", "opacities", "rgbs", "model_id")}
+    names = list(nodes.keys()) if node_names is None else list(node_names)
+    for mid, name in enumerate(names):
+        p = {k: v.to(device) for k, v in nodes[name].items()}
+        kind = node_kind(p)
+        if kind == "dynamic":
+            raise NotImplementedError(f"collect_gaussians: node {name!r} carries per-frame state "
+                                      f"({sorted(k for k in p if k not in GAUSS_PARAM_NAMES)[:3]}...); only vanilla and "
+                                      "multi-colour nodes are supported")
+        if p["scales"].shape[-1] == 1:   # isotropic nodes store one log-scale (vanilla_gaussian_splatting.py:185-196)
+            p["scales"] = p["scales"].expand(-1, 3)
+        if "quats" not in p:
+            p["quats"] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device).expand(p["means"].shape[0], 4)
+        dc, rest, add = p["features_dc"], p["features_rest"], None
+        if kind == "multicolor":
+            if rest.dim() == 4:          # multi_feature_rest: [N, T, K-1, 3]
+                rest = rest[:, traversal_index] if traversal_index is not None else torch.zeros_like(rest[:, 0])
+            if traversal_index is not None:
+                add = p["features_adapters"][:, traversal_index]
+        g = node_gaussians(p["means"], p["scales"].contiguous(), p["quats"].contiguous(), p["opacities"], dc, rest,
+                           camera_to_worlds.to(device), sh_degree_to_use, model_sh_degree, features_dc_add=add)
+        for k in ("means", "scales", "quats", "opacities", "rgbs"):
+            out[k].append(g[k])
+        out["model_id"].append(torch.full((p["means"].shape[0],), mid, device=device))
+    return {k: torch.cat(v, dim=0) for k, v in out.items()}
