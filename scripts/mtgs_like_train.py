@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] in miniature, on synthetic data (no nuPlan road block can reach the GPU box): an MTGS-style
+training iteration -- shared static nodes with per-traversal appearance (a multi-colour background node with T
+traversals + a vanilla road node), one camera / traversal per step, node activations -> rasterization (RGB+ED,
+antialiased, absgrad) -> background composite -> 0.8 L1 + 0.2 (1 - masked SSIM) -> backward -> densification
+statistics -> Adam -- run two ways on the same parameters:
+
+  chain : the PyTorch operator chains MTGS runs around the drop-in rasterizer (exp / normalize / sigmoid / cat / SH op /
+          clamp; SSIM as 5 grouped convolutions x 2; masked-tensor statistics), i.e. MTGS unchanged on this library;
+  fused : mtgs_amd.nodes.node_gaussians, mtgs_amd.loss.masked_ssim, mtgs_amd.densify.update_statistics.
+
+Prints the per-iteration GPU time of both and checks that they compute the same loss.  `--steps` > 0 also trains
+(fused) and prints the loss curve.
+"""
+import argparse
+import math
+import sys
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
+from mtgs_amd.densify import update_statistics  # noqa: E402
+from mtgs_amd.loss import masked_ssim  # noqa: E402
+from mtgs_amd.nodes import node_gaussians  # noqa: E402
+from mtgs_amd.synthetic import make_camera  # noqa: E402
+
+
+def make_nodes(n_bg, n_road, T, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    def base(n, extent, y0):
+        return {"means": (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor(extent) + torch.tensor([0.0, y0, 0.0]),
+                "scales": torch.log(torch.exp(torch.rand(n, 3, generator=g) * (math.log(0.25) - math.log(0.03)) + math.log(0.03))),
+                "quats": torch.randn(n, 4, generator=g), "opacities": torch.randn(n, 1, generator=g) + 1.0,
+                "features_dc": (torch.rand(n, 3, generator=g) - 0.5) / 0.2820947917738781}
+    bg = base(n_bg, (40.0, 6.0, 40.0), 0.0)
+    bg["features_rest"] = 0.05 * torch.randn(n_bg, T, 15, 3, generator=g)
+    bg["features_adapters"] = 0.1 * torch.randn(n_bg, T, 3, generator=g)
+    road = base(n_road, (40.0, 0.2, 40.0), 1.6)
+    road["features_rest"] = 0.05 * torch.randn(n_road, 15, 3, generator=g)
+    return {"background": {k: v.to(dev) for k, v in bg.items()}, "road": {k: v.to(dev) for k, v in road.items()}}
+
+
+def gaussians_chain(P, c2w, t, n):
+    """VanillaGaussianSplattingModel / MultiColorGaussianSplattingModel.get_gaussians, operator by operator."""
+    out = {"means": [], "scales": [], "quats": [], "opacities": [], "rgbs": []}
+    for name, p in P.items():
+        if "features_adapters" in p:
+            dc, rest = p["features_dc"] + p["features_adapters"][:, t, :], p["features_rest"][:, t, :, :]
+        else:
+            dc, rest = p["features_dc"], p["features_rest"]
+        colors = torch.cat((dc[:, None, :], rest), dim=1)
+        viewdirs = p["means"].detach() - c2w[..., :3, 3]
+        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        rgbs = torch.clamp(spherical_harmonics(n, viewdirs, colors) + 0.5, 0.0, 1.0)
+        out["means"].append(p["means"]); out["scales"].append(torch.exp(p["scales"]))
+        out["quats"].append(p["quats"] / p["quats"].norm(dim=-1, keepdim=True))
+        out["opacities"].append(torch.sigmoid(p["opacities"]).squeeze(-1)); out["rgbs"].append(rgbs)
+    return {k: torch.cat(v, 0) for k, v in out.items()}
+
+
+def gaussians_fused(P, c2w, t, n):
+    out = {"means": [], "scales": [], "quats": [], "opacities": [], "rgbs": []}
+    for name, p in P.items():
+        if "features_adapters" in p:
+            g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"][:, t],
+                               c2w, n, 3, features_dc_add=p["features_adapters"][:, t])
+        else:
+            g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, n, 3)
+        for k in out:
+            out[k].append(g[k])
+    return {k: torch.cat(v, 0) for k, v in out.items()}
+
+
+def _win(dev):
+    c = torch.arange(11, dtype=torch.float) - 5
+    g = torch.exp(-(c ** 2) / (2 * 1.5 ** 2))
+    return (g / g.sum())[None, None].repeat(3, 1, 1, 1).to(dev)
+
+
+def ssim_chain(gt, pred, mask, win):
+    X, Y = gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None]
+    m = mask.permute(2, 0, 1).unsqueeze(0).expand_as(X)[..., 5:-5, 5:-5]
+    f = lambda x: F.conv2d(F.conv2d(x, win.transpose(2, 3), groups=3), win, groups=3)
+    mu1, mu2 = f(X), f(Y)
+    s1, s2, s12 = f(X * X) - mu1.pow(2), f(Y * Y) - mu2.pow(2), f(X * Y) - mu1 * mu2
+    smap = ((2 * mu1 * mu2 + 1e-4) / (mu1.pow(2) + mu2.pow(2) + 1e-4)) * ((2 * s12 + 9e-4) / (s1 + s2 + 9e-4))
+    return torch.masked_select(smap, m).mean()
+
+
+def stats_chain(stats, radii, absgrad, sizes, W, H):
+    start = 0
+    for (gn, vc, m2), n in zip(stats, sizes):
+        grads = (absgrad[0, start:start + n] * absgrad.new_tensor([W, H]) * 0.5).norm(dim=-1)
+        r = radii[0, start:start + n]
+        vis = r > 0
+        vc[vis] += 1; gn[vis] += grads[vis]; m2[vis] = torch.maximum(m2[vis], r[vis].float())
+        start += n
+
+
+def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3):
+    vm, K, c2w, t = cam
+    gs = (gaussians_fused if fused else gaussians_chain)(P, c2w, t, n)
+    render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], gs["rgbs"], vm, K, W, H,
+                                        packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+    info["means2d"].retain_grad()
+    rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)          # black background (mtgs_scene_graph.py:672-676)
+    l1 = torch.abs(gt - rgb)[mask.squeeze(-1)].mean()
+    ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)
+    loss = 0.8 * l1 + 0.2 * (1 - ssim)
+    loss.backward()
+    sizes = [p["means"].shape[0] for p in P.values()]
+    with torch.no_grad():
+        if fused:
+            start = 0
+            for s, n_ in zip(stats, sizes):
+                update_statistics(*s, info["radii"], info["means2d"].absgrad, W, H, start=start)
+                start += n_
+        else:
+            stats_chain(stats, info["radii"], info["means2d"].absgrad, sizes, W, H)
+    return loss.detach()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-background", type=int, default=1_600_000)
+    ap.add_argument("--n-road", type=int, default=400_000)
+    ap.add_argument("--traversals", type=int, default=3)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--height", type=int, default=540)
+    ap.add_argument("--steps", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    W, H, T = args.width, args.height, args.traversals
+    truth = make_nodes(args.n_background, args.n_road, T, 0, dev)
+    cams = []
+    for t in range(T):
+        vm, K = make_camera(W, H, yaw_deg=20.0 * t)
+        cams.append((vm.to(dev), K.to(dev), torch.inverse(vm)[:, :3, :].to(dev), t))
+    win = _win(dev)
+    with torch.no_grad():
+        targets = []
+        for cam in cams:
+            gs = gaussians_fused(truth, cam[2], cam[3], 3)
+            r, a, _ = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], gs["rgbs"], cam[0], cam[1], W, H,
+                                    packed=False, render_mode="RGB", rasterize_mode="antialiased")
+            targets.append(r[0].clamp(0, 1))
+    mask = torch.ones(H, W, 1, dtype=torch.bool, device=dev)
+    mask[: H // 8] = False                                                            # e.g. ego-vehicle / sky mask
+    g = torch.Generator().manual_seed(5)
+    P = {name: {k: (v + (0.3 * torch.randn(v.shape, generator=g)).to(dev) * (k in ("features_dc", "features_rest", "features_adapters"))
+                    ).clone().requires_grad_(True) for k, v in p.items()} for name, p in truth.items()}
+    params = [v for p in P.values() for v in p.values()]
+    mk_stats = lambda: [[torch.zeros(p["means"].shape[0], device=dev), torch.ones(p["means"].shape[0], device=dev),
+                         torch.zeros(p["means"].shape[0], device=dev)] for p in P.values()]
+
+    def timed(fused):
+        stats = mk_stats()
+        def one(i):
+            for q in params:
+                q.grad = None
+            return iteration(P, cams[i % T], targets[i % T], mask, fused, stats, win, W, H)
+        for i in range(3):
+            loss = one(i)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for i in range(args.reps):
+            one(i)
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) / args.reps, float(one(0)), stats
+
+    tc, lc, sc = timed(False)
+    tf, lf, sf = timed(True)
+    n_all = args.n_background + args.n_road
+    print(f"{n_all} Gaussians ({T} traversals), {W}x{H}: iteration (fwd + loss + bwd + statistics) "
+          f"chain {tc:.2f} ms -> fused {tf:.2f} ms ({tc / tf:.2f}x); loss chain {lc:.6f} fused {lf:.6f}")
+    assert abs(lc - lf) <= 2e-5 * max(1.0, abs(lc)), (lc, lf)
+    for a, b in zip(sc, sf):
+        assert torch.allclose(a[1], b[1]) and torch.allclose(a[2], b[2])
+    if args.steps:
+        opt = torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
+                                {"params": [p[k] for p in P.values() for k in p if not k.startswith("features")], "lr": 1e-4}])
+        stats = mk_stats()
+        curve = []
+        for i in range(args.steps):
+            opt.zero_grad(set_to_none=True)
+            curve.append(float(iteration(P, cams[i % T], targets[i % T], mask, True, stats, win, W, H)))
+            opt.step()
+        k = max(1, args.steps // 8)
+        print("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
+        assert sum(curve[-T:]) < 0.7 * sum(curve[:T]), "training did not reduce the loss"
+
+
+if __name__ == "__main__":
+    main()

@@ -155,3 +155,18 @@ def test_viewer_style_arbitrary_resolutions_and_threads():
     for (W, H) in sizes:
         shape, finite, acc = results[(W, H)]
         assert shape == (H, W, 3) and finite and acc > 0
+
+
+def test_mtgs_like_iteration_fused_equals_chain_and_trains():
+    """scripts/mtgs_like_train.py (BASELINE configs[4] in miniature): the fused neighbours of the path (node
+    activations, masked SSIM, densification statistics) give the same loss and statistics as the operator chains MTGS
+    runs, and 45 Adam steps on a synthetic multi-traversal scene reduce the loss."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--n-background", "30000", "--n-road",
+                        "10000", "--width", "320", "--height", "200", "--steps", "45", "--reps", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "fused" in r.stdout and "loss:" in r.stdout
