@@ -81,45 +81,48 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
         qr = *reinterpret_cast<const F4 *>(P.quats_raw + gl * 4);
         orw = P.opac_raw[gl];
     }
-    // ---- coefficient rows, 16 steps of 4 Gaussians, loads issued 8 steps ahead
+    // unit view direction, once per Gaussian in the lane-per-Gaussian mapping (the rows fetch it by ds_bpermute)
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    if (P.use_sh && okl) {
+        const F3 mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
+        dx = mn.x - camx; dy = mn.y - camy; dz = mn.z - camz;
+        const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+        dx *= inorm; dy *= inorm; dz *= inorm;
+    }
+    // ---- coefficient rows: 16 steps of 4 consecutive Gaussians, every load issued before the first use
+    F3 c[NODE_STEPS];
+#pragma unroll
+    for (int it = 0; it < NODE_STEPS; ++it) {
+        const int64_t g = g0 + it * 4 + sub;
+        c[it] = F3{0.f, 0.f, 0.f};
+        if (g < N && active) {
+            if (k == 0) {
+                c[it] = *reinterpret_cast<const F3 *>(P.dc + g * P.dc_stride);
+                if (P.dc_add) {
+                    const F3 a = *reinterpret_cast<const F3 *>(P.dc_add + g * P.dc_add_stride);
+                    c[it].x += a.x; c[it].y += a.y; c[it].z += a.z;
+                }
+            } else {
+                c[it] = *reinterpret_cast<const F3 *>(P.rest + g * P.rest_stride + (k - 1) * 3);
+            }
+        }
+    }
     float myr = 0.f, myg = 0.f, myb = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        F3 c[8], m[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t g = g0 + (h * 8 + u) * 4 + sub;
-            c[u] = F3{0.f, 0.f, 0.f}; m[u] = F3{0.f, 0.f, 1.f};
-            if (g < N) {
-                if (P.use_sh) m[u] = *reinterpret_cast<const F3 *>(P.means + g * 3);
-                if (active) {
-                    if (k == 0) {
-                        c[u] = *reinterpret_cast<const F3 *>(P.dc + g * P.dc_stride);
-                        if (P.dc_add) {
-                            const F3 a = *reinterpret_cast<const F3 *>(P.dc_add + g * P.dc_add_stride);
-                            c[u].x += a.x; c[u].y += a.y; c[u].z += a.z;
-                        }
-                    } else {
-                        c[u] = *reinterpret_cast<const F3 *>(P.rest + g * P.rest_stride + (k - 1) * 3);
-                    }
-                }
-            }
+    for (int it = 0; it < NODE_STEPS; ++it) {
+        float r, gg, bb;
+        if (P.use_sh) {
+            const int src = (it * 4 + sub) << 2;   // the lane that owns Gaussian 4*it + sub
+            const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dx)));
+            const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
+            const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
+            const float b = sh_lane_basis<DEG>(lc, x, y, z);
+            r = row16_sum(b * c[it].x); gg = row16_sum(b * c[it].y); bb = row16_sum(b * c[it].z);
+        } else {  // lane 0 of the row holds the coefficients; every lane of the row gets them
+            r = row16_sum(c[it].x); gg = row16_sum(c[it].y); bb = row16_sum(c[it].z);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float r, gg, bb;
-            if (P.use_sh) {
-                float x = m[u].x - camx, y = m[u].y - camy, z = m[u].z - camz;
-                const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
-                x *= inorm; y *= inorm; z *= inorm;
-                const float b = sh_lane_basis<DEG>(lc, x, y, z);
-                r = row16_sum(b * c[u].x); gg = row16_sum(b * c[u].y); bb = row16_sum(b * c[u].z);
-            } else {  // lane 0 of the row holds the coefficients; every lane of the row gets them
-                r = row16_sum(c[u].x); gg = row16_sum(c[u].y); bb = row16_sum(c[u].z);
-            }
-            const bool mine = k == h * 8 + u;  // lane k of the row keeps the result of step k
-            myr = mine ? r : myr; myg = mine ? gg : myg; myb = mine ? bb : myb;
-        }
+        const bool mine = k == it;  // lane k of the row keeps the result of step k
+        myr = mine ? r : myr; myg = mine ? gg : myg; myb = mine ? bb : myb;
     }
     {   // the owner of Gaussian l fetches its colour from lane 16 * (l % 4) + l / 4
         const int src = ((lane & 3) * 16 + (lane >> 2)) << 2;

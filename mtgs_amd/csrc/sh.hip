@@ -191,7 +191,12 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
     v += dpp_mov<0x140>(v);  // row_mirror
     return v;
 }
-constexpr int SH16_BLOCK = 256, SH16_UNROLL = 8, SH16_PER_WAVE = 4 * SH16_UNROLL;
+// A wave owns 64 consecutive Gaussians.  Directions, masks and results use the lane-per-Gaussian mapping (768
+// contiguous bytes per instruction; the direction is normalised ONCE per Gaussian), the coefficients the row mapping:
+// in step `it` row `sub` works on Gaussian 4*it + sub, whose direction it fetches from lane 4*it + sub by
+// ds_bpermute; lane k of a row keeps the result of step k, which the owner lane l = 4k + sub reads back from lane
+// 16*(l % 4) + l / 4.  All 16 coefficient loads of a lane are issued before the first is used.
+constexpr int SH16_BLOCK = 256, SH16_STEPS = 16, SH16_PER_WAVE = 64;
 struct F3 { float x, y, z; };
 template <int DEG>
 __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const float *__restrict__ dirs,
@@ -202,32 +207,43 @@ __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
     const bool active = k < NB;
-    const int64_t wave = (int64_t)blockIdx.x * (SH16_BLOCK / 64) + (threadIdx.x >> 6);
-    const int64_t g_first = wave * SH16_PER_WAVE + sub;
-    F3 c[SH16_UNROLL], d[SH16_UNROLL];
-    bool on[SH16_UNROLL];
-#pragma unroll
-    for (int u = 0; u < SH16_UNROLL; ++u) {   // all loads of the wave's 32 Gaussians are issued up front
-        const int64_t g = g_first + 4 * u;
-        on[u] = g < n && (!masks || masks[g]);
-        c[u] = F3{0.f, 0.f, 0.f};
-        d[u] = F3{0.f, 0.f, 1.f};
-        if (on[u]) {
-            d[u] = *reinterpret_cast<const F3 *>(dirs + g * 3);
-            if (active) c[u] = *reinterpret_cast<const F3 *>(coeffs + (g * 16 + k) * 3);
-        }
+    const int64_t g0 = ((int64_t)blockIdx.x * (SH16_BLOCK / 64) + (threadIdx.x >> 6)) * SH16_PER_WAVE;
+    if (g0 >= n) return;
+    // ---- lane-per-Gaussian: direction (normalised once) and mask
+    const int64_t gl = g0 + lane;
+    const bool onl = gl < n && (!masks || masks[gl]);
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    if (onl) {
+        const F3 d = *reinterpret_cast<const F3 *>(dirs + gl * 3);
+        const float inorm = 1.0f / sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
+        dx = d.x * inorm; dy = d.y * inorm; dz = d.z * inorm;
     }
+    const unsigned long long on_mask = __builtin_amdgcn_ballot_w64(onl);
+    // ---- rows
+    F3 c[SH16_STEPS];
 #pragma unroll
-    for (int u = 0; u < SH16_UNROLL; ++u) {
-        const int64_t g = g_first + 4 * u;
-        float x = d[u].x, y = d[u].y, z = d[u].z;
-        const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
-        x *= inorm; y *= inorm; z *= inorm;
+    for (int it = 0; it < SH16_STEPS; ++it) {
+        const int gi = it * 4 + sub;
+        c[it] = F3{0.f, 0.f, 0.f};
+        if (active && ((on_mask >> gi) & 1ull)) c[it] = *reinterpret_cast<const F3 *>(coeffs + ((g0 + gi) * 16 + k) * 3);
+    }
+    float myr = 0.f, myg = 0.f, myb = 0.f;
+#pragma unroll
+    for (int it = 0; it < SH16_STEPS; ++it) {
+        const int src = (it * 4 + sub) << 2;
+        const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dx)));
+        const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
+        const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
         const float b = sh_lane_basis<DEG>(lc, x, y, z);
-        const float r = row16_sum(b * c[u].x), gg = row16_sum(b * c[u].y), bb = row16_sum(b * c[u].z);
-        // lanes 0..2 of the row write the three channels: 4 rows -> 48 contiguous bytes per instruction
-        if (k < 3 && g < n) colors[g * 3 + k] = on[u] ? (k == 0 ? r : (k == 1 ? gg : bb)) : 0.f;
+        const float r = row16_sum(b * c[it].x), gg = row16_sum(b * c[it].y), bb = row16_sum(b * c[it].z);
+        const bool mine = k == it;
+        myr = mine ? r : myr; myg = mine ? gg : myg; myb = mine ? bb : myb;
     }
+    const int back = ((lane & 3) * 16 + (lane >> 2)) << 2;
+    myr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(myr)));
+    myg = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(myg)));
+    myb = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(myb)));
+    if (gl < n) *reinterpret_cast<F3 *>(colors + gl * 3) = onl ? F3{myr, myg, myb} : F3{0.f, 0.f, 0.f};
 }
 
 template <int DEG>
