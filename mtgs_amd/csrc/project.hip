@@ -29,13 +29,16 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     const int c = (int)(idx / N);
     const int64_t n = idx - (int64_t)c * N;
     const Cam cam = load_cam(viewmats + c * 16, Ks + c * 9);
-    const float m[3] = {means[n * 3], means[n * 3 + 1], means[n * 3 + 2]};
+    struct F3 { float x, y, z; };  // 12-byte rows move as one dwordx3 access
+    const F3 m3 = *reinterpret_cast<const F3 *>(means + n * 3);
+    const float m[3] = {m3.x, m3.y, m3.z};
     int32_t r_out = 0;
     float mx = 0.f, my = 0.f, depth = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, comp = 0.f;
     const float zc = ((cam.R[6] * m[0] + cam.R[7] * m[1]) + cam.R[8] * m[2]) + cam.t[2];
     if (!(zc < near_plane || zc > far_plane)) {
         const float4 q = reinterpret_cast<const float4 *>(quats)[n];
-        const float sc[3] = {scales[n * 3], scales[n * 3 + 1], scales[n * 3 + 2]};
+        const F3 s3 = *reinterpret_cast<const F3 *>(scales + n * 3);
+        const float sc[3] = {s3.x, s3.y, s3.z};
         ProjState s;
         proj_common(m, q, sc, cam, W, H, s);
         const float pmx = cam.fx * s.mean_c[0] * s.rz + cam.cx;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     radii[idx] = r_out;
     reinterpret_cast<float2 *>(means2d)[idx] = make_float2(mx, my);
     depths[idx] = depth;
-    conics[idx * 3] = ca; conics[idx * 3 + 1] = cb; conics[idx * 3 + 2] = cc;
+    *reinterpret_cast<F3 *>(conics + idx * 3) = F3{ca, cb, cc};
     if (compensations) compensations[idx] = comp;
     // gsplat rendering.py: opacities.repeat(C, 1) [* compensations]
     if (opac_eff) opac_eff[idx] = r_out > 0 ? (compensations ? opacities[n] * comp : opacities[n]) : 0.f;
