@@ -78,11 +78,19 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_emit_kernel(
     __shared__ int32_t s_c[EMIT_TILE];
     const int tid = threadIdx.x;
     const int64_t s0 = (int64_t)blockIdx.x * EMIT_TILE;
-    // r0 = first r with cum[r] > s0   (cum is the inclusive prefix sum, so slot s0 belongs to r0)
-    int64_t lo = 0, hi = n_vis;
+    // r0 = first r with cum[r] > s0   (cum is the inclusive prefix sum, so slot s0 belongs to r0).  A 256-ary
+    // search: every thread probes one position per round, so the block pays 3 dependent global loads at 300k
+    // Gaussians instead of the 19 of a binary search.
+    int64_t lo = 0, hi = n_vis;  // the answer lies in [lo, hi]
     while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (cum[mid] > s0) hi = mid; else lo = mid + 1;
+        const int64_t step = (hi - lo + BIN_BLOCK - 1) / BIN_BLOCK;
+        const int64_t pos = lo + (int64_t)tid * step;
+        const bool below = pos < hi && cum[pos] <= s0;           // monotone in tid: true ... true false ... false
+        const int cnt = __syncthreads_count(below);
+        if (cnt == 0) { hi = lo; break; }
+        const int64_t last_below = lo + (int64_t)(cnt - 1) * step;
+        hi = min(hi, lo + (int64_t)cnt * step);
+        lo = last_below + 1;
     }
     const int64_t r0 = lo;
     // every Gaussian owns >= 1 slot, so the block's slots touch at most Gaussians r0 .. r0+EMIT_TILE-1
@@ -108,7 +116,9 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_emit_kernel(
         const Rect q = tile_rect(m.x, m.y, radii[idx], ts, tw, th);
         const int local = (int)(i - excl), bw = q.x1 - q.x0;
         const int row = local / bw, col = local - row * bw;
-        tile_keys[i] = (uint32_t)(idx / N) * (uint32_t)(tw * th) + (uint32_t)((q.y0 + row) * tw + q.x0 + col);
+        // camera of flatten id idx: a 32-bit division (C*N < 2^31), none at all for the single camera MTGS renders
+        const uint32_t cam = (uint32_t)idx < (uint32_t)N ? 0u : (uint32_t)idx / (uint32_t)N;
+        tile_keys[i] = cam * (uint32_t)(tw * th) + (uint32_t)((q.y0 + row) * tw + q.x0 + col);
         gids[i] = idx;
     }
 }
