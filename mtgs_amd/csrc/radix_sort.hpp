@@ -234,7 +234,9 @@ int sort_pairs(int64_t n, int key_bits, const K *keys_in, const int32_t *vals_in
     bool to_out = (npass % 2) == 1;  // odd: in->out->tmp->out ; even: in->tmp->out
     int shift = 0;
     for (int p = 0; p < npass; ++p) {
-        const int bits = (key_bits - shift) < RADIX_BITS ? (key_bits - shift) : RADIX_BITS;
+        // the remaining bits are spread evenly over the remaining passes (13 tile bits: 7 + 6, not 8 + 5): fewer
+        // digits in a pass mean longer per-digit runs in a block's tile, i.e. longer contiguous stores
+        const int bits = (key_bits - shift + (npass - p) - 1) / (npass - p);
         const unsigned mask = (1u << bits) - 1u;
         K *kout = to_out ? keys_out : keys_tmp;
         int32_t *vout = to_out ? vals_out : vals_tmp;
