@@ -459,10 +459,15 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
     constexpr int NW = NT / 64;
     __shared__ float s_grad[BATCH_FLUSH ? NW * CAND * 16 : 1];
     const int a_col = lane & 15, a_row = lane >> 4;
-    const int j = BATCH_FLUSH ? (tid & 15) : 4 * a_col + a_row;
+    // 12 or 16 components: the PACKED reduction leaves component packed_component(lane) in every lane of a quad
+    // (wave_reduce.hpp); the first lane of the quad issues the atomic.  Other counts: one register per 4 components.
+    constexpr bool PACKED = NR == 3 || NR == 4;
+    const int j_red = PACKED ? packed_component(lane) : 4 * a_col + a_row;
+    const bool red_lane = PACKED ? (lane & 3) == 0 : a_col < NR;
+    const int j = BATCH_FLUSH ? (tid & 15) : j_red;
     float *a_base = nullptr;
     uint32_t a_stride_bytes = 0;
-    if ((BATCH_FLUSH || a_col < NR) && j < NV) {
+    if ((BATCH_FLUSH || red_lane) && j < NV) {
         if (j < 2) { a_base = v_means2d + j; a_stride_bytes = gs.means2d; }
         else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride_bytes = gs.means2d_abs; }
         else if (j < 7) { a_base = v_conics + (j - 4); a_stride_bytes = gs.conics; }
@@ -563,18 +568,18 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             gv[4] = 0.5f * dx * dx * S0;
             gv[5] = dx * S1;
             gv[6] = 0.5f * S2;
-            float red[NR];
-#if defined(MTGS_EXP_NO_REDUCE)
+            float val;
+            if constexpr (PACKED) {
+                val = wave_reduce_x4_packed<NR>(gv);
+            } else {
+                float red[NR];
+                wave_reduce_x4<NR>(gv, red);
+                val = red[0];
 #pragma unroll
-            for (int i = 0; i < NR; ++i) red[i] = gv[4 * i] + gv[4 * i + 1] + gv[4 * i + 2] + gv[4 * i + 3];
-#else
-            wave_reduce_x4<NR>(gv, red);
-#endif
-            float val = red[0];
-#pragma unroll
-            for (int i = 1; i < NR; ++i) val = (a_col == i) ? red[i] : val;
+                for (int i = 1; i < NR; ++i) val = (a_col == i) ? red[i] : val;
+            }
             if (BATCH_FLUSH) {
-                if (a_col < NR) s_grad[((tid >> 6) * CAND + t) * 16 + 4 * a_col + a_row] = val;
+                if (red_lane && j_red < 16) s_grad[((tid >> 6) * CAND + t) * 16 + j_red] = val;
             } else {
 #if defined(MTGS_EXP_NO_ATOMIC)
                 asm volatile("" ::"v"(val), "v"(gid));

@@ -47,3 +47,58 @@ __device__ __forceinline__ void wave_reduce_x4(float *in, float *out) {
         out[i] = a;
     }
 }
+
+// ---- packed variant: the in-row steps are transposed too ------------------------------------------------------------
+// After the cross-row swaps register i holds, in row r, 16 per-lane partial sums of value 4*i + r.  Summing each
+// register separately costs 4 DPP adds per register.  Instead two registers share one (lanes 0-7 of a row keep X,
+// lanes 8-15 keep Y: v_add_dpp with a bank mask), and at the next level two such registers share the quads, so that
+// ONE register finishes with one value per quad:
+//      quad 0 (lanes 0-3 of the row): register 0     quad 2 (lanes 8-11):  register 1
+//      quad 1 (lanes 4-7):            register 2     quad 3 (lanes 12-15): register 3
+// 12 values: 6+6 cross-row + 7 in-row instead of + 12;  16 values: 8+8 + 8 instead of + 16.
+// packed_component(lane) gives the value index 4*i + r a lane ends up holding (every lane of a quad holds the same).
+__device__ __forceinline__ void row_pair(float &dst, float y) {
+    // dst (banks 2,3 = lanes 8-15 of every row) = y + y rotated by 8 lanes; lanes 0-7 keep dst
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(dst) : "v"(y));
+}
+__device__ __forceinline__ void quad_pair(float &dst, float w) {
+    // dst (banks 1,3 = quads 1 and 3 of every row) = w + half-mirrored w; quads 0 and 2 keep dst
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(dst) : "v"(w));
+}
+__device__ __forceinline__ int packed_component(int lane) {
+    const int q = (lane >> 2) & 3, row = lane >> 4;
+    const int reg = q == 0 ? 0 : (q == 2 ? 1 : (q == 1 ? 2 : 3));
+    return 4 * reg + row;
+}
+// in: 4*NR values per lane (clobbered), NR = 3 or 4.  Returns the packed register described above.
+template <int NR>
+__device__ __forceinline__ float wave_reduce_x4_packed(float *in) {
+    static_assert(NR == 3 || NR == 4, "packed reduction handles 12 or 16 values");
+    float reg[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        float a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], d = in[4 * i + 3];
+        permlane16_swap(a, b);
+        a += b;
+        permlane16_swap(c, d);
+        c += d;
+        permlane32_swap(a, c);
+        reg[i] = a + c;
+    }
+    // level 1: halves of a row
+    float w01 = reg[0] + dpp_perm<0x128>(reg[0]);   // row_ror:8 -> lanes i and i^8 summed, in every lane
+    row_pair(w01, reg[1]);                          // lanes 8-15 <- register 1
+    float w23;
+    if (NR == 4) {
+        w23 = reg[2] + dpp_perm<0x128>(reg[2]);
+        row_pair(w23, reg[3]);
+    } else {
+        w23 = reg[2] + dpp_perm<0x128>(reg[2]);     // both halves hold register 2
+    }
+    // level 2: quads
+    float v = w01 + dpp_perm<0x141>(w01);           // row_half_mirror: the 4 distinct pair sums of a half, twice
+    quad_pair(v, w23);                              // quads 1 and 3 <- registers 2 / 3
+    v += dpp_perm<0xB1>(v);                         // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);                         // quad_perm [2,3,0,1]
+    return v;
+}
