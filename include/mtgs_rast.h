@@ -140,6 +140,9 @@ int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in,
  *                      index order; totals[1] i64 (device) = n_vis<<32 | M.  ws: mtgs_scan_workspace_bytes(C*N).
  *                      vis_rank[C*N] i32 (nullable): position of every visible c*N+n in that list (other
  *                      entries are left untouched) -- the grad_row_index of the two backward kernels.
+ *                      host_totals (nullable): PINNED HOST int64[2]; {totals, host_tag} is published (system scope)
+ *                      as soon as the totals are known, one kernel before the call's work ends, so a host thread
+ *                      polling host_totals[1] == host_tag reads n_vis and M without synchronising the stream.
  *  mtgs_bin_scan     : cum[n_vis] i64 = inclusive sum of tiles_per_gauss[ids_sorted[r]].
  *  mtgs_bin_emit     : tile_keys[M] u32 = cam*n_tiles + tile, gids[M] i32, in depth order.
  *  mtgs_sort_pairs_u32 : stable LSD sort of (u32 key, i32 value) on key bits [0, key_bits).
@@ -148,7 +151,8 @@ int mtgs_sort_pairs(int64_t M, int key_bits, int64_t *keys_in, int32_t *vals_in,
  *  mtgs_bin_finalize : isect_ids[M] i64 from already sorted (tile key, index) pairs and depths. */
 int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
                      const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
-                     int32_t *vis_rank, int64_t *totals, void *ws, size_t ws_bytes, void *stream);
+                     int32_t *vis_rank, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws,
+                     size_t ws_bytes, void *stream);
 int mtgs_bin_scan(int64_t n_vis, const int32_t *ids_sorted, const int32_t *tiles_per_gauss,
                   int64_t *cum, void *ws, size_t ws_bytes, void *stream);
 int mtgs_bin_emit(int64_t M, int64_t n_vis, const int32_t *ids_sorted, int64_t N,

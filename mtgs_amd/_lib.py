@@ -33,7 +33,7 @@ _SIGNATURES = {
     "mtgs_isect_emit": [_i32, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mtgs_sort_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_sort_pairs": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "mtgs_bin_compact": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "mtgs_bin_compact": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp],
     "mtgs_bin_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_bin_emit": [_i64, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mtgs_sort_u32_workspace_bytes": [_i64, C.POINTER(_sz)],

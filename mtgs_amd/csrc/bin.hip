@@ -155,7 +155,8 @@ inline int bit_length_u32(uint32_t v) {
 
 extern "C" int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const float *depths,
                                 const int32_t *tiles_per_gauss, int64_t *vis_keys, int32_t *vis_ids,
-                                int32_t *vis_rank, int64_t *totals, void *ws, size_t ws_bytes, void *stream) {
+                                int32_t *vis_rank, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws,
+                                size_t ws_bytes, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0, MTGS_EINVAL, "mtgs_bin_compact: bad sizes");
     const int64_t total = (int64_t)C * N;
     hipStream_t st = (hipStream_t)stream;
@@ -163,12 +164,16 @@ extern "C" int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const fl
     if (total == 0) {
         hipError_t e = hipMemsetAsync(totals, 0, sizeof(int64_t), st);
         MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_bin_compact: memset failed");
+        if (host_totals) {  // host memory: nothing to wait for
+            host_totals[0] = 0;
+            __atomic_store_n(host_totals + 1, host_tag, __ATOMIC_RELEASE);
+        }
         return MTGS_OK;
     }
     MTGS_REQUIRE(radii && depths && tiles_per_gauss && vis_keys && vis_ids && ws, MTGS_EINVAL, "mtgs_bin_compact: null pointer");
     MTGS_REQUIRE(ws_bytes >= mtgs_scan::workspace_bytes(total), MTGS_EWORKSPACE, "mtgs_bin_compact: workspace too small");
     mtgs_scan::run(total, PackedVisTiles{radii, tiles_per_gauss}, CompactSink{radii, depths, N, vis_keys, vis_ids, vis_rank},
-                   (int64_t *)ws, totals, st);
+                   (int64_t *)ws, totals, st, host_totals, host_tag);
     MTGS_CHECK_LAUNCH("mtgs_bin_compact");
     return MTGS_OK;
 }

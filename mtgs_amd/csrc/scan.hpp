@@ -51,9 +51,13 @@ __global__ __launch_bounds__(BLOCK) void partials_kernel(int64_t n, Value value,
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+// host_total (nullable): HOST-visible (pinned) int64[2].  The grand total is known here, one kernel before the
+// per-element pass: it is published as {total, tag} with system-scope ordering so that a host thread polling
+// host_total[1] for `tag` learns the total while the GPU is still busy (no stream synchronisation).
 template <int DUMMY = 0>
 __global__ __launch_bounds__(BLOCK) void spine_kernel(int64_t nblocks, int64_t *__restrict__ partials,
-                                                      int64_t *__restrict__ total_out) {
+                                                      int64_t *__restrict__ total_out, int64_t *host_total = nullptr,
+                                                      int64_t tag = 0) {
     __shared__ int64_t lds[BLOCK / 64];
     int64_t carry = 0;
     for (int64_t b0 = 0; b0 < nblocks; b0 += BLOCK) {
@@ -65,6 +69,10 @@ __global__ __launch_bounds__(BLOCK) void spine_kernel(int64_t nblocks, int64_t *
         carry += tot;
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;
+    if (threadIdx.x == 0 && host_total) {
+        __hip_atomic_store(host_total, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_total + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <class Value, class Sink>
@@ -90,10 +98,11 @@ __global__ __launch_bounds__(BLOCK) void final_kernel(int64_t n, Value value, Si
 }
 
 template <class Value, class Sink>
-inline void run(int64_t n, Value value, Sink sink, int64_t *partials, int64_t *total_out, hipStream_t st) {
+inline void run(int64_t n, Value value, Sink sink, int64_t *partials, int64_t *total_out, hipStream_t st,
+                int64_t *host_total = nullptr, int64_t tag = 0) {
     const int64_t nblocks = ceil_div64(n, TILE);
     partials_kernel<<<(unsigned)nblocks, BLOCK, 0, st>>>(n, value, partials);
-    spine_kernel<0><<<1, BLOCK, 0, st>>>(nblocks, partials, total_out);
+    spine_kernel<0><<<1, BLOCK, 0, st>>>(nblocks, partials, total_out, host_total, tag);
     final_kernel<<<(unsigned)nblocks, BLOCK, 0, st>>>(n, value, sink, partials);
 }
 
