@@ -55,6 +55,47 @@ struct CompactSink {
         }
     }
 };
+// final pass of mtgs_bin_compact's scan, specialised: a thread owns 8 consecutive (camera, Gaussian) pairs and reads
+// their radii / tile counts as two 16-byte loads each (the generic mtgs_scan::final_kernel issues 8 element loads at a
+// 32-byte lane stride per array and ran at 2 TB/s); depths are only gathered for the visible ones.
+__global__ __launch_bounds__(mtgs_scan::BLOCK) void bin_compact_final_kernel(
+    int64_t n, int64_t N, const int32_t *__restrict__ radii, const int32_t *__restrict__ tpg,
+    const float *__restrict__ depths, const int64_t *__restrict__ partials, int64_t *__restrict__ keys,
+    int32_t *__restrict__ ids, int32_t *__restrict__ rank) {
+    constexpr int ITEMS = mtgs_scan::ITEMS;
+    static_assert(ITEMS == 8, "two int4 loads per array");
+    __shared__ int64_t lds[mtgs_scan::BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * mtgs_scan::TILE + (int64_t)threadIdx.x * ITEMS;
+    int32_t r[ITEMS], t[ITEMS];
+    if (base + ITEMS <= n) {
+        const int4 r0 = *reinterpret_cast<const int4 *>(radii + base), r1 = *reinterpret_cast<const int4 *>(radii + base + 4);
+        const int4 t0 = *reinterpret_cast<const int4 *>(tpg + base), t1 = *reinterpret_cast<const int4 *>(tpg + base + 4);
+        r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+        t[0] = t0.x; t[1] = t0.y; t[2] = t0.z; t[3] = t0.w; t[4] = t1.x; t[5] = t1.y; t[6] = t1.z; t[7] = t1.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            r[i] = base + i < n ? radii[base + i] : 0;
+            t[i] = base + i < n ? tpg[base + i] : 0;
+        }
+    }
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) s += ((int64_t)(r[i] > 0) << 32) | (int64_t)(uint32_t)t[i];
+    int64_t tot;
+    int64_t run = partials[blockIdx.x] + mtgs_scan::block_exclusive_scan(s, lds, tot);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        if (r[i] > 0) {   // (implies base + i < n)
+            const int64_t e = base + i, pos = run >> 32;
+            keys[pos] = ((e / N) << 32) | (int64_t)__float_as_uint(depths[e]);
+            ids[pos] = (int32_t)e;
+            if (rank) rank[e] = (int32_t)pos;
+        }
+        run += ((int64_t)(r[i] > 0) << 32) | (int64_t)(uint32_t)t[i];
+    }
+}
+
 struct GatherTiles {
     const int32_t *ids, *tpg;
     __device__ __forceinline__ int64_t operator()(int64_t r) const { return tpg[ids[r]]; }
@@ -172,8 +213,17 @@ extern "C" int mtgs_bin_compact(int C, int64_t N, const int32_t *radii, const fl
     }
     MTGS_REQUIRE(radii && depths && tiles_per_gauss && vis_keys && vis_ids && ws, MTGS_EINVAL, "mtgs_bin_compact: null pointer");
     MTGS_REQUIRE(ws_bytes >= mtgs_scan::workspace_bytes(total), MTGS_EWORKSPACE, "mtgs_bin_compact: workspace too small");
-    mtgs_scan::run(total, PackedVisTiles{radii, tiles_per_gauss}, CompactSink{radii, depths, N, vis_keys, vis_ids, vis_rank},
-                   (int64_t *)ws, totals, st, host_totals, host_tag);
+    if ((reinterpret_cast<uintptr_t>(radii) | reinterpret_cast<uintptr_t>(tiles_per_gauss)) & 15) {
+        mtgs_scan::run(total, PackedVisTiles{radii, tiles_per_gauss}, CompactSink{radii, depths, N, vis_keys, vis_ids, vis_rank},
+                       (int64_t *)ws, totals, st, host_totals, host_tag);
+    } else {
+        const int64_t nblocks = ceil_div64(total, mtgs_scan::TILE);
+        mtgs_scan::partials_kernel<<<(unsigned)nblocks, mtgs_scan::BLOCK, 0, st>>>(total, PackedVisTiles{radii, tiles_per_gauss},
+                                                                                   (int64_t *)ws);
+        mtgs_scan::spine_kernel<0><<<1, mtgs_scan::BLOCK, 0, st>>>(nblocks, (int64_t *)ws, totals, host_totals, host_tag);
+        bin_compact_final_kernel<<<(unsigned)nblocks, mtgs_scan::BLOCK, 0, st>>>(total, N, radii, tiles_per_gauss, depths,
+                                                                                 (const int64_t *)ws, vis_keys, vis_ids, vis_rank);
+    }
     MTGS_CHECK_LAUNCH("mtgs_bin_compact");
     return MTGS_OK;
 }
