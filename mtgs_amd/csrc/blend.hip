@@ -689,10 +689,15 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 static int pick_ppl(int64_t total_tiles, int DT, bool backward) {
     if (DT > 8) return 1;
     if (const char *e = getenv("MTGS_PPL")) return atoi(e);  // development knob (scripts/kbench.py sweeps)
-    // measured on MI355X, N = 2M, after exact culling (us, pixels per lane 4 / 2 / 1):
-    //   fwd: 1200 tiles 405/291/220   2040 tiles 282/202/159   3600 tiles 237/187/169   8160 tiles 230/-/-
-    //   bwd: 1200 tiles 508/407/327   2040 tiles 378/419/420   3600 tiles 358/549/573   8160 tiles 533/-/-
-    if (backward) return total_tiles >= 1536 ? 4 : 1;
+    // measured on MI355X, N = 2M (us, pixels per lane 4 / 2 / 1):
+    //   fwd, 4 channels: 1200 tiles 405/291/220   2040 tiles 282/202/159   3600 tiles 237/187/169   8160 tiles 230/-/-
+    //   bwd, 4 channels: 1200 tiles 424/344/324   2040 tiles 319/277/408   2800 tiles 320/310/484   8160 tiles 430/-/-
+    //   bwd, 7 channels: 1200 tiles  - /389/600   2040 tiles 362/323/804   3600 tiles 349/383/ -    8160 tiles 505/591/-
+    // (re-measured after the compact gradient rows and the packed reduction: two waves per tile now win the middle range)
+    if (backward) {
+        if (total_tiles >= 3200) return 4;
+        return (DT <= 4 && total_tiles < 1536) ? 1 : 2;
+    }
     return total_tiles >= 6144 ? 4 : (total_tiles >= 4608 ? 2 : 1);
 }
 
