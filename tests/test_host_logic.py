@@ -103,3 +103,27 @@ def test_flat_grad_bucket_single_process():
     bucket.zero()
     assert bucket.flat.abs().max() == 0 and a.grad.data_ptr() == bucket.views[0].data_ptr()
     assert bucket.all_reduce() is None          # no process group: no-op
+
+
+def test_neighbour_modules_have_no_cpu_fallback_and_validate_arguments():
+    """mtgs_amd.nodes / loss / densify: CPU tensors raise, shapes are checked before any launch."""
+    from mtgs_amd.densify import update_statistics
+    from mtgs_amd.loss import masked_ssim
+    from mtgs_amd.nodes import node_gaussians
+    N = 8
+    z = lambda *s: torch.zeros(*s)
+    c2w = torch.eye(4)[None, :3]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        node_gaussians(z(N, 3), z(N, 3), torch.ones(N, 4), z(N, 1), z(N, 3), z(N, 15, 3), c2w, 3, 3)
+    with pytest.raises(AssertionError):
+        node_gaussians(z(N, 3), z(N, 3), torch.ones(N, 4), z(N, 1), z(N, 3), z(N, 3, 3), c2w, 3, 3)   # degree 3 needs K = 16
+    with pytest.raises(NotImplementedError, match="degree"):
+        node_gaussians(z(N, 3), z(N, 3), torch.ones(N, 4), z(N, 1), z(N, 3), z(N, 24, 3), c2w, 4, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        masked_ssim(z(32, 32, 3), z(32, 32, 3))
+    with pytest.raises(ValueError, match="11x11"):
+        masked_ssim(z(8, 32, 3), z(8, 32, 3))
+    with pytest.raises(NotImplementedError, match="gt"):
+        masked_ssim(z(32, 32, 3).requires_grad_(True), z(32, 32, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        update_statistics(z(N), z(N), z(N), torch.zeros(1, N, dtype=torch.int32), z(1, N, 2), 64, 48)
