@@ -222,6 +222,14 @@ def main():
     D = 4 if args.variant == "mtgs" else 3
     A = 1 if args.variant == "mtgs" else 0
     bytes_bwd = P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A)
+    # whole-step algorithmic HBM bytes, SURVEY.md section 8(d): B_F + B_B (K = 16 SH bases when the step includes SH)
+    N, T = args.n_gaussians, -(-args.width // 16) * -(-args.height // 16)
+    Ksh = 16 if args.variant == "mtgs" else 0
+    b_fwd = (N * (12 + 12 * Ksh) + N * 12 if Ksh else 0) + N * 44 + N * 4 + n_vis * 28 + n_vis * 16 + M * 12 + 2 * M * 12 \
+        + M * 8 + T * 4 + M * (28 + 4 * D) + P * (4 * D + 8)
+    b_bwd = P * (4 * D + 12) + M * (28 + 4 * D) + n_vis * (24 + 4 * D + 8 * A) + n_vis * (40 + 28 + 24 + 4 * D) + n_vis * 40 + 64 \
+        + (N * 12 * Ksh if Ksh else 0)
+    step_bytes = b_fwd + b_bwd
     k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     achieved = bytes_bwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic = None
@@ -253,7 +261,11 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
                      "launches_timed": len(kernel_ms),
-                     "note": "kernel is VALU/LDS/atomic bound, not HBM bound (DESIGN.md section 4)"},
+                     "note": "kernel is VALU/LDS/atomic bound, not HBM bound (DESIGN.md section 4)",
+                     "whole_step": {"algorithmic_bytes": step_bytes, "unit": "GB/s",
+                                    "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                    "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "formula": "SURVEY.md section 8(d) B_F + B_B"}},
     }
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)
