@@ -63,3 +63,43 @@ def masked_ssim(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None, win_sig
     if gt.requires_grad:
         raise NotImplementedError("masked_ssim: gradient with respect to gt (the first argument) is not implemented")
     return _MaskedSSIM.apply(gt, pred, mask, win_sigma, data_range, K[0], K[1])
+
+
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt, pred, mask):
+        require_gpu(gt, pred, mask)
+        H, W = pred.shape[:2]
+        gt_c = gt.detach().to(torch.float32).contiguous()
+        pred_c = pred.detach().to(torch.float32).contiguous()
+        mask_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        n = C.c_size_t(0)
+        call("mtgs_l1_workspace_floats", W, H, C.byref(n))
+        partials = torch.empty(n.value, dtype=torch.float32, device=pred.device)
+        out = torch.empty(2, dtype=torch.float32, device=pred.device)
+        call("mtgs_l1_fwd", W, H, ptr(gt_c), ptr(pred_c), ptr(mask_c), ptr(partials), ptr(out), stream_of(pred))
+        ctx.save_for_backward(gt_c, pred_c, mask_c, out)
+        ctx.dims = (H, W, pred.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, v_out):
+        gt_c, pred_c, mask_c, out = ctx.saved_tensors
+        H, W, dtype = ctx.dims
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        v_pred = torch.empty_like(pred_c)
+        call("mtgs_l1_bwd", W, H, ptr(gt_c), ptr(pred_c), ptr(mask_c), ptr(v), ptr(out), ptr(v_pred), stream_of(pred_c))
+        return None, v_pred.to(dtype), None
+
+
+def masked_l1(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """torch.abs(gt - pred)[mask.squeeze(-1)].mean() as MTGS forms its L1 loss
+    (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:823): gt, pred [H,W,3], mask [H,W,1] / [H,W] bool or None.
+    One launch per direction instead of boolean-mask indexing (nonzero + gather, sorted index_put backward).
+    Differentiable with respect to `pred`."""
+    assert pred.dim() == 3 and pred.shape[2] == 3 and gt.shape == pred.shape, (gt.shape, pred.shape)
+    if mask is not None:
+        assert mask.numel() == pred.shape[0] * pred.shape[1], mask.shape
+    if gt.requires_grad:
+        raise NotImplementedError("masked_l1: gradient with respect to gt is not implemented")
+    return _MaskedL1.apply(gt, pred, mask)

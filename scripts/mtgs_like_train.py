@@ -7,7 +7,7 @@ statistics -> Adam -- run two ways on the same parameters:
 
   chain : the PyTorch operator chains MTGS runs around the drop-in rasterizer (exp / normalize / sigmoid / cat / SH op /
           clamp; SSIM as 5 grouped convolutions x 2; masked-tensor statistics), i.e. MTGS unchanged on this library;
-  fused : mtgs_amd.nodes.node_gaussians, mtgs_amd.loss.masked_ssim, mtgs_amd.densify.update_statistics.
+  fused : mtgs_amd.nodes.node_gaussians, mtgs_amd.loss.masked_l1 / masked_ssim, mtgs_amd.densify.update_statistics.
 
 Prints the per-iteration GPU time of both and checks that they compute the same loss.  `--steps` > 0 also trains
 (fused) and prints the loss curve.
@@ -23,7 +23,7 @@ import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
 from mtgs_amd.densify import update_statistics  # noqa: E402
-from mtgs_amd.loss import masked_ssim  # noqa: E402
+from mtgs_amd.loss import masked_l1, masked_ssim  # noqa: E402
 from mtgs_amd.nodes import node_gaussians  # noqa: E402
 from mtgs_amd.synthetic import make_camera  # noqa: E402
 
@@ -107,7 +107,7 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3):
                                         packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
     info["means2d"].retain_grad()
     rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)          # black background (mtgs_scene_graph.py:672-676)
-    l1 = torch.abs(gt - rgb)[mask.squeeze(-1)].mean()
+    l1 = masked_l1(gt, rgb, mask) if fused else torch.abs(gt - rgb)[mask.squeeze(-1)].mean()
     ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)
     loss = 0.8 * l1 + 0.2 * (1 - ssim)
     loss.backward()
@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", choices=["both", "fused", "chain"], default="both", help="profiling aid: time one variant only")
     args = ap.parse_args()
     dev = torch.device("cuda")
     W, H, T = args.width, args.height, args.traversals
@@ -173,6 +174,10 @@ def main():
         e.record(); torch.cuda.synchronize()
         return s.elapsed_time(e) / args.reps, float(one(0)), stats
 
+    if args.only != "both":
+        t1, l1, _ = timed(args.only == "fused")
+        print(f"{args.only}: {t1:.2f} ms per iteration, loss {l1:.6f}")
+        return
     tc, lc, sc = timed(False)
     tf, lf, sf = timed(True)
     n_all = args.n_background + args.n_road

@@ -47,3 +47,25 @@ def test_masked_ssim_training_resolution(hip_lib):
     assert np.abs(p.grad.cpu().numpy() - grad_ref).max() <= 2e-5 * np.abs(grad_ref).max()
     v2 = masked_ssim(gt.to(dev), p.detach(), mask.to(dev))
     assert float(v2) == float(val.detach())               # fixed summation order: bit-identical between runs
+
+
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_masked_l1_matches_torch_formulation(hip_lib, use_mask):
+    """mtgs_scene_graph.py:823: torch.abs(gt_img - pred)[combined_mask.squeeze(-1)].mean()"""
+    from mtgs_amd.loss import masked_l1
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    H, W = 211, 333
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    pred0 = torch.rand(H, W, 3, generator=g)
+    pred0[5, 7] = gt[5, 7].cpu()                                    # exact ties: sign(0) = 0
+    mask = (torch.rand(H, W, 1, generator=g) > 0.4).to(dev) if use_mask else None
+    p_ref = pred0.to(dev).double().requires_grad_(True)
+    d = torch.abs(gt.double() - p_ref)
+    ref = d[mask.squeeze(-1)].mean() if use_mask else d.mean()
+    (0.8 * ref).backward()
+    p = pred0.to(dev).requires_grad_(True)
+    val = masked_l1(gt, p, mask)
+    (0.8 * val).backward()
+    assert abs(float(val.detach()) - float(ref.detach())) <= 2e-6
+    assert torch.allclose(p.grad.double(), p_ref.grad, rtol=1e-5, atol=1e-12)
