@@ -265,7 +265,11 @@ int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, cons
  * K_rest = K - 1 <= 15, degree <= 3.  clamp_mask[N] u8 (bit c: channel c passed the clamp) is saved for the backward.
  * bwd: gradients with respect to the RAW parameters; g_features_dc[N,3] (also the gradient of features_dc_add) and
  * g_features_rest[N,K_rest,3] are dense and fully written (zeros above the active degree).  means / cam_pos get no
- * gradient: MTGS detaches the view directions (vanilla_gaussian_splatting.py:314). */
+ * gradient: MTGS detaches the view directions (vanilla_gaussian_splatting.py:314).
+ * n_traversals > 0 (multi-colour nodes): the coefficients were slice `traversal` of per-traversal parameters
+ * [N,T,K_rest,3] / [N,T,3]; the backward then writes the gradients of the FULL tensors -- g_features_rest[N,T,K_rest,3]
+ * and g_features_dc_add[N,T,3] (nullable): values in slice `traversal`, zeros elsewhere -- in the same pass, instead
+ * of the zero-fill + strided slice copy autograd performs for an indexed view. */
 int mtgs_node_fwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *scales_raw,
                   const float *quats_raw, const float *opacities_raw, const float *features_dc,
                   const float *features_dc_add, const float *features_rest, const int64_t *row_strides,
@@ -275,7 +279,8 @@ int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *me
                   const float *cam_pos, const float *scales, const float *opacities, const float *rgbs,
                   const uint8_t *clamp_mask, const float *v_scales, const float *v_quats, const float *v_opacities,
                   const float *v_rgbs, float *g_scales_raw, float *g_quats_raw, float *g_opacities_raw,
-                  float *g_features_dc, float *g_features_rest, void *stream);
+                  float *g_features_dc, float *g_features_rest, float *g_features_dc_add, int n_traversals,
+                  int traversal, void *stream);
 
 /* ---- densification statistics of one node in one launch ------------------------------
  * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous

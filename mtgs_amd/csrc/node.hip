@@ -159,7 +159,8 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
                                                               const float *__restrict__ v_opacities,
                                                               const float *__restrict__ v_rgbs, float *__restrict__ g_scales_raw,
                                                               float *__restrict__ g_quats_raw, float *__restrict__ g_opac_raw,
-                                                              float *__restrict__ g_dc, float *__restrict__ g_rest) {
+                                                              float *__restrict__ g_dc, float *__restrict__ g_rest,
+                                                              float *__restrict__ g_dc_add, int n_trav, int trav) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
@@ -196,6 +197,40 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
     const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
     dx *= inorm; dy *= inorm; dz *= inorm;
     // ---- rows: v_coeff[k, :] = basis_k(dir) * v
+    if (n_trav > 0) {
+        // Per-traversal parameters [N, T, ...]: the gradient of the FULL tensors is written here -- slice `trav` gets the
+        // values, the other traversals zeros -- instead of autograd's zero-fill + strided slice copy.  Row `sub` of step
+        // s handles (Gaussian, traversal) pair 4 s + sub, so the four rows of a store instruction cover four CONSECUTIVE
+        // [K-1, 3] blocks (720 contiguous bytes); the pair's Gaussian is found with a multiply-high (T is small).
+        if (okl) *reinterpret_cast<F3 *>(g_dc + gl * 3) = P.use_sh ? F3{0.2820947917738781f * v.x, 0.2820947917738781f * v.y, 0.2820947917738781f * v.z} : v;
+        const uint32_t magic = 0xFFFFFFFFu / (uint32_t)n_trav + 1u;
+        const int n_here = (int)min((int64_t)NODE_PER_WAVE, N - g0);
+        const int n_steps = (n_here * n_trav + 3) >> 2;
+        for (int st = 0; st < n_steps; ++st) {
+            const uint32_t q = (uint32_t)(4 * st + sub);
+            const uint32_t gi = __umulhi(q, magic);          // q / n_trav
+            const int tt = (int)(q - gi * (uint32_t)n_trav);
+            const int src = (int)(gi & 63u) << 2;            // the lane that owns Gaussian gi
+            const float vx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x)));
+            const float vy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)));
+            const float vz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.z)));
+            float b = 0.f;
+            if (P.use_sh) {
+                const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dx)));
+                const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
+                const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
+                b = (k < NB && tt == trav) ? sh_lane_basis<DEG>(lc, x, y, z) : 0.f;
+            } else {
+                b = (k == 0 && tt == trav) ? 1.f : 0.f;
+            }
+            if ((int)gi >= n_here) continue;
+            const int64_t pair = (g0 + gi) * n_trav + tt;
+            const F3 o = F3{b * vx, b * vy, b * vz};
+            if (k == 0) { if (g_dc_add) *reinterpret_cast<F3 *>(g_dc_add + pair * 3) = o; }
+            else if (k - 1 < P.Kr) *reinterpret_cast<F3 *>(g_rest + (pair * P.Kr + (k - 1)) * 3) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < NODE_STEPS; ++it) {
         const int src = (it * 4 + sub) << 2;   // the lane that owns Gaussian 4*it + sub
@@ -263,7 +298,8 @@ extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, cons
                              const float *cam_pos, const float *scales, const float *opacities, const float *rgbs,
                              const uint8_t *clamp_mask, const float *v_scales, const float *v_quats,
                              const float *v_opacities, const float *v_rgbs, float *g_scales_raw, float *g_quats_raw,
-                             float *g_opacities_raw, float *g_features_dc, float *g_features_rest, void *stream) {
+                             float *g_opacities_raw, float *g_features_dc, float *g_features_rest,
+                             float *g_features_dc_add, int n_traversals, int traversal, void *stream) {
     const int64_t strides[3] = {3, 3, (int64_t)K_rest * 3};
     if (int rc = node_check("mtgs_node_bwd", N, K_rest, degree, use_sh, strides)) return rc;
     if (N == 0) return MTGS_OK;
@@ -271,11 +307,14 @@ extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, cons
                      v_opacities && v_rgbs && g_scales_raw && g_quats_raw && g_opacities_raw && g_features_dc &&
                      (g_features_rest || K_rest == 0),
                  MTGS_EINVAL, "mtgs_node_bwd: null pointer");
+    MTGS_REQUIRE(n_traversals >= 0 && (n_traversals == 0 || (traversal >= 0 && traversal < n_traversals)), MTGS_EINVAL,
+                 "mtgs_node_bwd: traversal %d of %d", traversal, n_traversals);
     const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh};
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
     MTGS_NODE_DISPATCH(node_bwd_kernel, N, P, scales, opacities, rgbs, clamp_mask, v_scales, v_quats, v_opacities, v_rgbs,
-                       g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc, g_features_rest)
+                       g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc, g_features_rest, g_features_dc_add, n_traversals,
+                       traversal)
     MTGS_CHECK_LAUNCH("mtgs_node_bwd");
     return MTGS_OK;
 }

@@ -38,10 +38,17 @@ def _rows(t: Optional[Tensor], width: int):
 class _NodeActivations(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos,
-                degree, use_sh):
+                degree, use_sh, trav):
         require_gpu(means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos)
         N = means.shape[0]
         Kr = features_rest.shape[-2]
+        # trav >= 0: features_rest is the FULL [N,T,K-1,3] (and features_dc_add the full [N,T,3]); slice `trav` is read
+        # in place and the backward writes the full-size gradients itself
+        T = features_rest.shape[1] if trav >= 0 else 0
+        full_rest, full_add = features_rest, features_dc_add
+        if trav >= 0:
+            features_rest = features_rest[:, trav]
+            features_dc_add = None if features_dc_add is None else features_dc_add[:, trav]
         means_c, scales_c, quats_c = means.detach().contiguous(), scales_raw.contiguous(), quats_raw.contiguous()
         opac_c = opacities_raw.reshape(N).contiguous()
         dc, s_dc = _rows(features_dc, 3)
@@ -58,13 +65,13 @@ class _NodeActivations(torch.autograd.Function):
              ptr(dca), ptr(rest), host_i64([s_dc, s_dca, s_rest]), ptr(cam), ptr(scales), ptr(quats), ptr(opacities),
              ptr(rgbs), ptr(mask), stream_of(means))
         ctx.save_for_backward(means_c, quats_c, cam, scales, opacities, rgbs, mask)
-        ctx.dims = (N, Kr, int(degree), int(use_sh), opacities_raw.shape, features_dc_add is not None)
+        ctx.dims = (N, Kr, int(degree), int(use_sh), opacities_raw.shape, features_dc_add is not None, T, int(trav))
         return scales, quats, opacities, rgbs
 
     @staticmethod
     def backward(ctx, v_scales, v_quats, v_opacities, v_rgbs):
         means_c, quats_c, cam, scales, opacities, rgbs, mask = ctx.saved_tensors
-        N, Kr, degree, use_sh, opac_shape, has_add = ctx.dims
+        N, Kr, degree, use_sh, opac_shape, has_add, T, trav = ctx.dims
         dev = means_c.device
         z = lambda g, like: (torch.zeros_like(like) if g is None else g.to(torch.float32).contiguous())
         v_scales, v_quats = z(v_scales, scales), z(v_quats, torch.empty((N, 4), device=dev))
@@ -73,23 +80,51 @@ class _NodeActivations(torch.autograd.Function):
         g_quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
         g_opac = torch.empty((N,), dtype=torch.float32, device=dev)
         g_dc = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        g_rest = torch.empty((N, Kr, 3), dtype=torch.float32, device=dev)
+        if T:
+            g_rest = torch.empty((N, T, Kr, 3), dtype=torch.float32, device=dev)
+            g_add = torch.empty((N, T, 3), dtype=torch.float32, device=dev) if has_add else None
+        else:
+            g_rest = torch.empty((N, Kr, 3), dtype=torch.float32, device=dev)
+            g_add = None
         call("mtgs_node_bwd", N, Kr, degree, use_sh, ptr(means_c), ptr(quats_c), ptr(cam), ptr(scales), ptr(opacities),
              ptr(rgbs), ptr(mask), ptr(v_scales), ptr(v_quats), ptr(v_opacities), ptr(v_rgbs), ptr(g_scales), ptr(g_quats),
-             ptr(g_opac), ptr(g_dc), ptr(g_rest), stream_of(means_c))
-        return (None, g_scales, g_quats, g_opac.reshape(opac_shape), g_dc, g_dc if has_add else None, g_rest, None, None,
-                None)
+             ptr(g_opac), ptr(g_dc), ptr(g_rest), ptr(g_add), T, max(trav, 0), stream_of(means_c))
+        if not T:
+            g_add = g_dc if has_add else None
+        return (None, g_scales, g_quats, g_opac.reshape(opac_shape), g_dc, g_add, g_rest, None, None, None, None)
 
 
 def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, features_dc: Tensor,
                    features_rest: Tensor, camera_to_worlds: Tensor, sh_degree_to_use: int, model_sh_degree: int,
-                   features_dc_add: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                   features_dc_add: Optional[Tensor] = None, traversal_index: Optional[int] = None) -> Dict[str, Tensor]:
     """The dict VanillaGaussianSplattingModel.get_gaussians(camera_to_worlds) returns, from the RAW parameters:
     means[N,3], scales[N,3] (log), quats[N,4], opacities[N,1] (logits), features_dc[N,3], features_rest[N,K-1,3];
     `sh_degree_to_use` = min(step // sh_degree_interval, sh_degree), `model_sh_degree` = the model's sh_degree
     (0 selects rgbs = sigmoid(features_dc), vanilla_gaussian_splatting.py:319-320).  camera_to_worlds[...,3,4]:
-    only its translation is used, as in the reference (:314)."""
+    only its translation is used, as in the reference (:314).
+    Multi-colour nodes (multi_color_gaussian_splatting.py:77-86), either
+      * pass the slices: features_rest[:, t], features_dc_add=features_adapters[:, t]  (autograd then zero-fills the
+        full-size gradients and copies the slice in), or
+      * pass the FULL per-traversal parameters features_rest[N,T,K-1,3], features_dc_add=features_adapters[N,T,3] and
+        traversal_index=t: slice t is read in place and the backward writes the full-size gradients in its own pass."""
     N = means.shape[0]
+    if traversal_index is not None:
+        assert features_rest.dim() == 4 and features_rest.shape[0] == N and features_rest.shape[3] == 3, features_rest.shape
+        T = features_rest.shape[1]
+        assert 0 <= traversal_index < T, (traversal_index, T)
+        assert features_dc_add is None or features_dc_add.shape == (N, T, 3), features_dc_add.shape
+        assert scales.shape == (N, 3) and quats.shape == (N, 4) and opacities.numel() == N and features_dc.shape == (N, 3)
+        use_sh = model_sh_degree > 0
+        if use_sh:
+            assert (sh_degree_to_use + 1) ** 2 <= features_rest.shape[2] + 1, (sh_degree_to_use, features_rest.shape)
+        if features_rest.shape[2] > 15 or sh_degree_to_use > 3:
+            raise NotImplementedError("node_gaussians: SH degree > 3 (MTGS configs use <= 3)")
+        cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
+        s, q, o, rgb = _NodeActivations.apply(means, scales, quats, opacities, features_dc,
+                                              None if features_dc_add is None else features_dc_add.contiguous(),
+                                              features_rest.contiguous(), cam_pos, int(sh_degree_to_use), bool(use_sh),
+                                              int(traversal_index))
+        return {"means": means, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}
     assert scales.shape == (N, 3) and quats.shape == (N, 4), (scales.shape, quats.shape)
     assert opacities.numel() == N, opacities.shape
     assert features_dc.shape == (N, 3), features_dc.shape
@@ -103,5 +138,5 @@ def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tens
         raise NotImplementedError("node_gaussians: SH degree > 3 (MTGS configs use <= 3)")
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
     s, q, o, rgb = _NodeActivations.apply(means, scales, quats, opacities, features_dc, features_dc_add, features_rest,
-                                          cam_pos, int(sh_degree_to_use), bool(use_sh))
+                                          cam_pos, int(sh_degree_to_use), bool(use_sh), -1)
     return {"means": means, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}

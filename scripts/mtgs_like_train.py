@@ -65,8 +65,8 @@ def gaussians_fused(P, c2w, t, n):
     out = {"means": [], "scales": [], "quats": [], "opacities": [], "rgbs": []}
     for name, p in P.items():
         if "features_adapters" in p:
-            g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"][:, t],
-                               c2w, n, 3, features_dc_add=p["features_adapters"][:, t])
+            g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
+                               c2w, n, 3, features_dc_add=p["features_adapters"], traversal_index=t)
         else:
             g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, n, 3)
         for k in out:

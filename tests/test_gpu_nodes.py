@@ -48,8 +48,11 @@ def _params(N, K, T, seed):
     (777, 9, 2, 2, 0),                                               # WildGaussians-sized coefficients (sh_degree 2)
     (513, 16, 0, 0, 0),                                              # sh_degree 0 model: rgbs = sigmoid(features_dc)
     (2050, 16, 3, 3, 3),                                             # multi-colour node, traversal 1 of 3, strided views
+    (2050, 16, 2, 3, -3),                                            # same, FULL per-traversal tensors + traversal_index
 ])
 def test_node_gaussians_match_reference_chain(hip_lib, N, K, n, model_deg, T):
+    full = T < 0
+    T = abs(T)
     from mtgs_amd.nodes import node_gaussians
     dev = torch.device("cuda")
     P = _params(N, K, T, 11)
@@ -65,7 +68,10 @@ def test_node_gaussians_match_reference_chain(hip_lib, N, K, n, model_deg, T):
     sum((ref[k] * cot[k].double()).sum() for k in cot).backward()
     # fused (HIP)
     D = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
-    if T:
+    if T and full:
+        out = node_gaussians(D["means"], D["scales"], D["quats"], D["opacities"], D["features_dc"], D["features_rest"],
+                             c2w.to(dev), n, model_deg, features_dc_add=D["features_adapters"], traversal_index=t)
+    elif T:
         out = node_gaussians(D["means"], D["scales"], D["quats"], D["opacities"], D["features_dc"],
                              D["features_rest"][:, t], c2w.to(dev), n, model_deg,
                              features_dc_add=D["features_adapters"][:, t])
