@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU (development / pre-release check, ~2 minutes):
+  * rasterization() (one autograd node, compact gradient rows) vs the operator-by-operator composition of the same
+    kernels, forward bit-for-bit and gradients to fp32-atomic accuracy, over random sizes / cameras / channel counts /
+    render modes, including degenerate inputs (nothing visible, one Gaussian, huge splats, image smaller than a tile);
+  * a sample of the cases against the CPU oracle;
+  * node_gaussians / masked_ssim / masked_l1 / update_statistics vs their PyTorch formulations at random sizes.
+Exits non-zero on the first mismatch, printing the failing configuration (re-run with --seed / --case)."""
+import argparse
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+from mtgs_amd import rasterization, wrapper  # noqa: E402
+from mtgs_amd.densify import update_statistics  # noqa: E402
+from mtgs_amd.loss import masked_l1, masked_ssim  # noqa: E402
+from mtgs_amd.nodes import node_gaussians  # noqa: E402
+
+dev = torch.device("cuda")
+
+
+def rand_case(rng):
+    N = int(rng.choice([1, 2, 63, 64, 65, 300, 1023, 1025, 4000, 20000]))
+    W = int(rng.integers(5, 420)); H = int(rng.integers(5, 300))
+    C = int(rng.choice([1, 1, 1, 2]))
+    D = int(rng.choice([1, 2, 3, 3, 3, 4, 6, 7, 8, 15, 16]))
+    mode = str(rng.choice(["RGB", "RGB+D", "RGB+ED"])) if D + 1 in wrapper.SUPPORTED_CHANNELS or D in wrapper.SUPPORTED_CHANNELS else "RGB"
+    if mode != "RGB" and (D + 1) not in wrapper.SUPPORTED_CHANNELS:
+        mode = "RGB"
+    if mode == "RGB" and D not in wrapper.SUPPORTED_CHANNELS:
+        D = 3
+    return dict(N=N, W=W, H=H, C=C, D=D, mode=mode, aa=bool(rng.integers(2)), absgrad=bool(rng.integers(2)),
+                bg=bool(rng.integers(2)) and mode == "RGB", scale=float(rng.choice([0.02, 0.1, 0.5, 3.0])),
+                spread=float(rng.choice([0.5, 3.0, 10.0])), behind=bool(rng.integers(8) == 0), seed=int(rng.integers(1 << 30)))
+
+
+def build(cfg):
+    g = torch.Generator().manual_seed(cfg["seed"])
+    N, C = cfg["N"], cfg["C"]
+    means = (torch.rand(N, 3, generator=g) * 2 - 1) * cfg["spread"]
+    means[:, 2] = means[:, 2].abs() + 0.5
+    if cfg["behind"]:
+        means[:, 2] = -means[:, 2]
+    P = {"means": means, "quats": torch.randn(N, 4, generator=g), "scales": torch.rand(N, 3, generator=g) * cfg["scale"] + 1e-3,
+         "opacities": torch.rand(N, generator=g), "colors": torch.rand(N, cfg["D"], generator=g)}
+    vms = []
+    for c in range(C):
+        a = 0.3 * c
+        R = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=torch.float32)
+        vm = torch.eye(4); vm[:3, :3] = R; vm[:3, 3] = torch.tensor([0.1 * c, 0.0, 0.2])
+        vms.append(vm)
+    K = torch.tensor([[0.8 * cfg["W"], 0, cfg["W"] / 2], [0, 0.8 * cfg["W"], cfg["H"] / 2], [0, 0, 1]], dtype=torch.float32)
+    return P, torch.stack(vms), K[None].repeat(C, 1, 1)
+
+
+def compose(P, vm, K, cfg, bg):
+    W, H, C = cfg["W"], cfg["H"], cfg["C"]
+    radii, m2d, dep, con, comp, opac = wrapper.projection_with_opacities(P["means"], P["quats"], P["scales"], vm, K, P["opacities"],
+                                                                         W, H, calc_compensations=cfg["aa"])
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, ids, flat = wrapper.isect_tiles(m2d, radii, dep, 16, tw, th)
+    off = wrapper.isect_offset_encode(ids, C, tw, th)
+    cols = P["colors"].unsqueeze(0).expand(C, -1, -1)
+    if cfg["mode"] == "RGB":
+        r, a = wrapper.rasterize_to_pixels(m2d, con, cols, opac, W, H, 16, off, flat, backgrounds=bg, absgrad=cfg["absgrad"])
+    else:
+        r, a = wrapper.rasterize_to_pixels_with_depth(m2d, con, cols, opac, dep, cfg["mode"] == "RGB+ED", W, H, 16, off, flat,
+                                                      backgrounds=bg, absgrad=cfg["absgrad"])
+    return r, a, {"means2d": m2d, "radii": radii, "flatten_ids": flat}
+
+
+def run_paths(cfg, P0, vm0, K0, Gc, Ga, bg0):
+    W, H = cfg["W"], cfg["H"]
+    res = []
+    for fused in (True, False):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in P0.items()}
+        vm = vm0.to(dev).requires_grad_(True)
+        bg = None if bg0 is None else bg0.to(dev)
+        if fused:
+            r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K0.to(dev), W, H,
+                                       packed=False, render_mode=cfg["mode"], rasterize_mode="antialiased" if cfg["aa"] else "classic",
+                                       absgrad=cfg["absgrad"], backgrounds=bg)
+        else:
+            r, a, info = compose(P, vm, K0.to(dev), cfg, bg)
+        info["means2d"].retain_grad()
+        ((r * Gc).sum() + (a * Ga).sum()).backward()
+        grads = {k: P[k].grad for k in P}
+        grads["viewmat"] = vm.grad
+        grads["m2d"] = info["means2d"].grad
+        if cfg["absgrad"]:
+            grads["abs"] = info["means2d"].absgrad
+        res.append((r.detach(), a.detach(), info, grads))
+    return res
+
+
+def check_raster(cfg, with_oracle):
+    P0, vm0, K0 = build(cfg)
+    W, H, C, D = cfg["W"], cfg["H"], cfg["C"], cfg["D"]
+    DT = D + (cfg["mode"] != "RGB")
+    g = torch.Generator().manual_seed(cfg["seed"] + 1)
+    Gc, Ga = torch.randn(C, H, W, DT, generator=g).to(dev), torch.randn(C, H, W, 1, generator=g).to(dev)
+    bg0 = torch.rand(C, D, generator=g) if cfg["bg"] else None
+    (r1, a1, i1, g1), (r0, a0, i0, g0) = run_paths(cfg, P0, vm0, K0, Gc, Ga, bg0)
+    assert torch.equal(r1, r0) and torch.equal(a1, a0), "forward differs"
+    assert torch.equal(i1["radii"], i0["radii"]) and torch.equal(i1["flatten_ids"], i0["flatten_ids"]), "binning differs"
+    noise = None
+    for k in g0:
+        if g0[k] is None and g1[k] is None:
+            continue
+        a_, b_ = g1[k], g0[k]
+        if a_ is None or b_ is None:   # no gradient produced on one side: must be all zero on the other
+            t = a_ if a_ is not None else b_
+            assert float(t.abs().max()) == 0.0, f"grad {k}: None vs non-zero"
+            continue
+        assert torch.isfinite(a_).all(), f"grad {k} not finite"
+        scale = float(b_.abs().max())
+        err = float((a_ - b_).abs().max())
+        # fp32 atomics in another order: 2e-3 of the tensor's max (the bar of the oracle tests).  Scenes of image-filling
+        # splats (hundreds of intersections per Gaussian, large cancelling terms) are ill-conditioned: there TWO RUNS OF
+        # THE SAME PATH differ by up to ~1e-2, so the bound is calibrated on the composition path's own run-to-run noise.
+        if err > 2e-3 * scale + 1e-6:
+            if noise is None:
+                again = run_paths(cfg, P0, vm0, K0, Gc, Ga, bg0)
+                noise = {kk: float((again[1][3][kk] - g0[kk]).abs().max()) for kk in g0 if g0[kk] is not None and again[1][3][kk] is not None}
+            assert err <= 4.0 * noise.get(k, 0.0) + 2e-3 * scale, f"grad {k}: {err} vs {scale} (run-to-run noise {noise.get(k)})"
+    if with_oracle and cfg["C"] == 1 and cfg["N"] <= 4000:
+        from oracle import oracle as orc
+        a = {k: v.numpy() for k, v in P0.items()}
+        rr, aa, m = orc.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], vm0.numpy(), K0.numpy(), W, H,
+                                      render_mode=cfg["mode"], rasterize_mode="antialiased" if cfg["aa"] else "classic",
+                                      backgrounds=None if bg0 is None else bg0.numpy())
+        assert np.array_equal(i1["radii"].cpu().numpy(), m["radii"]), "radii vs oracle"
+        assert np.array_equal(i1["flatten_ids"].cpu().numpy(), m["flatten_ids"]), "flatten_ids vs oracle"
+        ok = ~m["critical"] if "critical" in m else np.ones(rr.shape[:3], bool)
+        d = np.abs(r1.cpu().numpy() - rr).max(-1)
+        tol = 1e-4 * max(1.0, float(np.abs(rr).max()))
+        assert (d[ok] <= tol).all(), f"render vs oracle: {d[ok].max()}"
+
+
+def check_neighbours(rng):
+    N = int(rng.choice([1, 63, 64, 65, 777, 4099]))
+    K = int(rng.choice([16, 16, 9, 4]))
+    model_deg = {16: 3, 9: 2, 4: 1}[K]
+    n = int(rng.integers(0, model_deg + 1))
+    T = int(rng.choice([0, 0, 2, 5]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    P = {"means": torch.randn(N, 3, generator=g) * 4, "scales": torch.randn(N, 3, generator=g) - 1, "quats": torch.randn(N, 4, generator=g),
+         "opacities": torch.randn(N, 1, generator=g), "features_dc": torch.randn(N, 3, generator=g)}
+    P["features_rest"] = torch.randn(*((N, T, K - 1, 3) if T else (N, K - 1, 3)), generator=g) * 0.3
+    if T:
+        P["features_adapters"] = torch.randn(N, T, 3, generator=g) * 0.2
+    t = int(rng.integers(0, T)) if T else None
+    c2w = torch.eye(4)[None, :3].clone(); c2w[0, :, 3] = torch.randn(3, generator=g)
+    cot = {"scales": torch.randn(N, 3, generator=g), "quats": torch.randn(N, 4, generator=g), "opacities": torch.randn(N, generator=g),
+           "rgbs": torch.randn(N, 3, generator=g)}
+    from mtgs_amd import spherical_harmonics
+    out = []
+    for fused in (True, False):
+        D = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
+        if fused:
+            o = node_gaussians(D["means"], D["scales"], D["quats"], D["opacities"], D["features_dc"], D["features_rest"], c2w.to(dev), n,
+                               model_deg, features_dc_add=D.get("features_adapters"), traversal_index=t)
+        else:
+            dc = D["features_dc"] + D["features_adapters"][:, t] if T else D["features_dc"]
+            rest = D["features_rest"][:, t] if T else D["features_rest"]
+            col = torch.cat((dc[:, None], rest), 1)
+            vd = D["means"].detach() - c2w.to(dev)[..., :3, 3]
+            vd = vd / vd.norm(dim=-1, keepdim=True)
+            o = {"scales": torch.exp(D["scales"]), "quats": D["quats"] / D["quats"].norm(dim=-1, keepdim=True),
+                 "opacities": torch.sigmoid(D["opacities"]).squeeze(-1),
+                 "rgbs": torch.clamp(spherical_harmonics(n, vd, col) + 0.5, 0.0, 1.0)}
+        sum((o[k] * cot[k].to(dev)).sum() for k in cot).backward()
+        out.append(({k: o[k].detach() for k in cot}, {k: D[k].grad for k in D if k != "means"}))
+    for k in cot:
+        assert torch.allclose(out[0][0][k], out[1][0][k], rtol=1e-5, atol=2e-6), f"node {k} (N={N} K={K} n={n} T={T})"
+    for k in out[1][1]:
+        s = float(out[1][1][k].abs().max())
+        assert float((out[0][1][k] - out[1][1][k]).abs().max()) <= 2e-5 * s + 1e-7, f"node grad {k} (N={N} K={K} n={n} T={T})"
+    # loss head
+    H, W = int(rng.integers(11, 200)), int(rng.integers(11, 260))
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    pred0 = torch.rand(H, W, 3, generator=g)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.3).to(dev)
+    mask[H // 2, W // 2] = True
+    from oracle import ssim_oracle
+    vref, gref = ssim_oracle.masked_ssim(gt.cpu().numpy(), pred0.numpy(), mask.cpu().numpy(), with_grad=True)
+    p = pred0.to(dev).requires_grad_(True)
+    v = masked_ssim(gt, p, mask); v.backward()
+    assert abs(float(v.detach()) - vref) <= 1e-5 and np.abs(p.grad.cpu().numpy() - gref).max() <= 5e-5 * np.abs(gref).max() + 1e-9, f"ssim {H}x{W}"
+    p2 = pred0.to(dev).requires_grad_(True)
+    l = masked_l1(gt, p2, mask); l.backward()
+    pr = pred0.to(dev).double().requires_grad_(True)
+    lr = torch.abs(gt.double() - pr)[mask.squeeze(-1)].mean(); lr.backward()
+    assert abs(float(l.detach()) - float(lr.detach())) <= 2e-6 and torch.allclose(p2.grad.double(), pr.grad, rtol=1e-5, atol=1e-12), f"l1 {H}x{W}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    for i in range(args.cases):
+        cfg = rand_case(rng)
+        try:
+            check_raster(cfg, with_oracle=(i % 5 == 0))
+            if i % 3 == 0:
+                check_neighbours(rng)
+        except Exception as e:  # noqa: BLE001
+            print(f"FAIL case {i}: {cfg}\n  {type(e).__name__}: {e}")
+            raise
+    print(f"fuzz ok: {args.cases} rasterization cases, {(args.cases + 2) // 3} neighbour cases")
+
+
+if __name__ == "__main__":
+    main()
