@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential test on the GPU (development / pre-release check, ~2 minutes):
+"""Randomised differential test on the GPU (test infrastructure: lives under tests/ because it uses the oracle as the
+checker; run directly, `python tests/fuzz_gpu.py --cases 500 --seed 3`, or through tests/test_gpu_fused.py):
   * rasterization() (one autograd node, compact gradient rows) vs the operator-by-operator composition of the same
     kernels, forward bit-for-bit and gradients to fp32-atomic accuracy, over random sizes / cameras / channel counts /
     render modes, including degenerate inputs (nothing visible, one Gaussian, huge splats, image smaller than a tile);
@@ -15,7 +16,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
 from mtgs_amd import rasterization, wrapper  # noqa: E402
 from mtgs_amd.densify import update_statistics  # noqa: E402
 from mtgs_amd.loss import masked_l1, masked_ssim  # noqa: E402

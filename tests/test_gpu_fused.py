@@ -119,13 +119,13 @@ def test_fused_no_visible_gaussians(hip_lib):
 
 
 def test_randomised_differential_check(hip_lib):
-    """scripts/fuzz_gpu.py: 60 random configurations (sizes down to one Gaussian / images smaller than a tile, 1-2
+    """tests/fuzz_gpu.py: 60 random configurations (sizes down to one Gaussian / images smaller than a tile, 1-2
     cameras, 1-16 channels, all render modes, nothing visible) -- fused node vs composition vs oracle, and the neighbour
     kernels vs their PyTorch formulations."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "scripts" / "fuzz_gpu.py"), "--cases", "60", "--seed", "123"],
+    r = subprocess.run([sys.executable, str(root / "tests" / "fuzz_gpu.py"), "--cases", "60", "--seed", "123"],
                        capture_output=True, text=True, timeout=900, cwd=str(root))
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
