@@ -73,10 +73,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sparse_exchange_equals_dense_allreduce(tmp_path, hip_lib):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sparse_exchange_equals_dense_allreduce(tmp_path, hip_lib, world):
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         a = np.load(tmp_path / f"r{r}.npy")
