@@ -60,10 +60,10 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
     mtgs_amd.nodes.node_gaussians and concatenated in order (MTGSSceneModel.get_gaussians,
     mtgs_scene_graph.py:408-461).  Multi-colour nodes need `traversal_index` (get_pertravel_features,
     multi_color_gaussian_splatting.py:77-86; None = the shared colour only, as eval_mode 'null')."""
-    from .nodes import node_gaussians
-    out = {k: [] for k in ("means", "scales", "quats", "opacities", "rgbs", "model_id")}
+    from .nodes import collect_gaussians as _collect
     names = list(nodes.keys()) if node_names is None else list(node_names)
-    for mid, name in enumerate(names):
+    specs = []
+    for name in names:
         p = {k: v.to(device) for k, v in nodes[name].items()}
         kind = node_kind(p)
         if kind == "dynamic":
@@ -71,18 +71,15 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
                                       f"({sorted(k for k in p if k not in GAUSS_PARAM_NAMES)[:3]}...); only vanilla and "
                                       "multi-colour nodes are supported")
         if p["scales"].shape[-1] == 1:   # isotropic nodes store one log-scale (vanilla_gaussian_splatting.py:185-196)
-            p["scales"] = p["scales"].expand(-1, 3)
+            p["scales"] = p["scales"].expand(-1, 3).contiguous()
         if "quats" not in p:
-            p["quats"] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device).expand(p["means"].shape[0], 4)
-        dc, rest, add = p["features_dc"], p["features_rest"], None
+            p["quats"] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device).expand(p["means"].shape[0], 4).contiguous()
         if kind == "multicolor":
-            if rest.dim() == 4:          # multi_feature_rest: [N, T, K-1, 3]
-                rest = rest[:, traversal_index] if traversal_index is not None else torch.zeros_like(rest[:, 0])
-            if traversal_index is not None:
-                add = p["features_adapters"][:, traversal_index]
-        g = node_gaussians(p["means"], p["scales"].contiguous(), p["quats"].contiguous(), p["opacities"], dc, rest,
-                           camera_to_worlds.to(device), sh_degree_to_use, model_sh_degree, features_dc_add=add)
-        for k in ("means", "scales", "quats", "opacities", "rgbs"):
-            out[k].append(g[k])
-        out["model_id"].append(torch.full((p["means"].shape[0],), mid, device=device))
-    return {k: torch.cat(v, dim=0) for k, v in out.items()}
+            if traversal_index is None:   # eval_mode "null": the shared colour only (multi_color_gaussian_splatting.py:84-86)
+                p.pop("features_adapters")
+                if p["features_rest"].dim() == 4:
+                    p["features_rest"] = torch.zeros_like(p["features_rest"][:, 0])
+            else:
+                p["traversal_index"] = traversal_index
+        specs.append(p)
+    return _collect(specs, camera_to_worlds.to(device), sh_degree_to_use, model_sh_degree)

@@ -62,16 +62,8 @@ def gaussians_chain(P, c2w, t, n):
 
 
 def gaussians_fused(P, c2w, t, n):
-    out = {"means": [], "scales": [], "quats": [], "opacities": [], "rgbs": []}
-    for name, p in P.items():
-        if "features_adapters" in p:
-            g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"],
-                               c2w, n, 3, features_dc_add=p["features_adapters"], traversal_index=t)
-        else:
-            g = node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, n, 3)
-        for k in out:
-            out[k].append(g[k])
-    return {k: torch.cat(v, 0) for k, v in out.items()}
+    from mtgs_amd.nodes import collect_gaussians
+    return collect_gaussians([dict(p, traversal_index=t) if "features_adapters" in p else p for p in P.values()], c2w, n, 3)
 
 
 def _win(dev):

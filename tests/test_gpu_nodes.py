@@ -111,3 +111,40 @@ def test_node_rgbs_golden_reference_helpers(hip_lib):
                          torch.zeros(N, 15, 3, device=dev), torch.eye(4, device=dev)[None, :3], 3, 3)
     assert float((out["rgbs"].cpu() - rgb.clamp(0, 1)).abs().max()) <= 2e-6
     assert float((out["scales"] - 1.0).abs().max()) == 0.0 and float((out["opacities"] - 0.5).abs().max()) == 0.0
+
+
+def test_collect_gaussians_equals_per_node_concatenation(hip_lib):
+    """mtgs_amd.nodes.collect_gaussians (one autograd node, kernels write into slices) == node_gaussians per node +
+    torch.cat, as MTGSSceneModel.get_gaussians concatenates (mtgs_scene_graph.py:408-461)."""
+    from mtgs_amd.nodes import collect_gaussians, node_gaussians
+    dev = torch.device("cuda")
+    c2w = torch.eye(4)[None, :3].clone().to(dev)
+    c2w[0, :3, 3] = torch.tensor([0.4, -1.1, 2.3])
+    base = [_params(1500, 16, 3, 1), _params(64, 16, 0, 2), _params(1, 16, 0, 3), _params(777, 16, 4, 4)]
+    travs = [1, None, None, 3]
+    g = torch.Generator().manual_seed(8)
+    total = sum(p["means"].shape[0] for p in base)
+    cot = {"means": torch.randn(total, 3, generator=g), "scales": torch.randn(total, 3, generator=g),
+           "quats": torch.randn(total, 4, generator=g), "opacities": torch.randn(total, generator=g),
+           "rgbs": torch.randn(total, 3, generator=g)}
+    res = []
+    for collected in (True, False):
+        P = [{k: v.to(dev).requires_grad_(True) for k, v in p.items()} for p in base]
+        P[2]["scales"].requires_grad_(False)                     # a frozen parameter
+        if collected:
+            out = collect_gaussians([dict(p, traversal_index=t) if t is not None else p for p, t in zip(P, travs)], c2w, 2, 3)
+        else:
+            parts = [node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, 2, 3,
+                                    features_dc_add=p.get("features_adapters"), traversal_index=t) for p, t in zip(P, travs)]
+            out = {k: torch.cat([q[k] for q in parts], 0) for k in cot}
+        sum((out[k] * cot[k].to(dev)).sum() for k in cot).backward()
+        res.append(({k: out[k].detach() for k in cot}, [{k: v.grad for k, v in p.items()} for p in P], out))
+    for k in cot:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    for ga, gb in zip(res[0][1], res[1][1]):
+        for k in ga:
+            assert (ga[k] is None) == (gb[k] is None), k
+            if ga[k] is not None:
+                assert torch.equal(ga[k], gb[k]), k
+    mid = res[0][2]["model_id"]
+    assert mid.shape == (total,) and int(mid[0]) == 0 and int(mid[-1]) == 3 and int((mid == 1).sum()) == 64
