@@ -269,18 +269,25 @@ int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, cons
  * n_traversals > 0 (multi-colour nodes): the coefficients were slice `traversal` of per-traversal parameters
  * [N,T,K_rest,3] / [N,T,3]; the backward then writes the gradients of the FULL tensors -- g_features_rest[N,T,K_rest,3]
  * and g_features_dc_add[N,T,3] (nullable): values in slice `traversal`, zeros elsewhere -- in the same pass, instead
- * of the zero-fill + strided slice copy autograd performs for an indexed view. */
+ * of the zero-fill + strided slice copy autograd performs for an indexed view.
+ * Rigid nodes (rigid_node.py:205-216, shipped configs have fourier_features_dim = None): pose[7] (DEVICE, nullable) =
+ * instance quaternion wxyz | translation; global mean = quat_to_rotmat(q) m + t (utils.py:14-41, q is NOT normalised
+ * there), global quaternion = quat_mult(q, q_local / |q_local|) (utils.py:60-70), view directions from the global
+ * mean.  means_out[N,3] (nullable) receives the (global) means.  bwd: v_means[N,3] (nullable) is the gradient that
+ * reached the global means, g_means[N,3] (nullable) = R^T v_means (v_means without pose), g_pose[7] (nullable) is
+ * ACCUMULATED with atomics (zero it first): d quaternion from both the rotation and the quaternion product, d t. */
 int mtgs_node_fwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *scales_raw,
                   const float *quats_raw, const float *opacities_raw, const float *features_dc,
                   const float *features_dc_add, const float *features_rest, const int64_t *row_strides,
                   const float *cam_pos, float *scales, float *quats, float *opacities, float *rgbs,
-                  uint8_t *clamp_mask, void *stream);
+                  uint8_t *clamp_mask, const float *pose, float *means_out, void *stream);
 int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *means, const float *quats_raw,
                   const float *cam_pos, const float *scales, const float *opacities, const float *rgbs,
                   const uint8_t *clamp_mask, const float *v_scales, const float *v_quats, const float *v_opacities,
                   const float *v_rgbs, float *g_scales_raw, float *g_quats_raw, float *g_opacities_raw,
                   float *g_features_dc, float *g_features_rest, float *g_features_dc_add, int n_traversals,
-                  int traversal, void *stream);
+                  int traversal, const float *pose, const float *v_means, float *g_means, float *g_pose,
+                  void *stream);
 
 /* ---- densification statistics of one node in one launch ------------------------------
  * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous

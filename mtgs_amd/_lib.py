@@ -48,9 +48,10 @@ _SIGNATURES = {
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_dp_reduce": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "mtgs_node_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_node_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                      _vp, _vp],
     "mtgs_node_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                      _vp, _vp, _i32, _i32, _vp],
+                      _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_ssim_workspace_floats": [_i32, _i32, C.POINTER(_sz)],
     "mtgs_ssim_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],

@@ -45,7 +45,22 @@ struct NodeParams {
     const float *cam_pos;                                    // [3] device
     int Kr;                                                  // SH bases in `rest` (K - 1)
     int use_sh;                                              // 0: rgbs = sigmoid(dc [+ dc_add])
+    const float *pose;                                       // [7] device: instance quaternion wxyz | translation; nullable
 };
+
+// Rigid nodes (rigid_node.py:205-216): global mean = R(q) m + t with mtgs utils.quat_to_rotmat (NO normalisation of q:
+// get_object_pose hands over a unit quaternion), global quaternion = utils.quat_mult(q, q_local / |q_local|).
+struct Pose { float w, x, y, z, tx, ty, tz; float R[9]; };
+__device__ __forceinline__ Pose load_pose(const float *p) {
+    Pose o;
+    o.w = p[0]; o.x = p[1]; o.y = p[2]; o.z = p[3]; o.tx = p[4]; o.ty = p[5]; o.tz = p[6];
+    const float xx = o.x * o.x, yy = o.y * o.y, zz = o.z * o.z, xy = o.x * o.y, xz = o.x * o.z, yz = o.y * o.z;
+    const float wx = o.w * o.x, wy = o.w * o.y, wz = o.w * o.z;
+    o.R[0] = 1.f - 2.f * (yy + zz); o.R[1] = 2.f * (xy - wz); o.R[2] = 2.f * (xz + wy);
+    o.R[3] = 2.f * (xy + wz); o.R[4] = 1.f - 2.f * (xx + zz); o.R[5] = 2.f * (yz - wx);
+    o.R[6] = 2.f * (xz - wy); o.R[7] = 2.f * (yz + wx); o.R[8] = 1.f - 2.f * (xx + yy);
+    return o;
+}
 
 // A wave owns 64 consecutive Gaussians and uses TWO lane mappings:
 //   * lane-per-Gaussian for the small activations and for everything that is 3..4 floats per Gaussian
@@ -62,7 +77,8 @@ struct F4 { float x, y, z, w; };
 template <int DEG>
 __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const NodeParams P, float *__restrict__ scales,
                                                               float *__restrict__ quats, float *__restrict__ opacities,
-                                                              float *__restrict__ rgbs, uint8_t *__restrict__ clamp_mask) {
+                                                              float *__restrict__ rgbs, uint8_t *__restrict__ clamp_mask,
+                                                              float *__restrict__ means_out) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
@@ -83,8 +99,14 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
     }
     // unit view direction, once per Gaussian in the lane-per-Gaussian mapping (the rows fetch it by ds_bpermute)
     float dx = 0.f, dy = 0.f, dz = 1.f;
-    if (P.use_sh && okl) {
-        const F3 mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
+    Pose ps;
+    if (P.pose) ps = load_pose(P.pose);
+    if ((P.use_sh || P.pose || means_out) && okl) {
+        F3 mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
+        if (P.pose)   // rigid node: the Gaussian lives in the object frame
+            mn = F3{(ps.R[0] * mn.x + ps.R[1] * mn.y) + ps.R[2] * mn.z + ps.tx, (ps.R[3] * mn.x + ps.R[4] * mn.y) + ps.R[5] * mn.z + ps.ty,
+                    (ps.R[6] * mn.x + ps.R[7] * mn.y) + ps.R[8] * mn.z + ps.tz};
+        if (means_out) *reinterpret_cast<F3 *>(means_out + gl * 3) = mn;
         dx = mn.x - camx; dy = mn.y - camy; dz = mn.z - camz;
         const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
         dx *= inorm; dy *= inorm; dz *= inorm;
@@ -145,7 +167,13 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
     *reinterpret_cast<F3 *>(rgbs + gl * 3) = rgb;
     *reinterpret_cast<F3 *>(scales + gl * 3) = F3{expf(sr.x), expf(sr.y), expf(sr.z)};
     const float qinv = 1.0f / sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
-    *reinterpret_cast<F4 *>(quats + gl * 4) = F4{qr.x * qinv, qr.y * qinv, qr.z * qinv, qr.w * qinv};
+    F4 qn = F4{qr.x * qinv, qr.y * qinv, qr.z * qinv, qr.w * qinv};   // (w, x, y, z)
+    if (P.pose) {   // utils.quat_mult(q_instance, q_local)
+        const float w2 = qn.x, x2 = qn.y, y2 = qn.z, z2 = qn.w;
+        qn = F4{((ps.w * w2 - ps.x * x2) - ps.y * y2) - ps.z * z2, ((ps.w * x2 + ps.x * w2) + ps.y * z2) - ps.z * y2,
+                ((ps.w * y2 - ps.x * z2) + ps.y * w2) + ps.z * x2, ((ps.w * z2 + ps.x * y2) - ps.y * x2) + ps.z * w2};
+    }
+    *reinterpret_cast<F4 *>(quats + gl * 4) = qn;
     opacities[gl] = 1.f / (1.f + expf(-orw));
 }
 
@@ -160,7 +188,9 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
                                                               const float *__restrict__ v_rgbs, float *__restrict__ g_scales_raw,
                                                               float *__restrict__ g_quats_raw, float *__restrict__ g_opac_raw,
                                                               float *__restrict__ g_dc, float *__restrict__ g_rest,
-                                                              float *__restrict__ g_dc_add, int n_trav, int trav) {
+                                                              float *__restrict__ g_dc_add, int n_trav, int trav,
+                                                              const float *__restrict__ v_means, float *__restrict__ g_means,
+                                                              float *__restrict__ g_pose) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
@@ -171,26 +201,72 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
     const int64_t gl = g0 + lane;
     const bool okl = gl < N;
     F3 v = F3{0.f, 0.f, 0.f}, mn = F3{0.f, 0.f, 1.f};
+    Pose ps;
+    if (P.pose) ps = load_pose(P.pose);
+    float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f, pq3 = 0.f, pt0 = 0.f, pt1 = 0.f, pt2 = 0.f;   // this Gaussian's part of d pose
     if (okl) {
         v = *reinterpret_cast<const F3 *>(v_rgbs + gl * 3);
         if (P.use_sh) {
             const unsigned mk = clamp_mask[gl];
             v.x = (mk & 1u) ? v.x : 0.f; v.y = (mk & 2u) ? v.y : 0.f; v.z = (mk & 4u) ? v.z : 0.f;
-            mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
         } else {
             const F3 y = *reinterpret_cast<const F3 *>(rgbs + gl * 3);
             v.x *= y.x * (1.f - y.x); v.y *= y.y * (1.f - y.y); v.z *= y.z * (1.f - y.z);
         }
+        if (P.use_sh || P.pose) {
+            const F3 ml = *reinterpret_cast<const F3 *>(P.means + gl * 3);
+            mn = ml;
+            if (P.pose)
+                mn = F3{(ps.R[0] * ml.x + ps.R[1] * ml.y) + ps.R[2] * ml.z + ps.tx, (ps.R[3] * ml.x + ps.R[4] * ml.y) + ps.R[5] * ml.z + ps.ty,
+                        (ps.R[6] * ml.x + ps.R[7] * ml.y) + ps.R[8] * ml.z + ps.tz};
+            if (g_means || (P.pose && g_pose)) {
+                const F3 vm = v_means ? *reinterpret_cast<const F3 *>(v_means + gl * 3) : F3{0.f, 0.f, 0.f};
+                if (P.pose) {
+                    // m_g = R m + t:  d m = R^T v,  d t = v,  d R[i][j] = v_i m_j  contracted with d R / d q (quat_to_rotmat)
+                    if (g_means)
+                        *reinterpret_cast<F3 *>(g_means + gl * 3) =
+                            F3{(ps.R[0] * vm.x + ps.R[3] * vm.y) + ps.R[6] * vm.z, (ps.R[1] * vm.x + ps.R[4] * vm.y) + ps.R[7] * vm.z,
+                               (ps.R[2] * vm.x + ps.R[5] * vm.y) + ps.R[8] * vm.z};
+                    pt0 = vm.x; pt1 = vm.y; pt2 = vm.z;
+                    const float r00 = vm.x * ml.x, r01 = vm.x * ml.y, r02 = vm.x * ml.z, r10 = vm.y * ml.x, r11 = vm.y * ml.y,
+                                r12 = vm.y * ml.z, r20 = vm.z * ml.x, r21 = vm.z * ml.y, r22 = vm.z * ml.z;
+                    pq0 = 2.f * (((-ps.z * r01 + ps.y * r02) + (ps.z * r10 - ps.x * r12)) + (-ps.y * r20 + ps.x * r21));
+                    pq1 = 2.f * ((((ps.y * r01 + ps.z * r02) + ps.y * r10) - 2.f * ps.x * r11 - ps.w * r12) + ((ps.z * r20 + ps.w * r21) - 2.f * ps.x * r22));
+                    pq2 = 2.f * ((((-2.f * ps.y * r00 + ps.x * r01) + ps.w * r02) + (ps.x * r10 + ps.z * r12)) + ((-ps.w * r20 + ps.z * r21) - 2.f * ps.y * r22));
+                    pq3 = 2.f * ((((-2.f * ps.z * r00 - ps.w * r01) + ps.x * r02) + ((ps.w * r10 - 2.f * ps.z * r11) + ps.y * r12)) + (ps.x * r20 + ps.y * r21));
+                } else if (g_means) {
+                    *reinterpret_cast<F3 *>(g_means + gl * 3) = vm;
+                }
+            }
+        }
         const F3 s = *reinterpret_cast<const F3 *>(scales + gl * 3), vs = *reinterpret_cast<const F3 *>(v_scales + gl * 3);
         *reinterpret_cast<F3 *>(g_scales_raw + gl * 3) = F3{vs.x * s.x, vs.y * s.y, vs.z * s.z};  // d exp = exp
-        const F4 q = *reinterpret_cast<const F4 *>(P.quats_raw + gl * 4), vq = *reinterpret_cast<const F4 *>(v_quats + gl * 4);
+        const F4 q = *reinterpret_cast<const F4 *>(P.quats_raw + gl * 4);
+        F4 vq = *reinterpret_cast<const F4 *>(v_quats + gl * 4);
         const float qinv = 1.0f / sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
         const F4 qn = F4{q.x * qinv, q.y * qinv, q.z * qinv, q.w * qinv};
+        if (P.pose) {   // VJP of utils.quat_mult(q_instance, qn) with respect to both factors
+            const float vw = vq.x, vx = vq.y, vy = vq.z, vz = vq.w, w2 = qn.x, x2 = qn.y, y2 = qn.z, z2 = qn.w;
+            pq0 += ((vw * w2 + vx * x2) + vy * y2) + vz * z2;
+            pq1 += ((-vw * x2 + vx * w2) - vy * z2) + vz * y2;
+            pq2 += ((-vw * y2 + vx * z2) + vy * w2) - vz * x2;
+            pq3 += ((-vw * z2 - vx * y2) + vy * x2) + vz * w2;
+            vq = F4{((vw * ps.w + vx * ps.x) + vy * ps.y) + vz * ps.z, ((-vw * ps.x + vx * ps.w) + vy * ps.z) - vz * ps.y,
+                    ((-vw * ps.y - vx * ps.z) + vy * ps.w) + vz * ps.x, ((-vw * ps.z + vx * ps.y) - vy * ps.x) + vz * ps.w};
+        }
         const float dot = ((vq.x * qn.x + vq.y * qn.y) + vq.z * qn.z) + vq.w * qn.w;                // d (q / |q|)
         *reinterpret_cast<F4 *>(g_quats_raw + gl * 4) =
             F4{(vq.x - dot * qn.x) * qinv, (vq.y - dot * qn.y) * qinv, (vq.z - dot * qn.z) * qinv, (vq.w - dot * qn.w) * qinv};
         const float o = opacities[gl];
         g_opac_raw[gl] = v_opacities[gl] * o * (1.f - o);                                           // d sigmoid
+    }
+    if (P.pose && g_pose) {   // every lane takes part (zeros outside the node): one atomic per wave and component
+        const float t0 = wave_sum_to_lane63(pq0), t1 = wave_sum_to_lane63(pq1), t2 = wave_sum_to_lane63(pq2), t3 = wave_sum_to_lane63(pq3);
+        const float t4 = wave_sum_to_lane63(pt0), t5 = wave_sum_to_lane63(pt1), t6 = wave_sum_to_lane63(pt2);
+        if (lane == 63) {
+            atomicAdd(g_pose + 0, t0); atomicAdd(g_pose + 1, t1); atomicAdd(g_pose + 2, t2); atomicAdd(g_pose + 3, t3);
+            atomicAdd(g_pose + 4, t4); atomicAdd(g_pose + 5, t5); atomicAdd(g_pose + 6, t6);
+        }
     }
     // the basis needs the unit view direction: computed once per Gaussian here, moved to the rows below
     float dx = mn.x - camx, dy = mn.y - camy, dz = mn.z - camz;
@@ -279,17 +355,17 @@ extern "C" int mtgs_node_fwd(int64_t N, int K_rest, int degree, int use_sh, cons
                              const float *quats_raw, const float *opacities_raw, const float *features_dc,
                              const float *features_dc_add, const float *features_rest, const int64_t *row_strides,
                              const float *cam_pos, float *scales, float *quats, float *opacities, float *rgbs,
-                             uint8_t *clamp_mask, void *stream) {
+                             uint8_t *clamp_mask, const float *pose, float *means_out, void *stream) {
     if (int rc = node_check("mtgs_node_fwd", N, K_rest, degree, use_sh, row_strides)) return rc;
     if (N == 0) return MTGS_OK;
     MTGS_REQUIRE(means && scales_raw && quats_raw && opacities_raw && features_dc && (features_rest || K_rest == 0) && cam_pos &&
                      scales && quats && opacities && rgbs && clamp_mask,
                  MTGS_EINVAL, "mtgs_node_fwd: null pointer");
     const NodeParams P{means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest,
-                       row_strides[0], row_strides[1], row_strides[2], cam_pos, K_rest, use_sh};
+                       row_strides[0], row_strides[1], row_strides[2], cam_pos, K_rest, use_sh, pose};
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
-    MTGS_NODE_DISPATCH(node_fwd_kernel, N, P, scales, quats, opacities, rgbs, clamp_mask)
+    MTGS_NODE_DISPATCH(node_fwd_kernel, N, P, scales, quats, opacities, rgbs, clamp_mask, means_out)
     MTGS_CHECK_LAUNCH("mtgs_node_fwd");
     return MTGS_OK;
 }
@@ -299,7 +375,8 @@ extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, cons
                              const uint8_t *clamp_mask, const float *v_scales, const float *v_quats,
                              const float *v_opacities, const float *v_rgbs, float *g_scales_raw, float *g_quats_raw,
                              float *g_opacities_raw, float *g_features_dc, float *g_features_rest,
-                             float *g_features_dc_add, int n_traversals, int traversal, void *stream) {
+                             float *g_features_dc_add, int n_traversals, int traversal, const float *pose,
+                             const float *v_means, float *g_means, float *g_pose, void *stream) {
     const int64_t strides[3] = {3, 3, (int64_t)K_rest * 3};
     if (int rc = node_check("mtgs_node_bwd", N, K_rest, degree, use_sh, strides)) return rc;
     if (N == 0) return MTGS_OK;
@@ -309,12 +386,12 @@ extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, cons
                  MTGS_EINVAL, "mtgs_node_bwd: null pointer");
     MTGS_REQUIRE(n_traversals >= 0 && (n_traversals == 0 || (traversal >= 0 && traversal < n_traversals)), MTGS_EINVAL,
                  "mtgs_node_bwd: traversal %d of %d", traversal, n_traversals);
-    const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh};
+    const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh, pose};
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
     MTGS_NODE_DISPATCH(node_bwd_kernel, N, P, scales, opacities, rgbs, clamp_mask, v_scales, v_quats, v_opacities, v_rgbs,
                        g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc, g_features_rest, g_features_dc_add, n_traversals,
-                       traversal)
+                       traversal, v_means, g_means, g_pose)
     MTGS_CHECK_LAUNCH("mtgs_node_bwd");
     return MTGS_OK;
 }

@@ -36,8 +36,9 @@ def _rows(t: Optional[Tensor], width: int):
 
 
 def _launch_fwd(means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam, degree, use_sh,
-                trav, scales, quats, opacities, rgbs, mask):
-    """One mtgs_node_fwd launch into the given (contiguous) output tensors.  Returns what the backward needs."""
+                trav, scales, quats, opacities, rgbs, mask, pose=None, means_out=None):
+    """One mtgs_node_fwd launch into the given (contiguous) output tensors.  Returns what the backward needs.
+    pose: float32[7] (instance quaternion wxyz | translation) of a rigid node, or None; means_out: [N,3] or None."""
     N = means.shape[0]
     Kr = features_rest.shape[-2]
     T = features_rest.shape[1] if trav >= 0 else 0
@@ -51,12 +52,14 @@ def _launch_fwd(means, scales_raw, quats_raw, opacities_raw, features_dc, featur
     rest, s_rest = _rows(features_rest, Kr * 3)
     call("mtgs_node_fwd", N, Kr, int(degree), int(use_sh), ptr(means_c), ptr(scales_c), ptr(quats_c), ptr(opac_c), ptr(dc),
          ptr(dca), ptr(rest), host_i64([s_dc, s_dca, s_rest]), ptr(cam), ptr(scales), ptr(quats), ptr(opacities),
-         ptr(rgbs), ptr(mask), stream_of(means))
+         ptr(rgbs), ptr(mask), ptr(pose), ptr(means_out), stream_of(means))
     return means_c, quats_c, (N, Kr, int(degree), int(use_sh), opacities_raw.shape, features_dc_add is not None, T, int(trav))
 
 
-def _launch_bwd(means_c, quats_c, cam, scales, opacities, rgbs, mask, dims, v_scales, v_quats, v_opacities, v_rgbs):
-    """One mtgs_node_bwd launch.  Returns (g_scales, g_quats, g_opacities, g_dc, g_dc_add, g_rest)."""
+def _launch_bwd(means_c, quats_c, cam, scales, opacities, rgbs, mask, dims, v_scales, v_quats, v_opacities, v_rgbs, pose=None,
+                v_means=None, want_means=False):
+    """One mtgs_node_bwd launch.  Returns (g_scales, g_quats, g_opacities, g_dc, g_dc_add, g_rest, g_means, g_pose);
+    g_means / g_pose are None unless a rigid node's pose is given (g_means then = R^T v_means, g_pose float32[7])."""
     N, Kr, degree, use_sh, opac_shape, has_add, T, trav = dims
     dev = means_c.device
     z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous())
@@ -72,40 +75,59 @@ def _launch_bwd(means_c, quats_c, cam, scales, opacities, rgbs, mask, dims, v_sc
     else:
         g_rest = torch.empty((N, Kr, 3), dtype=torch.float32, device=dev)
         g_add = None
+    g_means = g_pose = v_means_c = None
+    if pose is not None:
+        v_means_c = None if v_means is None else v_means.to(torch.float32).contiguous()
+        g_means = torch.empty((N, 3), dtype=torch.float32, device=dev) if want_means else None
+        g_pose = torch.zeros(7, dtype=torch.float32, device=dev)   # accumulated with atomics
     call("mtgs_node_bwd", N, Kr, degree, use_sh, ptr(means_c), ptr(quats_c), ptr(cam), ptr(scales), ptr(opacities),
          ptr(rgbs), ptr(mask), ptr(v_scales), ptr(v_quats), ptr(v_opacities), ptr(v_rgbs), ptr(g_scales), ptr(g_quats),
-         ptr(g_opac), ptr(g_dc), ptr(g_rest), ptr(g_add), T, max(trav, 0), stream_of(means_c))
+         ptr(g_opac), ptr(g_dc), ptr(g_rest), ptr(g_add), T, max(trav, 0), ptr(pose), ptr(v_means_c), ptr(g_means), ptr(g_pose),
+         stream_of(means_c))
     if not T:
         g_add = g_dc if has_add else None
-    return g_scales, g_quats, g_opac.reshape(opac_shape), g_dc, g_add, g_rest
+    return g_scales, g_quats, g_opac.reshape(opac_shape), g_dc, g_add, g_rest, g_means, g_pose
 
 
 class _NodeActivations(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos,
-                degree, use_sh, trav):
-        require_gpu(means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos)
+                degree, use_sh, trav, inst_quat, inst_trans):
+        require_gpu(means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest, cam_pos, inst_quat,
+                    inst_trans)
         N, dev = means.shape[0], means.device
         cam = cam_pos.detach().reshape(3).to(torch.float32).contiguous()
+        pose = None if inst_quat is None else torch.cat([inst_quat.detach().reshape(4), inst_trans.detach().reshape(3)]).to(torch.float32)
         scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
         quats = torch.empty((N, 4), dtype=torch.float32, device=dev)
         opacities = torch.empty((N,), dtype=torch.float32, device=dev)
         rgbs = torch.empty((N, 3), dtype=torch.float32, device=dev)
         mask = torch.empty((N,), dtype=torch.uint8, device=dev)
+        means_g = torch.empty((N, 3), dtype=torch.float32, device=dev) if pose is not None else None
         means_c, quats_c, ctx.dims = _launch_fwd(means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add,
-                                                 features_rest, cam, degree, use_sh, trav, scales, quats, opacities, rgbs, mask)
-        ctx.save_for_backward(means_c, quats_c, cam, scales, opacities, rgbs, mask)
-        return scales, quats, opacities, rgbs
+                                                 features_rest, cam, degree, use_sh, trav, scales, quats, opacities, rgbs, mask,
+                                                 pose, means_g)
+        ctx.save_for_backward(means_c, quats_c, cam, scales, opacities, rgbs, mask, pose)
+        if means_g is None:   # static node: the means pass through unchanged (returned by the caller)
+            means_g = torch.empty(0, device=dev)
+            ctx.mark_non_differentiable(means_g)
+        return scales, quats, opacities, rgbs, means_g
 
     @staticmethod
-    def backward(ctx, v_scales, v_quats, v_opacities, v_rgbs):
-        means_c, quats_c, cam, scales, opacities, rgbs, mask = ctx.saved_tensors
-        g_scales, g_quats, g_opac, g_dc, g_add, g_rest = _launch_bwd(means_c, quats_c, cam, scales, opacities, rgbs, mask,
-                                                                    ctx.dims, v_scales, v_quats, v_opacities, v_rgbs)
-        return (None, g_scales, g_quats, g_opac, g_dc, g_add, g_rest, None, None, None, None)
+    def backward(ctx, v_scales, v_quats, v_opacities, v_rgbs, v_means_g):
+        means_c, quats_c, cam, scales, opacities, rgbs, mask, pose = ctx.saved_tensors
+        g_scales, g_quats, g_opac, g_dc, g_add, g_rest, g_means, g_pose = _launch_bwd(
+            means_c, quats_c, cam, scales, opacities, rgbs, mask, ctx.dims, v_scales, v_quats, v_opacities, v_rgbs, pose, v_means_g,
+            want_means=ctx.needs_input_grad[0])
+        g_q = g_t = None
+        if g_pose is not None:
+            g_q, g_t = g_pose[:4], g_pose[4:]
+        return (g_means, g_scales, g_quats, g_opac, g_dc, g_add, g_rest, None, None, None, None, g_q, g_t)
 
 
-_NODE_KEYS = ("means", "scales", "quats", "opacities", "features_dc", "features_dc_add", "features_rest")
+_NODE_KEYS = ("means", "scales", "quats", "opacities", "features_dc", "features_dc_add", "features_rest", "instance_quat",
+              "instance_trans")
+_NK = len(_NODE_KEYS)
 
 
 class _CollectNodes(torch.autograd.Function):
@@ -114,9 +136,9 @@ class _CollectNodes(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam_pos, specs, *flat):
-        # specs[i] = (degree, use_sh, trav); flat = 7 tensors (or None) per node in _NODE_KEYS order
+        # specs[i] = (degree, use_sh, trav); flat = _NK tensors (or None) per node in _NODE_KEYS order
         n_nodes = len(specs)
-        nodes = [dict(zip(_NODE_KEYS, flat[7 * i:7 * i + 7])) for i in range(n_nodes)]
+        nodes = [dict(zip(_NODE_KEYS, flat[_NK * i:_NK * i + _NK])) for i in range(n_nodes)]
         require_gpu(cam_pos, *[t for t in flat if t is not None])
         sizes = [nd["means"].shape[0] for nd in nodes]
         total, dev = sum(sizes), nodes[0]["means"].device
@@ -130,12 +152,14 @@ class _CollectNodes(torch.autograd.Function):
         saved, ctx.node_dims, start = [], [], 0
         for nd, (degree, use_sh, trav), n in zip(nodes, specs, sizes):
             sl = slice(start, start + n)
-            means[sl].copy_(nd["means"].detach())
+            pose = None
+            if nd["instance_quat"] is not None:   # rigid node: the kernel writes the GLOBAL means
+                pose = torch.cat([nd["instance_quat"].detach().reshape(4), nd["instance_trans"].detach().reshape(3)]).to(torch.float32)
             means_c, quats_c, dims = _launch_fwd(nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"],
                                                  nd["features_dc_add"], nd["features_rest"], cam, degree, use_sh, trav,
-                                                 scales[sl], quats[sl], opacities[sl], rgbs[sl], mask[sl])
-            saved += [means_c, quats_c]
-            ctx.node_dims.append((dims, start, n))
+                                                 scales[sl], quats[sl], opacities[sl], rgbs[sl], mask[sl], pose, means[sl])
+            saved += [means_c, quats_c, pose if pose is not None else cam[:0]]
+            ctx.node_dims.append((dims, start, n, pose is not None))
             start += n
         ctx.save_for_backward(cam, scales, opacities, rgbs, mask, *saved)
         return means, scales, quats, opacities, rgbs
@@ -144,15 +168,18 @@ class _CollectNodes(torch.autograd.Function):
     def backward(ctx, v_means, v_scales, v_quats, v_opacities, v_rgbs):
         cam, scales, opacities, rgbs, mask, *saved = ctx.saved_tensors
         grads = []
-        for i, (dims, start, n) in enumerate(ctx.node_dims):
+        need = ctx.needs_input_grad[2:]
+        for i, (dims, start, n, has_pose) in enumerate(ctx.node_dims):
             sl = slice(start, start + n)
             cut = lambda g: None if g is None else g[sl]
-            g_scales, g_quats, g_opac, g_dc, g_add, g_rest = _launch_bwd(
-                saved[2 * i], saved[2 * i + 1], cam, scales[sl], opacities[sl], rgbs[sl], mask[sl], dims, cut(v_scales), cut(v_quats),
-                cut(v_opacities), cut(v_rgbs))
-            g_means = None if v_means is None else v_means[sl]
-            grads += [g_means, g_scales, g_quats, g_opac, g_dc, g_add, g_rest]
-        need = ctx.needs_input_grad[2:]
+            pose = saved[3 * i + 2] if has_pose else None
+            g_scales, g_quats, g_opac, g_dc, g_add, g_rest, g_means, g_pose = _launch_bwd(
+                saved[3 * i], saved[3 * i + 1], cam, scales[sl], opacities[sl], rgbs[sl], mask[sl], dims, cut(v_scales), cut(v_quats),
+                cut(v_opacities), cut(v_rgbs), pose, cut(v_means), want_means=need[_NK * i])
+            if not has_pose:
+                g_means = None if v_means is None else v_means[sl]
+            g_q, g_t = (g_pose[:4], g_pose[4:]) if g_pose is not None else (None, None)
+            grads += [g_means, g_scales, g_quats, g_opac, g_dc, g_add, g_rest, g_q, g_t]
         return (None, None) + tuple(g if need[j] else None for j, g in enumerate(grads))
 
 
@@ -160,7 +187,8 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     """MTGSSceneModel.get_gaussians for static nodes (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:408-461): the
     activated Gaussians of every node, concatenated in order, plus `model_id`.  `nodes` is a sequence of dicts of RAW
     parameters {"means", "scales", "quats", "opacities", "features_dc", "features_rest"} with, for multi-colour nodes,
-    "features_adapters" [N,T,3], a 4-D "features_rest" [N,T,K-1,3] and "traversal_index".  One autograd node for the whole
+    "features_adapters" [N,T,3], a 4-D "features_rest" [N,T,K-1,3] and "traversal_index"; for rigid nodes the pose of the
+    current frame "instance_quat" [4] (wxyz) and "instance_trans" [3] (see node_gaussians).  One autograd node for the whole
     scene: each node's kernel writes into its slice of the collected tensors (no torch.cat of per-node outputs)."""
     specs, flat, sizes = [], [], []
     use_sh = model_sh_degree > 0
@@ -184,7 +212,9 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
             assert (sh_degree_to_use + 1) ** 2 <= Kr + 1, (sh_degree_to_use, rest.shape)
         assert nd["scales"].shape == (N, 3) and nd["quats"].shape == (N, 4) and nd["opacities"].numel() == N
         specs.append((int(sh_degree_to_use), bool(use_sh), -1 if trav is None else int(trav)))
-        flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest]
+        iq, it = nd.get("instance_quat"), nd.get("instance_trans")
+        assert (iq is None) == (it is None) and (iq is None or (iq.numel() == 4 and it.numel() == 3)), "rigid pose: quat[4] + trans[3]"
+        flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest, iq, it]
         sizes.append(N)
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
     means, scales, quats, opacities, rgbs = _CollectNodes.apply(cam_pos, tuple(specs), *flat)
@@ -198,7 +228,8 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
 
 def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, features_dc: Tensor,
                    features_rest: Tensor, camera_to_worlds: Tensor, sh_degree_to_use: int, model_sh_degree: int,
-                   features_dc_add: Optional[Tensor] = None, traversal_index: Optional[int] = None) -> Dict[str, Tensor]:
+                   features_dc_add: Optional[Tensor] = None, traversal_index: Optional[int] = None,
+                   instance_quat: Optional[Tensor] = None, instance_trans: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """The dict VanillaGaussianSplattingModel.get_gaussians(camera_to_worlds) returns, from the RAW parameters:
     means[N,3], scales[N,3] (log), quats[N,4], opacities[N,1] (logits), features_dc[N,3], features_rest[N,K-1,3];
     `sh_degree_to_use` = min(step // sh_degree_interval, sh_degree), `model_sh_degree` = the model's sh_degree
@@ -208,8 +239,15 @@ def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tens
       * pass the slices: features_rest[:, t], features_dc_add=features_adapters[:, t]  (autograd then zero-fills the
         full-size gradients and copies the slice in), or
       * pass the FULL per-traversal parameters features_rest[N,T,K-1,3], features_dc_add=features_adapters[N,T,3] and
-        traversal_index=t: slice t is read in place and the backward writes the full-size gradients in its own pass."""
+        traversal_index=t: slice t is read in place and the backward writes the full-size gradients in its own pass.
+    Rigid nodes (rigid_node.py:205-216, 283-291; fourier_features_dim = None as in the shipped configs): pass the pose
+    get_object_pose returned -- instance_quat[4] (wxyz), instance_trans[3]; "means" is then the GLOBAL mean
+    quat_to_rotmat(q) m + t, "quats" = quat_mult(q, q_local / |q_local|), the view directions use the global means, and
+    gradients flow back to the local means, the local quaternions and the pose."""
     N = means.shape[0]
+    assert (instance_quat is None) == (instance_trans is None), "instance_quat and instance_trans go together"
+    if instance_quat is not None:
+        assert instance_quat.numel() == 4 and instance_trans.numel() == 3, (instance_quat.shape, instance_trans.shape)
     if traversal_index is not None:
         assert features_rest.dim() == 4 and features_rest.shape[0] == N and features_rest.shape[3] == 3, features_rest.shape
         T = features_rest.shape[1]
@@ -222,11 +260,11 @@ def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tens
         if features_rest.shape[2] > 15 or sh_degree_to_use > 3:
             raise NotImplementedError("node_gaussians: SH degree > 3 (MTGS configs use <= 3)")
         cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
-        s, q, o, rgb = _NodeActivations.apply(means, scales, quats, opacities, features_dc,
-                                              None if features_dc_add is None else features_dc_add.contiguous(),
-                                              features_rest.contiguous(), cam_pos, int(sh_degree_to_use), bool(use_sh),
-                                              int(traversal_index))
-        return {"means": means, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}
+        s, q, o, rgb, mg = _NodeActivations.apply(means, scales, quats, opacities, features_dc,
+                                                  None if features_dc_add is None else features_dc_add.contiguous(),
+                                                  features_rest.contiguous(), cam_pos, int(sh_degree_to_use), bool(use_sh),
+                                                  int(traversal_index), instance_quat, instance_trans)
+        return {"means": means if instance_quat is None else mg, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}
     assert scales.shape == (N, 3) and quats.shape == (N, 4), (scales.shape, quats.shape)
     assert opacities.numel() == N, opacities.shape
     assert features_dc.shape == (N, 3), features_dc.shape
@@ -239,6 +277,6 @@ def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tens
     if features_rest.shape[1] > 15 or sh_degree_to_use > 3:
         raise NotImplementedError("node_gaussians: SH degree > 3 (MTGS configs use <= 3)")
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
-    s, q, o, rgb = _NodeActivations.apply(means, scales, quats, opacities, features_dc, features_dc_add, features_rest,
-                                          cam_pos, int(sh_degree_to_use), bool(use_sh), -1)
-    return {"means": means, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}
+    s, q, o, rgb, mg = _NodeActivations.apply(means, scales, quats, opacities, features_dc, features_dc_add, features_rest,
+                                              cam_pos, int(sh_degree_to_use), bool(use_sh), -1, instance_quat, instance_trans)
+    return {"means": means if instance_quat is None else mg, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}

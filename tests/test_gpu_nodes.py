@@ -148,3 +148,57 @@ def test_collect_gaussians_equals_per_node_concatenation(hip_lib):
                 assert torch.equal(ga[k], gb[k]), k
     mid = res[0][2]["model_id"]
     assert mid.shape == (total,) and int(mid[0]) == 0 and int(mid[-1]) == 3 and int((mid == 1).sum()) == 64
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_rigid_node_pose_reference_vectors(hip_lib, case):
+    """Rigid nodes: global means / quaternions and their gradients (to the local means, the local quaternions and the
+    instance pose) against vectors produced by the reference's own quat_to_rotmat / quat_mult
+    (tests/golden/rigid_ref.npz, tests/golden/make_rigid_golden.py; rigid_node.py:205-216)."""
+    import numpy as np
+    from pathlib import Path
+    from mtgs_amd.nodes import collect_gaussians, node_gaussians
+    Z = np.load(Path(__file__).parent / "golden" / "rigid_ref.npz")
+    dev = torch.device("cuda")
+    f = lambda k: torch.from_numpy(Z[f"{case}_{k}"]).float().to(dev)
+    N = Z[f"{case}_means"].shape[0]
+    for collected in (False, True):
+        means, quats, q, t = (f(k).requires_grad_(True) for k in ("means", "quats", "q", "t"))
+        z = lambda *s: torch.zeros(*s, device=dev, requires_grad=True)
+        node = {"means": means, "scales": z(N, 3), "quats": quats, "opacities": z(N, 1), "features_dc": z(N, 3),
+                "features_rest": z(N, 15, 3), "instance_quat": q, "instance_trans": t}
+        c2w = torch.eye(4, device=dev)[None, :3]
+        if collected:
+            extra = {k: v.detach().clone().requires_grad_(True) for k, v in node.items() if not k.startswith("instance")}
+            out = collect_gaussians([extra, node], c2w, 3, 3)          # a static node in front: slices, not whole tensors
+            gm, gq = out["means"][N:], out["quats"][N:]
+            assert torch.equal(out["means"][:N], extra["means"])
+        else:
+            out = node_gaussians(means, node["scales"], quats, node["opacities"], node["features_dc"], node["features_rest"], c2w,
+                                 3, 3, instance_quat=q, instance_trans=t)
+            gm, gq = out["means"], out["quats"]
+        for got, name in ((gm, "global_means"), (gq, "global_quats")):
+            ref = Z[f"{case}_{name}"]
+            assert np.abs(got.detach().cpu().numpy() - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), name
+        ((gm * f("Gm")).sum() + (gq * f("Gq")).sum()).backward()
+        for p, name in ((means, "g_means"), (quats, "g_quats"), (q, "g_q"), (t, "g_t")):
+            ref = Z[f"{case}_{name}"]
+            err = np.abs(p.grad.cpu().numpy().astype(np.float64) - ref).max()
+            assert err <= 2e-5 * max(1.0, np.abs(ref).max()), f"{name} ({'collected' if collected else 'single'}): {err}"
+
+
+def test_rigid_node_colours_use_the_global_means(hip_lib):
+    """rigid_node.py:238-251: the view directions of a rigid node come from the GLOBAL means."""
+    from mtgs_amd.nodes import node_gaussians
+    dev = torch.device("cuda")
+    P = {k: v.to(dev) for k, v in _params(3001, 16, 0, 21).items()}
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(4, generator=g); q = (q / q.norm()).to(dev)
+    t = (torch.randn(3, generator=g) * 4).to(dev)
+    c2w = torch.eye(4, device=dev)[None, :3].clone(); c2w[0, :, 3] = torch.tensor([1.0, -2.0, 0.5], device=dev)
+    rigid = node_gaussians(P["means"], P["scales"], P["quats"], P["opacities"], P["features_dc"], P["features_rest"], c2w, 3, 3,
+                           instance_quat=q, instance_trans=t)
+    static = node_gaussians(rigid["means"].detach(), P["scales"], P["quats"], P["opacities"], P["features_dc"], P["features_rest"],
+                            c2w, 3, 3)
+    assert torch.allclose(rigid["rgbs"], static["rgbs"], atol=1e-6) and torch.equal(rigid["scales"], static["scales"])
+    assert not torch.allclose(rigid["means"], P["means"])
