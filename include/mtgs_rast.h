@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 3
+#define MTGS_RAST_ABI_VERSION 4
 
 enum {
     MTGS_OK = 0,
