@@ -9,9 +9,10 @@ vanilla_gaussian_splatting.py:174-213, multi_color_gaussian_splatting.py:48-71).
 
 `load_gaussian_nodes` returns the raw parameters per node; `collect_gaussians` does what
 MTGSSceneModel.get_gaussians does for the static node types (vanilla / multi-colour: activations through the fused
-node kernels, then one concatenation) so that a released checkpoint can be rendered with `rasterization`.  Rigid /
-deformable nodes (per-frame poses, deformation networks) carry state this module does not interpret: they are listed,
-and `collect_gaussians` refuses them by name instead of rendering them wrongly.
+node kernels, then one concatenation) so that a released checkpoint can be rendered with `rasterization`; rigid nodes are posed
+with `frame_idx` (rigid_node.py:127-144, in-frame masks and traversal gating are the caller's: pass `node_names`).
+Deformable nodes / Fourier features carry state this module does not interpret: `collect_gaussians` refuses them by name
+instead of rendering them wrongly.
 """
 from __future__ import annotations
 
@@ -45,17 +46,23 @@ def load_gaussian_nodes(ckpt: Union[str, Mapping], map_location="cpu") -> Dict[s
     return nodes
 
 
+RIGID_KEYS = ("instance_quats", "instance_trans")
+
+
 def node_kind(params: Mapping[str, Tensor]) -> str:
-    """'vanilla' | 'multicolor' | 'dynamic' (anything with per-frame poses or extra modules)."""
+    """'vanilla' | 'multicolor' | 'rigid' (instance poses only, rigid_node.py:85-112) | 'dynamic' (anything else:
+    deformation networks, Fourier features ...)."""
     extra = [k for k in params if k not in GAUSS_PARAM_NAMES]
     if extra:
-        return "dynamic"
+        rigid = set(extra) == set(RIGID_KEYS) and params["features_dc"].dim() == 2
+        return "rigid" if rigid else "dynamic"
     return "multicolor" if "features_adapters" in params else "vanilla"
 
 
 def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_worlds: Tensor, sh_degree_to_use: int,
                       model_sh_degree: int = 3, traversal_index: Optional[int] = None,
-                      node_names: Optional[Iterable[str]] = None, device="cuda") -> Dict[str, Tensor]:
+                      node_names: Optional[Iterable[str]] = None, device="cuda",
+                      frame_idx: Optional[int] = None) -> Dict[str, Tensor]:
     """means / scales / quats / opacities / rgbs / model_id of the listed static nodes, activated by
     mtgs_amd.nodes.node_gaussians and concatenated in order (MTGSSceneModel.get_gaussians,
     mtgs_scene_graph.py:408-461).  Multi-colour nodes need `traversal_index` (get_pertravel_features,
@@ -66,10 +73,18 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
     for name in names:
         p = {k: v.to(device) for k, v in nodes[name].items()}
         kind = node_kind(p)
+        if kind == "rigid":
+            # RigidSubModel.get_object_pose (rigid_node.py:127-144): static objects store one pose, moving ones one per frame
+            iq, it = p.pop("instance_quats"), p.pop("instance_trans")
+            if it.dim() > 1:
+                if frame_idx is None:
+                    raise ValueError(f"collect_gaussians: rigid node {name!r} has per-frame poses: pass frame_idx")
+                iq, it = iq[frame_idx] / iq[frame_idx].norm(dim=-1, keepdim=True), it[frame_idx]
+            p["instance_quat"], p["instance_trans"] = iq.contiguous(), it.contiguous()
         if kind == "dynamic":
             raise NotImplementedError(f"collect_gaussians: node {name!r} carries per-frame state "
-                                      f"({sorted(k for k in p if k not in GAUSS_PARAM_NAMES)[:3]}...); only vanilla and "
-                                      "multi-colour nodes are supported")
+                                      f"({sorted(k for k in p if k not in GAUSS_PARAM_NAMES)[:3]}...); only vanilla, "
+                                      "multi-colour and rigid nodes are supported")
         if p["scales"].shape[-1] == 1:   # isotropic nodes store one log-scale (vanilla_gaussian_splatting.py:185-196)
             p["scales"] = p["scales"].expand(-1, 3).contiguous()
         if "quats" not in p:

@@ -24,6 +24,8 @@ def _state(T=2):
     node("background", 300, multicolor=True)
     node("road", 200)
     node("object_vehicle_12", 50, dynamic=True)
+    node("object_deform_3", 20)
+    sd["_model.gaussian_models.object_deform_3.deform_network.fc.weight"] = torch.zeros(4, 4)
     return sd
 
 
@@ -32,10 +34,10 @@ def test_load_nodes_from_checkpoint_file(tmp_path):
     path = tmp_path / "step-000030000.ckpt"
     torch.save({"step": 30000, "pipeline": _state()}, path)
     nodes = ck.load_gaussian_nodes(str(path))
-    assert list(nodes) == ["background", "road", "object_vehicle_12"]
+    assert list(nodes) == ["background", "road", "object_vehicle_12", "object_deform_3"]
     assert set(nodes["road"]) == {"means", "scales", "quats", "opacities", "features_dc", "features_rest"}
     assert nodes["background"]["features_rest"].shape == (300, 2, 15, 3)
-    assert [ck.node_kind(nodes[n]) for n in nodes] == ["multicolor", "vanilla", "dynamic"]
+    assert [ck.node_kind(nodes[n]) for n in nodes] == ["multicolor", "vanilla", "rigid", "dynamic"]
     assert "instance_trans" in nodes["object_vehicle_12"]
     with pytest.raises(ValueError):
         ck.load_gaussian_nodes({"pipeline": {"_model.foo": torch.zeros(1)}})
@@ -47,10 +49,21 @@ def test_collect_and_render_checkpoint(hip_lib):
     from mtgs_amd.synthetic import make_camera
     nodes = ck.load_gaussian_nodes({"pipeline": _state()})
     c2w = torch.eye(4)[None, :3]
-    with pytest.raises(NotImplementedError, match="object_vehicle_12"):
-        ck.collect_gaussians(nodes, c2w, 3)
-    gs = ck.collect_gaussians(nodes, c2w, 3, traversal_index=1, node_names=["background", "road"])
-    assert gs["means"].shape == (500, 3) and gs["rgbs"].shape == (500, 3) and int(gs["model_id"].max()) == 1
+    with pytest.raises(NotImplementedError, match="object_deform_3"):
+        ck.collect_gaussians(nodes, c2w, 3, frame_idx=0)
+    with pytest.raises(ValueError, match="frame_idx"):
+        ck.collect_gaussians(nodes, c2w, 3, node_names=["object_vehicle_12"])
+    gs = ck.collect_gaussians(nodes, c2w, 3, traversal_index=1, node_names=["background", "road", "object_vehicle_12"], frame_idx=2)
+    assert gs["means"].shape == (550, 3) and gs["rgbs"].shape == (550, 3) and int(gs["model_id"].max()) == 2
+    # the rigid node is posed with frame 2: R(q) m + t with the normalised per-frame quaternion (rigid_node.py:142, :205-209)
+    v = nodes["object_vehicle_12"]
+    q = (v["instance_quats"][2] / v["instance_quats"][2].norm()).double()
+    w, x, y, z = q.tolist()
+    R = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float64)
+    expect = v["means"].double() @ R.T + v["instance_trans"][2].double()
+    assert torch.allclose(gs["means"][500:].cpu().double(), expect, atol=1e-5)
     # the multi-colour node used traversal 1: features_dc + adapters[:, 1], features_rest[:, 1]
     from mtgs_amd.nodes import node_gaussians
     p = {k: v.cuda() for k, v in nodes["background"].items()}
