@@ -18,7 +18,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_LIB_PATH = _HERE / "libgsplat_oracle.so"
+# MTGS_ORACLE_LIB: an alternative build of the same source (the sanitizer build of tests/test_oracle_sanitizers.py)
+_LIB_PATH = Path(os.environ.get("MTGS_ORACLE_LIB") or _HERE / "libgsplat_oracle.so")
 
 c_f = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 c_i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -28,6 +29,8 @@ c_u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> Path:
     src = _HERE / "gsplat_oracle.c"
+    if os.environ.get("MTGS_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
         subprocess.check_call(["make", "-s", "-C", str(_HERE), "-B", "libgsplat_oracle.so"])
     return _LIB_PATH
