@@ -124,7 +124,22 @@ def make_step(args, dev, world):
         info_box["info"] = info
         return render, alpha
 
-    return step, all_params, info_box
+    def step_fwd():
+        if args.variant == "mtgs":
+            dirs = params["means"] - cam_pos
+            rgb = torch.clamp(spherical_harmonics(3, dirs, params["coeffs"]) + 0.5, 0.0, 1.0)
+            return rasterization(
+                means=params["means"], quats=params["quats"], scales=params["scales"],
+                opacities=params["opacities"], colors=rgb, viewmats=viewmat, Ks=K, width=W, height=H,
+                tile_size=16, packed=False, near_plane=0.01, far_plane=1e10, render_mode="RGB+ED",
+                sparse_grad=False, absgrad=True, rasterize_mode="antialiased")
+        return rasterization(
+            means=params["means"], quats=params["quats"], scales=params["scales"],
+            opacities=params["opacities"], colors=params["colors"], viewmats=viewmat, Ks=K,
+            width=W, height=H, tile_size=16, packed=False, render_mode="RGB", absgrad=False,
+            rasterize_mode="classic")
+
+    return step, step_fwd, all_params, info_box
 
 
 def cpu_baseline(args, host, steps):
@@ -185,7 +200,7 @@ def main():
     device = torch.device("cuda", torch.cuda.current_device())
     _lib.load()
     host, dev = build_inputs(args, rank, device)
-    step, all_params, info_box = make_step(args, dev, world)
+    step, step_fwd, all_params, info_box = make_step(args, dev, world)
 
     def barrier():
         if world > 1:
@@ -210,6 +225,22 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # outside the timed region: the forward-only rate SURVEY.md section 8(d) asks to be reported beside the headline
+    # (what eval / the viewer run: the same calls under no_grad)
+    fwd_ms = None
+    if world == 1:
+        params_were = [p.requires_grad for p in all_params]
+        with torch.no_grad():
+            for _ in range(2):
+                step_fwd()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(args.steps // 2, 1)):
+                step_fwd()
+            torch.cuda.synchronize()
+            fwd_ms = (time.perf_counter() - t1) / max(args.steps // 2, 1) * 1e3
+        assert params_were == [p.requires_grad for p in all_params]
 
     info = info_box["info"]
     n_vis = int((info["radii"] > 0).sum().item())
@@ -267,6 +298,9 @@ def main():
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "formula": "SURVEY.md section 8(d) B_F + B_B"}},
     }
+    if fwd_ms is not None:
+        out["also"] = {"fwd_only_ms": round(fwd_ms, 3), "fwd_only_mpix_s": round(P / fwd_ms / 1e3, 1),
+                       "gaussians_per_s_fwd_bwd": round(world * args.n_gaussians / (ms_per_step * 1e-3), 0)}
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)
     if rank == 0:
