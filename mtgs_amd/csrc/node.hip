@@ -24,6 +24,13 @@
 
 namespace {
 
+// The addend must be a ROUNDED product (mul_rounded at the call sites; HIP's __fmul_rn is a plain, contractable `*`): if the compiler contracts the multiply into the
+// first add, lane L gets fma(b_L, c_L, round(b_M c_M)) and its partner M the mirror image -- 1 ulp apart, which made a
+// Gaussian's colour depend on its position in the wave (tests/test_gpu_large.py renders a subset bit-identically).
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
 __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
             const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
             const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
             const float b = sh_lane_basis<DEG>(lc, x, y, z);
-            r = row16_sum(b * c[it].x); gg = row16_sum(b * c[it].y); bb = row16_sum(b * c[it].z);
+            r = row16_sum(mul_rounded(b, c[it].x)); gg = row16_sum(mul_rounded(b, c[it].y)); bb = row16_sum(mul_rounded(b, c[it].z));
         } else {  // lane 0 of the row holds the coefficients; every lane of the row gets them
             r = row16_sum(c[it].x); gg = row16_sum(c[it].y); bb = row16_sum(c[it].z);
         }

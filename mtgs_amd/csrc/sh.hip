@@ -184,6 +184,13 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(int64_t n, int K,
 //   b_k = (a0 + a1 z + a2 z^2 + a3 z^3) * s_k,  s_k in {1, x, y, 2xy, x^2-y^2, fS2, fC2}
 // (associated Legendre polynomial in z times the azimuthal factor), with per-lane constants a0..a3.
 // Measured 125 -> see DESIGN.md table (sh_fwd_k16_kernel).
+// The addend must be a ROUNDED product (mul_rounded at the call sites; HIP's __fmul_rn is a plain, contractable `*`): if the compiler contracts the multiply into the
+// first add, lane L gets fma(b_L, c_L, round(b_M c_M)) and its partner M the mirror image -- 1 ulp apart, which made a
+// Gaussian's colour depend on its position in the wave (tests/test_gpu_large.py renders a subset bit-identically).
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
 __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const
         const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
         const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
         const float b = sh_lane_basis<DEG>(lc, x, y, z);
-        const float r = row16_sum(b * c[it].x), gg = row16_sum(b * c[it].y), bb = row16_sum(b * c[it].z);
+        const float r = row16_sum(mul_rounded(b, c[it].x)), gg = row16_sum(mul_rounded(b, c[it].y)), bb = row16_sum(mul_rounded(b, c[it].z));
         const bool mine = k == it;
         myr = mine ? r : myr; myg = mine ? gg : myg; myb = mine ? bb : myb;
     }
