@@ -10,11 +10,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _scene(N, gen):
+def _scene(N, gen, scale_mul=0.35):
     dev = "cuda"
     ext = torch.tensor([50.0, 7.5, 50.0], device=dev)
     means = (torch.rand(N, 3, device=dev, generator=gen) * 2 - 1) * ext
-    scales = torch.exp(torch.empty(N, 3, device=dev).uniform_(-3.9, -1.6, generator=gen)) * 0.35   # denser scene, smaller splats
+    scales = torch.exp(torch.empty(N, 3, device=dev).uniform_(-3.9, -1.6, generator=gen)) * scale_mul
     quats = torch.randn(N, 4, device=dev, generator=gen)
     opac = torch.sigmoid(torch.randn(N, device=dev, generator=gen))
     coeffs = torch.empty(N, 16, 3, device=dev)
@@ -35,13 +35,15 @@ def _step(gs, P, vm, K, W, H, Gc, Ga):
 
 
 @pytest.mark.timeout(900)
-def test_48m_gaussians_culling_invariance(hip_lib):
+@pytest.mark.parametrize("N,W,H,scale_mul,min_M", [
+    (48_000_000, 640, 360, 0.35, 0),            # element indices past 2^31 (N * 48 coefficients), small splats
+    (24_000_000, 1920, 1080, 3.0, 2 ** 28),     # a quarter of a billion intersections: 32-bit byte offsets overflow in the sort
+])
+def test_large_scene_culling_invariance(hip_lib, N, W, H, scale_mul, min_M):
     import mtgs_amd as gs
     from mtgs_amd.synthetic import make_camera
-    N, W, H = 48_000_000, 640, 360
-    assert N * 16 * 3 > 2 ** 31
     gen = torch.Generator(device="cuda").manual_seed(7)
-    sc = _scene(N, gen)
+    sc = _scene(N, gen, scale_mul)
     vm, K = make_camera(W, H)
     vm, K = vm.cuda(), K.cuda()
     Gc = torch.randn(1, H, W, 4, device="cuda", generator=gen)
@@ -54,8 +56,9 @@ def test_48m_gaussians_culling_invariance(hip_lib):
     idx = vis.nonzero()[:, 0]
     n_vis = idx.numel()
     assert 0.05 * N < n_vis < 0.3 * N
-    assert int(idx[-1]) * 48 > 2 ** 31          # visible rows on both sides of the 32-bit element boundary
-    assert int(info["flatten_ids"].max()) == int(idx[-1]) or int(info["flatten_ids"].max()) < N
+    if N * 48 > 2 ** 31:
+        assert int(idx[-1]) * 48 > 2 ** 31      # visible rows on both sides of the 32-bit element boundary
+    assert info["flatten_ids"].numel() >= min_M, info["flatten_ids"].numel()
 
     Q = {k: v.detach()[idx].clone().requires_grad_(True) for k, v in sc.items()}
     vm_sub = vm.clone().requires_grad_(True)
