@@ -84,3 +84,66 @@ def test_large_scene_culling_invariance(hip_lib, N, W, H, scale_mul, min_M):
     a_full = info["means2d"].absgrad[0][idx]
     a_sub = info_s["means2d"].absgrad[0]
     assert float((a_full - a_sub).abs().max()) <= 2e-4 * float(a_sub.abs().max())
+
+
+@pytest.mark.timeout(900)
+def test_48m_node_activations_slice_invariance(hip_lib):
+    """Fused node activations (mtgs_amd.nodes) at 48M Gaussians: features_rest has 2.16e9 elements.  Rows near the end of
+    the tensors must equal the same rows computed alone (a slice that starts on a wave boundary), forward and backward."""
+    from mtgs_amd.nodes import node_gaussians
+    N, dev = 48_000_000, "cuda"
+    gen = torch.Generator(device=dev).manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    P = dict(means=rnd(N, 3) * 20, scales=rnd(N, 3) * 0.3 - 2, quats=rnd(N, 4), opacities=rnd(N, 1), features_dc=rnd(N, 3) * 0.5,
+             features_rest=rnd(N, 15, 3) * 0.1)
+    assert P["features_rest"].numel() > 2 ** 31
+    c2w = torch.eye(4, device=dev)[None, :3]
+    c2w[0, :, 3] = torch.tensor([1.0, -0.5, 2.0])
+    cot = {k: rnd(N, w) for k, w in (("scales", 3), ("quats", 4), ("rgbs", 3))}
+    cot["opacities"] = rnd(N)
+
+    def run(lo, hi):
+        Q = {k: v[lo:hi].detach().clone().requires_grad_(True) for k, v in P.items()}
+        out = node_gaussians(Q["means"], Q["scales"], Q["quats"], Q["opacities"], Q["features_dc"], Q["features_rest"], c2w, 3, 3)
+        loss = sum((out[k].reshape(hi - lo, -1) * cot[k][lo:hi].reshape(hi - lo, -1)).sum() for k in cot)
+        loss.backward()
+        return {k: out[k].detach() for k in cot}, {k: v.grad for k, v in Q.items()}
+
+    out_full, grad_full = run(0, N)
+    for lo, hi in ((N - 64 * 1000, N), (64 * 745_640, 64 * 745_640 + 8192)):     # past / across the 2^31-element boundary
+        assert hi * 45 > 2 ** 31
+        out_s, grad_s = run(lo, hi)
+        for k in out_s:
+            assert torch.equal(out_full[k][lo:hi], out_s[k]), k
+        for k in grad_s:
+            if grad_s[k] is None:
+                assert grad_full[k] is None or not grad_full[k][lo:hi].any(), k
+                continue
+            assert torch.equal(grad_full[k][lo:hi], grad_s[k]), k
+
+
+@pytest.mark.timeout(900)
+def test_48m_sparse_exchange_reduce(hip_lib):
+    """The one-pass receiver reduction of the view-parallel gradient exchange (mtgs_dp_pack_ordered + mtgs_dp_reduce) at
+    48M Gaussians, world = 1: identity on the visible rows and the SH-coefficient gradient rebuilt from its factors
+    must equal the local SH backward, also past the 2^31st element of v_coeffs."""
+    from mtgs_amd import dist as mdist
+    from mtgs_amd import spherical_harmonics
+    N, K, dev = 48_000_000, 16, torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    vis = torch.rand(N, device=dev, generator=gen) > 0.85
+    radii = vis.int()
+    mk = lambda *s: (torch.randn(*s, device=dev, generator=gen) * vis.view(-1, *([1] * (len(s) - 1)))).contiguous()
+    v_means, v_quats, v_scales, v_opac, v_rgb = mk(N, 3), mk(N, 4), mk(N, 3), mk(N), mk(N, 3)
+    means = torch.randn(N, 3, device=dev, generator=gen)
+    cam = torch.tensor([0.3, -0.2, 0.1], device=dev)
+    coeffs = torch.zeros(N, K, 3, device=dev, requires_grad=True)
+    spherical_harmonics(3, means - cam, coeffs).backward(v_rgb)
+    ex = mdist.SparseGradExchange(N, K, dev)
+    out = ex.exchange(radii, means, cam, v_means, v_quats, v_scales, v_opac, v_rgb, 3)
+    for got, ref in zip(out, (v_means, v_quats, v_scales, v_opac, coeffs.grad)):
+        assert got.shape == ref.shape
+        tail = slice(N - 1_000_000, N)
+        assert torch.allclose(got[tail], ref[tail], atol=2e-6, rtol=1e-5)
+        assert torch.allclose(got[:1_000_000], ref[:1_000_000], atol=2e-6, rtol=1e-5)
+        assert float((got - ref).abs().max()) < 1e-5
