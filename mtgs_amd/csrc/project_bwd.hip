@@ -458,7 +458,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
         MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
         if (n_vis > 0) {
             const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
-            project_bwd_vis_kernel<<<(unsigned)(blocks < 1024 ? blocks : 1024), PROJ_BLOCK, 0, st>>>(
+            project_bwd_vis_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
                 v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats);
         }
