@@ -484,7 +484,8 @@ class _FusedRasterization(torch.autograd.Function):
                  host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
-        if n_vis > 0:
+        direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
+        if n_vis > 0 and direct:
             vi = vis_ids.long()
             if g_means2d is not None:
                 r_xy += g_means2d.reshape(Cn * N, 2)[vi]
