@@ -117,6 +117,32 @@ def test_sort_is_stable_on_masked_bits(gs, oracle):
     assert np.array_equal(ko.cpu().numpy(), r_k) and np.array_equal(vo.cpu().numpy(), r_v)
 
 
+@pytest.mark.parametrize("M", [1, 63, 1025, 5000, 300_000, 1 << 20, (1 << 20) + 1, 3_000_001])
+@pytest.mark.parametrize("key_bits", [1, 7, 12, 23, 32, 33, 46, 64])
+def test_sort_pairs_all_digit_plans(gs, M, key_bits):
+    """mtgs_sort_pairs against torch's stable sort of the masked keys: up to 2^20 keys take 1024-key tiles, larger sorts
+    4096-key tiles; every (size class, pass count, last-digit width) combination must be stable and must ignore the
+    bits above key_bits."""
+    from mtgs_amd._lib import call, ptr
+    g = torch.Generator(device="cuda").manual_seed(M * 131 + key_bits)
+    keys = torch.randint(-(1 << 62), 1 << 62, (M,), generator=g, dtype=torch.int64, device="cuda")
+    if key_bits >= 12:   # ties in the low bits too: a few distinct values only
+        keys = torch.where(torch.rand(M, device="cuda", generator=g) < 0.3, keys & 0x7, keys)
+    vals = torch.arange(M, dtype=torch.int32, device="cuda")
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    ws = C.c_size_t(0)
+    call("mtgs_sort_workspace_bytes", M, C.byref(ws))
+    w = torch.empty(ws.value, dtype=torch.uint8, device="cuda")
+    call("mtgs_sort_pairs", M, key_bits, ptr(keys), ptr(vals), ptr(ko), ptr(vo), ptr(w), ws.value,
+         torch.cuda.current_stream().cuda_stream)
+    masked = keys if key_bits == 64 else keys & ((1 << key_bits) - 1)
+    if key_bits == 64:    # unsigned order of the 64-bit pattern
+        masked = keys ^ (-(1 << 63))
+    order = torch.sort(masked, stable=True).indices
+    assert torch.equal(vo.long(), order)
+    assert torch.equal(ko, keys[order])
+
+
 CONFIGS = [
     # (render_mode, rasterize_mode, absgrad, D, backgrounds, W, H)
     ("RGB", "classic", False, 3, False, 100, 70),
