@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 4
+#define MTGS_RAST_ABI_VERSION 5
 
 enum {
     MTGS_OK = 0,
@@ -288,6 +288,40 @@ int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, const float *me
                   float *g_features_dc, float *g_features_rest, float *g_features_dc_add, int n_traversals,
                   int traversal, const float *pose, const float *v_means, float *g_means, float *g_pose,
                   void *stream);
+
+/* ---- all nodes of a scene in ONE launch -------------------------------------------------------------------------------
+ * MTGSSceneModel.get_gaussians (mtgs_scene_graph.py:408-461) loops over the nodes of the scene graph -- background, road,
+ * and one rigid node per object instance present in the frame (rigid_node.py:259-261): tens to hundreds of nodes of a few
+ * thousand Gaussians each, i.e. hundreds of launches of microseconds of work.  The batched entry points take a TABLE of
+ * descriptors in device memory (one per node, in output order) and run mtgs_node_fwd / mtgs_node_bwd for every node in a
+ * single launch: workgroup b serves 256 Gaussians of the node with first_block <= b < next first_block.
+ * All pointers are device pointers with the meaning of the same-named arguments of mtgs_node_fwd / mtgs_node_bwd; the
+ * output pointers are the node's slices of the collected tensors.  The forward ignores the v_* / g_* fields; the backward
+ * reads features_* only through k_rest / use_sh (gradient rows are dense: [n,3], [n,k_rest,3] or, with n_traversals > 0,
+ * [n,T,k_rest,3] / [n,T,3]). */
+typedef struct mtgs_node_desc {
+    int64_t n;                 /* Gaussians of this node */
+    int64_t first_block;       /* index of the node's first workgroup: sum over earlier nodes of ceil(n / 256) */
+    int64_t start;             /* offset of the node's first Gaussian in the collected tensors (model_id) */
+    const float *means, *scales_raw, *quats_raw, *opacities_raw;
+    const float *features_dc, *features_dc_add, *features_rest;
+    int64_t dc_stride, dc_add_stride, rest_stride;          /* row strides in floats */
+    const float *pose;         /* [7] instance quaternion wxyz | translation of a rigid node, or NULL */
+    int32_t k_rest, use_sh, n_traversals, traversal;
+    float *scales, *quats, *opacities, *rgbs;               /* forward outputs = activations saved for the backward */
+    uint8_t *clamp_mask;
+    float *means_out;          /* global means (written when non-NULL) */
+    const float *v_scales, *v_quats, *v_opacities, *v_rgbs, *v_means;
+    float *g_scales_raw, *g_quats_raw, *g_opacities_raw, *g_features_dc, *g_features_rest, *g_features_dc_add, *g_means,
+        *g_pose;
+} mtgs_node_desc;
+int mtgs_node_desc_bytes(void);   /* sizeof(mtgs_node_desc): bindings check their layout against it */
+/* total_blocks = sum over nodes of ceil(n / 256); `degree` = sh_degree_to_use of the step (all nodes);
+ * model_id[sum n] (nullable) receives the node index of every collected Gaussian (mtgs_scene_graph.py:449-455). */
+int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree, const float *cam_pos,
+                        int64_t *model_id, void *stream);
+int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree, const float *cam_pos,
+                        void *stream);
 
 /* ---- densification statistics of one node in one launch ------------------------------
  * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous

@@ -52,6 +52,9 @@ _SIGNATURES = {
                       _vp, _vp],
     "mtgs_node_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                       _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_node_desc_bytes": [],
+    "mtgs_node_fwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp, _vp],
+    "mtgs_node_bwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_ssim_workspace_floats": [_i32, _i32, C.POINTER(_sz)],
     "mtgs_ssim_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
@@ -66,7 +69,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

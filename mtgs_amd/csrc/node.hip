@@ -81,17 +81,16 @@ __device__ __forceinline__ Pose load_pose(const float *p) {
 constexpr int NODE_BLOCK = 256, NODE_PER_WAVE = 64, NODE_STEPS = 16;
 struct F4 { float x, y, z, w; };
 
+// The work of ONE wave: Gaussians [g0, g0 + 64) of a node with N Gaussians.
 template <int DEG>
-__global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const NodeParams P, float *__restrict__ scales,
-                                                              float *__restrict__ quats, float *__restrict__ opacities,
-                                                              float *__restrict__ rgbs, uint8_t *__restrict__ clamp_mask,
-                                                              float *__restrict__ means_out) {
+__device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams &P, const int64_t g0, float *__restrict__ scales,
+                                              float *__restrict__ quats, float *__restrict__ opacities,
+                                              float *__restrict__ rgbs, uint8_t *__restrict__ clamp_mask,
+                                              float *__restrict__ means_out) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
     const bool active = P.use_sh ? (k < NB && k - 1 < P.Kr) : (k == 0);
-    const int64_t g0 = ((int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
-    if (g0 >= N) return;
     const float camx = P.cam_pos[0], camy = P.cam_pos[1], camz = P.cam_pos[2];
     // ---- lane-per-Gaussian loads
     const int64_t gl = g0 + lane;
@@ -185,24 +184,66 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const N
 }
 
 template <int DEG>
-__global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const NodeParams P, const float *__restrict__ scales,
-                                                              const float *__restrict__ opacities,
-                                                              const float *__restrict__ rgbs,
-                                                              const uint8_t *__restrict__ clamp_mask,
-                                                              const float *__restrict__ v_scales,
-                                                              const float *__restrict__ v_quats,
-                                                              const float *__restrict__ v_opacities,
-                                                              const float *__restrict__ v_rgbs, float *__restrict__ g_scales_raw,
-                                                              float *__restrict__ g_quats_raw, float *__restrict__ g_opac_raw,
-                                                              float *__restrict__ g_dc, float *__restrict__ g_rest,
-                                                              float *__restrict__ g_dc_add, int n_trav, int trav,
-                                                              const float *__restrict__ v_means, float *__restrict__ g_means,
-                                                              float *__restrict__ g_pose) {
+__global__ __launch_bounds__(NODE_BLOCK) void node_fwd_kernel(int64_t N, const NodeParams P, float *__restrict__ scales,
+                                                              float *__restrict__ quats, float *__restrict__ opacities,
+                                                              float *__restrict__ rgbs, uint8_t *__restrict__ clamp_mask,
+                                                              float *__restrict__ means_out) {
+    const int64_t g0 = ((int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
+    if (g0 >= N) return;
+    node_fwd_wave<DEG>(N, P, g0, scales, quats, opacities, rgbs, clamp_mask, means_out);
+}
+
+// ---- all nodes of a scene in ONE launch: a table of descriptors in device memory (include/mtgs_rast.h) --------------
+// Workgroup b belongs to the node i with table[i].first_block <= b < table[i + 1].first_block (binary search; the index
+// is wave-uniform, so the descriptor arrives through scalar loads) and handles 256 of its Gaussians.
+__device__ __forceinline__ int node_of_block(const mtgs_node_desc *__restrict__ table, int n_nodes, int64_t b) {
+    int lo = 0, hi = n_nodes - 1;   // last node whose first_block <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+__device__ __forceinline__ NodeParams params_of(const mtgs_node_desc &d, const float *cam_pos) {
+    return NodeParams{d.means, d.scales_raw, d.quats_raw, d.opacities_raw, d.features_dc, d.features_dc_add, d.features_rest,
+                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, d.pose};
+}
+
+template <int DEG>
+__global__ __launch_bounds__(NODE_BLOCK) void node_fwd_batch_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
+                                                                    const float *__restrict__ cam_pos,
+                                                                    int64_t *__restrict__ model_id) {
+    const int i = node_of_block(table, n_nodes, blockIdx.x);
+    const mtgs_node_desc &d = table[i];
+    const int64_t g0 = (((int64_t)blockIdx.x - d.first_block) * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
+    if (g0 >= d.n) return;
+    if (model_id) {
+        const int64_t gl = g0 + (threadIdx.x & 63);
+        if (gl < d.n) model_id[d.start + gl] = i;
+    }
+    node_fwd_wave<DEG>(d.n, params_of(d, cam_pos), g0, d.scales, d.quats, d.opacities, d.rgbs, d.clamp_mask, d.means_out);
+}
+
+struct NodeGrads {   // cotangents of the activated Gaussians and the gradients of the raw parameters
+    const float *v_scales, *v_quats, *v_opacities, *v_rgbs, *v_means;
+    float *g_scales_raw, *g_quats_raw, *g_opac_raw, *g_dc, *g_rest, *g_dc_add, *g_means, *g_pose;
+    int n_trav, trav;
+};
+
+template <int DEG>
+__device__ __forceinline__ void node_bwd_wave(const int64_t N, const NodeParams &P, const int64_t g0,
+                                              const float *__restrict__ scales, const float *__restrict__ opacities,
+                                              const float *__restrict__ rgbs, const uint8_t *__restrict__ clamp_mask,
+                                              const NodeGrads &G) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
-    const int64_t g0 = ((int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
-    if (g0 >= N) return;
+    const float *__restrict__ v_scales = G.v_scales, *__restrict__ v_quats = G.v_quats, *__restrict__ v_opacities = G.v_opacities,
+                *__restrict__ v_rgbs = G.v_rgbs, *__restrict__ v_means = G.v_means;
+    float *__restrict__ g_scales_raw = G.g_scales_raw, *__restrict__ g_quats_raw = G.g_quats_raw, *__restrict__ g_opac_raw = G.g_opac_raw,
+          *__restrict__ g_dc = G.g_dc, *__restrict__ g_rest = G.g_rest, *__restrict__ g_dc_add = G.g_dc_add,
+          *__restrict__ g_means = G.g_means, *__restrict__ g_pose = G.g_pose;
+    const int n_trav = G.n_trav, trav = G.trav;
     const float camx = P.cam_pos[0], camy = P.cam_pos[1], camz = P.cam_pos[2];
     // ---- lane-per-Gaussian: activations, and the colour cotangent with the clamp / sigmoid VJP applied
     const int64_t gl = g0 + lane;
@@ -337,6 +378,30 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const N
     }
 }
 
+template <int DEG>
+__global__ __launch_bounds__(NODE_BLOCK) void node_bwd_kernel(int64_t N, const NodeParams P, const float *__restrict__ scales,
+                                                              const float *__restrict__ opacities,
+                                                              const float *__restrict__ rgbs,
+                                                              const uint8_t *__restrict__ clamp_mask, const NodeGrads G) {
+    const int64_t g0 = ((int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
+    if (g0 >= N) return;
+    node_bwd_wave<DEG>(N, P, g0, scales, opacities, rgbs, clamp_mask, G);
+}
+
+template <int DEG>
+__global__ __launch_bounds__(NODE_BLOCK) void node_bwd_batch_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
+                                                                    const float *__restrict__ cam_pos) {
+    const int i = node_of_block(table, n_nodes, blockIdx.x);
+    const mtgs_node_desc &d = table[i];
+    const int64_t g0 = (((int64_t)blockIdx.x - d.first_block) * (NODE_BLOCK / 64) + (threadIdx.x >> 6)) * NODE_PER_WAVE;
+    if (g0 >= d.n) return;
+    NodeParams P = params_of(d, cam_pos);
+    P.dc_stride = 3; P.dc_add_stride = 3; P.rest_stride = (int64_t)d.k_rest * 3;   // the gradients are dense rows
+    const NodeGrads G{d.v_scales, d.v_quats, d.v_opacities, d.v_rgbs, d.v_means, d.g_scales_raw, d.g_quats_raw, d.g_opacities_raw,
+                      d.g_features_dc, d.g_features_rest, d.g_features_dc_add, d.g_means, d.g_pose, d.n_traversals, d.traversal};
+    node_bwd_wave<DEG>(d.n, P, g0, d.scales, d.opacities, d.rgbs, d.clamp_mask, G);
+}
+
 }  // namespace
 
 #define MTGS_NODE_DISPATCH(KERNEL, ...)                                                 \
@@ -396,9 +461,37 @@ extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, cons
     const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh, pose};
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
-    MTGS_NODE_DISPATCH(node_bwd_kernel, N, P, scales, opacities, rgbs, clamp_mask, v_scales, v_quats, v_opacities, v_rgbs,
-                       g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc, g_features_rest, g_features_dc_add, n_traversals,
-                       traversal, v_means, g_means, g_pose)
+    const NodeGrads G{v_scales, v_quats, v_opacities, v_rgbs, v_means, g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc,
+                      g_features_rest, g_features_dc_add, g_means, g_pose, n_traversals, traversal};
+    MTGS_NODE_DISPATCH(node_bwd_kernel, N, P, scales, opacities, rgbs, clamp_mask, G)
     MTGS_CHECK_LAUNCH("mtgs_node_bwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_node_desc_bytes(void) { return (int)sizeof(mtgs_node_desc); }
+
+extern "C" int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree,
+                                   const float *cam_pos, int64_t *model_id, void *stream) {
+    MTGS_REQUIRE(n_nodes >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_node_fwd_batch: bad sizes");
+    MTGS_REQUIRE(degree >= 0 && degree <= 3, MTGS_EUNSUPPORTED, "mtgs_node_fwd_batch: degree %d (<= 3)", degree);
+    if (n_nodes == 0 || total_blocks == 0) return MTGS_OK;
+    MTGS_REQUIRE(table && cam_pos, MTGS_EINVAL, "mtgs_node_fwd_batch: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)total_blocks;
+    MTGS_NODE_DISPATCH(node_fwd_batch_kernel, table, n_nodes, cam_pos, model_id)
+    MTGS_CHECK_LAUNCH("mtgs_node_fwd_batch");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree,
+                                   const float *cam_pos, void *stream) {
+    MTGS_REQUIRE(n_nodes >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_node_bwd_batch: bad sizes");
+    MTGS_REQUIRE(degree >= 0 && degree <= 3, MTGS_EUNSUPPORTED, "mtgs_node_bwd_batch: degree %d (<= 3)", degree);
+    if (n_nodes == 0 || total_blocks == 0) return MTGS_OK;
+    MTGS_REQUIRE(table && cam_pos, MTGS_EINVAL, "mtgs_node_bwd_batch: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)total_blocks;
+    MTGS_NODE_DISPATCH(node_bwd_batch_kernel, table, n_nodes, cam_pos)
+    MTGS_CHECK_LAUNCH("mtgs_node_bwd_batch");
     return MTGS_OK;
 }

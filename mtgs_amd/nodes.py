@@ -16,6 +16,7 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -130,18 +131,44 @@ _NODE_KEYS = ("means", "scales", "quats", "opacities", "features_dc", "features_
 _NK = len(_NODE_KEYS)
 
 
+# mtgs_node_desc of include/mtgs_rast.h (checked against mtgs_node_desc_bytes() on first use)
+_DESC = np.dtype([(k, "<i8") for k in ("n", "first_block", "start")]
+                 + [(k, "<u8") for k in ("means", "scales_raw", "quats_raw", "opacities_raw", "features_dc", "features_dc_add",
+                                         "features_rest")]
+                 + [(k, "<i8") for k in ("dc_stride", "dc_add_stride", "rest_stride")] + [("pose", "<u8")]
+                 + [(k, "<i4") for k in ("k_rest", "use_sh", "n_traversals", "traversal")]
+                 + [(k, "<u8") for k in ("scales", "quats", "opacities", "rgbs", "clamp_mask", "means_out", "v_scales", "v_quats",
+                                         "v_opacities", "v_rgbs", "v_means", "g_scales_raw", "g_quats_raw", "g_opacities_raw",
+                                         "g_features_dc", "g_features_rest", "g_features_dc_add", "g_means", "g_pose")], align=True)
+_desc_checked = False
+
+
+def _upload(tab: np.ndarray, dev) -> Tensor:
+    global _desc_checked
+    if not _desc_checked:
+        from ._lib import load
+        want = load().mtgs_node_desc_bytes()
+        if want != _DESC.itemsize:
+            raise RuntimeError(f"mtgs_node_desc is {want} bytes in libmtgs_rast.so, {_DESC.itemsize} in mtgs_amd.nodes")
+        _desc_checked = True
+    return torch.from_numpy(tab.view(np.uint8)).to(dev)
+
+
 class _CollectNodes(torch.autograd.Function):
-    """All nodes of a scene as ONE autograd node: every node's kernel writes straight into its slice of the collected
-    tensors (no torch.cat of the per-node outputs), and the backward reads the slices of the incoming gradients."""
+    """All nodes of a scene as ONE autograd node and ONE launch per direction (mtgs_node_fwd_batch / mtgs_node_bwd_batch: a
+    table of node descriptors in device memory): every node's workgroups write straight into its slice of the collected
+    tensors (no torch.cat of the per-node outputs), the backward reads the slices of the incoming gradients and writes
+    every node's parameter gradients into slices of a few flat buffers."""
 
     @staticmethod
     def forward(ctx, cam_pos, specs, *flat):
         # specs[i] = (degree, use_sh, trav); flat = _NK tensors (or None) per node in _NODE_KEYS order
         n_nodes = len(specs)
-        nodes = [dict(zip(_NODE_KEYS, flat[_NK * i:_NK * i + _NK])) for i in range(n_nodes)]
         require_gpu(cam_pos, *[t for t in flat if t is not None])
-        sizes = [nd["means"].shape[0] for nd in nodes]
-        total, dev = sum(sizes), nodes[0]["means"].device
+        sizes = [flat[_NK * i].shape[0] for i in range(n_nodes)]
+        total, dev = sum(sizes), flat[0].device
+        degree = specs[0][0]
+        assert all(sp[0] == degree for sp in specs), "one sh_degree_to_use per step"
         cam = cam_pos.detach().reshape(3).to(torch.float32).contiguous()
         means = torch.empty((total, 3), dtype=torch.float32, device=dev)
         scales = torch.empty((total, 3), dtype=torch.float32, device=dev)
@@ -149,37 +176,120 @@ class _CollectNodes(torch.autograd.Function):
         opacities = torch.empty((total,), dtype=torch.float32, device=dev)
         rgbs = torch.empty((total, 3), dtype=torch.float32, device=dev)
         mask = torch.empty((total,), dtype=torch.uint8, device=dev)
-        saved, ctx.node_dims, start = [], [], 0
-        for nd, (degree, use_sh, trav), n in zip(nodes, specs, sizes):
-            sl = slice(start, start + n)
-            pose = None
-            if nd["instance_quat"] is not None:   # rigid node: the kernel writes the GLOBAL means
-                pose = torch.cat([nd["instance_quat"].detach().reshape(4), nd["instance_trans"].detach().reshape(3)]).to(torch.float32)
-            means_c, quats_c, dims = _launch_fwd(nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"],
-                                                 nd["features_dc_add"], nd["features_rest"], cam, degree, use_sh, trav,
-                                                 scales[sl], quats[sl], opacities[sl], rgbs[sl], mask[sl], pose, means[sl])
-            saved += [means_c, quats_c, pose if pose is not None else cam[:0]]
-            ctx.node_dims.append((dims, start, n, pose is not None))
+        model_id = torch.empty((total,), dtype=torch.int64, device=dev)
+        # the poses of the rigid nodes, gathered with one cat: [R, 7] = quaternion wxyz | translation
+        rigid = [i for i in range(n_nodes) if flat[_NK * i + 7] is not None]
+        pose_all = None
+        if rigid:
+            pose_all = torch.cat([flat[_NK * i + j].detach().reshape(-1) for i in rigid for j in (7, 8)]).to(torch.float32)
+            assert pose_all.numel() == 7 * len(rigid)
+        pose_ptr = {i: pose_all.data_ptr() + 28 * r for r, i in enumerate(rigid)}
+        tab = np.zeros(n_nodes, dtype=_DESC)
+        p_means, p_scales, p_quats, p_opac, p_rgbs, p_mask = (t.data_ptr() for t in (means, scales, quats, opacities, rgbs, mask))
+        saved, keep, dims, start, blk = [], [], [], 0, 0
+        for i in range(n_nodes):
+            m, sr, qr, orw, dc, add, rest, _, _ = flat[_NK * i:_NK * i + _NK]
+            _, use_sh, trav = specs[i]
+            n = sizes[i]
+            Kr = rest.shape[-2]
+            T = rest.shape[1] if trav >= 0 else 0
+            if trav >= 0:   # FULL per-traversal parameters: slice `trav` is read in place
+                rest = rest[:, trav]
+                add = None if add is None else add[:, trav]
+            m_c, sr_c, qr_c = m.detach().contiguous(), sr.contiguous(), qr.contiguous()
+            o_c = orw.reshape(n).contiguous()
+            dc_c, s_dc = _rows(dc, 3)
+            add_c, s_add = _rows(add, 3)
+            rest_c, s_rest = _rows(rest, Kr * 3)
+            keep += [sr_c, o_c, dc_c, add_c, rest_c]
+            saved += [m_c, qr_c]
+            dims.append((n, Kr, orw.shape, add is not None, T, int(trav), start))
+            row = tab[i]
+            row["n"], row["first_block"], row["start"] = n, blk, start
+            row["means"], row["scales_raw"], row["quats_raw"], row["opacities_raw"] = (m_c.data_ptr(), sr_c.data_ptr(),
+                                                                                       qr_c.data_ptr(), o_c.data_ptr())
+            row["features_dc"], row["features_rest"] = dc_c.data_ptr(), rest_c.data_ptr()
+            row["features_dc_add"] = 0 if add_c is None else add_c.data_ptr()
+            row["dc_stride"], row["dc_add_stride"], row["rest_stride"] = s_dc, s_add, s_rest
+            row["pose"] = pose_ptr.get(i, 0)
+            row["k_rest"], row["use_sh"], row["n_traversals"], row["traversal"] = Kr, int(use_sh), T, max(int(trav), 0)
+            row["scales"], row["quats"], row["opacities"] = p_scales + 12 * start, p_quats + 16 * start, p_opac + 4 * start
+            row["rgbs"], row["clamp_mask"], row["means_out"] = p_rgbs + 12 * start, p_mask + start, p_means + 12 * start
             start += n
-        ctx.save_for_backward(cam, scales, opacities, rgbs, mask, *saved)
-        return means, scales, quats, opacities, rgbs
+            blk += -(-n // 256)
+        tab_dev = _upload(tab, dev)
+        call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, int(degree), ptr(cam), ptr(model_id), stream_of(means))
+        del keep   # (stream-ordered allocator: the launch above is already enqueued)
+        ctx.tab, ctx.dims, ctx.blocks, ctx.degree, ctx.rigid = tab, dims, blk, int(degree), rigid
+        ctx.save_for_backward(cam, scales, opacities, rgbs, mask, pose_all, *saved)
+        ctx.mark_non_differentiable(model_id)
+        return means, scales, quats, opacities, rgbs, model_id
 
     @staticmethod
-    def backward(ctx, v_means, v_scales, v_quats, v_opacities, v_rgbs):
-        cam, scales, opacities, rgbs, mask, *saved = ctx.saved_tensors
-        grads = []
+    def backward(ctx, v_means, v_scales, v_quats, v_opacities, v_rgbs, _v_id):
+        cam, scales, opacities, rgbs, mask, pose_all, *saved = ctx.saved_tensors
+        dims, rigid = ctx.dims, ctx.rigid
+        n_nodes, total, dev = len(dims), scales.shape[0], scales.device
         need = ctx.needs_input_grad[2:]
-        for i, (dims, start, n, has_pose) in enumerate(ctx.node_dims):
-            sl = slice(start, start + n)
-            cut = lambda g: None if g is None else g[sl]
-            pose = saved[3 * i + 2] if has_pose else None
-            g_scales, g_quats, g_opac, g_dc, g_add, g_rest, g_means, g_pose = _launch_bwd(
-                saved[3 * i], saved[3 * i + 1], cam, scales[sl], opacities[sl], rgbs[sl], mask[sl], dims, cut(v_scales), cut(v_quats),
-                cut(v_opacities), cut(v_rgbs), pose, cut(v_means), want_means=need[_NK * i])
-            if not has_pose:
-                g_means = None if v_means is None else v_means[sl]
-            g_q, g_t = (g_pose[:4], g_pose[4:]) if g_pose is not None else (None, None)
-            grads += [g_means, g_scales, g_quats, g_opac, g_dc, g_add, g_rest, g_q, g_t]
+        z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous())
+        v_scales, v_quats = z(v_scales, (total, 3)), z(v_quats, (total, 4))
+        v_opacities, v_rgbs = z(v_opacities, (total,)), z(v_rgbs, (total, 3))
+        v_means_c = None if v_means is None else v_means.to(torch.float32).contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_scales, g_quats, g_opac, g_dc = new(total, 3), new(total, 4), new(total), new(total, 3)
+        rest_sizes = [n * Kr * 3 * max(T, 1) for (n, Kr, _, _, T, _, _) in dims]
+        add_sizes = [n * T * 3 if (T and has_add) else 0 for (n, _, _, has_add, T, _, _) in dims]
+        g_rest_flat, g_add_flat = new(sum(rest_sizes)), new(sum(add_sizes))
+        want_gm = bool(rigid) and any(need[_NK * i] for i in rigid)
+        g_means_all = new(total, 3) if want_gm else None
+        g_pose_all = torch.zeros((len(rigid), 7), dtype=torch.float32, device=dev) if rigid else None   # atomics
+        rigid_row = {i: r for r, i in enumerate(rigid)}
+        tab = ctx.tab.copy()
+        pv = [t.data_ptr() for t in (v_scales, v_quats, v_opacities, v_rgbs)]
+        pvm = 0 if v_means_c is None else v_means_c.data_ptr()
+        pg = [t.data_ptr() for t in (g_scales, g_quats, g_opac, g_dc)]
+        p_rest, p_add = g_rest_flat.data_ptr(), g_add_flat.data_ptr()
+        p_gm = 0 if g_means_all is None else g_means_all.data_ptr()
+        p_gp = 0 if g_pose_all is None else g_pose_all.data_ptr()
+        off_rest = off_add = 0
+        for i, (n, Kr, _, has_add, T, trav, start) in enumerate(dims):
+            row = tab[i]
+            row["means"], row["quats_raw"] = saved[2 * i].data_ptr(), saved[2 * i + 1].data_ptr()
+            row["v_scales"], row["v_quats"] = pv[0] + 12 * start, pv[1] + 16 * start
+            row["v_opacities"], row["v_rgbs"] = pv[2] + 4 * start, pv[3] + 12 * start
+            row["v_means"] = pvm + 12 * start if pvm else 0
+            row["g_scales_raw"], row["g_quats_raw"] = pg[0] + 12 * start, pg[1] + 16 * start
+            row["g_opacities_raw"], row["g_features_dc"] = pg[2] + 4 * start, pg[3] + 12 * start
+            row["g_features_rest"] = p_rest + 4 * off_rest
+            row["g_features_dc_add"] = p_add + 4 * off_add if add_sizes[i] else 0
+            if i in rigid_row:
+                row["g_means"] = p_gm + 12 * start if (p_gm and need[_NK * i]) else 0
+                row["g_pose"] = p_gp + 28 * rigid_row[i]
+            off_rest += rest_sizes[i]
+            off_add += add_sizes[i]
+        tab_dev = _upload(tab, dev)
+        call("mtgs_node_bwd_batch", n_nodes, ptr(tab_dev), ctx.blocks, ctx.degree, ptr(cam), stream_of(scales))
+        # per-node views of the flat buffers, in _NODE_KEYS order
+        sizes = [d[0] for d in dims]
+        sp = lambda t: t.split(sizes) if total else [t] * n_nodes
+        s_scales, s_quats, s_opac, s_dc = sp(g_scales), sp(g_quats), sp(g_opac), sp(g_dc)
+        s_rest, s_add = g_rest_flat.split(rest_sizes), g_add_flat.split(add_sizes)
+        s_vm = sp(v_means_c) if v_means_c is not None else [None] * n_nodes
+        s_gm = sp(g_means_all) if g_means_all is not None else [None] * n_nodes
+        grads = []
+        for i, (n, Kr, opac_shape, has_add, T, trav, start) in enumerate(dims):
+            if T:
+                g_r = s_rest[i].view(n, T, Kr, 3)
+                g_a = s_add[i].view(n, T, 3) if has_add else None
+            else:
+                g_r = s_rest[i].view(n, Kr, 3)
+                g_a = s_dc[i] if has_add else None
+            if i in rigid_row:
+                gp = g_pose_all[rigid_row[i]]
+                g_m, g_q, g_t = s_gm[i], gp[:4], gp[4:]
+            else:
+                g_m, g_q, g_t = s_vm[i], None, None
+            grads += [g_m, s_scales[i], s_quats[i], s_opac[i].reshape(opac_shape), s_dc[i], g_a, g_r, g_q, g_t]
         return (None, None) + tuple(g if need[j] else None for j, g in enumerate(grads))
 
 
@@ -188,8 +298,10 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     activated Gaussians of every node, concatenated in order, plus `model_id`.  `nodes` is a sequence of dicts of RAW
     parameters {"means", "scales", "quats", "opacities", "features_dc", "features_rest"} with, for multi-colour nodes,
     "features_adapters" [N,T,3], a 4-D "features_rest" [N,T,K-1,3] and "traversal_index"; for rigid nodes the pose of the
-    current frame "instance_quat" [4] (wxyz) and "instance_trans" [3] (see node_gaussians).  One autograd node for the whole
-    scene: each node's kernel writes into its slice of the collected tensors (no torch.cat of per-node outputs)."""
+    current frame "instance_quat" [4] (wxyz) and "instance_trans" [3] (see node_gaussians).  One autograd node and ONE kernel
+    launch per direction for the whole scene, however many nodes it has (a scene graph holds one rigid node per object
+    instance in view): each node's workgroups write into its slice of the collected tensors (no torch.cat of per-node
+    outputs); "model_id" is written by the same launch."""
     specs, flat, sizes = [], [], []
     use_sh = model_sh_degree > 0
     for nd in nodes:
@@ -217,12 +329,7 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
         flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest, iq, it]
         sizes.append(N)
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
-    means, scales, quats, opacities, rgbs = _CollectNodes.apply(cam_pos, tuple(specs), *flat)
-    model_id = torch.empty(sum(sizes), dtype=torch.int64, device=means.device)   # one fill per node (repeat_interleave
-    start = 0                                                                    # costs 0.6 ms at 2M Gaussians)
-    for i, n in enumerate(sizes):
-        model_id[start:start + n] = i
-        start += n
+    means, scales, quats, opacities, rgbs, model_id = _CollectNodes.apply(cam_pos, tuple(specs), *flat)
     return {"means": means, "scales": scales, "quats": quats, "opacities": opacities, "rgbs": rgbs, "model_id": model_id}
 
 

@@ -202,3 +202,56 @@ def test_rigid_node_colours_use_the_global_means(hip_lib):
                             c2w, 3, 3)
     assert torch.allclose(rigid["rgbs"], static["rgbs"], atol=1e-6) and torch.equal(rigid["scales"], static["scales"])
     assert not torch.allclose(rigid["means"], P["means"])
+
+
+def test_collect_many_small_nodes_one_launch(hip_lib):
+    """A scene graph with 150 nodes -- background, a multi-colour node, and many small rigid object nodes with awkward
+    sizes (0, 1, 63, 64, 65, 255, 256, 257 ...) -- through the batched launch (mtgs_node_fwd_batch / mtgs_node_bwd_batch)
+    equals the per-node calls bit for bit, forward and backward, including the pose gradients and model_id."""
+    from mtgs_amd.nodes import collect_gaussians, node_gaussians
+    dev = torch.device("cuda")
+    c2w = torch.eye(4)[None, :3].clone().to(dev)
+    c2w[0, :3, 3] = torch.tensor([0.4, -1.1, 2.3])
+    g = torch.Generator().manual_seed(21)
+    sizes = [5000, 3001] + [0, 1, 63, 64, 65, 255, 256, 257, 511, 513] + [int(x) for x in torch.randint(1, 900, (138,), generator=g)]
+    base, travs = [], []
+    for i, n in enumerate(sizes):
+        p = _params(n, 16, 3 if i == 1 else 0, 100 + i)
+        if i >= 2:   # rigid object node with the pose of the current frame
+            q = torch.randn(4, generator=g)
+            p["instance_quat"], p["instance_trans"] = q / q.norm(), torch.randn(3, generator=g) * 3
+        base.append(p)
+        travs.append(2 if i == 1 else None)
+    total = sum(sizes)
+    cot = {"means": torch.randn(total, 3, generator=g), "scales": torch.randn(total, 3, generator=g),
+           "quats": torch.randn(total, 4, generator=g), "opacities": torch.randn(total, generator=g),
+           "rgbs": torch.randn(total, 3, generator=g)}
+    res = []
+    for collected in (True, False):
+        P = [{k: v.to(dev).requires_grad_(True) for k, v in p.items()} for p in base]
+        P[5]["quats"].requires_grad_(False)
+        P[7]["means"].requires_grad_(False)
+        if collected:
+            out = collect_gaussians([dict(p, traversal_index=t) if t is not None else p for p, t in zip(P, travs)], c2w, 3, 3)
+        else:
+            parts = [node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, 3, 3,
+                                    features_dc_add=p.get("features_adapters"), traversal_index=t,
+                                    instance_quat=p.get("instance_quat"), instance_trans=p.get("instance_trans"))
+                     for p, t in zip(P, travs)]
+            out = {k: torch.cat([q[k] for q in parts], 0) for k in cot}
+        sum((out[k] * cot[k].to(dev)).sum() for k in cot).backward()
+        res.append(({k: out[k].detach() for k in cot}, [{k: v.grad for k, v in p.items()} for p in P], out))
+    for k in cot:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    for i, (ga, gb) in enumerate(zip(res[0][1], res[1][1])):
+        for k in ga:
+            assert (ga[k] is None) == (gb[k] is None), (i, k)
+            if ga[k] is None:
+                continue
+            if k in ("instance_quat", "instance_trans"):   # per-wave atomics: summation order differs
+                assert torch.allclose(ga[k], gb[k], rtol=1e-4, atol=1e-4 * float(gb[k].abs().max()) + 1e-6), (i, k)
+            else:
+                assert ga[k].shape == gb[k].shape and torch.equal(ga[k], gb[k]), (i, k)
+    mid = res[0][2]["model_id"].cpu()
+    expect = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    assert torch.equal(mid, expect)
