@@ -29,6 +29,8 @@ def _rows(t: Optional[Tensor], width: int):
         return None, width
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32 tensor, got {t.dtype}")
+    if t.is_contiguous():
+        return t, width
     N = t.shape[0]
     inner_ok = t[0].is_contiguous() if N > 0 else True
     if N > 1 and inner_ok and t.stride(0) >= width:
@@ -183,10 +185,11 @@ class _CollectNodes(torch.autograd.Function):
         if rigid:
             pose_all = torch.cat([flat[_NK * i + j].detach().reshape(-1) for i in rigid for j in (7, 8)]).to(torch.float32)
             assert pose_all.numel() == 7 * len(rigid)
-        pose_ptr = {i: pose_all.data_ptr() + 28 * r for r, i in enumerate(rigid)}
         tab = np.zeros(n_nodes, dtype=_DESC)
-        p_means, p_scales, p_quats, p_opac, p_rgbs, p_mask = (t.data_ptr() for t in (means, scales, quats, opacities, rgbs, mask))
-        saved, keep, dims, start, blk = [], [], [], 0, 0
+        saved, keep, dims = [], [], []
+        col = {k: [] for k in ("means", "scales_raw", "quats_raw", "opacities_raw", "features_dc", "features_dc_add", "features_rest",
+                               "dc_stride", "dc_add_stride", "rest_stride", "k_rest", "use_sh", "n_traversals", "traversal")}
+        start = 0
         for i in range(n_nodes):
             m, sr, qr, orw, dc, add, rest, _, _ = flat[_NK * i:_NK * i + _NK]
             _, use_sh, trav = specs[i]
@@ -204,19 +207,24 @@ class _CollectNodes(torch.autograd.Function):
             keep += [sr_c, o_c, dc_c, add_c, rest_c]
             saved += [m_c, qr_c]
             dims.append((n, Kr, orw.shape, add is not None, T, int(trav), start))
-            row = tab[i]
-            row["n"], row["first_block"], row["start"] = n, blk, start
-            row["means"], row["scales_raw"], row["quats_raw"], row["opacities_raw"] = (m_c.data_ptr(), sr_c.data_ptr(),
-                                                                                       qr_c.data_ptr(), o_c.data_ptr())
-            row["features_dc"], row["features_rest"] = dc_c.data_ptr(), rest_c.data_ptr()
-            row["features_dc_add"] = 0 if add_c is None else add_c.data_ptr()
-            row["dc_stride"], row["dc_add_stride"], row["rest_stride"] = s_dc, s_add, s_rest
-            row["pose"] = pose_ptr.get(i, 0)
-            row["k_rest"], row["use_sh"], row["n_traversals"], row["traversal"] = Kr, int(use_sh), T, max(int(trav), 0)
-            row["scales"], row["quats"], row["opacities"] = p_scales + 12 * start, p_quats + 16 * start, p_opac + 4 * start
-            row["rgbs"], row["clamp_mask"], row["means_out"] = p_rgbs + 12 * start, p_mask + start, p_means + 12 * start
+            for k, v in zip(col, (m_c.data_ptr(), sr_c.data_ptr(), qr_c.data_ptr(), o_c.data_ptr(), dc_c.data_ptr(),
+                                  0 if add_c is None else add_c.data_ptr(), rest_c.data_ptr(), s_dc, s_add, s_rest, Kr, int(use_sh),
+                                  T, max(int(trav), 0))):
+                col[k].append(v)
             start += n
-            blk += -(-n // 256)
+        for k, v in col.items():
+            tab[k] = v
+        n_arr = np.asarray(sizes, dtype=np.int64)
+        starts = np.cumsum(n_arr) - n_arr
+        nblk = (n_arr + 255) // 256
+        tab["n"], tab["start"], tab["first_block"] = n_arr, starts, np.cumsum(nblk) - nblk
+        blk = int(nblk.sum())
+        ustarts = starts.astype(np.uint64)
+        for k, t, w in (("scales", scales, 12), ("quats", quats, 16), ("opacities", opacities, 4), ("rgbs", rgbs, 12),
+                        ("clamp_mask", mask, 1), ("means_out", means, 12)):
+            tab[k] = np.uint64(t.data_ptr()) + np.uint64(w) * ustarts
+        if rigid:
+            tab["pose"][rigid] = np.uint64(pose_all.data_ptr()) + np.uint64(28) * np.arange(len(rigid), dtype=np.uint64)
         tab_dev = _upload(tab, dev)
         call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, int(degree), ptr(cam), ptr(model_id), stream_of(means))
         del keep   # (stream-ordered allocator: the launch above is already enqueued)
@@ -245,28 +253,22 @@ class _CollectNodes(torch.autograd.Function):
         g_pose_all = torch.zeros((len(rigid), 7), dtype=torch.float32, device=dev) if rigid else None   # atomics
         rigid_row = {i: r for r, i in enumerate(rigid)}
         tab = ctx.tab.copy()
-        pv = [t.data_ptr() for t in (v_scales, v_quats, v_opacities, v_rgbs)]
-        pvm = 0 if v_means_c is None else v_means_c.data_ptr()
-        pg = [t.data_ptr() for t in (g_scales, g_quats, g_opac, g_dc)]
-        p_rest, p_add = g_rest_flat.data_ptr(), g_add_flat.data_ptr()
-        p_gm = 0 if g_means_all is None else g_means_all.data_ptr()
-        p_gp = 0 if g_pose_all is None else g_pose_all.data_ptr()
-        off_rest = off_add = 0
-        for i, (n, Kr, _, has_add, T, trav, start) in enumerate(dims):
-            row = tab[i]
-            row["means"], row["quats_raw"] = saved[2 * i].data_ptr(), saved[2 * i + 1].data_ptr()
-            row["v_scales"], row["v_quats"] = pv[0] + 12 * start, pv[1] + 16 * start
-            row["v_opacities"], row["v_rgbs"] = pv[2] + 4 * start, pv[3] + 12 * start
-            row["v_means"] = pvm + 12 * start if pvm else 0
-            row["g_scales_raw"], row["g_quats_raw"] = pg[0] + 12 * start, pg[1] + 16 * start
-            row["g_opacities_raw"], row["g_features_dc"] = pg[2] + 4 * start, pg[3] + 12 * start
-            row["g_features_rest"] = p_rest + 4 * off_rest
-            row["g_features_dc_add"] = p_add + 4 * off_add if add_sizes[i] else 0
-            if i in rigid_row:
-                row["g_means"] = p_gm + 12 * start if (p_gm and need[_NK * i]) else 0
-                row["g_pose"] = p_gp + 28 * rigid_row[i]
-            off_rest += rest_sizes[i]
-            off_add += add_sizes[i]
+        ustarts = tab["start"].astype(np.uint64)
+        at = lambda t, w: np.uint64(t.data_ptr()) + np.uint64(w) * ustarts
+        tab["means"] = [t.data_ptr() for t in saved[0::2]]
+        tab["quats_raw"] = [t.data_ptr() for t in saved[1::2]]
+        tab["v_scales"], tab["v_quats"], tab["v_opacities"], tab["v_rgbs"] = at(v_scales, 12), at(v_quats, 16), at(v_opacities, 4), at(v_rgbs, 12)
+        tab["v_means"] = at(v_means_c, 12) if v_means_c is not None else 0
+        tab["g_scales_raw"], tab["g_quats_raw"], tab["g_opacities_raw"], tab["g_features_dc"] = (at(g_scales, 12), at(g_quats, 16),
+                                                                                               at(g_opac, 4), at(g_dc, 12))
+        rs, ads = np.asarray(rest_sizes, dtype=np.uint64), np.asarray(add_sizes, dtype=np.uint64)
+        tab["g_features_rest"] = np.uint64(g_rest_flat.data_ptr()) + np.uint64(4) * (np.cumsum(rs) - rs)
+        tab["g_features_dc_add"] = np.where(ads > 0, np.uint64(g_add_flat.data_ptr()) + np.uint64(4) * (np.cumsum(ads) - ads), np.uint64(0))
+        if rigid:
+            if g_means_all is not None:
+                want = np.asarray([bool(need[_NK * i]) for i in rigid])
+                tab["g_means"][rigid] = np.where(want, at(g_means_all, 12)[rigid], np.uint64(0))
+            tab["g_pose"][rigid] = np.uint64(g_pose_all.data_ptr()) + np.uint64(28) * np.arange(len(rigid), dtype=np.uint64)
         tab_dev = _upload(tab, dev)
         call("mtgs_node_bwd_batch", n_nodes, ptr(tab_dev), ctx.blocks, ctx.degree, ptr(cam), stream_of(scales))
         # per-node views of the flat buffers, in _NODE_KEYS order
