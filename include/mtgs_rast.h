@@ -331,6 +331,18 @@ int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_
 int mtgs_densify_stats(int64_t n, const int32_t *radii, const float *grad2d, int width, int height,
                        float *xys_grad_norm, float *vis_counts, float *max_2dsize, void *stream);
 
+/* The same for every node of the scene graph in ONE launch (update_submodel_statistics loops over the nodes,
+ * mtgs_scene_graph.py:1157-1183): a table of descriptors in device memory, in any order; node i owns rows
+ * [start, start + n) of radii / grad2d (the collected arrays) and its own three statistics arrays [n].
+ * total_blocks = sum over nodes of ceil(n / 256); first_block = the running sum. */
+typedef struct mtgs_stats_desc {
+    int64_t n, first_block, start;
+    float *xys_grad_norm, *vis_counts, *max_2dsize;
+} mtgs_stats_desc;
+int mtgs_stats_desc_bytes(void);
+int mtgs_densify_stats_batch(int n_nodes, const mtgs_stats_desc *table, int64_t total_blocks, const int32_t *radii,
+                             const float *grad2d, int width, int height, void *stream);
+
 /* ---- masked SSIM of the loss head, fused ---------------------------------------------
  * mtgs.utils.ssim.MaskedSSIM(data_range=1.0, size_average=True, channel=3)(gt, pred, mask)  (mtgs/utils/ssim.py:57-190,
  * mtgs_scene_graph.py:322, :831-841).  gt, pred: [H,W,3] f32 (the rasterizer's layout: no NCHW copies); mask[H,W] u8

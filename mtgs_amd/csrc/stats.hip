@@ -27,7 +27,43 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int64_t n, const int
     vis_counts[i] += 1.f;
     max_2dsize[i] = fmaxf(max_2dsize[i], (float)r);
 }
+// every node of the scene graph in one launch: workgroup b serves 256 Gaussians of the node with
+// first_block <= b < next first_block (include/mtgs_rast.h: mtgs_stats_desc)
+__global__ __launch_bounds__(256) void densify_stats_batch_kernel(const mtgs_stats_desc *__restrict__ table, int n_nodes,
+                                                                  const int32_t *__restrict__ radii,
+                                                                  const float *__restrict__ grad2d, float half_w, float half_h) {
+    int lo = 0, hi = n_nodes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mtgs_stats_desc &d = table[__builtin_amdgcn_readfirstlane(lo)];
+    const int64_t i = ((int64_t)blockIdx.x - d.first_block) * 256 + threadIdx.x;
+    if (i >= d.n) return;
+    const int32_t r = radii[d.start + i];
+    if (r <= 0) return;
+    const float2 g = reinterpret_cast<const float2 *>(grad2d)[d.start + i];
+    const float gx = g.x * half_w, gy = g.y * half_h;
+    d.xys_grad_norm[i] += sqrtf(gx * gx + gy * gy);
+    d.vis_counts[i] += 1.f;
+    d.max_2dsize[i] = fmaxf(d.max_2dsize[i], (float)r);
+}
 }  // namespace
+
+extern "C" int mtgs_stats_desc_bytes(void) { return (int)sizeof(mtgs_stats_desc); }
+
+extern "C" int mtgs_densify_stats_batch(int n_nodes, const mtgs_stats_desc *table, int64_t total_blocks, const int32_t *radii,
+                                        const float *grad2d, int width, int height, void *stream) {
+    MTGS_REQUIRE(n_nodes >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31) && width > 0 && height > 0, MTGS_EINVAL,
+                 "mtgs_densify_stats_batch: bad sizes");
+    if (n_nodes == 0 || total_blocks == 0) return MTGS_OK;
+    MTGS_REQUIRE(table && radii && grad2d, MTGS_EINVAL, "mtgs_densify_stats_batch: null pointer");
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(grad2d) & 7) == 0, MTGS_EINVAL, "mtgs_densify_stats_batch: grad2d must be 8-byte aligned");
+    densify_stats_batch_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>(table, n_nodes, radii, grad2d,
+                                                                                      0.5f * (float)width, 0.5f * (float)height);
+    MTGS_CHECK_LAUNCH("mtgs_densify_stats_batch");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_densify_stats(int64_t n, const int32_t *radii, const float *grad2d, int width, int height,
                                   float *xys_grad_norm, float *vis_counts, float *max_2dsize, void *stream) {

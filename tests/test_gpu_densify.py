@@ -42,3 +42,28 @@ def test_update_statistics_matches_reference(hip_lib, sizes):
     for sr, sd in zip(stats_ref, stats_dev):
         for a, b, name in zip(sr, sd, ("xys_grad_norm", "vis_counts", "max_2Dsize")):
             assert torch.allclose(a, b.cpu(), rtol=1e-6, atol=1e-7), name
+
+
+def test_update_statistics_all_nodes_one_launch(hip_lib):
+    """update_statistics_all (one launch for the scene graph) == update_statistics per node, bit for bit, with 120 nodes
+    of awkward sizes (0, 1, 255, 256, 257 ...)."""
+    from mtgs_amd.densify import update_statistics, update_statistics_all
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(9)
+    sizes = [4000, 0, 1, 255, 256, 257, 63, 64] + [int(x) for x in torch.randint(1, 700, (112,), generator=g)]
+    N, W, H = sum(sizes), 960, 540
+    mk = lambda: [[torch.rand(n, generator=g).to(dev), (torch.ones(n) + torch.randint(0, 5, (n,), generator=g).float()).to(dev),
+                   (torch.rand(n, generator=g) * 30).to(dev)] for n in sizes]
+    a = mk()
+    b = [[t.clone() for t in s] for s in a]
+    for step in range(2):
+        radii = (torch.randint(0, 40, (1, N), generator=g) * (torch.rand(1, N, generator=g) < 0.3)).int().to(dev)
+        absgrad = (torch.rand(1, N, 2, generator=g) * 1e-3).to(dev)
+        start = 0
+        for i, n in enumerate(sizes):
+            update_statistics(*a[i], radii, absgrad, W, H, start=start)
+            start += n
+        update_statistics_all([tuple(s) for s in b], radii, absgrad, W, H)
+    for sa, sb in zip(a, b):
+        for x, y in zip(sa, sb):
+            assert torch.equal(x, y)
