@@ -306,14 +306,20 @@ typedef struct mtgs_node_desc {
     const float *means, *scales_raw, *quats_raw, *opacities_raw;
     const float *features_dc, *features_dc_add, *features_rest;
     int64_t dc_stride, dc_add_stride, rest_stride;          /* row strides in floats */
-    const float *pose;         /* [7] instance quaternion wxyz | translation of a rigid node, or NULL */
+    const float *pose;         /* [4] instance quaternion wxyz of a rigid node, or NULL (static node) */
+    const float *pose_trans;   /* [3] instance translation */
     int32_t k_rest, use_sh, n_traversals, traversal;
+    int32_t pose_normalize;    /* 1: `pose` is a raw row of the per-frame parameters instance_quats[frame]: the kernel normalises
+                                * it as RigidSubModel.get_object_pose does (rigid_node.py:142) */
+    int32_t reserved;
     float *scales, *quats, *opacities, *rgbs;               /* forward outputs = activations saved for the backward */
     uint8_t *clamp_mask;
     float *means_out;          /* global means (written when non-NULL) */
     const float *v_scales, *v_quats, *v_opacities, *v_rgbs, *v_means;
     float *g_scales_raw, *g_quats_raw, *g_opacities_raw, *g_features_dc, *g_features_rest, *g_features_dc_add, *g_means,
-        *g_pose;
+        *g_pose;               /* g_pose[7]: zeroed accumulator (atomics), gradient of (normalised quaternion | translation) */
+    float *g_pose_quat_row, *g_pose_trans_row;   /* pose_normalize: rows [4] / [3] of the gradients of the per-frame parameters,
+                                                  * written after the launch from g_pose (nullable) */
 } mtgs_node_desc;
 int mtgs_node_desc_bytes(void);   /* sizeof(mtgs_node_desc): bindings check their layout against it */
 /* total_blocks = sum over nodes of ceil(n / 256); `degree` = sh_degree_to_use of the step (all nodes);

@@ -52,15 +52,21 @@ struct NodeParams {
     const float *cam_pos;                                    // [3] device
     int Kr;                                                  // SH bases in `rest` (K - 1)
     int use_sh;                                              // 0: rgbs = sigmoid(dc [+ dc_add])
-    const float *pose;                                       // [7] device: instance quaternion wxyz | translation; nullable
+    const float *pose;                                       // [4] device: instance quaternion wxyz; nullable (static node)
+    const float *pose_t;                                     // [3] device: instance translation
+    int pose_norm;                                           // 1: the quaternion is a raw parameter row, normalise it
 };
 
 // Rigid nodes (rigid_node.py:205-216): global mean = R(q) m + t with mtgs utils.quat_to_rotmat (NO normalisation of q:
 // get_object_pose hands over a unit quaternion), global quaternion = utils.quat_mult(q, q_local / |q_local|).
 struct Pose { float w, x, y, z, tx, ty, tz; float R[9]; };
-__device__ __forceinline__ Pose load_pose(const float *p) {
+__device__ __forceinline__ Pose load_pose(const float *q, const float *t, int normalize) {
     Pose o;
-    o.w = p[0]; o.x = p[1]; o.y = p[2]; o.z = p[3]; o.tx = p[4]; o.ty = p[5]; o.tz = p[6];
+    o.w = q[0]; o.x = q[1]; o.y = q[2]; o.z = q[3]; o.tx = t[0]; o.ty = t[1]; o.tz = t[2];
+    if (normalize) {   // RigidSubModel.get_object_pose: instance_quats[frame] / |instance_quats[frame]| (rigid_node.py:142)
+        const float inv = 1.0f / sqrtf(((o.w * o.w + o.x * o.x) + o.y * o.y) + o.z * o.z);
+        o.w *= inv; o.x *= inv; o.y *= inv; o.z *= inv;
+    }
     const float xx = o.x * o.x, yy = o.y * o.y, zz = o.z * o.z, xy = o.x * o.y, xz = o.x * o.z, yz = o.y * o.z;
     const float wx = o.w * o.x, wy = o.w * o.y, wz = o.w * o.z;
     o.R[0] = 1.f - 2.f * (yy + zz); o.R[1] = 2.f * (xy - wz); o.R[2] = 2.f * (xz + wy);
@@ -106,7 +112,7 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
     // unit view direction, once per Gaussian in the lane-per-Gaussian mapping (the rows fetch it by ds_bpermute)
     float dx = 0.f, dy = 0.f, dz = 1.f;
     Pose ps;
-    if (P.pose) ps = load_pose(P.pose);
+    if (P.pose) ps = load_pose(P.pose, P.pose_t, P.pose_norm);
     if ((P.use_sh || P.pose || means_out) && okl) {
         F3 mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
         if (P.pose)   // rigid node: the Gaussian lives in the object frame
@@ -206,7 +212,7 @@ __device__ __forceinline__ int node_of_block(const mtgs_node_desc *__restrict__ 
 }
 __device__ __forceinline__ NodeParams params_of(const mtgs_node_desc &d, const float *cam_pos) {
     return NodeParams{d.means, d.scales_raw, d.quats_raw, d.opacities_raw, d.features_dc, d.features_dc_add, d.features_rest,
-                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, d.pose};
+                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, d.pose, d.pose_trans, d.pose_normalize};
 }
 
 template <int DEG>
@@ -250,7 +256,7 @@ __device__ __forceinline__ void node_bwd_wave(const int64_t N, const NodeParams 
     const bool okl = gl < N;
     F3 v = F3{0.f, 0.f, 0.f}, mn = F3{0.f, 0.f, 1.f};
     Pose ps;
-    if (P.pose) ps = load_pose(P.pose);
+    if (P.pose) ps = load_pose(P.pose, P.pose_t, P.pose_norm);
     float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f, pq3 = 0.f, pt0 = 0.f, pt1 = 0.f, pt2 = 0.f;   // this Gaussian's part of d pose
     if (okl) {
         v = *reinterpret_cast<const F3 *>(v_rgbs + gl * 3);
@@ -402,6 +408,23 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_batch_kernel(const mtgs_n
     node_bwd_wave<DEG>(d.n, P, g0, d.scales, d.opacities, d.rgbs, d.clamp_mask, G);
 }
 
+// After the batched backward: for the nodes whose pose is a row of the per-frame parameter tables, turn the accumulated
+// gradient of the NORMALISED quaternion into the gradient of the raw row (d (q / |q|)) and store both rows.
+__global__ void node_pose_finalize_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const mtgs_node_desc &d = table[i];
+    if (!d.pose || !d.pose_normalize || !d.g_pose) return;
+    const float w = d.pose[0], x = d.pose[1], y = d.pose[2], z = d.pose[3];
+    const float inv = 1.0f / sqrtf(((w * w + x * x) + y * y) + z * z);
+    const float qn[4] = {w * inv, x * inv, y * inv, z * inv};
+    const float dot = ((d.g_pose[0] * qn[0] + d.g_pose[1] * qn[1]) + d.g_pose[2] * qn[2]) + d.g_pose[3] * qn[3];
+    if (d.g_pose_quat_row)
+        for (int k = 0; k < 4; ++k) d.g_pose_quat_row[k] = (d.g_pose[k] - dot * qn[k]) * inv;
+    if (d.g_pose_trans_row)
+        for (int k = 0; k < 3; ++k) d.g_pose_trans_row[k] = d.g_pose[4 + k];
+}
+
 }  // namespace
 
 #define MTGS_NODE_DISPATCH(KERNEL, ...)                                                 \
@@ -434,7 +457,7 @@ extern "C" int mtgs_node_fwd(int64_t N, int K_rest, int degree, int use_sh, cons
                      scales && quats && opacities && rgbs && clamp_mask,
                  MTGS_EINVAL, "mtgs_node_fwd: null pointer");
     const NodeParams P{means, scales_raw, quats_raw, opacities_raw, features_dc, features_dc_add, features_rest,
-                       row_strides[0], row_strides[1], row_strides[2], cam_pos, K_rest, use_sh, pose};
+                       row_strides[0], row_strides[1], row_strides[2], cam_pos, K_rest, use_sh, pose, pose ? pose + 4 : nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
     MTGS_NODE_DISPATCH(node_fwd_kernel, N, P, scales, quats, opacities, rgbs, clamp_mask, means_out)
@@ -458,7 +481,8 @@ extern "C" int mtgs_node_bwd(int64_t N, int K_rest, int degree, int use_sh, cons
                  MTGS_EINVAL, "mtgs_node_bwd: null pointer");
     MTGS_REQUIRE(n_traversals >= 0 && (n_traversals == 0 || (traversal >= 0 && traversal < n_traversals)), MTGS_EINVAL,
                  "mtgs_node_bwd: traversal %d of %d", traversal, n_traversals);
-    const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh, pose};
+    const NodeParams P{means, nullptr, quats_raw, nullptr, nullptr, nullptr, nullptr, 3, 3, (int64_t)K_rest * 3, cam_pos, K_rest, use_sh, pose,
+                       pose ? pose + 4 : nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(N, NODE_PER_WAVE * (NODE_BLOCK / 64));
     const NodeGrads G{v_scales, v_quats, v_opacities, v_rgbs, v_means, g_scales_raw, g_quats_raw, g_opacities_raw, g_features_dc,
@@ -492,6 +516,7 @@ extern "C" int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)total_blocks;
     MTGS_NODE_DISPATCH(node_bwd_batch_kernel, table, n_nodes, cam_pos)
+    node_pose_finalize_kernel<<<(unsigned)((n_nodes + 255) / 256), 256, 0, st>>>(table, n_nodes);
     MTGS_CHECK_LAUNCH("mtgs_node_bwd_batch");
     return MTGS_OK;
 }

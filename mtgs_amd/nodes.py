@@ -137,11 +137,12 @@ _NK = len(_NODE_KEYS)
 _DESC = np.dtype([(k, "<i8") for k in ("n", "first_block", "start")]
                  + [(k, "<u8") for k in ("means", "scales_raw", "quats_raw", "opacities_raw", "features_dc", "features_dc_add",
                                          "features_rest")]
-                 + [(k, "<i8") for k in ("dc_stride", "dc_add_stride", "rest_stride")] + [("pose", "<u8")]
-                 + [(k, "<i4") for k in ("k_rest", "use_sh", "n_traversals", "traversal")]
+                 + [(k, "<i8") for k in ("dc_stride", "dc_add_stride", "rest_stride")] + [("pose", "<u8"), ("pose_trans", "<u8")]
+                 + [(k, "<i4") for k in ("k_rest", "use_sh", "n_traversals", "traversal", "pose_normalize", "reserved")]
                  + [(k, "<u8") for k in ("scales", "quats", "opacities", "rgbs", "clamp_mask", "means_out", "v_scales", "v_quats",
                                          "v_opacities", "v_rgbs", "v_means", "g_scales_raw", "g_quats_raw", "g_opacities_raw",
-                                         "g_features_dc", "g_features_rest", "g_features_dc_add", "g_means", "g_pose")], align=True)
+                                         "g_features_dc", "g_features_rest", "g_features_dc_add", "g_means", "g_pose", "g_pose_quat_row",
+                                         "g_pose_trans_row")], align=True)
 _desc_checked = False
 
 
@@ -164,7 +165,7 @@ class _CollectNodes(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam_pos, specs, *flat):
-        # specs[i] = (degree, use_sh, trav); flat = _NK tensors (or None) per node in _NODE_KEYS order
+        # specs[i] = (degree, use_sh, trav, frame); flat = _NK tensors (or None) per node in _NODE_KEYS order
         n_nodes = len(specs)
         require_gpu(cam_pos, *[t for t in flat if t is not None])
         sizes = [flat[_NK * i].shape[0] for i in range(n_nodes)]
@@ -179,12 +180,18 @@ class _CollectNodes(torch.autograd.Function):
         rgbs = torch.empty((total, 3), dtype=torch.float32, device=dev)
         mask = torch.empty((total,), dtype=torch.uint8, device=dev)
         model_id = torch.empty((total,), dtype=torch.int64, device=dev)
-        # the poses of the rigid nodes, gathered with one cat: [R, 7] = quaternion wxyz | translation
+        # rigid nodes: either the pose of the frame is given (instance_quat[4], instance_trans[3]: gathered with ONE cat into
+        # [R', 7]) or the per-frame parameter tables + frame index (specs[i][3] >= 0: the kernel reads and normalises row `frame`)
         rigid = [i for i in range(n_nodes) if flat[_NK * i + 7] is not None]
+        given = [i for i in rigid if specs[i][3] < 0]
+        framed = [i for i in rigid if specs[i][3] >= 0]
         pose_all = None
-        if rigid:
-            pose_all = torch.cat([flat[_NK * i + j].detach().reshape(-1) for i in rigid for j in (7, 8)]).to(torch.float32)
-            assert pose_all.numel() == 7 * len(rigid)
+        if given:
+            pose_all = torch.cat([flat[_NK * i + j].detach().reshape(-1) for i in given for j in (7, 8)]).to(torch.float32)
+            assert pose_all.numel() == 7 * len(given)
+        pose_tabs = []
+        for i in framed:
+            pose_tabs += [flat[_NK * i + 7].detach().to(torch.float32).contiguous(), flat[_NK * i + 8].detach().to(torch.float32).contiguous()]
         tab = np.zeros(n_nodes, dtype=_DESC)
         saved, keep, dims = [], [], []
         col = {k: [] for k in ("means", "scales_raw", "quats_raw", "opacities_raw", "features_dc", "features_dc_add", "features_rest",
@@ -192,7 +199,7 @@ class _CollectNodes(torch.autograd.Function):
         start = 0
         for i in range(n_nodes):
             m, sr, qr, orw, dc, add, rest, _, _ = flat[_NK * i:_NK * i + _NK]
-            _, use_sh, trav = specs[i]
+            _, use_sh, trav, _ = specs[i]
             n = sizes[i]
             Kr = rest.shape[-2]
             T = rest.shape[1] if trav >= 0 else 0
@@ -223,20 +230,28 @@ class _CollectNodes(torch.autograd.Function):
         for k, t, w in (("scales", scales, 12), ("quats", quats, 16), ("opacities", opacities, 4), ("rgbs", rgbs, 12),
                         ("clamp_mask", mask, 1), ("means_out", means, 12)):
             tab[k] = np.uint64(t.data_ptr()) + np.uint64(w) * ustarts
-        if rigid:
-            tab["pose"][rigid] = np.uint64(pose_all.data_ptr()) + np.uint64(28) * np.arange(len(rigid), dtype=np.uint64)
+        if given:
+            base = np.uint64(pose_all.data_ptr()) + np.uint64(28) * np.arange(len(given), dtype=np.uint64)
+            tab["pose"][given], tab["pose_trans"][given] = base, base + np.uint64(16)
+        if framed:
+            fr = [specs[i][3] for i in framed]
+            tab["pose"][framed] = [q.data_ptr() + 16 * f for q, f in zip(pose_tabs[0::2], fr)]
+            tab["pose_trans"][framed] = [t.data_ptr() + 12 * f for t, f in zip(pose_tabs[1::2], fr)]
+            tab["pose_normalize"][framed] = 1
         tab_dev = _upload(tab, dev)
         call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, int(degree), ptr(cam), ptr(model_id), stream_of(means))
         del keep   # (stream-ordered allocator: the launch above is already enqueued)
         ctx.tab, ctx.dims, ctx.blocks, ctx.degree, ctx.rigid = tab, dims, blk, int(degree), rigid
-        ctx.save_for_backward(cam, scales, opacities, rgbs, mask, pose_all, *saved)
+        ctx.framed = [(i, specs[i][3], flat[_NK * i + 7].shape[0]) for i in framed]
+        ctx.save_for_backward(cam, scales, opacities, rgbs, mask, pose_all, *saved, *pose_tabs)
         ctx.mark_non_differentiable(model_id)
         return means, scales, quats, opacities, rgbs, model_id
 
     @staticmethod
     def backward(ctx, v_means, v_scales, v_quats, v_opacities, v_rgbs, _v_id):
         cam, scales, opacities, rgbs, mask, pose_all, *saved = ctx.saved_tensors
-        dims, rigid = ctx.dims, ctx.rigid
+        dims, rigid, framed = ctx.dims, ctx.rigid, ctx.framed
+        saved = saved[:2 * len(dims)]   # (the pose tables behind them are only kept alive: the table holds their addresses)
         n_nodes, total, dev = len(dims), scales.shape[0], scales.device
         need = ctx.needs_input_grad[2:]
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous())
@@ -269,6 +284,16 @@ class _CollectNodes(torch.autograd.Function):
                 want = np.asarray([bool(need[_NK * i]) for i in rigid])
                 tab["g_means"][rigid] = np.where(want, at(g_means_all, 12)[rigid], np.uint64(0))
             tab["g_pose"][rigid] = np.uint64(g_pose_all.data_ptr()) + np.uint64(28) * np.arange(len(rigid), dtype=np.uint64)
+        gq_tab = gt_tab = None
+        if framed:   # gradients of the per-frame pose parameters: zero but for row `frame` (written after the launch)
+            frames = sum(F for _, _, F in framed)
+            gq_tab = torch.zeros((frames, 4), dtype=torch.float32, device=dev)
+            gt_tab = torch.zeros((frames, 3), dtype=torch.float32, device=dev)
+            F_arr = np.asarray([F for _, _, F in framed], dtype=np.uint64)
+            rows = (np.cumsum(F_arr) - F_arr) + np.asarray([f for _, f, _ in framed], dtype=np.uint64)
+            idx = [i for i, _, _ in framed]
+            tab["g_pose_quat_row"][idx] = np.uint64(gq_tab.data_ptr()) + np.uint64(16) * rows
+            tab["g_pose_trans_row"][idx] = np.uint64(gt_tab.data_ptr()) + np.uint64(12) * rows
         tab_dev = _upload(tab, dev)
         call("mtgs_node_bwd_batch", n_nodes, ptr(tab_dev), ctx.blocks, ctx.degree, ptr(cam), stream_of(scales))
         # per-node views of the flat buffers, in _NODE_KEYS order
@@ -278,6 +303,11 @@ class _CollectNodes(torch.autograd.Function):
         s_rest, s_add = g_rest_flat.split(rest_sizes), g_add_flat.split(add_sizes)
         s_vm = sp(v_means_c) if v_means_c is not None else [None] * n_nodes
         s_gm = sp(g_means_all) if g_means_all is not None else [None] * n_nodes
+        framed_grads = {}
+        if framed:
+            Fs = [F for _, _, F in framed]
+            for (i, _, _), gq, gt in zip(framed, gq_tab.split(Fs), gt_tab.split(Fs)):
+                framed_grads[i] = (gq, gt)
         grads = []
         for i, (n, Kr, opac_shape, has_add, T, trav, start) in enumerate(dims):
             if T:
@@ -286,7 +316,9 @@ class _CollectNodes(torch.autograd.Function):
             else:
                 g_r = s_rest[i].view(n, Kr, 3)
                 g_a = s_dc[i] if has_add else None
-            if i in rigid_row:
+            if i in framed_grads:
+                g_m, (g_q, g_t) = s_gm[i], framed_grads[i]
+            elif i in rigid_row:
                 gp = g_pose_all[rigid_row[i]]
                 g_m, g_q, g_t = s_gm[i], gp[:4], gp[4:]
             else:
@@ -299,8 +331,11 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     """MTGSSceneModel.get_gaussians for static nodes (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:408-461): the
     activated Gaussians of every node, concatenated in order, plus `model_id`.  `nodes` is a sequence of dicts of RAW
     parameters {"means", "scales", "quats", "opacities", "features_dc", "features_rest"} with, for multi-colour nodes,
-    "features_adapters" [N,T,3], a 4-D "features_rest" [N,T,K-1,3] and "traversal_index"; for rigid nodes the pose of the
-    current frame "instance_quat" [4] (wxyz) and "instance_trans" [3] (see node_gaussians).  One autograd node and ONE kernel
+    "features_adapters" [N,T,3], a 4-D "features_rest" [N,T,K-1,3] and "traversal_index"; for rigid nodes either the pose of the
+    current frame "instance_quat" [4] (wxyz) and "instance_trans" [3] (see node_gaussians), or the per-frame pose PARAMETERS
+    "instance_quats" [F,4], "instance_trans" [F,3] and "frame_idx": the kernel then reads row frame_idx and normalises the
+    quaternion as RigidSubModel.get_object_pose does (rigid_node.py:139-144), and the backward returns the gradients of the
+    full tables (zero but for that row).  One autograd node and ONE kernel
     launch per direction for the whole scene, however many nodes it has (a scene graph holds one rigid node per object
     instance in view): each node's workgroups write into its slice of the collected tensors (no torch.cat of per-node
     outputs); "model_id" is written by the same launch."""
@@ -325,9 +360,15 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
         if use_sh:
             assert (sh_degree_to_use + 1) ** 2 <= Kr + 1, (sh_degree_to_use, rest.shape)
         assert nd["scales"].shape == (N, 3) and nd["quats"].shape == (N, 4) and nd["opacities"].numel() == N
-        specs.append((int(sh_degree_to_use), bool(use_sh), -1 if trav is None else int(trav)))
-        iq, it = nd.get("instance_quat"), nd.get("instance_trans")
-        assert (iq is None) == (it is None) and (iq is None or (iq.numel() == 4 and it.numel() == 3)), "rigid pose: quat[4] + trans[3]"
+        iq, it, frame = nd.get("instance_quat"), nd.get("instance_trans"), -1
+        if nd.get("instance_quats") is not None:   # per-frame pose parameters [F,4] / [F,3] + the frame of this step
+            assert iq is None, "pass either instance_quat (the pose) or instance_quats + frame_idx (the parameters)"
+            iq, frame = nd["instance_quats"], int(nd["frame_idx"])
+            assert iq.dim() == 2 and iq.shape[1] == 4 and it is not None and it.shape == (iq.shape[0], 3), (iq.shape, None if it is None else it.shape)
+            assert 0 <= frame < iq.shape[0], (frame, iq.shape)
+        else:
+            assert (iq is None) == (it is None) and (iq is None or (iq.numel() == 4 and it.numel() == 3)), "rigid pose: quat[4] + trans[3]"
+        specs.append((int(sh_degree_to_use), bool(use_sh), -1 if trav is None else int(trav), frame))
         flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest, iq, it]
         sizes.append(N)
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]

@@ -255,3 +255,52 @@ def test_collect_many_small_nodes_one_launch(hip_lib):
     mid = res[0][2]["model_id"].cpu()
     expect = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     assert torch.equal(mid, expect)
+
+
+def test_collect_rigid_nodes_with_per_frame_pose_parameters(hip_lib):
+    """Rigid nodes given as their per-frame pose PARAMETERS + frame_idx: the batched launch reads row frame_idx, normalises
+    the quaternion (RigidSubModel.get_object_pose, rigid_node.py:139-144) and returns the gradients of the full tables.
+    Reference: the same indexing / normalisation in torch in front of the explicit-pose path."""
+    from mtgs_amd.nodes import collect_gaussians
+    dev = torch.device("cuda")
+    c2w = torch.eye(4)[None, :3].clone().to(dev)
+    c2w[0, :3, 3] = torch.tensor([0.4, -1.1, 2.3])
+    g = torch.Generator().manual_seed(33)
+    sizes = [2000, 700, 65, 1, 300]
+    frames = [None, 12, 40, 3, 7]          # node 0 is static
+    fidx = [None, 5, 39, 0, 6]
+    base = []
+    for i, (n, F) in enumerate(zip(sizes, frames)):
+        p = _params(n, 16, 0, 200 + i)
+        if F is not None:
+            p["instance_quats"], p["instance_trans"] = torch.randn(F, 4, generator=g) * 1.7, torch.randn(F, 3, generator=g) * 3
+        base.append(p)
+    total = sum(sizes)
+    cot = {k: torch.randn(total, w, generator=g).squeeze(-1) for k, w in (("means", 3), ("scales", 3), ("quats", 4), ("opacities", 1), ("rgbs", 3))}
+    res = []
+    for in_kernel in (True, False):
+        P = [{k: v.to(dev).requires_grad_(True) for k, v in p.items()} for p in base]
+        nodes = []
+        for p, f in zip(P, fidx):
+            if f is None:
+                nodes.append(p)
+            elif in_kernel:
+                nodes.append(dict(p, frame_idx=f))
+            else:
+                q = p["instance_quats"][f] / p["instance_quats"][f].norm(dim=-1, keepdim=True)
+                nd = {k: v for k, v in p.items() if k not in ("instance_quats", "instance_trans")}
+                nodes.append(dict(nd, instance_quat=q, instance_trans=p["instance_trans"][f]))
+        out = collect_gaussians(nodes, c2w, 3, 3)
+        sum((out[k] * cot[k].to(dev)).sum() for k in cot).backward()
+        res.append(({k: out[k].detach() for k in cot}, [{k: v.grad for k, v in p.items()} for p in P]))
+    for k in cot:
+        assert torch.allclose(res[0][0][k], res[1][0][k], rtol=1e-5, atol=1e-5), k
+    for i, (ga, gb) in enumerate(zip(res[0][1], res[1][1])):
+        for k in ga:
+            assert ga[k] is not None and gb[k] is not None, (i, k)
+            scale = float(gb[k].abs().max()) + 1e-12
+            assert ga[k].shape == gb[k].shape and float((ga[k] - gb[k]).abs().max()) <= 2e-4 * scale, (i, k)
+        if frames[i] is not None:   # only the row of the frame carries a gradient
+            other = torch.ones(frames[i], dtype=torch.bool); other[fidx[i]] = False
+            assert not ga["instance_quats"][other.to(dev)].any() and not ga["instance_trans"][other.to(dev)].any()
+            assert ga["instance_quats"][fidx[i]].abs().sum() > 0
