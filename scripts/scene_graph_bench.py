@@ -4,7 +4,7 @@ road node and `--objects` rigid nodes of a few thousand Gaussians each (one per 
 backward of the per-node activations, wall-clock per step (host + GPU: with hundreds of nodes the HOST is the limit):
 
   chain   : the reference's PyTorch operator chain per node (exp / normalise / sigmoid / cat / SH / clamp; rigid nodes:
-            quat_to_rotmat, matmul, quat_mult) + torch.cat of the per-node outputs, SH through the HIP spherical_harmonics
+            get_object_pose -- index + normalise the per-frame pose parameters --, quat_to_rotmat, matmul, quat_mult) + torch.cat of the per-node outputs, SH through the HIP spherical_harmonics
   pernode : mtgs_amd.nodes.node_gaussians per node (one fused kernel per node and direction) + torch.cat
   batched : mtgs_amd.nodes.collect_gaussians (ONE launch per direction for the whole scene graph)
 """
@@ -24,6 +24,7 @@ ap.add_argument("--objects", type=int, default=150)
 ap.add_argument("--object-size", type=int, default=3000)
 ap.add_argument("--background", type=int, default=1_200_000)
 ap.add_argument("--road", type=int, default=350_000)
+ap.add_argument("--frames", type=int, default=200, help="frames of every object's pose parameters instance_quats[F,4] / instance_trans[F,3]")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="chain,pernode,batched")
 args = ap.parse_args()
@@ -36,15 +37,15 @@ def params(n, rigid):
     p = {"means": torch.randn(n, 3, generator=g) * 20, "scales": torch.randn(n, 3, generator=g) - 2,
          "quats": torch.randn(n, 4, generator=g), "opacities": torch.randn(n, 1, generator=g),
          "features_dc": torch.randn(n, 3, generator=g), "features_rest": torch.randn(n, K - 1, 3, generator=g) * 0.1}
-    if rigid:
-        q = torch.randn(4, generator=g)
-        p["instance_quat"], p["instance_trans"] = q / q.norm(), torch.randn(3, generator=g) * 10
+    if rigid:   # RigidSubModel: one pose per frame of the traversal (rigid_node.py:107-108)
+        p["instance_quats"], p["instance_trans"] = torch.randn(args.frames, 4, generator=g), torch.randn(args.frames, 3, generator=g) * 10
     return {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
 
 
 sizes = [args.background, args.road] + [max(1, int(args.object_size * (0.3 + 1.4 * torch.rand(1, generator=g).item())))
                                         for _ in range(args.objects)]
 nodes = [params(n, i >= 2) for i, n in enumerate(sizes)]
+frame_of = [None, None] + [int(torch.randint(0, args.frames, (1,), generator=g)) for _ in range(args.objects)]
 total = sum(sizes)
 c2w = torch.eye(4, device=dev)[None, :3]
 cot = {"means": torch.randn(total, 3, device=dev), "scales": torch.randn(total, 3, device=dev),
@@ -64,13 +65,18 @@ def quat_mult(a, b):
                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
 
 
+def pose_of(p, f):   # get_object_pose (rigid_node.py:139-144)
+    return p["instance_quats"][f] / p["instance_quats"][f].norm(dim=-1, keepdim=True), p["instance_trans"][f]
+
+
 def chain():
     parts = []
-    for p in nodes:
+    for p, f in zip(nodes, frame_of):
         means, quats = p["means"], p["quats"] / p["quats"].norm(dim=-1, keepdim=True)
-        if "instance_quat" in p:
-            means = means @ quat_to_rotmat(p["instance_quat"]).T + p["instance_trans"]
-            quats = quat_mult(p["instance_quat"][None], quats)
+        if f is not None:
+            iq, it = pose_of(p, f)
+            means = means @ quat_to_rotmat(iq).T + it
+            quats = quat_mult(iq[None], quats)
         colors = torch.cat((p["features_dc"][:, None, :], p["features_rest"]), dim=1)
         viewdirs = means.detach() - c2w[..., :3, 3]
         viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
@@ -80,13 +86,16 @@ def chain():
 
 
 def pernode():
-    parts = [node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, 3, 3,
-                            instance_quat=p.get("instance_quat"), instance_trans=p.get("instance_trans")) for p in nodes]
+    parts = []
+    for p, f in zip(nodes, frame_of):
+        iq, it = pose_of(p, f) if f is not None else (None, None)
+        parts.append(node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2w, 3, 3,
+                                    instance_quat=iq, instance_trans=it))
     return {k: torch.cat([q[k] for q in parts], 0) for k in cot}
 
 
 def batched():
-    return collect_gaussians(nodes, c2w, 3, 3)
+    return collect_gaussians([p if f is None else dict(p, frame_idx=f) for p, f in zip(nodes, frame_of)], c2w, 3, 3)
 
 
 def step(fn):
