@@ -15,6 +15,7 @@ Prints the per-iteration GPU time of both and checks that they compute the same 
 import argparse
 import math
 import sys
+import time
 from pathlib import Path
 
 import torch
@@ -22,13 +23,16 @@ import torch.nn.functional as F
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
-from mtgs_amd.densify import update_statistics  # noqa: E402
+from mtgs_amd.densify import update_statistics, update_statistics_all  # noqa: E402
 from mtgs_amd.loss import masked_l1, masked_ssim  # noqa: E402
 from mtgs_amd.nodes import node_gaussians  # noqa: E402
 from mtgs_amd.synthetic import make_camera  # noqa: E402
 
 
-def make_nodes(n_bg, n_road, T, seed, dev):
+FRAMES = 40   # frames of an object's pose parameters
+
+
+def make_nodes(n_bg, n_road, T, seed, dev, n_objects=0, object_size=3000):
     g = torch.Generator().manual_seed(seed)
     def base(n, extent, y0):
         return {"means": (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor(extent) + torch.tensor([0.0, y0, 0.0]),
@@ -40,11 +44,40 @@ def make_nodes(n_bg, n_road, T, seed, dev):
     bg["features_adapters"] = 0.1 * torch.randn(n_bg, T, 3, generator=g)
     road = base(n_road, (40.0, 0.2, 40.0), 1.6)
     road["features_rest"] = 0.05 * torch.randn(n_road, 15, 3, generator=g)
-    return {"background": {k: v.to(dev) for k, v in bg.items()}, "road": {k: v.to(dev) for k, v in road.items()}}
+    nodes = {"background": bg, "road": road}
+    for i in range(n_objects):   # rigid object nodes (rigid_node.py): Gaussians in the object frame + one pose per frame
+        n = max(1, int(object_size * (0.3 + 1.4 * torch.rand(1, generator=g).item())))
+        ob = base(n, (1.0, 0.8, 2.2), 0.0)
+        ob["scales"] = ob["scales"] - 0.7
+        ob["features_rest"] = 0.05 * torch.randn(n, 15, 3, generator=g)
+        centre = (torch.rand(3, generator=g) * 2 - 1) * torch.tensor([30.0, 0.0, 30.0]) + torch.tensor([0.0, 0.8, 0.0])
+        drift = torch.linspace(0, 1, FRAMES)[:, None] * torch.tensor([0.0, 0.0, 3.0])
+        ob["instance_trans"] = centre + drift
+        ob["instance_quats"] = torch.tensor([1.0, 0.0, 0.3, 0.0]) * (1.0 + 0.2 * torch.rand(FRAMES, 1, generator=g)) \
+            + 0.05 * torch.randn(FRAMES, 4, generator=g)
+        nodes[f"object_{i}"] = ob
+    return {name: {k: v.to(dev) for k, v in p.items()} for name, p in nodes.items()}
+
+
+def quat_to_rotmat(q):   # wxyz, mtgs utils.quat_to_rotmat (no normalisation)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(3, 3)
+
+
+def quat_mult(a, b):     # mtgs utils.quat_mult
+    w1, x1, y1, z1 = a.unbind(-1)
+    w2, x2, y2, z2 = b.unbind(-1)
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
+
+
+def frame_of(t):
+    return (7 * t + 3) % FRAMES
 
 
 def gaussians_chain(P, c2w, t, n):
-    """VanillaGaussianSplattingModel / MultiColorGaussianSplattingModel.get_gaussians, operator by operator."""
+    """VanillaGaussianSplattingModel / MultiColorGaussianSplattingModel / RigidSubModel.get_gaussians, operator by operator."""
     out = {"means": [], "scales": [], "quats": [], "opacities": [], "rgbs": []}
     for name, p in P.items():
         if "features_adapters" in p:
@@ -52,18 +85,25 @@ def gaussians_chain(P, c2w, t, n):
         else:
             dc, rest = p["features_dc"], p["features_rest"]
         colors = torch.cat((dc[:, None, :], rest), dim=1)
-        viewdirs = p["means"].detach() - c2w[..., :3, 3]
+        means, quats = p["means"], p["quats"] / p["quats"].norm(dim=-1, keepdim=True)
+        if "instance_quats" in p:   # get_object_pose (rigid_node.py:139-144) + rigid_node.py:205-216
+            f = frame_of(t)
+            iq, it = p["instance_quats"][f] / p["instance_quats"][f].norm(dim=-1, keepdim=True), p["instance_trans"][f]
+            means = means @ quat_to_rotmat(iq).T + it
+            quats = quat_mult(iq[None], quats)
+        viewdirs = means.detach() - c2w[..., :3, 3]
         viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
         rgbs = torch.clamp(spherical_harmonics(n, viewdirs, colors) + 0.5, 0.0, 1.0)
-        out["means"].append(p["means"]); out["scales"].append(torch.exp(p["scales"]))
-        out["quats"].append(p["quats"] / p["quats"].norm(dim=-1, keepdim=True))
+        out["means"].append(means); out["scales"].append(torch.exp(p["scales"]))
+        out["quats"].append(quats)
         out["opacities"].append(torch.sigmoid(p["opacities"]).squeeze(-1)); out["rgbs"].append(rgbs)
     return {k: torch.cat(v, 0) for k, v in out.items()}
 
 
 def gaussians_fused(P, c2w, t, n):
     from mtgs_amd.nodes import collect_gaussians
-    return collect_gaussians([dict(p, traversal_index=t) if "features_adapters" in p else p for p in P.values()], c2w, n, 3)
+    return collect_gaussians([dict(p, traversal_index=t) if "features_adapters" in p else
+                              (dict(p, frame_idx=frame_of(t)) if "instance_quats" in p else p) for p in P.values()], c2w, n, 3)
 
 
 def _win(dev):
@@ -105,7 +145,9 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3):
     loss.backward()
     sizes = [p["means"].shape[0] for p in P.values()]
     with torch.no_grad():
-        if fused:
+        if fused and len(stats) > 2:   # scene graph with object nodes: one launch for all of them
+            update_statistics_all([tuple(s) for s in stats], info["radii"], info["means2d"].absgrad, W, H)
+        elif fused:
             start = 0
             for s, n_ in zip(stats, sizes):
                 update_statistics(*s, info["radii"], info["means2d"].absgrad, W, H, start=start)
@@ -122,13 +164,15 @@ def main():
     ap.add_argument("--traversals", type=int, default=3)
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--height", type=int, default=540)
+    ap.add_argument("--objects", type=int, default=0, help="rigid object nodes (per-frame pose parameters) in the scene graph")
+    ap.add_argument("--object-size", type=int, default=3000)
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", choices=["both", "fused", "chain"], default="both", help="profiling aid: time one variant only")
     args = ap.parse_args()
     dev = torch.device("cuda")
     W, H, T = args.width, args.height, args.traversals
-    truth = make_nodes(args.n_background, args.n_road, T, 0, dev)
+    truth = make_nodes(args.n_background, args.n_road, T, 0, dev, args.objects, args.object_size)
     cams = []
     for t in range(T):
         vm, K = make_camera(W, H, yaw_deg=20.0 * t)
@@ -159,12 +203,11 @@ def main():
         for i in range(3):
             loss = one(i)
         torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        t0 = time.perf_counter()          # wall clock: with many nodes the host, not the GPU, sets the pace
         for i in range(args.reps):
             one(i)
-        e.record(); torch.cuda.synchronize()
-        return s.elapsed_time(e) / args.reps, float(one(0)), stats
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.reps * 1e3, float(one(0)), stats
 
     if args.only != "both":
         t1, l1, _ = timed(args.only == "fused")
@@ -172,15 +215,15 @@ def main():
         return
     tc, lc, sc = timed(False)
     tf, lf, sf = timed(True)
-    n_all = args.n_background + args.n_road
-    print(f"{n_all} Gaussians ({T} traversals), {W}x{H}: iteration (fwd + loss + bwd + statistics) "
+    n_all = sum(p["means"].shape[0] for p in P.values())
+    print(f"{n_all} Gaussians in {len(P)} nodes ({T} traversals), {W}x{H}: iteration (fwd + loss + bwd + statistics) "
           f"chain {tc:.2f} ms -> fused {tf:.2f} ms ({tc / tf:.2f}x); loss chain {lc:.6f} fused {lf:.6f}")
     assert abs(lc - lf) <= 2e-5 * max(1.0, abs(lc)), (lc, lf)
     for a, b in zip(sc, sf):
         assert torch.allclose(a[1], b[1]) and torch.allclose(a[2], b[2])
     if args.steps:
         opt = torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
-                                {"params": [p[k] for p in P.values() for k in p if not k.startswith("features")], "lr": 1e-4}])
+                                {"params": [p[k] for p in P.values() for k in p if not k.startswith("features")], "lr": 1e-4}], foreach=True)
         stats = mk_stats()
         curve = []
         for i in range(args.steps):

@@ -170,3 +170,9 @@ def test_mtgs_like_iteration_fused_equals_chain_and_trains():
                        capture_output=True, text=True, timeout=600, cwd=str(root))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "fused" in r.stdout and "loss:" in r.stdout
+    # the same with a scene graph: 12 rigid object nodes with per-frame pose parameters (one batched launch per direction)
+    r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--n-background", "30000", "--n-road",
+                        "10000", "--objects", "12", "--object-size", "500", "--width", "320", "--height", "200", "--steps", "45",
+                        "--reps", "2"], capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "in 14 nodes" in r.stdout and "loss:" in r.stdout
