@@ -74,6 +74,7 @@ def update_statistics_all(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii:
     tab["n"], tab["start"], tab["first_block"] = n, st, np.cumsum(nblk) - nblk
     for j, k in enumerate(("xys_grad_norm", "vis_counts", "max_2dsize")):
         tab[k] = [s_[j].data_ptr() for s_ in stats]
-    tab_dev = torch.from_numpy(tab.view(np.uint8)).to(r.device)
+    from .nodes import upload_table
+    tab_dev = upload_table(tab, r.device)
     call("mtgs_densify_stats_batch", len(stats), ptr(tab_dev), int(nblk.sum()), ptr(r), ptr(g), int(width), int(height),
          stream_of(r))

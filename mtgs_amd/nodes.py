@@ -154,7 +154,17 @@ def _upload(tab: np.ndarray, dev) -> Tensor:
         if want != _DESC.itemsize:
             raise RuntimeError(f"mtgs_node_desc is {want} bytes in libmtgs_rast.so, {_DESC.itemsize} in mtgs_amd.nodes")
         _desc_checked = True
-    return torch.from_numpy(tab.view(np.uint8)).to(dev)
+    return upload_table(tab, dev)
+
+
+def upload_table(tab: np.ndarray, dev) -> Tensor:
+    """Host table -> device, WITHOUT blocking the host: a copy from pageable memory waits for everything already enqueued
+    on the stream (the host could no longer run ahead of the GPU: +0.2 ms per iteration at MTGS's training size).  The
+    staging buffer comes from PyTorch's pinned-memory cache, which does not hand it out again before the copy has run."""
+    raw = tab.view(np.uint8).reshape(-1)
+    staged = torch.empty(raw.size, dtype=torch.uint8, pin_memory=True)
+    staged.numpy()[:] = raw
+    return staged.to(dev, non_blocking=True)
 
 
 class _CollectNodes(torch.autograd.Function):
