@@ -57,3 +57,29 @@ def test_host_side_argument_validation(hip_lib):
     # empty problems are a no-op success
     assert hip_lib.mtgs_sh_fwd(0, 16, 3, None, None, None, None, None) == 0
     assert hip_lib.mtgs_sort_pairs(0, 46, None, None, None, None, None, 0, None) == 0
+
+
+def test_descriptor_tables_match_the_c_structs(hip_lib):
+    """The numpy record layouts the Python layer fills (mtgs_amd.nodes._DESC, mtgs_amd.densify._STATS_DESC) have the size
+    of the C structs they are uploaded as (include/mtgs_rast.h: mtgs_node_desc, mtgs_stats_desc), and the field offsets
+    follow the declaration order with natural alignment."""
+    import re
+    from mtgs_amd import densify, nodes
+    assert hip_lib.mtgs_node_desc_bytes() == nodes._DESC.itemsize == 312
+    assert hip_lib.mtgs_stats_desc_bytes() == densify._STATS_DESC.itemsize == 48
+    header = (ROOT / "include" / "mtgs_rast.h").read_text()
+
+    def c_fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                out.append(re.sub(r"[^A-Za-z0-9_]", " ", part).split()[-1])
+        return out
+
+    assert c_fields("mtgs_node_desc") == list(nodes._DESC.names)
+    assert c_fields("mtgs_stats_desc") == list(densify._STATS_DESC.names)
