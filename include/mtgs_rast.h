@@ -329,6 +329,23 @@ int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_
 int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree, const float *cam_pos,
                         void *stream);
 
+/* ---- camera-space normals of the Gaussians (predict_normals, the shipped MTGS.py config: 3 more blended channels) ------
+ * MTGSSceneModel._get_gaussian_camera_space_normals (mtgs_scene_graph.py:526-545), ~25 PyTorch launches per direction and a
+ * host synchronisation (boolean-mask write), in one kernel per direction:
+ *   k = argmin(scales[n]) (first of equal minima); col = column k of quat_to_rotmat(quats[n]) (utils.py:14-41, wxyz, the
+ *   quaternion as given); n0 = col / max(|col|, 1e-12); s = -1 if <n0, normalize(c2w[:,3] - means[n])> < 0 else +1;
+ *   normals[n] = (s n0) @ c2w[:3,:3].
+ * quats[N,4] (16-byte aligned), scales[N,3] (activated or raw: only their order matters), means[N,3], c2w = DEVICE
+ * pointer to camera_to_worlds[3,4] row-major (no host copy of the camera).  out: row n starts at out + n * out_stride;
+ * rgbs (nullable [N,3]): when given the row is [rgbs[n] | normals[n]] (out_stride >= 6: the torch.cat of :638 is gone),
+ * otherwise the normals alone (out_stride >= 3).
+ * bwd: v_normals = cotangent of the NORMAL columns (pointer to the first of them, row stride v_stride floats);
+ * g_quats[N,4] is fully written.  scales, means and the camera get no gradient (argmin; .detach(); data). */
+int mtgs_normals_fwd(int64_t N, const float *quats, const float *scales, const float *means, const float *c2w,
+                     const float *rgbs, float *out, int64_t out_stride, void *stream);
+int mtgs_normals_bwd(int64_t N, const float *quats, const float *scales, const float *means, const float *c2w,
+                     const float *v_normals, int64_t v_stride, float *g_quats, void *stream);
+
 /* ---- densification statistics of one node in one launch ------------------------------
  * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous
  * slice of the collected arrays; pass pointers to the slice) with radii > 0:

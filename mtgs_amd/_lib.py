@@ -55,6 +55,8 @@ _SIGNATURES = {
     "mtgs_node_desc_bytes": [],
     "mtgs_node_fwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp, _vp],
     "mtgs_node_bwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp],
+    "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_stats_desc_bytes": [],
     "mtgs_densify_stats_batch": [_i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp],

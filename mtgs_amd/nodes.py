@@ -440,3 +440,50 @@ def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tens
     s, q, o, rgb, mg = _NodeActivations.apply(means, scales, quats, opacities, features_dc, features_dc_add, features_rest,
                                               cam_pos, int(sh_degree_to_use), bool(use_sh), -1, instance_quat, instance_trans)
     return {"means": means if instance_quat is None else mg, "scales": s, "quats": q, "opacities": o, "rgbs": rgb}
+
+
+class _CameraSpaceNormals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, quats, scales, means, c2w, rgbs):
+        require_gpu(quats, scales, means, c2w, rgbs)
+        N, dev = quats.shape[0], quats.device
+        q_c = quats.detach().to(torch.float32).contiguous()
+        s_c = scales.detach().to(torch.float32).contiguous()
+        m_c = means.detach().to(torch.float32).contiguous()
+        cam = c2w.detach().to(torch.float32).reshape(-1, 3, 4)[0].contiguous()
+        r_c = None if rgbs is None else rgbs.detach().to(torch.float32).contiguous()
+        width = 3 if rgbs is None else 6
+        out = torch.empty((N, width), dtype=torch.float32, device=dev)
+        call("mtgs_normals_fwd", N, ptr(q_c), ptr(s_c), ptr(m_c), ptr(cam), ptr(r_c), ptr(out), width, stream_of(out))
+        ctx.save_for_backward(q_c, s_c, m_c, cam)
+        ctx.with_rgbs = rgbs is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        q_c, s_c, m_c, cam = ctx.saved_tensors
+        N = q_c.shape[0]
+        v = v_out.to(torch.float32)
+        if v.stride(-1) != 1:
+            v = v.contiguous()
+        col0 = 3 if ctx.with_rgbs else 0
+        g_quats = torch.empty_like(q_c)
+        if N:
+            call("mtgs_normals_bwd", N, ptr(q_c), ptr(s_c), ptr(m_c), ptr(cam), v.data_ptr() + 4 * col0, v.stride(0), ptr(g_quats),
+                 stream_of(q_c))
+        return g_quats, None, None, None, (v[:, :3] if ctx.with_rgbs else None)
+
+
+def camera_space_normals(quats: Tensor, scales: Tensor, means: Tensor, camera_to_worlds: Tensor,
+                         rgbs: Optional[Tensor] = None) -> Tensor:
+    """MTGSSceneModel._get_gaussian_camera_space_normals (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:526-545):
+    the shortest axis of every Gaussian -- column argmin(scales) of quat_to_rotmat(quats), normalised, flipped to face the
+    camera -- rotated into camera space, [N,3].  quats / scales / means are the COLLECTED (activated) Gaussians,
+    camera_to_worlds[(1,)3,4] the camera of the step (`camera.camera_to_worlds`; read on the device, no host copy).
+    With `rgbs` [N,3] the result is `torch.cat([rgbs, normals], -1)` [N,6] -- what `predict_normals` hands to
+    `rasterization(colors=...)` (:636-638) -- written by the same kernel.  Gradients: quats (and rgbs, passed through)."""
+    N = quats.shape[0]
+    assert quats.shape == (N, 4) and scales.shape == (N, 3) and means.shape == (N, 3), (quats.shape, scales.shape, means.shape)
+    assert camera_to_worlds.shape[-2:] == (3, 4) and camera_to_worlds.numel() == 12, camera_to_worlds.shape
+    assert rgbs is None or rgbs.shape == (N, 3), rgbs.shape
+    return _CameraSpaceNormals.apply(quats, scales, means, camera_to_worlds, rgbs)
