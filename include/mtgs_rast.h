@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 5
+#define MTGS_RAST_ABI_VERSION 6
 
 enum {
     MTGS_OK = 0,
@@ -379,14 +379,15 @@ int mtgs_ssim_fwd(int width, int height, const float *gt, const float *pred, con
                   float data_range, float K1, float K2, float *gmaps, float *partials, float *out, void *stream);
 int mtgs_ssim_bwd(int width, int height, const float *gt, const float *pred, const float *gmaps, float win_sigma,
                   const float *v_out, const float *fwd_out, float *v_pred, void *stream);
-/* Masked L1 of the same loss head: torch.abs(gt - pred)[mask].mean() (mtgs_scene_graph.py:823), same conventions:
- * out[0] = mean over the masked pixels x 3 channels, out[1] = their number; v_pred = v_out[0] * mask * sign(pred - gt) /
+/* Masked L1 of the same loss head: torch.abs(gt - pred)[mask].mean() -- the RGB term (mtgs_scene_graph.py:823, 3 channels),
+ * the depth terms (:881-883, 1 channel) and the normal term (:934, 3 channels); gt, pred [H,W,channels], 1 <= channels <= 8;
+ * out[0] = mean over the masked pixels x channels, out[1] = their number; v_pred = v_out[0] * mask * sign(pred - gt) /
  * out[1].  Replaces a nonzero + gather forward and a sorted index_put backward. */
 int mtgs_l1_workspace_floats(int width, int height, size_t *n);
-int mtgs_l1_fwd(int width, int height, const float *gt, const float *pred, const uint8_t *mask, float *partials,
-                float *out, void *stream);
-int mtgs_l1_bwd(int width, int height, const float *gt, const float *pred, const uint8_t *mask, const float *v_out,
-                const float *fwd_out, float *v_pred, void *stream);
+int mtgs_l1_fwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
+                float *partials, float *out, void *stream);
+int mtgs_l1_bwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
+                const float *v_out, const float *fwd_out, float *v_pred, void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,8 +64,8 @@ _SIGNATURES = {
     "mtgs_ssim_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "mtgs_ssim_bwd": [_i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp],
     "mtgs_l1_workspace_floats": [_i32, _i32, C.POINTER(_sz)],
-    "mtgs_l1_fwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "mtgs_l1_bwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_l1_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_l1_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
@@ -73,7 +73,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

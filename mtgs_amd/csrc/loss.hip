@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
 // PyTorch runs the boolean-mask indexing as nonzero + gather forward and a sorted index_put backward (~300 us per
 // iteration at 960x540); here: per-block partial sums in a fixed order, and d/d pred = mask * sign(pred - gt) / count.
 constexpr int L1_PIX = 1024;  // pixels per block
-__global__ __launch_bounds__(256) void l1_fwd_kernel(int64_t n_pix, const float *__restrict__ X, const float *__restrict__ Y,
+__global__ __launch_bounds__(256) void l1_fwd_kernel(int64_t n_pix, int ch, const float *__restrict__ X, const float *__restrict__ Y,
                                                      const uint8_t *__restrict__ mask, float *__restrict__ partials) {
     __shared__ float s_red[4];
     float s = 0.f, c = 0.f;
@@ -169,24 +169,29 @@ __global__ __launch_bounds__(256) void l1_fwd_kernel(int64_t n_pix, const float 
     for (int i = threadIdx.x; i < L1_PIX; i += 256) {
         const int64_t p = p0 + i;
         if (p < n_pix && (!mask || mask[p])) {
-            s += (fabsf(X[p * 3] - Y[p * 3]) + fabsf(X[p * 3 + 1] - Y[p * 3 + 1])) + fabsf(X[p * 3 + 2] - Y[p * 3 + 2]);
-            c += 3.f;
+            if (ch == 3) {
+                s += (fabsf(X[p * 3] - Y[p * 3]) + fabsf(X[p * 3 + 1] - Y[p * 3 + 1])) + fabsf(X[p * 3 + 2] - Y[p * 3 + 2]);
+            } else {
+                float t = 0.f;
+                for (int k = 0; k < ch; ++k) t += fabsf(X[p * ch + k] - Y[p * ch + k]);
+                s += t;
+            }
+            c += (float)ch;
         }
     }
     const float bs = block_sum_256(s, s_red);
     const float bc = block_sum_256(c, s_red);
     if (threadIdx.x == 0) { partials[blockIdx.x * 2] = bs; partials[blockIdx.x * 2 + 1] = bc; }
 }
-__global__ __launch_bounds__(256) void l1_bwd_kernel(int64_t n_pix, const float *__restrict__ X, const float *__restrict__ Y,
+__global__ __launch_bounds__(256) void l1_bwd_kernel(int64_t n_pix, int ch, const float *__restrict__ X, const float *__restrict__ Y,
                                                      const uint8_t *__restrict__ mask, const float *__restrict__ v_out,
                                                      const float *__restrict__ fwd_out, float *__restrict__ v_Y) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pix) return;
     const float scale = (!mask || mask[p]) ? v_out[0] / fwd_out[1] : 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float d = Y[p * 3 + c] - X[p * 3 + c];
-        v_Y[p * 3 + c] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);   // torch: sign(0) = 0
+    for (int c = 0; c < ch; ++c) {
+        const float d = Y[p * ch + c] - X[p * ch + c];
+        v_Y[p * ch + c] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);   // torch: sign(0) = 0
     }
 }
 
@@ -246,24 +251,24 @@ extern "C" int mtgs_l1_workspace_floats(int width, int height, size_t *n) {
     return MTGS_OK;
 }
 
-extern "C" int mtgs_l1_fwd(int width, int height, const float *gt, const float *pred, const uint8_t *mask, float *partials,
-                           float *out, void *stream) {
-    MTGS_REQUIRE(width > 0 && height > 0, MTGS_EINVAL, "mtgs_l1_fwd: bad sizes");
+extern "C" int mtgs_l1_fwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
+                           float *partials, float *out, void *stream) {
+    MTGS_REQUIRE(width > 0 && height > 0 && channels >= 1 && channels <= 8, MTGS_EINVAL, "mtgs_l1_fwd: bad sizes");
     MTGS_REQUIRE(gt && pred && partials && out, MTGS_EINVAL, "mtgs_l1_fwd: null pointer");
     const int64_t n_pix = (int64_t)width * height, nblocks = ceil_div64(n_pix, L1_PIX);
     hipStream_t st = (hipStream_t)stream;
-    l1_fwd_kernel<<<(unsigned)nblocks, 256, 0, st>>>(n_pix, gt, pred, mask, partials);
+    l1_fwd_kernel<<<(unsigned)nblocks, 256, 0, st>>>(n_pix, channels, gt, pred, mask, partials);
     ssim_finish_kernel<<<1, 256, 0, st>>>(nblocks, partials, out);
     MTGS_CHECK_LAUNCH("mtgs_l1_fwd");
     return MTGS_OK;
 }
 
-extern "C" int mtgs_l1_bwd(int width, int height, const float *gt, const float *pred, const uint8_t *mask,
+extern "C" int mtgs_l1_bwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
                            const float *v_out, const float *fwd_out, float *v_pred, void *stream) {
-    MTGS_REQUIRE(width > 0 && height > 0, MTGS_EINVAL, "mtgs_l1_bwd: bad sizes");
+    MTGS_REQUIRE(width > 0 && height > 0 && channels >= 1 && channels <= 8, MTGS_EINVAL, "mtgs_l1_bwd: bad sizes");
     MTGS_REQUIRE(gt && pred && v_out && fwd_out && v_pred, MTGS_EINVAL, "mtgs_l1_bwd: null pointer");
     const int64_t n_pix = (int64_t)width * height;
-    l1_bwd_kernel<<<(unsigned)ceil_div64(n_pix, 256), 256, 0, (hipStream_t)stream>>>(n_pix, gt, pred, mask, v_out, fwd_out, v_pred);
+    l1_bwd_kernel<<<(unsigned)ceil_div64(n_pix, 256), 256, 0, (hipStream_t)stream>>>(n_pix, channels, gt, pred, mask, v_out, fwd_out, v_pred);
     MTGS_CHECK_LAUNCH("mtgs_l1_bwd");
     return MTGS_OK;
 }

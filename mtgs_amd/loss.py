@@ -54,7 +54,7 @@ def masked_ssim(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None, win_sig
     """gt, pred: [H, W, 3]; mask: [H, W, 1] / [H, W] bool or None.  Returns the scalar the reference's MaskedSSIM
     returns (mean of the SSIM map over the masked elements; the mask is cropped by the 5-pixel window margin).
     Differentiable with respect to `pred` (the reference's second argument); `gt` gets no gradient."""
-    assert pred.dim() == 3 and pred.shape[2] == 3 and gt.shape == pred.shape, (gt.shape, pred.shape)
+    assert pred.dim() == 3 and 1 <= pred.shape[2] <= 8 and gt.shape == pred.shape, (gt.shape, pred.shape)
     H, W = pred.shape[:2]
     if H <= 10 or W <= 10:
         raise ValueError(f"masked_ssim: image {H}x{W} is smaller than the 11x11 window")
@@ -77,27 +77,29 @@ class _MaskedL1(torch.autograd.Function):
         call("mtgs_l1_workspace_floats", W, H, C.byref(n))
         partials = torch.empty(n.value, dtype=torch.float32, device=pred.device)
         out = torch.empty(2, dtype=torch.float32, device=pred.device)
-        call("mtgs_l1_fwd", W, H, ptr(gt_c), ptr(pred_c), ptr(mask_c), ptr(partials), ptr(out), stream_of(pred))
+        ch = pred.shape[2]
+        call("mtgs_l1_fwd", W, H, ch, ptr(gt_c), ptr(pred_c), ptr(mask_c), ptr(partials), ptr(out), stream_of(pred))
         ctx.save_for_backward(gt_c, pred_c, mask_c, out)
-        ctx.dims = (H, W, pred.dtype)
+        ctx.dims = (H, W, ch, pred.dtype)
         return out[0]
 
     @staticmethod
     def backward(ctx, v_out):
         gt_c, pred_c, mask_c, out = ctx.saved_tensors
-        H, W, dtype = ctx.dims
+        H, W, ch, dtype = ctx.dims
         v = v_out.to(torch.float32).reshape(1).contiguous()
         v_pred = torch.empty_like(pred_c)
-        call("mtgs_l1_bwd", W, H, ptr(gt_c), ptr(pred_c), ptr(mask_c), ptr(v), ptr(out), ptr(v_pred), stream_of(pred_c))
+        call("mtgs_l1_bwd", W, H, ch, ptr(gt_c), ptr(pred_c), ptr(mask_c), ptr(v), ptr(out), ptr(v_pred), stream_of(pred_c))
         return None, v_pred.to(dtype), None
 
 
 def masked_l1(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None) -> Tensor:
     """torch.abs(gt - pred)[mask.squeeze(-1)].mean() as MTGS forms its L1 loss
-    (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:823): gt, pred [H,W,3], mask [H,W,1] / [H,W] bool or None.
+    (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:823; the same form carries the depth terms, :881-883 with
+    [H,W,1] images, and the normal term, :934): gt, pred [H,W,C] with 1 <= C <= 8, mask [H,W,1] / [H,W] bool or None.
     One launch per direction instead of boolean-mask indexing (nonzero + gather, sorted index_put backward).
     Differentiable with respect to `pred`."""
-    assert pred.dim() == 3 and pred.shape[2] == 3 and gt.shape == pred.shape, (gt.shape, pred.shape)
+    assert pred.dim() == 3 and 1 <= pred.shape[2] <= 8 and gt.shape == pred.shape, (gt.shape, pred.shape)
     if mask is not None:
         assert mask.numel() == pred.shape[0] * pred.shape[1], mask.shape
     if gt.requires_grad:

@@ -50,14 +50,16 @@ def test_masked_ssim_training_resolution(hip_lib):
 
 
 @pytest.mark.parametrize("use_mask", [True, False])
-def test_masked_l1_matches_torch_formulation(hip_lib, use_mask):
-    """mtgs_scene_graph.py:823: torch.abs(gt_img - pred)[combined_mask.squeeze(-1)].mean()"""
+@pytest.mark.parametrize("ch", [3, 1, 4])
+def test_masked_l1_matches_torch_formulation(hip_lib, use_mask, ch):
+    """mtgs_scene_graph.py:823: torch.abs(gt_img - pred)[combined_mask.squeeze(-1)].mean(); one channel: the depth terms
+    (:881-883, mask [H,W,1] indexing [H,W,1] images), three: the normal term (:934)."""
     from mtgs_amd.loss import masked_l1
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(3)
     H, W = 211, 333
-    gt = torch.rand(H, W, 3, generator=g).to(dev)
-    pred0 = torch.rand(H, W, 3, generator=g)
+    gt = torch.rand(H, W, ch, generator=g).to(dev)
+    pred0 = torch.rand(H, W, ch, generator=g)
     pred0[5, 7] = gt[5, 7].cpu()                                    # exact ties: sign(0) = 0
     mask = (torch.rand(H, W, 1, generator=g) > 0.4).to(dev) if use_mask else None
     p_ref = pred0.to(dev).double().requires_grad_(True)
