@@ -366,6 +366,26 @@ int mtgs_stats_desc_bytes(void);
 int mtgs_densify_stats_batch(int n_nodes, const mtgs_stats_desc *table, int64_t total_blocks, const int32_t *radii,
                              const float *grad2d, int width, int height, void *stream);
 
+/* ---- the output head between the rasterizer and the losses ------------------------
+ * mtgs_scene_graph.py:672-690 + LearnableExposureRGBModel.forward (module/appearance.py:73-87), one kernel per direction:
+ *   rgb[H,W,3]            = clamp(render[..., :3] + (1 - alpha) * background, 0, 1)
+ *   rgb_appearance[H,W,3] = clamp(rgb @ E[:3,:3] + E[:3,3], 0, 1)         E = exposure[3,4] of the camera (nullable: skipped)
+ *   depth[H,W]            = alpha > 0 ? render[..., depth_channel] : depth_max[0]     (depth_channel < 0: skipped;
+ *                           depth_max = DEVICE scalar, the detached maximum of the depth channel)
+ *   normal[H,W,3]         = (n / |n| + 1) / 2,  n = render[..., normal_channel : normal_channel + 3]  (< 0: skipped; no eps)
+ * render[H,W,channels], alpha[H,W]; background[3], exposure[12] are DEVICE pointers.
+ * bwd: any of the four cotangents may be NULL; v_render[H,W,channels] (every channel written) and v_alpha[H,W] are the
+ * complete gradients of this head; v_background[3], v_exposure[12] (nullable) are reduced through `partials`
+ * (mtgs_head_workspace_floats) in a fixed order. */
+int mtgs_head_fwd(int width, int height, int channels, int depth_channel, int normal_channel, const float *render,
+                  const float *alpha, const float *background, const float *exposure, const float *depth_max, float *rgb,
+                  float *rgb_appearance, float *depth, float *normal, void *stream);
+int mtgs_head_workspace_floats(int width, int height, size_t *n);
+int mtgs_head_bwd(int width, int height, int channels, int depth_channel, int normal_channel, const float *render,
+                  const float *alpha, const float *background, const float *exposure, const float *v_rgb,
+                  const float *v_rgb_appearance, const float *v_depth, const float *v_normal, float *v_render, float *v_alpha,
+                  float *v_background, float *v_exposure, float *partials, void *stream);
+
 /* ---- masked SSIM of the loss head, fused ---------------------------------------------
  * mtgs.utils.ssim.MaskedSSIM(data_range=1.0, size_average=True, channel=3)(gt, pred, mask)  (mtgs/utils/ssim.py:57-190,
  * mtgs_scene_graph.py:322, :831-841).  gt, pred: [H,W,3] f32 (the rasterizer's layout: no NCHW copies); mask[H,W] u8

@@ -105,3 +105,70 @@ def masked_l1(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None) -> Tensor
     if gt.requires_grad:
         raise NotImplementedError("masked_l1: gradient with respect to gt is not implemented")
     return _MaskedL1.apply(gt, pred, mask)
+
+
+class _OutputHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, alpha, background, exposure, want_depth, normal_channel):
+        require_gpu(render, alpha, background, exposure)
+        D = render.shape[-1]
+        H, W = render.shape[-3], render.shape[-2]
+        dev = render.device
+        r_c = render.detach().to(torch.float32).reshape(H, W, D).contiguous()
+        a_c = alpha.detach().to(torch.float32).reshape(H, W).contiguous()
+        bg_c = background.detach().to(torch.float32).reshape(3).contiguous()
+        e_c = None if exposure is None else exposure.detach().to(torch.float32).reshape(12).contiguous()
+        depth_ch = D - 1 if want_depth else -1
+        dmax = r_c[..., depth_ch].max().reshape(1) if want_depth else None      # depth_im.detach().max() (:680)
+        rgb = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        app = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if e_c is not None else None
+        depth = torch.empty((H, W, 1), dtype=torch.float32, device=dev) if want_depth else None
+        normal = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if normal_channel >= 0 else None
+        call("mtgs_head_fwd", W, H, D, depth_ch, int(normal_channel), ptr(r_c), ptr(a_c), ptr(bg_c), ptr(e_c), ptr(dmax), ptr(rgb),
+             ptr(app), ptr(depth), ptr(normal), stream_of(render))
+        ctx.save_for_backward(r_c, a_c, bg_c, e_c)
+        ctx.cfg = (H, W, D, depth_ch, int(normal_channel), render.shape, alpha.shape, background.shape,
+                   None if exposure is None else exposure.shape)
+        ctx.set_materialize_grads(False)
+        return rgb, app, depth, normal
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_app, v_depth, v_normal):
+        r_c, a_c, bg_c, e_c = ctx.saved_tensors
+        H, W, D, depth_ch, normal_ch, r_shape, a_shape, bg_shape, e_shape = ctx.cfg
+        dev = r_c.device
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        v_rgb, v_app, v_depth, v_normal = c(v_rgb), c(v_app), c(v_depth), c(v_normal)
+        v_render = torch.empty((H, W, D), dtype=torch.float32, device=dev)
+        v_alpha = torch.empty((H, W), dtype=torch.float32, device=dev)
+        need_bg, need_e = ctx.needs_input_grad[2], e_c is not None and ctx.needs_input_grad[3]
+        v_bg = torch.empty(3, dtype=torch.float32, device=dev) if need_bg else None
+        v_e = torch.empty(12, dtype=torch.float32, device=dev) if need_e else None
+        n = C.c_size_t(0)
+        call("mtgs_head_workspace_floats", W, H, C.byref(n))
+        partials = torch.empty(n.value, dtype=torch.float32, device=dev)
+        call("mtgs_head_bwd", W, H, D, depth_ch, normal_ch, ptr(r_c), ptr(a_c), ptr(bg_c), ptr(e_c), ptr(v_rgb), ptr(v_app),
+             ptr(v_depth), ptr(v_normal), ptr(v_render), ptr(v_alpha), ptr(v_bg), ptr(v_e), ptr(partials), stream_of(r_c))
+        return (v_render.reshape(r_shape), v_alpha.reshape(a_shape), None if v_bg is None else v_bg.reshape(bg_shape),
+                None if v_e is None else v_e.reshape(e_shape), None, None)
+
+
+def output_head(render: Tensor, alpha: Tensor, background: Tensor, exposure: Optional[Tensor] = None, depth: bool = True,
+                normal_channel: int = -1):
+    """What MTGSSceneModel.get_outputs derives from the rasterizer's result (one camera) before the losses
+    (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:672-690), with the shipped appearance model
+    (LearnableExposureRGBModel.forward, module/appearance.py:73-87), in ONE launch per direction:
+
+        rgb            = clamp(render[..., :3] + (1 - alpha) * background, 0, 1)                      [H,W,3]
+        rgb_appearance = clamp(rgb @ exposure[:3,:3] + exposure[:3,3], 0, 1)      (exposure [3,4]; None: not computed)
+        depth          = where(alpha > 0, render[..., -1:], render[..., -1:].detach().max())          [H,W,1]  (depth=True)
+        normal         = (n / |n| + 1) / 2, n = render[..., c:c+3]                [H,W,3]  (normal_channel = c >= 0)
+
+    render [1,H,W,D] or [H,W,D], alpha [1,H,W,1] or [H,W,1], background [3].  Returns (rgb, rgb_appearance, depth, normal)
+    with None for what was not requested.  Differentiable with respect to render, alpha, background and exposure."""
+    D = render.shape[-1]
+    assert render.dim() in (3, 4) and (render.dim() == 3 or render.shape[0] == 1) and D >= 3, render.shape
+    assert alpha.numel() == render.numel() // D and background.numel() == 3, (alpha.shape, background.shape)
+    assert exposure is None or exposure.shape == (3, 4), exposure.shape
+    assert normal_channel < 0 or normal_channel + 3 <= D - int(bool(depth)), (normal_channel, D)
+    return _OutputHead.apply(render, alpha, background, exposure, bool(depth), int(normal_channel))

@@ -71,3 +71,65 @@ def test_masked_l1_matches_torch_formulation(hip_lib, use_mask, ch):
     (0.8 * val).backward()
     assert abs(float(val.detach()) - float(ref.detach())) <= 2e-6
     assert torch.allclose(p.grad.double(), p_ref.grad, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("D,with_exposure,with_depth,normal_ch", [(8, True, True, 3), (4, True, True, -1), (3, False, False, -1),
+                                                                  (7, False, True, 3)])
+def test_output_head_matches_the_reference_formulation(hip_lib, D, with_exposure, with_depth, normal_ch):
+    """mtgs_amd.loss.output_head against mtgs_scene_graph.py:672-690 + LearnableExposureRGBModel.forward
+    (module/appearance.py:73-87) written out in torch float64: values to 2e-6, every gradient (render, alpha, background,
+    exposure) to 2e-5 relative.  Values are kept away from the clamp edges by construction of the cotangent test only where
+    the reference itself is continuous; exact edge hits are covered by the inclusive-mask rule (0 and 1 pass)."""
+    from mtgs_amd.loss import output_head
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(D * 7 + normal_ch)
+    H, W = 97, 131
+    render = torch.rand(1, H, W, D, generator=g) * 1.4 - 0.2
+    if with_depth:
+        render[..., -1] = torch.rand(1, H, W, generator=g) * 30
+    alpha = torch.rand(1, H, W, 1, generator=g)
+    alpha[0, :5] = 0.0                                             # nothing hit: depth takes the maximum
+    alpha[0, 7, 9] = 0.5                                           # exactly representable: lands ON the clamp edges in fp32 and fp64
+    render[0, 7, 9, :3] = torch.tensor([0.0, 1.0, 0.5]) - 0.125
+    bg = torch.full((3,), 0.25)
+    E = (torch.eye(3, 4) + 0.1 * torch.randn(3, 4, generator=g)) if with_exposure else None
+    cots = [torch.randn(H, W, 3, generator=g), torch.randn(H, W, 3, generator=g), torch.randn(H, W, 1, generator=g),
+            torch.randn(H, W, 3, generator=g)]
+
+    def reference(render, alpha, bg, E):
+        rgb = torch.clamp(render[..., :3] + (1 - alpha) * bg, 0.0, 1.0).squeeze(0)
+        app = torch.clamp(rgb.matmul(E[:3, :3]) + E[None, None, :3, 3], 0, 1) if E is not None else None
+        depth = None
+        if with_depth:
+            d = render[..., -1:]
+            depth = torch.where(alpha > 0, d, d.detach().max()).squeeze(0)
+        normal = None
+        if normal_ch >= 0:
+            n = render[..., normal_ch:normal_ch + 3].squeeze(0)
+            normal = (n / n.norm(dim=-1, keepdim=True) + 1) / 2
+        return rgb, app, depth, normal
+
+    def run(fn, dtype, device):
+        P = [t.to(device=device, dtype=dtype).requires_grad_(True) if t is not None else None for t in (render, alpha, bg, E)]
+        outs = fn(*P)
+        loss = sum((o * c.to(device=device, dtype=dtype)).sum() for o, c in zip(outs, cots) if o is not None)
+        loss.backward()
+        return outs, [None if p is None else p.grad for p in P]
+
+    ref_out, ref_grad = run(reference, torch.float64, "cpu")
+    out, grad = run(lambda r, a, b, e: output_head(r, a, b, e, depth=with_depth, normal_channel=normal_ch), torch.float32, dev)
+    for o, r, name in zip(out, ref_out, ("rgb", "rgb_appearance", "depth", "normal")):
+        assert (o is None) == (r is None), name
+        if o is not None:
+            assert o.shape == r.shape, (name, o.shape, r.shape)
+            assert float((o.detach().cpu().double() - r.detach()).abs().max()) < 3e-6, name
+    for gq, gr, name in zip(grad, ref_grad, ("render", "alpha", "background", "exposure")):
+        assert (gq is None) == (gr is None), name
+        if gq is not None:
+            scale = float(gr.abs().max()) + 1e-12
+            # pixels whose fp32 value sits within rounding of a clamp edge may take the other branch than fp64
+            diff = (gq.cpu().double() - gr).abs()
+            if name in ("render", "alpha"):
+                assert float((diff > 2e-5 * scale).double().mean()) < 1e-3, name
+            else:
+                assert float(diff.max()) < 5e-4 * scale, name
