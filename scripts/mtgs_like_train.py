@@ -193,6 +193,8 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
             loss_d = torch.abs(inv_gt - inv_pred)[dmask].mean()
             loss_n = torch.abs(gt_n - normal)[mask.squeeze(-1)].mean()
         ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)     # use_ssim_on_raw_rgb
+        # pixels nothing was splatted on have a 0/0 normal; MTGS adds the term only when it is finite (mtgs_scene_graph.py:939)
+        loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
         loss = 0.8 * l1 + 0.2 * (1 - ssim) + 0.5 * loss_d + 0.1 * loss_n
     else:
         rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)          # black background (mtgs_scene_graph.py:672-676)
