@@ -366,6 +366,27 @@ int mtgs_stats_desc_bytes(void);
 int mtgs_densify_stats_batch(int n_nodes, const mtgs_stats_desc *table, int64_t total_blocks, const int32_t *radii,
                              const float *grad2d, int width, int height, void *stream);
 
+/* ---- out-of-box regulariser of the rigid object nodes (config/MTGS.py:117 oob_lambda = 1.0) -----------------------------
+ * mtgs_scene_graph.py:949-967 loops over the rigid models with a full-size `model_id == id` comparison, boolean-mask
+ * gathers and two host synchronisations per node; here every node of the frame in one pass.  For the nodes with at least
+ * one visible Gaussian (radii[start .. start + n) > 0): oob = any(|means_local| > limit), limit = instance_size / 2 +
+ * tolerance;  out[0] = sum over the oob Gaussians of -log(1 - sigmoid(opacities) + 1e-6) / their number (0 if none),
+ * out[1] = that number.  flags[n_nodes] (int32 scratch, receives the per-node visibility), partials[2 * total_blocks].
+ * bwd: g_opacities[n] of every node fully written (zeros outside the oob set). */
+typedef struct mtgs_oob_desc {
+    int64_t n, first_block, start;      /* Gaussians of the node; its first 256-thread block; its offset in radii */
+    const float *means;                 /* [n,3] LOCAL means of the rigid node */
+    const float *opacities;             /* [n] logits */
+    float *g_opacities;                 /* [n] (backward) */
+    float limit[3];
+    float reserved;
+} mtgs_oob_desc;
+int mtgs_oob_desc_bytes(void);
+int mtgs_oob_fwd(int n_nodes, const mtgs_oob_desc *table, int64_t total_blocks, const int32_t *radii, int32_t *flags,
+                 float *partials, float *out, void *stream);
+int mtgs_oob_bwd(int n_nodes, const mtgs_oob_desc *table, int64_t total_blocks, const int32_t *flags, const float *v_out,
+                 const float *fwd_out, void *stream);
+
 /* ---- the output head between the rasterizer and the losses ------------------------
  * mtgs_scene_graph.py:672-690 + LearnableExposureRGBModel.forward (module/appearance.py:73-87), one kernel per direction:
  *   rgb[H,W,3]            = clamp(render[..., :3] + (1 - alpha) * background, 0, 1)

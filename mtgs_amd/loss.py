@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -172,3 +173,77 @@ def output_head(render: Tensor, alpha: Tensor, background: Tensor, exposure: Opt
     assert exposure is None or exposure.shape == (3, 4), exposure.shape
     assert normal_channel < 0 or normal_channel + 3 <= D - int(bool(depth)), (normal_channel, D)
     return _OutputHead.apply(render, alpha, background, exposure, bool(depth), int(normal_channel))
+
+
+_OOB_DESC = np.dtype([("n", "<i8"), ("first_block", "<i8"), ("start", "<i8"), ("means", "<u8"), ("opacities", "<u8"),
+                      ("g_opacities", "<u8"), ("limit", "<f4", (3,)), ("reserved", "<f4")], align=True)
+
+
+class _OobLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, radii, starts, limits, *flat):
+        from ._lib import load
+        from .nodes import upload_table
+        require_gpu(radii, *flat)
+        if load().mtgs_oob_desc_bytes() != _OOB_DESC.itemsize:
+            raise RuntimeError("mtgs_oob_desc layout mismatch between libmtgs_rast.so and mtgs_amd.loss")
+        n_nodes, dev = len(flat) // 2, radii.device
+        means = [m.detach().to(torch.float32).contiguous() for m in flat[0::2]]
+        opacs = [o.detach().to(torch.float32).reshape(-1).contiguous() for o in flat[1::2]]
+        n = np.asarray([m.shape[0] for m in means], dtype=np.int64)
+        r = radii.reshape(-1)
+        r = (r if r.dtype == torch.int32 else r.to(torch.int32)).contiguous()
+        st = np.asarray(starts, dtype=np.int64)
+        assert st.shape == n.shape and (n_nodes == 0 or ((st >= 0).all() and int((st + n).max()) <= r.numel())), (st, n, r.shape)
+        tab = np.zeros(n_nodes, dtype=_OOB_DESC)
+        nblk = (n + 255) // 256
+        tab["n"], tab["start"], tab["first_block"] = n, st, np.cumsum(nblk) - nblk
+        tab["means"] = [m.data_ptr() for m in means]
+        tab["opacities"] = [o.data_ptr() for o in opacs]
+        tab["limit"] = np.asarray(limits, dtype=np.float32).reshape(n_nodes, 3)
+        blocks = int(nblk.sum())
+        flags = torch.empty(max(n_nodes, 1), dtype=torch.int32, device=dev)
+        partials = torch.empty(max(2 * blocks, 1), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        tab_dev = upload_table(tab, dev) if n_nodes else None
+        call("mtgs_oob_fwd", n_nodes, ptr(tab_dev), blocks, ptr(r), ptr(flags), ptr(partials), ptr(out), stream_of(radii))
+        ctx.tab, ctx.blocks, ctx.shapes = tab, blocks, [o.shape for o in flat[1::2]]
+        ctx.save_for_backward(flags, out, *means, *opacs)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, v_out):
+        from .nodes import upload_table
+        flags, out, *rest = ctx.saved_tensors
+        n_nodes = len(ctx.shapes)
+        if n_nodes == 0:
+            return (None, None, None)
+        dev = out.device
+        sizes = [int(k) for k in ctx.tab["n"]]
+        g_flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        tab = ctx.tab.copy()
+        off = np.cumsum(ctx.tab["n"]) - ctx.tab["n"]
+        tab["g_opacities"] = np.uint64(g_flat.data_ptr()) + np.uint64(4) * off.astype(np.uint64)
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        tab_dev = upload_table(tab, dev)
+        call("mtgs_oob_bwd", n_nodes, ptr(tab_dev), ctx.blocks, ptr(flags), ptr(v), ptr(out), stream_of(out))
+        grads = []
+        for g, shape in zip(g_flat.split(sizes), ctx.shapes):
+            grads += [None, g.reshape(shape)]
+        return (None, None, None) + tuple(grads)
+
+
+def oob_loss(nodes, radii: Tensor, starts, tolerance: float = 1.5) -> Tensor:
+    """The out-of-box regulariser of MTGS's rigid object nodes (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:949-967,
+    `oob_lambda` = 1.0 in config/MTGS.py) for every rigid node of the frame in one pass, without the per-node host
+    synchronisations of the reference loop.  nodes: sequence of (means [n,3] -- the node's LOCAL means --, opacities [n,1]
+    logits, instance_size (3 floats)); radii: info["radii"] of the frame; starts[i]: offset of node i in the collected
+    arrays.  Returns  sum over { Gaussians of nodes with a visible Gaussian whose |mean| exceeds instance_size / 2 +
+    tolerance on some axis } of -log(1 - sigmoid(opacity) + 1e-6), divided by their number (0 when there is none).
+    Differentiable with respect to the opacities."""
+    flat, limits = [], []
+    for means, opacities, size in nodes:
+        assert means.dim() == 2 and means.shape[1] == 3 and opacities.numel() == means.shape[0], (means.shape, opacities.shape)
+        flat += [means, opacities]
+        limits.append([float(s) / 2 + float(tolerance) for s in size])
+    return _OobLoss.apply(radii, tuple(int(s) for s in starts), limits, *flat)

@@ -19,7 +19,7 @@ def test_header_declares_the_operator_table():
     syms = header_symbols()
     for must in ("mtgs_sh_fwd", "mtgs_sh_bwd", "mtgs_project_fwd", "mtgs_project_bwd", "mtgs_isect_count",
                  "mtgs_isect_scan", "mtgs_isect_emit", "mtgs_sort_pairs", "mtgs_isect_offsets", "mtgs_blend_fwd",
-                 "mtgs_blend_bwd", "mtgs_tile_schedule", "mtgs_bin_compact", "mtgs_bin_emit", "mtgs_sort_pairs_u32", "mtgs_bin_sort_tiles", "mtgs_bin_build", "mtgs_dp_pack", "mtgs_dp_accumulate", "mtgs_dp_pack_ordered", "mtgs_node_fwd", "mtgs_node_bwd", "mtgs_node_fwd_batch", "mtgs_node_bwd_batch", "mtgs_densify_stats", "mtgs_densify_stats_batch", "mtgs_normals_fwd", "mtgs_normals_bwd", "mtgs_head_fwd", "mtgs_head_bwd", "mtgs_ssim_workspace_floats", "mtgs_ssim_fwd", "mtgs_ssim_bwd", "mtgs_l1_workspace_floats", "mtgs_l1_fwd", "mtgs_l1_bwd", "mtgs_dp_reduce", "mtgs_rast_version", "mtgs_rast_last_error"):
+                 "mtgs_blend_bwd", "mtgs_tile_schedule", "mtgs_bin_compact", "mtgs_bin_emit", "mtgs_sort_pairs_u32", "mtgs_bin_sort_tiles", "mtgs_bin_build", "mtgs_dp_pack", "mtgs_dp_accumulate", "mtgs_dp_pack_ordered", "mtgs_node_fwd", "mtgs_node_bwd", "mtgs_node_fwd_batch", "mtgs_node_bwd_batch", "mtgs_densify_stats", "mtgs_densify_stats_batch", "mtgs_normals_fwd", "mtgs_normals_bwd", "mtgs_head_fwd", "mtgs_head_bwd", "mtgs_oob_fwd", "mtgs_oob_bwd", "mtgs_ssim_workspace_floats", "mtgs_ssim_fwd", "mtgs_ssim_bwd", "mtgs_l1_workspace_floats", "mtgs_l1_fwd", "mtgs_l1_bwd", "mtgs_dp_reduce", "mtgs_rast_version", "mtgs_rast_last_error"):
         assert must in syms
 
 
@@ -67,6 +67,8 @@ def test_descriptor_tables_match_the_c_structs(hip_lib):
     from mtgs_amd import densify, nodes
     assert hip_lib.mtgs_node_desc_bytes() == nodes._DESC.itemsize == 312
     assert hip_lib.mtgs_stats_desc_bytes() == densify._STATS_DESC.itemsize == 48
+    from mtgs_amd import loss
+    assert hip_lib.mtgs_oob_desc_bytes() == loss._OOB_DESC.itemsize == 64
     header = (ROOT / "include" / "mtgs_rast.h").read_text()
 
     def c_fields(name):
@@ -78,8 +80,9 @@ def test_descriptor_tables_match_the_c_structs(hip_lib):
             if not decl:
                 continue
             for part in decl.split(","):
-                out.append(re.sub(r"[^A-Za-z0-9_]", " ", part).split()[-1])
+                out.append(re.sub(r"[^A-Za-z0-9_]", " ", re.sub(r"\[\d+\]", "", part)).split()[-1])
         return out
 
     assert c_fields("mtgs_node_desc") == list(nodes._DESC.names)
     assert c_fields("mtgs_stats_desc") == list(densify._STATS_DESC.names)
+    assert c_fields("mtgs_oob_desc") == list(loss._OOB_DESC.names)

@@ -133,3 +133,53 @@ def test_output_head_matches_the_reference_formulation(hip_lib, D, with_exposure
                 assert float((diff > 2e-5 * scale).double().mean()) < 1e-3, name
             else:
                 assert float(diff.max()) < 5e-4 * scale, name
+
+
+@pytest.mark.parametrize("n_nodes", [0, 1, 40])
+def test_oob_loss_matches_the_reference_loop(hip_lib, n_nodes):
+    """mtgs_amd.loss.oob_loss against the per-node loop of mtgs_scene_graph.py:949-967 written out in torch float64
+    (model_id comparison, visible-node test, |means| > size / 2 + tolerance, -log(1 - sigmoid + 1e-6), mean)."""
+    from mtgs_amd.loss import oob_loss
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(n_nodes + 11)
+    sizes = [int(x) for x in torch.randint(1, 700, (n_nodes,), generator=g)]
+    if n_nodes > 5:
+        sizes[2], sizes[3] = 256, 257
+    static = 1000                                                   # a static node in front: rigid nodes start after it
+    starts, s = [], static
+    for k in sizes:
+        starts.append(s); s += k
+    total = s + 333
+    radii = (torch.randint(0, 30, (1, total), generator=g) * (torch.rand(1, total, generator=g) < 0.05)).int()
+    if n_nodes > 5:
+        radii[0, starts[4]:starts[4] + sizes[4]] = 0                # an object that is entirely invisible: skipped
+    nodes = []
+    for k in sizes:
+        means = torch.randn(k, 3, generator=g) * 2.0
+        nodes.append((means, torch.randn(k, 1, generator=g) * 2, [2.0 + torch.rand(1, generator=g).item(), 1.5, 4.0]))
+
+    # reference loop, float64
+    ops = [o.double().requires_grad_(True) for _, o, _ in nodes]
+    visible = (radii > 0).flatten()
+    loss, count = 0.0, 0
+    for (means, _, size), o, st, k in zip(nodes, ops, starts, sizes):
+        if visible[st:st + k].sum() == 0:
+            continue
+        oob = (means.double().abs() > (torch.tensor(size, dtype=torch.float64) / 2 + 1.5)[None]).any(-1)
+        if oob.sum() != 0:
+            loss = loss + (-torch.log(1 - o[oob].sigmoid() + 1e-6)).sum()
+            count += int(oob.sum())
+    ref = loss / count if count else torch.zeros((), dtype=torch.float64)
+    if count:
+        (3.0 * ref).backward()
+
+    P = [o.to(dev).requires_grad_(True) for _, o, _ in nodes]
+    val = oob_loss([(m.to(dev), p, size) for (m, _, size), p in zip(nodes, P)], radii.to(dev), starts, tolerance=1.5)
+    ref = ref.detach() if torch.is_tensor(ref) else ref
+    assert abs(float(val.detach()) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    if n_nodes:
+        (3.0 * val).backward()
+        for p, o in zip(P, ops):
+            expect = o.grad if o.grad is not None else torch.zeros_like(o)
+            assert p.grad.shape == o.shape
+            assert torch.allclose(p.grad.cpu().double(), expect, rtol=2e-4, atol=1e-7)
