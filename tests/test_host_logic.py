@@ -127,3 +127,36 @@ def test_neighbour_modules_have_no_cpu_fallback_and_validate_arguments():
         masked_ssim(z(32, 32, 3).requires_grad_(True), z(32, 32, 3))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         update_statistics(z(N), z(N), z(N), torch.zeros(1, N, dtype=torch.int32), z(1, N, 2), 64, 48)
+
+
+def test_later_neighbours_have_no_cpu_fallback_and_validate_arguments():
+    """collect_gaussians (batched), camera_space_normals, output_head, masked_l1, oob_loss, update_statistics_all: CPU tensors
+    raise, shapes are checked before any launch."""
+    from mtgs_amd.densify import update_statistics_all
+    from mtgs_amd.loss import masked_l1, oob_loss, output_head
+    from mtgs_amd.nodes import camera_space_normals, collect_gaussians
+    N = 8
+    z = lambda *s: torch.zeros(*s)
+    c2w = torch.eye(4)[None, :3]
+    node = {"means": z(N, 3), "scales": z(N, 3), "quats": torch.ones(N, 4), "opacities": z(N, 1), "features_dc": z(N, 3),
+            "features_rest": z(N, 15, 3)}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        collect_gaussians([node, dict(node, instance_quats=torch.ones(5, 4), instance_trans=z(5, 3), frame_idx=2)], c2w, 3, 3)
+    with pytest.raises(AssertionError):     # frame index outside the pose table
+        collect_gaussians([dict(node, instance_quats=torch.ones(5, 4), instance_trans=z(5, 3), frame_idx=5)], c2w, 3, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        camera_space_normals(torch.ones(N, 4), torch.ones(N, 3), z(N, 3), c2w, rgbs=z(N, 3))
+    with pytest.raises(AssertionError):
+        camera_space_normals(torch.ones(N, 4), torch.ones(N, 2), z(N, 3), c2w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        output_head(z(1, 16, 16, 8), z(1, 16, 16, 1), z(3), torch.eye(3, 4), depth=True, normal_channel=3)
+    with pytest.raises(AssertionError):     # the normal channels would overlap the depth channel
+        output_head(z(1, 16, 16, 6), z(1, 16, 16, 1), z(3), None, depth=True, normal_channel=3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        masked_l1(z(16, 16, 1), z(16, 16, 1), torch.ones(16, 16, 1, dtype=torch.bool))
+    with pytest.raises(AssertionError):
+        masked_l1(z(16, 16, 9), z(16, 16, 9))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        oob_loss([(z(N, 3), z(N, 1), [4.0, 2.0, 1.5])], torch.zeros(1, 20, dtype=torch.int32), [3])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        update_statistics_all([(z(N), z(N), z(N))], torch.zeros(1, N, dtype=torch.int32), z(1, N, 2), 64, 48)
