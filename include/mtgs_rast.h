@@ -366,6 +366,18 @@ int mtgs_stats_desc_bytes(void);
 int mtgs_densify_stats_batch(int n_nodes, const mtgs_stats_desc *table, int64_t total_blocks, const int32_t *radii,
                              const float *grad2d, int width, int height, void *stream);
 
+/* ---- patch-wise depth NCC of the loss head (ncc_loss_lambda = 0.1 in config/MTGS.py; patches 32 x 32, stride 16) ---------
+ * calculate_depth_ncc_loss (mtgs/utils/geometric_loss.py:322-348): F.unfold of pred / gt / mask with padding k/2, patches
+ * whose mask is all ones (boolean index: host sync, sorting backward), per patch pc = p - mean(p), gc = g - mean(g),
+ * ncc = mean(pc gc) / (sqrt(mean(pc^2) + 1e-8) sqrt(mean(gc^2) + 1e-8));  out[0] = 1 - mean over valid patches (NaN when
+ * none), out[1] = their number.  pred, gt [H,W] f32, mask [H,W] u8 (nullable).  patch_stats[mtgs_ncc_patches * 6] is
+ * written by the forward and read by the backward; bwd: v_pred[H,W] fully written (gt gets no gradient). */
+int mtgs_ncc_patches(int width, int height, int patch_size, int stride, int64_t *n);
+int mtgs_ncc_fwd(int width, int height, int patch_size, int stride, const float *pred, const float *gt, const uint8_t *mask,
+                 float *patch_stats, float *out, void *stream);
+int mtgs_ncc_bwd(int width, int height, int patch_size, int stride, const float *pred, const float *gt,
+                 const float *patch_stats, const float *v_out, const float *fwd_out, float *v_pred, void *stream);
+
 /* ---- out-of-box regulariser of the rigid object nodes (config/MTGS.py:117 oob_lambda = 1.0) -----------------------------
  * mtgs_scene_graph.py:949-967 loops over the rigid models with a full-size `model_id == id` comparison, boolean-mask
  * gathers and two host synchronisations per node; here every node of the frame in one pass.  For the nodes with at least

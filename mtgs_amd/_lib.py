@@ -60,6 +60,9 @@ _SIGNATURES = {
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_stats_desc_bytes": [],
     "mtgs_densify_stats_batch": [_i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp],
+    "mtgs_ncc_patches": [_i32, _i32, _i32, _i32, _i64p],
+    "mtgs_ncc_fwd": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_ncc_bwd": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_oob_desc_bytes": [],
     "mtgs_oob_fwd": [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mtgs_oob_bwd": [_i32, _vp, _i64, _vp, _vp, _vp, _vp],

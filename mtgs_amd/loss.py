@@ -247,3 +247,46 @@ def oob_loss(nodes, radii: Tensor, starts, tolerance: float = 1.5) -> Tensor:
         flat += [means, opacities]
         limits.append([float(s) / 2 + float(tolerance) for s in size])
     return _OobLoss.apply(radii, tuple(int(s) for s in starts), limits, *flat)
+
+
+class _DepthNcc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, mask, patch_size, stride):
+        require_gpu(pred, gt, mask)
+        H, W = pred.shape[0], pred.shape[1]
+        dev = pred.device
+        p_c = pred.detach().to(torch.float32).reshape(H, W).contiguous()
+        g_c = gt.detach().to(torch.float32).reshape(H, W).contiguous()
+        m_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        n = C.c_int64(0)
+        call("mtgs_ncc_patches", W, H, patch_size, stride, C.byref(n))
+        stats = torch.empty(n.value * 6, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        call("mtgs_ncc_fwd", W, H, patch_size, stride, ptr(p_c), ptr(g_c), ptr(m_c), ptr(stats), ptr(out), stream_of(pred))
+        ctx.save_for_backward(p_c, g_c, stats, out)
+        ctx.cfg = (H, W, patch_size, stride, pred.shape, pred.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, v_out):
+        p_c, g_c, stats, out = ctx.saved_tensors
+        H, W, patch_size, stride, shape, dtype = ctx.cfg
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        v_pred = torch.empty_like(p_c)
+        call("mtgs_ncc_bwd", W, H, patch_size, stride, ptr(p_c), ptr(g_c), ptr(stats), ptr(v), ptr(out), ptr(v_pred), stream_of(p_c))
+        return v_pred.reshape(shape).to(dtype), None, None, None, None
+
+
+def depth_ncc_loss(pred_depth: Tensor, gt_depth: Tensor, patch_size: int = 32, stride: int = 16,
+                   mask: Optional[Tensor] = None) -> Tensor:
+    """calculate_depth_ncc_loss(pred_depth, gt_depth, patch_size, stride, mask=mask)
+    (/root/reference/mtgs/utils/geometric_loss.py:322-348; called at mtgs_scene_graph.py:886-894 with the config's
+    ncc_patch_size = 32, ncc_stride = 16): one minus the mean, over the patches whose mask is entirely set, of the normalised
+    cross-correlation between the two depth images.  pred_depth, gt_depth [H,W,1] (or [H,W]), mask [H,W,1] bool.  Two
+    launches forward, one backward, no host synchronisation; differentiable with respect to pred_depth."""
+    assert pred_depth.dim() in (2, 3) and pred_depth.numel() == pred_depth.shape[0] * pred_depth.shape[1], pred_depth.shape
+    assert gt_depth.numel() == pred_depth.numel() and (mask is None or mask.numel() == pred_depth.numel()), (gt_depth.shape,)
+    assert patch_size > 0 and stride > 0
+    if gt_depth.requires_grad:
+        raise NotImplementedError("depth_ncc_loss: gradient with respect to gt_depth is not implemented")
+    return _DepthNcc.apply(pred_depth, gt_depth, mask, int(patch_size), int(stride))

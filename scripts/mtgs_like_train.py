@@ -24,7 +24,7 @@ import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
 from mtgs_amd.densify import update_statistics, update_statistics_all  # noqa: E402
-from mtgs_amd.loss import masked_l1, masked_ssim, output_head  # noqa: E402
+from mtgs_amd.loss import depth_ncc_loss, masked_l1, masked_ssim, output_head  # noqa: E402
 from mtgs_amd.nodes import camera_space_normals, node_gaussians  # noqa: E402
 from mtgs_amd.synthetic import make_camera  # noqa: E402
 
@@ -138,6 +138,22 @@ def head_chain(render, alpha, bg, E, normals):
     return rgb, app, depth, normal
 
 
+def ncc_chain(pred_depth, gt_depth, patch_size=32, stride=16, mask=None):
+    """calculate_depth_ncc_loss (mtgs/utils/geometric_loss.py:322-348), operator by operator."""
+    pred_depth, gt_depth = pred_depth.squeeze(-1), gt_depth.squeeze(-1)
+    pad = patch_size // 2
+    mask = mask.squeeze(-1).float()
+    pp = F.unfold(pred_depth[None, None], kernel_size=patch_size, padding=pad, stride=stride)
+    gp = F.unfold(gt_depth[None, None], kernel_size=patch_size, padding=pad, stride=stride)
+    mp = F.unfold(mask[None, None], kernel_size=patch_size, padding=pad, stride=stride)
+    valid = mp.all(dim=1).squeeze(0)
+    pp, gp = pp[:, :, valid], gp[:, :, valid]
+    pc, gc = pp - pp.mean(dim=1, keepdim=True), gp - gp.mean(dim=1, keepdim=True)
+    ps = torch.sqrt((pc ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    gs = torch.sqrt((gc ** 2).mean(dim=1, keepdim=True) + 1e-8)
+    return 1 - ((pc / ps) * (gc / gs)).mean(dim=1).mean()
+
+
 def _win(dev):
     c = torch.arange(11, dtype=torch.float) - 5
     g = torch.exp(-(c ** 2) / (2 * 1.5 ** 2))
@@ -167,7 +183,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
 def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     """shipped = None: RGB only (the path + L1 + SSIM).  shipped = dict(exposure=[T,3,4] parameter, bg=[3], gt_depth, gt_normal
     per camera): the option set of config/MTGS.py -- predict_normals (7 blended channels), the exposure model, the lidar
-    inverse-depth L1 and the normal L1 (mtgs_scene_graph.py:856-883, 897-936)."""
+    inverse-depth L1, the depth NCC and the normal L1 (mtgs_scene_graph.py:856-894, 897-936)."""
     vm, K, c2w, t = cam
     gs = (gaussians_fused if fused else gaussians_chain)(P, c2w, t, n)
     colors = gs["rgbs"]
@@ -193,9 +209,10 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
             loss_d = torch.abs(inv_gt - inv_pred)[dmask].mean()
             loss_n = torch.abs(gt_n - normal)[mask.squeeze(-1)].mean()
         ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)     # use_ssim_on_raw_rgb
+        ncc = depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask) if fused else ncc_chain(depth, gt_d, 32, 16, mask=dmask)   # :886-894
         # pixels nothing was splatted on have a 0/0 normal; MTGS adds the term only when it is finite (mtgs_scene_graph.py:939)
         loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
-        loss = 0.8 * l1 + 0.2 * (1 - ssim) + 0.5 * loss_d + 0.1 * loss_n
+        loss = 0.8 * l1 + 0.2 * (1 - ssim) + 0.5 * loss_d + 0.1 * loss_n + 0.1 * ncc
     else:
         rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)          # black background (mtgs_scene_graph.py:672-676)
         l1 = masked_l1(gt, rgb, mask) if fused else torch.abs(gt - rgb)[mask.squeeze(-1)].mean()

@@ -183,3 +183,46 @@ def test_oob_loss_matches_the_reference_loop(hip_lib, n_nodes):
             expect = o.grad if o.grad is not None else torch.zeros_like(o)
             assert p.grad.shape == o.shape
             assert torch.allclose(p.grad.cpu().double(), expect, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,W,k,s", [(211, 333, 32, 16), (64, 96, 7, 7), (100, 100, 16, 5), (40, 40, 64, 16)])
+def test_depth_ncc_loss_matches_the_reference_formulation(hip_lib, H, W, k, s):
+    """mtgs_amd.loss.depth_ncc_loss against calculate_depth_ncc_loss (geometric_loss.py:322-348) restated with F.unfold in
+    float64: value to 2e-5, gradient to 1e-3 of its maximum (fp32 sums over 1024-pixel patches); a 64-pixel patch on a
+    40-pixel image has no valid patch: NaN, as the reference's mean of an empty tensor."""
+    import torch.nn.functional as F
+    from mtgs_amd.loss import depth_ncc_loss
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(H + k)
+    gt = torch.rand(H, W, 1, generator=g) * 30 + 1
+    pred0 = gt + torch.randn(H, W, 1, generator=g) * 2
+    pred0[10:30, 10:30] = 7.25                                     # a flat region: variance ~ 0, the 1e-8 floor matters
+    mask = torch.rand(H, W, 1, generator=g) > 0.0005
+    mask[: H // 8] = False
+
+    def reference(pred_depth, gt_depth, mask):
+        pred_depth, gt_depth = pred_depth.squeeze(-1), gt_depth.squeeze(-1)
+        pad = k // 2
+        m = mask.squeeze(-1).to(pred_depth.dtype)
+        pp = F.unfold(pred_depth[None, None], kernel_size=k, padding=pad, stride=s)
+        gp = F.unfold(gt_depth[None, None], kernel_size=k, padding=pad, stride=s)
+        mp = F.unfold(m[None, None], kernel_size=k, padding=pad, stride=s)
+        valid = mp.all(dim=1).squeeze(0)
+        pp, gp = pp[:, :, valid], gp[:, :, valid]
+        pc, gc = pp - pp.mean(dim=1, keepdim=True), gp - gp.mean(dim=1, keepdim=True)
+        ps = torch.sqrt((pc ** 2).mean(dim=1, keepdim=True) + 1e-8)
+        gs = torch.sqrt((gc ** 2).mean(dim=1, keepdim=True) + 1e-8)
+        return 1 - ((pc / ps) * (gc / gs)).mean(dim=1).mean(), int(valid.sum())
+
+    p_ref = pred0.double().requires_grad_(True)
+    ref, n_valid = reference(p_ref, gt.double(), mask)
+    p = pred0.to(dev).requires_grad_(True)
+    val = depth_ncc_loss(p, gt.to(dev), patch_size=k, stride=s, mask=mask.to(dev))
+    if n_valid == 0:
+        assert torch.isnan(val) and torch.isnan(ref)
+        return
+    (2.0 * ref).backward()
+    (2.0 * val).backward()
+    assert abs(float(val.detach()) - float(ref.detach())) <= 2e-5
+    scale = float(p_ref.grad.abs().max())
+    assert float((p.grad.cpu().double() - p_ref.grad).abs().max()) <= 1e-3 * scale
