@@ -5,7 +5,9 @@ checker; run directly, `python tests/fuzz_gpu.py --cases 500 --seed 3`, or throu
     kernels, forward bit-for-bit and gradients to fp32-atomic accuracy, over random sizes / cameras / channel counts /
     render modes, including degenerate inputs (nothing visible, one Gaussian, huge splats, image smaller than a tile);
   * a sample of the cases against the CPU oracle;
-  * node_gaussians / masked_ssim / masked_l1 / update_statistics vs their PyTorch formulations at random sizes.
+  * node_gaussians / masked_ssim / masked_l1 / update_statistics vs their PyTorch formulations at random sizes;
+  * camera_space_normals vs its oracle, output_head / depth_ncc_loss vs their PyTorch formulations, the batched
+    collect_gaussians vs per-node calls.
 Exits non-zero on the first mismatch, printing the failing configuration (re-run with --seed / --case)."""
 import argparse
 import math
@@ -199,6 +201,135 @@ def check_neighbours(rng):
     assert abs(float(l.detach()) - float(lr.detach())) <= 2e-6 and torch.allclose(p2.grad.double(), pr.grad, rtol=1e-5, atol=1e-12), f"l1 {H}x{W}"
 
 
+def check_later_neighbours(rng):
+    """camera_space_normals vs oracle/normals_oracle.py, output_head and depth_ncc_loss vs their PyTorch formulations,
+    the batched collect_gaussians vs per-node calls -- at random sizes."""
+    import torch.nn.functional as F
+    from mtgs_amd.loss import depth_ncc_loss, output_head
+    from mtgs_amd.nodes import camera_space_normals, collect_gaussians
+    from oracle import normals_oracle as no
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    # ---- normals
+    N = int(rng.choice([1, 63, 64, 65, 257, 5000]))
+    quats = torch.randn(N, 4, generator=g); scales = torch.exp(torch.randn(N, 3, generator=g)); means = torch.randn(N, 3, generator=g) * 8
+    A = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    c2w = torch.cat([A, torch.randn(3, 1, generator=g)], 1)[None]
+    G = torch.randn(N, 3, generator=g)
+    q = quats.to(dev).requires_grad_(True)
+    nrm = camera_space_normals(q, scales.to(dev), means.to(dev), c2w.to(dev))
+    (nrm * G.to(dev)).sum().backward()
+    ref_n = no.normals_fwd(quats.numpy(), scales.numpy(), means.numpy(), c2w.numpy())
+    ref_g = no.normals_bwd(quats.numpy(), scales.numpy(), means.numpy(), c2w.numpy(), G.numpy())
+    d = c2w[0, :, 3][None] - means
+    safe = ((torch.from_numpy(ref_n).float() @ A.T * (d / d.norm(dim=-1, keepdim=True))).sum(-1).abs() > 1e-5).numpy()
+    if safe.any():
+        assert np.abs(nrm.detach().cpu().numpy() - ref_n)[safe].max() < 3e-6, f"normals N={N}"
+        assert np.abs(q.grad.cpu().numpy() - ref_g)[safe].max() < 3e-5 * max(1.0, np.abs(ref_g).max()), f"normals grad N={N}"
+    # ---- output head
+    H, W = int(rng.integers(3, 120)), int(rng.integers(3, 150))
+    D = int(rng.choice([4, 7, 8]))
+    nc = 3 if D >= 7 else -1
+    render = torch.rand(1, H, W, D, generator=g) * 1.4 - 0.2
+    render[..., -1] = torch.rand(1, H, W, generator=g) * 20
+    alpha = torch.rand(1, H, W, 1, generator=g) * (torch.rand(1, H, W, 1, generator=g) > 0.1)
+    bg = torch.rand(3, generator=g)
+    E = torch.eye(3, 4) + 0.1 * torch.randn(3, 4, generator=g)
+    cots = [torch.randn(H, W, 3, generator=g), torch.randn(H, W, 3, generator=g), torch.randn(H, W, 1, generator=g), torch.randn(H, W, 3, generator=g)]
+
+    def head_ref(render, alpha, bg, E):
+        rgb = torch.clamp(render[..., :3] + (1 - alpha) * bg, 0.0, 1.0).squeeze(0)
+        app = torch.clamp(rgb.matmul(E[:3, :3]) + E[None, None, :3, 3], 0, 1)
+        dd = render[..., -1:]
+        depth = torch.where(alpha > 0, dd, dd.detach().max()).squeeze(0)
+        normal = None
+        if nc >= 0:
+            nm = render[..., nc:nc + 3].squeeze(0)
+            normal = (nm / nm.norm(dim=-1, keepdim=True) + 1) / 2
+        return rgb, app, depth, normal
+
+    outs = []
+    for fn, dt, dv in ((head_ref, torch.float64, "cpu"), (lambda r, a, b, e: output_head(r, a, b, e, depth=True, normal_channel=nc), torch.float32, dev)):
+        Pp = [t.to(device=dv, dtype=dt).requires_grad_(True) for t in (render, alpha, bg, E)]
+        o = fn(*Pp)
+        sum((x * c.to(device=dv, dtype=dt)).sum() for x, c in zip(o, cots) if x is not None).backward()
+        outs.append((o, [t.grad for t in Pp]))
+    for x, y in zip(outs[0][0], outs[1][0]):
+        if x is not None:
+            assert float((x.detach() - y.detach().cpu().double()).abs().max()) < 5e-6, f"head value {H}x{W} D={D}"
+    for x, y, nm in zip(outs[0][1], outs[1][1], ("render", "alpha", "bg", "E")):
+        diff = (x - y.cpu().double()).abs()
+        sc = float(x.abs().max()) + 1e-12
+        if nm in ("render", "alpha"):   # a pixel within fp32 rounding of a clamp edge may take the other branch
+            assert float((diff > 3e-5 * sc).double().mean()) < 5e-3, f"head grad {nm} {H}x{W} D={D}"
+    # ---- depth NCC
+    H, W = int(rng.integers(20, 150)), int(rng.integers(20, 200))
+    k = int(rng.choice([4, 7, 16, 32])); st = int(rng.choice([k, max(1, k // 2), 5]))
+    gt = torch.rand(H, W, 1, generator=g) * 30 + 1
+    pred0 = gt + torch.randn(H, W, 1, generator=g)
+    mask = torch.rand(H, W, 1, generator=g) > 0.002
+
+    def ncc_ref(pd, gd, m):
+        pd, gd = pd.squeeze(-1), gd.squeeze(-1)
+        pad = k // 2
+        mm = m.squeeze(-1).to(pd.dtype)
+        pp = F.unfold(pd[None, None], kernel_size=k, padding=pad, stride=st)
+        gp = F.unfold(gd[None, None], kernel_size=k, padding=pad, stride=st)
+        valid = F.unfold(mm[None, None], kernel_size=k, padding=pad, stride=st).all(dim=1).squeeze(0)
+        pp, gp = pp[:, :, valid], gp[:, :, valid]
+        pc, gc = pp - pp.mean(dim=1, keepdim=True), gp - gp.mean(dim=1, keepdim=True)
+        ps, gs = torch.sqrt((pc ** 2).mean(dim=1, keepdim=True) + 1e-8), torch.sqrt((gc ** 2).mean(dim=1, keepdim=True) + 1e-8)
+        return 1 - ((pc / ps) * (gc / gs)).mean(dim=1).mean(), int(valid.sum())
+
+    pr = pred0.double().requires_grad_(True)
+    ref, nv = ncc_ref(pr, gt.double(), mask)
+    pq = pred0.to(dev).requires_grad_(True)
+    val = depth_ncc_loss(pq, gt.to(dev), k, st, mask=mask.to(dev))
+    if nv == 0:
+        assert torch.isnan(val), f"ncc {H}x{W} k={k} s={st}: expected NaN"
+    else:
+        ref.backward(); val.backward()
+        assert abs(float(val.detach()) - float(ref.detach())) < 3e-5, f"ncc {H}x{W} k={k} s={st}"
+        assert float((pq.grad.cpu().double() - pr.grad).abs().max()) <= 2e-3 * float(pr.grad.abs().max()) + 1e-9, f"ncc grad {H}x{W} k={k} s={st}"
+    # ---- batched collect vs per-node
+    sizes = [int(x) for x in rng.choice([0, 1, 63, 64, 65, 300, 1000], size=int(rng.integers(1, 7)))]
+    if sum(sizes) == 0:
+        sizes.append(5)
+    c2 = torch.eye(4)[None, :3].clone(); c2[0, :, 3] = torch.randn(3, generator=g)
+    base = []
+    for n_ in sizes:
+        p = {"means": torch.randn(n_, 3, generator=g) * 4, "scales": torch.randn(n_, 3, generator=g) - 1, "quats": torch.randn(n_, 4, generator=g),
+             "opacities": torch.randn(n_, 1, generator=g), "features_dc": torch.randn(n_, 3, generator=g),
+             "features_rest": torch.randn(n_, 15, 3, generator=g) * 0.3}
+        if rng.integers(2):
+            qq = torch.randn(4, generator=g)
+            p["instance_quat"], p["instance_trans"] = qq / qq.norm(), torch.randn(3, generator=g)
+        base.append(p)
+    tot = sum(sizes)
+    cot = {"means": torch.randn(tot, 3, generator=g), "scales": torch.randn(tot, 3, generator=g), "quats": torch.randn(tot, 4, generator=g),
+           "opacities": torch.randn(tot, generator=g), "rgbs": torch.randn(tot, 3, generator=g)}
+    res = []
+    for batched in (True, False):
+        Pn = [{k_: v.to(dev).requires_grad_(True) for k_, v in p.items()} for p in base]
+        if batched:
+            o = collect_gaussians(Pn, c2.to(dev), 3, 3)
+        else:
+            parts = [node_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"], p["features_rest"], c2.to(dev), 3, 3,
+                                    instance_quat=p.get("instance_quat"), instance_trans=p.get("instance_trans")) for p in Pn]
+            o = {k_: torch.cat([q_[k_] for q_ in parts], 0) for k_ in cot}
+        sum((o[k_] * cot[k_].to(dev)).sum() for k_ in cot).backward()
+        res.append(({k_: o[k_].detach() for k_ in cot}, [{k_: v.grad for k_, v in p.items()} for p in Pn]))
+    for k_ in cot:
+        assert torch.equal(res[0][0][k_], res[1][0][k_]), f"collect {k_} sizes={sizes}"
+    for ga, gb in zip(res[0][1], res[1][1]):
+        for k_ in ga:
+            assert (ga[k_] is None) == (gb[k_] is None), f"collect grad {k_} sizes={sizes}"
+            if ga[k_] is not None:
+                if k_.startswith("instance_"):
+                    assert torch.allclose(ga[k_], gb[k_], rtol=1e-4, atol=1e-4 * float(gb[k_].abs().max()) + 1e-6), f"collect pose grad sizes={sizes}"
+                else:
+                    assert torch.equal(ga[k_], gb[k_]), f"collect grad {k_} sizes={sizes}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=150)
@@ -211,10 +342,12 @@ def main():
             check_raster(cfg, with_oracle=(i % 5 == 0))
             if i % 3 == 0:
                 check_neighbours(rng)
+            if i % 3 == 1:
+                check_later_neighbours(rng)
         except Exception as e:  # noqa: BLE001
             print(f"FAIL case {i}: {cfg}\n  {type(e).__name__}: {e}")
             raise
-    print(f"fuzz ok: {args.cases} rasterization cases, {(args.cases + 2) // 3} neighbour cases")
+    print(f"fuzz ok: {args.cases} rasterization cases, {(args.cases + 2) // 3} + {(args.cases + 1) // 3} neighbour cases")
 
 
 if __name__ == "__main__":
