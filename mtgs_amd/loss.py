@@ -55,7 +55,7 @@ def masked_ssim(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None, win_sig
     """gt, pred: [H, W, 3]; mask: [H, W, 1] / [H, W] bool or None.  Returns the scalar the reference's MaskedSSIM
     returns (mean of the SSIM map over the masked elements; the mask is cropped by the 5-pixel window margin).
     Differentiable with respect to `pred` (the reference's second argument); `gt` gets no gradient."""
-    assert pred.dim() == 3 and 1 <= pred.shape[2] <= 8 and gt.shape == pred.shape, (gt.shape, pred.shape)
+    assert pred.dim() == 3 and pred.shape[2] == 3 and gt.shape == pred.shape, (gt.shape, pred.shape)
     H, W = pred.shape[:2]
     if H <= 10 or W <= 10:
         raise ValueError(f"masked_ssim: image {H}x{W} is smaller than the 11x11 window")

@@ -160,3 +160,9 @@ def test_later_neighbours_have_no_cpu_fallback_and_validate_arguments():
         oob_loss([(z(N, 3), z(N, 1), [4.0, 2.0, 1.5])], torch.zeros(1, 20, dtype=torch.int32), [3])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         update_statistics_all([(z(N), z(N), z(N))], torch.zeros(1, N, dtype=torch.int32), z(1, N, 2), 64, 48)
+
+
+def test_masked_ssim_takes_three_channels_only():
+    from mtgs_amd.loss import masked_ssim
+    with pytest.raises(AssertionError):
+        masked_ssim(torch.zeros(32, 32, 1), torch.zeros(32, 32, 1))
