@@ -351,8 +351,14 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     outputs); "model_id" is written by the same launch."""
     specs, flat, sizes = [], [], []
     use_sh = model_sh_degree > 0
+    if len(nodes) == 0:
+        raise ValueError("collect_gaussians: no nodes (MTGS returns its empty outputs before reaching the rasterizer, "
+                         "mtgs_scene_graph.py:595-598)")
     for nd in nodes:
         N = nd["means"].shape[0]
+        for k in ("means", "scales", "quats", "opacities", "features_dc", "features_rest"):
+            if nd[k].dtype != torch.float32:
+                raise TypeError(f"collect_gaussians: {k} must be float32, got {nd[k].dtype}")
         rest, add, trav = nd["features_rest"], nd.get("features_adapters"), nd.get("traversal_index")
         if rest.dim() == 4:
             if trav is None:

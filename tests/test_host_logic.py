@@ -166,3 +166,15 @@ def test_masked_ssim_takes_three_channels_only():
     from mtgs_amd.loss import masked_ssim
     with pytest.raises(AssertionError):
         masked_ssim(torch.zeros(32, 32, 1), torch.zeros(32, 32, 1))
+
+
+def test_collect_gaussians_rejects_empty_and_wrong_dtype():
+    from mtgs_amd.nodes import collect_gaussians
+    c2w = torch.eye(4)[None, :3]
+    with pytest.raises(ValueError, match="no nodes"):
+        collect_gaussians([], c2w, 3, 3)
+    N = 4
+    node = {"means": torch.zeros(N, 3, dtype=torch.float64), "scales": torch.zeros(N, 3), "quats": torch.ones(N, 4),
+            "opacities": torch.zeros(N, 1), "features_dc": torch.zeros(N, 3), "features_rest": torch.zeros(N, 15, 3)}
+    with pytest.raises(TypeError, match="float32"):
+        collect_gaussians([node], c2w, 3, 3)
