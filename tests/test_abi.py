@@ -86,3 +86,19 @@ def test_descriptor_tables_match_the_c_structs(hip_lib):
     assert c_fields("mtgs_node_desc") == list(nodes._DESC.names)
     assert c_fields("mtgs_stats_desc") == list(densify._STATS_DESC.names)
     assert c_fields("mtgs_oob_desc") == list(loss._OOB_DESC.names)
+
+
+def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
+    """include/mtgs_rast.h compiles as C99 (no C++-isms, no torch types) and the descriptor structs have the sizes the
+    Python layer uploads."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not installed")
+    src = tmp_path / "h.c"
+    src.write_text('#include "mtgs_rast.h"\n'
+                   'int main(void) { return sizeof(mtgs_node_desc) == 312 && sizeof(mtgs_stats_desc) == 48 && '
+                   'sizeof(mtgs_oob_desc) == 64 ? 0 : 1; }\n')
+    exe = tmp_path / "h"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
