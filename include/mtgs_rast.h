@@ -378,6 +378,14 @@ int mtgs_ncc_fwd(int width, int height, int patch_size, int stride, const float 
 int mtgs_ncc_bwd(int width, int height, int patch_size, int stride, const float *pred, const float *gt,
                  const float *patch_stats, const float *v_out, const float *fwd_out, float *v_pred, void *stream);
 
+/* ---- total variation of the normal image (use_normal_tv_loss = True in config/MTGS.py:114) ---------------------------------
+ * TVLoss.forward (mtgs/utils/geometric_loss.py:293-303) for one image[H,W,channels]:
+ *   out[0] = mean |image[:, :-1] - image[:, 1:]| + mean |image[:-1] - image[1:]|      (NaN inputs propagate)
+ * partials: mtgs_tv_workspace_floats; bwd: v_image fully written (v_out = DEVICE pointer to the scalar cotangent). */
+int mtgs_tv_workspace_floats(int width, int height, int channels, size_t *n);
+int mtgs_tv_fwd(int width, int height, int channels, const float *image, float *partials, float *out, void *stream);
+int mtgs_tv_bwd(int width, int height, int channels, const float *image, const float *v_out, float *v_image, void *stream);
+
 /* ---- out-of-box regulariser of the rigid object nodes (config/MTGS.py:117 oob_lambda = 1.0) -----------------------------
  * mtgs_scene_graph.py:949-967 loops over the rigid models with a full-size `model_id == id` comparison, boolean-mask
  * gathers and two host synchronisations per node; here every node of the frame in one pass.  For the nodes with at least

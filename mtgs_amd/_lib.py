@@ -63,6 +63,9 @@ _SIGNATURES = {
     "mtgs_ncc_patches": [_i32, _i32, _i32, _i32, _i64p],
     "mtgs_ncc_fwd": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_ncc_bwd": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_tv_workspace_floats": [_i32, _i32, _i32, C.POINTER(_sz)],
+    "mtgs_tv_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "mtgs_tv_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_oob_desc_bytes": [],
     "mtgs_oob_fwd": [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mtgs_oob_bwd": [_i32, _vp, _i64, _vp, _vp, _vp, _vp],

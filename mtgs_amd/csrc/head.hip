@@ -101,7 +101,11 @@ __global__ __launch_bounds__(HEAD_BLOCK) void head_bwd_kernel(int64_t P, HeadCfg
             const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
             const float w0 = 0.5f * v_normal[p * 3], w1 = 0.5f * v_normal[p * 3 + 1], w2 = 0.5f * v_normal[p * 3 + 2];
             const float dot = (ux * w0 + uy * w1) + uz * w2;
-            o[cfg.normal_ch] = (w0 - ux * dot) * inv; o[cfg.normal_ch + 1] = (w1 - uy * dot) * inv; o[cfg.normal_ch + 2] = (w2 - uz * dot) * inv;
+            // a zero cotangent gives a zero gradient even where n = 0 (0 / 0 normal): a caller that drops a non-finite
+            // normal term with torch.where instead of MTGS's host-side `if isfinite` (:939) must not get NaN back
+            if (w0 != 0.f || w1 != 0.f || w2 != 0.f) {
+                o[cfg.normal_ch] = (w0 - ux * dot) * inv; o[cfg.normal_ch + 1] = (w1 - uy * dot) * inv; o[cfg.normal_ch + 2] = (w2 - uz * dot) * inv;
+            }
         }
     }
 #pragma unroll

@@ -290,3 +290,36 @@ def depth_ncc_loss(pred_depth: Tensor, gt_depth: Tensor, patch_size: int = 32, s
     if gt_depth.requires_grad:
         raise NotImplementedError("depth_ncc_loss: gradient with respect to gt_depth is not implemented")
     return _DepthNcc.apply(pred_depth, gt_depth, mask, int(patch_size), int(stride))
+
+
+class _TvLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image):
+        require_gpu(image)
+        H, W, Cc = image.shape[-3], image.shape[-2], image.shape[-1]
+        x = image.detach().to(torch.float32).reshape(H, W, Cc).contiguous()
+        n = C.c_size_t(0)
+        call("mtgs_tv_workspace_floats", W, H, Cc, C.byref(n))
+        partials = torch.empty(n.value, dtype=torch.float32, device=x.device)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        call("mtgs_tv_fwd", W, H, Cc, ptr(x), ptr(partials), ptr(out), stream_of(x))
+        ctx.save_for_backward(x)
+        ctx.cfg = (H, W, Cc, image.shape, image.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, v_out):
+        (x,) = ctx.saved_tensors
+        H, W, Cc, shape, dtype = ctx.cfg
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        v_x = torch.empty_like(x)
+        call("mtgs_tv_bwd", W, H, Cc, ptr(x), ptr(v), ptr(v_x), stream_of(x))
+        return v_x.reshape(shape).to(dtype)
+
+
+def tv_loss(image: Tensor) -> Tensor:
+    """TVLoss()(image) of MTGS's normal term (/root/reference/mtgs/utils/geometric_loss.py:293-303, used at
+    mtgs_scene_graph.py:931-932): mean |image[:, :-1] - image[:, 1:]| + mean |image[:-1] - image[1:]| for one image
+    [H,W,C] (or [1,H,W,C]).  Two launches forward, one backward."""
+    assert image.dim() in (3, 4) and (image.dim() == 3 or image.shape[0] == 1), image.shape
+    return _TvLoss.apply(image)

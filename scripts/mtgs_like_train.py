@@ -24,7 +24,7 @@ import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
 from mtgs_amd.densify import update_statistics, update_statistics_all  # noqa: E402
-from mtgs_amd.loss import depth_ncc_loss, masked_l1, masked_ssim, output_head  # noqa: E402
+from mtgs_amd.loss import depth_ncc_loss, masked_l1, masked_ssim, output_head, tv_loss  # noqa: E402
 from mtgs_amd.nodes import camera_space_normals, node_gaussians  # noqa: E402
 from mtgs_amd.synthetic import make_camera  # noqa: E402
 
@@ -203,11 +203,12 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         if fused:
             l1 = masked_l1(gt, app, mask)
             loss_d = masked_l1(inv_gt, inv_pred, dmask)
-            loss_n = masked_l1(gt_n, normal, mask)
+            loss_n = masked_l1(gt_n, normal, mask) + tv_loss(normal)                 # :931-934
         else:
             l1 = torch.abs(gt - app)[mask.squeeze(-1)].mean()
             loss_d = torch.abs(inv_gt - inv_pred)[dmask].mean()
-            loss_n = torch.abs(gt_n - normal)[mask.squeeze(-1)].mean()
+            loss_n = torch.abs(gt_n - normal)[mask.squeeze(-1)].mean() + \
+                torch.mean(torch.abs(normal[:, :-1, :] - normal[:, 1:, :])) + torch.mean(torch.abs(normal[:-1, :, :] - normal[1:, :, :]))
         ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)     # use_ssim_on_raw_rgb
         ncc = depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask) if fused else ncc_chain(depth, gt_d, 32, 16, mask=dmask)   # :886-894
         # pixels nothing was splatted on have a 0/0 normal; MTGS adds the term only when it is finite (mtgs_scene_graph.py:939)

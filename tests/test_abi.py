@@ -19,7 +19,7 @@ def test_header_declares_the_operator_table():
     syms = header_symbols()
     for must in ("mtgs_sh_fwd", "mtgs_sh_bwd", "mtgs_project_fwd", "mtgs_project_bwd", "mtgs_isect_count",
                  "mtgs_isect_scan", "mtgs_isect_emit", "mtgs_sort_pairs", "mtgs_isect_offsets", "mtgs_blend_fwd",
-                 "mtgs_blend_bwd", "mtgs_tile_schedule", "mtgs_bin_compact", "mtgs_bin_emit", "mtgs_sort_pairs_u32", "mtgs_bin_sort_tiles", "mtgs_bin_build", "mtgs_dp_pack", "mtgs_dp_accumulate", "mtgs_dp_pack_ordered", "mtgs_node_fwd", "mtgs_node_bwd", "mtgs_node_fwd_batch", "mtgs_node_bwd_batch", "mtgs_densify_stats", "mtgs_densify_stats_batch", "mtgs_normals_fwd", "mtgs_normals_bwd", "mtgs_head_fwd", "mtgs_head_bwd", "mtgs_oob_fwd", "mtgs_oob_bwd", "mtgs_ncc_fwd", "mtgs_ncc_bwd", "mtgs_ssim_workspace_floats", "mtgs_ssim_fwd", "mtgs_ssim_bwd", "mtgs_l1_workspace_floats", "mtgs_l1_fwd", "mtgs_l1_bwd", "mtgs_dp_reduce", "mtgs_rast_version", "mtgs_rast_last_error"):
+                 "mtgs_blend_bwd", "mtgs_tile_schedule", "mtgs_bin_compact", "mtgs_bin_emit", "mtgs_sort_pairs_u32", "mtgs_bin_sort_tiles", "mtgs_bin_build", "mtgs_dp_pack", "mtgs_dp_accumulate", "mtgs_dp_pack_ordered", "mtgs_node_fwd", "mtgs_node_bwd", "mtgs_node_fwd_batch", "mtgs_node_bwd_batch", "mtgs_densify_stats", "mtgs_densify_stats_batch", "mtgs_normals_fwd", "mtgs_normals_bwd", "mtgs_head_fwd", "mtgs_head_bwd", "mtgs_oob_fwd", "mtgs_oob_bwd", "mtgs_ncc_fwd", "mtgs_ncc_bwd", "mtgs_tv_fwd", "mtgs_tv_bwd", "mtgs_ssim_workspace_floats", "mtgs_ssim_fwd", "mtgs_ssim_bwd", "mtgs_l1_workspace_floats", "mtgs_l1_fwd", "mtgs_l1_bwd", "mtgs_dp_reduce", "mtgs_rast_version", "mtgs_rast_last_error"):
         assert must in syms
 
 

@@ -226,3 +226,25 @@ def test_depth_ncc_loss_matches_the_reference_formulation(hip_lib, H, W, k, s):
     assert abs(float(val.detach()) - float(ref.detach())) <= 2e-5
     scale = float(p_ref.grad.abs().max())
     assert float((p.grad.cpu().double() - p_ref.grad).abs().max()) <= 1e-3 * scale
+
+
+@pytest.mark.parametrize("H,W,C_", [(97, 131, 3), (1, 50, 3), (40, 1, 1), (64, 64, 4)])
+def test_tv_loss_matches_the_reference_formulation(hip_lib, H, W, C_):
+    """mtgs_amd.loss.tv_loss against TVLoss.forward (geometric_loss.py:293-303) in float64; a one-pixel-wide image has an
+    empty difference tensor whose mean is NaN in the reference too."""
+    from mtgs_amd.loss import tv_loss
+    g = torch.Generator().manual_seed(H * 3 + W)
+    x0 = torch.rand(H, W, C_, generator=g)
+    if H > 5 and W > 5:
+        x0[2, 3] = x0[2, 4]                       # exact ties: sign(0) = 0
+    xr = x0.double().requires_grad_(True)
+    ref = torch.mean(torch.abs(xr[:, :-1, :] - xr[:, 1:, :])) + torch.mean(torch.abs(xr[:-1, :, :] - xr[1:, :, :]))
+    x = x0.cuda().requires_grad_(True)
+    val = tv_loss(x)
+    if torch.isnan(ref):
+        assert torch.isnan(val)
+        return
+    (1.5 * ref).backward()
+    (1.5 * val).backward()
+    assert abs(float(val.detach()) - float(ref.detach())) < 2e-6
+    assert torch.allclose(x.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-9)
