@@ -263,14 +263,15 @@ def main():
     step_bytes = b_fwd + b_bwd
     k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     achieved = bytes_bwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic = None
+    traffic = valu_busy = None
     pmc = ROOT / "profiles" / "pmc_blend_bwd.json"
     if pmc.exists():
         try:
             if (args.n_gaussians, args.width, args.height) == (2_000_000, 1920, 1080):  # the profiled workload
-                traffic = json.loads(pmc.read_text()).get(args.variant, {}).get("hbm_bytes_per_launch")
+                rec = json.loads(pmc.read_text()).get(args.variant, {})
+                traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac")
         except Exception:
-            traffic = None
+            traffic = valu_busy = None
 
     out = {
         "metric": "rendered Mpix/s (fwd+bwd) @ 2M Gaussians 1920x1080",
@@ -292,7 +293,9 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
                      "launches_timed": len(kernel_ms),
-                     "note": "kernel is VALU/LDS/atomic bound, not HBM bound (DESIGN.md section 4)",
+                     "note": "kernel is VALU bound, not HBM bound (DESIGN.md section 4); valu_busy_frac = SQ_ACTIVE_INST_VALU*4/1024 "
+                             "over GRBM_GUI_ACTIVE/8 from the committed rocprofv3 --pmc passes of this workload",
+                     "valu_busy_frac": valu_busy,
                      "whole_step": {"algorithmic_bytes": step_bytes, "unit": "GB/s",
                                     "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
