@@ -234,6 +234,72 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     return loss.detach()
 
 
+def iteration_nograd(P, cam, gt, mask, stats, win, W, H, shipped):
+    """the loss of `iteration` without backward / statistics (debug aid)"""
+    vm, K, c2w, t = cam
+    gs = gaussians_fused(P, c2w, t, 3)
+    colors = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w, rgbs=gs["rgbs"]) if shipped else gs["rgbs"]
+    render, alpha, _ = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H, packed=False,
+                                     render_mode="RGB+ED", rasterize_mode="antialiased")
+    rgb = torch.clamp(render[0, ..., :3], 0.0, 1.0)
+    return 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
+
+
+@torch.no_grad()
+def refine(P, stats, max_growth=0.03):
+    """Densification in miniature, after VanillaGaussianSplattingModel.refinement_after (vanilla_gaussian_splatting.py:476-577):
+    per static node, from the accumulated statistics -- average screen-space gradient = xys_grad_norm / vis_counts --
+    duplicate the small Gaussians and split the large ones among the highest-gradient few per cent, cull the nearly
+    transparent ones; the parameters become NEW leaf tensors of a different length (rigid object nodes are left alone).
+    Returns the number of Gaussians added and culled.  What matters here is that N changes under the fused path."""
+    added = culled = 0
+    surgery = []
+    for (name, p), st in zip(P.items(), stats):
+        if "instance_quats" in p:
+            continue
+        n = p["means"].shape[0]
+        avg = st[0] / st[1].clamp(min=1)
+        k = max(1, int(n * max_growth))
+        high = torch.zeros(n, dtype=torch.bool, device=avg.device)
+        high[torch.topk(avg, k).indices] = True
+        high &= avg > 0
+        big = torch.exp(p["scales"]).amax(dim=-1) > 0.12
+        dup, split = high & ~big, high & big
+        keep = torch.sigmoid(p["opacities"]).squeeze(-1) > 0.02
+        keep &= ~split                                   # a split Gaussian is replaced by its two halves
+        # both copies of a duplicated Gaussian get the opacity that composites to the original one
+        # (1 - (1 - a')^2 = a), so that the image does not jump at the refinement step
+        opac = p["opacities"].clone()
+        sel = dup                                        # (split samples are smaller and displaced: they keep their opacity)
+        a2 = 1 - torch.sqrt(1 - torch.sigmoid(opac[sel]).clamp(max=0.9999))
+        opac[sel] = torch.log(a2 / (1 - a2))
+        new = {}
+        n_add = int(dup.sum()) + 2 * int(split.sum())
+        for key, v in p.items():
+            surgery.append((v, keep, dup, split))        # old parameter and the row selections (for the Adam state)
+            if key == "opacities":
+                v = opac
+            parts = [v[keep], v[dup], v[split], v[split]]
+            if key == "means" and split.any():           # two halves along the LONGEST axis (rotated into the world), +- 0.45 sigma
+                sc = torch.exp(p["scales"][split])
+                local = torch.zeros_like(sc).scatter_(1, sc.argmax(dim=1, keepdim=True), 0.45 * sc.amax(dim=1, keepdim=True))
+                qn = p["quats"][split] / p["quats"][split].norm(dim=-1, keepdim=True)
+                off = torch.bmm(quat_to_rotmat_n(qn), local[:, :, None]).squeeze(-1)
+                parts[2], parts[3] = v[split] + off, v[split] - off
+            if key == "scales" and split.any():          # only that axis shrinks
+                sc = v[split]
+                shrink = torch.zeros_like(sc).scatter_(1, sc.argmax(dim=1, keepdim=True), math.log(1.6))
+                parts[2] = parts[3] = sc - shrink
+            new[key] = torch.cat(parts, 0).contiguous().requires_grad_(True)
+            surgery[-1] = surgery[-1] + (new[key],)
+        P[name] = new
+        n_new = new["means"].shape[0]
+        added += int(dup.sum()) + 2 * int(split.sum())
+        culled += n - int(keep.sum())
+        st[0], st[1], st[2] = torch.zeros(n_new, device=avg.device), torch.ones(n_new, device=avg.device), torch.zeros(n_new, device=avg.device)
+    return added, culled, surgery
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-background", type=int, default=1_600_000)
@@ -246,6 +312,8 @@ def main():
     ap.add_argument("--shipped", action="store_true", help="the option set of config/MTGS.py: predict_normals (7 blended channels), "
                     "exposure model, inverse-depth and normal losses")
     ap.add_argument("--steps", type=int, default=0)
+    ap.add_argument("--debug-refine", action="store_true")
+    ap.add_argument("--refine-every", type=int, default=0, help="with --steps: densify (duplicate / split / cull) every so many steps")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", choices=["both", "fused", "chain"], default="both", help="profiling aid: time one variant only")
     args = ap.parse_args()
@@ -315,17 +383,50 @@ def main():
     for a, b in zip(sc, sf):
         assert torch.allclose(a[1], b[1]) and torch.allclose(a[2], b[2])
     if args.steps:
-        opt = torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
-                                {"params": [p[k] for p in P.values() for k in p if not k.startswith("features")], "lr": 1e-4}], foreach=True)
+        def make_opt():
+            extra = [shipped["exposure"]] if shipped else []
+            return torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
+                                     {"params": [p[k] for p in P.values() for k in p if not k.startswith("features")] + extra, "lr": 1e-4}],
+                                    foreach=True)
+        opt = make_opt()
         stats = mk_stats()
         curve = []
         for i in range(args.steps):
             opt.zero_grad(set_to_none=True)
             curve.append(float(iteration(P, cams[i % T], targets[i % T], mask, True, stats, win, W, H, shipped=shipped)))
             opt.step()
+            if args.refine_every and (i + 1) % args.refine_every == 0 and i + 1 < args.steps:
+                before = sum(p["means"].shape[0] for p in P.values())
+                full_state = {id(q): opt.state[q] for q in opt.state}
+                added, culled, surgery = refine(P, stats)
+                # the Adam moments follow their rows, in the spirit of MTGS's remove_from_optim / dup_in_optim
+                # (vanilla_gaussian_splatting.py:392-446; there the new rows start from zero moments)
+                old_state = {id(o): opt.state.get(o) for o, _, _, _, _ in surgery}
+                opt = make_opt()
+                for o, keep, dup, split, new_p in surgery:
+                    st_o = old_state.get(id(o))
+                    if st_o:   # new rows inherit the moments of their source row (zeros would make their first steps ~3x larger)
+                        pad = lambda t: torch.cat([t[keep], t[dup], t[split], t[split]], 0)
+                        opt.state[new_p] = {"step": st_o["step"], "exp_avg": pad(st_o["exp_avg"]), "exp_avg_sq": pad(st_o["exp_avg_sq"])}
+                # the untouched parameters (object nodes, exposure) keep their whole state
+                for grp in opt.param_groups:
+                    for q in grp["params"]:
+                        if q not in opt.state and id(q) in full_state:
+                            opt.state[q] = full_state[id(q)]
+                if args.debug_refine:
+                    with torch.no_grad():
+                        for mode in ("after",):
+                            l_dbg = float(iteration_nograd(P, cams[i % T], targets[i % T], mask, stats, win, W, H, shipped))
+                    print(f"   loss at camera {i % T}: before step {curve[-1]:.4f}, right after refine {l_dbg:.4f}")
+                print(f"step {i + 1}: refine {before} -> {sum(p['means'].shape[0] for p in P.values())} Gaussians (+{added} -{culled})")
         k = max(1, args.steps // 8)
         print("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
-        assert sum(curve[-T:]) < 0.7 * sum(curve[:T]), "training did not reduce the loss"
+        if args.refine_every:
+            # the synthetic scene starts from the TRUE geometry, so every split perturbs a correct model: the run checks
+            # that N can change under the fused path (tables, statistics, optimizer state) and that training keeps working
+            assert all(math.isfinite(c) for c in curve) and min(curve) < 0.7 * curve[0] and curve[-1] < 1.2 * curve[0], curve[-5:]
+        else:
+            assert sum(curve[-T:]) < 0.7 * sum(curve[:T]), "training did not reduce the loss"
 
 
 if __name__ == "__main__":

@@ -176,6 +176,13 @@ def test_mtgs_like_iteration_fused_equals_chain_and_trains():
                         "--reps", "2"], capture_output=True, text=True, timeout=600, cwd=str(root))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "in 14 nodes" in r.stdout and "loss:" in r.stdout
+    # ... and with densification every 20 steps: N changes (duplicate / split / cull, Adam state carried along)
+    r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--n-background", "150000", "--n-road",
+                        "40000", "--objects", "6", "--object-size", "500", "--shipped", "--width", "320", "--height", "200",
+                        "--steps", "65", "--refine-every", "20", "--reps", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("refine ") == 3 and "loss:" in r.stdout
     # the option set of config/MTGS.py: camera-space normals as 3 more blended channels, exposure model, output head,
     # inverse-depth and normal L1 terms -- fused == operator chains, and it trains
     r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--n-background", "150000", "--n-road",
