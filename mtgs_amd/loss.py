@@ -171,6 +171,7 @@ def output_head(render: Tensor, alpha: Tensor, background: Tensor, exposure: Opt
     assert render.dim() in (3, 4) and (render.dim() == 3 or render.shape[0] == 1) and D >= 3, render.shape
     assert alpha.numel() == render.numel() // D and background.numel() == 3, (alpha.shape, background.shape)
     assert exposure is None or exposure.shape == (3, 4), exposure.shape
+    assert not depth or D >= 4, f"output_head: depth=True needs the depth channel behind the colours (render has {D} channels)"
     assert normal_channel < 0 or normal_channel + 3 <= D - int(bool(depth)), (normal_channel, D)
     return _OutputHead.apply(render, alpha, background, exposure, bool(depth), int(normal_channel))
 
