@@ -147,6 +147,7 @@ def cpu_baseline(args, host, steps):
     import numpy as np
     from oracle import oracle as orc
     orc.build()
+    build_label = orc.select_native()      # timing leg: -O3 -march=native build of the same source (not the checker build)
     a = {k: v.numpy() for k, v in host.items()}
     W, H = args.width, args.height
     mtgs = args.variant == "mtgs"
@@ -184,7 +185,7 @@ def cpu_baseline(args, host, steps):
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
     return {"value": round(W * H / t / 1e6, 4), "unit": "Mpix/s", "cores": orc.num_threads(),
-            "kind": "port", "ms_per_step": round(t * 1e3, 1),
+            "kind": "port", "build": build_label, "ms_per_step": round(t * 1e3, 1),
             "sample": f"{steps} full step(s) of the same workload ({args.n_gaussians} Gaussians, {W}x{H}, "
                       f"fwd+bwd, variant {args.variant}) by oracle/gsplat_oracle.c with OpenMP; median"}
 

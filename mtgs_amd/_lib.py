@@ -6,14 +6,22 @@ raised.  Nothing here (or anywhere under mtgs_amd/) touches oracle/.
 from __future__ import annotations
 
 import ctypes as C
-import os
 from pathlib import Path
 
 import torch
 
 _PKG = Path(__file__).resolve().parent
-# MTGS_RAST_LIB: development override (A/B builds of the library, scripts/build_variant.py)
-LIB_PATH = Path(os.environ["MTGS_RAST_LIB"]) if os.environ.get("MTGS_RAST_LIB") else _PKG / "libmtgs_rast.so"
+LIB_PATH = _PKG / "libmtgs_rast.so"
+
+
+def use_library(path) -> None:
+    """Development only (scripts/kbench.py --lib, A/B builds of scripts/build_variant.py): load another build of the
+    library instead of the in-tree one.  Must be called before the first load(); nothing in the product reads the
+    environment for this."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() after the library was loaded")
+    LIB_PATH = Path(path)
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _i64p = C.POINTER(C.c_int64)  # HOST array (row strides), nullable

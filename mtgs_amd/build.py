@@ -29,11 +29,15 @@ COMMON_FLAGS = [
 PER_FILE_FLAGS = {"project.hip": ["-ffp-contract=off"]}
 
 
+class HipccNotFound(RuntimeError):
+    """No hipcc on this machine (a GPU box running the prebuilt in-tree .so): the only build error callers may ignore."""
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and Path(cand).exists():
             return cand
-    raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
+    raise HipccNotFound("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
 def sources():
@@ -45,6 +49,15 @@ def _stale(out: Path, deps) -> bool:
         return True
     t = out.stat().st_mtime
     return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def stale_sources():
+    """csrc files (and headers) newer than the built library -- empty when the .so is up to date."""
+    if not LIB.exists():
+        return sources()
+    t = LIB.stat().st_mtime
+    deps = sources() + list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "mtgs_rast.h"]
+    return [d for d in deps if d.stat().st_mtime > t]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

@@ -25,12 +25,16 @@ GAUSS_PARAM_NAMES = ("means", "scales", "quats", "features_dc", "features_rest",
 _PREFIXES = ("_model.gaussian_models.", "gaussian_models.")
 
 
-def load_gaussian_nodes(ckpt: Union[str, Mapping], map_location="cpu") -> Dict[str, Dict[str, Tensor]]:
+def load_gaussian_nodes(ckpt: Union[str, Mapping], map_location="cpu", trusted: bool = False) -> Dict[str, Dict[str, Tensor]]:
     """{node name: {parameter or buffer name: tensor}} from a checkpoint path, a checkpoint dict or a state dict.
     `gauss_params.<name>` entries are returned under <name>; anything else a node stores (instance_quats,
-    instance_trans, deformation networks ...) keeps its full sub-key."""
+    instance_trans, deformation networks ...) keeps its full sub-key.
+
+    A path is read with `torch.load(weights_only=True)` (tensors and plain containers only -- what the trainer's
+    checkpoints hold).  `trusted=True` allows the full unpickler for checkpoints that carry other Python objects:
+    that executes code from the file, so use it only on files you produced."""
     if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
-        ckpt = torch.load(ckpt, map_location=map_location, weights_only=False)
+        ckpt = torch.load(ckpt, map_location=map_location, weights_only=not trusted)
     state = ckpt.get("pipeline", ckpt) if isinstance(ckpt, Mapping) else ckpt
     nodes: Dict[str, Dict[str, Tensor]] = {}
     for key, value in state.items():

@@ -688,7 +688,9 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 // trains at 960x540 = 2040 tiles) get 2 or 4 waves per tile instead.  Thresholds from kbench.py.
 static int pick_ppl(int64_t total_tiles, int DT, bool backward) {
     if (DT > 8) return 1;
-    if (const char *e = getenv("MTGS_PPL")) return atoi(e);  // development knob (scripts/kbench.py sweeps)
+#ifdef MTGS_DEV  // development builds only (scripts/build_variant.py NAME -DMTGS_DEV): kbench.py sweeps
+    if (const char *e = getenv("MTGS_PPL")) return atoi(e);
+#endif
     // measured on MI355X, N = 2M (us, pixels per lane 4 / 2 / 1):
     //   fwd, 4 channels: 1200 tiles 405/291/220   2040 tiles 282/202/159   3600 tiles 237/187/169   8160 tiles 230/-/-
     //   bwd, 4 channels: 1200 tiles 424/344/324   2040 tiles 319/277/408   2800 tiles 320/310/484   8160 tiles 430/-/-

@@ -259,13 +259,51 @@ class SparseGradExchange:
 
 
 def all_reduce_stats(sum_tensors: Iterable[torch.Tensor] = (), max_tensors: Iterable[torch.Tensor] = (),
-                     group=None) -> None:
-    """Densification statistics must be identical on every rank: running
-    grad-norm sums and visibility counts are summed, max screen-space radii are max-reduced
-    (/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:457-474)."""
+                     group=None, sum_init: Sequence[float] = ()) -> None:
+    """Densification statistics must be identical on every rank before `refinement_after` reads them (SURVEY.md
+    section 8e): running grad-norm sums and visibility counts are summed, max screen-space radii are max-reduced
+    (/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:457-474).
+
+    CONTRACT: the tensors are each rank's LOCAL running accumulators since the last reset, and this is called exactly
+    ONCE per refinement interval, right before the refine decision (after which the reference resets them,
+    vanilla_gaussian_splatting.py:571-574).  Calling it twice on the same accumulators would count the other ranks'
+    contributions twice -- use `StatsReducer` below when the statistics must also be readable between refinements.
+    `sum_init[i]` is the value accumulator i was initialised with (the reference starts `vis_counts` at ONE, :462): it is
+    counted once, not once per rank: result = init + sum_r (local_r - init).
+    One collective per reduction kind (the tensors are packed), not one per tensor."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for t in sum_tensors:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    for t in max_tensors:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    sum_tensors, max_tensors = list(sum_tensors), list(max_tensors)
+    inits = list(sum_init) + [0.0] * (len(sum_tensors) - len(sum_init))
+    for tensors, op in ((sum_tensors, dist.ReduceOp.SUM), (max_tensors, dist.ReduceOp.MAX)):
+        if not tensors:
+            continue
+        if op == dist.ReduceOp.SUM:
+            flat = torch.cat([(t - i0 if i0 else t).reshape(-1) for t, i0 in zip(tensors, inits)])
+        else:
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=op, group=group)
+        off = 0
+        for k, t in enumerate(tensors):
+            part = flat[off:off + t.numel()].view_as(t)
+            t.copy_(part + inits[k] if (op == dist.ReduceOp.SUM and inits[k]) else part)
+            off += t.numel()
+
+
+class StatsReducer:
+    """Local accumulators + a global view for densification statistics that are read more than once per interval.
+
+    The ranks accumulate into `local_*`; `reduce()` may be called any number of times and always returns
+    (sum over ranks of the local sums [+ init], max over ranks of the local maxima) without modifying the local
+    accumulators, so repeated calls never double count."""
+
+    def __init__(self, sum_tensors: Sequence[torch.Tensor], max_tensors: Sequence[torch.Tensor], sum_init: Sequence[float] = (),
+                 group=None):
+        self.local_sum, self.local_max, self.group = list(sum_tensors), list(max_tensors), group
+        self.sum_init = list(sum_init) + [0.0] * (len(self.local_sum) - len(sum_init))
+
+    def reduce(self):
+        g_sum = [t.clone() for t in self.local_sum]
+        g_max = [t.clone() for t in self.local_max]
+        all_reduce_stats(g_sum, g_max, group=self.group, sum_init=self.sum_init)
+        return g_sum, g_max

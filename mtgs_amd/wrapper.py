@@ -259,15 +259,33 @@ def _host_mailbox():
     return mb, _mailboxes.tag
 
 
-def _wait_mailbox(mailbox, tag, device_totals) -> int:
+def _wait_mailbox(mailbox, tag, device_totals, limit: int) -> Tuple[int, int]:
+    """(n_vis, M) published by mtgs_bin_compact's spine kernel into the thread's pinned mailbox.
+
+    The mailbox is `torch.Tensor.pin_memory()` memory, i.e. hipHostMalloc'ed and host-coherent (fine-grained) on ROCm:
+    the kernel's system-scope release store becomes visible without a stream synchronisation.  The wait spins a few
+    hundred times (the totals are normally 10-20 us away), then yields the GIL between polls so that the viewer /
+    dataloader threads run while the GPU drains a backlog.  A mailbox that never answers (5 s) or answers with
+    impossible totals falls back to the synchronising device read."""
     view = _mailboxes.view
-    t0 = None
+    spins, t0 = 0, None
     while view[1] != tag:
-        if t0 is None:
-            t0 = time.perf_counter()
-        elif time.perf_counter() - t0 > 5.0:   # never expected: fall back to the synchronising read
-            return int(device_totals.item())
-    return int(view[0])
+        spins += 1
+        if spins > 256:
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > 5.0:
+                break
+            time.sleep(0)          # release the GIL
+    packed = int(view[0]) if view[1] == tag else int(device_totals.item())
+    n_vis, M = packed >> 32, packed & 0xFFFFFFFF
+    if n_vis > limit or M >= (1 << 31):    # a carry out of the low word (M >= 2^32) would land in n_vis
+        packed = int(device_totals.item())
+        n_vis, M = packed >> 32, packed & 0xFFFFFFFF
+        if n_vis > limit or M >= (1 << 31):
+            raise RuntimeError(f"tile binning: {M} intersections / {n_vis} visible of {limit}: intersection count "
+                               "must stay below 2^31 (render fewer cameras per call)")
+    return n_vis, M
 
 
 def _bin_depth_ordered(means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tile_width, tile_height,
@@ -287,8 +305,7 @@ def _bin_depth_ordered(means2d, radii, depths, tiles_per_gauss, scan_ws, scan_by
     # the one host round trip of a frame: n_vis and M together.  The kernel publishes them to pinned host memory as
     # soon as they are known (one kernel before the compaction ends); polling that word instead of synchronising the
     # stream lets the host enqueue the rest of the frame while the GPU is still busy (27 us per frame otherwise).
-    packed_totals = _wait_mailbox(mailbox, tag, totals)
-    n_vis, M = packed_totals >> 32, packed_totals & 0xFFFFFFFF
+    n_vis, M = _wait_mailbox(mailbox, tag, totals, total)
     isect_ids = torch.empty(M, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(M, dtype=torch.int32, device=dev)
     # depth sort -> scan -> emit -> tile sort (+ isect_ids) -> offsets -> tile schedule, enqueued by ONE call

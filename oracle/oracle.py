@@ -36,6 +36,43 @@ def build(force: bool = False) -> Path:
     return _LIB_PATH
 
 
+def build_native() -> Path:
+    """A second build of the SAME source for bench.py's `cpu_baseline` leg only: -O3 -march=native (SURVEY.md section
+    8d), FMA contraction allowed -- a timing baseline, not the checker (tests always use the -ffp-contract=off build).
+    Built on the machine that runs it; the file name carries a hash of this CPU's feature flags so that a build made on
+    another host is never loaded."""
+    import hashlib
+    flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+    except OSError:
+        pass
+    out = _HERE / "_native" / f"libgsplat_oracle_native_{hashlib.sha1(flags.encode()).hexdigest()[:10]}.so"
+    src = _HERE / "gsplat_oracle.c"
+    if not out.exists() or out.stat().st_mtime < src.stat().st_mtime:
+        out.parent.mkdir(exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", str(out),
+                               str(src), "-lm"])
+    return out
+
+
+def select_native() -> str:
+    """Route this module's calls to the -O3 -march=native build (bench.py cpu_baseline).  Returns a label of the build in
+    use; falls back to the checker build when gcc is missing."""
+    global _lib
+    try:
+        path, label = build_native(), "gcc -O3 -march=native -fopenmp"
+    except (OSError, subprocess.CalledProcessError):
+        path, label = build(), "gcc -O2 -ffp-contract=off -fopenmp (checker build; gcc unavailable for a native build)"
+    _lib = C.CDLL(str(path))
+    _lib.orc_isect_count.restype = C.c_int64
+    _lib.orc_num_threads.restype = C.c_int
+    return label
+
+
 _lib = None
 
 

@@ -4,7 +4,7 @@
 for lib in "" mtgs_amd/_variants/*.so; do
   for rep in 1 2; do
     echo "== ${lib:-current} (run $rep)"
-    MTGS_RAST_LIB=$lib timeout 300 python scripts/kbench.py "$@" 2>&1 | grep -E "blend|total|isect|sh_|project" | tr '\n' ' '
+    timeout 300 python scripts/kbench.py ${lib:+--lib $lib} "$@" 2>&1 | grep -E "blend|total|isect|sh_|project" | tr '\n' ' '
     echo
   done
 done

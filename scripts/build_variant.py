@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development: build an A/B variant of the library with extra compiler flags.
    python scripts/build_variant.py NAME -DMTGS_EARLY_COLOR_LOAD=0 ...
-writes mtgs_amd/_variants/libmtgs_rast_NAME.so; select it with MTGS_RAST_LIB=<path>."""
+writes mtgs_amd/_variants/libmtgs_rast_NAME.so; select it with scripts/kbench.py --lib <path>
+(mtgs_amd._lib.use_library)."""
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor

@@ -48,9 +48,12 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--variant", default="mtgs")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--lib", default=None, help="development: another build of libmtgs_rast.so (scripts/build_variant.py)")
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--extra-channels", type=int, default=0, help="extra colour channels (MTGS.py blends 3 normal channels too)")
     args = ap.parse_args()
+    if args.lib:
+        _lib.use_library(args.lib)
     dev = torch.device("cuda")
     W, H = args.width, args.height
     mtgs = args.variant == "mtgs"

@@ -25,8 +25,12 @@ def hip_lib():
     """Builds (if hipcc is present and the .so is stale/missing) and loads libmtgs_rast.so."""
     from mtgs_amd import _lib, build
     try:
-        build.build()
-    except RuntimeError:
+        build.build()          # compile / link failures propagate: never test a stale binary
+    except build.HipccNotFound:
+        # a box without the compiler runs the prebuilt in-tree library -- which must exist and be current
         if not _lib.LIB_PATH.exists():
             raise
+        stale = build.stale_sources()
+        if stale:
+            raise RuntimeError(f"libmtgs_rast.so is older than {[p.name for p in stale]} and hipcc is missing")
     return _lib.load()
