@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 6
+#define MTGS_RAST_ABI_VERSION 7
 
 enum {
     MTGS_OK = 0,
@@ -220,6 +220,62 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    float *v_means2d_abs, float *v_conics, float *v_colors, float *v_depths,
                    float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
                    const int32_t *tile_order, void *stream);
+
+/* ---- fused rasterization front end + binning (ABI v7; what mtgs_amd.wrapper._FusedRasterization runs) ------------
+ * The gsplat-shaped operators above stay; these entry points run the same stages of gsplat.rendering.rasterization
+ * (mtgs/scene_model/mtgs_scene_graph.py:641-662) with fewer launches, one gather per intersection, and WITHOUT the host
+ * knowing n_vis / M when it enqueues them.
+ *
+ * mtgs_front_fwd: mtgs_project_fwd (+ opacities * compensations + the tile count) fused with the compaction of the
+ * visible (camera, Gaussian) pairs.  Dense outputs as mtgs_project_fwd.  Compact outputs, indexed by RANK (= number of
+ * visible pairs with a smaller flat index c*N+n; entries with rank >= cap_vis are not written):
+ *   recs[cap_vis,16] f32  packed record: x y | conic a b c | opacity_eff | s2max = 2 ln(255 opacity_eff) | radius (i32 bits)
+ *                         | colours[D] (from colors[C*N,D]), depth (if with_depth), zeros   (D + with_depth <= 8)
+ *   vis_ids[cap_vis] i32  flat index;  vis_keys[cap_vis] i64 = tile count << 40 | camera << 32 | bits(depth)
+ *   vis_rank[C*N] i32     rank of every visible pair (dense; culled entries unspecified)
+ *   dp_words[ceil(C*N/64)] u64, dp_prefix[ceil(C*N/64)] u32 (both nullable): visibility bitmap and rank of the first
+ *                         pair of each word (the map mtgs_dp_reduce reads)
+ *   totals[1] i64 (device) = n_vis << 32 | M; host_totals (nullable): PINNED HOST int64[2], receives {totals, host_tag}
+ *   as soon as the last block finishes (system-scope release store), so the host can poll instead of synchronising.
+ *   M = 2^31 - 1 signals more than 2^31 - 2 intersections (or an internal failure): the frame cannot be rendered.
+ * ws: mtgs_front_workspace_bytes(C*N), 8-byte aligned; zeroed by the call.
+ *
+ * mtgs_bin2_build: depth sort of the visible pairs, emission in depth order, per-tile counts -> offsets[C*th*tw + 1]
+ * (last entry = M) + tile_order (nullable), tile sort -> rank_ids[cap_M] (record / gradient-row index of every
+ * intersection), flatten_ids[cap_M] (gsplat), isect_ids[cap_M] (gsplat; nullable).  Sizes come from `totals` on the
+ * device, clamped to (cap_vis, cap_M): the caller sizes buffers and this call sizes grids for the capacities; if the
+ * true totals exceed them the outputs are truncated (never out of bounds) and the caller repeats with larger ones.
+ * Supported when mtgs_bin2_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 12288, cap_M < 2^30), else use
+ * mtgs_bin_build.  ws: mtgs_bin2_workspace_bytes, 256-byte aligned.
+ *
+ * mtgs_blend_fwd_packed / mtgs_blend_bwd_packed: mtgs_blend_fwd / _bwd reading the records through rank_ids.
+ * grad_rows[n_vis, row_stride] f32 (zeroed by the caller): [xy 2 | |xy| 2 (absgrad) | conic 3 | opacity 1 | colours D |
+ * depth 1 | pad], accumulated with atomics, one 64-byte line per visible pair for row_stride = 16. */
+int mtgs_front_workspace_bytes(int64_t total_pairs, size_t *bytes);
+int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                   const float *viewmats, const float *Ks, int width, int height, float eps2d, float near_plane,
+                   float far_plane, float radius_clip, const float *opacities, const float *colors, int D,
+                   int with_depth, int32_t *radii, float *means2d, float *depths, float *conics,
+                   float *compensations, float *opac_eff, int tile_size, int tile_w, int tile_h,
+                   int32_t *tiles_per_gauss, float *recs, int32_t *vis_ids, int64_t *vis_keys,
+                   int32_t *vis_rank, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int64_t *totals,
+                   int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes, void *stream);
+int mtgs_bin2_supported(int C, int tile_w, int tile_h, int64_t cap_M);
+int mtgs_bin2_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
+int mtgs_bin2_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
+                    int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
+                    const int64_t *vis_keys, int32_t *rank_ids, int32_t *flatten_ids,
+                    int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, void *ws, size_t ws_bytes,
+                    void *stream);
+int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
+                          int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
+                          const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,
+                          const int32_t *tile_order, void *stream);
+int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
+                          int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
+                          const int32_t *rank_ids, const float *alphas, const int32_t *last_ids,
+                          const float *render, const float *v_render, const float *v_alphas, float *grad_rows,
+                          int64_t row_stride, int absgrad, const int32_t *tile_order, void *stream);
 
 /* ---- view-parallel data parallelism: sparse, factored gradient exchange (mtgs_amd/csrc/dp.hip) ------
  * No gsplat counterpart.  Rows are 16 floats: v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, spare,

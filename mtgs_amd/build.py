@@ -26,7 +26,7 @@ COMMON_FLAGS = [
     "-Wall", "-Wno-unused-function", f"-I{PKG.parent / 'include'}",
 ]
 # The projection forward must round after every operation (bit-exact tile binning inputs).
-PER_FILE_FLAGS = {"project.hip": ["-ffp-contract=off"]}
+PER_FILE_FLAGS = {"project.hip": ["-ffp-contract=off"], "front.hip": ["-ffp-contract=off"]}
 
 
 class HipccNotFound(RuntimeError):

@@ -170,9 +170,14 @@ struct IsectIdEpilogue {
     const float *depths;
     uint32_t n_tiles;
     int tile_bits;
-    __device__ __forceinline__ int64_t operator()(uint64_t key, int32_t gid) const {
+    int32_t *flatten_ids;
+    int64_t *isect_ids;
+    struct G { uint32_t depth_bits; };
+    __device__ __forceinline__ G gather(int32_t gid) const { return G{__float_as_uint(depths[gid])}; }
+    __device__ __forceinline__ void store(uint32_t dst, uint64_t key, int32_t gid, const G &g) const {
         const int64_t cam = (uint32_t)key / n_tiles, tile = (uint32_t)key % n_tiles;
-        return (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)__float_as_uint(depths[gid]);
+        isect_ids[dst] = (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)g.depth_bits;
+        flatten_ids[dst] = gid;
     }
 };
 
@@ -282,7 +287,7 @@ extern "C" int mtgs_bin_sort_tiles(int64_t M, int C, int tile_w, int tile_h, con
     const int key_bits = bit_length_u32((uint32_t)C * n_tiles - 1u) > 0 ? bit_length_u32((uint32_t)C * n_tiles - 1u) : 1;
     return mtgs_sort::sort_pairs<uint32_t, IsectIdEpilogue>(
         M, key_bits, tile_keys, gids, keys_scratch, flatten_ids, ws, ws_bytes, (hipStream_t)stream,
-        "mtgs_bin_sort_tiles", IsectIdEpilogue{depths, n_tiles, bit_length_u32(n_tiles)}, isect_ids);
+        "mtgs_bin_sort_tiles", IsectIdEpilogue{depths, n_tiles, bit_length_u32(n_tiles), flatten_ids, isect_ids});
 }
 
 extern "C" int mtgs_bin_finalize(int64_t M, const uint32_t *tile_keys_sorted, const int32_t *flatten_ids,

@@ -32,11 +32,11 @@
 #include <stdlib.h>
 #include "common.hpp"
 #include "wave_reduce.hpp"
+#include "raster_rec.hpp"
 
 namespace {
 
 constexpr float kAlphaMax = MTGS_ALPHA_MAX;
-constexpr float kAlphaMin = MTGS_ALPHA_MIN;
 constexpr float kTMin = MTGS_T_MIN;
 
 // LDS record per staged Gaussian, in floats:  x y a b | c opac s2max idx | col[D] (padded to x4)
@@ -70,9 +70,12 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount 
 //   FWD: candidate k of the batch is sorted index base + k;  BWD: base - k (back to front).
 // Returns the number of survivors (uniform over the workgroup).  With more than one wave per tile
 // the per-wave ballots are chained through a small LDS array (two workgroup barriers per round).
-template <int D, int NT, int CAND, bool BWD, bool CULL>
+// PK (packed input, the fused rasterization path): the list holds RANKS and a candidate is ONE 64-byte record of
+// front.hip (raster_rec.hpp) -- xy, conic, opacity, the precomputed s2max and the blended channels in the LDS layout
+// -- instead of six gathers from six dense arrays and a log2 per candidate and tile.
+template <int D, int NT, int CAND, bool BWD, bool CULL, bool PK>
 __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *__restrict__ s_id,
-                                           int *__restrict__ s_wc,
+                                           int *__restrict__ s_wc, const float *__restrict__ recs,
                                            const float *__restrict__ means2d,
                                            const float *__restrict__ conics,
                                            const float *__restrict__ colors,
@@ -91,12 +94,21 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
         bool keep = in_range;
         float2 xy = make_float2(0.f, 0.f);
         float ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f, s2max = 0.f;
+        float4 pk[REC / 4];
         if (in_range) {
-            xy = reinterpret_cast<const float2 *>(means2d)[g[r]];
-            ca = conics[(int64_t)g[r] * 3]; cb = conics[(int64_t)g[r] * 3 + 1]; cc = conics[(int64_t)g[r] * 3 + 2];
-            op = opacities[g[r]];
-            // alpha = min(0.999, op e^{-s2/2}) >= 1/255  <=>  s2 <= 2 ln(255 op)
-            s2max = 2.0f * 0.6931471805599453f * __log2f(op * (1.0f / kAlphaMin));
+            if (PK) {
+                static_assert(!PK || REC <= REC_FLOATS, "packed records hold at most 8 channels");
+                const float4 *rp = reinterpret_cast<const float4 *>(recs + (int64_t)g[r] * REC_FLOATS);
+#pragma unroll
+                for (int c = 0; c < REC / 4; ++c) pk[c] = rp[c];
+                xy = make_float2(pk[0].x, pk[0].y);
+                ca = pk[0].z; cb = pk[0].w; cc = pk[1].x; op = pk[1].y; s2max = pk[1].z;
+            } else {
+                xy = reinterpret_cast<const float2 *>(means2d)[g[r]];
+                ca = conics[(int64_t)g[r] * 3]; cb = conics[(int64_t)g[r] * 3 + 1]; cc = conics[(int64_t)g[r] * 3 + 2];
+                op = opacities[g[r]];
+                s2max = rec_s2max(op);   // alpha = min(0.999, op e^{-s2/2}) >= 1/255  <=>  s2 <= 2 ln(255 op)
+            }
             // opacity < 1/255 (or NaN): alpha >= 1/255 is unreachable.  Dropped here unconditionally -- the
             // per-pixel range test compares bit patterns and relies on s2max >= 0.
             keep = s2max >= 0.f;
@@ -147,17 +159,24 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
             }
         }
         if (keep) {
-            float rec[REC];
-            rec[0] = xy.x; rec[1] = xy.y; rec[2] = ca; rec[3] = cb; rec[4] = cc; rec[5] = op; rec[6] = s2max;
-            rec[7] = __int_as_float((int32_t)(BWD ? base - k : base + k));
-#pragma unroll
-            for (int c = 0; c < D; ++c) rec[8 + c] = c < DC ? colors[(int64_t)g[r] * DC + c] : depths[g[r]];
-#pragma unroll
-            for (int c = 8 + D; c < REC; ++c) rec[c] = 0.f;
             float4 *dst = reinterpret_cast<float4 *>(s_rec + slot * REC);
+            const float idxf = __int_as_float((int32_t)(BWD ? base - k : base + k));
+            if (PK) {
+                pk[1].w = idxf;   // (the radius is not needed any more)
 #pragma unroll
-            for (int c = 0; c < REC / 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
-            if (s_id) s_id[slot] = row_index ? row_index[g[r]] : g[r];  // gradient row of this Gaussian
+                for (int c = 0; c < REC / 4; ++c) dst[c] = pk[c];
+            } else {
+                float rec[REC];
+                rec[0] = xy.x; rec[1] = xy.y; rec[2] = ca; rec[3] = cb; rec[4] = cc; rec[5] = op; rec[6] = s2max;
+                rec[7] = idxf;
+#pragma unroll
+                for (int c = 0; c < D; ++c) rec[8 + c] = c < DC ? colors[(int64_t)g[r] * DC + c] : depths[g[r]];
+#pragma unroll
+                for (int c = 8 + D; c < REC; ++c) rec[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < REC / 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
+            }
+            if (s_id) s_id[slot] = (!PK && row_index) ? row_index[g[r]] : g[r];  // gradient row of this Gaussian
         }
     }
     return CULL ? count : n_cand;
@@ -221,9 +240,9 @@ __device__ __forceinline__ float *row_address(float *base, uint32_t row, uint32_
 constexpr float kHalfLog2e = 0.5f * 1.4426950408889634f;  // exp(-s2/2) = exp2(-s2 * log2(e)/2)
 
 // ------------------------------------------------------------------------------------------------
-template <int D, int PPL>
+template <int D, int PPL, bool PK>
 __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
-    int C, const float *__restrict__ means2d, const float *__restrict__ conics,
+    int C, const float *__restrict__ recs, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
     int tw, int th, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
@@ -260,7 +279,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
         for (int k = 0; k < D; ++k) acc[p][k] = 0.f;
     }
     const int64_t start = offsets[tile];
-    const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
+    // (packed input: offsets has one more entry, the total -- M is not known when the launch is enqueued)
+    const int64_t end = (!PK && tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
 
     // flatten_ids of the NEXT batch are fetched while the current batch is composited
     int32_t g_next[NR];
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, end - b0);
-        const int bsz = stage_batch<D, NT, CAND, false, CULL>(s_rec, nullptr, s_wc, means2d, conics, colors, depths, DC,
+        const int bsz = stage_batch<D, NT, CAND, false, CULL, PK>(s_rec, nullptr, s_wc, recs, means2d, conics, colors, depths, DC,
                                                               opacities, nullptr, g_cur, b0, n_cand, (float)(tx * 16),
                                                               (float)(ty * 16));
 #pragma unroll
@@ -374,9 +394,9 @@ struct GradLayout {
 
 // (second launch-bound argument = waves per SIMD the register allocator must leave room for: the
 //  one-wave-per-tile mapping is latency-sensitive, 5 waves/SIMD measured better than 4)
-template <int D, int PPL>
+template <int D, int PPL, bool PK>
 __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend_bwd_kernel(
-    int C, const float *__restrict__ means2d, const float *__restrict__ conics,
+    int C, const float *__restrict__ recs, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
     int tw, int th, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
@@ -396,7 +416,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
     const int64_t n_tiles = (int64_t)tw * th, total_tiles = (int64_t)C * n_tiles;
     const int64_t tile = block_to_tile(order);
     const int64_t start = offsets[tile];
-    const int64_t end = (tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
+    const int64_t end = (!PK && tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
     if (end <= start) return;
     const int cam = (int)(tile / n_tiles);
     const int t_in = (int)(tile - (int64_t)cam * n_tiles);
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
 #pragma unroll
         for (int r = 0; r < NRD; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, hi - start + 1);
-        const int bsz = stage_batch<D, NT, CAND, true, CULL>(s_rec, s_id, s_wc, means2d, conics, colors, depths, DC, opacities,
+        const int bsz = stage_batch<D, NT, CAND, true, CULL, PK>(s_rec, s_id, s_wc, recs, means2d, conics, colors, depths, DC, opacities,
                                                              row_index, g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16));
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
@@ -614,22 +634,22 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
     }
 }
 
-template <int D, int PPL>
-int launch_fwd(int C, const float *means2d, const float *conics, const float *colors,
+template <int D, int PPL, bool PK = false>
+int launch_fwd(int C, const float *recs, const float *means2d, const float *conics, const float *colors,
                const float *opacities, const float *backgrounds, const float *depths, int DC, int ed, int W,
                int H, int tw, int th,
                const int32_t *offsets, const int32_t *flatten_ids, int64_t M, float *render,
                float *alphas, int32_t *last_ids, const int32_t *order, hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
-    blend_fwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(C, means2d, conics, colors, opacities,
+    blend_fwd_kernel<D, PPL, PK><<<grid, 256 / PPL, 0, st>>>(C, recs, means2d, conics, colors, opacities,
                                                          backgrounds, depths, DC, ed, W, H, tw, th, offsets,
                                                          flatten_ids, M, render, alphas, last_ids, order);
     return 0;
 }
 
-template <int D, int PPL>
-int launch_bwd(int C, const float *means2d, const float *conics, const float *colors,
+template <int D, int PPL, bool PK = false>
+int launch_bwd(int C, const float *recs, const float *means2d, const float *conics, const float *colors,
                const float *opacities, const float *backgrounds, const float *depths, int DC, int ed, int W,
                int H, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids, int64_t M,
                const float *alphas, const int32_t *last_ids, const float *render, const float *v_render,
@@ -638,8 +658,8 @@ int launch_bwd(int C, const float *means2d, const float *conics, const float *co
                hipStream_t st) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
-    blend_bwd_kernel<D, PPL><<<grid, 256 / PPL, 0, st>>>(
-        C, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
+    blend_bwd_kernel<D, PPL, PK><<<grid, 256 / PPL, 0, st>>>(
+        C, recs, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
         alphas, last_ids, render, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_depths,
         v_opacities, gs, row_index, order);
     return 0;
@@ -742,7 +762,7 @@ extern "C" int mtgs_blend_fwd(int C, int64_t N, int D, const float *means2d, con
                  MTGS_EINVAL, "mtgs_blend_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, false);
-    MTGS_DISPATCH_D(launch_fwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
+    MTGS_DISPATCH_D(launch_fwd, C, nullptr, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, render, alphas, last_ids, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_fwd");
     return MTGS_OK;
@@ -782,11 +802,81 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
     }
     const GradRowBytes gs{sb[0], sb[1], sb[2], sb[3], sb[4], sb[5]};
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
-    MTGS_DISPATCH_D(launch_bwd, C, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
+    MTGS_DISPATCH_D(launch_bwd, C, nullptr, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, render, v_render, v_alphas,
                     v_means2d, v_means2d_abs, v_conics, v_colors, v_depths, v_opacities, gs, grad_row_index, tile_order,
                     st);
     MTGS_CHECK_LAUNCH("mtgs_blend_bwd");
+    return MTGS_OK;
+}
+
+// ---- packed input (fused rasterization path): records of front.hip + rank_ids / offsets[T + 1] of bin2.hip ----
+#define MTGS_DISPATCH_PK_ONE(FN, DD, ...)                                      \
+    if (ppl == 4) FN<DD, 4, true>(__VA_ARGS__);                                \
+    else if (ppl == 2) FN<DD, 2, true>(__VA_ARGS__);                           \
+    else FN<DD, 1, true>(__VA_ARGS__);
+
+#define MTGS_DISPATCH_PK(FN, ...)                                     \
+    switch (DT) {                                                     \
+        case 1: MTGS_DISPATCH_PK_ONE(FN, 1, __VA_ARGS__) break;       \
+        case 2: MTGS_DISPATCH_PK_ONE(FN, 2, __VA_ARGS__) break;       \
+        case 3: MTGS_DISPATCH_PK_ONE(FN, 3, __VA_ARGS__) break;       \
+        case 4: MTGS_DISPATCH_PK_ONE(FN, 4, __VA_ARGS__) break;       \
+        case 5: MTGS_DISPATCH_PK_ONE(FN, 5, __VA_ARGS__) break;       \
+        case 6: MTGS_DISPATCH_PK_ONE(FN, 6, __VA_ARGS__) break;       \
+        case 7: MTGS_DISPATCH_PK_ONE(FN, 7, __VA_ARGS__) break;       \
+        default: MTGS_DISPATCH_PK_ONE(FN, 8, __VA_ARGS__) break;      \
+    }
+
+extern "C" int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
+                                     int ed_normalize, int width, int height, int tile_w, int tile_h,
+                                     const int32_t *offsets, const int32_t *rank_ids, float *render, float *alphas,
+                                     int32_t *last_ids, const int32_t *tile_order, void *stream) {
+    MTGS_REQUIRE(C >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_fwd_packed: bad sizes");
+    MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
+                 "mtgs_blend_fwd_packed: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
+    const int DT = D + (with_depth ? 1 : 0);
+    MTGS_REQUIRE(DT >= 1 && DT <= REC_MAX_CHANNELS, MTGS_EUNSUPPORTED, "mtgs_blend_fwd_packed: %d blended channels (1..%d)", DT,
+                 REC_MAX_CHANNELS);
+    MTGS_REQUIRE(!ed_normalize || with_depth, MTGS_EINVAL, "mtgs_blend_fwd_packed: ed_normalize needs the depth channel");
+    if (C == 0) return MTGS_OK;
+    MTGS_REQUIRE(recs && offsets && rank_ids && render && alphas && last_ids, MTGS_EINVAL, "mtgs_blend_fwd_packed: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, false);
+    MTGS_DISPATCH_PK(launch_fwd, C, recs, nullptr, nullptr, nullptr, nullptr, backgrounds, nullptr, D, ed_normalize, width, height,
+                     tile_w, tile_h, offsets, rank_ids, (int64_t)-1, render, alphas, last_ids, tile_order, st);
+    MTGS_CHECK_LAUNCH("mtgs_blend_fwd_packed");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
+                                     int ed_normalize, int width, int height, int tile_w, int tile_h,
+                                     const int32_t *offsets, const int32_t *rank_ids, const float *alphas,
+                                     const int32_t *last_ids, const float *render, const float *v_render,
+                                     const float *v_alphas, float *grad_rows, int64_t row_stride, int absgrad,
+                                     const int32_t *tile_order, void *stream) {
+    MTGS_REQUIRE(C >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd_packed: bad sizes");
+    MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
+                 "mtgs_blend_bwd_packed: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
+    const int DT = D + (with_depth ? 1 : 0);
+    MTGS_REQUIRE(DT >= 1 && DT <= REC_MAX_CHANNELS, MTGS_EUNSUPPORTED, "mtgs_blend_bwd_packed: %d blended channels (1..%d)", DT,
+                 REC_MAX_CHANNELS);
+    MTGS_REQUIRE(!ed_normalize || (with_depth && render), MTGS_EINVAL, "mtgs_blend_bwd_packed: ed_normalize needs depth and render");
+    MTGS_REQUIRE(row_stride >= 8 + DT && row_stride < ((int64_t)1 << 28), MTGS_EINVAL, "mtgs_blend_bwd_packed: row_stride=%lld",
+                 (long long)row_stride);
+    if (C == 0) return MTGS_OK;
+    MTGS_REQUIRE(recs && offsets && rank_ids && alphas && last_ids && v_render && v_alphas && grad_rows, MTGS_EINVAL,
+                 "mtgs_blend_bwd_packed: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    // rows: [xy 2 | |xy| 2 | conic 3 | opacity 1 | colour D | depth 1 | pad]
+    const uint32_t sb = (uint32_t)(row_stride * 4);
+    const GradRowBytes gs{sb, sb, sb, sb, sb, sb};
+    const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
+    MTGS_DISPATCH_PK(launch_bwd, C, recs, nullptr, nullptr, nullptr, nullptr, backgrounds, nullptr, D, ed_normalize, width, height,
+                     tile_w, tile_h, offsets, rank_ids, (int64_t)-1, alphas, last_ids, render, v_render, v_alphas, grad_rows,
+                     absgrad ? grad_rows + 2 : nullptr, grad_rows + 4, grad_rows + 8, grad_rows + 8 + D, grad_rows + 7, gs, nullptr,
+                     tile_order, st);
+    MTGS_CHECK_LAUNCH("mtgs_blend_bwd_packed");
     return MTGS_OK;
 }
 

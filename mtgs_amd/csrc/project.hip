@@ -11,7 +11,7 @@
 // This translation unit is compiled with -ffp-contract=off: the forward rounds after every
 // operation in a fixed order, so radii / means2d / depths (the inputs of the integer tile-binning
 // stage, whose results must be bit-exact) have exactly one IEEE-754 value per input.
-#include "project_common.hpp"
+#include "project_fwd_body.hpp"
 #include "tile_rect.hpp"
 
 namespace {
@@ -29,53 +29,18 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_fwd_kernel(
     const int c = (int)(idx / N);
     const int64_t n = idx - (int64_t)c * N;
     const Cam cam = load_cam(viewmats + c * 16, Ks + c * 9);
-    struct F3 { float x, y, z; };  // 12-byte rows move as one dwordx3 access
-    const F3 m3 = *reinterpret_cast<const F3 *>(means + n * 3);
-    const float m[3] = {m3.x, m3.y, m3.z};
-    int32_t r_out = 0;
-    float mx = 0.f, my = 0.f, depth = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, comp = 0.f;
-    const float zc = ((cam.R[6] * m[0] + cam.R[7] * m[1]) + cam.R[8] * m[2]) + cam.t[2];
-    if (!(zc < near_plane || zc > far_plane)) {
-        const float4 q = reinterpret_cast<const float4 *>(quats)[n];
-        const F3 s3 = *reinterpret_cast<const F3 *>(scales + n * 3);
-        const float sc[3] = {s3.x, s3.y, s3.z};
-        ProjState s;
-        proj_common(m, q, sc, cam, W, H, s);
-        const float pmx = cam.fx * s.mean_c[0] * s.rz + cam.cx;
-        const float pmy = cam.fy * s.mean_c[1] * s.rz + cam.cy;
-        float c00 = s.cov2d[0];
-        const float c01 = s.cov2d[1];
-        float c11 = s.cov2d[3];
-        const float det_orig = c00 * c11 - c01 * c01;
-        c00 += eps2d; c11 += eps2d;
-        const float det = c00 * c11 - c01 * c01;
-        const float cmp = sqrtf(fmaxf(0.f, det_orig / det));
-        if (det > 0.f) {
-            const float idet = 1.0f / det;
-            const float b = 0.5f * (c00 + c11);
-            const float v1 = b + sqrtf(fmaxf(kRadiusFloor, b * b - det));
-            const float radius = ceilf(kRadiusSigma * sqrtf(v1));
-            const bool out = radius <= radius_clip || pmx + radius <= 0.f || pmx - radius >= (float)W ||
-                             pmy + radius <= 0.f || pmy - radius >= (float)H;
-            if (!out) {
-                r_out = (int32_t)radius;
-                mx = pmx; my = pmy; depth = s.mean_c[2];
-                ca = c11 * idet; cb = -c01 * idet; cc = c00 * idet;
-                comp = cmp;
-            }
-        }
-    }
-    radii[idx] = r_out;
-    reinterpret_cast<float2 *>(means2d)[idx] = make_float2(mx, my);
-    depths[idx] = depth;
-    *reinterpret_cast<F3 *>(conics + idx * 3) = F3{ca, cb, cc};
-    if (compensations) compensations[idx] = comp;
+    const ProjOut o = project_pair(means, quats, scales, cam, n, W, H, eps2d, near_plane, far_plane, radius_clip);
+    radii[idx] = o.radius;
+    reinterpret_cast<float2 *>(means2d)[idx] = make_float2(o.mx, o.my);
+    depths[idx] = o.depth;
+    *reinterpret_cast<F3 *>(conics + idx * 3) = F3{o.ca, o.cb, o.cc};
+    if (compensations) compensations[idx] = o.comp;
     // gsplat rendering.py: opacities.repeat(C, 1) [* compensations]
-    if (opac_eff) opac_eff[idx] = r_out > 0 ? (compensations ? opacities[n] * comp : opacities[n]) : 0.f;
+    if (opac_eff) opac_eff[idx] = o.radius > 0 ? (compensations ? opacities[n] * o.comp : opacities[n]) : 0.f;
     if (tiles_per_gauss) {  // gsplat isect_tiles, count pass (what mtgs_isect_count computes from the arrays above)
         int32_t cnt = 0;
-        if (r_out > 0) {
-            const Rect q = tile_rect(mx, my, r_out, tile_size, tile_w, tile_h);
+        if (o.radius > 0) {
+            const Rect q = tile_rect(o.mx, o.my, o.radius, tile_size, tile_w, tile_h);
             cnt = (q.x1 - q.x0) * (q.y1 - q.y0);
         }
         tiles_per_gauss[idx] = cnt;

@@ -27,20 +27,35 @@ __device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
     return (unsigned)(key >> shift) & mask;
 }
 
+// n_dev (nullable): the element count lives in DEVICE memory (bin2.hip: the host sized buffers and grids for a
+// capacity `n` before it knew the count); the kernels then work on min(n, *n_dev) elements.
+__device__ __forceinline__ int64_t effective_n(int64_t n, const int64_t *n_dev) {
+    if (n_dev) {
+        const int64_t d = *n_dev;
+        if (d < n) n = d;
+    }
+    return n;
+}
+
 template <typename K, int ITEMS>
 __global__ __launch_bounds__(THREADS) void hist_kernel(int64_t n, const K *__restrict__ keys, int shift,
                                                        unsigned mask, int nblocks,
-                                                       uint32_t *__restrict__ g_hist) {
+                                                       uint32_t *__restrict__ g_hist, const int64_t *__restrict__ n_dev = nullptr) {
     __shared__ uint32_t s_hist[RADIX];
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
     __syncthreads();
+    n = effective_n(n, n_dev);
     const int64_t base = (int64_t)blockIdx.x * (THREADS * ITEMS);
+    K k[ITEMS];   // all loads first: one memory round trip per block
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int64_t j = base + (int64_t)i * THREADS + tid;
-        if (j < n) atomicAdd(&s_hist[digit_of(keys[j], shift, mask)], 1u);
+        k[i] = j < n ? keys[j] : (K)0;
     }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (base + (int64_t)i * THREADS + tid < n) atomicAdd(&s_hist[digit_of(k[i], shift, mask)], 1u);
     __syncthreads();
     g_hist[(int64_t)tid * nblocks + blockIdx.x] = s_hist[tid];
 }
@@ -78,11 +93,14 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(int nblocks, uint32_t *__
     if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-// Optional epilogue of the LAST pass: instead of the raw key, a 64-bit value derived from
-// (key, value) is written (bin.hip uses it to emit gsplat's isect_ids directly).
+// Optional epilogue of the LAST pass: gather(value) fetches what the outputs need (issued for four elements before the
+// first store), store(dst, key, value, gathered) writes them INSTEAD of the key / value stores (bin.hip: gsplat's
+// isect_ids; bin2.hip: rank_ids / flatten_ids / isect_ids).
 struct NoEpilogue {
     static constexpr bool enabled = false;
-    __device__ __forceinline__ int64_t operator()(uint64_t, int32_t) const { return 0; }
+    struct G {};
+    __device__ __forceinline__ G gather(int32_t) const { return G{}; }
+    __device__ __forceinline__ void store(uint32_t, uint64_t, int32_t, const G &) const {}
 };
 
 template <typename K, int ITEMS, class Epi>
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__
                                                           int shift, unsigned mask, int bits, int nblocks,
                                                           const uint32_t *__restrict__ g_hist,
                                                           const uint32_t *__restrict__ totals, Epi epi,
-                                                          int64_t *__restrict__ epi_out) {
+                                                          const int64_t *__restrict__ n_dev = nullptr) {
     constexpr int TILE = THREADS * ITEMS;
     __shared__ uint32_t s_off[WAVES][RADIX];  // per-wave digit counts, then running LOCAL offsets
     __shared__ uint32_t s_gbase[RADIX];       // global position of local slot 0 of each digit
@@ -104,22 +122,24 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__
     for (int w = 0; w < WAVES; ++w) s_off[w][tid] = 0;
     __syncthreads();
     // ---- load this wave's sub-tile (order: wave, iteration, lane == increasing index) + count digits
+    n = effective_n(n, n_dev);
     const int64_t tile_base = (int64_t)blockIdx.x * TILE;
+    if (tile_base >= n) return;   // (block-uniform; capacity-sized grids)
     const int64_t wbase = tile_base + (int64_t)wave * (64 * ITEMS);
     K key[ITEMS];
     int32_t val[ITEMS];
     unsigned dig[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {   // every load of the tile is issued before the first is used
         const int64_t j = wbase + i * 64 + lane;
-        if (j < n) {
-            key[i] = keys_in[j];
-            val[i] = vals_in[j];
-            dig[i] = digit_of(key[i], shift, mask);
-            atomicAdd(&s_off[wave][dig[i]], 1u);
-        } else {
-            key[i] = 0; val[i] = 0; dig[i] = 0;
-        }
+        key[i] = j < n ? keys_in[j] : (K)0;
+        val[i] = j < n ? vals_in[j] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        dig[i] = digit_of(key[i], shift, mask);
+        if (wbase + i * 64 + lane < n) atomicAdd(&s_off[wave][dig[i]], 1u);
+        else dig[i] = 0;
     }
     __syncthreads();
     // ---- per digit (one thread each): count in this block, local exclusive offset, global base
@@ -188,13 +208,35 @@ __global__ __launch_bounds__(THREADS) void reorder_kernel(int64_t n, const K *__
     __syncthreads();
     // ---- write out: consecutive threads hold consecutive elements of a digit run -> coalesced runs
     const int count = (int)min((int64_t)TILE, n - tile_base);
-    for (int k = tid; k < count; k += THREADS) {
-        const K kk = s_key[k];
-        const int32_t vv = s_val[k];
-        const uint32_t dst = s_gbase[digit_of(kk, shift, mask)] + (uint32_t)k;
-        if (Epi::enabled) epi_out[dst] = epi((uint64_t)kk, vv);
-        else keys_out[dst] = kk;
-        vals_out[dst] = vv;
+    constexpr int WB = 4;
+    for (int k0 = tid; k0 < count; k0 += WB * THREADS) {
+        K kk[WB];
+        int32_t vv[WB];
+        typename Epi::G gg[WB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+            const int k = k0 + u * THREADS;
+            kk[u] = k < count ? s_key[k] : (K)0;
+            vv[u] = k < count ? s_val[k] : 0;
+        }
+        if (Epi::enabled) {
+#pragma unroll
+            for (int u = 0; u < WB; ++u)
+                if (k0 + u * THREADS < count) gg[u] = epi.gather(vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+            const int k = k0 + u * THREADS;
+            if (k < count) {
+                const uint32_t dst = s_gbase[digit_of(kk[u], shift, mask)] + (uint32_t)k;
+                if (Epi::enabled) {
+                    epi.store(dst, (uint64_t)kk[u], vv[u], gg[u]);
+                } else {
+                    keys_out[dst] = kk[u];
+                    vals_out[dst] = vv[u];
+                }
+            }
+        }
     }
 }
 
@@ -214,7 +256,7 @@ inline size_t workspace_bytes(int64_t n) {
 template <typename K, class Epi = NoEpilogue>
 int sort_pairs(int64_t n, int key_bits, const K *keys_in, const int32_t *vals_in, K *keys_out, int32_t *vals_out,
                void *ws, size_t ws_bytes, hipStream_t st, const char *who, Epi epi = Epi(),
-               int64_t *epi_out = nullptr) {
+               const int64_t *n_dev = nullptr) {
     if (n == 0) return MTGS_OK;
     MTGS_REQUIRE(ws_bytes >= workspace_bytes<K>(n), MTGS_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes,
                  workspace_bytes<K>(n));
@@ -242,23 +284,23 @@ int sort_pairs(int64_t n, int key_bits, const K *keys_in, const int32_t *vals_in
         int32_t *vout = to_out ? vals_out : vals_tmp;
         const bool last = p == npass - 1;
         if (small) {
-            hist_kernel<K, 4><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist);
+            hist_kernel<K, 4><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist, n_dev);
             scan_kernel<0><<<RADIX, THREADS, 0, st>>>(nblocks, g_hist, totals);
             if (last && Epi::enabled)
                 reorder_kernel<K, 4, Epi><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
-                                                                      nblocks, g_hist, totals, epi, epi_out);
+                                                                      nblocks, g_hist, totals, epi, n_dev);
             else
                 reorder_kernel<K, 4, NoEpilogue><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
-                                                                             nblocks, g_hist, totals, NoEpilogue(), nullptr);
+                                                                             nblocks, g_hist, totals, NoEpilogue(), n_dev);
         } else {
-            hist_kernel<K, 16><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist);
+            hist_kernel<K, 16><<<nblocks, THREADS, 0, st>>>(n, kin, shift, mask, nblocks, g_hist, n_dev);
             scan_kernel<0><<<RADIX, THREADS, 0, st>>>(nblocks, g_hist, totals);
             if (last && Epi::enabled)
                 reorder_kernel<K, 16, Epi><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
-                                                                       nblocks, g_hist, totals, epi, epi_out);
+                                                                       nblocks, g_hist, totals, epi, n_dev);
             else
                 reorder_kernel<K, 16, NoEpilogue><<<nblocks, THREADS, 0, st>>>(n, kin, vin, kout, vout, shift, mask, bits,
-                                                                              nblocks, g_hist, totals, NoEpilogue(), nullptr);
+                                                                              nblocks, g_hist, totals, NoEpilogue(), n_dev);
         }
         shift += bits;
         kin = kout;

@@ -409,14 +409,57 @@ class _RasterizeToPixels(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------- fused path
+RECORD_CHANNELS = 8      # blended channels a packed record holds (csrc/raster_rec.hpp)
+speculative_sizing = True  # enqueue binning + compositing before the host knows (n_vis, M); see _SizePlan
+_force_caps = None       # tests: (cap_vis, cap_M) used for the speculative attempt, to exercise the overflow path
+
+
+class _SizePlan(threading.local):
+    """Per thread: the largest (n_vis, M) seen recently for a frame shape (C, N, width, height).
+
+    With a plan, a frame's binning and compositing are enqueued with CAPACITIES (1.5x the recent maxima: the extra
+    workgroups exit at once, the extra bytes are never touched) while the front kernels are still running; the kernels read
+    the true sizes from device memory.  The host reads the front kernel's mailbox afterwards -- normally it is there
+    already -- and repeats the frame with exact sizes in the rare case the capacities were too small."""
+
+    def __init__(self):
+        self.seen = {}
+
+    def caps(self, key, total):
+        rec = self.seen.get(key)
+        if rec is None:
+            return None
+        n_vis, M = rec
+        cap_vis = min(total, max(4096, n_vis + n_vis // 2))
+        cap_M = max(1 << 16, M + M // 2)
+        return cap_vis, -(-cap_M // (1 << 16)) * (1 << 16)
+
+    def update(self, key, n_vis, M):
+        old = self.seen.get(key)
+        if old is not None:   # slowly forget a peak
+            n_vis, M = max(n_vis, old[0] - old[0] // 16), max(M, old[1] - old[1] // 16)
+        self.seen[key] = (n_vis, M)
+
+
+_size_plan = _SizePlan()
+
+
+def _bin2_ok(Cn, tw, th, cap_M) -> bool:
+    return bool(_lib.load().mtgs_bin2_supported(Cn, tw, th, cap_M))
+
+
 class _FusedRasterization(torch.autograd.Function):
     """projection -> tile binning -> compositing as ONE autograd node: what gsplat.rendering.rasterization
-    chains from fully_fused_projection / isect_tiles / rasterize_to_pixels (same kernels, same results).
+    chains from fully_fused_projection / isect_tiles / rasterize_to_pixels (same results).
 
-    Being one node lets the backward keep the compositing gradients in COMPACT rows -- one 64-byte row per
-    VISIBLE Gaussian (mtgs_bin_compact's vis_rank), 19 MB instead of a zero-filled dense 128 MB buffer at 2M
-    Gaussians -- and lets the projection backward emit the gradients that leave the rasterizer (colours,
-    means2d for retain_grad(), |means2d| for absgrad) as dense contiguous tensors while it reads those rows.
+    Forward (csrc/front.hip, bin2.hip, blend.hip): ONE kernel projects, counts tiles, ranks the visible Gaussians and
+    writes a packed 64-byte record per visible Gaussian; eleven more sort / emit them into per-tile lists of record
+    indices; the compositing kernels stage a candidate with ONE 64-byte gather.  No size is needed on the host to
+    enqueue any of it (see _SizePlan).  Being one node also lets the backward keep the compositing gradients in COMPACT
+    rows -- one 64-byte row per VISIBLE Gaussian, indexed like the records -- and lets the projection backward emit the
+    gradients that leave the rasterizer (colours, means2d for retain_grad(), |means2d| for absgrad) as dense contiguous
+    tensors while it reads those rows.  Channel counts above 8, more than 12288 (camera, tile) pairs or 2^30
+    intersections take the earlier gather-based kernels (same results).
     Outputs: render, alphas, radii, means2d, depths, conics, compensations, opacities_eff, tiles_per_gauss,
     isect_ids, flatten_ids, isect_offsets  (the tensors of gsplat's `meta`)."""
 
@@ -430,7 +473,10 @@ class _FusedRasterization(torch.autograd.Function):
         dev, st = means.device, stream_of(means)
         tile_size = 16
         tw, th = -(-width // tile_size), -(-height // tile_size)
-        # (1) projection (+ opacity * compensation)
+        DC = 0 if col is None else col.shape[-1]
+        DT = DC + int(with_depth)
+        ed = bool(expected_depth)
+        total = Cn * N
         radii = torch.empty((Cn, N), dtype=torch.int32, device=dev)
         means2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev)
         depths = torch.empty((Cn, N), dtype=torch.float32, device=dev)
@@ -438,31 +484,95 @@ class _FusedRasterization(torch.autograd.Function):
         comps = torch.empty((Cn, N), dtype=torch.float32, device=dev) if calc_compensations else None
         opac_eff = torch.empty((Cn, N), dtype=torch.float32, device=dev)
         tiles_per_gauss = torch.empty((Cn, N), dtype=torch.int32, device=dev)
-        call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
-             width, height, eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(radii),
-             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
-             ptr(tiles_per_gauss), st)     # (+ the count pass of isect_tiles)
-        # (2) tile binning
-        scan_ws, scan_bytes = _ws("mtgs_scan_workspace_bytes", Cn * N, dev)
-        _, isect_ids, flatten_ids, offsets, order, vis_ids, vis_rank = _bin_depth_ordered(
-            means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tw, th, want_rank=True)
-        # (3) compositing
-        DC = 0 if col is None else col.shape[-1]
-        DT = DC + int(with_depth)
         render = torch.empty((Cn, height, width, DT), dtype=torch.float32, device=dev)
         alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
-        M = flatten_ids.numel()
-        dep = depths if with_depth else None
-        ed = bool(expected_depth)
-        call("mtgs_blend_fwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
-             width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), M, ptr(render), ptr(alphas),
-             ptr(last_ids), ptr(order), st)
+        packed = total > 0 and 1 <= DT <= RECORD_CHANNELS and _bin2_ok(Cn, tw, th, 0)
+        if not packed:
+            # ---- gather-based kernels (csrc/project.hip, bin.hip, blend.hip with dense attribute arrays)
+            call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+                 width, height, eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(radii),
+                 ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
+                 ptr(tiles_per_gauss), st)     # (+ the count pass of isect_tiles)
+            scan_ws, scan_bytes = _ws("mtgs_scan_workspace_bytes", total, dev)
+            _, isect_ids, flatten_ids, offsets, order, vis_ids, vis_rank = _bin_depth_ordered(
+                means2d, radii, depths, tiles_per_gauss, scan_ws, scan_bytes, tile_size, tw, th, want_rank=True)
+            dep = depths if with_depth else None
+            call("mtgs_blend_fwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
+                 width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), flatten_ids.numel(), ptr(render),
+                 ptr(alphas), ptr(last_ids), ptr(order), st)
+            recs = rank_ids = None
+        else:
+            # ---- packed records
+            key = (Cn, N, width, height)
+            front_ws, front_bytes = _ws("mtgs_front_workspace_bytes", total, dev)
+            totals = torch.empty(1, dtype=torch.int64, device=dev)
+            vis_rank = torch.empty(total, dtype=torch.int32, device=dev)
+            offsets_buf = torch.empty(Cn * th * tw + 1, dtype=torch.int32, device=dev)
+            order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
+
+            def front(cap_vis):
+                b = {"recs": torch.empty((cap_vis, 16), dtype=torch.float32, device=dev),
+                     "vis_ids": torch.empty(cap_vis, dtype=torch.int32, device=dev),
+                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis}
+                mailbox, tag = _host_mailbox()
+                call("mtgs_front_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
+                     eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
+                     ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
+                     ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
+                     ptr(vis_rank), cap_vis, None, None, ptr(totals), mailbox.data_ptr(), tag, ptr(front_ws), front_bytes, st)
+                b["mailbox"], b["tag"] = mailbox, tag
+                return b
+
+            def rest(b, cap_M):
+                cap_alloc = max(cap_M, 1)
+                out = {"rank_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
+                       "flatten_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
+                       "isect_ids": torch.empty(cap_alloc, dtype=torch.int64, device=dev)}
+                nbytes = C.c_size_t(0)
+                call("mtgs_bin2_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
+                ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+                off = (-ws.data_ptr()) % 256
+                call("mtgs_bin2_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
+                     ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
+                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
+                     nbytes.value, st)
+                call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
+                     ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), st)
+                return out
+
+            caps = _force_caps or (_size_plan.caps(key, total) if speculative_sizing else None)
+            if caps is not None and not _bin2_ok(Cn, tw, th, caps[1]):
+                caps = None
+            if caps is not None:
+                b = front(min(caps[0], total))
+                out = rest(b, caps[1])                    # enqueued before the totals are known
+                n_vis, M = _wait_mailbox(b["mailbox"], b["tag"], totals, total)
+                if n_vis > b["cap_vis"] or M > caps[1]:   # capacities too small: repeat with exact sizes
+                    if not _bin2_ok(Cn, tw, th, M):
+                        raise NotImplementedError(f"rasterization: {M} tile intersections in one call (limit 2^30)")
+                    if n_vis > b["cap_vis"]:
+                        b = front(n_vis)
+                    out = rest(b, M)
+            else:
+                b = front(total)
+                n_vis, M = _wait_mailbox(b["mailbox"], b["tag"], totals, total)
+                if not _bin2_ok(Cn, tw, th, M):
+                    raise NotImplementedError(f"rasterization: {M} tile intersections in one call (limit 2^30)")
+                b["cap_vis"] = max(n_vis, 0)              # (buffers are larger; the kernels only need a bound)
+                out = rest(b, M)
+            _size_plan.update(key, n_vis, M)
+            recs, vis_ids = b["recs"], b["vis_ids"][:n_vis]
+            rank_ids, flatten_ids, isect_ids = out["rank_ids"][:M], out["flatten_ids"][:M], out["isect_ids"][:M]
+            offsets = offsets_buf[:Cn * th * tw].view(Cn, th, tw)
+            offsets._mtgs_tile_order = order
+            isect_ids._mtgs_offsets = offsets
         ctx.save_for_backward(means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics,
-                              comps, opac_eff, offsets, flatten_ids, alphas, last_ids, order, vis_ids, vis_rank,
-                              render if ed else None)
+                              comps, opac_eff, offsets if not packed else offsets_buf, flatten_ids, alphas, last_ids, order,
+                              vis_ids, vis_rank, render if ed else None, recs, rank_ids)
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
         ctx.absgrad = bool(absgrad)
+        ctx.packed = packed
         ctx.set_materialize_grads(False)
         # classic mode: an empty placeholder keeps the output arity fixed
         comps_out = comps if comps is not None else torch.empty(0, device=dev)
@@ -474,7 +584,7 @@ class _FusedRasterization(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alphas, _r, g_means2d, g_depths, g_conics, g_comps, g_opac, *_ints):
         (means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics, comps, opac_eff, offsets,
-         flatten_ids, alphas, last_ids, order, vis_ids, vis_rank, render) = ctx.saved_tensors
+         flatten_ids, alphas, last_ids, order, vis_ids, vis_rank, render, recs, rank_ids) = ctx.saved_tensors
         width, height, tile_size, tw, th, DC, with_depth, ed, eps2d = ctx.dims
         Cn, N = means2d.shape[:2]
         dev, st = means.device, stream_of(means)
@@ -494,11 +604,17 @@ class _FusedRasterization(torch.autograd.Function):
             if v_alphas is None:
                 v_alphas = torch.zeros((Cn, height, width, 1), dtype=torch.float32, device=dev)
             v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
-            call("mtgs_blend_bwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
-                 width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), flatten_ids.numel(), ptr(alphas),
-                 ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(r_xy),
-                 ptr(r_abs) if ctx.absgrad else None, ptr(r_con), ptr(r_col), ptr(r_dep), ptr(r_opa),
-                 host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
+            if ctx.packed:
+                if rank_ids.numel() > 0:
+                    call("mtgs_blend_bwd_packed", Cn, DC, int(with_depth), ptr(recs), ptr(bg), int(ed), width, height, tw, th,
+                         ptr(offsets), ptr(rank_ids), ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas),
+                         ptr(G), RS, int(ctx.absgrad), ptr(order), st)
+            else:
+                call("mtgs_blend_bwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
+                     width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), flatten_ids.numel(), ptr(alphas),
+                     ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(r_xy),
+                     ptr(r_abs) if ctx.absgrad else None, ptr(r_con), ptr(r_col), ptr(r_dep), ptr(r_opa),
+                     host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Development: stage times of the fused rasterization path (HIP events around the C-ABI calls it makes), headline
+workload by default.  `--lib` selects an A/B build (scripts/build_variant.py)."""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mtgs_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=2_000_000)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--extra-channels", type=int, default=0)
+ap.add_argument("--lib", default=None)
+args = ap.parse_args()
+if args.lib:
+    _lib.use_library(args.lib)
+from mtgs_amd import rasterization  # noqa: E402
+from mtgs_amd.synthetic import make_camera, make_scene  # noqa: E402
+
+dev = torch.device("cuda")
+sc = make_scene(args.n, seed=0, sh_degree=None)
+vm, K = make_camera(args.width, args.height)
+P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+if args.extra_channels:
+    P["colors"] = torch.cat([P["colors"].detach(), torch.rand(args.n, args.extra_channels, device=dev)], -1).requires_grad_(True)
+vm, K = vm.to(dev).requires_grad_(True), K.to(dev)
+g = torch.Generator().manual_seed(1)
+D = P["colors"].shape[-1] + 1
+Gc, Ga = torch.randn(1, args.height, args.width, D, generator=g).to(dev), torch.randn(1, args.height, args.width, 1, generator=g).to(dev)
+names = ["mtgs_front_fwd", "mtgs_bin2_build", "mtgs_blend_fwd_packed", "mtgs_blend_bwd_packed", "mtgs_project_bwd"]
+
+
+def step():
+    r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K, args.width, args.height,
+                               packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+    torch.autograd.backward([r, a], [Gc, Ga])
+    return info
+
+
+for _ in range(3):
+    info = step()
+torch.cuda.synchronize()
+_lib.time_calls(names)
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(args.reps):
+    step()
+t1.record()
+torch.cuda.synchronize()
+ms = _lib.timed_ms()
+print(f"lib={args.lib or 'in-tree'} N={args.n} {args.width}x{args.height} D={D} n_vis={int((info['radii'] > 0).sum())} M={info['flatten_ids'].numel()}")
+for n in names:
+    v = sorted(ms.get(n, [0.0]))
+    print(f"  {n:26s} median {v[len(v) // 2] * 1e3:8.1f} us   min {v[0] * 1e3:8.1f} us")
+print(f"  whole step (raster only)   {t0.elapsed_time(t1) / args.reps * 1e3:8.1f} us")

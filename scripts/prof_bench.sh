@@ -1,7 +1,9 @@
 #!/bin/bash
-# rocprofv3 kernel-trace summary of the default bench workload -> gpurun_out/bench_prof/
+# rocprofv3 kernel trace of bench.py -> gpurun_out/prof_bench/ (copied to profiles/ by scripts/collect_profiles.py)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/bench_prof && mkdir -p $R/gpurun_out/bench_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/bench_prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-steps 0 > $R/gpurun_out/bench_prof/log.txt 2>&1
-tail -1 $R/gpurun_out/bench_prof/log.txt | cut -c1-200
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_bench
+rm -rf $OUT; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 3 --cpu-steps 0 > $OUT/bench.log 2>&1
+echo "rc=$?"
+find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'cut -d, -f1-4 {} | cut -c1-150 | head -40'

@@ -129,3 +129,39 @@ def test_randomised_differential_check(hip_lib):
     r = subprocess.run([sys.executable, str(root / "tests" / "fuzz_gpu.py"), "--cases", "60", "--seed", "123"],
                        capture_output=True, text=True, timeout=900, cwd=str(root))
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_speculative_sizing_overflow_repeats_the_frame_exactly(hip_lib):
+    """The fused path enqueues binning + compositing with CAPACITIES before the host knows (n_vis, M).  Capacities that
+    turn out too small (forced here) must give exactly the frame an exact-size run gives: same lists, same image, same
+    gradients -- and nothing may be written out of bounds on the way (the truncated attempt is discarded)."""
+    from mtgs_amd import rasterization, wrapper
+    from tests.util import small_scene
+    sc, vm, K = small_scene(N=4000, W=200, H=120, seed=11)
+    dev = torch.device("cuda")
+
+    def run(force):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+        old = (wrapper._force_caps, wrapper.speculative_sizing)
+        wrapper._force_caps, wrapper.speculative_sizing = force, force is not None
+        try:
+            r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm.to(dev), K.to(dev),
+                                       200, 120, packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+            (r.sum() + 2 * a.sum()).backward()
+        finally:
+            wrapper._force_caps, wrapper.speculative_sizing = old
+        torch.cuda.synchronize()
+        return r.detach(), a.detach(), info, {k: p.grad for k, p in P.items()}
+
+    r0, a0, i0, g0 = run(None)
+    n_vis, M = int((i0["radii"] > 0).sum()), i0["flatten_ids"].numel()
+    assert n_vis > 500 and M > 2000
+    for caps in [(n_vis // 2, 1 << 16), (n_vis + 10, M // 3), (64, 64), (n_vis, M)]:
+        r1, a1, i1, g1 = run(caps)
+        for k in ("flatten_ids", "isect_ids", "isect_offsets", "radii", "tiles_per_gauss"):
+            assert torch.equal(i0[k], i1[k]), (caps, k)
+        assert torch.equal(r0, r1) and torch.equal(a0, a1), caps
+        for k in g0:
+            # (fp32 atomics accumulate in a different order from run to run)
+            assert (g0[k] - g1[k]).abs().max() <= 2e-4 * g0[k].abs().max() + 1e-7, (caps, k)
