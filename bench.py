@@ -87,17 +87,35 @@ def make_step(args, dev, world):
     sparse = world > 1 and args.dp_exchange == "sparse" and args.variant == "mtgs"
     exchange = SparseGradExchange(args.n_gaussians, 16, dev["means"].device) if sparse else None
 
+    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rows", "end")}
+    info_box["events"] = ev
+
     def step():
         for p in all_params:
             p.grad = None
+        ev["start"].record()
+        if sparse:
+            # ONE exchange per step: the sum of the Gaussian gradients over the ranks (cameras).  The exchange renders
+            # (MTGS's colour activation fused), its backward leaves 64-byte wire rows of the visible Gaussians, and
+            # finish() all-gathers them in chunks and rebuilds every dense gradient -- the SH-coefficient gradient of
+            # every rank's rows, this rank's included, from its rank-1 factors (mtgs_amd.dist.SparseGradExchange)
+            dirs = params["means"].detach() - cam_pos
+            sh_out = spherical_harmonics(3, dirs, params["coeffs"].detach())
+            render, alpha, info = exchange.rasterization(params["means"], params["quats"], params["scales"],
+                                                         params["opacities"], sh_out, viewmat, K, W, H, cam_pos,
+                                                         render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+            torch.autograd.backward([render, alpha], [Gc, Ga])
+            ev["rows"].record()
+            g = exchange.finish(params["means"], 3)
+            for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
+                params[name].grad = t
+            ev["end"].record()
+            info_box["grad_bytes"] = exchange.last_bytes
+            info_box["info"] = info
+            return render, alpha
         if args.variant == "mtgs":
             dirs = params["means"].detach() - cam_pos
-            if sparse:
-                # the SH output is the autograd leaf: its gradient (3 floats per Gaussian) is the factor
-                # that is exchanged; every rank rebuilds the summed coefficient gradient from the factors
-                sh_out = spherical_harmonics(3, dirs, params["coeffs"].detach()).requires_grad_(True)
-            else:
-                sh_out = spherical_harmonics(3, dirs, params["coeffs"])
+            sh_out = spherical_harmonics(3, dirs, params["coeffs"])
             rgb = torch.clamp(sh_out + 0.5, 0.0, 1.0)
             render, alpha, info = rasterization(
                 means=params["means"], quats=params["quats"], scales=params["scales"],
@@ -112,15 +130,10 @@ def make_step(args, dev, world):
                 rasterize_mode="classic")
         info["means2d"].retain_grad()
         torch.autograd.backward([render, alpha], [Gc, Ga])
-        if sparse:  # ONE exchange per step: sum of the Gaussian gradients over the ranks (cameras); the SH
-            # backward of every rank's rows (this rank's included) happens inside the receiver's reduction pass
-            g = exchange.exchange(info["radii"][0], params["means"].detach(), cam_pos, params["means"].grad,
-                                  params["quats"].grad, params["scales"].grad, params["opacities"].grad, sh_out.grad, 3)
-            for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
-                params[name].grad = t
-            info_box["grad_bytes"] = exchange.last_bytes
-        elif world > 1:
-            info_box["grad_bytes"] = all_reduce_grads(all_params)
+        ev["rows"].record()
+        if world > 1:   # dense exchange: every Gaussian gradient tensor (the camera's own viewmat gradient stays local)
+            info_box["grad_bytes"] = all_reduce_grads(list(params.values()))
+        ev["end"].record()
         info_box["info"] = info
         return render, alpha
 
@@ -139,6 +152,7 @@ def make_step(args, dev, world):
             width=W, height=H, tile_size=16, packed=False, render_mode="RGB", absgrad=False,
             rasterize_mode="classic")
 
+    info_box["exchange"] = exchange
     return step, step_fwd, all_params, info_box
 
 
@@ -302,6 +316,20 @@ def main():
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "formula": "SURVEY.md section 8(d) B_F + B_B"}},
     }
+    if world > 1:
+        # phase breakdown of the LAST timed step on this rank (HIP events; phases overlap by design, so they do not add up
+        # to ms_per_step): render = forward + backward up to the wire rows (dense: up to the local gradients), meta =
+        # all-gather of the visibility maps on the side stream (hidden behind the compositing), wire = first row
+        # all-gather issued -> last complete, reduce = the reduction kernels, exchange = rows ready -> gradients ready
+        evs = info_box["events"]
+        torch.cuda.synchronize()
+        phases = {"render": round(evs["start"].elapsed_time(evs["rows"]), 3),
+                  "exchange": round(evs["rows"].elapsed_time(evs["end"]), 3)}
+        if info_box["exchange"] is not None:
+            phases.update({k: round(v, 3) for k, v in info_box["exchange"].phases_ms().items()})
+        out["dp_phases_ms"] = phases
+        out["dp_world_size"] = torch.distributed.get_world_size()
+        out["dp_backend"] = torch.distributed.get_backend()
     if fwd_ms is not None:
         out["also"] = {"fwd_only_ms": round(fwd_ms, 3), "fwd_only_mpix_s": round(P / fwd_ms / 1e3, 1),
                        "gaussians_per_s_fwd_bwd": round(world * args.n_gaussians / (ms_per_step * 1e-3), 0)}

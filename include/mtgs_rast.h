@@ -234,11 +234,13 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
  *   vis_ids[cap_vis] i32  flat index;  vis_keys[cap_vis] i64 = tile count << 40 | camera << 32 | bits(depth)
  *   vis_rank[C*N] i32     rank of every visible pair (dense; culled entries unspecified)
  *   dp_words[ceil(C*N/64)] u64, dp_prefix[ceil(C*N/64)] u32 (both nullable): visibility bitmap and rank of the first
- *                         pair of each word (the map mtgs_dp_reduce reads)
+ *                         pair of each word (the map mtgs_dp_reduce reads); dp_count[1] i32 (nullable) = n_vis
+ *   color_mode            0: colours as given; 1: the first three channels are SH output x, blended as
+ *                         clamp(x + 0.5, 0, 1) (MTGS's colour activation, vanilla_gaussian_splatting.py:318)
  *   totals[1] i64 (device) = n_vis << 32 | M; host_totals (nullable): PINNED HOST int64[2], receives {totals, host_tag}
  *   as soon as the last block finishes (system-scope release store), so the host can poll instead of synchronising.
  *   M = 2^31 - 1 signals more than 2^31 - 2 intersections (or an internal failure): the frame cannot be rendered.
- * ws: mtgs_front_workspace_bytes(C*N), 8-byte aligned; zeroed by the call.
+ * ws: mtgs_front_workspace_bytes(C*N), 256-byte aligned.
  *
  * mtgs_bin2_build: depth sort of the visible pairs, emission in depth order, per-tile counts -> offsets[C*th*tw + 1]
  * (last entry = M) + tile_order (nullable), tile sort -> rank_ids[cap_M] (record / gradient-row index of every
@@ -258,8 +260,9 @@ int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, con
                    int with_depth, int32_t *radii, float *means2d, float *depths, float *conics,
                    float *compensations, float *opac_eff, int tile_size, int tile_w, int tile_h,
                    int32_t *tiles_per_gauss, float *recs, int32_t *vis_ids, int64_t *vis_keys,
-                   int32_t *vis_rank, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int64_t *totals,
-                   int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes, void *stream);
+                   int32_t *vis_rank, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
+                   int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes,
+                   void *stream);
 int mtgs_bin2_supported(int C, int tile_w, int tile_h, int64_t cap_M);
 int mtgs_bin2_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
 int mtgs_bin2_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
@@ -299,7 +302,10 @@ int mtgs_dp_accumulate(int64_t n_rows, const float *rows, int64_t N, int K, int 
  * mtgs_dp_reduce: W senders' maps (sender r's words at (char*)words + r*map_stride_bytes, prefix likewise), rows
  * (sender r at rows + r*row_stride floats), cams[W,3]; ONE pass over the N Gaussians sums every sender's rows in
  * registers (v_rgb expanded through basis(normalize(mean - cam_r))) and WRITES v_means[N,3] v_quats[N,4]
- * v_scales[N,3] v_opacities[N] v_coeffs[N,K,3] (nullable) -- the sum over senders, zeros where no sender has a row. */
+ * v_scales[N,3] v_opacities[N] v_coeffs[N,K,3] (nullable) -- the sum over senders, zeros where no sender has a row.
+ * [g_begin, g_end) (g_begin a multiple of 64; g_end < 0 = N): only that range of Gaussians is reduced and written, and
+ * every sender's `rows` then starts at ITS first row of the range (row of Gaussian n = prefix[n/64] - prefix[g_begin/64]
+ * + ...): the caller exchanges the rows in chunks of the index range and reduces a chunk while the next is on the wire. */
 int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float *v_means, const float *v_quats,
                          const float *v_scales, const float *v_opacities, const float *v_rgb, uint64_t *words,
                          uint32_t *prefix, int32_t *count, uint32_t *block_counts, float *rows, int64_t capacity,
@@ -307,7 +313,18 @@ int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float *v_means, 
 int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
                    const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
                    const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
-                   float *v_coeffs, void *stream);
+                   float *v_coeffs, int64_t g_begin, int64_t g_end, void *stream);
+/* Wire rows straight from the compositing backward's compact gradient rows (no dense tensor, no pack pass): the VJP of
+ * the projection per VISIBLE Gaussian (vis_ids[n_vis], index order; C = 1) writes wire_rows[n_vis,16] =
+ * {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, 0, Gaussian index (int bits)}.  grad_rows[n_vis,row_stride] as mtgs_blend_bwd_packed
+ * leaves them (D <= 3 colour channels).  color_mode 1: colours were clamp(colors_pre + 0.5, 0, 1) (mtgs_front_fwd),
+ * v_rgb is the gradient with respect to colors_pre[N,3].  v_viewmats[1,4,4] nullable, overwritten. */
+int mtgs_project_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
+                          const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                          const float *conics, const float *compensations, const float *opacities,
+                          const float *grad_rows, int64_t row_stride, int D, int with_depth, const float *colors_pre,
+                          int color_mode, const int32_t *vis_ids, int64_t n_vis, float *wire_rows, float *v_viewmats,
+                          void *stream);
 
 /* ---- caller side of the path: fused per-node activations ----------------------------
  * One kernel per direction for what VanillaGaussianSplattingModel.get_gaussians does per step with a dozen PyTorch

@@ -53,8 +53,8 @@ _SIGNATURES = {
     "mtgs_bin_finalize": [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_front_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_front_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32,
-                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                       _vp, _i64, _vp, _sz, _vp],
+                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32,
+                       _vp, _vp, _i64, _vp, _sz, _vp],
     "mtgs_bin2_supported": [_i32, _i32, _i32, _i64],
     "mtgs_bin2_workspace_bytes": [_i32, _i32, _i32, _i64, _i64, C.POINTER(_sz)],
     "mtgs_bin2_build": [_i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -66,7 +66,9 @@ _SIGNATURES = {
     "mtgs_dp_pack": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "mtgs_dp_reduce": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_dp_reduce": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "mtgs_project_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
+                              _vp, _i64, _vp, _vp, _vp],
     "mtgs_node_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                       _vp, _vp],
     "mtgs_node_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -227,10 +227,11 @@ struct DpSenders {
     const unsigned long long *words;  // sender r: (char*)words + r * map_stride_bytes
     const uint32_t *prefix;           //           (char*)prefix + r * map_stride_bytes
     int64_t map_stride_bytes;
-    const float *rows;                // sender r: rows + r * row_stride (floats)
+    const float *rows;                // sender r: rows + r * row_stride (floats); row 0 = first row of word `word0`
     int64_t row_stride;
     const float *cams;                // [W,3]
     int W;
+    int64_t word0;                    // first visibility word of the Gaussian range the rows cover
 };
 constexpr int DP_MAX_SENDERS = 64;  // one lane per sender computes its row span of a tile
 constexpr int DP_TILE = 32;    // Gaussians per wave (half a visibility word)
@@ -239,19 +240,25 @@ constexpr int DP_MAXSTEP = DP_TILE / 4;
 // (lane k: geometry component k | coefficient k x rgb) in LDS.  Rows are packed in index order, so the rows a sender
 // has for the tile are CONTIGUOUS: [prefix + popcount(bits below the tile), + popcount(tile bits)).  The wave walks
 // them four at a time (16 lanes per row: dense lanes, ~5 rows per sender and tile at 15 % visibility), finds the
-// Gaussian from the index stored in the row, evaluates ITS basis function for the sender's camera and adds into the
-// LDS accumulators; the dense gradients are written once at the end.  (A Gaussian-centric loop with a predicate per
-// (Gaussian, sender) pair ran 48 % of its steps with ~30 % of the lanes useful: 512 us at 8 senders.)
+// Gaussian from the index in the row's last word -- the 14 gradient floats leave two spare words in a 64-byte row, so
+// the index costs no wire byte, and deriving the position from the map instead (j-th set bit, an LDS table per sender)
+// measured 274 us against 225 us at 8 senders --, evaluates the Gaussian's basis function for the sender's camera and
+// adds into the LDS accumulators; the dense gradients are written once at the end.  (A
+// Gaussian-centric loop with a predicate per (Gaussian, sender) pair ran 48 % of its steps with ~30 % of the lanes
+// useful: 512 us at 8 senders.)  The Gaussian range [g_begin, g_end) lets the caller reduce one CHUNK of the index
+// range while the next chunk's rows are still on the wire.
 template <int MAXDEG>
-__global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t N, int K, int nb, const float *__restrict__ means,
-                                                        const DpSenders S, float *__restrict__ v_means,
-                                                        float *__restrict__ v_quats, float *__restrict__ v_scales,
-                                                        float *__restrict__ v_opacities, float *__restrict__ v_coeffs) {
+__global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t g_end, int K, int nb,
+                                                        const float *__restrict__ means, const DpSenders S,
+                                                        float *__restrict__ v_means, float *__restrict__ v_quats,
+                                                        float *__restrict__ v_scales, float *__restrict__ v_opacities,
+                                                        float *__restrict__ v_coeffs) {
     __shared__ float4 s_acc[4][DP_TILE][16];
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t tile = g_begin / DP_TILE + (int64_t)blockIdx.x * 4 + wave;
     const int64_t g0 = tile * DP_TILE;
-    if (g0 >= N) return;
+    if (g0 >= g_end) return;
+    const int64_t N = g_end;
     const int64_t wi = g0 >> 6;
     const int half = (int)(tile & 1);
     ShLaneConst lc = sh_lane_const(k);
@@ -259,22 +266,21 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t N, int K, int nb
     float4(*acc)[16] = s_acc[wave];
 #pragma unroll
     for (int it = 0; it < DP_MAXSTEP; ++it) acc[it * 4 + sub][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the tile's means in LDS: a global gather by the row's index would put a dependent memory round trip into
-    // every step (row -> index -> mean), which is what bounded the kernel (576 us at 8 senders)
+    // the tile's means in LDS: a global gather per row would put a dependent memory round trip into every step
     __shared__ float s_mean[4][DP_TILE * 3];
     float *tmean = s_mean[wave];
     if (v_coeffs) {
         for (int e = lane; e < DP_TILE * 3; e += 64) tmean[e] = g0 * 3 + e < N * 3 ? means[g0 * 3 + e] : 1.f;
     }
-    const int row_lane0 = (lane & ~15) << 2;  // byte address of lane 0 of this 16-lane row (ds_bpermute)
-    // (first row, number of rows) every sender has for this tile: one lane per sender, one memory round trip
+    // (first row, number of rows, tile bits) every sender has for this tile: one lane per sender, one memory round trip
     __shared__ int2 s_span[4][DP_MAX_SENDERS];
     if (lane < S.W) {
-        const char *wp = reinterpret_cast<const char *>(S.words) + lane * S.map_stride_bytes + wi * 8;
-        const char *pp = reinterpret_cast<const char *>(S.prefix) + lane * S.map_stride_bytes + wi * 4;
-        const unsigned long long wv = *reinterpret_cast<const unsigned long long *>(wp);
+        const char *wp = reinterpret_cast<const char *>(S.words) + lane * S.map_stride_bytes;
+        const char *pp = reinterpret_cast<const char *>(S.prefix) + lane * S.map_stride_bytes;
+        const unsigned long long wv = reinterpret_cast<const unsigned long long *>(wp)[wi];
         const unsigned lo = (unsigned)wv, hi = (unsigned)(wv >> 32);
-        const int start = (int)*reinterpret_cast<const uint32_t *>(pp) + (half ? __builtin_popcount(lo) : 0);
+        const uint32_t p_w = reinterpret_cast<const uint32_t *>(pp)[wi], p_0 = reinterpret_cast<const uint32_t *>(pp)[S.word0];
+        const int start = (int)(p_w - p_0) + (half ? __builtin_popcount(lo) : 0);
         s_span[wave][lane] = make_int2(start, __builtin_popcount(half ? hi : lo));
     }
     // Software pipeline over the senders: the rows of sender r + 1 are in flight while sender r is accumulated
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t N, int K, int nb
             dst[st] = j < cnt ? rows_r[j * 16 + k] : 0.f;
         }
     };
+    const int row_lane0 = (lane & ~15) << 2;  // byte address of lane 0 of this 16-lane row (ds_bpermute)
     issue(0, nxt, nxt_cnt);
     for (int r = 0; r < S.W; ++r) {
         float cur[DP_MAXSTEP];
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t N, int K, int nb
             if (st * 4 >= cnt) break;  // wave-uniform
             const bool on = st * 4 + sub < cnt;
             const int vi = __float_as_int(cur[st]);
-            const int idx = __builtin_amdgcn_ds_bpermute(row_lane0 + 15 * 4, vi);
+            const int idx = __builtin_amdgcn_ds_bpermute(row_lane0 + 15 * 4, vi);   // the row's Gaussian index (last word)
             const int pos = on ? (int)(idx - (int)g0) : 0;
             float4 a = acc[pos][k];
             a.x += k < 11 ? cur[st] : 0.f;
@@ -406,11 +413,16 @@ extern "C" int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float
 extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
                               const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
                               int64_t row_stride, const float *cams, float *v_means, float *v_quats,
-                              float *v_scales, float *v_opacities, float *v_coeffs, void *stream) {
+                              float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
+                              void *stream) {
     MTGS_REQUIRE(W >= 1 && N >= 0 && map_stride_bytes >= 0 && row_stride >= 0, MTGS_EINVAL, "mtgs_dp_reduce: bad sizes");
     MTGS_REQUIRE(W <= DP_MAX_SENDERS, MTGS_EUNSUPPORTED, "mtgs_dp_reduce: %d senders (at most %d; use mtgs_dp_accumulate)", W,
                  DP_MAX_SENDERS);
-    if (N == 0) return MTGS_OK;
+    if (g_end < 0) g_end = N;
+    MTGS_REQUIRE(g_begin >= 0 && g_begin <= g_end && g_end <= N && (g_begin % 64) == 0, MTGS_EINVAL,
+                 "mtgs_dp_reduce: range [%lld, %lld) of %lld (the start must be a multiple of 64)", (long long)g_begin,
+                 (long long)g_end, (long long)N);
+    if (g_end == g_begin) return MTGS_OK;
     MTGS_REQUIRE(words && prefix && rows && v_means && v_quats && v_scales && v_opacities, MTGS_EINVAL,
                  "mtgs_dp_reduce: null pointer");
     int nb = 0;
@@ -423,14 +435,15 @@ extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *
         nb = (degree + 1) * (degree + 1);
     }
     MTGS_REQUIRE(means, MTGS_EINVAL, "mtgs_dp_reduce: null pointer");
-    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W};
-    const unsigned grid = (unsigned)ceil_div64(ceil_div64(N, DP_TILE), 4);  // one wave per 32-Gaussian tile
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
+    const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);  // one wave per 32-Gaussian tile
     hipStream_t st = (hipStream_t)stream;
+    // (the kernel bounds its writes by g_end: the last range ends at N)
     switch (degree) {
-        case 0: dp_reduce_kernel<0><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
-        case 1: dp_reduce_kernel<1><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
-        case 2: dp_reduce_kernel<2><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
-        default: dp_reduce_kernel<3><<<grid, 256, 0, st>>>(N, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        case 0: dp_reduce_kernel<0><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        case 1: dp_reduce_kernel<1><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        case 2: dp_reduce_kernel<2><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        default: dp_reduce_kernel<3><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
     }
     MTGS_CHECK_LAUNCH("mtgs_dp_reduce");
     return MTGS_OK;

@@ -83,7 +83,7 @@ struct CompactArgs {
     const int32_t *radii, *tiles_per_gauss;
     const float *means2d, *depths, *conics, *opac_eff;
     const float *colors;  // [C*N, DC] (nullable when DC == 0)
-    int DC, with_depth;
+    int DC, with_depth, color_mode;
     const uint64_t *chunk_counts, *group_counts;
     // compact outputs, indexed by rank (< cap_vis)
     float *recs;
@@ -93,6 +93,7 @@ struct CompactArgs {
     int64_t cap_vis;
     unsigned long long *dp_words;  // nullable
     uint32_t *dp_prefix;           // nullable
+    int32_t *dp_count;             // nullable: n_vis as int32 (the first word of the exchange's meta record)
     int64_t *totals;       // device: n_vis << 32 | M
     int64_t *host_totals;  // pinned host mailbox {totals, tag}; nullable
     int64_t host_tag;
@@ -174,6 +175,10 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
 #pragma unroll
                 for (int k = 0; k < REC_MAX_CHANNELS; ++k)
                     if (k < a.DC) ch[k] = a.colors[idx * a.DC + k];
+                if (a.color_mode == 1) {   // MTGS's colour activation on SH output: clamp(x + 0.5, 0, 1), first 3 channels
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ch[k] = fminf(fmaxf(ch[k] + 0.5f, 0.f), 1.f);
+                }
                 if (a.with_depth) {
 #pragma unroll
                     for (int k = 0; k < REC_MAX_CHANNELS; ++k)
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
         if (M > 0x7fffffffull) M = 0x7fffffffull;
         const int64_t packed = (int64_t)((n_vis << 32) | M);
         *a.totals = packed;
+        if (a.dp_count) *a.dp_count = (int32_t)n_vis;
         if (a.host_totals) {
             __hip_atomic_store(a.host_totals, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_totals + 1, a.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -230,8 +236,9 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
                               float *depths, float *conics, float *compensations, float *opac_eff,
                               int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, float *recs,
                               int32_t *vis_ids, int64_t *vis_keys, int32_t *vis_rank,
-                              int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int64_t *totals,
-                              int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes, void *stream) {
+                              int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
+                              int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws,
+                              size_t ws_bytes, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0 && D >= 0 && cap_vis >= 0, MTGS_EINVAL,
                  "mtgs_front_fwd: bad sizes C=%d N=%lld W=%d H=%d D=%d", C, (long long)N, width, height, D);
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_front_fwd: tile_size=%d (only 16 is implemented)", tile_size);
@@ -260,6 +267,7 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
                      vis_rank && ws,
                  MTGS_EINVAL, "mtgs_front_fwd: null pointer");
     MTGS_REQUIRE(!dp_words == !dp_prefix, MTGS_EINVAL, "mtgs_front_fwd: dp_words and dp_prefix go together");
+    MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D >= 3), MTGS_EINVAL, "mtgs_front_fwd: color_mode=%d with %d channels", color_mode, D);
     MTGS_REQUIRE(ws_bytes >= front_ws_bytes(total), MTGS_EWORKSPACE, "mtgs_front_fwd: workspace %zu < %zu bytes", ws_bytes,
                  front_ws_bytes(total));
     MTGS_REQUIRE((reinterpret_cast<uintptr_t>(recs) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, MTGS_EINVAL,
@@ -277,7 +285,7 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
     a.conics = conics; a.opac_eff = opac_eff; a.colors = colors; a.DC = D; a.with_depth = with_depth ? 1 : 0;
     a.chunk_counts = chunk_counts; a.group_counts = (const uint64_t *)group_counts;
     a.recs = recs; a.vis_ids = vis_ids; a.vis_keys = (uint64_t *)vis_keys; a.vis_rank = vis_rank; a.cap_vis = cap_vis;
-    a.dp_words = (unsigned long long *)dp_words; a.dp_prefix = dp_prefix;
+    a.dp_words = (unsigned long long *)dp_words; a.dp_prefix = dp_prefix; a.dp_count = dp_count; a.color_mode = color_mode;
     a.totals = totals; a.host_totals = host_totals; a.host_tag = host_tag;
     front_compact_kernel<<<(unsigned)ceil_div64(total, COMPACT_TILE), COMPACT_THREADS, 0, st>>>(a);
     MTGS_CHECK_LAUNCH("mtgs_front_fwd");

@@ -350,6 +350,81 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     }
 }
 
+// ---- wire rows (view-parallel data parallelism, mtgs_amd.dist / csrc/dp.hip) ----------------------------------------
+// The same per-visible-Gaussian VJP, reading the compositing backward's compact gradient rows
+//   G[r] = [v_xy 2 | |v_xy| 2 | v_conic 3 | v_opacity_eff 1 | v_colour DC | v_depth 1 | ...]
+// and writing, per visible Gaussian in index order, the 64-byte row the gradient exchange puts on the wire:
+//   [v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | v_rgb 3 | 0 | Gaussian index (int bits)]
+// v_rgb is the gradient with respect to the SH OUTPUT x: with color_mode 1 the colour was clamp(x + 0.5, 0, 1)
+// (front.hip), whose VJP passes the gradient where 0 <= x + 0.5 <= 1 (torch.clamp's rule).  No dense tensor is
+// written: the receivers' reduction (mtgs_dp_reduce) rebuilds every dense gradient, this rank's included.
+constexpr int WIRE_ROW = 16;
+__global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
+    int64_t n_vis, const int32_t *__restrict__ vis_ids, const float *__restrict__ means, const float *__restrict__ quats,
+    const float *__restrict__ scales, const float *__restrict__ viewmats, const float *__restrict__ Ks, int W, int H,
+    float eps2d, const float *__restrict__ conics, const float *__restrict__ compensations,
+    const float *__restrict__ opacities, const float *__restrict__ G, int64_t gs, int DC, int with_depth,
+    const float *__restrict__ colors_pre, int color_mode, float *__restrict__ wire, float *__restrict__ v_viewmats) {
+    __shared__ float red[(PROJ_BLOCK / 64) * 12];
+    __shared__ float s_acc[12];
+    if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
+    const Cam cam = load_cam(viewmats, Ks);
+    for (int64_t r0 = (int64_t)blockIdx.x * PROJ_BLOCK; r0 < n_vis; r0 += (int64_t)gridDim.x * PROJ_BLOCK) {
+        const int64_t r = r0 + threadIdx.x;
+        float vRt[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) vRt[k] = 0.f;
+        if (r < n_vis) {
+            const int64_t n = vis_ids[r];
+            float m[3], sc[3], am[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f}, ao = 0.f;
+            m[0] = means[n * 3]; m[1] = means[n * 3 + 1]; m[2] = means[n * 3 + 2];
+            const float4 q = reinterpret_cast<const float4 *>(quats)[n];
+            sc[0] = scales[n * 3]; sc[1] = scales[n * 3 + 1]; sc[2] = scales[n * 3 + 2];
+            const float4 *g4 = reinterpret_cast<const float4 *>(G + r * gs);
+            const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2];
+            PairIn in;
+            in.conic[0] = conics[n * 3]; in.conic[1] = conics[n * 3 + 1]; in.conic[2] = conics[n * 3 + 2];
+            in.v_mean2d = make_float2(g0.x, g0.y);
+            in.v_conic[0] = g1.x; in.v_conic[1] = g1.y; in.v_conic[2] = g1.z;
+            const float gc[4] = {g2.x, g2.y, g2.z, g2.w};
+            in.v_depth = with_depth ? (DC < 4 ? gc[DC] : G[r * gs + 8 + DC]) : 0.f;
+            in.has_comp = compensations != nullptr; in.has_vcomp = false; in.has_opac = true;
+            in.comp = in.has_comp ? compensations[n] : 1.f;
+            in.v_comp = 0.f;
+            in.opac = opacities[n];
+            in.v_opac_eff = g1.w;
+            project_vjp_pair(m, q, sc, cam, W, H, eps2d, in, am, aq, as, ao, vRt);
+            float vrgb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < DC) {
+                    float v = gc[k];
+                    if (color_mode == 1) {
+                        const float x = colors_pre[n * DC + k] + 0.5f;
+                        v = (x >= 0.f && x <= 1.f) ? v : 0.f;
+                    }
+                    vrgb[k] = v;
+                }
+            }
+            float4 *out = reinterpret_cast<float4 *>(wire + r * WIRE_ROW);
+            out[0] = make_float4(am[0], am[1], am[2], aq[0]);
+            out[1] = make_float4(aq[1], aq[2], aq[3], as[0]);
+            out[2] = make_float4(as[1], as[2], ao, vrgb[0]);
+            out[3] = make_float4(vrgb[1], vrgb[2], 0.f, __int_as_float((int)n));
+        }
+        if (v_viewmats) {
+            __syncthreads();
+            block_reduce_viewmat(vRt, s_acc, red);
+        }
+    }
+    __syncthreads();
+    if (v_viewmats && threadIdx.x < 12) {
+        const int k = threadIdx.x;
+        const float v = s_acc[k];
+        if (v != 0.f) atomicAdd(v_viewmats + (k < 9 ? (k / 3) * 4 + (k % 3) : (k - 9) * 4 + 3), v);
+    }
+}
+
 constexpr int EXP_STAGE_COL = 8;  // colour channels staged through LDS (more: per-lane stores)
 // `count` floats from LDS to consecutive global addresses, whole block, 16-byte stores when aligned
 __device__ __forceinline__ void block_store(float *__restrict__ dst, const float *lds, int count) {
@@ -474,5 +549,33 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                                     v_opac_eff, v_means, v_quats, v_scales, v_viewmats,
                                                     v_opacities, gs, grad_row_index, ex);
     MTGS_CHECK_LAUNCH("mtgs_project_bwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_project_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
+                                     const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                                     const float *conics, const float *compensations, const float *opacities,
+                                     const float *grad_rows, int64_t row_stride, int D, int with_depth,
+                                     const float *colors_pre, int color_mode, const int32_t *vis_ids, int64_t n_vis,
+                                     float *wire_rows, float *v_viewmats, void *stream) {
+    MTGS_REQUIRE(N >= 0 && n_vis >= 0 && n_vis <= N && width > 0 && height > 0, MTGS_EINVAL, "mtgs_project_bwd_rows: bad sizes");
+    MTGS_REQUIRE(D >= 0 && D <= 3 && row_stride >= 8 + D + (with_depth ? 1 : 0) && (row_stride % 4) == 0, MTGS_EINVAL,
+                 "mtgs_project_bwd_rows: D=%d (0..3 colour channels) row_stride=%lld", D, (long long)row_stride);
+    MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D == 3 && colors_pre), MTGS_EINVAL, "mtgs_project_bwd_rows: color_mode");
+    hipStream_t st = (hipStream_t)stream;
+    if (v_viewmats) {
+        hipError_t e = hipMemsetAsync(v_viewmats, 0, sizeof(float) * 16, st);
+        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_project_bwd_rows: memset failed: %s", hipGetErrorString(e));
+    }
+    if (n_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(means && quats && scales && viewmats && Ks && conics && opacities && grad_rows && vis_ids && wire_rows,
+                 MTGS_EINVAL, "mtgs_project_bwd_rows: null pointer");
+    MTGS_REQUIRE(((reinterpret_cast<uintptr_t>(grad_rows) | reinterpret_cast<uintptr_t>(wire_rows)) & 15) == 0, MTGS_EINVAL,
+                 "mtgs_project_bwd_rows: rows must be 16-byte aligned");
+    const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
+    project_bwd_rows_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
+        n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities, grad_rows,
+        row_stride, D, with_depth ? 1 : 0, colors_pre, color_mode, wire_rows, v_viewmats);
+    MTGS_CHECK_LAUNCH("mtgs_project_bwd_rows");
     return MTGS_OK;
 }

@@ -128,38 +128,186 @@ def all_reduce_grads(params: Sequence[torch.Tensor], average: bool = False, grou
 class SparseGradExchange:
     """Sparse, factored replacement for the dense gradient all-reduce of view-parallel DP.
 
-    A rank renders one camera per step, so only the Gaussians visible in it (~15 % of a road block)
-    have a non-zero gradient, and the gradient of the SH coefficients is rank-1 per Gaussian:
-    v_coeffs[n,k,:] = basis_k(normalize(mean_n - cam_pos)) * v_rgb[n,:].  Each rank therefore sends
-    64-byte rows {v_mean, v_quat, v_scale, v_opacity, v_rgb, index} of its visible Gaussians, in INDEX
-    order, plus a visibility map (one bit per Gaussian + a popcount prefix per 64) and its camera
-    position: 19 MB + 0.4 MB instead of 472 MB at 2M Gaussians / SH degree 3.  The rows are all-gathered
-    (xGMI is point-to-point: bytes are what costs) and every rank rebuilds the SUM of all ranks' dense
-    gradients in ONE streaming pass over the Gaussians (csrc/dp.hip: mtgs_dp_reduce looks every
-    Gaussian up in every sender's rows through the sender's map, sums in registers, and writes each
-    dense tensor once).  Equal to the dense all-reduce up to fp32 summation order.
+    A rank renders one camera per step, so only the Gaussians visible in it (~15 % of a road block) have a non-zero
+    gradient, and the gradient of the SH coefficients is rank-1 per Gaussian:
+    v_coeffs[n,k,:] = basis_k(normalize(mean_n - cam_pos)) * v_rgb[n,:].  Each rank therefore sends 64-byte rows
+    {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, -, index} of its visible Gaussians, in INDEX order, plus a visibility map
+    (one bit per Gaussian + the row of the first Gaussian of every 64) and its camera position: 19 MB + 0.4 MB instead of
+    472 MB at 2M Gaussians / SH degree 3.  Every rank rebuilds the SUM of all ranks' dense gradients in a streaming
+    pass over the Gaussians (csrc/dp.hip: mtgs_dp_reduce finds every Gaussian in every sender's rows through the sender's
+    map, sums in LDS, and writes each dense tensor once).  Equal to the dense all-reduce up to fp32 summation order.
 
-    Two collectives per step: a fixed-size one (row count, camera, map) whose counts the host needs
-    to size the second (the rows).  With a single process the exchange degenerates to a local
-    pack + reduce of the own rows.  SH layouts the one-pass kernel does not cover (K > 16 or
+    Integrated form (what bench.py and the training harness use; `rasterization()` + `finish()`):
+      * the rows ARE the projection backward's per-visible output (mtgs_project_bwd_rows): no dense gradient tensor, no
+        SH backward, no pack pass on the sender (the receivers' reduction writes every dense tensor, own rows included);
+      * the visibility map is written by the forward's front kernels and all-gathered on a side stream WHILE the frame
+        is composited; the row counts reach the host from that stream, so nothing on the critical path synchronises;
+      * the rows travel in `chunks` pieces of the Gaussian index range, and chunk i is reduced while chunk i + 1 is on
+        the wire.
+    CONTRACT: what is summed over ranks is the gradient that flows through the rasterizer.  Gradients that other loss terms
+    put on the parameters (scale / opacity regularisers, ...) reach `param.grad` through autograd as usual and are NOT
+    exchanged here: they are identical on every rank when computed from the replicated parameters; if they are not,
+    reduce them with `all_reduce_grads`.
+
+    Tensor form (`exchange()`; any colour pipeline, K <= 16): this rank's dense rasterizer gradients in, sums out; only
+    rows of Gaussians with radii > 0 are sent, so a gradient sitting on a Gaussian this rank's camera does not see would
+    be dropped -- `check_contract=True` asserts there is none.  SH layouts the one-pass kernel does not cover (K > 16 or
     degree > 3) take the per-sender read-modify-write path (mtgs_dp_pack / mtgs_dp_accumulate)."""
 
     ROW = 16
 
-    def __init__(self, n_gaussians: int, n_sh_bases: int, device, group=None):
+    def __init__(self, n_gaussians: int, n_sh_bases: int, device, group=None, chunks: int = 4):
         self.N, self.K, self.device, self.group = int(n_gaussians), int(n_sh_bases), device, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.rows = torch.empty((self.N, self.ROW), dtype=torch.float32, device=device)  # send buffer (worst case)
+        N = self.N
+        # chunk boundaries of the index range (multiples of 2048, so that they are visibility-word and tile aligned)
+        per = -(-max(N, 1) // max(int(chunks), 1))
+        per = -(-per // 2048) * 2048
+        self.bounds = list(range(0, N, per)) + [N] if N > 0 else [0, 0]
+        self.n_chunks = len(self.bounds) - 1
+        slack = min(per, N) + 64
+        self.rows = torch.empty((N + slack, self.ROW), dtype=torch.float32, device=device)  # send buffer (index order)
         self.count = torch.zeros(1, dtype=torch.int64, device=device)
         # meta record of a rank, int32 words: [count, cam x, cam y, cam z | words (u64) ... | prefix (u32) ...]
-        self.n_words = (self.N + 63) // 64
+        self.n_words = (N + 63) // 64
         self.meta_len = 4 + 3 * self.n_words + (self.n_words & 1)   # even: every rank's u64 words stay 8-byte aligned
         self.meta = torch.zeros(self.meta_len, dtype=torch.int32, device=device)
-        self.block_counts = torch.empty((self.N + 1023) // 1024 + 1, dtype=torch.int32, device=device)  # pack scratch
+        self.block_counts = torch.empty((N + 1023) // 1024 + 1, dtype=torch.int32, device=device)  # pack scratch
+        # what the host needs from every rank's meta: the row count and the row index at every chunk boundary
+        self._sample_idx = torch.tensor([0] + [4 + 2 * self.n_words + min(b // 64, max(self.n_words - 1, 0))
+                                               for b in self.bounds[:-1]], dtype=torch.int64, device=device)
+        is_cuda = torch.device(device).type == "cuda"
+        self._samples_host = torch.zeros((self.world, len(self.bounds)), dtype=torch.int32)
+        if is_cuda:
+            self._samples_host = self._samples_host.pin_memory()
+        self.comm_stream = torch.cuda.Stream(device) if is_cuda else None
         self.last_bytes = 0
+        self._pending = None
+        self._events = {}
+        self.grad_rows = self.vis_ids = None
 
-    # ---- one-pass path -------------------------------------------------------------------------------
+    # ---- integrated form -----------------------------------------------------------------------------------------
+    def rasterization(self, means, quats, scales, opacities, sh_out, viewmats, Ks, width, height, cam_pos, near_plane=0.01,
+                      far_plane=1e10, radius_clip=0.0, eps2d=0.3, render_mode="RGB+ED", rasterize_mode="antialiased",
+                      absgrad=True):
+        """This rank's camera of the step.  Same outputs as `mtgs_amd.rasterization(colors=clamp(sh_out + 0.5, 0, 1), ...)`
+        with MTGS's options (mtgs_scene_graph.py:641-659); `sh_out[N,3]` is the SH evaluation for THIS camera
+        (`spherical_harmonics(n, means - cam_pos, coeffs)`, detached: its backward happens on the receivers).  The
+        backward leaves the gradients as wire rows; call `finish()` after it."""
+        from .wrapper import fused_rasterization
+        assert viewmats.shape[0] == 1 and sh_out.shape == (self.N, 3) and means.shape == (self.N, 3)
+        assert render_mode in ("RGB", "RGB+D", "RGB+ED") and rasterize_mode in ("classic", "antialiased")
+        self.meta[1:4].copy_(cam_pos.reshape(3).to(torch.float32).contiguous().view(torch.int32))
+        self._pending = {"stage": "forward"}
+        render, alphas, m = fused_rasterization(
+            means, quats, scales, opacities, sh_out.detach().unsqueeze(0), viewmats, Ks, None, width, height, eps2d,
+            near_plane, far_plane, radius_clip, rasterize_mode == "antialiased", render_mode != "RGB",
+            render_mode == "RGB+ED", absgrad, dp=self)
+        return render, alphas, m
+
+    def front_pointers(self):
+        """(visibility words, row prefix per word, row count) inside this rank's meta record: written by mtgs_front_fwd."""
+        base, nw = self.meta.data_ptr(), self.n_words
+        return base + 16, base + 16 + 8 * nw, base
+
+    def after_front(self):
+        """Called right after the front kernels are enqueued: all-gather the meta records on the side stream and bring
+        the row counts / chunk starts of every rank to pinned host memory -- overlaps the binning and the compositing."""
+        ev = torch.cuda.Event()
+        ev.record()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            t0.record()
+            if self.world > 1:
+                metas = torch.empty((self.world, self.meta_len), dtype=torch.int32, device=self.device)
+                dist.all_gather_into_tensor(metas, self.meta[None], group=self.group)
+            else:
+                metas = self.meta[None]
+            self._samples_host.copy_(metas[:, self._sample_idx], non_blocking=True)
+            t1.record()
+            done = torch.cuda.Event()
+            done.record()
+        self._pending = {"stage": "meta", "metas": metas, "done": done}
+        self._events["meta"] = (t0, t1)
+
+    def after_backward(self, n_vis, grad_rows, vis_ids):
+        assert self._pending is not None and self._pending["stage"] == "meta", "rasterization() of this exchange first"
+        self._pending.update(stage="rows", n_vis=int(n_vis))
+        self.grad_rows, self.vis_ids = grad_rows, vis_ids   # compact |means2d| gradients etc. for the densification statistics
+
+    def finish(self, means: torch.Tensor, sh_degree: int):
+        """After backward(): exchange the wire rows and return (v_means, v_quats, v_scales, v_opacities, v_coeffs) --
+        the dense sums over all ranks of the gradients that flowed through `rasterization()`."""
+        from ._lib import call, ptr, stream_of
+        P = self._pending
+        assert P is not None and P["stage"] == "rows", "finish() follows rasterization() + backward()"
+        self._pending = None
+        N, K, dev, world, nw = self.N, self.K, self.device, self.world, self.n_words
+        means = means.detach().contiguous()
+        st = stream_of(means)
+        P["done"].synchronize()          # side stream only: finished while the frame was composited
+        samples = self._samples_host.numpy()
+        metas = P["metas"]
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        cams = metas[:, 1:4].contiguous().view(torch.float32)
+        words_all, prefix_all = metas[:, 4:], metas[:, 4 + 2 * nw:]
+        out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
+               torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+               torch.empty((N, K, 3), dtype=torch.float32, device=dev))
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        w0, w1, red = ev(), ev(), []
+        # every chunk's all-gather is issued up front (they queue on the collective stream); chunk c is reduced as soon as
+        # it has arrived, while the later chunks are still on the wire
+        starts = [[int(samples[r][1 + c]) for c in range(self.n_chunks)] + [int(samples[r][0])] for r in range(world)]
+        works, recvs, caps = [], [], []
+        w0.record()
+        self.last_bytes = 0
+        for c in range(self.n_chunks):
+            cap = max(max(starts[r][c + 1] - starts[r][c] for r in range(world)), 1)
+            if world > 1:
+                recv = torch.empty((world, cap, self.ROW), dtype=torch.float32, device=dev)
+                s0 = starts[self.rank][c]
+                works.append(dist.all_gather_into_tensor(recv.view(world * cap, self.ROW), self.rows[s0:s0 + cap],
+                                                         group=self.group, async_op=True))
+                self.last_bytes += world * cap * self.ROW * 4
+            else:
+                recv, s0 = self.rows[starts[0][c]:], 0
+                works.append(None)
+            recvs.append(recv)
+            caps.append(cap)
+        self.last_bytes += world * self.meta_len * 4 if world > 1 else 0
+        for c in range(self.n_chunks):
+            if works[c] is not None:
+                works[c].wait()
+            if c == self.n_chunks - 1:
+                w1.record()
+            e0, e1 = ev(), ev()
+            e0.record()
+            call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4,
+                 ptr(recvs[c]), caps[c] * self.ROW if world > 1 else 0, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                 ptr(out[3]), ptr(out[4]), self.bounds[c], self.bounds[c + 1], st)
+            e1.record()
+            red.append((e0, e1))
+        self._events.update(wire=(w0, w1), reduce=red)
+        return out
+
+    def phases_ms(self) -> dict:
+        """Durations of the last step's exchange phases (synchronises): meta = all-gather of the visibility maps (side
+        stream, overlapped with the compositing), wire = first row all-gather issued -> last one complete (includes the
+        reductions of the earlier chunks it overlaps with), reduce = the reduction kernels."""
+        torch.cuda.synchronize()
+        out = {}
+        if "meta" in self._events:
+            out["meta"] = self._events["meta"][0].elapsed_time(self._events["meta"][1])
+        if "wire" in self._events:
+            out["wire"] = self._events["wire"][0].elapsed_time(self._events["wire"][1])
+            out["reduce"] = sum(a.elapsed_time(b) for a, b in self._events["reduce"])
+        return out
+
+    # ---- tensor form ---------------------------------------------------------------------------------------------
     def _exchange_ordered(self, radii, means, cam_pos, v_means, v_quats, v_scales, v_opacities, v_rgb, sh_degree):
         from ._lib import call, ptr, stream_of
         N, K, dev, world = self.N, self.K, self.device, self.world
@@ -186,15 +334,17 @@ class SparseGradExchange:
         # the dense inputs were copied into the rows: they are overwritten with the sums
         call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all),
              self.meta_len * 4, ptr(recv), cap * self.ROW, ptr(cams), ptr(v_means), ptr(v_quats), ptr(v_scales),
-             ptr(v_opacities), ptr(v_coeffs), st)
+             ptr(v_opacities), ptr(v_coeffs), 0, -1, st)
         return v_means, v_quats, v_scales, v_opacities, v_coeffs
 
     def exchange(self, radii: torch.Tensor, means: torch.Tensor, cam_pos: torch.Tensor, v_means: torch.Tensor,
                  v_quats: torch.Tensor, v_scales: torch.Tensor, v_opacities: torch.Tensor,
-                 v_rgb: Optional[torch.Tensor], sh_degree: int, local_coeff_grad=None):
-        """radii[N] (this rank's camera), means[N,3], cam_pos[3]; this rank's dense gradients v_* (they are
+                 v_rgb: Optional[torch.Tensor], sh_degree: int, local_coeff_grad=None, check_contract: bool = False):
+        """radii[N] (this rank's camera), means[N,3], cam_pos[3]; this rank's dense RASTERIZER gradients v_* (they are
         OVERWRITTEN with the sums over all ranks); v_rgb[N,3] is the gradient with respect to the SH
         OUTPUT (before the +0.5 / clamp), or None for no SH part.
+        Only the rows of Gaussians with radii > 0 are sent (see the class docstring): gradients of other loss terms must
+        be added AFTER the exchange.  `check_contract=True` (debugging) asserts that the inputs are zero elsewhere.
         `local_coeff_grad` is only used by the per-sender fallback path (K > 16 or degree > 3): a callable
         returning this rank's own dense v_coeffs[N,K,3], invoked while the payload is in flight.
         Returns (v_means, v_quats, v_scales, v_opacities, v_coeffs | None): dense sums over all ranks."""
@@ -204,6 +354,13 @@ class SparseGradExchange:
         assert radii.numel() == N and means.shape == (N, 3)
         for t in (v_means, v_quats, v_scales, v_opacities):
             assert t.is_contiguous(), "the local dense gradients are overwritten in place"
+        if check_contract:
+            hidden = radii <= 0
+            for name, t in (("v_means", v_means), ("v_quats", v_quats), ("v_scales", v_scales), ("v_opacities", v_opacities),
+                            ("v_rgb", v_rgb)):
+                if t is not None and bool((t[hidden] != 0).any()):
+                    raise ValueError(f"SparseGradExchange.exchange: {name} is non-zero on Gaussians this rank's camera does not "
+                                     "see; only rasterizer gradients may be passed (add regulariser gradients after the exchange)")
         v_rgb = None if v_rgb is None else v_rgb.contiguous()
         means = means.contiguous()
         cam_pos = cam_pos.reshape(3).to(torch.float32).contiguous()

@@ -465,7 +465,10 @@ class _FusedRasterization(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
-                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad):
+                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad, dp=None):
+        """dp (mtgs_amd.dist.SparseGradExchange | None): data-parallel mode -- `colors` is the SH output x[1,N,3], blended
+        as clamp(x + 0.5, 0, 1); the front kernel writes the visibility map of the exchange, and the backward leaves
+        the gradients as wire rows in the exchange's send buffer instead of dense tensors (see dist.py)."""
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
         means, quats, scales, opacities, col, viewmats, Ks, bg = map(
             _f32c, (means, quats, scales, opacities, colors, viewmats, Ks, backgrounds))
@@ -488,6 +491,8 @@ class _FusedRasterization(torch.autograd.Function):
         alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
         packed = total > 0 and 1 <= DT <= RECORD_CHANNELS and _bin2_ok(Cn, tw, th, 0)
+        if dp is not None and not (packed and Cn == 1 and DC == 3 and bg is None):
+            raise NotImplementedError("data-parallel rasterization: one camera, 3 colour channels (SH output), no backgrounds")
         if not packed:
             # ---- gather-based kernels (csrc/project.hip, bin.hip, blend.hip with dense attribute arrays)
             call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
@@ -520,8 +525,11 @@ class _FusedRasterization(torch.autograd.Function):
                      eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
-                     ptr(vis_rank), cap_vis, None, None, ptr(totals), mailbox.data_ptr(), tag, ptr(front_ws), front_bytes, st)
+                     ptr(vis_rank), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
+                     1 if dp is not None else 0, ptr(totals), mailbox.data_ptr(), tag, ptr(front_ws), front_bytes, st)
                 b["mailbox"], b["tag"] = mailbox, tag
+                if dp is not None:
+                    dp.after_front()       # the visibility maps travel while this frame is composited
                 return b
 
             def rest(b, cap_M):
@@ -573,6 +581,7 @@ class _FusedRasterization(torch.autograd.Function):
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
         ctx.absgrad = bool(absgrad)
         ctx.packed = packed
+        ctx.dp = dp
         ctx.set_materialize_grads(False)
         # classic mode: an empty placeholder keeps the output arity fixed
         comps_out = comps if comps is not None else torch.empty(0, device=dev)
@@ -615,6 +624,17 @@ class _FusedRasterization(torch.autograd.Function):
                      ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(r_xy),
                      ptr(r_abs) if ctx.absgrad else None, ptr(r_con), ptr(r_col), ptr(r_dep), ptr(r_opa),
                      host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
+        if ctx.dp is not None:
+            # data-parallel mode: the per-visible VJP writes this rank's wire rows (index order) into the exchange's send
+            # buffer; dense gradients are rebuilt for all ranks at once by SparseGradExchange.finish()
+            if any(g is not None for g in (g_means2d, g_depths, g_conics, g_comps, g_opac)):
+                raise NotImplementedError("data-parallel rasterization: gradients on info[...] tensors")
+            v_viewmats = torch.empty_like(viewmats) if ctx.needs_input_grad[5] else None
+            call("mtgs_project_bwd_rows", N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height, eps2d,
+                 ptr(conics), ptr(comps), ptr(opacities), ptr(G), RS, DC, int(with_depth), ptr(col), 1, ptr(vis_ids), n_vis,
+                 ptr(ctx.dp.rows), ptr(v_viewmats), st)
+            ctx.dp.after_backward(n_vis, G, vis_ids)
+            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 11
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
@@ -659,11 +679,12 @@ class _FusedRasterization(torch.autograd.Function):
         if bg is not None and need[7] and v_render is not None:
             v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
-                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 10
+                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 11
 
 
 def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
-                        near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad):
+                        near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad,
+                        dp=None):
     """One-node projection + binning + compositing (see _FusedRasterization).  colors[C,N,D] | None.
     Returns (render, alphas, dict of gsplat's meta tensors)."""
     import weakref
@@ -673,7 +694,7 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
             raise ValueError(f"fused_rasterization: {total} blended channels (supported: {SUPPORTED_CHANNELS})")
     out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
                                     int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-                                    bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad))
+                                    bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp)
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
      offsets) = out
     if render.grad_fn is not None:  # the backward sets .grad / .absgrad on this very tensor (weak: no cycle)

@@ -60,6 +60,47 @@ for world in (2, 4, 8):
     out = [torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev),
            torch.empty(N, device=dev), torch.empty(N, K, 3, device=dev)]
     red = lambda: call("mtgs_dp_reduce", world, N, K, 3, ptr(means), ptr(metas[:, 4:]), ptr(metas[:, 4 + 2 * nw:]), L * 4,
-                       ptr(recv), cap * 16, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), st)
+                       ptr(recv), cap * 16, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, st)
     covered = sum(counts)
     print("world %d: one-pass reduce over %d rows (%d MB received): %.1f us" % (world, covered, world * cap * 64 >> 20, t(red)))
+
+
+# ---- the render leg of a data-parallel step (integrated form, one process): forward + backward down to the wire rows,
+# then finish() with this rank as the only sender (the reduction over W senders is timed above)
+def render_leg():
+    from mtgs_amd import rasterization, spherical_harmonics
+    scs = make_scene(N, seed=0, sh_degree=3)
+    P = {k: v.to(dev).requires_grad_(True) for k, v in scs.items()}
+    vm, Kmat = make_camera(W, H)
+    vm, Kmat = vm.to(dev).requires_grad_(True), Kmat.to(dev)
+    cam = torch.inverse(vm.detach())[0, :3, 3]
+    gg = torch.Generator().manual_seed(1)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=gg).to(dev), torch.randn(1, H, W, 1, generator=gg).to(dev)
+    ex = mdist.SparseGradExchange(N, K, dev, chunks=4)
+
+    def dp_step(finish=True):
+        sh = spherical_harmonics(3, P["means"].detach() - cam, P["coeffs"].detach())
+        r, a, _ = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm, Kmat, W, H, cam)
+        torch.autograd.backward([r, a], [Gc, Ga])
+        out = ex.finish(P["means"], 3) if finish else None
+        if not finish:
+            ex._pending = None
+        return out
+
+    def plain_step():
+        for p in P.values():
+            p.grad = None
+        sh = spherical_harmonics(3, P["means"].detach() - cam, P["coeffs"])
+        rgb = torch.clamp(sh + 0.5, 0.0, 1.0)
+        r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, Kmat, W, H, packed=False,
+                                   render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+        info["means2d"].retain_grad()
+        torch.autograd.backward([r, a], [Gc, Ga])
+
+    print("single-GPU step, dense gradients (bench.py N = 1):              %.1f us" % t(plain_step, 20))
+    print("data-parallel render leg (forward + backward to wire rows):     %.1f us" % t(lambda: dp_step(False), 20))
+    print("data-parallel step, 1 sender (render leg + reduce of own rows): %.1f us" % t(dp_step, 20))
+    print("   phases of the last step (ms):", {k: round(v, 3) for k, v in ex.phases_ms().items()})
+
+
+render_leg()

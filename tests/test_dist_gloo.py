@@ -74,8 +74,18 @@ def _worker(rank, world, port, out_dir):
     assert sent == sum(p.grad.numel() * 4 for p in params2)
     for p, q in zip(params, params2):
         assert torch.equal(p.grad, q.grad)
+    local_sum, local_max = torch.from_numpy(s_sum.copy()), torch.from_numpy(s_max.copy())
     t_sum, t_max = torch.from_numpy(s_sum), torch.from_numpy(s_max)
     mdist.all_reduce_stats([t_sum], [t_max])
+    # an accumulator that starts at ONE (the reference's vis_counts, vanilla_gaussian_splatting.py:462): the initial value
+    # is counted once, not once per rank; and the reducer's global view can be read twice without double counting
+    t_one = local_sum + 1.0
+    red = mdist.StatsReducer([t_one], [local_max], sum_init=[1.0])
+    g1, _ = red.reduce()
+    g2, m2 = red.reduce()
+    assert torch.equal(g1[0], g2[0]), "second read differs"
+    assert torch.allclose(g1[0].double(), t_sum.double() + 1.0), (g1[0][:8], t_sum[:8])
+    assert torch.allclose(m2[0].double(), t_max.double())
     np.savez(Path(out_dir) / f"rank{rank}.npz", vis=t_sum.numpy(), maxr=t_max.numpy(),
              **{n: p.grad.numpy() for p, n in zip(params, names)})
     dist.barrier()

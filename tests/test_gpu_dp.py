@@ -68,12 +68,33 @@ def _worker(rank, world, port, out_dir):
         scale = float(dense[k].abs().max())
         res[k] = (float((dense[k] - sparse[k]).abs().max()), scale)
     n_vis = int((info["radii"] > 0).sum())
-    np.save(Path(out_dir) / f"r{rank}.npy", np.array([[e, s] for e, s in res.values()] + [[n_vis, ex.last_bytes]]))
+    tensor_form_bytes = ex.last_bytes
+    # integrated form: the exchange renders (colour activation fused, visibility map from the front kernels, all-gathered
+    # during the frame), the backward leaves wire rows, finish() exchanges them in chunks -- same sums, same image
+    P2 = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    vm2 = vm.to(dev).requires_grad_(True)
+    sh3 = spherical_harmonics(3, P2["means"].detach() - cam_pos, P2["coeffs"].detach())
+    for chunks in (1, 3):
+        ex2 = mdist.SparseGradExchange(N, K, dev, chunks=chunks)
+        r2, a2, info2 = ex2.rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], sh3, vm2, Kmat.to(dev), W, H,
+                                          cam_pos)
+        assert torch.equal(r2, render) and torch.equal(a2, alpha) and torch.equal(info2["flatten_ids"], info["flatten_ids"])
+        torch.autograd.backward([r2, a2], [Gc, Ga])
+        assert all(P2[k].grad is None for k in ("means", "quats", "scales", "opacities")) and vm2.grad is not None
+        o3 = ex2.finish(P2["means"], 3)
+        for k, t in zip(("means", "quats", "scales", "opacities", "coeffs"), o3):
+            scale = float(dense[k].abs().max())
+            err = float((dense[k] - t).abs().max())
+            assert err <= 1e-5 * scale + 1e-7, f"integrated form, chunks={chunks}, {k}: {err} vs {scale}"
+        ph = ex2.phases_ms()
+        assert set(ph) == {"meta", "wire", "reduce"} and all(v >= 0 for v in ph.values())
+        vm2.grad = None
+    np.save(Path(out_dir) / f"r{rank}.npy", np.array([[e, s] for e, s in res.values()] + [[n_vis, tensor_form_bytes]]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sparse_exchange_equals_dense_allreduce(tmp_path, hip_lib, world):
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
@@ -130,3 +151,8 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert "cpu_baseline" not in out and out["roofline"]["launches_timed"] == 3
     assert exchange in out["config"]["parallelism"]
+    # the N > 1 line carries the phase breakdown that makes a scaling run diagnostic
+    ph = out["dp_phases_ms"]
+    assert out["dp_world_size"] == 2 and out["dp_backend"] == "gloo"
+    want = {"render", "exchange"} | ({"meta", "wire", "reduce"} if exchange == "sparse" else set())
+    assert want <= set(ph) and all(ph[k] >= 0 for k in want), ph
