@@ -34,3 +34,18 @@ def hip_lib():
         if stale:
             raise RuntimeError(f"libmtgs_rast.so is older than {[p.name for p in stale]} and hipcc is missing")
     return _lib.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity report: the measured errors of every image / gradient comparison of this session (tests/util.py REPORT)."""
+    try:
+        from tests import util
+    except Exception:
+        return
+    if not util.REPORT:
+        return
+    import json
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    with open(out / "parity_report.json", "w") as f:
+        json.dump(util.REPORT, f, indent=0)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from mtgs_amd.synthetic import make_camera, make_scene
-from tests.util import assert_image_close
+from tests.util import assert_grad_close, assert_image_close
 
 pytestmark = pytest.mark.gpu
 
@@ -39,8 +39,8 @@ def test_config1_100k_640x480_forward(gs, oracle):
         assert np.array_equal(info[key].cpu().numpy(), m[key]), key
     for key in ("means2d", "depths", "conics"):
         assert np.array_equal(info[key].cpu().numpy(), m[key]), key
-    assert_image_close(render.cpu().numpy(), r_ref, m["critical"], name="render")
-    assert_image_close(alpha.cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0)
+    assert_image_close(render.cpu().numpy(), r_ref, m["critical"], name="render", case="C1 100k 640x480")
+    assert_image_close(alpha.cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0, case="C1 100k 640x480")
 
 
 @pytest.mark.parametrize("N,sh", [(500_000, True), (2_000_000, False)])
@@ -80,8 +80,9 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
     off = info["isect_offsets"].flatten()
     assert bool((off[1:] >= off[:-1]).all()) and int(off[-1]) <= ids.numel()
     assert float(alpha.detach().min()) >= 0.0 and float(alpha.detach().max()) < 1.0
-    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render")
-    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0)
+    case = f"C{2 if sh else 3} {N // 1000}k 1920x1080 mtgs options"
+    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render", case=case)
+    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0, case=case)
     # ---- backward against the oracle
     torch.autograd.backward([render, alpha], [dev(Gc), dev(Ga)])
     Gc_n, Ga_n = Gc.numpy(), Ga.numpy()
@@ -95,10 +96,8 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
                                                  m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
                                                  vcon, vop * a["opacities"][None])
 
-    def close(name, got, ref, rel=2e-3):
-        got = got.detach().cpu().numpy()
-        err, scale = np.abs(got - ref).max(), np.abs(ref).max()
-        assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+    def close(name, got, ref, **kw):
+        assert_grad_close(name, got, ref, case=case, **kw)
 
     close("means2d.grad", info["means2d"].grad, v2d)
     close("means2d.absgrad", info["means2d"].absgrad, vabs)
@@ -106,7 +105,9 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
     close("v_means", P["means"].grad, r_vm)
     close("v_quats", P["quats"].grad, r_vq)
     close("v_scales", P["scales"].grad, r_vs)
-    close("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0))
+    # (the opacity gradient is the sum with the most cancellation under random cotangents: measured 99.9th percentile
+    #  4e-4 at 500k, 1.4e-3 at 2M Gaussians, against <= 6e-4 for every other tensor)
+    close("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0), row_rel_p999=2.5e-3)
     close("v_viewmats", vmd.grad[0], r_vvm[0])
     if sh:
         mask = (rgb_ref > 0.0) & (rgb_ref < 1.0)
@@ -134,8 +135,8 @@ def test_midsize_images_use_more_waves_per_tile(gs, oracle, W, H):
                                            rasterize_mode="antialiased", absgrad=True)
     info["means2d"].retain_grad()
     assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
-    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render")
-    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0)
+    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render", case=f"200k {W}x{H}")
+    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0, case=f"200k {W}x{H}")
     torch.autograd.backward([render, alpha], [dev(Gc), dev(Ga)])
     alc = np.maximum(a_ref, 1e-10)
     Gc_raw = Gc.numpy().copy()
@@ -145,8 +146,7 @@ def test_midsize_images_use_more_waves_per_tile(gs, oracle, W, H):
                                                   m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw, Ga_tot)
     for name, got, ref in (("means2d.grad", info["means2d"].grad, v2d), ("absgrad", info["means2d"].absgrad, vabs),
                            ("v_colors", P["colors"].grad, vcol[0, :, :3])):
-        err, scale = np.abs(got.detach().cpu().numpy() - ref).max(), np.abs(ref).max()
-        assert err <= 2e-3 * scale, f"{name}: {err:.3e} vs {scale:.3e}"
+        assert_grad_close(name, got, ref, case=f"200k {W}x{H}")
 
 
 def test_fullsize_properties_linearity_and_determinism(gs):
@@ -177,3 +177,45 @@ def test_fullsize_properties_linearity_and_determinism(gs):
         assert float((g12[k] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), k
     culled = info1["radii"][0] == 0
     assert float(g1["means"][culled].abs().max()) == 0.0 and float(g1["colors"][culled].abs().max()) == 0.0
+
+
+def test_shipped_option_cell_7_channels_960x540(gs, oracle):
+    """The cell the shipped config/MTGS.py drives: RGB + camera-space normals = 6 colour channels
+    + expected depth = 7 blended channels, antialiased, absgrad, viewmat gradient, at MTGS's training size 960x540
+    (camera_res_scale_factor 0.5), 500k Gaussians -- forward and backward against the oracle."""
+    N, W, H, D = 500_000, 960, 540, 6
+    sc = make_scene(N, seed=5)
+    g = torch.Generator().manual_seed(9)
+    sc["colors"] = torch.cat([sc["colors"], torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)], -1)
+    vm, K = make_camera(W, H, yaw_deg=15.0)
+    a = {k: v.numpy() for k, v in sc.items()}
+    Gc, Ga = torch.randn(1, H, W, D + 1, generator=g), torch.randn(1, H, W, 1, generator=g)
+    r_ref, a_ref, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], vm.numpy(),
+                                           K.numpy(), W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+    P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
+    vmd = dev(vm).requires_grad_(True)
+    render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vmd, dev(K), W, H,
+                                           packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+    info["means2d"].retain_grad()
+    case = "shipped cell 7ch 500k 960x540"
+    for key in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(info[key].cpu().numpy(), m[key]), key
+    assert render.shape == (1, H, W, 7)
+    assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render", case=case)
+    assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", scale=1.0, case=case)
+    torch.autograd.backward([render, alpha], [dev(Gc), dev(Ga)])
+    alc = np.maximum(a_ref, 1e-10)
+    Gc_raw = Gc.numpy().copy()
+    Gc_raw[..., -1:] = Gc.numpy()[..., -1:] / alc
+    Ga_tot = Ga.numpy() - (m["render_raw"][..., -1:] / alc ** 2) * Gc.numpy()[..., -1:] * (a_ref > 1e-10)
+    v2d, vabs, vcon, vcol, vop = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                  m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw, Ga_tot)
+    r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3,
+                                                 m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
+                                                 vcon, vop * a["opacities"][None])
+    for name, got, ref in (("means2d.grad", info["means2d"].grad, v2d), ("means2d.absgrad", info["means2d"].absgrad, vabs),
+                           ("v_means", P["means"].grad, r_vm), ("v_quats", P["quats"].grad, r_vq),
+                           ("v_scales", P["scales"].grad, r_vs),
+                           ("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0)),
+                           ("v_viewmats", vmd.grad[0], r_vvm[0]), ("v_colors", P["colors"].grad, vcol[0, :, :D])):
+        assert_grad_close(name, got, ref, case=case)

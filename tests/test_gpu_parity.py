@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_image_close, small_scene, to_np
+from tests.util import assert_grad_close, assert_image_close, small_scene, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -179,8 +179,9 @@ def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad
     assert np.array_equal(info["isect_ids"].cpu().numpy(), m["isect_ids"])
     assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
     assert np.array_equal(info["isect_offsets"].cpu().numpy(), m["isect_offsets"])
-    assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render")
-    assert_image_close(alpha.detach().cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", scale=1.0)
+    case = f"small {render_mode}/{rmode} D={D} {W}x{H}"
+    assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render", case=case)
+    assert_image_close(alpha.detach().cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", scale=1.0, case=case)
     # ---- backward
     (render * dev(Gc)).sum().add((alpha * dev(Ga)).sum()).backward()
     Gc_raw, Ga_tot = Gc.numpy().copy(), Ga.numpy().copy()
@@ -199,11 +200,9 @@ def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad
                                                  m["radii"], m["conics"], m["compensations"], v2d, v_depth, vcon, v_comp)
     r_vo = (vop * (m["compensations"] if aa else 1.0)).sum(0)
 
-    def close(name, got, ref, rel=2e-3):
-        got = got.detach().cpu().numpy()
-        scale = np.abs(ref).max() + 1e-12
-        err = np.abs(got - ref).max()
-        assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+    def close(name, got, ref):
+        # (a 400-Gaussian scene: ONE pixel whose alpha >= 1/255 decision flips moves a gradient row by ~1e-3 of the maximum)
+        assert_grad_close(name, got, ref, case=f"small {render_mode}/{rmode} D={D} {W}x{H}", rel_to_max=2e-3)
 
     close("means2d.grad", info["means2d"].grad, v2d)
     if absgrad:
@@ -318,3 +317,42 @@ def test_hip_reproduces_golden_fixture(gs, name):
         assert err <= 2e-3 * np.abs(ref).max(), (key, err)
     ref = z["v_viewmat"]
     assert np.abs(vm.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", ["gsplat_1_4_0_classic", "gsplat_1_4_0_mtgs"])
+def test_hip_reproduces_gsplat_fixture(gs, name):
+    """Outputs of the REAL gsplat 1.4.0 (tests/golden/make_gsplat_golden.py, run on a machine that has it).  Skipped until
+    the two files are committed -- until then the hot path's parity is pinned by the oracle only ("parity unpinned").
+    gsplat leaves culled rows of means2d / depths / conics unspecified and contracts FMAs, so the projection outputs are
+    compared on visible rows with a relative tolerance; the integer stages, the image and the gradients as for the
+    oracle-made fixtures."""
+    path = GOLD / f"{name}.npz"
+    if not path.exists():
+        pytest.skip(f"{path.name} not generated yet (needs gsplat==1.4.0 + CUDA: tests/golden/make_gsplat_golden.py)")
+    z = np.load(path)
+    W, H = int(z["W"]), int(z["H"])
+    P = {k: dev(z[k]).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    vm = dev(z["viewmat"]).requires_grad_(True)
+    bg = dev(z["backgrounds"]) if z["backgrounds"].size else None
+    render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm,
+                                           dev(z["K"]), W, H, packed=False, render_mode=str(z["render_mode"]),
+                                           rasterize_mode=str(z["rasterize_mode"]), backgrounds=bg, absgrad=True)
+    info["means2d"].retain_grad()
+    vis = z["radii"] > 0
+    assert np.array_equal(info["radii"].cpu().numpy() > 0, vis), "visibility differs from gsplat"
+    assert np.array_equal(info["radii"].cpu().numpy(), z["radii"]), "radii differ from gsplat"
+    for key in ("means2d", "depths", "conics", "opacities"):
+        ref = z["opacities_eff" if key == "opacities" else key]
+        np.testing.assert_allclose(info[key].detach().cpu().numpy()[vis], ref[vis], rtol=2e-5, atol=1e-6, err_msg=key)
+    for key in ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(info[key].cpu().numpy(), z[key]), key
+    assert np.abs(render.detach().cpu().numpy() - z["render"]).max() <= RENDER_TOL * max(1.0, np.abs(z["render"]).max())
+    assert np.abs(alpha.detach().cpu().numpy() - z["alpha"]).max() <= RENDER_TOL
+    torch.autograd.backward([render, alpha], [dev(z["Gc"]), dev(z["Ga"])])
+    case = f"gsplat fixture {name}"
+    for key, gname in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
+                       ("colors", "v_colors")]:
+        assert_grad_close(gname, P[key].grad, z[gname], case=case)
+    assert_grad_close("v_viewmat", vm.grad, z["v_viewmat"], case=case)
+    assert_grad_close("means2d.grad", info["means2d"].grad, z["v_means2d"], case=case)
+    assert_grad_close("means2d.absgrad", info["means2d"].absgrad, z["v_means2d_abs"], case=case)

@@ -170,3 +170,31 @@ def test_oracle_reproduces_golden_fixture(oracle, name):
                        ("colors", "v_colors"), ("viewmat", "v_viewmat")]:
         ref = z[gname]
         assert np.abs(grads[key] - ref).max() <= 3e-5 * np.abs(ref).max() + 1e-6, key
+
+
+@pytest.mark.parametrize("name", ["gsplat_1_4_0_classic", "gsplat_1_4_0_mtgs"])
+def test_oracle_reproduces_gsplat_fixture(oracle, name):
+    """THE PIN: outputs of the real gsplat 1.4.0 (tests/golden/make_gsplat_golden.py).  Skipped until the files exist --
+    gsplat cannot be installed or run in the build container, so the oracle stays "parity unpinned" until someone runs that
+    script on a CUDA machine and commits its two files."""
+    path = GOLD / f"{name}.npz"
+    if not path.exists():
+        pytest.skip(f"{path.name} not generated yet (needs gsplat==1.4.0 + CUDA: tests/golden/make_gsplat_golden.py)")
+    z = np.load(path)
+    W, H = int(z["W"]), int(z["H"])
+    a = {k: z[k] for k in ("means", "quats", "scales", "opacities", "colors")}
+    bg = z["backgrounds"] if z["backgrounds"].size else None
+    r, al, m, grads = oracle_backward(oracle, a, z["viewmat"], z["K"], W, H, str(z["render_mode"]), str(z["rasterize_mode"]),
+                                      bg, z["Gc"], z["Ga"])
+    vis = z["radii"] > 0
+    assert np.array_equal(m["radii"], z["radii"]), "radii differ from gsplat"
+    for key in ("means2d", "depths", "conics"):
+        np.testing.assert_allclose(m[key][vis], z[key][vis], rtol=2e-5, atol=1e-6, err_msg=key)   # gsplat contracts FMAs
+    for key in ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(m[key], z[key]), key
+    np.testing.assert_allclose(r, z["render"], atol=1e-4 * max(1.0, np.abs(z["render"]).max()))
+    np.testing.assert_allclose(al, z["alpha"], atol=1e-4)
+    for key, gname in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
+                       ("colors", "v_colors"), ("viewmat", "v_viewmat")]:
+        ref = z[gname]
+        assert np.abs(grads[key] - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6, key
