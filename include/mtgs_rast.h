@@ -93,7 +93,9 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * leave the rasterizer per Gaussian (retain_grad / absgrad / colours), expanded while their rows are read.
  * vis_ids[n_vis] i32 + vis_ws[n_vis*12] f32 scratch (both nullable): the visible Gaussians in increasing order
  * with grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank).  With them (and C == 1) the
- * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced. */
+ * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced.
+ * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals; the number of rows is then min(n_vis, *n_vis_dev >> 32)
+ * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count). */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
@@ -109,7 +111,7 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
                      const float *x_means2d_abs, const float *x_colors, int x_channels,
                      const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
-                     const int32_t *vis_ids, int64_t n_vis, float *vis_ws, void *stream);
+                     const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.

@@ -381,8 +381,7 @@ extern "C" int mtgs_bin2_build(int C, int64_t N, int tile_size, int tile_w, int 
     Bin2Workspace w = carve2((char *)ws, cap_vis, cap_M, n_bins, dbits, tbits);
     MTGS_REQUIRE(ws_bytes >= w.total, MTGS_EWORKSPACE, "mtgs_bin2_build: workspace %zu < %zu bytes", ws_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(w.control, 0, w.control_bytes, st);
-    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_bin2_build: memset failed: %s", hipGetErrorString(e));
+    if (int rc = mtgs_zero_async(w.control, w.control_bytes, st)) return rc;
     const mtgs_os::SizeRef n_vis_ref{totals, 1, cap_vis}, m_ref{w.m_eff, 0, cap_M};
     // 1. depth sort of (key, rank): the values of the first pass are the positions themselves
     {

@@ -31,6 +31,13 @@ void mtgs_set_error(const char *fmt, ...);
 
 static inline __host__ __device__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zero-fill of control words that KERNELS then update with atomics / flags, as a kernel of this library (zero.hip) --
+// not hipMemsetAsync: inside a captured HIP graph a memset node may run on a copy engine, whose writes bypass the
+// XCDs' L2s, and graph nodes are not separated by the cache maintenance that separates eager launches; stale L2 lines
+// of the "zeroed" words then survive into the kernels (observed: look-back flags of the previous replay -> wild
+// scatter addresses -> memory fault on replay).  `bytes` and `p` must be multiples of 4.
+int mtgs_zero_async(void *p, size_t bytes, hipStream_t stream);
+
 #ifdef __HIPCC__
 // ---- wave64 cross-lane helpers (DPP; CDNA has row_bcast) ---------------------------------------
 // v_add_f32 with a DPP-permuted operand is ONE VALU instruction; a full 64-lane sum is 6 of them

@@ -272,8 +272,7 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
                  front_ws_bytes(total));
     MTGS_REQUIRE((reinterpret_cast<uintptr_t>(recs) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, MTGS_EINVAL,
                  "mtgs_front_fwd: recs must be 16-byte aligned, ws 256-byte aligned");
-    hipError_t e = hipMemsetAsync(ws, 0, front_group_bytes(total), st);
-    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_front_fwd: memset failed: %s", hipGetErrorString(e));
+    if (int rc = mtgs_zero_async(ws, front_group_bytes(total), st)) return rc;
     unsigned long long *group_counts = (unsigned long long *)ws;
     uint64_t *chunk_counts = (uint64_t *)((char *)ws + front_group_bytes(total));
     front_project_kernel<<<(unsigned)ceil_div64(total, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(

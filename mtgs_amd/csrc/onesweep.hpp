@@ -151,6 +151,7 @@ __global__ __launch_bounds__(THREADS) void hist_all_kernel(const SizeRef size, c
 // store(dst, key, value, gathered) writes them INSTEAD of the key / value stores.
 struct NoEpilogue {
     static constexpr bool enabled = false;
+    int unused = 0;   // (never an EMPTY struct as a by-value kernel argument)
     struct G {};
     __device__ __forceinline__ G gather(int32_t) const { return G{}; }
     __device__ __forceinline__ void store(uint32_t, uint64_t, int32_t, const G &) const {}

@@ -100,7 +100,7 @@ extern "C" int mtgs_oob_fwd(int n_nodes, const mtgs_oob_desc *table, int64_t tot
                  "mtgs_oob_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (n_nodes > 0) {
-        hipError_t e = hipMemsetAsync(flags, 0, (size_t)n_nodes * sizeof(int32_t), st);
+        hipError_t e = mtgs_zero_async(flags, (size_t)n_nodes * sizeof(int32_t), st) == MTGS_OK ? hipSuccess : hipErrorLaunchFailure;
         MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_oob_fwd: memset failed: %s", hipGetErrorString(e));
     }
     if (total_blocks > 0) {

@@ -304,10 +304,14 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     const float *__restrict__ compensations, const float *__restrict__ opacities,
     const float *__restrict__ v_means2d, const float *__restrict__ v_depths, const float *__restrict__ v_conics,
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff, const ProjGradStrides gs,
-    float *__restrict__ ws, float *__restrict__ v_viewmats) {
+    float *__restrict__ ws, float *__restrict__ v_viewmats, const int64_t *__restrict__ n_vis_dev) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
+    if (n_vis_dev) {   // the count lives on the device (front.hip's packed totals); n_vis is the capacity of the row buffers
+        const int64_t d = *n_vis_dev >> 32;
+        if (d < n_vis) n_vis = d;
+    }
     const Cam cam = load_cam(viewmats, Ks);
     for (int64_t r0 = (int64_t)blockIdx.x * PROJ_BLOCK; r0 < n_vis; r0 += (int64_t)gridDim.x * PROJ_BLOCK) {
         const int64_t r = r0 + threadIdx.x;
@@ -438,7 +442,7 @@ __device__ __forceinline__ void block_store(float *__restrict__ dst, const float
     }
 }
 __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
-    int64_t N, const int32_t *__restrict__ radii, const int32_t *__restrict__ row_index,
+    int64_t N, int64_t n_rows, const int32_t *__restrict__ radii, const int32_t *__restrict__ row_index,
     const float *__restrict__ ws, const float *__restrict__ v_means2d, int64_t m2d_stride,
     float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
     float *__restrict__ v_opacities, const ProjExpand ex) {
@@ -449,12 +453,15 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
     const int n_chunk = (int)min((int64_t)PROJ_BLOCK, N - chunk);
     const int64_t n = chunk + t;
     const bool stage_col = ex.colors && ex.channels <= EXP_STAGE_COL;
-    const bool vis = n < N && radii[n] > 0;
+    bool vis = n < N && radii[n] > 0;
     float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0;
     float2 xy = make_float2(0.f, 0.f), ab = xy;
     int64_t r = 0;
     if (vis) {
         r = row_index[n];
+        vis = r < n_rows;   // (capacity-sized row buffers, graph mode: a Gaussian beyond them has no row)
+    }
+    if (vis) {
         const float4 *row = reinterpret_cast<const float4 *>(ws + r * VIS_ROW);
         w0 = row[0]; w1 = row[1]; w2 = row[2];
         if (ex.means2d) xy = make_float2(v_means2d[r * m2d_stride], v_means2d[r * m2d_stride + 1]);
@@ -494,13 +501,12 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const float *x_means2d_abs, const float *x_colors, int x_channels,
                                 const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
                                 float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
-                                void *stream) {
+                                const int64_t *n_vis_dev, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
     if (v_viewmats && C > 0) {
-        hipError_t e = hipMemsetAsync(v_viewmats, 0, sizeof(float) * 16 * (size_t)C, st);
-        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_project_bwd: memset failed: %s", hipGetErrorString(e));
+        if (int rc = mtgs_zero_async(v_viewmats, sizeof(float) * 16 * (size_t)C, st)) return rc;
     }
     if (N == 0 || C == 0) return MTGS_OK;
     MTGS_REQUIRE(means && quats && scales && viewmats && Ks && radii && conics && v_means2d &&
@@ -535,10 +541,10 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
             const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
             project_bwd_vis_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
-                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats);
+                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev);
         }
         project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
-            N, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);
+            N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);
         MTGS_CHECK_LAUNCH("mtgs_project_bwd");
         return MTGS_OK;
     }
@@ -564,8 +570,7 @@ extern "C" int mtgs_project_bwd_rows(int64_t N, const float *means, const float 
     MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D == 3 && colors_pre), MTGS_EINVAL, "mtgs_project_bwd_rows: color_mode");
     hipStream_t st = (hipStream_t)stream;
     if (v_viewmats) {
-        hipError_t e = hipMemsetAsync(v_viewmats, 0, sizeof(float) * 16, st);
-        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_project_bwd_rows: memset failed: %s", hipGetErrorString(e));
+        if (int rc = mtgs_zero_async(v_viewmats, sizeof(float) * 16, st)) return rc;
     }
     if (n_vis == 0) return MTGS_OK;
     MTGS_REQUIRE(means && quats && scales && viewmats && Ks && conics && opacities && grad_rows && vis_ids && wire_rows,

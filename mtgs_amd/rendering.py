@@ -114,6 +114,9 @@ def rasterization(
                          "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
                          "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width,
                          "height": height, "tile_size": tile_size, "n_cameras": C})
+            for k in ("n_visible", "n_intersections", "overflow"):   # only inside mtgs_amd.graph_mode
+                if k in m:
+                    meta[k] = m[k]
             return render_colors, render_alphas, meta
 
     # (1) projection, fused with `opacities.repeat(C, 1) [* compensations]`

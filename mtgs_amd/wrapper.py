@@ -142,7 +142,7 @@ class _FullyFusedProjection(torch.autograd.Function):
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
-             None, 0, None, stream_of(means))
+             None, 0, None, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -444,6 +444,63 @@ class _SizePlan(threading.local):
 _size_plan = _SizePlan()
 
 
+class _GraphState:
+    """(Process-wide, not per thread: the backward of a captured iteration runs on autograd's device thread.)"""
+    caps = None       # (cap_vis, cap_M) while graph_mode() is active
+    keep = None       # host staging buffers that captured copies read at every replay
+
+
+_graph = _GraphState()
+
+
+class graph_mode:
+    """`with mtgs_amd.graph_mode(cap_vis, cap_M): ...` -- rasterization() for HIP graph capture (torch.cuda.graph).
+
+    Inside, a frame never talks to the host: binning and compositing run for the given CAPACITIES (visible Gaussians,
+    tile intersections) and read the true counts on the device, so the calls can be captured once and replayed with new
+    camera / parameter VALUES in the same tensors -- a whole training iteration becomes one graph launch instead of
+    ~110 kernel launches, which is what bounds MTGS's 960x540 iteration.
+    What changes for the caller while the mode is on:
+      * `info["flatten_ids"]`, `info["isect_ids"]` have cap_M entries and only the first M are meaningful; the counts are
+        device scalars: `info["n_visible"]`, `info["n_intersections"]` (int64), and `info["overflow"]` (bool) is True
+        when a count exceeded its capacity -- the frame is then TRUNCATED (never out of bounds) and must be repeated
+        with larger capacities (outside the mode, `rasterization()` does that by itself);
+      * host tables that kernels read (node descriptors) are kept alive in `.keep` for the lifetime of the graph.
+    Capacities: take them from an eager frame (`info["flatten_ids"].numel()`, `(info["radii"] > 0).sum()`) plus a margin."""
+
+    def __init__(self, cap_vis: int, cap_M: int):
+        self.caps, self.keep, self.cursor = (int(cap_vis), int(cap_M)), [], 0
+
+    def __enter__(self):
+        if _graph.caps is not None:
+            raise RuntimeError("graph_mode is already active")
+        _graph.caps, _graph.keep = self.caps, self
+        self.cursor = 0      # every entry walks the same sequence of staging buffers (warm-up pass, then capture)
+        return self
+
+    def __exit__(self, *exc):
+        _graph.caps = _graph.keep = None
+        return False
+
+
+def staging_buffer(nbytes: int) -> Tensor:
+    """Pinned host staging buffer for a table that a kernel reads.  Outside graph_mode: a fresh one from PyTorch's pinned
+    cache.  Inside: the i-th request of a pass gets the i-th buffer of the mode object -- allocated by the warm-up pass
+    (pinned allocation is not permitted while a stream is capturing), reused by the capture pass, and kept alive with the
+    mode object because the captured copy re-reads it at every replay."""
+    gm = _graph.keep
+    if gm is None:
+        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    if gm.cursor < len(gm.keep) and gm.keep[gm.cursor].numel() == nbytes:
+        buf = gm.keep[gm.cursor]
+    else:
+        buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        del gm.keep[gm.cursor:]
+        gm.keep.append(buf)
+    gm.cursor += 1
+    return buf
+
+
 def _bin2_ok(Cn, tw, th, cap_M) -> bool:
     return bool(_lib.load().mtgs_bin2_supported(Cn, tw, th, cap_M))
 
@@ -516,17 +573,20 @@ class _FusedRasterization(torch.autograd.Function):
             offsets_buf = torch.empty(Cn * th * tw + 1, dtype=torch.int32, device=dev)
             order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
 
+            graph_caps = _graph.caps
+
             def front(cap_vis):
                 b = {"recs": torch.empty((cap_vis, 16), dtype=torch.float32, device=dev),
                      "vis_ids": torch.empty(cap_vis, dtype=torch.int32, device=dev),
                      "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis}
-                mailbox, tag = _host_mailbox()
+                mailbox, tag = _host_mailbox() if graph_caps is None else (None, 0)
                 call("mtgs_front_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
                      eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
                      ptr(vis_rank), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
-                     1 if dp is not None else 0, ptr(totals), mailbox.data_ptr(), tag, ptr(front_ws), front_bytes, st)
+                     1 if dp is not None else 0, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
+                     ptr(front_ws), front_bytes, st)
                 b["mailbox"], b["tag"] = mailbox, tag
                 if dp is not None:
                     dp.after_front()       # the visibility maps travel while this frame is composited
@@ -552,7 +612,14 @@ class _FusedRasterization(torch.autograd.Function):
             caps = _force_caps or (_size_plan.caps(key, total) if speculative_sizing else None)
             if caps is not None and not _bin2_ok(Cn, tw, th, caps[1]):
                 caps = None
-            if caps is not None:
+            if graph_caps is not None:
+                # graph mode: fixed capacities, nothing waits for the host; the counts stay on the device
+                if dp is not None or not _bin2_ok(Cn, tw, th, graph_caps[1]):
+                    raise NotImplementedError("graph_mode: unsupported configuration (data-parallel exchange / capacity >= 2^30)")
+                b = front(min(graph_caps[0], total))
+                out = rest(b, graph_caps[1])
+                n_vis, M = b["cap_vis"], graph_caps[1]
+            elif caps is not None:
                 b = front(min(caps[0], total))
                 out = rest(b, caps[1])                    # enqueued before the totals are known
                 n_vis, M = _wait_mailbox(b["mailbox"], b["tag"], totals, total)
@@ -569,15 +636,19 @@ class _FusedRasterization(torch.autograd.Function):
                     raise NotImplementedError(f"rasterization: {M} tile intersections in one call (limit 2^30)")
                 b["cap_vis"] = max(n_vis, 0)              # (buffers are larger; the kernels only need a bound)
                 out = rest(b, M)
-            _size_plan.update(key, n_vis, M)
+            if graph_caps is None:
+                _size_plan.update(key, n_vis, M)
             recs, vis_ids = b["recs"], b["vis_ids"][:n_vis]
             rank_ids, flatten_ids, isect_ids = out["rank_ids"][:M], out["flatten_ids"][:M], out["isect_ids"][:M]
             offsets = offsets_buf[:Cn * th * tw].view(Cn, th, tw)
             offsets._mtgs_tile_order = order
             isect_ids._mtgs_offsets = offsets
+        if not packed:
+            totals = torch.zeros(1, dtype=torch.int64, device=dev)
         ctx.save_for_backward(means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics,
                               comps, opac_eff, offsets if not packed else offsets_buf, flatten_ids, alphas, last_ids, order,
-                              vis_ids, vis_rank, render if ed else None, recs, rank_ids)
+                              vis_ids, vis_rank, render if ed else None, recs, rank_ids, totals)
+        ctx.graph = packed and _graph.caps is not None
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
         ctx.absgrad = bool(absgrad)
         ctx.packed = packed
@@ -585,15 +656,15 @@ class _FusedRasterization(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # classic mode: an empty placeholder keeps the output arity fixed
         comps_out = comps if comps is not None else torch.empty(0, device=dev)
-        nd = [radii, tiles_per_gauss, isect_ids, flatten_ids, offsets] + ([comps_out] if comps is None else [])
+        nd = [radii, tiles_per_gauss, isect_ids, flatten_ids, offsets, totals] + ([comps_out] if comps is None else [])
         ctx.mark_non_differentiable(*nd)
         return (render, alphas, radii, means2d, depths, conics, comps_out, opac_eff, tiles_per_gauss, isect_ids,
-                flatten_ids, offsets)
+                flatten_ids, offsets, totals)
 
     @staticmethod
     def backward(ctx, v_render, v_alphas, _r, g_means2d, g_depths, g_conics, g_comps, g_opac, *_ints):
         (means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics, comps, opac_eff, offsets,
-         flatten_ids, alphas, last_ids, order, vis_ids, vis_rank, render, recs, rank_ids) = ctx.saved_tensors
+         flatten_ids, alphas, last_ids, order, vis_ids, vis_rank, render, recs, rank_ids, totals) = ctx.saved_tensors
         width, height, tile_size, tw, th, DC, with_depth, ed, eps2d = ctx.dims
         Cn, N = means2d.shape[:2]
         dev, st = means.device, stream_of(means)
@@ -638,6 +709,8 @@ class _FusedRasterization(torch.autograd.Function):
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
+        if direct and ctx.graph:
+            raise NotImplementedError("graph_mode: gradients on info[...] tensors (the visible list is capacity-sized)")
         if n_vis > 0 and direct:
             vi = vis_ids.long()
             if g_means2d is not None:
@@ -670,7 +743,8 @@ class _FusedRasterization(torch.autograd.Function):
              eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities), ptr(r_xy), ptr(r_dep_total), ptr(r_con),
              ptr(r_cmp), ptr(r_opa), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs), ptr(r_col), DC,
-             host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws), st)
+             host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
+             ptr(totals) if ctx.graph else None, st)
         if want_m2d:
             m2d_out.grad = d_m2d      # what retain_grad() would have kept: the gradient reaching means2d
         if d_abs is not None:
@@ -696,13 +770,17 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
                                     int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                     bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp)
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
-     offsets) = out
+     offsets, totals) = out
     if render.grad_fn is not None:  # the backward sets .grad / .absgrad on this very tensor (weak: no cycle)
         render.grad_fn.means2d_ref = weakref.ref(means2d)
-    return render, alphas, {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
-                            "compensations": comps if calc_compensations else None, "opacities": opac_eff,
-                            "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
-                            "isect_offsets": offsets}
+    meta = {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+            "compensations": comps if calc_compensations else None, "opacities": opac_eff,
+            "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": offsets}
+    if _graph.caps is not None:   # graph mode: the counts live on the device (see graph_mode)
+        n_v, n_m = totals[0] >> 32, totals[0] & 0xFFFFFFFF
+        meta.update({"n_visible": n_v, "n_intersections": n_m,
+                     "overflow": (n_v > min(_graph.caps[0], radii.numel())) | (n_m > _graph.caps[1])})
+    return render, alphas, meta
 
 
 def _pad_channels(colors: Optional[Tensor], backgrounds: Optional[Tensor], extra: int):

@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--refine-every", type=int, default=0, help="with --steps: densify (duplicate / split / cull) every so many steps")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", choices=["both", "fused", "chain"], default="both", help="profiling aid: time one variant only")
+    ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
+                    "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
     dev = torch.device("cuda")
     W, H, T = args.width, args.height, args.traversals
@@ -370,6 +372,63 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.reps * 1e3, float(one(0)), stats
 
+    def graphed():
+        """The fused iteration as ONE graph launch per traversal: static camera / target tensors; the gradients are the
+        tensors the captured backward assigned (`grads_of[t]`, static addresses inside graph t's memory pool -- what an
+        optimizer would be pointed at after a replay).  Returns (wall ms, GPU ms, eager wall ms, loss check)."""
+        import mtgs_amd
+        from mtgs_amd import wrapper
+        stats = mk_stats()
+        grads_of = {}
+
+        def body(t):
+            for q in params:
+                q.grad = None
+            return iteration(P, cams[t], targets[t], mask, True, stats, win, W, H, shipped=shipped)
+
+        eager_loss = [float(body(t)) for t in range(T)]        # also teaches the size plan this scene's (n_vis, M)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.reps):
+            body(i % T)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / args.reps * 1e3
+        n_all = sum(p["means"].shape[0] for p in P.values())
+        n_vis, M = wrapper._size_plan.seen[(1, n_all, W, H)]
+        caps = (int(1.3 * n_vis) + 4096, int(1.3 * M) + 65536)
+        graphs, losses, modes, flags = [], [], [], []
+        side = torch.cuda.Stream()
+        for t in range(T):
+            gm = mtgs_amd.graph_mode(*caps)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), gm:                    # warm-up on the capture stream (allocator, lazy init)
+                body(t)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with gm, torch.cuda.graph(g):
+                losses.append(body(t))
+            grads_of[t] = [q.grad for q in params]
+            graphs.append(g); modes.append(gm)
+        for t in range(T):
+            graphs[t].replay()
+        torch.cuda.synchronize()
+        graph_loss = [float(l) for l in losses]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(args.reps):
+            graphs[i % T].replay()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / args.reps * 1e3
+        return wall, e0.elapsed_time(e1) / args.reps, eager_ms, eager_loss, graph_loss, caps
+
+    if args.graph:
+        wall, gpu, eager_ms, l_e, l_g, caps = graphed()
+        print(f"fused iteration, {W}x{H}{' shipped options' if shipped else ''}: eager {eager_ms:.3f} ms wall -> one graph launch "
+              f"{wall:.3f} ms wall ({gpu:.3f} ms between GPU events); capacities {caps}; loss eager {l_e} graph {l_g}")
+        assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(l_e, l_g)), (l_e, l_g)
+        return
     if args.only != "both":
         t1, l1, _ = timed(args.only == "fused")
         print(f"{args.only}: {t1:.2f} ms per iteration, loss {l1:.6f}")

@@ -165,3 +165,91 @@ def test_speculative_sizing_overflow_repeats_the_frame_exactly(hip_lib):
         for k in g0:
             # (fp32 atomics accumulate in a different order from run to run)
             assert (g0[k] - g1[k]).abs().max() <= 2e-4 * g0[k].abs().max() + 1e-7, (caps, k)
+
+
+@pytest.mark.gpu
+def test_graph_mode_capture_replay_equals_eager(hip_lib):
+    """mtgs_amd.graph_mode: forward + backward captured ONCE as a HIP graph (torch.cuda.graph), replayed with new
+    camera / parameter VALUES in the same tensors; every replay must give the eager result of those values, the counts
+    must be right on the device, and capacities that are too small must raise the overflow flag (never go out of bounds)."""
+    import mtgs_amd
+    from mtgs_amd import rasterization
+    from mtgs_amd.synthetic import make_camera
+    from tests.util import small_scene
+    W, H, N = 200, 120, 4000
+    sc, vm0, K = small_scene(N=N, W=W, H=H, seed=12)
+    dev = torch.device("cuda")
+    P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    vm, Kd = vm0.to(dev).clone(), K.to(dev)
+    g = torch.Generator().manual_seed(4)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=g).to(dev), torch.randn(1, H, W, 1, generator=g).to(dev)
+
+    def run():
+        r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, Kd, W, H, packed=False,
+                                   render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+        info["means2d"].retain_grad()
+        torch.autograd.backward([r, a], [Gc, Ga])
+        return r, a, info
+
+    def eager():
+        for p in P.values():
+            p.grad = None
+        r, a, info = run()
+        torch.cuda.synchronize()
+        return (r.detach().clone(), a.detach().clone(), {k: p.grad.clone() for k, p in P.items()}, info["means2d"].absgrad.clone(),
+                int((info["radii"] > 0).sum()), info["flatten_ids"].clone())
+
+    ref0 = eager()
+    n_vis, M = ref0[4], ref0[5].numel()
+    for p in P.values():
+        p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in P.values()]
+
+    def capture(caps):
+        gm = mtgs_amd.graph_mode(*caps)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), gm:
+            torch._foreach_zero_(grads)
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with gm, torch.cuda.graph(graph):
+            torch._foreach_zero_(grads)
+            out = run()
+        return graph, out, gm
+
+    graph, (r, a, info), gm = capture((n_vis + 500, M + 5000))
+    assert info["flatten_ids"].numel() == M + 5000      # capacity-sized in graph mode
+
+    def check(ref):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(info["n_visible"]) == ref[4] and int(info["n_intersections"]) == ref[5].numel() and not bool(info["overflow"])
+        assert torch.equal(info["flatten_ids"][:ref[5].numel()], ref[5])
+        assert torch.equal(r, ref[0]) and torch.equal(a, ref[1])
+        for k, p in P.items():
+            assert (p.grad - ref[2][k]).abs().max() <= 2e-4 * ref[2][k].abs().max() + 1e-7, k
+        assert (info["means2d"].absgrad - ref[3]).abs().max() <= 2e-4 * ref[3].abs().max() + 1e-7
+
+    check(ref0)
+    # new VALUES in the same tensors: another camera, perturbed parameters -> the replay follows
+    vm.copy_(make_camera(W, H, yaw_deg=10.0)[0].to(dev))
+    vm[0, :3, 3] += torch.tensor([0.1, -0.2, 0.3], device=dev)
+    with torch.no_grad():
+        P["means"] += 0.01
+        P["opacities"].mul_(0.9)
+    saved = [p.grad for p in P.values()]
+    ref1 = eager()                      # (eager() detaches the .grad tensors; restore the graph's)
+    for p, gr in zip(P.values(), saved):
+        p.grad = gr
+    assert ref1[4] + 500 > ref1[4] and ref1[5].numel() <= M + 5000 and ref1[4] <= n_vis + 500, "test scene: capacities must still fit"
+    check(ref1)
+    # capacities too small: flagged, truncated, nothing crashes
+    for p in P.values():
+        p.grad = torch.zeros_like(p)
+    grads[:] = [p.grad for p in P.values()]
+    g2, (r2, a2, i2), _ = capture((max(ref1[4] // 2, 64), max(ref1[5].numel() // 3, 1 << 16)))
+    g2.replay()
+    torch.cuda.synchronize()
+    assert bool(i2["overflow"]) and int(i2["n_visible"]) == ref1[4] and torch.isfinite(r2).all()
