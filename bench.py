@@ -156,6 +156,50 @@ def make_step(args, dev, world):
     return step, step_fwd, all_params, info_box
 
 
+def shipped_cells(args, dev):
+    """ms per rasterization() forward + backward with the option set of the shipped config/MTGS.py (6 colour channels +
+    expected depth, antialiased, absgrad, viewmat gradient; colours given), same Gaussians: 1920x1080 and 960x540, and the
+    forward alone at 960x540 (what eval / the viewer run).  Not part of the headline figure."""
+    from mtgs_amd import rasterization
+    from mtgs_amd.synthetic import make_camera
+    N = args.n_gaussians
+    g = torch.Generator().manual_seed(3)
+    cols = torch.cat([torch.rand(N, 3, generator=g), torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)], -1)
+    P = {k: dev[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
+    P["colors"] = cols.to(dev["means"].device).requires_grad_(True)
+    res = {}
+    for W, H, key in ((args.width, args.height, f"shipped_7ch_{args.width}x{args.height}_ms"), (960, 540, "shipped_7ch_960x540_ms")):
+        vm, K = make_camera(W, H)
+        vm, K = vm.to(P["means"].device).requires_grad_(True), K.to(P["means"].device)
+        Gc = torch.randn(1, H, W, 7, generator=g).to(vm.device)
+        Ga = torch.randn(1, H, W, 1, generator=g).to(vm.device)
+
+        def fb(backward=True):
+            for q in list(P.values()) + [vm]:
+                q.grad = None
+            r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K, W, H, packed=False,
+                                       render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+            if backward:
+                info["means2d"].retain_grad()
+                torch.autograd.backward([r, a], [Gc, Ga])
+
+        def timed(fn, reps=8):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / reps * 1e3, 3)
+
+        res[key] = timed(fb)
+        if (W, H) == (960, 540):
+            with torch.no_grad():
+                res["fwd_only_7ch_960x540_ms"] = timed(lambda: fb(False))
+    return res
+
+
 def cpu_baseline(args, host, steps):
     """oracle/gsplat_oracle.c (CPU restatement of the same path) on this box's host cores."""
     import numpy as np
@@ -278,15 +322,39 @@ def main():
     step_bytes = b_fwd + b_bwd
     k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     achieved = bytes_bwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # counter-based traffic (and VALU-busy fraction) per kernel: committed rocprofv3 --pmc passes of THIS command on the
+    # headline workload (scripts/pmc_step.sh -> profiles/r02_pmc_step.json; FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated there)
     traffic = valu_busy = None
-    pmc = ROOT / "profiles" / "pmc_blend_bwd.json"
-    if pmc.exists():
+    kernels = []
+    pmc = ROOT / "profiles" / "r02_pmc_step.json"
+    if pmc.exists() and (args.n_gaussians, args.width, args.height, args.variant) == (2_000_000, 1920, 1080, "mtgs"):
         try:
-            if (args.n_gaussians, args.width, args.height) == (2_000_000, 1920, 1080):  # the profiled workload
-                rec = json.loads(pmc.read_text()).get(args.variant, {})
-                traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac")
+            rec = json.loads(pmc.read_text())["kernels"]
+            Ksh_ = 16
+            alg = {   # algorithmic HBM bytes per launch of the streaming kernels
+                "sh_fwd_k16_kernel<3>": args.n_gaussians * (12 + 12 * Ksh_ + 12),
+                "sh_bwd_kernel<3>": args.n_gaussians * (24 + 12 * Ksh_),
+                "front_project_kernel": args.n_gaussians * (40 + 4 + 40),
+                "front_compact_kernel": args.n_gaussians * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
+                "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
+                "project_bwd_expand_kernel": args.n_gaussians * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
+                "bin2_emit_kernel": n_vis * 16 + M * 8,
+                "mtgs_sort::reorder_kernel<unsigned int, 16, mtgs_sort::NoEpilogue>": M * 16,
+                "mtgs_sort::reorder_kernel<unsigned int, 16, TileEpilogue>": M * (8 + 12 + 16),
+                "blend_fwd_kernel<4, 4, true>": M * (4 + 64) + P * (4 * D + 8),
+                "blend_bwd_kernel<4, 4, true>": bytes_bwd,
+            }
+            for name, a_bytes in alg.items():
+                r = rec.get(name)
+                if r and r.get("avg_us"):
+                    kernels.append({"kernel": name, "algorithmic_bytes": int(a_bytes), "counter_bytes": r["hbm_bytes"],
+                                    "avg_us": r["avg_us"], "frac_of_peak_algorithmic": round(a_bytes / r["avg_us"] / 1e3 / HBM_PEAK_GBS, 4),
+                                    "frac_of_peak_counter": r.get("frac_of_8TBs"), "valu_busy_frac": r.get("valu_busy_frac")})
+            dom = rec.get("blend_bwd_kernel<4, 4, true>", {})
+            traffic, valu_busy = dom.get("hbm_bytes"), dom.get("valu_busy_frac")
         except Exception:
             traffic = valu_busy = None
+            kernels = []
 
     out = {
         "metric": "rendered Mpix/s (fwd+bwd) @ 2M Gaussians 1920x1080",
@@ -303,7 +371,7 @@ def main():
             "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange, "
                            f"{info_box['grad_bytes']} bytes received per rank per step",
         },
-        "roofline": {"kernel": "blend_bwd_kernel (mtgs_blend_bwd)", "bound": "hbm",
+        "roofline": {"kernel": "blend_bwd_kernel<4,4,packed> (mtgs_blend_bwd_packed)", "bound": "hbm",
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
@@ -311,6 +379,9 @@ def main():
                      "note": "kernel is VALU bound, not HBM bound (DESIGN.md section 4); valu_busy_frac = SQ_ACTIVE_INST_VALU*4/1024 "
                              "over GRBM_GUI_ACTIVE/8 from the committed rocprofv3 --pmc passes of this workload",
                      "valu_busy_frac": valu_busy,
+                     "kernels": kernels,
+                     "kernels_note": "per kernel of the step: algorithmic bytes of THIS run's (N, n_vis, M), counter bytes / avg_us / "
+                                     "VALU-busy from the committed profiles (profiles/r02_pmc_step.json, r02_bench_kernel_stats.csv)",
                      "whole_step": {"algorithmic_bytes": step_bytes, "unit": "GB/s",
                                     "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -333,6 +404,10 @@ def main():
     if fwd_ms is not None:
         out["also"] = {"fwd_only_ms": round(fwd_ms, 3), "fwd_only_mpix_s": round(P / fwd_ms / 1e3, 1),
                        "gaussians_per_s_fwd_bwd": round(world * args.n_gaussians / (ms_per_step * 1e-3), 0)}
+        if args.variant == "mtgs":
+            # what the SHIPPED config/MTGS.py drives (outside the timed region): RGB + camera-space normals + expected depth
+            # = 7 blended channels, antialiased, absgrad -- at the headline size and at MTGS's training size 960x540
+            out["also"].update(shipped_cells(args, dev))
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)
     if rank == 0:

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Copies the rocprofv3 outputs merged into gpurun_out/ (scripts/prof_bench.sh, pmc_traffic.sh,
-pmc_blend.sh, bench.py) into profiles/ and derives profiles/pmc_blend_bwd.json.  Run in the build
-container after the gpurun call."""
+"""Copies the rocprofv3 outputs merged into gpurun_out/ (scripts/prof_bench.sh, scripts/pmc_step.sh) into profiles/ and
+derives profiles/<round>_pmc_step.json: per kernel of the benchmark step the counter-based HBM traffic (FETCH_SIZE and
+WRITE_SIZE from SEPARATE --pmc passes, corrected by the factors measured on kernels with a known byte count), the
+VALU-busy fraction, and the average duration from the kernel trace of the same command.  Run in the build container after
+the gpurun calls:   python scripts/collect_profiles.py r02"""
 import collections
 import csv
 import glob
@@ -11,7 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -20,53 +22,72 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
-def avg_counters(path):
+def per_kernel(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        k = "blend_fwd" if "blend_fwd" in r["Kernel_Name"] else "blend_bwd"
-        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}, {k: len(next(iter(d.values()))) for k, d in agg.items()}
 
 
-shutil.copy(newest("bench_prof/**/*kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(G, "bench_r01.json"), os.path.join(P, f"{tag}_bench.json"))
-out = {}
-for name in ("fetch", "write", "req"):
-    p = newest(f"pmc_traffic/{name}/**/*counter_collection.csv")
-    shutil.copy(p, os.path.join(P, f"{tag}_pmc_{name}_counter_collection.csv"))
-    for k, d in avg_counters(p).items():
-        out.setdefault(k, {}).update(d)
-sq = {}
-for name in ("p1", "p2", "p3"):
-    p = newest(f"pmc/{name}/**/*counter_collection.csv")
-    shutil.copy(p, os.path.join(P, f"{tag}_pmc_sq_{name}_counter_collection.csv"))
-    for k, d in avg_counters(p).items():
-        sq.setdefault(k, {}).update(d)
-bw = out["blend_bwd"]
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
-def valu_busy(d):
-    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over 8 XCDs
-    return round(d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
-
-
-summary = {
-    "mtgs": {
-        "kernel": "blend_bwd_kernel<4,4>", "workload": "bench.py default (2M Gaussians, 1920x1080, variant mtgs)",
-        "FETCH_SIZE_KB": round(bw["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(bw["WRITE_SIZE"], 1),
-        "TCC_EA0_RDREQ_sum": round(bw["TCC_EA0_RDREQ_sum"]), "TCC_EA0_WRREQ_sum": round(bw["TCC_EA0_WRREQ_sum"]),
-        "TCC_HIT_sum": round(bw["TCC_HIT_sum"]), "TCC_MISS_sum": round(bw["TCC_MISS_sum"]),
-        "hbm_bytes_per_launch": int((bw["FETCH_SIZE"] + bw["WRITE_SIZE"]) * 1024),
-        "SQ_INSTS_VALU": round(sq["blend_bwd"]["SQ_INSTS_VALU"]), "valu_busy_frac": valu_busy(sq["blend_bwd"]),
-        "note": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes (scripts/pmc_traffic.sh), averaged over the "
-                "launches of the run, KB -> bytes x1024.  The guide's gfx950 x2 FETCH_SIZE correction is calibrated for wide "
-                "coalesced streams only; this kernel's reads are 4-16 B gathers and its writes are fp32 atomics, so the "
-                "value is reported UNCORRECTED.  Infinity-Cache hits are counted by these counters "
-                "(MI355X_MICROARCH.md, HBM section).  valu_busy_frac = SQ_ACTIVE_INST_VALU*4/1024 / (GRBM_GUI_ACTIVE/8).",
-    },
-    "blend_fwd_mtgs": {"FETCH_SIZE_KB": round(out["blend_fwd"]["FETCH_SIZE"], 1),
-                       "WRITE_SIZE_KB": round(out["blend_fwd"]["WRITE_SIZE"], 1),
-                       "SQ_INSTS_VALU": round(sq["blend_fwd"]["SQ_INSTS_VALU"]), "valu_busy_frac": valu_busy(sq["blend_fwd"])},
-}
-json.dump(summary, open(os.path.join(P, "pmc_blend_bwd.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+stats = newest("prof_bench/**/*kernel_stats.csv")
+shutil.copy(stats, os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+avg_us = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(stats))}
+out = {"_about": "scripts/pmc_step.sh on the MI355X box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ counters in SEPARATE passes "
+                 "over `bench.py --steps 6 --warmup 2 --cpu-steps 0` (headline workload), per-kernel averages over the launches of "
+                 "the run; avg_us from the rocprofv3 --kernel-trace --stats run of scripts/prof_bench.sh.  Counters are KB: bytes = "
+                 "value x 1024 x correction.",
+       "calibration": {}}
+# ---- calibration on kernels that move exactly 384 MiB (scripts/dev/read_bench.hip --calibrate)
+true_bytes = 384 << 20
+for c, kernels in (("FETCH_SIZE", ("rd<HIP_vector_type<float, 4u>, 16>", "rd<float, 16>")), ("WRITE_SIZE", ("wr(",))):
+    p = newest(f"pmc_step/cal_{c}/**/*counter_collection.csv")
+    shutil.copy(p, os.path.join(P, f"{tag}_pmc_cal_{c}_counter_collection.csv"))
+    vals, _ = per_kernel(p)
+    for k, d in vals.items():
+        if any(x in k for x in kernels):
+            out["calibration"][f"{c} {short(k)}"] = {"counter_KB": d[c], "true_bytes": true_bytes,
+                                                     "true_over_counter": round(true_bytes / (d[c] * 1024), 4)}
+fetch_corr = round(sum(v["true_over_counter"] for k, v in out["calibration"].items() if k.startswith("FETCH")) /
+                   max(sum(1 for k in out["calibration"] if k.startswith("FETCH")), 1), 3)
+write_corr = round(sum(v["true_over_counter"] for k, v in out["calibration"].items() if k.startswith("WRITE")) /
+                   max(sum(1 for k in out["calibration"] if k.startswith("WRITE")), 1), 3)
+out["corrections"] = {"FETCH_SIZE": fetch_corr, "WRITE_SIZE": write_corr,
+                      "note": "the guide's gfx950 note (FETCH_SIZE reports half of a coalesced streaming read) verified here for 16-byte and "
+                              "4-byte per-lane loads; WRITE_SIZE is exact for 16-byte streaming stores.  Gather-dominated kernels (compositing) "
+                              "are reported with the same factors: an upper bound on their fetch traffic if partial-line requests are "
+                              "tallied differently."}
+F, nF = per_kernel(newest("pmc_step/FETCH_SIZE/**/*counter_collection.csv"))
+W, _ = per_kernel(newest("pmc_step/WRITE_SIZE/**/*counter_collection.csv"))
+S, _ = per_kernel(newest("pmc_step/sq/**/*counter_collection.csv"))
+for name in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
+    shutil.copy(newest(f"pmc_step/{name}/**/*counter_collection.csv"), os.path.join(P, f"{tag}_pmc_step_{name}_counter_collection.csv"))
+kernels = {}
+for k in F:
+    if "at::native" in k or "rocclr" in k or "rocsolver" in k or "elementwise_kernel_with_index" in k:
+        continue   # the library's kernels only (PyTorch's glue kernels stay in the CSVs)
+    fb = F[k]["FETCH_SIZE"] * 1024 * fetch_corr
+    wb = W.get(k, {}).get("WRITE_SIZE", 0.0) * 1024 * write_corr
+    rec = {"launches_in_pmc_run": nF[k], "fetch_bytes": int(fb), "write_bytes": int(wb), "hbm_bytes": int(fb + wb),
+           "avg_us": round(avg_us.get(k, 0.0), 2)}
+    if rec["avg_us"] > 0:
+        rec["counter_GBs"] = round((fb + wb) / rec["avg_us"] / 1e3, 1)
+        rec["frac_of_8TBs"] = round((fb + wb) / rec["avg_us"] / 1e3 / 8000.0, 4)
+    s = S.get(k)
+    if s and s.get("GRBM_GUI_ACTIVE"):
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over 8 XCDs
+        rec["valu_busy_frac"] = round(s["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 3)
+        rec["SQ_INSTS_VALU"] = int(s["SQ_INSTS_VALU"])
+    kernels[short(k)] = rec
+out["kernels"] = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes"]))
+json.dump(out, open(os.path.join(P, f"{tag}_pmc_step.json"), "w"), indent=1)
+b = newest("prof_bench/bench.log")
+if b:
+    lines = [ln for ln in open(b) if ln.startswith("{")]
+    if lines:
+        open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+print(json.dumps({"corrections": out["corrections"], "kernels": {k: (v["hbm_bytes"], v.get("avg_us"), v.get("frac_of_8TBs"))
+                                                                  for k, v in list(out["kernels"].items())[:14]}}, indent=1))

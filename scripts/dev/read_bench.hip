@@ -45,7 +45,28 @@ void run(const char *name, void *buf, size_t bytes, float *fl, size_t fl_n, floa
     }
     printf("%-22s %s %7.1f us  %6.0f GB/s\n", name, mode ? "after clean flush" : "after dirty flush", best * 1e3, bytes / (best * 1e-3) / 1e9);
 }
-int main() {
+// pure streaming WRITE (16 bytes per lane), for the WRITE_SIZE calibration
+__global__ __launch_bounds__(256) void wr(float4 *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+int main(int argc, char **argv) {
+    if (argc > 1) {   // calibration mode for rocprofv3 --pmc: exactly ONE kind of access per kernel, known byte counts
+        const size_t bytes = (size_t)384 << 20;
+        void *buf; float *out;
+        hipMalloc(&buf, bytes); hipMalloc(&out, 16);
+        hipMemset(buf, 0, bytes);
+        for (int rep = 0; rep < 3; ++rep) {
+            const size_t n4 = bytes / 16, waves = (n4 + 64 * 16 - 1) / (64 * 16);
+            rd<float4, 16><<<(unsigned)((waves + 3) / 4), 256>>>((const float4 *)buf, 0, n4, out);     // reads 384 MiB
+            const size_t n1 = bytes / 4, waves1 = (n1 + 64 * 16 - 1) / (64 * 16);
+            rd<float, 16><<<(unsigned)((waves1 + 3) / 4), 256>>>((const float *)buf, 0, n1, out);       // reads 384 MiB, 4 B/lane
+            wr<<<(unsigned)((n4 + 255) / 256), 256>>>((float4 *)buf, n4);                                // writes 384 MiB
+        }
+        hipDeviceSynchronize();
+        printf("calibration kernels done: each moves %zu bytes\n", bytes);
+        return 0;
+    }
     const size_t bytes = (size_t)384 << 20, fl_n = (size_t)192 << 20;
     void *buf; float *fl, *out;
     hipMalloc(&buf, bytes); hipMalloc(&fl, fl_n * 4); hipMalloc(&out, 16);
