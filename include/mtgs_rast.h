@@ -223,6 +223,29 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
                    const int32_t *tile_order, void *stream);
 
+/* ---- densification of a Gaussian node on the device (csrc/refine.hip) -------------------
+ * Restates refinement_after / split_gaussians / dup_gaussians / cull_gaussians + the optimizer surgery of
+ * mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:392-446, 476-699.
+ * thresholds (HOST float[6]): densify_grad_thresh, densify_size_thresh, split_screen_size, cull_alpha_thresh,
+ *   cull_scale_thresh, cull_screen_size.  options (HOST int[5]): n_split_samples (1..4), split by screen size
+ *   (step < stop_screen_size_at), cull by world size (step > refine_every * reset_alpha_every), cull by screen size,
+ *   clone_sample_means.  Samples: Philox4x32-10 keyed by (seed, step, Gaussian index, sample) -- identical on every rank.
+ * mtgs_refine_classify: counts[(2 + n_split_samples), N] i32 (old row kept | child of sample s kept | duplicate kept),
+ *   flags[N] u8.  The caller takes exclusive prefix sums of the count columns (pos, i64) and the first output row of each
+ *   column's block (bases: old rows, then children sample-major, then duplicates -- the reference's order) and the total.
+ * mtgs_refine_apply: src_index[n_out] i32 / kind[n_out] u8 of every output row and out_means / out_scales[n_out,3].
+ * mtgs_refine_rows: dst[n_out,width] = src[src_index,:]; zero_new: rows of new Gaussians are zero (Adam moments). */
+int mtgs_refine_classify(int64_t N, const float *means, const float *scales, const float *quats,
+                         const float *opacities, const float *grad_norm, const float *vis_counts,
+                         const float *max_2dsize, const float *thresholds, const int *options, uint64_t seed,
+                         int64_t step, int32_t *counts, uint8_t *flags, void *stream);
+int mtgs_refine_apply(int64_t N, int64_t n_out, const uint8_t *flags, const int64_t *pos, const int64_t *bases,
+                      const float *means, const float *scales, const float *quats, const float *thresholds,
+                      const int *options, uint64_t seed, int64_t step, int32_t *src_index, uint8_t *kind,
+                      float *out_means, float *out_scales, void *stream);
+int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32_t *src_index, const uint8_t *kind,
+                     int zero_new, float *dst, void *stream);
+
 /* ---- fused rasterization front end + binning (ABI v7; what mtgs_amd.wrapper._FusedRasterization runs) ------------
  * The gsplat-shaped operators above stay; these entry points run the same stages of gsplat.rendering.rasterization
  * (mtgs/scene_model/mtgs_scene_graph.py:641-662) with fewer launches, one gather per intersection, and WITHOUT the host

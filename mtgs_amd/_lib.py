@@ -79,6 +79,11 @@ _SIGNATURES = {
     "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "mtgs_refine_classify": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_uint64, _i64,
+                             _vp, _vp, _vp],
+    "mtgs_refine_apply": [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_uint64, _i64,
+                          _vp, _vp, _vp, _vp, _vp],
+    "mtgs_refine_rows": [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp],
     "mtgs_stats_desc_bytes": [],
     "mtgs_densify_stats_batch": [_i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp],
     "mtgs_ncc_patches": [_i32, _i32, _i32, _i32, _i64p],

@@ -78,3 +78,105 @@ def update_statistics_all(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii:
     tab_dev = upload_table(tab, r.device)
     call("mtgs_densify_stats_batch", len(stats), ptr(tab_dev), int(nblk.sum()), ptr(r), ptr(g), int(width), int(height),
          stream_of(r))
+
+
+# ------------------------------------------------------------------------------------------------ refinement on device
+import ctypes as _C
+from dataclasses import dataclass
+from typing import Dict
+
+
+@dataclass
+class RefineConfig:
+    """The control fields of GaussianSplattingControlConfig that refinement_after reads
+    (vanilla_gaussian_splatting.py:29-66; values of the shipped config/MTGS.py:59-71 with iteration_factor 1)."""
+    refine_every: int = 100
+    stop_split_at: int = 15000
+    reset_alpha_every: int = 30
+    continue_cull_post_densification: bool = False
+    cull_alpha_thresh: float = 0.005
+    cull_scale_thresh: float = 0.5
+    densify_size_thresh: float = 0.2
+    densify_grad_thresh: float = 0.001
+    n_split_samples: int = 2
+    clone_sample_means: bool = True
+    stop_screen_size_at: int = 15000
+    cull_screen_size: float = 150.0
+    split_screen_size: float = 100.0
+
+
+@torch.no_grad()
+def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Tensor], cfg: RefineConfig, step: int, seed: int,
+                     moments: Optional[Dict[str, Tuple[Tensor, Tensor]]] = None):
+    """VanillaGaussianSplattingModel.refinement_after (densification branch, step < stop_split_at) for one node, on the
+    device: split / duplicate / cull, every per-Gaussian tensor of `params` (means[N,3], scales[N,3] log, quats[N,4] wxyz,
+    opacities[N,1] logit, + any other [N, ...] tensors: features_dc / features_rest / features_adapters ...) compacted and
+    appended in the reference's order, the Adam moments `moments[name] = (exp_avg, exp_avg_sq)` following their rows
+    (zeros for new Gaussians, dup_in_optim / remove_from_optim).  stats = (xys_grad_norm, vis_counts, max_2Dsize).
+
+    Rank-deterministic: the split / clone samples come from a counter-based generator keyed by (seed, step, Gaussian index,
+    sample) -- with all-reduced statistics (mtgs_amd.dist.all_reduce_stats) every rank of a data-parallel job produces
+    bit-identical tensors, so N stays identical without a broadcast (the reference draws torch.randn per rank, :642, :687).
+    ONE host synchronisation: the new N (tensor sizes).  Returns (new_params, new_moments | None, info) with
+    info = {n_before, n_after, n_split, n_dup, n_culled_old, src_index, kind}."""
+    from ._lib import call, ptr, stream_of
+    means, scales, quats, opac = (params[k] for k in ("means", "scales", "quats", "opacities"))
+    require_gpu(means, scales, quats, opac, *stats)
+    N, dev = means.shape[0], means.device
+    assert means.shape == (N, 3) and scales.shape == (N, 3) and quats.shape == (N, 4) and opac.numel() == N
+    for t in params.values():
+        assert t.dtype == torch.float32 and t.shape[0] == N, "every parameter is float32 with one row per Gaussian"
+    gn, vc, m2 = (t.reshape(-1).to(torch.float32).contiguous() for t in stats)
+    assert gn.numel() == N and vc.numel() == N and m2.numel() == N
+    S = int(cfg.n_split_samples)
+    th = (_C.c_float * 6)(cfg.densify_grad_thresh, cfg.densify_size_thresh, cfg.split_screen_size, cfg.cull_alpha_thresh,
+                          cfg.cull_scale_thresh, cfg.cull_screen_size)
+    cull_big = step > cfg.refine_every * cfg.reset_alpha_every
+    opt = (_C.c_int * 5)(S, int(step < cfg.stop_screen_size_at), int(cull_big), int(cull_big and step < cfg.stop_screen_size_at),
+                         int(cfg.clone_sample_means))
+    st = stream_of(means)
+    c = {k: params[k].detach().contiguous() for k in params}
+    counts = torch.empty((2 + S, max(N, 1)), dtype=torch.int32, device=dev)
+    flags = torch.empty(max(N, 1), dtype=torch.uint8, device=dev)
+    call("mtgs_refine_classify", N, ptr(c["means"]), ptr(c["scales"]), ptr(c["quats"]), ptr(c["opacities"]), ptr(gn), ptr(vc), ptr(m2),
+         th, opt, _C.c_uint64(seed & (2 ** 64 - 1)), int(step), ptr(counts), ptr(flags), st)
+    counts = counts[:, :N]
+    incl = torch.cumsum(counts, dim=1, dtype=torch.int64)
+    pos = (incl - counts).contiguous()
+    totals = incl[:, -1] if N > 0 else torch.zeros(2 + S, dtype=torch.int64, device=dev)
+    bases = (torch.cumsum(totals, 0) - totals).contiguous()
+    tot_h = totals.tolist()                      # the one host synchronisation: the new tensor sizes
+    n_out = int(sum(tot_h))
+    src_index = torch.empty(max(n_out, 1), dtype=torch.int32, device=dev)
+    kind = torch.empty(max(n_out, 1), dtype=torch.uint8, device=dev)
+    new = {"means": torch.empty((n_out, 3), dtype=torch.float32, device=dev),
+           "scales": torch.empty((n_out, 3), dtype=torch.float32, device=dev)}
+    call("mtgs_refine_apply", N, n_out, ptr(flags), ptr(pos), ptr(bases), ptr(c["means"]), ptr(c["scales"]), ptr(c["quats"]), th, opt,
+         _C.c_uint64(seed & (2 ** 64 - 1)), int(step), ptr(src_index), ptr(kind), ptr(new["means"]), ptr(new["scales"]), st)
+
+    def rows(src, zero_new):
+        w = src.numel() // max(N, 1)
+        dst = torch.empty((n_out,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
+        call("mtgs_refine_rows", n_out, w, ptr(src.contiguous()), ptr(src_index), ptr(kind), int(zero_new), ptr(dst), st)
+        return dst
+
+    for k, t in c.items():
+        if k not in new:
+            new[k] = rows(t, False)
+    new_moments = None
+    if moments is not None:
+        new_moments = {k: (rows(a.detach(), True), rows(b.detach(), True)) for k, (a, b) in moments.items()}
+    n_split = int((flags[:N] >> 7).sum()) if N else 0
+    info = {"n_before": N, "n_after": n_out, "n_old_kept": tot_h[0], "n_children": sum(tot_h[1:1 + S]), "n_dups": tot_h[1 + S],
+            "n_split": n_split, "src_index": src_index[:n_out], "kind": kind[:n_out]}
+    return new, new_moments, info
+
+
+@torch.no_grad()
+def reset_opacities(opacities: Tensor, cfg: RefineConfig, moments: Optional[Tuple[Tensor, Tensor]] = None) -> None:
+    """The opacity reset of refinement_after (:555-572): clamp the logits at logit(2 cull_alpha_thresh), zero their moments."""
+    v = 2.0 * cfg.cull_alpha_thresh
+    opacities.clamp_(max=float(np.log(v / (1.0 - v))))
+    if moments is not None:
+        moments[0].zero_()
+        moments[1].zero_()

@@ -245,59 +245,95 @@ def iteration_nograd(P, cam, gt, mask, stats, win, W, H, shipped):
     return 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
 
 
-@torch.no_grad()
-def refine(P, stats, max_growth=0.03):
-    """Densification in miniature, after VanillaGaussianSplattingModel.refinement_after (vanilla_gaussian_splatting.py:476-577):
-    per static node, from the accumulated statistics -- average screen-space gradient = xys_grad_norm / vis_counts --
-    duplicate the small Gaussians and split the large ones among the highest-gradient few per cent, cull the nearly
-    transparent ones; the parameters become NEW leaf tensors of a different length (rigid object nodes are left alone).
-    Returns the number of Gaussians added and culled.  What matters here is that N changes under the fused path."""
+def refine_device(P, stats, opt_state_of, step, seed, growth=0.02):
+    """Densification of every static node with mtgs_amd.densify.refine_gaussians (csrc/refine.hip): the reference's rules
+    (vanilla_gaussian_splatting.py:476-699) on the device, Adam moments following their rows, samples from a generator keyed
+    by (seed, step, Gaussian index) -- identical on every rank of a data-parallel run.  The gradient threshold is set per
+    node to the (1 - growth) quantile of the average screen-space gradient so that the synthetic scene refines at a steady
+    rate (the statistics are all-reduced before, so every rank computes the same threshold).
+    Returns (added, culled, {old parameter id: (new parameter, new moments | None)})."""
+    from mtgs_amd.densify import RefineConfig, refine_gaussians
     added = culled = 0
-    surgery = []
-    for (name, p), st in zip(P.items(), stats):
+    swap = {}
+    for (name, p), st in zip(list(P.items()), stats):
         if "instance_quats" in p:
             continue
-        n = p["means"].shape[0]
-        avg = st[0] / st[1].clamp(min=1)
-        k = max(1, int(n * max_growth))
-        high = torch.zeros(n, dtype=torch.bool, device=avg.device)
-        high[torch.topk(avg, k).indices] = True
-        high &= avg > 0
-        big = torch.exp(p["scales"]).amax(dim=-1) > 0.12
-        dup, split = high & ~big, high & big
-        keep = torch.sigmoid(p["opacities"]).squeeze(-1) > 0.02
-        keep &= ~split                                   # a split Gaussian is replaced by its two halves
-        # both copies of a duplicated Gaussian get the opacity that composites to the original one
-        # (1 - (1 - a')^2 = a), so that the image does not jump at the refinement step
-        opac = p["opacities"].clone()
-        sel = dup                                        # (split samples are smaller and displaced: they keep their opacity)
-        a2 = 1 - torch.sqrt(1 - torch.sigmoid(opac[sel]).clamp(max=0.9999))
-        opac[sel] = torch.log(a2 / (1 - a2))
-        new = {}
-        n_add = int(dup.sum()) + 2 * int(split.sum())
-        for key, v in p.items():
-            surgery.append((v, keep, dup, split))        # old parameter and the row selections (for the Adam state)
-            if key == "opacities":
-                v = opac
-            parts = [v[keep], v[dup], v[split], v[split]]
-            if key == "means" and split.any():           # two halves along the LONGEST axis (rotated into the world), +- 0.45 sigma
-                sc = torch.exp(p["scales"][split])
-                local = torch.zeros_like(sc).scatter_(1, sc.argmax(dim=1, keepdim=True), 0.45 * sc.amax(dim=1, keepdim=True))
-                qn = p["quats"][split] / p["quats"][split].norm(dim=-1, keepdim=True)
-                off = torch.bmm(quat_to_rotmat_n(qn), local[:, :, None]).squeeze(-1)
-                parts[2], parts[3] = v[split] + off, v[split] - off
-            if key == "scales" and split.any():          # only that axis shrinks
-                sc = v[split]
-                shrink = torch.zeros_like(sc).scatter_(1, sc.argmax(dim=1, keepdim=True), math.log(1.6))
-                parts[2] = parts[3] = sc - shrink
-            new[key] = torch.cat(parts, 0).contiguous().requires_grad_(True)
-            surgery[-1] = surgery[-1] + (new[key],)
+        avg = st[0] / st[1]
+        thr = float(torch.quantile(avg[:: max(1, avg.numel() // 1_000_000)], 1.0 - growth))
+        cfg = RefineConfig(densify_grad_thresh=max(thr, 1e-12), densify_size_thresh=0.12, cull_alpha_thresh=0.02, refine_every=20,
+                           reset_alpha_every=10 ** 6, split_screen_size=1e9, cull_screen_size=1e9, clone_sample_means=False)
+        moments = {k: (opt_state_of(v)["exp_avg"], opt_state_of(v)["exp_avg_sq"]) for k, v in p.items()
+                   if opt_state_of(v) and "exp_avg" in opt_state_of(v)}
+        new, new_m, info = refine_gaussians({k: v.detach() for k, v in p.items()}, tuple(st), cfg, step, seed,
+                                            moments=moments or None)
+        n_new = info["n_after"]
+        for k, v in p.items():
+            q = new[k].requires_grad_(True)
+            swap[id(v)] = (v, q, new_m.get(k) if new_m else None)
+            new[k] = q
         P[name] = new
-        n_new = new["means"].shape[0]
-        added += int(dup.sum()) + 2 * int(split.sum())
-        culled += n - int(keep.sum())
-        st[0], st[1], st[2] = torch.zeros(n_new, device=avg.device), torch.ones(n_new, device=avg.device), torch.zeros(n_new, device=avg.device)
-    return added, culled, surgery
+        added += info["n_children"] + info["n_dups"]
+        culled += info["n_before"] - info["n_old_kept"]
+        dev = new["means"].device
+        st[0], st[1], st[2] = torch.zeros(n_new, device=dev), torch.ones(n_new, device=dev), torch.zeros(n_new, device=dev)
+    return added, culled, swap
+
+
+def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=None, world=1, rank=0, accumulate=1, seed=7,
+               log=print):
+    """Adam on the fused iteration.  world > 1: view-parallel data parallelism (one process per rank, camera
+    (step * world + rank) % T, ONE dense all-reduce of every gradient per step, statistics all-reduced before each
+    refinement, refinement identical on every rank).  accumulate = K in ONE process: the K cameras of a step rendered one
+    after the other with the gradients accumulated -- the single-process statement of the same training step
+    (parity for C4 is defined against it)."""
+    from mtgs_amd import dist as mdist
+    T = len(cams)
+
+    def make_opt():
+        extra = [shipped["exposure"]] if shipped else []
+        geo = [p[k] for p in P.values() for k in p if not k.startswith("features") and k != "opacities"]
+        return torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
+                                 {"params": [p["opacities"] for p in P.values()], "lr": 5e-2},      # config/MTGS.py: opacities 0.05
+                                 {"params": geo + extra, "lr": 1e-4}], foreach=True)
+
+    opt = make_opt()
+    mk = lambda: [[torch.zeros(p["means"].shape[0], device=p["means"].device), torch.ones(p["means"].shape[0], device=p["means"].device),
+                   torch.zeros(p["means"].shape[0], device=p["means"].device)] for p in P.values()]
+    stats = mk()
+    curve, sizes = [], []
+    group = max(world, accumulate)
+    for i in range(steps):
+        opt.zero_grad(set_to_none=True)
+        losses = []
+        for a in range(accumulate):
+            c = (i * group + (rank if world > 1 else a)) % T
+            losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
+        loss = torch.stack(losses).sum()
+        params = [q for g in opt.param_groups for q in g["params"]]
+        if world > 1:
+            mdist.all_reduce_grads(params)
+            torch.distributed.all_reduce(loss)
+        curve.append(float(loss) / group)
+        opt.step()
+        if refine_every and (i + 1) % refine_every == 0 and i + 1 < steps:
+            if world > 1:   # every rank must see the same statistics (vis_counts starts at ONE: counted once)
+                mdist.all_reduce_stats([t for s in stats for t in s[:2]], [s[2] for s in stats],
+                                       sum_init=[v for _ in stats for v in (0.0, 1.0)])
+            before = sum(p["means"].shape[0] for p in P.values())
+            state = {id(q): opt.state.get(q) for q in params}
+            added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed)
+            opt = make_opt()
+            for old_id, (old, new_p, mom) in swap.items():
+                st_o = state.get(old_id)
+                if st_o and mom is not None:
+                    opt.state[new_p] = {"step": st_o["step"], "exp_avg": mom[0], "exp_avg_sq": mom[1]}
+            for grp in opt.param_groups:      # untouched parameters (object nodes, exposure) keep their whole state
+                for q in grp["params"]:
+                    if q not in opt.state and state.get(id(q)):
+                        opt.state[q] = state[id(q)]
+            sizes.append(sum(p["means"].shape[0] for p in P.values()))
+            log(f"step {i + 1}: refine {before} -> {sizes[-1]} Gaussians (+{added} -{culled})")
+    return curve, sizes
 
 
 def main():
@@ -312,10 +348,12 @@ def main():
     ap.add_argument("--shipped", action="store_true", help="the option set of config/MTGS.py: predict_normals (7 blended channels), "
                     "exposure model, inverse-depth and normal losses")
     ap.add_argument("--steps", type=int, default=0)
-    ap.add_argument("--debug-refine", action="store_true")
     ap.add_argument("--refine-every", type=int, default=0, help="with --steps: densify (duplicate / split / cull) every so many steps")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", choices=["both", "fused", "chain"], default="both", help="profiling aid: time one variant only")
+    ap.add_argument("--dp", action="store_true", help="with --steps: view-parallel data parallelism under torch.distributed.run "
+                    "(one camera per rank and step, dense gradient all-reduce, rank-identical refinement)")
+    ap.add_argument("--accumulate", type=int, default=1, help="with --steps: cameras per step in ONE process (gradient accumulation)")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
@@ -429,61 +467,42 @@ def main():
               f"{wall:.3f} ms wall ({gpu:.3f} ms between GPU events); capacities {caps}; loss eager {l_e} graph {l_g}")
         assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(l_e, l_g)), (l_e, l_g)
         return
-    if args.only != "both":
+    if args.only != "both" and not args.steps:
         t1, l1, _ = timed(args.only == "fused")
         print(f"{args.only}: {t1:.2f} ms per iteration, loss {l1:.6f}")
         return
-    tc, lc, sc = timed(False)
-    tf, lf, sf = timed(True)
-    n_all = sum(p["means"].shape[0] for p in P.values())
-    print(f"{n_all} Gaussians in {len(P)} nodes ({T} traversals), {W}x{H}: iteration (fwd + loss + bwd + statistics) "
-          f"chain {tc:.2f} ms -> fused {tf:.2f} ms ({tc / tf:.2f}x); loss chain {lc:.6f} fused {lf:.6f}")
-    assert abs(lc - lf) <= (2e-4 if shipped else 2e-5) * max(1.0, abs(lc)), (lc, lf)
-    for a, b in zip(sc, sf):
-        assert torch.allclose(a[1], b[1]) and torch.allclose(a[2], b[2])
+    if args.only == "both":
+      tc, lc, sc = timed(False)
+      tf, lf, sf = timed(True)
+      n_all = sum(p["means"].shape[0] for p in P.values())
+      print(f"{n_all} Gaussians in {len(P)} nodes ({T} traversals), {W}x{H}: iteration (fwd + loss + bwd + statistics) "
+            f"chain {tc:.2f} ms -> fused {tf:.2f} ms ({tc / tf:.2f}x); loss chain {lc:.6f} fused {lf:.6f}")
+      assert abs(lc - lf) <= (2e-4 if shipped else 2e-5) * max(1.0, abs(lc)), (lc, lf)
+      for a, b in zip(sc, sf):
+          assert torch.allclose(a[1], b[1]) and torch.allclose(a[2], b[2])
     if args.steps:
-        def make_opt():
-            extra = [shipped["exposure"]] if shipped else []
-            return torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
-                                     {"params": [p[k] for p in P.values() for k in p if not k.startswith("features")] + extra, "lr": 1e-4}],
-                                    foreach=True)
-        opt = make_opt()
-        stats = mk_stats()
-        curve = []
-        for i in range(args.steps):
-            opt.zero_grad(set_to_none=True)
-            curve.append(float(iteration(P, cams[i % T], targets[i % T], mask, True, stats, win, W, H, shipped=shipped)))
-            opt.step()
-            if args.refine_every and (i + 1) % args.refine_every == 0 and i + 1 < args.steps:
-                before = sum(p["means"].shape[0] for p in P.values())
-                full_state = {id(q): opt.state[q] for q in opt.state}
-                added, culled, surgery = refine(P, stats)
-                # the Adam moments follow their rows, in the spirit of MTGS's remove_from_optim / dup_in_optim
-                # (vanilla_gaussian_splatting.py:392-446; there the new rows start from zero moments)
-                old_state = {id(o): opt.state.get(o) for o, _, _, _, _ in surgery}
-                opt = make_opt()
-                for o, keep, dup, split, new_p in surgery:
-                    st_o = old_state.get(id(o))
-                    if st_o:   # new rows inherit the moments of their source row (zeros would make their first steps ~3x larger)
-                        pad = lambda t: torch.cat([t[keep], t[dup], t[split], t[split]], 0)
-                        opt.state[new_p] = {"step": st_o["step"], "exp_avg": pad(st_o["exp_avg"]), "exp_avg_sq": pad(st_o["exp_avg_sq"])}
-                # the untouched parameters (object nodes, exposure) keep their whole state
-                for grp in opt.param_groups:
-                    for q in grp["params"]:
-                        if q not in opt.state and id(q) in full_state:
-                            opt.state[q] = full_state[id(q)]
-                if args.debug_refine:
-                    with torch.no_grad():
-                        for mode in ("after",):
-                            l_dbg = float(iteration_nograd(P, cams[i % T], targets[i % T], mask, stats, win, W, H, shipped))
-                    print(f"   loss at camera {i % T}: before step {curve[-1]:.4f}, right after refine {l_dbg:.4f}")
-                print(f"step {i + 1}: refine {before} -> {sum(p['means'].shape[0] for p in P.values())} Gaussians (+{added} -{culled})")
+        rank, world = 0, 1
+        if args.dp:
+            from mtgs_amd import dist as mdist
+            rank, _, world = mdist.init_from_env()
+        log = print if rank == 0 else (lambda *a, **k: None)
+        curve, sizes = train_loop(P, cams, targets, mask, win, W, H, args.steps, args.refine_every, shipped=shipped, world=world,
+                                  rank=rank, accumulate=args.accumulate, log=log)
         k = max(1, args.steps // 8)
-        print("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
+        log("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
+        n_now = sum(p["means"].shape[0] for p in P.values())
+        if args.dp:
+            t = torch.tensor([n_now, -n_now], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            assert int(t[0]) == n_now and int(-t[1]) == n_now, "N differs between the ranks"
+            log(f"{world} ranks: N = {n_now} on every rank after {len(sizes)} refinements")
+            torch.distributed.destroy_process_group()
         if args.refine_every:
-            # the synthetic scene starts from the TRUE geometry, so every split perturbs a correct model: the run checks
-            # that N can change under the fused path (tables, statistics, optimizer state) and that training keeps working
-            assert all(math.isfinite(c) for c in curve) and min(curve) < 0.7 * curve[0] and curve[-1] < 1.2 * curve[0], curve[-5:]
+            # the synthetic scene starts from the TRUE geometry and the reference's duplication is not image-preserving (a
+            # clone doubles its parent's contribution until the opacities adapt), so every refinement perturbs a correct
+            # model: the run checks that N can change under the fused path (tables, statistics, optimizer state) and
+            # that training keeps working
+            assert all(math.isfinite(c) for c in curve) and min(curve) < 0.7 * curve[0] and curve[-1] < 1.5 * curve[0], curve[-5:]
         else:
             assert sum(curve[-T:]) < 0.7 * sum(curve[:T]), "training did not reduce the loss"
 

@@ -1,6 +1,7 @@
 """mtgs_amd.densify.update_statistics against the reference's masked-tensor formulation
 (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:1157-1183 and
  /root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:448-474), restated line by line."""
+import numpy as np
 import pytest
 import torch
 
@@ -67,3 +68,72 @@ def test_update_statistics_all_nodes_one_launch(hip_lib):
     for sa, sb in zip(a, b):
         for x, y in zip(sa, sb):
             assert torch.equal(x, y)
+
+
+def _refine_case(N, seed, T=None):
+    g = torch.Generator().manual_seed(seed)
+    p = {"means": (torch.rand(N, 3, generator=g) * 2 - 1) * torch.tensor([60.0, 8.0, 140.0]),   # some beyond |x| = 100
+         "scales": torch.log(torch.rand(N, 3, generator=g) * 0.6 + 0.01), "quats": torch.randn(N, 4, generator=g) * 1.7,
+         "opacities": torch.randn(N, 1, generator=g) * 3.0, "features_dc": torch.randn(N, 3, generator=g)}
+    if T is None:
+        p["features_rest"] = torch.randn(N, 15, 3, generator=g)
+    else:                                            # multi-colour node: per-traversal appearance tensors
+        p["features_rest"] = torch.randn(N, T, 15, 3, generator=g)
+        p["features_adapters"] = torch.randn(N, T, 3, generator=g)
+    stats = (torch.rand(N, generator=g) * 0.004 * 7, torch.randint(1, 12, (N,), generator=g).float(),
+             torch.rand(N, generator=g) * 180.0)
+    moments = {k: (torch.randn(v.shape, generator=g), torch.rand(v.shape, generator=g)) for k, v in p.items()}
+    return p, stats, moments
+
+
+@pytest.mark.parametrize("step,clone,T", [(500, True, None), (4000, True, None), (4000, False, 3), (16000, True, None)])
+def test_refinement_on_device_equals_the_reference_restatement(hip_lib, step, clone, T):
+    """split / duplicate / cull + optimizer-moment surgery of one node (mtgs_amd.densify.refine_gaussians, csrc/refine.hip)
+    against the numpy restatement of refinement_after (oracle/refine_oracle.py, which follows the reference line by line),
+    fed with the SAME samples (Philox4x32-10 keyed by seed / step / index / slot, restated in numpy): masks, counts and
+    order identical, every row equal.  Steps: before the world-size cull starts (500), with every rule on (4000), after
+    the screen-size rules stop (16000 with stop_split_at raised)."""
+    from mtgs_amd.densify import RefineConfig, refine_gaussians
+    from oracle import refine_oracle as ro
+    N, seed = 20000, 1234567
+    cfg = RefineConfig(clone_sample_means=clone, stop_split_at=20000)
+    p, stats, moments = _refine_case(N, seed=step, T=T)
+    dev = torch.device("cuda")
+    new, new_m, info = refine_gaussians({k: v.to(dev) for k, v in p.items()}, tuple(s.to(dev) for s in stats), cfg, step, seed,
+                                        moments={k: (a.to(dev), b.to(dev)) for k, (a, b) in moments.items()})
+    ref, ref_m, masks = ro.refinement_after({k: v.numpy() for k, v in p.items()}, tuple(s.numpy() for s in stats), cfg, step,
+                                            lambda idx, slot: ro.normals3(seed, step, idx, slot),
+                                            moments={k: (a.numpy(), b.numpy()) for k, (a, b) in moments.items()})
+    n_ref = ref["means"].shape[0]
+    assert masks["splits"].sum() > 200 and masks["dups"].sum() > 200 and (~masks["keep"]).sum() > 200, "the case must exercise every branch"
+    assert info["n_after"] == n_ref, (info["n_after"], n_ref)
+    assert info["n_split"] == int(masks["splits"].sum())
+    assert np.array_equal(info["src_index"].cpu().numpy(), masks["src_index"]) and np.array_equal(info["kind"].cpu().numpy(), masks["kind"])
+    for k in ref:
+        got = new[k].cpu().numpy().astype(np.float64)
+        assert got.shape == ref[k].shape, k
+        tol = 2e-5 if k == "means" else 2e-6          # (means: float32 Box-Muller + rotation against float64)
+        assert np.abs(got - ref[k]).max() <= tol * max(1.0, np.abs(ref[k]).max()), (k, np.abs(got - ref[k]).max())
+        for j in (0, 1):
+            gm = new_m[k][j].cpu().numpy().astype(np.float64)
+            assert np.array_equal(gm, ref_m[k][j].astype(np.float32).astype(np.float64)), (k, j)   # moments: copied or zero, exactly
+
+
+def test_refinement_is_deterministic_across_launches_and_keys(hip_lib):
+    """The same (seed, step) gives bit-identical tensors on every call -- what keeps the ranks of a data-parallel job in
+    lockstep without a broadcast; another step or seed gives other samples."""
+    from mtgs_amd.densify import RefineConfig, refine_gaussians
+    cfg = RefineConfig()
+    p, stats, _ = _refine_case(5000, seed=3)
+    dev = torch.device("cuda")
+    pd, sd = {k: v.to(dev) for k, v in p.items()}, tuple(s.to(dev) for s in stats)
+    a, _, ia = refine_gaussians(pd, sd, cfg, 4000, 99)
+    b, _, ib = refine_gaussians({k: v.clone() for k, v in pd.items()}, sd, cfg, 4000, 99)
+    assert ia["n_after"] == ib["n_after"] and all(torch.equal(a[k], b[k]) for k in a)
+    c, _, _ = refine_gaussians(pd, sd, cfg, 4100, 99)
+    d, _, _ = refine_gaussians(pd, sd, cfg, 4000, 100)
+    assert c["means"].shape == a["means"].shape and not torch.equal(c["means"], a["means"])
+    assert not torch.equal(d["means"], a["means"])
+    # empty node and a node where nothing changes
+    e, _, ie = refine_gaussians({k: v[:0] for k, v in pd.items()}, tuple(s[:0] for s in sd), cfg, 4000, 1)
+    assert ie["n_after"] == 0 and e["means"].shape == (0, 3)

@@ -190,3 +190,35 @@ def test_mtgs_like_iteration_fused_equals_chain_and_trains():
                        capture_output=True, text=True, timeout=600, cwd=str(root))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "fused" in r.stdout and "loss:" in r.stdout
+
+
+def test_mtgs_like_training_data_parallel_keeps_ranks_in_lockstep():
+    """BASELINE configs[4] in miniature under view-parallel data parallelism (scripts/mtgs_like_train.py --dp, two ranks
+    on the test box's GPU over gloo): one camera per rank and step, one gradient all-reduce, statistics all-reduced,
+    device-side refinement with rank-independent samples -- N must be identical on both ranks after three refinements, and
+    the loss curve must equal the SINGLE-process run that renders the two cameras of every step one after the other and
+    accumulates their gradients (the definition of parity for the data-parallel step)."""
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "4", "--width", "320", "--height", "200", "--steps",
+              "65", "--refine-every", "20", "--reps", "1", "--only", "fused"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), str(root / "scripts" / "mtgs_like_train.py"), "--dp"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert dp.returncode == 0, dp.stdout[-1500:] + dp.stderr[-2500:]
+    assert "2 ranks: N = " in dp.stdout and dp.stdout.count("refine ") == 3, dp.stdout[-800:]
+    one = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--accumulate", "2"] + common,
+                         capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-2500:]
+    sizes = lambda out: re.findall(r"refine (\d+) -> (\d+) Gaussians", out)
+    assert sizes(dp.stdout) == sizes(one.stdout) and len(sizes(dp.stdout)) == 3, (sizes(dp.stdout), sizes(one.stdout))
+    curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
+    a, b = curve(dp.stdout), curve(one.stdout)
+    assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
