@@ -223,6 +223,13 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
                    const int32_t *tile_order, void *stream);
 
+/* ---- Fourier-series features_dc of rigid object nodes (rigid_node.py:217-221; csrc/fourier.hip) -------------------------
+ * dc[N,3] = sum_f features_dc[N,F,3] * w[F]  (F <= 32; w = IDFT(x) computed by the caller, utils.py:335-352).
+ * bwd: v_features_dc[N,F,3] = w[f] * v_dc[N,3]; partial_w[ceil(3N/256), F] (nullable): per-block partial sums of v_w. */
+int mtgs_fourier_dc_fwd(int64_t N, int F, const float *features_dc, const float *w, float *dc, void *stream);
+int mtgs_fourier_dc_bwd(int64_t N, int F, const float *features_dc, const float *w, const float *v_dc,
+                        float *v_features_dc, float *partial_w, void *stream);
+
 /* ---- densification of a Gaussian node on the device (csrc/refine.hip) -------------------
  * Restates refinement_after / split_gaussians / dup_gaussians / cull_gaussians + the optimizer surgery of
  * mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:392-446, 476-699.

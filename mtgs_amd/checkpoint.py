@@ -57,21 +57,26 @@ def node_kind(params: Mapping[str, Tensor]) -> str:
     """'vanilla' | 'multicolor' | 'rigid' (instance poses only, rigid_node.py:85-112) | 'dynamic' (anything else:
     deformation networks, Fourier features ...)."""
     extra = [k for k in params if k not in GAUSS_PARAM_NAMES]
-    if extra:
-        rigid = set(extra) == set(RIGID_KEYS) and params["features_dc"].dim() == 2
-        return "rigid" if rigid else "dynamic"
+    if extra:   # (a rigid node's features_dc is [N,3], or [N,F,3] with Fourier features: rigid_node.py:217-229)
+        return "rigid" if set(extra) == set(RIGID_KEYS) else "dynamic"
     return "multicolor" if "features_adapters" in params else "vanilla"
 
 
 def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_worlds: Tensor, sh_degree_to_use: int,
                       model_sh_degree: int = 3, traversal_index: Optional[int] = None,
                       node_names: Optional[Iterable[str]] = None, device="cuda",
-                      frame_idx: Optional[int] = None) -> Dict[str, Tensor]:
-    """means / scales / quats / opacities / rgbs / model_id of the listed static nodes, activated by
+                      frame_idx: Optional[int] = None, timestamp: Optional[float] = None,
+                      frame_timestamps: Optional[Tensor] = None, fourier: Optional[Mapping] = None) -> Dict[str, Tensor]:
+    """means / scales / quats / opacities / rgbs / model_id of the listed nodes, activated by
     mtgs_amd.nodes.node_gaussians and concatenated in order (MTGSSceneModel.get_gaussians,
     mtgs_scene_graph.py:408-461).  Multi-colour nodes need `traversal_index` (get_pertravel_features,
-    multi_color_gaussian_splatting.py:77-86; None = the shared colour only, as eval_mode 'null')."""
-    from .nodes import collect_gaussians as _collect
+    multi_color_gaussian_splatting.py:77-86; None = the shared colour only, as eval_mode 'null').
+    Rigid nodes are posed for `frame_idx`, or BETWEEN frames for `timestamp` + `frame_timestamps`
+    (RigidSubModel.get_object_pose, rigid_node.py:127-166; objects that are not in the frame are left out, as
+    get_gaussians returns None for them).  Rigid nodes with Fourier colours (features_dc[N,F,3]) need
+    `fourier = {"x": normalised timestamp (temporal) | None (spatial: the camera-object yaw is computed), "scale": ..,
+    "space": "temporal" | "spatial"}` -- the node's portable_config (rigid_node.py:114-125)."""
+    from .nodes import cam_obj_yaw, collect_gaussians as _collect, fourier_features_dc, object_pose
     names = list(nodes.keys()) if node_names is None else list(node_names)
     specs = []
     for name in names:
@@ -81,10 +86,21 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
             # RigidSubModel.get_object_pose (rigid_node.py:127-144): static objects store one pose, moving ones one per frame
             iq, it = p.pop("instance_quats"), p.pop("instance_trans")
             if it.dim() > 1:
-                if frame_idx is None:
-                    raise ValueError(f"collect_gaussians: rigid node {name!r} has per-frame poses: pass frame_idx")
-                iq, it = iq[frame_idx] / iq[frame_idx].norm(dim=-1, keepdim=True), it[frame_idx]
+                if frame_idx is None and timestamp is None:
+                    raise ValueError(f"collect_gaussians: rigid node {name!r} has per-frame poses: pass frame_idx (or timestamp)")
+                iq, it = object_pose(iq, it, frame_idx=frame_idx, timestamp=timestamp, frame_timestamps=frame_timestamps)
+                if iq is None:
+                    continue                      # not in this frame
             p["instance_quat"], p["instance_trans"] = iq.contiguous(), it.contiguous()
+            if p["features_dc"].dim() == 3:       # Fourier-series colour (rigid_node.py:217-229)
+                if fourier is None:
+                    raise ValueError(f"collect_gaussians: rigid node {name!r} has Fourier features_dc {tuple(p['features_dc'].shape)}: "
+                                     "pass fourier={'x', 'scale', 'space'}")
+                space = fourier.get("space", "temporal")
+                x = fourier.get("x")
+                if space == "spatial":
+                    x = cam_obj_yaw(camera_to_worlds.to(device), iq)
+                p["features_dc"] = fourier_features_dc(p["features_dc"], x, fourier.get("scale", 1.0), space)
         if kind == "dynamic":
             raise NotImplementedError(f"collect_gaussians: node {name!r} carries per-frame state "
                                       f"({sorted(k for k in p if k not in GAUSS_PARAM_NAMES)[:3]}...); only vanilla, "

@@ -14,6 +14,7 @@ No CPU / PyTorch fallback (mtgs_amd._lib raises without the HIP library).
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional
 
 import numpy as np
@@ -494,3 +495,105 @@ def camera_space_normals(quats: Tensor, scales: Tensor, means: Tensor, camera_to
     assert camera_to_worlds.shape[-2:] == (3, 4) and camera_to_worlds.numel() == 12, camera_to_worlds.shape
     assert rgbs is None or rgbs.shape == (N, 3), rgbs.shape
     return _CameraSpaceNormals.apply(quats, scales, means, camera_to_worlds, rgbs)
+
+
+# ------------------------------------------------------------------------------------ rigid nodes: pose between frames, Fourier colour
+def interpolate_quats(q1: Tensor, q2: Tensor, fraction) -> Tensor:
+    """mtgs utils.interpolate_quats (utils.py:201-233): slerp with the nlerp branch above dot 0.9995, result normalised.
+    Device-side torch (8 floats), differentiable like the reference."""
+    q1 = q1[None] if q1.dim() == 1 else q1
+    q2 = q2[None] if q2.dim() == 1 else q2
+    q1 = q1 / torch.norm(q1, dim=-1, keepdim=True)
+    q2 = q2 / torch.norm(q2, dim=-1, keepdim=True)
+    dot = torch.clamp((q1 * q2).sum(dim=-1, keepdim=True), -1, 1)
+    q2 = torch.where(dot < 0, -q2, q2)
+    dot = torch.abs(dot)
+    similar = dot > 0.9995
+    lin = q1 + fraction * (q2 - q1)
+    theta_0 = torch.acos(dot)
+    theta = theta_0 * fraction
+    s2 = torch.sin(theta) / torch.sin(theta_0)
+    s1 = torch.cos(theta) - dot * s2
+    out = torch.where(similar, lin, s1 * q1 + s2 * q2)
+    return out / torch.norm(out, dim=-1, keepdim=True)
+
+
+def object_pose(instance_quats: Tensor, instance_trans: Tensor, frame_idx: Optional[int] = None, timestamp=None,
+                frame_timestamps: Optional[Tensor] = None, in_frame_mask: Optional[Tensor] = None, num_frames: Optional[int] = None):
+    """RigidSubModel.get_object_pose (rigid_node.py:127-166) for a non-static object: (quat[4], trans[3]) of the frame, or
+    (None, None) when the object is not in it.  With `frame_idx` the normalised row; otherwise the pose BETWEEN the two
+    frames adjacent to `timestamp` (slerp of the quaternions, lerp of the translations); a timestamp that matches a frame
+    returns that row as stored (the reference does not normalise it there, :155-157).
+    The frame search reads three scalars back (as the reference's `if not in_frame_mask[...]` does)."""
+    F = instance_quats.shape[0] if num_frames is None else num_frames
+    if frame_idx is not None:
+        if frame_idx >= F or (in_frame_mask is not None and not bool(in_frame_mask[frame_idx])):
+            return None, None
+        q = instance_quats[frame_idx]
+        return q / q.norm(dim=-1, keepdim=True), instance_trans[frame_idx]
+    assert timestamp is not None and frame_timestamps is not None, "frame_idx, or timestamp + frame_timestamps"
+    ts = frame_timestamps.to(instance_quats.device)
+    diffs = timestamp - ts
+    inf = torch.full_like(diffs, float("inf"))
+    prev_f = int(torch.argmin(torch.where(diffs >= 0, diffs, inf)))
+    next_f = int(torch.argmin(torch.where(diffs <= 0, -diffs, inf)))
+    if in_frame_mask is not None and not (bool(in_frame_mask[next_f]) and bool(in_frame_mask[prev_f])):
+        return None, None
+    if next_f == prev_f:
+        return instance_quats[next_f], instance_trans[next_f]
+    t = (timestamp - ts[prev_f]) / (ts[next_f] - ts[prev_f])
+    return (interpolate_quats(instance_quats[prev_f], instance_quats[next_f], t).squeeze(0),
+            torch.lerp(instance_trans[prev_f], instance_trans[next_f], t))
+
+
+def idft_weights(x, dim: int, input_normalized: bool = True, device=None) -> Tensor:
+    """mtgs utils.IDFT (utils.py:335-352) for ONE x: w[dim], cos on the even indices, sin(index + 1) on the odd ones."""
+    x = torch.as_tensor(x, dtype=torch.float32, device=device).reshape(())
+    idx = torch.arange(dim, dtype=torch.float32, device=x.device)
+    odd = (torch.arange(dim, device=x.device) % 2) == 1
+    k = torch.where(odd, idx + 1, idx)
+    ang = x * k * (2 * math.pi / dim) if input_normalized else x * k
+    return torch.where(odd, torch.sin(ang), torch.cos(ang))
+
+
+class _FourierDC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features_dc, w):
+        require_gpu(features_dc, w)
+        ctx.w_shape = w.shape
+        f, w = features_dc.contiguous(), w.to(torch.float32).reshape(-1).contiguous()
+        N, F = f.shape[0], f.shape[1]
+        assert w.numel() == F, (w.shape, f.shape)
+        dc = torch.empty((N, 3), dtype=torch.float32, device=f.device)
+        call("mtgs_fourier_dc_fwd", N, F, ptr(f), ptr(w), ptr(dc), stream_of(f))
+        ctx.save_for_backward(f, w)
+        return dc
+
+    @staticmethod
+    def backward(ctx, v_dc):
+        f, w = ctx.saved_tensors
+        N, F = f.shape[0], f.shape[1]
+        v_f = torch.empty_like(f)
+        nblk = (N * 3 + 255) // 256
+        part = torch.empty((max(nblk, 1), F), dtype=torch.float32, device=f.device) if ctx.needs_input_grad[1] else None
+        call("mtgs_fourier_dc_bwd", N, F, ptr(f), ptr(w), ptr(v_dc.contiguous()), ptr(v_f), ptr(part), stream_of(f))
+        v_w = None
+        if part is not None:
+            v_w = (part.sum(0) if N > 0 else torch.zeros_like(w)).reshape(ctx.w_shape)
+        return v_f, v_w
+
+
+def fourier_features_dc(features_dc: Tensor, x, scale: float = 1.0, space: str = "temporal") -> Tensor:
+    """RigidSubModel.get_true_features_dc / get_fourier_features (rigid_node.py:217-229): features_dc[N,F,3] ->
+    true_features_dc[N,3] for the frame's normalised timestamp (space 'temporal') or the camera-object yaw ('spatial')."""
+    assert features_dc.dim() == 3 and features_dc.shape[2] == 3, features_dc.shape
+    w = idft_weights(torch.as_tensor(x, device=features_dc.device) * scale, features_dc.shape[1], space == "temporal",
+                     device=features_dc.device)
+    return _FourierDC.apply(features_dc, w)
+
+
+def cam_obj_yaw(camera_to_world: Tensor, quat_cur_frame: Tensor) -> Tensor:
+    """RigidSubModel.get_cam_obj_yaw (rigid_node.py:231-237)."""
+    w, x, y, z = quat_cur_frame.unbind(-1)
+    r00, r02 = 1 - 2 * (y * y + z * z), 2 * (x * z + w * y)        # quat_to_rotmat rows (utils.py:14-40)
+    return torch.atan2(camera_to_world[..., 0, 0], camera_to_world[..., 0, 2]) - torch.atan2(r00, r02)

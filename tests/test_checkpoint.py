@@ -75,3 +75,46 @@ def test_collect_and_render_checkpoint(hip_lib):
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], gs["rgbs"], vm.cuda(),
                                         K.cuda(), 160, 120, packed=False, render_mode="RGB+ED")
     assert render.shape == (1, 120, 160, 4) and torch.isfinite(render).all() and float(alpha.max()) > 0.1
+
+
+@pytest.mark.gpu
+def test_rigid_node_between_frames_and_fourier_colour(hip_lib):
+    """A rigid node posed BETWEEN two frames (timestamp interpolation, rigid_node.py:145-166) and coloured by a Fourier
+    series of the normalised timestamp (rigid_node.py:217-229): collect_gaussians against the reference composition in
+    torch (interpolate_quats / IDFT restated in mtgs_amd.nodes and pinned by reference vectors in test_ply_and_pose.py)."""
+    import numpy as np
+    from pathlib import Path
+    from mtgs_amd import checkpoint as ck
+    from mtgs_amd.nodes import fourier_features_dc, interpolate_quats
+    g = torch.Generator().manual_seed(4)
+    n, F, frames = 70, 5, 6
+    node = {"means": torch.randn(n, 3, generator=g), "scales": torch.randn(n, 3, generator=g) * 0.3 - 2, "quats": torch.randn(n, 4, generator=g),
+            "opacities": torch.randn(n, 1, generator=g), "features_dc": torch.randn(n, F, 3, generator=g),
+            "features_rest": torch.randn(n, 15, 3, generator=g) * 0.1, "instance_quats": torch.randn(frames, 4, generator=g),
+            "instance_trans": torch.randn(frames, 3, generator=g) * 4}
+    ts = torch.arange(frames, dtype=torch.float32) * 0.1
+    c2w = torch.eye(4)[None, :3]
+    gs = ck.collect_gaussians({"car": node}, c2w, 3, timestamp=0.23, frame_timestamps=ts,
+                              fourier={"x": 0.23 / 0.5, "scale": 1.0, "space": "temporal"})
+    t = (0.23 - 0.2) / 0.1
+    q = interpolate_quats(node["instance_quats"][2].double(), node["instance_quats"][3].double(), t).squeeze(0)
+    tr = torch.lerp(node["instance_trans"][2].double(), node["instance_trans"][3].double(), torch.tensor(t, dtype=torch.float64))
+    w, x, y, z = q.tolist()
+    R = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=torch.float64)
+    assert torch.allclose(gs["means"].cpu().double(), node["means"].double() @ R.T + tr, atol=2e-5)
+    # the Fourier kernel against the reference-generated vectors (value, gradient of the parameter and of the weights)
+    zf = np.load(Path(__file__).resolve().parent / "golden" / "pose_fourier_ref.npz")
+    for name in ("t5", "t8", "s6", "s1"):
+        fdc = torch.from_numpy(zf[f"four_{name}_fdc"]).float().cuda().requires_grad_(True)
+        from mtgs_amd.nodes import _FourierDC
+        wv = torch.from_numpy(zf[f"four_{name}_w"]).float().cuda().requires_grad_(True)
+        dc = _FourierDC.apply(fdc, wv)
+        assert np.abs(dc.detach().cpu().numpy() - zf[f"four_{name}_dc"]).max() < 5e-6 * max(1.0, np.abs(zf[f"four_{name}_dc"]).max())
+        (dc * torch.from_numpy(zf[f"four_{name}_G"]).float().cuda()).sum().backward()
+        assert np.abs(fdc.grad.cpu().numpy() - zf[f"four_{name}_g_fdc"]).max() < 5e-6 * np.abs(zf[f"four_{name}_g_fdc"]).max()
+        assert np.abs(wv.grad.cpu().numpy() - zf[f"four_{name}_g_w"]).max() < 2e-5 * max(1.0, np.abs(zf[f"four_{name}_g_w"]).max())
+    x = float(zf["four_t5_x"])
+    dc = fourier_features_dc(torch.from_numpy(zf["four_t5_fdc"]).float().cuda(), x, 1.0, "temporal")
+    assert np.abs(dc.cpu().numpy() - zf["four_t5_dc"]).max() < 1e-5 * max(1.0, np.abs(zf["four_t5_dc"]).max())
