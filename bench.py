@@ -56,6 +56,8 @@ def parse_args():
                          "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
                          "dense = plain all-reduce of every gradient tensor")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-also", action="store_true", help="skip the untimed extras (forward-only rate, shipped 7-channel cells): "
+                                                            "profiling runs, so that the trace holds the headline step only")
     return ap.parse_args()
 
 
@@ -288,7 +290,7 @@ def main():
     # outside the timed region: the forward-only rate SURVEY.md section 8(d) asks to be reported beside the headline
     # (what eval / the viewer run: the same calls under no_grad)
     fwd_ms = None
-    if world == 1:
+    if world == 1 and not args.no_also:
         params_were = [p.requires_grad for p in all_params]
         with torch.no_grad():
             for _ in range(2):
