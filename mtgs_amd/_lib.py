@@ -53,8 +53,12 @@ _SIGNATURES = {
     "mtgs_bin_finalize": [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_front_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_front_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32,
-                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32,
+                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32,
                        _vp, _vp, _i64, _vp, _sz, _vp],
+    "mtgs_bin3_supported": [_i32, _i32, _i32, _i64],
+    "mtgs_bin3_workspace_bytes": [_i32, _i32, _i32, _i64, _i64, C.POINTER(_sz)],
+    "mtgs_bin3_build": [_i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                        _vp, _sz, _vp],
     "mtgs_bin2_supported": [_i32, _i32, _i32, _i64],
     "mtgs_bin2_workspace_bytes": [_i32, _i32, _i32, _i64, _i64, C.POINTER(_sz)],
     "mtgs_bin2_build": [_i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -113,7 +117,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 

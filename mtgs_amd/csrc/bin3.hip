@@ -1,0 +1,645 @@
+// bin3.hip -- tile binning of the fused rasterization path WITHOUT a global sort.
+//
+// Same result as gsplat 1.4.0 isect_tiles(sort=True) + isect_offset_encode (the binning stage of
+// gsplat.rendering.rasterization, /root/reference/mtgs/scene_model/mtgs_scene_graph.py:641-662): flatten_ids,
+// isect_ids and isect_offsets are bit-identical (tests/test_gpu_parity.py, tests/test_gpu_fused.py).
+//
+// gsplat sorts all M intersections on a 64-bit (camera | tile | depth) key: six radix passes over 12-byte pairs.
+// bin2.hip sorts the visible Gaussians by depth and then the intersections on the tile bits: 4 + 2 passes.  Here no
+// array is sorted globally at all.  The order gsplat defines is "by tile, then by depth, then by Gaussian index"; which
+// intersections belong to a tile does not depend on any order, only their arrangement INSIDE the tile's list does:
+//   1. bin3_rows_{count,place}_kernel   (Gaussian, tile row) ITEMS grouped by row: 3.6 per visible Gaussian; the
+//                             count pass hands every (workgroup, row) pair its base inside the row's segment with one
+//                             returning atomic, the place pass numbers the items with LDS atomics;
+//   2. bin3_tiles_count_kernel   a workgroup's 1024 items lie in one or two rows, so the tiles they cover are a short
+//                             range of the LDS histogram: per-tile counts; the block that finishes last turns them into
+//                             isect_offsets and into the longest-list-first dispatch order of the tiles;
+//   3. bin3_tiles_place_kernel   the items are expanded into intersections: a workgroup reserves its slots in a tile's
+//                             segment with one returning atomic per (workgroup, tile) and stores the 64-bit keys
+//                             depth bits << 32 | rank  in runs of ~30: the segments now hold the right SETS, unordered;
+//   4. bin3_sort_{small,large}_kernel   every tile's segment is sorted on that key by ONE workgroup (or one wave)
+//                             in LDS -- a bitonic network run eight keys per thread, three stages per LDS round
+//                             trip -- and written out as rank_ids, flatten_ids and gsplat's isect_ids.  rank order ==
+//                             Gaussian index order, so the key order IS gsplat's (tile, depth, index) order, and the
+//                             result does not depend on the order in which the atomics of steps 1-3 were served.
+// Why two levels: a scatter of the M intersections straight into 8160 tile segments is M single 8-byte stores to random
+// lines (measured 63 us for 4M, with or without a per-intersection atomic: 85 us); splitting by row first keeps every
+// store run long -- the principle of an MSD radix sort, applied to the 1.1M row items instead of the 4M intersections.
+// Segments longer than the LDS holds (16384 keys) are sorted in 16384-key chunks and merged through global memory
+// by the same workgroup.
+// Every kernel reads its element count from device memory and its grid is sized for a CAPACITY (speculative sizing /
+// graph capture, see wrapper.py); seven launches per frame.
+//
+// Roofline: HBM / latency for 1-3 (rows 2 * n_vis*64 + items*8; tiles items*8*2 + M*8), LDS / VALU for 4
+// (M*(8+16) bytes of HBM against ~log2(L)^2/2 compare-exchanges per key).
+#include "common.hpp"
+#include "tile_rect.hpp"
+#include "onesweep.hpp"
+#include "raster_rec.hpp"
+
+namespace {
+
+using mtgs_os::SizeRef;
+
+constexpr int B3_BLOCK = 256;
+constexpr int MAX_BINS = 12288;  // (camera, tile) pairs whose counts fit the histogram kernel's LDS
+
+// ---- 1. row items: (Gaussian, tile row) pairs grouped by row ------------------------------------------------------
+// An item = {rank, first tile of the Gaussian in this row << 14 | number of tiles - 1}.
+struct Item { uint32_t rank, span; };
+constexpr int SPAN_BITS = 14;   // tile ids and row widths below 2^14 (MAX_BINS)
+constexpr int MAX_ROWS = 1024;  // (camera, tile row) bins of the row kernels' LDS histogram
+
+struct RowGeom { int row0, h, tile0, w; };   // first (camera, row) bin, rows, first tile id of the first row, tiles per row
+__device__ __forceinline__ RowGeom row_geom(const float *__restrict__ recs, const int32_t *__restrict__ vis_ids, int64_t rank,
+                                            int64_t N, int C, float ts, int tw, int th) {
+    const float *rec = recs + rank * REC_FLOATS;
+    const float2 m = *reinterpret_cast<const float2 *>(rec);
+    const Rect q = tile_rect(m.x, m.y, __float_as_int(rec[7]), ts, tw, th);
+    const int cam = C == 1 ? 0 : (int)((uint32_t)vis_ids[rank] / (uint32_t)N);
+    RowGeom g;
+    g.row0 = cam * th + q.y0; g.h = q.y1 - q.y0; g.w = q.x1 - q.x0;
+    g.tile0 = g.row0 * tw + q.x0;
+    if (g.w <= 0) g.h = 0;
+    return g;
+}
+
+// Last-block hand-off of the two counting kernels: true in every thread of the workgroup that arrives last among the
+// `active` workgroups that have data (the others never touch the counter: returning atomics on ONE address are served
+// at ~90 per us, so thousands of empty workgroups of a capacity-sized grid would cost more than the kernel).  No fence:
+// what the last workgroup reads was written by agent-scope atomics, which are complete when __syncthreads' vmcnt(0)
+// lets their issuers pass; an agent-scope release fence would write back the XCD's L2 for nothing (microseconds each).
+__device__ __forceinline__ bool arrive_last(uint32_t *done, int64_t active, int *s_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *s_flag = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(active - 1);
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+constexpr int R_BLOCK = 1024;
+// counts per (workgroup, row); every pair gets its base inside the row's segment from ONE returning atomic
+__global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef n_vis_ref, const float *__restrict__ recs,
+                                                                 const int32_t *__restrict__ vis_ids, int64_t N, int C, float ts,
+                                                                 int tw, int th, int n_rows, uint32_t *__restrict__ row_count,
+                                                                 uint32_t *__restrict__ rbase, uint32_t *__restrict__ done,
+                                                                 uint32_t *__restrict__ row_start /* [n_rows + 1] */) {
+    __shared__ uint32_t s_row[MAX_ROWS];
+    __shared__ uint32_t s_ws[R_BLOCK / 64];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n_vis = mtgs_os::size_of(n_vis_ref);
+    const int64_t r = (int64_t)blockIdx.x * R_BLOCK + tid;
+    if ((int64_t)blockIdx.x * R_BLOCK >= n_vis) {
+        if (n_vis == 0 && blockIdx.x == 0)
+            for (int b = tid; b <= n_rows; b += R_BLOCK) row_start[b] = 0;
+        return;
+    }
+    for (int b = tid; b < n_rows; b += R_BLOCK) s_row[b] = 0;
+    __syncthreads();
+    if (r < n_vis) {
+        const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
+        for (int y = 0; y < g.h; ++y) atomicAdd(&s_row[g.row0 + y], 1u);
+    }
+    __syncthreads();
+    for (int b = tid; b < n_rows; b += R_BLOCK) {
+        const uint32_t c = s_row[b];
+        if (c) rbase[(size_t)blockIdx.x * n_rows + b] = __hip_atomic_fetch_add(row_count + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!arrive_last(done, ceil_div64(n_vis, R_BLOCK), &s_last)) return;
+    // exclusive scan of the row totals (n_rows <= MAX_ROWS = one per thread)
+    static_assert(MAX_ROWS == R_BLOCK, "one row total per thread");
+    uint32_t v[1], mine = 0;
+#pragma unroll
+    for (int e = 0; e < 1; ++e) {
+        const int b = tid + e;
+        v[e] = b < n_rows ? mtgs_os::ld32(row_count + b) : 0u;
+        mine += v[e];
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_ws[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (int w = 0; w < wave; ++w) run += s_ws[w];
+    if (tid < n_rows) row_start[tid] = run;
+    if (tid == n_rows - 1) row_start[n_rows] = run + v[0];   // number of items
+}
+
+__global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef n_vis_ref, const float *__restrict__ recs,
+                                                                 const int32_t *__restrict__ vis_ids, int64_t N, int C, float ts,
+                                                                 int tw, int th, int n_rows, const uint32_t *__restrict__ row_start,
+                                                                 const uint32_t *__restrict__ rbase, int64_t cap_items,
+                                                                 Item *__restrict__ items) {
+    __shared__ uint32_t s_row[MAX_ROWS];   // next free slot of this workgroup in each row's segment
+    const int tid = threadIdx.x;
+    const int64_t n_vis = mtgs_os::size_of(n_vis_ref);
+    if ((int64_t)blockIdx.x * R_BLOCK >= n_vis) return;
+    // (rows this workgroup has no item in were never given a base: their entry is not read below)
+    for (int b = tid; b < n_rows; b += R_BLOCK) s_row[b] = row_start[b] + rbase[(size_t)blockIdx.x * n_rows + b];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * R_BLOCK + tid;
+    if (r >= n_vis) return;
+    const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
+    for (int y = 0; y < g.h; ++y) {
+        const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
+        if (pos < cap_items) items[pos] = Item{(uint32_t)r, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
+    }
+}
+
+// ---- 2. per-tile counts -> offsets, tile dispatch order ---------------------------------------------------------
+// The items are grouped by row, so the tiles a workgroup's 1024 items touch are a short contiguous range of tile ids
+// (one or two rows): only that range of the LDS histogram is cleared and flushed.
+constexpr int T_THREADS = 1024, T_ITEMS = 2, T_TILE = T_THREADS * T_ITEMS, SCHED_BUCKETS = 1024;
+struct TileRange { int lo, hi; };
+__device__ __forceinline__ TileRange tile_range(const Item *__restrict__ items, int64_t base, int64_t n_items, int tw) {
+    const int64_t last = min(n_items, base + T_TILE) - 1;
+    const int first_tile = (int)(items[base].span >> SPAN_BITS), last_tile = (int)(items[last].span >> SPAN_BITS);
+    return TileRange{(first_tile / tw) * tw, (last_tile / tw + 1) * tw};
+}
+
+__global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
+    const uint32_t *__restrict__ n_items_ptr, int64_t cap_items, const Item *__restrict__ items, int tw, int n_bins,
+    int64_t cap_M, uint32_t *__restrict__ bins /* [n_bins], zero */, uint32_t *__restrict__ done /* zero */,
+    int32_t *__restrict__ offsets /* [n_bins + 1] */, int32_t *__restrict__ order /* [n_bins] */) {
+    extern __shared__ uint32_t s_bins[];  // [n_bins]
+    __shared__ uint32_t s_aux[SCHED_BUCKETS];
+    __shared__ uint32_t s_ws[T_THREADS / 64];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n_items = min((int64_t)*n_items_ptr, cap_items);
+    const int64_t base = (int64_t)blockIdx.x * T_TILE;
+    if (base >= n_items) {
+        if (n_items == 0 && blockIdx.x == 0) {   // nothing visible: empty lists, any order
+            for (int b = tid; b <= n_bins; b += T_THREADS) offsets[b] = 0;
+            for (int b = tid; b < n_bins; b += T_THREADS) order[b] = b;
+        }
+        return;
+    }
+    {
+        const TileRange tr = tile_range(items, base, n_items, tw);
+        for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) s_bins[b] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < T_ITEMS; ++e) {
+            const int64_t i = base + e * T_THREADS + tid;
+            if (i < n_items) {
+                const Item it = items[i];
+                const int t0 = (int)(it.span >> SPAN_BITS), w = (int)(it.span & ((1u << SPAN_BITS) - 1)) + 1;
+                for (int x = 0; x < w; ++x) atomicAdd(&s_bins[t0 + x], 1u);
+            }
+        }
+        __syncthreads();
+        for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
+            const uint32_t c = s_bins[b];
+            if (c) __hip_atomic_fetch_add(bins + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!arrive_last(done, ceil_div64(n_items, T_TILE), &s_last)) return;
+    for (int b = tid; b < n_bins; b += T_THREADS) s_bins[b] = mtgs_os::ld32(bins + b);
+    __syncthreads();
+    // exclusive scan of the counts -> offsets, clamped to the capacity of the key / id arrays: a frame beyond its
+    // capacities is repeated by the caller, but every kernel behind this one must stay inside the buffers
+    const int per = (n_bins + T_THREADS - 1) / T_THREADS;   // consecutive bins per thread
+    const int b0 = tid * per, b1 = min(n_bins, b0 + per);
+    uint32_t mine = 0;
+    for (int b = b0; b < b1; ++b) mine += s_bins[b];
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_ws[wave] = inc;
+    __syncthreads();
+    uint32_t wb = 0;
+    for (int w = 0; w < wave; ++w) wb += s_ws[w];
+    uint64_t run = (uint64_t)wb + inc - mine;
+    const uint64_t cap = (uint64_t)cap_M;
+    for (int b = b0; b < b1; ++b) {
+        const uint64_t lo = run < cap ? run : cap;
+        run += s_bins[b];
+        const uint64_t hi = run < cap ? run : cap;
+        offsets[b] = (int32_t)lo;
+        s_bins[b] = (uint32_t)(hi - lo);   // the (clamped) list length: what the dispatch order is built from
+        if (b == n_bins - 1) offsets[n_bins] = (int32_t)hi;
+    }
+    // tile dispatch order: counting sort by decreasing list length (bucket width 4), as blend.hip::tile_schedule_kernel
+    s_aux[tid] = 0;
+    __syncthreads();
+    auto bucket_of = [&](int t) { return SCHED_BUCKETS - 1 - min((int)(s_bins[t] >> 2), SCHED_BUCKETS - 1); };
+    for (int t = tid; t < n_bins; t += T_THREADS) atomicAdd(&s_aux[bucket_of(t)], 1u);
+    __syncthreads();
+    const uint32_t hv = s_aux[tid];
+    uint32_t hinc = hv;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(hinc, o, 64);
+        if (lane >= o) hinc += up;
+    }
+    if (lane == 63) s_ws[wave] = hinc;
+    __syncthreads();
+    uint32_t hb = 0;
+    for (int w = 0; w < wave; ++w) hb += s_ws[w];
+    __syncthreads();
+    s_aux[tid] = hb + hinc - hv;
+    __syncthreads();
+    // (ties inside a bucket land in arrival order: a scheduling aid, results do not depend on it)
+    for (int t = tid; t < n_bins; t += T_THREADS) order[atomicAdd(&s_aux[bucket_of(t)], 1u)] = t;
+}
+
+// ---- 3. every intersection into its tile's segment --------------------------------------------------------------
+// A workgroup's intersections of one tile take CONSECUTIVE slots of the tile's segment: one returning global atomic per
+// (workgroup, tile) reserves them, LDS atomics hand them out -- ~130k global atomics per frame instead of one per
+// intersection, and the segment is written in runs of ~60 keys instead of single 8-byte stores.
+__global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
+    const uint32_t *__restrict__ n_items_ptr, int64_t cap_items, const Item *__restrict__ items, int tw, int n_bins,
+    const int32_t *__restrict__ offsets, uint32_t *__restrict__ cursor /* [n_bins], zero */,
+    const uint64_t *__restrict__ vis_keys, uint64_t *__restrict__ keys64) {
+    extern __shared__ uint32_t s_mem[];   // next free slot [n_bins] | end of the tile's segment [n_bins]
+    uint32_t *s_bins = s_mem, *s_end = s_mem + n_bins;
+    const int tid = threadIdx.x;
+    const int64_t n_items = min((int64_t)*n_items_ptr, cap_items);
+    const int64_t base = (int64_t)blockIdx.x * T_TILE;
+    if (base >= n_items) return;
+    const TileRange tr = tile_range(items, base, n_items, tw);
+    for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) s_bins[b] = 0;
+    __syncthreads();
+    Item it[T_ITEMS];
+    int t0[T_ITEMS], w[T_ITEMS];
+    uint32_t depth[T_ITEMS];
+#pragma unroll
+    for (int e = 0; e < T_ITEMS; ++e) {
+        const int64_t i = base + e * T_THREADS + tid;
+        it[e] = Item{0, 0}; t0[e] = 0; w[e] = 0; depth[e] = 0;
+        if (i < n_items) {
+            it[e] = items[i];
+            t0[e] = (int)(it[e].span >> SPAN_BITS); w[e] = (int)(it[e].span & ((1u << SPAN_BITS) - 1)) + 1;
+            depth[e] = (uint32_t)vis_keys[it[e].rank];
+            for (int x = 0; x < w[e]; ++x) atomicAdd(&s_bins[t0[e] + x], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
+        const uint32_t c = s_bins[b];
+        if (c) {
+            s_bins[b] = (uint32_t)offsets[b] + __hip_atomic_fetch_add(cursor + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_end[b] = (uint32_t)offsets[b + 1];   // (shorter than the count only in a frame beyond its capacities)
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < T_ITEMS; ++e) {
+        const uint64_t key = ((uint64_t)depth[e] << 32) | it[e].rank;
+        for (int x = 0; x < w[e]; ++x) {
+            const uint32_t pos = atomicAdd(&s_bins[t0[e] + x], 1u);
+            if (pos < s_end[t0[e] + x]) keys64[pos] = key;
+        }
+    }
+}
+
+// ---- 4. per-tile sort in LDS ------------------------------------------------------------------------------------
+struct SortEpilogue {
+    int32_t *rank_ids, *flatten_ids;
+    int64_t *isect_ids;  // nullable
+    const int32_t *vis_ids;
+    uint32_t n_tiles;
+    int tile_bits;
+    bool single_cam;
+    __device__ __forceinline__ void store(int64_t dst, uint32_t bin, uint64_t key) const {
+        const int32_t rank = (int32_t)(uint32_t)key;
+        rank_ids[dst] = rank;
+        flatten_ids[dst] = vis_ids[rank];
+        if (isect_ids) {
+            const int64_t cam = single_cam ? 0 : bin / n_tiles, tile = single_cam ? bin : bin % n_tiles;
+            isect_ids[dst] = (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)(key >> 32);
+        }
+    }
+};
+
+constexpr uint64_t KEY_INF = ~0ull;
+// one spare key per 32: eight keys of a thread at power-of-two strides spread over the banks
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }
+__device__ __forceinline__ void cswap(uint64_t &a, uint64_t &b, bool desc) {
+    const bool sw = (a > b) != desc;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+template <bool WAVE> __device__ __forceinline__ void lds_sync() {
+    if constexpr (WAVE) {
+        // one wave: its LDS instructions execute in program order, only the compiler must not move them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// Up to three consecutive stages of one bitonic level k in ONE LDS round trip: a thread owns the eight keys whose
+// indices differ in the bits S2 > S1 > S0 (the stage strides, compile-time so that the eight LDS addresses are one
+// base plus immediates: x has zeros at those bits, so lpad(x + d) = lpad(x) + d + (d >> 5) without carries);
+// `apply` = which of the three stages run (bit 2: S2 ...).
+template <bool WAVE, int S2>
+__device__ __forceinline__ void trip(uint64_t *s, int groups, int nthr, int tid, int k, int apply) {
+    constexpr int S1 = S2 >> 1, S0 = S2 >> 2;
+    constexpr int O0 = S0 + (S0 >> 5), O1 = S1 + (S1 >> 5), O2 = S2 + (S2 >> 5);
+    for (int g = tid; g < groups; g += nthr) {
+        int x = g;
+        x = ((x & ~(S0 - 1)) << 1) | (x & (S0 - 1));
+        x = ((x & ~(S1 - 1)) << 1) | (x & (S1 - 1));
+        x = ((x & ~(S2 - 1)) << 1) | (x & (S2 - 1));
+        const bool desc = (x & k) != 0;
+        uint64_t *p = s + lpad(x);
+        uint64_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[((e & 4) ? O2 : 0) + ((e & 2) ? O1 : 0) + ((e & 1) ? O0 : 0)];
+        if (apply & 4) { cswap(v[0], v[4], desc); cswap(v[1], v[5], desc); cswap(v[2], v[6], desc); cswap(v[3], v[7], desc); }
+        if (apply & 2) { cswap(v[0], v[2], desc); cswap(v[1], v[3], desc); cswap(v[4], v[6], desc); cswap(v[5], v[7], desc); }
+        if (apply & 1) { cswap(v[0], v[1], desc); cswap(v[2], v[3], desc); cswap(v[4], v[5], desc); cswap(v[6], v[7], desc); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[((e & 4) ? O2 : 0) + ((e & 2) ? O1 : 0) + ((e & 1) ? O0 : 0)] = v[e];
+    }
+    lds_sync<WAVE>();
+}
+template <bool WAVE>
+__device__ __forceinline__ void trip_dyn(uint64_t *s, int groups, int nthr, int tid, int k, int j, int apply) {
+    switch (j) {
+        case 4: trip<WAVE, 4>(s, groups, nthr, tid, k, apply); break;
+        case 8: trip<WAVE, 8>(s, groups, nthr, tid, k, apply); break;
+        case 16: trip<WAVE, 16>(s, groups, nthr, tid, k, apply); break;
+        case 32: trip<WAVE, 32>(s, groups, nthr, tid, k, apply); break;
+        case 64: trip<WAVE, 64>(s, groups, nthr, tid, k, apply); break;
+        case 128: trip<WAVE, 128>(s, groups, nthr, tid, k, apply); break;
+        case 256: trip<WAVE, 256>(s, groups, nthr, tid, k, apply); break;
+        case 512: trip<WAVE, 512>(s, groups, nthr, tid, k, apply); break;
+        case 1024: trip<WAVE, 1024>(s, groups, nthr, tid, k, apply); break;
+        case 2048: trip<WAVE, 2048>(s, groups, nthr, tid, k, apply); break;
+        case 4096: trip<WAVE, 4096>(s, groups, nthr, tid, k, apply); break;
+        default: trip<WAVE, 8192>(s, groups, nthr, tid, k, apply); break;
+    }
+}
+
+// the stages of level k from stride j down to 1 (j a power of two, 4 <= j <= 8192)
+template <bool WAVE>
+__device__ __forceinline__ void level_tail(uint64_t *s, int groups, int nthr, int tid, int k, int j) {
+    int upper = 0;
+    for (int q = j; q >= 8; q >>= 1) ++upper;   // stages with stride >= 8
+    while (upper > 0) {
+        const int take = upper >= 3 ? 3 : upper;
+        trip_dyn<WAVE>(s, groups, nthr, tid, k, j, take == 3 ? 7 : take == 2 ? 6 : 4);
+        j >>= take;
+        upper -= take;
+    }
+    trip<WAVE, 4>(s, groups, nthr, tid, k, 7);
+}
+
+// ascending bitonic sort of s[0, P) (P a power of two >= 8, keys at lpad(i)); callers synchronise before
+template <bool WAVE>
+__device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int nthr, int tid) {
+    const int groups = P >> 3;
+    for (int g = tid; g < groups; g += nthr) {   // levels 2, 4, 8 on eight contiguous keys
+        const int x = g << 3;
+        uint64_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = s[lpad(x + e)];
+        cswap(v[0], v[1], false); cswap(v[2], v[3], true); cswap(v[4], v[5], false); cswap(v[6], v[7], true);
+        cswap(v[0], v[2], false); cswap(v[1], v[3], false); cswap(v[4], v[6], true); cswap(v[5], v[7], true);
+        cswap(v[0], v[1], false); cswap(v[2], v[3], false); cswap(v[4], v[5], true); cswap(v[6], v[7], true);
+        const bool desc = (x & 8) != 0;
+        cswap(v[0], v[4], desc); cswap(v[1], v[5], desc); cswap(v[2], v[6], desc); cswap(v[3], v[7], desc);
+        cswap(v[0], v[2], desc); cswap(v[1], v[3], desc); cswap(v[4], v[6], desc); cswap(v[5], v[7], desc);
+        cswap(v[0], v[1], desc); cswap(v[2], v[3], desc); cswap(v[4], v[5], desc); cswap(v[6], v[7], desc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[lpad(x + e)] = v[e];
+    }
+    lds_sync<WAVE>();
+    for (int k = 16; k <= P; k <<= 1) level_tail<WAVE>(s, groups, nthr, tid, k, k >> 1);
+}
+
+__device__ __forceinline__ int pow2_ceil(int n) {
+    int p = 8;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// one tile whose list fits the LDS buffer: load, sort, write the three output arrays
+template <bool WAVE>
+__device__ __forceinline__ void sort_tile_lds(uint64_t *s, const uint64_t *__restrict__ keys, int64_t o0, int L, uint32_t bin,
+                                              int nthr, int tid, const SortEpilogue &epi) {
+    const int P = pow2_ceil(L);
+    for (int i = tid; i < P; i += nthr) s[lpad(i)] = i < L ? keys[o0 + i] : KEY_INF;
+    lds_sync<WAVE>();
+    bitonic_sort<WAVE>(s, P, nthr, tid);
+    for (int i = tid; i < L; i += nthr) epi.store(o0 + i, bin, s[lpad(i)]);
+    lds_sync<WAVE>();
+}
+
+constexpr int SM_CAP = 2048, SM_WAVE_CAP = 1024, SM_TILES = 4;
+constexpr int LG_THREADS = 1024, LG_CAP = 16384;
+// A workgroup takes four consecutive tiles of the dispatch order (longest lists first).  Lists of up to 1024 keys are
+// sorted by ONE wave each (no workgroup barrier at all), longer ones by the four waves together, one tile after the
+// other; lists beyond SM_CAP are left to bin3_sort_large_kernel.
+__global__ __launch_bounds__(B3_BLOCK) void bin3_sort_small_kernel(const int32_t *__restrict__ offsets,
+                                                                  const int32_t *__restrict__ order, int n_bins, int64_t cap_M,
+                                                                  const uint64_t *__restrict__ keys, const SortEpilogue epi) {
+    __shared__ uint64_t s_keys[SM_TILES * (SM_WAVE_CAP + SM_WAVE_CAP / 32)];   // >= lpad(SM_CAP)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int bin[SM_TILES], L[SM_TILES], o0[SM_TILES], max_l = 0;
+#pragma unroll
+    for (int q = 0; q < SM_TILES; ++q) {
+        const int g = blockIdx.x * SM_TILES + q;
+        bin[q] = 0; L[q] = 0; o0[q] = 0;
+        if (g < n_bins) {
+            bin[q] = order[g];
+            o0[q] = offsets[bin[q]];
+            L[q] = offsets[bin[q] + 1] - o0[q];
+            if (L[q] > SM_CAP || (int64_t)o0[q] + L[q] > cap_M) L[q] = 0;   // the large kernel's / a frame beyond its capacities
+        }
+        max_l = max(max_l, L[q]);
+    }
+    if (max_l == 0) return;
+    if (max_l > SM_WAVE_CAP) {
+#pragma unroll 1
+        for (int q = 0; q < SM_TILES; ++q)
+            if (L[q] > 0) sort_tile_lds<false>(s_keys, keys, o0[q], L[q], (uint32_t)bin[q], B3_BLOCK, tid, epi);
+    } else {
+        int bq = 0, lq = 0, oq = 0;   // (static indexing keeps the arrays in registers)
+#pragma unroll
+        for (int q = 0; q < SM_TILES; ++q)
+            if (q == wave) { bq = bin[q]; lq = L[q]; oq = o0[q]; }
+        if (lq > 0) sort_tile_lds<true>(s_keys + wave * (SM_WAVE_CAP + SM_WAVE_CAP / 32), keys, oq, lq, (uint32_t)bq, 64, lane, epi);
+    }
+}
+
+// Lists longer than SM_CAP: one 1024-thread workgroup per list, up to LG_CAP keys in LDS; beyond that the list is
+// sorted in LG_CAP-key chunks and the chunks are merged with the upper levels of the all-ascending form of the
+// network (first stage of a level mirrors, i <-> i ^ (k - 1), the others are plain butterflies), whose comparators
+// never move a key upwards past the end of the list -- so the list needs no padding in global memory.
+__global__ __launch_bounds__(LG_THREADS) void bin3_sort_large_kernel(const int32_t *__restrict__ offsets,
+                                                                    const int32_t *__restrict__ order, int n_bins, int64_t cap_M,
+                                                                    uint64_t *keys, const SortEpilogue epi) {
+    extern __shared__ uint64_t s_big[];   // lpad(LG_CAP)
+    const int tid = threadIdx.x;
+    for (int g = blockIdx.x; g < n_bins; g += gridDim.x) {
+        const int bin = order[g];
+        const int64_t o0 = offsets[bin];
+        const int L = offsets[bin + 1] - (int)o0;
+        if (L <= SM_CAP) {
+            if (L + 4 <= SM_CAP) break;   // the order is by decreasing (length >> 2): nothing longer follows
+            continue;
+        }
+        if (o0 + L > cap_M) continue;     // a frame beyond its capacities (it is repeated)
+        if (L <= LG_CAP) {
+            sort_tile_lds<false>(s_big, keys, o0, L, (uint32_t)bin, LG_THREADS, tid, epi);
+            continue;
+        }
+        uint64_t *seg = keys + o0;
+        const int nch = (L + LG_CAP - 1) / LG_CAP;
+        for (int c = 0; c < nch; ++c) {   // every chunk ascending
+            const int c0 = c * LG_CAP, n = min(LG_CAP, L - c0);
+            for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[lpad(i)] = i < n ? seg[c0 + i] : KEY_INF;
+            __syncthreads();
+            bitonic_sort<false>(s_big, LG_CAP, LG_THREADS, tid);
+            for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[lpad(i)];
+            __syncthreads();
+        }
+        int64_t P = LG_CAP;
+        while (P < L) P <<= 1;
+        for (int64_t k = 2 * LG_CAP; k <= P; k <<= 1) {
+            const int64_t half = k >> 1;
+            for (int64_t i = tid; i < P / 2; i += LG_THREADS) {   // mirror stage
+                const int64_t b = (i / half) * k, o = i % half, lo = b + o, hi = b + k - 1 - o;
+                if (hi < L) {
+                    uint64_t a = seg[lo], z = seg[hi];
+                    if (a > z) { seg[lo] = z; seg[hi] = a; }
+                }
+            }
+            __syncthreads();
+            for (int64_t j = k >> 2; j >= LG_CAP; j >>= 1) {       // butterflies across chunks
+                for (int64_t i = tid; i < P / 2; i += LG_THREADS) {
+                    const int64_t lo = (i / j) * 2 * j + i % j, hi = lo + j;
+                    if (hi < L) {
+                        uint64_t a = seg[lo], z = seg[hi];
+                        if (a > z) { seg[lo] = z; seg[hi] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+            for (int c = 0; c < nch; ++c) {                       // the remaining stages inside each chunk, in LDS
+                const int c0 = c * LG_CAP, n = min(LG_CAP, L - c0);
+                for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[lpad(i)] = i < n ? seg[c0 + i] : KEY_INF;
+                __syncthreads();
+                level_tail<false>(s_big, LG_CAP >> 3, LG_THREADS, tid, /*k: all ascending*/ 1 << 30, LG_CAP >> 1);
+                for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[lpad(i)];
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < L; i += LG_THREADS) epi.store(o0 + i, (uint32_t)bin, seg[i]);
+        __syncthreads();
+    }
+}
+
+inline int bit_length_u32(uint32_t v) {
+    int b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+struct Bin3Workspace {
+    char *control;          // zeroed region
+    size_t control_bytes;
+    uint32_t *done_rows, *done_tiles, *row_count, *bins, *cursor;
+    uint32_t *row_start, *rbase;
+    int32_t *order;
+    Item *items;
+    uint64_t *keys64;
+    size_t total;
+};
+inline Bin3Workspace carve3(char *base, int64_t cap_vis, int64_t cap_M, int n_rows, int n_bins) {
+    Bin3Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += mtgs_os::align256(bytes); return p; };
+    const int64_t m = cap_M > 0 ? cap_M : 1, nv = cap_vis > 0 ? cap_vis : 1;
+    w.control = base;
+    char *misc = take(64);
+    w.done_rows = (uint32_t *)misc; w.done_tiles = (uint32_t *)misc + 1;
+    w.row_count = (uint32_t *)take((size_t)n_rows * 4);
+    w.bins = (uint32_t *)take((size_t)n_bins * 4);
+    w.cursor = (uint32_t *)take((size_t)n_bins * 4);
+    w.control_bytes = off;
+    w.row_start = (uint32_t *)take((size_t)(n_rows + 1) * 4);
+    w.rbase = (uint32_t *)take((size_t)ceil_div64(nv, R_BLOCK) * n_rows * 4);
+    w.order = (int32_t *)take((size_t)n_bins * 4);
+    w.items = (Item *)take((size_t)m * sizeof(Item));
+    w.keys64 = (uint64_t *)take((size_t)m * 8);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M) {
+    return C > 0 && tile_w > 0 && tile_h > 0 && (int64_t)C * tile_w * tile_h <= MAX_BINS && (int64_t)C * tile_h <= MAX_ROWS &&
+                   cap_M < ((int64_t)1 << 30)
+               ? 1 : 0;
+}
+
+extern "C" int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes) {
+    MTGS_REQUIRE(C > 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0 && bytes, MTGS_EINVAL,
+                 "mtgs_bin3_workspace_bytes: bad arguments");
+    *bytes = carve3(nullptr, cap_vis, cap_M, C * tile_h, C * tile_w * tile_h).total;
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
+                               int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
+                               const int64_t *vis_keys, int32_t *rank_ids,
+                               int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order,
+                               void *ws, size_t ws_bytes, void *stream) {
+    MTGS_REQUIRE(C > 0 && N >= 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0, MTGS_EINVAL, "mtgs_bin3_build: bad sizes");
+    MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_bin3_build: tile_size=%d (only 16 is implemented)", tile_size);
+    MTGS_REQUIRE(mtgs_bin3_supported(C, tile_w, tile_h, cap_M), MTGS_EUNSUPPORTED,
+                 "mtgs_bin3_build: %d x %d x %d (camera, tile) pairs / %lld intersections (at most %d pairs, %d (camera, tile row) "
+                 "pairs and 2^30 intersections; use mtgs_bin_build)", C, tile_w, tile_h, (long long)cap_M, MAX_BINS, MAX_ROWS);
+    MTGS_REQUIRE(totals && recs && vis_ids && vis_keys && rank_ids && flatten_ids && offsets && ws, MTGS_EINVAL,
+                 "mtgs_bin3_build: null pointer");
+    const int n_bins = C * tile_w * tile_h, n_rows = C * tile_h;
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, MTGS_EINVAL, "mtgs_bin3_build: workspace must be 256-byte aligned");
+    Bin3Workspace w = carve3((char *)ws, cap_vis, cap_M, n_rows, n_bins);
+    MTGS_REQUIRE(ws_bytes >= w.total, MTGS_EWORKSPACE, "mtgs_bin3_build: workspace %zu < %zu bytes", ws_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mtgs_zero_async(w.control, w.control_bytes, st)) return rc;
+    const SizeRef n_vis_ref{totals, 1, cap_vis};
+    int32_t *order = tile_order ? tile_order : w.order;
+    const unsigned r_grid = (unsigned)ceil_div64(cap_vis > 0 ? cap_vis : 1, R_BLOCK);
+    const unsigned t_grid = (unsigned)ceil_div64(cap_M > 0 ? cap_M : 1, T_TILE);
+    const float ts = (float)tile_size;
+    bin3_rows_count_kernel<<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_count,
+                                                      w.rbase, w.done_rows, w.row_start);
+    bin3_rows_place_kernel<<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_start,
+                                                      w.rbase, cap_M, w.items);
+    bin3_tiles_count_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
+                                                                            cap_M, w.bins, w.done_tiles, offsets, order);
+    bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 8, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
+                                                                            offsets, w.cursor, (const uint64_t *)vis_keys, w.keys64);
+    const SortEpilogue epi{rank_ids, flatten_ids, isect_ids, vis_ids, (uint32_t)(tile_w * tile_h),
+                           bit_length_u32((uint32_t)(tile_w * tile_h)), C == 1};
+    static const bool big_lds = [] {
+        return hipFuncSetAttribute((const void *)bin3_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (LG_CAP + LG_CAP / 32) * 8) == hipSuccess &&
+               hipFuncSetAttribute((const void *)bin3_tiles_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   MAX_BINS * 8) == hipSuccess;
+    }();
+    MTGS_REQUIRE(big_lds, MTGS_ELAUNCH, "mtgs_bin3_build: cannot reserve %d bytes of LDS per workgroup", (LG_CAP + LG_CAP / 32) * 8);
+    bin3_sort_large_kernel<<<(unsigned)min(n_bins, 256), LG_THREADS, (size_t)(LG_CAP + LG_CAP / 32) * 8, st>>>(
+        offsets, order, n_bins, cap_M, w.keys64, epi);
+    bin3_sort_small_kernel<<<(unsigned)((n_bins + SM_TILES - 1) / SM_TILES), B3_BLOCK, 0, st>>>(offsets, order, n_bins, cap_M,
+                                                                                             w.keys64, epi);
+    MTGS_CHECK_LAUNCH("mtgs_bin3_build");
+    return MTGS_OK;
+}

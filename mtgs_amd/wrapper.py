@@ -12,6 +12,7 @@ a HIP kernel launched through the C ABI (include/mtgs_rast.h).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import time
 from typing import Optional, Tuple
@@ -501,8 +502,12 @@ def staging_buffer(nbytes: int) -> Tensor:
     return buf
 
 
+_BIN_LEGACY = os.environ.get("MTGS_DEV_BIN2") == "1"     # development switch: the depth-sort + tile-sort binning (bin2.hip)
+
+
 def _bin2_ok(Cn, tw, th, cap_M) -> bool:
-    return bool(_lib.load().mtgs_bin2_supported(Cn, tw, th, cap_M))
+    lib = _lib.load()
+    return bool((lib.mtgs_bin2_supported if _BIN_LEGACY else lib.mtgs_bin3_supported)(Cn, tw, th, cap_M))
 
 
 class _FusedRasterization(torch.autograd.Function):
@@ -578,13 +583,14 @@ class _FusedRasterization(torch.autograd.Function):
             def front(cap_vis):
                 b = {"recs": torch.empty((cap_vis, 16), dtype=torch.float32, device=dev),
                      "vis_ids": torch.empty(cap_vis, dtype=torch.int32, device=dev),
-                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis}
+                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev),
+                     "vis_cum": torch.empty(cap_vis, dtype=torch.int32, device=dev), "cap_vis": cap_vis}
                 mailbox, tag = _host_mailbox() if graph_caps is None else (None, 0)
                 call("mtgs_front_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
                      eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
-                     ptr(vis_rank), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
+                     ptr(vis_rank), ptr(b["vis_cum"]), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
                      1 if dp is not None else 0, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 b["mailbox"], b["tag"] = mailbox, tag
@@ -598,13 +604,22 @@ class _FusedRasterization(torch.autograd.Function):
                        "flatten_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
                        "isect_ids": torch.empty(cap_alloc, dtype=torch.int64, device=dev)}
                 nbytes = C.c_size_t(0)
-                call("mtgs_bin2_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
-                ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
-                off = (-ws.data_ptr()) % 256
-                call("mtgs_bin2_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
-                     ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
-                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
-                     nbytes.value, st)
+                if _BIN_LEGACY:
+                    call("mtgs_bin2_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
+                    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+                    off = (-ws.data_ptr()) % 256
+                    call("mtgs_bin2_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
+                         ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
+                         ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
+                         nbytes.value, st)
+                else:
+                    call("mtgs_bin3_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
+                    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+                    off = (-ws.data_ptr()) % 256
+                    call("mtgs_bin3_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
+                         ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
+                         ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
+                         nbytes.value, st)
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
                      ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), st)
                 return out

@@ -253,3 +253,47 @@ def test_graph_mode_capture_replay_equals_eager(hip_lib):
     g2.replay()
     torch.cuda.synchronize()
     assert bool(i2["overflow"]) and int(i2["n_visible"]) == ref1[4] and torch.isfinite(r2).all()
+
+
+@pytest.mark.parametrize("n,equal_depths", [(300, False), (1500, True), (6000, False), (40_000, True)])
+def test_long_tile_lists_every_sort_path(hip_lib, n, equal_depths):
+    """Binning without a global sort (csrc/bin3.hip): the per-tile sort has a one-wave path (<= 512 keys), a workgroup
+    path (<= 2048), a 1024-thread path (<= 16384 keys in LDS) and a chunked path that merges through global memory.
+    n Gaussians in front of a 48x40 image put ~n intersections into each of its 9 tiles; with equal_depths many of
+    them share their depth bit for bit, so the order inside a tile is decided by the Gaussian index (gsplat: stable
+    sort).  isect_ids / flatten_ids / offsets must equal the operator path's (one global radix sort) bit for bit."""
+    from mtgs_amd import rasterization
+    from mtgs_amd import wrapper as w
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    W, H = 48, 40
+    g = torch.Generator().manual_seed(n)
+    vm, K = make_camera(W, H)
+    vm, K = vm.to(dev), K.to(dev)
+    # the camera sits at the origin looking down +z (identity view matrix): world z IS the depth, bit for bit
+    z = torch.rand(n, generator=g) * 4.0 + 3.0
+    if equal_depths:
+        z = torch.round(z * 4.0) / 4.0                      # 17 distinct depths
+    xy = (torch.rand(n, 2, generator=g) - 0.5) * 0.4
+    means = torch.cat([xy * z[:, None], z[:, None]], dim=1).to(dev).contiguous()
+    quats = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1).to(dev)
+    scales = (torch.rand(n, 3, generator=g) * 0.6 + 0.3).to(dev)
+    opac = (torch.rand(n, generator=g) * 0.2 + 0.02).to(dev)
+    cols = torch.rand(n, 3, generator=g).to(dev)
+    render, alpha, info = rasterization(means=means, quats=quats, scales=scales, opacities=opac, colors=cols, viewmats=vm,
+                                        Ks=K, width=W, height=H, packed=False, render_mode="RGB+ED",
+                                        rasterize_mode="antialiased", absgrad=True)
+    radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(means, quats, scales, vm, K, opac, W, H,
+                                                                            calc_compensations=True)
+    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 3, 3)
+    off = w.isect_offset_encode(isect_ids, 1, 3, 3)
+    lens = torch.diff(torch.cat([off.reshape(-1), torch.tensor([isect_ids.numel()], device=dev, dtype=off.dtype)]))
+    assert int(lens.max()) > n // 2, "the construction should fill the tiles"
+    if equal_depths:
+        d = depths[0][radii[0] > 0]
+        assert d.unique().numel() < d.numel(), "expected Gaussians with bit-identical depths"
+    assert torch.equal(info["isect_offsets"], off)
+    assert torch.equal(info["flatten_ids"], flat)
+    assert torch.equal(info["isect_ids"], isect_ids)
+    r2, a2 = w.rasterize_to_pixels_with_depth(means2d, conics, cols.unsqueeze(0), oe, depths, True, W, H, 16, off, flat)
+    assert torch.allclose(render, r2, atol=1e-5) and torch.allclose(alpha, a2, atol=1e-5)
