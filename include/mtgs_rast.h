@@ -265,8 +265,6 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  *                         | colours[D] (from colors[C*N,D]), depth (if with_depth), zeros   (D + with_depth <= 8)
  *   vis_ids[cap_vis] i32  flat index;  vis_keys[cap_vis] i64 = tile count << 40 | camera << 32 | bits(depth)
  *   vis_rank[C*N] i32     rank of every visible pair (dense; culled entries unspecified)
- *   vis_cum[cap_vis] i32  (nullable) inclusive prefix sum of the tile counts in rank order: the intersections of the
- *                         pair with rank r are output slots [vis_cum[r-1], vis_cum[r]) of an emission in index order
  *   dp_words[ceil(C*N/64)] u64, dp_prefix[ceil(C*N/64)] u32 (both nullable): visibility bitmap and rank of the first
  *                         pair of each word (the map mtgs_dp_reduce reads); dp_count[1] i32 (nullable) = n_vis
  *   color_mode            0: colours as given; 1: the first three channels are SH output x, blended as
@@ -294,13 +292,12 @@ int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, con
                    int with_depth, int32_t *radii, float *means2d, float *depths, float *conics,
                    float *compensations, float *opac_eff, int tile_size, int tile_w, int tile_h,
                    int32_t *tiles_per_gauss, float *recs, int32_t *vis_ids, int64_t *vis_keys,
-                   int32_t *vis_rank, int32_t *vis_cum, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix,
-                   int32_t *dp_count,
+                   int32_t *vis_rank, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
                    int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes,
                    void *stream);
-/* mtgs_bin3_*: the same outputs as mtgs_bin2_build (bit-identical) without any global sort: intersections are emitted
- * in index order (vis_cum of mtgs_front_fwd), counted per tile, scattered into their tile's segment and every segment
- * is sorted on (depth bits, rank) by one workgroup in LDS.  Six launches; same capacity / device-side size rules. */
+/* mtgs_bin3_*: the same outputs as mtgs_bin2_build (bit-identical) without any global sort: (Gaussian, tile row) items
+ * grouped by row, expanded into per-tile segments (unordered), every segment sorted on (depth bits, rank) by one
+ * workgroup in LDS.  Seven launches; same capacity / device-side size rules; additionally C * tile_h <= 1024. */
 int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M);
 int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
 int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,

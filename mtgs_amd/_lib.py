@@ -53,7 +53,7 @@ _SIGNATURES = {
     "mtgs_bin_finalize": [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_front_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_front_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32,
-                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32,
+                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32,
                        _vp, _vp, _i64, _vp, _sz, _vp],
     "mtgs_bin3_supported": [_i32, _i32, _i32, _i64],
     "mtgs_bin3_workspace_bytes": [_i32, _i32, _i32, _i64, _i64, C.POINTER(_sz)],

@@ -90,7 +90,6 @@ struct CompactArgs {
     int32_t *vis_ids;
     uint64_t *vis_keys;
     int32_t *vis_rank;  // dense [C*N]
-    int32_t *vis_cum;   // [cap_vis], nullable: inclusive prefix of the tile counts in rank order
     int64_t cap_vis;
     unsigned long long *dp_words;  // nullable
     uint32_t *dp_prefix;           // nullable
@@ -186,10 +185,6 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                         if (k == a.DC) ch[k] = dep;
                 }
                 a.vis_ids[rank] = (int32_t)idx;
-                if (a.vis_cum) {
-                    const uint64_t cm = excl_m + pk_m(pre[r]) + pk_m(incl_w[r]);
-                    a.vis_cum[rank] = (int32_t)(cm < 0x7fffffffull ? cm : 0x7fffffffull);
-                }
                 // depth sort key: tile count | camera | depth bits -- only the low 32 + camera bits are sorted on, the
                 // count rides along so that the scan in depth order reads it without a gather
                 a.vis_keys[rank] = ((uint64_t)(uint32_t)cnt[r] << 40) | ((uint64_t)(a.C == 1 ? 0 : idx / a.N) << 32) |
@@ -240,7 +235,7 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
                               const float *colors, int D, int with_depth, int32_t *radii, float *means2d,
                               float *depths, float *conics, float *compensations, float *opac_eff,
                               int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, float *recs,
-                              int32_t *vis_ids, int64_t *vis_keys, int32_t *vis_rank, int32_t *vis_cum,
+                              int32_t *vis_ids, int64_t *vis_keys, int32_t *vis_rank,
                               int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
                               int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws,
                               size_t ws_bytes, void *stream) {
@@ -288,7 +283,7 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
     a.C = C; a.N = N; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss; a.means2d = means2d; a.depths = depths;
     a.conics = conics; a.opac_eff = opac_eff; a.colors = colors; a.DC = D; a.with_depth = with_depth ? 1 : 0;
     a.chunk_counts = chunk_counts; a.group_counts = (const uint64_t *)group_counts;
-    a.recs = recs; a.vis_ids = vis_ids; a.vis_keys = (uint64_t *)vis_keys; a.vis_rank = vis_rank; a.vis_cum = vis_cum; a.cap_vis = cap_vis;
+    a.recs = recs; a.vis_ids = vis_ids; a.vis_keys = (uint64_t *)vis_keys; a.vis_rank = vis_rank; a.cap_vis = cap_vis;
     a.dp_words = (unsigned long long *)dp_words; a.dp_prefix = dp_prefix; a.dp_count = dp_count; a.color_mode = color_mode;
     a.totals = totals; a.host_totals = host_totals; a.host_tag = host_tag;
     front_compact_kernel<<<(unsigned)ceil_div64(total, COMPACT_TILE), COMPACT_THREADS, 0, st>>>(a);

@@ -583,14 +583,13 @@ class _FusedRasterization(torch.autograd.Function):
             def front(cap_vis):
                 b = {"recs": torch.empty((cap_vis, 16), dtype=torch.float32, device=dev),
                      "vis_ids": torch.empty(cap_vis, dtype=torch.int32, device=dev),
-                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev),
-                     "vis_cum": torch.empty(cap_vis, dtype=torch.int32, device=dev), "cap_vis": cap_vis}
+                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis}
                 mailbox, tag = _host_mailbox() if graph_caps is None else (None, 0)
                 call("mtgs_front_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
                      eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
-                     ptr(vis_rank), ptr(b["vis_cum"]), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
+                     ptr(vis_rank), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
                      1 if dp is not None else 0, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 b["mailbox"], b["tag"] = mailbox, tag
