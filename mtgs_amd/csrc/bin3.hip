@@ -154,7 +154,10 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef 
 // ---- 2. per-tile counts -> offsets, tile dispatch order ---------------------------------------------------------
 // The items are grouped by row, so the tiles a workgroup's 1024 items touch are a short contiguous range of tile ids
 // (one or two rows): only that range of the LDS histogram is cleared and flushed.
-constexpr int T_THREADS = 1024, T_ITEMS = 2, T_TILE = T_THREADS * T_ITEMS, SCHED_BUCKETS = 1024;
+#ifndef B3_T_ITEMS
+#define B3_T_ITEMS 2
+#endif
+constexpr int T_THREADS = 1024, T_ITEMS = B3_T_ITEMS, T_TILE = T_THREADS * T_ITEMS, SCHED_BUCKETS = 1024;
 struct TileRange { int lo, hi; };
 __device__ __forceinline__ TileRange tile_range(const Item *__restrict__ items, int64_t base, int64_t n_items, int tw) {
     const int64_t last = min(n_items, base + T_TILE) - 1;
@@ -297,7 +300,11 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
         const uint64_t key = ((uint64_t)depth[e] << 32) | it[e].rank;
         for (int x = 0; x < w[e]; ++x) {
             const uint32_t pos = atomicAdd(&s_bins[t0[e] + x], 1u);
+#ifdef B3_NO_STORE
+            if (pos == 0xffffffffu) keys64[pos] = key;
+#else
             if (pos < s_end[t0[e] + x]) keys64[pos] = key;
+#endif
         }
     }
 }
@@ -321,13 +328,34 @@ struct SortEpilogue {
     }
 };
 
-constexpr uint64_t KEY_INF = ~0ull;
-// one spare key per 32: eight keys of a thread at power-of-two strides spread over the banks
-__device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }
-__device__ __forceinline__ void cswap(uint64_t &a, uint64_t &b, bool desc) {
-    const bool sw = (a > b) != desc;
-    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
-    a = lo; b = hi;
+// The keys are compared as DOUBLES: depth bits of a positive finite float in the high word make the 64-bit pattern a
+// positive finite double whose order is the integer order, and v_min_f64 / v_max_f64 are full-rate instructions -- a
+// compare-exchange is two VALU instructions instead of a 64-bit compare and four selects (it was 7-8 issue slots).
+// The network is the all-ascending form of the bitonic sort (first stage of a level mirrors, i <-> i ^ (k - 1), the
+// others are plain butterflies), so no comparator needs a direction, and padding keys (+inf) never move down: work
+// items that hold only padding are skipped.
+constexpr uint64_t KEY_INF = 0x7ff0000000000000ull;
+// LDS layout: key i lives at i ^ T(bits 5..7 of i), T linear over GF(2) with columns (31, 27, 22).  ds_read_b64 serves
+// 32 lanes per cycle from 64 four-byte banks, i.e. it is conflict-free when the 32 keys fall into 32 different 8-byte
+// columns of the 256-byte row.  The 32 lanes of a group hold work items whose keys differ in five index bits -- the
+// lowest five that are not stage strides of the trip: {3..7}, {0,4..7}, {0,1,5,6,7}, {0,1,2,6,7}, {0,1,2,3,7} or
+// {0..4} -- and with these columns each of those sets maps onto the five column bits bijectively (a padding of one key
+// per 32 left 45 % of the LDS cycles of the sort to bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+__host__ __device__ constexpr int swz_t(int hi3) { return ((hi3 & 1) ? 31 : 0) ^ ((hi3 & 2) ? 27 : 0) ^ ((hi3 & 4) ? 22 : 0); }
+__device__ __forceinline__ int swz(int i) {
+    return i ^ (int)((0x120d0916041b1f00ull >> ((i >> 2) & 0x38)) & 31);   // bytes = swz_t(0..7)
+}
+static_assert(swz_t(1) == 0x1f && swz_t(2) == 0x1b && swz_t(3) == 0x04 && swz_t(4) == 0x16 && swz_t(5) == 0x09 &&
+              swz_t(6) == 0x0d && swz_t(7) == 0x12, "packed table");
+// swz(x ^ d) = swz(x) ^ swz_d(d) for any d (T is linear); the stage strides are compile-time, so a thread's eight keys
+// are one swizzled base and eight XOR constants
+__host__ __device__ constexpr int swz_d(int d) { return d ^ swz_t((d >> 5) & 7); }
+__device__ __forceinline__ void cswap(uint64_t &a, uint64_t &b) {   // a <- min, b <- max
+    const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    a = (uint64_t)__double_as_longlong(lo); b = (uint64_t)__double_as_longlong(hi);
 }
 template <bool WAVE> __device__ __forceinline__ void lds_sync() {
     if constexpr (WAVE) {
@@ -340,85 +368,112 @@ template <bool WAVE> __device__ __forceinline__ void lds_sync() {
     }
 }
 
-// Up to three consecutive stages of one bitonic level k in ONE LDS round trip: a thread owns the eight keys whose
-// indices differ in the bits S2 > S1 > S0 (the stage strides, compile-time so that the eight LDS addresses are one
-// base plus immediates: x has zeros at those bits, so lpad(x + d) = lpad(x) + d + (d >> 5) without carries);
-// `apply` = which of the three stages run (bit 2: S2 ...).
+// Up to three consecutive butterfly stages in ONE LDS round trip: a thread owns the eight keys whose indices differ in
+// the bits S2 > S1 > S0 (the stage strides, compile-time so that the eight LDS addresses are one base plus immediates:
+// x has zeros at those bits, so swz(x + d) = swz(x) + d + (d >> 5) without carries); `apply` = which of the three
+// stages run (bit 2: S2 ...).  n = number of real keys (the rest of [0, P) is padding).
 template <bool WAVE, int S2>
-__device__ __forceinline__ void trip(uint64_t *s, int groups, int nthr, int tid, int k, int apply) {
+__device__ __forceinline__ void trip(uint64_t *s, int groups, int n, int nthr, int tid, int apply) {
     constexpr int S1 = S2 >> 1, S0 = S2 >> 2;
-    constexpr int O0 = S0 + (S0 >> 5), O1 = S1 + (S1 >> 5), O2 = S2 + (S2 >> 5);
     for (int g = tid; g < groups; g += nthr) {
         int x = g;
         x = ((x & ~(S0 - 1)) << 1) | (x & (S0 - 1));
         x = ((x & ~(S1 - 1)) << 1) | (x & (S1 - 1));
         x = ((x & ~(S2 - 1)) << 1) | (x & (S2 - 1));
-        const bool desc = (x & k) != 0;
-        uint64_t *p = s + lpad(x);
+        if (x >= n) continue;
+        const int px = swz(x);
         uint64_t v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = p[((e & 4) ? O2 : 0) + ((e & 2) ? O1 : 0) + ((e & 1) ? O0 : 0)];
-        if (apply & 4) { cswap(v[0], v[4], desc); cswap(v[1], v[5], desc); cswap(v[2], v[6], desc); cswap(v[3], v[7], desc); }
-        if (apply & 2) { cswap(v[0], v[2], desc); cswap(v[1], v[3], desc); cswap(v[4], v[6], desc); cswap(v[5], v[7], desc); }
-        if (apply & 1) { cswap(v[0], v[1], desc); cswap(v[2], v[3], desc); cswap(v[4], v[5], desc); cswap(v[6], v[7], desc); }
+        for (int e = 0; e < 8; ++e) v[e] = s[px ^ swz_d(((e & 4) ? S2 : 0) | ((e & 2) ? S1 : 0) | ((e & 1) ? S0 : 0))];
+        if (apply & 4) { cswap(v[0], v[4]); cswap(v[1], v[5]); cswap(v[2], v[6]); cswap(v[3], v[7]); }
+        if (apply & 2) { cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]); }
+        if (apply & 1) { cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]); }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) p[((e & 4) ? O2 : 0) + ((e & 2) ? O1 : 0) + ((e & 1) ? O0 : 0)] = v[e];
+        for (int e = 0; e < 8; ++e) s[px ^ swz_d(((e & 4) ? S2 : 0) | ((e & 2) ? S1 : 0) | ((e & 1) ? S0 : 0))] = v[e];
     }
     lds_sync<WAVE>();
 }
-template <bool WAVE>
-__device__ __forceinline__ void trip_dyn(uint64_t *s, int groups, int nthr, int tid, int k, int j, int apply) {
-    switch (j) {
-        case 4: trip<WAVE, 4>(s, groups, nthr, tid, k, apply); break;
-        case 8: trip<WAVE, 8>(s, groups, nthr, tid, k, apply); break;
-        case 16: trip<WAVE, 16>(s, groups, nthr, tid, k, apply); break;
-        case 32: trip<WAVE, 32>(s, groups, nthr, tid, k, apply); break;
-        case 64: trip<WAVE, 64>(s, groups, nthr, tid, k, apply); break;
-        case 128: trip<WAVE, 128>(s, groups, nthr, tid, k, apply); break;
-        case 256: trip<WAVE, 256>(s, groups, nthr, tid, k, apply); break;
-        case 512: trip<WAVE, 512>(s, groups, nthr, tid, k, apply); break;
-        case 1024: trip<WAVE, 1024>(s, groups, nthr, tid, k, apply); break;
-        case 2048: trip<WAVE, 2048>(s, groups, nthr, tid, k, apply); break;
-        case 4096: trip<WAVE, 4096>(s, groups, nthr, tid, k, apply); break;
-        default: trip<WAVE, 8192>(s, groups, nthr, tid, k, apply); break;
+// The first three stages of level k = 2 H: mirror (i <-> i ^ (k - 1)), then the butterflies H/2 and H/4.  A thread owns
+// four keys of the lower half of a k-block (x + {0, H/4, H/2, 3H/4}) and their four mirror images in the upper half.
+template <bool WAVE, int H>
+__device__ __forceinline__ void mirror_trip(uint64_t *s, int groups, int n, int nthr, int tid) {
+    constexpr int A = H >> 1, B = H >> 2;
+    for (int g = tid; g < groups; g += nthr) {
+        int x = g;
+        x = ((x & ~(B - 1)) << 1) | (x & (B - 1));
+        x = ((x & ~(A - 1)) << 1) | (x & (A - 1));
+        x = ((x & ~(H - 1)) << 1) | (x & (H - 1));
+        if (x >= n) continue;
+        const int low = x & (B - 1);
+        const int pl = swz(x), pu = swz(x - low + H + (B - 1 - low));
+        uint64_t v[8];
+        v[0] = s[pl]; v[1] = s[pl ^ swz_d(B)]; v[2] = s[pl ^ swz_d(A)]; v[3] = s[pl ^ swz_d(A | B)];
+        v[4] = s[pu]; v[5] = s[pu ^ swz_d(B)]; v[6] = s[pu ^ swz_d(A)]; v[7] = s[pu ^ swz_d(A | B)];
+        cswap(v[0], v[7]); cswap(v[1], v[6]); cswap(v[2], v[5]); cswap(v[3], v[4]);
+        cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+        s[pl] = v[0]; s[pl ^ swz_d(B)] = v[1]; s[pl ^ swz_d(A)] = v[2]; s[pl ^ swz_d(A | B)] = v[3];
+        s[pu] = v[4]; s[pu ^ swz_d(B)] = v[5]; s[pu ^ swz_d(A)] = v[6]; s[pu ^ swz_d(A | B)] = v[7];
     }
+    lds_sync<WAVE>();
 }
+#define B3_STRIDE_SWITCH(J, CALL)                                                                                   \
+    switch (J) {                                                                                                     \
+        case 4: CALL(4); break; case 8: CALL(8); break; case 16: CALL(16); break; case 32: CALL(32); break;          \
+        case 64: CALL(64); break; case 128: CALL(128); break; case 256: CALL(256); break; case 512: CALL(512); break; \
+        case 1024: CALL(1024); break; case 2048: CALL(2048); break; case 4096: CALL(4096); break;                   \
+        default: CALL(8192); break;                                                                                   \
+    }
 
-// the stages of level k from stride j down to 1 (j a power of two, 4 <= j <= 8192)
+// the butterfly stages from stride j down to 1 (j a power of two, 1 <= j <= 8192)
 template <bool WAVE>
-__device__ __forceinline__ void level_tail(uint64_t *s, int groups, int nthr, int tid, int k, int j) {
+__device__ __forceinline__ void level_tail(uint64_t *s, int groups, int n, int nthr, int tid, int j) {
+    if (j < 4) {
+        trip<WAVE, 4>(s, groups, n, nthr, tid, j == 2 ? 3 : 1);
+        return;
+    }
     int upper = 0;
     for (int q = j; q >= 8; q >>= 1) ++upper;   // stages with stride >= 8
     while (upper > 0) {
         const int take = upper >= 3 ? 3 : upper;
-        trip_dyn<WAVE>(s, groups, nthr, tid, k, j, take == 3 ? 7 : take == 2 ? 6 : 4);
+        const int apply = take == 3 ? 7 : take == 2 ? 6 : 4;
+#define B3_CALL(S) trip<WAVE, S>(s, groups, n, nthr, tid, apply)
+        B3_STRIDE_SWITCH(j, B3_CALL)
+#undef B3_CALL
         j >>= take;
         upper -= take;
     }
-    trip<WAVE, 4>(s, groups, nthr, tid, k, 7);
+    trip<WAVE, 4>(s, groups, n, nthr, tid, 7);
 }
 
-// ascending bitonic sort of s[0, P) (P a power of two >= 8, keys at lpad(i)); callers synchronise before
+// ascending sort of s[0, P) (P a power of two >= 8, keys at swz(i), [n, P) holds KEY_INF); callers synchronise before
 template <bool WAVE>
-__device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int nthr, int tid) {
+__device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int n, int nthr, int tid) {
     const int groups = P >> 3;
     for (int g = tid; g < groups; g += nthr) {   // levels 2, 4, 8 on eight contiguous keys
         const int x = g << 3;
+        if (x >= n) continue;
+        const int px = swz(x);
         uint64_t v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = s[lpad(x + e)];
-        cswap(v[0], v[1], false); cswap(v[2], v[3], true); cswap(v[4], v[5], false); cswap(v[6], v[7], true);
-        cswap(v[0], v[2], false); cswap(v[1], v[3], false); cswap(v[4], v[6], true); cswap(v[5], v[7], true);
-        cswap(v[0], v[1], false); cswap(v[2], v[3], false); cswap(v[4], v[5], true); cswap(v[6], v[7], true);
-        const bool desc = (x & 8) != 0;
-        cswap(v[0], v[4], desc); cswap(v[1], v[5], desc); cswap(v[2], v[6], desc); cswap(v[3], v[7], desc);
-        cswap(v[0], v[2], desc); cswap(v[1], v[3], desc); cswap(v[4], v[6], desc); cswap(v[5], v[7], desc);
-        cswap(v[0], v[1], desc); cswap(v[2], v[3], desc); cswap(v[4], v[5], desc); cswap(v[6], v[7], desc);
+        for (int e = 0; e < 8; ++e) v[e] = s[px ^ e];
+        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+        cswap(v[0], v[3]); cswap(v[1], v[2]); cswap(v[4], v[7]); cswap(v[5], v[6]);
+        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+        cswap(v[0], v[7]); cswap(v[1], v[6]); cswap(v[2], v[5]); cswap(v[3], v[4]);
+        cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[lpad(x + e)] = v[e];
+        for (int e = 0; e < 8; ++e) s[px ^ e] = v[e];
     }
     lds_sync<WAVE>();
-    for (int k = 16; k <= P; k <<= 1) level_tail<WAVE>(s, groups, nthr, tid, k, k >> 1);
+    for (int k = 16; k <= P; k <<= 1) {
+        const int h = k >> 1;
+#define B3_CALL(S) mirror_trip<WAVE, S>(s, groups, n, nthr, tid)
+        B3_STRIDE_SWITCH(h, B3_CALL)
+#undef B3_CALL
+        level_tail<WAVE>(s, groups, n, nthr, tid, k >> 4);
+    }
 }
 
 __device__ __forceinline__ int pow2_ceil(int n) {
@@ -432,10 +487,10 @@ template <bool WAVE>
 __device__ __forceinline__ void sort_tile_lds(uint64_t *s, const uint64_t *__restrict__ keys, int64_t o0, int L, uint32_t bin,
                                               int nthr, int tid, const SortEpilogue &epi) {
     const int P = pow2_ceil(L);
-    for (int i = tid; i < P; i += nthr) s[lpad(i)] = i < L ? keys[o0 + i] : KEY_INF;
+    for (int i = tid; i < P; i += nthr) s[swz(i)] = i < L ? keys[o0 + i] : KEY_INF;
     lds_sync<WAVE>();
-    bitonic_sort<WAVE>(s, P, nthr, tid);
-    for (int i = tid; i < L; i += nthr) epi.store(o0 + i, bin, s[lpad(i)]);
+    bitonic_sort<WAVE>(s, P, L, nthr, tid);
+    for (int i = tid; i < L; i += nthr) epi.store(o0 + i, bin, s[swz(i)]);
     lds_sync<WAVE>();
 }
 
@@ -447,7 +502,7 @@ constexpr int LG_THREADS = 1024, LG_CAP = 16384;
 __global__ __launch_bounds__(B3_BLOCK) void bin3_sort_small_kernel(const int32_t *__restrict__ offsets,
                                                                   const int32_t *__restrict__ order, int n_bins, int64_t cap_M,
                                                                   const uint64_t *__restrict__ keys, const SortEpilogue epi) {
-    __shared__ uint64_t s_keys[SM_TILES * (SM_WAVE_CAP + SM_WAVE_CAP / 32)];   // >= lpad(SM_CAP)
+    __shared__ uint64_t s_keys[SM_TILES * SM_WAVE_CAP];   // >= SM_CAP
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int bin[SM_TILES], L[SM_TILES], o0[SM_TILES], max_l = 0;
 #pragma unroll
@@ -472,7 +527,7 @@ __global__ __launch_bounds__(B3_BLOCK) void bin3_sort_small_kernel(const int32_t
 #pragma unroll
         for (int q = 0; q < SM_TILES; ++q)
             if (q == wave) { bq = bin[q]; lq = L[q]; oq = o0[q]; }
-        if (lq > 0) sort_tile_lds<true>(s_keys + wave * (SM_WAVE_CAP + SM_WAVE_CAP / 32), keys, oq, lq, (uint32_t)bq, 64, lane, epi);
+        if (lq > 0) sort_tile_lds<true>(s_keys + wave * SM_WAVE_CAP, keys, oq, lq, (uint32_t)bq, 64, lane, epi);
     }
 }
 
@@ -483,7 +538,7 @@ __global__ __launch_bounds__(B3_BLOCK) void bin3_sort_small_kernel(const int32_t
 __global__ __launch_bounds__(LG_THREADS) void bin3_sort_large_kernel(const int32_t *__restrict__ offsets,
                                                                     const int32_t *__restrict__ order, int n_bins, int64_t cap_M,
                                                                     uint64_t *keys, const SortEpilogue epi) {
-    extern __shared__ uint64_t s_big[];   // lpad(LG_CAP)
+    extern __shared__ uint64_t s_big[];   // [LG_CAP]
     const int tid = threadIdx.x;
     for (int g = blockIdx.x; g < n_bins; g += gridDim.x) {
         const int bin = order[g];
@@ -502,10 +557,10 @@ __global__ __launch_bounds__(LG_THREADS) void bin3_sort_large_kernel(const int32
         const int nch = (L + LG_CAP - 1) / LG_CAP;
         for (int c = 0; c < nch; ++c) {   // every chunk ascending
             const int c0 = c * LG_CAP, n = min(LG_CAP, L - c0);
-            for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[lpad(i)] = i < n ? seg[c0 + i] : KEY_INF;
+            for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[swz(i)] = i < n ? seg[c0 + i] : KEY_INF;
             __syncthreads();
-            bitonic_sort<false>(s_big, LG_CAP, LG_THREADS, tid);
-            for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[lpad(i)];
+            bitonic_sort<false>(s_big, LG_CAP, n, LG_THREADS, tid);
+            for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[swz(i)];
             __syncthreads();
         }
         int64_t P = LG_CAP;
@@ -532,10 +587,10 @@ __global__ __launch_bounds__(LG_THREADS) void bin3_sort_large_kernel(const int32
             }
             for (int c = 0; c < nch; ++c) {                       // the remaining stages inside each chunk, in LDS
                 const int c0 = c * LG_CAP, n = min(LG_CAP, L - c0);
-                for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[lpad(i)] = i < n ? seg[c0 + i] : KEY_INF;
+                for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[swz(i)] = i < n ? seg[c0 + i] : KEY_INF;
                 __syncthreads();
-                level_tail<false>(s_big, LG_CAP >> 3, LG_THREADS, tid, /*k: all ascending*/ 1 << 30, LG_CAP >> 1);
-                for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[lpad(i)];
+                level_tail<false>(s_big, LG_CAP >> 3, n, LG_THREADS, tid, LG_CAP >> 1);
+                for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[swz(i)];
                 __syncthreads();
             }
         }
@@ -631,12 +686,12 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
                            bit_length_u32((uint32_t)(tile_w * tile_h)), C == 1};
     static const bool big_lds = [] {
         return hipFuncSetAttribute((const void *)bin3_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (LG_CAP + LG_CAP / 32) * 8) == hipSuccess &&
+                                   LG_CAP * 8) == hipSuccess &&
                hipFuncSetAttribute((const void *)bin3_tiles_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    MAX_BINS * 8) == hipSuccess;
     }();
-    MTGS_REQUIRE(big_lds, MTGS_ELAUNCH, "mtgs_bin3_build: cannot reserve %d bytes of LDS per workgroup", (LG_CAP + LG_CAP / 32) * 8);
-    bin3_sort_large_kernel<<<(unsigned)min(n_bins, 256), LG_THREADS, (size_t)(LG_CAP + LG_CAP / 32) * 8, st>>>(
+    MTGS_REQUIRE(big_lds, MTGS_ELAUNCH, "mtgs_bin3_build: cannot reserve %d bytes of LDS per workgroup", LG_CAP * 8);
+    bin3_sort_large_kernel<<<(unsigned)min(n_bins, 256), LG_THREADS, (size_t)LG_CAP * 8, st>>>(
         offsets, order, n_bins, cap_M, w.keys64, epi);
     bin3_sort_small_kernel<<<(unsigned)((n_bins + SM_TILES - 1) / SM_TILES), B3_BLOCK, 0, st>>>(offsets, order, n_bins, cap_M,
                                                                                              w.keys64, epi);

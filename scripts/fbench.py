@@ -33,7 +33,7 @@ vm, K = vm.to(dev).requires_grad_(True), K.to(dev)
 g = torch.Generator().manual_seed(1)
 D = P["colors"].shape[-1] + 1
 Gc, Ga = torch.randn(1, args.height, args.width, D, generator=g).to(dev), torch.randn(1, args.height, args.width, 1, generator=g).to(dev)
-names = ["mtgs_front_fwd", "mtgs_bin2_build", "mtgs_blend_fwd_packed", "mtgs_blend_bwd_packed", "mtgs_project_bwd"]
+names = ["mtgs_front_fwd", "mtgs_bin3_build", "mtgs_blend_fwd_packed", "mtgs_blend_bwd_packed", "mtgs_project_bwd"]
 
 
 def step():
