@@ -305,6 +305,11 @@ def main():
 
     info = info_box["info"]
     n_vis = int((info["radii"] > 0).sum().item())
+    # (Gaussian, tile row) items of the binning (csrc/bin3.hip): the tile rows each visible Gaussian's 3-sigma square spans
+    _r, _y = info["radii"].reshape(-1).float(), info["means2d"].detach().reshape(-1, 2)[:, 1]
+    _th = -(-args.height // 16)
+    _rows = (torch.ceil((_y + _r) / 16).clamp(0, _th) - torch.floor((_y - _r) / 16).clamp(0, _th))[_r > 0]
+    n_items = int(_rows.sum().item())
     M = int(info["flatten_ids"].numel())
     P = args.width * args.height
     ms_per_step = elapsed / args.steps * 1e3
@@ -340,9 +345,11 @@ def main():
                 "front_compact_kernel": args.n_gaussians * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
                 "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
                 "project_bwd_expand_kernel": args.n_gaussians * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
-                "bin2_emit_kernel": n_vis * 16 + M * 8,
-                "mtgs_sort::reorder_kernel<unsigned int, 16, mtgs_sort::NoEpilogue>": M * 16,
-                "mtgs_sort::reorder_kernel<unsigned int, 16, TileEpilogue>": M * (8 + 12 + 16),
+                "bin3_rows_count_kernel": n_vis * 64,
+                "bin3_rows_place_kernel": n_vis * 64 + n_items * 8,
+                "bin3_tiles_count_kernel": n_items * 8,
+                "bin3_tiles_place_kernel": n_items * (8 + 4) + M * 8,
+                "bin3_sort_small_kernel": M * (8 + 4 + 4 + 4 + 8),
                 "blend_fwd_kernel<4, 4, true>": M * (4 + 64) + P * (4 * D + 8),
                 "blend_bwd_kernel<4, 4, true>": bytes_bwd,
             }

@@ -274,13 +274,15 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  *   M = 2^31 - 1 signals more than 2^31 - 2 intersections (or an internal failure): the frame cannot be rendered.
  * ws: mtgs_front_workspace_bytes(C*N), 256-byte aligned.
  *
- * mtgs_bin2_build: depth sort of the visible pairs, emission in depth order, per-tile counts -> offsets[C*th*tw + 1]
- * (last entry = M) + tile_order (nullable), tile sort -> rank_ids[cap_M] (record / gradient-row index of every
- * intersection), flatten_ids[cap_M] (gsplat), isect_ids[cap_M] (gsplat; nullable).  Sizes come from `totals` on the
- * device, clamped to (cap_vis, cap_M): the caller sizes buffers and this call sizes grids for the capacities; if the
- * true totals exceed them the outputs are truncated (never out of bounds) and the caller repeats with larger ones.
- * Supported when mtgs_bin2_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 12288, cap_M < 2^30), else use
- * mtgs_bin_build.  ws: mtgs_bin2_workspace_bytes, 256-byte aligned.
+ * mtgs_bin3_build: the tile binning of the frame WITHOUT a global sort -- (Gaussian, tile row) items grouped by row,
+ * expanded into per-tile segments (unordered), every segment sorted on (depth bits, rank) by one workgroup in LDS:
+ * offsets[C*th*tw + 1] (last entry = M) + tile_order (nullable), rank_ids[cap_M] (record / gradient-row index of
+ * every intersection), flatten_ids[cap_M] (gsplat), isect_ids[cap_M] (gsplat; nullable) -- bit-identical to gsplat's
+ * isect_tiles(sort=True) + isect_offset_encode.  Sizes come from `totals` on the device, clamped to (cap_vis, cap_M):
+ * the caller sizes buffers and this call sizes grids for the capacities; if the true totals exceed them the outputs are
+ * truncated (never out of bounds) and the caller repeats with larger ones.  Seven launches.
+ * Supported when mtgs_bin3_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 12288, C*tile_h <= 1024,
+ * cap_M < 2^30), else use mtgs_bin_build.  ws: mtgs_bin3_workspace_bytes, 256-byte aligned.
  *
  * mtgs_blend_fwd_packed / mtgs_blend_bwd_packed: mtgs_blend_fwd / _bwd reading the records through rank_ids.
  * grad_rows[n_vis, row_stride] f32 (zeroed by the caller): [xy 2 | |xy| 2 (absgrad) | conic 3 | opacity 1 | colours D |
@@ -295,22 +297,12 @@ int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, con
                    int32_t *vis_rank, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
                    int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes,
                    void *stream);
-/* mtgs_bin3_*: the same outputs as mtgs_bin2_build (bit-identical) without any global sort: (Gaussian, tile row) items
- * grouped by row, expanded into per-tile segments (unordered), every segment sorted on (depth bits, rank) by one
- * workgroup in LDS.  Seven launches; same capacity / device-side size rules; additionally C * tile_h <= 1024. */
 int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M);
 int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
 int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
                     int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                     const int64_t *vis_keys, int32_t *rank_ids, int32_t *flatten_ids, int64_t *isect_ids,
                     int32_t *offsets, int32_t *tile_order, void *ws, size_t ws_bytes, void *stream);
-int mtgs_bin2_supported(int C, int tile_w, int tile_h, int64_t cap_M);
-int mtgs_bin2_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
-int mtgs_bin2_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
-                    int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
-                    const int64_t *vis_keys, int32_t *rank_ids, int32_t *flatten_ids,
-                    int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, void *ws, size_t ws_bytes,
-                    void *stream);
 int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,

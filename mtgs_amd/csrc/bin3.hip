@@ -5,8 +5,9 @@
 // isect_ids and isect_offsets are bit-identical (tests/test_gpu_parity.py, tests/test_gpu_fused.py).
 //
 // gsplat sorts all M intersections on a 64-bit (camera | tile | depth) key: six radix passes over 12-byte pairs.
-// bin2.hip sorts the visible Gaussians by depth and then the intersections on the tile bits: 4 + 2 passes.  Here no
-// array is sorted globally at all.  The order gsplat defines is "by tile, then by depth, then by Gaussian index"; which
+// bin.hip (operator level) sorts the visible Gaussians by depth and then the intersections on the tile bits: 4 + 2
+// passes (its device-sized, 17-launch form was this path until round 2: 241 us at the headline size against 160 us
+// here).  Here no array is sorted globally at all.  The order gsplat defines is "by tile, then by depth, then by Gaussian index"; which
 // intersections belong to a tile does not depend on any order, only their arrangement INSIDE the tile's list does:
 //   1. bin3_rows_{count,place}_kernel   (Gaussian, tile row) ITEMS grouped by row: 3.6 per visible Gaussian; the
 //                             count pass hands every (workgroup, row) pair its base inside the row's segment with one
@@ -34,7 +35,7 @@
 // (M*(8+16) bytes of HBM against ~log2(L)^2/2 compare-exchanges per key).
 #include "common.hpp"
 #include "tile_rect.hpp"
-#include "onesweep.hpp"
+#include "devsize.hpp"
 #include "raster_rec.hpp"
 
 namespace {
@@ -78,6 +79,11 @@ __device__ __forceinline__ bool arrive_last(uint32_t *done, int64_t active, int 
 }
 
 constexpr int R_BLOCK = 1024;
+// A thread walks the rows of its Gaussian (the tiles of its item) itself up to SERIAL_MAX of them; larger ones -- a
+// Gaussian right in front of the camera covers all 68 rows x 120 tiles -- are queued in LDS and shared out over the
+// lanes of a wave.  (With a low threshold the queue costs more than it saves -- 8: 49 us against 38 us for the tile
+// placement -- because every queued item is re-read from global memory by the wave that expands it.)
+constexpr int SERIAL_MAX = 48;
 // counts per (workgroup, row); every pair gets its base inside the row's segment from ONE returning atomic
 __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef n_vis_ref, const float *__restrict__ recs,
                                                                  const int32_t *__restrict__ vis_ids, int64_t N, int C, float ts,
@@ -86,6 +92,8 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef 
                                                                  uint32_t *__restrict__ row_start /* [n_rows + 1] */) {
     __shared__ uint32_t s_row[MAX_ROWS];
     __shared__ uint32_t s_ws[R_BLOCK / 64];
+    __shared__ uint16_t s_tall[R_BLOCK];
+    __shared__ uint32_t s_ntall;
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_vis = mtgs_os::size_of(n_vis_ref);
@@ -96,10 +104,20 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef 
         return;
     }
     for (int b = tid; b < n_rows; b += R_BLOCK) s_row[b] = 0;
+    if (tid == 0) s_ntall = 0;
     __syncthreads();
     if (r < n_vis) {
         const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
-        for (int y = 0; y < g.h; ++y) atomicAdd(&s_row[g.row0 + y], 1u);
+        if (g.h <= SERIAL_MAX) {
+            for (int y = 0; y < g.h; ++y) atomicAdd(&s_row[g.row0 + y], 1u);
+        } else {
+            s_tall[atomicAdd(&s_ntall, 1u)] = (uint16_t)tid;   // a wave shares its rows (below)
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = wave; q < s_ntall; q += R_BLOCK / 64) {
+        const RowGeom g = row_geom(recs, vis_ids, (int64_t)blockIdx.x * R_BLOCK + s_tall[q], N, C, ts, tw, th);
+        for (int y = lane; y < g.h; y += 64) atomicAdd(&s_row[g.row0 + y], 1u);
     }
     __syncthreads();
     for (int b = tid; b < n_rows; b += R_BLOCK) {
@@ -136,28 +154,42 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef 
                                                                  const uint32_t *__restrict__ rbase, int64_t cap_items,
                                                                  Item *__restrict__ items) {
     __shared__ uint32_t s_row[MAX_ROWS];   // next free slot of this workgroup in each row's segment
-    const int tid = threadIdx.x;
+    __shared__ uint16_t s_tall[R_BLOCK];
+    __shared__ uint32_t s_ntall;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_vis = mtgs_os::size_of(n_vis_ref);
     if ((int64_t)blockIdx.x * R_BLOCK >= n_vis) return;
     // (rows this workgroup has no item in were never given a base: their entry is not read below)
     for (int b = tid; b < n_rows; b += R_BLOCK) s_row[b] = row_start[b] + rbase[(size_t)blockIdx.x * n_rows + b];
+    if (tid == 0) s_ntall = 0;
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * R_BLOCK + tid;
-    if (r >= n_vis) return;
-    const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
-    for (int y = 0; y < g.h; ++y) {
-        const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
-        if (pos < cap_items) items[pos] = Item{(uint32_t)r, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
+    if (r < n_vis) {
+        const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
+        if (g.h <= SERIAL_MAX) {
+            for (int y = 0; y < g.h; ++y) {
+                const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
+                if (pos < cap_items) items[pos] = Item{(uint32_t)r, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
+            }
+        } else {
+            s_tall[atomicAdd(&s_ntall, 1u)] = (uint16_t)tid;
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = wave; q < s_ntall; q += R_BLOCK / 64) {
+        const int64_t rq = (int64_t)blockIdx.x * R_BLOCK + s_tall[q];
+        const RowGeom g = row_geom(recs, vis_ids, rq, N, C, ts, tw, th);
+        for (int y = lane; y < g.h; y += 64) {
+            const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
+            if (pos < cap_items) items[pos] = Item{(uint32_t)rq, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
+        }
     }
 }
 
 // ---- 2. per-tile counts -> offsets, tile dispatch order ---------------------------------------------------------
 // The items are grouped by row, so the tiles a workgroup's 1024 items touch are a short contiguous range of tile ids
 // (one or two rows): only that range of the LDS histogram is cleared and flushed.
-#ifndef B3_T_ITEMS
-#define B3_T_ITEMS 2
-#endif
-constexpr int T_THREADS = 1024, T_ITEMS = B3_T_ITEMS, T_TILE = T_THREADS * T_ITEMS, SCHED_BUCKETS = 1024;
+constexpr int T_THREADS = 1024, T_ITEMS = 2, T_TILE = T_THREADS * T_ITEMS, SCHED_BUCKETS = 1024;
 struct TileRange { int lo, hi; };
 __device__ __forceinline__ TileRange tile_range(const Item *__restrict__ items, int64_t base, int64_t n_items, int tw) {
     const int64_t last = min(n_items, base + T_TILE) - 1;
@@ -172,20 +204,24 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
     extern __shared__ uint32_t s_bins[];  // [n_bins]
     __shared__ uint32_t s_aux[SCHED_BUCKETS];
     __shared__ uint32_t s_ws[T_THREADS / 64];
+    __shared__ uint16_t s_wide[T_TILE];
+    __shared__ uint32_t s_nwide;
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_items = min((int64_t)*n_items_ptr, cap_items);
-    const int64_t base = (int64_t)blockIdx.x * T_TILE;
-    if (base >= n_items) {
+    if ((int64_t)blockIdx.x * T_TILE >= n_items) {
         if (n_items == 0 && blockIdx.x == 0) {   // nothing visible: empty lists, any order
             for (int b = tid; b <= n_bins; b += T_THREADS) offsets[b] = 0;
             for (int b = tid; b < n_bins; b += T_THREADS) order[b] = b;
         }
         return;
     }
-    {
+    // (the grid is a few workgroups per CU, not one per chunk: a capacity-sized grid of 1024-thread workgroups that
+    // find nothing to do costs more to dispatch than the kernel takes)
+    for (int64_t base = (int64_t)blockIdx.x * T_TILE; base < n_items; base += (int64_t)gridDim.x * T_TILE) {
         const TileRange tr = tile_range(items, base, n_items, tw);
         for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) s_bins[b] = 0;
+        if (tid == 0) s_nwide = 0;
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < T_ITEMS; ++e) {
@@ -193,16 +229,27 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
             if (i < n_items) {
                 const Item it = items[i];
                 const int t0 = (int)(it.span >> SPAN_BITS), w = (int)(it.span & ((1u << SPAN_BITS) - 1)) + 1;
-                for (int x = 0; x < w; ++x) atomicAdd(&s_bins[t0 + x], 1u);
+                if (w <= SERIAL_MAX) {
+                    for (int x = 0; x < w; ++x) atomicAdd(&s_bins[t0 + x], 1u);
+                } else {
+                    s_wide[atomicAdd(&s_nwide, 1u)] = (uint16_t)(e * T_THREADS + tid);
+                }
             }
+        }
+        __syncthreads();
+        for (uint32_t q = wave; q < s_nwide; q += T_THREADS / 64) {
+            const Item it = items[base + s_wide[q]];
+            const int t0 = (int)(it.span >> SPAN_BITS), w = (int)(it.span & ((1u << SPAN_BITS) - 1)) + 1;
+            for (int x = lane; x < w; x += 64) atomicAdd(&s_bins[t0 + x], 1u);
         }
         __syncthreads();
         for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
             const uint32_t c = s_bins[b];
             if (c) __hip_atomic_fetch_add(bins + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __syncthreads();
     }
-    if (!arrive_last(done, ceil_div64(n_items, T_TILE), &s_last)) return;
+    if (!arrive_last(done, min((int64_t)gridDim.x, ceil_div64(n_items, T_TILE)), &s_last)) return;
     for (int b = tid; b < n_bins; b += T_THREADS) s_bins[b] = mtgs_os::ld32(bins + b);
     __syncthreads();
     // exclusive scan of the counts -> offsets, clamped to the capacity of the key / id arrays: a frame beyond its
@@ -264,48 +311,69 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
     const int32_t *__restrict__ offsets, uint32_t *__restrict__ cursor /* [n_bins], zero */,
     const uint64_t *__restrict__ vis_keys, uint64_t *__restrict__ keys64) {
     extern __shared__ uint32_t s_mem[];   // next free slot [n_bins] | end of the tile's segment [n_bins]
+    __shared__ uint16_t s_wide[T_TILE];
+    __shared__ uint32_t s_nwide;
     uint32_t *s_bins = s_mem, *s_end = s_mem + n_bins;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_items = min((int64_t)*n_items_ptr, cap_items);
-    const int64_t base = (int64_t)blockIdx.x * T_TILE;
-    if (base >= n_items) return;
-    const TileRange tr = tile_range(items, base, n_items, tw);
-    for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) s_bins[b] = 0;
-    __syncthreads();
-    Item it[T_ITEMS];
-    int t0[T_ITEMS], w[T_ITEMS];
-    uint32_t depth[T_ITEMS];
+    for (int64_t base = (int64_t)blockIdx.x * T_TILE; base < n_items; base += (int64_t)gridDim.x * T_TILE) {
+        const TileRange tr = tile_range(items, base, n_items, tw);
+        for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) s_bins[b] = 0;
+        if (tid == 0) s_nwide = 0;
+        __syncthreads();
+        Item it[T_ITEMS];
+        int t0[T_ITEMS], w[T_ITEMS];
+        uint32_t depth[T_ITEMS];
 #pragma unroll
-    for (int e = 0; e < T_ITEMS; ++e) {
-        const int64_t i = base + e * T_THREADS + tid;
-        it[e] = Item{0, 0}; t0[e] = 0; w[e] = 0; depth[e] = 0;
-        if (i < n_items) {
-            it[e] = items[i];
-            t0[e] = (int)(it[e].span >> SPAN_BITS); w[e] = (int)(it[e].span & ((1u << SPAN_BITS) - 1)) + 1;
-            depth[e] = (uint32_t)vis_keys[it[e].rank];
-            for (int x = 0; x < w[e]; ++x) atomicAdd(&s_bins[t0[e] + x], 1u);
+        for (int e = 0; e < T_ITEMS; ++e) {
+            const int64_t i = base + e * T_THREADS + tid;
+            it[e] = Item{0, 0}; t0[e] = 0; w[e] = 0; depth[e] = 0;
+            if (i < n_items) {
+                it[e] = items[i];
+                t0[e] = (int)(it[e].span >> SPAN_BITS); w[e] = (int)(it[e].span & ((1u << SPAN_BITS) - 1)) + 1;
+                depth[e] = (uint32_t)vis_keys[it[e].rank];
+                if (w[e] <= SERIAL_MAX) {
+                    for (int x = 0; x < w[e]; ++x) atomicAdd(&s_bins[t0[e] + x], 1u);
+                } else {
+                    s_wide[atomicAdd(&s_nwide, 1u)] = (uint16_t)(e * T_THREADS + tid);
+                    w[e] = 0;   // a wave shares its tiles (below)
+                }
+            }
         }
-    }
-    __syncthreads();
-    for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
-        const uint32_t c = s_bins[b];
-        if (c) {
-            s_bins[b] = (uint32_t)offsets[b] + __hip_atomic_fetch_add(cursor + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_end[b] = (uint32_t)offsets[b + 1];   // (shorter than the count only in a frame beyond its capacities)
+        __syncthreads();
+        const uint32_t n_wide = s_nwide;
+        for (uint32_t q = wave; q < n_wide; q += T_THREADS / 64) {
+            const Item iw = items[base + s_wide[q]];
+            const int tq = (int)(iw.span >> SPAN_BITS), wq = (int)(iw.span & ((1u << SPAN_BITS) - 1)) + 1;
+            for (int x = lane; x < wq; x += 64) atomicAdd(&s_bins[tq + x], 1u);
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
+            const uint32_t c = s_bins[b];
+            if (c) {
+                s_bins[b] = (uint32_t)offsets[b] + __hip_atomic_fetch_add(cursor + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_end[b] = (uint32_t)offsets[b + 1];   // (shorter than the count only in a frame beyond its capacities)
+            }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int e = 0; e < T_ITEMS; ++e) {
-        const uint64_t key = ((uint64_t)depth[e] << 32) | it[e].rank;
-        for (int x = 0; x < w[e]; ++x) {
-            const uint32_t pos = atomicAdd(&s_bins[t0[e] + x], 1u);
-#ifdef B3_NO_STORE
-            if (pos == 0xffffffffu) keys64[pos] = key;
-#else
-            if (pos < s_end[t0[e] + x]) keys64[pos] = key;
-#endif
+        for (int e = 0; e < T_ITEMS; ++e) {
+            const uint64_t key = ((uint64_t)depth[e] << 32) | it[e].rank;
+            for (int x = 0; x < w[e]; ++x) {
+                const uint32_t pos = atomicAdd(&s_bins[t0[e] + x], 1u);
+                if (pos < s_end[t0[e] + x]) keys64[pos] = key;
+            }
         }
+        for (uint32_t q = wave; q < n_wide; q += T_THREADS / 64) {
+            const Item iw = items[base + s_wide[q]];
+            const int tq = (int)(iw.span >> SPAN_BITS), wq = (int)(iw.span & ((1u << SPAN_BITS) - 1)) + 1;
+            const uint64_t key = ((uint64_t)(uint32_t)vis_keys[iw.rank] << 32) | iw.rank;
+            for (int x = lane; x < wq; x += 64) {
+                const uint32_t pos = atomicAdd(&s_bins[tq + x], 1u);
+                if (pos < s_end[tq + x]) keys64[pos] = key;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -335,21 +403,25 @@ struct SortEpilogue {
 // others are plain butterflies), so no comparator needs a direction, and padding keys (+inf) never move down: work
 // items that hold only padding are skipped.
 constexpr uint64_t KEY_INF = 0x7ff0000000000000ull;
-// LDS layout: key i lives at i ^ T(bits 5..7 of i), T linear over GF(2) with columns (31, 27, 22).  ds_read_b64 serves
-// 32 lanes per cycle from 64 four-byte banks, i.e. it is conflict-free when the 32 keys fall into 32 different 8-byte
-// columns of the 256-byte row.  The 32 lanes of a group hold work items whose keys differ in five index bits -- the
-// lowest five that are not stage strides of the trip: {3..7}, {0,4..7}, {0,1,5,6,7}, {0,1,2,6,7}, {0,1,2,3,7} or
-// {0..4} -- and with these columns each of those sets maps onto the five column bits bijectively (a padding of one key
-// per 32 left 45 % of the LDS cycles of the sort to bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
-__host__ __device__ constexpr int swz_t(int hi3) { return ((hi3 & 1) ? 31 : 0) ^ ((hi3 & 2) ? 27 : 0) ^ ((hi3 & 4) ? 22 : 0); }
-__device__ __forceinline__ int swz(int i) {
-    return i ^ (int)((0x120d0916041b1f00ull >> ((i >> 2) & 0x38)) & 31);   // bytes = swz_t(0..7)
+// LDS layout: key i lives at i ^ T(bits 5..8 of i), T linear over GF(2) with columns (15, 11, 29, 17).  ds_read_b64
+// serves 32 lanes per cycle from 64 four-byte banks, i.e. it is conflict-free when the 32 keys fall into 32 different
+// 8-byte columns of the 256-byte row.  The 32 lanes of a group hold work items whose keys differ in five index bits --
+// the lowest five that are not stage strides of the trip: with 8 keys per thread {3..7}, {0,4..7}, {0,1,5,6,7},
+// {0,1,2,6,7}, {0,1,2,3,7} or {0..4}, with 16 keys {4..8}, {0,5..8}, {0,1,6,7,8}, {0,1,2,7,8}, {0,1,2,3,8} or {0..4} --
+// and with these columns each of those sets maps onto the five column bits bijectively (a padding of one key per 32
+// left 45 % of the LDS cycles of the sort to bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+__host__ __device__ constexpr int swz_t(int hi4) {
+    return ((hi4 & 1) ? 15 : 0) ^ ((hi4 & 2) ? 11 : 0) ^ ((hi4 & 4) ? 29 : 0) ^ ((hi4 & 8) ? 17 : 0);
 }
-static_assert(swz_t(1) == 0x1f && swz_t(2) == 0x1b && swz_t(3) == 0x04 && swz_t(4) == 0x16 && swz_t(5) == 0x09 &&
-              swz_t(6) == 0x0d && swz_t(7) == 0x12, "packed table");
-// swz(x ^ d) = swz(x) ^ swz_d(d) for any d (T is linear); the stage strides are compile-time, so a thread's eight keys
-// are one swizzled base and eight XOR constants
-__host__ __device__ constexpr int swz_d(int d) { return d ^ swz_t((d >> 5) & 7); }
+__device__ __forceinline__ int swz(int i) {
+    const int t = (int)((0x1916121d040b0f00ull >> ((i >> 2) & 0x38)) & 31);   // bytes = swz_t(0..7)
+    return i ^ t ^ ((i & 256) ? 17 : 0);
+}
+static_assert(swz_t(1) == 0x0f && swz_t(2) == 0x0b && swz_t(3) == 0x04 && swz_t(4) == 0x1d && swz_t(5) == 0x12 &&
+              swz_t(6) == 0x16 && swz_t(7) == 0x19 && swz_t(8) == 17, "packed table");
+// swz(x ^ d) = swz(x) ^ swz_d(d) for any d (T is linear); the stage strides are compile-time, so a thread's keys are
+// one swizzled base and XOR constants
+__host__ __device__ constexpr int swz_d(int d) { return d ^ swz_t((d >> 5) & 15); }
 __device__ __forceinline__ void cswap(uint64_t &a, uint64_t &b) {   // a <- min, b <- max
     const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
     double lo, hi;
@@ -368,54 +440,60 @@ template <bool WAVE> __device__ __forceinline__ void lds_sync() {
     }
 }
 
-// Up to three consecutive butterfly stages in ONE LDS round trip: a thread owns the eight keys whose indices differ in
-// the bits S2 > S1 > S0 (the stage strides, compile-time so that the eight LDS addresses are one base plus immediates:
-// x has zeros at those bits, so swz(x + d) = swz(x) + d + (d >> 5) without carries); `apply` = which of the three
-// stages run (bit 2: S2 ...).  n = number of real keys (the rest of [0, P) is padding).
-template <bool WAVE, int S2>
+// LOGE consecutive butterfly stages in ONE LDS round trip: a thread owns the E = 2^LOGE keys x + e * SLOW whose indices
+// differ in the stage strides STOP, STOP/2 ... SLOW (compile-time, x has zeros at those bits); `apply` = which of the
+// stages run (bit LOGE-1: STOP ...).  n = number of real keys (the rest of [0, P) is padding).
+template <bool WAVE, int LOGE, int STOP>
 __device__ __forceinline__ void trip(uint64_t *s, int groups, int n, int nthr, int tid, int apply) {
-    constexpr int S1 = S2 >> 1, S0 = S2 >> 2;
-    for (int g = tid; g < groups; g += nthr) {
-        int x = g;
-        x = ((x & ~(S0 - 1)) << 1) | (x & (S0 - 1));
-        x = ((x & ~(S1 - 1)) << 1) | (x & (S1 - 1));
-        x = ((x & ~(S2 - 1)) << 1) | (x & (S2 - 1));
-        if (x >= n) continue;
-        const int px = swz(x);
-        uint64_t v[8];
+    constexpr int E = 1 << LOGE, SLOW = STOP >> (LOGE - 1);
+    if constexpr (SLOW >= 1) {
+        for (int g = tid; g < groups; g += nthr) {
+            const int x = ((g & ~(SLOW - 1)) << LOGE) | (g & (SLOW - 1));
+            if (x >= n) continue;
+            const int px = swz(x);
+            uint64_t v[E];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = s[px ^ swz_d(((e & 4) ? S2 : 0) | ((e & 2) ? S1 : 0) | ((e & 1) ? S0 : 0))];
-        if (apply & 4) { cswap(v[0], v[4]); cswap(v[1], v[5]); cswap(v[2], v[6]); cswap(v[3], v[7]); }
-        if (apply & 2) { cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]); }
-        if (apply & 1) { cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]); }
+            for (int e = 0; e < E; ++e) v[e] = s[px ^ swz_d(e * SLOW)];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[px ^ swz_d(((e & 4) ? S2 : 0) | ((e & 2) ? S1 : 0) | ((e & 1) ? S0 : 0))] = v[e];
+            for (int bit = E >> 1; bit >= 1; bit >>= 1)
+                if (apply & bit) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (!(e & bit)) cswap(v[e], v[e | bit]);
+                }
+#pragma unroll
+            for (int e = 0; e < E; ++e) s[px ^ swz_d(e * SLOW)] = v[e];
+        }
+        lds_sync<WAVE>();
     }
-    lds_sync<WAVE>();
 }
-// The first three stages of level k = 2 H: mirror (i <-> i ^ (k - 1)), then the butterflies H/2 and H/4.  A thread owns
-// four keys of the lower half of a k-block (x + {0, H/4, H/2, 3H/4}) and their four mirror images in the upper half.
-template <bool WAVE, int H>
+// The first LOGE stages of level k = 2 H: mirror (i <-> i ^ (k - 1)), then the butterflies H/2 ... B = H >> (LOGE-1).
+// A thread owns E/2 keys of the lower half of a k-block (x + f B) and their mirror images in the upper half.
+template <bool WAVE, int LOGE, int H>
 __device__ __forceinline__ void mirror_trip(uint64_t *s, int groups, int n, int nthr, int tid) {
-    constexpr int A = H >> 1, B = H >> 2;
-    for (int g = tid; g < groups; g += nthr) {
-        int x = g;
-        x = ((x & ~(B - 1)) << 1) | (x & (B - 1));
-        x = ((x & ~(A - 1)) << 1) | (x & (A - 1));
-        x = ((x & ~(H - 1)) << 1) | (x & (H - 1));
-        if (x >= n) continue;
-        const int low = x & (B - 1);
-        const int pl = swz(x), pu = swz(x - low + H + (B - 1 - low));
-        uint64_t v[8];
-        v[0] = s[pl]; v[1] = s[pl ^ swz_d(B)]; v[2] = s[pl ^ swz_d(A)]; v[3] = s[pl ^ swz_d(A | B)];
-        v[4] = s[pu]; v[5] = s[pu ^ swz_d(B)]; v[6] = s[pu ^ swz_d(A)]; v[7] = s[pu ^ swz_d(A | B)];
-        cswap(v[0], v[7]); cswap(v[1], v[6]); cswap(v[2], v[5]); cswap(v[3], v[4]);
-        cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
-        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
-        s[pl] = v[0]; s[pl ^ swz_d(B)] = v[1]; s[pl ^ swz_d(A)] = v[2]; s[pl ^ swz_d(A | B)] = v[3];
-        s[pu] = v[4]; s[pu ^ swz_d(B)] = v[5]; s[pu ^ swz_d(A)] = v[6]; s[pu ^ swz_d(A | B)] = v[7];
+    constexpr int E = 1 << LOGE, HALF = E >> 1, B = H >> (LOGE - 1);
+    if constexpr (B >= 1) {
+        for (int g = tid; g < groups; g += nthr) {
+            const int x = ((g & ~(B - 1)) << LOGE) | (g & (B - 1));
+            if (x >= n) continue;
+            const int low = x & (B - 1);
+            const int pl = swz(x), pu = swz(x - low + H + (B - 1 - low));
+            uint64_t v[E];
+#pragma unroll
+            for (int f = 0; f < HALF; ++f) { v[f] = s[pl ^ swz_d(f * B)]; v[HALF + f] = s[pu ^ swz_d(f * B)]; }
+#pragma unroll
+            for (int f = 0; f < HALF; ++f) cswap(v[f], v[E - 1 - f]);
+#pragma unroll
+            for (int bit = HALF >> 1; bit >= 1; bit >>= 1) {
+#pragma unroll
+                for (int f = 0; f < HALF; ++f)
+                    if (!(f & bit)) { cswap(v[f], v[f | bit]); cswap(v[HALF + f], v[HALF + (f | bit)]); }
+            }
+#pragma unroll
+            for (int f = 0; f < HALF; ++f) { s[pl ^ swz_d(f * B)] = v[f]; s[pu ^ swz_d(f * B)] = v[HALF + f]; }
+        }
+        lds_sync<WAVE>();
     }
-    lds_sync<WAVE>();
 }
 #define B3_STRIDE_SWITCH(J, CALL)                                                                                   \
     switch (J) {                                                                                                     \
@@ -425,55 +503,67 @@ __device__ __forceinline__ void mirror_trip(uint64_t *s, int groups, int n, int 
         default: CALL(8192); break;                                                                                   \
     }
 
-// the butterfly stages from stride j down to 1 (j a power of two, 1 <= j <= 8192)
-template <bool WAVE>
+// the butterfly stages from stride j down to 1 (j a power of two, 1 <= j <= 8192; groups = P >> LOGE)
+template <bool WAVE, int LOGE>
 __device__ __forceinline__ void level_tail(uint64_t *s, int groups, int n, int nthr, int tid, int j) {
-    if (j < 4) {
-        trip<WAVE, 4>(s, groups, n, nthr, tid, j == 2 ? 3 : 1);
-        return;
-    }
-    int upper = 0;
-    for (int q = j; q >= 8; q >>= 1) ++upper;   // stages with stride >= 8
-    while (upper > 0) {
-        const int take = upper >= 3 ? 3 : upper;
-        const int apply = take == 3 ? 7 : take == 2 ? 6 : 4;
-#define B3_CALL(S) trip<WAVE, S>(s, groups, n, nthr, tid, apply)
+    constexpr int E = 1 << LOGE;
+    int r = 0;
+    for (int q = j; q >= 1; q >>= 1) ++r;       // stages left
+    while (r > LOGE) {                           // from the top, LOGE at a time, down to stride E
+        const int take = r - LOGE >= LOGE ? LOGE : r - LOGE;
+        const int apply = ((1 << take) - 1) << (LOGE - take);
+#define B3_CALL(S) trip<WAVE, LOGE, S>(s, groups, n, nthr, tid, apply)
         B3_STRIDE_SWITCH(j, B3_CALL)
 #undef B3_CALL
         j >>= take;
-        upper -= take;
+        r -= take;
     }
-    trip<WAVE, 4>(s, groups, n, nthr, tid, 7);
+    trip<WAVE, LOGE, E / 2>(s, groups, n, nthr, tid, (1 << r) - 1);   // strides E/2 ... 1 (the last r of them)
 }
 
-// ascending sort of s[0, P) (P a power of two >= 8, keys at swz(i), [n, P) holds KEY_INF); callers synchronise before
-template <bool WAVE>
-__device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int n, int nthr, int tid) {
-    const int groups = P >> 3;
-    for (int g = tid; g < groups; g += nthr) {   // levels 2, 4, 8 on eight contiguous keys
-        const int x = g << 3;
+// ascending sort of s[0, P) (P a power of two >= E, key i at swz(i), [n, P) holds KEY_INF); callers synchronise before
+template <bool WAVE, int LOGE>
+__device__ __forceinline__ void bitonic_sort_e(uint64_t *s, int P, int n, int nthr, int tid) {
+    constexpr int E = 1 << LOGE;
+    const int groups = P >> LOGE;
+    for (int g = tid; g < groups; g += nthr) {   // levels 2 ... E on E contiguous keys, in registers
+        const int x = g << LOGE;
         if (x >= n) continue;
         const int px = swz(x);
-        uint64_t v[8];
+        uint64_t v[E];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = s[px ^ e];
-        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
-        cswap(v[0], v[3]); cswap(v[1], v[2]); cswap(v[4], v[7]); cswap(v[5], v[6]);
-        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
-        cswap(v[0], v[7]); cswap(v[1], v[6]); cswap(v[2], v[5]); cswap(v[3], v[4]);
-        cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
-        cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+        for (int e = 0; e < E; ++e) v[e] = s[px ^ e];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[px ^ e] = v[e];
+        for (int k = 2; k <= E; k <<= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((e ^ (k - 1)) > e) cswap(v[e], v[e ^ (k - 1)]);
+#pragma unroll
+            for (int j = k >> 2; j >= 1; j >>= 1) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (!(e & j)) cswap(v[e], v[e | j]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[px ^ e] = v[e];
     }
     lds_sync<WAVE>();
-    for (int k = 16; k <= P; k <<= 1) {
+    for (int k = 2 * E; k <= P; k <<= 1) {
         const int h = k >> 1;
-#define B3_CALL(S) mirror_trip<WAVE, S>(s, groups, n, nthr, tid)
+#define B3_CALL(S) mirror_trip<WAVE, LOGE, S>(s, groups, n, nthr, tid)
         B3_STRIDE_SWITCH(h, B3_CALL)
 #undef B3_CALL
-        level_tail<WAVE>(s, groups, n, nthr, tid, k >> 4);
+        if ((k >> (LOGE + 1)) >= 1) level_tail<WAVE, LOGE>(s, groups, n, nthr, tid, k >> (LOGE + 1));
     }
+}
+#ifndef B3_LOGE
+#define B3_LOGE 3
+#endif
+template <bool WAVE>
+__device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int n, int nthr, int tid) {
+    if (B3_LOGE == 4 && P >= 1024) bitonic_sort_e<WAVE, B3_LOGE>(s, P, n, nthr, tid);
+    else bitonic_sort_e<WAVE, 3>(s, P, n, nthr, tid);
 }
 
 __device__ __forceinline__ int pow2_ceil(int n) {
@@ -589,7 +679,7 @@ __global__ __launch_bounds__(LG_THREADS) void bin3_sort_large_kernel(const int32
                 const int c0 = c * LG_CAP, n = min(LG_CAP, L - c0);
                 for (int i = tid; i < LG_CAP; i += LG_THREADS) s_big[swz(i)] = i < n ? seg[c0 + i] : KEY_INF;
                 __syncthreads();
-                level_tail<false>(s_big, LG_CAP >> 3, n, LG_THREADS, tid, LG_CAP >> 1);
+                level_tail<false, 3>(s_big, LG_CAP >> 3, n, LG_THREADS, tid, LG_CAP >> 1);
                 for (int i = tid; i < n; i += LG_THREADS) seg[c0 + i] = s_big[swz(i)];
                 __syncthreads();
             }
@@ -672,7 +762,7 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
     const SizeRef n_vis_ref{totals, 1, cap_vis};
     int32_t *order = tile_order ? tile_order : w.order;
     const unsigned r_grid = (unsigned)ceil_div64(cap_vis > 0 ? cap_vis : 1, R_BLOCK);
-    const unsigned t_grid = (unsigned)ceil_div64(cap_M > 0 ? cap_M : 1, T_TILE);
+    const unsigned t_grid = (unsigned)min((int64_t)512, ceil_div64(cap_M > 0 ? cap_M : 1, T_TILE));
     const float ts = (float)tile_size;
     bin3_rows_count_kernel<<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_count,
                                                       w.rbase, w.done_rows, w.row_start);

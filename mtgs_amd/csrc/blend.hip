@@ -810,7 +810,7 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
     return MTGS_OK;
 }
 
-// ---- packed input (fused rasterization path): records of front.hip + rank_ids / offsets[T + 1] of bin2.hip ----
+// ---- packed input (fused rasterization path): records of front.hip + rank_ids / offsets[T + 1] of bin3.hip ----
 #define MTGS_DISPATCH_PK_ONE(FN, DD, ...)                                      \
     if (ppl == 4) FN<DD, 4, true>(__VA_ARGS__);                                \
     else if (ppl == 2) FN<DD, 2, true>(__VA_ARGS__);                           \

@@ -9,7 +9,7 @@
 //      one atomic per block, per 64-chunk group) the number of visible pairs and intersections;
 //   2. front_compact_kernel: every visible pair gets its RANK in index order (group counts + chunk counts in front +
 //      an in-block scan: no inter-block dependency) and, indexed by rank: the 64-byte record (raster_rec.hpp), the flat
-//      index (vis_ids) and the depth sort key (tile count << 40 | camera << 32 | depth bits); vis_rank[flat index] =
+//      index (vis_ids) and the depth key (tile count << 40 | camera << 32 | depth bits); vis_rank[flat index] =
 //      rank for the backward's expansion pass; the totals (n_vis, M) go to device memory AND to a pinned host mailbox,
 //      so that the host learns them without synchronising the stream;
 //      optionally the visibility bitmap + per-word rank prefix that the data-parallel gradient exchange
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                         if (k == a.DC) ch[k] = dep;
                 }
                 a.vis_ids[rank] = (int32_t)idx;
-                // depth sort key: tile count | camera | depth bits -- only the low 32 + camera bits are sorted on, the
-                // count rides along so that the scan in depth order reads it without a gather
+                // depth key: tile count | camera | depth bits (bin3.hip reads the depth bits: the high word of its
+                // per-tile sort keys)
                 a.vis_keys[rank] = ((uint64_t)(uint32_t)cnt[r] << 40) | ((uint64_t)(a.C == 1 ? 0 : idx / a.N) << 32) |
                                    (uint64_t)__float_as_uint(dep);
                 float4 *dst = reinterpret_cast<float4 *>(a.recs + rank * REC_FLOATS);

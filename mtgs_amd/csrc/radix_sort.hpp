@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
     return (unsigned)(key >> shift) & mask;
 }
 
-// n_dev (nullable): the element count lives in DEVICE memory (bin2.hip: the host sized buffers and grids for a
+// n_dev (nullable): the element count lives in DEVICE memory (the host sized buffers and grids for a
 // capacity `n` before it knew the count); the kernels then work on min(n, *n_dev) elements.
 __device__ __forceinline__ int64_t effective_n(int64_t n, const int64_t *n_dev) {
     if (n_dev) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(int nblocks, uint32_t *__
 
 // Optional epilogue of the LAST pass: gather(value) fetches what the outputs need (issued for four elements before the
 // first store), store(dst, key, value, gathered) writes them INSTEAD of the key / value stores (bin.hip: gsplat's
-// isect_ids; bin2.hip: rank_ids / flatten_ids / isect_ids).
+// isect_ids).
 struct NoEpilogue {
     static constexpr bool enabled = false;
     struct G {};

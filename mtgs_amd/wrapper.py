@@ -12,7 +12,6 @@ a HIP kernel launched through the C ABI (include/mtgs_rast.h).
 from __future__ import annotations
 
 import ctypes as C
-import os
 import threading
 import time
 from typing import Optional, Tuple
@@ -502,19 +501,15 @@ def staging_buffer(nbytes: int) -> Tensor:
     return buf
 
 
-_BIN_LEGACY = os.environ.get("MTGS_DEV_BIN2") == "1"     # development switch: the depth-sort + tile-sort binning (bin2.hip)
-
-
-def _bin2_ok(Cn, tw, th, cap_M) -> bool:
-    lib = _lib.load()
-    return bool((lib.mtgs_bin2_supported if _BIN_LEGACY else lib.mtgs_bin3_supported)(Cn, tw, th, cap_M))
+def _bin3_ok(Cn, tw, th, cap_M) -> bool:
+    return bool(_lib.load().mtgs_bin3_supported(Cn, tw, th, cap_M))
 
 
 class _FusedRasterization(torch.autograd.Function):
     """projection -> tile binning -> compositing as ONE autograd node: what gsplat.rendering.rasterization
     chains from fully_fused_projection / isect_tiles / rasterize_to_pixels (same results).
 
-    Forward (csrc/front.hip, bin2.hip, blend.hip): ONE kernel projects, counts tiles, ranks the visible Gaussians and
+    Forward (csrc/front.hip, bin3.hip, blend.hip): ONE kernel projects, counts tiles, ranks the visible Gaussians and
     writes a packed 64-byte record per visible Gaussian; eleven more sort / emit them into per-tile lists of record
     indices; the compositing kernels stage a candidate with ONE 64-byte gather.  No size is needed on the host to
     enqueue any of it (see _SizePlan).  Being one node also lets the backward keep the compositing gradients in COMPACT
@@ -552,7 +547,7 @@ class _FusedRasterization(torch.autograd.Function):
         render = torch.empty((Cn, height, width, DT), dtype=torch.float32, device=dev)
         alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
-        packed = total > 0 and 1 <= DT <= RECORD_CHANNELS and _bin2_ok(Cn, tw, th, 0)
+        packed = total > 0 and 1 <= DT <= RECORD_CHANNELS and _bin3_ok(Cn, tw, th, 0)
         if dp is not None and not (packed and Cn == 1 and DC == 3 and bg is None):
             raise NotImplementedError("data-parallel rasterization: one camera, 3 colour channels (SH output), no backgrounds")
         if not packed:
@@ -603,32 +598,23 @@ class _FusedRasterization(torch.autograd.Function):
                        "flatten_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
                        "isect_ids": torch.empty(cap_alloc, dtype=torch.int64, device=dev)}
                 nbytes = C.c_size_t(0)
-                if _BIN_LEGACY:
-                    call("mtgs_bin2_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
-                    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
-                    off = (-ws.data_ptr()) % 256
-                    call("mtgs_bin2_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
-                         ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
-                         ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
-                         nbytes.value, st)
-                else:
-                    call("mtgs_bin3_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
-                    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
-                    off = (-ws.data_ptr()) % 256
-                    call("mtgs_bin3_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
-                         ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
-                         ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
-                         nbytes.value, st)
+                call("mtgs_bin3_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
+                ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+                off = (-ws.data_ptr()) % 256
+                call("mtgs_bin3_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
+                     ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
+                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
+                     nbytes.value, st)
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
                      ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), st)
                 return out
 
             caps = _force_caps or (_size_plan.caps(key, total) if speculative_sizing else None)
-            if caps is not None and not _bin2_ok(Cn, tw, th, caps[1]):
+            if caps is not None and not _bin3_ok(Cn, tw, th, caps[1]):
                 caps = None
             if graph_caps is not None:
                 # graph mode: fixed capacities, nothing waits for the host; the counts stay on the device
-                if dp is not None or not _bin2_ok(Cn, tw, th, graph_caps[1]):
+                if dp is not None or not _bin3_ok(Cn, tw, th, graph_caps[1]):
                     raise NotImplementedError("graph_mode: unsupported configuration (data-parallel exchange / capacity >= 2^30)")
                 b = front(min(graph_caps[0], total))
                 out = rest(b, graph_caps[1])
@@ -638,7 +624,7 @@ class _FusedRasterization(torch.autograd.Function):
                 out = rest(b, caps[1])                    # enqueued before the totals are known
                 n_vis, M = _wait_mailbox(b["mailbox"], b["tag"], totals, total)
                 if n_vis > b["cap_vis"] or M > caps[1]:   # capacities too small: repeat with exact sizes
-                    if not _bin2_ok(Cn, tw, th, M):
+                    if not _bin3_ok(Cn, tw, th, M):
                         raise NotImplementedError(f"rasterization: {M} tile intersections in one call (limit 2^30)")
                     if n_vis > b["cap_vis"]:
                         b = front(n_vis)
@@ -646,7 +632,7 @@ class _FusedRasterization(torch.autograd.Function):
             else:
                 b = front(total)
                 n_vis, M = _wait_mailbox(b["mailbox"], b["tag"], totals, total)
-                if not _bin2_ok(Cn, tw, th, M):
+                if not _bin3_ok(Cn, tw, th, M):
                     raise NotImplementedError(f"rasterization: {M} tile intersections in one call (limit 2^30)")
                 b["cap_vis"] = max(n_vis, 0)              # (buffers are larger; the kernels only need a bound)
                 out = rest(b, M)
