@@ -223,6 +223,12 @@ int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                    float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
                    const int32_t *tile_order, void *stream);
 
+/* ---- input embedding of the deformation network of deformable object nodes (deformable_node.py:173-203,
+ * utils.py:235-333; csrc/deform.hip): row n of out[N, ld] = [x, sin/cos(x 2^i) i < x_freqs | t, sin/cos(t 2^i) i < t_freqs |
+ * cond[E]] with x = means[n] / height * 2.  The linear layers behind it are library GEMMs (mtgs_amd/deform.py). */
+int mtgs_deform_embed(int64_t N, const float *means, float height, float t, const float *cond, int E, int x_freqs,
+                      int t_freqs, float *out, int64_t ld, void *stream);
+
 /* ---- Fourier-series features_dc of rigid object nodes (rigid_node.py:217-221; csrc/fourier.hip) -------------------------
  * dc[N,3] = sum_f features_dc[N,F,3] * w[F]  (F <= 32; w = IDFT(x) computed by the caller, utils.py:335-352).
  * bwd: v_features_dc[N,F,3] = w[f] * v_dc[N,3]; partial_w[ceil(3N/256), F] (nullable): per-block partial sums of v_w. */

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "mtgs_deform_embed": [_i64, _vp, _f32, _f32, _vp, _i32, _i32, _i32, _vp, _i64, _vp],
     "mtgs_fourier_dc_fwd": [_i64, _i32, _vp, _vp, _vp, _vp],
     "mtgs_fourier_dc_bwd": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_refine_classify": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_uint64, _i64,

@@ -10,9 +10,10 @@ vanilla_gaussian_splatting.py:174-213, multi_color_gaussian_splatting.py:48-71).
 `load_gaussian_nodes` returns the raw parameters per node; `collect_gaussians` does what
 MTGSSceneModel.get_gaussians does for the static node types (vanilla / multi-colour: activations through the fused
 node kernels, then one concatenation) so that a released checkpoint can be rendered with `rasterization`; rigid nodes are posed
-with `frame_idx` (rigid_node.py:127-144, in-frame masks and traversal gating are the caller's: pass `node_names`).
-Deformable nodes / Fourier features carry state this module does not interpret: `collect_gaussians` refuses them by name
-instead of rendering them wrongly.
+with `frame_idx` or a timestamp (rigid_node.py:127-166; in-frame masks and traversal gating are the caller's: pass
+`node_names`), Fourier colours are evaluated (rigid_node.py:217-229), and deformable nodes (deformable_node.py) run their
+deformation network (mtgs_amd.deform) when the caller supplies what the reference keeps outside the state dict: the
+instance heights.  Anything else that carries unknown per-frame state is refused by name instead of rendered wrongly.
 """
 from __future__ import annotations
 
@@ -54,11 +55,16 @@ RIGID_KEYS = ("instance_quats", "instance_trans")
 
 
 def node_kind(params: Mapping[str, Tensor]) -> str:
-    """'vanilla' | 'multicolor' | 'rigid' (instance poses only, rigid_node.py:85-112) | 'dynamic' (anything else:
-    deformation networks, Fourier features ...)."""
+    """'vanilla' | 'multicolor' | 'rigid' (instance poses only, rigid_node.py:85-112) | 'deformable' (poses + instance
+    embedding + `deform_network.*`, deformable_node.py:85-94) | 'dynamic' (anything else)."""
     extra = [k for k in params if k not in GAUSS_PARAM_NAMES]
     if extra:   # (a rigid node's features_dc is [N,3], or [N,F,3] with Fourier features: rigid_node.py:217-229)
-        return "rigid" if set(extra) == set(RIGID_KEYS) else "dynamic"
+        if set(extra) == set(RIGID_KEYS):
+            return "rigid"
+        rest = [k for k in extra if k not in RIGID_KEYS and k != "instances_embedding" and not k.startswith("deform_network.")]
+        if not rest and "instances_embedding" in params and "deform_network.linear.0.weight" in params:
+            return "deformable"
+        return "dynamic"
     return "multicolor" if "features_adapters" in params else "vanilla"
 
 
@@ -66,7 +72,8 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
                       model_sh_degree: int = 3, traversal_index: Optional[int] = None,
                       node_names: Optional[Iterable[str]] = None, device="cuda",
                       frame_idx: Optional[int] = None, timestamp: Optional[float] = None,
-                      frame_timestamps: Optional[Tensor] = None, fourier: Optional[Mapping] = None) -> Dict[str, Tensor]:
+                      frame_timestamps: Optional[Tensor] = None, fourier: Optional[Mapping] = None,
+                      instance_heights: Optional[Mapping[str, float]] = None, deform_time: Optional[float] = None) -> Dict[str, Tensor]:
     """means / scales / quats / opacities / rgbs / model_id of the listed nodes, activated by
     mtgs_amd.nodes.node_gaussians and concatenated in order (MTGSSceneModel.get_gaussians,
     mtgs_scene_graph.py:408-461).  Multi-colour nodes need `traversal_index` (get_pertravel_features,
@@ -75,14 +82,18 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
     (RigidSubModel.get_object_pose, rigid_node.py:127-166; objects that are not in the frame are left out, as
     get_gaussians returns None for them).  Rigid nodes with Fourier colours (features_dc[N,F,3]) need
     `fourier = {"x": normalised timestamp (temporal) | None (spatial: the camera-object yaw is computed), "scale": ..,
-    "space": "temporal" | "spatial"}` -- the node's portable_config (rigid_node.py:114-125)."""
+    "space": "temporal" | "spatial"}` -- the node's portable_config (rigid_node.py:114-125).
+    Deformable nodes (deformable_node.py:206-247) are posed like rigid ones and, when `deform_time` (the frame's
+    timestamp as get_deformation uses it) and `instance_heights[name]` (instance_size[2]) are given, displaced by their
+    deformation network; without them they are rendered undeformed, as the reference does before `use_deformgs_after`."""
+    from .deform import deformation_from_state
     from .nodes import cam_obj_yaw, collect_gaussians as _collect, fourier_features_dc, object_pose
     names = list(nodes.keys()) if node_names is None else list(node_names)
-    specs = []
+    specs, scale_deltas, start = [], [], 0
     for name in names:
         p = {k: v.to(device) for k, v in nodes[name].items()}
         kind = node_kind(p)
-        if kind == "rigid":
+        if kind in ("rigid", "deformable"):
             # RigidSubModel.get_object_pose (rigid_node.py:127-144): static objects store one pose, moving ones one per frame
             iq, it = p.pop("instance_quats"), p.pop("instance_trans")
             if it.dim() > 1:
@@ -101,10 +112,20 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
                 if space == "spatial":
                     x = cam_obj_yaw(camera_to_worlds.to(device), iq)
                 p["features_dc"] = fourier_features_dc(p["features_dc"], x, fourier.get("scale", 1.0), space)
+        if kind == "deformable":
+            state = {k: p.pop(k) for k in list(p) if k == "instances_embedding" or k.startswith("deform_network.")}
+            if deform_time is not None and instance_heights is not None and name in instance_heights:
+                state["means"] = p["means"]
+                d_xyz, d_quat, d_scale = deformation_from_state(state, float(instance_heights[name]), float(deform_time))
+                p["means"] = p["means"].detach() + d_xyz                      # stop_optimizing_canonical_xyz (default)
+                if d_quat is not None:
+                    p["quats"] = p["quats"] / p["quats"].norm(dim=-1, keepdim=True) + d_quat
+                if d_scale is not None:
+                    scale_deltas.append((start, d_scale))
         if kind == "dynamic":
             raise NotImplementedError(f"collect_gaussians: node {name!r} carries per-frame state "
                                       f"({sorted(k for k in p if k not in GAUSS_PARAM_NAMES)[:3]}...); only vanilla, "
-                                      "multi-colour and rigid nodes are supported")
+                                      "multi-colour, rigid and deformable nodes are supported")
         if p["scales"].shape[-1] == 1:   # isotropic nodes store one log-scale (vanilla_gaussian_splatting.py:185-196)
             p["scales"] = p["scales"].expand(-1, 3).contiguous()
         if "quats" not in p:
@@ -117,4 +138,12 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
             else:
                 p["traversal_index"] = traversal_index
         specs.append(p)
-    return _collect(specs, camera_to_worlds.to(device), sh_degree_to_use, model_sh_degree)
+        start += p["means"].shape[0]
+    out = _collect(specs, camera_to_worlds.to(device), sh_degree_to_use, model_sh_degree)
+    if scale_deltas:                              # get_scales: exp(scales) + delta_scale (deformable_node.py:115-119)
+        parts, at = [], 0
+        for s0, d in scale_deltas:
+            parts += [out["scales"][at:s0], out["scales"][s0:s0 + d.shape[0]] + d]
+            at = s0 + d.shape[0]
+        out["scales"] = torch.cat(parts + [out["scales"][at:]])
+    return out
