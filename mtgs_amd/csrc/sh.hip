@@ -232,7 +232,16 @@ __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const
     for (int it = 0; it < SH16_STEPS; ++it) {
         const int gi = it * 4 + sub;
         c[it] = F3{0.f, 0.f, 0.f};
-        if (active && ((on_mask >> gi) & 1ull)) c[it] = *reinterpret_cast<const F3 *>(coeffs + ((g0 + gi) * 16 + k) * 3);
+        if (active && ((on_mask >> gi) & 1ull)) {
+            // non-temporal: 384 MB of coefficients are read once per frame and fit no cache; a plain load allocates
+            // every line in the 256 MB Infinity Cache and has to push out the dirty lines the previous kernels left
+            // there first (inside the training step this kernel ran at 4.0 TB/s, alone at 5.8; with `nt` 6.1 TB/s
+            // inside the step).  The projection's parameter loads do NOT get the hint: its backward gathers the same
+            // rows again and finds them cached (tried: 33 -> 39 us for project_bwd_vis).
+            typedef float f3v __attribute__((ext_vector_type(3)));
+            const f3v v = __builtin_nontemporal_load(reinterpret_cast<const f3v *>(coeffs + ((g0 + gi) * 16 + k) * 3));
+            c[it] = F3{v.x, v.y, v.z};
+        }
     }
     float myr = 0.f, myg = 0.f, myb = 0.f;
 #pragma unroll
