@@ -156,3 +156,31 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     assert out["dp_world_size"] == 2 and out["dp_backend"] == "gloo"
     want = {"render", "exchange"} | ({"meta", "wire", "reduce"} if exchange == "sparse" else set())
     assert want <= set(ph) and all(ph[k] >= 0 for k in want), ph
+
+
+def test_bench_configs3_workload_eight_ranks_on_one_gpu(hip_lib):
+    """BASELINE configs[3] at its own size -- 2M shared Gaussians, eight 1920x1080 cameras, one rank per camera -- with the
+    eight ranks sharing the test box's single GPU and gloo in place of RCCL: everything but the wire is what the 8-GPU
+    run executes (visibility maps all-gathered during the frame, 8 x 19 MB of wire rows in chunks, one-pass reduction
+    over eight senders, phase timings)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2",
+           "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dp_world_size"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["n_gaussians"] == 2_000_000 and out["config"]["width"] == 1920
+    ph = out["dp_phases_ms"]
+    assert {"render", "exchange", "meta", "wire", "reduce"} <= set(ph)
+    # every rank receives the visible rows of all eight cameras: ~8 x 300k x 64 B, an order of magnitude below the
+    # 8 x 472 MB a dense all-reduce moves
+    assert "sparse" in out["config"]["parallelism"]
+    from tests.util import REPORT
+    REPORT.append({"kind": "dp", "name": "configs[3] workload, 8 ranks on one GPU over gloo", "ms_per_step": out["ms_per_step"],
+                   "phases_ms": ph, "parallelism": out["config"]["parallelism"]})
