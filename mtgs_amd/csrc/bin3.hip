@@ -189,6 +189,7 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef 
 // ---- 2. per-tile counts -> offsets, tile dispatch order ---------------------------------------------------------
 // The items are grouped by row, so the tiles a workgroup's 1024 items touch are a short contiguous range of tile ids
 // (one or two rows): only that range of the LDS histogram is cleared and flushed.
+constexpr int SM_LONG_BUCKET = 255;   // (bin3_sort_small_kernel: lists of length >> 2 >= 255 are sorted by a whole workgroup)
 constexpr int T_THREADS = 1024, T_ITEMS = 2, T_TILE = T_THREADS * T_ITEMS, SCHED_BUCKETS = 1024;
 struct TileRange { int lo, hi; };
 __device__ __forceinline__ TileRange tile_range(const Item *__restrict__ items, int64_t base, int64_t n_items, int tw) {
@@ -200,7 +201,8 @@ __device__ __forceinline__ TileRange tile_range(const Item *__restrict__ items, 
 __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
     const uint32_t *__restrict__ n_items_ptr, int64_t cap_items, const Item *__restrict__ items, int tw, int n_bins,
     int64_t cap_M, uint32_t *__restrict__ bins /* [n_bins], zero */, uint32_t *__restrict__ done /* zero */,
-    int32_t *__restrict__ offsets /* [n_bins + 1] */, int32_t *__restrict__ order /* [n_bins] */) {
+    int32_t *__restrict__ offsets /* [n_bins + 1] */, int32_t *__restrict__ order /* [n_bins] */,
+    uint32_t *__restrict__ n_long /* number of lists of at least SM_LONG keys: the first n_long of the order */) {
     extern __shared__ uint32_t s_bins[];  // [n_bins]
     __shared__ uint32_t s_aux[SCHED_BUCKETS];
     __shared__ uint32_t s_ws[T_THREADS / 64];
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
         if (n_items == 0 && blockIdx.x == 0) {   // nothing visible: empty lists, any order
             for (int b = tid; b <= n_bins; b += T_THREADS) offsets[b] = 0;
             for (int b = tid; b < n_bins; b += T_THREADS) order[b] = b;
+            if (tid == 0) *n_long = 0;
         }
         return;
     }
@@ -297,6 +300,8 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
     for (int w = 0; w < wave; ++w) hb += s_ws[w];
     __syncthreads();
     s_aux[tid] = hb + hinc - hv;
+    __syncthreads();
+    if (tid == 0) *n_long = s_aux[SCHED_BUCKETS - SM_LONG_BUCKET];   // lists in the buckets in front of it: length >> 2 >= 255
     __syncthreads();
     // (ties inside a bucket land in arrival order: a scheduling aid, results do not depend on it)
     for (int t = tid; t < n_bins; t += T_THREADS) order[atomicAdd(&s_aux[bucket_of(t)], 1u)] = t;
@@ -586,39 +591,26 @@ __device__ __forceinline__ void sort_tile_lds(uint64_t *s, const uint64_t *__res
 
 constexpr int SM_CAP = 2048, SM_WAVE_CAP = 1024, SM_TILES = 4;
 constexpr int LG_THREADS = 1024, LG_CAP = 16384;
-// A workgroup takes four consecutive tiles of the dispatch order (longest lists first).  Lists of up to 1024 keys are
-// sorted by ONE wave each (no workgroup barrier at all), longer ones by the four waves together, one tile after the
-// other; lists beyond SM_CAP are left to bin3_sort_large_kernel.
+// Position g of the dispatch order (longest lists first) is sorted by workgroup g when its list is LONG (at least
+// 4 * SM_LONG_BUCKET = 1020 keys: the four waves work together, up to SM_CAP keys; beyond that the list is bin3_sort_large_kernel's), and by
+// ONE wave otherwise: the short lists follow the n_long long ones in the order, four to a workgroup, no workgroup
+// barrier at all.  n_long comes from the kernel that built the order.  (Four long lists per workgroup, one after the
+// other, left the chip a quarter full at MTGS's 960x540, where most lists are long: 69 -> 40 us there.)
 __global__ __launch_bounds__(B3_BLOCK) void bin3_sort_small_kernel(const int32_t *__restrict__ offsets,
-                                                                  const int32_t *__restrict__ order, int n_bins, int64_t cap_M,
+                                                                  const int32_t *__restrict__ order, int n_bins,
+                                                                  const uint32_t *__restrict__ n_long_ptr, int64_t cap_M,
                                                                   const uint64_t *__restrict__ keys, const SortEpilogue epi) {
     __shared__ uint64_t s_keys[SM_TILES * SM_WAVE_CAP];   // >= SM_CAP
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int bin[SM_TILES], L[SM_TILES], o0[SM_TILES], max_l = 0;
-#pragma unroll
-    for (int q = 0; q < SM_TILES; ++q) {
-        const int g = blockIdx.x * SM_TILES + q;
-        bin[q] = 0; L[q] = 0; o0[q] = 0;
-        if (g < n_bins) {
-            bin[q] = order[g];
-            o0[q] = offsets[bin[q]];
-            L[q] = offsets[bin[q] + 1] - o0[q];
-            if (L[q] > SM_CAP || (int64_t)o0[q] + L[q] > cap_M) L[q] = 0;   // the large kernel's / a frame beyond its capacities
-        }
-        max_l = max(max_l, L[q]);
-    }
-    if (max_l == 0) return;
-    if (max_l > SM_WAVE_CAP) {
-#pragma unroll 1
-        for (int q = 0; q < SM_TILES; ++q)
-            if (L[q] > 0) sort_tile_lds<false>(s_keys, keys, o0[q], L[q], (uint32_t)bin[q], B3_BLOCK, tid, epi);
-    } else {
-        int bq = 0, lq = 0, oq = 0;   // (static indexing keeps the arrays in registers)
-#pragma unroll
-        for (int q = 0; q < SM_TILES; ++q)
-            if (q == wave) { bq = bin[q]; lq = L[q]; oq = o0[q]; }
-        if (lq > 0) sort_tile_lds<true>(s_keys + wave * SM_WAVE_CAP, keys, oq, lq, (uint32_t)bq, 64, lane, epi);
-    }
+    const int n_long = (int)*n_long_ptr;
+    const bool together = (int)blockIdx.x < n_long;
+    const int g = together ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * SM_TILES + wave;
+    if (g >= n_bins) return;
+    const int bin = order[g];
+    const int o0 = offsets[bin], L = offsets[bin + 1] - o0;
+    if (L == 0 || L > SM_CAP || (int64_t)o0 + L > cap_M) return;   // nothing / the large kernel's / a frame beyond its capacities
+    if (together) sort_tile_lds<false>(s_keys, keys, o0, L, (uint32_t)bin, B3_BLOCK, tid, epi);
+    else if (L <= SM_WAVE_CAP) sort_tile_lds<true>(s_keys + wave * SM_WAVE_CAP, keys, o0, L, (uint32_t)bin, 64, lane, epi);
 }
 
 // Lists longer than SM_CAP: one 1024-thread workgroup per list, up to LG_CAP keys in LDS; beyond that the list is
@@ -698,7 +690,7 @@ inline int bit_length_u32(uint32_t v) {
 struct Bin3Workspace {
     char *control;          // zeroed region
     size_t control_bytes;
-    uint32_t *done_rows, *done_tiles, *row_count, *bins, *cursor;
+    uint32_t *done_rows, *done_tiles, *n_long, *row_count, *bins, *cursor;
     uint32_t *row_start, *rbase;
     int32_t *order;
     Item *items;
@@ -712,7 +704,7 @@ inline Bin3Workspace carve3(char *base, int64_t cap_vis, int64_t cap_M, int n_ro
     const int64_t m = cap_M > 0 ? cap_M : 1, nv = cap_vis > 0 ? cap_vis : 1;
     w.control = base;
     char *misc = take(64);
-    w.done_rows = (uint32_t *)misc; w.done_tiles = (uint32_t *)misc + 1;
+    w.done_rows = (uint32_t *)misc; w.done_tiles = (uint32_t *)misc + 1; w.n_long = (uint32_t *)misc + 2;
     w.row_count = (uint32_t *)take((size_t)n_rows * 4);
     w.bins = (uint32_t *)take((size_t)n_bins * 4);
     w.cursor = (uint32_t *)take((size_t)n_bins * 4);
@@ -769,7 +761,7 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
     bin3_rows_place_kernel<<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_start,
                                                       w.rbase, cap_M, w.items);
     bin3_tiles_count_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
-                                                                            cap_M, w.bins, w.done_tiles, offsets, order);
+                                                                            cap_M, w.bins, w.done_tiles, offsets, order, w.n_long);
     bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 8, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
                                                                             offsets, w.cursor, (const uint64_t *)vis_keys, w.keys64);
     const SortEpilogue epi{rank_ids, flatten_ids, isect_ids, vis_ids, (uint32_t)(tile_w * tile_h),
@@ -783,8 +775,7 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
     MTGS_REQUIRE(big_lds, MTGS_ELAUNCH, "mtgs_bin3_build: cannot reserve %d bytes of LDS per workgroup", LG_CAP * 8);
     bin3_sort_large_kernel<<<(unsigned)min(n_bins, 256), LG_THREADS, (size_t)LG_CAP * 8, st>>>(
         offsets, order, n_bins, cap_M, w.keys64, epi);
-    bin3_sort_small_kernel<<<(unsigned)((n_bins + SM_TILES - 1) / SM_TILES), B3_BLOCK, 0, st>>>(offsets, order, n_bins, cap_M,
-                                                                                             w.keys64, epi);
+    bin3_sort_small_kernel<<<(unsigned)n_bins, B3_BLOCK, 0, st>>>(offsets, order, n_bins, w.n_long, cap_M, w.keys64, epi);
     MTGS_CHECK_LAUNCH("mtgs_bin3_build");
     return MTGS_OK;
 }
