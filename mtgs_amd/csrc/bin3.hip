@@ -562,12 +562,12 @@ __device__ __forceinline__ void bitonic_sort_e(uint64_t *s, int P, int n, int nt
         if ((k >> (LOGE + 1)) >= 1) level_tail<WAVE, LOGE>(s, groups, n, nthr, tid, k >> (LOGE + 1));
     }
 }
-#ifndef B3_LOGE
-#define B3_LOGE 3
-#endif
+// One wave sorting 513..1024 keys holds them 16 per lane (four stages per LDS round trip, one pass per trip instead of
+// two: 60 -> 55 us at the headline size, at 128 VGPRs); with more threads than work items 8 per thread is the better
+// split (16 keys per thread everywhere: 186 VGPRs in the one-wave kernel, spills in the 1024-thread one, 57 -> 90 us).
 template <bool WAVE>
 __device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int n, int nthr, int tid) {
-    if (B3_LOGE == 4 && P >= 1024) bitonic_sort_e<WAVE, B3_LOGE>(s, P, n, nthr, tid);
+    if (WAVE && P >= 1024) bitonic_sort_e<WAVE, 4>(s, P, n, nthr, tid);
     else bitonic_sort_e<WAVE, 3>(s, P, n, nthr, tid);
 }
 
@@ -596,7 +596,7 @@ constexpr int LG_THREADS = 1024, LG_CAP = 16384;
 // ONE wave otherwise: the short lists follow the n_long long ones in the order, four to a workgroup, no workgroup
 // barrier at all.  n_long comes from the kernel that built the order.  (Four long lists per workgroup, one after the
 // other, left the chip a quarter full at MTGS's 960x540, where most lists are long: 69 -> 40 us there.)
-__global__ __launch_bounds__(B3_BLOCK) void bin3_sort_small_kernel(const int32_t *__restrict__ offsets,
+__global__ __launch_bounds__(B3_BLOCK, 4) void bin3_sort_small_kernel(const int32_t *__restrict__ offsets,
                                                                   const int32_t *__restrict__ order, int n_bins,
                                                                   const uint32_t *__restrict__ n_long_ptr, int64_t cap_M,
                                                                   const uint64_t *__restrict__ keys, const SortEpilogue epi) {
