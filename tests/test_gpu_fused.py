@@ -297,3 +297,32 @@ def test_long_tile_lists_every_sort_path(hip_lib, n, equal_depths):
     assert torch.equal(info["isect_ids"], isect_ids)
     r2, a2 = w.rasterize_to_pixels_with_depth(means2d, conics, cols.unsqueeze(0), oe, depths, True, W, H, 16, off, flat)
     assert torch.allclose(render, r2, atol=1e-5) and torch.allclose(alpha, a2, atol=1e-5)
+
+
+def test_more_tile_rows_than_the_packed_path_takes(hip_lib):
+    """A 32 x 16500 image has 1032 tile rows: beyond mtgs_bin3_supported (C * tile_h <= 1024), so the frame takes the
+    gather-based kernels -- same ids as the operator path, and gradients flow."""
+    from mtgs_amd import _lib, rasterization
+    from mtgs_amd import wrapper as w
+    dev = torch.device("cuda")
+    W, H, n = 32, 16500, 4000
+    assert not _lib.load().mtgs_bin3_supported(1, 2, 1032, 0) and _lib.load().mtgs_bin3_supported(1, 2, 1024, 0)
+    g = torch.Generator().manual_seed(1)
+    K = torch.tensor([[[40.0, 0.0, W / 2.0], [0.0, 40.0, H / 2.0], [0.0, 0.0, 1.0]]], device=dev)
+    vm = torch.eye(4, device=dev)[None]
+    z = torch.rand(n, generator=g) * 4.0 + 3.0
+    y = (torch.rand(n, generator=g) - 0.5) * (H / 40.0) * z * 0.98
+    x = (torch.rand(n, generator=g) - 0.5) * 0.5 * z
+    means = torch.stack([x, y, z], 1).to(dev).requires_grad_(True)
+    quats = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1).to(dev)
+    scales = (torch.rand(n, 3, generator=g) * 0.3 + 0.05).to(dev)
+    opac = (torch.rand(n, generator=g) * 0.5 + 0.2).to(dev)
+    cols = torch.rand(n, 3, generator=g).to(dev)
+    render, alpha, info = rasterization(means=means, quats=quats, scales=scales, opacities=opac, colors=cols, viewmats=vm, Ks=K,
+                                        width=W, height=H, packed=False, render_mode="RGB+ED", rasterize_mode="antialiased")
+    radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(means.detach(), quats, scales, vm, K, opac, W, H,
+                                                                            calc_compensations=True)
+    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 2, 1032)
+    assert isect_ids.numel() > n and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
+    (render.sum() + alpha.sum()).backward()
+    assert means.grad is not None and float(means.grad.abs().sum()) > 0
