@@ -589,7 +589,7 @@ __device__ __forceinline__ void sort_tile_lds(uint64_t *s, const uint64_t *__res
     lds_sync<WAVE>();
 }
 
-constexpr int SM_CAP = 2048, SM_WAVE_CAP = 1024, SM_TILES = 4;
+constexpr int SM_CAP = 4096, SM_WAVE_CAP = 1024, SM_TILES = 4;   // SM_CAP = SM_TILES * SM_WAVE_CAP keys of LDS
 constexpr int LG_THREADS = 1024, LG_CAP = 16384;
 // Position g of the dispatch order (longest lists first) is sorted by workgroup g when its list is LONG (at least
 // 4 * SM_LONG_BUCKET = 1020 keys: the four waves work together, up to SM_CAP keys; beyond that the list is bin3_sort_large_kernel's), and by
@@ -600,7 +600,8 @@ __global__ __launch_bounds__(B3_BLOCK, 4) void bin3_sort_small_kernel(const int3
                                                                   const int32_t *__restrict__ order, int n_bins,
                                                                   const uint32_t *__restrict__ n_long_ptr, int64_t cap_M,
                                                                   const uint64_t *__restrict__ keys, const SortEpilogue epi) {
-    __shared__ uint64_t s_keys[SM_TILES * SM_WAVE_CAP];   // >= SM_CAP
+    __shared__ uint64_t s_keys[SM_CAP];
+    static_assert(SM_CAP == SM_TILES * SM_WAVE_CAP, "one buffer: a long list, or four short ones");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_long = (int)*n_long_ptr;
     const bool together = (int)blockIdx.x < n_long;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(B3_BLOCK, 4) void bin3_sort_small_kernel(const int3
     else if (L <= SM_WAVE_CAP) sort_tile_lds<true>(s_keys + wave * SM_WAVE_CAP, keys, o0, L, (uint32_t)bin, 64, lane, epi);
 }
 
-// Lists longer than SM_CAP: one 1024-thread workgroup per list, up to LG_CAP keys in LDS; beyond that the list is
+// Lists longer than SM_CAP (4096 keys): one 1024-thread workgroup per list, up to LG_CAP keys in LDS; beyond that the list is
 // sorted in LG_CAP-key chunks and the chunks are merged with the upper levels of the all-ascending form of the
 // network (first stage of a level mirrors, i <-> i ^ (k - 1), the others are plain butterflies), whose comparators
 // never move a key upwards past the end of the list -- so the list needs no padding in global memory.
@@ -627,7 +628,9 @@ __global__ __launch_bounds__(LG_THREADS) void bin3_sort_large_kernel(const int32
         const int64_t o0 = offsets[bin];
         const int L = offsets[bin + 1] - (int)o0;
         if (L <= SM_CAP) {
-            if (L + 4 <= SM_CAP) break;   // the order is by decreasing (length >> 2): nothing longer follows
+            // the order is by decreasing min(length >> 2, SCHED_BUCKETS - 1): behind a list outside the first bucket
+            // nothing longer follows (inside it, lists of 4092 keys and more are mixed)
+            if ((L >> 2) < SCHED_BUCKETS - 1) break;
             continue;
         }
         if (o0 + L > cap_M) continue;     // a frame beyond its capacities (it is repeated)

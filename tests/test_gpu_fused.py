@@ -255,10 +255,11 @@ def test_graph_mode_capture_replay_equals_eager(hip_lib):
     assert bool(i2["overflow"]) and int(i2["n_visible"]) == ref1[4] and torch.isfinite(r2).all()
 
 
-@pytest.mark.parametrize("n,equal_depths", [(300, False), (1500, True), (6000, False), (40_000, True)])
+@pytest.mark.parametrize("n,equal_depths", [(300, False), (1500, True), (3000, False), (4200, True), (6000, False), (40_000, True)])
 def test_long_tile_lists_every_sort_path(hip_lib, n, equal_depths):
-    """Binning without a global sort (csrc/bin3.hip): the per-tile sort has a one-wave path (<= 512 keys), a workgroup
-    path (<= 2048), a 1024-thread path (<= 16384 keys in LDS) and a chunked path that merges through global memory.
+    """Binning without a global sort (csrc/bin3.hip): the per-tile sort has a one-wave path (< 1020 keys), a workgroup
+    path (<= 4096; around 4200 Gaussians the nine lists straddle that limit inside the dispatch order's first length
+    bucket), a 1024-thread path (<= 16384 keys in LDS) and a chunked path that merges through global memory.
     n Gaussians in front of a 48x40 image put ~n intersections into each of its 9 tiles; with equal_depths many of
     them share their depth bit for bit, so the order inside a tile is decided by the Gaussian index (gsplat: stable
     sort).  isect_ids / flatten_ids / offsets must equal the operator path's (one global radix sort) bit for bit."""
