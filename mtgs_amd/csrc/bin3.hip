@@ -562,13 +562,16 @@ __device__ __forceinline__ void bitonic_sort_e(uint64_t *s, int P, int n, int nt
         if ((k >> (LOGE + 1)) >= 1) level_tail<WAVE, LOGE>(s, groups, n, nthr, tid, k >> (LOGE + 1));
     }
 }
-// One wave sorting 513..1024 keys holds them 16 per lane (four stages per LDS round trip, one pass per trip instead of
-// two: 60 -> 55 us at the headline size, at 128 VGPRs); with more threads than work items 8 per thread is the better
-// split (16 keys per thread everywhere: 186 VGPRs in the one-wave kernel, spills in the 1024-thread one, 57 -> 90 us).
-template <bool WAVE>
+// One wave sorting 513..1024 keys holds them 16 per lane, and four waves sorting 2049..4096 keys 16 per thread (four
+// stages per LDS round trip, one pass per trip instead of two: 60 -> 55 us at the headline size, at 128 VGPRs); with
+// more threads than work items 8 per thread is the better split (16 keys per thread everywhere: 186 VGPRs in the
+// one-wave kernel, spills in the 1024-thread one, 57 -> 90 us).
+template <bool WAVE, int P16 = 1 << 30>   // P16: from this padded length on, 16 keys per thread (never: the 1024-thread kernel)
 __device__ __forceinline__ void bitonic_sort(uint64_t *s, int P, int n, int nthr, int tid) {
-    if (WAVE && P >= 1024) bitonic_sort_e<WAVE, 4>(s, P, n, nthr, tid);
-    else bitonic_sort_e<WAVE, 3>(s, P, n, nthr, tid);
+    if constexpr (P16 < (1 << 30)) {
+        if (P >= P16) { bitonic_sort_e<WAVE, 4>(s, P, n, nthr, tid); return; }
+    }
+    bitonic_sort_e<WAVE, 3>(s, P, n, nthr, tid);
 }
 
 __device__ __forceinline__ int pow2_ceil(int n) {
@@ -578,13 +581,13 @@ __device__ __forceinline__ int pow2_ceil(int n) {
 }
 
 // one tile whose list fits the LDS buffer: load, sort, write the three output arrays
-template <bool WAVE>
+template <bool WAVE, int P16 = 1 << 30>
 __device__ __forceinline__ void sort_tile_lds(uint64_t *s, const uint64_t *__restrict__ keys, int64_t o0, int L, uint32_t bin,
                                               int nthr, int tid, const SortEpilogue &epi) {
     const int P = pow2_ceil(L);
     for (int i = tid; i < P; i += nthr) s[swz(i)] = i < L ? keys[o0 + i] : KEY_INF;
     lds_sync<WAVE>();
-    bitonic_sort<WAVE>(s, P, L, nthr, tid);
+    bitonic_sort<WAVE, P16>(s, P, L, nthr, tid);
     for (int i = tid; i < L; i += nthr) epi.store(o0 + i, bin, s[swz(i)]);
     lds_sync<WAVE>();
 }
@@ -610,8 +613,9 @@ __global__ __launch_bounds__(B3_BLOCK, 4) void bin3_sort_small_kernel(const int3
     const int bin = order[g];
     const int o0 = offsets[bin], L = offsets[bin + 1] - o0;
     if (L == 0 || L > SM_CAP || (int64_t)o0 + L > cap_M) return;   // nothing / the large kernel's / a frame beyond its capacities
-    if (together) sort_tile_lds<false>(s_keys, keys, o0, L, (uint32_t)bin, B3_BLOCK, tid, epi);
-    else if (L <= SM_WAVE_CAP) sort_tile_lds<true>(s_keys + wave * SM_WAVE_CAP, keys, o0, L, (uint32_t)bin, 64, lane, epi);
+    // (16 keys per thread exactly where 8 would need two passes per trip: 64 lanes x 1024 keys, 256 threads x 4096 keys)
+    if (together) sort_tile_lds<false, 4096>(s_keys, keys, o0, L, (uint32_t)bin, B3_BLOCK, tid, epi);
+    else if (L <= SM_WAVE_CAP) sort_tile_lds<true, 1024>(s_keys + wave * SM_WAVE_CAP, keys, o0, L, (uint32_t)bin, 64, lane, epi);
 }
 
 // Lists longer than SM_CAP (4096 keys): one 1024-thread workgroup per list, up to LG_CAP keys in LDS; beyond that the list is
