@@ -12,24 +12,26 @@
 //   1. bin3_rows_{count,place}_kernel   (Gaussian, tile row) ITEMS grouped by row: 3.6 per visible Gaussian; the
 //                             count pass hands every (workgroup, row) pair its base inside the row's segment with one
 //                             returning atomic, the place pass numbers the items with LDS atomics;
-//   2. bin3_tiles_count_kernel   a workgroup's 1024 items lie in one or two rows, so the tiles they cover are a short
+//   2. bin3_tiles_count_kernel   a workgroup's 2048 items lie in one or two rows, so the tiles they cover are a short
 //                             range of the LDS histogram: per-tile counts; the block that finishes last turns them into
 //                             isect_offsets and into the longest-list-first dispatch order of the tiles;
 //   3. bin3_tiles_place_kernel   the items are expanded into intersections: a workgroup reserves its slots in a tile's
 //                             segment with one returning atomic per (workgroup, tile) and stores the 64-bit keys
-//                             depth bits << 32 | rank  in runs of ~30: the segments now hold the right SETS, unordered;
-//   4. bin3_sort_{small,large}_kernel   every tile's segment is sorted on that key by ONE workgroup (or one wave)
-//                             in LDS -- a bitonic network run eight keys per thread, three stages per LDS round
-//                             trip -- and written out as rank_ids, flatten_ids and gsplat's isect_ids.  rank order ==
-//                             Gaussian index order, so the key order IS gsplat's (tile, depth, index) order, and the
-//                             result does not depend on the order in which the atomics of steps 1-3 were served.
+//                             depth bits << 32 | rank  in runs of ~60: the segments now hold the right SETS, unordered;
+//   4. bin3_sort_{small,large}_kernel   every tile's segment is sorted on that key by ONE wave (< 1020 keys), one
+//                             workgroup (<= 4096) or one 1024-thread workgroup in LDS -- a bitonic network in its
+//                             all-ascending form, 8 or 16 keys per thread, three or four stages per LDS round trip,
+//                             compare-exchange = v_min_f64 + v_max_f64, XOR-swizzled layout -- and written out as
+//                             rank_ids, flatten_ids and gsplat's isect_ids.  rank order == Gaussian index order, so
+//                             the key order IS gsplat's (tile, depth, index) order, and the result does not depend on
+//                             the order in which the atomics of steps 1-3 were served.
 // Why two levels: a scatter of the M intersections straight into 8160 tile segments is M single 8-byte stores to random
 // lines (measured 63 us for 4M, with or without a per-intersection atomic: 85 us); splitting by row first keeps every
 // store run long -- the principle of an MSD radix sort, applied to the 1.1M row items instead of the 4M intersections.
 // Segments longer than the LDS holds (16384 keys) are sorted in 16384-key chunks and merged through global memory
 // by the same workgroup.
 // Every kernel reads its element count from device memory and its grid is sized for a CAPACITY (speculative sizing /
-// graph capture, see wrapper.py); seven launches per frame.
+// graph capture, see wrapper.py); seven launches per frame behind the one that clears the counters.
 //
 // Roofline: HBM / latency for 1-3 (rows 2 * n_vis*64 + items*8; tiles items*8*2 + M*8), LDS / VALU for 4
 // (M*(8+16) bytes of HBM against ~log2(L)^2/2 compare-exchanges per key).
