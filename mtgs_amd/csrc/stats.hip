@@ -48,7 +48,47 @@ __global__ __launch_bounds__(256) void densify_stats_batch_kernel(const mtgs_sta
     d.vis_counts[i] += 1.f;
     d.max_2dsize[i] = fmaxf(d.max_2dsize[i], (float)r);
 }
+// The same update from the COMPACT gradient rows of the one-node rasterization (one 64-byte row per visible Gaussian:
+// wrapper._FusedRasterization; what the data-parallel exchange keeps instead of a dense means2d gradient): thread per
+// visible Gaussian, its node found by binary search over the nodes' first rows.  Only visible Gaussians are touched at
+// all -- 300k rows instead of 2M radii at the headline size.
+__global__ __launch_bounds__(256) void densify_stats_rows_kernel(int64_t n_vis, const int32_t *__restrict__ vis_ids,
+                                                                 const float *__restrict__ rows, int64_t row_stride, int col,
+                                                                 const int32_t *__restrict__ radii,
+                                                                 const mtgs_stats_desc *__restrict__ table, int n_nodes,
+                                                                 float half_w, float half_h) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_vis) return;
+    const int64_t id = vis_ids[r];
+    int lo = 0, hi = n_nodes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].start <= id) lo = mid; else hi = mid - 1;
+    }
+    const mtgs_stats_desc &d = table[lo];
+    const int64_t i = id - d.start;
+    if (i < 0 || i >= d.n) return;                      // a Gaussian of no listed node
+    const float gx = rows[r * row_stride + col] * half_w, gy = rows[r * row_stride + col + 1] * half_h;
+    d.xys_grad_norm[i] += sqrtf(gx * gx + gy * gy);
+    d.vis_counts[i] += 1.f;
+    d.max_2dsize[i] = fmaxf(d.max_2dsize[i], (float)radii[id]);
+}
 }  // namespace
+
+/* table: n_nodes descriptors sorted by `start` (first_block unused); rows[n_vis, row_stride] floats, the 2-D gradient of
+ * visible Gaussian r (flat index vis_ids[r]) in columns col, col + 1 (0: means2d.grad, 2: means2d.absgrad). */
+extern "C" int mtgs_densify_stats_rows(int64_t n_vis, const int32_t *vis_ids, const float *rows, int64_t row_stride, int col,
+                                       const int32_t *radii, int n_nodes, const mtgs_stats_desc *table, int width, int height,
+                                       void *stream) {
+    MTGS_REQUIRE(n_vis >= 0 && n_nodes >= 0 && row_stride >= 4 && (col == 0 || col == 2) && width > 0 && height > 0, MTGS_EINVAL,
+                 "mtgs_densify_stats_rows: bad arguments");
+    if (n_vis == 0 || n_nodes == 0) return MTGS_OK;
+    MTGS_REQUIRE(vis_ids && rows && radii && table, MTGS_EINVAL, "mtgs_densify_stats_rows: null pointer");
+    densify_stats_rows_kernel<<<(unsigned)ceil_div64(n_vis, 256), 256, 0, (hipStream_t)stream>>>(
+        n_vis, vis_ids, rows, row_stride, col, radii, table, n_nodes, 0.5f * (float)width, 0.5f * (float)height);
+    MTGS_CHECK_LAUNCH("mtgs_densify_stats_rows");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_stats_desc_bytes(void) { return (int)sizeof(mtgs_stats_desc); }
 

@@ -80,6 +80,43 @@ def update_statistics_all(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii:
          stream_of(r))
 
 
+@torch.no_grad()
+def update_statistics_rows(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii: Tensor, grad_rows: Tensor, vis_ids: Tensor,
+                           width: int, height: int, starts: Optional[Sequence[int]] = None, absgrad: bool = True,
+                           n_vis: Optional[int] = None) -> None:
+    """`update_statistics_all` from the COMPACT gradient rows of the one-node rasterization instead of a dense
+    means2d gradient: grad_rows[n_vis, 16] (columns 0-1 the 2-D gradient, 2-3 its absolute-value sum) and vis_ids[n_vis]
+    (flat index of each row's Gaussian), as the data-parallel exchange keeps them after the backward
+    (mtgs_amd.dist.SparseGradExchange.grad_rows / .vis_ids) -- in that mode no dense gradient exists.  Same update,
+    visible Gaussians only (mtgs_scene_graph.py:1157-1183, vanilla_gaussian_splatting.py:448-474)."""
+    from ._lib import load
+    if not stats:
+        return
+    flat = [t for s_ in stats for t in s_]
+    require_gpu(radii, grad_rows, vis_ids, *flat)
+    for t in flat:
+        assert t.dtype == torch.float32 and t.is_contiguous(), "statistics must be contiguous float32"
+    n = np.asarray([s_[0].numel() for s_ in stats], dtype=np.int64)
+    st = np.cumsum(n) - n if starts is None else np.asarray(starts, dtype=np.int64)
+    assert (np.diff(st) >= 0).all(), "nodes in the order of the collected arrays"
+    r = radii.reshape(-1)
+    r = (r if r.dtype == torch.int32 else r.to(torch.int32)).contiguous()
+    assert grad_rows.dim() == 2 and grad_rows.shape[1] >= 4 and grad_rows.dtype == torch.float32 and grad_rows.is_contiguous()
+    assert vis_ids.dtype == torch.int32 and vis_ids.is_contiguous()
+    nv = int(vis_ids.numel() if n_vis is None else n_vis)
+    assert nv <= vis_ids.numel() and nv <= grad_rows.shape[0] and int((st + n).max()) <= r.numel()
+    if load().mtgs_stats_desc_bytes() != _STATS_DESC.itemsize:
+        raise RuntimeError("mtgs_stats_desc layout mismatch between libmtgs_rast.so and mtgs_amd.densify")
+    tab = np.zeros(len(stats), dtype=_STATS_DESC)
+    tab["n"], tab["start"] = n, st
+    for j, k in enumerate(("xys_grad_norm", "vis_counts", "max_2dsize")):
+        tab[k] = [s_[j].data_ptr() for s_ in stats]
+    from .nodes import upload_table
+    tab_dev = upload_table(tab, r.device)
+    call("mtgs_densify_stats_rows", nv, ptr(vis_ids), ptr(grad_rows), int(grad_rows.shape[1]), 2 if absgrad else 0, ptr(r),
+         len(stats), ptr(tab_dev), int(width), int(height), stream_of(r))
+
+
 # ------------------------------------------------------------------------------------------------ refinement on device
 import ctypes as _C
 from dataclasses import dataclass

@@ -235,7 +235,9 @@ class SparseGradExchange:
     def after_backward(self, n_vis, grad_rows, vis_ids):
         assert self._pending is not None and self._pending["stage"] == "meta", "rasterization() of this exchange first"
         self._pending.update(stage="rows", n_vis=int(n_vis))
-        self.grad_rows, self.vis_ids = grad_rows, vis_ids   # compact |means2d| gradients etc. for the densification statistics
+        # the compact gradient rows of this frame: what mtgs_amd.densify.update_statistics_rows reads (no dense means2d
+        # gradient exists in this mode)
+        self.grad_rows, self.vis_ids = grad_rows, vis_ids
 
     def finish(self, means: torch.Tensor, sh_degree: int):
         """After backward(): exchange the wire rows and return (v_means, v_quats, v_scales, v_opacities, v_coeffs) --

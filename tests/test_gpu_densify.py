@@ -137,3 +137,44 @@ def test_refinement_is_deterministic_across_launches_and_keys(hip_lib):
     # empty node and a node where nothing changes
     e, _, ie = refine_gaussians({k: v[:0] for k, v in pd.items()}, tuple(s[:0] for s in sd), cfg, 4000, 1)
     assert ie["n_after"] == 0 and e["means"].shape == (0, 3)
+
+
+def test_statistics_from_the_exchange_rows_equal_the_dense_update(hip_lib):
+    """In data-parallel mode the backward leaves compact gradient rows instead of a dense means2d gradient
+    (SparseGradExchange.rasterization): update_statistics_rows on them = update_statistics_all on the dense absgrad of the
+    same frame rendered the ordinary way."""
+    from mtgs_amd import dist as mdist, rasterization, spherical_harmonics
+    from mtgs_amd.densify import update_statistics_all, update_statistics_rows
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda")
+    N, W, H = 40_000, 320, 240
+    sc = make_scene(N, seed=3, sh_degree=3, extent=(12.0, 4.0, 12.0))
+    vm, K = make_camera(W, H, yaw_deg=20.0)
+    vm, K = vm.to(dev), K.to(dev)
+    cam_pos = torch.inverse(vm)[0, :3, 3]
+    g = torch.Generator().manual_seed(1)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=g).to(dev), torch.randn(1, H, W, 1, generator=g).to(dev)
+    sizes = [25_000, 10_000, 5_000]                       # three nodes, concatenated as get_gaussians does
+    mk = lambda: [(torch.zeros(n, device=dev), torch.ones(n, device=dev), torch.zeros(n, device=dev)) for n in sizes]
+
+    P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    sh = spherical_harmonics(3, P["means"].detach() - cam_pos, P["coeffs"].detach())
+    render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], torch.clamp(sh + 0.5, 0.0, 1.0), vm, K,
+                                        W, H, packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+    info["means2d"].retain_grad()
+    torch.autograd.backward([render, alpha], [Gc, Ga])
+    dense = mk()
+    update_statistics_all(dense, info["radii"], info["means2d"].absgrad, W, H)
+
+    P2 = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    ex = mdist.SparseGradExchange(N, 16, dev)
+    r2, a2, info2 = ex.rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], sh, vm, K, W, H, cam_pos)
+    torch.autograd.backward([r2, a2], [Gc, Ga])
+    rows = mk()
+    n_vis = int((info2["radii"] > 0).sum())
+    assert ex.grad_rows is not None and ex.vis_ids.numel() >= n_vis
+    update_statistics_rows(rows, info2["radii"], ex.grad_rows, ex.vis_ids, W, H, n_vis=n_vis)
+    ex.finish(P2["means"], 3)
+    for (a_n, a_c, a_m), (b_n, b_c, b_m) in zip(dense, rows):
+        assert torch.equal(a_c, b_c) and torch.equal(a_m, b_m)
+        assert float(a_n.max()) > 0 and torch.allclose(a_n, b_n, rtol=2e-4, atol=1e-6 * float(a_n.max()))   # fp32 atomics in another order
