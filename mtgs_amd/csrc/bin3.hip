@@ -250,7 +250,12 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
         __syncthreads();
         for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
             const uint32_t c = s_bins[b];
-            if (c) __hip_atomic_fetch_add(bins + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c) {
+                // the RETURNING form: its completion is what the vmcnt(0) of the barrier below waits for, and the last
+                // workgroup's reads of the totals (arrive_last) rely on exactly that
+                const uint32_t before = __hip_atomic_fetch_add(bins + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::"v"(before));
+            }
         }
         __syncthreads();
     }
