@@ -387,7 +387,8 @@ def main():
                      "launches_timed": len(kernel_ms),
                      "note": "kernel is VALU bound, not HBM bound (DESIGN.md section 4); valu_busy_frac = SQ_ACTIVE_INST_VALU*4/1024 "
                              "over GRBM_GUI_ACTIVE/8 from the committed rocprofv3 --pmc passes of this workload",
-                     "valu_busy_frac": valu_busy,
+                     # (the two counters come from different blocks of the chip: a ratio a percent above 1 is "busy throughout")
+                     "valu_busy_frac": None if valu_busy is None else min(1.0, valu_busy), "valu_busy_raw": valu_busy,
                      "kernels": kernels,
                      "kernels_note": "per kernel of the step: algorithmic bytes of THIS run's (N, n_vis, M), counter bytes / avg_us / "
                                      "VALU-busy from the committed profiles (profiles/r02_pmc_step.json, r02_bench_kernel_stats.csv)",
