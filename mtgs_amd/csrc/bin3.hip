@@ -45,12 +45,12 @@ namespace {
 using mtgs_os::SizeRef;
 
 constexpr int B3_BLOCK = 256;
-constexpr int MAX_BINS = 12288;  // (camera, tile) pairs whose counts fit the histogram kernel's LDS
+constexpr int MAX_BINS = 32768;  // (camera, tile) pairs whose counts fit the counting kernels' LDS (3840x2160: 32400 tiles)
 
 // ---- 1. row items: (Gaussian, tile row) pairs grouped by row ------------------------------------------------------
-// An item = {rank, first tile of the Gaussian in this row << 14 | number of tiles - 1}.
+// An item = {rank, first tile of the Gaussian in this row << 12 | number of tiles - 1}.
 struct Item { uint32_t rank, span; };
-constexpr int SPAN_BITS = 14;   // tile ids and row widths below 2^14 (MAX_BINS)
+constexpr int SPAN_BITS = 12;   // row widths up to 2^12 tiles, tile ids below 2^20 (MAX_BINS)
 constexpr int MAX_ROWS = 1024;  // (camera, tile row) bins of the row kernels' LDS histogram
 
 struct RowGeom { int row0, h, tile0, w; };   // first (camera, row) bin, rows, first tile id of the first row, tiles per row
@@ -321,11 +321,13 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
 __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
     const uint32_t *__restrict__ n_items_ptr, int64_t cap_items, const Item *__restrict__ items, int tw, int n_bins,
     const int32_t *__restrict__ offsets, uint32_t *__restrict__ cursor /* [n_bins], zero */,
-    const uint64_t *__restrict__ vis_keys, uint64_t *__restrict__ keys64) {
-    extern __shared__ uint32_t s_mem[];   // next free slot [n_bins] | end of the tile's segment [n_bins]
+    const uint64_t *__restrict__ vis_keys, uint32_t cap_keys, uint64_t *__restrict__ keys64) {
+    // (In a frame beyond its capacities the offsets are clamped and a tile's keys may spill into its neighbour's slots or
+    // past cap_keys: the stores stay inside the buffer, slots may stay unwritten, and the sort's epilogue clamps the
+    // rank it reads from them -- the caller repeats such a frame.)
+    extern __shared__ uint32_t s_bins[];   // [n_bins]: count, then next free slot, of the tiles this chunk touches
     __shared__ uint16_t s_wide[T_TILE];
     __shared__ uint32_t s_nwide;
-    uint32_t *s_bins = s_mem, *s_end = s_mem + n_bins;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n_items = min((int64_t)*n_items_ptr, cap_items);
     for (int64_t base = (int64_t)blockIdx.x * T_TILE; base < n_items; base += (int64_t)gridDim.x * T_TILE) {
@@ -362,10 +364,7 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
         __syncthreads();
         for (int b = tr.lo + tid; b < tr.hi; b += T_THREADS) {
             const uint32_t c = s_bins[b];
-            if (c) {
-                s_bins[b] = (uint32_t)offsets[b] + __hip_atomic_fetch_add(cursor + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_end[b] = (uint32_t)offsets[b + 1];   // (shorter than the count only in a frame beyond its capacities)
-            }
+            if (c) s_bins[b] = (uint32_t)offsets[b] + __hip_atomic_fetch_add(cursor + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
 #pragma unroll
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
             const uint64_t key = ((uint64_t)depth[e] << 32) | it[e].rank;
             for (int x = 0; x < w[e]; ++x) {
                 const uint32_t pos = atomicAdd(&s_bins[t0[e] + x], 1u);
-                if (pos < s_end[t0[e] + x]) keys64[pos] = key;
+                if (pos < cap_keys) keys64[pos] = key;
             }
         }
         for (uint32_t q = wave; q < n_wide; q += T_THREADS / 64) {
@@ -382,7 +381,7 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
             const uint64_t key = ((uint64_t)(uint32_t)vis_keys[iw.rank] << 32) | iw.rank;
             for (int x = lane; x < wq; x += 64) {
                 const uint32_t pos = atomicAdd(&s_bins[tq + x], 1u);
-                if (pos < s_end[tq + x]) keys64[pos] = key;
+                if (pos < cap_keys) keys64[pos] = key;
             }
         }
         __syncthreads();
@@ -397,8 +396,9 @@ struct SortEpilogue {
     uint32_t n_tiles;
     int tile_bits;
     bool single_cam;
+    uint32_t rank_max;   // cap_vis - 1: a slot a truncated frame left unwritten must not index outside the records
     __device__ __forceinline__ void store(int64_t dst, uint32_t bin, uint64_t key) const {
-        const int32_t rank = (int32_t)(uint32_t)key;
+        const int32_t rank = (int32_t)min((uint32_t)key, rank_max);
         rank_ids[dst] = rank;
         flatten_ids[dst] = vis_ids[rank];
         if (isect_ids) {
@@ -735,7 +735,7 @@ inline Bin3Workspace carve3(char *base, int64_t cap_vis, int64_t cap_M, int n_ro
 }  // namespace
 
 extern "C" int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M) {
-    return C > 0 && tile_w > 0 && tile_h > 0 && (int64_t)C * tile_w * tile_h <= MAX_BINS && (int64_t)C * tile_h <= MAX_ROWS &&
+    return C > 0 && tile_w > 0 && tile_h > 0 && (int64_t)C * tile_w * tile_h <= MAX_BINS && (int64_t)C * tile_h <= MAX_ROWS && tile_w <= (1 << SPAN_BITS) &&
                    cap_M < ((int64_t)1 << 30)
                ? 1 : 0;
 }
@@ -776,15 +776,17 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
                                                       w.rbase, cap_M, w.items);
     bin3_tiles_count_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
                                                                             cap_M, w.bins, w.done_tiles, offsets, order, w.n_long);
-    bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 8, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
-                                                                            offsets, w.cursor, (const uint64_t *)vis_keys, w.keys64);
+    bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
+                                                                            offsets, w.cursor, (const uint64_t *)vis_keys, (uint32_t)(cap_M > 0 ? cap_M : 1), w.keys64);
     const SortEpilogue epi{rank_ids, flatten_ids, isect_ids, vis_ids, (uint32_t)(tile_w * tile_h),
-                           bit_length_u32((uint32_t)(tile_w * tile_h)), C == 1};
+                           bit_length_u32((uint32_t)(tile_w * tile_h)), C == 1, (uint32_t)(cap_vis > 0 ? cap_vis - 1 : 0)};
     static const bool big_lds = [] {
         return hipFuncSetAttribute((const void *)bin3_sort_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LG_CAP * 8) == hipSuccess &&
                hipFuncSetAttribute((const void *)bin3_tiles_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   MAX_BINS * 8) == hipSuccess;
+                                   MAX_BINS * 4) == hipSuccess &&
+               hipFuncSetAttribute((const void *)bin3_tiles_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   MAX_BINS * 4) == hipSuccess;
     }();
     MTGS_REQUIRE(big_lds, MTGS_ELAUNCH, "mtgs_bin3_build: cannot reserve %d bytes of LDS per workgroup", LG_CAP * 8);
     bin3_sort_large_kernel<<<(unsigned)min(n_bins, 256), LG_THREADS, (size_t)LG_CAP * 8, st>>>(

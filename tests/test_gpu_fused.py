@@ -327,3 +327,31 @@ def test_more_tile_rows_than_the_packed_path_takes(hip_lib):
     assert isect_ids.numel() > n and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
     (render.sum() + alpha.sum()).backward()
     assert means.grad is not None and float(means.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("W,H", [(2560, 1440), (3840, 2160)])
+def test_high_resolution_frames_take_the_packed_path(hip_lib, W, H):
+    """14400 and 32400 tiles (one LDS histogram entry per tile: up to 32768): same ids and image as the operator path."""
+    from mtgs_amd import _lib, rasterization
+    from mtgs_amd import wrapper as w
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda")
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    assert _lib.load().mtgs_bin3_supported(1, tw, th, 0)
+    N = 300_000
+    sc = make_scene(N, seed=11, sh_degree=None)
+    P = {k: v.to(dev) for k, v in sc.items()}
+    vm, K = make_camera(W, H)
+    vm, K = vm.to(dev), K.to(dev)
+    cols = torch.rand(N, 3, device=dev)
+    render, alpha, info = rasterization(means=P["means"], quats=P["quats"], scales=P["scales"], opacities=P["opacities"], colors=cols,
+                                        viewmats=vm, Ks=K, width=W, height=H, packed=False, render_mode="RGB+ED",
+                                        rasterize_mode="antialiased")
+    radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(P["means"], P["quats"], P["scales"], vm, K, P["opacities"],
+                                                                            W, H, calc_compensations=True)
+    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, tw, th)
+    off = w.isect_offset_encode(isect_ids, 1, tw, th)
+    assert isect_ids.numel() > 100_000
+    assert torch.equal(info["isect_offsets"], off) and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
+    r2, a2 = w.rasterize_to_pixels_with_depth(means2d, conics, cols.unsqueeze(0), oe, depths, True, W, H, 16, off, flat)
+    assert torch.allclose(render, r2, atol=1e-5) and torch.allclose(alpha, a2, atol=1e-5)
