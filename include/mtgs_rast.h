@@ -287,7 +287,7 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  * isect_tiles(sort=True) + isect_offset_encode.  Sizes come from `totals` on the device, clamped to (cap_vis, cap_M):
  * the caller sizes buffers and this call sizes grids for the capacities; if the true totals exceed them the outputs are
  * truncated (never out of bounds) and the caller repeats with larger ones.  Seven launches.
- * Supported when mtgs_bin3_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 32768 (3840x2160 has 32400 tiles), C*tile_h <= 1024, tile_w <= 4096,
+ * Supported when mtgs_bin3_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 32768 (3840x2160 has 32400 tiles), C*tile_h <= 4096, tile_w <= 4096,
  * cap_M < 2^30), else use mtgs_bin_build.  ws: mtgs_bin3_workspace_bytes, 256-byte aligned.
  *
  * mtgs_blend_fwd_packed / mtgs_blend_bwd_packed: mtgs_blend_fwd / _bwd reading the records through rank_ids.

@@ -51,7 +51,7 @@ constexpr int MAX_BINS = 32768;  // (camera, tile) pairs whose counts fit the co
 // An item = {rank, first tile of the Gaussian in this row << 12 | number of tiles - 1}.
 struct Item { uint32_t rank, span; };
 constexpr int SPAN_BITS = 12;   // row widths up to 2^12 tiles, tile ids below 2^20 (MAX_BINS)
-constexpr int MAX_ROWS = 1024;  // (camera, tile row) bins of the row kernels' LDS histogram
+constexpr int MAX_ROWS = 4096;  // (camera, tile row) bins of the row kernels' LDS histogram (60 cameras at 1080p)
 
 struct RowGeom { int row0, h, tile0, w; };   // first (camera, row) bin, rows, first tile id of the first row, tiles per row
 __device__ __forceinline__ RowGeom row_geom(const float *__restrict__ recs, const int32_t *__restrict__ vis_ids, int64_t rank,
@@ -127,12 +127,13 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef 
         if (c) rbase[(size_t)blockIdx.x * n_rows + b] = __hip_atomic_fetch_add(row_count + b, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!arrive_last(done, ceil_div64(n_vis, R_BLOCK), &s_last)) return;
-    // exclusive scan of the row totals (n_rows <= MAX_ROWS = one per thread)
-    static_assert(MAX_ROWS == R_BLOCK, "one row total per thread");
-    uint32_t v[1], mine = 0;
+    // exclusive scan of the row totals (ROWS_PER_THREAD consecutive rows per thread)
+    constexpr int ROWS_PER_THREAD = MAX_ROWS / R_BLOCK;
+    static_assert(MAX_ROWS % R_BLOCK == 0, "whole rows per thread");
+    uint32_t v[ROWS_PER_THREAD], mine = 0;
 #pragma unroll
-    for (int e = 0; e < 1; ++e) {
-        const int b = tid + e;
+    for (int e = 0; e < ROWS_PER_THREAD; ++e) {
+        const int b = tid * ROWS_PER_THREAD + e;
         v[e] = b < n_rows ? mtgs_os::ld32(row_count + b) : 0u;
         mine += v[e];
     }
@@ -146,8 +147,13 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef 
     __syncthreads();
     uint32_t run = inc - mine;
     for (int w = 0; w < wave; ++w) run += s_ws[w];
-    if (tid < n_rows) row_start[tid] = run;
-    if (tid == n_rows - 1) row_start[n_rows] = run + v[0];   // number of items
+#pragma unroll
+    for (int e = 0; e < ROWS_PER_THREAD; ++e) {
+        const int b = tid * ROWS_PER_THREAD + e;
+        if (b < n_rows) row_start[b] = run;
+        run += v[e];
+        if (b == n_rows - 1) row_start[n_rows] = run;   // number of items
+    }
 }
 
 __global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef n_vis_ref, const float *__restrict__ recs,

@@ -515,7 +515,7 @@ class _FusedRasterization(torch.autograd.Function):
     enqueue any of it (see _SizePlan).  Being one node also lets the backward keep the compositing gradients in COMPACT
     rows -- one 64-byte row per VISIBLE Gaussian, indexed like the records -- and lets the projection backward emit the
     gradients that leave the rasterizer (colours, means2d for retain_grad(), |means2d| for absgrad) as dense contiguous
-    tensors while it reads those rows.  Channel counts above 8, more than 32768 (camera, tile) pairs, 1024 (camera, tile row) pairs or 2^30
+    tensors while it reads those rows.  Channel counts above 8, more than 32768 (camera, tile) pairs, 4096 (camera, tile row) pairs or 2^30
     intersections take the earlier gather-based kernels (same results).
     Outputs: render, alphas, radii, means2d, depths, conics, compensations, opacities_eff, tiles_per_gauss,
     isect_ids, flatten_ids, isect_offsets  (the tensors of gsplat's `meta`)."""

@@ -301,13 +301,13 @@ def test_long_tile_lists_every_sort_path(hip_lib, n, equal_depths):
 
 
 def test_more_tile_rows_than_the_packed_path_takes(hip_lib):
-    """A 32 x 16500 image has 1032 tile rows: beyond mtgs_bin3_supported (C * tile_h <= 1024), so the frame takes the
+    """A 32 x 66000 image has 4125 tile rows: beyond mtgs_bin3_supported (C * tile_h <= 4096), so the frame takes the
     gather-based kernels -- same ids as the operator path, and gradients flow."""
     from mtgs_amd import _lib, rasterization
     from mtgs_amd import wrapper as w
     dev = torch.device("cuda")
-    W, H, n = 32, 16500, 4000
-    assert not _lib.load().mtgs_bin3_supported(1, 2, 1032, 0) and _lib.load().mtgs_bin3_supported(1, 2, 1024, 0)
+    W, H, n = 32, 66000, 4000
+    assert not _lib.load().mtgs_bin3_supported(1, 2, 4125, 0) and _lib.load().mtgs_bin3_supported(1, 2, 4096, 0)
     g = torch.Generator().manual_seed(1)
     K = torch.tensor([[[40.0, 0.0, W / 2.0], [0.0, 40.0, H / 2.0], [0.0, 0.0, 1.0]]], device=dev)
     vm = torch.eye(4, device=dev)[None]
@@ -323,7 +323,7 @@ def test_more_tile_rows_than_the_packed_path_takes(hip_lib):
                                         width=W, height=H, packed=False, render_mode="RGB+ED", rasterize_mode="antialiased")
     radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(means.detach(), quats, scales, vm, K, opac, W, H,
                                                                             calc_compensations=True)
-    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 2, 1032)
+    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 2, 4125)
     assert isect_ids.numel() > n and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
     (render.sum() + alpha.sum()).backward()
     assert means.grad is not None and float(means.grad.abs().sum()) > 0
@@ -355,3 +355,27 @@ def test_high_resolution_frames_take_the_packed_path(hip_lib, W, H):
     assert torch.equal(info["isect_offsets"], off) and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
     r2, a2 = w.rasterize_to_pixels_with_depth(means2d, conics, cols.unsqueeze(0), oe, depths, True, W, H, 16, off, flat)
     assert torch.allclose(render, r2, atol=1e-5) and torch.allclose(alpha, a2, atol=1e-5)
+
+
+def test_many_cameras_in_one_call_take_the_packed_path(hip_lib):
+    """24 cameras of 640x480: 24 x 30 = 720 (camera, tile row) bins, 28800 (camera, tile) bins -- one call, same ids as the
+    operator path."""
+    from mtgs_amd import _lib, rasterization
+    from mtgs_amd import wrapper as w
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda")
+    C, W, H, N = 24, 640, 480, 60_000
+    assert _lib.load().mtgs_bin3_supported(C, 40, 30, 0)
+    sc = make_scene(N, seed=4, sh_degree=None)
+    P = {k: v.to(dev) for k, v in sc.items()}
+    vms, Ks = zip(*[make_camera(W, H, yaw_deg=15.0 * c) for c in range(C)])
+    vm, K = torch.cat(vms).to(dev), torch.cat(Ks).to(dev)
+    cols = torch.rand(N, 3, device=dev)
+    render, alpha, info = rasterization(means=P["means"], quats=P["quats"], scales=P["scales"], opacities=P["opacities"], colors=cols,
+                                        viewmats=vm, Ks=K, width=W, height=H, packed=False, render_mode="RGB+ED",
+                                        rasterize_mode="antialiased")
+    radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(P["means"], P["quats"], P["scales"], vm, K, P["opacities"],
+                                                                            W, H, calc_compensations=True)
+    _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 40, 30)
+    off = w.isect_offset_encode(isect_ids, C, 40, 30)
+    assert torch.equal(info["isect_offsets"], off) and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
