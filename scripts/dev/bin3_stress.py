@@ -35,8 +35,12 @@ for case in range(cases):
     opac = (0.02 + 0.9 * torch.rand(N, generator=g)).to(dev)
     cols = torch.rand(N, 3, generator=g).to(dev)
     mode = "antialiased" if rf() < 0.5 else "classic"
-    r, a, info = rasterization(means=means, quats=quats, scales=scales, opacities=opac, colors=cols, viewmats=vm, Ks=K, width=W,
-                               height=H, packed=False, render_mode="RGB+ED", rasterize_mode=mode)
+    try:
+        r, a, info = rasterization(means=means, quats=quats, scales=scales, opacities=opac, colors=cols, viewmats=vm, Ks=K, width=W,
+                                   height=H, packed=False, render_mode="RGB+ED", rasterize_mode=mode)
+    except NotImplementedError as e:      # more than 2^30 intersections in one call: refused by name
+        assert "tile intersections" in str(e), e
+        continue
     radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(means, quats, scales, vm, K, opac, W, H,
                                                                             calc_compensations=(mode == "antialiased"))
     _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, tw, th)
