@@ -38,8 +38,8 @@ for case in range(cases):
     try:
         r, a, info = rasterization(means=means, quats=quats, scales=scales, opacities=opac, colors=cols, viewmats=vm, Ks=K, width=W,
                                    height=H, packed=False, render_mode="RGB+ED", rasterize_mode=mode)
-    except NotImplementedError as e:      # more than 2^30 intersections in one call: refused by name
-        assert "tile intersections" in str(e), e
+    except (NotImplementedError, RuntimeError) as e:      # more than 2^30 (2^31) intersections in one call: refused by name
+        assert "intersections" in str(e), e
         continue
     radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(means, quats, scales, vm, K, opac, W, H,
                                                                             calc_compensations=(mode == "antialiased"))
