@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 8
+#define MTGS_RAST_ABI_VERSION 9
 
 enum {
     MTGS_OK = 0,
@@ -353,6 +353,16 @@ int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, cons
                    const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
                    const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                    float *v_coeffs, int64_t g_begin, int64_t g_end, void *stream);
+/* mtgs_dp_reduce_slices: the same pass for PER-TRAVERSAL appearance parameters (MTGS's multi-colour nodes: ranks of one
+ * step render cameras of different traversals, and a sender's colour gradient belongs to ITS traversal's coefficients).
+ * coeff_mask: bit r = sender r contributes to v_coeffs; Gaussian n's coefficients start at v_coeffs + n * coeff_stride
+ * floats (a slice of [N, T, K, 3]: coeff_stride = T K 3, v_coeffs pre-offset by t K 3); write_geometry = 0 skips the four
+ * geometry gradients (summed over ALL senders, written by one of the T passes). */
+int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                          const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
+                          const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                          float *v_coeffs, int64_t g_begin, int64_t g_end, uint64_t coeff_mask, int write_geometry,
+                          int64_t coeff_stride, void *stream);
 /* Wire rows straight from the compositing backward's compact gradient rows (no dense tensor, no pack pass): the VJP of
  * the projection per VISIBLE Gaussian (vis_ids[n_vis], index order; C = 1) writes wire_rows[n_vis,16] =
  * {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, 0, Gaussian index (int bits)}.  grad_rows[n_vis,row_stride] as mtgs_blend_bwd_packed

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_dp_reduce": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "mtgs_dp_reduce_slices": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                              C.c_uint64, _i32, _i64, _vp],
     "mtgs_project_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
                               _vp, _i64, _vp, _vp, _vp],
     "mtgs_node_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -115,7 +117,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 

@@ -252,7 +252,11 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
                                                         const float *__restrict__ means, const DpSenders S,
                                                         float *__restrict__ v_means, float *__restrict__ v_quats,
                                                         float *__restrict__ v_scales, float *__restrict__ v_opacities,
-                                                        float *__restrict__ v_coeffs) {
+                                                        float *__restrict__ v_coeffs, unsigned long long coeff_mask, int geom,
+                                                        int64_t coeff_stride) {
+    // coeff_mask: the senders whose colour factors go into v_coeffs (per-traversal appearance: one pass per traversal
+    // writes that traversal's slice, Gaussian n at v_coeffs + n * coeff_stride); geom: this pass also sums and writes
+    // the geometry gradients (over ALL senders).
     __shared__ float4 s_acc[4][DP_TILE][16];
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t tile = g_begin / DP_TILE + (int64_t)blockIdx.x * 4 + wave;
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         for (int st = 0; st < DP_MAXSTEP; ++st) cur[st] = nxt[st];
         const int cnt = nxt_cnt;
         if (r + 1 < S.W) issue(r + 1, nxt, nxt_cnt);
-        if (cnt == 0) continue;  // wave-uniform: this sender has none of the tile's Gaussians
+        const bool colour = v_coeffs && ((coeff_mask >> r) & 1ull);
+        if (cnt == 0 || !(geom || colour)) continue;  // wave-uniform: none of the tile's Gaussians / nothing to take from it
         const float cx = S.cams[r * 3], cy = S.cams[r * 3 + 1], cz = S.cams[r * 3 + 2];
 #pragma unroll
         for (int st = 0; st < DP_MAXSTEP; ++st) {
@@ -316,8 +321,8 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
             const int idx = __builtin_amdgcn_ds_bpermute(row_lane0 + 15 * 4, vi);   // the row's Gaussian index (last word)
             const int pos = on ? (int)(idx - (int)g0) : 0;
             float4 a = acc[pos][k];
-            a.x += k < 11 ? cur[st] : 0.f;
-            if (v_coeffs) {
+            a.x += (geom && k < 11) ? cur[st] : 0.f;
+            if (colour) {
                 const float q0 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 11 * 4, vi));
                 const float q1 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 12 * 4, vi));
                 const float q2 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 13 * 4, vi));
@@ -335,12 +340,14 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         const int64_t n = g0 + it * 4 + sub;
         if (n >= N) continue;
         const float4 a = acc[it * 4 + sub][k];
-        if (k < 3) v_means[n * 3 + k] = a.x;
-        else if (k < 7) v_quats[n * 4 + (k - 3)] = a.x;
-        else if (k < 10) v_scales[n * 3 + (k - 7)] = a.x;
-        else if (k == 10) v_opacities[n] = a.x;
+        if (geom) {
+            if (k < 3) v_means[n * 3 + k] = a.x;
+            else if (k < 7) v_quats[n * 4 + (k - 3)] = a.x;
+            else if (k < 10) v_scales[n * 3 + (k - 7)] = a.x;
+            else if (k == 10) v_opacities[n] = a.x;
+        }
         if (v_coeffs && k < K) {
-            float *dst = v_coeffs + (n * K + k) * 3;
+            float *dst = v_coeffs + n * coeff_stride + k * 3;
             dst[0] = a.y; dst[1] = a.z; dst[2] = a.w;
         }
     }
@@ -410,11 +417,11 @@ extern "C" int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float
     return MTGS_OK;
 }
 
-extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
-                              const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
-                              int64_t row_stride, const float *cams, float *v_means, float *v_quats,
-                              float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
-                              void *stream) {
+extern "C" int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                                     const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
+                                     int64_t row_stride, const float *cams, float *v_means, float *v_quats,
+                                     float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
+                                     uint64_t coeff_mask, int write_geometry, int64_t coeff_stride, void *stream) {
     MTGS_REQUIRE(W >= 1 && N >= 0 && map_stride_bytes >= 0 && row_stride >= 0, MTGS_EINVAL, "mtgs_dp_reduce: bad sizes");
     MTGS_REQUIRE(W <= DP_MAX_SENDERS, MTGS_EUNSUPPORTED, "mtgs_dp_reduce: %d senders (at most %d; use mtgs_dp_accumulate)", W,
                  DP_MAX_SENDERS);
@@ -423,8 +430,9 @@ extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *
                  "mtgs_dp_reduce: range [%lld, %lld) of %lld (the start must be a multiple of 64)", (long long)g_begin,
                  (long long)g_end, (long long)N);
     if (g_end == g_begin) return MTGS_OK;
-    MTGS_REQUIRE(words && prefix && rows && v_means && v_quats && v_scales && v_opacities, MTGS_EINVAL,
+    MTGS_REQUIRE(words && prefix && rows && (!write_geometry || (v_means && v_quats && v_scales && v_opacities)), MTGS_EINVAL,
                  "mtgs_dp_reduce: null pointer");
+    MTGS_REQUIRE(write_geometry || v_coeffs, MTGS_EINVAL, "mtgs_dp_reduce: nothing to write");
     int nb = 0;
     if (v_coeffs) {
         MTGS_REQUIRE(means && cams && degree >= 0 && (degree + 1) * (degree + 1) <= K, MTGS_EINVAL,
@@ -432,19 +440,31 @@ extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *
         MTGS_REQUIRE(degree <= 3 && K <= 16, MTGS_EUNSUPPORTED,
                      "mtgs_dp_reduce: degree %d / K %d (one basis per lane of a 16-lane row: degree <= 3, K <= 16; "
                      "use mtgs_dp_accumulate)", degree, K);
+        MTGS_REQUIRE(coeff_stride >= (int64_t)K * 3, MTGS_EINVAL, "mtgs_dp_reduce: coefficient stride %lld < K * 3", (long long)coeff_stride);
         nb = (degree + 1) * (degree + 1);
     }
     MTGS_REQUIRE(means, MTGS_EINVAL, "mtgs_dp_reduce: null pointer");
     const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
     const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);  // one wave per 32-Gaussian tile
     hipStream_t st = (hipStream_t)stream;
+    const unsigned long long cm = coeff_mask;
+    const int geom = write_geometry ? 1 : 0;
     // (the kernel bounds its writes by g_end: the last range ends at N)
     switch (degree) {
-        case 0: dp_reduce_kernel<0><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
-        case 1: dp_reduce_kernel<1><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
-        case 2: dp_reduce_kernel<2><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
-        default: dp_reduce_kernel<3><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs); break;
+        case 0: dp_reduce_kernel<0><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs, cm, geom, coeff_stride); break;
+        case 1: dp_reduce_kernel<1><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs, cm, geom, coeff_stride); break;
+        case 2: dp_reduce_kernel<2><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs, cm, geom, coeff_stride); break;
+        default: dp_reduce_kernel<3><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs, cm, geom, coeff_stride); break;
     }
     MTGS_CHECK_LAUNCH("mtgs_dp_reduce");
     return MTGS_OK;
+}
+
+extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                              const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
+                              int64_t row_stride, const float *cams, float *v_means, float *v_quats,
+                              float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
+                              void *stream) {
+    return mtgs_dp_reduce_slices(W, N, K, degree, means, words, prefix, map_stride_bytes, rows, row_stride, cams, v_means, v_quats,
+                                 v_scales, v_opacities, v_coeffs, g_begin, g_end, ~0ull, 1, (int64_t)K * 3, stream);
 }

@@ -156,7 +156,7 @@ class SparseGradExchange:
 
     ROW = 16
 
-    def __init__(self, n_gaussians: int, n_sh_bases: int, device, group=None, chunks: int = 4):
+    def __init__(self, n_gaussians: int, n_sh_bases: int, device, group=None, chunks: int = 4, traversals: int = 1):
         self.N, self.K, self.device, self.group = int(n_gaussians), int(n_sh_bases), device, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -171,14 +171,18 @@ class SparseGradExchange:
         self.count = torch.zeros(1, dtype=torch.int64, device=device)
         # meta record of a rank, int32 words: [count, cam x, cam y, cam z | words (u64) ... | prefix (u32) ...]
         self.n_words = (N + 63) // 64
-        self.meta_len = 4 + 3 * self.n_words + (self.n_words & 1)   # even: every rank's u64 words stay 8-byte aligned
+        # (two trailing words: the traversal of this rank's camera -- per-traversal appearance parameters -- and a spare;
+        #  the length stays even, so every rank's u64 words stay 8-byte aligned)
+        self.meta_len = 4 + 3 * self.n_words + (self.n_words & 1) + 2
         self.meta = torch.zeros(self.meta_len, dtype=torch.int32, device=device)
+        self.T = int(traversals)
+        assert self.T >= 1
         self.block_counts = torch.empty((N + 1023) // 1024 + 1, dtype=torch.int32, device=device)  # pack scratch
         # what the host needs from every rank's meta: the row count and the row index at every chunk boundary
         self._sample_idx = torch.tensor([0] + [4 + 2 * self.n_words + min(b // 64, max(self.n_words - 1, 0))
-                                               for b in self.bounds[:-1]], dtype=torch.int64, device=device)
+                                               for b in self.bounds[:-1]] + [self.meta_len - 2], dtype=torch.int64, device=device)
         is_cuda = torch.device(device).type == "cuda"
-        self._samples_host = torch.zeros((self.world, len(self.bounds)), dtype=torch.int32)
+        self._samples_host = torch.zeros((self.world, len(self.bounds) + 1), dtype=torch.int32)
         if is_cuda:
             self._samples_host = self._samples_host.pin_memory()
         self.comm_stream = torch.cuda.Stream(device) if is_cuda else None
@@ -190,15 +194,20 @@ class SparseGradExchange:
     # ---- integrated form -----------------------------------------------------------------------------------------
     def rasterization(self, means, quats, scales, opacities, sh_out, viewmats, Ks, width, height, cam_pos, near_plane=0.01,
                       far_plane=1e10, radius_clip=0.0, eps2d=0.3, render_mode="RGB+ED", rasterize_mode="antialiased",
-                      absgrad=True):
+                      absgrad=True, traversal: int = 0):
         """This rank's camera of the step.  Same outputs as `mtgs_amd.rasterization(colors=clamp(sh_out + 0.5, 0, 1), ...)`
         with MTGS's options (mtgs_scene_graph.py:641-659); `sh_out[N,3]` is the SH evaluation for THIS camera
         (`spherical_harmonics(n, means - cam_pos, coeffs)`, detached: its backward happens on the receivers).  The
-        backward leaves the gradients as wire rows; call `finish()` after it."""
+        backward leaves the gradients as wire rows; call `finish()` after it.  `traversal` (with traversals = T > 1): the
+        traversal this rank's camera belongs to -- MTGS's multi-colour nodes have one set of SH coefficients per traversal
+        (multi_color_gaussian_splatting.py:77-101), and finish() then returns the coefficient gradient as [N, T, K, 3]
+        with every sender's contribution in ITS traversal's slice."""
         from .wrapper import fused_rasterization
         assert viewmats.shape[0] == 1 and sh_out.shape == (self.N, 3) and means.shape == (self.N, 3)
         assert render_mode in ("RGB", "RGB+D", "RGB+ED") and rasterize_mode in ("classic", "antialiased")
+        assert 0 <= int(traversal) < self.T, (traversal, self.T)
         self.meta[1:4].copy_(cam_pos.reshape(3).to(torch.float32).contiguous().view(torch.int32))
+        self.meta[self.meta_len - 2:self.meta_len - 1].fill_(int(traversal))
         self._pending = {"stage": "forward"}
         render, alphas, m = fused_rasterization(
             means, quats, scales, opacities, sh_out.detach().unsqueeze(0), viewmats, Ks, None, width, height, eps2d,
@@ -256,9 +265,13 @@ class SparseGradExchange:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         cams = metas[:, 1:4].contiguous().view(torch.float32)
         words_all, prefix_all = metas[:, 4:], metas[:, 4 + 2 * nw:]
+        T = self.T
         out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
                torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
-               torch.empty((N, K, 3), dtype=torch.float32, device=dev))
+               torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
+        # per-traversal appearance: the senders of traversal t (a bit mask) write slice t of the coefficient gradient
+        trav = [int(samples[r][len(self.bounds)]) for r in range(world)]
+        masks = [sum(1 << r for r in range(world) if trav[r] == t) for t in range(T)]
         ev = lambda: torch.cuda.Event(enable_timing=True)
         w0, w1, red = ev(), ev(), []
         # every chunk's all-gather is issued up front (they queue on the collective stream); chunk c is reduced as soon as
@@ -288,9 +301,17 @@ class SparseGradExchange:
                 w1.record()
             e0, e1 = ev(), ev()
             e0.record()
-            call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4,
-                 ptr(recvs[c]), caps[c] * self.ROW if world > 1 else 0, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]),
-                 ptr(out[3]), ptr(out[4]), self.bounds[c], self.bounds[c + 1], st)
+            if T == 1:
+                call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4,
+                     ptr(recvs[c]), caps[c] * self.ROW if world > 1 else 0, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                     ptr(out[3]), ptr(out[4]), self.bounds[c], self.bounds[c + 1], st)
+            else:
+                import ctypes as _C
+                for t in range(T):      # one pass per traversal's slice; the first also sums the geometry over all senders
+                    call("mtgs_dp_reduce_slices", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all),
+                         self.meta_len * 4, ptr(recvs[c]), caps[c] * self.ROW if world > 1 else 0, ptr(cams), ptr(out[0]),
+                         ptr(out[1]), ptr(out[2]), ptr(out[3]), out[4].data_ptr() + t * K * 3 * 4, self.bounds[c],
+                         self.bounds[c + 1], _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
             e1.record()
             red.append((e0, e1))
         self._events.update(wire=(w0, w1), reduce=red)
