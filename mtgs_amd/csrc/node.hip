@@ -51,7 +51,7 @@ struct NodeParams {
     int64_t dc_stride, dc_add_stride, rest_stride;           // row strides in floats
     const float *cam_pos;                                    // [3] device
     int Kr;                                                  // SH bases in `rest` (K - 1)
-    int use_sh;                                              // 0: rgbs = sigmoid(dc [+ dc_add])
+    int use_sh;                                              // 0: rgbs = sigmoid(dc [+ dc_add]); 1: clamp(SH + 0.5, 0, 1); 2: SH
     const float *pose;                                       // [4] device: instance quaternion wxyz; nullable (static node)
     const float *pose_t;                                     // [3] device: instance translation
     int pose_norm;                                           // 1: the quaternion is a raw parameter row, normalise it
@@ -167,7 +167,10 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
     if (!okl) return;
     // ---- lane-per-Gaussian results
     F3 rgb;
-    if (P.use_sh) {
+    if (P.use_sh == 2) {   // the raw SH value: the colour activation is the consumer's (data-parallel exchange, front.hip)
+        rgb = F3{myr, myg, myb};
+        clamp_mask[gl] = 7;
+    } else if (P.use_sh) {
         const float x = myr + 0.5f, y = myg + 0.5f, z = myb + 0.5f;
         rgb = F3{fminf(fmaxf(x, 0.f), 1.f), fminf(fmaxf(y, 0.f), 1.f), fminf(fmaxf(z, 0.f), 1.f)};
         // torch.clamp passes the gradient where min <= x <= max (inclusive): one bit per channel

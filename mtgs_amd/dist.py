@@ -244,6 +244,7 @@ class SparseGradExchange:
     def after_backward(self, n_vis, grad_rows, vis_ids):
         assert self._pending is not None and self._pending["stage"] == "meta", "rasterization() of this exchange first"
         self._pending.update(stage="rows", n_vis=int(n_vis))
+        self.n_vis = int(n_vis)
         # the compact gradient rows of this frame: what mtgs_amd.densify.update_statistics_rows reads (no dense means2d
         # gradient exists in this mode)
         self.grad_rows, self.vis_ids = grad_rows, vis_ids

@@ -339,7 +339,8 @@ class _CollectNodes(torch.autograd.Function):
         return (None, None) + tuple(g if need[j] else None for j, g in enumerate(grads))
 
 
-def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, model_sh_degree: int = 3) -> Dict[str, Tensor]:
+def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, model_sh_degree: int = 3,
+                      raw_colors: bool = False) -> Dict[str, Tensor]:
     """MTGSSceneModel.get_gaussians for static nodes (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:408-461): the
     activated Gaussians of every node, concatenated in order, plus `model_id`.  `nodes` is a sequence of dicts of RAW
     parameters {"means", "scales", "quats", "opacities", "features_dc", "features_rest"} with, for multi-colour nodes,
@@ -350,9 +351,12 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     full tables (zero but for that row).  One autograd node and ONE kernel
     launch per direction for the whole scene, however many nodes it has (a scene graph holds one rigid node per object
     instance in view): each node's workgroups write into its slice of the collected tensors (no torch.cat of per-node
-    outputs); "model_id" is written by the same launch."""
+    outputs); "model_id" is written by the same launch.
+    raw_colors: "rgbs" is the SH value itself, without clamp(. + 0.5, 0, 1) -- what the data-parallel exchange takes
+    (mtgs_amd.dist.SparseGradExchange.rasterization applies the activation and differentiates it)."""
     specs, flat, sizes = [], [], []
     use_sh = model_sh_degree > 0
+    assert use_sh or not raw_colors, "raw_colors needs an SH colour model"
     if len(nodes) == 0:
         raise ValueError("collect_gaussians: no nodes (MTGS returns its empty outputs before reaching the rasterizer, "
                          "mtgs_scene_graph.py:595-598)")
@@ -386,7 +390,7 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
             assert 0 <= frame < iq.shape[0], (frame, iq.shape)
         else:
             assert (iq is None) == (it is None) and (iq is None or (iq.numel() == 4 and it.numel() == 3)), "rigid pose: quat[4] + trans[3]"
-        specs.append((int(sh_degree_to_use), bool(use_sh), -1 if trav is None else int(trav), frame))
+        specs.append((int(sh_degree_to_use), 2 if raw_colors else int(use_sh), -1 if trav is None else int(trav), frame))
         flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest, iq, it]
         sizes.append(N)
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]

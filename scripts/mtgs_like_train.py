@@ -234,6 +234,46 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     return loss.detach()
 
 
+def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3):
+    """The fused iteration of one rank under view-parallel data parallelism with the SPARSE gradient exchange
+    (mtgs_amd.dist.SparseGradExchange with per-traversal colour routing) instead of a dense all-reduce of every parameter
+    gradient: the node kernels hand out the activated geometry and the RAW SH colours of every Gaussian; the exchange
+    renders, its backward leaves 64-byte wire rows, finish() returns the SUMS over all ranks of the gradients with respect
+    to the activated geometry and to the SH coefficients (every sender's colour factor in its own traversal's slice); the
+    geometry sums go back through the node activations (one launch), the coefficient sums ARE the gradients of
+    features_dc / features_adapters / features_rest.  Statistics from the compact rows.  RGB + L1 + SSIM (the exchange does
+    not carry the extra channels of the shipped option set)."""
+    from mtgs_amd.densify import update_statistics_rows
+    from mtgs_amd.nodes import collect_gaussians
+    vm, K, c2w, t = cam
+    gs = collect_gaussians([dict(p, traversal_index=t) if "features_adapters" in p else
+                            (dict(p, frame_idx=frame_of(t)) if "instance_quats" in p else p) for p in P.values()], c2w, n, 3,
+                           raw_colors=True)
+    leaves = {k: gs[k].detach().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
+    cam_pos = c2w[..., :3, 3].reshape(3)
+    render, alpha, info = ex.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], gs["rgbs"].detach(),
+                                           vm, K, W, H, cam_pos, traversal=t)
+    rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)
+    loss = 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
+    loss.backward()
+    with torch.no_grad():
+        update_statistics_rows([tuple(s) for s in stats], info["radii"], ex.grad_rows, ex.vis_ids, W, H, n_vis=ex.n_vis)
+    g_means, g_quats, g_scales, g_opac, g_coeffs = ex.finish(leaves["means"], n)          # sums over all ranks
+    torch.autograd.backward([gs["means"], gs["quats"], gs["scales"], gs["opacities"]], [g_means, g_quats, g_scales, g_opac])
+    start = 0
+    for p in P.values():
+        n_i = p["means"].shape[0]
+        gc = g_coeffs[start:start + n_i]                                                  # [n_i, T, 16, 3]
+        p["features_dc"].grad = gc[:, :, 0].sum(1)
+        if "features_adapters" in p:       # per-traversal appearance: every traversal's slice from ITS cameras only
+            p["features_adapters"].grad = gc[:, :, 0].contiguous()
+            p["features_rest"].grad = gc[:, :, 1:].contiguous()
+        else:
+            p["features_rest"].grad = gc[:, :, 1:].sum(1)
+        start += n_i
+    return loss.detach()
+
+
 def iteration_nograd(P, cam, gt, mask, stats, win, W, H, shipped):
     """the loss of `iteration` without backward / statistics (debug aid)"""
     vm, K, c2w, t = cam
@@ -280,7 +320,7 @@ def refine_device(P, stats, opt_state_of, step, seed, growth=0.02):
 
 
 def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=None, world=1, rank=0, accumulate=1, seed=7,
-               log=print):
+               log=print, sparse=False):
     """Adam on the fused iteration.  world > 1: view-parallel data parallelism (one process per rank, camera
     (step * world + rank) % T, ONE dense all-reduce of every gradient per step, statistics all-reduced before each
     refinement, refinement identical on every rank).  accumulate = K in ONE process: the K cameras of a step rendered one
@@ -302,16 +342,25 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     stats = mk()
     curve, sizes = [], []
     group = max(world, accumulate)
+    sparse = sparse and world > 1
+    assert not (sparse and shipped), "the sparse exchange carries RGB only"
+    mk_ex = lambda: mdist.SparseGradExchange(sum(p["means"].shape[0] for p in P.values()), 16, next(iter(P.values()))["means"].device,
+                                             traversals=T) if sparse else None
+    ex = mk_ex()
     for i in range(steps):
         opt.zero_grad(set_to_none=True)
         losses = []
         for a in range(accumulate):
             c = (i * group + (rank if world > 1 else a)) % T
-            losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
+            if sparse:
+                losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex))
+            else:
+                losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
         loss = torch.stack(losses).sum()
         params = [q for g in opt.param_groups for q in g["params"]]
         if world > 1:
-            mdist.all_reduce_grads(params)
+            if not sparse:
+                mdist.all_reduce_grads(params)
             torch.distributed.all_reduce(loss)
         curve.append(float(loss) / group)
         opt.step()
@@ -332,6 +381,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                     if q not in opt.state and state.get(id(q)):
                         opt.state[q] = state[id(q)]
             sizes.append(sum(p["means"].shape[0] for p in P.values()))
+            ex = mk_ex()                      # N changed: new send buffers and visibility maps
             log(f"step {i + 1}: refine {before} -> {sizes[-1]} Gaussians (+{added} -{culled})")
     return curve, sizes
 
@@ -353,6 +403,8 @@ def main():
     ap.add_argument("--only", choices=["both", "fused", "chain"], default="both", help="profiling aid: time one variant only")
     ap.add_argument("--dp", action="store_true", help="with --steps: view-parallel data parallelism under torch.distributed.run "
                     "(one camera per rank and step, dense gradient all-reduce, rank-identical refinement)")
+    ap.add_argument("--dp-exchange", choices=["dense", "sparse"], default="dense", help="with --dp: dense all-reduce of every "
+                    "parameter gradient, or the sparse factored exchange of mtgs_amd.dist (RGB option set only)")
     ap.add_argument("--accumulate", type=int, default=1, help="with --steps: cameras per step in ONE process (gradient accumulation)")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
@@ -487,7 +539,7 @@ def main():
             rank, _, world = mdist.init_from_env()
         log = print if rank == 0 else (lambda *a, **k: None)
         curve, sizes = train_loop(P, cams, targets, mask, win, W, H, args.steps, args.refine_every, shipped=shipped, world=world,
-                                  rank=rank, accumulate=args.accumulate, log=log)
+                                  rank=rank, accumulate=args.accumulate, log=log, sparse=args.dp_exchange == "sparse")
         k = max(1, args.steps // 8)
         log("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
         n_now = sum(p["means"].shape[0] for p in P.values())

@@ -222,3 +222,14 @@ def test_mtgs_like_training_data_parallel_keeps_ranks_in_lockstep():
     curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
     a, b = curve(dp.stdout), curve(one.stdout)
     assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
+    # the same job with the SPARSE gradient exchange: wire rows of the visible Gaussians instead of every parameter gradient,
+    # colour factors routed to the sender's traversal (the background node has per-traversal coefficients), statistics from
+    # the compact rows -- same refinements, same loss curve
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    sp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), str(root / "scripts" / "mtgs_like_train.py"), "--dp",
+                         "--dp-exchange", "sparse"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert sp.returncode == 0, sp.stdout[-1500:] + sp.stderr[-2500:]
+    assert "2 ranks: N = " in sp.stdout and sizes(sp.stdout) == sizes(one.stdout), (sizes(sp.stdout), sizes(one.stdout))
+    c = curve(sp.stdout)
+    assert len(c) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(c, b)), (c, b)
