@@ -325,6 +325,9 @@ __device__ __forceinline__ void node_bwd_wave(const int64_t N, const NodeParams 
             atomicAdd(g_pose + 4, t4); atomicAdd(g_pose + 5, t5); atomicAdd(g_pose + 6, t6);
         }
     }
+    // no colour gradient asked for (the data-parallel exchange rebuilds it on the receivers): the coefficient rows are
+    // not written at all -- N * K * 12 bytes, the largest stream of this kernel
+    if (!g_dc && !g_rest) return;
     // the basis needs the unit view direction: computed once per Gaussian here, moved to the rows below
     float dx = mn.x - camx, dy = mn.y - camy, dz = mn.z - camz;
     const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);

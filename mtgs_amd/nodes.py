@@ -272,9 +272,14 @@ class _CollectNodes(torch.autograd.Function):
         v_means_c = None if v_means is None else v_means.to(torch.float32).contiguous()
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         g_scales, g_quats, g_opac, g_dc = new(total, 3), new(total, 4), new(total), new(total, 3)
-        rest_sizes = [n * Kr * 3 * max(T, 1) for (n, Kr, _, _, T, _, _) in dims]
-        add_sizes = [n * T * 3 if (T and has_add) else 0 for (n, _, _, has_add, T, _, _) in dims]
+        # no node wants a colour gradient (features passed detached: the data-parallel exchange rebuilds the coefficient
+        # gradient on the receivers): the kernel then skips the coefficient rows, the largest stream of the backward
+        colours = any(need[_NK * i + j] for i in range(n_nodes) for j in (4, 5, 6))
+        rest_sizes = [n * Kr * 3 * max(T, 1) if colours else 0 for (n, Kr, _, _, T, _, _) in dims]
+        add_sizes = [n * T * 3 if (T and has_add and colours) else 0 for (n, _, _, has_add, T, _, _) in dims]
         g_rest_flat, g_add_flat = new(sum(rest_sizes)), new(sum(add_sizes))
+        if not colours:
+            g_dc = None
         want_gm = bool(rigid) and any(need[_NK * i] for i in rigid)
         g_means_all = new(total, 3) if want_gm else None
         g_pose_all = torch.zeros((len(rigid), 7), dtype=torch.float32, device=dev) if rigid else None   # atomics
@@ -286,10 +291,10 @@ class _CollectNodes(torch.autograd.Function):
         tab["quats_raw"] = [t.data_ptr() for t in saved[1::2]]
         tab["v_scales"], tab["v_quats"], tab["v_opacities"], tab["v_rgbs"] = at(v_scales, 12), at(v_quats, 16), at(v_opacities, 4), at(v_rgbs, 12)
         tab["v_means"] = at(v_means_c, 12) if v_means_c is not None else 0
-        tab["g_scales_raw"], tab["g_quats_raw"], tab["g_opacities_raw"], tab["g_features_dc"] = (at(g_scales, 12), at(g_quats, 16),
-                                                                                               at(g_opac, 4), at(g_dc, 12))
+        tab["g_scales_raw"], tab["g_quats_raw"], tab["g_opacities_raw"] = at(g_scales, 12), at(g_quats, 16), at(g_opac, 4)
+        tab["g_features_dc"] = at(g_dc, 12) if colours else 0
         rs, ads = np.asarray(rest_sizes, dtype=np.uint64), np.asarray(add_sizes, dtype=np.uint64)
-        tab["g_features_rest"] = np.uint64(g_rest_flat.data_ptr()) + np.uint64(4) * (np.cumsum(rs) - rs)
+        tab["g_features_rest"] = (np.uint64(g_rest_flat.data_ptr()) + np.uint64(4) * (np.cumsum(rs) - rs)) if colours else 0
         tab["g_features_dc_add"] = np.where(ads > 0, np.uint64(g_add_flat.data_ptr()) + np.uint64(4) * (np.cumsum(ads) - ads), np.uint64(0))
         if rigid:
             if g_means_all is not None:
@@ -311,7 +316,8 @@ class _CollectNodes(torch.autograd.Function):
         # per-node views of the flat buffers, in _NODE_KEYS order
         sizes = [d[0] for d in dims]
         sp = lambda t: t.split(sizes) if total else [t] * n_nodes
-        s_scales, s_quats, s_opac, s_dc = sp(g_scales), sp(g_quats), sp(g_opac), sp(g_dc)
+        s_scales, s_quats, s_opac = sp(g_scales), sp(g_quats), sp(g_opac)
+        s_dc = sp(g_dc) if colours else [None] * n_nodes
         s_rest, s_add = g_rest_flat.split(rest_sizes), g_add_flat.split(add_sizes)
         s_vm = sp(v_means_c) if v_means_c is not None else [None] * n_nodes
         s_gm = sp(g_means_all) if g_means_all is not None else [None] * n_nodes
@@ -322,7 +328,9 @@ class _CollectNodes(torch.autograd.Function):
                 framed_grads[i] = (gq, gt)
         grads = []
         for i, (n, Kr, opac_shape, has_add, T, trav, start) in enumerate(dims):
-            if T:
+            if not colours:
+                g_r = g_a = None
+            elif T:
                 g_r = s_rest[i].view(n, T, Kr, 3)
                 g_a = s_add[i].view(n, T, 3) if has_add else None
             else:

@@ -246,8 +246,9 @@ def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3):
     from mtgs_amd.densify import update_statistics_rows
     from mtgs_amd.nodes import collect_gaussians
     vm, K, c2w, t = cam
-    gs = collect_gaussians([dict(p, traversal_index=t) if "features_adapters" in p else
-                            (dict(p, frame_idx=frame_of(t)) if "instance_quats" in p else p) for p in P.values()], c2w, n, 3,
+    det = lambda p: {k: (v.detach() if k.startswith("features") else v) for k, v in p.items()}   # no colour gradient through the nodes
+    gs = collect_gaussians([dict(det(p), traversal_index=t) if "features_adapters" in p else
+                            (dict(det(p), frame_idx=frame_of(t)) if "instance_quats" in p else det(p)) for p in P.values()], c2w, n, 3,
                            raw_colors=True)
     leaves = {k: gs[k].detach().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
     cam_pos = c2w[..., :3, 3].reshape(3)
