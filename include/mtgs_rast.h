@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 9
+#define MTGS_RAST_ABI_VERSION 10
 
 enum {
     MTGS_OK = 0,
@@ -366,7 +366,8 @@ int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *mean
 /* Wire rows straight from the compositing backward's compact gradient rows (no dense tensor, no pack pass): the VJP of
  * the projection per VISIBLE Gaussian (vis_ids[n_vis], index order; C = 1) writes wire_rows[n_vis,16] =
  * {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, 0, Gaussian index (int bits)}.  grad_rows[n_vis,row_stride] as mtgs_blend_bwd_packed
- * leaves them (D <= 3 colour channels).  color_mode 1: colours were clamp(colors_pre + 0.5, 0, 1) (mtgs_front_fwd),
+ * leaves them (the first three of D <= 7 colour channels; further channels are folded into the rows by their own VJP,
+ * e.g. mtgs_normals_bwd_rows).  color_mode 1: colours were clamp(colors_pre + 0.5, 0, 1) (mtgs_front_fwd),
  * v_rgb is the gradient with respect to colors_pre[N,3].  v_viewmats[1,4,4] nullable, overwritten. */
 int mtgs_project_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
                           const float *viewmats, const float *Ks, int width, int height, float eps2d,
@@ -467,6 +468,12 @@ int mtgs_normals_fwd(int64_t N, const float *quats, const float *scales, const f
                      const float *rgbs, float *out, int64_t out_stride, void *stream);
 int mtgs_normals_bwd(int64_t N, const float *quats, const float *scales, const float *means, const float *c2w,
                      const float *v_normals, int64_t v_stride, float *g_quats, void *stream);
+/* The normal channels' gradient of the VISIBLE Gaussians folded into the quaternion gradient of their data-parallel wire
+ * rows (wire_rows[r, 16], Gaussian vis_ids[r]): v_normal = grad_rows[r, col .. col + 2] (the compositing backward's compact
+ * rows).  The camera-space normal depends on the sender's camera, so this happens before the rows are exchanged. */
+int mtgs_normals_bwd_rows(int64_t n_vis, const int32_t *vis_ids, const float *quats, const float *scales, const float *means,
+                          const float *c2w, const float *grad_rows, int64_t row_stride, int col, float *wire_rows,
+                          void *stream);
 
 /* ---- densification statistics of one node in one launch ------------------------------
  * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous

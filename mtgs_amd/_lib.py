@@ -80,6 +80,7 @@ _SIGNATURES = {
     "mtgs_node_bwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp],
     "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "mtgs_normals_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_deform_embed": [_i64, _vp, _f32, _f32, _vp, _i32, _i32, _i32, _vp, _i64, _vp],
     "mtgs_fourier_dc_fwd": [_i64, _i32, _vp, _vp, _vp, _vp],
@@ -117,7 +118,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 

@@ -49,6 +49,27 @@ __device__ __forceinline__ NormalGeom geometry(const F4 q, const F3 s, const F3 
     return g;
 }
 
+// v (cotangent of the camera-space normal) -> cotangent of the quaternion
+__device__ __forceinline__ F4 normal_vjp(const F4 q, const NormalGeom &g, const F3 v, const float *__restrict__ c2w) {
+    // back through the camera rotation (v_world = R v) and the flip
+    float vx = g.sign * ((c2w[0] * v.x + c2w[1] * v.y) + c2w[2] * v.z);
+    float vy = g.sign * ((c2w[4] * v.x + c2w[5] * v.y) + c2w[6] * v.z);
+    float vz = g.sign * ((c2w[8] * v.x + c2w[9] * v.y) + c2w[10] * v.z);
+    // F.normalize: d (col / |col|) = (v - n0 <n0, v>) / |col|
+    const float dot = (g.n0.x * vx + g.n0.y * vy) + g.n0.z * vz;
+    vx = (vx - g.n0.x * dot) * g.inv_len; vy = (vy - g.n0.y * dot) * g.inv_len; vz = (vz - g.n0.z * dot) * g.inv_len;
+    const float w = q.x, x = q.y, y = q.z, z = q.w;
+    if (g.k == 0)        // col = (1 - 2(yy + zz), 2(xy + wz), 2(xz - wy))
+        return F4{2.f * (z * vy - y * vz), 2.f * (y * vy + z * vz), (-4.f * y * vx + 2.f * x * vy) - 2.f * w * vz,
+                  (-4.f * z * vx + 2.f * w * vy) + 2.f * x * vz};
+    if (g.k == 1)        // col = (2(xy - wz), 1 - 2(xx + zz), 2(yz + wx))
+        return F4{2.f * (x * vz - z * vx), (2.f * y * vx - 4.f * x * vy) + 2.f * w * vz, 2.f * (x * vx + z * vz),
+                  (-2.f * w * vx - 4.f * z * vy) + 2.f * y * vz};
+    // col = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))
+    return F4{2.f * (y * vx - x * vy), (2.f * z * vx - 2.f * w * vy) - 4.f * x * vz, (2.f * w * vx + 2.f * z * vy) - 4.f * y * vz,
+              2.f * (x * vx + y * vy)};
+}
+
 __global__ __launch_bounds__(256) void normals_fwd_kernel(int64_t N, const float *__restrict__ quats,
                                                           const float *__restrict__ scales, const float *__restrict__ means,
                                                           const float *__restrict__ c2w, const float *__restrict__ rgbs,
@@ -82,27 +103,45 @@ __global__ __launch_bounds__(256) void normals_bwd_kernel(int64_t N, const float
     const F3 m = *reinterpret_cast<const F3 *>(means + i * 3);
     const NormalGeom g = geometry(q, s, m, c2w);
     const F3 v = *reinterpret_cast<const F3 *>(v_out + i * v_stride);
-    // back through the camera rotation (v_world = R v) and the flip
-    float vx = g.sign * ((c2w[0] * v.x + c2w[1] * v.y) + c2w[2] * v.z);
-    float vy = g.sign * ((c2w[4] * v.x + c2w[5] * v.y) + c2w[6] * v.z);
-    float vz = g.sign * ((c2w[8] * v.x + c2w[9] * v.y) + c2w[10] * v.z);
-    // F.normalize: d (col / |col|) = (v - n0 <n0, v>) / |col|
-    const float dot = (g.n0.x * vx + g.n0.y * vy) + g.n0.z * vz;
-    vx = (vx - g.n0.x * dot) * g.inv_len; vy = (vy - g.n0.y * dot) * g.inv_len; vz = (vz - g.n0.z * dot) * g.inv_len;
-    const float w = q.x, x = q.y, y = q.z, z = q.w;
-    F4 o;
-    if (g.k == 0)        // col = (1 - 2(yy + zz), 2(xy + wz), 2(xz - wy))
-        o = F4{2.f * (z * vy - y * vz), 2.f * (y * vy + z * vz), (-4.f * y * vx + 2.f * x * vy) - 2.f * w * vz,
-               (-4.f * z * vx + 2.f * w * vy) + 2.f * x * vz};
-    else if (g.k == 1)   // col = (2(xy - wz), 1 - 2(xx + zz), 2(yz + wx))
-        o = F4{2.f * (x * vz - z * vx), (2.f * y * vx - 4.f * x * vy) + 2.f * w * vz, 2.f * (x * vx + z * vz),
-               (-2.f * w * vx - 4.f * z * vy) + 2.f * y * vz};
-    else                 // col = (2(xz + wy), 2(yz - wx), 1 - 2(xx + yy))
-        o = F4{2.f * (y * vx - x * vy), (2.f * z * vx - 2.f * w * vy) - 4.f * x * vz, (2.f * w * vx + 2.f * z * vy) - 4.f * y * vz,
-               2.f * (x * vx + y * vy)};
+    const F4 o = normal_vjp(q, g, v, c2w);
     *reinterpret_cast<F4 *>(g_quats + i * 4) = o;
 }
+// The backward for the VISIBLE Gaussians of one frame, added into the wire rows of the data-parallel gradient exchange
+// (csrc/dp.hip, project_bwd.hip: row r = [v_mean 3 | v_quat 4 | ...] of Gaussian vis_ids[r]).  The normal channels are
+// a function of each rank's OWN camera, so their gradient cannot be summed over the ranks and pulled back afterwards:
+// the sender folds it into the quaternion gradient of its row before the row leaves.  v_normal = columns
+// col .. col + 2 of the compositing backward's compact gradient rows G[n_vis, row_stride].
+__global__ __launch_bounds__(256) void normals_bwd_rows_kernel(int64_t n_vis, const int32_t *__restrict__ vis_ids,
+                                                               const float *__restrict__ quats, const float *__restrict__ scales,
+                                                               const float *__restrict__ means, const float *__restrict__ c2w,
+                                                               const float *__restrict__ G, int64_t row_stride, int col,
+                                                               float *__restrict__ wire) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_vis) return;
+    const int64_t i = vis_ids[r];
+    const F4 q = *reinterpret_cast<const F4 *>(quats + i * 4);
+    const F3 s = *reinterpret_cast<const F3 *>(scales + i * 3);
+    const F3 m = *reinterpret_cast<const F3 *>(means + i * 3);
+    const NormalGeom g = geometry(q, s, m, c2w);
+    const F3 v = F3{G[r * row_stride + col], G[r * row_stride + col + 1], G[r * row_stride + col + 2]};
+    const F4 o = normal_vjp(q, g, v, c2w);
+    float *w = wire + r * 16 + 3;
+    w[0] += o.x; w[1] += o.y; w[2] += o.z; w[3] += o.w;
+}
 }  // namespace
+
+extern "C" int mtgs_normals_bwd_rows(int64_t n_vis, const int32_t *vis_ids, const float *quats, const float *scales,
+                                     const float *means, const float *c2w, const float *grad_rows, int64_t row_stride, int col,
+                                     float *wire_rows, void *stream) {
+    MTGS_REQUIRE(n_vis >= 0 && col >= 0 && row_stride >= col + 3, MTGS_EINVAL, "mtgs_normals_bwd_rows: bad sizes");
+    if (n_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(vis_ids && quats && scales && means && c2w && grad_rows && wire_rows, MTGS_EINVAL, "mtgs_normals_bwd_rows: null pointer");
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(quats) & 15) == 0, MTGS_EINVAL, "mtgs_normals_bwd_rows: quats must be 16-byte aligned");
+    normals_bwd_rows_kernel<<<(unsigned)ceil_div64(n_vis, 256), 256, 0, (hipStream_t)stream>>>(n_vis, vis_ids, quats, scales, means,
+                                                                                              c2w, grad_rows, row_stride, col, wire_rows);
+    MTGS_CHECK_LAUNCH("mtgs_normals_bwd_rows");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_normals_fwd(int64_t N, const float *quats, const float *scales, const float *means, const float *c2w,
                                 const float *rgbs, float *out, int64_t out_stride, void *stream) {

@@ -565,9 +565,11 @@ extern "C" int mtgs_project_bwd_rows(int64_t N, const float *means, const float 
                                      const float *colors_pre, int color_mode, const int32_t *vis_ids, int64_t n_vis,
                                      float *wire_rows, float *v_viewmats, void *stream) {
     MTGS_REQUIRE(N >= 0 && n_vis >= 0 && n_vis <= N && width > 0 && height > 0, MTGS_EINVAL, "mtgs_project_bwd_rows: bad sizes");
-    MTGS_REQUIRE(D >= 0 && D <= 3 && row_stride >= 8 + D + (with_depth ? 1 : 0) && (row_stride % 4) == 0, MTGS_EINVAL,
-                 "mtgs_project_bwd_rows: D=%d (0..3 colour channels) row_stride=%lld", D, (long long)row_stride);
-    MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D == 3 && colors_pre), MTGS_EINVAL, "mtgs_project_bwd_rows: color_mode");
+    // (colour channels beyond the third -- camera-space normals ... -- are not this call's: their gradient is folded into
+    //  the rows by their own VJP, e.g. mtgs_normals_bwd_rows)
+    MTGS_REQUIRE(D >= 0 && D <= 7 && row_stride >= 8 + D + (with_depth ? 1 : 0) && (row_stride % 4) == 0, MTGS_EINVAL,
+                 "mtgs_project_bwd_rows: D=%d (0..7 colour channels) row_stride=%lld", D, (long long)row_stride);
+    MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D >= 3 && colors_pre), MTGS_EINVAL, "mtgs_project_bwd_rows: color_mode");
     hipStream_t st = (hipStream_t)stream;
     if (v_viewmats) {
         if (int rc = mtgs_zero_async(v_viewmats, sizeof(float) * 16, st)) return rc;

@@ -190,6 +190,9 @@ class SparseGradExchange:
         self._pending = None
         self._events = {}
         self.grad_rows = self.vis_ids = None
+        # colour channels beyond the SH output (camera-space normals ...) are functions of THIS rank's camera: the caller
+        # sets rows_hook(grad_rows, row_stride, vis_ids, n_vis) to fold their gradient into the wire rows before they leave
+        self.rows_hook = None
 
     # ---- integrated form -----------------------------------------------------------------------------------------
     def rasterization(self, means, quats, scales, opacities, sh_out, viewmats, Ks, width, height, cam_pos, near_plane=0.01,
@@ -203,7 +206,7 @@ class SparseGradExchange:
         (multi_color_gaussian_splatting.py:77-101), and finish() then returns the coefficient gradient as [N, T, K, 3]
         with every sender's contribution in ITS traversal's slice."""
         from .wrapper import fused_rasterization
-        assert viewmats.shape[0] == 1 and sh_out.shape == (self.N, 3) and means.shape == (self.N, 3)
+        assert viewmats.shape[0] == 1 and sh_out.dim() == 2 and sh_out.shape[0] == self.N and sh_out.shape[1] >= 3 and means.shape == (self.N, 3)
         assert render_mode in ("RGB", "RGB+D", "RGB+ED") and rasterize_mode in ("classic", "antialiased")
         assert 0 <= int(traversal) < self.T, (traversal, self.T)
         self.meta[1:4].copy_(cam_pos.reshape(3).to(torch.float32).contiguous().view(torch.int32))

@@ -548,8 +548,10 @@ class _FusedRasterization(torch.autograd.Function):
         alphas = torch.empty((Cn, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((Cn, height, width), dtype=torch.int32, device=dev)
         packed = total > 0 and 1 <= DT <= RECORD_CHANNELS and _bin3_ok(Cn, tw, th, 0)
-        if dp is not None and not (packed and Cn == 1 and DC == 3 and bg is None):
-            raise NotImplementedError("data-parallel rasterization: one camera, 3 colour channels (SH output), no backgrounds")
+        if dp is not None and not (packed and Cn == 1 and DC >= 3 and bg is None and (DC == 3 or dp.rows_hook is not None)):
+            raise NotImplementedError("data-parallel rasterization: one camera, the SH output in the first 3 colour channels (further "
+                                      "channels need SparseGradExchange.rows_hook to fold their gradient into the wire rows), no "
+                                      "backgrounds")
         if not packed:
             # ---- gather-based kernels (csrc/project.hip, bin.hip, blend.hip with dense attribute arrays)
             call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
@@ -704,6 +706,8 @@ class _FusedRasterization(torch.autograd.Function):
             call("mtgs_project_bwd_rows", N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height, eps2d,
                  ptr(conics), ptr(comps), ptr(opacities), ptr(G), RS, DC, int(with_depth), ptr(col), 1, ptr(vis_ids), n_vis,
                  ptr(ctx.dp.rows), ptr(v_viewmats), st)
+            if ctx.dp.rows_hook is not None:    # camera-dependent extra channels (normals): their VJP goes into the rows here
+                ctx.dp.rows_hook(G, RS, vis_ids, n_vis)
             ctx.dp.after_backward(n_vis, G, vis_ids)
             return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 11
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):

@@ -234,15 +234,18 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     return loss.detach()
 
 
-def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3):
+def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=None):
     """The fused iteration of one rank under view-parallel data parallelism with the SPARSE gradient exchange
     (mtgs_amd.dist.SparseGradExchange with per-traversal colour routing) instead of a dense all-reduce of every parameter
     gradient: the node kernels hand out the activated geometry and the RAW SH colours of every Gaussian; the exchange
     renders, its backward leaves 64-byte wire rows, finish() returns the SUMS over all ranks of the gradients with respect
     to the activated geometry and to the SH coefficients (every sender's colour factor in its own traversal's slice); the
     geometry sums go back through the node activations (one launch), the coefficient sums ARE the gradients of
-    features_dc / features_adapters / features_rest.  Statistics from the compact rows.  RGB + L1 + SSIM (the exchange does
-    not carry the extra channels of the shipped option set)."""
+    features_dc / features_adapters / features_rest.  Statistics from the compact rows.
+    shipped: the option set of config/MTGS.py.  Its three normal channels are a function of THIS rank's camera, so their
+    gradient is folded into the quaternion gradient of the wire rows on the sender (mtgs_normals_bwd_rows, via the
+    exchange's rows_hook) before the rows are exchanged; the exposure parameters are replicated and all-reduced densely."""
+    from mtgs_amd._lib import call, ptr, stream_of
     from mtgs_amd.densify import update_statistics_rows
     from mtgs_amd.nodes import collect_gaussians
     vm, K, c2w, t = cam
@@ -252,10 +255,31 @@ def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3):
                            raw_colors=True)
     leaves = {k: gs[k].detach().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
     cam_pos = c2w[..., :3, 3].reshape(3)
-    render, alpha, info = ex.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], gs["rgbs"].detach(),
+    colors = gs["rgbs"].detach()
+    ex.rows_hook = None
+    if shipped:
+        with torch.no_grad():
+            colors = camera_space_normals(leaves["quats"], leaves["scales"], leaves["means"], c2w, rgbs=colors)     # [N, 6]
+        c2w_f = c2w.reshape(-1)[:12].to(torch.float32).contiguous()
+
+        def hook(G, row_stride, vis_ids, n_vis):      # v_normals = colour channels 3..5 of the compact rows (column 8 + 3)
+            call("mtgs_normals_bwd_rows", n_vis, ptr(vis_ids), ptr(leaves["quats"]), ptr(leaves["scales"]), ptr(leaves["means"]),
+                 ptr(c2w_f), ptr(G), row_stride, 8 + 3, ptr(ex.rows), stream_of(G))
+        ex.rows_hook = hook
+    render, alpha, info = ex.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], colors,
                                            vm, K, W, H, cam_pos, traversal=t)
-    rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)
-    loss = 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
+    if shipped:
+        E, bg = shipped["exposure"][t], shipped["bg"]
+        rgb, app, depth, normal = output_head(render, alpha, bg, E, depth=True, normal_channel=3)
+        gt_d, gt_n = shipped["gt_depth"][t], shipped["gt_normal"][t]
+        dmask = (gt_d > 0.1) & (gt_d < 80) & mask
+        loss_n = masked_l1(gt_n, normal, mask) + tv_loss(normal)
+        loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
+        loss = 0.8 * masked_l1(gt, app, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask)) + \
+            0.5 * masked_l1(1 / (gt_d + 1e-5), 1 / (depth + 1e-5), dmask) + 0.1 * loss_n + 0.1 * depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask)
+    else:
+        rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)
+        loss = 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
     loss.backward()
     with torch.no_grad():
         update_statistics_rows([tuple(s) for s in stats], info["radii"], ex.grad_rows, ex.vis_ids, W, H, n_vis=ex.n_vis)
@@ -344,7 +368,6 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     curve, sizes = [], []
     group = max(world, accumulate)
     sparse = sparse and world > 1
-    assert not (sparse and shipped), "the sparse exchange carries RGB only"
     mk_ex = lambda: mdist.SparseGradExchange(sum(p["means"].shape[0] for p in P.values()), 16, next(iter(P.values()))["means"].device,
                                              traversals=T) if sparse else None
     ex = mk_ex()
@@ -354,7 +377,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
         for a in range(accumulate):
             c = (i * group + (rank if world > 1 else a)) % T
             if sparse:
-                losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex))
+                losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex, shipped=shipped))
             else:
                 losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
         loss = torch.stack(losses).sum()
@@ -362,6 +385,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
         if world > 1:
             if not sparse:
                 mdist.all_reduce_grads(params)
+            elif shipped:                       # the replicated non-Gaussian parameters (exposure): a few floats
+                mdist.all_reduce_grads([shipped["exposure"]])
             torch.distributed.all_reduce(loss)
         curve.append(float(loss) / group)
         opt.step()
@@ -405,7 +430,7 @@ def main():
     ap.add_argument("--dp", action="store_true", help="with --steps: view-parallel data parallelism under torch.distributed.run "
                     "(one camera per rank and step, dense gradient all-reduce, rank-identical refinement)")
     ap.add_argument("--dp-exchange", choices=["dense", "sparse"], default="dense", help="with --dp: dense all-reduce of every "
-                    "parameter gradient, or the sparse factored exchange of mtgs_amd.dist (RGB option set only)")
+                    "parameter gradient, or the sparse factored exchange of mtgs_amd.dist")
     ap.add_argument("--accumulate", type=int, default=1, help="with --steps: cameras per step in ONE process (gradient accumulation)")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
@@ -439,7 +464,8 @@ def main():
                                         packed=False, render_mode="RGB+ED", rasterize_mode="antialiased")
                 _, _, d, nrm = output_head(r, a, bg, None, depth=True, normal_channel=3)
                 gt_depth.append(d); gt_normal.append(torch.nan_to_num(nrm, nan=0.5))
-        shipped = {"exposure": (torch.eye(3, 4, device=dev)[None].repeat(T, 1, 1) + 0.02 * torch.randn(T, 3, 4, device=dev)).requires_grad_(True),
+        ge = torch.Generator().manual_seed(11)      # (seeded on the host: every rank of a data-parallel run starts from the same model)
+        shipped = {"exposure": (torch.eye(3, 4, device=dev)[None].repeat(T, 1, 1) + 0.02 * torch.randn(T, 3, 4, generator=ge).to(dev)).requires_grad_(True),
                    "bg": bg, "gt_depth": gt_depth, "gt_normal": gt_normal}
     g = torch.Generator().manual_seed(5)
     P = {name: {k: (v + (0.3 * torch.randn(v.shape, generator=g)).to(dev) * (k in ("features_dc", "features_rest", "features_adapters"))

@@ -233,3 +233,33 @@ def test_mtgs_like_training_data_parallel_keeps_ranks_in_lockstep():
     assert "2 ranks: N = " in sp.stdout and sizes(sp.stdout) == sizes(one.stdout), (sizes(sp.stdout), sizes(one.stdout))
     c = curve(sp.stdout)
     assert len(c) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(c, b)), (c, b)
+
+
+def test_mtgs_like_training_shipped_options_under_the_sparse_exchange():
+    """The option set of config/MTGS.py (camera-space normals as three more blended channels, exposure model, depth / normal
+    losses) data-parallel through the SPARSE exchange: the normal channels depend on each rank's own camera, so their
+    gradient is folded into the wire rows on the sender (mtgs_normals_bwd_rows); two ranks, four traversals, one refinement --
+    same N and the same loss curve as the single-process run that accumulates the two cameras of every step."""
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    common = ["--n-background", "50000", "--n-road", "15000", "--traversals", "4", "--width", "320", "--height", "200", "--steps",
+              "30", "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), str(root / "scripts" / "mtgs_like_train.py"), "--dp",
+                         "--dp-exchange", "sparse"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert sp.returncode == 0, sp.stdout[-1500:] + sp.stderr[-2500:]
+    one = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--accumulate", "2"] + common,
+                         capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-2500:]
+    sizes = lambda out: re.findall(r"refine (\d+) -> (\d+) Gaussians", out)
+    assert "2 ranks: N = " in sp.stdout and sizes(sp.stdout) == sizes(one.stdout) and len(sizes(sp.stdout)) == 1
+    curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
+    a, b = curve(sp.stdout), curve(one.stdout)
+    assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
