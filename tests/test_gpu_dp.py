@@ -243,4 +243,5 @@ def test_sparse_exchange_routes_colour_gradients_to_the_senders_traversal(tmp_pa
     mp.spawn(_worker_traversals, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         for (err, scale), name in zip(np.load(tmp_path / f"t{r}.npy"), ("means", "quats", "scales", "opacities", "coeffs[N,T,K,3]")):
-            assert scale > 0 and err <= 1e-5 * scale + 1e-7, f"rank {r} {name}: {err} vs {scale}"
+            # (fp32 atomics in another order on the two paths: a few 1e-6 of the largest gradient)
+            assert scale > 0 and err <= 3e-5 * scale + 1e-7, f"rank {r} {name}: {err} vs {scale}"
