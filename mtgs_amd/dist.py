@@ -209,6 +209,7 @@ class SparseGradExchange:
         assert viewmats.shape[0] == 1 and sh_out.dim() == 2 and sh_out.shape[0] == self.N and sh_out.shape[1] >= 3 and means.shape == (self.N, 3)
         assert render_mode in ("RGB", "RGB+D", "RGB+ED") and rasterize_mode in ("classic", "antialiased")
         assert 0 <= int(traversal) < self.T, (traversal, self.T)
+        self.abandon()      # a previous frame that never reached finish() (forward-only / eval call, an exception in between)
         self.meta[1:4].copy_(cam_pos.reshape(3).to(torch.float32).contiguous().view(torch.int32))
         self.meta[self.meta_len - 2:self.meta_len - 1].fill_(int(traversal))
         self._pending = {"stage": "forward"}
@@ -217,6 +218,14 @@ class SparseGradExchange:
             near_plane, far_plane, radius_clip, rasterize_mode == "antialiased", render_mode != "RGB",
             render_mode == "RGB+ED", absgrad, dp=self)
         return render, alphas, m
+
+    def abandon(self):
+        """Drops a frame whose exchange was started (rasterization()) but never finished: waits -- on the side stream only --
+        until the all-gather of its meta record no longer reads `self.meta`, which the next frame rewrites.  Forward-only
+        callers (evaluation) call this instead of backward() + finish()."""
+        P, self._pending = self._pending, None
+        if P is not None and P.get("done") is not None:
+            torch.cuda.current_stream().wait_event(P["done"])
 
     def front_pointers(self):
         """(visibility words, row prefix per word, row count) inside this rank's meta record: written by mtgs_front_fwd."""

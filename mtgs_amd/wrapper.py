@@ -577,7 +577,11 @@ class _FusedRasterization(torch.autograd.Function):
 
             graph_caps = _graph.caps
 
-            def front(cap_vis):
+            def front(cap_vis, repeat=False):
+                # repeat=True: the capacity-overflow repeat of a frame.  The visibility map / row count of the exchange do not
+                # depend on cap_vis and are already on their way: they are neither rewritten nor gathered a second time
+                # (a second meta all-gather on ONE rank would desynchronise the ranks' collectives).
+                dpf = dp if not repeat else None
                 b = {"recs": torch.empty((cap_vis, 16), dtype=torch.float32, device=dev),
                      "vis_ids": torch.empty(cap_vis, dtype=torch.int32, device=dev),
                      "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis}
@@ -586,12 +590,12 @@ class _FusedRasterization(torch.autograd.Function):
                      eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
-                     ptr(vis_rank), cap_vis, *(dp.front_pointers() if dp is not None else (None, None, None)),
+                     ptr(vis_rank), cap_vis, *(dpf.front_pointers() if dpf is not None else (None, None, None)),
                      1 if dp is not None else 0, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 b["mailbox"], b["tag"] = mailbox, tag
-                if dp is not None:
-                    dp.after_front()       # the visibility maps travel while this frame is composited
+                if dpf is not None:
+                    dpf.after_front()      # the visibility maps travel while this frame is composited
                 return b
 
             def rest(b, cap_M):
@@ -629,7 +633,7 @@ class _FusedRasterization(torch.autograd.Function):
                     if not _bin3_ok(Cn, tw, th, M):
                         raise NotImplementedError(f"rasterization: {M} tile intersections in one call (limit 2^30)")
                     if n_vis > b["cap_vis"]:
-                        b = front(n_vis)
+                        b = front(n_vis, repeat=True)
                     out = rest(b, M)
             else:
                 b = front(total)

@@ -89,6 +89,35 @@ def _worker(rank, world, port, out_dir):
         ph = ex2.phases_ms()
         assert set(ph) == {"meta", "wire", "reduce"} and all(v >= 0 for v in ph.values())
         vm2.grad = None
+    # capacity overflow on ONE rank only (its speculative capacities were too small: the frame is repeated with exact sizes);
+    # the repeat must not issue a second meta all-gather, or the ranks' collectives pair up wrongly from here on -- two
+    # frames in a row, the second one checks that the exchange is still in step
+    from mtgs_amd import wrapper
+    ex3 = mdist.SparseGradExchange(N, K, dev, chunks=2)
+    for frame in range(2):
+        old = (wrapper._force_caps, wrapper.speculative_sizing)
+        if rank == 0:
+            wrapper._force_caps, wrapper.speculative_sizing = (n_vis // 2, 1 << 16), True
+        try:
+            r3, a3, info3 = ex3.rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], sh3, vm2, Kmat.to(dev), W, H,
+                                              cam_pos)
+        finally:
+            wrapper._force_caps, wrapper.speculative_sizing = old
+        assert n_vis > 500 and torch.equal(r3, render) and torch.equal(info3["flatten_ids"], info["flatten_ids"])
+        torch.autograd.backward([r3, a3], [Gc, Ga])
+        o4 = ex3.finish(P2["means"], 3)
+        for k, t in zip(("means", "quats", "scales", "opacities", "coeffs"), o4):
+            scale = float(dense[k].abs().max())
+            err = float((dense[k] - t).abs().max())
+            assert err <= 1e-5 * scale + 1e-7, f"overflow repeat on rank 0, frame {frame}, {k}: {err} vs {scale}"
+        vm2.grad = None
+    # a forward-only frame (evaluation) followed by a training frame: abandon() / the next rasterization() drop the first
+    with torch.no_grad():
+        ex3.rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], sh3, vm2, Kmat.to(dev), W, H, cam_pos)
+    r3, a3, _ = ex3.rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], sh3, vm2, Kmat.to(dev), W, H, cam_pos)
+    torch.autograd.backward([r3, a3], [Gc, Ga])
+    o5 = ex3.finish(P2["means"], 3)
+    assert float((o5[0] - dense["means"]).abs().max()) <= 1e-5 * float(dense["means"].abs().max()) + 1e-7
     np.save(Path(out_dir) / f"r{rank}.npy", np.array([[e, s] for e, s in res.values()] + [[n_vis, tensor_form_bytes]]))
     dist.barrier()
     dist.destroy_process_group()
