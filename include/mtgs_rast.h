@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 10
+#define MTGS_RAST_ABI_VERSION 11
 
 enum {
     MTGS_OK = 0,
@@ -583,6 +583,38 @@ int mtgs_l1_fwd(int width, int height, int channels, const float *gt, const floa
                 float *partials, float *out, void *stream);
 int mtgs_l1_bwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
                 const float *v_out, const float *fwd_out, float *v_pred, void *stream);
+
+/* ---- SURVEY.md section 8f, rank 2 (second half): the optimizer step of every Gaussian parameter group in ONE launch ----
+ * Reference: one torch.optim.Adam per parameter group with one tensor each (mtgs/scene_model/custom_trainer.py:115-136;
+ * groups, learning rates and eps = 1e-15 in mtgs/config/MTGS.py:121-181); the densification moves the moments with their
+ * rows (vanilla_gaussian_splatting.py:392-446 -> mtgs_refine_rows).  Arithmetic = torch.optim.Adam (amsgrad = False,
+ * maximize = False) in fp32:  g = grad_scale * g + weight_decay * p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ * p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)  with step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) computed
+ * by the caller in double for the step t being taken and passed as `hyper[n_groups][2]` = {step_size, bc2_sqrt} per group in
+ * DEVICE memory -- apart from the table, so that a step captured in a HIP graph is advanced by one small copy per replay
+ * (learning-rate schedules and the bias corrections change every step; the table does not).
+ * A table of descriptors in DEVICE memory (8-byte aligned), one per tensor; workgroup b works on group i with
+ * first_block[i] <= b < first_block[i + 1], first_block = running sum of ceil(n / mtgs_adam_block_elems()).
+ * Gradient source of a group: `g` (dense, n floats), or `rows` + `row_of` -- element e belongs to item i = e / width
+ * (a Gaussian: width floats of this tensor), its gradient is rows[row_of[i] * row_stride + row_col + e % width], or 0 when
+ * row_of[i] < 0 (a Gaussian the frame did not see: exact zero-gradient update, no dense gradient tensor) -- or neither
+ * (all-zero gradient).  vec_ok = 1: p, m, v (and g) are 16-byte aligned. */
+typedef struct mtgs_adam_group {
+    float *p, *m, *v;           /* parameter, exp_avg, exp_avg_sq: n floats each, updated in place */
+    const float *g;             /* dense gradient or NULL */
+    const float *rows;          /* compact gradient rows or NULL */
+    const int32_t *row_of;      /* [n / width] row of every item, < 0: none */
+    int64_t n, first_block;
+    int64_t row_stride;         /* floats between rows */
+    int32_t width, row_col;
+    int32_t vec_ok, reserved;
+    float beta1, beta2, eps, weight_decay, grad_scale, reserved_f;
+} mtgs_adam_group;
+int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check their layout against it */
+int mtgs_adam_block_elems(void);    /* elements one workgroup updates */
+/* nontemporal != 0: moments (and a dense gradient) are streamed past the caches (they are touched once per step). */
+int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, const float *hyper, int64_t total_blocks, int nontemporal,
+                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,164 @@
+// adam.hip -- the optimizer step of every Gaussian parameter group in ONE launch.
+//
+// Reference: one torch.optim.Adam per parameter group, each holding one tensor
+// (/root/reference/mtgs/scene_model/custom_trainer.py:115-136, groups / learning rates / eps = 1e-15 in
+// mtgs/config/MTGS.py:121-181); the densification moves the moments with their rows (vanilla_gaussian_splatting.py:392-446,
+// here csrc/refine.hip).  torch runs that as ~10 multi-tensor passes per group set; this is one streaming pass:
+// p, m, v are read once and written once (24 B per element) plus the gradient (4 B) when it is dense.
+//
+// Two gradient sources per group:
+//   dense  g[n]                                -- what autograd leaves in param.grad;
+//   rows   rows[row_of[i] * row_stride + col + c], i = e / width, c = e % width, row_of[i] < 0 -> 0
+//          -- compact gradient rows of the VISIBLE Gaussians (the rasterizer's backward works per visible Gaussian; a frame
+//          sees ~15 % of a road block).  Culled Gaussians get the exact zero-gradient update (their moments decay, the
+//          parameter keeps moving along exp_avg) without a dense gradient tensor ever being written or read.
+//
+// Arithmetic = torch.optim.Adam (amsgrad = False, maximize = False), fp32, in torch's operation order:
+//   g += weight_decay * p;  m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),   bc1 = 1 - beta1^t, bc2 = 1 - beta2^t computed by the HOST in double
+// and handed over as hyper[group] = {lr / bc1, sqrt(bc2)} in device memory: the only per-step state, so a step captured
+// in a HIP graph is advanced by one 8-byte-per-group copy in front of the replay.
+// HBM-bound: 28 B per element dense, 24 B + the visible rows otherwise.
+#include "common.hpp"
+
+#define ADAM_BLOCK 256
+#define ADAM_VEC 4
+#define ADAM_UNROLL 4
+#define ADAM_ELEMS (ADAM_BLOCK * ADAM_VEC * ADAM_UNROLL)   // elements per workgroup
+
+namespace {
+
+struct Hyper {
+    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, wd, gscale;
+};
+
+__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const Hyper &h) {
+    g = g * h.gscale;
+    if (h.wd != 0.f) g = fmaf(h.wd, p, g);
+    m = m + (g - m) * h.one_minus_b1;
+    v = v * h.b2 + h.one_minus_b2 * g * g;
+    const float denom = __fsqrt_rn(v) / h.bc2_sqrt + h.eps;
+    p = p - h.step_size * (m / denom);
+}
+
+// Workgroup b belongs to group i with table[i].first_block <= b < table[i + 1].first_block (wave-uniform: scalar loads).
+__device__ __forceinline__ int find_group(const mtgs_adam_group *table, int n, int64_t b) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float *p) {
+    if (NT) {
+        const f4v r = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));   // global_load_dwordx4 ... nt
+        return make_float4(r.x, r.y, r.z, r.w);
+    }
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float *p, float4 r) {
+    if (NT) {
+        f4v t = {r.x, r.y, r.z, r.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
+        return;
+    }
+    *reinterpret_cast<float4 *>(p) = r;
+}
+
+// gradient of element e of a rows-source group (i = e / width tracked incrementally by the caller)
+__device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, int c) {
+    const int32_t r = d.row_of[i];
+    return r < 0 ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c];
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group *__restrict__ table,
+                                                          const float *__restrict__ hyper, int n_groups) {
+    const int gi = find_group(table, n_groups, (int64_t)blockIdx.x);
+    const mtgs_adam_group d = table[gi];
+    Hyper h;
+    h.one_minus_b1 = 1.f - d.beta1; h.b2 = d.beta2; h.one_minus_b2 = 1.f - d.beta2;
+    h.step_size = hyper[2 * gi]; h.bc2_sqrt = hyper[2 * gi + 1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
+    const int64_t base = ((int64_t)blockIdx.x - d.first_block) * ADAM_ELEMS;
+    float *__restrict__ P = d.p, *__restrict__ M = d.m, *__restrict__ V = d.v;
+    const bool dense = d.g != nullptr;
+    const bool rows = d.rows != nullptr;
+    if (d.vec_ok && base + ADAM_ELEMS <= d.n) {
+        // full chunk, 16-byte accesses: UNROLL x 3 (4) loads per lane in flight before the first use
+        float4 p[ADAM_UNROLL], m[ADAM_UNROLL], v[ADAM_UNROLL], g[ADAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ADAM_UNROLL; ++u) {
+            const int64_t e = base + ((int64_t)u * ADAM_BLOCK + threadIdx.x) * ADAM_VEC;
+            p[u] = ld4<false>(P + e);
+            m[u] = ld4<NT>(M + e);
+            v[u] = ld4<NT>(V + e);
+            if (dense) g[u] = ld4<NT>(d.g + e);
+        }
+        if (!dense) {
+#pragma unroll
+            for (int u = 0; u < ADAM_UNROLL; ++u) {
+                g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rows) {
+                    const int64_t e = base + ((int64_t)u * ADAM_BLOCK + threadIdx.x) * ADAM_VEC;
+                    int64_t i = e / d.width;
+                    int c = (int)(e - i * d.width);
+                    float t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        t[k] = row_grad(d, i, c);
+                        if (++c == d.width) { c = 0; ++i; }
+                    }
+                    g[u] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ADAM_UNROLL; ++u) {
+            const int64_t e = base + ((int64_t)u * ADAM_BLOCK + threadIdx.x) * ADAM_VEC;
+            adam_update(p[u].x, m[u].x, v[u].x, g[u].x, h);
+            adam_update(p[u].y, m[u].y, v[u].y, g[u].y, h);
+            adam_update(p[u].z, m[u].z, v[u].z, g[u].z, h);
+            adam_update(p[u].w, m[u].w, v[u].w, g[u].w, h);
+            st4<false>(P + e, p[u]);
+            st4<NT>(M + e, m[u]);
+            st4<NT>(V + e, v[u]);
+        }
+        return;
+    }
+    // ragged tail of a group, or a group whose tensors are not 16-byte aligned: one element per lane and trip
+    const int64_t end = base + ADAM_ELEMS < d.n ? base + ADAM_ELEMS : d.n;
+    for (int64_t e = base + threadIdx.x; e < end; e += ADAM_BLOCK) {
+        float g = 0.f;
+        if (dense) g = d.g[e];
+        else if (rows) { const int64_t i = e / d.width; g = row_grad(d, i, (int)(e - i * d.width)); }
+        float p = P[e], m = M[e], v = V[e];
+        adam_update(p, m, v, g, h);
+        P[e] = p; M[e] = m; V[e] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int mtgs_adam_group_bytes(void) { return (int)sizeof(mtgs_adam_group); }
+extern "C" int mtgs_adam_block_elems(void) { return ADAM_ELEMS; }
+
+extern "C" int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, const float *hyper, int64_t total_blocks,
+                              int nontemporal, void *stream) {
+    MTGS_REQUIRE(n_groups >= 0 && total_blocks >= 0, MTGS_EINVAL, "mtgs_adam_step: negative size");
+    if (n_groups == 0 || total_blocks == 0) return MTGS_OK;
+    MTGS_REQUIRE(table != nullptr && hyper != nullptr, MTGS_EINVAL, "mtgs_adam_step: null table");
+    MTGS_REQUIRE(((uintptr_t)table & 7) == 0, MTGS_EINVAL, "mtgs_adam_step: table must be 8-byte aligned");
+    MTGS_REQUIRE(total_blocks < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_adam_step: more than 2^31 workgroups");
+    hipStream_t st = (hipStream_t)stream;
+    if (nontemporal)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)total_blocks), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)total_blocks), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
+    MTGS_CHECK_LAUNCH("mtgs_adam_step");
+    return MTGS_OK;
+}

@@ -1,0 +1,204 @@
+"""Fused Adam for the Gaussian parameter groups: ONE launch per step over every tensor (csrc/adam.hip).
+
+Reference: nerfstudio builds one `torch.optim.Adam` per parameter group, each with one tensor
+(/root/reference/mtgs/scene_model/custom_trainer.py:115-136; groups, learning rates and eps = 1e-15 in
+/root/reference/mtgs/config/MTGS.py:121-181), and the densification edits `optimizer.state[param]` by hand
+(vanilla_gaussian_splatting.py:392-446).  `FusedAdam` IS a `torch.optim.Optimizer` with torch.optim.Adam's state layout
+(`state[p] = {"step", "exp_avg", "exp_avg_sq"}`, `param_groups[i] = {"params", "lr", "betas", "eps", "weight_decay"}`), so
+schedulers, `state_dict()` / `load_state_dict()` (interchangeable with torch.optim.Adam's) and that kind of state surgery
+keep working; only `step()` differs: every tensor of every group is updated by one kernel that reads p, m, v once and
+writes them once (torch's foreach path makes ~10 passes per tensor list).
+
+Two gradient sources per parameter:
+  * `p.grad` (dense), as usual;
+  * `set_row_gradient(p, rows, row_of, col)`: compact gradient rows of the VISIBLE Gaussians plus a map Gaussian -> row
+    (< 0: not visible).  Gaussians without a row get the exact zero-gradient Adam update -- the moments decay, the
+    parameter keeps moving along exp_avg -- without a dense gradient tensor ever being written or read.
+
+HIP graphs: the per-step scalars (lr / (1 - beta1^t), sqrt(1 - beta2^t)) live in a small device array that `advance()`
+refreshes with one copy; `step()` = `advance()` + the launch.  Capture `step()` once, then per replay call `advance()` and
+replay (the copy is enqueued on the stream in front of the graph launch).
+No CPU / PyTorch fallback: parameters must be float32 HIP tensors."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import call, load, ptr, stream_of
+
+_GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"),
+                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
+                   ("vec_ok", "<i4"), ("reserved", "<i4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"),
+                   ("weight_decay", "<f4"), ("grad_scale", "<f4"), ("reserved_f", "<f4")], align=True)
+_checked = False
+
+
+def _check_layout():
+    global _checked
+    if not _checked:
+        want = load().mtgs_adam_group_bytes()
+        if want != _GROUP.itemsize:
+            raise RuntimeError(f"mtgs_adam_group is {want} bytes in libmtgs_rast.so, {_GROUP.itemsize} in mtgs_amd.optim")
+        _checked = True
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False,
+                 nontemporal=True):
+        if amsgrad or maximize:
+            raise NotImplementedError("FusedAdam: amsgrad / maximize (MTGS's AdamOptimizerConfig uses neither)")
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0.0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.nontemporal = bool(nontemporal)
+        self.grad_scale = 1.0          # every gradient is multiplied by this inside the kernel (1 / world for a DDP-style mean)
+        self._rows = {}                # id(param) -> (rows, row_of, col, stride)
+        self._table_key = None
+        self._table_dev = self._hyper_dev = None
+        self._active = []
+        self._blocks = 0
+
+    # ---- gradient source 2 -------------------------------------------------------------------------------------------
+    def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0) -> None:
+        """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
+        Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
+        int32 [N].  `param.grad` is ignored for this parameter.  Cleared by step() / zero_grad()."""
+        width = param.numel() // max(param.shape[0], 1) if param.dim() else 1
+        if rows.dtype != torch.float32 or row_of.dtype != torch.int32 or row_of.numel() != param.shape[0]:
+            raise ValueError("set_row_gradient: rows float32 [R, stride], row_of int32 [N]")
+        if rows.dim() != 2 or rows.stride(1) != 1 or col < 0 or col + width > rows.shape[1] or not row_of.is_contiguous():
+            raise ValueError("set_row_gradient: row layout")
+        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width))
+
+    def zero_grad(self, set_to_none: bool = True):
+        self._rows.clear()
+        return super().zero_grad(set_to_none=set_to_none)
+
+    # ---- the step ----------------------------------------------------------------------------------------------------
+    def _collect(self):
+        """The tensors this step updates (torch.optim.Adam: those with a gradient), with lazily created state."""
+        act = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                src = self._rows.get(id(p))
+                if p.grad is None and src is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("FusedAdam: float32 HIP parameters only (no CPU / PyTorch fallback)")
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                g = None
+                if src is None:
+                    g = p.grad
+                    if g.is_sparse:
+                        raise RuntimeError("FusedAdam: sparse gradients are passed with set_row_gradient()")
+                    if g.dtype != torch.float32 or g.shape != p.shape:
+                        raise RuntimeError("FusedAdam: gradient dtype / shape")
+                    if not g.is_contiguous():
+                        g = g.contiguous()
+                act.append((gi, p, st, g, src))
+        return act
+
+    def _table(self, act):
+        """Descriptor table on the device; rebuilt when a pointer, a size or a static hyper-parameter changed (in eager
+        training autograd allocates new gradient tensors every iteration; under a HIP graph everything is static)."""
+        _check_layout()
+        elems = load().mtgs_adam_block_elems()
+        tab = np.zeros(len(act), _GROUP)
+        fb = 0
+        keep = []
+        for i, (gi, p, st, g, src) in enumerate(act):
+            grp = self.param_groups[gi]
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
+                raise RuntimeError("FusedAdam: exp_avg / exp_avg_sq must be contiguous and shaped like their parameter")
+            r = tab[i]
+            r["p"], r["m"], r["v"], r["n"], r["first_block"] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), fb
+            align = p.data_ptr() | m.data_ptr() | v.data_ptr()
+            if g is not None:
+                r["g"] = g.data_ptr()
+                align |= g.data_ptr()
+                keep.append(g)
+            elif src is not None:
+                rows, row_of, col, stride, width = src
+                r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
+                keep.append((rows, row_of))
+            r["vec_ok"] = int(align % 16 == 0)
+            r["beta1"], r["beta2"] = grp["betas"]
+            r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
+            fb += -(-p.numel() // elems)
+        key = tab.tobytes()
+        if key != self._table_key:
+            from .nodes import upload_table
+            dev = act[0][1].device
+            self._table_dev = upload_table(tab, dev)
+            if self._hyper_dev is None or self._hyper_dev.numel() != 2 * len(act) or self._hyper_dev.device != dev:
+                self._hyper_dev = torch.empty(2 * len(act), dtype=torch.float32, device=dev)
+            self._table_key = key
+        self._blocks = fb
+        self._keep = keep
+        return self._table_dev
+
+    def advance(self) -> None:
+        """In front of every replay of a HIP graph that captured step(): increments the step count of the tensors that
+        step updates and copies this step's {lr / (1 - beta1^t), sqrt(1 - beta2^t)} per tensor to the device
+        (asynchronously, from a fresh pinned buffer, on the current stream)."""
+        self._advance(self._active)
+
+    def _advance(self, act) -> None:
+        if not act:
+            return
+        hyper = np.empty((len(act), 2), np.float32)
+        for i, (gi, p, st, g, src) in enumerate(act):
+            grp = self.param_groups[gi]
+            st["step"] += 1
+            t = float(st["step"])
+            b1, b2 = grp["betas"]
+            hyper[i, 0] = grp["lr"] / (1.0 - b1 ** t)
+            hyper[i, 1] = math.sqrt(1.0 - b2 ** t)
+        if self._hyper_dev is None or self._hyper_dev.numel() != hyper.size:
+            self._hyper_dev = torch.empty(hyper.size, dtype=torch.float32, device=act[0][1].device)
+        staged = torch.empty(hyper.size, dtype=torch.float32, pin_memory=True)
+        staged.numpy()[:] = hyper.reshape(-1)
+        self._hyper_dev.copy_(staged, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        act = self._collect()
+        self._active = act
+        if not act:
+            return loss
+        if not torch.cuda.is_current_stream_capturing():
+            self._advance(act)
+        elif self._hyper_dev is None or self._hyper_dev.numel() != 2 * len(act):
+            # (pinned allocation is not permitted while capturing, and the step count must not advance at capture time)
+            raise RuntimeError("FusedAdam: run one eager step() before capturing one (state and device buffers are created there)")
+        table = self._table(act)
+        call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, int(self.nontemporal),
+             stream_of(act[0][1]))
+        self._rows.clear()
+        return loss
+
+
+def adam_reference_step(p, m, v, g, step: int, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam's single-tensor update written out (amsgrad = False, maximize = False), any dtype / device --
+    documentation of the arithmetic the kernel restates; the tests compare against torch.optim.Adam itself."""
+    b1, b2 = betas
+    if weight_decay:
+        g = g + weight_decay * p
+    m = m + (g - m) * (1 - b1)
+    v = v * b2 + (1 - b2) * g * g
+    denom = v.sqrt() / math.sqrt(1 - b2 ** step) + eps
+    return p - (lr / (1 - b1 ** step)) * (m / denom), m, v

@@ -412,6 +412,7 @@ class _RasterizeToPixels(torch.autograd.Function):
 RECORD_CHANNELS = 8      # blended channels a packed record holds (csrc/raster_rec.hpp)
 speculative_sizing = True  # enqueue binning + compositing before the host knows (n_vis, M); see _SizePlan
 _force_caps = None       # tests: (cap_vis, cap_M) used for the speculative attempt, to exercise the overflow path
+_debug_rows = None       # tests: a dict that the fused backward fills with its compact gradient rows {"G", "vis_ids", "DC"}
 
 
 class _SizePlan(threading.local):
@@ -701,6 +702,8 @@ class _FusedRasterization(torch.autograd.Function):
                      ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(r_xy),
                      ptr(r_abs) if ctx.absgrad else None, ptr(r_con), ptr(r_col), ptr(r_dep), ptr(r_opa),
                      host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
+        if _debug_rows is not None:
+            _debug_rows.update(G=G, vis_ids=vis_ids, DC=DC, with_depth=with_depth)
         if ctx.dp is not None:
             # data-parallel mode: the per-visible VJP writes this rank's wire rows (index order) into the exchange's send
             # buffer; dense gradients are rebuilt for all ranks at once by SparseGradExchange.finish()

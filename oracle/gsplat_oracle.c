@@ -593,10 +593,13 @@ void orc_isect_offsets(int64_t M, const int64_t *ids_sorted, int C, int tw, int 
  * next_T == 1e-4 stop threshold).  There an fp32-rounding-level change of alpha flips a discrete
  * decision and moves the pixel by up to alpha_min * |colour|, so comparisons against another
  * fp32 implementation (different exp, FMA contraction) are ill-conditioned at exactly those pixels. */
-void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
-                   const float *colors, const float *opacities, const float *backgrounds, int W, int H,
-                   int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
-                   int64_t M, float *render, float *alphas, int32_t *last_ids, uint8_t *critical) {
+/* _ex: plus critical_gauss[C*N] (nullable, zero-initialised by the caller, test aid): 1 for a Gaussian that ITSELF sits at
+ * one of the two thresholds at some pixel -- its own contribution at that pixel is what a flipped decision adds or removes. */
+void orc_blend_fwd_ex(int C, int64_t N, int D, const float *means2d, const float *conics,
+                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                      int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
+                      int64_t M, float *render, float *alphas, int32_t *last_ids, uint8_t *critical,
+                      uint8_t *critical_gauss) {
     (void)N;
     int64_t n_tiles = (int64_t)C * tw * th;
 #pragma omp parallel for schedule(dynamic, 4)
@@ -618,11 +621,11 @@ void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *c
                     float a = conics[g * 3], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
                     float sigma = 0.5f * (a * dx * dx + cc * dy * dy) + b * dx * dy;
                     float alpha = fminf(ALPHA_MAX, opacities[g] * expf(-sigma));
-                    if (fabsf(alpha - ALPHA_MIN) <= 1e-4f * ALPHA_MIN && sigma >= -1e-6f) crit = 1;
-                    if (fabsf(sigma) <= 1e-6f && alpha >= ALPHA_MIN) crit = 1;
+                    if (fabsf(alpha - ALPHA_MIN) <= 1e-4f * ALPHA_MIN && sigma >= -1e-6f) { crit = 1; if (critical_gauss) critical_gauss[g] = 1; }
+                    if (fabsf(sigma) <= 1e-6f && alpha >= ALPHA_MIN) { crit = 1; if (critical_gauss) critical_gauss[g] = 1; }
                     if (sigma < 0.f || alpha < ALPHA_MIN) continue;
                     float next_T = T * (1.f - alpha);
-                    if (fabsf(next_T - T_MIN) <= 1e-4f * T_MIN) crit = 1;
+                    if (fabsf(next_T - T_MIN) <= 1e-4f * T_MIN) { crit = 1; if (critical_gauss) critical_gauss[g] = 1; }
                     if (next_T <= T_MIN) break;
                     float vis = alpha * T;
                     const float *col = colors + (int64_t)g * D;
@@ -640,17 +643,31 @@ void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *c
     }
 }
 
-/* rasterize_to_pixels_bwd.  Per-Gaussian sums in fp64, written (overwriting) at the end.
- * v_means2d_abs nullable. */
-void orc_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
+void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *conics,
                    const float *colors, const float *opacities, const float *backgrounds, int W, int H,
                    int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
-                   int64_t M, const float *alphas, const int32_t *last_ids, const float *v_render,
-                   const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
-                   float *v_colors, float *v_opacities) {
+                   int64_t M, float *render, float *alphas, int32_t *last_ids, uint8_t *critical) {
+    orc_blend_fwd_ex(C, N, D, means2d, conics, colors, opacities, backgrounds, W, H, tile_size, tw, th, offsets, flatten_ids, M,
+                     render, alphas, last_ids, critical, NULL);
+}
+
+/* rasterize_to_pixels_bwd.  Per-Gaussian sums in fp64, written (overwriting) at the end.
+ * v_means2d_abs nullable. */
+/* _ex: the same, plus term_abs[C,N,4+D] (nullable, test aid): per Gaussian the sums of the ABSOLUTE values of the
+ * per-pixel terms of {conic 3, opacity 1, colour D} (for xy that sum is v_means2d_abs itself).  |sum| << sum of |terms|
+ * marks a row whose terms cancel: its fp32-summed device value cannot be expected within a relative bound of the sum,
+ * only within (per-term relative error) x (sum of |terms|) -- tests/util.py::assert_grad_close. */
+void orc_blend_bwd_ex(int C, int64_t N, int D, const float *means2d, const float *conics,
+                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                      int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
+                      int64_t M, const float *alphas, const int32_t *last_ids, const float *v_render,
+                      const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
+                      float *v_colors, float *v_opacities, float *term_abs) {
     int64_t CN = (int64_t)C * N;
     int S = 8 + D; /* xy(2) abs(2) conic(3) opac(1) colour(D) */
+    int SA = 4 + D;
     double *acc = (double *)calloc((size_t)CN * S, sizeof(double));
+    double *aab = term_abs ? (double *)calloc((size_t)CN * SA, sizeof(double)) : NULL;
     int64_t n_tiles = (int64_t)C * tw * th;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t t = 0; t < n_tiles; ++t) {
@@ -702,6 +719,21 @@ void orc_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
                         vxy1 = v_sigma * (b * dx + cc * dy);
                         vo = vis * v_alpha;
                     }
+                    if (aab) {
+                        double *B = aab + (int64_t)g * SA;
+#pragma omp atomic
+                        B[0] += (double)fabsf(vc0);
+#pragma omp atomic
+                        B[1] += (double)fabsf(vc1);
+#pragma omp atomic
+                        B[2] += (double)fabsf(vc2);
+#pragma omp atomic
+                        B[3] += (double)fabsf(vo);
+                        for (int k = 0; k < D; ++k) {
+#pragma omp atomic
+                            B[4 + k] += (double)fabsf(fac * vr[k]);
+                        }
+                    }
                     for (int k = 0; k < D; ++k) {
                         float vcol = fac * vr[k];
 #pragma omp atomic
@@ -735,6 +767,20 @@ void orc_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *c
         v_conics[g * 3] = (float)A[4]; v_conics[g * 3 + 1] = (float)A[5]; v_conics[g * 3 + 2] = (float)A[6];
         v_opacities[g] = (float)A[7];
         for (int k = 0; k < D; ++k) v_colors[g * D + k] = (float)A[8 + k];
+        if (aab)
+            for (int k = 0; k < SA; ++k) term_abs[g * SA + k] = (float)aab[g * SA + k];
     }
     free(acc);
+    free(aab);
+}
+
+void orc_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,
+                   const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                   int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
+                   int64_t M, const float *alphas, const int32_t *last_ids, const float *v_render,
+                   const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
+                   float *v_colors, float *v_opacities) {
+    orc_blend_bwd_ex(C, N, D, means2d, conics, colors, opacities, backgrounds, W, H, tile_size, tw, th, offsets, flatten_ids,
+                     M, alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities,
+                     NULL);
 }

@@ -223,18 +223,22 @@ def blend_fwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, 
     alphas = np.empty((Cc, H, W, 1), np.float32)
     last = np.empty((Cc, H, W), np.int32)
     crit = np.zeros((Cc, H, W), np.uint8) if want_critical else None
-    lib().orc_blend_fwd(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
-                        _p(colors, C.c_float), _p(opacities, C.c_float), _p(backgrounds, C.c_float),
-                        W, H, tile_size, tw, th, _p(offsets, C.c_int32), _p(flatten_ids, C.c_int32),
-                        C.c_int64(flatten_ids.shape[0]), _p(render, C.c_float), _p(alphas, C.c_float),
-                        _p(last, C.c_int32), _p(crit, C.c_uint8))
+    crit_g = np.zeros((Cc, N), np.uint8) if want_critical else None
+    lib().orc_blend_fwd_ex(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
+                           _p(colors, C.c_float), _p(opacities, C.c_float), _p(backgrounds, C.c_float),
+                           W, H, tile_size, tw, th, _p(offsets, C.c_int32), _p(flatten_ids, C.c_int32),
+                           C.c_int64(flatten_ids.shape[0]), _p(render, C.c_float), _p(alphas, C.c_float),
+                           _p(last, C.c_int32), _p(crit, C.c_uint8), _p(crit_g, C.c_uint8))
     if want_critical:
+        blend_fwd.critical_gaussians = crit_g.astype(bool)     # (side channel: the Gaussians that sit at a threshold themselves)
         return render, alphas, last, crit.astype(bool)
     return render, alphas, last
 
 
 def blend_bwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, offsets, flatten_ids,
-              alphas, last_ids, v_render, v_alphas, absgrad=True):
+              alphas, last_ids, v_render, v_alphas, absgrad=True, want_term_abs=False):
+    """want_term_abs: also returns term_abs[C,N,4+D] = per Gaussian the sums of |per-pixel term| of {conic 3, opacity 1,
+    colour D} (test aid: the conditioning of each row's sum; for xy it is v_means2d_abs)."""
     means2d, conics, colors, opacities, backgrounds = map(_f, (means2d, conics, colors, opacities, backgrounds))
     alphas, v_render, v_alphas = map(_f, (alphas, v_render, v_alphas))
     Cc, N, D = colors.shape
@@ -247,14 +251,35 @@ def blend_bwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, 
     v_conics = np.empty((Cc, N, 3), np.float32)
     v_colors = np.empty((Cc, N, D), np.float32)
     v_opac = np.empty((Cc, N), np.float32)
-    lib().orc_blend_bwd(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
-                        _p(colors, C.c_float), _p(opacities, C.c_float), _p(backgrounds, C.c_float),
-                        W, H, tile_size, tw, th, _p(offsets, C.c_int32), _p(flatten_ids, C.c_int32),
-                        C.c_int64(flatten_ids.shape[0]), _p(alphas, C.c_float), _p(last_ids, C.c_int32),
-                        _p(v_render, C.c_float), _p(v_alphas, C.c_float), _p(v_means2d, C.c_float),
-                        _p(v_abs, C.c_float), _p(v_conics, C.c_float), _p(v_colors, C.c_float),
-                        _p(v_opac, C.c_float))
+    term_abs = np.empty((Cc, N, 4 + D), np.float32) if want_term_abs else None
+    lib().orc_blend_bwd_ex(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
+                           _p(colors, C.c_float), _p(opacities, C.c_float), _p(backgrounds, C.c_float),
+                           W, H, tile_size, tw, th, _p(offsets, C.c_int32), _p(flatten_ids, C.c_int32),
+                           C.c_int64(flatten_ids.shape[0]), _p(alphas, C.c_float), _p(last_ids, C.c_int32),
+                           _p(v_render, C.c_float), _p(v_alphas, C.c_float), _p(v_means2d, C.c_float),
+                           _p(v_abs, C.c_float), _p(v_conics, C.c_float), _p(v_colors, C.c_float),
+                           _p(v_opac, C.c_float), _p(term_abs, C.c_float))
+    if want_term_abs:
+        return v_means2d, v_abs, v_conics, v_colors, v_opac, term_abs
     return v_means2d, v_abs, v_conics, v_colors, v_opac
+
+
+def gaussians_on_pixels(pixel_mask, last_ids, offsets, flatten_ids, n_rows, tile_size=16, margin=8):
+    """Test aid: bool[n_rows] -- the (camera, Gaussian) pairs that lie on the composited part of the tile list of some
+    pixel of pixel_mask[C,H,W] (list start .. the pixel's last contributor + margin: a flipped alpha / transmittance decision
+    at a pixel changes T for every later entry and the backward's suffix sums for every earlier one, and can move the
+    point of termination by a few entries)."""
+    Cc, H, W = pixel_mask.shape
+    th, tw = offsets.shape[1:]
+    off = np.append(offsets.reshape(-1).astype(np.int64), flatten_ids.shape[0])
+    out = np.zeros(n_rows, bool)
+    for c, y, x in zip(*np.nonzero(pixel_mask)):
+        t = (c * th + y // tile_size) * tw + x // tile_size
+        s, e = off[t], off[t + 1]
+        e = min(e, int(last_ids[c, y, x]) + 1 + margin)
+        if e > s:
+            out[flatten_ids[s:e]] = True
+    return out
 
 
 # ---------------------------------------------------------------- orchestration
@@ -303,5 +328,6 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
                 tile_width=tw, tile_height=th, tiles_per_gauss=tpg, isect_ids=isect_ids,
                 flatten_ids=flatten_ids, isect_offsets=offsets, width=width, height=height,
                 tile_size=tile_size, n_cameras=Cc, compensations=comps, colors=cols,
-                backgrounds=bg, last_ids=last_ids, render_raw=render_raw, critical=critical)
+                backgrounds=bg, last_ids=last_ids, render_raw=render_raw, critical=critical,
+                critical_gaussians=blend_fwd.critical_gaussians)
     return render, alphas, meta

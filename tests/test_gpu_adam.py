@@ -1,0 +1,202 @@
+"""Fused Adam (csrc/adam.hip, mtgs_amd.optim.FusedAdam) against torch.optim.Adam on the CPU in float64 -- the reference's
+optimizer (one torch.optim.Adam per parameter group: custom_trainer.py:115-136, config/MTGS.py:121-181) -- over several steps
+including a refinement (rows removed and appended with the moments following, vanilla_gaussian_splatting.py:392-446)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# the groups of config/MTGS.py:121-181 (name, shape per Gaussian, lr); eps = 1e-15 everywhere
+MTGS_GROUPS = [("means", (3,), 8e-4), ("features_dc", (3,), 0.0025), ("features_rest", (15, 3), 0.0025 / 20),
+               ("opacities", (1,), 0.05), ("scales", (3,), 0.005), ("quats", (4,), 0.001)]
+
+
+def _params(N, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.randn(N, *shp, generator=g) * (30.0 if k == "means" else 0.3)) for k, shp, _ in MTGS_GROUPS}
+
+
+def _oracle_opt(P64):
+    return [torch.optim.Adam([P64[k]], lr=lr, eps=1e-15) for k, _, lr in MTGS_GROUPS]
+
+
+def _close(got, ref, what):
+    """<= 1e-6 relative on p (+ 1e-9 absolute for entries that are themselves ~0)."""
+    got, ref = got.detach().cpu().double(), ref.detach().double()
+    err = (got - ref).abs()
+    bound = 1e-6 * ref.abs() + 1e-9
+    assert bool((err <= bound).all()), f"{what}: max err {float(err.max()):.3e}, worst ratio {float((err / bound).max()):.2f}"
+
+
+@pytest.mark.parametrize("N", [1, 1023, 50_000])
+def test_fused_adam_matches_torch_adam_fp64_over_steps_and_a_refinement(hip_lib, N):
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    P0 = _params(N, 0, dev)
+    P = {k: v.clone().to(dev).requires_grad_(True) for k, v in P0.items()}
+    P64 = {k: v.clone().double().requires_grad_(True) for k, v in P0.items()}
+    opt = FusedAdam([{"params": [P[k]], "lr": lr} for k, _, lr in MTGS_GROUPS], eps=1e-15)
+    refs = _oracle_opt(P64)
+    g = torch.Generator().manual_seed(1)
+
+    def one_step(P, P64, opt, refs, zero_rows=None):
+        for k in P:
+            gr = torch.randn(P[k].shape, generator=g) * 0.01
+            if zero_rows is not None:          # Gaussians outside the frame: exactly-zero gradient rows
+                gr[zero_rows] = 0.0
+            P[k].grad = gr.to(dev)
+            P64[k].grad = gr.double()
+        opt.step()
+        for r in refs:
+            r.step()
+
+    zero_rows = torch.rand(N, generator=g) < 0.8
+    for s in range(3):
+        one_step(P, P64, opt, refs, zero_rows)
+        for k in P:
+            _close(P[k], P64[k], f"step {s + 1} {k}")
+            _close(opt.state[P[k]]["exp_avg"], refs[[n for n, _, _ in MTGS_GROUPS].index(k)].state[P64[k]]["exp_avg"], f"step {s + 1} m {k}")
+            assert float(opt.state[P[k]]["step"]) == s + 1 == float(refs[0].state[P64["means"]]["step"])
+    # ---- refinement: cull a third of the rows, append 7 new ones (zero moments), as remove_from_optim / dup_in_optim do
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[::3] = N < 3
+    n_new = 7
+    newP, newP64, new_refs = {}, {}, []
+    params = []
+    for k, shp, lr in MTGS_GROUPS:
+        add = torch.randn(n_new, *shp, generator=g)
+        st, st64 = opt.state[P[k]], refs[len(new_refs)].state[P64[k]]
+        q = torch.cat([P[k].detach()[keep.to(dev)], add.to(dev)]).requires_grad_(True)
+        q64 = torch.cat([P64[k].detach()[keep], add.double()]).requires_grad_(True)
+        z = lambda t, a: torch.cat([t[keep.to(t.device)], torch.zeros_like(a, dtype=t.dtype, device=t.device)])
+        newP[k], newP64[k] = q, q64
+        r = torch.optim.Adam([q64], lr=lr, eps=1e-15)
+        r.state[q64] = {"step": st64["step"], "exp_avg": z(st64["exp_avg"], add), "exp_avg_sq": z(st64["exp_avg_sq"], add)}
+        new_refs.append(r)
+        params.append({"params": [q], "lr": lr})
+    opt2 = FusedAdam(params, eps=1e-15)
+    for k in newP:
+        st = opt.state[P[k]]
+        opt2.state[newP[k]] = {"step": st["step"], "exp_avg": z(st["exp_avg"], torch.zeros(n_new, *P[k].shape[1:])),
+                               "exp_avg_sq": z(st["exp_avg_sq"], torch.zeros(n_new, *P[k].shape[1:]))}
+    for s in range(2):
+        one_step(newP, newP64, opt2, new_refs)
+        for k in newP:
+            _close(newP[k], newP64[k], f"after refinement, step {s + 1} {k}")
+            assert float(opt2.state[newP[k]]["step"]) == 3 + s + 1
+
+
+def test_fused_adam_row_gradients_equal_dense_gradients(hip_lib):
+    """Gradient source 2: compact rows of the visible Gaussians + a row map.  Must equal the dense-gradient step with the
+    rows scattered into zeros (culled Gaussians: exact zero-gradient update), bit for bit, including a tensor whose rows
+    straddle the 16-byte vectors (width 45) and one that is not 16-byte aligned."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    N = 20_011
+    g = torch.Generator().manual_seed(3)
+    vis = torch.rand(N, generator=g) < 0.15
+    n_vis = int(vis.sum())
+    row_of = torch.full((N,), -1, dtype=torch.int32)
+    row_of[vis] = torch.arange(n_vis, dtype=torch.int32)
+    STRIDE = 64
+    rows = torch.randn(n_vis, STRIDE, generator=g)
+    layout = [("means", (3,), 0), ("quats", (4,), 3), ("scales", (3,), 7), ("opacities", (), 10), ("rest", (15, 3), 16)]
+    base = {k: torch.randn(N, *shp, generator=g) for k, shp, _ in layout}
+    flat = torch.zeros(N * 3 + 1)                      # an unaligned tensor: a view one float into a buffer
+    flat[1:] = base["means"].reshape(-1)
+
+    def make():
+        P = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        holder = flat.clone().to(dev)
+        P["means"] = holder[1:].view(N, 3).requires_grad_(True)
+        return P, FusedAdam([{"params": [p], "lr": 1e-2 * (i + 1)} for i, p in enumerate(P.values())], eps=1e-15)
+
+    Pa, oa = make()
+    Pb, ob = make()
+    rows_d, row_of_d = rows.to(dev), row_of.to(dev)
+    for step in range(3):
+        for k, shp, col in layout:
+            width = int(np.prod(shp)) if shp else 1
+            dense = torch.zeros(N, width)
+            dense[vis] = rows[:, col:col + width]
+            Pa[k].grad = dense.view(N, *shp).to(dev)
+            ob.set_row_gradient(Pb[k], rows_d, row_of_d, col)
+        oa.step()
+        ob.step()
+        for k in Pa:
+            assert torch.equal(Pa[k], Pb[k]), (step, k)
+            assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), (step, k)
+        rows_d = rows_d * 0.5
+        rows = rows * 0.5
+
+
+def test_fused_adam_state_dict_round_trip_with_torch_adam(hip_lib):
+    """state_dict() is torch.optim.Adam's: a run can switch optimizers in either direction (checkpoints of the reference
+    keep `optimizers` per group, custom_trainer.py:148-157)."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    w0 = torch.randn(1000, 3, generator=g)
+    a = w0.clone().to(dev).requires_grad_(True)
+    b = w0.clone().to(dev).requires_grad_(True)
+    oa, ob = FusedAdam([a], lr=1e-2, eps=1e-15), torch.optim.Adam([b], lr=1e-2, eps=1e-15)
+    for _ in range(2):
+        gr = torch.randn(1000, 3, generator=g).to(dev)
+        a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    ob2 = torch.optim.Adam([b], lr=1e-2, eps=1e-15)
+    ob2.load_state_dict(oa.state_dict())          # fused -> torch
+    oa2 = FusedAdam([a], lr=1e-2, eps=1e-15)
+    oa2.load_state_dict(ob.state_dict())          # torch -> fused
+    gr = torch.randn(1000, 3, generator=g).to(dev)
+    a.grad, b.grad = gr.clone(), gr.clone()
+    oa2.step(); ob2.step()
+    assert float(oa2.state[a]["step"]) == float(ob2.state[b]["step"]) == 3
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+
+
+def test_fused_adam_in_a_hip_graph(hip_lib):
+    """step() captured once; advance() + replay per step: the same trajectory as eager steps, with a learning-rate
+    schedule changing lr between replays (means: ExponentialDecay in config/MTGS.py:123-128)."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(7)
+    w0 = torch.randn(5000, 4, generator=g)
+    grads = [torch.randn(5000, 4, generator=g).to(dev) for _ in range(5)]
+    lrs = [1e-2 * 0.9 ** i for i in range(5)]
+    a = w0.clone().to(dev).requires_grad_(True)
+    oa = FusedAdam([a], lr=lrs[0], eps=1e-15)
+    for i in range(5):
+        oa.param_groups[0]["lr"] = lrs[i]
+        a.grad = grads[i].clone()
+        oa.step()
+    b = w0.clone().to(dev).requires_grad_(True)
+    ob = FusedAdam([b], lr=lrs[0], eps=1e-15)
+    static_g = grads[0].clone()
+    b.grad = static_g
+    ob.step()                                      # eager step 1 (creates state and buffers)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ob.step()
+    for i in range(1, 5):
+        ob.param_groups[0]["lr"] = lrs[i]
+        static_g.copy_(grads[i])
+        ob.advance()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert float(ob.state[b]["step"]) == 5
+    assert torch.equal(a, b)
+
+
+def test_fused_adam_refuses_what_it_does_not_implement(hip_lib):
+    from mtgs_amd.optim import FusedAdam
+    p = torch.zeros(4, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        FusedAdam([p], amsgrad=True)
+    q = torch.zeros(4, requires_grad=True)
+    q.grad = torch.zeros(4)
+    with pytest.raises(RuntimeError):
+        FusedAdam([q]).step()

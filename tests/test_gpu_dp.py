@@ -274,3 +274,94 @@ def test_sparse_exchange_routes_colour_gradients_to_the_senders_traversal(tmp_pa
         for (err, scale), name in zip(np.load(tmp_path / f"t{r}.npy"), ("means", "quats", "scales", "opacities", "coeffs[N,T,K,3]")):
             # (fp32 atomics in another order on the two paths: a few 1e-6 of the largest gradient)
             assert scale > 0 and err <= 3e-5 * scale + 1e-7, f"rank {r} {name}: {err} vs {scale}"
+
+
+def _worker_configs3(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MTGS_DIST_BACKEND="gloo")
+    sys.path.insert(0, str(ROOT))
+    import json
+    import torch.distributed as dist
+    from mtgs_amd import dist as mdist, spherical_harmonics
+    from mtgs_amd.synthetic import make_camera, make_scene
+    mdist.init_from_env()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    N, W, H, K = 2_000_000, 1920, 1080, 16
+    sc = make_scene(N, seed=0, sh_degree=3)                       # WB-v1, as bench.py --gpus 8
+    cams = [make_camera(W, H, yaw_deg=45.0 * r) for r in range(world)]
+
+    def cotangents(r):
+        g = torch.Generator().manual_seed(1000 + r)
+        return torch.randn(1, H, W, 4, generator=g), torch.randn(1, H, W, 1, generator=g)
+
+    vm, Kmat = cams[rank]
+    P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    cam_pos = torch.inverse(vm)[0, :3, 3].to(dev)
+    Gc, Ga = cotangents(rank)
+    ex = mdist.SparseGradExchange(N, K, dev)
+    sh = spherical_harmonics(3, P["means"].detach() - cam_pos, P["coeffs"].detach())
+    r_, a_, info = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm.to(dev), Kmat.to(dev), W, H, cam_pos)
+    torch.autograd.backward([r_, a_], [Gc.to(dev), Ga.to(dev)])
+    sums = ex.finish(P["means"], 3)
+    torch.cuda.synchronize()
+    if rank == 0:
+        # the oracle's eight-camera backward, summed over the cameras in fp64 (one camera at a time: ~7 s each on the box)
+        from oracle import oracle as orc
+        from tests import util
+        orc.build()
+        a = {k: v.numpy() for k, v in sc.items()}
+        acc = {k: np.zeros(a[k].shape, np.float64) for k in ("means", "quats", "scales", "opacities", "coeffs")}
+        for r in range(world):
+            vm_r, K_r = cams[r]
+            dirs = a["means"] - torch.inverse(vm_r)[0, :3, 3].numpy()
+            x = orc.sh_fwd(3, dirs, a["coeffs"])
+            rgb = np.clip(x + 0.5, 0.0, 1.0)
+            r_ref, a_ref, m = orc.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], rgb, vm_r.numpy(), K_r.numpy(),
+                                                W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+            if r == 0:   # this rank's own frame: the exchange renders what rasterization() renders
+                assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
+            Gc_r, Ga_r = (t.numpy() for t in cotangents(r))
+            alc = np.maximum(a_ref, 1e-10)
+            Gc_raw = Gc_r.copy()
+            Gc_raw[..., -1:] = Gc_r[..., -1:] / alc
+            Ga_tot = Ga_r - (m["render_raw"][..., -1:] / alc ** 2) * Gc_r[..., -1:] * (a_ref > 1e-10)
+            v2d, vabs, vcon, vcol, vop = orc.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                       m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw, Ga_tot)
+            vm_, vq_, vs_, _ = orc.project_bwd(a["means"], a["quats"], a["scales"], vm_r.numpy(), K_r.numpy(), W, H, 0.3, m["radii"],
+                                               m["conics"], m["compensations"], v2d, vcol[..., -1].copy(), vcon,
+                                               vop * a["opacities"][None], need_v_viewmats=False)
+            mask = (x + 0.5 > 0.0) & (x + 0.5 < 1.0)
+            vc_, _ = orc.sh_bwd(3, dirs, a["coeffs"], vcol[0, :, :3] * mask)
+            for k, v in (("means", vm_), ("quats", vq_), ("scales", vs_), ("opacities", (vop * m["compensations"]).sum(0)),
+                         ("coeffs", vc_)):
+                acc[k] += v
+        case = "configs[3]: 2M Gaussians, 8 cameras 1920x1080, sparse exchange over 8 ranks vs the oracle's 8-camera sum"
+        failures = []
+        for k, got in zip(("means", "quats", "scales", "opacities", "coeffs"), sums):
+            try:
+                # (opacity: the sum with the most cancellation under random cotangents, as at one camera)
+                util.assert_grad_close("sum v_" + k, got, acc[k].astype(np.float32), case=case,
+                                       row_rel_p999=2.5e-3 if k == "opacities" else 1e-3)
+            except AssertionError as e:
+                failures.append(str(e))
+        with open(Path(out_dir) / "report.json", "w") as f:
+            json.dump({"report": util.REPORT, "failures": failures}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_full_size_gradient_sums_vs_oracle(tmp_path, hip_lib):
+    """BASELINE configs[3] NUMERICALLY at its own size: 2M shared Gaussians, eight 1920x1080 cameras, one rank per camera
+    (the eight ranks share the test box's one GPU, gloo in place of RCCL).  The gradient sums the sparse exchange hands to
+    the optimizer -- v_means, v_quats, v_scales, v_opacities and the SH coefficient gradient rebuilt from 3 floats per row
+    on the receivers -- against the oracle's eight-camera backward summed in fp64, with the per-row bars of the
+    one-camera comparisons (reference semantics: one camera per step and rank, mtgs_scene_graph.py:641-690)."""
+    import json
+    import torch.multiprocessing as mp
+    from tests.util import REPORT
+    world = 8
+    mp.spawn(_worker_configs3, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = json.load(open(tmp_path / "report.json"))
+    REPORT.extend(out["report"])
+    assert not out["failures"], out["failures"]
+    assert len([r for r in out["report"] if r["kind"] == "gradient"]) == 5

@@ -180,8 +180,9 @@ def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad
     assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
     assert np.array_equal(info["isect_offsets"].cpu().numpy(), m["isect_offsets"])
     case = f"small {render_mode}/{rmode} D={D} {W}x{H}"
-    assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render", case=case)
-    assert_image_close(alpha.detach().cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", scale=1.0, case=case)
+    assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render", case=case,
+                       depth_channel=None if render_mode == "RGB" else -1, alpha=r_alpha)
+    assert_image_close(alpha.detach().cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", case=case)
     # ---- backward
     (render * dev(Gc)).sum().add((alpha * dev(Ga)).sum()).backward()
     Gc_raw, Ga_tot = Gc.numpy().copy(), Ga.numpy().copy()
@@ -225,7 +226,7 @@ def test_rasterization_sh_path(gs, oracle):
     render, alpha, info = gs.rasterization(dev(sc["means"]), dev(sc["quats"]), dev(sc["scales"]), dev(sc["opacities"]),
                                            dev(sc["coeffs"]), dev(vm), dev(K), 80, 60, sh_degree=2, packed=False)
     assert_image_close(render.cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render")
-    assert_image_close(alpha.cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", scale=1.0)
+    assert_image_close(alpha.cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha")
 
 
 def test_empty_and_degenerate_inputs(gs):
@@ -307,16 +308,18 @@ def test_hip_reproduces_golden_fixture(gs, name):
         assert np.array_equal(info[key].cpu().numpy(), z[key]), key
     for key in ("means2d", "depths", "conics"):
         assert np.array_equal(info[key].detach().cpu().numpy(), z[key]), key
-    assert np.abs(render.detach().cpu().numpy() - z["render"]).max() <= RENDER_TOL * max(1.0, np.abs(z["render"]).max())
-    assert np.abs(alpha.detach().cpu().numpy() - z["alpha"]).max() <= RENDER_TOL
+    has_depth = str(z["render_mode"]) != "RGB"
+    nocrit = np.zeros(z["alpha"].shape[:3], bool)      # (the fixtures carry no critical-pixel map: every pixel is held to tol)
+    assert_image_close(render.detach().cpu().numpy(), z["render"], nocrit, RENDER_TOL, name="render", case=f"fixture {name}",
+                       depth_channel=-1 if has_depth else None, alpha=z["alpha"])
+    assert_image_close(alpha.detach().cpu().numpy(), z["alpha"], nocrit, RENDER_TOL, name="alpha", case=f"fixture {name}")
     torch.autograd.backward([render, alpha], [dev(z["Gc"]), dev(z["Ga"])])
+    # the same bars as every other comparison (fp64 autograd values in the fixture); 2e-3 of the maximum as for the other
+    # few-hundred-Gaussian scenes of this file, where one flipped pixel is 1e-3 of a row
     for key, gname in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
                        ("colors", "v_colors")]:
-        ref = z[gname]
-        err = np.abs(P[key].grad.cpu().numpy() - ref).max()
-        assert err <= 2e-3 * np.abs(ref).max(), (key, err)
-    ref = z["v_viewmat"]
-    assert np.abs(vm.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+        assert_grad_close(gname, P[key].grad, z[gname], case=f"fixture {name}", rel_to_max=2e-3)
+    assert_grad_close("v_viewmat", vm.grad, z["v_viewmat"], case=f"fixture {name}", rel_to_max=2e-3)
 
 
 @pytest.mark.parametrize("name", ["gsplat_1_4_0_classic", "gsplat_1_4_0_mtgs"])
@@ -346,10 +349,12 @@ def test_hip_reproduces_gsplat_fixture(gs, name):
         np.testing.assert_allclose(info[key].detach().cpu().numpy()[vis], ref[vis], rtol=2e-5, atol=1e-6, err_msg=key)
     for key in ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
         assert np.array_equal(info[key].cpu().numpy(), z[key]), key
-    assert np.abs(render.detach().cpu().numpy() - z["render"]).max() <= RENDER_TOL * max(1.0, np.abs(z["render"]).max())
-    assert np.abs(alpha.detach().cpu().numpy() - z["alpha"]).max() <= RENDER_TOL
-    torch.autograd.backward([render, alpha], [dev(z["Gc"]), dev(z["Ga"])])
     case = f"gsplat fixture {name}"
+    nocrit = np.zeros(z["alpha"].shape[:3], bool)
+    assert_image_close(render.detach().cpu().numpy(), z["render"], nocrit, RENDER_TOL, name="render", case=case,
+                       depth_channel=-1 if str(z["render_mode"]) != "RGB" else None, alpha=z["alpha"])
+    assert_image_close(alpha.detach().cpu().numpy(), z["alpha"], nocrit, RENDER_TOL, name="alpha", case=case)
+    torch.autograd.backward([render, alpha], [dev(z["Gc"]), dev(z["Ga"])])
     for key, gname in [("means", "v_means"), ("quats", "v_quats"), ("scales", "v_scales"), ("opacities", "v_opacities"),
                        ("colors", "v_colors")]:
         assert_grad_close(gname, P[key].grad, z[gname], case=case)
