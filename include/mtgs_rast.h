@@ -608,7 +608,8 @@ typedef struct mtgs_adam_group {
     int64_t row_stride;         /* floats between rows */
     int32_t width, row_col;
     int32_t vec_ok, reserved;
-    float beta1, beta2, eps, weight_decay, grad_scale, reserved_f;
+    float one_minus_beta1, beta2, one_minus_beta2;   /* 1 - beta rounded from double by the caller (1 - 0.999f is 5e-5 off) */
+    float eps, weight_decay, grad_scale;
 } mtgs_adam_group;
 int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check their layout against it */
 int mtgs_adam_block_elems(void);    /* elements one workgroup updates */

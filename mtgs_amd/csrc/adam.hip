@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
     const int gi = find_group(table, n_groups, (int64_t)blockIdx.x);
     const mtgs_adam_group d = table[gi];
     Hyper h;
-    h.one_minus_b1 = 1.f - d.beta1; h.b2 = d.beta2; h.one_minus_b2 = 1.f - d.beta2;
+    h.one_minus_b1 = d.one_minus_beta1; h.b2 = d.beta2; h.one_minus_b2 = d.one_minus_beta2;
     h.step_size = hyper[2 * gi]; h.bc2_sqrt = hyper[2 * gi + 1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
     const int64_t base = ((int64_t)blockIdx.x - d.first_block) * ADAM_ELEMS;
     float *__restrict__ P = d.p, *__restrict__ M = d.m, *__restrict__ V = d.v;

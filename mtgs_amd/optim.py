@@ -31,8 +31,8 @@ from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"),
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
-                   ("vec_ok", "<i4"), ("reserved", "<i4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"),
-                   ("weight_decay", "<f4"), ("grad_scale", "<f4"), ("reserved_f", "<f4")], align=True)
+                   ("vec_ok", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"),
+                   ("one_minus_beta2", "<f4"), ("eps", "<f4"), ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
 _checked = False
 
 
@@ -132,7 +132,8 @@ class FusedAdam(torch.optim.Optimizer):
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 keep.append((rows, row_of))
             r["vec_ok"] = int(align % 16 == 0)
-            r["beta1"], r["beta2"] = grp["betas"]
+            b1, b2 = grp["betas"]
+            r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2   # (differences taken in double)
             r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
             fb += -(-p.numel() // elems)
         key = tab.tobytes()

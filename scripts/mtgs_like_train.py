@@ -344,8 +344,22 @@ def refine_device(P, stats, opt_state_of, step, seed, growth=0.02):
     return added, culled, swap
 
 
+def make_optimizer(kind, P, shipped=None, capturable=False):
+    """One optimizer over every parameter group.  kind = "fused": mtgs_amd.optim.FusedAdam (one launch per step, csrc/adam.hip);
+    "torch": torch.optim.Adam(foreach=True), what nerfstudio builds per group (custom_trainer.py:115-136)."""
+    extra = [shipped["exposure"]] if shipped else []
+    geo = [p[k] for p in P.values() for k in p if not k.startswith("features") and k != "opacities"]
+    groups = [{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
+              {"params": [p["opacities"] for p in P.values()], "lr": 5e-2},      # config/MTGS.py: opacities 0.05
+              {"params": geo + extra, "lr": 1e-4}]
+    if kind == "fused":
+        from mtgs_amd.optim import FusedAdam
+        return FusedAdam(groups, eps=1e-15)
+    return torch.optim.Adam(groups, eps=1e-15, foreach=True, capturable=capturable)
+
+
 def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=None, world=1, rank=0, accumulate=1, seed=7,
-               log=print, sparse=False):
+               log=print, sparse=False, optimizer="fused"):
     """Adam on the fused iteration.  world > 1: view-parallel data parallelism (one process per rank, camera
     (step * world + rank) % T, ONE dense all-reduce of every gradient per step, statistics all-reduced before each
     refinement, refinement identical on every rank).  accumulate = K in ONE process: the K cameras of a step rendered one
@@ -355,11 +369,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     T = len(cams)
 
     def make_opt():
-        extra = [shipped["exposure"]] if shipped else []
-        geo = [p[k] for p in P.values() for k in p if not k.startswith("features") and k != "opacities"]
-        return torch.optim.Adam([{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
-                                 {"params": [p["opacities"] for p in P.values()], "lr": 5e-2},      # config/MTGS.py: opacities 0.05
-                                 {"params": geo + extra, "lr": 1e-4}], foreach=True)
+        return make_optimizer(optimizer, P, shipped)
 
     opt = make_opt()
     mk = lambda: [[torch.zeros(p["means"].shape[0], device=p["means"].device), torch.ones(p["means"].shape[0], device=p["means"].device),
@@ -432,6 +442,9 @@ def main():
     ap.add_argument("--dp-exchange", choices=["dense", "sparse"], default="dense", help="with --dp: dense all-reduce of every "
                     "parameter gradient, or the sparse factored exchange of mtgs_amd.dist")
     ap.add_argument("--accumulate", type=int, default=1, help="with --steps: cameras per step in ONE process (gradient accumulation)")
+    ap.add_argument("--optimizer", choices=["none", "torch", "fused"], default=None, help="the optimizer step: torch.optim.Adam(foreach) "
+                    "or mtgs_amd.optim.FusedAdam (one launch).  Timing runs (--only / --graph / default) leave it out unless "
+                    "given; --steps trains with the fused one unless told otherwise")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
@@ -474,12 +487,19 @@ def main():
     mk_stats = lambda: [[torch.zeros(p["means"].shape[0], device=dev), torch.ones(p["means"].shape[0], device=dev),
                          torch.zeros(p["means"].shape[0], device=dev)] for p in P.values()]
 
+    # (the chain-vs-fused comparison below runs both variants on the SAME parameters: no optimizer there)
+    opt_kind = args.optimizer if (args.optimizer not in (None, "none") and (args.graph or args.only != "both")) else None
+
     def timed(fused):
         stats = mk_stats()
+        opt = make_optimizer(opt_kind, P, shipped) if opt_kind else None
         def one(i):
             for q in params:
                 q.grad = None
-            return iteration(P, cams[i % T], targets[i % T], mask, fused, stats, win, W, H, shipped=shipped)
+            loss = iteration(P, cams[i % T], targets[i % T], mask, fused, stats, win, W, H, shipped=shipped)
+            if opt is not None:
+                opt.step()
+            return loss
         for i in range(3):
             loss = one(i)
         torch.cuda.synchronize()
@@ -497,11 +517,20 @@ def main():
         from mtgs_amd import wrapper
         stats = mk_stats()
         grads_of = {}
+        opt = make_optimizer(opt_kind, P, shipped, capturable=True) if opt_kind else None
 
         def body(t):
             for q in params:
                 q.grad = None
-            return iteration(P, cams[t], targets[t], mask, True, stats, win, W, H, shipped=shipped)
+            loss = iteration(P, cams[t], targets[t], mask, True, stats, win, W, H, shipped=shipped)
+            if opt is not None:
+                opt.step()
+            return loss
+
+        def replay(t):
+            if opt_kind == "fused":
+                opt.advance()          # this step's {lr / bc1, sqrt(bc2)}: one small copy in front of the graph launch
+            graphs[t].replay()
 
         eager_loss = [float(body(t)) for t in range(T)]        # also teaches the size plan this scene's (n_vis, M)
         torch.cuda.synchronize()
@@ -526,15 +555,16 @@ def main():
                 losses.append(body(t))
             grads_of[t] = [q.grad for q in params]
             graphs.append(g); modes.append(gm)
+        graph_loss = []
         for t in range(T):
-            graphs[t].replay()
-        torch.cuda.synchronize()
-        graph_loss = [float(l) for l in losses]
+            replay(t)
+            torch.cuda.synchronize()
+            graph_loss.append(float(losses[t]))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
         for i in range(args.reps):
-            graphs[i % T].replay()
+            replay(i % T)
         e1.record()
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / args.reps * 1e3
@@ -544,7 +574,10 @@ def main():
         wall, gpu, eager_ms, l_e, l_g, caps = graphed()
         print(f"fused iteration, {W}x{H}{' shipped options' if shipped else ''}: eager {eager_ms:.3f} ms wall -> one graph launch "
               f"{wall:.3f} ms wall ({gpu:.3f} ms between GPU events); capacities {caps}; loss eager {l_e} graph {l_g}")
-        assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(l_e, l_g)), (l_e, l_g)
+        if not opt_kind:      # (with an optimizer in the loop the parameters move between the eager pass and the replays)
+            assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(l_e, l_g)), (l_e, l_g)
+        else:
+            assert all(math.isfinite(v) for v in l_g), (l_e, l_g)
         return
     if args.only != "both" and not args.steps:
         t1, l1, _ = timed(args.only == "fused")
@@ -566,7 +599,8 @@ def main():
             rank, _, world = mdist.init_from_env()
         log = print if rank == 0 else (lambda *a, **k: None)
         curve, sizes = train_loop(P, cams, targets, mask, win, W, H, args.steps, args.refine_every, shipped=shipped, world=world,
-                                  rank=rank, accumulate=args.accumulate, log=log, sparse=args.dp_exchange == "sparse")
+                                  rank=rank, accumulate=args.accumulate, log=log, sparse=args.dp_exchange == "sparse",
+                                  optimizer=args.optimizer if args.optimizer in ("torch", "fused") else "fused")
         k = max(1, args.steps // 8)
         log("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
         n_now = sum(p["means"].shape[0] for p in P.values())

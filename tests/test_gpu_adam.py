@@ -23,11 +23,12 @@ def _oracle_opt(P64):
     return [torch.optim.Adam([P64[k]], lr=lr, eps=1e-15) for k, _, lr in MTGS_GROUPS]
 
 
-def _close(got, ref, what):
-    """<= 1e-6 relative on p (+ 1e-9 absolute for entries that are themselves ~0)."""
+def _close(got, ref, what, lr=0.0):
+    """<= 1e-6 relative on p -- of max(|p|, lr): an entry that is smaller than one step cannot be held to 1e-6 of ITSELF in
+    fp32, the step that produced it carries a relative rounding of ~1e-7."""
     got, ref = got.detach().cpu().double(), ref.detach().double()
     err = (got - ref).abs()
-    bound = 1e-6 * ref.abs() + 1e-9
+    bound = 1e-6 * torch.clamp(ref.abs(), min=lr) + 1e-12
     assert bool((err <= bound).all()), f"{what}: max err {float(err.max()):.3e}, worst ratio {float((err / bound).max()):.2f}"
 
 
@@ -57,8 +58,9 @@ def test_fused_adam_matches_torch_adam_fp64_over_steps_and_a_refinement(hip_lib,
     for s in range(3):
         one_step(P, P64, opt, refs, zero_rows)
         for k in P:
-            _close(P[k], P64[k], f"step {s + 1} {k}")
-            _close(opt.state[P[k]]["exp_avg"], refs[[n for n, _, _ in MTGS_GROUPS].index(k)].state[P64[k]]["exp_avg"], f"step {s + 1} m {k}")
+            lr = dict((n, l) for n, _, l in MTGS_GROUPS)[k]
+            _close(P[k], P64[k], f"step {s + 1} {k}", lr)
+            _close(opt.state[P[k]]["exp_avg"], refs[[n for n, _, _ in MTGS_GROUPS].index(k)].state[P64[k]]["exp_avg"], f"step {s + 1} m {k}", 1e-3)
             assert float(opt.state[P[k]]["step"]) == s + 1 == float(refs[0].state[P64["means"]]["step"])
     # ---- refinement: cull a third of the rows, append 7 new ones (zero moments), as remove_from_optim / dup_in_optim do
     keep = torch.ones(N, dtype=torch.bool)
@@ -85,7 +87,7 @@ def test_fused_adam_matches_torch_adam_fp64_over_steps_and_a_refinement(hip_lib,
     for s in range(2):
         one_step(newP, newP64, opt2, new_refs)
         for k in newP:
-            _close(newP[k], newP64[k], f"after refinement, step {s + 1} {k}")
+            _close(newP[k], newP64[k], f"after refinement, step {s + 1} {k}", dict((n, l) for n, _, l in MTGS_GROUPS)[k])
             assert float(opt2.state[newP[k]]["step"]) == 3 + s + 1
 
 
