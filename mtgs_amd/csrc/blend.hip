@@ -30,6 +30,7 @@
 //   fwd: M*(4 + 24 + 4D) gathered attributes + P*(4D + 8) written
 //   bwd: P*(4D + 12) read + M*(4 + 24 + 4D) gathered + N_vis*(24 + 4D (+8 absgrad)) accumulated
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "wave_reduce.hpp"
 #include "raster_rec.hpp"
@@ -38,6 +39,9 @@ namespace {
 
 constexpr float kAlphaMax = MTGS_ALPHA_MAX;
 constexpr float kTMin = MTGS_T_MIN;
+// alpha = opacity * exp(-sigma) <= opacity (sigma >= 0): below this opacity the min(0.999, .) of the reference can never bind,
+// and a batch of candidates without such a Gaussian runs the loop without the clamp and its gradient mask
+constexpr float kNoClampOpacity = 0.9989f;
 
 // LDS record per staged Gaussian, in floats:  x y a b | c opac s2max idx | col[D] (padded to x4)
 //   a b c   = conic,  s2max = 2 ln(255 opac)  (alpha >= 1/255  <=>  dx u + dy w <= s2max),
@@ -83,10 +87,11 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                                            const float *__restrict__ opacities,
                                            const int32_t *__restrict__ row_index,
                                            const int32_t (&g)[CAND / NT], int64_t base, int n_cand,
-                                           float tile_x0, float tile_y0) {
+                                           float tile_x0, float tile_y0, bool *may_clamp = nullptr) {
     constexpr int REC = Rec<D>::N;
     const int tid = threadIdx.x;
     int count = 0;
+    unsigned long long clamp_any = 0;   // some kept candidate has an opacity whose alpha can reach the 0.999 clamp
 #pragma unroll
     for (int r = 0; r < CAND / NT; ++r) {
         const int k = r * NT + tid;
@@ -136,6 +141,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                 }
             }
         }
+        clamp_any |= __ballot(keep && op > kNoClampOpacity);
         int slot = k;
         if (CULL) {
             const unsigned long long m = __ballot(keep);
@@ -177,6 +183,19 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                 for (int c = 0; c < REC / 4; ++c) dst[c] = make_float4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
             }
             if (s_id) s_id[slot] = (!PK && row_index) ? row_index[g[r]] : g[r];  // gradient row of this Gaussian
+        }
+    }
+    if (may_clamp) {
+        if (NT == 64) {
+            *may_clamp = clamp_any != 0;
+        } else {   // (the staging barriers above separate the rounds; one more pair for the flag)
+            if ((tid & 63) == 0) s_wc[tid >> 6] = clamp_any != 0;
+            __syncthreads();
+            int f = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) f |= s_wc[w];
+            __syncthreads();
+            *may_clamp = f != 0;
         }
     }
     return CULL ? count : n_cand;
@@ -223,6 +242,14 @@ struct ColorRow {
                 q[i] = *reinterpret_cast<const f32x4 *>(s_rec + t * REC + 8 + 4 * i);
         }
     }
+    // the same with the record's LDS address in a VGPR the caller shares between all reads of a pair of entries
+    // (one v_mov per pair instead of one per read): byte offset OFF + 32 + 16 i as the instruction's immediate
+    template <int OFF>
+    __device__ __forceinline__ void load_at(uint32_t base, float &anchor) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            asm volatile("ds_read_b128 %0, %2 offset:%3" : "=v"(q[i]), "+v"(anchor) : "v"(base), "n"(OFF + 32 + 16 * i));
+    }
     __device__ __forceinline__ void wait() {
         if (MTGS_EARLY_COLOR_LOAD) {
 #pragma unroll
@@ -238,10 +265,20 @@ __device__ __forceinline__ float *row_address(float *base, uint32_t row, uint32_
     return reinterpret_cast<float *>(addr);
 }
 constexpr float kHalfLog2e = 0.5f * 1.4426950408889634f;  // exp(-s2/2) = exp2(-s2 * log2(e)/2)
+// alpha = opacity * exp(-sigma) as a ROUNDED product: the reference rounds alpha before it forms 1 - alpha; left to the
+// compiler the product is contracted into 1 - opacity * e (one fma), which moves T by an ulp per Gaussian and doubles the
+// number of pixels whose T <= 1e-4 / alpha >= 1/255 decisions differ from the oracle's (measured at the headline size).
+__device__ __forceinline__ float alpha_rounded(float opac, float e) {
+#pragma clang fp contract(off)
+    return opac * e;
+}
 
 // ------------------------------------------------------------------------------------------------
+#ifndef MTGS_FWD_WAVES
+#define MTGS_FWD_WAVES 6
+#endif
 template <int D, int PPL, bool PK>
-__global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
+__global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 1) void blend_fwd_kernel(
     int C, const float *__restrict__ recs, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
@@ -264,15 +301,18 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     int iy[PPL];
     float py[PPL], T[PPL], acc[PPL][D];
     int32_t last[PPL];
-    // A finished pixel (T would drop to <= 1e-4, or outside the image) is marked by py = +inf: its
-    // quadratic form becomes inf/NaN and fails the validity test without a separate flag.
+    // Finished pixels (T would drop to <= 1e-4, or outside the image) are kept as one WAVE MASK per pixel slot -- an SGPR
+    // pair: removing them from a candidate's validity mask is a scalar AND, and a slot's updates are three selects under
+    // ONE mask {valid and not stopping} instead of the "alpha = 0 for invalid lanes" select plus four that froze a stopping
+    // pixel's weight / T / last index / finished flag (17 -> 15 VALU per slot).
+    unsigned long long done[PPL];
     bool inside[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
         iy[p] = ty * 16 + ly + p * ROWS;
         py[p] = (float)iy[p] + 0.5f;
         inside[p] = ix < W && iy[p] < H;
-        if (!inside[p]) py[p] = INFINITY;
+        done[p] = __ballot(!inside[p]);
         T[p] = 1.f;
         last[p] = 0;
 #pragma unroll
@@ -289,33 +329,37 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     for (int64_t b0 = start; b0 < end; b0 += CAND) {
         bool all_done = true;
 #pragma unroll
-        for (int p = 0; p < PPL; ++p) all_done = all_done && py[p] == INFINITY;
+        for (int p = 0; p < PPL; ++p) all_done = all_done && done[p] == ~0ull;
         if (__syncthreads_and(all_done)) break;
         int32_t g_cur[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, end - b0);
+        bool may_clamp;
         const int bsz = stage_batch<D, NT, CAND, false, CULL, PK>(s_rec, nullptr, s_wc, recs, means2d, conics, colors, depths, DC,
                                                               opacities, nullptr, g_cur, b0, n_cand, (float)(tx * 16),
-                                                              (float)(ty * 16));
+                                                              (float)(ty * 16), &may_clamp);
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (b0 + CAND + r * NT + tid < end) g_next[r] = flatten_ids[b0 + CAND + r * NT + tid];
         __syncthreads();
         // One staged entry against the lane's pixels; returns true once every pixel of the wave is finished.
-        auto entry = [&](const float4 &r0, const float4 &r1, const int t) -> bool {
+        // OFF / va: the entry's record is at LDS address va + OFF * REC * 4 (one address VGPR per pair of entries);
+        // CLAMP = false: no candidate of the batch can reach alpha = 0.999 (stage_batch).
+        auto entry = [&](const float4 &r0, const float4 &r1, const uint32_t va, auto off_tag, auto clamp_tag) -> bool {
+            constexpr int OFF = decltype(off_tag)::value;
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
             ColorRow<D, REC> col;
-            float mx = r0.x;
-            col.load(s_rec, t, mx);
-            const float dx = mx - px;
+            col.template load_at<OFF * REC * 4>(va, py[0]);
+            const float dx = r0.x - px;
             const float adx = r0.z * dx, bdx = r0.w * dx;
             const float q0 = adx * dx, b2dx = bdx + bdx;
             float s2[PPL];
             unsigned long long vmask[PPL], any = 0;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
-                s2[p] = eval_s2(q0, b2dx, r1.x, r0.y - py[p]);  // finished pixel: py = +inf -> s2 = +inf / NaN
-                vmask[p] = in_range_mask(s2[p], r1.z);
+                s2[p] = eval_s2(q0, b2dx, r1.x, r0.y - py[p]);
+                vmask[p] = in_range_mask(s2[p], r1.z) & ~done[p];
                 any |= vmask[p];
             }
             col.wait();
@@ -325,39 +369,59 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 if (vmask[p] != 0) {  // wave-uniform: skip the strips of the tile this Gaussian does not reach
-                    // invalid lanes run with alpha = 0: T, acc and last are unchanged, and T(1-0) > 1e-4
-                    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask[p]);
-                    const float alpha = valid ? fminf(kAlphaMax, r1.y * __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p])) : 0.f;
-                    const float next_T = T[p] * (1.f - alpha);
-                    const bool stop = next_T <= kTMin;
-                    stopped |= __builtin_amdgcn_ballot_w64(stop);
-                    const float w = stop ? 0.f : alpha * T[p];
+                    // every lane computes (an invalid lane's s2 is anything from a large number to NaN: its alpha is 0,
+                    // tiny or NaN and never used); the masks stay wave-uniform values in SGPRs
+                    const float e = __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]);
+                    const float alpha = CLAMP ? fminf(kAlphaMax, alpha_rounded(r1.y, e)) : alpha_rounded(r1.y, e);
+                    const float w = alpha * T[p];
+                    const float next_T = T[p] * (1.f - alpha);     // (the reference's expression: the T <= 1e-4 decision hangs on it)
+                    const unsigned long long sm = __builtin_amdgcn_fcmpf(next_T, kTMin, 5 /* FCMP_OLE */) & vmask[p];
+                    done[p] |= sm;
+                    stopped |= sm;
+                    // the Gaussian that would cross T = 1e-4 is not composited: lanes that are invalid or stopping keep
+                    // their state (weight 0: colour + 0)
+                    const bool upd = __builtin_amdgcn_inverse_ballot_w64(vmask[p] & ~sm);
+                    const float wu = upd ? w : 0.f;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) acc[p][k] += col[k] * w;
-                    last[p] = (valid && !stop) ? idx : last[p];
-                    T[p] = stop ? T[p] : next_T;
-                    py[p] = stop ? INFINITY : py[p];
+                    for (int k = 0; k < D; ++k) acc[p][k] = fmaf(col[k], wu, acc[p][k]);
+                    T[p] = upd ? next_T : T[p];
+                    last[p] = upd ? idx : last[p];
                 }
             }
             if (stopped) {
-                bool ad = true;
+                unsigned long long ad = done[0];
 #pragma unroll
-                for (int p = 0; p < PPL; ++p) ad = ad && py[p] == INFINITY;
-                if (__all(ad)) return true;
+                for (int p = 1; p < PPL; ++p) ad &= done[p];
+                return ad == ~0ull;
             }
             return false;
         };
         // Entries are consumed two per iteration from two alternating register sets (A, B): the record of the
         // next entry is in flight while the current one is processed, without register copies.
-        auto rec4 = [&](int t, int q) { return *reinterpret_cast<const float4 *>(s_rec + t * REC + 4 * q); };
-        float4 ra0 = rec4(0, 0), ra1 = rec4(0, 1), rb0 = ra0, rb1 = ra1;
-        for (int t = 0; t < bsz; t += 2) {
-            if (t + 1 < bsz) { rb0 = rec4(t + 1, 0); rb1 = rec4(t + 1, 1); }
-            if (entry(ra0, ra1, t)) break;
-            if (t + 1 >= bsz) break;
-            if (t + 2 < bsz) { ra0 = rec4(t + 2, 0); ra1 = rec4(t + 2, 1); }
-            if (entry(rb0, rb1, t + 1)) break;
-        }
+        auto run = [&](auto clamp_tag) {
+            using Z = std::integral_constant<int, 0>;
+            using O = std::integral_constant<int, 1>;
+            const uint32_t rec0 = lds_offset(s_rec);
+            auto rec_at = [&](uint32_t va, int q) {
+                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(va + 16 * q));
+                return make_float4(v.x, v.y, v.z, v.w);
+            };
+            uint32_t va;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0));
+            float4 ra0 = rec_at(va, 0), ra1 = rec_at(va, 1), rb0 = ra0, rb1 = ra1;
+            bool fin = false;     // (a single loop exit: with `break`s out of the entries the register allocator kept two
+                                  //  copies of the per-pixel state and moved 24 registers on every skipped candidate)
+            for (int t = 0; t < bsz && !fin; t += 2) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0 + (uint32_t)t * (REC * 4)));
+                if (t + 1 < bsz) { rb0 = rec_at(va, REC / 4); rb1 = rec_at(va, REC / 4 + 1); }
+                fin = entry(ra0, ra1, va, Z{}, clamp_tag);
+                if (t + 1 < bsz && !fin) {
+                    if (t + 2 < bsz) { ra0 = rec_at(va, 2 * (REC / 4)); ra1 = rec_at(va, 2 * (REC / 4) + 1); }
+                    fin = entry(rb0, rb1, va, O{}, clamp_tag);
+                }
+            }
+        };
+        if (may_clamp) run(std::true_type{}); else run(std::false_type{});
     }
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
@@ -394,8 +458,12 @@ struct GradLayout {
 
 // (second launch-bound argument = waves per SIMD the register allocator must leave room for: the
 //  one-wave-per-tile mapping is latency-sensitive, 5 waves/SIMD measured better than 4)
+#ifndef MTGS_BWD_WAVES
+#define MTGS_BWD_WAVES 4
+#endif
+
 template <int D, int PPL, bool PK>
-__global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend_bwd_kernel(
+__global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 1) void blend_bwd_kernel(
     int C, const float *__restrict__ recs, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
@@ -505,8 +573,10 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
 #pragma unroll
         for (int r = 0; r < NRD; ++r) g_cur[r] = g_next[r];
         const int n_cand = (int)min((int64_t)CAND, hi - start + 1);
+        bool may_clamp;
         const int bsz = stage_batch<D, NT, CAND, true, CULL, PK>(s_rec, s_id, s_wc, recs, means2d, conics, colors, depths, DC, opacities,
-                                                             row_index, g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16));
+                                                             row_index, g_cur, hi, n_cand, (float)(tx * 16), (float)(ty * 16),
+                                                             &may_clamp);
 #pragma unroll
         for (int r = 0; r < NRD; ++r)
             if (hi - CAND - r * NT - tid >= start) g_next[r] = flatten_ids[hi - CAND - r * NT - tid];
@@ -515,18 +585,23 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             for (int e = tid; e < NW * bsz * 4; e += NT) z[(e / (bsz * 4)) * (CAND * 4) + e % (bsz * 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        auto entry = [&](const float4 &r0, const float4 &r1, const int t) {
+        // One staged entry against the lane's pixels.  OFF = byte offset of the entry's record from the address in `va`
+        // (a VGPR shared by the two entries of an iteration: every LDS read of the loop is `va` / `vi` + an immediate),
+        // CLAMP = false: no candidate of the batch can reach alpha = 0.999 (stage_batch), so the clamp and the mask of
+        // its gradient are compiled out.
+        auto entry = [&](const float4 &r0, const float4 &r1, const int t, const uint32_t va, const uint32_t vi, auto off_tag,
+                         auto clamp_tag) {
+            constexpr int OFF = decltype(off_tag)::value;
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
             ColorRow<D, REC> col;
-            float mx = r0.x;
-            col.load(s_rec, t, mx);
+            // (the anchor of the hand-issued loads is the lane's first pixel y: the validity test below depends on it, so
+            //  the scheduler cannot sink the loads under the test, and no copy of a record register is needed)
+            col.template load_at<OFF * REC * 4>(va, py[0]);
             int32_t gid;  // Gaussian row for the atomics at the end of the entry, fetched the same way
-            if (MTGS_EARLY_COLOR_LOAD)
-                asm volatile("ds_read_b32 %0, %2" : "=v"(gid), "+v"(mx) : "v"(lds_offset(s_id + t)));
-            else
-                gid = s_id[t];
+            asm volatile("ds_read_b32 %0, %2 offset:%3" : "=v"(gid), "+v"(py[0]) : "v"(vi), "n"(OFF * 4));
             const int32_t idx = __float_as_int(r1.w);
             const float opac = r1.y;
-            const float dx = mx - px;
+            const float dx = r0.x - px;
             const float adx = r0.z * dx, bdx = r0.w * dx;
             const float q0 = adx * dx, b2dx = bdx + bdx;
             float dy[PPL], s2[PPL];
@@ -552,12 +627,13 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             for (int p = 0; p < PPL; ++p) {
                 // Wave-uniform branch per pixel slot; inside, invalid lanes run with vis = 0, hence alpha = 0
                 // (then 1/(1-alpha) == 1 exactly, fac == 0: T and Bq are unchanged and every contribution
-                // is 0), so there is no exec-mask divergence in the gradient math.
+                // is 0), so there is no exec-mask divergence in the gradient math (switching the lanes off instead
+                // saves the select but costs the explicit zeroing of ten accumulators per entry: measured worse).
                 if (vmask[p] != 0) {
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask[p]);
                     const float vis = valid ? __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]) : 0.f;
-                    const float alpha_raw = opac * vis;
-                    const float alpha = fminf(kAlphaMax, alpha_raw);
+                    const float alpha_raw = alpha_rounded(opac, vis);
+                    const float alpha = CLAMP ? fminf(kAlphaMax, alpha_raw) : alpha_raw;
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[p] *= ra;
                     const float fac = alpha * T[p];
@@ -571,14 +647,15 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
                     const float v_alpha = A * T[p] - ra * Bq[p];
                     Bq[p] += fac * A;
                     // alpha clamped at 0.999: no gradient through sigma / opacity (invalid lanes: vis == 0)
-                    const float g = alpha_raw <= kAlphaMax ? v_alpha : 0.f;
+                    const float g = (!CLAMP || alpha_raw <= kAlphaMax) ? v_alpha : 0.f;
                     const float v_sigma = -alpha_raw * g;
                     const float vsdy = v_sigma * dy[p];
                     S0 += v_sigma;
                     S1 += vsdy;
                     S2 += vsdy * dy[p];
-                    gv[2] += fabsf(v_sigma * fmaf(r0.w, dy[p], adx));   // |v_sigma u|,  u = a dx + b dy
-                    gv[3] += fabsf(v_sigma * fmaf(r1.x, dy[p], bdx));   // |v_sigma w|,  w = b dx + c dy
+                    // |v_sigma u|, u = a dx + b dy and |v_sigma w|, w = b dx + c dy  (|x| is a source modifier: 2 FMAs each)
+                    gv[2] = fmaf(fabsf(v_sigma), fabsf(fmaf(r0.w, dy[p], adx)), gv[2]);
+                    gv[3] = fmaf(fabsf(v_sigma), fabsf(fmaf(r1.x, dy[p], bdx)), gv[3]);
                     gv[7] += vis * g;
                 }
             }
@@ -611,16 +688,30 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? 5 : 1) void blend
             }
         };
         // Entries are consumed two per iteration from two alternating register sets (A, B): the record of the
-        // next entry is in flight while the current one is processed, without register copies.
-        auto rec4 = [&](int t, int q) { return *reinterpret_cast<const float4 *>(s_rec + t * REC + 4 * q); };
-        float4 ra0 = rec4(0, 0), ra1 = rec4(0, 1), rb0 = ra0, rb1 = ra1;
-        for (int t = 0; t < bsz; t += 2) {
-            if (t + 1 < bsz) { rb0 = rec4(t + 1, 0); rb1 = rec4(t + 1, 1); }
-            entry(ra0, ra1, t);
-            if (t + 1 >= bsz) break;
-            if (t + 2 < bsz) { ra0 = rec4(t + 2, 0); ra1 = rec4(t + 2, 1); }
-            entry(rb0, rb1, t + 1);
-        }
+        // next entry is in flight while the current one is processed, without register copies.  `va` / `vi` hold the
+        // LDS addresses of the pair's first record / row id.
+        auto run = [&](auto clamp_tag) {
+            using Z = std::integral_constant<int, 0>;
+            using O = std::integral_constant<int, 1>;
+            const uint32_t rec0 = lds_offset(s_rec), id0 = lds_offset(s_id);
+            auto rec_at = [&](uint32_t va, int q) {
+                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)(va + 16 * q));
+                return make_float4(v.x, v.y, v.z, v.w);
+            };
+            uint32_t va, vi;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0));
+            float4 ra0 = rec_at(va, 0), ra1 = rec_at(va, 1), rb0 = ra0, rb1 = ra1;
+            for (int t = 0; t < bsz; t += 2) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0 + (uint32_t)t * (REC * 4)));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(vi) : "s"(id0 + (uint32_t)t * 4));
+                if (t + 1 < bsz) { rb0 = rec_at(va, REC / 4); rb1 = rec_at(va, REC / 4 + 1); }
+                entry(ra0, ra1, t, va, vi, Z{}, clamp_tag);
+                if (t + 1 >= bsz) break;
+                if (t + 2 < bsz) { ra0 = rec_at(va, 2 * (REC / 4)); ra1 = rec_at(va, 2 * (REC / 4) + 1); }
+                entry(rb0, rb1, t + 1, va, vi, O{}, clamp_tag);
+            }
+        };
+        if (may_clamp) run(std::true_type{}); else run(std::false_type{});
         if (BATCH_FLUSH) {
             __syncthreads();
             for (int e = tid; e < bsz * 16; e += NT) {
