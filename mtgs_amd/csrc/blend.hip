@@ -35,6 +35,18 @@
 #include "wave_reduce.hpp"
 #include "raster_rec.hpp"
 
+#ifdef MTGS_COUNT   // development: scripts/build_variant.py count -DMTGS_COUNT; read with mtgs_blend_counters()
+__device__ unsigned long long g_blend_counters[8];
+#define MTGS_COUNT_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_blend_counters[i], (unsigned long long)(v)); } while (0)
+extern "C" int mtgs_blend_counters(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_counters), sizeof(g_blend_counters));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_blend_counters), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define MTGS_COUNT_ADD(i, v) do { } while (0)
+#endif
+
 namespace {
 
 constexpr float kAlphaMax = MTGS_ALPHA_MAX;
@@ -616,7 +628,13 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
             }
             col.wait();
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gid));
+            MTGS_COUNT_ADD(0, 1);
             if (any == 0) return;
+            MTGS_COUNT_ADD(1, 1);
+#ifdef MTGS_COUNT
+            { int ns = 0; for (int p = 0; p < PPL; ++p) ns += vmask[p] != 0; MTGS_COUNT_ADD(2, ns);
+              int nl = 0; for (int p = 0; p < PPL; ++p) nl += __popcll(vmask[p]); MTGS_COUNT_ADD(3, nl); }
+#endif
             float gv[4 * NR];
 #pragma unroll
             for (int k = 0; k < 4 * NR; ++k) gv[k] = 0.f;
