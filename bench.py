@@ -37,6 +37,19 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 DOMINANT = ("mtgs_blend_bwd_packed", "mtgs_blend_bwd")   # the compositing backward (packed-record / gather form)
+# every C-ABI entry point the step calls, with the kernels behind it (timed live in a second, untimed pass)
+ENTRY_POINTS = {
+    "mtgs_sh_fwd": ["sh_fwd_k16_kernel<3>"],
+    "mtgs_front_fwd": ["front_project_kernel", "front_compact_kernel"],
+    "mtgs_bin3_build": ["bin3_rows_count_kernel", "bin3_rows_place_kernel", "bin3_tiles_count_kernel", "bin3_tiles_place_kernel",
+                        "bin3_sort_small_kernel", "bin3_sort_large_kernel", "zero"],
+    "mtgs_blend_fwd_packed": ["blend_fwd_kernel<4, 4, true>"],
+    "mtgs_blend_bwd_packed": ["blend_bwd_kernel<4, 4, true>"],
+    "mtgs_project_bwd": ["project_bwd_vis_kernel", "project_bwd_expand_kernel"],
+    "mtgs_project_bwd_rows": ["project_bwd_rows_kernel"],
+    "mtgs_sh_bwd": ["sh_bwd_kernel<3>"],
+    "mtgs_dp_reduce": ["dp_reduce_kernel"],
+}
 
 
 def parse_args():
@@ -253,7 +266,7 @@ def cpu_baseline(args, host, steps):
 def main():
     args = parse_args()
     from mtgs_amd import _lib, dist as mdist
-    rank, local_rank, world = mdist.init_from_env()
+    rank, local_rank, world = mdist.init_from_env(timeout_s=300.0)
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -267,21 +280,54 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
+    def fail(where, exc):
+        """A failed step (a collective that errors out or times out, a kernel error): say WHICH phase, exit non-zero.  No
+        in-process restart -- a process that has touched the GPU is never re-exec'ed; retry = a fresh launch, e.g. with
+        --dp-exchange dense."""
+        ex = info_box.get("exchange")
+        phase = ex.phase if ex is not None else ("dense all-reduce" if world > 1 else "single GPU")
+        print(json.dumps({"bench_error": f"{type(exc).__name__}: {exc}"[:600], "during": where, "exchange_phase": phase, "rank": rank,
+                          "world": world, "dp_exchange": args.dp_exchange if world > 1 else None}), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    try:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+    except Exception as e:      # noqa: BLE001
+        fail("warm-up", e)
     _lib.time_calls(DOMINANT)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
+    try:
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+    except Exception as e:      # noqa: BLE001
+        fail("timed steps", e)
     elapsed = time.perf_counter() - t0
     kernel_ms = [t for name in DOMINANT for t in _lib.timed_ms().get(name, [])]
     _lib.time_calls(())
+    # per-rank phase breakdown of the last timed step (N > 1), read before anything else touches the events
+    rank_phases = None
+    if world > 1:
+        evs = info_box["events"]
+        torch.cuda.synchronize()
+        rank_phases = {"render": evs["start"].elapsed_time(evs["rows"]), "exchange": evs["rows"].elapsed_time(evs["end"])}
+        if info_box["exchange"] is not None:
+            rank_phases.update(info_box["exchange"].phases_ms())
+    # second, UNTIMED pass: every entry point of the step bracketed by HIP events on the launch stream (the events
+    # serialise nothing, but they are kept out of the headline figure)
+    _lib.time_calls(tuple(ENTRY_POINTS))
+    for _ in range(min(args.steps, 8)):
+        step()
+    torch.cuda.synchronize()
+    entry_ms = {n: v for n, v in _lib.timed_ms().items() if v}
+    _lib.time_calls(())
+    barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -329,38 +375,58 @@ def main():
     step_bytes = b_fwd + b_bwd
     k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     achieved = bytes_bwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    # counter-based traffic (and VALU-busy fraction) per kernel: committed rocprofv3 --pmc passes of THIS command on the
-    # headline workload (scripts/pmc_step.sh -> profiles/r02_pmc_step.json; FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated there)
+    # algorithmic HBM bytes per launch of every kernel of the step, from THIS run's (N, n_vis, M)
+    Ksh_ = 16
+    alg = {
+        "sh_fwd_k16_kernel<3>": N * (12 + 12 * Ksh_ + 12),
+        "sh_bwd_kernel<3>": N * (24 + 12 * Ksh_),
+        "front_project_kernel": N * (40 + 4 + 40),
+        "front_compact_kernel": N * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
+        "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
+        "project_bwd_expand_kernel": N * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
+        "bin3_rows_count_kernel": n_vis * 64,
+        "bin3_rows_place_kernel": n_vis * 64 + n_items * 8,
+        "bin3_tiles_count_kernel": n_items * 8,
+        "bin3_tiles_place_kernel": n_items * (8 + 4) + M * 8,
+        "bin3_sort_small_kernel": M * (8 + 4 + 4 + 4 + 8),
+        "blend_fwd_kernel<4, 4, true>": M * (4 + 64) + P * (4 * D + 8),
+        "blend_bwd_kernel<4, 4, true>": bytes_bwd,
+    }
+    # (1) measured in THIS run: HIP events around every C-ABI entry point of the step (second, untimed pass)
+    entry_points = []
+    for name, kerns in ENTRY_POINTS.items():
+        v = entry_ms.get(name)
+        if not v:
+            continue
+        a_bytes = sum(alg.get(k, 0) for k in kerns)
+        us = sum(v) / len(v) * 1e3
+        entry_points.append({"entry_point": name, "kernels": kerns, "avg_us_live": round(us, 2), "launches_timed": len(v),
+                             "algorithmic_bytes": int(a_bytes) if a_bytes else None,
+                             "frac_of_peak_algorithmic": round(a_bytes / us / 1e3 / HBM_PEAK_GBS, 4) if a_bytes else None})
+    # (2) counter-based traffic and VALU-busy fraction per kernel: COMMITTED rocprofv3 --pmc passes of this command on the
+    # headline workload (scripts/pmc_step.sh -> profiles/rNN_pmc_step.json, FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated there).
+    # They are builder-held numbers echoed into this line, labelled as such, and dropped when the file was made with
+    # another ABI version of the library than the one running.
     traffic = valu_busy = None
-    kernels = []
-    pmc = ROOT / "profiles" / "r02_pmc_step.json"
-    if pmc.exists() and (args.n_gaussians, args.width, args.height, args.variant) == (2_000_000, 1920, 1080, "mtgs"):
+    kernels, counters_from = [], None
+    headline = (args.n_gaussians, args.width, args.height, args.variant) == (2_000_000, 1920, 1080, "mtgs")
+    for pmc in sorted((ROOT / "profiles").glob("r*_pmc_step.json"), reverse=True):
+        if not headline:
+            break
         try:
-            rec = json.loads(pmc.read_text())["kernels"]
-            Ksh_ = 16
-            alg = {   # algorithmic HBM bytes per launch of the streaming kernels
-                "sh_fwd_k16_kernel<3>": args.n_gaussians * (12 + 12 * Ksh_ + 12),
-                "sh_bwd_kernel<3>": args.n_gaussians * (24 + 12 * Ksh_),
-                "front_project_kernel": args.n_gaussians * (40 + 4 + 40),
-                "front_compact_kernel": args.n_gaussians * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
-                "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
-                "project_bwd_expand_kernel": args.n_gaussians * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
-                "bin3_rows_count_kernel": n_vis * 64,
-                "bin3_rows_place_kernel": n_vis * 64 + n_items * 8,
-                "bin3_tiles_count_kernel": n_items * 8,
-                "bin3_tiles_place_kernel": n_items * (8 + 4) + M * 8,
-                "bin3_sort_small_kernel": M * (8 + 4 + 4 + 4 + 8),
-                "blend_fwd_kernel<4, 4, true>": M * (4 + 64) + P * (4 * D + 8),
-                "blend_bwd_kernel<4, 4, true>": bytes_bwd,
-            }
+            doc = json.loads(pmc.read_text())
+            if doc.get("abi_version") != _lib.ABI_VERSION:
+                continue
+            rec = doc["kernels"]
             for name, a_bytes in alg.items():
                 r = rec.get(name)
-                if r and r.get("avg_us"):
-                    kernels.append({"kernel": name, "algorithmic_bytes": int(a_bytes), "counter_bytes": r["hbm_bytes"],
-                                    "avg_us": r["avg_us"], "frac_of_peak_algorithmic": round(a_bytes / r["avg_us"] / 1e3 / HBM_PEAK_GBS, 4),
-                                    "frac_of_peak_counter": r.get("frac_of_8TBs"), "valu_busy_frac": r.get("valu_busy_frac")})
+                if r and r.get("hbm_bytes"):
+                    kernels.append({"kernel": name, "algorithmic_bytes": int(a_bytes), "counter_bytes_committed": r["hbm_bytes"],
+                                    "avg_us_committed": r.get("avg_us"), "valu_busy_frac_committed": r.get("valu_busy_frac")})
             dom = rec.get("blend_bwd_kernel<4, 4, true>", {})
             traffic, valu_busy = dom.get("hbm_bytes"), dom.get("valu_busy_frac")
+            counters_from = pmc.name
+            break
         except Exception:
             traffic = valu_busy = None
             kernels = []
@@ -385,32 +451,48 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
                      "launches_timed": len(kernel_ms),
-                     "note": "kernel is VALU bound, not HBM bound (DESIGN.md section 4); valu_busy_frac = SQ_ACTIVE_INST_VALU*4/1024 "
-                             "over GRBM_GUI_ACTIVE/8 from the committed rocprofv3 --pmc passes of this workload",
+                     "note": "kernel is VALU bound, not HBM bound (DESIGN.md section 4); avg_launch_ms is measured in this run; traffic and "
+                             "valu_busy_frac (SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8) come from the committed rocprofv3 "
+                             "--pmc passes named in counters_from (null when none matches this library's ABI version)",
+                     "counters_from": counters_from,
                      # (the two counters come from different blocks of the chip: a ratio a percent above 1 is "busy throughout")
                      "valu_busy_frac": None if valu_busy is None else min(1.0, valu_busy), "valu_busy_raw": valu_busy,
+                     "entry_points": entry_points,
+                     "entry_points_note": "measured in THIS run: HIP events on the launch stream around every C-ABI entry point of the "
+                                          "step, in a second untimed pass; algorithmic bytes from this run's (N, n_vis, M)",
                      "kernels": kernels,
-                     "kernels_note": "per kernel of the step: algorithmic bytes of THIS run's (N, n_vis, M), counter bytes / avg_us / "
-                                     "VALU-busy from the committed profiles (profiles/r02_pmc_step.json, r02_bench_kernel_stats.csv)",
+                     "kernels_note": "per kernel: algorithmic bytes of this run; *_committed = builder-held rocprofv3 numbers from "
+                                     "counters_from, not measured in this run",
                      "whole_step": {"algorithmic_bytes": step_bytes, "unit": "GB/s",
                                     "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "formula": "SURVEY.md section 8(d) B_F + B_B"}},
     }
     if world > 1:
-        # phase breakdown of the LAST timed step on this rank (HIP events; phases overlap by design, so they do not add up
-        # to ms_per_step): render = forward + backward up to the wire rows (dense: up to the local gradients), meta =
-        # all-gather of the visibility maps on the side stream (hidden behind the compositing), wire = first row
-        # all-gather issued -> last complete, reduce = the reduction kernels, exchange = rows ready -> gradients ready
-        evs = info_box["events"]
-        torch.cuda.synchronize()
-        phases = {"render": round(evs["start"].elapsed_time(evs["rows"]), 3),
-                  "exchange": round(evs["rows"].elapsed_time(evs["end"]), 3)}
-        if info_box["exchange"] is not None:
-            phases.update({k: round(v, 3) for k, v in info_box["exchange"].phases_ms().items()})
-        out["dp_phases_ms"] = phases
+        # phase breakdown of the LAST timed step (HIP events; phases overlap by design, so they do not add up to
+        # ms_per_step): render = forward + backward up to the wire rows (dense: up to the local gradients), meta = all-gather
+        # of the visibility maps on the side stream (hidden behind the compositing), wire = first row all-gather issued ->
+        # last complete, reduce = the reduction kernels, exchange = rows ready -> gradients ready.  Reduced over the ranks:
+        # a straggler shows up as a max far above the min.
+        keys = sorted(rank_phases)
+        mine = torch.tensor([rank_phases[k] for k in keys] + [float(n_vis), float(info_box["grad_bytes"])], dtype=torch.float64,
+                            device=device)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        table = torch.stack(allr).cpu()
+        out["dp_phases_ms"] = {k: round(float(table[0, i]), 3) for i, k in enumerate(keys)}       # rank 0 (as in round 2)
+        out["dp_phases_ms_max"] = {k: round(float(table[:, i].max()), 3) for i, k in enumerate(keys)}
+        out["dp_phases_ms_min"] = {k: round(float(table[:, i].min()), 3) for i, k in enumerate(keys)}
+        out["dp_n_visible_per_rank"] = [int(v) for v in table[:, len(keys)]]
+        out["dp_bytes_received_per_rank"] = [int(v) for v in table[:, len(keys) + 1]]
         out["dp_world_size"] = torch.distributed.get_world_size()
         out["dp_backend"] = torch.distributed.get_backend()
+        try:
+            out["dp_rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:       # noqa: BLE001
+            out["dp_rccl_version"] = None
+        out["dp_env"] = {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_P2P_LEVEL", "NCCL_MIN_NCHANNELS",
+                                                       "HSA_ENABLE_IPC_MODE_LEGACY", "MTGS_DIST_BACKEND")}
     if fwd_ms is not None:
         out["also"] = {"fwd_only_ms": round(fwd_ms, 3), "fwd_only_mpix_s": round(P / fwd_ms / 1e3, 1),
                        "gaussians_per_s_fwd_bwd": round(world * args.n_gaussians / (ms_per_step * 1e-3), 0)}

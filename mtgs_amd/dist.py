@@ -19,9 +19,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None) -> tuple:
     """Initialises torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
-    Returns (rank, local_rank, world_size).  A single process (no env) returns (0, 0, 1)."""
+    Returns (rank, local_rank, world_size).  A single process (no env) returns (0, 0, 1).
+    timeout_s: collective timeout (a rank that never arrives then fails the job instead of hanging it)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -36,6 +37,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        if timeout_s is not None:
+            import datetime
+            kwargs["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
 
@@ -160,6 +164,9 @@ class SparseGradExchange:
         self.N, self.K, self.device, self.group = int(n_gaussians), int(n_sh_bases), device, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # tests: issue the collectives also in a one-rank group (normally short-cut), so that the RCCL code path of the
+        # integrated form executes on a single-GPU box
+        self.world_collectives = False
         N = self.N
         # chunk boundaries of the index range (multiples of 2048, so that they are visibility-word and tile aligned)
         per = -(-max(N, 1) // max(int(chunks), 1))
@@ -187,6 +194,7 @@ class SparseGradExchange:
             self._samples_host = self._samples_host.pin_memory()
         self.comm_stream = torch.cuda.Stream(device) if is_cuda else None
         self.last_bytes = 0
+        self.phase = "idle"      # where the exchange is: named by bench.py / the harness when a collective fails
         self._pending = None
         self._events = {}
         self.grad_rows = self.vis_ids = None
@@ -213,6 +221,7 @@ class SparseGradExchange:
         self.meta[1:4].copy_(cam_pos.reshape(3).to(torch.float32).contiguous().view(torch.int32))
         self.meta[self.meta_len - 2:self.meta_len - 1].fill_(int(traversal))
         self._pending = {"stage": "forward"}
+        self.phase = "render (forward; meta all-gather on the side stream)"
         render, alphas, m = fused_rasterization(
             means, quats, scales, opacities, sh_out.detach().unsqueeze(0), viewmats, Ks, None, width, height, eps2d,
             near_plane, far_plane, radius_clip, rasterize_mode == "antialiased", render_mode != "RGB",
@@ -241,7 +250,7 @@ class SparseGradExchange:
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
             t0.record()
-            if self.world > 1:
+            if self.world > 1 or self.world_collectives:
                 metas = torch.empty((self.world, self.meta_len), dtype=torch.int32, device=self.device)
                 dist.all_gather_into_tensor(metas, self.meta[None], group=self.group)
             else:
@@ -256,6 +265,7 @@ class SparseGradExchange:
     def after_backward(self, n_vis, grad_rows, vis_ids):
         assert self._pending is not None and self._pending["stage"] == "meta", "rasterization() of this exchange first"
         self._pending.update(stage="rows", n_vis=int(n_vis))
+        self.phase = "render done (wire rows written)"
         self.n_vis = int(n_vis)
         # the compact gradient rows of this frame: what mtgs_amd.densify.update_statistics_rows reads (no dense means2d
         # gradient exists in this mode)
@@ -271,6 +281,7 @@ class SparseGradExchange:
         N, K, dev, world, nw = self.N, self.K, self.device, self.world, self.n_words
         means = means.detach().contiguous()
         st = stream_of(means)
+        self.phase = "exchange: waiting for the meta all-gather (visibility maps)"
         P["done"].synchronize()          # side stream only: finished while the frame was composited
         samples = self._samples_host.numpy()
         metas = P["metas"]
@@ -295,7 +306,8 @@ class SparseGradExchange:
         self.last_bytes = 0
         for c in range(self.n_chunks):
             cap = max(max(starts[r][c + 1] - starts[r][c] for r in range(world)), 1)
-            if world > 1:
+            self.phase = f"exchange: issuing the row all-gather of chunk {c} of {self.n_chunks} ({cap} rows per rank)"
+            if world > 1 or self.world_collectives:
                 recv = torch.empty((world, cap, self.ROW), dtype=torch.float32, device=dev)
                 s0 = starts[self.rank][c]
                 works.append(dist.all_gather_into_tensor(recv.view(world * cap, self.ROW), self.rows[s0:s0 + cap],
@@ -308,6 +320,7 @@ class SparseGradExchange:
             caps.append(cap)
         self.last_bytes += world * self.meta_len * 4 if world > 1 else 0
         for c in range(self.n_chunks):
+            self.phase = f"exchange: wire + reduction of chunk {c} of {self.n_chunks}"
             if works[c] is not None:
                 works[c].wait()
             if c == self.n_chunks - 1:
@@ -316,18 +329,19 @@ class SparseGradExchange:
             e0.record()
             if T == 1:
                 call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4,
-                     ptr(recvs[c]), caps[c] * self.ROW if world > 1 else 0, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]),
-                     ptr(out[3]), ptr(out[4]), self.bounds[c], self.bounds[c + 1], st)
+                     ptr(recvs[c]), caps[c] * self.ROW if (world > 1 or self.world_collectives) else 0, ptr(cams), ptr(out[0]),
+                     ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), self.bounds[c], self.bounds[c + 1], st)
             else:
                 import ctypes as _C
                 for t in range(T):      # one pass per traversal's slice; the first also sums the geometry over all senders
                     call("mtgs_dp_reduce_slices", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all),
-                         self.meta_len * 4, ptr(recvs[c]), caps[c] * self.ROW if world > 1 else 0, ptr(cams), ptr(out[0]),
+                         self.meta_len * 4, ptr(recvs[c]), caps[c] * self.ROW if (world > 1 or self.world_collectives) else 0, ptr(cams), ptr(out[0]),
                          ptr(out[1]), ptr(out[2]), ptr(out[3]), out[4].data_ptr() + t * K * 3 * 4, self.bounds[c],
                          self.bounds[c + 1], _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
             e1.record()
             red.append((e0, e1))
         self._events.update(wire=(w0, w1), reduce=red)
+        self.phase = "idle"
         return out
 
     def phases_ms(self) -> dict:

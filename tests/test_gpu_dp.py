@@ -365,3 +365,53 @@ def test_configs3_full_size_gradient_sums_vs_oracle(tmp_path, hip_lib):
     REPORT.extend(out["report"])
     assert not out["failures"], out["failures"]
     assert len([r for r in out["report"] if r["kind"] == "gradient"]) == 5
+
+
+def _worker_nccl_world1(out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from mtgs_amd import dist as mdist, spherical_harmonics
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    N, W, H, K = 20_000, 320, 240, 16
+    sc = make_scene(N, seed=7, sh_degree=3, extent=(12.0, 4.0, 12.0))
+    vm, Kmat = make_camera(W, H)
+    P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    cam_pos = torch.inverse(vm)[0, :3, 3].to(dev)
+    ex = mdist.SparseGradExchange(N, K, dev, chunks=2)
+    ex.world_collectives = True            # a one-rank group short-cuts the collectives: take their code path anyway
+    sh = spherical_harmonics(3, P["means"].detach() - cam_pos, P["coeffs"].detach())
+    g = torch.Generator().manual_seed(1)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=g).to(dev), torch.randn(1, H, W, 1, generator=g).to(dev)
+    r_, a_, info = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm.to(dev), Kmat.to(dev), W, H, cam_pos)
+    torch.autograd.backward([r_, a_], [Gc, Ga])
+    sums = ex.finish(P["means"], 3)
+    t = torch.ones(1024, device=dev)
+    dist.all_reduce(t)                      # and a plain RCCL all-reduce (the dense exchange's collective)
+    torch.cuda.synchronize()
+    ok = bool(torch.isfinite(sums[0]).all()) and float(t.sum()) == 1024.0 and float(sums[0].abs().max()) > 0
+    ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    with open(out_path, "w") as f:
+        f.write(f"{int(ok)} {ver} {dist.get_backend()}")
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_runs_once_on_the_box(tmp_path, hip_lib):
+    """The first execution of the RCCL path itself: a one-rank `nccl` process group on the test box's GPU, the sparse
+    exchange with its side-stream all-gathers FORCED onto the collectives (world = 1 normally short-cuts them), and one
+    plain all-reduce.  No scaling is measured here -- only that the library loads, the communicator initialises and the
+    collectives the N > 1 run issues complete on this image."""
+    import subprocess
+    code = (f"import sys; sys.path.insert(0, {str(ROOT)!r}); from tests.test_gpu_dp import _worker_nccl_world1; "
+            f"_worker_nccl_world1({str(tmp_path / 'out.txt')!r})")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    ok, ver, backend = (tmp_path / "out.txt").read_text().split()
+    assert ok == "1" and backend == "nccl", (ok, ver, backend)
+    from tests.util import REPORT
+    REPORT.append({"kind": "dp", "name": "one-rank RCCL process group: sparse exchange (forced collectives) + all-reduce", "rccl_version": ver})

@@ -263,3 +263,48 @@ def test_mtgs_like_training_shipped_options_under_the_sparse_exchange():
     curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
     a, b = curve(sp.stdout), curve(one.stdout)
     assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
+
+
+def test_configs4_at_its_own_scale_eight_ranks_on_one_gpu():
+    """BASELINE configs[4] at its own scale: the MTGS-style training loop (shared static background with per-traversal
+    appearance + road node, shipped option set, device-side refinement, fused Adam) on a 2M-Gaussian scene with four
+    traversals at MTGS's training size 960x540, eight ranks -- one camera per rank and step, two ranks per traversal -- through
+    the sparse gradient exchange; the ranks share the test box's one GPU and gloo stands in for RCCL.  Two refinements: N must
+    be identical on every rank, and sizes and loss curve must equal the single-process run that renders the eight cameras of
+    every step one after the other and accumulates (parity for the data-parallel step; reference loop
+    mtgs_scene_graph.py:547-708, 1157-1183, sampler.py:27-58)."""
+    import json
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    # (2M Gaussians: the script's default 1.6M + 0.4M.  Four traversals, two ranks per traversal and step: with eight, the
+    #  per-traversal coefficients, their moments and gradients are 32 GB per rank and eight ranks do not fit the ONE GPU they share
+    #  here -- on eight GPUs they would)
+    common = ["--traversals", "4", "--width", "960", "--height", "540", "--steps", "24", "--refine-every", "10", "--reps", "1",
+              "--only", "fused", "--shipped"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), str(root / "scripts" / "mtgs_like_train.py"), "--dp",
+                         "--dp-exchange", "sparse"] + common, capture_output=True, text=True, timeout=2400, env=env, cwd=str(root))
+    assert sp.returncode == 0, sp.stdout[-1500:] + sp.stderr[-2500:]
+    one = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py"), "--accumulate", "8"] + common,
+                         capture_output=True, text=True, timeout=2400, cwd=str(root))
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-2500:]
+    sizes = lambda out: re.findall(r"refine (\d+) -> (\d+) Gaussians", out)
+    assert "8 ranks: N = " in sp.stdout and sizes(sp.stdout) == sizes(one.stdout) and len(sizes(sp.stdout)) == 2, \
+        (sizes(sp.stdout), sizes(one.stdout))
+    assert int(sizes(sp.stdout)[0][0]) == 2_000_000
+    curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
+    a, b = curve(sp.stdout), curve(one.stdout)
+    assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
+    from tests.util import REPORT
+    for tag, out in (("8 ranks on one GPU over gloo, sparse exchange", sp.stdout), ("one process, 8 cameras accumulated", one.stdout)):
+        m = re.search(r"timing: ([\d.]+) ms per step .* phases_ms (\{.*\})", out)
+        REPORT.append({"kind": "dp", "name": f"configs[4] at its own scale (2M Gaussians, 4 traversals, 960x540, shipped options): {tag}",
+                       "ms_per_step": float(m.group(1)) if m else None, "phases_ms": json.loads(m.group(2)) if m else None,
+                       "sizes": sizes(out), "loss_curve": curve(out)})
