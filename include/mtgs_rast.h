@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 11
+#define MTGS_RAST_ABI_VERSION 12
 
 enum {
     MTGS_OK = 0,
@@ -270,11 +270,13 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  *   recs[cap_vis,16] f32  packed record: x y | conic a b c | opacity_eff | s2max = 2 ln(255 opacity_eff) | radius (i32 bits)
  *                         | colours[D] (from colors[C*N,D]), depth (if with_depth), zeros   (D + with_depth <= 8)
  *   vis_ids[cap_vis] i32  flat index;  vis_keys[cap_vis] i64 = tile count << 40 | camera << 32 | bits(depth)
- *   vis_rank[C*N] i32     rank of every visible pair (dense; culled entries unspecified)
+ *   vis_rank[C*N] i32     rank of every visible pair (dense; -1 for culled pairs: the row map of mtgs_adam_step)
  *   dp_words[ceil(C*N/64)] u64, dp_prefix[ceil(C*N/64)] u32 (both nullable): visibility bitmap and rank of the first
  *                         pair of each word (the map mtgs_dp_reduce reads); dp_count[1] i32 (nullable) = n_vis
  *   color_mode            0: colours as given; 1: the first three channels are SH output x, blended as
- *                         clamp(x + 0.5, 0, 1) (MTGS's colour activation, vanilla_gaussian_splatting.py:318)
+ *                         clamp(x + 0.5, 0, 1) (MTGS's colour activation, vanilla_gaussian_splatting.py:318);
+ *                         2: the first three channels of the records are left open for mtgs_vis_color_fwd (colours of the
+ *                         visible Gaussians only); `colors` then holds the OTHER D - 3 channels [C*N, D - 3] (nullable when D = 3)
  *   totals[1] i64 (device) = n_vis << 32 | M; host_totals (nullable): PINNED HOST int64[2], receives {totals, host_tag}
  *   as soon as the last block finishes (system-scope release store), so the host can poll instead of synchronising.
  *   M = 2^31 - 1 signals more than 2^31 - 2 intersections (or an internal failure): the frame cannot be rendered.
@@ -434,7 +436,8 @@ typedef struct mtgs_node_desc {
     int32_t k_rest, use_sh, n_traversals, traversal;
     int32_t pose_normalize;    /* 1: `pose` is a raw row of the per-frame parameters instance_quats[frame]: the kernel normalises
                                 * it as RigidSubModel.get_object_pose does (rigid_node.py:142) */
-    int32_t reserved;
+    int32_t skip_colors;       /* 1: geometry only (no coefficient reads, no rgbs / clamp_mask writes): the colours of the VISIBLE
+                                * Gaussians are evaluated by mtgs_vis_color_fwd from this same table */
     float *scales, *quats, *opacities, *rgbs;               /* forward outputs = activations saved for the backward */
     uint8_t *clamp_mask;
     float *means_out;          /* global means (written when non-NULL) */
@@ -584,6 +587,25 @@ int mtgs_l1_fwd(int width, int height, int channels, const float *gt, const floa
 int mtgs_l1_bwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
                 const float *v_out, const float *fwd_out, float *v_pred, void *stream);
 
+/* ---- colours of the VISIBLE Gaussians only (visibility-first node path) ------------------------------------------------
+ * MTGS evaluates SH + clamp for every Gaussian of every node each step (vanilla_gaussian_splatting.py:309-322,
+ * multi_color_gaussian_splatting.py:77-101) although a camera sees ~15 % of a road block; gsplat's own sh_degree path masks
+ * SH with radii > 0 (rendering.py).  Here the node kernels run geometry-only (mtgs_node_desc.skip_colors) and, after
+ * mtgs_front_fwd (called with color_offset = 3: the first three channels of the records are left open), this call fills
+ * them for the n_vis = totals >> 32 visible Gaussians: Gaussian g = vis_ids[r] belongs to the node with start <= g < start + n
+ * (table sorted by start: the collected order); colour = clamp(SH_degree(normalize(means[g] - cam_pos), coefficients) + 0.5,
+ * 0, 1) for use_sh = 1, sigmoid(features_dc [+ dc_add]) for use_sh = 0, coefficients read in place through the node's row
+ * strides.  vis_mask[r] = the clamp's pass-through bits.  C = 1.  `means` = the collected (global) means [N,3].
+ * bwd: v_rgb = grad_rows[r * row_stride + col .. + 2] (the compositing backward's compact rows) -> feat_rows[r, 48] =
+ * d L / d coefficient k, channel c at [3 k + c] (k = 0: features_dc (and the adapter), k >= 1: features_rest[k - 1]; zeros above the
+ * degree in use): the gradient of the VISIBLE rows only -- consumed as rows by mtgs_adam_step, never expanded. */
+int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                       const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
+                       void *stream);
+int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                       const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
+                       int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows, void *stream);
+
 /* ---- SURVEY.md section 8f, rank 2 (second half): the optimizer step of every Gaussian parameter group in ONE launch ----
  * Reference: one torch.optim.Adam per parameter group with one tensor each (mtgs/scene_model/custom_trainer.py:115-136;
  * groups, learning rates and eps = 1e-15 in mtgs/config/MTGS.py:121-181); the densification moves the moments with their
@@ -607,7 +629,11 @@ typedef struct mtgs_adam_group {
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
     int32_t width, row_col;
-    int32_t vec_ok, reserved;
+    int32_t vec_ok;
+    int32_t sub_width, sub_index;   /* sub_width > 0: an item is `width / sub_width` slices of sub_width floats (a per-traversal
+                                     * tensor [N, T, ...]); only slice sub_index takes the row's gradient
+                                     * rows[.., row_col + e % sub_width], the other slices get zero */
+    int32_t reserved;
     float one_minus_beta1, beta2, one_minus_beta2;   /* 1 - beta rounded from double by the caller (1 - 0.999f is 5e-5 off) */
     float eps, weight_decay, grad_scale;
 } mtgs_adam_group;

@@ -111,6 +111,8 @@ _SIGNATURES = {
     "mtgs_l1_workspace_floats": [_i32, _i32, C.POINTER(_sz)],
     "mtgs_l1_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_l1_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "mtgs_adam_group_bytes": [],
     "mtgs_adam_block_elems": [],
     "mtgs_adam_step": [_i32, _vp, _vp, _i64, _i32, _vp],
@@ -121,7 +123,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 

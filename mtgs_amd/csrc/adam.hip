@@ -11,7 +11,8 @@
 //   rows   rows[row_of[i] * row_stride + col + c], i = e / width, c = e % width, row_of[i] < 0 -> 0
 //          -- compact gradient rows of the VISIBLE Gaussians (the rasterizer's backward works per visible Gaussian; a frame
 //          sees ~15 % of a road block).  Culled Gaussians get the exact zero-gradient update (their moments decay, the
-//          parameter keeps moving along exp_avg) without a dense gradient tensor ever being written or read.
+//          parameter keeps moving along exp_avg) without a dense gradient tensor ever being written or read; for a
+//          per-traversal tensor [N, T, ...] only the slice of the frame's traversal takes the row (sub_width / sub_index).
 //
 // Arithmetic = torch.optim.Adam (amsgrad = False, maximize = False), fp32, in torch's operation order:
 //   g += weight_decay * p;  m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g;
@@ -70,10 +71,17 @@ __device__ __forceinline__ void st4(float *p, float4 r) {
     *reinterpret_cast<float4 *>(p) = r;
 }
 
-// gradient of element e of a rows-source group (i = e / width tracked incrementally by the caller)
+// gradient of element e of a rows-source group (i = e / width tracked incrementally by the caller).  sub_width > 0: the
+// item is width / sub_width slices (a per-traversal tensor [N, T, ...]) and only slice sub_index has a gradient.
 __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, int c) {
     const int32_t r = d.row_of[i];
-    return r < 0 ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c];
+    if (r < 0) return 0.f;
+    if (d.sub_width > 0) {
+        const int s = c / d.sub_width;
+        if (s != d.sub_index) return 0.f;
+        c -= s * d.sub_width;
+    }
+    return d.rows[(int64_t)r * d.row_stride + d.row_col + c];
 }
 
 template <bool NT>

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                 a.dp_prefix[idx >> 6] = (uint32_t)rank;   // lane 0: number of visible pairs in front of this word
             }
         }
+        if (idx < total) a.vis_rank[idx] = vis ? (int32_t)rank : -1;
         if (vis) {
-            a.vis_rank[idx] = (int32_t)rank;
             if (rank < a.cap_vis) {
                 const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[idx];
                 const F3 con = *reinterpret_cast<const F3 *>(a.conics + idx * 3);
@@ -172,9 +172,15 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                 float ch[REC_MAX_CHANNELS];
 #pragma unroll
                 for (int k = 0; k < REC_MAX_CHANNELS; ++k) ch[k] = 0.f;
+                if (a.color_mode == 2) {   // channels 0..2 are filled later (viscolor.hip); `colors` holds channels 3 .. DC - 1
 #pragma unroll
-                for (int k = 0; k < REC_MAX_CHANNELS; ++k)
-                    if (k < a.DC) ch[k] = a.colors[idx * a.DC + k];
+                    for (int k = 3; k < REC_MAX_CHANNELS; ++k)
+                        if (k < a.DC) ch[k] = a.colors[idx * (a.DC - 3) + (k - 3)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < REC_MAX_CHANNELS; ++k)
+                        if (k < a.DC) ch[k] = a.colors[idx * a.DC + k];
+                }
                 if (a.color_mode == 1) {   // MTGS's colour activation on SH output: clamp(x + 0.5, 0, 1), first 3 channels
 #pragma unroll
                     for (int k = 0; k < 3; ++k) ch[k] = fminf(fmaxf(ch[k] + 0.5f, 0.f), 1.f);
@@ -262,12 +268,13 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
         return MTGS_OK;
     }
     MTGS_REQUIRE(total < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_front_fwd: C*N must fit int32 (flatten_ids are int32)");
-    MTGS_REQUIRE(means && quats && scales && viewmats && Ks && opacities && (colors || D == 0) && radii && means2d &&
+    MTGS_REQUIRE(means && quats && scales && viewmats && Ks && opacities && (colors || D == 0 || (color_mode == 2 && D == 3)) && radii && means2d &&
                      depths && conics && opac_eff && tiles_per_gauss && recs && vis_ids && vis_keys &&
                      vis_rank && ws,
                  MTGS_EINVAL, "mtgs_front_fwd: null pointer");
     MTGS_REQUIRE(!dp_words == !dp_prefix, MTGS_EINVAL, "mtgs_front_fwd: dp_words and dp_prefix go together");
-    MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D >= 3), MTGS_EINVAL, "mtgs_front_fwd: color_mode=%d with %d channels", color_mode, D);
+    MTGS_REQUIRE(color_mode == 0 || ((color_mode == 1 || color_mode == 2) && D >= 3), MTGS_EINVAL,
+                 "mtgs_front_fwd: color_mode=%d with %d channels", color_mode, D);
     MTGS_REQUIRE(ws_bytes >= front_ws_bytes(total), MTGS_EWORKSPACE, "mtgs_front_fwd: workspace %zu < %zu bytes", ws_bytes,
                  front_ws_bytes(total));
     MTGS_REQUIRE((reinterpret_cast<uintptr_t>(recs) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, MTGS_EINVAL,

@@ -55,6 +55,8 @@ struct NodeParams {
     const float *pose;                                       // [4] device: instance quaternion wxyz; nullable (static node)
     const float *pose_t;                                     // [3] device: instance translation
     int pose_norm;                                           // 1: the quaternion is a raw parameter row, normalise it
+    int skip_colors;                                         // 1: geometry only -- the colours are evaluated for the VISIBLE
+                                                             // Gaussians by the rasterizer's front end (viscolor.hip)
 };
 
 // Rigid nodes (rigid_node.py:205-216): global mean = R(q) m + t with mtgs utils.quat_to_rotmat (NO normalisation of q:
@@ -96,7 +98,7 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
-    const bool active = P.use_sh ? (k < NB && k - 1 < P.Kr) : (k == 0);
+    const bool active = !P.skip_colors && (P.use_sh ? (k < NB && k - 1 < P.Kr) : (k == 0));
     const float camx = P.cam_pos[0], camy = P.cam_pos[1], camz = P.cam_pos[2];
     // ---- lane-per-Gaussian loads
     const int64_t gl = g0 + lane;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
     float dx = 0.f, dy = 0.f, dz = 1.f;
     Pose ps;
     if (P.pose) ps = load_pose(P.pose, P.pose_t, P.pose_norm);
-    if ((P.use_sh || P.pose || means_out) && okl) {
+    if (((P.use_sh && !P.skip_colors) || P.pose || means_out) && okl) {
         F3 mn = *reinterpret_cast<const F3 *>(P.means + gl * 3);
         if (P.pose)   // rigid node: the Gaussian lives in the object frame
             mn = F3{(ps.R[0] * mn.x + ps.R[1] * mn.y) + ps.R[2] * mn.z + ps.tx, (ps.R[3] * mn.x + ps.R[4] * mn.y) + ps.R[5] * mn.z + ps.ty,
@@ -142,6 +144,7 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
         }
     }
     float myr = 0.f, myg = 0.f, myb = 0.f;
+    if (!P.skip_colors) {
 #pragma unroll
     for (int it = 0; it < NODE_STEPS; ++it) {
         float r, gg, bb;
@@ -164,10 +167,13 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
         myg = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myg)));
         myb = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myb)));
     }
+    }
     if (!okl) return;
     // ---- lane-per-Gaussian results
     F3 rgb;
-    if (P.use_sh == 2) {   // the raw SH value: the colour activation is the consumer's (data-parallel exchange, front.hip)
+    if (P.skip_colors) {
+        rgb = F3{0.f, 0.f, 0.f};
+    } else if (P.use_sh == 2) {   // the raw SH value: the colour activation is the consumer's (data-parallel exchange, front.hip)
         rgb = F3{myr, myg, myb};
         clamp_mask[gl] = 7;
     } else if (P.use_sh) {
@@ -179,7 +185,7 @@ __device__ __forceinline__ void node_fwd_wave(const int64_t N, const NodeParams 
         rgb = F3{1.f / (1.f + expf(-myr)), 1.f / (1.f + expf(-myg)), 1.f / (1.f + expf(-myb))};
         clamp_mask[gl] = 7;
     }
-    *reinterpret_cast<F3 *>(rgbs + gl * 3) = rgb;
+    if (!P.skip_colors) *reinterpret_cast<F3 *>(rgbs + gl * 3) = rgb;
     *reinterpret_cast<F3 *>(scales + gl * 3) = F3{expf(sr.x), expf(sr.y), expf(sr.z)};
     const float qinv = 1.0f / sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
     F4 qn = F4{qr.x * qinv, qr.y * qinv, qr.z * qinv, qr.w * qinv};   // (w, x, y, z)
@@ -215,7 +221,8 @@ __device__ __forceinline__ int node_of_block(const mtgs_node_desc *__restrict__ 
 }
 __device__ __forceinline__ NodeParams params_of(const mtgs_node_desc &d, const float *cam_pos) {
     return NodeParams{d.means, d.scales_raw, d.quats_raw, d.opacities_raw, d.features_dc, d.features_dc_add, d.features_rest,
-                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, d.pose, d.pose_trans, d.pose_normalize};
+                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, d.pose, d.pose_trans, d.pose_normalize,
+                      d.skip_colors};
 }
 
 template <int DEG>
@@ -262,8 +269,9 @@ __device__ __forceinline__ void node_bwd_wave(const int64_t N, const NodeParams 
     if (P.pose) ps = load_pose(P.pose, P.pose_t, P.pose_norm);
     float pq0 = 0.f, pq1 = 0.f, pq2 = 0.f, pq3 = 0.f, pt0 = 0.f, pt1 = 0.f, pt2 = 0.f;   // this Gaussian's part of d pose
     if (okl) {
-        v = *reinterpret_cast<const F3 *>(v_rgbs + gl * 3);
-        if (P.use_sh) {
+        if (v_rgbs) v = *reinterpret_cast<const F3 *>(v_rgbs + gl * 3);
+        if (!v_rgbs) {
+        } else if (P.use_sh) {
             const unsigned mk = clamp_mask[gl];
             v.x = (mk & 1u) ? v.x : 0.f; v.y = (mk & 2u) ? v.y : 0.f; v.z = (mk & 4u) ? v.z : 0.f;
         } else {

@@ -1,0 +1,173 @@
+// viscolor.hip -- colours of the VISIBLE Gaussians only, forward and backward (visibility-first node path).
+//
+// MTGS evaluates spherical harmonics + clamp for every Gaussian of every node at every step
+// (/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:309-322, multi_color_gaussian_splatting.py:77-101,
+// collected by mtgs_scene_graph.py:408-461), 192 B of coefficients per Gaussian, although one camera sees ~15 % of a road
+// block; gsplat's own `sh_degree` path masks SH with radii > 0.  Here the node kernels run geometry-only (node.hip,
+// skip_colors), the front end projects and ranks the visible Gaussians with the colour channels of their records left open
+// (front.hip, color_mode 2), and this file fills them: one 16-lane DPP row per visible Gaussian, lane k = SH basis k
+// (sh_lane.hpp, the layout of sh_fwd_k16_kernel / node.hip), coefficients read in place through the node's row strides.
+// Backward: the compositing backward's compact rows hold d L / d rgb per visible Gaussian; lane k writes
+// basis_k(dir) * mask * v_rgb, i.e. a 192-byte coefficient-gradient ROW per visible Gaussian -- the optimizer consumes the
+// rows through a row map (adam.hip) and the dense [N, (T,) K, 3] gradients (zeros for ~85 % of the rows, and for every
+// other traversal) are never written.  Roofline: HBM, ~250 B per VISIBLE Gaussian per direction.
+#include "common.hpp"
+#include "sh_lane.hpp"
+#include "raster_rec.hpp"
+
+namespace {
+
+constexpr int VC_BLOCK = 256, VC_ROWS_PER_BLOCK = VC_BLOCK / 16;
+
+__device__ __forceinline__ float mul_rounded(float a, float b) {   // (see node.hip: keeps the colour independent of the lane)
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+// the node of collected Gaussian g: last table entry with start <= g
+__device__ __forceinline__ int node_of(const mtgs_node_desc *__restrict__ table, int n_nodes, int64_t g) {
+    int lo = 0, hi = n_nodes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].start <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+struct F3 { float x, y, z; };
+
+template <int DEG>
+__global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
+                                                                 const float *__restrict__ cam_pos, const float *__restrict__ means,
+                                                                 const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
+                                                                 int64_t cap_vis, float *__restrict__ recs, uint8_t *__restrict__ vis_mask) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    int64_t n_vis = *totals >> 32;
+    if (n_vis > cap_vis) n_vis = cap_vis;
+    const int k = threadIdx.x & 15;
+    const int64_t r = (int64_t)blockIdx.x * VC_ROWS_PER_BLOCK + (threadIdx.x >> 4);
+    const bool ok = r < n_vis;            // (whole rows: the DPP sums below run with every lane of the wave)
+    float b = 0.f;
+    F3 c = F3{0.f, 0.f, 0.f};
+    int use_sh = 1;
+    if (ok) {
+        const int64_t g = vis_ids[r];
+        const mtgs_node_desc &d = table[node_of(table, n_nodes, g)];
+        const int64_t gl = g - d.start;
+        use_sh = d.use_sh;
+        const bool active = use_sh ? (k < NB && k - 1 < d.k_rest) : (k == 0);
+        if (active) {
+            if (k == 0) {
+                c = *reinterpret_cast<const F3 *>(d.features_dc + gl * d.dc_stride);
+                if (d.features_dc_add) {
+                    const F3 a = *reinterpret_cast<const F3 *>(d.features_dc_add + gl * d.dc_add_stride);
+                    c.x += a.x; c.y += a.y; c.z += a.z;
+                }
+            } else {
+                c = *reinterpret_cast<const F3 *>(d.features_rest + gl * d.rest_stride + (k - 1) * 3);
+            }
+        }
+        if (use_sh) {
+            const F3 m = *reinterpret_cast<const F3 *>(means + g * 3);
+            float dx = m.x - cam_pos[0], dy = m.y - cam_pos[1], dz = m.z - cam_pos[2];
+            const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            b = sh_lane_basis<DEG>(sh_lane_const(k), dx, dy, dz);
+        } else {
+            b = 1.f;
+        }
+    }
+    const float sr = row16_sum(mul_rounded(b, c.x)), sg = row16_sum(mul_rounded(b, c.y)), sb = row16_sum(mul_rounded(b, c.z));
+    if (!ok || k != 0) return;
+    F3 rgb;
+    uint8_t mk = 7;
+    if (use_sh) {
+        const float x = sr + 0.5f, y = sg + 0.5f, z = sb + 0.5f;
+        rgb = F3{fminf(fmaxf(x, 0.f), 1.f), fminf(fmaxf(y, 0.f), 1.f), fminf(fmaxf(z, 0.f), 1.f)};
+        mk = (uint8_t)((x >= 0.f && x <= 1.f) | ((y >= 0.f && y <= 1.f) << 1) | ((z >= 0.f && z <= 1.f) << 2));
+    } else {
+        rgb = F3{1.f / (1.f + expf(-sr)), 1.f / (1.f + expf(-sg)), 1.f / (1.f + expf(-sb))};
+    }
+    float *dst = recs + r * REC_FLOATS + 8;
+    dst[0] = rgb.x; dst[1] = rgb.y; dst[2] = rgb.z;
+    vis_mask[r] = mk;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
+                                                                 const float *__restrict__ cam_pos, const float *__restrict__ means,
+                                                                 const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
+                                                                 int64_t cap_vis, const float *__restrict__ grad_rows, int64_t row_stride,
+                                                                 int col, const float *__restrict__ recs,
+                                                                 const uint8_t *__restrict__ vis_mask, float *__restrict__ feat_rows) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    int64_t n_vis = *totals >> 32;
+    if (n_vis > cap_vis) n_vis = cap_vis;
+    const int k = threadIdx.x & 15;
+    const int64_t r = (int64_t)blockIdx.x * VC_ROWS_PER_BLOCK + (threadIdx.x >> 4);
+    if (r >= n_vis) return;
+    const int64_t g = vis_ids[r];
+    const mtgs_node_desc &d = table[node_of(table, n_nodes, g)];
+    const float *gr = grad_rows + r * row_stride + col;
+    F3 v = F3{gr[0], gr[1], gr[2]};
+    float b;
+    if (d.use_sh) {
+        const unsigned mk = vis_mask[r];   // torch.clamp passes the gradient where min <= x <= max
+        v.x = (mk & 1u) ? v.x : 0.f; v.y = (mk & 2u) ? v.y : 0.f; v.z = (mk & 4u) ? v.z : 0.f;
+        const F3 m = *reinterpret_cast<const F3 *>(means + g * 3);
+        float dx = m.x - cam_pos[0], dy = m.y - cam_pos[1], dz = m.z - cam_pos[2];
+        const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+        dx *= inorm; dy *= inorm; dz *= inorm;
+        b = (k < NB && k - 1 < d.k_rest) ? sh_lane_basis<DEG>(sh_lane_const(k), dx, dy, dz) : 0.f;
+    } else {
+        const float *y = recs + r * REC_FLOATS + 8;   // d sigmoid = y (1 - y)
+        v.x *= y[0] * (1.f - y[0]); v.y *= y[1] * (1.f - y[1]); v.z *= y[2] * (1.f - y[2]);
+        b = k == 0 ? 1.f : 0.f;
+    }
+    *reinterpret_cast<F3 *>(feat_rows + r * 48 + k * 3) = F3{b * v.x, b * v.y, b * v.z};
+}
+
+#define MTGS_VC_DISPATCH(KERNEL, ...)                                                              \
+    switch (degree) {                                                                              \
+        case 0: KERNEL<0><<<grid, VC_BLOCK, 0, st>>>(__VA_ARGS__); break;                          \
+        case 1: KERNEL<1><<<grid, VC_BLOCK, 0, st>>>(__VA_ARGS__); break;                          \
+        case 2: KERNEL<2><<<grid, VC_BLOCK, 0, st>>>(__VA_ARGS__); break;                          \
+        default: KERNEL<3><<<grid, VC_BLOCK, 0, st>>>(__VA_ARGS__); break;                         \
+    }
+
+}  // namespace
+
+extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                                  const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
+                                  void *stream) {
+    MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0, MTGS_EINVAL, "mtgs_vis_color_fwd: bad sizes (degree <= 3)");
+    if (cap_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && recs && vis_mask, MTGS_EINVAL, "mtgs_vis_color_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS_PER_BLOCK);
+    MTGS_VC_DISPATCH(vis_color_fwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, recs, vis_mask)
+    MTGS_CHECK_LAUNCH("mtgs_vis_color_fwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                                  const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
+                                  int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
+                                  void *stream) {
+    MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0 && row_stride >= col + 3 && col >= 0, MTGS_EINVAL,
+                 "mtgs_vis_color_bwd: bad sizes");
+    if (cap_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && grad_rows && recs && vis_mask && feat_rows, MTGS_EINVAL,
+                 "mtgs_vis_color_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS_PER_BLOCK);
+    MTGS_VC_DISPATCH(vis_color_bwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, grad_rows, row_stride, col, recs,
+                     vis_mask, feat_rows)
+    MTGS_CHECK_LAUNCH("mtgs_vis_color_bwd");
+    return MTGS_OK;
+}

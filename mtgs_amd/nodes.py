@@ -139,7 +139,7 @@ _DESC = np.dtype([(k, "<i8") for k in ("n", "first_block", "start")]
                  + [(k, "<u8") for k in ("means", "scales_raw", "quats_raw", "opacities_raw", "features_dc", "features_dc_add",
                                          "features_rest")]
                  + [(k, "<i8") for k in ("dc_stride", "dc_add_stride", "rest_stride")] + [("pose", "<u8"), ("pose_trans", "<u8")]
-                 + [(k, "<i4") for k in ("k_rest", "use_sh", "n_traversals", "traversal", "pose_normalize", "reserved")]
+                 + [(k, "<i4") for k in ("k_rest", "use_sh", "n_traversals", "traversal", "pose_normalize", "skip_colors")]
                  + [(k, "<u8") for k in ("scales", "quats", "opacities", "rgbs", "clamp_mask", "means_out", "v_scales", "v_quats",
                                          "v_opacities", "v_rgbs", "v_means", "g_scales_raw", "g_quats_raw", "g_opacities_raw",
                                          "g_features_dc", "g_features_rest", "g_features_dc_add", "g_means", "g_pose", "g_pose_quat_row",
@@ -169,6 +169,60 @@ def upload_table(tab: np.ndarray, dev) -> Tensor:
     return staged.to(dev, non_blocking=True)
 
 
+class ColorSource:
+    """Visibility-first colours (collect_gaussians(..., deferred_colors=True) -> rasterization(..., color_source=...)).
+
+    Holds the node table (csrc/viscolor.hip reads the SH coefficients of the VISIBLE Gaussians through it), and after the
+    backward of the rasterization the coefficient gradient in ROW form: `rows[n_vis, 48]` (d L / d coefficient k, channel c at
+    3 k + c) and `row_of[N]` (int32: a Gaussian's row, or -1 when the frame did not see it).  The colour parameters get no
+    autograd gradient -- no dense [N, (T,) K, 3] tensor with zeros for ~85 % of the rows and for every other traversal is
+    written; `apply_to(optimizer)` hands the rows to mtgs_amd.optim.FusedAdam, which gives Gaussians without a row the exact
+    zero-gradient update.  `dense_gradients()` expands them (slow path: tests, other optimizers)."""
+
+    def __init__(self, table, n_nodes, degree, cam, keep, node_params):
+        self.table, self.n_nodes, self.degree, self.cam, self._keep = table, int(n_nodes), int(degree), cam, keep
+        self.node_params = node_params     # per node: (start, n, features_dc, features_adapters | None, features_rest, traversal | None)
+        self.rows = self.row_of = None
+
+    def apply_to(self, optimizer) -> None:
+        """optimizer.set_row_gradient(...) for every colour parameter of every node (call between backward() and step())."""
+        assert self.rows is not None, "backward() of the rasterization first"
+        for start, n, dc, adapters, rest, trav in self.node_params:
+            ro = self.row_of[start:start + n]
+            if dc.requires_grad:
+                optimizer.set_row_gradient(dc, self.rows, ro, 0)
+            if adapters is not None and adapters.requires_grad:
+                optimizer.set_row_gradient(adapters, self.rows, ro, 0, slice_index=trav if adapters.dim() == 3 else None)
+            if rest.requires_grad and rest.shape[-2] > 0:
+                optimizer.set_row_gradient(rest, self.rows, ro, 3, slice_index=trav if rest.dim() == 4 else None)
+
+    def dense_gradients(self):
+        """[(features_dc grad, features_adapters grad | None, features_rest grad)] per node, dense (zeros where no row)."""
+        assert self.rows is not None, "backward() of the rasterization first"
+        out = []
+        for start, n, dc, adapters, rest, trav in self.node_params:
+            ro = self.row_of[start:start + n].long()
+            vis = ro >= 0
+            r = self.rows[ro[vis]]
+            Kr = rest.shape[-2]
+            g_dc = torch.zeros(n, 3, device=r.device)
+            g_dc[vis] = r[:, 0:3]
+            g_rest = torch.zeros_like(rest)
+            g_ad = None
+            if rest.dim() == 4:
+                g_rest[vis, trav] = r[:, 3:3 + 3 * Kr].view(-1, Kr, 3)
+            else:
+                g_rest[vis] = r[:, 3:3 + 3 * Kr].view(-1, Kr, 3)
+            if adapters is not None:
+                g_ad = torch.zeros_like(adapters)
+                if adapters.dim() == 3:
+                    g_ad[vis, trav] = r[:, 0:3]
+                else:
+                    g_ad[vis] = r[:, 0:3]
+            out.append((g_dc, g_ad, g_rest))
+        return out
+
+
 class _CollectNodes(torch.autograd.Function):
     """All nodes of a scene as ONE autograd node and ONE launch per direction (mtgs_node_fwd_batch / mtgs_node_bwd_batch: a
     table of node descriptors in device memory): every node's workgroups write straight into its slice of the collected
@@ -177,8 +231,9 @@ class _CollectNodes(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam_pos, specs, *flat):
-        # specs[i] = (degree, use_sh, trav, frame); flat = _NK tensors (or None) per node in _NODE_KEYS order
+        # specs[i] = (degree, use_sh, trav, frame[, deferred colours]); flat = _NK tensors (or None) per node in _NODE_KEYS order
         n_nodes = len(specs)
+        deferred = len(specs[0]) > 4 and bool(specs[0][4])
         require_gpu(cam_pos, *[t for t in flat if t is not None])
         sizes = [flat[_NK * i].shape[0] for i in range(n_nodes)]
         total, dev = sum(sizes), flat[0].device
@@ -211,7 +266,7 @@ class _CollectNodes(torch.autograd.Function):
         start = 0
         for i in range(n_nodes):
             m, sr, qr, orw, dc, add, rest, _, _ = flat[_NK * i:_NK * i + _NK]
-            _, use_sh, trav, _ = specs[i]
+            _, use_sh, trav = specs[i][:3]
             n = sizes[i]
             Kr = rest.shape[-2]
             T = rest.shape[1] if trav >= 0 else 0
@@ -237,6 +292,7 @@ class _CollectNodes(torch.autograd.Function):
         starts = np.cumsum(n_arr) - n_arr
         nblk = (n_arr + 255) // 256
         tab["n"], tab["start"], tab["first_block"] = n_arr, starts, np.cumsum(nblk) - nblk
+        tab["skip_colors"] = int(deferred)
         blk = int(nblk.sum())
         ustarts = starts.astype(np.uint64)
         for k, t, w in (("scales", scales, 12), ("quats", quats, 16), ("opacities", opacities, 4), ("rgbs", rgbs, 12),
@@ -252,8 +308,12 @@ class _CollectNodes(torch.autograd.Function):
             tab["pose_normalize"][framed] = 1
         tab_dev = _upload(tab, dev)
         call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, int(degree), ptr(cam), ptr(model_id), stream_of(means))
+        ctx.color_source = None
+        if deferred:   # the front end of the rasterizer reads the coefficients of the VISIBLE Gaussians through this table
+            node_params = [(int(starts[i]), sizes[i]) for i in range(n_nodes)]   # (+ the leaf parameters: collect_gaussians)
+            _CollectNodes.last_color_source = ColorSource(tab_dev, n_nodes, int(degree), cam, keep, node_params)
         del keep   # (stream-ordered allocator: the launch above is already enqueued)
-        ctx.tab, ctx.dims, ctx.blocks, ctx.degree, ctx.rigid = tab, dims, blk, int(degree), rigid
+        ctx.tab, ctx.dims, ctx.blocks, ctx.degree, ctx.rigid, ctx.deferred = tab, dims, blk, int(degree), rigid, deferred
         ctx.framed = [(i, specs[i][3], flat[_NK * i + 7].shape[0]) for i in framed]
         ctx.save_for_backward(cam, scales, opacities, rgbs, mask, pose_all, *saved, *pose_tabs)
         ctx.mark_non_differentiable(model_id)
@@ -268,13 +328,13 @@ class _CollectNodes(torch.autograd.Function):
         need = ctx.needs_input_grad[2:]
         z = lambda g, shape: (torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous())
         v_scales, v_quats = z(v_scales, (total, 3)), z(v_quats, (total, 4))
-        v_opacities, v_rgbs = z(v_opacities, (total,)), z(v_rgbs, (total, 3))
+        v_opacities, v_rgbs = z(v_opacities, (total,)), (None if ctx.deferred else z(v_rgbs, (total, 3)))
         v_means_c = None if v_means is None else v_means.to(torch.float32).contiguous()
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         g_scales, g_quats, g_opac, g_dc = new(total, 3), new(total, 4), new(total), new(total, 3)
         # no node wants a colour gradient (features passed detached: the data-parallel exchange rebuilds the coefficient
         # gradient on the receivers): the kernel then skips the coefficient rows, the largest stream of the backward
-        colours = any(need[_NK * i + j] for i in range(n_nodes) for j in (4, 5, 6))
+        colours = (not ctx.deferred) and any(need[_NK * i + j] for i in range(n_nodes) for j in (4, 5, 6))
         rest_sizes = [n * Kr * 3 * max(T, 1) if colours else 0 for (n, Kr, _, _, T, _, _) in dims]
         add_sizes = [n * T * 3 if (T and has_add and colours) else 0 for (n, _, _, has_add, T, _, _) in dims]
         g_rest_flat, g_add_flat = new(sum(rest_sizes)), new(sum(add_sizes))
@@ -289,7 +349,8 @@ class _CollectNodes(torch.autograd.Function):
         at = lambda t, w: np.uint64(t.data_ptr()) + np.uint64(w) * ustarts
         tab["means"] = [t.data_ptr() for t in saved[0::2]]
         tab["quats_raw"] = [t.data_ptr() for t in saved[1::2]]
-        tab["v_scales"], tab["v_quats"], tab["v_opacities"], tab["v_rgbs"] = at(v_scales, 12), at(v_quats, 16), at(v_opacities, 4), at(v_rgbs, 12)
+        tab["v_scales"], tab["v_quats"], tab["v_opacities"] = at(v_scales, 12), at(v_quats, 16), at(v_opacities, 4)
+        tab["v_rgbs"] = 0 if ctx.deferred else at(v_rgbs, 12)
         tab["v_means"] = at(v_means_c, 12) if v_means_c is not None else 0
         tab["g_scales_raw"], tab["g_quats_raw"], tab["g_opacities_raw"] = at(g_scales, 12), at(g_quats, 16), at(g_opac, 4)
         tab["g_features_dc"] = at(g_dc, 12) if colours else 0
@@ -348,7 +409,7 @@ class _CollectNodes(torch.autograd.Function):
 
 
 def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, model_sh_degree: int = 3,
-                      raw_colors: bool = False) -> Dict[str, Tensor]:
+                      raw_colors: bool = False, deferred_colors: bool = False) -> Dict[str, Tensor]:
     """MTGSSceneModel.get_gaussians for static nodes (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:408-461): the
     activated Gaussians of every node, concatenated in order, plus `model_id`.  `nodes` is a sequence of dicts of RAW
     parameters {"means", "scales", "quats", "opacities", "features_dc", "features_rest"} with, for multi-colour nodes,
@@ -361,7 +422,12 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     instance in view): each node's workgroups write into its slice of the collected tensors (no torch.cat of per-node
     outputs); "model_id" is written by the same launch.
     raw_colors: "rgbs" is the SH value itself, without clamp(. + 0.5, 0, 1) -- what the data-parallel exchange takes
-    (mtgs_amd.dist.SparseGradExchange.rasterization applies the activation and differentiates it)."""
+    (mtgs_amd.dist.SparseGradExchange.rasterization applies the activation and differentiates it).
+    deferred_colors: VISIBILITY FIRST -- the node kernels run geometry-only (no coefficient reads, no "rgbs"), and the returned
+    "color_source" (ColorSource) makes `rasterization(..., color_source=...)` evaluate SH + clamp for the Gaussians its
+    projection found visible, straight into their records; the coefficient gradient comes back as compact rows
+    (ColorSource.apply_to(FusedAdam)).  MTGS computes the colours of all Gaussians of all nodes every step
+    (vanilla_gaussian_splatting.py:309-322); a camera sees ~15 % of them."""
     specs, flat, sizes = [], [], []
     use_sh = model_sh_degree > 0
     assert use_sh or not raw_colors, "raw_colors needs an SH colour model"
@@ -398,12 +464,21 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
             assert 0 <= frame < iq.shape[0], (frame, iq.shape)
         else:
             assert (iq is None) == (it is None) and (iq is None or (iq.numel() == 4 and it.numel() == 3)), "rigid pose: quat[4] + trans[3]"
-        specs.append((int(sh_degree_to_use), 2 if raw_colors else int(use_sh), -1 if trav is None else int(trav), frame))
+        specs.append((int(sh_degree_to_use), 2 if raw_colors else int(use_sh), -1 if trav is None else int(trav), frame,
+                      bool(deferred_colors)))
         flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest, iq, it]
         sizes.append(N)
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]
+    assert not (deferred_colors and raw_colors)
     means, scales, quats, opacities, rgbs, model_id = _CollectNodes.apply(cam_pos, tuple(specs), *flat)
-    return {"means": means, "scales": scales, "quats": quats, "opacities": opacities, "rgbs": rgbs, "model_id": model_id}
+    out = {"means": means, "scales": scales, "quats": quats, "opacities": opacities, "rgbs": rgbs, "model_id": model_id}
+    if deferred_colors:
+        out["rgbs"] = None
+        cs, _CollectNodes.last_color_source = _CollectNodes.last_color_source, None
+        cs.node_params = [(st, n, nd["features_dc"], nd.get("features_adapters"), nd["features_rest"], nd.get("traversal_index"))
+                          for (st, n), nd in zip(cs.node_params, nodes)]
+        out["color_source"] = cs
+    return out
 
 
 def node_gaussians(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, features_dc: Tensor,

@@ -31,7 +31,7 @@ from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"),
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
-                   ("vec_ok", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"),
+                   ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"),
                    ("one_minus_beta2", "<f4"), ("eps", "<f4"), ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
 _checked = False
 
@@ -62,16 +62,25 @@ class FusedAdam(torch.optim.Optimizer):
         self._blocks = 0
 
     # ---- gradient source 2 -------------------------------------------------------------------------------------------
-    def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0) -> None:
+    def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0,
+                         slice_index: Optional[int] = None) -> None:
         """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
         Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
-        int32 [N].  `param.grad` is ignored for this parameter.  Cleared by step() / zero_grad()."""
+        int32 [N].  slice_index = t for a per-traversal tensor `param[N, T, ...]`: only `param[:, t]` takes the row (width =
+        elements of one slice), the other traversals get the zero gradient.  `param.grad` is ignored for this parameter.
+        Cleared by step() / zero_grad()."""
         width = param.numel() // max(param.shape[0], 1) if param.dim() else 1
+        sub_w, sub_i = 0, 0
+        if slice_index is not None:
+            T = param.shape[1]
+            if not 0 <= int(slice_index) < T:
+                raise ValueError("set_row_gradient: slice_index")
+            sub_w, sub_i = width // T, int(slice_index)
         if rows.dtype != torch.float32 or row_of.dtype != torch.int32 or row_of.numel() != param.shape[0]:
             raise ValueError("set_row_gradient: rows float32 [R, stride], row_of int32 [N]")
-        if rows.dim() != 2 or rows.stride(1) != 1 or col < 0 or col + width > rows.shape[1] or not row_of.is_contiguous():
+        if rows.dim() != 2 or rows.stride(1) != 1 or col < 0 or col + (sub_w or width) > rows.shape[1] or not row_of.is_contiguous():
             raise ValueError("set_row_gradient: row layout")
-        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width))
+        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i)
 
     def zero_grad(self, set_to_none: bool = True):
         self._rows.clear()
@@ -128,8 +137,9 @@ class FusedAdam(torch.optim.Optimizer):
                 align |= g.data_ptr()
                 keep.append(g)
             elif src is not None:
-                rows, row_of, col, stride, width = src
+                rows, row_of, col, stride, width, sub_w, sub_i = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
+                r["sub_width"], r["sub_index"] = sub_w, sub_i
                 keep.append((rows, row_of))
             r["vec_ok"] = int(align % 16 == 0)
             b1, b2 = grp["betas"]

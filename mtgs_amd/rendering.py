@@ -46,10 +46,15 @@ def rasterization(
     distributed: bool = False,
     camera_model: Literal["pinhole", "ortho", "fisheye"] = "pinhole",
     covars: Optional[Tensor] = None,
+    color_source=None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize a set of 3D Gaussians (N) to a batch of image planes (C).
 
     Returns (render_colors [C, height, width, X], render_alphas [C, height, width, 1], meta).
+
+    color_source (extension, not in gsplat's signature; mtgs_amd.nodes.ColorSource from collect_gaussians(...,
+    deferred_colors=True)): the RGB channels are evaluated from the nodes' SH coefficients for the VISIBLE Gaussians only;
+    `colors` then holds the other colour channels ([N, DX], e.g. camera-space normals) or is None.
     """
     meta: Dict = {}
     N = means.shape[0]
@@ -78,6 +83,23 @@ def rasterization(
     assert quats.shape == (N, 4), quats.shape
     assert scales.shape == (N, 3), scales.shape
 
+    if color_source is not None:
+        if sh_degree is not None or C != 1 or render_mode in ["D", "ED"] or backgrounds is not None:
+            raise NotImplementedError("rasterization(color_source=...): one camera, an RGB render mode, no sh_degree / backgrounds")
+        cols = None if colors is None else (colors if colors.dim() == 3 else colors.unsqueeze(0))
+        render_colors, render_alphas, m = fused_rasterization(
+            means, quats, scales, opacities, cols, viewmats, Ks, None, width, height, eps2d, near_plane, far_plane, radius_clip,
+            rasterize_mode == "antialiased", render_mode in ["RGB+D", "RGB+ED"], render_mode == "RGB+ED", absgrad,
+            color_source=color_source)
+        meta.update({"camera_ids": None, "gaussian_ids": None, "radii": m["radii"], "means2d": m["means2d"], "depths": m["depths"],
+                     "conics": m["conics"], "opacities": m["opacities"], "tile_width": math.ceil(width / 16.0),
+                     "tile_height": math.ceil(height / 16.0), "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
+                     "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width, "height": height,
+                     "tile_size": tile_size, "n_cameras": C})
+        for k in ("n_visible", "n_intersections", "overflow"):
+            if k in m:
+                meta[k] = m[k]
+        return render_colors, render_alphas, meta
     if sh_degree is None:
         # colors are post-activation values [N, D] or [C, N, D]
         assert (colors.dim() == 2 and colors.shape[0] == N) or (

@@ -523,10 +523,13 @@ class _FusedRasterization(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
-                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad, dp=None):
+                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad, dp=None, cs=None):
         """dp (mtgs_amd.dist.SparseGradExchange | None): data-parallel mode -- `colors` is the SH output x[1,N,3], blended
         as clamp(x + 0.5, 0, 1); the front kernel writes the visibility map of the exchange, and the backward leaves
-        the gradients as wire rows in the exchange's send buffer instead of dense tensors (see dist.py)."""
+        the gradients as wire rows in the exchange's send buffer instead of dense tensors (see dist.py).
+        cs (mtgs_amd.nodes.ColorSource | None): visibility-first colours -- channels 0..2 of the blended colours are evaluated
+        from the nodes' SH coefficients for the VISIBLE Gaussians only (csrc/viscolor.hip), `colors` holds the remaining
+        channels ([C,N,DX] or None); the backward leaves the coefficient gradient as compact rows in `cs` (rows, row_of)."""
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
         means, quats, scales, opacities, col, viewmats, Ks, bg = map(
             _f32c, (means, quats, scales, opacities, colors, viewmats, Ks, backgrounds))
@@ -534,7 +537,7 @@ class _FusedRasterization(torch.autograd.Function):
         dev, st = means.device, stream_of(means)
         tile_size = 16
         tw, th = -(-width // tile_size), -(-height // tile_size)
-        DC = 0 if col is None else col.shape[-1]
+        DC = (0 if col is None else col.shape[-1]) + (3 if cs is not None else 0)
         DT = DC + int(with_depth)
         ed = bool(expected_depth)
         total = Cn * N
@@ -553,6 +556,8 @@ class _FusedRasterization(torch.autograd.Function):
             raise NotImplementedError("data-parallel rasterization: one camera, the SH output in the first 3 colour channels (further "
                                       "channels need SparseGradExchange.rows_hook to fold their gradient into the wire rows), no "
                                       "backgrounds")
+        if cs is not None and not (packed and Cn == 1 and dp is None and bg is None):
+            raise NotImplementedError("rasterization(color_source=...): one camera, at most 8 blended channels, no backgrounds")
         if not packed:
             # ---- gather-based kernels (csrc/project.hip, bin.hip, blend.hip with dense attribute arrays)
             call("mtgs_project_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
@@ -585,15 +590,19 @@ class _FusedRasterization(torch.autograd.Function):
                 dpf = dp if not repeat else None
                 b = {"recs": torch.empty((cap_vis, 16), dtype=torch.float32, device=dev),
                      "vis_ids": torch.empty(cap_vis, dtype=torch.int32, device=dev),
-                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis}
+                     "vis_keys": torch.empty(cap_vis, dtype=torch.int64, device=dev), "cap_vis": cap_vis,
+                     "vis_mask": torch.empty(cap_vis, dtype=torch.uint8, device=dev) if cs is not None else None}
                 mailbox, tag = _host_mailbox() if graph_caps is None else (None, 0)
                 call("mtgs_front_fwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
                      eps2d, near_plane, far_plane, radius_clip, ptr(opacities), ptr(col), DC, int(with_depth), ptr(radii),
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
                      ptr(vis_rank), cap_vis, *(dpf.front_pointers() if dpf is not None else (None, None, None)),
-                     1 if dp is not None else 0, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
+                     (1 if dp is not None else 0) if cs is None else 2, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
+                if cs is not None:   # colours of the visible Gaussians, straight into their records
+                    call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
+                         ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), st)
                 b["mailbox"], b["tag"] = mailbox, tag
                 if dpf is not None:
                     dpf.after_front()      # the visibility maps travel while this frame is composited
@@ -655,6 +664,7 @@ class _FusedRasterization(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, opacities, col, viewmats, Ks, bg, radii, means2d, depths, conics,
                               comps, opac_eff, offsets if not packed else offsets_buf, flatten_ids, alphas, last_ids, order,
                               vis_ids, vis_rank, render if ed else None, recs, rank_ids, totals)
+        ctx.cs, ctx.vis_mask, ctx.cap_vis = cs, (b["vis_mask"] if cs is not None else None), (b["cap_vis"] if packed else 0)
         ctx.graph = packed and _graph.caps is not None
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
         ctx.absgrad = bool(absgrad)
@@ -704,6 +714,14 @@ class _FusedRasterization(torch.autograd.Function):
                      host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
         if _debug_rows is not None:
             _debug_rows.update(G=G, vis_ids=vis_ids, DC=DC, with_depth=with_depth)
+        cs = ctx.cs
+        if cs is not None:
+            # visibility-first colours: d L / d (SH coefficients) of the VISIBLE Gaussians as 192-byte rows; the optimizer takes
+            # them through the row map (vis_rank: rank or -1) -- no dense [N, (T,) K, 3] gradient is written
+            feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev)
+            call("mtgs_vis_color_bwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(vis_ids), ptr(totals),
+                 n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), st)
+            cs.rows, cs.row_of = feat, vis_rank
         if ctx.dp is not None:
             # data-parallel mode: the per-visible VJP writes this rank's wire rows (index order) into the exchange's send
             # buffer; dense gradients are rebuilt for all ranks at once by SparseGradExchange.finish()
@@ -716,7 +734,7 @@ class _FusedRasterization(torch.autograd.Function):
             if ctx.dp.rows_hook is not None:    # camera-dependent extra channels (normals): their VJP goes into the rows here
                 ctx.dp.rows_hook(G, RS, vis_ids, n_vis)
             ctx.dp.after_backward(n_vis, G, vis_ids)
-            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 11
+            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 12
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
@@ -748,12 +766,14 @@ class _FusedRasterization(torch.autograd.Function):
         want_m2d = m2d_out is not None and m2d_out.retains_grad
         d_m2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if want_m2d else None
         d_abs = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if (ctx.absgrad and m2d_out is not None) else None
-        d_col = torch.empty((Cn, N, DC), dtype=torch.float32, device=dev) if (DC and need[4]) else None
+        c0 = 3 if cs is not None else 0     # (deferred colours: the dense colour gradient covers the other channels only)
+        d_col = torch.empty((Cn, N, DC - c0), dtype=torch.float32, device=dev) if (DC - c0 and need[4]) else None
         vis_ws = torch.empty((max(n_vis, 1), 12), dtype=torch.float32, device=dev)  # scratch of the compact VJP
         call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
              eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities), ptr(r_xy), ptr(r_dep_total), ptr(r_con),
              ptr(r_cmp), ptr(r_opa), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
-             host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs), ptr(r_col), DC,
+             host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs),
+             None if d_col is None else G.data_ptr() + 4 * (8 + c0), DC - c0 if d_col is not None else 0,
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
              ptr(totals) if ctx.graph else None, st)
         if want_m2d:
@@ -764,22 +784,23 @@ class _FusedRasterization(torch.autograd.Function):
         if bg is not None and need[7] and v_render is not None:
             v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
-                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 11
+                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12
 
 
 def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
                         near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad,
-                        dp=None):
+                        dp=None, color_source=None):
     """One-node projection + binning + compositing (see _FusedRasterization).  colors[C,N,D] | None.
     Returns (render, alphas, dict of gsplat's meta tensors)."""
     import weakref
-    if colors is not None:
-        total = colors.shape[-1] + int(with_depth)
+    if colors is not None or color_source is not None:
+        total = (0 if colors is None else colors.shape[-1]) + (3 if color_source is not None else 0) + int(with_depth)
         if total not in SUPPORTED_CHANNELS:
             raise ValueError(f"fused_rasterization: {total} blended channels (supported: {SUPPORTED_CHANNELS})")
     out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
                                     int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-                                    bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp)
+                                    bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp,
+                                    color_source)
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
      offsets, totals) = out
     if render.grad_fn is not None:  # the backward sets .grad / .absgrad on this very tensor (weak: no cycle)

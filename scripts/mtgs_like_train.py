@@ -101,10 +101,11 @@ def gaussians_chain(P, c2w, t, n):
     return {k: torch.cat(v, 0) for k, v in out.items()}
 
 
-def gaussians_fused(P, c2w, t, n):
+def gaussians_fused(P, c2w, t, n, deferred=False):
     from mtgs_amd.nodes import collect_gaussians
     return collect_gaussians([dict(p, traversal_index=t) if "features_adapters" in p else
-                              (dict(p, frame_idx=frame_of(t)) if "instance_quats" in p else p) for p in P.values()], c2w, n, 3)
+                              (dict(p, frame_idx=frame_of(t)) if "instance_quats" in p else p) for p in P.values()], c2w, n, 3,
+                             deferred_colors=deferred)
 
 
 def normals_chain(gs, c2w):
@@ -181,18 +182,24 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
         start += n
 
 
+VISFIRST = {"on": False, "cs": None}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
+
+
 def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     """shipped = None: RGB only (the path + L1 + SSIM).  shipped = dict(exposure=[T,3,4] parameter, bg=[3], gt_depth, gt_normal
     per camera): the option set of config/MTGS.py -- predict_normals (7 blended channels), the exposure model, the lidar
     inverse-depth L1, the depth NCC and the normal L1 (mtgs_scene_graph.py:856-894, 897-936)."""
     vm, K, c2w, t = cam
-    gs = (gaussians_fused if fused else gaussians_chain)(P, c2w, t, n)
+    vf = fused and VISFIRST["on"]
+    gs = gaussians_fused(P, c2w, t, n, deferred=vf) if fused else gaussians_chain(P, c2w, t, n)
     colors = gs["rgbs"]
     if shipped:
         colors = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w, rgbs=colors) if fused else \
-            torch.cat([colors, normals_chain(gs, c2w)], dim=-1)
+            torch.cat([colors, normals_chain(gs, c2w)], dim=-1)       # (visibility first: rgbs = None -> the normals alone)
+    VISFIRST["cs"] = gs.get("color_source") if vf else None
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H,
-                                        packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+                                        packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True,
+                                        **({"color_source": VISFIRST["cs"]} if vf else {}))
     info["means2d"].retain_grad()
     if shipped:
         E, bg = shipped["exposure"][t], shipped["bg"]
@@ -404,6 +411,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 mdist.all_reduce_grads([shipped["exposure"]])
             torch.distributed.all_reduce(loss)
         curve.append(float(loss) / group)
+        if VISFIRST["cs"] is not None and accumulate == 1 and not sparse:
+            VISFIRST["cs"].apply_to(opt)
         opt.step()
         if refine_every and (i + 1) % refine_every == 0 and i + 1 < steps:
             if world > 1:   # every rank must see the same statistics (vis_counts starts at ONE: counted once)
@@ -456,9 +465,14 @@ def main():
     ap.add_argument("--optimizer", choices=["none", "torch", "fused"], default=None, help="the optimizer step: torch.optim.Adam(foreach) "
                     "or mtgs_amd.optim.FusedAdam (one launch).  Timing runs (--only / --graph / default) leave it out unless "
                     "given; --steps trains with the fused one unless told otherwise")
+    ap.add_argument("--visfirst", action="store_true", help="visibility first: node kernels geometry-only, SH + clamp for the VISIBLE "
+                    "Gaussians inside the rasterizer's front end, coefficient gradients as compact rows into the fused Adam")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
+    VISFIRST["on"] = bool(args.visfirst)
+    if args.visfirst and args.optimizer == "torch":
+        raise SystemExit("--visfirst hands the colour gradients over as rows: --optimizer fused (or none)")
     dev = torch.device("cuda")
     W, H, T = args.width, args.height, args.traversals
     truth = make_nodes(args.n_background, args.n_road, T, 0, dev, args.objects, args.object_size)
@@ -509,6 +523,8 @@ def main():
                 q.grad = None
             loss = iteration(P, cams[i % T], targets[i % T], mask, fused, stats, win, W, H, shipped=shipped)
             if opt is not None:
+                if VISFIRST["cs"] is not None:
+                    VISFIRST["cs"].apply_to(opt)
                 opt.step()
             return loss
         for i in range(3):
@@ -535,6 +551,8 @@ def main():
                 q.grad = None
             loss = iteration(P, cams[t], targets[t], mask, True, stats, win, W, H, shipped=shipped)
             if opt is not None:
+                if VISFIRST["cs"] is not None:
+                    VISFIRST["cs"].apply_to(opt)
                 opt.step()
             return loss
 

@@ -308,3 +308,27 @@ def test_configs4_at_its_own_scale_eight_ranks_on_one_gpu():
         REPORT.append({"kind": "dp", "name": f"configs[4] at its own scale (2M Gaussians, 4 traversals, 960x540, shipped options): {tag}",
                        "ms_per_step": float(m.group(1)) if m else None, "phases_ms": json.loads(m.group(2)) if m else None,
                        "sizes": sizes(out), "loss_curve": curve(out)})
+
+
+def test_mtgs_like_training_visibility_first_equals_dense_colours():
+    """scripts/mtgs_like_train.py --visfirst (node kernels geometry-only, SH + clamp for the visible Gaussians inside the
+    rasterizer's front end, coefficient gradients as compact rows into the fused Adam) trains like the dense node path: same
+    refinements, same loss curve (shipped option set, multi-traversal background, object nodes)."""
+    import re
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "3", "--objects", "4", "--width", "320", "--height", "200",
+              "--steps", "45", "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped", "--optimizer", "fused"]
+    outs = []
+    for extra in ([], ["--visfirst"]):
+        r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py")] + common + extra, capture_output=True,
+                           text=True, timeout=900, cwd=str(root))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        outs.append(r.stdout)
+    sizes = lambda out: re.findall(r"refine (\d+) -> (\d+) Gaussians", out)
+    curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
+    assert sizes(outs[0]) == sizes(outs[1]) and len(sizes(outs[0])) == 2, (sizes(outs[0]), sizes(outs[1]))
+    a, b = curve(outs[0]), curve(outs[1])
+    assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)

@@ -304,3 +304,92 @@ def test_collect_rigid_nodes_with_per_frame_pose_parameters(hip_lib):
             other = torch.ones(frames[i], dtype=torch.bool); other[fidx[i]] = False
             assert not ga["instance_quats"][other.to(dev)].any() and not ga["instance_trans"][other.to(dev)].any()
             assert ga["instance_quats"][fidx[i]].abs().sum() > 0
+
+
+@pytest.mark.parametrize("degree,extra", [(3, 0), (1, 3)])
+def test_visibility_first_colours_equal_the_dense_node_path(hip_lib, degree, extra):
+    """collect_gaussians(deferred_colors=True) + rasterization(color_source=...): SH + clamp evaluated for the VISIBLE Gaussians
+    only (csrc/viscolor.hip), coefficient gradients as compact rows.  Against the dense node path (colours of every Gaussian,
+    dense gradients) on a scene with a vanilla node, a multi-colour node (per-traversal coefficients + adapters) and a
+    shared-rest multi-colour node: same image, same geometry gradients, row gradients equal to the dense ones on the
+    visible rows (zero elsewhere, and in the other traversals' slices), and the same parameters after a FusedAdam step from
+    rows as from the dense gradients."""
+    from mtgs_amd import rasterization
+    from mtgs_amd.nodes import camera_space_normals, collect_gaussians
+    from mtgs_amd.optim import FusedAdam
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    W, H, T, t = 320, 200, 3, 1
+    g = torch.Generator().manual_seed(21)
+
+    def node(n, kind, seed):
+        gg = torch.Generator().manual_seed(seed)
+        P = {"means": (torch.rand(n, 3, generator=gg) * 2 - 1) * torch.tensor([8.0, 2.0, 8.0]) + torch.tensor([0.0, 0.0, 6.0]),
+             "scales": torch.log(torch.rand(n, 3, generator=gg) * 0.2 + 0.03), "quats": torch.randn(n, 4, generator=gg),
+             "opacities": torch.randn(n, 1, generator=gg), "features_dc": torch.randn(n, 3, generator=gg) * 0.7}
+        if kind == "vanilla":
+            P["features_rest"] = torch.randn(n, 15, 3, generator=gg) * 0.2
+        elif kind == "multi":
+            P["features_rest"] = torch.randn(n, T, 15, 3, generator=gg) * 0.2
+            P["features_adapters"] = torch.randn(n, T, 3, generator=gg) * 0.1
+        else:   # adapters per traversal, shared features_rest
+            P["features_rest"] = torch.randn(n, 15, 3, generator=gg) * 0.2
+            P["features_adapters"] = torch.randn(n, T, 3, generator=gg) * 0.1
+        return P
+
+    raw = [node(9000, "vanilla", 1), node(7001, "multi", 2), node(3000, "shared", 3)]
+    vm, K = make_camera(W, H)
+    vm, K = vm.to(dev), K.to(dev)
+    c2w = torch.inverse(vm)[:, :3, :]
+    Gc = torch.randn(1, H, W, 4 + extra, generator=g).to(dev)
+    Ga = torch.randn(1, H, W, 1, generator=g).to(dev)
+
+    def run(deferred):
+        P = [{k: v.clone().to(dev).requires_grad_(True) for k, v in nd.items()} for nd in raw]
+        nodes = [dict(p, traversal_index=t) if "features_adapters" in p else p for p in P]
+        gs = collect_gaussians(nodes, c2w, degree, deferred_colors=deferred)
+        if deferred:
+            cols = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w) if extra else None
+            r, a, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], cols, vm, K, W, H, packed=False,
+                                       render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True, color_source=gs["color_source"])
+        else:
+            cols = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w, rgbs=gs["rgbs"]) if extra else gs["rgbs"]
+            r, a, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], cols, vm, K, W, H, packed=False,
+                                       render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+        torch.autograd.backward([r, a], [Gc, Ga])
+        return P, r.detach(), a.detach(), info, gs.get("color_source")
+
+    Pd, rd, ad, info_d, _ = run(False)
+    Pv, rv, av, info_v, cs = run(True)
+    n_vis = int((info_d["radii"] > 0).sum())
+    assert 2000 < n_vis < 15000
+    assert torch.equal(info_d["flatten_ids"], info_v["flatten_ids"])
+    assert float((rd - rv).abs().max()) <= 2e-6 * max(1.0, float(rd.abs().max())) and float((ad - av).abs().max()) <= 2e-6
+    for pd, pv in zip(Pd, Pv):
+        for k in ("means", "scales", "quats", "opacities"):
+            ref = pd[k].grad
+            assert float((pv[k].grad - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9, k    # (fp32 atomics order)
+        assert pv["features_dc"].grad is None and pv["features_rest"].grad is None
+    for (g_dc, g_ad, g_rest), pd in zip(cs.dense_gradients(), Pd):
+        for got, ref in ((g_dc, pd["features_dc"].grad), (g_rest, pd["features_rest"].grad),
+                         (g_ad, pd["features_adapters"].grad if "features_adapters" in pd else None)):
+            if ref is None:
+                assert got is None
+                continue
+            assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9
+    # the same FusedAdam step from the rows as from the dense gradients
+    col_keys = ("features_dc", "features_rest", "features_adapters")
+    od = FusedAdam([{"params": [p[k] for p in Pd for k in col_keys if k in p], "lr": 1e-2}], eps=1e-15)
+    ov = FusedAdam([{"params": [p[k] for p in Pv for k in col_keys if k in p], "lr": 1e-2}], eps=1e-15)
+    cs.apply_to(ov)
+    od.step()
+    ov.step()
+    for pd, pv in zip(Pd, Pv):
+        for k in col_keys:
+            if k in pd:
+                assert float((pd[k] - pv[k]).abs().max()) <= 2e-6, k
+                # rows the frame did not see, and the other traversals' slices, took the zero-gradient update: unchanged at step 1
+    vis = (info_d["radii"][0] > 0)
+    n0 = raw[0]["means"].shape[0]
+    assert torch.equal(Pv[0]["features_rest"][~vis[:n0]].detach().cpu(), raw[0]["features_rest"][~vis[:n0].cpu()])
+    assert torch.equal(Pv[1]["features_rest"][:, 0].detach().cpu(), raw[1]["features_rest"][:, 0])
