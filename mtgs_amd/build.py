@@ -63,6 +63,10 @@ def stale_sources():
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     OBJ.mkdir(exist_ok=True)
+    live = {s.stem for s in sources()}
+    for stale in OBJ.glob("*.o"):          # objects of sources that no longer exist (bin2.o after round 2)
+        if stale.stem not in live:
+            stale.unlink()
     headers = list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "mtgs_rast.h", Path(__file__)]
     jobs = []
     for src in sources():

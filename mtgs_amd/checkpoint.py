@@ -73,7 +73,8 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
                       node_names: Optional[Iterable[str]] = None, device="cuda",
                       frame_idx: Optional[int] = None, timestamp: Optional[float] = None,
                       frame_timestamps: Optional[Tensor] = None, fourier: Optional[Mapping] = None,
-                      instance_heights: Optional[Mapping[str, float]] = None, deform_time: Optional[float] = None) -> Dict[str, Tensor]:
+                      instance_heights: Optional[Mapping[str, float]] = None, deform_time: Optional[float] = None,
+                      undeformed: bool = False) -> Dict[str, Tensor]:
     """means / scales / quats / opacities / rgbs / model_id of the listed nodes, activated by
     mtgs_amd.nodes.node_gaussians and concatenated in order (MTGSSceneModel.get_gaussians,
     mtgs_scene_graph.py:408-461).  Multi-colour nodes need `traversal_index` (get_pertravel_features,
@@ -83,9 +84,12 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
     get_gaussians returns None for them).  Rigid nodes with Fourier colours (features_dc[N,F,3]) need
     `fourier = {"x": normalised timestamp (temporal) | None (spatial: the camera-object yaw is computed), "scale": ..,
     "space": "temporal" | "spatial"}` -- the node's portable_config (rigid_node.py:114-125).
-    Deformable nodes (deformable_node.py:206-247) are posed like rigid ones and, when `deform_time` (the frame's
-    timestamp as get_deformation uses it) and `instance_heights[name]` (instance_size[2]) are given, displaced by their
-    deformation network; without them they are rendered undeformed, as the reference does before `use_deformgs_after`."""
+    Deformable nodes (deformable_node.py:206-247) are posed like rigid ones and displaced by their deformation network, which
+    needs `deform_time` (the frame's timestamp as get_deformation uses it; with timestamp interpolation the reference feeds
+    the interpolation FRACTION, deformable_node.py:190) and `instance_heights[name]` (instance_size[2], kept outside the state
+    dict).  The reference applies the network whenever step > use_deformgs_after (deformable_node.py:230-232), so a trained
+    checkpoint rendered without them would be rendered WRONGLY: that raises unless `undeformed=True` asks for the canonical
+    geometry explicitly."""
     from .deform import deformation_from_state
     from .nodes import cam_obj_yaw, collect_gaussians as _collect, fourier_features_dc, object_pose
     names = list(nodes.keys()) if node_names is None else list(node_names)
@@ -114,7 +118,11 @@ def collect_gaussians(nodes: Mapping[str, Mapping[str, Tensor]], camera_to_world
                 p["features_dc"] = fourier_features_dc(p["features_dc"], x, fourier.get("scale", 1.0), space)
         if kind == "deformable":
             state = {k: p.pop(k) for k in list(p) if k == "instances_embedding" or k.startswith("deform_network.")}
-            if deform_time is not None and instance_heights is not None and name in instance_heights:
+            have = deform_time is not None and instance_heights is not None and name in instance_heights
+            if not have and not undeformed:
+                raise ValueError(f"collect_gaussians: deformable node {name!r} needs deform_time and instance_heights[{name!r}] "
+                                 "(pass undeformed=True to render its canonical geometry)")
+            if have:
                 state["means"] = p["means"]
                 d_xyz, d_quat, d_scale = deformation_from_state(state, float(instance_heights[name]), float(deform_time))
                 p["means"] = p["means"].detach() + d_xyz                      # stop_optimizing_canonical_xyz (default)

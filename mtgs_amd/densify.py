@@ -155,7 +155,8 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
     sample) -- with all-reduced statistics (mtgs_amd.dist.all_reduce_stats) every rank of a data-parallel job produces
     bit-identical tensors, so N stays identical without a broadcast (the reference draws torch.randn per rank, :642, :687).
     ONE host synchronisation: the new N (tensor sizes).  Returns (new_params, new_moments | None, info) with
-    info = {n_before, n_after, n_split, n_dup, n_culled_old, src_index, kind}."""
+    info = {n_before, n_after, n_old_kept (old Gaussians kept), n_children (split children), n_dups, n_split (split parents; a device scalar),
+    src_index, kind}."""
     from ._lib import call, ptr, stream_of
     means, scales, quats, opac = (params[k] for k in ("means", "scales", "quats", "opacities"))
     require_gpu(means, scales, quats, opac, *stats)
@@ -203,9 +204,11 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
     new_moments = None
     if moments is not None:
         new_moments = {k: (rows(a.detach(), True), rows(b.detach(), True)) for k, (a, b) in moments.items()}
-    n_split = int((flags[:N] >> 7).sum()) if N else 0
+    # (n_split stays a DEVICE scalar: children can be culled one by one, so the number of split parents does not follow from
+    #  the totals, and a second host synchronisation is not worth a log line -- int(info["n_split"]) reads it when wanted)
     info = {"n_before": N, "n_after": n_out, "n_old_kept": tot_h[0], "n_children": sum(tot_h[1:1 + S]), "n_dups": tot_h[1 + S],
-            "n_split": n_split, "src_index": src_index[:n_out], "kind": kind[:n_out]}
+            "n_split": (flags[:N] >> 7).sum() if N else torch.zeros((), dtype=torch.int64, device=dev),
+            "src_index": src_index[:n_out], "kind": kind[:n_out]}
     return new, new_moments, info
 
 

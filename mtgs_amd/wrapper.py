@@ -446,9 +446,13 @@ _size_plan = _SizePlan()
 
 
 class _GraphState:
-    """(Process-wide, not per thread: the backward of a captured iteration runs on autograd's device thread.)"""
+    """(Process-wide, not per thread: the backward of a captured iteration runs on autograd's device thread.  The thread that
+    entered graph_mode OWNS it: a rasterization() forward from any other thread while it is active -- a viewer thread next to
+    a capturing trainer -- is refused by name instead of silently inheriting the graph's capacities.  MTGS serialises the two
+    with train_lock, render_state_machine.py:142.)"""
     caps = None       # (cap_vis, cap_M) while graph_mode() is active
     keep = None       # host staging buffers that captured copies read at every replay
+    owner = None      # threading.get_ident() of the thread inside graph_mode
 
 
 _graph = _GraphState()
@@ -475,12 +479,12 @@ class graph_mode:
     def __enter__(self):
         if _graph.caps is not None:
             raise RuntimeError("graph_mode is already active")
-        _graph.caps, _graph.keep = self.caps, self
+        _graph.caps, _graph.keep, _graph.owner = self.caps, self, threading.get_ident()
         self.cursor = 0      # every entry walks the same sequence of staging buffers (warm-up pass, then capture)
         return self
 
     def __exit__(self, *exc):
-        _graph.caps = _graph.keep = None
+        _graph.caps = _graph.keep = _graph.owner = None
         return False
 
 
@@ -582,6 +586,9 @@ class _FusedRasterization(torch.autograd.Function):
             order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
 
             graph_caps = _graph.caps
+            if graph_caps is not None and _graph.owner != threading.get_ident():
+                raise RuntimeError("rasterization(): mtgs_amd.graph_mode is active on another thread (fixed capacities, no host "
+                                   "read-back); serialise the two callers or leave graph_mode first")
 
             def front(cap_vis, repeat=False):
                 # repeat=True: the capacity-overflow repeat of a frame.  The visibility map / row count of the exchange do not

@@ -174,5 +174,7 @@ def test_collect_gaussians_poses_and_deforms_deformable_nodes(hip_lib):
     ref = deformable_gaussians(p, q.contiguous(), t.contiguous(), c2w.to(dev), 3, 3, deformation=deformation_from_state(p, 1.8, 0.4))
     for k in ("means", "scales", "quats", "opacities", "rgbs"):
         assert torch.allclose(gs[k][400:], ref[k], atol=1e-6), k
-    plain = ck.collect_gaussians(nodes, c2w, 3, frame_idx=4)            # before use_deformgs_after: posed, not deformed
+    with pytest.raises(ValueError):     # a trained deformable node without its deformation inputs is refused, not rendered wrongly
+        ck.collect_gaussians(nodes, c2w, 3, frame_idx=4)
+    plain = ck.collect_gaussians(nodes, c2w, 3, frame_idx=4, undeformed=True)   # before use_deformgs_after: posed, not deformed
     assert not torch.allclose(plain["means"][400:], gs["means"][400:]) and torch.equal(plain["means"][:400], gs["means"][:400])

@@ -107,7 +107,7 @@ def test_refinement_on_device_equals_the_reference_restatement(hip_lib, step, cl
     n_ref = ref["means"].shape[0]
     assert masks["splits"].sum() > 200 and masks["dups"].sum() > 200 and (~masks["keep"]).sum() > 200, "the case must exercise every branch"
     assert info["n_after"] == n_ref, (info["n_after"], n_ref)
-    assert info["n_split"] == int(masks["splits"].sum())
+    assert int(info["n_split"]) == int(masks["splits"].sum())
     assert np.array_equal(info["src_index"].cpu().numpy(), masks["src_index"]) and np.array_equal(info["kind"].cpu().numpy(), masks["kind"])
     for k in ref:
         got = new[k].cpu().numpy().astype(np.float64)
