@@ -604,7 +604,15 @@ int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, con
                        void *stream);
 int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
-                       int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows, void *stream);
+                       int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
+                       float *dir_rows, float *dir_part, void *stream);
+/* use_sh = 4 in a descriptor: gsplat's own sh_degree path -- clamp_min(SH + 0.5, 0) (gsplat/rendering.py), and dir_rows
+ * (nullable [cap_vis, 3]) receives d L / d (means - camera position) of the visible rows (gsplat's view directions are
+ * differentiable; MTGS detaches them) and dir_part[ceil(cap_vis / 128), 3] (zeroed by the caller) their per-workgroup sums
+ * (minus their total is the camera position's gradient).  mtgs_rows_expand: dense expansion of gradient rows for autograd callers:
+ * out[n, c] = row_of[n] >= 0 ? rows[row_of[n] * row_stride + c] : 0 for c < width. */
+int mtgs_rows_expand(int64_t N, int width, const int32_t *row_of, const float *rows, int64_t row_stride, float *out,
+                     void *stream);
 
 /* ---- SURVEY.md section 8f, rank 2 (second half): the optimizer step of every Gaussian parameter group in ONE launch ----
  * Reference: one torch.optim.Adam per parameter group with one tensor each (mtgs/scene_model/custom_trainer.py:115-136;

@@ -41,6 +41,7 @@ constexpr int VC_STEPS = 8, VC_ROWS = VC_ROWS_PER_BLOCK * VC_STEPS, VC_LDS_NODES
 struct RowInfo {
     const float *dc, *dc_add, *rest;   // addresses of this Gaussian's coefficient rows (dc_add nullable)
     float dx, dy, dz;                  // unit view direction
+    float inorm;                       // 1 / |mean - cam|
     int32_t k_rest, use_sh;
 };
 
@@ -56,7 +57,7 @@ __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ 
     if (tid < VC_ROWS) {
         const int64_t r = r0 + tid;
         RowInfo ri;
-        ri.dc = nullptr; ri.dc_add = nullptr; ri.rest = nullptr; ri.dx = 0.f; ri.dy = 0.f; ri.dz = 1.f; ri.k_rest = 0; ri.use_sh = 1;
+        ri.dc = nullptr; ri.dc_add = nullptr; ri.rest = nullptr; ri.dx = 0.f; ri.dy = 0.f; ri.dz = 1.f; ri.inorm = 0.f; ri.k_rest = 0; ri.use_sh = 1;
         if (r < n_vis) {
             const int64_t g = vis_ids[r];
             int lo = 0, hi = n_nodes - 1;
@@ -74,7 +75,7 @@ __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ 
             const F3 m = *reinterpret_cast<const F3 *>(means + g * 3);
             float dx = m.x - cam_pos[0], dy = m.y - cam_pos[1], dz = m.z - cam_pos[2];
             const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-            ri.dx = dx * inorm; ri.dy = dy * inorm; ri.dz = dz * inorm;
+            ri.dx = dx * inorm; ri.dy = dy * inorm; ri.dz = dz * inorm; ri.inorm = inorm;
         }
         s_row[tid] = ri;
     }
@@ -124,7 +125,11 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
         if (k != 0 || r >= n_vis) continue;
         F3 rgb;
         uint8_t mk = 7;
-        if (ri.use_sh) {
+        if (ri.use_sh == 4) {   // gsplat's own sh_degree path (rendering.py): clamp_min(SH + 0.5, 0), no upper clamp
+            const float x = sr + 0.5f, y = sg + 0.5f, z = sb + 0.5f;
+            rgb = F3{fmaxf(x, 0.f), fmaxf(y, 0.f), fmaxf(z, 0.f)};
+            mk = (uint8_t)((x >= 0.f) | ((y >= 0.f) << 1) | ((z >= 0.f) << 2));
+        } else if (ri.use_sh) {
             const float x = sr + 0.5f, y = sg + 0.5f, z = sb + 0.5f;
             rgb = F3{fminf(fmaxf(x, 0.f), 1.f), fminf(fmaxf(y, 0.f), 1.f), fminf(fmaxf(z, 0.f), 1.f)};
             // torch.clamp passes the gradient where min <= x <= max (inclusive): one bit per channel
@@ -144,7 +149,8 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
                                                                  const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
                                                                  int64_t cap_vis, const float *__restrict__ grad_rows, int64_t row_stride,
                                                                  int col, const float *__restrict__ recs,
-                                                                 const uint8_t *__restrict__ vis_mask, float *__restrict__ feat_rows) {
+                                                                 const uint8_t *__restrict__ vis_mask, float *__restrict__ feat_rows,
+                                                                 float *__restrict__ dir_rows, float *__restrict__ dir_part) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     __shared__ RowInfo s_row[VC_ROWS];
     __shared__ int64_t s_start[VC_LDS_NODES];
@@ -175,6 +181,79 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
         }
         *reinterpret_cast<F3 *>(feat_rows + r * 48 + k * 3) = F3{b * v.x, b * v.y, b * v.z};
     }
+    if (!dir_rows) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    // gsplat's view directions are differentiable (dirs = means - camera position, rendering.py): d L / d dirs of the
+    // visible rows.  Lane k: w = <coefficient k, masked v_rgb>, times the gradient of ITS basis function
+    // b_k = P(z) S(x, y) with respect to the unit direction; summed over the row, then through the normalisation.
+#pragma unroll
+    for (int it = 0; it < VC_STEPS; ++it) {
+        const int row = it * VC_ROWS_PER_BLOCK + sub;
+        const int64_t r = r0 + row;
+        const RowInfo &ri = s_row[row];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (r < n_vis && ri.use_sh && k < NB && k - 1 < ri.k_rest && k > 0) {
+            const F3 c = *reinterpret_cast<const F3 *>(ri.rest + (k - 1) * 3);
+            const float *gr = grad_rows + r * row_stride + col;
+            const unsigned mk = vis_mask[r];
+            const float w = ((mk & 1u) ? c.x * gr[0] : 0.f) + ((mk & 2u) ? c.y * gr[1] : 0.f) + ((mk & 4u) ? c.z * gr[2] : 0.f);
+            const float x = ri.dx, y = ri.dy, z = ri.dz;
+            const float P = lc.a0 + z * (lc.a1 + z * (lc.a2 + z * lc.a3)), dP = lc.a1 + z * (2.f * lc.a2 + 3.f * z * lc.a3);
+            float S = 1.f, Sx = 0.f, Sy = 0.f;
+            switch (lc.sel) {
+                case 1: S = x; Sx = 1.f; break;
+                case 2: S = y; Sy = 1.f; break;
+                case 3: S = 2.f * x * y; Sx = 2.f * y; Sy = 2.f * x; break;
+                case 4: S = x * x - y * y; Sx = 2.f * x; Sy = -2.f * y; break;
+                case 5: S = 3.f * x * x * y - y * y * y; Sx = 6.f * x * y; Sy = 3.f * (x * x - y * y); break;
+                case 6: S = x * x * x - 3.f * x * y * y; Sx = 3.f * (x * x - y * y); Sy = -6.f * x * y; break;
+                default: break;
+            }
+            gx = w * P * Sx; gy = w * P * Sy; gz = w * dP * S;
+        }
+        gx = row16_sum(gx); gy = row16_sum(gy); gz = row16_sum(gz);
+        if (k == 0 && r < n_vis) {
+            const float dot = gx * ri.dx + gy * ri.dy + gz * ri.dz;      // d (d / |d|): (v - n <n, v>) / |d|
+            const F3 o = F3{(gx - ri.dx * dot) * ri.inorm, (gy - ri.dy * dot) * ri.inorm, (gz - ri.dz * dot) * ri.inorm};
+            *reinterpret_cast<F3 *>(dir_rows + r * 3) = o;
+            sx += o.x; sy += o.y; sz += o.z;
+        }
+    }
+    // sum over the workgroup's rows (the camera position's gradient is minus the sum over all rows): one partial per
+    // workgroup, summed by the caller -- 3 x n_vis same-address atomics would be the kernel time
+    sx = wave_sum_to_lane63(sx); sy = wave_sum_to_lane63(sy); sz = wave_sum_to_lane63(sz);
+    __shared__ float s_part[VC_BLOCK / 64][3];
+    if ((threadIdx.x & 63) == 63) { s_part[threadIdx.x >> 6][0] = sx; s_part[threadIdx.x >> 6][1] = sy; s_part[threadIdx.x >> 6][2] = sz; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < VC_BLOCK / 64; ++w) t += s_part[w][threadIdx.x];
+        dir_part[(int64_t)blockIdx.x * 3 + threadIdx.x] = t;
+    }
+}
+
+// Dense expansion of the coefficient-gradient rows for autograd callers (gsplat's rasterization(sh_degree=...) hands its
+// `colors` gradient back as a dense [N, K, 3] tensor): out[n, :width] = row_of[n] >= 0 ? rows[row_of[n], :width] : 0, every
+// byte written once (width a multiple of 4 floats... the tail of a row is written element-wise).
+__global__ __launch_bounds__(256) void rows_expand_kernel(int64_t N, int width, const int32_t *__restrict__ row_of,
+                                                          const float *__restrict__ rows, int64_t row_stride, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * width) return;
+    const int64_t n = e / width;
+    const int c = (int)(e - n * width);
+    const int32_t r = row_of[n];
+    out[e] = r >= 0 ? rows[(int64_t)r * row_stride + c] : 0.f;
+}
+// the same, 16 bytes per lane (width and row_stride multiples of 4, 16-byte aligned pointers)
+__global__ __launch_bounds__(256) void rows_expand4_kernel(int64_t N, int width4, const int32_t *__restrict__ row_of,
+                                                           const float4 *__restrict__ rows, int64_t row_stride4, float4 *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * width4) return;
+    const int64_t n = e / width4;
+    const int c = (int)(e - n * width4);
+    const int32_t r = row_of[n];
+    out[e] = r >= 0 ? rows[(int64_t)r * row_stride4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 #define MTGS_VC_DISPATCH(KERNEL, ...)                                                              \
@@ -203,16 +282,31 @@ extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int 
 extern "C" int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                                   const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                                   int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
-                                  void *stream) {
+                                  float *dir_rows, float *dir_part, void *stream) {
     MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0 && row_stride >= col + 3 && col >= 0, MTGS_EINVAL,
                  "mtgs_vis_color_bwd: bad sizes");
     if (cap_vis == 0) return MTGS_OK;
-    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && grad_rows && recs && vis_mask && feat_rows, MTGS_EINVAL,
-                 "mtgs_vis_color_bwd: null pointer");
+    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && grad_rows && recs && vis_mask && feat_rows && (!dir_rows == !dir_part),
+                 MTGS_EINVAL, "mtgs_vis_color_bwd: null pointer (dir_rows and dir_part go together)");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
     MTGS_VC_DISPATCH(vis_color_bwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, grad_rows, row_stride, col, recs,
-                     vis_mask, feat_rows)
+                     vis_mask, feat_rows, dir_rows, dir_part)
     MTGS_CHECK_LAUNCH("mtgs_vis_color_bwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_rows_expand(int64_t N, int width, const int32_t *row_of, const float *rows, int64_t row_stride, float *out,
+                                void *stream) {
+    MTGS_REQUIRE(N >= 0 && width > 0 && row_stride >= width, MTGS_EINVAL, "mtgs_rows_expand: bad sizes");
+    if (N == 0) return MTGS_OK;
+    MTGS_REQUIRE(row_of && rows && out, MTGS_EINVAL, "mtgs_rows_expand: null pointer");
+    MTGS_REQUIRE(N * width < ((int64_t)1 << 39), MTGS_EINVAL, "mtgs_rows_expand: too many elements");
+    if (width % 4 == 0 && row_stride % 4 == 0 && (((uintptr_t)rows | (uintptr_t)out) & 15) == 0)
+        rows_expand4_kernel<<<(unsigned)ceil_div64(N * (width / 4), 256), 256, 0, (hipStream_t)stream>>>(
+            N, width / 4, row_of, (const float4 *)rows, row_stride / 4, (float4 *)out);
+    else
+        rows_expand_kernel<<<(unsigned)ceil_div64(N * width, 256), 256, 0, (hipStream_t)stream>>>(N, width, row_of, rows, row_stride, out);
+    MTGS_CHECK_LAUNCH("mtgs_rows_expand");
     return MTGS_OK;
 }

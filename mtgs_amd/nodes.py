@@ -183,6 +183,7 @@ class ColorSource:
         self.table, self.n_nodes, self.degree, self.cam, self._keep = table, int(n_nodes), int(degree), cam, keep
         self.node_params = node_params     # per node: (start, n, features_dc, features_adapters | None, features_rest, traversal | None)
         self.rows = self.row_of = None
+        self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
 
     def apply_to(self, optimizer) -> None:
         """optimizer.set_row_gradient(...) for every colour parameter of every node (call between backward() and step())."""
@@ -221,6 +222,24 @@ class ColorSource:
                     g_ad[vis] = r[:, 0:3]
             out.append((g_dc, g_ad, g_rest))
         return out
+
+
+def sh_coefficient_source(coeffs: Tensor, sh_degree: int, campos: Tensor) -> ColorSource:
+    """ColorSource for gsplat's own call style `rasterization(colors=coeffs[N,K,3], sh_degree=n)` (gsplat/rendering.py: SH masked
+    with radii > 0, clamp_min(. + 0.5, 0), differentiable view directions): ONE descriptor over the coefficient tensor."""
+    N, K = coeffs.shape[0], coeffs.shape[1]
+    assert coeffs.dim() == 3 and coeffs.shape[2] == 3 and coeffs.dtype == torch.float32 and K <= 16 and sh_degree <= 3
+    c = coeffs.detach().contiguous()
+    tab = np.zeros(1, dtype=_DESC)
+    tab["n"], tab["start"], tab["first_block"] = N, 0, 0
+    tab["features_dc"], tab["features_rest"] = c.data_ptr(), c.data_ptr() + 12
+    tab["dc_stride"] = tab["rest_stride"] = K * 3
+    tab["dc_add_stride"] = 3
+    tab["k_rest"], tab["use_sh"] = K - 1, 4
+    cam = campos.detach().reshape(3).to(torch.float32).contiguous()
+    cs = ColorSource(_upload(tab, c.device), 1, int(sh_degree), cam, [c], [(0, N, coeffs, None, coeffs, None)])
+    cs.autograd, cs.width = True, K * 3
+    return cs
 
 
 class _CollectNodes(torch.autograd.Function):

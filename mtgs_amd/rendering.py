@@ -141,6 +141,25 @@ def rasterization(
                     meta[k] = m[k]
             return render_colors, render_alphas, meta
 
+    # gsplat's own call style (SH coefficients + sh_degree) through the same one-node path: SH + clamp_min evaluated for the
+    # Gaussians the projection found visible (gsplat masks SH with radii > 0 too), straight into their records; the
+    # coefficient gradient comes back through compact rows and is expanded once, the view directions stay differentiable.
+    if (sh_degree is not None and C == 1 and colors.dim() == 3 and colors.shape[1] <= 16 and sh_degree <= 3
+            and backgrounds is None and render_mode in ["RGB", "RGB+D", "RGB+ED"] and colors.dtype == torch.float32
+            and (3 + int(with_depth)) in SUPPORTED_CHANNELS and N > 0):
+        from .nodes import sh_coefficient_source
+        campos = torch.inverse(viewmats)[0, :3, 3]                 # differentiable: d dirs / d viewmat flows through it
+        cs = sh_coefficient_source(colors, sh_degree, campos)
+        render_colors, render_alphas, m = fused_rasterization(
+            means, quats, scales, opacities, None, viewmats, Ks, None, width, height, eps2d, near_plane, far_plane, radius_clip,
+            rasterize_mode == "antialiased", with_depth, expected, absgrad, color_source=cs, sh_source=(colors, campos))
+        meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": m["radii"], "means2d": m["means2d"],
+                     "depths": m["depths"], "conics": m["conics"], "opacities": m["opacities"], "tile_width": tile_width,
+                     "tile_height": tile_height, "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
+                     "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width, "height": height,
+                     "tile_size": tile_size, "n_cameras": C})
+        return render_colors, render_alphas, meta
+
     # (1) projection, fused with `opacities.repeat(C, 1) [* compensations]`
     radii, means2d, depths, conics, compensations, opacities = projection_with_opacities(
         means, quats, scales, viewmats, Ks, opacities, width, height, eps2d=eps2d, near_plane=near_plane,

@@ -527,13 +527,16 @@ class _FusedRasterization(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
-                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad, dp=None, cs=None):
+                near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad, dp=None, cs=None,
+                sh_coeffs=None, campos=None):
         """dp (mtgs_amd.dist.SparseGradExchange | None): data-parallel mode -- `colors` is the SH output x[1,N,3], blended
         as clamp(x + 0.5, 0, 1); the front kernel writes the visibility map of the exchange, and the backward leaves
         the gradients as wire rows in the exchange's send buffer instead of dense tensors (see dist.py).
         cs (mtgs_amd.nodes.ColorSource | None): visibility-first colours -- channels 0..2 of the blended colours are evaluated
         from the nodes' SH coefficients for the VISIBLE Gaussians only (csrc/viscolor.hip), `colors` holds the remaining
-        channels ([C,N,DX] or None); the backward leaves the coefficient gradient as compact rows in `cs` (rows, row_of)."""
+        channels ([C,N,DX] or None); the backward leaves the coefficient gradient as compact rows in `cs` (rows, row_of).
+        sh_coeffs [N,K,3], campos [3] (with cs.autograd): gsplat's own `sh_degree` call style -- the coefficient gradient is
+        expanded to a dense tensor for autograd, and the view directions are differentiable (means, camera position)."""
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
         means, quats, scales, opacities, col, viewmats, Ks, bg = map(
             _f32c, (means, quats, scales, opacities, colors, viewmats, Ks, backgrounds))
@@ -726,8 +729,10 @@ class _FusedRasterization(torch.autograd.Function):
             # visibility-first colours: d L / d (SH coefficients) of the VISIBLE Gaussians as 192-byte rows; the optimizer takes
             # them through the row map (vis_rank: rank or -1) -- no dense [N, (T,) K, 3] gradient is written
             feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev)
+            dir_rows = torch.empty((max(n_vis, 1), 3), dtype=torch.float32, device=dev) if cs.autograd else None
+            dir_part = torch.zeros((-(-max(n_vis, 1) // 128), 3), dtype=torch.float32, device=dev) if cs.autograd else None
             call("mtgs_vis_color_bwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(vis_ids), ptr(totals),
-                 n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), st)
+                 n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), ptr(dir_rows), ptr(dir_part), st)
             cs.rows, cs.row_of = feat, vis_rank
         if ctx.dp is not None:
             # data-parallel mode: the per-visible VJP writes this rank's wire rows (index order) into the exchange's send
@@ -741,7 +746,7 @@ class _FusedRasterization(torch.autograd.Function):
             if ctx.dp.rows_hook is not None:    # camera-dependent extra channels (normals): their VJP goes into the rows here
                 ctx.dp.rows_hook(G, RS, vis_ids, n_vis)
             ctx.dp.after_backward(n_vis, G, vis_ids)
-            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 12
+            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 14
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
@@ -783,6 +788,18 @@ class _FusedRasterization(torch.autograd.Function):
              None if d_col is None else G.data_ptr() + 4 * (8 + c0), DC - c0 if d_col is not None else 0,
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
              ptr(totals) if ctx.graph else None, st)
+        d_coeffs = d_campos = None
+        if cs is not None and cs.autograd:
+            if ctx.graph:
+                raise NotImplementedError("graph_mode: rasterization(sh_degree=...) (dense coefficient gradient)")
+            K3 = cs.width
+            d_coeffs = torch.empty((N, K3 // 3, 3), dtype=torch.float32, device=dev)
+            call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
+            if n_vis > 0:     # differentiable view directions: dirs = means - camera position
+                v_means.index_add_(0, vis_ids.long(), dir_rows[:n_vis])
+                d_campos = -dir_part.sum(0)
+            else:
+                d_campos = torch.zeros(3, dtype=torch.float32, device=dev)
         if want_m2d:
             m2d_out.grad = d_m2d      # what retain_grad() would have kept: the gradient reaching means2d
         if d_abs is not None:
@@ -791,12 +808,12 @@ class _FusedRasterization(torch.autograd.Function):
         if bg is not None and need[7] and v_render is not None:
             v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
-                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12
+                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos)
 
 
 def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
                         near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad,
-                        dp=None, color_source=None):
+                        dp=None, color_source=None, sh_source=None):
     """One-node projection + binning + compositing (see _FusedRasterization).  colors[C,N,D] | None.
     Returns (render, alphas, dict of gsplat's meta tensors)."""
     import weakref
@@ -807,7 +824,7 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
     out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
                                     int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                     bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp,
-                                    color_source)
+                                    color_source, *(sh_source or (None, None)))
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
      offsets, totals) = out
     if render.grad_fn is not None:  # the backward sets .grad / .absgrad on this very tensor (weak: no cycle)

@@ -229,6 +229,57 @@ def test_rasterization_sh_path(gs, oracle):
     assert_image_close(alpha.cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha")
 
 
+@pytest.mark.parametrize("N,W,H,deg,mode", [(300, 80, 60, 2, "RGB"), (20_000, 320, 200, 3, "RGB+ED")])
+def test_rasterization_sh_path_backward(gs, oracle, N, W, H, deg, mode):
+    """gsplat's own call style -- rasterization(colors=coeffs[N,K,3], sh_degree=n) -- forward AND backward against the oracle:
+    SH masked with radii > 0, clamp_min(. + 0.5, 0), and DIFFERENTIABLE view directions (dirs = means - camera position:
+    gradients reach means and, through inverse(viewmat), the view matrix).  Runs through the visibility-first one-node path
+    (colours of the visible Gaussians only; dense coefficient gradient expanded from compact rows)."""
+    sc, vm, K = small_scene(N=N, W=W, H=H, sh_degree=3)
+    a = to_np(sc)
+    g = torch.Generator().manual_seed(5)
+    n_out = 3 + (mode != "RGB")
+    Gc, Ga = torch.randn(1, H, W, n_out, generator=g), torch.randn(1, H, W, 1, generator=g)
+    aa = mode != "RGB"
+    rmode = "antialiased" if aa else "classic"
+    r_render, r_alpha, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["coeffs"], vm.numpy(), K.numpy(),
+                                                W, H, sh_degree=deg, render_mode=mode, rasterize_mode=rmode)
+    P = {k: dev(v).requires_grad_(True) for k, v in sc.items() if k != "colors"}
+    vmd = dev(vm).requires_grad_(True)
+    render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["coeffs"], vmd, dev(K), W, H,
+                                           sh_degree=deg, packed=False, render_mode=mode, rasterize_mode=rmode, absgrad=True)
+    assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
+    assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render", case=f"sh_degree path N={N}",
+                       depth_channel=-1 if aa else None, alpha=r_alpha)
+    assert_image_close(alpha.detach().cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", case=f"sh_degree path N={N}")
+    torch.autograd.backward([render, alpha], [dev(Gc), dev(Ga)])
+    # ---- oracle backward
+    Gc_raw, Ga_tot = Gc.numpy().copy(), Ga.numpy().copy()
+    if mode == "RGB+ED":
+        al = np.maximum(r_alpha, 1e-10)
+        Gc_raw[..., -1:] = Gc.numpy()[..., -1:] / al
+        Ga_tot = Ga_tot + (-(m["render_raw"][..., -1:] / al ** 2) * Gc.numpy()[..., -1:]) * (r_alpha > 1e-10)
+    v2d, vabs, vcon, vcol, vop = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                  m["isect_offsets"], m["flatten_ids"], r_alpha, m["last_ids"], Gc_raw, Ga_tot)
+    v_depth = vcol[..., -1].copy() if aa else np.zeros_like(vop)
+    v_comp = vop * a["opacities"][None] if aa else None
+    r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3, m["radii"],
+                                                 m["conics"], m["compensations"], v2d, v_depth, vcon, v_comp)
+    campos = np.linalg.inv(vm.numpy()[0].astype(np.float64))[:3, 3].astype(np.float32)
+    dirs = a["means"] - campos
+    x = oracle.sh_fwd(deg, dirs, a["coeffs"], masks=m["radii"][0] > 0)
+    v_rgb = vcol[0, :, :3] * (x + 0.5 >= 0.0)                     # clamp_min(x + 0.5, 0)
+    r_vc, r_vd = oracle.sh_bwd(deg, dirs, a["coeffs"], v_rgb, masks=m["radii"][0] > 0, need_v_dirs=True)
+    vm64 = torch.tensor(vm.numpy(), dtype=torch.float64, requires_grad=True)
+    torch.inverse(vm64)[0, :3, 3].backward(torch.tensor(-r_vd.astype(np.float64).sum(0)))
+    case = f"sh_degree path N={N} {mode}"
+    tol = dict(rel_to_max=2e-3) if N < 1000 else {}
+    assert_grad_close("v_coeffs", P["coeffs"].grad, r_vc, case=case, **tol)
+    assert_grad_close("v_means (incl. view directions)", P["means"].grad, r_vm + r_vd, case=case, **tol)
+    assert_grad_close("v_quats", P["quats"].grad, r_vq, case=case, **tol)
+    assert_grad_close("v_viewmats (incl. camera position)", vmd.grad[0], r_vvm[0] + vm64.grad[0].numpy().astype(np.float32), case=case, **tol)
+
+
 def test_empty_and_degenerate_inputs(gs):
     W, H = 40, 30
     vm = torch.eye(4)[None].cuda(); K = torch.tensor([[[30.0, 0, 20], [0, 30.0, 15], [0, 0, 1]]]).cuda()
