@@ -634,6 +634,7 @@ typedef struct mtgs_adam_group {
     const float *g;             /* dense gradient or NULL */
     const float *rows;          /* compact gradient rows or NULL */
     const int32_t *row_of;      /* [n / width] row of every item, < 0: none */
+    const float *catchup;       /* catchup_k > 0: {step_size, bc2_sqrt} of the catchup_k steps to apply, oldest first (DEVICE) */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
     int32_t width, row_col;
@@ -641,10 +642,20 @@ typedef struct mtgs_adam_group {
     int32_t sub_width, sub_index;   /* sub_width > 0: an item is `width / sub_width` slices of sub_width floats (a per-traversal
                                      * tensor [N, T, ...]); only slice sub_index takes the row's gradient
                                      * rows[.., row_col + e % sub_width], the other slices get zero */
+    int32_t slice_only;             /* 1 (with sub_width): the group IS slice sub_index of a [N, T, ...] tensor -- n = N * sub_width
+                                     * virtual elements, element e lives at p[(e / sub_width) * width + sub_index * sub_width + e % sub_width];
+                                     * the other slices are neither read nor written (exact lazy Adam, below) */
+    int32_t catchup_k;              /* > 0: no gradient step -- apply catchup_k ZERO-gradient steps with the scalars in `catchup` */
     int32_t reserved;
     float one_minus_beta1, beta2, one_minus_beta2;   /* 1 - beta rounded from double by the caller (1 - 0.999f is 5e-5 off) */
     float eps, weight_decay, grad_scale;
 } mtgs_adam_group;
+/* Exact lazy Adam for per-traversal tensors [N, T, ...] (MTGS's features_rest / features_adapters,
+ * multi_color_gaussian_splatting.py:53-71): a step renders ONE traversal; the other traversals' slices get the zero gradient,
+ * i.e. their moments only decay and p moves along exp_avg -- a recurrence in per-step scalars the host knows.  Such a slice
+ * can be left untouched (slice_only groups step the rendered slice alone) and CAUGHT UP before its traversal is rendered
+ * again: catchup_k zero-gradient steps per element in registers, the same operations in the same order as stepping every
+ * time (bit-identical), at 24 B per element of ONE slice instead of 24 B x T per step. */
 int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check their layout against it */
 int mtgs_adam_block_elems(void);    /* elements one workgroup updates */
 /* nontemporal != 0: moments (and a dense gradient) are streamed past the caches (they are touched once per step). */

@@ -96,6 +96,52 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
     float *__restrict__ P = d.p, *__restrict__ M = d.m, *__restrict__ V = d.v;
     const bool dense = d.g != nullptr;
     const bool rows = d.rows != nullptr;
+    if (d.slice_only) {
+        // ONE slice of a per-traversal tensor: virtual element e -> p[(e / sub_width) * width + sub_index * sub_width + e % sub_width];
+        // the other slices are not touched.  A slice row is sub_width contiguous floats at a 4-byte-aligned offset: 4-byte
+        // accesses, coalesced across the wave.  (A 16-elements-per-lane version with multiply-high row indices and
+        // non-temporal moments measured SLOWER, 3.70 against 3.41 ms for the T = 8 iteration: 48 more live registers.  The
+        // slices are 180-byte pieces every T * 180 bytes, so the fabric moves whole lines around them: at T = 3 the lazy
+        // scheme's two passes over one slice cost more than one pass over three, it pays from T ~ 5.)
+        const int64_t end = base + ADAM_ELEMS < d.n ? base + ADAM_ELEMS : d.n;
+        const int sw = d.sub_width;
+        const int64_t off = (int64_t)d.sub_index * sw;
+        for (int64_t e0 = base + threadIdx.x; e0 < end; e0 += ADAM_BLOCK * ADAM_UNROLL) {
+            float p[ADAM_UNROLL], m[ADAM_UNROLL], v[ADAM_UNROLL], g[ADAM_UNROLL];
+            int64_t phys[ADAM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ADAM_UNROLL; ++u) {
+                const int64_t e = e0 + (int64_t)u * ADAM_BLOCK;
+                phys[u] = -1;
+                if (e < end) {
+                    const int64_t i = e / sw;
+                    const int c = (int)(e - i * sw);
+                    phys[u] = i * d.width + off + c;
+                    p[u] = P[phys[u]]; m[u] = M[phys[u]]; v[u] = V[phys[u]];
+                    g[u] = 0.f;
+                    if (d.catchup_k == 0) {
+                        if (dense) g[u] = d.g[phys[u]];
+                        else if (rows) { const int32_t r = d.row_of[i]; g[u] = r < 0 ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < ADAM_UNROLL; ++u) {
+                if (phys[u] < 0) continue;
+                if (d.catchup_k > 0) {
+                    Hyper hj = h;
+                    for (int j = 0; j < d.catchup_k; ++j) {      // the missed zero-gradient steps, oldest first
+                        hj.step_size = d.catchup[2 * j]; hj.bc2_sqrt = d.catchup[2 * j + 1];
+                        adam_update(p[u], m[u], v[u], 0.f, hj);
+                    }
+                } else {
+                    adam_update(p[u], m[u], v[u], g[u], h);
+                }
+                P[phys[u]] = p[u]; M[phys[u]] = m[u]; V[phys[u]] = v[u];
+            }
+        }
+        return;
+    }
     if (d.vec_ok && base + ADAM_ELEMS <= d.n) {
         // full chunk, 16-byte accesses: UNROLL x 3 (4) loads per lane in flight before the first use
         float4 p[ADAM_UNROLL], m[ADAM_UNROLL], v[ADAM_UNROLL], g[ADAM_UNROLL];

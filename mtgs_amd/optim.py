@@ -15,6 +15,13 @@ Two gradient sources per parameter:
     (< 0: not visible).  Gaussians without a row get the exact zero-gradient Adam update -- the moments decay, the
     parameter keeps moving along exp_avg -- without a dense gradient tensor ever being written or read.
 
+Exact lazy Adam for per-traversal tensors (`set_lazy_slices(param)` for `[N, T, ...]` parameters: MTGS's features_rest /
+features_adapters): a step renders ONE traversal; the other traversals' slices only decay.  A lazy parameter's step touches
+the rendered slice alone, and `prepare(t)` -- called before the forward that reads traversal t -- catches slice t up with
+the zero-gradient steps it missed (the same operations in the same order as stepping every time: bit-identical), so the
+optimizer's traffic no longer grows with the number of traversals.  `flush()` before anything else reads the parameters
+(checkpoints, refinement, evaluation with another traversal).
+
 HIP graphs: the per-step scalars (lr / (1 - beta1^t), sqrt(1 - beta2^t)) live in a small device array that `advance()`
 refreshes with one copy; `step()` = `advance()` + the launch.  Capture `step()` once, then per replay call `advance()` and
 replay (the copy is enqueued on the stream in front of the graph launch).
@@ -29,10 +36,11 @@ import torch
 
 from ._lib import call, load, ptr, stream_of
 
-_GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"),
+_GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
-                   ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"),
-                   ("one_minus_beta2", "<f4"), ("eps", "<f4"), ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
+                   ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("slice_only", "<i4"), ("catchup_k", "<i4"),
+                   ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
+                   ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
 _checked = False
 
 
@@ -56,6 +64,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.nontemporal = bool(nontemporal)
         self.grad_scale = 1.0          # every gradient is multiplied by this inside the kernel (1 / world for a DDP-style mean)
         self._rows = {}                # id(param) -> (rows, row_of, col, stride)
+        self._lazy = {}                # id(param) -> {"param", "T", "last": [step up to which slice t is current], "hist": [(step_size, bc2_sqrt)]}
+        self._active_slice = {}        # id(param) -> slice the coming step() updates (lazy parameters)
         self._table_key = None
         self._table_dev = self._hyper_dev = None
         self._active = []
@@ -85,6 +95,78 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         self._rows.clear()
         return super().zero_grad(set_to_none=set_to_none)
+
+    # ---- exact lazy Adam for per-traversal tensors ----------------------------------------------------------------------
+    def set_lazy_slices(self, param: torch.Tensor) -> None:
+        """`param[N, T, ...]`: step() updates only the slice of the step's traversal (set_active_slice / the slice_index of
+        set_row_gradient); the other slices are caught up by prepare(t) / flush().  Call before the first step."""
+        assert param.dim() >= 2 and param.is_contiguous()
+        # "last" is filled in at the first use from the parameter's step count at that time: every slice is taken to be current
+        # then (a new optimizer that inherits state after a refinement: flush() the old one first)
+        self._lazy[id(param)] = {"param": param, "T": int(param.shape[1]), "last": None, "hist": {}}
+
+    def _last(self, L):
+        if L["last"] is None:
+            st = self.state.get(L["param"], {})
+            s0 = int(float(st["step"])) if "step" in st else 0
+            L["last"] = [s0] * L["T"]
+        return L["last"]
+
+    def set_active_slice(self, param: torch.Tensor, t: int) -> None:
+        self._active_slice[id(param)] = int(t)
+
+    def _catch_up(self, items) -> None:
+        """items: [(lazy record, slice)]: apply the zero-gradient steps each slice missed, one launch for all of them."""
+        _check_layout()
+        elems = load().mtgs_adam_block_elems()
+        todo = []
+        for L, t in items:
+            p = L["param"]
+            st = self.state.get(p)
+            if not st or "exp_avg" not in st:
+                continue
+            cur = int(float(st["step"]))
+            k = cur - self._last(L)[t]
+            if k > 0:
+                todo.append((L, t, k, cur))
+        if not todo:
+            return
+        hist = np.concatenate([np.asarray([L["hist"][j] for j in range(cur - k + 1, cur + 1)], np.float32).reshape(-1)
+                               for L, t, k, cur in todo])
+        dev = todo[0][0]["param"].device
+        from .nodes import upload_table
+        hist_dev = upload_table(hist, dev).view(torch.float32)
+        tab = np.zeros(len(todo), _GROUP)
+        fb, off = 0, 0
+        for i, (L, t, k, cur) in enumerate(todo):
+            p = L["param"]
+            st = self.state[p]
+            grp = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+            width = p.numel() // p.shape[0]
+            sw = width // L["T"]
+            r = tab[i]
+            r["p"], r["m"], r["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            r["n"], r["first_block"], r["width"], r["sub_width"], r["sub_index"], r["slice_only"] = p.shape[0] * sw, fb, width, sw, t, 1
+            r["catchup"], r["catchup_k"] = hist_dev.data_ptr() + 4 * off, k
+            b1, b2 = grp["betas"]
+            r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2
+            r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
+            fb += -(-(p.shape[0] * sw) // elems)
+            off += 2 * k
+            L["last"][t] = cur
+        table = upload_table(tab, dev)
+        dummy = hist_dev     # (the per-group {step_size, bc2_sqrt} array is not read by catch-up groups)
+        if dummy.numel() < 2 * len(todo):
+            dummy = torch.zeros(2 * len(todo), dtype=torch.float32, device=dev)
+        call("mtgs_adam_step", len(todo), ptr(table), ptr(dummy), fb, int(self.nontemporal), stream_of(todo[0][0]["param"]))
+
+    def prepare(self, t: int) -> None:
+        """Before the forward that reads traversal t: bring slice t of every lazy parameter up to date."""
+        self._catch_up([(L, int(t)) for L in self._lazy.values() if 0 <= int(t) < L["T"]])
+
+    def flush(self) -> None:
+        """Every slice of every lazy parameter up to date (checkpoints, refinement, evaluation)."""
+        self._catch_up([(L, t) for L in self._lazy.values() for t in range(L["T"])])
 
     # ---- the step ----------------------------------------------------------------------------------------------------
     def _collect(self):
@@ -142,10 +224,18 @@ class FusedAdam(torch.optim.Optimizer):
                 r["sub_width"], r["sub_index"] = sub_w, sub_i
                 keep.append((rows, row_of))
             r["vec_ok"] = int(align % 16 == 0)
+            L = self._lazy.get(id(p))
+            if L is not None:       # lazy per-traversal tensor: this step touches the rendered slice alone
+                t = self._active_slice.get(id(p), src[6] if (src is not None and src[5] > 0) else None)
+                if t is None:
+                    raise RuntimeError("FusedAdam: a lazy per-traversal parameter needs its slice (set_active_slice / slice_index)")
+                width = p.numel() // p.shape[0]
+                sw = width // L["T"]
+                r["width"], r["sub_width"], r["sub_index"], r["slice_only"], r["n"] = width, sw, int(t), 1, p.shape[0] * sw
             b1, b2 = grp["betas"]
             r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2   # (differences taken in double)
             r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
-            fb += -(-p.numel() // elems)
+            fb += -(-int(r["n"]) // elems)
         key = tab.tobytes()
         if key != self._table_key:
             from .nodes import upload_table
@@ -158,23 +248,40 @@ class FusedAdam(torch.optim.Optimizer):
         self._keep = keep
         return self._table_dev
 
-    def advance(self) -> None:
+    def advance(self, active_slice: Optional[int] = None) -> None:
         """In front of every replay of a HIP graph that captured step(): increments the step count of the tensors that
         step updates and copies this step's {lr / (1 - beta1^t), sqrt(1 - beta2^t)} per tensor to the device
-        (asynchronously, from a fresh pinned buffer, on the current stream)."""
-        self._advance(self._active)
+        (asynchronously, from a fresh pinned buffer, on the current stream).  active_slice: the traversal the replayed
+        graph renders (lazy per-traversal parameters; call prepare(t) before the replay as before an eager forward)."""
+        self._advance(self._active, active_slice)
 
-    def _advance(self, act) -> None:
+    def _advance(self, act, active_slice=None) -> None:
         if not act:
             return
         hyper = np.empty((len(act), 2), np.float32)
         for i, (gi, p, st, g, src) in enumerate(act):
             grp = self.param_groups[gi]
+            if id(p) in self._lazy:
+                self._last(self._lazy[id(p)])        # (first use: every slice current as of the step count BEFORE this step)
             st["step"] += 1
             t = float(st["step"])
             b1, b2 = grp["betas"]
             hyper[i, 0] = grp["lr"] / (1.0 - b1 ** t)
             hyper[i, 1] = math.sqrt(1.0 - b2 ** t)
+            L = self._lazy.get(id(p))
+            if L is not None:
+                step_i = int(t)
+                L["hist"][step_i] = (float(hyper[i, 0]), float(hyper[i, 1]))
+                ts = active_slice if active_slice is not None else \
+                    self._active_slice.get(id(p), src[6] if (src is not None and src[5] > 0) else None)
+                if ts is not None:
+                    if L["last"][ts] != step_i - 1:
+                        raise RuntimeError(f"FusedAdam: slice {ts} of a lazy parameter is {step_i - 1 - L['last'][ts]} steps behind: "
+                                           "call prepare(t) before the forward of traversal t")
+                    L["last"][ts] = step_i
+                oldest = min(L["last"])
+                for j in [j for j in L["hist"] if j <= oldest]:
+                    del L["hist"][j]
         if self._hyper_dev is None or self._hyper_dev.numel() != hyper.size:
             self._hyper_dev = torch.empty(hyper.size, dtype=torch.float32, device=act[0][1].device)
         staged = torch.empty(hyper.size, dtype=torch.float32, pin_memory=True)
@@ -200,6 +307,7 @@ class FusedAdam(torch.optim.Optimizer):
         call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, int(self.nontemporal),
              stream_of(act[0][1]))
         self._rows.clear()
+        self._active_slice.clear()
         return loss
 
 

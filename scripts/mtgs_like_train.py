@@ -183,6 +183,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
 
 
 VISFIRST = {"on": False, "cs": None}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
+LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
 
 
 def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
@@ -362,7 +363,13 @@ def make_optimizer(kind, P, shipped=None, capturable=False):
               {"params": geo + extra, "lr": 1e-4}]
     if kind == "fused":
         from mtgs_amd.optim import FusedAdam
-        return FusedAdam(groups, eps=1e-15)
+        opt = FusedAdam(groups, eps=1e-15)
+        if LAZY["on"]:      # exact lazy Adam: a step touches the rendered traversal's slice of the per-traversal tensors only
+            for p in P.values():
+                for k in ("features_rest", "features_adapters"):
+                    if k in p and p[k].dim() == (4 if k == "features_rest" else 3) and "features_adapters" in p:
+                        opt.set_lazy_slices(p[k])
+        return opt
     return torch.optim.Adam(groups, eps=1e-15, foreach=True, capturable=capturable)
 
 
@@ -401,6 +408,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             if sparse:
                 losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex, shipped=shipped))
             else:
+                if LAZY["on"]:
+                    opt.prepare(c)
                 losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
         loss = torch.stack(losses).sum()
         params = [q for g in opt.param_groups for q in g["params"]]
@@ -419,6 +428,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 mdist.all_reduce_stats([t for s in stats for t in s[:2]], [s[2] for s in stats],
                                        sum_init=[v for _ in stats for v in (0.0, 1.0)])
             before = sum(p["means"].shape[0] for p in P.values())
+            if LAZY["on"]:
+                opt.flush()                   # every traversal's slice up to date before rows move
             state = {id(q): opt.state.get(q) for q in params}
             added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed)
             opt = make_opt()
@@ -433,6 +444,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             sizes.append(sum(p["means"].shape[0] for p in P.values()))
             ex = mk_ex()                      # N changed: new send buffers and visibility maps
             log(f"step {i + 1}: refine {before} -> {sizes[-1]} Gaussians (+{added} -{culled})")
+    if LAZY["on"]:
+        opt.flush()
     torch.cuda.synchronize()
     if t_start is not None and steps > i_start:
         ms = (time.perf_counter() - t_start) / (steps - i_start) * 1e3
@@ -467,10 +480,15 @@ def main():
                     "given; --steps trains with the fused one unless told otherwise")
     ap.add_argument("--visfirst", action="store_true", help="visibility first: node kernels geometry-only, SH + clamp for the VISIBLE "
                     "Gaussians inside the rasterizer's front end, coefficient gradients as compact rows into the fused Adam")
+    ap.add_argument("--lazy-adam", action="store_true", help="with --visfirst --optimizer fused: the per-traversal tensors' other "
+                    "slices are left untouched by a step and caught up (bit-identically) before their traversal is rendered again")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
     VISFIRST["on"] = bool(args.visfirst)
+    LAZY["on"] = bool(args.lazy_adam)
+    if args.lazy_adam and not (args.visfirst and args.optimizer in (None, "fused")):
+        raise SystemExit("--lazy-adam needs --visfirst and the fused optimizer")
     if args.visfirst and args.optimizer == "torch":
         raise SystemExit("--visfirst hands the colour gradients over as rows: --optimizer fused (or none)")
     dev = torch.device("cuda")
@@ -521,6 +539,8 @@ def main():
         def one(i):
             for q in params:
                 q.grad = None
+            if opt is not None and LAZY["on"]:
+                opt.prepare(i % T)
             loss = iteration(P, cams[i % T], targets[i % T], mask, fused, stats, win, W, H, shipped=shipped)
             if opt is not None:
                 if VISFIRST["cs"] is not None:
@@ -558,13 +578,21 @@ def main():
 
         def replay(t):
             if opt_kind == "fused":
-                opt.advance()          # this step's {lr / bc1, sqrt(bc2)}: one small copy in front of the graph launch
+                if LAZY["on"]:
+                    opt.prepare(t)     # slice t of the per-traversal tensors caught up with the steps it missed (eager launch)
+                opt.advance(active_slice=t if LAZY["on"] else None)   # this step's {lr / bc1, sqrt(bc2)}: one small copy
             graphs[t].replay()
 
-        eager_loss = [float(body(t)) for t in range(T)]        # also teaches the size plan this scene's (n_vis, M)
+        prep = (lambda t: opt.prepare(t)) if (opt is not None and LAZY["on"]) else (lambda t: None)   # (never inside graph_mode:
+        #   its staging buffers are handed out in a fixed sequence; the catch-up is an eager launch in front of a frame)
+        eager_loss = []
+        for t in range(T):                                     # also teaches the size plan this scene's (n_vis, M)
+            prep(t)
+            eager_loss.append(float(body(t)))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.reps):
+            prep(i % T)
             body(i % T)
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) / args.reps * 1e3
@@ -575,6 +603,7 @@ def main():
         side = torch.cuda.Stream()
         for t in range(T):
             gm = mtgs_amd.graph_mode(*caps)
+            prep(t)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), gm:                    # warm-up on the capture stream (allocator, lazy init)
                 body(t)

@@ -202,3 +202,63 @@ def test_fused_adam_refuses_what_it_does_not_implement(hip_lib):
     q.grad = torch.zeros(4)
     with pytest.raises(RuntimeError):
         FusedAdam([q]).step()
+
+
+def test_exact_lazy_adam_for_per_traversal_tensors(hip_lib):
+    """set_lazy_slices: a step updates only the rendered traversal's slice of `[N, T, ...]` tensors; prepare(t) catches slice t
+    up with the zero-gradient steps it missed.  Over a random sequence of traversals with a learning-rate schedule, after
+    flush() parameters AND moments are BIT-IDENTICAL to the optimizer that touches every slice at every step; a slice is
+    current after prepare(t); a step on a slice that is behind is refused."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    N, T = 3001, 4
+    g = torch.Generator().manual_seed(9)
+    base = {"rest": torch.randn(N, T, 15, 3, generator=g) * 0.2, "adapters": torch.randn(N, T, 3, generator=g) * 0.1,
+            "dc": torch.randn(N, 3, generator=g)}
+
+    def make(lazy):
+        P = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        opt = FusedAdam([{"params": [P["rest"]], "lr": 1e-2}, {"params": [P["adapters"], P["dc"]], "lr": 3e-3}], eps=1e-15)
+        if lazy:
+            opt.set_lazy_slices(P["rest"])
+            opt.set_lazy_slices(P["adapters"])
+        return P, opt
+
+    Pa, oa = make(False)
+    Pb, ob = make(True)
+    seq = [0, 2, 2, 1, 0, 3, 3, 3, 1, 2, 0, 0, 1]
+    for step, t in enumerate(seq):
+        vis = torch.rand(N, generator=g) < 0.2
+        n_vis = int(vis.sum())
+        row_of = torch.full((N,), -1, dtype=torch.int32)
+        row_of[vis] = torch.arange(n_vis, dtype=torch.int32)
+        rows = (torch.randn(n_vis, 48, generator=g) * 0.01).to(dev)
+        row_of = row_of.to(dev)
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-2 * 0.95 ** step
+        ob.prepare(t)
+        # after prepare(t) slice t equals the always-stepping optimizer's
+        assert torch.equal(Pa["rest"][:, t], Pb["rest"][:, t]) and torch.equal(Pa["adapters"][:, t], Pb["adapters"][:, t]), step
+        for P, o in ((Pa, oa), (Pb, ob)):
+            o.set_row_gradient(P["dc"], rows, row_of, 0)
+            o.set_row_gradient(P["adapters"], rows, row_of, 0, slice_index=t)
+            o.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t)
+            o.step()
+    behind = [tt for tt in range(T) if tt != seq[-1]]
+    assert any(not torch.equal(Pa["rest"][:, tt], Pb["rest"][:, tt]) for tt in behind)      # (really lazy)
+    ob.flush()
+    for k in base:
+        assert torch.equal(Pa[k], Pb[k]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
+    # a step on a slice that is behind is refused
+    t_bad = 1
+    ob.set_row_gradient(Pb["rest"], rows, row_of, 3, slice_index=t_bad)
+    ob.set_row_gradient(Pb["adapters"], rows, row_of, 0, slice_index=t_bad)
+    ob.set_row_gradient(Pb["dc"], rows, row_of, 0)
+    ob.step()                                   # all slices are current right after flush(): fine
+    ob.set_row_gradient(Pb["rest"], rows, row_of, 3, slice_index=2)
+    ob.set_row_gradient(Pb["adapters"], rows, row_of, 0, slice_index=2)
+    ob.set_row_gradient(Pb["dc"], rows, row_of, 0)
+    with pytest.raises(RuntimeError):
+        ob.step()                               # slice 2 missed the previous step and was not prepared
