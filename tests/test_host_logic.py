@@ -178,3 +178,33 @@ def test_collect_gaussians_rejects_empty_and_wrong_dtype():
             "opacities": torch.zeros(N, 1), "features_dc": torch.zeros(N, 3), "features_rest": torch.zeros(N, 15, 3)}
     with pytest.raises(TypeError, match="float32"):
         collect_gaussians([node], c2w, 3, 3)
+
+
+def test_round3_host_logic_without_a_gpu():
+    """FusedAdam refuses CPU parameters and the options it does not implement before anything touches the library; the
+    descriptor record has the documented fields; the exchange exposes its phase; a ColorSource cannot hand rows over before a
+    backward."""
+    import pytest
+    import torch
+    from mtgs_amd import dist as mdist, nodes, optim
+    p = torch.zeros(8, requires_grad=True)
+    p.grad = torch.zeros(8)
+    with pytest.raises(RuntimeError):
+        optim.FusedAdam([p]).step()
+    with pytest.raises(NotImplementedError):
+        optim.FusedAdam([p], amsgrad=True)
+    with pytest.raises(ValueError):
+        optim.FusedAdam([p], lr=-1.0)
+    o = optim.FusedAdam([p])
+    with pytest.raises(ValueError):      # rows must be float32 [R, stride] with an int32 map of one entry per Gaussian
+        o.set_row_gradient(p, torch.zeros(3, 4), torch.zeros(7, dtype=torch.int32), 0)
+    assert {"p", "m", "v", "g", "rows", "row_of", "catchup", "sub_width", "sub_index", "slice_only", "catchup_k"} <= set(optim._GROUP.names)
+    m, v, _ = None, None, None
+    ref = optim.adam_reference_step(torch.ones(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64),
+                                    torch.full((3,), 0.5, dtype=torch.float64), 1, 1e-2, eps=1e-15)
+    assert torch.allclose(ref[0], torch.full((3,), 1.0 - 1e-2, dtype=torch.float64))     # first Adam step = lr * sign(g)
+    ex = mdist.SparseGradExchange(1000, 16, "cpu")
+    assert ex.phase == "idle" and ex.world_collectives is False
+    cs = nodes.ColorSource(None, 1, 3, None, [], [])
+    with pytest.raises(AssertionError):
+        cs.apply_to(o)
