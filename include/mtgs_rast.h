@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 12
+#define MTGS_RAST_ABI_VERSION 13
 
 enum {
     MTGS_OK = 0,

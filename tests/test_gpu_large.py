@@ -76,7 +76,10 @@ def test_large_scene_culling_invariance(hip_lib, N, W, H, scale_mul, min_M):
         sel = g_full[idx]
         scale = float(g_sub.abs().max()) + 1e-20
         err = float((sel - g_sub).abs().max()) / scale
-        assert err < 2e-4, (k, err)             # fp32 atomic order only
+        # fp32 atomic order only.  The position gradient of a large near-camera splat sums ~10^4 per-tile contributions of
+        # both signs: over ten runs its worst row moved by 1e-5 ... 1.7e-4 of the largest gradient, every other tensor by
+        # < 2e-5 (scripts/dev/large_margin.py)
+        assert err < (6e-4 if k == "means" else 1e-4), (k, err)
         # rows of culled Gaussians are exactly zero: all of the gradient mass sits in the visible rows
         nz = (g_full.reshape(N, -1) != 0).any(1)
         assert int(nz.sum()) == int(nz[idx].sum()), k

@@ -249,3 +249,16 @@ def projection_vjp_accounted(case, oracle, dbg, a, vm, K, W, H, m, got, bound=1e
     for name, ref in (("means", r_vm), ("quats", r_vq), ("scales", r_vs), ("opacities", r_vo)):
         st = assert_grad_close(f"VJP(device rows) v_{name}", got[name], ref, case=case, row_rel_p999=bound, rel_to_max=bound)
         assert st["row_rel_max"] <= bound, f"projection VJP on the device's rows, v_{name}: a row is {st['row_rel_max']:.3e} off"
+
+
+def refinement_sizes(stdout):
+    """(N before, N after) of every refinement scripts/mtgs_like_train.py printed."""
+    import re
+    return [(int(a), int(b)) for a, b in re.findall(r"refine (\d+) -> (\d+) Gaussians", stdout)]
+
+
+def same_refinements(x, y, count):
+    """Two runs of the same job that add the same numbers in a different order (ranks vs accumulation, compact vs dense colour
+    gradients; the compositing atomics have no fixed order at all) refine alike -- except that a Gaussian whose statistic sits
+    within rounding of a threshold may fall on either side: at most one in 10^4 (and never fewer than 2 allowed)."""
+    return len(x) == len(y) == count and all(abs(p - q) <= max(2, q // 10000) for a, b in zip(x, y) for p, q in zip(a, b))
