@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 13
+#define MTGS_RAST_ABI_VERSION 14
 
 enum {
     MTGS_OK = 0,
@@ -620,8 +620,9 @@ int mtgs_rows_expand(int64_t N, int width, const int32_t *row_of, const float *r
  * rows (vanilla_gaussian_splatting.py:392-446 -> mtgs_refine_rows).  Arithmetic = torch.optim.Adam (amsgrad = False,
  * maximize = False) in fp32:  g = grad_scale * g + weight_decay * p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
  * p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)  with step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) computed
- * by the caller in double for the step t being taken and passed as `hyper[n_groups][2]` = {step_size, bc2_sqrt} per group in
- * DEVICE memory -- apart from the table, so that a step captured in a HIP graph is advanced by one small copy per replay
+ * by the caller in double for the step t being taken and passed as `hyper[.][4]` = {step_size f32, bc2_sqrt f32, t i32,
+ * pending i32} per group in DEVICE memory (row hyper_index of the group; t and pending are read by the row-lazy groups
+ * below only) -- apart from the table, so that a step captured in a HIP graph is advanced by one small copy per replay
  * (learning-rate schedules and the bias corrections change every step; the table does not).
  * A table of descriptors in DEVICE memory (8-byte aligned), one per tensor; workgroup b works on group i with
  * first_block[i] <= b < first_block[i + 1], first_block = running sum of ceil(n / mtgs_adam_block_elems()).
@@ -635,6 +636,8 @@ typedef struct mtgs_adam_group {
     const float *rows;          /* compact gradient rows or NULL */
     const int32_t *row_of;      /* [n / width] row of every item, < 0: none */
     const float *catchup;       /* catchup_k > 0: {step_size, bc2_sqrt} of the catchup_k steps to apply, oldest first (DEVICE) */
+    int32_t *last;              /* row-lazy groups: [n, T] step up to which slice (i, t) of item i is current */
+    float *hist;                /* row-lazy groups: {step_size, bc2_sqrt} of step j at hist[2 j] (DEVICE; the step launch appends) */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
     int32_t width, row_col;
@@ -642,11 +645,14 @@ typedef struct mtgs_adam_group {
     int32_t sub_width, sub_index;   /* sub_width > 0: an item is `width / sub_width` slices of sub_width floats (a per-traversal
                                      * tensor [N, T, ...]); only slice sub_index takes the row's gradient
                                      * rows[.., row_col + e % sub_width], the other slices get zero */
-    int32_t slice_only;             /* 1 (with sub_width): the group IS slice sub_index of a [N, T, ...] tensor -- n = N * sub_width
+    int32_t mode;                   /* MTGS_ADAM_DENSE: every element, as above.
+                                     * MTGS_ADAM_SLICE (with sub_width): the group IS slice sub_index of a [N, T, ...] tensor -- n = N * sub_width
                                      * virtual elements, element e lives at p[(e / sub_width) * width + sub_index * sub_width + e % sub_width];
-                                     * the other slices are neither read nor written (exact lazy Adam, below) */
-    int32_t catchup_k;              /* > 0: no gradient step -- apply catchup_k ZERO-gradient steps with the scalars in `catchup` */
-    int32_t reserved;
+                                     * the other slices are neither read nor written (exact lazy Adam, below).
+                                     * MTGS_ADAM_ROWS_CATCHUP / _ROWS_STEP / _ROWS_FLUSH: row-lazy groups, below (n = number of ITEMS) */
+    int32_t catchup_k;              /* SLICE: > 0: no gradient step -- apply catchup_k ZERO-gradient steps with the scalars in `catchup`.
+                                     * ROWS_CATCHUP / ROWS_FLUSH: the step to catch up to, or < 0: hyper.t - hyper.pending */
+    int32_t hyper_index;            /* row of `hyper` that belongs to this group */
     float one_minus_beta1, beta2, one_minus_beta2;   /* 1 - beta rounded from double by the caller (1 - 0.999f is 5e-5 off) */
     float eps, weight_decay, grad_scale;
 } mtgs_adam_group;
@@ -656,10 +662,26 @@ typedef struct mtgs_adam_group {
  * can be left untouched (slice_only groups step the rendered slice alone) and CAUGHT UP before its traversal is rendered
  * again: catchup_k zero-gradient steps per element in registers, the same operations in the same order as stepping every
  * time (bit-identical), at 24 B per element of ONE slice instead of 24 B x T per step. */
+enum { MTGS_ADAM_DENSE = 0, MTGS_ADAM_SLICE = 1, MTGS_ADAM_ROWS_CATCHUP = 2, MTGS_ADAM_ROWS_STEP = 3, MTGS_ADAM_ROWS_FLUSH = 4 };
+/* Row-lazy Adam (exact) for tensors of which a frame READS ONLY THE VISIBLE ROWS -- with visibility-first colours
+ * (mtgs_vis_color_fwd) the SH coefficients: 48 of a Gaussian's 59 floats, of which a camera needs ~15 %.  A Gaussian the
+ * frame does not see gets the zero gradient: its moments decay and p drifts along exp_avg, which nothing reads until the
+ * Gaussian is seen again.  So `last[i, t]` records the step up to which slice t of item i is current, `hist` the per-step
+ * scalars, and
+ *   ROWS_CATCHUP (the forward, after mtgs_front_fwd and before mtgs_vis_color_fwd): for every item with row_of[i] >= 0 apply
+ *                the zero-gradient steps last + 1 .. target in registers (the same operations in the same order as stepping
+ *                every time: BIT-IDENTICAL), target = catchup_k or, < 0, hyper.t - hyper.pending = the steps already taken;
+ *   ROWS_STEP    (the optimizer step, same launch as the other groups): for the items with row_of[i] >= 0 catch up to t - 1 if
+ *                needed, apply step t with the gradient rows[row_of[i] * row_stride + row_col + c], set last = t; one
+ *                thread appends hist[t] and clears hyper.pending (which the caller's copy of this step's scalars had set:
+ *                a forward captured in the same HIP graph as its step reads t - 1 as the steps already taken);
+ *   ROWS_FLUSH   every item behind the target is caught up (checkpoints, refinement, anything else that reads the tensor).
+ * Items untouched by a launch cost 4 bytes (row_of or last).  first_block advances by ceil(n / mtgs_adam_block_rows()). */
 int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check their layout against it */
 int mtgs_adam_block_elems(void);    /* elements one workgroup updates */
+int mtgs_adam_block_rows(void);     /* items one workgroup scans (row-lazy groups) */
 /* nontemporal != 0: moments (and a dense gradient) are streamed past the caches (they are touched once per step). */
-int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, const float *hyper, int64_t total_blocks, int nontemporal,
+int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks, int nontemporal,
                    void *stream);
 
 #ifdef __cplusplus

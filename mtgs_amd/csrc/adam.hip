@@ -20,12 +20,20 @@
 // and handed over as hyper[group] = {lr / bc1, sqrt(bc2)} in device memory: the only per-step state, so a step captured
 // in a HIP graph is advanced by one 8-byte-per-group copy in front of the replay.
 // HBM-bound: 28 B per element dense, 24 B + the visible rows otherwise.
+//
+// Row-lazy groups (MTGS_ADAM_ROWS_*, include/mtgs_rast.h): tensors of which a frame reads the visible rows only (the SH
+// coefficients under visibility-first colours).  A workgroup scans ADAM_ROWS items: every wave reads 64 row_of (or last)
+// entries, compacts the selected ones with a ballot and walks them four at a time -- 16 lanes per row, up to three
+// 16-float segments of the row per lane in flight.  A row lives in ONE wave, so `last` is read by all of the row's lanes
+// before one of them rewrites it.
 #include "common.hpp"
 
 #define ADAM_BLOCK 256
 #define ADAM_VEC 4
 #define ADAM_UNROLL 4
 #define ADAM_ELEMS (ADAM_BLOCK * ADAM_VEC * ADAM_UNROLL)   // elements per workgroup
+#define ADAM_ROWS 1024                                      // items a workgroup scans (row-lazy groups): 4 waves x 4 x 64
+#define ADAM_SEG 3                                          // 16-float segments of a row per pass (48 floats: degree-3 SH)
 
 namespace {
 
@@ -84,19 +92,96 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
     return d.rows[(int64_t)r * d.row_stride + d.row_col + c];
 }
 
+// Row-lazy group: see the header of this file.  `hy` = the group's hyper row {step_size, bc2_sqrt, t, pending}.
+__device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
+    __shared__ int s_list[ADAM_BLOCK / 64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sw = d.sub_width > 0 ? d.sub_width : d.width;          // floats of the slice this group works on
+    const int T = d.sub_width > 0 ? d.width / d.sub_width : 1;
+    const int64_t off = d.sub_width > 0 ? (int64_t)d.sub_index * sw : 0;
+    const int t_now = reinterpret_cast<const int32_t *>(hy)[2], pending = reinterpret_cast<const int32_t *>(hy)[3];
+    const bool step = d.mode == MTGS_ADAM_ROWS_STEP, flush = d.mode == MTGS_ADAM_ROWS_FLUSH;
+    const int target = step ? t_now - 1 : (d.catchup_k >= 0 ? d.catchup_k : t_now - pending);   // zero-gradient steps up to here
+    if (step && block_in_group == 0 && threadIdx.x == 0) {
+        d.hist[2 * (int64_t)t_now] = h.step_size;
+        d.hist[2 * (int64_t)t_now + 1] = h.bc2_sqrt;
+        reinterpret_cast<int32_t *>(hy)[3] = 0;      // (nothing in a step launch reads it)
+    }
+    const int q_in_wave = lane >> 4, c0 = lane & 15;
+#pragma unroll 1
+    for (int chunk = 0; chunk < ADAM_ROWS / ADAM_BLOCK; ++chunk) {
+        const int64_t i0 = block_in_group * ADAM_ROWS + ((int64_t)wave * (ADAM_ROWS / ADAM_BLOCK) + chunk) * 64;
+        if (i0 >= d.n) break;
+        const int64_t i_own = i0 + lane;
+        bool sel = false;
+        if (i_own < d.n) sel = flush ? d.last[i_own * T + d.sub_index] < target : d.row_of[i_own] >= 0;
+        const unsigned long long mask = __ballot(sel);
+        const int cnt = __popcll(mask);
+        if (cnt == 0) continue;
+        if (sel) s_list[wave][__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = lane;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int q0 = 0; q0 < cnt; q0 += 4) {
+            const int q = q0 + q_in_wave;
+            const bool act = q < cnt;
+            const int64_t i = i0 + (act ? s_list[wave][q] : 0);
+            int32_t *lastp = d.last + i * T + d.sub_index;
+            const int L = act ? *lastp : target;
+            const int32_t r = (act && step) ? d.row_of[i] : -1;
+            const bool work = act && (step || L < target);
+#pragma unroll 1
+            for (int cb = 0; cb < sw; cb += 16 * ADAM_SEG) {
+                float p[ADAM_SEG], m[ADAM_SEG], v[ADAM_SEG], g[ADAM_SEG];
+                int64_t phys[ADAM_SEG];
+#pragma unroll
+                for (int u = 0; u < ADAM_SEG; ++u) {
+                    const int c = cb + 16 * u + c0;
+                    phys[u] = (work && c < sw) ? i * d.width + off + c : -1;
+                    g[u] = 0.f;
+                    if (phys[u] >= 0) {
+                        p[u] = d.p[phys[u]]; m[u] = d.m[phys[u]]; v[u] = d.v[phys[u]];
+                        if (r >= 0) g[u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
+                    }
+                }
+                Hyper hj = h;
+                for (int j = L + 1; j <= target; ++j) {      // the zero-gradient steps this row missed, oldest first
+                    hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1];
+#pragma unroll
+                    for (int u = 0; u < ADAM_SEG; ++u)
+                        if (phys[u] >= 0) adam_update(p[u], m[u], v[u], 0.f, hj);
+                }
+#pragma unroll
+                for (int u = 0; u < ADAM_SEG; ++u) {
+                    if (phys[u] < 0) continue;
+                    if (step) adam_update(p[u], m[u], v[u], g[u], h);
+                    d.p[phys[u]] = p[u]; d.m[phys[u]] = m[u]; d.v[phys[u]] = v[u];
+                }
+            }
+            // (every lane of the row has read `last` above: same wave, program order)
+            if (work && c0 == 0) *lastp = step ? t_now : target;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group *__restrict__ table,
-                                                          const float *__restrict__ hyper, int n_groups) {
+                                                          float *__restrict__ hyper, int n_groups) {
     const int gi = find_group(table, n_groups, (int64_t)blockIdx.x);
     const mtgs_adam_group d = table[gi];
+    float *hy = hyper + 4 * (int64_t)d.hyper_index;
     Hyper h;
     h.one_minus_b1 = d.one_minus_beta1; h.b2 = d.beta2; h.one_minus_b2 = d.one_minus_beta2;
-    h.step_size = hyper[2 * gi]; h.bc2_sqrt = hyper[2 * gi + 1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
+    h.step_size = hy[0]; h.bc2_sqrt = hy[1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
+    if (d.mode >= MTGS_ADAM_ROWS_CATCHUP) {
+        adam_rows(d, h, hy, (int64_t)blockIdx.x - d.first_block);
+        return;
+    }
     const int64_t base = ((int64_t)blockIdx.x - d.first_block) * ADAM_ELEMS;
     float *__restrict__ P = d.p, *__restrict__ M = d.m, *__restrict__ V = d.v;
     const bool dense = d.g != nullptr;
     const bool rows = d.rows != nullptr;
-    if (d.slice_only) {
+    if (d.mode == MTGS_ADAM_SLICE) {
         // ONE slice of a per-traversal tensor: virtual element e -> p[(e / sub_width) * width + sub_index * sub_width + e % sub_width];
         // the other slices are not touched.  A slice row is sub_width contiguous floats at a 4-byte-aligned offset: 4-byte
         // accesses, coalesced across the wave.  (A 16-elements-per-lane version with multiply-high row indices and
@@ -200,8 +285,9 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
 
 extern "C" int mtgs_adam_group_bytes(void) { return (int)sizeof(mtgs_adam_group); }
 extern "C" int mtgs_adam_block_elems(void) { return ADAM_ELEMS; }
+extern "C" int mtgs_adam_block_rows(void) { return ADAM_ROWS; }
 
-extern "C" int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, const float *hyper, int64_t total_blocks,
+extern "C" int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks,
                               int nontemporal, void *stream) {
     MTGS_REQUIRE(n_groups >= 0 && total_blocks >= 0, MTGS_EINVAL, "mtgs_adam_step: negative size");
     if (n_groups == 0 || total_blocks == 0) return MTGS_OK;

@@ -184,6 +184,22 @@ class ColorSource:
         self.node_params = node_params     # per node: (start, n, features_dc, features_adapters | None, features_rest, traversal | None)
         self.rows = self.row_of = None
         self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
+        self.optimizer = None   # a FusedAdam with row-lazy colour parameters: catch_up() runs before the coefficients are read
+
+    def catch_up(self, vis_rank: Tensor) -> None:
+        """Called by the rasterization between its front end and the colour kernel: the coefficient rows of the Gaussians
+        the frame sees are brought up to date (FusedAdam.set_row_lazy / catch_up_rows).  vis_rank int32 [N]: row or -1."""
+        if self.optimizer is None:
+            return
+        items = []
+        for start, n, dc, adapters, rest, trav in self.node_params:
+            ro = vis_rank[start:start + n]
+            items.append((dc, ro, None))
+            if adapters is not None:
+                items.append((adapters, ro, trav if adapters.dim() == 3 else None))
+            if rest.shape[-2] > 0:
+                items.append((rest, ro, trav if rest.dim() == 4 else None))
+        self.optimizer.catch_up_rows(items)
 
     def apply_to(self, optimizer) -> None:
         """optimizer.set_row_gradient(...) for every colour parameter of every node (call between backward() and step())."""

@@ -22,6 +22,14 @@ the zero-gradient steps it missed (the same operations in the same order as step
 optimizer's traffic no longer grows with the number of traversals.  `flush()` before anything else reads the parameters
 (checkpoints, refinement, evaluation with another traversal).
 
+Exact ROW-lazy Adam (`set_row_lazy(param)`) for parameters of which a frame reads the visible rows only -- the SH
+coefficients under visibility-first colours (mtgs_amd.nodes.ColorSource): a Gaussian the frame does not see has a zero
+gradient, its moments decay and its value drifts along exp_avg, but nothing reads it until it is seen again.  The step then
+touches the VISIBLE rows alone, and the forward catches a row up (the zero-gradient steps it missed, in registers, the same
+operations in the same order: bit-identical) right before it is read (`ColorSource.optimizer = opt` wires
+`catch_up_rows()` between the front end and the colour kernel).  Optimizer traffic for the coefficients drops from every
+Gaussian x every traversal to the visible rows of the rendered traversal.  `flush()` as above; `state_dict()` flushes.
+
 HIP graphs: the per-step scalars (lr / (1 - beta1^t), sqrt(1 - beta2^t)) live in a small device array that `advance()`
 refreshes with one copy; `step()` = `advance()` + the launch.  Capture `step()` once, then per replay call `advance()` and
 replay (the copy is enqueued on the stream in front of the graph launch).
@@ -37,10 +45,12 @@ import torch
 from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
+                   ("last", "<u8"), ("hist", "<u8"),
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
-                   ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("slice_only", "<i4"), ("catchup_k", "<i4"),
-                   ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
+                   ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
+                   ("hyper_index", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
                    ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
+MODE_DENSE, MODE_SLICE, MODE_ROWS_CATCHUP, MODE_ROWS_STEP, MODE_ROWS_FLUSH = 0, 1, 2, 3, 4   # include/mtgs_rast.h MTGS_ADAM_*
 _checked = False
 
 
@@ -66,6 +76,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._rows = {}                # id(param) -> (rows, row_of, col, stride)
         self._lazy = {}                # id(param) -> {"param", "T", "last": [step up to which slice t is current], "hist": [(step_size, bc2_sqrt)]}
         self._active_slice = {}        # id(param) -> slice the coming step() updates (lazy parameters)
+        self._rowlazy = {}             # id(param) -> {"param", "T", "last": int32 [N * T], "hist": float32 [2 * cap], "cap"}
+        self._hyper_index = {}         # id(param) -> row of the device hyper array (position in the active list)
+        self._captured = False         # a step() was captured in a HIP graph: the host no longer knows which steps have run
+        self._pending_host = False     # eager: _advance() ran, the launch did not yet
+        self._catch_key = self._catch_table = None
         self._table_key = None
         self._table_dev = self._hyper_dev = None
         self._active = []
@@ -146,7 +161,7 @@ class FusedAdam(torch.optim.Optimizer):
             sw = width // L["T"]
             r = tab[i]
             r["p"], r["m"], r["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            r["n"], r["first_block"], r["width"], r["sub_width"], r["sub_index"], r["slice_only"] = p.shape[0] * sw, fb, width, sw, t, 1
+            r["n"], r["first_block"], r["width"], r["sub_width"], r["sub_index"], r["mode"] = p.shape[0] * sw, fb, width, sw, t, MODE_SLICE
             r["catchup"], r["catchup_k"] = hist_dev.data_ptr() + 4 * off, k
             b1, b2 = grp["betas"]
             r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2
@@ -155,9 +170,7 @@ class FusedAdam(torch.optim.Optimizer):
             off += 2 * k
             L["last"][t] = cur
         table = upload_table(tab, dev)
-        dummy = hist_dev     # (the per-group {step_size, bc2_sqrt} array is not read by catch-up groups)
-        if dummy.numel() < 2 * len(todo):
-            dummy = torch.zeros(2 * len(todo), dtype=torch.float32, device=dev)
+        dummy = torch.zeros(4, dtype=torch.float32, device=dev)     # (hyper row 0: not used by catch-up groups)
         call("mtgs_adam_step", len(todo), ptr(table), ptr(dummy), fb, int(self.nontemporal), stream_of(todo[0][0]["param"]))
 
     def prepare(self, t: int) -> None:
@@ -167,6 +180,117 @@ class FusedAdam(torch.optim.Optimizer):
     def flush(self) -> None:
         """Every slice of every lazy parameter up to date (checkpoints, refinement, evaluation)."""
         self._catch_up([(L, t) for L in self._lazy.values() for t in range(L["T"])])
+        self._flush_rows()
+
+    # ---- exact row-lazy Adam (visible rows only) ---------------------------------------------------------------------------
+    def set_row_lazy(self, param: torch.Tensor, traversals: Optional[int] = None, hist_capacity: int = 1 << 17) -> None:
+        """`param[N, ...]` (traversals=None) or `param[N, T, ...]` (traversals=T: the step's set_row_gradient names the slice):
+        from now on step() updates only the rows the step's row map marks visible, catch_up_rows() brings rows up to date
+        before a forward reads them, flush() all of them.  The parameter's gradient must come through set_row_gradient().
+        hist_capacity: optimizer steps the per-step scalar history holds (8 bytes each; grown on demand outside HIP graphs)."""
+        if not param.is_contiguous() or param.dtype != torch.float32 or not param.is_cuda:
+            raise RuntimeError("FusedAdam.set_row_lazy: contiguous float32 HIP parameter")
+        T = 1 if traversals is None else int(traversals)
+        if traversals is not None and (param.dim() < 2 or param.shape[1] != T):
+            raise ValueError("set_row_lazy: traversals must equal param.shape[1]")
+        st = self.state.get(param, {})
+        s0 = int(float(st["step"])) if "step" in st else 0
+        cap = max(int(hist_capacity), s0 + 2)
+        self._rowlazy[id(param)] = {"param": param, "T": T, "cap": cap,
+                                    "last": torch.full((param.shape[0] * T,), s0, dtype=torch.int32, device=param.device),
+                                    "hist": torch.zeros(2 * cap, dtype=torch.float32, device=param.device)}
+
+    def _rows_target(self, p) -> int:
+        """The step zero-gradient catch-up goes up to: the steps already TAKEN.  Known to the host in eager use; once a step
+        has been captured in a HIP graph only the device knows (< 0: the kernel reads it next to the step's scalars)."""
+        if self._captured or torch.cuda.is_current_stream_capturing():
+            return -1
+        return int(float(self.state[p]["step"])) - (1 if self._pending_host else 0)
+
+    def _rows_groups(self, items, mode):
+        """Descriptor rows for [(row-lazy record, row_of | None, slice)] -> (table, blocks) or None."""
+        _check_layout()
+        per_block = load().mtgs_adam_block_rows()
+        recs = []
+        for RL, ro, t in items:
+            p = RL["param"]
+            st = self.state.get(p)
+            if not st or "exp_avg" not in st or self._hyper_dev is None:
+                continue                       # no step taken yet: nothing to catch up
+            target = self._rows_target(p)
+            hi = self._hyper_index.get(id(p))
+            if hi is None:
+                if target < 0:
+                    raise RuntimeError("FusedAdam: a row-lazy parameter that the captured step does not update")
+                hi = 0                         # (explicit target: the hyper row is not read)
+            recs.append((RL, ro, t, target, hi))
+        if not recs:
+            return None
+        tab = np.zeros(len(recs), _GROUP)
+        fb = 0
+        for i, (RL, ro, t, target, hi) in enumerate(recs):
+            p = RL["param"]
+            st = self.state[p]
+            grp = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+            N = p.shape[0]
+            width = p.numel() // max(N, 1)
+            r = tab[i]
+            r["p"], r["m"], r["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            r["last"], r["hist"], r["n"], r["first_block"], r["width"] = RL["last"].data_ptr(), RL["hist"].data_ptr(), N, fb, width
+            if RL["T"] > 1:
+                r["sub_width"], r["sub_index"] = width // RL["T"], int(t)
+            if ro is not None:
+                if ro.dtype != torch.int32 or ro.numel() != N or not ro.is_contiguous():
+                    raise ValueError("catch_up_rows: row_of int32 [N]")
+                r["row_of"] = ro.data_ptr()
+            r["mode"], r["catchup_k"], r["hyper_index"] = mode, target, hi
+            b1, b2 = grp["betas"]
+            r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2
+            r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
+            fb += -(-N // per_block)
+        return tab, fb
+
+    def catch_up_rows(self, items) -> None:
+        """items: [(param, row_of int32 [N], slice | None)] -- the rows with row_of >= 0 of every row-lazy parameter among them
+        are brought up to date (the zero-gradient steps since they were last touched), one launch.  Called by the forward
+        between the front end (which knows the visible Gaussians) and the kernel that reads their coefficients."""
+        todo = []
+        for p, ro, t in items:
+            RL = self._rowlazy.get(id(p))
+            if RL is not None:
+                if RL["T"] > 1 and t is None:
+                    raise ValueError("catch_up_rows: a per-traversal parameter needs its slice")
+                todo.append((RL, ro, 0 if t is None else int(t)))
+        built = self._rows_groups(todo, MODE_ROWS_CATCHUP)
+        if built is None:
+            return
+        tab, blocks = built
+        key = tab.tobytes()
+        if key != self._catch_key or torch.cuda.is_current_stream_capturing():
+            from .nodes import upload_table
+            self._catch_table, self._catch_key = upload_table(tab, todo[0][0]["param"].device), key
+        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, stream_of(todo[0][0]["param"]))
+
+    def _flush_rows(self) -> None:
+        items = [(RL, None, t) for RL in self._rowlazy.values() for t in range(RL["T"])]
+        built = self._rows_groups(items, MODE_ROWS_FLUSH)
+        if built is None:
+            return
+        tab, blocks = built
+        from .nodes import upload_table
+        dev = items[0][0]["param"].device
+        call("mtgs_adam_step", len(tab), ptr(upload_table(tab, dev)), ptr(self._hyper_dev), blocks, 0, stream_of(items[0][0]["param"]))
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for RL in list(self._rowlazy.values()):      # everything loaded is current as of its step count
+            self.set_row_lazy(RL["param"], None if RL["T"] == 1 else RL["T"], RL["cap"])
+        for L in self._lazy.values():
+            L["last"], L["hist"] = None, {}
 
     # ---- the step ----------------------------------------------------------------------------------------------------
     def _collect(self):
@@ -224,6 +348,19 @@ class FusedAdam(torch.optim.Optimizer):
                 r["sub_width"], r["sub_index"] = sub_w, sub_i
                 keep.append((rows, row_of))
             r["vec_ok"] = int(align % 16 == 0)
+            r["hyper_index"] = i
+            RL = self._rowlazy.get(id(p))
+            if RL is not None:      # row-lazy: the visible rows alone (scan of the row map: ceil(N / rows per block) workgroups)
+                if src is None:
+                    raise RuntimeError("FusedAdam: a row-lazy parameter takes its gradient through set_row_gradient()")
+                if (RL["T"] > 1) != (src[5] > 0) or (src[5] > 0 and src[4] // src[5] != RL["T"]):
+                    raise RuntimeError("FusedAdam: row-lazy parameter and the slice of its row gradient do not match")
+                r["mode"], r["last"], r["hist"], r["n"] = MODE_ROWS_STEP, RL["last"].data_ptr(), RL["hist"].data_ptr(), p.shape[0]
+                fb += -(-int(p.shape[0]) // load().mtgs_adam_block_rows())
+                b1, b2 = grp["betas"]
+                r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2
+                r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
+                continue
             L = self._lazy.get(id(p))
             if L is not None:       # lazy per-traversal tensor: this step touches the rendered slice alone
                 t = self._active_slice.get(id(p), src[6] if (src is not None and src[5] > 0) else None)
@@ -231,18 +368,18 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: a lazy per-traversal parameter needs its slice (set_active_slice / slice_index)")
                 width = p.numel() // p.shape[0]
                 sw = width // L["T"]
-                r["width"], r["sub_width"], r["sub_index"], r["slice_only"], r["n"] = width, sw, int(t), 1, p.shape[0] * sw
+                r["width"], r["sub_width"], r["sub_index"], r["mode"], r["n"] = width, sw, int(t), MODE_SLICE, p.shape[0] * sw
             b1, b2 = grp["betas"]
             r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2   # (differences taken in double)
             r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
             fb += -(-int(r["n"]) // elems)
         key = tab.tobytes()
-        if key != self._table_key:
+        # (while capturing the table is always uploaded: the copy becomes part of the graph and its destination lives in the
+        #  graph's memory pool -- a cached table of an earlier eager step would be freed when the next graph replaces it)
+        if key != self._table_key or torch.cuda.is_current_stream_capturing():
             from .nodes import upload_table
             dev = act[0][1].device
             self._table_dev = upload_table(tab, dev)
-            if self._hyper_dev is None or self._hyper_dev.numel() != 2 * len(act) or self._hyper_dev.device != dev:
-                self._hyper_dev = torch.empty(2 * len(act), dtype=torch.float32, device=dev)
             self._table_key = key
         self._blocks = fb
         self._keep = keep
@@ -258,7 +395,8 @@ class FusedAdam(torch.optim.Optimizer):
     def _advance(self, act, active_slice=None) -> None:
         if not act:
             return
-        hyper = np.empty((len(act), 2), np.float32)
+        hyper = np.zeros((len(act), 4), np.float32)      # {step_size, bc2_sqrt, step (int32), pending (int32)} per tensor
+        hyper_i = hyper.view(np.int32)
         for i, (gi, p, st, g, src) in enumerate(act):
             grp = self.param_groups[gi]
             if id(p) in self._lazy:
@@ -268,6 +406,14 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = grp["betas"]
             hyper[i, 0] = grp["lr"] / (1.0 - b1 ** t)
             hyper[i, 1] = math.sqrt(1.0 - b2 ** t)
+            hyper_i[i, 2], hyper_i[i, 3] = int(t), 1
+            RL = self._rowlazy.get(id(p))
+            if RL is not None and int(t) >= RL["cap"]:      # room for this step's scalars (the step launch appends them)
+                if self._captured:
+                    raise RuntimeError("FusedAdam: the row-lazy history is full; set_row_lazy(..., hist_capacity=) before capturing")
+                grown = torch.zeros(4 * RL["cap"], dtype=torch.float32, device=p.device)
+                grown[:2 * RL["cap"]] = RL["hist"]
+                RL["hist"], RL["cap"] = grown, 2 * RL["cap"]
             L = self._lazy.get(id(p))
             if L is not None:
                 step_i = int(t)
@@ -287,6 +433,7 @@ class FusedAdam(torch.optim.Optimizer):
         staged = torch.empty(hyper.size, dtype=torch.float32, pin_memory=True)
         staged.numpy()[:] = hyper.reshape(-1)
         self._hyper_dev.copy_(staged, non_blocking=True)
+        self._pending_host = True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -298,9 +445,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._active = act
         if not act:
             return loss
+        self._hyper_index = {id(a[1]): i for i, a in enumerate(act)}
         if not torch.cuda.is_current_stream_capturing():
             self._advance(act)
-        elif self._hyper_dev is None or self._hyper_dev.numel() != 2 * len(act):
+        elif self._hyper_dev is None or self._hyper_dev.numel() != 4 * len(act):
             # (pinned allocation is not permitted while capturing, and the step count must not advance at capture time)
             raise RuntimeError("FusedAdam: run one eager step() before capturing one (state and device buffers are created there)")
         table = self._table(act)
@@ -308,6 +456,9 @@ class FusedAdam(torch.optim.Optimizer):
              stream_of(act[0][1]))
         self._rows.clear()
         self._active_slice.clear()
+        self._pending_host = False
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
         return loss
 
 

@@ -611,6 +611,7 @@ class _FusedRasterization(torch.autograd.Function):
                      (1 if dp is not None else 0) if cs is None else 2, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 if cs is not None:   # colours of the visible Gaussians, straight into their records
+                    cs.catch_up(vis_rank)     # (row-lazy optimizer: the rows about to be read, brought up to date)
                     call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
                          ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), st)
                 b["mailbox"], b["tag"] = mailbox, tag

@@ -262,3 +262,154 @@ def test_exact_lazy_adam_for_per_traversal_tensors(hip_lib):
     ob.set_row_gradient(Pb["dc"], rows, row_of, 0)
     with pytest.raises(RuntimeError):
         ob.step()                               # slice 2 missed the previous step and was not prepared
+
+
+def _row_lazy_case(dev, N, T, g):
+    base = {"rest": torch.randn(N, T, 15, 3, generator=g) * 0.2, "adapters": torch.randn(N, T, 3, generator=g) * 0.1,
+            "dc": torch.randn(N, 3, generator=g), "means": torch.randn(N, 3, generator=g)}
+
+    def make(lazy, **kw):
+        from mtgs_amd.optim import FusedAdam
+        P = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        opt = FusedAdam([{"params": [P["rest"]], "lr": 1e-2}, {"params": [P["adapters"], P["dc"]], "lr": 3e-3},
+                         {"params": [P["means"]], "lr": 1e-4}], eps=1e-15)
+        if lazy:
+            opt.set_row_lazy(P["rest"], traversals=T, **kw)
+            opt.set_row_lazy(P["adapters"], traversals=T, **kw)
+            opt.set_row_lazy(P["dc"], **kw)
+        return P, opt
+    return base, make
+
+
+def _frame(N, g, dev, frac=0.2):
+    vis = torch.rand(N, generator=g) < frac
+    n_vis = int(vis.sum())
+    row_of = torch.full((N,), -1, dtype=torch.int32)
+    row_of[vis] = torch.arange(n_vis, dtype=torch.int32)
+    rows = (torch.randn(max(n_vis, 1), 48, generator=g) * 0.01).to(dev)
+    return vis.to(dev), row_of.to(dev), rows
+
+
+def test_exact_row_lazy_adam_touches_only_the_visible_rows(hip_lib):
+    """set_row_lazy: step() updates only the rows the frame saw (of the rendered traversal's slice), catch_up_rows() applies
+    the zero-gradient steps a row missed right before it is read.  Random traversal order, random visibility, a learning-rate
+    schedule, a history that has to grow: (1) after catch_up_rows the visible rows are BIT-IDENTICAL to the optimizer that
+    steps every row every time, (2) the lazy optimizer really left the other rows alone, (3) after flush() parameters AND
+    moments of every row are bit-identical, (4) state_dict() flushes."""
+    dev = torch.device("cuda")
+    N, T = 3001, 4
+    g = torch.Generator().manual_seed(11)
+    base, make = _row_lazy_case(dev, N, T, g)
+    Pa, oa = make(False)
+    Pb, ob = make(True, hist_capacity=4)
+    seq = [0, 2, 2, 1, 0, 3, 3, 3, 1, 2, 0, 0, 1, 3, 2, 1, 1, 0]
+    for step, t in enumerate(seq):
+        vis, row_of, rows = _frame(N, g, dev, frac=0.05 if step % 5 == 4 else 0.25)
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-2 * 0.95 ** step
+            o.param_groups[1]["lr"] = 3e-3 * (1.0 + 0.1 * (step % 3))
+        ob.catch_up_rows([(Pb["dc"], row_of, None), (Pb["adapters"], row_of, t), (Pb["rest"], row_of, t)])
+        assert torch.equal(Pa["dc"][vis], Pb["dc"][vis]), step
+        assert torch.equal(Pa["rest"][vis, t], Pb["rest"][vis, t]) and torch.equal(Pa["adapters"][vis, t], Pb["adapters"][vis, t]), step
+        grad_means = (torch.randn(N, 3, generator=g) * 0.1).to(dev)
+        for P, o in ((Pa, oa), (Pb, ob)):
+            P["means"].grad = grad_means.clone()
+            o.set_row_gradient(P["dc"], rows, row_of, 0)
+            o.set_row_gradient(P["adapters"], rows, row_of, 0, slice_index=t)
+            o.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t)
+            o.step()
+        assert torch.equal(Pa["means"], Pb["means"])
+        assert torch.equal(Pa["rest"][vis, t], Pb["rest"][vis, t]) and torch.equal(Pa["dc"][vis], Pb["dc"][vis]), step
+    assert not torch.equal(Pa["rest"], Pb["rest"]) and not torch.equal(Pa["dc"], Pb["dc"])           # (really lazy)
+    sd = ob.state_dict()                                                                             # flushes
+    for k in base:
+        assert torch.equal(Pa[k], Pb[k]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
+    # ... and goes on from a loaded state: every row current as of the loaded step count
+    Pc, oc = make(True)
+    with torch.no_grad():
+        for k in base:
+            Pc[k].copy_(Pb[k])
+    oc.load_state_dict(sd)
+    vis, row_of, rows = _frame(N, g, dev)
+    for P, o in ((Pa, oa), (Pc, oc)):
+        o.catch_up_rows([(P["dc"], row_of, None), (P["adapters"], row_of, 1), (P["rest"], row_of, 1)])
+        P["means"].grad = torch.zeros(N, 3, device=dev)
+        o.set_row_gradient(P["dc"], rows, row_of, 0)
+        o.set_row_gradient(P["adapters"], rows, row_of, 0, slice_index=1)
+        o.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=1)
+        o.step()
+    oc.flush()
+    for k in base:
+        assert torch.equal(Pa[k], Pc[k]), k
+    # a row-lazy parameter with a dense gradient is refused
+    Pb["dc"].grad = torch.zeros_like(Pb["dc"])
+    with pytest.raises(RuntimeError):
+        ob.step()
+
+
+def test_row_lazy_adam_in_a_hip_graph(hip_lib):
+    """catch_up_rows + step captured in ONE HIP graph (static row buffers, advance() per replay): after flush() bit-identical
+    to the eager optimizer that steps every row -- the captured forward reads `t - 1` as the steps already taken."""
+    dev = torch.device("cuda")
+    N, T = 2000, 2
+    g = torch.Generator().manual_seed(12)
+    base, make = _row_lazy_case(dev, N, T, g)
+    Pa, oa = make(False)
+    Pb, ob = make(True)
+    frames = [_frame(N, g, dev) for _ in range(9)]
+    cap = max(f[2].shape[0] for f in frames)
+    row_of_s = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    rows_s = torch.zeros(cap, 48, device=dev)
+    gm_s = torch.zeros(N, 3, device=dev)
+    Pb["means"].grad = gm_s
+
+    def load(i):
+        vis, row_of, rows = frames[i]
+        row_of_s.copy_(row_of)
+        rows_s.zero_()
+        rows_s[:rows.shape[0]].copy_(rows)
+        gm_s.copy_(torch.full((N, 3), 0.01 * (i + 1), device=dev))
+
+    def body(o, P, ro, rw, t):
+        o.catch_up_rows([(P["dc"], ro, None), (P["adapters"], ro, t), (P["rest"], ro, t)])
+        o.set_row_gradient(P["dc"], rw, ro, 0)
+        o.set_row_gradient(P["adapters"], rw, ro, 0, slice_index=t)
+        o.set_row_gradient(P["rest"], rw, ro, 3, slice_index=t)
+        o.step()
+
+    def ref(i, t):
+        vis, row_of, rows = frames[i]
+        Pa["means"].grad = torch.full((N, 3), 0.01 * (i + 1), device=dev)
+        body(oa, Pa, row_of, rows, t)
+
+    import mtgs_amd
+    for t in range(T):                        # plain eager steps first: optimizer state and device buffers exist from here on
+        load(t)
+        ref(t, t)
+        body(ob, Pb, row_of_s, rows_s, t)
+    graphs = []
+    side = torch.cuda.Stream()
+    for t in range(T):
+        gm = mtgs_amd.graph_mode(1, 1)        # (the staging buffers of the tables live with the mode object)
+        load(T + t)
+        ref(T + t, t)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), gm:
+            body(ob, Pb, row_of_s, rows_s, t)             # warm-up on the capture stream = a real step
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with gm, torch.cuda.graph(gr):
+            body(ob, Pb, row_of_s, rows_s, t)             # (captured, not run)
+        graphs.append((gr, gm))
+    for i, t in [(4, 1), (5, 0), (6, 0), (7, 1), (8, 0), (3, 1)]:
+        ref(i, t)
+        load(i)
+        ob.advance()
+        graphs[t][0].replay()
+    ob.flush()
+    torch.cuda.synchronize()
+    for k in base:
+        assert torch.equal(Pa[k], Pb[k]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
