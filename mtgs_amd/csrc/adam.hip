@@ -22,17 +22,14 @@
 // HBM-bound: 28 B per element dense, 24 B + the visible rows otherwise.
 //
 // Row-lazy groups (MTGS_ADAM_ROWS_*, include/mtgs_rast.h): tensors of which a frame reads the visible rows only (the SH
-// coefficients under visibility-first colours).  A workgroup scans ADAM_ROWS items: every wave reads 64 row_of (or last)
-// entries, compacts the selected ones with a ballot and walks them four at a time -- 16 lanes per row, up to three
-// 16-float segments of the row per lane in flight.  A row lives in ONE wave, so `last` is read by all of the row's lanes
-// before one of them rewrites it.
+// coefficients under visibility-first colours); a workgroup scans ADAM_ROWS items and touches the selected rows (adam_rows).
 #include "common.hpp"
 
 #define ADAM_BLOCK 256
 #define ADAM_VEC 4
 #define ADAM_UNROLL 4
 #define ADAM_ELEMS (ADAM_BLOCK * ADAM_VEC * ADAM_UNROLL)   // elements per workgroup
-#define ADAM_ROWS 1024                                      // items a workgroup scans (row-lazy groups): 4 waves x 4 x 64
+#define ADAM_ROWS 256                                       // items a workgroup scans (row-lazy groups): one per thread
 #define ADAM_SEG 3                                          // 16-float segments of a row per pass (48 floats: degree-3 SH)
 
 namespace {
@@ -93,74 +90,132 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
 }
 
 // Row-lazy group: see the header of this file.  `hy` = the group's hyper row {step_size, bc2_sqrt, t, pending}.
+// Phase A: the workgroup reads row_of / last of its ADAM_ROWS items (independent loads) and compacts the selected ones into
+// LDS; phase B: sixteen 16-lane groups walk that list -- per row ONE memory round trip (p, m, v and the gradient of up to
+// three 16-float segments in flight), the per-step scalars of the last ADAM_HWIN steps come from LDS.  (A first version
+// compacted per wave and read `last`, then the row, then the history entry of every missed step as dependent round trips:
+// 300 us for the catch-up of 370 MB -- latency, not bandwidth.)
+#define ADAM_HWIN 64
 __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
-    __shared__ int s_list[ADAM_BLOCK / 64][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_item[ADAM_ROWS], s_L[ADAM_ROWS], s_r[ADAM_ROWS];
+    __shared__ float s_hist[2 * ADAM_HWIN];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
     const int sw = d.sub_width > 0 ? d.sub_width : d.width;          // floats of the slice this group works on
     const int T = d.sub_width > 0 ? d.width / d.sub_width : 1;
     const int64_t off = d.sub_width > 0 ? (int64_t)d.sub_index * sw : 0;
     const int t_now = reinterpret_cast<const int32_t *>(hy)[2], pending = reinterpret_cast<const int32_t *>(hy)[3];
     const bool step = d.mode == MTGS_ADAM_ROWS_STEP, flush = d.mode == MTGS_ADAM_ROWS_FLUSH;
     const int target = step ? t_now - 1 : (d.catchup_k >= 0 ? d.catchup_k : t_now - pending);   // zero-gradient steps up to here
-    if (step && block_in_group == 0 && threadIdx.x == 0) {
+    if (step && block_in_group == 0 && tid == 0) {
         d.hist[2 * (int64_t)t_now] = h.step_size;
         d.hist[2 * (int64_t)t_now + 1] = h.bc2_sqrt;
         reinterpret_cast<int32_t *>(hy)[3] = 0;      // (nothing in a step launch reads it)
     }
-    const int q_in_wave = lane >> 4, c0 = lane & 15;
-#pragma unroll 1
+    const int win0 = target - ADAM_HWIN + 1;         // s_hist[2 (j - win0)] = scalars of step j
+    if (tid < 2 * ADAM_HWIN) {
+        const int j = win0 + (tid >> 1);
+        s_hist[tid] = j >= 1 ? d.hist[2 * (int64_t)j + (tid & 1)] : 0.f;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t base = block_in_group * ADAM_ROWS;
+#pragma unroll
     for (int chunk = 0; chunk < ADAM_ROWS / ADAM_BLOCK; ++chunk) {
-        const int64_t i0 = block_in_group * ADAM_ROWS + ((int64_t)wave * (ADAM_ROWS / ADAM_BLOCK) + chunk) * 64;
-        if (i0 >= d.n) break;
-        const int64_t i_own = i0 + lane;
+        const int local = chunk * ADAM_BLOCK + tid;
+        const int64_t i = base + local;
         bool sel = false;
-        if (i_own < d.n) sel = flush ? d.last[i_own * T + d.sub_index] < target : d.row_of[i_own] >= 0;
+        int L = target, r = -1;
+        if (i < d.n) {
+            L = d.last[i * T + d.sub_index];
+            if (!flush) r = d.row_of[i];
+            sel = flush ? L < target : (r >= 0 && (step || L < target));
+        }
         const unsigned long long mask = __ballot(sel);
-        const int cnt = __popcll(mask);
-        if (cnt == 0) continue;
-        if (sel) s_list[wave][__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = lane;
-        __builtin_amdgcn_wave_barrier();
+        if (mask != 0) {
+            int wbase = 0;
+            if ((tid & 63) == 0) wbase = atomicAdd(&s_cnt, __popcll(mask));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (sel) {
+                const int at = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                s_item[at] = local; s_L[at] = L; s_r[at] = r;
+            }
+        }
+    }
+    __syncthreads();      // every `last` of this workgroup's items has been read; the list is complete
+    const int cnt = s_cnt;
+    const int c0 = tid & 15;
+    constexpr int RPI = 2, NG = ADAM_BLOCK / 16;     // rows per 16-lane group and trip: 2 x 3 x (p, m, v, g) loads in flight
 #pragma unroll 1
-        for (int q0 = 0; q0 < cnt; q0 += 4) {
-            const int q = q0 + q_in_wave;
-            const bool act = q < cnt;
-            const int64_t i = i0 + (act ? s_list[wave][q] : 0);
-            int32_t *lastp = d.last + i * T + d.sub_index;
-            const int L = act ? *lastp : target;
-            const int32_t r = (act && step) ? d.row_of[i] : -1;
-            const bool work = act && (step || L < target);
+    for (int q0 = tid >> 4; q0 < cnt; q0 += RPI * NG) {
 #pragma unroll 1
-            for (int cb = 0; cb < sw; cb += 16 * ADAM_SEG) {
-                float p[ADAM_SEG], m[ADAM_SEG], v[ADAM_SEG], g[ADAM_SEG];
-                int64_t phys[ADAM_SEG];
+        for (int cb = 0; cb < sw; cb += 16 * ADAM_SEG) {
+            float p[RPI][ADAM_SEG], m[RPI][ADAM_SEG], v[RPI][ADAM_SEG], g[RPI][ADAM_SEG];
+            int64_t phys[RPI][ADAM_SEG];
+            int L[RPI];
+#pragma unroll
+            for (int w = 0; w < RPI; ++w) {
+                const int q = q0 + w * NG;
+                const bool have = q < cnt;
+                const int64_t i = base + (have ? s_item[q] : 0);
+                const int r = (have && step) ? s_r[q] : -1;
+                L[w] = have ? s_L[q] : target;
 #pragma unroll
                 for (int u = 0; u < ADAM_SEG; ++u) {
                     const int c = cb + 16 * u + c0;
-                    phys[u] = (work && c < sw) ? i * d.width + off + c : -1;
-                    g[u] = 0.f;
-                    if (phys[u] >= 0) {
-                        p[u] = d.p[phys[u]]; m[u] = d.m[phys[u]]; v[u] = d.v[phys[u]];
-                        if (r >= 0) g[u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
+                    phys[w][u] = (have && c < sw) ? i * d.width + off + c : -1;
+                    g[w][u] = 0.f;
+                    if (phys[w][u] >= 0) {
+                        p[w][u] = d.p[phys[w][u]]; m[w][u] = d.m[phys[w][u]]; v[w][u] = d.v[phys[w][u]];
+                        if (r >= 0) g[w][u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
                     }
                 }
-                Hyper hj = h;
-                for (int j = L + 1; j <= target; ++j) {      // the zero-gradient steps this row missed, oldest first
-                    hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1];
+            }
 #pragma unroll
-                    for (int u = 0; u < ADAM_SEG; ++u)
-                        if (phys[u] >= 0) adam_update(p[u], m[u], v[u], 0.f, hj);
+            for (int w = 0; w < RPI; ++w) {
+                Hyper hj = h;
+                // A row that has not been seen for ~900 steps has exp_avg at a FIXED POINT of the zero-gradient recurrence
+                // (0, or a denormal that m * (1 - beta1) no longer moves), and step_size * m / (sqrt(v) / bc2 + eps) -- at most
+                // step_size * |m| / eps -- is below a quarter ulp of p: from then on a step leaves m and p bit-for-bit alone and
+                // only multiplies v by beta2.  `settled` lanes take that one-instruction step as long as the bound holds for
+                // the step's scalar (checked per step: learning rates move), so a gap costs 40 instructions per element for
+                // its first ~900 steps and 2 for the rest -- still the same bits as stepping every time.
+                bool settled = false;
+                float m_max = 0.f, lim_min = 0.f;
+                for (int j = L[w] + 1; j <= target; ++j) {      // the zero-gradient steps this row missed, oldest first
+                    if (j >= win0) { hj.step_size = s_hist[2 * (j - win0)]; hj.bc2_sqrt = s_hist[2 * (j - win0) + 1]; }
+                    else { hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1]; }
+                    if (settled && hj.step_size * m_max < lim_min) {
+#pragma unroll
+                        for (int u = 0; u < ADAM_SEG; ++u) v[w][u] = v[w][u] * h.b2;     // (phys < 0: an unused register)
+                        continue;
+                    }
+                    bool fixed = h.wd == 0.f && h.eps > 0.f;
+                    m_max = 0.f; lim_min = 3.0e38f;
+#pragma unroll
+                    for (int u = 0; u < ADAM_SEG; ++u) {
+                        if (phys[w][u] < 0) continue;
+                        const float m_old = m[w][u];
+                        adam_update(p[w][u], m[w][u], v[w][u], 0.f, hj);
+                        fixed = fixed && m[w][u] == m_old;
+                        m_max = fmaxf(m_max, fabsf(m_old));
+                        lim_min = fminf(lim_min, h.eps * fabsf(p[w][u]) * 7.450580596923828e-09f);   // eps |p| 2^-27
+                    }
+                    settled = fixed;
                 }
 #pragma unroll
                 for (int u = 0; u < ADAM_SEG; ++u) {
-                    if (phys[u] < 0) continue;
-                    if (step) adam_update(p[u], m[u], v[u], g[u], h);
-                    d.p[phys[u]] = p[u]; d.m[phys[u]] = m[u]; d.v[phys[u]] = v[u];
+                    if (phys[w][u] < 0) continue;
+                    if (step) adam_update(p[w][u], m[w][u], v[w][u], g[w][u], h);
+                    d.p[phys[w][u]] = p[w][u]; d.m[phys[w][u]] = m[w][u]; d.v[phys[w][u]] = v[w][u];
                 }
             }
-            // (every lane of the row has read `last` above: same wave, program order)
-            if (work && c0 == 0) *lastp = step ? t_now : target;
         }
-        __builtin_amdgcn_wave_barrier();
+        if (c0 == 0) {
+#pragma unroll
+            for (int w = 0; w < RPI; ++w)
+                if (q0 + w * NG < cnt) d.last[(base + s_item[q0 + w * NG]) * T + d.sub_index] = step ? t_now : target;
+        }
     }
 }
 

@@ -20,7 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--only", default="", help="profiling aid: run one variant only (fused-nt | fused | rows | torch-foreach | torch-fused)")
+    ap.add_argument("--traversals", type=int, default=3)
+    ap.add_argument("--clustered", action="store_true", help="rowlazy: visible Gaussians in runs of 4096 consecutive indices")
+    ap.add_argument("--only", default="", help="profiling aid: run one variant only (fused-nt | fused | rows | rowlazy | torch-foreach | torch-fused)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     N = args.n
@@ -83,6 +85,49 @@ def main():
         nbytes = elems * 24 + n_vis * 256 + N * 4 * len(P)
         print(f"{'fused rows':14s} {gpu * 1e3:8.1f} us GPU  {wall * 1e3:8.1f} us wall  {nbytes / gpu / 1e6:7.0f} GB/s ({nbytes / 1e6:.0f} MB: p,m,v + "
               f"{n_vis} rows + the row map per tensor)")
+
+    if not args.only or args.only == "rowlazy":
+        # exact row-lazy Adam: colour tensors [N, 3], [N, T, 3], [N, T, 15, 3]; every step renders one traversal and sees a fresh
+        # random 15 % (worst case for the catch-up: a row is T / 0.15 steps behind on average)
+        T = args.traversals
+        Pc = {"dc": torch.randn(N, 3, device=dev, generator=g), "ad": torch.randn(N, T, 3, device=dev, generator=g),
+              "rest": torch.randn(N, T, 15, 3, device=dev, generator=g)}
+        for variant in ("rows (every row, every traversal)", "row-lazy"):
+            P = {k: v.clone().requires_grad_(True) for k, v in Pc.items()}
+            opt = FusedAdam([{"params": [P["dc"], P["ad"]], "lr": 0.0025}, {"params": [P["rest"]], "lr": 0.0025 / 20}], eps=1e-15)
+            lazy = variant == "row-lazy"
+            if lazy:
+                opt.set_row_lazy(P["dc"]); opt.set_row_lazy(P["ad"], traversals=T); opt.set_row_lazy(P["rest"], traversals=T)
+            frames = []
+            for i in range(8):
+                if args.clustered:     # visibility in runs of 4096 consecutive Gaussians (spatially sorted scenes)
+                    vis = (torch.rand((N + 4095) // 4096, device=dev, generator=g) < 0.15).repeat_interleave(4096)[:N]
+                else:
+                    vis = torch.rand(N, device=dev, generator=g) < 0.15
+                n_vis = int(vis.sum())
+                row_of = torch.full((N,), -1, dtype=torch.int32, device=dev)
+                row_of[vis] = torch.arange(n_vis, dtype=torch.int32, device=dev)
+                frames.append((row_of, torch.randn(n_vis, 48, device=dev, generator=g) * 0.01, n_vis))
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.reps + 8)]
+            for i in range(args.reps + 8):
+                row_of, rows, n_vis = frames[i % 8]
+                t = i % T
+                ev[i][0].record()
+                if lazy:
+                    opt.catch_up_rows([(P["dc"], row_of, None), (P["ad"], row_of, t), (P["rest"], row_of, t)])
+                ev[i][1].record()
+                opt.set_row_gradient(P["dc"], rows, row_of, 0)
+                opt.set_row_gradient(P["ad"], rows, row_of, 0, slice_index=t)
+                opt.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t)
+                opt.step()
+                ev[i][2].record()
+            torch.cuda.synchronize()
+            cu = sorted(e[0].elapsed_time(e[1]) for e in ev[8:])[len(ev[8:]) // 2]
+            stp = sorted(e[1].elapsed_time(e[2]) for e in ev[8:])[len(ev[8:]) // 2]
+            touched = n_vis * 51 * 4
+            print(f"{variant:36s} T={T}: catch-up {cu * 1e3:7.1f} us  step {stp * 1e3:7.1f} us   (visible rows: {n_vis}, "
+                  f"{touched * 6 / 1e6:.0f} MB p,m,v r+w per pass; dense: {N * (3 + 48 * T) * 24 / 1e6:.0f} MB)")
+            del P, opt
 
 
 if __name__ == "__main__":

@@ -183,6 +183,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
 
 
 VISFIRST = {"on": False, "cs": None}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
+ROWLAZY = {"on": False, "opt": None}     # --row-lazy: exact row-lazy Adam for the colour parameters (needs --visfirst --optimizer fused)
 LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
 
 
@@ -198,6 +199,8 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         colors = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w, rgbs=colors) if fused else \
             torch.cat([colors, normals_chain(gs, c2w)], dim=-1)       # (visibility first: rgbs = None -> the normals alone)
     VISFIRST["cs"] = gs.get("color_source") if vf else None
+    if VISFIRST["cs"] is not None and ROWLAZY["on"]:
+        VISFIRST["cs"].optimizer = ROWLAZY["opt"]      # the coefficient rows this frame sees are caught up before they are read
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H,
                                         packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True,
                                         **({"color_source": VISFIRST["cs"]} if vf else {}))
@@ -373,6 +376,23 @@ def make_optimizer(kind, P, shipped=None, capturable=False):
     return torch.optim.Adam(groups, eps=1e-15, foreach=True, capturable=capturable)
 
 
+def enable_row_lazy(opt, P):
+    """--row-lazy: the colour parameters (read for the visible Gaussians only under --visfirst) are stepped for the visible
+    rows of the rendered traversal alone.  Call on a new optimizer AFTER its state is in place (refinement)."""
+    if not ROWLAZY["on"] or not hasattr(opt, "set_row_lazy"):
+        return opt
+    for p in P.values():
+        opt.set_row_lazy(p["features_dc"])
+        if "features_adapters" in p:
+            a = p["features_adapters"]
+            opt.set_row_lazy(a, traversals=a.shape[1] if a.dim() == 3 else None)
+        r = p["features_rest"]
+        if r.shape[-2] > 0:
+            opt.set_row_lazy(r, traversals=r.shape[1] if r.dim() == 4 else None)
+    ROWLAZY["opt"] = opt
+    return opt
+
+
 def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=None, world=1, rank=0, accumulate=1, seed=7,
                log=print, sparse=False, optimizer="fused"):
     """Adam on the fused iteration.  world > 1: view-parallel data parallelism (one process per rank, camera
@@ -386,7 +406,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     def make_opt():
         return make_optimizer(optimizer, P, shipped)
 
-    opt = make_opt()
+    opt = enable_row_lazy(make_opt(), P)
     mk = lambda: [[torch.zeros(p["means"].shape[0], device=p["means"].device), torch.ones(p["means"].shape[0], device=p["means"].device),
                    torch.zeros(p["means"].shape[0], device=p["means"].device)] for p in P.values()]
     stats = mk()
@@ -428,8 +448,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 mdist.all_reduce_stats([t for s in stats for t in s[:2]], [s[2] for s in stats],
                                        sum_init=[v for _ in stats for v in (0.0, 1.0)])
             before = sum(p["means"].shape[0] for p in P.values())
-            if LAZY["on"]:
-                opt.flush()                   # every traversal's slice up to date before rows move
+            if LAZY["on"] or ROWLAZY["on"]:
+                opt.flush()                   # every slice / row up to date before rows move
             state = {id(q): opt.state.get(q) for q in params}
             added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed)
             opt = make_opt()
@@ -441,10 +461,11 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 for q in grp["params"]:
                     if q not in opt.state and state.get(id(q)):
                         opt.state[q] = state[id(q)]
+            enable_row_lazy(opt, P)
             sizes.append(sum(p["means"].shape[0] for p in P.values()))
             ex = mk_ex()                      # N changed: new send buffers and visibility maps
             log(f"step {i + 1}: refine {before} -> {sizes[-1]} Gaussians (+{added} -{culled})")
-    if LAZY["on"]:
+    if LAZY["on"] or ROWLAZY["on"]:
         opt.flush()
     torch.cuda.synchronize()
     if t_start is not None and steps > i_start:
@@ -482,11 +503,17 @@ def main():
                     "Gaussians inside the rasterizer's front end, coefficient gradients as compact rows into the fused Adam")
     ap.add_argument("--lazy-adam", action="store_true", help="with --visfirst --optimizer fused: the per-traversal tensors' other "
                     "slices are left untouched by a step and caught up (bit-identically) before their traversal is rendered again")
+    ap.add_argument("--row-lazy", action="store_true", help="with --visfirst --optimizer fused: exact row-lazy Adam -- the colour "
+                    "parameters are stepped for the VISIBLE rows of the rendered traversal only and a row is caught up (bit-identically) "
+                    "right before the forward reads it (mtgs_amd.optim.FusedAdam.set_row_lazy)")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
     VISFIRST["on"] = bool(args.visfirst)
     LAZY["on"] = bool(args.lazy_adam)
+    ROWLAZY["on"] = bool(args.row_lazy)
+    if ROWLAZY["on"] and not (args.visfirst and args.optimizer in (None, "fused")) or (ROWLAZY["on"] and LAZY["on"]):
+        raise SystemExit("--row-lazy needs --visfirst and the fused optimizer (and replaces --lazy-adam)")
     if args.lazy_adam and not (args.visfirst and args.optimizer in (None, "fused")):
         raise SystemExit("--lazy-adam needs --visfirst and the fused optimizer")
     if args.visfirst and args.optimizer == "torch":
@@ -535,7 +562,7 @@ def main():
 
     def timed(fused):
         stats = mk_stats()
-        opt = make_optimizer(opt_kind, P, shipped) if opt_kind else None
+        opt = enable_row_lazy(make_optimizer(opt_kind, P, shipped), P) if opt_kind else None
         def one(i):
             for q in params:
                 q.grad = None
@@ -564,7 +591,7 @@ def main():
         from mtgs_amd import wrapper
         stats = mk_stats()
         grads_of = {}
-        opt = make_optimizer(opt_kind, P, shipped, capturable=True) if opt_kind else None
+        opt = enable_row_lazy(make_optimizer(opt_kind, P, shipped, capturable=True), P) if opt_kind else None
 
         def body(t):
             for q in params:

@@ -413,3 +413,46 @@ def test_row_lazy_adam_in_a_hip_graph(hip_lib):
     for k in base:
         assert torch.equal(Pa[k], Pb[k]), k
         assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
+
+
+def test_row_lazy_adam_long_gaps_settle_without_changing_a_bit(hip_lib):
+    """Rows unseen for thousands of steps: exp_avg reaches a fixed point of the zero-gradient recurrence and the catch-up
+    switches to its one-multiplication step (csrc/adam.hip) -- the result must still be bit-identical to stepping every row
+    every time, including across a learning-rate change that lifts the settled bound, rows that were never stepped, zeros
+    and tiny parameters, and a history longer than the LDS window."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    N = 300
+    g = torch.Generator().manual_seed(13)
+    base = torch.randn(N, 15, 3, generator=g) * 0.3
+    base[:20] = 0.0
+    base[20:40] *= 1e-24
+    Pa = base.clone().to(dev).requires_grad_(True)
+    Pb = base.clone().to(dev).requires_grad_(True)
+    oa = FusedAdam([Pa], lr=2e-3, eps=1e-15)
+    ob = FusedAdam([Pb], lr=2e-3, eps=1e-15)
+    ob.set_row_lazy(Pb, hist_capacity=64)
+    seen_at = {0: range(0, 200), 3: range(100, 300), 1200: range(0, 50), 2400: range(0, 300), 2401: range(250, 300), 2600: range(0, 300)}
+    empty = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    zero_rows = torch.zeros(1, 48, device=dev)
+    for step in range(2601):
+        lr = 2e-3 * (0.999 ** step) * (50.0 if 1500 <= step < 1510 else 1.0)
+        oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = lr
+        if step in seen_at:
+            idx = torch.tensor(list(seen_at[step]))
+            row_of = torch.full((N,), -1, dtype=torch.int32)
+            row_of[idx] = torch.arange(idx.numel(), dtype=torch.int32)
+            row_of = row_of.to(dev)
+            rows = (torch.randn(idx.numel(), 48, generator=g) * 0.01).to(dev)
+            ob.catch_up_rows([(Pb, row_of, None)])
+            sel = idx.to(dev)
+            assert torch.equal(Pa[sel], Pb[sel]), step
+        else:
+            row_of, rows = empty, zero_rows
+        for P, o in ((Pa, oa), (Pb, ob)):
+            o.set_row_gradient(P, rows, row_of, 3)
+            o.step()
+    ob.flush()
+    assert torch.equal(Pa, Pb)
+    assert torch.equal(oa.state[Pa]["exp_avg"], ob.state[Pb]["exp_avg"])
+    assert torch.equal(oa.state[Pa]["exp_avg_sq"], ob.state[Pb]["exp_avg_sq"])

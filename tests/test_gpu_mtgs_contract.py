@@ -313,7 +313,9 @@ def test_configs4_at_its_own_scale_eight_ranks_on_one_gpu():
 def test_mtgs_like_training_visibility_first_equals_dense_colours():
     """scripts/mtgs_like_train.py --visfirst (node kernels geometry-only, SH + clamp for the visible Gaussians inside the
     rasterizer's front end, coefficient gradients as compact rows into the fused Adam) trains like the dense node path: same
-    refinements, same loss curve (shipped option set, multi-traversal background, object nodes)."""
+    refinements, same loss curve (shipped option set, multi-traversal background, object nodes) -- and so does --row-lazy on top
+    of it: the exact row-lazy Adam steps the colour parameters of the VISIBLE rows only and catches rows up right before the
+    forward reads them (bit-identical parameters: tests/test_gpu_adam.py), across two refinements that move rows and moments."""
     import re
     import subprocess
     import sys
@@ -322,13 +324,14 @@ def test_mtgs_like_training_visibility_first_equals_dense_colours():
     common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "3", "--objects", "4", "--width", "320", "--height", "200",
               "--steps", "45", "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped", "--optimizer", "fused"]
     outs = []
-    for extra in ([], ["--visfirst"]):
+    for extra in ([], ["--visfirst"], ["--visfirst", "--row-lazy"]):
         r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py")] + common + extra, capture_output=True,
                            text=True, timeout=900, cwd=str(root))
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
         outs.append(r.stdout)
     from tests.util import refinement_sizes as sizes, same_refinements
     curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
-    assert same_refinements(sizes(outs[0]), sizes(outs[1]), 2), (sizes(outs[0]), sizes(outs[1]))
-    a, b = curve(outs[0]), curve(outs[1])
-    assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
+    for other in outs[1:]:
+        assert same_refinements(sizes(outs[0]), sizes(other), 2), (sizes(outs[0]), sizes(other))
+        a, b = curve(outs[0]), curve(other)
+        assert len(a) == len(b) and all(abs(x - y) <= 2e-3 * max(abs(y), 1e-3) for x, y in zip(a, b)), (a, b)
