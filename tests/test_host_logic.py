@@ -198,7 +198,13 @@ def test_round3_host_logic_without_a_gpu():
     o = optim.FusedAdam([p])
     with pytest.raises(ValueError):      # rows must be float32 [R, stride] with an int32 map of one entry per Gaussian
         o.set_row_gradient(p, torch.zeros(3, 4), torch.zeros(7, dtype=torch.int32), 0)
-    assert {"p", "m", "v", "g", "rows", "row_of", "catchup", "sub_width", "sub_index", "slice_only", "catchup_k"} <= set(optim._GROUP.names)
+    assert {"p", "m", "v", "g", "rows", "row_of", "catchup", "last", "hist", "sub_width", "sub_index", "mode", "catchup_k",
+            "hyper_index"} <= set(optim._GROUP.names)
+    assert (optim.MODE_DENSE, optim.MODE_SLICE, optim.MODE_ROWS_CATCHUP, optim.MODE_ROWS_STEP, optim.MODE_ROWS_FLUSH) == (0, 1, 2, 3, 4)
+    with pytest.raises(RuntimeError):    # row-lazy parameters live on the GPU
+        o.set_row_lazy(p)
+    cs0 = nodes.ColorSource(None, 1, 3, None, [], [])
+    cs0.catch_up(torch.zeros(4, dtype=torch.int32))      # no optimizer attached: nothing to do
     m, v, _ = None, None, None
     ref = optim.adam_reference_step(torch.ones(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64),
                                     torch.full((3,), 0.5, dtype=torch.float64), 1, 1e-2, eps=1e-15)
