@@ -448,7 +448,8 @@ typedef struct mtgs_node_desc {
                                                   * written after the launch from g_pose (nullable) */
 } mtgs_node_desc;
 int mtgs_node_desc_bytes(void);   /* sizeof(mtgs_node_desc): bindings check their layout against it */
-/* total_blocks = sum over nodes of ceil(n / 256); `degree` = sh_degree_to_use of the step (all nodes);
+/* total_blocks = sum over nodes of ceil(n / 256); `degree` = sh_degree_to_use of the step (all nodes), or -1 for
+ * mtgs_node_fwd_batch when EVERY descriptor has skip_colors = 1: the lean geometry-only kernel (same results);
  * model_id[sum n] (nullable) receives the node index of every collected Gaussian (mtgs_scene_graph.py:449-455). */
 int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree, const float *cam_pos,
                         int64_t *model_id, void *stream);

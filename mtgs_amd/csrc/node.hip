@@ -240,6 +240,41 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_batch_kernel(const mtgs_n
     node_fwd_wave<DEG>(d.n, params_of(d, cam_pos), g0, d.scales, d.quats, d.opacities, d.rgbs, d.clamp_mask, d.means_out);
 }
 
+// Geometry only (every descriptor has skip_colors = 1: visibility-first colours), `degree = -1` of mtgs_node_fwd_batch: the
+// activations alone -- exp, normalise (+ the rigid pose), sigmoid, the means -- one Gaussian per lane, 44 bytes in and 52 out.
+// Separate from node_fwd_wave because that kernel's 16 coefficient rows per lane fix its register count (and the skipped colour
+// loop still issued its address arithmetic): 86 us for 192 MB there.  Same expressions in the same order: same bits.
+__global__ __launch_bounds__(NODE_BLOCK) void node_fwd_geom_batch_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
+                                                                         int64_t *__restrict__ model_id) {
+    const int i = node_of_block(table, n_nodes, blockIdx.x);
+    const mtgs_node_desc &d = table[i];
+    const int64_t gl = ((int64_t)blockIdx.x - d.first_block) * NODE_BLOCK + threadIdx.x;
+    if (gl >= d.n) return;
+    const F3 sr = *reinterpret_cast<const F3 *>(d.scales_raw + gl * 3);
+    const F4 qr = *reinterpret_cast<const F4 *>(d.quats_raw + gl * 4);
+    const float orw = d.opacities_raw[gl];
+    F3 mn = F3{0.f, 0.f, 0.f};
+    if (d.pose || d.means_out) mn = *reinterpret_cast<const F3 *>(d.means + gl * 3);
+    if (model_id) model_id[d.start + gl] = i;
+    Pose ps;
+    if (d.pose) {
+        ps = load_pose(d.pose, d.pose_trans, d.pose_normalize);
+        mn = F3{(ps.R[0] * mn.x + ps.R[1] * mn.y) + ps.R[2] * mn.z + ps.tx, (ps.R[3] * mn.x + ps.R[4] * mn.y) + ps.R[5] * mn.z + ps.ty,
+                (ps.R[6] * mn.x + ps.R[7] * mn.y) + ps.R[8] * mn.z + ps.tz};
+    }
+    if (d.means_out) *reinterpret_cast<F3 *>(d.means_out + gl * 3) = mn;
+    *reinterpret_cast<F3 *>(d.scales + gl * 3) = F3{expf(sr.x), expf(sr.y), expf(sr.z)};
+    const float qinv = 1.0f / sqrtf(((qr.x * qr.x + qr.y * qr.y) + qr.z * qr.z) + qr.w * qr.w);
+    F4 qn = F4{qr.x * qinv, qr.y * qinv, qr.z * qinv, qr.w * qinv};   // (w, x, y, z)
+    if (d.pose) {   // utils.quat_mult(q_instance, q_local)
+        const float w2 = qn.x, x2 = qn.y, y2 = qn.z, z2 = qn.w;
+        qn = F4{((ps.w * w2 - ps.x * x2) - ps.y * y2) - ps.z * z2, ((ps.w * x2 + ps.x * w2) + ps.y * z2) - ps.z * y2,
+                ((ps.w * y2 - ps.x * z2) + ps.y * w2) + ps.z * x2, ((ps.w * z2 + ps.x * y2) - ps.y * x2) + ps.z * w2};
+    }
+    *reinterpret_cast<F4 *>(d.quats + gl * 4) = qn;
+    d.opacities[gl] = 1.f / (1.f + expf(-orw));
+}
+
 struct NodeGrads {   // cotangents of the activated Gaussians and the gradients of the raw parameters
     const float *v_scales, *v_quats, *v_opacities, *v_rgbs, *v_means;
     float *g_scales_raw, *g_quats_raw, *g_opac_raw, *g_dc, *g_rest, *g_dc_add, *g_means, *g_pose;
@@ -511,11 +546,16 @@ extern "C" int mtgs_node_desc_bytes(void) { return (int)sizeof(mtgs_node_desc); 
 extern "C" int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree,
                                    const float *cam_pos, int64_t *model_id, void *stream) {
     MTGS_REQUIRE(n_nodes >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_node_fwd_batch: bad sizes");
-    MTGS_REQUIRE(degree >= 0 && degree <= 3, MTGS_EUNSUPPORTED, "mtgs_node_fwd_batch: degree %d (<= 3)", degree);
+    MTGS_REQUIRE(degree >= -1 && degree <= 3, MTGS_EUNSUPPORTED, "mtgs_node_fwd_batch: degree %d (-1 .. 3)", degree);
     if (n_nodes == 0 || total_blocks == 0) return MTGS_OK;
     MTGS_REQUIRE(table && cam_pos, MTGS_EINVAL, "mtgs_node_fwd_batch: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)total_blocks;
+    if (degree < 0) {   // geometry only: every descriptor has skip_colors = 1
+        node_fwd_geom_batch_kernel<<<grid, NODE_BLOCK, 0, st>>>(table, n_nodes, model_id);
+        MTGS_CHECK_LAUNCH("mtgs_node_fwd_batch");
+        return MTGS_OK;
+    }
     MTGS_NODE_DISPATCH(node_fwd_batch_kernel, table, n_nodes, cam_pos, model_id)
     MTGS_CHECK_LAUNCH("mtgs_node_fwd_batch");
     return MTGS_OK;

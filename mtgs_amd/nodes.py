@@ -342,7 +342,8 @@ class _CollectNodes(torch.autograd.Function):
             tab["pose_trans"][framed] = [t.data_ptr() + 12 * f for t, f in zip(pose_tabs[1::2], fr)]
             tab["pose_normalize"][framed] = 1
         tab_dev = _upload(tab, dev)
-        call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, int(degree), ptr(cam), ptr(model_id), stream_of(means))
+        call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, -1 if deferred else int(degree), ptr(cam), ptr(model_id),
+             stream_of(means))
         ctx.color_source = None
         if deferred:   # the front end of the rasterizer reads the coefficients of the VISIBLE Gaussians through this table
             node_params = [(int(starts[i]), sizes[i]) for i in range(n_nodes)]   # (+ the leaf parameters: collect_gaussians)
