@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 14
+#define MTGS_RAST_ABI_VERSION 15
 
 enum {
     MTGS_OK = 0,
@@ -682,8 +682,10 @@ int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check t
 int mtgs_adam_block_elems(void);    /* elements one workgroup updates */
 int mtgs_adam_block_rows(void);     /* items one workgroup scans (row-lazy groups) */
 /* nontemporal != 0: moments (and a dense gradient) are streamed past the caches (they are touched once per step). */
-int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks, int nontemporal,
-                   void *stream);
+/* rows_from_block: the row-lazy groups come LAST in the table and own the workgroups [rows_from_block, total_blocks) -- they run
+ * as a second kernel with its own register budget (= total_blocks when the table has none, 0 when it has nothing else). */
+int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks, int64_t rows_from_block,
+                   int nontemporal, void *stream);
 
 #ifdef __cplusplus
 }

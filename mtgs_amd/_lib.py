@@ -117,7 +117,7 @@ _SIGNATURES = {
     "mtgs_adam_group_bytes": [],
     "mtgs_adam_block_elems": [],
     "mtgs_adam_block_rows": [],
-    "mtgs_adam_step": [_i32, _vp, _vp, _i64, _i32, _vp],
+    "mtgs_adam_step": [_i32, _vp, _vp, _i64, _i64, _i32, _vp],
     "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
@@ -125,7 +125,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 

@@ -96,6 +96,9 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
 // compacted per wave and read `last`, then the row, then the history entry of every missed step as dependent round trips:
 // 300 us for the catch-up of 370 MB -- latency, not bandwidth.)
 #define ADAM_HWIN 64
+#ifndef MTGS_ADAM_RPI
+#define MTGS_ADAM_RPI 1
+#endif
 __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
     __shared__ int s_item[ADAM_ROWS], s_L[ADAM_ROWS], s_r[ADAM_ROWS];
     __shared__ float s_hist[2 * ADAM_HWIN];
@@ -145,7 +148,7 @@ __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper 
     __syncthreads();      // every `last` of this workgroup's items has been read; the list is complete
     const int cnt = s_cnt;
     const int c0 = tid & 15;
-    constexpr int RPI = 2, NG = ADAM_BLOCK / 16;     // rows per 16-lane group and trip: 2 x 3 x (p, m, v, g) loads in flight
+    constexpr int RPI = MTGS_ADAM_RPI, NG = ADAM_BLOCK / 16;     // rows per 16-lane group and trip: 2 x 3 x (p, m, v, g) loads in flight
 #pragma unroll 1
     for (int q0 = tid >> 4; q0 < cnt; q0 += RPI * NG) {
 #pragma unroll 1
@@ -228,10 +231,6 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
     Hyper h;
     h.one_minus_b1 = d.one_minus_beta1; h.b2 = d.beta2; h.one_minus_b2 = d.one_minus_beta2;
     h.step_size = hy[0]; h.bc2_sqrt = hy[1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
-    if (d.mode >= MTGS_ADAM_ROWS_CATCHUP) {
-        adam_rows(d, h, hy, (int64_t)blockIdx.x - d.first_block);
-        return;
-    }
     const int64_t base = ((int64_t)blockIdx.x - d.first_block) * ADAM_ELEMS;
     float *__restrict__ P = d.p, *__restrict__ M = d.m, *__restrict__ V = d.v;
     const bool dense = d.g != nullptr;
@@ -336,6 +335,27 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
     }
 }
 
+// The row-lazy groups of a table (the last ones): their own kernel, because the streaming kernel above holds 64 data registers
+// per lane (4 waves per SIMD) and this one lives on memory round trips.  Measured (adam_bench --only rowlazy, catch-up / step):
+// two rows per 16-lane group at 4 waves per SIMD 453 / 218 us, one row at 6 waves (66 registers) 400 / 212 us, at 8 waves 393 /
+// 220 us; forcing the two-row version to 6 waves spills 25 registers: 502 / 402 us.  The step's ~2 TB/s is the rate 180-byte
+// pieces at 540-byte pitch move at on this chip (vis_color_fwd's coefficient gather sees the same), not an occupancy limit.
+#ifndef MTGS_ADAM_ROWS_WAVES
+#define MTGS_ADAM_ROWS_WAVES 6
+#endif
+__global__ void __launch_bounds__(ADAM_BLOCK, MTGS_ADAM_ROWS_WAVES) adam_rows_kernel(const mtgs_adam_group *__restrict__ table,
+                                                                                     float *__restrict__ hyper, int n_groups,
+                                                                                     int64_t block_offset) {
+    const int64_t b = (int64_t)blockIdx.x + block_offset;
+    const int gi = find_group(table, n_groups, b);
+    const mtgs_adam_group d = table[gi];
+    float *hy = hyper + 4 * (int64_t)d.hyper_index;
+    Hyper h;
+    h.one_minus_b1 = d.one_minus_beta1; h.b2 = d.beta2; h.one_minus_b2 = d.one_minus_beta2;
+    h.step_size = hy[0]; h.bc2_sqrt = hy[1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
+    adam_rows(d, h, hy, b - d.first_block);
+}
+
 }  // namespace
 
 extern "C" int mtgs_adam_group_bytes(void) { return (int)sizeof(mtgs_adam_group); }
@@ -343,17 +363,23 @@ extern "C" int mtgs_adam_block_elems(void) { return ADAM_ELEMS; }
 extern "C" int mtgs_adam_block_rows(void) { return ADAM_ROWS; }
 
 extern "C" int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks,
-                              int nontemporal, void *stream) {
-    MTGS_REQUIRE(n_groups >= 0 && total_blocks >= 0, MTGS_EINVAL, "mtgs_adam_step: negative size");
+                              int64_t rows_from_block, int nontemporal, void *stream) {
+    MTGS_REQUIRE(n_groups >= 0 && total_blocks >= 0 && rows_from_block >= 0 && rows_from_block <= total_blocks, MTGS_EINVAL,
+                 "mtgs_adam_step: bad sizes");
     if (n_groups == 0 || total_blocks == 0) return MTGS_OK;
     MTGS_REQUIRE(table != nullptr && hyper != nullptr, MTGS_EINVAL, "mtgs_adam_step: null table");
     MTGS_REQUIRE(((uintptr_t)table & 7) == 0, MTGS_EINVAL, "mtgs_adam_step: table must be 8-byte aligned");
     MTGS_REQUIRE(total_blocks < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_adam_step: more than 2^31 workgroups");
     hipStream_t st = (hipStream_t)stream;
-    if (nontemporal)
-        hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)total_blocks), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
-    else
-        hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)total_blocks), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
+    if (rows_from_block > 0) {
+        if (nontemporal)
+            hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)rows_from_block), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
+        else
+            hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)rows_from_block), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
+    }
+    if (rows_from_block < total_blocks)
+        hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)(total_blocks - rows_from_block)), dim3(ADAM_BLOCK), 0, st, table, hyper,
+                           n_groups, rows_from_block);
     MTGS_CHECK_LAUNCH("mtgs_adam_step");
     return MTGS_OK;
 }

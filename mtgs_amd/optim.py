@@ -171,7 +171,7 @@ class FusedAdam(torch.optim.Optimizer):
             L["last"][t] = cur
         table = upload_table(tab, dev)
         dummy = torch.zeros(4, dtype=torch.float32, device=dev)     # (hyper row 0: not used by catch-up groups)
-        call("mtgs_adam_step", len(todo), ptr(table), ptr(dummy), fb, int(self.nontemporal), stream_of(todo[0][0]["param"]))
+        call("mtgs_adam_step", len(todo), ptr(table), ptr(dummy), fb, fb, int(self.nontemporal), stream_of(todo[0][0]["param"]))
 
     def prepare(self, t: int) -> None:
         """Before the forward that reads traversal t: bring slice t of every lazy parameter up to date."""
@@ -269,7 +269,7 @@ class FusedAdam(torch.optim.Optimizer):
         if key != self._catch_key or torch.cuda.is_current_stream_capturing():
             from .nodes import upload_table
             self._catch_table, self._catch_key = upload_table(tab, todo[0][0]["param"].device), key
-        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, stream_of(todo[0][0]["param"]))
+        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, 0, stream_of(todo[0][0]["param"]))
 
     def _flush_rows(self) -> None:
         items = [(RL, None, t) for RL in self._rowlazy.values() for t in range(RL["T"])]
@@ -279,7 +279,7 @@ class FusedAdam(torch.optim.Optimizer):
         tab, blocks = built
         from .nodes import upload_table
         dev = items[0][0]["param"].device
-        call("mtgs_adam_step", len(tab), ptr(upload_table(tab, dev)), ptr(self._hyper_dev), blocks, 0, stream_of(items[0][0]["param"]))
+        call("mtgs_adam_step", len(tab), ptr(upload_table(tab, dev)), ptr(self._hyper_dev), blocks, 0, 0, stream_of(items[0][0]["param"]))
 
     def state_dict(self):
         self.flush()
@@ -330,12 +330,19 @@ class FusedAdam(torch.optim.Optimizer):
         tab = np.zeros(len(act), _GROUP)
         fb = 0
         keep = []
-        for i, (gi, p, st, g, src) in enumerate(act):
+        # table order: the row-lazy tensors last (they run as a second kernel, mtgs_adam_step's rows_from_block); the device
+        # scalars stay indexed by the position in `act` (hyper_index)
+        order = sorted(range(len(act)), key=lambda i: id(act[i][1]) in self._rowlazy)
+        self._rows_from = None
+        for j, i in enumerate(order):
+            gi, p, st, g, src = act[i]
             grp = self.param_groups[gi]
             m, v = st["exp_avg"], st["exp_avg_sq"]
             if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
                 raise RuntimeError("FusedAdam: exp_avg / exp_avg_sq must be contiguous and shaped like their parameter")
-            r = tab[i]
+            r = tab[j]
+            if id(p) in self._rowlazy and self._rows_from is None:
+                self._rows_from = fb
             r["p"], r["m"], r["v"], r["n"], r["first_block"] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), fb
             align = p.data_ptr() | m.data_ptr() | v.data_ptr()
             if g is not None:
@@ -382,6 +389,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._table_dev = upload_table(tab, dev)
             self._table_key = key
         self._blocks = fb
+        if self._rows_from is None:
+            self._rows_from = fb
         self._keep = keep
         return self._table_dev
 
@@ -452,7 +461,7 @@ class FusedAdam(torch.optim.Optimizer):
             # (pinned allocation is not permitted while capturing, and the step count must not advance at capture time)
             raise RuntimeError("FusedAdam: run one eager step() before capturing one (state and device buffers are created there)")
         table = self._table(act)
-        call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, int(self.nontemporal),
+        call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, self._rows_from, int(self.nontemporal),
              stream_of(act[0][1]))
         self._rows.clear()
         self._active_slice.clear()

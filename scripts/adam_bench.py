@@ -10,6 +10,9 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+if "--lib" in sys.argv:      # development: an A/B build of the library (scripts/build_variant.py)
+    from mtgs_amd import _lib
+    _lib.use_library(sys.argv[sys.argv.index("--lib") + 1])
 from mtgs_amd.optim import FusedAdam  # noqa: E402
 
 GROUPS = [("means", (3,), 8e-4), ("features_dc", (3,), 0.0025), ("features_rest", (15, 3), 0.0025 / 20),
@@ -21,6 +24,7 @@ def main():
     ap.add_argument("--n", type=int, default=2_000_000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--traversals", type=int, default=3)
+    ap.add_argument("--lib", default=None, help="development: path of an A/B build of the library")
     ap.add_argument("--clustered", action="store_true", help="rowlazy: visible Gaussians in runs of 4096 consecutive indices")
     ap.add_argument("--only", default="", help="profiling aid: run one variant only (fused-nt | fused | rows | rowlazy | torch-foreach | torch-fused)")
     args = ap.parse_args()
