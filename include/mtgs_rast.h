@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 15
+#define MTGS_RAST_ABI_VERSION 16
 
 enum {
     MTGS_OK = 0,
@@ -587,6 +587,14 @@ int mtgs_l1_fwd(int width, int height, int channels, const float *gt, const floa
                 float *partials, float *out, void *stream);
 int mtgs_l1_bwd(int width, int height, int channels, const float *gt, const float *pred, const uint8_t *mask,
                 const float *v_out, const float *fwd_out, float *v_pred, void *stream);
+/* The lidar depth term (mtgs_scene_graph.py:849-856, 875-879, DepthLossType.InverseL1) in one launch per direction:
+ *   m = (gt > lo) & (gt < hi) & mask;   out[0] = |1 / (gt + eps) - 1 / (pred + eps)|[m].mean()  (0 when m is empty, :857),
+ *   out[1] = count(m);  mask_out[H*W] (nullable) = m, which the depth NCC term reuses (:891).  gt, pred [H,W] f32; mask
+ * [H,W] u8, nullable.  PyTorch forms it with a dozen elementwise launches per direction.  partials: mtgs_l1_workspace_floats. */
+int mtgs_inv_depth_l1_fwd(int width, int height, const float *gt_depth, const float *pred_depth, const uint8_t *mask,
+                          float lo, float hi, float eps, uint8_t *mask_out, float *partials, float *out, void *stream);
+int mtgs_inv_depth_l1_bwd(int width, int height, const float *gt_depth, const float *pred_depth, const uint8_t *mask,
+                          float lo, float hi, float eps, const float *v_out, const float *fwd_out, float *v_pred, void *stream);
 
 /* ---- colours of the VISIBLE Gaussians only (visibility-first node path) ------------------------------------------------
  * MTGS evaluates SH + clamp for every Gaussian of every node each step (vanilla_gaussian_splatting.py:309-322,

@@ -111,6 +111,8 @@ _SIGNATURES = {
     "mtgs_l1_workspace_floats": [_i32, _i32, C.POINTER(_sz)],
     "mtgs_l1_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_l1_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_inv_depth_l1_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "mtgs_inv_depth_l1_bwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_rows_expand": [_i64, _i32, _vp, _vp, _i64, _vp, _vp],
@@ -125,7 +127,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 

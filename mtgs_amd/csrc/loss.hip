@@ -110,6 +110,17 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(int64_t nblocks, const
     if (threadIdx.x == 0) { out[0] = ts / tc; out[1] = tc; }
 }
 
+// the same with the reference's guard for an empty mask (mtgs_scene_graph.py:857-858: the depth term is 0 then)
+__global__ __launch_bounds__(256) void mean_or_zero_finish_kernel(int64_t nblocks, const float *__restrict__ partials,
+                                                                  float *__restrict__ out) {
+    __shared__ float s_red[4];
+    float s = 0.f, c = 0.f;
+    for (int64_t b = threadIdx.x; b < nblocks; b += 256) { s += partials[b * 2]; c += partials[b * 2 + 1]; }
+    const float ts = block_sum_256(s, s_red);
+    const float tc = block_sum_256(c, s_red);
+    if (threadIdx.x == 0) { out[0] = tc > 0.f ? ts / tc : 0.f; out[1] = tc; }
+}
+
 // v_Y[q] = (v_out / count) * sum_p w2d(q - p) * (g_mu[p] + 2 Y[q] g_e22[p] + X[q] g_e12[p])
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float *__restrict__ X, const float *__restrict__ Y,
                                                        const float *__restrict__ gmaps, const Window win,
@@ -195,6 +206,47 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(int64_t n_pix, int ch, cons
     }
 }
 
+// ---- the lidar depth term of the same loss head (mtgs_scene_graph.py:849-856, 875-879):
+//   mask = (gt > lo) & (gt < hi) & combined_mask;  loss = |1 / (gt + eps) - 1 / (pred + eps)|[mask].mean()
+// PyTorch: two compares, two ands, two adds, two reciprocals (1 / x is reciprocal then mul), the masked mean and their
+// backward chain -- a dozen launches for one number per pixel.  One launch per direction; the mask is a by-product (the depth
+// NCC term uses the same one, :891).  Arithmetic as torch: 1 / x = IEEE division, differences in that order.
+__global__ __launch_bounds__(256) void inv_depth_l1_fwd_kernel(int64_t n_pix, const float *__restrict__ gt, const float *__restrict__ pred,
+                                                               const uint8_t *__restrict__ mask, float lo, float hi, float eps,
+                                                               uint8_t *__restrict__ mask_out, float *__restrict__ partials) {
+    __shared__ float s_red[4];
+    float s = 0.f, c = 0.f;
+    const int64_t p0 = (int64_t)blockIdx.x * L1_PIX;
+    for (int i = threadIdx.x; i < L1_PIX; i += 256) {
+        const int64_t p = p0 + i;
+        if (p >= n_pix) continue;
+        const float g = gt[p];
+        const bool m = g > lo && g < hi && (!mask || mask[p]);
+        if (mask_out) mask_out[p] = m ? 1 : 0;
+        if (m) { s += fabsf(1.0f / (g + eps) - 1.0f / (pred[p] + eps)); c += 1.f; }
+    }
+    const float bs = block_sum_256(s, s_red);
+    const float bc = block_sum_256(c, s_red);
+    if (threadIdx.x == 0) { partials[blockIdx.x * 2] = bs; partials[blockIdx.x * 2 + 1] = bc; }
+}
+// d/d pred of |a - 1 / (pred + eps)| = sign(1 / (pred + eps) - a) * (-1 / (pred + eps)^2); torch's chain: grad of abs = sign(.),
+// of the subtraction -1, of reciprocal -y^2.
+__global__ __launch_bounds__(256) void inv_depth_l1_bwd_kernel(int64_t n_pix, const float *__restrict__ gt, const float *__restrict__ pred,
+                                                               const uint8_t *__restrict__ mask, float lo, float hi, float eps,
+                                                               const float *__restrict__ v_out, const float *__restrict__ fwd_out,
+                                                               float *__restrict__ v_pred) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    const float g = gt[p];
+    float out = 0.f;
+    if (g > lo && g < hi && (!mask || mask[p])) {
+        const float a = 1.0f / (g + eps), y = 1.0f / (pred[p] + eps), d = a - y;
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        out = (v_out[0] / fwd_out[1]) * sg * (y * y);      // d |a - y| / d y = -sign(a - y); d y / d pred = -y^2
+    }
+    v_pred[p] = out;
+}
+
 }  // namespace
 
 static Window make_window(float sigma) {
@@ -270,5 +322,29 @@ extern "C" int mtgs_l1_bwd(int width, int height, int channels, const float *gt,
     const int64_t n_pix = (int64_t)width * height;
     l1_bwd_kernel<<<(unsigned)ceil_div64(n_pix, 256), 256, 0, (hipStream_t)stream>>>(n_pix, channels, gt, pred, mask, v_out, fwd_out, v_pred);
     MTGS_CHECK_LAUNCH("mtgs_l1_bwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_inv_depth_l1_fwd(int width, int height, const float *gt_depth, const float *pred_depth, const uint8_t *mask,
+                                     float lo, float hi, float eps, uint8_t *mask_out, float *partials, float *out, void *stream) {
+    MTGS_REQUIRE(width > 0 && height > 0, MTGS_EINVAL, "mtgs_inv_depth_l1_fwd: bad sizes");
+    MTGS_REQUIRE(gt_depth && pred_depth && partials && out, MTGS_EINVAL, "mtgs_inv_depth_l1_fwd: null pointer");
+    const int64_t n_pix = (int64_t)width * height, nblocks = ceil_div64(n_pix, L1_PIX);
+    hipStream_t st = (hipStream_t)stream;
+    inv_depth_l1_fwd_kernel<<<(unsigned)nblocks, 256, 0, st>>>(n_pix, gt_depth, pred_depth, mask, lo, hi, eps, mask_out, partials);
+    mean_or_zero_finish_kernel<<<1, 256, 0, st>>>(nblocks, partials, out);
+    MTGS_CHECK_LAUNCH("mtgs_inv_depth_l1_fwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_inv_depth_l1_bwd(int width, int height, const float *gt_depth, const float *pred_depth, const uint8_t *mask,
+                                     float lo, float hi, float eps, const float *v_out, const float *fwd_out, float *v_pred,
+                                     void *stream) {
+    MTGS_REQUIRE(width > 0 && height > 0, MTGS_EINVAL, "mtgs_inv_depth_l1_bwd: bad sizes");
+    MTGS_REQUIRE(gt_depth && pred_depth && v_out && fwd_out && v_pred, MTGS_EINVAL, "mtgs_inv_depth_l1_bwd: null pointer");
+    const int64_t n_pix = (int64_t)width * height;
+    inv_depth_l1_bwd_kernel<<<(unsigned)ceil_div64(n_pix, 256), 256, 0, (hipStream_t)stream>>>(n_pix, gt_depth, pred_depth, mask, lo, hi,
+                                                                                              eps, v_out, fwd_out, v_pred);
+    MTGS_CHECK_LAUNCH("mtgs_inv_depth_l1_bwd");
     return MTGS_OK;
 }

@@ -108,6 +108,52 @@ def masked_l1(gt: Tensor, pred: Tensor, mask: Optional[Tensor] = None) -> Tensor
     return _MaskedL1.apply(gt, pred, mask)
 
 
+class _InverseDepthL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt_depth, depth, mask, lo, hi, eps):
+        require_gpu(gt_depth, depth, mask)
+        H, W = depth.shape[:2]
+        gt_c = gt_depth.detach().to(torch.float32).reshape(H, W).contiguous()
+        d_c = depth.detach().to(torch.float32).reshape(H, W).contiguous()
+        mask_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        n = C.c_size_t(0)
+        call("mtgs_l1_workspace_floats", W, H, C.byref(n))
+        partials = torch.empty(n.value, dtype=torch.float32, device=depth.device)
+        out = torch.empty(2, dtype=torch.float32, device=depth.device)
+        used = torch.empty((H, W), dtype=torch.uint8, device=depth.device)
+        call("mtgs_inv_depth_l1_fwd", W, H, ptr(gt_c), ptr(d_c), ptr(mask_c), float(lo), float(hi), float(eps), ptr(used),
+             ptr(partials), ptr(out), stream_of(depth))
+        ctx.save_for_backward(gt_c, d_c, mask_c, out)
+        ctx.cfg = (H, W, float(lo), float(hi), float(eps), depth.shape, depth.dtype)
+        used = used.view(torch.bool).reshape(H, W, 1)
+        ctx.mark_non_differentiable(used)
+        return out[0], used
+
+    @staticmethod
+    def backward(ctx, v_out, _v_mask):
+        gt_c, d_c, mask_c, out = ctx.saved_tensors
+        H, W, lo, hi, eps, shape, dtype = ctx.cfg
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        v_d = torch.empty_like(d_c)
+        call("mtgs_inv_depth_l1_bwd", W, H, ptr(gt_c), ptr(d_c), ptr(mask_c), lo, hi, eps, ptr(v), ptr(out), ptr(v_d), stream_of(d_c))
+        return None, v_d.reshape(shape).to(dtype), None, None, None, None
+
+
+def inverse_depth_l1(depth: Tensor, gt_depth: Tensor, mask: Optional[Tensor] = None, lo: float = 0.1, hi: float = 80.0,
+                     eps: float = 1e-5):
+    """MTGS's lidar depth term (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:849-858, 875-879, InverseL1):
+        m = (gt_depth > lo) & (gt_depth < hi) & mask
+        loss = torch.abs(1 / (gt_depth + eps) - 1 / (depth + eps))[m].mean()          (0 when m is empty)
+    in one launch per direction.  depth, gt_depth [H,W,1] / [H,W]; mask [H,W,1] / [H,W] bool or None.
+    Returns (loss, m [H,W,1] bool) -- the depth NCC term takes the same mask (:891).  Differentiable with respect to `depth`."""
+    assert depth.numel() == gt_depth.numel() and depth.dim() in (2, 3), (depth.shape, gt_depth.shape)
+    if mask is not None:
+        assert mask.numel() == depth.numel(), mask.shape
+    if gt_depth.requires_grad:
+        raise NotImplementedError("inverse_depth_l1: gradient with respect to gt_depth is not implemented")
+    return _InverseDepthL1.apply(gt_depth, depth, mask, lo, hi, eps)
+
+
 class _OutputHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, render, alpha, background, exposure, want_depth, normal_channel):

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
 from mtgs_amd.densify import update_statistics, update_statistics_all  # noqa: E402
-from mtgs_amd.loss import depth_ncc_loss, masked_l1, masked_ssim, output_head, tv_loss  # noqa: E402
+from mtgs_amd.loss import depth_ncc_loss, inverse_depth_l1, masked_l1, masked_ssim, output_head, tv_loss  # noqa: E402
 from mtgs_amd.nodes import camera_space_normals, node_gaussians  # noqa: E402
 from mtgs_amd.synthetic import make_camera  # noqa: E402
 
@@ -210,13 +210,13 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         rgb, app, depth, normal = output_head(render, alpha, bg, E, depth=True, normal_channel=3) if fused else \
             head_chain(render, alpha, bg, E, True)
         gt_d, gt_n = shipped["gt_depth"][t], shipped["gt_normal"][t]
-        dmask = (gt_d > 0.1) & (gt_d < 80) & mask
-        inv_gt, inv_pred = 1 / (gt_d + 1e-5), 1 / (depth + 1e-5)
         if fused:
             l1 = masked_l1(gt, app, mask)
-            loss_d = masked_l1(inv_gt, inv_pred, dmask)
+            loss_d, dmask = inverse_depth_l1(depth, gt_d, mask, 0.1, 80.0, 1e-5)     # :849-858, 875-879: the mask is a by-product
             loss_n = masked_l1(gt_n, normal, mask) + tv_loss(normal)                 # :931-934
         else:
+            dmask = (gt_d > 0.1) & (gt_d < 80) & mask
+            inv_gt, inv_pred = 1 / (gt_d + 1e-5), 1 / (depth + 1e-5)
             l1 = torch.abs(gt - app)[mask.squeeze(-1)].mean()
             loss_d = torch.abs(inv_gt - inv_pred)[dmask].mean()
             loss_n = torch.abs(gt_n - normal)[mask.squeeze(-1)].mean() + \
@@ -284,11 +284,11 @@ def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=Non
         E, bg = shipped["exposure"][t], shipped["bg"]
         rgb, app, depth, normal = output_head(render, alpha, bg, E, depth=True, normal_channel=3)
         gt_d, gt_n = shipped["gt_depth"][t], shipped["gt_normal"][t]
-        dmask = (gt_d > 0.1) & (gt_d < 80) & mask
+        loss_d, dmask = inverse_depth_l1(depth, gt_d, mask, 0.1, 80.0, 1e-5)
         loss_n = masked_l1(gt_n, normal, mask) + tv_loss(normal)
         loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
         loss = 0.8 * masked_l1(gt, app, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask)) + \
-            0.5 * masked_l1(1 / (gt_d + 1e-5), 1 / (depth + 1e-5), dmask) + 0.1 * loss_n + 0.1 * depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask)
+            0.5 * loss_d + 0.1 * loss_n + 0.1 * depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask)
     else:
         rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)
         loss = 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))

@@ -73,6 +73,41 @@ def test_masked_l1_matches_torch_formulation(hip_lib, use_mask, ch):
     assert torch.allclose(p.grad.double(), p_ref.grad, rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("use_mask,empty", [(True, False), (False, False), (True, True)])
+def test_inverse_depth_l1_matches_the_reference_formulation(hip_lib, use_mask, empty):
+    """mtgs_scene_graph.py:849-858, 875-879 (lidar depth, DepthLossType.InverseL1) written out in torch float64: the range mask
+    combined with the image mask, |1 / (gt + 1e-5) - 1 / (pred + 1e-5)| over it, 0 for an empty mask; value, gradient with
+    respect to the predicted depth, and the mask by-product (the NCC term's mask, :891)."""
+    from mtgs_amd.loss import inverse_depth_l1
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(4)
+    H, W = 135, 241
+    gt = (torch.rand(H, W, 1, generator=g) * 100.0)
+    gt[torch.rand(H, W, 1, generator=g) < 0.3] = 0.0             # lidar: most pixels have no return
+    if empty:
+        gt = gt * 0.0
+    pred0 = torch.rand(H, W, 1, generator=g) * 60.0 + 0.5
+    pred0[3, 4] = gt[3, 4]                                        # an exact tie inside the range: sign(0) = 0
+    gt = gt.to(dev)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.3).to(dev) if use_mask else None
+    m_ref = (gt > 0.1) & (gt < 80)
+    if use_mask:
+        m_ref = m_ref & mask
+    p_ref = pred0.to(dev).double().requires_grad_(True)
+    if int(m_ref.sum()) == 0:
+        ref = torch.zeros((), dtype=torch.float64, device=dev)
+    else:
+        ref = torch.abs(1 / (gt.double() + 1e-5) - 1 / (p_ref + 1e-5))[m_ref].mean()
+        (0.5 * ref).backward()
+    p = pred0.to(dev).requires_grad_(True)
+    val, m = inverse_depth_l1(p, gt, mask)
+    (0.5 * val).backward()
+    assert m.dtype == torch.bool and m.shape == (H, W, 1) and torch.equal(m, m_ref)
+    assert abs(float(val) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    want = p_ref.grad if p_ref.grad is not None else torch.zeros_like(p_ref)
+    assert torch.allclose(p.grad.double(), want, rtol=2e-5, atol=1e-12)
+
+
 @pytest.mark.parametrize("D,with_exposure,with_depth,normal_ch", [(8, True, True, 3), (4, True, True, -1), (3, False, False, -1),
                                                                   (7, False, True, 3)])
 def test_output_head_matches_the_reference_formulation(hip_lib, D, with_exposure, with_depth, normal_ch):
