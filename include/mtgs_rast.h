@@ -649,6 +649,8 @@ typedef struct mtgs_adam_group {
     float *hist;                /* row-lazy groups: {step_size, bc2_sqrt} of step j at hist[2 j] (DEVICE; the step launch appends) */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
+    int64_t n_rows;             /* rows in `rows`: a row_of entry >= n_rows (a capacity overflow of the frame that produced the
+                                 * map, graph mode) is treated as "no row" instead of being read */
     int32_t width, row_col;
     int32_t vec_ok;
     int32_t sub_width, sub_index;   /* sub_width > 0: an item is `width / sub_width` slices of sub_width floats (a per-traversal

@@ -80,7 +80,7 @@ __device__ __forceinline__ void st4(float *p, float4 r) {
 // item is width / sub_width slices (a per-traversal tensor [N, T, ...]) and only slice sub_index has a gradient.
 __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, int c) {
     const int32_t r = d.row_of[i];
-    if (r < 0) return 0.f;
+    if (r < 0 || r >= d.n_rows) return 0.f;
     if (d.sub_width > 0) {
         const int s = c / d.sub_width;
         if (s != d.sub_index) return 0.f;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper 
                     g[w][u] = 0.f;
                     if (phys[w][u] >= 0) {
                         p[w][u] = d.p[phys[w][u]]; m[w][u] = d.m[phys[w][u]]; v[w][u] = d.v[phys[w][u]];
-                        if (r >= 0) g[w][u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
+                        if (r >= 0 && r < d.n_rows) g[w][u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
                     }
                 }
             }
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
                     g[u] = 0.f;
                     if (d.catchup_k == 0) {
                         if (dense) g[u] = d.g[phys[u]];
-                        else if (rows) { const int32_t r = d.row_of[i]; g[u] = r < 0 ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c]; }
+                        else if (rows) { const int32_t r = d.row_of[i]; g[u] = (r < 0 || r >= d.n_rows) ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c]; }
                     }
                 }
             }

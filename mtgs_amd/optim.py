@@ -46,7 +46,7 @@ from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
                    ("last", "<u8"), ("hist", "<u8"),
-                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
+                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("n_rows", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
                    ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
                    ("hyper_index", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
                    ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
@@ -352,6 +352,7 @@ class FusedAdam(torch.optim.Optimizer):
             elif src is not None:
                 rows, row_of, col, stride, width, sub_w, sub_i = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
+                r["n_rows"] = rows.shape[0]
                 r["sub_width"], r["sub_index"] = sub_w, sub_i
                 keep.append((rows, row_of))
             r["vec_ok"] = int(align % 16 == 0)

@@ -456,3 +456,33 @@ def test_row_lazy_adam_long_gaps_settle_without_changing_a_bit(hip_lib):
     assert torch.equal(Pa, Pb)
     assert torch.equal(oa.state[Pa]["exp_avg"], ob.state[Pb]["exp_avg"])
     assert torch.equal(oa.state[Pa]["exp_avg_sq"], ob.state[Pb]["exp_avg_sq"])
+
+
+def test_row_map_entries_beyond_the_row_buffer_are_not_read(hip_lib):
+    """A frame whose visible count exceeded its capacity (graph mode) leaves ranks >= the capacity in the row map while the
+    gradient rows end at the capacity: such entries count as "no row" (zero gradient) -- never an out-of-bounds read --
+    for the streaming groups and for the row-lazy ones."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    N, R = 5000, 600
+    g = torch.Generator().manual_seed(21)
+    base = torch.randn(N, 15, 3, generator=g)
+    rows = (torch.randn(R, 48, generator=g) * 0.01).to(dev)
+    perm = torch.randperm(N, generator=g)[:900]
+    over = torch.full((N,), -1, dtype=torch.int32)
+    over[perm] = torch.arange(900, dtype=torch.int32)              # ranks 600 .. 899 have no row
+    cut = over.clone()
+    cut[over >= R] = -1
+    outs = []
+    for lazy in (False, True):
+        for row_of in (over, cut):
+            p = base.clone().to(dev).requires_grad_(True)
+            o = FusedAdam([p], lr=1e-2, eps=1e-15)
+            if lazy:
+                o.set_row_lazy(p)
+            for _ in range(3):
+                o.set_row_gradient(p, rows, row_of.to(dev), 3)
+                o.step()
+            o.flush()
+            outs.append(p.detach().clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
