@@ -608,9 +608,12 @@ int mtgs_inv_depth_l1_bwd(int width, int height, const float *gt_depth, const fl
  * bwd: v_rgb = grad_rows[r * row_stride + col .. + 2] (the compositing backward's compact rows) -> feat_rows[r, 48] =
  * d L / d coefficient k, channel c at [3 k + c] (k = 0: features_dc (and the adapter), k >= 1: features_rest[k - 1]; zeros above the
  * degree in use): the gradient of the VISIBLE rows only -- consumed as rows by mtgs_adam_step, never expanded. */
+/* coef_rows (nullable): the coefficients of visible Gaussian r are read from the compact row
+ * coef_rows[r * coef_stride ..] = [dc 3 | dc_add 3 | rest 3 k_rest] (coef_stride >= 51 floats) instead of the nodes' tensors --
+ * what mtgs_adam_step's MTGS_ADAM_ROWS_PEEK groups leave (row-lazy optimizer: up-to-date values without touching the parameters). */
 int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
-                       void *stream);
+                       const float *coef_rows, int64_t coef_stride, void *stream);
 int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                        int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
@@ -647,9 +650,12 @@ typedef struct mtgs_adam_group {
     const float *catchup;       /* catchup_k > 0: {step_size, bc2_sqrt} of the catchup_k steps to apply, oldest first (DEVICE) */
     int32_t *last;              /* row-lazy groups: [n, T] step up to which slice (i, t) of item i is current */
     float *hist;                /* row-lazy groups: {step_size, bc2_sqrt} of step j at hist[2 j] (DEVICE; the step launch appends) */
+    float *caught;              /* ROWS_PEEK: destination, ROWS_STEP: source (nullable) -- the up-to-date parameter rows of the
+                                 * frame, row r = row_of[i] at caught[r * caught_stride + caught_col ..] (n_rows rows) */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
-    int64_t n_rows;             /* rows in `rows`: a row_of entry >= n_rows (a capacity overflow of the frame that produced the
+    int64_t caught_stride;      /* floats between rows of `caught` */
+    int64_t n_rows;             /* rows in `rows` (and `caught`): a row_of entry >= n_rows (a capacity overflow of the frame that produced the
                                  * map, graph mode) is treated as "no row" instead of being read */
     int32_t width, row_col;
     int32_t vec_ok;
@@ -664,6 +670,7 @@ typedef struct mtgs_adam_group {
     int32_t catchup_k;              /* SLICE: > 0: no gradient step -- apply catchup_k ZERO-gradient steps with the scalars in `catchup`.
                                      * ROWS_CATCHUP / ROWS_FLUSH: the step to catch up to, or < 0: hyper.t - hyper.pending */
     int32_t hyper_index;            /* row of `hyper` that belongs to this group */
+    int32_t caught_col, reserved;
     float one_minus_beta1, beta2, one_minus_beta2;   /* 1 - beta rounded from double by the caller (1 - 0.999f is 5e-5 off) */
     float eps, weight_decay, grad_scale;
 } mtgs_adam_group;
@@ -673,7 +680,8 @@ typedef struct mtgs_adam_group {
  * can be left untouched (slice_only groups step the rendered slice alone) and CAUGHT UP before its traversal is rendered
  * again: catchup_k zero-gradient steps per element in registers, the same operations in the same order as stepping every
  * time (bit-identical), at 24 B per element of ONE slice instead of 24 B x T per step. */
-enum { MTGS_ADAM_DENSE = 0, MTGS_ADAM_SLICE = 1, MTGS_ADAM_ROWS_CATCHUP = 2, MTGS_ADAM_ROWS_STEP = 3, MTGS_ADAM_ROWS_FLUSH = 4 };
+enum { MTGS_ADAM_DENSE = 0, MTGS_ADAM_SLICE = 1, MTGS_ADAM_ROWS_CATCHUP = 2, MTGS_ADAM_ROWS_STEP = 3, MTGS_ADAM_ROWS_FLUSH = 4,
+       MTGS_ADAM_ROWS_PEEK = 5 };
 /* Row-lazy Adam (exact) for tensors of which a frame READS ONLY THE VISIBLE ROWS -- with visibility-first colours
  * (mtgs_vis_color_fwd) the SH coefficients: 48 of a Gaussian's 59 floats, of which a camera needs ~15 %.  A Gaussian the
  * frame does not see gets the zero gradient: its moments decay and p drifts along exp_avg, which nothing reads until the
@@ -686,7 +694,13 @@ enum { MTGS_ADAM_DENSE = 0, MTGS_ADAM_SLICE = 1, MTGS_ADAM_ROWS_CATCHUP = 2, MTG
  *                needed, apply step t with the gradient rows[row_of[i] * row_stride + row_col + c], set last = t; one
  *                thread appends hist[t] and clears hyper.pending (which the caller's copy of this step's scalars had set:
  *                a forward captured in the same HIP graph as its step reads t - 1 as the steps already taken);
- *   ROWS_FLUSH   every item behind the target is caught up (checkpoints, refinement, anything else that reads the tensor).
+ *   ROWS_FLUSH   every item behind the target is caught up (checkpoints, refinement, anything else that reads the tensor);
+ *   ROWS_PEEK    ROWS_CATCHUP without side effects: the caught-up PARAMETER rows go to the compact buffer `caught` (row
+ *                row_of[i]; p, m, v and `last` stay as they are) -- mtgs_vis_color_fwd reads its coefficients from there,
+ *                coalesced, and a forward no longer changes optimizer state.  A ROWS_STEP group that is handed the same
+ *                frame's `caught` rows takes p from them and replays only the moment recurrences of the missed steps
+ *                (m, v do not depend on p when weight_decay = 0; otherwise `caught` is ignored).  A PEEK group with m = v =
+ *                last = NULL is a plain row copy (tensors that are not row-lazy).
  * Items untouched by a launch cost 4 bytes (row_of or last).  first_block advances by ceil(n / mtgs_adam_block_rows()). */
 int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check their layout against it */
 int mtgs_adam_block_elems(void);    /* elements one workgroup updates */

@@ -113,7 +113,7 @@ _SIGNATURES = {
     "mtgs_l1_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_inv_depth_l1_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "mtgs_inv_depth_l1_bwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
-    "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_rows_expand": [_i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "mtgs_adam_group_bytes": [],

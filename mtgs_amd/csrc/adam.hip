@@ -38,13 +38,24 @@ struct Hyper {
     float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, wd, gscale;
 };
 
-__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const Hyper &h) {
+// The update in two halves with the operation sequence PINNED (no contraction beyond the fused multiply-adds written out): the
+// row-lazy groups replay the moment half alone where the parameter half has already been done (adam_rows), and all paths
+// -- streaming, slice, row catch-up, row step -- must produce the same bits.
+__device__ __forceinline__ void adam_moments(const float p, float &m, float &v, float g, const Hyper &h) {
+#pragma clang fp contract(off)
     g = g * h.gscale;
     if (h.wd != 0.f) g = fmaf(h.wd, p, g);
-    m = m + (g - m) * h.one_minus_b1;
-    v = v * h.b2 + h.one_minus_b2 * g * g;
+    m = fmaf(g - m, h.one_minus_b1, m);
+    v = fmaf(v, h.b2, (h.one_minus_b2 * g) * g);
+}
+__device__ __forceinline__ void adam_param(float &p, const float m, const float v, const Hyper &h) {
+#pragma clang fp contract(off)
     const float denom = __fsqrt_rn(v) / h.bc2_sqrt + h.eps;
     p = p - h.step_size * (m / denom);
+}
+__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const Hyper &h) {
+    adam_moments(p, m, v, g, h);
+    adam_param(p, m, v, h);
 }
 
 // Workgroup b belongs to group i with table[i].first_block <= b < table[i + 1].first_block (wave-uniform: scalar loads).
@@ -96,9 +107,11 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
 // compacted per wave and read `last`, then the row, then the history entry of every missed step as dependent round trips:
 // 300 us for the catch-up of 370 MB -- latency, not bandwidth.)
 #define ADAM_HWIN 64
-#ifndef MTGS_ADAM_RPI
-#define MTGS_ADAM_RPI 1
-#endif
+// Modes (include/mtgs_rast.h): CATCHUP / FLUSH replay the missed zero-gradient steps in place; PEEK does the same in registers
+// and leaves the up-to-date PARAMETER rows in the compact buffer `caught` (row r = row_of[i]) without touching p, m, v or
+// `last` -- the forward reads its coefficients from there, coalesced, and has no side effect on the optimizer; STEP applies
+// the step, and when the same frame's `caught` rows are handed back it takes p from them and replays only the MOMENT half of
+// the missed steps (3 instructions each instead of ~40: the parameter half needs a square root and two divisions).
 __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
     __shared__ int s_item[ADAM_ROWS], s_L[ADAM_ROWS], s_r[ADAM_ROWS];
     __shared__ float s_hist[2 * ADAM_HWIN];
@@ -108,7 +121,8 @@ __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper 
     const int T = d.sub_width > 0 ? d.width / d.sub_width : 1;
     const int64_t off = d.sub_width > 0 ? (int64_t)d.sub_index * sw : 0;
     const int t_now = reinterpret_cast<const int32_t *>(hy)[2], pending = reinterpret_cast<const int32_t *>(hy)[3];
-    const bool step = d.mode == MTGS_ADAM_ROWS_STEP, flush = d.mode == MTGS_ADAM_ROWS_FLUSH;
+    const bool step = d.mode == MTGS_ADAM_ROWS_STEP, flush = d.mode == MTGS_ADAM_ROWS_FLUSH, peek = d.mode == MTGS_ADAM_ROWS_PEEK;
+    const bool has_state = d.m != nullptr && d.last != nullptr;      // (PEEK of a tensor that is not row-lazy: a plain copy)
     const int target = step ? t_now - 1 : (d.catchup_k >= 0 ? d.catchup_k : t_now - pending);   // zero-gradient steps up to here
     if (step && block_in_group == 0 && tid == 0) {
         d.hist[2 * (int64_t)t_now] = h.step_size;
@@ -116,23 +130,21 @@ __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper 
         reinterpret_cast<int32_t *>(hy)[3] = 0;      // (nothing in a step launch reads it)
     }
     const int win0 = target - ADAM_HWIN + 1;         // s_hist[2 (j - win0)] = scalars of step j
-    if (tid < 2 * ADAM_HWIN) {
+    if (tid < 2 * ADAM_HWIN && has_state) {
         const int j = win0 + (tid >> 1);
         s_hist[tid] = j >= 1 ? d.hist[2 * (int64_t)j + (tid & 1)] : 0.f;
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     const int64_t base = block_in_group * ADAM_ROWS;
-#pragma unroll
-    for (int chunk = 0; chunk < ADAM_ROWS / ADAM_BLOCK; ++chunk) {
-        const int local = chunk * ADAM_BLOCK + tid;
-        const int64_t i = base + local;
+    {
+        const int64_t i = base + tid;
         bool sel = false;
         int L = target, r = -1;
         if (i < d.n) {
-            L = d.last[i * T + d.sub_index];
+            if (has_state) L = d.last[i * T + d.sub_index];
             if (!flush) r = d.row_of[i];
-            sel = flush ? L < target : (r >= 0 && (step || L < target));
+            sel = flush ? L < target : (peek ? (r >= 0 && r < d.n_rows) : (r >= 0 && (step || L < target)));
         }
         const unsigned long long mask = __ballot(sel);
         if (mask != 0) {
@@ -141,84 +153,88 @@ __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper 
             wbase = __builtin_amdgcn_readfirstlane(wbase);
             if (sel) {
                 const int at = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                s_item[at] = local; s_L[at] = L; s_r[at] = r;
+                s_item[at] = tid; s_L[at] = L; s_r[at] = r;
             }
         }
     }
     __syncthreads();      // every `last` of this workgroup's items has been read; the list is complete
     const int cnt = s_cnt;
     const int c0 = tid & 15;
-    constexpr int RPI = MTGS_ADAM_RPI, NG = ADAM_BLOCK / 16;     // rows per 16-lane group and trip: 2 x 3 x (p, m, v, g) loads in flight
 #pragma unroll 1
-    for (int q0 = tid >> 4; q0 < cnt; q0 += RPI * NG) {
+    for (int q = tid >> 4; q < cnt; q += ADAM_BLOCK / 16) {
+        const int64_t i = base + s_item[q];
+        const int L = s_L[q];
+        const int r = s_r[q];
+        const bool in_rows = r >= 0 && r < d.n_rows;
+        // STEP with this frame's caught rows: p comes from them, the missed steps are replayed for the moments only
+        const bool use_caught = step && d.caught != nullptr && in_rows && h.wd == 0.f;
+        const bool need_state = has_state && (step || L < target);
 #pragma unroll 1
         for (int cb = 0; cb < sw; cb += 16 * ADAM_SEG) {
-            float p[RPI][ADAM_SEG], m[RPI][ADAM_SEG], v[RPI][ADAM_SEG], g[RPI][ADAM_SEG];
-            int64_t phys[RPI][ADAM_SEG];
-            int L[RPI];
+            float p[ADAM_SEG], m[ADAM_SEG], v[ADAM_SEG], g[ADAM_SEG];
+            int64_t phys[ADAM_SEG];
 #pragma unroll
-            for (int w = 0; w < RPI; ++w) {
-                const int q = q0 + w * NG;
-                const bool have = q < cnt;
-                const int64_t i = base + (have ? s_item[q] : 0);
-                const int r = (have && step) ? s_r[q] : -1;
-                L[w] = have ? s_L[q] : target;
-#pragma unroll
-                for (int u = 0; u < ADAM_SEG; ++u) {
-                    const int c = cb + 16 * u + c0;
-                    phys[w][u] = (have && c < sw) ? i * d.width + off + c : -1;
-                    g[w][u] = 0.f;
-                    if (phys[w][u] >= 0) {
-                        p[w][u] = d.p[phys[w][u]]; m[w][u] = d.m[phys[w][u]]; v[w][u] = d.v[phys[w][u]];
-                        if (r >= 0 && r < d.n_rows) g[w][u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
-                    }
+            for (int u = 0; u < ADAM_SEG; ++u) {
+                const int c = cb + 16 * u + c0;
+                phys[u] = c < sw ? i * d.width + off + c : -1;
+                g[u] = 0.f; m[u] = 0.f; v[u] = 0.f; p[u] = 0.f;
+                if (phys[u] >= 0) {
+                    p[u] = use_caught ? d.caught[(int64_t)r * d.caught_stride + d.caught_col + c] : d.p[phys[u]];
+                    if (need_state) { m[u] = d.m[phys[u]]; v[u] = d.v[phys[u]]; }
+                    if (step && in_rows) g[u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
                 }
             }
-#pragma unroll
-            for (int w = 0; w < RPI; ++w) {
+            if (need_state) {
                 Hyper hj = h;
-                // A row that has not been seen for ~900 steps has exp_avg at a FIXED POINT of the zero-gradient recurrence
-                // (0, or a denormal that m * (1 - beta1) no longer moves), and step_size * m / (sqrt(v) / bc2 + eps) -- at most
-                // step_size * |m| / eps -- is below a quarter ulp of p: from then on a step leaves m and p bit-for-bit alone and
-                // only multiplies v by beta2.  `settled` lanes take that one-instruction step as long as the bound holds for
-                // the step's scalar (checked per step: learning rates move), so a gap costs 40 instructions per element for
-                // its first ~900 steps and 2 for the rest -- still the same bits as stepping every time.
-                bool settled = false;
-                float m_max = 0.f, lim_min = 0.f;
-                for (int j = L[w] + 1; j <= target; ++j) {      // the zero-gradient steps this row missed, oldest first
-                    if (j >= win0) { hj.step_size = s_hist[2 * (j - win0)]; hj.bc2_sqrt = s_hist[2 * (j - win0) + 1]; }
-                    else { hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1]; }
-                    if (settled && hj.step_size * m_max < lim_min) {
+                if (use_caught) {
+                    for (int j = L + 1; j <= target; ++j) {
 #pragma unroll
-                        for (int u = 0; u < ADAM_SEG; ++u) v[w][u] = v[w][u] * h.b2;     // (phys < 0: an unused register)
-                        continue;
+                        for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // (wd == 0: p is not read)
                     }
-                    bool fixed = h.wd == 0.f && h.eps > 0.f;
-                    m_max = 0.f; lim_min = 3.0e38f;
+                } else {
+                    // A row that has not been seen for ~900 steps has exp_avg at a FIXED POINT of the zero-gradient recurrence
+                    // (0, or a denormal that m * (1 - beta1) no longer moves), and step_size * m / (sqrt(v) / bc2 + eps) -- at most
+                    // step_size * |m| / eps -- is below a quarter ulp of p: from then on a step leaves m and p bit-for-bit alone
+                    // and only multiplies v by beta2.  `settled` lanes take that one-instruction step as long as the bound holds
+                    // for the step's scalar (checked per step: learning rates move), so a gap costs ~40 instructions per element
+                    // for its first ~900 steps and 2 for the rest -- still the same bits as stepping every time.
+                    bool settled = false;
+                    float m_max = 0.f, lim_min = 0.f;
+                    for (int j = L + 1; j <= target; ++j) {      // the zero-gradient steps this row missed, oldest first
+                        if (j >= win0) { hj.step_size = s_hist[2 * (j - win0)]; hj.bc2_sqrt = s_hist[2 * (j - win0) + 1]; }
+                        else { hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1]; }
+                        if (settled && hj.step_size * m_max < lim_min) {
 #pragma unroll
-                    for (int u = 0; u < ADAM_SEG; ++u) {
-                        if (phys[w][u] < 0) continue;
-                        const float m_old = m[w][u];
-                        adam_update(p[w][u], m[w][u], v[w][u], 0.f, hj);
-                        fixed = fixed && m[w][u] == m_old;
-                        m_max = fmaxf(m_max, fabsf(m_old));
-                        lim_min = fminf(lim_min, h.eps * fabsf(p[w][u]) * 7.450580596923828e-09f);   // eps |p| 2^-27
+                            for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // m stays, v *= beta2
+                            continue;
+                        }
+                        bool fixed = h.wd == 0.f && h.eps > 0.f;
+                        m_max = 0.f; lim_min = 3.0e38f;
+#pragma unroll
+                        for (int u = 0; u < ADAM_SEG; ++u) {
+                            if (phys[u] < 0) continue;
+                            const float m_old = m[u];
+                            adam_update(p[u], m[u], v[u], 0.f, hj);
+                            fixed = fixed && m[u] == m_old;
+                            m_max = fmaxf(m_max, fabsf(m_old));
+                            lim_min = fminf(lim_min, h.eps * fabsf(p[u]) * 7.450580596923828e-09f);   // eps |p| 2^-27
+                        }
+                        settled = fixed;
                     }
-                    settled = fixed;
-                }
-#pragma unroll
-                for (int u = 0; u < ADAM_SEG; ++u) {
-                    if (phys[w][u] < 0) continue;
-                    if (step) adam_update(p[w][u], m[w][u], v[w][u], g[w][u], h);
-                    d.p[phys[w][u]] = p[w][u]; d.m[phys[w][u]] = m[w][u]; d.v[phys[w][u]] = v[w][u];
                 }
             }
-        }
-        if (c0 == 0) {
 #pragma unroll
-            for (int w = 0; w < RPI; ++w)
-                if (q0 + w * NG < cnt) d.last[(base + s_item[q0 + w * NG]) * T + d.sub_index] = step ? t_now : target;
+            for (int u = 0; u < ADAM_SEG; ++u) {
+                if (phys[u] < 0) continue;
+                if (peek) {
+                    d.caught[(int64_t)r * d.caught_stride + d.caught_col + (cb + 16 * u + c0)] = p[u];
+                    continue;
+                }
+                if (step) adam_update(p[u], m[u], v[u], g[u], h);
+                d.p[phys[u]] = p[u]; d.m[phys[u]] = m[u]; d.v[phys[u]] = v[u];
+            }
         }
+        if (c0 == 0 && !peek) d.last[i * T + d.sub_index] = step ? t_now : target;
     }
 }
 

@@ -45,9 +45,12 @@ struct RowInfo {
     int32_t k_rest, use_sh;
 };
 
+// coef_rows (nullable): the coefficients of visible Gaussian r as ONE compact row [dc 3 | dc_add 3 | rest 3 k_rest] at
+// coef_rows + r * coef_stride (the optimizer's peek: mtgs_adam_step, MTGS_ADAM_ROWS_PEEK) instead of the nodes' tensors.
 __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ table, int n_nodes, const float *__restrict__ cam_pos,
                                              const float *__restrict__ means, const int32_t *__restrict__ vis_ids, int64_t r0,
-                                             int64_t n_vis, RowInfo *s_row, int64_t *s_start) {
+                                             int64_t n_vis, RowInfo *s_row, int64_t *s_start,
+                                             const float *__restrict__ coef_rows = nullptr, int64_t coef_stride = 0) {
     const int tid = threadIdx.x;
     const bool small = n_nodes <= VC_LDS_NODES;
     if (small) {
@@ -71,6 +74,11 @@ __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ 
             ri.dc = d.features_dc + gl * d.dc_stride;
             ri.dc_add = d.features_dc_add ? d.features_dc_add + gl * d.dc_add_stride : nullptr;
             ri.rest = d.features_rest + gl * d.rest_stride;
+            if (coef_rows) {
+                ri.dc = coef_rows + r * coef_stride;
+                ri.dc_add = d.features_dc_add ? ri.dc + 3 : nullptr;
+                ri.rest = ri.dc + 6;
+            }
             ri.k_rest = d.k_rest; ri.use_sh = d.use_sh;
             const F3 m = *reinterpret_cast<const F3 *>(means + g * 3);
             float dx = m.x - cam_pos[0], dy = m.y - cam_pos[1], dz = m.z - cam_pos[2];
@@ -86,7 +94,8 @@ template <int DEG>
 __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
                                                                  const float *__restrict__ cam_pos, const float *__restrict__ means,
                                                                  const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
-                                                                 int64_t cap_vis, float *__restrict__ recs, uint8_t *__restrict__ vis_mask) {
+                                                                 int64_t cap_vis, float *__restrict__ recs, uint8_t *__restrict__ vis_mask,
+                                                                 const float *__restrict__ coef_rows, int64_t coef_stride) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     __shared__ RowInfo s_row[VC_ROWS];
     __shared__ int64_t s_start[VC_LDS_NODES];
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r0 = (int64_t)blockIdx.x * VC_ROWS;
     if (r0 >= n_vis) return;
-    resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start);
+    resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, coef_rows, coef_stride);
     const int k = threadIdx.x & 15, sub = threadIdx.x >> 4;
     const ShLaneConst lc = sh_lane_const(k);
     F3 c[VC_STEPS];
@@ -268,13 +277,16 @@ __global__ __launch_bounds__(256) void rows_expand4_kernel(int64_t N, int width4
 
 extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                                   const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
-                                  void *stream) {
+                                  const float *coef_rows, int64_t coef_stride, void *stream) {
     MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0, MTGS_EINVAL, "mtgs_vis_color_fwd: bad sizes (degree <= 3)");
+    MTGS_REQUIRE(!coef_rows || coef_stride >= 51, MTGS_EINVAL, "mtgs_vis_color_fwd: coef_stride=%lld (a row is dc 3 | dc_add 3 | rest 45)",
+                 (long long)coef_stride);
     if (cap_vis == 0) return MTGS_OK;
     MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && recs && vis_mask, MTGS_EINVAL, "mtgs_vis_color_fwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
-    MTGS_VC_DISPATCH(vis_color_fwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, recs, vis_mask)
+    MTGS_VC_DISPATCH(vis_color_fwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, recs, vis_mask, coef_rows,
+                     coef_stride)
     MTGS_CHECK_LAUNCH("mtgs_vis_color_fwd");
     return MTGS_OK;
 }

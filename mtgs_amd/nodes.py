@@ -184,34 +184,49 @@ class ColorSource:
         self.node_params = node_params     # per node: (start, n, features_dc, features_adapters | None, features_rest, traversal | None)
         self.rows = self.row_of = None
         self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
-        self.optimizer = None   # a FusedAdam with row-lazy colour parameters: catch_up() runs before the coefficients are read
+        self.optimizer = None   # a FusedAdam with row-lazy colour parameters: prepare() peeks the visible rows for the colour kernel
+        self.caught = None
 
-    def catch_up(self, vis_rank: Tensor) -> None:
-        """Called by the rasterization between its front end and the colour kernel: the coefficient rows of the Gaussians
-        the frame sees are brought up to date (FusedAdam.set_row_lazy / catch_up_rows).  vis_rank int32 [N]: row or -1."""
+    COEF_STRIDE = 52            # floats of a compact coefficient row: dc 3 | dc_add (adapter) 3 | rest 45 | pad
+
+    def prepare(self, vis_rank: Tensor, cap_rows: int) -> Optional[Tensor]:
+        """Called by the rasterization between its front end and the colour kernel.  With a row-lazy optimizer attached
+        (`self.optimizer`, FusedAdam.set_row_lazy): the UP-TO-DATE coefficient rows of the Gaussians the frame sees, as one
+        compact buffer [cap_rows, COEF_STRIDE] that the colour kernel reads instead of the parameters (FusedAdam.peek_rows:
+        nothing in the optimizer changes) and that apply_to() hands back to the step.  vis_rank int32 [N]: row or -1.
+        Returns the buffer, or None (no optimizer: the colour kernel reads the parameters in place)."""
+        self.caught = None
         if self.optimizer is None:
-            return
+            return None
+        out = torch.empty((max(int(cap_rows), 1), self.COEF_STRIDE), dtype=torch.float32, device=vis_rank.device)
         items = []
         for start, n, dc, adapters, rest, trav in self.node_params:
             ro = vis_rank[start:start + n]
-            items.append((dc, ro, None))
+            items.append((dc, ro, None, 0))
             if adapters is not None:
-                items.append((adapters, ro, trav if adapters.dim() == 3 else None))
+                items.append((adapters, ro, trav if adapters.dim() == 3 else None, 3))
             if rest.shape[-2] > 0:
-                items.append((rest, ro, trav if rest.dim() == 4 else None))
-        self.optimizer.catch_up_rows(items)
+                items.append((rest, ro, trav if rest.dim() == 4 else None, 6))
+        self.optimizer.peek_rows(items, out)
+        self.caught = out
+        return out
 
     def apply_to(self, optimizer) -> None:
         """optimizer.set_row_gradient(...) for every colour parameter of every node (call between backward() and step())."""
         assert self.rows is not None, "backward() of the rasterization first"
+        c = getattr(self, "caught", None)
+        if c is not None and (optimizer is not self.optimizer or c.shape[0] < self.rows.shape[0]):
+            c = None     # (the peeked rows belong to the optimizer that made them, numbered like this frame's gradient rows)
+        lazy = getattr(optimizer, "_rowlazy", {})
+        ck = lambda p, col: {"caught": (c, col)} if (c is not None and id(p) in lazy) else {}
         for start, n, dc, adapters, rest, trav in self.node_params:
             ro = self.row_of[start:start + n]
             if dc.requires_grad:
-                optimizer.set_row_gradient(dc, self.rows, ro, 0)
+                optimizer.set_row_gradient(dc, self.rows, ro, 0, **ck(dc, 0))
             if adapters is not None and adapters.requires_grad:
-                optimizer.set_row_gradient(adapters, self.rows, ro, 0, slice_index=trav if adapters.dim() == 3 else None)
+                optimizer.set_row_gradient(adapters, self.rows, ro, 0, slice_index=trav if adapters.dim() == 3 else None, **ck(adapters, 3))
             if rest.requires_grad and rest.shape[-2] > 0:
-                optimizer.set_row_gradient(rest, self.rows, ro, 3, slice_index=trav if rest.dim() == 4 else None)
+                optimizer.set_row_gradient(rest, self.rows, ro, 3, slice_index=trav if rest.dim() == 4 else None, **ck(rest, 6))
 
     def dense_gradients(self):
         """[(features_dc grad, features_adapters grad | None, features_rest grad)] per node, dense (zeros where no row)."""

@@ -25,10 +25,12 @@ optimizer's traffic no longer grows with the number of traversals.  `flush()` be
 Exact ROW-lazy Adam (`set_row_lazy(param)`) for parameters of which a frame reads the visible rows only -- the SH
 coefficients under visibility-first colours (mtgs_amd.nodes.ColorSource): a Gaussian the frame does not see has a zero
 gradient, its moments decay and its value drifts along exp_avg, but nothing reads it until it is seen again.  The step then
-touches the VISIBLE rows alone, and the forward catches a row up (the zero-gradient steps it missed, in registers, the same
-operations in the same order: bit-identical) right before it is read (`ColorSource.optimizer = opt` wires
-`catch_up_rows()` between the front end and the colour kernel).  Optimizer traffic for the coefficients drops from every
-Gaussian x every traversal to the visible rows of the rendered traversal.  `flush()` as above; `state_dict()` flushes.
+touches the VISIBLE rows alone, and the forward PEEKS (`ColorSource.optimizer = opt` wires `peek_rows()` between the front end
+and the colour kernel): the zero-gradient steps a visible row missed are replayed in registers (the same operations in the same
+order: bit-identical) into a compact buffer that the colour kernel reads and that the step takes the parameter values back from;
+the optimizer's own state changes in `step()` / `flush()` only.  Optimizer traffic for the coefficients drops from every
+Gaussian x every traversal to the visible rows of the rendered traversal.  `flush()` as above; `state_dict()` flushes;
+`catch_up_rows()` is the in-place form of the peek for callers that read the parameters themselves.
 
 HIP graphs: the per-step scalars (lr / (1 - beta1^t), sqrt(1 - beta2^t)) live in a small device array that `advance()`
 refreshes with one copy; `step()` = `advance()` + the launch.  Capture `step()` once, then per replay call `advance()` and
@@ -45,12 +47,13 @@ import torch
 from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
-                   ("last", "<u8"), ("hist", "<u8"),
-                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("n_rows", "<i8"), ("width", "<i4"), ("row_col", "<i4"),
+                   ("last", "<u8"), ("hist", "<u8"), ("caught", "<u8"),
+                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("caught_stride", "<i8"), ("n_rows", "<i8"),
+                   ("width", "<i4"), ("row_col", "<i4"),
                    ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
-                   ("hyper_index", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
+                   ("hyper_index", "<i4"), ("caught_col", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
                    ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
-MODE_DENSE, MODE_SLICE, MODE_ROWS_CATCHUP, MODE_ROWS_STEP, MODE_ROWS_FLUSH = 0, 1, 2, 3, 4   # include/mtgs_rast.h MTGS_ADAM_*
+MODE_DENSE, MODE_SLICE, MODE_ROWS_CATCHUP, MODE_ROWS_STEP, MODE_ROWS_FLUSH, MODE_ROWS_PEEK = 0, 1, 2, 3, 4, 5   # MTGS_ADAM_*
 _checked = False
 
 
@@ -88,12 +91,13 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- gradient source 2 -------------------------------------------------------------------------------------------
     def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0,
-                         slice_index: Optional[int] = None) -> None:
+                         slice_index: Optional[int] = None, caught=None) -> None:
         """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
         Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
         int32 [N].  slice_index = t for a per-traversal tensor `param[N, T, ...]`: only `param[:, t]` takes the row (width =
         elements of one slice), the other traversals get the zero gradient.  `param.grad` is ignored for this parameter.
-        Cleared by step() / zero_grad()."""
+        caught: row-lazy parameters -- the up-to-date rows peek_rows() left for THIS frame (same row numbering); the step then
+        takes the parameter from them and only replays the moments of the missed steps.  Cleared by step() / zero_grad()."""
         width = param.numel() // max(param.shape[0], 1) if param.dim() else 1
         sub_w, sub_i = 0, 0
         if slice_index is not None:
@@ -105,7 +109,12 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("set_row_gradient: rows float32 [R, stride], row_of int32 [N]")
         if rows.dim() != 2 or rows.stride(1) != 1 or col < 0 or col + (sub_w or width) > rows.shape[1] or not row_of.is_contiguous():
             raise ValueError("set_row_gradient: row layout")
-        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i)
+        if caught is not None:    # (buffer [R', stride] float32, column): this frame's peek_rows() output for the parameter
+            cb, cc = caught
+            if cb.dtype != torch.float32 or cb.dim() != 2 or cb.stride(1) != 1 or cb.shape[0] < rows.shape[0] or \
+                    cc < 0 or cc + (sub_w or width) > cb.shape[1]:
+                raise ValueError("set_row_gradient: caught = (float32 [R' >= R, stride], column)")
+        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught)
 
     def zero_grad(self, set_to_none: bool = True):
         self._rows.clear()
@@ -207,38 +216,50 @@ class FusedAdam(torch.optim.Optimizer):
             return -1
         return int(float(self.state[p]["step"])) - (1 if self._pending_host else 0)
 
-    def _rows_groups(self, items, mode):
-        """Descriptor rows for [(row-lazy record, row_of | None, slice)] -> (table, blocks) or None."""
+    def _rows_groups(self, items, mode, out=None):
+        """Descriptor rows for [(row-lazy record | parameter, row_of | None, slice[, column of `out`])] -> (table, blocks) or
+        None.  A bare parameter (PEEK only) is a tensor without lazy state: its rows are copied as they are."""
         _check_layout()
         per_block = load().mtgs_adam_block_rows()
         recs = []
-        for RL, ro, t in items:
-            p = RL["param"]
-            st = self.state.get(p)
-            if not st or "exp_avg" not in st or self._hyper_dev is None:
-                continue                       # no step taken yet: nothing to catch up
+        for it in items:
+            RL, ro, t = it[0], it[1], it[2]
+            col = it[3] if len(it) > 3 else 0
+            lazy = isinstance(RL, dict)
+            p = RL["param"] if lazy else RL
+            st = self.state.get(p) if lazy else None
+            stateful = bool(st) and "exp_avg" in st and self._hyper_dev is not None
+            if not stateful:
+                if mode != MODE_ROWS_PEEK:
+                    continue                   # no step taken yet: nothing to catch up
+                recs.append((p, None, None, ro, t, 0, 0, col))
+                continue
             target = self._rows_target(p)
             hi = self._hyper_index.get(id(p))
             if hi is None:
                 if target < 0:
                     raise RuntimeError("FusedAdam: a row-lazy parameter that the captured step does not update")
                 hi = 0                         # (explicit target: the hyper row is not read)
-            recs.append((RL, ro, t, target, hi))
+            recs.append((p, RL, st, ro, t, target, hi, col))
         if not recs:
             return None
         tab = np.zeros(len(recs), _GROUP)
         fb = 0
-        for i, (RL, ro, t, target, hi) in enumerate(recs):
-            p = RL["param"]
-            st = self.state[p]
-            grp = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+        for i, (p, RL, st, ro, t, target, hi, col) in enumerate(recs):
+            grp = next((g for g in self.param_groups if any(q is p for q in g["params"])),
+                       {"betas": (0.0, 0.0), "eps": 0.0, "weight_decay": 0.0})      # (a tensor of another optimizer: copied)
             N = p.shape[0]
             width = p.numel() // max(N, 1)
             r = tab[i]
-            r["p"], r["m"], r["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            r["last"], r["hist"], r["n"], r["first_block"], r["width"] = RL["last"].data_ptr(), RL["hist"].data_ptr(), N, fb, width
-            if RL["T"] > 1:
-                r["sub_width"], r["sub_index"] = width // RL["T"], int(t)
+            r["p"], r["n"], r["first_block"], r["width"] = p.data_ptr(), N, fb, width
+            if st is not None:
+                r["m"], r["v"] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                r["last"], r["hist"] = RL["last"].data_ptr(), RL["hist"].data_ptr()
+            if t is not None and p.dim() >= 2 and (RL["T"] > 1 if RL is not None else True):
+                T = RL["T"] if RL is not None else p.shape[1]
+                r["sub_width"], r["sub_index"] = width // T, int(t)
+            if out is not None:
+                r["caught"], r["caught_stride"], r["caught_col"], r["n_rows"] = out.data_ptr(), out.stride(0), int(col), out.shape[0]
             if ro is not None:
                 if ro.dtype != torch.int32 or ro.numel() != N or not ro.is_contiguous():
                     raise ValueError("catch_up_rows: row_of int32 [N]")
@@ -270,6 +291,33 @@ class FusedAdam(torch.optim.Optimizer):
             from .nodes import upload_table
             self._catch_table, self._catch_key = upload_table(tab, todo[0][0]["param"].device), key
         call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, 0, stream_of(todo[0][0]["param"]))
+
+    def peek_rows(self, items, out: torch.Tensor) -> None:
+        """items: [(param, row_of int32 [N], slice | None, column)] -- for every Gaussian with row_of[n] = r >= 0 the UP-TO-DATE row
+        of the parameter (its slice) is written to out[r, column : column + width]: row-lazy parameters are caught up in
+        registers (nothing in the optimizer changes: a forward stays free of side effects), other tensors are copied.  `out`
+        float32 [R, stride]; ranks >= R are skipped.  One launch.  Hand `out` back through set_row_gradient(caught=...) and
+        the step reuses the caught-up parameter values instead of recomputing them."""
+        if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
+            raise ValueError("peek_rows: out float32 [R, stride]")
+        todo = []
+        for p, ro, t, col in items:
+            RL = self._rowlazy.get(id(p))
+            if RL is not None and RL["T"] > 1 and t is None:
+                raise ValueError("peek_rows: a per-traversal parameter needs its slice")
+            todo.append((RL if RL is not None else p, ro, t, int(col)))
+        built = self._rows_groups(todo, MODE_ROWS_PEEK, out)
+        if built is None:
+            return
+        tab, blocks = built
+        dev = out.device
+        hyper = self._hyper_dev if self._hyper_dev is not None else torch.zeros(4, dtype=torch.float32, device=dev)
+        key = tab.tobytes()
+        if key != self._catch_key or torch.cuda.is_current_stream_capturing():
+            from .nodes import upload_table
+            self._catch_table, self._catch_key = upload_table(tab, dev), key
+        self._peek_keep = (out, hyper)
+        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(hyper), blocks, 0, 0, stream_of(out))
 
     def _flush_rows(self) -> None:
         items = [(RL, None, t) for RL in self._rowlazy.values() for t in range(RL["T"])]
@@ -350,7 +398,7 @@ class FusedAdam(torch.optim.Optimizer):
                 align |= g.data_ptr()
                 keep.append(g)
             elif src is not None:
-                rows, row_of, col, stride, width, sub_w, sub_i = src
+                rows, row_of, col, stride, width, sub_w, sub_i, caught = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 r["n_rows"] = rows.shape[0]
                 r["sub_width"], r["sub_index"] = sub_w, sub_i
@@ -364,6 +412,9 @@ class FusedAdam(torch.optim.Optimizer):
                 if (RL["T"] > 1) != (src[5] > 0) or (src[5] > 0 and src[4] // src[5] != RL["T"]):
                     raise RuntimeError("FusedAdam: row-lazy parameter and the slice of its row gradient do not match")
                 r["mode"], r["last"], r["hist"], r["n"] = MODE_ROWS_STEP, RL["last"].data_ptr(), RL["hist"].data_ptr(), p.shape[0]
+                if src[7] is not None and grp["weight_decay"] == 0:
+                    r["caught"], r["caught_stride"], r["caught_col"] = src[7][0].data_ptr(), src[7][0].stride(0), int(src[7][1])
+                    keep.append(src[7][0])
                 fb += -(-int(p.shape[0]) // load().mtgs_adam_block_rows())
                 b1, b2 = grp["betas"]
                 r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2

@@ -611,9 +611,9 @@ class _FusedRasterization(torch.autograd.Function):
                      (1 if dp is not None else 0) if cs is None else 2, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 if cs is not None:   # colours of the visible Gaussians, straight into their records
-                    cs.catch_up(vis_rank)     # (row-lazy optimizer: the rows about to be read, brought up to date)
+                    coef = cs.prepare(vis_rank, cap_vis)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
                     call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
-                         ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), st)
+                         ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), ptr(coef), 0 if coef is None else coef.stride(0), st)
                 b["mailbox"], b["tag"] = mailbox, tag
                 if dpf is not None:
                     dpf.after_front()      # the visibility maps travel while this frame is composited

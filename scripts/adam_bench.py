@@ -96,10 +96,11 @@ def main():
         T = args.traversals
         Pc = {"dc": torch.randn(N, 3, device=dev, generator=g), "ad": torch.randn(N, T, 3, device=dev, generator=g),
               "rest": torch.randn(N, T, 15, 3, device=dev, generator=g)}
-        for variant in ("rows (every row, every traversal)", "row-lazy"):
+        for variant in ("rows (every row, every traversal)", "row-lazy", "row-lazy, peek + caught"):
             P = {k: v.clone().requires_grad_(True) for k, v in Pc.items()}
             opt = FusedAdam([{"params": [P["dc"], P["ad"]], "lr": 0.0025}, {"params": [P["rest"]], "lr": 0.0025 / 20}], eps=1e-15)
-            lazy = variant == "row-lazy"
+            lazy = variant.startswith("row-lazy")
+            peek = variant.endswith("caught")
             if lazy:
                 opt.set_row_lazy(P["dc"]); opt.set_row_lazy(P["ad"], traversals=T); opt.set_row_lazy(P["rest"], traversals=T)
             frames = []
@@ -117,12 +118,17 @@ def main():
                 row_of, rows, n_vis = frames[i % 8]
                 t = i % T
                 ev[i][0].record()
-                if lazy:
+                ck = lambda col: {}
+                if peek:
+                    Cb = torch.empty(n_vis, 52, device=dev)
+                    opt.peek_rows([(P["dc"], row_of, None, 0), (P["ad"], row_of, t, 3), (P["rest"], row_of, t, 6)], Cb)
+                    ck = lambda col: {"caught": (Cb, col)}
+                elif lazy:
                     opt.catch_up_rows([(P["dc"], row_of, None), (P["ad"], row_of, t), (P["rest"], row_of, t)])
                 ev[i][1].record()
-                opt.set_row_gradient(P["dc"], rows, row_of, 0)
-                opt.set_row_gradient(P["ad"], rows, row_of, 0, slice_index=t)
-                opt.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t)
+                opt.set_row_gradient(P["dc"], rows, row_of, 0, **ck(0))
+                opt.set_row_gradient(P["ad"], rows, row_of, 0, slice_index=t, **ck(3))
+                opt.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t, **ck(6))
                 opt.step()
                 ev[i][2].record()
             torch.cuda.synchronize()

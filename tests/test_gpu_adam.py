@@ -486,3 +486,59 @@ def test_row_map_entries_beyond_the_row_buffer_are_not_read(hip_lib):
             o.flush()
             outs.append(p.detach().clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+
+
+def test_row_lazy_peek_leaves_the_optimizer_alone_and_feeds_the_step(hip_lib):
+    """peek_rows: the up-to-date rows of the visible Gaussians in a compact buffer (what the colour kernel reads) WITHOUT any
+    change to parameters, moments or stamps; handed back through set_row_gradient(caught=...) the step takes the parameter
+    from them and replays only the moments of the missed steps.  Over a random sequence: (1) the peeked rows are bit-identical
+    to the every-row optimizer's parameters, (2) a peek changes nothing, (3) a peek that is NOT followed by its step (an
+    evaluation frame) is harmless, (4) after flush() everything is bit-identical, (5) tensors that are not row-lazy are
+    copied, (6) ranks beyond the buffer are skipped."""
+    dev = torch.device("cuda")
+    N, T = 2503, 3
+    g = torch.Generator().manual_seed(17)
+    base, make = _row_lazy_case(dev, N, T, g)
+    Pa, oa = make(False)
+    Pb, ob = make(True, hist_capacity=8)
+    seq = [0, 2, 2, 1, 0, 1, 1, 2, 0, 0, 1, 2, 2, 0]
+    for step, t in enumerate(seq):
+        vis, row_of, rows = _frame(N, g, dev, frac=0.3 if step % 4 else 0.06)
+        R = rows.shape[0]
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-2 * 0.9 ** step
+        items = [(Pb["dc"], row_of, None, 0), (Pb["adapters"], row_of, t, 3), (Pb["rest"], row_of, t, 6), (Pb["means"], row_of, None, 51)]
+        before = {k: Pb[k].detach().clone() for k in base}
+        mom = ob.state[Pb["rest"]]["exp_avg"].clone() if step else None
+        C = torch.full((R, 56), float("nan"), device=dev)
+        ob.peek_rows(items, C)
+        for k in base:
+            assert torch.equal(before[k], Pb[k]), (step, k)                                  # (2)
+        if mom is not None:
+            assert torch.equal(mom, ob.state[Pb["rest"]]["exp_avg"])
+        r = row_of[vis].long()
+        assert torch.equal(C[r, 0:3], Pa["dc"][vis]) and torch.equal(C[r, 3:6], Pa["adapters"][vis, t]), step       # (1)
+        assert torch.equal(C[r, 6:51], Pa["rest"][vis, t].reshape(-1, 45)), step
+        assert torch.equal(C[r, 51:54], Pa["means"][vis]), step                              # (5)
+        if step == 5:                                                                        # (3) an evaluation frame: no step
+            continue
+        if step == 7:                                                                        # (6) a buffer that is too short
+            short = torch.full((max(R // 2, 1), 56), float("nan"), device=dev)
+            ob.peek_rows(items, short)
+            keep = r < short.shape[0]
+            assert torch.equal(short[r[keep], 6:51], C[r[keep], 6:51])
+        grad_means = (torch.randn(N, 3, generator=g) * 0.1).to(dev)
+        for P, o, ck in ((Pa, oa, None), (Pb, ob, C)):
+            P["means"].grad = grad_means.clone()
+            kw = (lambda col: {"caught": (ck, col)}) if ck is not None else (lambda col: {})
+            o.set_row_gradient(P["dc"], rows, row_of, 0, **kw(0))
+            o.set_row_gradient(P["adapters"], rows, row_of, 0, slice_index=t, **kw(3))
+            o.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t, **kw(6))
+            o.step()
+        assert torch.equal(Pa["rest"][vis, t], Pb["rest"][vis, t]) and torch.equal(Pa["dc"][vis], Pb["dc"][vis]), step
+    assert not torch.equal(Pa["rest"], Pb["rest"])
+    ob.flush()
+    for k in base:
+        assert torch.equal(Pa[k], Pb[k]), k                                                  # (4)
+        assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k

@@ -204,7 +204,7 @@ def test_round3_host_logic_without_a_gpu():
     with pytest.raises(RuntimeError):    # row-lazy parameters live on the GPU
         o.set_row_lazy(p)
     cs0 = nodes.ColorSource(None, 1, 3, None, [], [])
-    cs0.catch_up(torch.zeros(4, dtype=torch.int32))      # no optimizer attached: nothing to do
+    assert cs0.prepare(torch.zeros(4, dtype=torch.int32), 4) is None      # no optimizer attached: the parameters are read in place
     m, v, _ = None, None, None
     ref = optim.adam_reference_step(torch.ones(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64),
                                     torch.full((3,), 0.5, dtype=torch.float64), 1, 1e-2, eps=1e-15)
