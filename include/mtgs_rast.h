@@ -650,11 +650,16 @@ typedef struct mtgs_adam_group {
     const float *catchup;       /* catchup_k > 0: {step_size, bc2_sqrt} of the catchup_k steps to apply, oldest first (DEVICE) */
     int32_t *last;              /* row-lazy groups: [n, T] step up to which slice (i, t) of item i is current */
     float *hist;                /* row-lazy groups: {step_size, bc2_sqrt} of step j at hist[2 j] (DEVICE; the step launch appends) */
+    const int32_t *row_ids;     /* row-lazy groups, LIST form (nullable): the frame's visible Gaussians in increasing order,
+                                 * row_ids[r] = global index of rank r (mtgs_front_fwd's vis_ids); this tensor's items are the
+                                 * indices item_start .. item_start + n - 1.  NULL: SCAN form, the rows are found through row_of */
+    const int64_t *row_count_dev; /* LIST: number of valid ranks = min(n_rows, *row_count_dev >> 32) (mtgs_front_fwd's totals; nullable) */
     float *caught;              /* ROWS_PEEK: destination, ROWS_STEP: source (nullable) -- the up-to-date parameter rows of the
                                  * frame, row r = row_of[i] at caught[r * caught_stride + caught_col ..] (n_rows rows) */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
     int64_t caught_stride;      /* floats between rows of `caught` */
+    int64_t item_start;         /* LIST: global index of this tensor's item 0 */
     int64_t n_rows;             /* rows in `rows` (and `caught`): a row_of entry >= n_rows (a capacity overflow of the frame that produced the
                                  * map, graph mode) is treated as "no row" instead of being read */
     int32_t width, row_col;
@@ -670,7 +675,10 @@ typedef struct mtgs_adam_group {
     int32_t catchup_k;              /* SLICE: > 0: no gradient step -- apply catchup_k ZERO-gradient steps with the scalars in `catchup`.
                                      * ROWS_CATCHUP / ROWS_FLUSH: the step to catch up to, or < 0: hyper.t - hyper.pending */
     int32_t hyper_index;            /* row of `hyper` that belongs to this group */
-    int32_t caught_col, reserved;
+    int32_t caught_col;
+    int32_t rank_start, rank_count; /* LIST: the ranks of this tensor's items -- WRITTEN by mtgs_adam_step (flags bit 1), which also
+                                     * rewrites first_block of the LIST groups from the counts */
+    int32_t reserved;
     float one_minus_beta1, beta2, one_minus_beta2;   /* 1 - beta rounded from double by the caller (1 - 0.999f is 5e-5 off) */
     float eps, weight_decay, grad_scale;
 } mtgs_adam_group;
@@ -701,15 +709,24 @@ enum { MTGS_ADAM_DENSE = 0, MTGS_ADAM_SLICE = 1, MTGS_ADAM_ROWS_CATCHUP = 2, MTG
  *                frame's `caught` rows takes p from them and replays only the moment recurrences of the missed steps
  *                (m, v do not depend on p when weight_decay = 0; otherwise `caught` is ignored).  A PEEK group with m = v =
  *                last = NULL is a plain row copy (tensors that are not row-lazy).
- * Items untouched by a launch cost 4 bytes (row_of or last).  first_block advances by ceil(n / mtgs_adam_block_rows()). */
+ * SCAN form (row_ids = NULL): a workgroup scans mtgs_adam_block_rows() items through row_of / last; items untouched by a
+ * launch cost 4 bytes; first_block advances by ceil(n / mtgs_adam_block_rows()).  LIST form (row_ids given; not for FLUSH): one
+ * row per 16 lanes straight from the frame's list of visible Gaussians.  LIST groups come last in the table; only the FIRST
+ * one's first_block matters (where the LIST workgroups begin), the others are assigned on the device from the number of
+ * visible items of each tensor.  total_blocks must be an upper bound: tensors that share row_ids and item_start (one node)
+ * have the same count and the counts of different nodes add up to at most n_rows, so
+ * (largest number of tensors per node) * ceil(n_rows / mtgs_adam_block_list_rows()) + (number of LIST groups) is one. */
 int mtgs_adam_group_bytes(void);    /* sizeof(mtgs_adam_group): bindings check their layout against it */
 int mtgs_adam_block_elems(void);    /* elements one workgroup updates */
-int mtgs_adam_block_rows(void);     /* items one workgroup scans (row-lazy groups) */
-/* nontemporal != 0: moments (and a dense gradient) are streamed past the caches (they are touched once per step). */
+int mtgs_adam_block_rows(void);     /* items one workgroup scans (row-lazy groups, SCAN form) */
+int mtgs_adam_block_list_rows(void);  /* rows one workgroup handles (row-lazy groups, LIST form) */
+/* flags bit 0 (nontemporal): moments (and a dense gradient) are streamed past the caches (they are touched once per step). */
 /* rows_from_block: the row-lazy groups come LAST in the table and own the workgroups [rows_from_block, total_blocks) -- they run
- * as a second kernel with its own register budget (= total_blocks when the table has none, 0 when it has nothing else). */
-int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks, int64_t rows_from_block,
-                   int nontemporal, void *stream);
+ * as a second kernel with its own register budget (= total_blocks when the table has none, 0 when it has nothing else).
+ * flags: bit 0 = nontemporal (above), bit 1 = the table has LIST-form groups: their rank_start is resolved first (one small launch;
+ * the table is written). */
+int mtgs_adam_step(int n_groups, mtgs_adam_group *table, float *hyper, int64_t total_blocks, int64_t rows_from_block,
+                   int flags, void *stream);
 
 #ifdef __cplusplus
 }

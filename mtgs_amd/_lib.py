@@ -119,6 +119,7 @@ _SIGNATURES = {
     "mtgs_adam_group_bytes": [],
     "mtgs_adam_block_elems": [],
     "mtgs_adam_block_rows": [],
+    "mtgs_adam_block_list_rows": [],
     "mtgs_adam_step": [_i32, _vp, _vp, _i64, _i64, _i32, _vp],
     "mtgs_tile_schedule": [_i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "mtgs_blend_fwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,

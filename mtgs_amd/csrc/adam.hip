@@ -100,51 +100,155 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
     return d.rows[(int64_t)r * d.row_stride + d.row_col + c];
 }
 
-// Row-lazy group: see the header of this file.  `hy` = the group's hyper row {step_size, bc2_sqrt, t, pending}.
-// Phase A: the workgroup reads row_of / last of its ADAM_ROWS items (independent loads) and compacts the selected ones into
-// LDS; phase B: sixteen 16-lane groups walk that list -- per row ONE memory round trip (p, m, v and the gradient of up to
-// three 16-float segments in flight), the per-step scalars of the last ADAM_HWIN steps come from LDS.  (A first version
-// compacted per wave and read `last`, then the row, then the history entry of every missed step as dependent round trips:
-// 300 us for the catch-up of 370 MB -- latency, not bandwidth.)
+// ---- row-lazy groups (include/mtgs_rast.h, MTGS_ADAM_ROWS_*) ---------------------------------------------------------------
+// Modes: CATCHUP / FLUSH replay the missed zero-gradient steps in place; PEEK does the same in registers and leaves the
+// up-to-date PARAMETER rows in the compact buffer `caught` (row r = the Gaussian's rank) without touching p, m, v or `last` --
+// the forward reads its coefficients from there, coalesced, and has no side effect on the optimizer; STEP applies the step,
+// and when the same frame's `caught` rows are handed back it takes p from them and replays only the MOMENT half of the
+// missed steps (3 instructions each instead of ~40: the parameter half needs a square root and two divisions).
+// Two ways to find the rows:
+//   LIST (row_ids given: the frame's visible Gaussians in increasing order, rank -> index): rows straight from the list --
+//        ids[r], then `last`, p, m, v, gradient / caught row all in flight together: ONE dependent round trip per row, 128 rows
+//        per workgroup, the workgroups of every tensor assigned on the device from its number of visible items;
+//   SCAN (row map only): a workgroup reads row_of / last of ADAM_ROWS items, compacts the selected ones in LDS (all `last` are
+//        read before any is rewritten: a row belongs to one workgroup) and walks them; for callers without the id list and for
+//        FLUSH, which selects by `last`.
+// What the pattern costs on this chip (scripts/dev/gather_bench{,2}.hip: plain kernels over a precomputed id list, no arithmetic,
+// 304k visible of 1.6M Gaussians, T = 3): the 180-byte pieces of ONE [N, T, 45] tensor from three arrays: 39 us read-only
+// (4.2 TB/s), 111 us read + write; MTGS's three colour tensors (dc [N, 3], adapter [N, T, 3], rest [N, T, 45]) each with p, m, v
+// and a stamp: 112 ... 148 us peek-like, 222 ... 253 us step-like -- the 12-byte and 4-byte pieces cost a memory transaction
+// each.  Measured here, arithmetic included (MTGS-like iteration, 960x540): peek 155 ... 180 us (SCAN 175 ... 200), step 243 ... 297.
 #define ADAM_HWIN 64
-// Modes (include/mtgs_rast.h): CATCHUP / FLUSH replay the missed zero-gradient steps in place; PEEK does the same in registers
-// and leaves the up-to-date PARAMETER rows in the compact buffer `caught` (row r = row_of[i]) without touching p, m, v or
-// `last` -- the forward reads its coefficients from there, coalesced, and has no side effect on the optimizer; STEP applies
-// the step, and when the same frame's `caught` rows are handed back it takes p from them and replays only the MOMENT half of
-// the missed steps (3 instructions each instead of ~40: the parameter half needs a square root and two divisions).
-__device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
+#define ADAM_LIST_ROWS 128
+struct RowCtx {
+    bool step, flush, peek, has_state;
+    int t_now, target, win0, sw, T;
+    int64_t off;
+    const float *s_hist;
+};
+__device__ __forceinline__ RowCtx row_ctx(const mtgs_adam_group &d, const Hyper &h, float *hy, bool first_thread, float *s_hist) {
+    RowCtx x;
+    x.sw = d.sub_width > 0 ? d.sub_width : d.width;          // floats of the slice this group works on
+    x.T = d.sub_width > 0 ? d.width / d.sub_width : 1;
+    x.off = d.sub_width > 0 ? (int64_t)d.sub_index * x.sw : 0;
+    x.t_now = reinterpret_cast<const int32_t *>(hy)[2];
+    const int pending = reinterpret_cast<const int32_t *>(hy)[3];
+    x.step = d.mode == MTGS_ADAM_ROWS_STEP; x.flush = d.mode == MTGS_ADAM_ROWS_FLUSH; x.peek = d.mode == MTGS_ADAM_ROWS_PEEK;
+    x.has_state = d.m != nullptr && d.last != nullptr;      // (PEEK of a tensor that is not row-lazy: a plain copy)
+    x.target = x.step ? x.t_now - 1 : (d.catchup_k >= 0 ? d.catchup_k : x.t_now - pending);   // zero-gradient steps up to here
+    if (x.step && first_thread) {
+        d.hist[2 * (int64_t)x.t_now] = h.step_size;
+        d.hist[2 * (int64_t)x.t_now + 1] = h.bc2_sqrt;
+        reinterpret_cast<int32_t *>(hy)[3] = 0;      // (nothing in a step launch reads it)
+    }
+    x.win0 = x.target - ADAM_HWIN + 1;               // s_hist[2 (j - win0)] = scalars of step j
+    if (threadIdx.x < 2 * ADAM_HWIN && x.has_state) {
+        const int j = x.win0 + ((int)threadIdx.x >> 1);
+        s_hist[threadIdx.x] = j >= 1 ? d.hist[2 * (int64_t)j + (threadIdx.x & 1)] : 0.f;
+    }
+    x.s_hist = s_hist;
+    return x;
+}
+
+// One row (item i, rank r) by one 16-lane group.  LIST: `last` is loaded here, together with the row (L_in is ignored).
+template <bool LIST, int LPR>
+__device__ __forceinline__ void row_work(const mtgs_adam_group &d, const Hyper &h, const RowCtx &x, const int64_t i, const int r,
+                                         const int L_in, const int c0) {
+    int32_t *lastp = x.has_state ? d.last + i * x.T + d.sub_index : nullptr;
+    int L = L_in;
+    if (LIST) L = x.has_state ? *lastp : x.target;
+    const bool in_rows = r >= 0 && r < d.n_rows;
+    // STEP with this frame's caught rows: p comes from them, the missed steps are replayed for the moments only
+    const bool use_caught = x.step && d.caught != nullptr && in_rows && h.wd == 0.f;
+    const bool need_state = LIST ? x.has_state : (x.has_state && (x.step || L < x.target));
+#pragma unroll 1
+    for (int cb = 0; cb < x.sw; cb += LPR * ADAM_SEG) {
+        float p[ADAM_SEG], m[ADAM_SEG], v[ADAM_SEG], g[ADAM_SEG];
+        int64_t phys[ADAM_SEG];
+#pragma unroll
+        for (int u = 0; u < ADAM_SEG; ++u) {
+            const int c = cb + LPR * u + c0;
+            phys[u] = c < x.sw ? i * d.width + x.off + c : -1;
+            g[u] = 0.f; m[u] = 0.f; v[u] = 0.f; p[u] = 0.f;
+            if (phys[u] >= 0) {
+                p[u] = use_caught ? d.caught[(int64_t)r * d.caught_stride + d.caught_col + c] : d.p[phys[u]];
+                if (need_state) { m[u] = d.m[phys[u]]; v[u] = d.v[phys[u]]; }
+                if (x.step && in_rows) g[u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
+            }
+        }
+        if (need_state) {
+            Hyper hj = h;
+            if (use_caught) {
+                for (int j = L + 1; j <= x.target; ++j) {
+#pragma unroll
+                    for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // (wd == 0: p is not read)
+                }
+            } else {
+                // A row that has not been seen for ~900 steps has exp_avg at a FIXED POINT of the zero-gradient recurrence
+                // (0, or a denormal that m * (1 - beta1) no longer moves), and step_size * m / (sqrt(v) / bc2 + eps) -- at most
+                // step_size * |m| / eps -- is below a quarter ulp of p: from then on a step leaves m and p bit-for-bit alone
+                // and only multiplies v by beta2.  `settled` lanes take that one-instruction step as long as the bound holds
+                // for the step's scalar (checked per step: learning rates move), so a gap costs ~40 instructions per element
+                // for its first ~900 steps and 2 for the rest -- still the same bits as stepping every time.
+                bool settled = false;
+                float m_max = 0.f, lim_min = 0.f;
+                for (int j = L + 1; j <= x.target; ++j) {      // the zero-gradient steps this row missed, oldest first
+                    if (j >= x.win0) { hj.step_size = x.s_hist[2 * (j - x.win0)]; hj.bc2_sqrt = x.s_hist[2 * (j - x.win0) + 1]; }
+                    else { hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1]; }
+                    if (settled && hj.step_size * m_max < lim_min) {
+#pragma unroll
+                        for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // m stays, v *= beta2
+                        continue;
+                    }
+                    bool fixed = h.wd == 0.f && h.eps > 0.f;
+                    m_max = 0.f; lim_min = 3.0e38f;
+#pragma unroll
+                    for (int u = 0; u < ADAM_SEG; ++u) {
+                        if (phys[u] < 0) continue;
+                        const float m_old = m[u];
+                        adam_update(p[u], m[u], v[u], 0.f, hj);
+                        fixed = fixed && m[u] == m_old;
+                        m_max = fmaxf(m_max, fabsf(m_old));
+                        lim_min = fminf(lim_min, h.eps * fabsf(p[u]) * 7.450580596923828e-09f);   // eps |p| 2^-27
+                    }
+                    settled = fixed;
+                }
+            }
+        }
+        const bool dirty = x.step || L < x.target;       // (LIST, catch-up in place: a row that is current is left alone)
+#pragma unroll
+        for (int u = 0; u < ADAM_SEG; ++u) {
+            if (phys[u] < 0) continue;
+            if (x.peek) {
+                if (in_rows) d.caught[(int64_t)r * d.caught_stride + d.caught_col + (cb + LPR * u + c0)] = p[u];
+                continue;
+            }
+            if (!dirty) continue;
+            if (x.step) adam_update(p[u], m[u], v[u], g[u], h);
+            d.p[phys[u]] = p[u]; d.m[phys[u]] = m[u]; d.v[phys[u]] = v[u];
+        }
+    }
+    // (SCAN: every lane of the workgroup has read its `last` before the barrier; LIST: the row's 16 lanes read it above, same wave)
+    if (c0 == 0 && !x.peek && x.has_state && (x.step || L < x.target)) *lastp = x.step ? x.t_now : x.target;
+}
+
+__device__ __forceinline__ void adam_rows_scan(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
     __shared__ int s_item[ADAM_ROWS], s_L[ADAM_ROWS], s_r[ADAM_ROWS];
     __shared__ float s_hist[2 * ADAM_HWIN];
     __shared__ int s_cnt;
     const int tid = threadIdx.x;
-    const int sw = d.sub_width > 0 ? d.sub_width : d.width;          // floats of the slice this group works on
-    const int T = d.sub_width > 0 ? d.width / d.sub_width : 1;
-    const int64_t off = d.sub_width > 0 ? (int64_t)d.sub_index * sw : 0;
-    const int t_now = reinterpret_cast<const int32_t *>(hy)[2], pending = reinterpret_cast<const int32_t *>(hy)[3];
-    const bool step = d.mode == MTGS_ADAM_ROWS_STEP, flush = d.mode == MTGS_ADAM_ROWS_FLUSH, peek = d.mode == MTGS_ADAM_ROWS_PEEK;
-    const bool has_state = d.m != nullptr && d.last != nullptr;      // (PEEK of a tensor that is not row-lazy: a plain copy)
-    const int target = step ? t_now - 1 : (d.catchup_k >= 0 ? d.catchup_k : t_now - pending);   // zero-gradient steps up to here
-    if (step && block_in_group == 0 && tid == 0) {
-        d.hist[2 * (int64_t)t_now] = h.step_size;
-        d.hist[2 * (int64_t)t_now + 1] = h.bc2_sqrt;
-        reinterpret_cast<int32_t *>(hy)[3] = 0;      // (nothing in a step launch reads it)
-    }
-    const int win0 = target - ADAM_HWIN + 1;         // s_hist[2 (j - win0)] = scalars of step j
-    if (tid < 2 * ADAM_HWIN && has_state) {
-        const int j = win0 + (tid >> 1);
-        s_hist[tid] = j >= 1 ? d.hist[2 * (int64_t)j + (tid & 1)] : 0.f;
-    }
+    const RowCtx x = row_ctx(d, h, hy, block_in_group == 0 && tid == 0, s_hist);
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     const int64_t base = block_in_group * ADAM_ROWS;
     {
         const int64_t i = base + tid;
         bool sel = false;
-        int L = target, r = -1;
+        int L = x.target, r = -1;
         if (i < d.n) {
-            if (has_state) L = d.last[i * T + d.sub_index];
-            if (!flush) r = d.row_of[i];
-            sel = flush ? L < target : (peek ? (r >= 0 && r < d.n_rows) : (r >= 0 && (step || L < target)));
+            if (x.has_state) L = d.last[i * x.T + d.sub_index];
+            if (!x.flush) r = d.row_of[i];
+            sel = x.flush ? L < x.target : (x.peek ? (r >= 0 && r < d.n_rows) : (r >= 0 && (x.step || L < x.target)));
         }
         const unsigned long long mask = __ballot(sel);
         if (mask != 0) {
@@ -159,82 +263,90 @@ __device__ __forceinline__ void adam_rows(const mtgs_adam_group &d, const Hyper 
     }
     __syncthreads();      // every `last` of this workgroup's items has been read; the list is complete
     const int cnt = s_cnt;
-    const int c0 = tid & 15;
 #pragma unroll 1
-    for (int q = tid >> 4; q < cnt; q += ADAM_BLOCK / 16) {
-        const int64_t i = base + s_item[q];
-        const int L = s_L[q];
-        const int r = s_r[q];
-        const bool in_rows = r >= 0 && r < d.n_rows;
-        // STEP with this frame's caught rows: p comes from them, the missed steps are replayed for the moments only
-        const bool use_caught = step && d.caught != nullptr && in_rows && h.wd == 0.f;
-        const bool need_state = has_state && (step || L < target);
+    for (int q = tid >> 4; q < cnt; q += ADAM_BLOCK / 16) row_work<false, 16>(d, h, x, base + s_item[q], s_r[q], s_L[q], tid & 15);
+}
+
+// LIST: a workgroup takes ADAM_LIST_ROWS consecutive ranks; rows of more than 4 floats by 16 lanes each (8 rows per lane group),
+// narrower ones (features_dc, one traversal's adapter: 3 floats) by 4 lanes each (2 rows per lane group) -- the prologue
+// (descriptor, scalars, history window, one barrier) is paid once per 128 rows.
+template <int LPR>
+__device__ __forceinline__ void adam_rows_list_t(const mtgs_adam_group &d, const Hyper &h, const RowCtx &x, int64_t block_in_group) {
+    const int tid = threadIdx.x;
+    constexpr int GROUPS = ADAM_BLOCK / LPR, TRIPS = ADAM_LIST_ROWS / GROUPS;
+    const int64_t q0 = block_in_group * ADAM_LIST_ROWS + tid / LPR;      // position among this tensor's ranks
+    int32_t id[TRIPS];
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {       // the block's ids first: TRIPS independent loads
+        const int64_t q = q0 + (int64_t)k * GROUPS;
+        id[k] = q < d.rank_count ? d.row_ids[d.rank_start + q] : -1;
+    }
 #pragma unroll 1
-        for (int cb = 0; cb < sw; cb += 16 * ADAM_SEG) {
-            float p[ADAM_SEG], m[ADAM_SEG], v[ADAM_SEG], g[ADAM_SEG];
-            int64_t phys[ADAM_SEG];
-#pragma unroll
-            for (int u = 0; u < ADAM_SEG; ++u) {
-                const int c = cb + 16 * u + c0;
-                phys[u] = c < sw ? i * d.width + off + c : -1;
-                g[u] = 0.f; m[u] = 0.f; v[u] = 0.f; p[u] = 0.f;
-                if (phys[u] >= 0) {
-                    p[u] = use_caught ? d.caught[(int64_t)r * d.caught_stride + d.caught_col + c] : d.p[phys[u]];
-                    if (need_state) { m[u] = d.m[phys[u]]; v[u] = d.v[phys[u]]; }
-                    if (step && in_rows) g[u] = d.rows[(int64_t)r * d.row_stride + d.row_col + c];
-                }
-            }
-            if (need_state) {
-                Hyper hj = h;
-                if (use_caught) {
-                    for (int j = L + 1; j <= target; ++j) {
-#pragma unroll
-                        for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // (wd == 0: p is not read)
-                    }
-                } else {
-                    // A row that has not been seen for ~900 steps has exp_avg at a FIXED POINT of the zero-gradient recurrence
-                    // (0, or a denormal that m * (1 - beta1) no longer moves), and step_size * m / (sqrt(v) / bc2 + eps) -- at most
-                    // step_size * |m| / eps -- is below a quarter ulp of p: from then on a step leaves m and p bit-for-bit alone
-                    // and only multiplies v by beta2.  `settled` lanes take that one-instruction step as long as the bound holds
-                    // for the step's scalar (checked per step: learning rates move), so a gap costs ~40 instructions per element
-                    // for its first ~900 steps and 2 for the rest -- still the same bits as stepping every time.
-                    bool settled = false;
-                    float m_max = 0.f, lim_min = 0.f;
-                    for (int j = L + 1; j <= target; ++j) {      // the zero-gradient steps this row missed, oldest first
-                        if (j >= win0) { hj.step_size = s_hist[2 * (j - win0)]; hj.bc2_sqrt = s_hist[2 * (j - win0) + 1]; }
-                        else { hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1]; }
-                        if (settled && hj.step_size * m_max < lim_min) {
-#pragma unroll
-                            for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // m stays, v *= beta2
-                            continue;
-                        }
-                        bool fixed = h.wd == 0.f && h.eps > 0.f;
-                        m_max = 0.f; lim_min = 3.0e38f;
-#pragma unroll
-                        for (int u = 0; u < ADAM_SEG; ++u) {
-                            if (phys[u] < 0) continue;
-                            const float m_old = m[u];
-                            adam_update(p[u], m[u], v[u], 0.f, hj);
-                            fixed = fixed && m[u] == m_old;
-                            m_max = fmaxf(m_max, fabsf(m_old));
-                            lim_min = fminf(lim_min, h.eps * fabsf(p[u]) * 7.450580596923828e-09f);   // eps |p| 2^-27
-                        }
-                        settled = fixed;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < ADAM_SEG; ++u) {
-                if (phys[u] < 0) continue;
-                if (peek) {
-                    d.caught[(int64_t)r * d.caught_stride + d.caught_col + (cb + 16 * u + c0)] = p[u];
-                    continue;
-                }
-                if (step) adam_update(p[u], m[u], v[u], g[u], h);
-                d.p[phys[u]] = p[u]; d.m[phys[u]] = m[u]; d.v[phys[u]] = v[u];
-            }
+    for (int k = 0; k < TRIPS; ++k) {
+        if (id[k] < 0) continue;
+        row_work<true, LPR>(d, h, x, (int64_t)id[k] - d.item_start, (int)(d.rank_start + q0 + (int64_t)k * GROUPS), 0, tid % LPR);
+    }
+}
+__device__ __forceinline__ void adam_rows_list(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
+    __shared__ float s_hist[2 * ADAM_HWIN];
+    const RowCtx x = row_ctx(d, h, hy, false, s_hist);      // (the step's bookkeeping: adam_list_schedule_kernel)
+    __syncthreads();      // s_hist
+    if (x.sw <= 4) adam_rows_list_t<4>(d, h, x, block_in_group);
+    else adam_rows_list_t<16>(d, h, x, block_in_group);
+}
+
+// Scheduling of the LIST groups (they are the LAST groups of a table), one workgroup before the row kernel: for every LIST group
+// the ranks of its tensor's items -- rank_start = first rank whose Gaussian index is >= item_start, rank_count = ranks below
+// item_start + n (row_ids is increasing; two 64-ary searches by one wave, three dependent loads each for 300k rows) -- and, from
+// the counts, the workgroups each group really needs: first_block of the LIST groups is REWRITTEN here (the host launches an
+// upper bound; surplus workgroups leave after one descriptor load).
+__device__ __forceinline__ int64_t wave_lower_bound(const int32_t *__restrict__ ids, int64_t count, int64_t key) {
+    const int lane = threadIdx.x & 63;
+    int64_t lo = 0, hi = count;          // ids[k] < key for k < lo, ids[k] >= key for k >= hi
+    while (hi > lo) {
+        const int64_t stride = (hi - lo + 63) / 64;
+        const int64_t k = lo + (int64_t)lane * stride;
+        const bool ge = k >= hi || (int64_t)ids[k] >= key;
+        const unsigned long long m = __ballot(ge);
+        const int f = m ? __builtin_ctzll(m) : 64;      // first probe that is >= key (lane 0 probes lo itself)
+        if (f == 0) { hi = lo; break; }
+        const int64_t new_lo = lo + (int64_t)(f - 1) * stride + 1;
+        const int64_t new_hi = f < 64 ? (lo + (int64_t)f * stride < hi ? lo + (int64_t)f * stride : hi) : hi;
+        lo = new_lo; hi = new_hi;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(ADAM_BLOCK) adam_list_schedule_kernel(mtgs_adam_group *__restrict__ table, float *__restrict__ hyper,
+                                                                        int n_groups) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int g = wave; g < n_groups; g += ADAM_BLOCK / 64) {
+        mtgs_adam_group &d = table[g];
+        if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) continue;
+        if (d.mode == MTGS_ADAM_ROWS_STEP && lane == 0) {
+            // the step's bookkeeping (row_ctx does it for SCAN groups): a LIST group may have no workgroup at all -- a node
+            // none of whose Gaussians the frame saw -- and the step still counts
+            float *hy = hyper + 4 * (int64_t)d.hyper_index;
+            const int t_now = reinterpret_cast<const int32_t *>(hy)[2];
+            d.hist[2 * (int64_t)t_now] = hy[0];
+            d.hist[2 * (int64_t)t_now + 1] = hy[1];
+            reinterpret_cast<int32_t *>(hy)[3] = 0;
         }
-        if (c0 == 0 && !peek) d.last[i * T + d.sub_index] = step ? t_now : target;
+        int64_t count = d.n_rows;
+        if (d.row_count_dev) { const int64_t c = *d.row_count_dev >> 32; if (c < count) count = c; }
+        const int64_t a = wave_lower_bound(d.row_ids, count, d.item_start);
+        const int64_t b = wave_lower_bound(d.row_ids, count, d.item_start + d.n);
+        if (lane == 0) { d.rank_start = (int32_t)a; d.rank_count = (int32_t)(b - a); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t next = -1;
+        for (int g = 0; g < n_groups; ++g) {
+            mtgs_adam_group &d = table[g];
+            if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) continue;
+            if (next < 0) next = d.first_block;      // (the first LIST group keeps the host's value)
+            d.first_block = next;
+            next += ((int64_t)d.rank_count + ADAM_LIST_ROWS - 1) / ADAM_LIST_ROWS;
+        }
     }
 }
 
@@ -365,11 +477,16 @@ __global__ void __launch_bounds__(ADAM_BLOCK, MTGS_ADAM_ROWS_WAVES) adam_rows_ke
     const int64_t b = (int64_t)blockIdx.x + block_offset;
     const int gi = find_group(table, n_groups, b);
     const mtgs_adam_group d = table[gi];
+    if (d.row_ids && (b - d.first_block) * ADAM_LIST_ROWS >= d.rank_count) return;      // (LIST: the grid is an upper bound)
     float *hy = hyper + 4 * (int64_t)d.hyper_index;
     Hyper h;
     h.one_minus_b1 = d.one_minus_beta1; h.b2 = d.beta2; h.one_minus_b2 = d.one_minus_beta2;
     h.step_size = hy[0]; h.bc2_sqrt = hy[1]; h.eps = d.eps; h.wd = d.weight_decay; h.gscale = d.grad_scale;
-    adam_rows(d, h, hy, b - d.first_block);
+    if (d.row_ids) {
+        adam_rows_list(d, h, hy, b - d.first_block);
+    } else {
+        adam_rows_scan(d, h, hy, b - d.first_block);
+    }
 }
 
 }  // namespace
@@ -378,8 +495,10 @@ extern "C" int mtgs_adam_group_bytes(void) { return (int)sizeof(mtgs_adam_group)
 extern "C" int mtgs_adam_block_elems(void) { return ADAM_ELEMS; }
 extern "C" int mtgs_adam_block_rows(void) { return ADAM_ROWS; }
 
-extern "C" int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float *hyper, int64_t total_blocks,
-                              int64_t rows_from_block, int nontemporal, void *stream) {
+extern "C" int mtgs_adam_block_list_rows(void) { return ADAM_LIST_ROWS; }
+
+extern "C" int mtgs_adam_step(int n_groups, mtgs_adam_group *table, float *hyper, int64_t total_blocks, int64_t rows_from_block,
+                              int flags, void *stream) {
     MTGS_REQUIRE(n_groups >= 0 && total_blocks >= 0 && rows_from_block >= 0 && rows_from_block <= total_blocks, MTGS_EINVAL,
                  "mtgs_adam_step: bad sizes");
     if (n_groups == 0 || total_blocks == 0) return MTGS_OK;
@@ -387,15 +506,18 @@ extern "C" int mtgs_adam_step(int n_groups, const mtgs_adam_group *table, float 
     MTGS_REQUIRE(((uintptr_t)table & 7) == 0, MTGS_EINVAL, "mtgs_adam_step: table must be 8-byte aligned");
     MTGS_REQUIRE(total_blocks < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_adam_step: more than 2^31 workgroups");
     hipStream_t st = (hipStream_t)stream;
+    const bool nontemporal = flags & 1;
     if (rows_from_block > 0) {
         if (nontemporal)
             hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)rows_from_block), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
         else
             hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)rows_from_block), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
     }
-    if (rows_from_block < total_blocks)
+    if (rows_from_block < total_blocks) {
+        if (flags & 2) hipLaunchKernelGGL(adam_list_schedule_kernel, dim3(1), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
         hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)(total_blocks - rows_from_block)), dim3(ADAM_BLOCK), 0, st, table, hyper,
                            n_groups, rows_from_block);
+    }
     MTGS_CHECK_LAUNCH("mtgs_adam_step");
     return MTGS_OK;
 }

@@ -189,25 +189,27 @@ class ColorSource:
 
     COEF_STRIDE = 52            # floats of a compact coefficient row: dc 3 | dc_add (adapter) 3 | rest 45 | pad
 
-    def prepare(self, vis_rank: Tensor, cap_rows: int) -> Optional[Tensor]:
+    def prepare(self, vis_rank: Tensor, cap_rows: int, vis_ids: Optional[Tensor] = None, totals: Optional[Tensor] = None) -> Optional[Tensor]:
         """Called by the rasterization between its front end and the colour kernel.  With a row-lazy optimizer attached
         (`self.optimizer`, FusedAdam.set_row_lazy): the UP-TO-DATE coefficient rows of the Gaussians the frame sees, as one
         compact buffer [cap_rows, COEF_STRIDE] that the colour kernel reads instead of the parameters (FusedAdam.peek_rows:
         nothing in the optimizer changes) and that apply_to() hands back to the step.  vis_rank int32 [N]: row or -1.
         Returns the buffer, or None (no optimizer: the colour kernel reads the parameters in place)."""
-        self.caught = None
+        self.caught = self.row_ids = None
         if self.optimizer is None:
             return None
         out = torch.empty((max(int(cap_rows), 1), self.COEF_STRIDE), dtype=torch.float32, device=vis_rank.device)
         items = []
         for start, n, dc, adapters, rest, trav in self.node_params:
             ro = vis_rank[start:start + n]
-            items.append((dc, ro, None, 0))
+            rid = None if vis_ids is None else (vis_ids, start, totals)     # (the frame's id list: rows straight from it)
+            items.append((dc, ro, None, 0, rid))
             if adapters is not None:
-                items.append((adapters, ro, trav if adapters.dim() == 3 else None, 3))
+                items.append((adapters, ro, trav if adapters.dim() == 3 else None, 3, rid))
             if rest.shape[-2] > 0:
-                items.append((rest, ro, trav if rest.dim() == 4 else None, 6))
+                items.append((rest, ro, trav if rest.dim() == 4 else None, 6, rid))
         self.optimizer.peek_rows(items, out)
+        self.row_ids = None if vis_ids is None else (vis_ids, totals)
         self.caught = out
         return out
 
@@ -218,15 +220,25 @@ class ColorSource:
         if c is not None and (optimizer is not self.optimizer or c.shape[0] < self.rows.shape[0]):
             c = None     # (the peeked rows belong to the optimizer that made them, numbered like this frame's gradient rows)
         lazy = getattr(optimizer, "_rowlazy", {})
-        ck = lambda p, col: {"caught": (c, col)} if (c is not None and id(p) in lazy) else {}
+        ids = getattr(self, "row_ids", None)
+
+        def ck(p, col, start):
+            kw = {}
+            if id(p) in lazy:
+                if c is not None:
+                    kw["caught"] = (c, col)
+                if ids is not None:
+                    kw["row_ids"] = (ids[0], start, ids[1])
+            return kw
         for start, n, dc, adapters, rest, trav in self.node_params:
             ro = self.row_of[start:start + n]
             if dc.requires_grad:
-                optimizer.set_row_gradient(dc, self.rows, ro, 0, **ck(dc, 0))
+                optimizer.set_row_gradient(dc, self.rows, ro, 0, **ck(dc, 0, start))
             if adapters is not None and adapters.requires_grad:
-                optimizer.set_row_gradient(adapters, self.rows, ro, 0, slice_index=trav if adapters.dim() == 3 else None, **ck(adapters, 3))
+                optimizer.set_row_gradient(adapters, self.rows, ro, 0, slice_index=trav if adapters.dim() == 3 else None,
+                                           **ck(adapters, 3, start))
             if rest.requires_grad and rest.shape[-2] > 0:
-                optimizer.set_row_gradient(rest, self.rows, ro, 3, slice_index=trav if rest.dim() == 4 else None, **ck(rest, 6))
+                optimizer.set_row_gradient(rest, self.rows, ro, 3, slice_index=trav if rest.dim() == 4 else None, **ck(rest, 6, start))
 
     def dense_gradients(self):
         """[(features_dc grad, features_adapters grad | None, features_rest grad)] per node, dense (zeros where no row)."""

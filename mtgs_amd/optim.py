@@ -47,11 +47,11 @@ import torch
 from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
-                   ("last", "<u8"), ("hist", "<u8"), ("caught", "<u8"),
-                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("caught_stride", "<i8"), ("n_rows", "<i8"),
+                   ("last", "<u8"), ("hist", "<u8"), ("row_ids", "<u8"), ("row_count_dev", "<u8"), ("caught", "<u8"),
+                   ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("caught_stride", "<i8"), ("item_start", "<i8"), ("n_rows", "<i8"),
                    ("width", "<i4"), ("row_col", "<i4"),
                    ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
-                   ("hyper_index", "<i4"), ("caught_col", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
+                   ("hyper_index", "<i4"), ("caught_col", "<i4"), ("rank_start", "<i4"), ("rank_count", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
                    ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
 MODE_DENSE, MODE_SLICE, MODE_ROWS_CATCHUP, MODE_ROWS_STEP, MODE_ROWS_FLUSH, MODE_ROWS_PEEK = 0, 1, 2, 3, 4, 5   # MTGS_ADAM_*
 _checked = False
@@ -64,6 +64,28 @@ def _check_layout():
         if want != _GROUP.itemsize:
             raise RuntimeError(f"mtgs_adam_group is {want} bytes in libmtgs_rast.so, {_GROUP.itemsize} in mtgs_amd.optim")
         _checked = True
+
+
+def _list_blocks(groups) -> int:
+    """Upper bound of the workgroups of LIST-form row groups [(item_start, n_rows)] (include/mtgs_rast.h: tensors of one node share
+    their count, the counts of different nodes add up to at most the number of rows)."""
+    if not groups:
+        return 0
+    per = load().mtgs_adam_block_list_rows()
+    per_node = {}
+    for start, _ in groups:
+        per_node[start] = per_node.get(start, 0) + 1
+    return max(per_node.values()) * -(-max(n for _, n in groups) // per) + len(groups)
+
+
+def _check_row_ids(row_ids):
+    if row_ids is None:
+        return None
+    ids, start, count = row_ids
+    if ids.dtype != torch.int32 or ids.dim() != 1 or not ids.is_contiguous() or \
+            (count is not None and (count.dtype != torch.int64 or count.numel() < 1)):
+        raise ValueError("row_ids = (int32 [R] contiguous, start, int64 device scalar | None)")
+    return ids, int(start), count
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -91,13 +113,17 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- gradient source 2 -------------------------------------------------------------------------------------------
     def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0,
-                         slice_index: Optional[int] = None, caught=None) -> None:
+                         slice_index: Optional[int] = None, caught=None, row_ids=None) -> None:
         """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
         Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
         int32 [N].  slice_index = t for a per-traversal tensor `param[N, T, ...]`: only `param[:, t]` takes the row (width =
         elements of one slice), the other traversals get the zero gradient.  `param.grad` is ignored for this parameter.
         caught: row-lazy parameters -- the up-to-date rows peek_rows() left for THIS frame (same row numbering); the step then
-        takes the parameter from them and only replays the moments of the missed steps.  Cleared by step() / zero_grad()."""
+        takes the parameter from them and only replays the moments of the missed steps.
+        row_ids = (ids int32 [R] increasing, start, count | None): row-lazy parameters -- the frame's list of visible Gaussians
+        (global index of every rank; this parameter's items are start .. start + N - 1; count: device int64 whose upper half is
+        the number of valid ranks, mtgs_front_fwd's totals).  With it the rows are taken straight from the list (2-3x faster
+        than scanning the row map).  Cleared by step() / zero_grad()."""
         width = param.numel() // max(param.shape[0], 1) if param.dim() else 1
         sub_w, sub_i = 0, 0
         if slice_index is not None:
@@ -114,7 +140,7 @@ class FusedAdam(torch.optim.Optimizer):
             if cb.dtype != torch.float32 or cb.dim() != 2 or cb.stride(1) != 1 or cb.shape[0] < rows.shape[0] or \
                     cc < 0 or cc + (sub_w or width) > cb.shape[1]:
                 raise ValueError("set_row_gradient: caught = (float32 [R' >= R, stride], column)")
-        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught)
+        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids))
 
     def zero_grad(self, set_to_none: bool = True):
         self._rows.clear()
@@ -225,6 +251,7 @@ class FusedAdam(torch.optim.Optimizer):
         for it in items:
             RL, ro, t = it[0], it[1], it[2]
             col = it[3] if len(it) > 3 else 0
+            rid = _check_row_ids(it[4]) if len(it) > 4 else None
             lazy = isinstance(RL, dict)
             p = RL["param"] if lazy else RL
             st = self.state.get(p) if lazy else None
@@ -232,7 +259,7 @@ class FusedAdam(torch.optim.Optimizer):
             if not stateful:
                 if mode != MODE_ROWS_PEEK:
                     continue                   # no step taken yet: nothing to catch up
-                recs.append((p, None, None, ro, t, 0, 0, col))
+                recs.append((p, None, None, ro, t, 0, 0, col, rid))
                 continue
             target = self._rows_target(p)
             hi = self._hyper_index.get(id(p))
@@ -240,12 +267,14 @@ class FusedAdam(torch.optim.Optimizer):
                 if target < 0:
                     raise RuntimeError("FusedAdam: a row-lazy parameter that the captured step does not update")
                 hi = 0                         # (explicit target: the hyper row is not read)
-            recs.append((p, RL, st, ro, t, target, hi, col))
+            recs.append((p, RL, st, ro, t, target, hi, col, rid))
         if not recs:
             return None
+        recs.sort(key=lambda rec: rec[8] is not None and mode != MODE_ROWS_FLUSH)      # (stable: LIST-form groups last)
         tab = np.zeros(len(recs), _GROUP)
         fb = 0
-        for i, (p, RL, st, ro, t, target, hi, col) in enumerate(recs):
+        lists = []
+        for i, (p, RL, st, ro, t, target, hi, col, rid) in enumerate(recs):
             grp = next((g for g in self.param_groups if any(q is p for q in g["params"])),
                        {"betas": (0.0, 0.0), "eps": 0.0, "weight_decay": 0.0})      # (a tensor of another optimizer: copied)
             N = p.shape[0]
@@ -268,32 +297,42 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = grp["betas"]
             r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2
             r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
-            fb += -(-N // per_block)
-        return tab, fb
+            if rid is not None and mode != MODE_ROWS_FLUSH:
+                ids, start, count = rid
+                cap = out.shape[0] if out is not None else ids.numel()
+                r["row_ids"], r["item_start"], r["n_rows"] = ids.data_ptr(), start, min(cap, ids.numel())
+                r["row_count_dev"] = 0 if count is None else count.data_ptr()
+                lists.append((start, int(r["n_rows"])))
+            else:
+                fb += -(-N // per_block)
+        return tab, fb + _list_blocks(lists), bool(lists)
 
     def catch_up_rows(self, items) -> None:
-        """items: [(param, row_of int32 [N], slice | None)] -- the rows with row_of >= 0 of every row-lazy parameter among them
+        """items: [(param, row_of int32 [N], slice | None[, row_ids])] -- the rows with row_of >= 0 of every row-lazy parameter among them
         are brought up to date (the zero-gradient steps since they were last touched), one launch.  Called by the forward
         between the front end (which knows the visible Gaussians) and the kernel that reads their coefficients."""
         todo = []
-        for p, ro, t in items:
+        for it in items:
+            p, ro, t = it[0], it[1], it[2]
             RL = self._rowlazy.get(id(p))
             if RL is not None:
                 if RL["T"] > 1 and t is None:
                     raise ValueError("catch_up_rows: a per-traversal parameter needs its slice")
-                todo.append((RL, ro, 0 if t is None else int(t)))
+                todo.append((RL, ro, 0 if t is None else int(t), 0, it[3] if len(it) > 3 else None))
         built = self._rows_groups(todo, MODE_ROWS_CATCHUP)
         if built is None:
             return
-        tab, blocks = built
+        tab, blocks, any_list = built
         key = tab.tobytes()
         if key != self._catch_key or torch.cuda.is_current_stream_capturing():
             from .nodes import upload_table
             self._catch_table, self._catch_key = upload_table(tab, todo[0][0]["param"].device), key
-        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, 0, stream_of(todo[0][0]["param"]))
+        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, 2 if any_list else 0,
+             stream_of(todo[0][0]["param"]))
 
     def peek_rows(self, items, out: torch.Tensor) -> None:
-        """items: [(param, row_of int32 [N], slice | None, column)] -- for every Gaussian with row_of[n] = r >= 0 the UP-TO-DATE row
+        """items: [(param, row_of int32 [N], slice | None, column[, row_ids])] (row_ids as in set_row_gradient: the fast LIST form)
+        -- for every Gaussian with row_of[n] = r >= 0 the UP-TO-DATE row
         of the parameter (its slice) is written to out[r, column : column + width]: row-lazy parameters are caught up in
         registers (nothing in the optimizer changes: a forward stays free of side effects), other tensors are copied.  `out`
         float32 [R, stride]; ranks >= R are skipped.  One launch.  Hand `out` back through set_row_gradient(caught=...) and
@@ -301,15 +340,16 @@ class FusedAdam(torch.optim.Optimizer):
         if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
             raise ValueError("peek_rows: out float32 [R, stride]")
         todo = []
-        for p, ro, t, col in items:
+        for it in items:
+            p, ro, t, col = it[0], it[1], it[2], it[3]
             RL = self._rowlazy.get(id(p))
             if RL is not None and RL["T"] > 1 and t is None:
                 raise ValueError("peek_rows: a per-traversal parameter needs its slice")
-            todo.append((RL if RL is not None else p, ro, t, int(col)))
+            todo.append((RL if RL is not None else p, ro, t, int(col), it[4] if len(it) > 4 else None))
         built = self._rows_groups(todo, MODE_ROWS_PEEK, out)
         if built is None:
             return
-        tab, blocks = built
+        tab, blocks, any_list = built
         dev = out.device
         hyper = self._hyper_dev if self._hyper_dev is not None else torch.zeros(4, dtype=torch.float32, device=dev)
         key = tab.tobytes()
@@ -317,14 +357,14 @@ class FusedAdam(torch.optim.Optimizer):
             from .nodes import upload_table
             self._catch_table, self._catch_key = upload_table(tab, dev), key
         self._peek_keep = (out, hyper)
-        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(hyper), blocks, 0, 0, stream_of(out))
+        call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(hyper), blocks, 0, 2 if any_list else 0, stream_of(out))
 
     def _flush_rows(self) -> None:
         items = [(RL, None, t) for RL in self._rowlazy.values() for t in range(RL["T"])]
         built = self._rows_groups(items, MODE_ROWS_FLUSH)
         if built is None:
             return
-        tab, blocks = built
+        tab, blocks, _ = built
         from .nodes import upload_table
         dev = items[0][0]["param"].device
         call("mtgs_adam_step", len(tab), ptr(upload_table(tab, dev)), ptr(self._hyper_dev), blocks, 0, 0, stream_of(items[0][0]["param"]))
@@ -380,8 +420,13 @@ class FusedAdam(torch.optim.Optimizer):
         keep = []
         # table order: the row-lazy tensors last (they run as a second kernel, mtgs_adam_step's rows_from_block); the device
         # scalars stay indexed by the position in `act` (hyper_index)
-        order = sorted(range(len(act)), key=lambda i: id(act[i][1]) in self._rowlazy)
+        def rank(i):      # streaming groups, then row groups found through the row map, then row groups with an id list
+            p, src = act[i][1], act[i][4]
+            return 0 if id(p) not in self._rowlazy else (2 if (src is not None and src[8] is not None) else 1)
+        order = sorted(range(len(act)), key=rank)
         self._rows_from = None
+        self._list_groups = False
+        lists = []
         for j, i in enumerate(order):
             gi, p, st, g, src = act[i]
             grp = self.param_groups[gi]
@@ -398,7 +443,7 @@ class FusedAdam(torch.optim.Optimizer):
                 align |= g.data_ptr()
                 keep.append(g)
             elif src is not None:
-                rows, row_of, col, stride, width, sub_w, sub_i, caught = src
+                rows, row_of, col, stride, width, sub_w, sub_i, caught, rid = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 r["n_rows"] = rows.shape[0]
                 r["sub_width"], r["sub_index"] = sub_w, sub_i
@@ -415,7 +460,15 @@ class FusedAdam(torch.optim.Optimizer):
                 if src[7] is not None and grp["weight_decay"] == 0:
                     r["caught"], r["caught_stride"], r["caught_col"] = src[7][0].data_ptr(), src[7][0].stride(0), int(src[7][1])
                     keep.append(src[7][0])
-                fb += -(-int(p.shape[0]) // load().mtgs_adam_block_rows())
+                if src[8] is not None:       # LIST form: one row per 16 lanes straight from the frame's list of visible Gaussians
+                    ids, start, count = src[8]
+                    r["row_ids"], r["item_start"] = ids.data_ptr(), start
+                    r["row_count_dev"] = 0 if count is None else count.data_ptr()
+                    lists.append((start, min(int(rows.shape[0]), int(ids.numel()))))     # (workgroups: assigned on the device)
+                    keep.append((ids, count))
+                    self._list_groups = True
+                else:
+                    fb += -(-int(p.shape[0]) // load().mtgs_adam_block_rows())
                 b1, b2 = grp["betas"]
                 r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2
                 r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale
@@ -440,9 +493,10 @@ class FusedAdam(torch.optim.Optimizer):
             dev = act[0][1].device
             self._table_dev = upload_table(tab, dev)
             self._table_key = key
-        self._blocks = fb
         if self._rows_from is None:
             self._rows_from = fb
+        fb += _list_blocks(lists)
+        self._blocks = fb
         self._keep = keep
         return self._table_dev
 
@@ -513,8 +567,8 @@ class FusedAdam(torch.optim.Optimizer):
             # (pinned allocation is not permitted while capturing, and the step count must not advance at capture time)
             raise RuntimeError("FusedAdam: run one eager step() before capturing one (state and device buffers are created there)")
         table = self._table(act)
-        call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, self._rows_from, int(self.nontemporal),
-             stream_of(act[0][1]))
+        call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, self._rows_from,
+             int(self.nontemporal) | (2 if self._list_groups else 0), stream_of(act[0][1]))
         self._rows.clear()
         self._active_slice.clear()
         self._pending_host = False

@@ -611,7 +611,7 @@ class _FusedRasterization(torch.autograd.Function):
                      (1 if dp is not None else 0) if cs is None else 2, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 if cs is not None:   # colours of the visible Gaussians, straight into their records
-                    coef = cs.prepare(vis_rank, cap_vis)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
+                    coef = cs.prepare(vis_rank, cap_vis, b["vis_ids"], totals)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
                     call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
                          ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), ptr(coef), 0 if coef is None else coef.stride(0), st)
                 b["mailbox"], b["tag"] = mailbox, tag

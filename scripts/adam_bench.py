@@ -96,11 +96,12 @@ def main():
         T = args.traversals
         Pc = {"dc": torch.randn(N, 3, device=dev, generator=g), "ad": torch.randn(N, T, 3, device=dev, generator=g),
               "rest": torch.randn(N, T, 15, 3, device=dev, generator=g)}
-        for variant in ("rows (every row, every traversal)", "row-lazy", "row-lazy, peek + caught"):
+        for variant in ("rows (every row, every traversal)", "row-lazy", "row-lazy, peek + caught", "row-lazy, id list, peek + caught"):
             P = {k: v.clone().requires_grad_(True) for k, v in Pc.items()}
             opt = FusedAdam([{"params": [P["dc"], P["ad"]], "lr": 0.0025}, {"params": [P["rest"]], "lr": 0.0025 / 20}], eps=1e-15)
             lazy = variant.startswith("row-lazy")
             peek = variant.endswith("caught")
+            lst = "id list" in variant
             if lazy:
                 opt.set_row_lazy(P["dc"]); opt.set_row_lazy(P["ad"], traversals=T); opt.set_row_lazy(P["rest"], traversals=T)
             frames = []
@@ -112,17 +113,19 @@ def main():
                 n_vis = int(vis.sum())
                 row_of = torch.full((N,), -1, dtype=torch.int32, device=dev)
                 row_of[vis] = torch.arange(n_vis, dtype=torch.int32, device=dev)
-                frames.append((row_of, torch.randn(n_vis, 48, device=dev, generator=g) * 0.01, n_vis))
+                frames.append((row_of, torch.randn(n_vis, 48, device=dev, generator=g) * 0.01, n_vis,
+                               torch.nonzero(vis).reshape(-1).to(torch.int32)))
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.reps + 8)]
             for i in range(args.reps + 8):
-                row_of, rows, n_vis = frames[i % 8]
+                row_of, rows, n_vis, ids = frames[i % 8]
                 t = i % T
                 ev[i][0].record()
                 ck = lambda col: {}
+                rid = ((ids, 0, None),) if lst else ()
                 if peek:
                     Cb = torch.empty(n_vis, 52, device=dev)
-                    opt.peek_rows([(P["dc"], row_of, None, 0), (P["ad"], row_of, t, 3), (P["rest"], row_of, t, 6)], Cb)
-                    ck = lambda col: {"caught": (Cb, col)}
+                    opt.peek_rows([(P["dc"], row_of, None, 0) + rid, (P["ad"], row_of, t, 3) + rid, (P["rest"], row_of, t, 6) + rid], Cb)
+                    ck = lambda col: {"caught": (Cb, col), **({"row_ids": (ids, 0, None)} if lst else {})}
                 elif lazy:
                     opt.catch_up_rows([(P["dc"], row_of, None), (P["ad"], row_of, t), (P["rest"], row_of, t)])
                 ev[i][1].record()

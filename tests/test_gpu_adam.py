@@ -542,3 +542,65 @@ def test_row_lazy_peek_leaves_the_optimizer_alone_and_feeds_the_step(hip_lib):
         assert torch.equal(Pa[k], Pb[k]), k                                                  # (4)
         assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), k
         assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
+
+
+def test_row_lazy_list_form_equals_scan_form_over_two_nodes(hip_lib):
+    """The LIST form (rows straight from the frame's list of visible Gaussians: `row_ids`, one row per 16 lanes) against the
+    SCAN form (row map only) for two nodes that share one id list -- peek, caught step, in-place catch-up, a device-side row
+    count smaller than the buffers, an empty node range: bit-identical parameters, moments and peeked rows."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    N1, N2, T = 1800, 700, 2
+    N = N1 + N2
+    g = torch.Generator().manual_seed(23)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.2)
+    base = {"dc1": mk(N1, 3), "rest1": mk(N1, T, 15, 3), "dc2": mk(N2, 3), "rest2": mk(N2, 15, 3)}
+
+    def make():
+        P = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        o = FusedAdam([{"params": [P["dc1"], P["dc2"]], "lr": 3e-3}, {"params": [P["rest1"], P["rest2"]], "lr": 1e-2}], eps=1e-15)
+        o.set_row_lazy(P["dc1"]); o.set_row_lazy(P["dc2"]); o.set_row_lazy(P["rest1"], traversals=T); o.set_row_lazy(P["rest2"])
+        return P, o
+    Ps, os_ = make()
+    Pl, ol = make()
+    for step in range(12):
+        t = step % T
+        frac = 0.25 if step % 5 else 0.05
+        vis = torch.rand(N, generator=g) < frac
+        if step == 7:
+            vis[N1:] = False                                   # nothing of the second node is visible
+        ids = torch.nonzero(vis).reshape(-1).to(torch.int32)
+        n_vis = ids.numel()
+        cap = n_vis + 37                                       # buffers larger than the count (graph mode)
+        row_of = torch.full((N,), -1, dtype=torch.int32)
+        row_of[vis] = torch.arange(n_vis, dtype=torch.int32)
+        ids_d = torch.cat([ids, torch.full((37,), 2 ** 30, dtype=torch.int32)]).to(dev)      # garbage beyond the count
+        row_of, rows = row_of.to(dev), (torch.randn(cap, 48, generator=g) * 0.01).to(dev)
+        totals = torch.tensor([(n_vis << 32) | 5], dtype=torch.int64, device=dev)
+        outs = []
+        for P, o, lst in ((Ps, os_, False), (Pl, ol, True)):
+            for grp in o.param_groups:
+                grp["lr"] = grp["lr"] * 0.97
+            rid = lambda start: ((ids_d, start, totals),) if lst else ()
+            C = torch.zeros(cap, 52, device=dev)
+            if step % 3 == 2:      # the in-place form
+                o.catch_up_rows([(P["dc1"], row_of[:N1], None) + rid(0), (P["rest1"], row_of[:N1], t) + rid(0),
+                                 (P["dc2"], row_of[N1:], None) + rid(N1), (P["rest2"], row_of[N1:], None) + rid(N1)])
+                ck = lambda col: {}
+            else:
+                o.peek_rows([(P["dc1"], row_of[:N1], None, 0) + rid(0), (P["rest1"], row_of[:N1], t, 6) + rid(0),
+                             (P["dc2"], row_of[N1:], None, 0) + rid(N1), (P["rest2"], row_of[N1:], None, 6) + rid(N1)], C)
+                ck = lambda col: {"caught": (C, col)}
+            kw = lambda start: ({"row_ids": (ids_d, start, totals)} if lst else {})
+            o.set_row_gradient(P["dc1"], rows, row_of[:N1], 0, **ck(0), **kw(0))
+            o.set_row_gradient(P["rest1"], rows, row_of[:N1], 3, slice_index=t, **ck(6), **kw(0))
+            o.set_row_gradient(P["dc2"], rows, row_of[N1:], 0, **ck(0), **kw(N1))
+            o.set_row_gradient(P["rest2"], rows, row_of[N1:], 3, **ck(6), **kw(N1))
+            o.step()
+            outs.append(C[:n_vis].clone())
+        assert torch.equal(outs[0], outs[1]), step
+        for k in base:
+            assert torch.equal(Ps[k], Pl[k]), (step, k)
+    os_.flush(); ol.flush()
+    for k in base:
+        assert torch.equal(Ps[k], Pl[k]) and torch.equal(os_.state[Ps[k]]["exp_avg_sq"], ol.state[Pl[k]]["exp_avg_sq"]), k
