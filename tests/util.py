@@ -262,3 +262,32 @@ def same_refinements(x, y, count):
     gradients; the compositing atomics have no fixed order at all) refine alike -- except that a Gaussian whose statistic sits
     within rounding of a threshold may fall on either side: at most one in 10^4 (and never fewer than 2 allowed)."""
     return len(x) == len(y) == count and all(abs(p - q) <= max(2, q // 10000) for a, b in zip(x, y) for p, q in zip(a, b))
+
+
+def assert_same_curve(a, b, rel=2e-3, floor=1e-3):
+    """Two loss curves of the same job (summation orders differ): element-wise within `rel` of max(|b|, floor)."""
+    assert len(a) == len(b), (len(a), len(b))
+    worst = max(range(len(a)), key=lambda i: abs(a[i] - b[i]) / max(abs(b[i]), floor)) if a else 0
+    bad = [i for i in range(len(a)) if abs(a[i] - b[i]) > rel * max(abs(b[i]), floor)]
+    assert not bad, (f"{len(bad)} of {len(a)} points differ by more than {rel:g}; worst at {worst}: {a[worst]!r} vs {b[worst]!r}", a, b)
+
+
+def assert_same_training(out_a, out_b, n_refinements, steps, refine_every, rel=2e-3, loose=0.15):
+    """Two runs of scripts/mtgs_like_train.py that are the same job up to the order of floating-point sums (ranks vs
+    accumulation, compact vs dense gradients; the compositing atomics have no fixed order even between two runs of ONE
+    configuration): same refinements (same_refinements) and the same loss curve -- to `rel` up to the first refinement at which
+    a threshold-critical Gaussian went the other way (sizes differ by a few), and only to `loose` after it: from there the two
+    runs are different, equally valid trainings (observed: 2 000 000 -> 2 015 797 vs 2 015 795 between two runs of the same
+    command, and 3 % on the last curve point)."""
+    import re
+    sa, sb = refinement_sizes(out_a), refinement_sizes(out_b)
+    assert same_refinements(sa, sb, n_refinements), (sa, sb)
+    curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
+    a, b = curve(out_a), curve(out_b)
+    assert len(a) == len(b), (a, b)
+    differ = [i for i, (x, y) in enumerate(zip(sa, sb)) if x != y]
+    cut = (differ[0] + 1) * refine_every if differ else steps          # steps before `cut` saw identical Gaussian sets
+    k = max(1, steps // 8)                                             # (one curve point = the mean over k steps)
+    for j, (x, y) in enumerate(zip(a, b)):
+        tol = rel if (j + 1) * k <= cut else loose
+        assert abs(x - y) <= tol * max(abs(y), 1e-3), (j, x, y, tol, sa, sb, a, b)
