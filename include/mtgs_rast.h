@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 16
+#define MTGS_RAST_ABI_VERSION 17
 
 enum {
     MTGS_OK = 0,
@@ -95,7 +95,9 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * with grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank).  With them (and C == 1) the
  * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced.
  * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals; the number of rows is then min(n_vis, *n_vis_dev >> 32)
- * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count). */
+ * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count).
+ * x_quat_rows[n_vis, 4] (nullable, compact path only, 16-byte aligned): quaternion gradients of the visible Gaussians that did
+ * not come through the projection -- the camera-space normals' (mtgs_normals_bwd_qrows) -- added to v_quats. */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
@@ -111,7 +113,8 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
                      const float *x_means2d_abs, const float *x_colors, int x_channels,
                      const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
-                     const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev, void *stream);
+                     const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
+                     const float *x_quat_rows, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -295,6 +298,9 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  * mtgs_blend_fwd_packed / mtgs_blend_bwd_packed: mtgs_blend_fwd / _bwd reading the records through rank_ids.
  * grad_rows[n_vis, row_stride] f32 (zeroed by the caller): [xy 2 | |xy| 2 (absgrad) | conic 3 | opacity 1 | colours D |
  * depth 1 | pad], accumulated with atomics, one 64-byte line per visible pair for row_stride = 16. */
+/* mtgs_front_fwd color_mode: 0 = `colors` as they are; 1 = clamp(colors[:3] + 0.5, 0, 1) (MTGS's activation on raw SH, data-parallel
+ * exchange); 2 = channels 0..2 of the records are left open for mtgs_vis_color_fwd and `colors` holds the other D - 3; 3 = channels
+ * 0..5 are left open (colours, then the camera-space normals: mtgs_normals_fwd_rows) and `colors` holds the other D - 6. */
 int mtgs_front_workspace_bytes(int64_t total_pairs, size_t *bytes);
 int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                    const float *viewmats, const float *Ks, int width, int height, float eps2d, float near_plane,
@@ -478,6 +484,15 @@ int mtgs_normals_bwd(int64_t N, const float *quats, const float *scales, const f
 int mtgs_normals_bwd_rows(int64_t n_vis, const int32_t *vis_ids, const float *quats, const float *scales, const float *means,
                           const float *c2w, const float *grad_rows, int64_t row_stride, int col, float *wire_rows,
                           void *stream);
+/* Visibility first (one process): the normals of the VISIBLE Gaussians only.  fwd_rows: the camera-space normal of Gaussian
+ * vis_ids[r] goes into channels `channel` .. + 2 of its record (mtgs_front_fwd color_mode 3 left them open), r < min(cap_vis,
+ * *totals >> 32) (totals nullable: cap_vis rows).  bwd_qrows: quat_rows[r, 4] = the quaternion gradient from v_normal =
+ * grad_rows[r, col .. col + 2], handed to mtgs_project_bwd as x_quat_rows.  No [N, 3] normal tensor and no dense gradient of it. */
+int mtgs_normals_fwd_rows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats, const float *scales,
+                          const float *means, const float *c2w, float *recs, int channel, void *stream);
+int mtgs_normals_bwd_qrows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats, const float *scales,
+                           const float *means, const float *c2w, const float *grad_rows, int64_t row_stride, int col,
+                           float *quat_rows, void *stream);
 
 /* ---- densification statistics of one node in one launch ------------------------------
  * mtgs_scene_graph.py:1157-1183 + vanilla_gaussian_splatting.py:448-474: for the n Gaussians of a node (a contiguous

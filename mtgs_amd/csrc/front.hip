@@ -172,10 +172,11 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                 float ch[REC_MAX_CHANNELS];
 #pragma unroll
                 for (int k = 0; k < REC_MAX_CHANNELS; ++k) ch[k] = 0.f;
-                if (a.color_mode == 2) {   // channels 0..2 are filled later (viscolor.hip); `colors` holds channels 3 .. DC - 1
+                if (a.color_mode >= 2) {   // channels 0..2 (mode 3: 0..5, the camera-space normals too) are filled later for the
+                    const int open = a.color_mode == 3 ? 6 : 3;   // visible Gaussians (viscolor.hip, normals.hip); `colors` = the rest
 #pragma unroll
                     for (int k = 3; k < REC_MAX_CHANNELS; ++k)
-                        if (k < a.DC) ch[k] = a.colors[idx * (a.DC - 3) + (k - 3)];
+                        if (k >= open && k < a.DC) ch[k] = a.colors[idx * (a.DC - open) + (k - open)];
                 } else {
 #pragma unroll
                     for (int k = 0; k < REC_MAX_CHANNELS; ++k)
@@ -268,12 +269,13 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
         return MTGS_OK;
     }
     MTGS_REQUIRE(total < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_front_fwd: C*N must fit int32 (flatten_ids are int32)");
-    MTGS_REQUIRE(means && quats && scales && viewmats && Ks && opacities && (colors || D == 0 || (color_mode == 2 && D == 3)) && radii && means2d &&
+    MTGS_REQUIRE(means && quats && scales && viewmats && Ks && opacities &&
+                     (colors || D == 0 || (color_mode == 2 && D == 3) || (color_mode == 3 && D == 6)) && radii && means2d &&
                      depths && conics && opac_eff && tiles_per_gauss && recs && vis_ids && vis_keys &&
                      vis_rank && ws,
                  MTGS_EINVAL, "mtgs_front_fwd: null pointer");
     MTGS_REQUIRE(!dp_words == !dp_prefix, MTGS_EINVAL, "mtgs_front_fwd: dp_words and dp_prefix go together");
-    MTGS_REQUIRE(color_mode == 0 || ((color_mode == 1 || color_mode == 2) && D >= 3), MTGS_EINVAL,
+    MTGS_REQUIRE(color_mode == 0 || ((color_mode == 1 || color_mode == 2) && D >= 3) || (color_mode == 3 && D >= 6), MTGS_EINVAL,
                  "mtgs_front_fwd: color_mode=%d with %d channels", color_mode, D);
     MTGS_REQUIRE(ws_bytes >= front_ws_bytes(total), MTGS_EWORKSPACE, "mtgs_front_fwd: workspace %zu < %zu bytes", ws_bytes,
                  front_ws_bytes(total));

@@ -14,6 +14,7 @@
 // tensor (and copy rgbs into columns 0..2), so there is no cat either.  Only `quats` receives a gradient.
 // Roofline: HBM; N * (40 + 12) B forward (+ 24 B with the rgbs copy), N * (40 + 12 + 16) B backward.
 #include "common.hpp"
+#include "raster_rec.hpp"
 
 namespace {
 struct F3 { float x, y, z; };
@@ -128,7 +129,73 @@ __global__ __launch_bounds__(256) void normals_bwd_rows_kernel(int64_t n_vis, co
     float *w = wire + r * 16 + 3;
     w[0] += o.x; w[1] += o.y; w[2] += o.z; w[3] += o.w;
 }
+// Visibility first (single process): the normals of the VISIBLE Gaussians only, straight into their records (channels
+// `channel` .. + 2; mtgs_front_fwd color_mode 3 left them open), and their backward as rows [n_vis, 4] of quaternion
+// gradients that mtgs_project_bwd adds to its own (x_quat_rows) -- no [N, 3] normal tensor, no dense gradient of it.
+__global__ __launch_bounds__(256) void normals_fwd_rows_kernel(int64_t cap_vis, const int32_t *__restrict__ vis_ids,
+                                                               const int64_t *__restrict__ totals, const float *__restrict__ quats,
+                                                               const float *__restrict__ scales, const float *__restrict__ means,
+                                                               const float *__restrict__ c2w, float *__restrict__ recs, int channel) {
+    int64_t n_vis = totals ? *totals >> 32 : cap_vis;
+    if (n_vis > cap_vis) n_vis = cap_vis;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_vis) return;
+    const int64_t i = vis_ids[r];
+    const F4 q = *reinterpret_cast<const F4 *>(quats + i * 4);
+    const F3 s = *reinterpret_cast<const F3 *>(scales + i * 3);
+    const F3 m = *reinterpret_cast<const F3 *>(means + i * 3);
+    const NormalGeom g = geometry(q, s, m, c2w);
+    const float nx = g.sign * g.n0.x, ny = g.sign * g.n0.y, nz = g.sign * g.n0.z;
+    float *dst = recs + r * REC_FLOATS + 8 + channel;
+    dst[0] = (nx * c2w[0] + ny * c2w[4]) + nz * c2w[8];
+    dst[1] = (nx * c2w[1] + ny * c2w[5]) + nz * c2w[9];
+    dst[2] = (nx * c2w[2] + ny * c2w[6]) + nz * c2w[10];
+}
+__global__ __launch_bounds__(256) void normals_bwd_qrows_kernel(int64_t cap_vis, const int32_t *__restrict__ vis_ids,
+                                                                const int64_t *__restrict__ totals, const float *__restrict__ quats,
+                                                                const float *__restrict__ scales, const float *__restrict__ means,
+                                                                const float *__restrict__ c2w, const float *__restrict__ G,
+                                                                int64_t row_stride, int col, float *__restrict__ qrows) {
+    int64_t n_vis = totals ? *totals >> 32 : cap_vis;
+    if (n_vis > cap_vis) n_vis = cap_vis;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_vis) return;
+    const int64_t i = vis_ids[r];
+    const F4 q = *reinterpret_cast<const F4 *>(quats + i * 4);
+    const F3 s = *reinterpret_cast<const F3 *>(scales + i * 3);
+    const F3 m = *reinterpret_cast<const F3 *>(means + i * 3);
+    const NormalGeom g = geometry(q, s, m, c2w);
+    const F3 v = F3{G[r * row_stride + col], G[r * row_stride + col + 1], G[r * row_stride + col + 2]};
+    *reinterpret_cast<F4 *>(qrows + r * 4) = normal_vjp(q, g, v, c2w);
+}
 }  // namespace
+
+extern "C" int mtgs_normals_fwd_rows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats,
+                                     const float *scales, const float *means, const float *c2w, float *recs, int channel,
+                                     void *stream) {
+    MTGS_REQUIRE(cap_vis >= 0 && channel >= 0 && channel + 3 <= REC_MAX_CHANNELS, MTGS_EINVAL, "mtgs_normals_fwd_rows: bad sizes");
+    if (cap_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(vis_ids && quats && scales && means && c2w && recs, MTGS_EINVAL, "mtgs_normals_fwd_rows: null pointer");
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(quats) & 15) == 0, MTGS_EINVAL, "mtgs_normals_fwd_rows: quats must be 16-byte aligned");
+    normals_fwd_rows_kernel<<<(unsigned)ceil_div64(cap_vis, 256), 256, 0, (hipStream_t)stream>>>(cap_vis, vis_ids, totals, quats, scales,
+                                                                                                 means, c2w, recs, channel);
+    MTGS_CHECK_LAUNCH("mtgs_normals_fwd_rows");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_normals_bwd_qrows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats,
+                                      const float *scales, const float *means, const float *c2w, const float *grad_rows,
+                                      int64_t row_stride, int col, float *quat_rows, void *stream) {
+    MTGS_REQUIRE(cap_vis >= 0 && col >= 0 && row_stride >= col + 3, MTGS_EINVAL, "mtgs_normals_bwd_qrows: bad sizes");
+    if (cap_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(vis_ids && quats && scales && means && c2w && grad_rows && quat_rows, MTGS_EINVAL, "mtgs_normals_bwd_qrows: null pointer");
+    MTGS_REQUIRE(((reinterpret_cast<uintptr_t>(quats) | reinterpret_cast<uintptr_t>(quat_rows)) & 15) == 0, MTGS_EINVAL,
+                 "mtgs_normals_bwd_qrows: quats / quat_rows must be 16-byte aligned");
+    normals_bwd_qrows_kernel<<<(unsigned)ceil_div64(cap_vis, 256), 256, 0, (hipStream_t)stream>>>(
+        cap_vis, vis_ids, totals, quats, scales, means, c2w, grad_rows, row_stride, col, quat_rows);
+    MTGS_CHECK_LAUNCH("mtgs_normals_bwd_qrows");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_normals_bwd_rows(int64_t n_vis, const int32_t *vis_ids, const float *quats, const float *scales,
                                      const float *means, const float *c2w, const float *grad_rows, int64_t row_stride, int col,

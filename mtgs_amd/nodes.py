@@ -184,6 +184,8 @@ class ColorSource:
         self.node_params = node_params     # per node: (start, n, features_dc, features_adapters | None, features_rest, traversal | None)
         self.rows = self.row_of = None
         self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
+        self.camera_normals = None   # camera_to_world [3,4] (device): the rasterization adds MTGS's three camera-space normal channels
+        #                              (mtgs_scene_graph.py:526-545, 636-638) after the colours, computed for the VISIBLE Gaussians only
         self.optimizer = None   # a FusedAdam with row-lazy colour parameters: prepare() peeks the visible rows for the colour kernel
         self.caught = None
 

@@ -54,7 +54,8 @@ def rasterization(
 
     color_source (extension, not in gsplat's signature; mtgs_amd.nodes.ColorSource from collect_gaussians(...,
     deferred_colors=True)): the RGB channels are evaluated from the nodes' SH coefficients for the VISIBLE Gaussians only;
-    `colors` then holds the other colour channels ([N, DX], e.g. camera-space normals) or is None.
+    `colors` then holds the other colour channels ([N, DX]) or is None; with `color_source.camera_normals = camera_to_world[3,4]`
+    MTGS's three camera-space normal channels follow the colours, likewise computed for the visible Gaussians only.
     """
     meta: Dict = {}
     N = means.shape[0]

@@ -142,7 +142,7 @@ class _FullyFusedProjection(torch.autograd.Function):
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
-             None, 0, None, None, stream_of(means))
+             None, 0, None, None, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -544,7 +544,9 @@ class _FusedRasterization(torch.autograd.Function):
         dev, st = means.device, stream_of(means)
         tile_size = 16
         tw, th = -(-width // tile_size), -(-height // tile_size)
-        DC = (0 if col is None else col.shape[-1]) + (3 if cs is not None else 0)
+        n2c = getattr(cs, "camera_normals", None) if cs is not None else None     # [3,4] camera_to_world: three normal channels
+        c_open = 0 if cs is None else (6 if n2c is not None else 3)                 # channels filled for the visible Gaussians
+        DC = (0 if col is None else col.shape[-1]) + c_open
         DT = DC + int(with_depth)
         ed = bool(expected_depth)
         total = Cn * N
@@ -608,12 +610,16 @@ class _FusedRasterization(torch.autograd.Function):
                      ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(opac_eff), tile_size, tw, th,
                      ptr(tiles_per_gauss), ptr(b["recs"]), ptr(b["vis_ids"]), ptr(b["vis_keys"]),
                      ptr(vis_rank), cap_vis, *(dpf.front_pointers() if dpf is not None else (None, None, None)),
-                     (1 if dp is not None else 0) if cs is None else 2, ptr(totals), None if mailbox is None else mailbox.data_ptr(), tag,
+                     (1 if dp is not None else 0) if cs is None else (3 if c_open == 6 else 2), ptr(totals),
+                     None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
                 if cs is not None:   # colours of the visible Gaussians, straight into their records
                     coef = cs.prepare(vis_rank, cap_vis, b["vis_ids"], totals)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
                     call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
                          ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), ptr(coef), 0 if coef is None else coef.stride(0), st)
+                    if n2c is not None:  # ... and their camera-space normals (channels 3..5)
+                        call("mtgs_normals_fwd_rows", cap_vis, ptr(b["vis_ids"]), ptr(totals), ptr(quats), ptr(scales), ptr(means),
+                             ptr(n2c), ptr(b["recs"]), 3, st)
                 b["mailbox"], b["tag"] = mailbox, tag
                 if dpf is not None:
                     dpf.after_front()      # the visibility maps travel while this frame is composited
@@ -676,6 +682,7 @@ class _FusedRasterization(torch.autograd.Function):
                               comps, opac_eff, offsets if not packed else offsets_buf, flatten_ids, alphas, last_ids, order,
                               vis_ids, vis_rank, render if ed else None, recs, rank_ids, totals)
         ctx.cs, ctx.vis_mask, ctx.cap_vis = cs, (b["vis_mask"] if cs is not None else None), (b["cap_vis"] if packed else 0)
+        ctx.n2c = n2c
         ctx.graph = packed and _graph.caps is not None
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
         ctx.absgrad = bool(absgrad)
@@ -779,7 +786,12 @@ class _FusedRasterization(torch.autograd.Function):
         want_m2d = m2d_out is not None and m2d_out.retains_grad
         d_m2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if want_m2d else None
         d_abs = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if (ctx.absgrad and m2d_out is not None) else None
-        c0 = 3 if cs is not None else 0     # (deferred colours: the dense colour gradient covers the other channels only)
+        c0 = 0 if cs is None else (6 if ctx.n2c is not None else 3)   # (the dense colour gradient covers the other channels only)
+        q_rows = None
+        if cs is not None and ctx.n2c is not None:   # the normals' gradient: quaternion rows of the visible Gaussians
+            q_rows = torch.empty((max(n_vis, 1), 4), dtype=torch.float32, device=dev)
+            call("mtgs_normals_bwd_qrows", n_vis, ptr(vis_ids), ptr(totals) if ctx.graph else None, ptr(quats), ptr(scales), ptr(means),
+                 ptr(ctx.n2c), ptr(G), RS, 8 + 3, ptr(q_rows), st)
         d_col = torch.empty((Cn, N, DC - c0), dtype=torch.float32, device=dev) if (DC - c0 and need[4]) else None
         vis_ws = torch.empty((max(n_vis, 1), 12), dtype=torch.float32, device=dev)  # scratch of the compact VJP
         call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
@@ -788,7 +800,7 @@ class _FusedRasterization(torch.autograd.Function):
              host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs),
              None if d_col is None else G.data_ptr() + 4 * (8 + c0), DC - c0 if d_col is not None else 0,
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
-             ptr(totals) if ctx.graph else None, st)
+             ptr(totals) if ctx.graph else None, ptr(q_rows), st)
         d_coeffs = d_campos = None
         if cs is not None and cs.autograd:
             if ctx.graph:
@@ -819,7 +831,8 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
     Returns (render, alphas, dict of gsplat's meta tensors)."""
     import weakref
     if colors is not None or color_source is not None:
-        total = (0 if colors is None else colors.shape[-1]) + (3 if color_source is not None else 0) + int(with_depth)
+        opened = 0 if color_source is None else (6 if getattr(color_source, "camera_normals", None) is not None else 3)
+        total = (0 if colors is None else colors.shape[-1]) + opened + int(with_depth)
         if total not in SUPPORTED_CHANNELS:
             raise ValueError(f"fused_rasterization: {total} blended channels (supported: {SUPPORTED_CHANNELS})")
     out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),

@@ -182,7 +182,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
         start += n
 
 
-VISFIRST = {"on": False, "cs": None}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
+VISFIRST = {"on": False, "cs": None, "normals": True}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
 ROWLAZY = {"on": False, "opt": None}     # --row-lazy: exact row-lazy Adam for the colour parameters (needs --visfirst --optimizer fused)
 LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
 
@@ -195,10 +195,14 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     vf = fused and VISFIRST["on"]
     gs = gaussians_fused(P, c2w, t, n, deferred=vf) if fused else gaussians_chain(P, c2w, t, n)
     colors = gs["rgbs"]
-    if shipped:
+    VISFIRST["cs"] = gs.get("color_source") if vf else None
+    if shipped and vf and VISFIRST["normals"]:
+        # the camera-space normals of the VISIBLE Gaussians only, inside the rasterization (channels 3..5 after the colours)
+        VISFIRST["cs"].camera_normals = c2w.reshape(-1, 4)[:3].to(torch.float32).contiguous()
+        colors = None
+    elif shipped:
         colors = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w, rgbs=colors) if fused else \
             torch.cat([colors, normals_chain(gs, c2w)], dim=-1)       # (visibility first: rgbs = None -> the normals alone)
-    VISFIRST["cs"] = gs.get("color_source") if vf else None
     if VISFIRST["cs"] is not None and ROWLAZY["on"]:
         VISFIRST["cs"].optimizer = ROWLAZY["opt"]      # the coefficient rows this frame sees are caught up before they are read
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H,
@@ -503,6 +507,8 @@ def main():
                     "Gaussians inside the rasterizer's front end, coefficient gradients as compact rows into the fused Adam")
     ap.add_argument("--lazy-adam", action="store_true", help="with --visfirst --optimizer fused: the per-traversal tensors' other "
                     "slices are left untouched by a step and caught up (bit-identically) before their traversal is rendered again")
+    ap.add_argument("--dense-normals", action="store_true", help="with --visfirst --shipped: the camera-space normals of EVERY Gaussian "
+                    "as extra colour channels (mtgs_amd.nodes.camera_space_normals) instead of the visible ones inside the rasterization")
     ap.add_argument("--row-lazy", action="store_true", help="with --visfirst --optimizer fused: exact row-lazy Adam -- the colour "
                     "parameters are stepped for the VISIBLE rows of the rendered traversal only and a row is caught up (bit-identically) "
                     "right before the forward reads it (mtgs_amd.optim.FusedAdam.set_row_lazy)")
@@ -510,6 +516,7 @@ def main():
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     args = ap.parse_args()
     VISFIRST["on"] = bool(args.visfirst)
+    VISFIRST["normals"] = not args.dense_normals
     LAZY["on"] = bool(args.lazy_adam)
     ROWLAZY["on"] = bool(args.row_lazy)
     if ROWLAZY["on"] and not (args.visfirst and args.optimizer in (None, "fused")) or (ROWLAZY["on"] and LAZY["on"]):

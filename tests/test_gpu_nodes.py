@@ -306,14 +306,16 @@ def test_collect_rigid_nodes_with_per_frame_pose_parameters(hip_lib):
             assert ga["instance_quats"][fidx[i]].abs().sum() > 0
 
 
-@pytest.mark.parametrize("degree,extra", [(3, 0), (1, 3)])
-def test_visibility_first_colours_equal_the_dense_node_path(hip_lib, degree, extra):
+@pytest.mark.parametrize("degree,extra,inside", [(3, 0, False), (1, 3, False), (2, 3, True)])
+def test_visibility_first_colours_equal_the_dense_node_path(hip_lib, degree, extra, inside):
     """collect_gaussians(deferred_colors=True) + rasterization(color_source=...): SH + clamp evaluated for the VISIBLE Gaussians
     only (csrc/viscolor.hip), coefficient gradients as compact rows.  Against the dense node path (colours of every Gaussian,
     dense gradients) on a scene with a vanilla node, a multi-colour node (per-traversal coefficients + adapters) and a
     shared-rest multi-colour node: same image, same geometry gradients, row gradients equal to the dense ones on the
     visible rows (zero elsewhere, and in the other traversals' slices), and the same parameters after a FusedAdam step from
-    rows as from the dense gradients."""
+    rows as from the dense gradients.  inside: the three camera-space normal channels are computed for the visible Gaussians
+    inside the rasterization too (ColorSource.camera_normals; mtgs_normals_fwd_rows / mtgs_normals_bwd_qrows) instead of being
+    handed over as extra colours of every Gaussian -- same image, same quaternion gradients."""
     from mtgs_amd import rasterization
     from mtgs_amd.nodes import camera_space_normals, collect_gaussians
     from mtgs_amd.optim import FusedAdam
@@ -349,7 +351,9 @@ def test_visibility_first_colours_equal_the_dense_node_path(hip_lib, degree, ext
         nodes = [dict(p, traversal_index=t) if "features_adapters" in p else p for p in P]
         gs = collect_gaussians(nodes, c2w, degree, deferred_colors=deferred)
         if deferred:
-            cols = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w) if extra else None
+            cols = camera_space_normals(gs["quats"], gs["scales"], gs["means"], c2w) if (extra and not inside) else None
+            if inside:
+                gs["color_source"].camera_normals = c2w[0].contiguous()
             r, a, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], cols, vm, K, W, H, packed=False,
                                        render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True, color_source=gs["color_source"])
         else:
