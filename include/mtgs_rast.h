@@ -611,6 +611,15 @@ int mtgs_inv_depth_l1_fwd(int width, int height, const float *gt_depth, const fl
 int mtgs_inv_depth_l1_bwd(int width, int height, const float *gt_depth, const float *pred_depth, const uint8_t *mask,
                           float lo, float hi, float eps, const float *v_out, const float *fwd_out, float *v_pred, void *stream);
 
+/* The sum of the loss dictionary (mtgs_scene_graph.py:823-945 scales every term by its lambda and adds the normal term only when
+ * it is finite, :939; the trainer adds the values up): out[0] = constant + sum_i weights[i] * terms[i] over the n <= 16 DEVICE
+ * scalars terms[i], a term whose bit is set in guard_mask being dropped when it is NaN / inf; kept[0] = bit mask of the terms that
+ * counted.  bwd: v_terms[i] = kept_i ? weights[i] * v_out[0] : 0.  weights: HOST array.  One launch each way instead of ~30
+ * one-element PyTorch kernels. */
+int mtgs_loss_combine_fwd(int n, const float *terms, const float *weights, unsigned guard_mask, float constant, float *out,
+                          uint32_t *kept, void *stream);
+int mtgs_loss_combine_bwd(int n, const float *v_out, const uint32_t *kept, const float *weights, float *v_terms, void *stream);
+
 /* ---- colours of the VISIBLE Gaussians only (visibility-first node path) ------------------------------------------------
  * MTGS evaluates SH + clamp for every Gaussian of every node each step (vanilla_gaussian_splatting.py:309-322,
  * multi_color_gaussian_splatting.py:77-101) although a camera sees ~15 % of a road block; gsplat's own sh_degree path masks

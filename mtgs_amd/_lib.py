@@ -115,6 +115,8 @@ _SIGNATURES = {
     "mtgs_l1_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_inv_depth_l1_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "mtgs_inv_depth_l1_bwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "mtgs_loss_combine_fwd": [_i32, _vp, C.POINTER(C.c_float), C.c_uint, _f32, _vp, _vp, _vp],
+    "mtgs_loss_combine_bwd": [_i32, _vp, _vp, C.POINTER(C.c_float), _vp, _vp],
     "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_rows_expand": [_i64, _i32, _vp, _vp, _i64, _vp, _vp],

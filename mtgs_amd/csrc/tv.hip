@@ -97,3 +97,47 @@ extern "C" int mtgs_tv_bwd(int width, int height, int channels, const float *ima
     MTGS_CHECK_LAUNCH("mtgs_tv_bwd");
     return MTGS_OK;
 }
+
+// ---- the sum of the loss dictionary (mtgs_scene_graph.py:823-945: every term scaled by its lambda, the normal term added only
+// when it is finite, :939; the trainer then adds the dictionary's values up): out = c + sum_i w_i t_i with guarded terms dropped
+// when they are not finite.  PyTorch: a multiply and an add per term, isfinite + where + zeros_like for the guard, and their
+// backward -- ~30 launches of one-element kernels; here one each way.
+struct CombineArgs { float w[16]; unsigned guard; float c; int n; };
+__global__ void combine_fwd_kernel(const float *__restrict__ terms, CombineArgs a, float *__restrict__ out, unsigned *__restrict__ kept) {
+    if (threadIdx.x != 0) return;
+    float s = a.c;
+    unsigned k = 0;
+    for (int i = 0; i < a.n; ++i) {
+        const float t = terms[i];
+        const bool drop = ((a.guard >> i) & 1u) && !(fabsf(t) <= 3.402823466e+38f);      // NaN or +-inf
+        if (!drop) { s += a.w[i] * t; k |= 1u << i; }
+    }
+    out[0] = s;
+    kept[0] = k;
+}
+__global__ void combine_bwd_kernel(const float *__restrict__ v_out, const unsigned *__restrict__ kept, CombineArgs a,
+                                   float *__restrict__ v_terms) {
+    const int i = threadIdx.x;
+    if (i < a.n) v_terms[i] = ((kept[0] >> i) & 1u) ? a.w[i] * v_out[0] : 0.f;
+}
+
+extern "C" int mtgs_loss_combine_fwd(int n, const float *terms, const float *weights, unsigned guard_mask, float constant, float *out,
+                                     uint32_t *kept, void *stream) {
+    MTGS_REQUIRE(n >= 1 && n <= 16 && terms && weights && out && kept, MTGS_EINVAL, "mtgs_loss_combine_fwd: 1 .. 16 terms");
+    CombineArgs a;
+    for (int i = 0; i < 16; ++i) a.w[i] = i < n ? weights[i] : 0.f;      // (HOST array)
+    a.guard = guard_mask; a.c = constant; a.n = n;
+    combine_fwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(terms, a, out, kept);
+    MTGS_CHECK_LAUNCH("mtgs_loss_combine_fwd");
+    return MTGS_OK;
+}
+extern "C" int mtgs_loss_combine_bwd(int n, const float *v_out, const uint32_t *kept, const float *weights, float *v_terms,
+                                     void *stream) {
+    MTGS_REQUIRE(n >= 1 && n <= 16 && v_out && kept && weights && v_terms, MTGS_EINVAL, "mtgs_loss_combine_bwd: 1 .. 16 terms");
+    CombineArgs a;
+    for (int i = 0; i < 16; ++i) a.w[i] = i < n ? weights[i] : 0.f;
+    a.guard = 0; a.c = 0.f; a.n = n;
+    combine_bwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(v_out, kept, a, v_terms);
+    MTGS_CHECK_LAUNCH("mtgs_loss_combine_bwd");
+    return MTGS_OK;
+}

@@ -154,6 +154,42 @@ def inverse_depth_l1(depth: Tensor, gt_depth: Tensor, mask: Optional[Tensor] = N
     return _InverseDepthL1.apply(gt_depth, depth, mask, lo, hi, eps)
 
 
+class _Combine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stacked, weights, guard_mask, constant):
+        require_gpu(stacked)
+        n = stacked.numel()
+        w = (C.c_float * n)(*weights)
+        out = torch.empty(1, dtype=torch.float32, device=stacked.device)
+        kept = torch.empty(1, dtype=torch.int32, device=stacked.device)
+        call("mtgs_loss_combine_fwd", n, ptr(stacked), w, int(guard_mask), float(constant), ptr(out), ptr(kept), stream_of(stacked))
+        ctx.save_for_backward(kept)
+        ctx.cfg = (n, tuple(float(x) for x in weights))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, v_out):
+        (kept,) = ctx.saved_tensors
+        n, weights = ctx.cfg
+        v = v_out.to(torch.float32).reshape(1).contiguous()
+        v_terms = torch.empty(n, dtype=torch.float32, device=v.device)
+        call("mtgs_loss_combine_bwd", n, ptr(v), ptr(kept), (C.c_float * n)(*weights), ptr(v_terms), stream_of(v))
+        return v_terms, None, None, None
+
+
+def combine_losses(terms, weights, constant: float = 0.0, drop_if_not_finite=()) -> Tensor:
+    """constant + sum_i weights[i] * terms[i] over scalar (0-dim) device tensors -- the sum of MTGS's loss dictionary
+    (/root/reference/mtgs/scene_model/mtgs_scene_graph.py:823-945: every term times its lambda; the trainer adds the values up).
+    drop_if_not_finite: indices of terms that are left out when they are NaN / inf (the normal term: `if torch.isfinite(...)`,
+    :939).  `0.2 * (1 - ssim)` is weight -0.2 and constant 0.2.  Two launches forward (the stack, the sum), one backward."""
+    assert 1 <= len(terms) <= 16 and len(weights) == len(terms)
+    stacked = torch.stack([t.reshape(()).to(torch.float32) for t in terms])
+    guard = 0
+    for i in drop_if_not_finite:
+        guard |= 1 << int(i)
+    return _Combine.apply(stacked, [float(w) for w in weights], guard, float(constant))
+
+
 class _OutputHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, render, alpha, background, exposure, want_depth, normal_channel):

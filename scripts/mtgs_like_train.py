@@ -25,7 +25,7 @@ import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, spherical_harmonics  # noqa: E402
 from mtgs_amd.densify import update_statistics, update_statistics_all  # noqa: E402
-from mtgs_amd.loss import depth_ncc_loss, inverse_depth_l1, masked_l1, masked_ssim, output_head, tv_loss  # noqa: E402
+from mtgs_amd.loss import combine_losses, depth_ncc_loss, inverse_depth_l1, masked_l1, masked_ssim, output_head, tv_loss  # noqa: E402
 from mtgs_amd.nodes import camera_space_normals, node_gaussians  # noqa: E402
 from mtgs_amd.synthetic import make_camera  # noqa: E402
 
@@ -228,8 +228,11 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)     # use_ssim_on_raw_rgb
         ncc = depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask) if fused else ncc_chain(depth, gt_d, 32, 16, mask=dmask)   # :886-894
         # pixels nothing was splatted on have a 0/0 normal; MTGS adds the term only when it is finite (mtgs_scene_graph.py:939)
-        loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
-        loss = 0.8 * l1 + 0.2 * (1 - ssim) + 0.5 * loss_d + 0.1 * loss_n + 0.1 * ncc
+        if fused:      # 0.8 l1 + 0.2 (1 - ssim) + 0.5 depth + 0.1 normal (when finite) + 0.1 ncc, one launch
+            loss = combine_losses([l1, ssim, loss_d, loss_n, ncc], [0.8, -0.2, 0.5, 0.1, 0.1], constant=0.2, drop_if_not_finite=(3,))
+        else:
+            loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
+            loss = 0.8 * l1 + 0.2 * (1 - ssim) + 0.5 * loss_d + 0.1 * loss_n + 0.1 * ncc
     else:
         rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)          # black background (mtgs_scene_graph.py:672-676)
         l1 = masked_l1(gt, rgb, mask) if fused else torch.abs(gt - rgb)[mask.squeeze(-1)].mean()
@@ -290,9 +293,9 @@ def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=Non
         gt_d, gt_n = shipped["gt_depth"][t], shipped["gt_normal"][t]
         loss_d, dmask = inverse_depth_l1(depth, gt_d, mask, 0.1, 80.0, 1e-5)
         loss_n = masked_l1(gt_n, normal, mask) + tv_loss(normal)
-        loss_n = torch.where(torch.isfinite(loss_n), loss_n, torch.zeros_like(loss_n))
-        loss = 0.8 * masked_l1(gt, app, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask)) + \
-            0.5 * loss_d + 0.1 * loss_n + 0.1 * depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask)
+        loss = combine_losses([masked_l1(gt, app, mask), masked_ssim(gt, rgb, mask), loss_d, loss_n,
+                               depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask)], [0.8, -0.2, 0.5, 0.1, 0.1], constant=0.2,
+                              drop_if_not_finite=(3,))
     else:
         rgb = torch.clamp(render[0, ..., :3] + (1 - alpha[0]) * 0.0, 0.0, 1.0)
         loss = 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))

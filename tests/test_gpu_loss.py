@@ -73,6 +73,27 @@ def test_masked_l1_matches_torch_formulation(hip_lib, use_mask, ch):
     assert torch.allclose(p.grad.double(), p_ref.grad, rtol=1e-5, atol=1e-12)
 
 
+def test_combine_losses_matches_the_written_out_sum(hip_lib):
+    """combine_losses = the weighted sum of the loss dictionary with MTGS's finite-check on the normal term
+    (mtgs_scene_graph.py:939), value and gradients, with the guarded term finite, NaN and inf."""
+    from mtgs_amd.loss import combine_losses
+    dev = torch.device("cuda")
+    w = [0.8, -0.2, 0.5, 0.1, 0.1]
+    for bad in (None, float("nan"), float("inf")):
+        vals = [0.31, 0.87, 0.044, 0.52 if bad is None else bad, 0.09]
+        ta = [torch.tensor(v, device=dev, requires_grad=True) for v in vals]
+        tb = [torch.tensor(v, device=dev, dtype=torch.float64, requires_grad=True) for v in vals]
+        got = combine_losses(ta, w, constant=0.2, drop_if_not_finite=(3,))
+        n_term = tb[3] if bad is None else torch.zeros((), dtype=torch.float64, device=dev)
+        ref = 0.8 * tb[0] + 0.2 * (1 - tb[1]) + 0.5 * tb[2] + 0.1 * n_term + 0.1 * tb[4]
+        (3.0 * got).backward()
+        (3.0 * ref).backward()
+        assert abs(float(got) - float(ref)) <= 1e-6
+        for i, (a, b) in enumerate(zip(ta, tb)):
+            want = 0.0 if (i == 3 and bad is not None) else float(b.grad)
+            assert abs(float(a.grad) - want) <= 1e-6, (bad, i)
+
+
 @pytest.mark.parametrize("use_mask,empty", [(True, False), (False, False), (True, True)])
 def test_inverse_depth_l1_matches_the_reference_formulation(hip_lib, use_mask, empty):
     """mtgs_scene_graph.py:849-858, 875-879 (lidar depth, DepthLossType.InverseL1) written out in torch float64: the range mask
