@@ -318,7 +318,11 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int32_t *__restrict__ 
 }
 __global__ void __launch_bounds__(ADAM_BLOCK) adam_list_schedule_kernel(mtgs_adam_group *__restrict__ table, float *__restrict__ hyper,
                                                                         int n_groups) {
+    constexpr int MAXG = 2048;                     // groups whose counts are kept in LDS for the prefix (more: read back)
+    __shared__ int s_count[MAXG];                  // -1: not a LIST group
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int g = threadIdx.x; g < n_groups && g < MAXG; g += ADAM_BLOCK) s_count[g] = -1;
+    __syncthreads();
     for (int g = wave; g < n_groups; g += ADAM_BLOCK / 64) {
         mtgs_adam_group &d = table[g];
         if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) continue;
@@ -335,17 +339,27 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_list_schedule_kernel(mtgs_ada
         if (d.row_count_dev) { const int64_t c = *d.row_count_dev >> 32; if (c < count) count = c; }
         const int64_t a = wave_lower_bound(d.row_ids, count, d.item_start);
         const int64_t b = wave_lower_bound(d.row_ids, count, d.item_start + d.n);
-        if (lane == 0) { d.rank_start = (int32_t)a; d.rank_count = (int32_t)(b - a); }
+        if (lane == 0) {
+            d.rank_start = (int32_t)a; d.rank_count = (int32_t)(b - a);
+            if (g < MAXG) s_count[g] = (int)(b - a);
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {      // (counts from LDS: the loop is a chain of stores, not of dependent loads)
         int64_t next = -1;
         for (int g = 0; g < n_groups; ++g) {
-            mtgs_adam_group &d = table[g];
-            if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) continue;
-            if (next < 0) next = d.first_block;      // (the first LIST group keeps the host's value)
-            d.first_block = next;
-            next += ((int64_t)d.rank_count + ADAM_LIST_ROWS - 1) / ADAM_LIST_ROWS;
+            int cnt;
+            if (g < MAXG) {
+                cnt = s_count[g];
+                if (cnt < 0) continue;
+            } else {
+                const mtgs_adam_group &e = table[g];
+                if (e.mode < MTGS_ADAM_ROWS_CATCHUP || e.row_ids == nullptr) continue;
+                cnt = e.rank_count;
+            }
+            if (next < 0) next = table[g].first_block;      // (the first LIST group keeps the host's value)
+            table[g].first_block = next;
+            next += ((int64_t)cnt + ADAM_LIST_ROWS - 1) / ADAM_LIST_ROWS;
         }
     }
 }

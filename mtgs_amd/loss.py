@@ -18,6 +18,15 @@ from torch import Tensor
 from ._lib import call, ptr, require_gpu, stream_of
 
 
+def _mask_u8(mask: Optional[Tensor], H: int, W: int) -> Optional[Tensor]:
+    """[H,W] uint8 view of a pixel mask for the kernels.  A bool mask is REINTERPRETED (True is the byte 1): `.to(torch.uint8)`
+    is a copy kernel, and the loss head takes the same mask four or five times per iteration."""
+    if mask is None:
+        return None
+    m = mask.reshape(H, W).contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+
+
 class _MaskedSSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gt, pred, mask, win_sigma, data_range, K1, K2):
@@ -25,7 +34,7 @@ class _MaskedSSIM(torch.autograd.Function):
         H, W = pred.shape[:2]
         gt_c = gt.detach().to(torch.float32).contiguous()
         pred_c = pred.detach().to(torch.float32).contiguous()
-        mask_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        mask_c = _mask_u8(mask, H, W)
         dev = pred.device
         n = C.c_size_t(0)
         call("mtgs_ssim_workspace_floats", W, H, C.byref(n))
@@ -73,7 +82,7 @@ class _MaskedL1(torch.autograd.Function):
         H, W = pred.shape[:2]
         gt_c = gt.detach().to(torch.float32).contiguous()
         pred_c = pred.detach().to(torch.float32).contiguous()
-        mask_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        mask_c = _mask_u8(mask, H, W)
         n = C.c_size_t(0)
         call("mtgs_l1_workspace_floats", W, H, C.byref(n))
         partials = torch.empty(n.value, dtype=torch.float32, device=pred.device)
@@ -115,7 +124,7 @@ class _InverseDepthL1(torch.autograd.Function):
         H, W = depth.shape[:2]
         gt_c = gt_depth.detach().to(torch.float32).reshape(H, W).contiguous()
         d_c = depth.detach().to(torch.float32).reshape(H, W).contiguous()
-        mask_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        mask_c = _mask_u8(mask, H, W)
         n = C.c_size_t(0)
         call("mtgs_l1_workspace_floats", W, H, C.byref(n))
         partials = torch.empty(n.value, dtype=torch.float32, device=depth.device)
@@ -127,12 +136,15 @@ class _InverseDepthL1(torch.autograd.Function):
         ctx.cfg = (H, W, float(lo), float(hi), float(eps), depth.shape, depth.dtype)
         used = used.view(torch.bool).reshape(H, W, 1)
         ctx.mark_non_differentiable(used)
+        ctx.set_materialize_grads(False)      # (no zero-filled "gradient" of the mask output)
         return out[0], used
 
     @staticmethod
     def backward(ctx, v_out, _v_mask):
         gt_c, d_c, mask_c, out = ctx.saved_tensors
         H, W, lo, hi, eps, shape, dtype = ctx.cfg
+        if v_out is None:
+            return None, None, None, None, None, None
         v = v_out.to(torch.float32).reshape(1).contiguous()
         v_d = torch.empty_like(d_c)
         call("mtgs_inv_depth_l1_bwd", W, H, ptr(gt_c), ptr(d_c), ptr(mask_c), lo, hi, eps, ptr(v), ptr(out), ptr(v_d), stream_of(d_c))
@@ -340,7 +352,7 @@ class _DepthNcc(torch.autograd.Function):
         dev = pred.device
         p_c = pred.detach().to(torch.float32).reshape(H, W).contiguous()
         g_c = gt.detach().to(torch.float32).reshape(H, W).contiguous()
-        m_c = None if mask is None else mask.reshape(H, W).to(torch.uint8).contiguous()
+        m_c = _mask_u8(mask, H, W)
         n = C.c_int64(0)
         call("mtgs_ncc_patches", W, H, patch_size, stride, C.byref(n))
         stats = torch.empty(n.value * 6, dtype=torch.float32, device=dev)
