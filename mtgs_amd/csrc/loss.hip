@@ -45,17 +45,36 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     // the mask is cropped by the window margin: output (oy, ox) <-> image pixel (oy + 5, ox + 5)
     const float m = valid ? (mask ? (mask[(int64_t)(oy + HALO / 2) * W + ox + HALO / 2] ? 1.f : 0.f) : 1.f) : 0.f;
     float sum = 0.f;
-    for (int c = 0; c < 3; ++c) {
-        __syncthreads();
-        for (int i = tid; i < IN_TILE * IN_TILE; i += 256) {
+    // The three channels are three passes over the LDS tiles; the NEXT channel's pixels are fetched into registers while the
+    // current one is filtered (a workgroup is resident for the whole image at 960x540: its time was three global round trips).
+    constexpr int PER = (IN_TILE * IN_TILE + 255) / 256;
+    float rx[PER], ry[PER];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * 256;
             const int r = i / IN_TILE, q = i - r * IN_TILE;
             const int gy = y0 + r, gx = x0 + q;
-            const bool in = gy < H && gx < W;
+            const bool in = i < IN_TILE * IN_TILE && gy < H && gx < W;
             const int64_t a = ((int64_t)gy * W + gx) * 3 + c;
-            sX[r][q] = in ? X[a] : 0.f;
-            sY[r][q] = in ? Y[a] : 0.f;
+            rx[u] = in ? X[a] : 0.f;
+            ry[u] = in ? Y[a] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * 256;
+            if (i < IN_TILE * IN_TILE) {
+                const int r = i / IN_TILE, q = i - r * IN_TILE;
+                sX[r][q] = rx[u];
+                sY[r][q] = ry[u];
+            }
         }
         __syncthreads();
+        if (c < 2) fetch(c + 1);
         for (int i = tid; i < IN_TILE * TILE; i += 256) {   // horizontal pass: 26 rows x 16 columns
             const int r = i >> 4, q = i & 15;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
@@ -133,17 +152,37 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
     const int px = x0 + tx, py = y0 + ty;
     const float scale = v_out[0] / fwd_out[1];
-    for (int c = 0; c < 3; ++c) {
-        __syncthreads();
-        // pixel (py, px) receives from outputs (py - a, px - b), a, b in [0, 10]: rows y0-10 .. y0+15
-        for (int i = tid; i < IN_TILE * IN_TILE; i += 256) {
+    // (the next channel's maps and pixels are fetched while the current channel is filtered, as in the forward)
+    constexpr int PER = (IN_TILE * IN_TILE + 255) / 256;
+    float rg[PER][3], xn = 0.f, yn = 0.f;
+    const bool own = px < W && py < H;
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            // pixel (py, px) receives from outputs (py - a, px - b), a, b in [0, 10]: rows y0-10 .. y0+15
+            const int i = tid + u * 256;
             const int r = i / IN_TILE, q = i - r * IN_TILE;
             const int gy = y0 - HALO + r, gx = x0 - HALO + q;
-            const bool in = gy >= 0 && gx >= 0 && gy < OH && gx < OW;
+            const bool in = i < IN_TILE * IN_TILE && gy >= 0 && gx >= 0 && gy < OH && gx < OW;
             const float *g = gmaps + ((int64_t)gy * OW + gx) * 9 + c * 3;
-            sG[0][r][q] = in ? g[0] : 0.f; sG[1][r][q] = in ? g[1] : 0.f; sG[2][r][q] = in ? g[2] : 0.f;
+            rg[u][0] = in ? g[0] : 0.f; rg[u][1] = in ? g[1] : 0.f; rg[u][2] = in ? g[2] : 0.f;
         }
+        if (own) { const int64_t a = ((int64_t)py * W + px) * 3 + c; xn = X[a]; yn = Y[a]; }
+    };
+    fetch(0);
+    for (int c = 0; c < 3; ++c) {
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * 256;
+            if (i < IN_TILE * IN_TILE) {
+                const int r = i / IN_TILE, q = i - r * IN_TILE;
+                sG[0][r][q] = rg[u][0]; sG[1][r][q] = rg[u][1]; sG[2][r][q] = rg[u][2];
+            }
+        }
+        const float xc = xn, yc = yn;
+        __syncthreads();
+        if (c < 2) fetch(c + 1);
         for (int i = tid; i < IN_TILE * TILE; i += 256) {   // horizontal: column q <-> tile columns q .. q+10, weight w[10-k]
             const int r = i >> 4, q = i & 15;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -161,9 +200,9 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
             const float w = win.w[HALO - k];
             t0 += w * sH[0][ty + k][tx]; t1 += w * sH[1][ty + k][tx]; t2 += w * sH[2][ty + k][tx];
         }
-        if (px < W && py < H) {
+        if (own) {
             const int64_t a = ((int64_t)py * W + px) * 3 + c;
-            v_Y[a] = scale * (t0 + 2.f * Y[a] * t1 + X[a] * t2);
+            v_Y[a] = scale * (t0 + 2.f * yc * t1 + xc * t2);
         }
     }
 }
