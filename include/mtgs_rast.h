@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 17
+#define MTGS_RAST_ABI_VERSION 18
 
 enum {
     MTGS_OK = 0,
@@ -97,7 +97,9 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals; the number of rows is then min(n_vis, *n_vis_dev >> 32)
  * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count).
  * x_quat_rows[n_vis, 4] (nullable, compact path only, 16-byte aligned): quaternion gradients of the visible Gaussians that did
- * not come through the projection -- the camera-space normals' (mtgs_normals_bwd_qrows) -- added to v_quats. */
+ * not come through the projection -- the camera-space normals' (mtgs_normals_bwd_qrows) -- added to v_quats; x_mean_rows[n_vis, 3]
+ * (nullable, compact path only): likewise position gradients (the view directions of gsplat's sh_degree colours:
+ * mtgs_vis_color_bwd's dir_rows), added to v_means. */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
@@ -114,7 +116,7 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *x_means2d_abs, const float *x_colors, int x_channels,
                      const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
                      const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
-                     const float *x_quat_rows, void *stream);
+                     const float *x_quat_rows, const float *x_mean_rows, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -610,6 +612,12 @@ int mtgs_inv_depth_l1_fwd(int width, int height, const float *gt_depth, const fl
                           float lo, float hi, float eps, uint8_t *mask_out, float *partials, float *out, void *stream);
 int mtgs_inv_depth_l1_bwd(int width, int height, const float *gt_depth, const float *pred_depth, const uint8_t *mask,
                           float lo, float hi, float eps, const float *v_out, const float *fwd_out, float *v_pred, void *stream);
+
+/* Camera position of ONE view matrix [A t; 0 1] (row-major 4x4, device): cam_pos = -A^-1 t = torch.inverse(viewmat)[:3, 3], which
+ * gsplat's sh_degree path forms for the view directions (rendering.py) -- there an LU factorisation with its backward, ~25 launches;
+ * here one each way.  bwd: v_viewmat[4,4] (fully written) from v_cam_pos[3]. */
+int mtgs_campos_fwd(const float *viewmat, float *cam_pos, void *stream);
+int mtgs_campos_bwd(const float *viewmat, const float *v_cam_pos, float *v_viewmat, void *stream);
 
 /* The sum of the loss dictionary (mtgs_scene_graph.py:823-945 scales every term by its lambda and adds the normal term only when
  * it is finite, :939; the trainer adds the values up): out[0] = constant + sum_i weights[i] * terms[i] over the n <= 16 DEVICE

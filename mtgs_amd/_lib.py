@@ -34,7 +34,7 @@ _SIGNATURES = {
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp,
-                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_isect_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -115,6 +115,8 @@ _SIGNATURES = {
     "mtgs_l1_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_inv_depth_l1_fwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "mtgs_inv_depth_l1_bwd": [_i32, _i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "mtgs_campos_fwd": [_vp, _vp, _vp],
+    "mtgs_campos_bwd": [_vp, _vp, _vp, _vp],
     "mtgs_loss_combine_fwd": [_i32, _vp, C.POINTER(C.c_float), C.c_uint, _f32, _vp, _vp, _vp],
     "mtgs_loss_combine_bwd": [_i32, _vp, _vp, C.POINTER(C.c_float), _vp, _vp],
     "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -132,7 +134,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 

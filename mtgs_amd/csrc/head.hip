@@ -169,3 +169,60 @@ extern "C" int mtgs_head_bwd(int width, int height, int channels, int depth_chan
     MTGS_CHECK_LAUNCH("mtgs_head_bwd");
     return MTGS_OK;
 }
+
+// ---- camera position of a view matrix [A t; 0 1]: c = -A^-1 t (the translation column of its inverse), one thread.
+// gsplat's sh_degree path forms torch.inverse(viewmats)[:, :3, 3] (rendering.py) -- an LU factorisation, two triangular solves,
+// a row swap and their backward: ~25 launches of one-element kernels, 110 us of a 1.2 ms step.  A = general 3x3 (adjugate).
+// bwd: with u = A^-T v_c:  v_A = -u c^T,  v_t = -u  (c = -A^-1 t  =>  dc = -A^-1 dA c - A^-1 dt), last row as torch.inverse's.
+namespace {
+struct Inv3 { float m[9]; };
+__device__ __forceinline__ Inv3 inverse3(const float *V) {     // V: row-major 4x4, A = V[:3, :3]
+    const float a = V[0], b = V[1], c = V[2], d = V[4], e = V[5], f = V[6], g = V[8], h = V[9], i = V[10];
+    const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const float det = (a * c00 + b * c01) + c * c02;
+    const float r = 1.0f / det;
+    Inv3 o;
+    o.m[0] = c00 * r; o.m[1] = (c * h - b * i) * r; o.m[2] = (b * f - c * e) * r;
+    o.m[3] = c01 * r; o.m[4] = (a * i - c * g) * r; o.m[5] = (c * d - a * f) * r;
+    o.m[6] = c02 * r; o.m[7] = (b * g - a * h) * r; o.m[8] = (a * e - b * d) * r;
+    return o;
+}
+__global__ void campos_fwd_kernel(const float *__restrict__ V, float *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const Inv3 I = inverse3(V);
+    const float tx = V[3], ty = V[7], tz = V[11];
+    out[0] = -((I.m[0] * tx + I.m[1] * ty) + I.m[2] * tz);
+    out[1] = -((I.m[3] * tx + I.m[4] * ty) + I.m[5] * tz);
+    out[2] = -((I.m[6] * tx + I.m[7] * ty) + I.m[8] * tz);
+}
+__global__ void campos_bwd_kernel(const float *__restrict__ V, const float *__restrict__ v_c, float *__restrict__ v_V) {
+    if (threadIdx.x != 0) return;
+    const Inv3 I = inverse3(V);
+    const float tx = V[3], ty = V[7], tz = V[11];
+    const float c[3] = {-((I.m[0] * tx + I.m[1] * ty) + I.m[2] * tz), -((I.m[3] * tx + I.m[4] * ty) + I.m[5] * tz),
+                        -((I.m[6] * tx + I.m[7] * ty) + I.m[8] * tz)};
+    float u[3];      // A^-T v_c
+    for (int k = 0; k < 3; ++k) u[k] = (I.m[k] * v_c[0] + I.m[3 + k] * v_c[1]) + I.m[6 + k] * v_c[2];
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) v_V[r * 4 + k] = -u[r] * c[k];
+        v_V[r * 4 + 3] = -u[r];
+    }
+    // torch.inverse treats all 16 entries as free: v_V = -C^T G C^T with C = V^-1 and G zero but for its column [v_c; 0] has the
+    // last row -(c . v_c) [c; 1] as well (the caller's view matrix has a constant last row; the gradient is reported as gsplat does)
+    const float cv = (c[0] * v_c[0] + c[1] * v_c[1]) + c[2] * v_c[2];
+    v_V[12] = -cv * c[0]; v_V[13] = -cv * c[1]; v_V[14] = -cv * c[2]; v_V[15] = -cv;
+}
+}  // namespace
+
+extern "C" int mtgs_campos_fwd(const float *viewmat, float *cam_pos, void *stream) {
+    MTGS_REQUIRE(viewmat && cam_pos, MTGS_EINVAL, "mtgs_campos_fwd: null pointer");
+    campos_fwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(viewmat, cam_pos);
+    MTGS_CHECK_LAUNCH("mtgs_campos_fwd");
+    return MTGS_OK;
+}
+extern "C" int mtgs_campos_bwd(const float *viewmat, const float *v_cam_pos, float *v_viewmat, void *stream) {
+    MTGS_REQUIRE(viewmat && v_cam_pos && v_viewmat, MTGS_EINVAL, "mtgs_campos_bwd: null pointer");
+    campos_bwd_kernel<<<1, 64, 0, (hipStream_t)stream>>>(viewmat, v_cam_pos, v_viewmat);
+    MTGS_CHECK_LAUNCH("mtgs_campos_bwd");
+    return MTGS_OK;
+}

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     const float *__restrict__ v_means2d, const float *__restrict__ v_depths, const float *__restrict__ v_conics,
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff, const ProjGradStrides gs,
     float *__restrict__ ws, float *__restrict__ v_viewmats, const int64_t *__restrict__ n_vis_dev,
-    const float *__restrict__ x_quat_rows) {
+    const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
@@ -340,6 +340,9 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
             if (x_quat_rows) {   // quaternion gradients that reached the Gaussian beside the projection (camera-space normals)
                 const float4 xq = reinterpret_cast<const float4 *>(x_quat_rows)[r];
                 aq[0] += xq.x; aq[1] += xq.y; aq[2] += xq.z; aq[3] += xq.w;
+            }
+            if (x_mean_rows) {   // ... and position gradients (gsplat's differentiable view directions of the SH colours)
+                am[0] += x_mean_rows[r * 3]; am[1] += x_mean_rows[r * 3 + 1]; am[2] += x_mean_rows[r * 3 + 2];
             }
             float4 *out = reinterpret_cast<float4 *>(ws + r * VIS_ROW);
             out[0] = make_float4(am[0], am[1], am[2], aq[0]);
@@ -506,7 +509,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const float *x_means2d_abs, const float *x_colors, int x_channels,
                                 const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
                                 float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
-                                const int64_t *n_vis_dev, const float *x_quat_rows, void *stream) {
+                                const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -541,6 +544,8 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
     MTGS_REQUIRE(ex.abs_stride >= 2 && ex.col_stride >= x_channels, MTGS_EINVAL, "mtgs_project_bwd: x_row_strides too small");
     MTGS_REQUIRE(!x_quat_rows || (vis_ids && vis_ws && grad_row_index && C == 1 && (reinterpret_cast<uintptr_t>(x_quat_rows) & 15) == 0),
                  MTGS_EINVAL, "mtgs_project_bwd: x_quat_rows needs the compact path (vis_ids, vis_ws, grad_row_index, C == 1), 16-byte aligned");
+    MTGS_REQUIRE(!x_mean_rows || (vis_ids && vis_ws && grad_row_index && C == 1), MTGS_EINVAL,
+                 "mtgs_project_bwd: x_mean_rows needs the compact path (vis_ids, vis_ws, grad_row_index, C == 1)");
     if (vis_ids && vis_ws && grad_row_index && C == 1) {
         // compact path: grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank)
         MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
@@ -548,7 +553,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
             const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
             project_bwd_vis_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
-                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows);
+                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows);
         }
         project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
             N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);

@@ -254,15 +254,35 @@ __global__ __launch_bounds__(256) void rows_expand_kernel(int64_t N, int width, 
     const int32_t r = row_of[n];
     out[e] = r >= 0 ? rows[(int64_t)r * row_stride + c] : 0.f;
 }
-// the same, 16 bytes per lane (width and row_stride multiples of 4, 16-byte aligned pointers)
+// the same, 16 bytes per lane (width and row_stride multiples of 4, 16-byte aligned pointers): four float4 per thread, the 64-bit
+// division once per workgroup, the dense output streamed past the caches (it is 384 MB at 2M Gaussians x 48 floats and nobody
+// reads it before the optimizer)
+typedef float vc_f4 __attribute__((ext_vector_type(4)));
+constexpr int RX_PER = 4;
 __global__ __launch_bounds__(256) void rows_expand4_kernel(int64_t N, int width4, const int32_t *__restrict__ row_of,
                                                            const float4 *__restrict__ rows, int64_t row_stride4, float4 *__restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * width4) return;
-    const int64_t n = e / width4;
-    const int c = (int)(e - n * width4);
-    const int32_t r = row_of[n];
-    out[e] = r >= 0 ? rows[(int64_t)r * row_stride4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t base = (int64_t)blockIdx.x * (256 * RX_PER), total = N * width4;
+    const int64_t n0 = base / width4;
+    const unsigned rem0 = (unsigned)(base - n0 * width4);
+    float4 v[RX_PER];
+    int64_t e[RX_PER];
+#pragma unroll
+    for (int u = 0; u < RX_PER; ++u) {
+        const unsigned local = rem0 + (unsigned)(u * 256 + threadIdx.x);
+        const unsigned dn = local / (unsigned)width4, c = local - dn * (unsigned)width4;
+        e[u] = base + u * 256 + threadIdx.x;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e[u] < total) {
+            const int32_t r = row_of[n0 + dn];
+            if (r >= 0) v[u] = rows[(int64_t)r * row_stride4 + c];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RX_PER; ++u)
+        if (e[u] < total) {
+            vc_f4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<vc_f4 *>(out + e[u]));
+        }
 }
 
 #define MTGS_VC_DISPATCH(KERNEL, ...)                                                              \
@@ -315,7 +335,7 @@ extern "C" int mtgs_rows_expand(int64_t N, int width, const int32_t *row_of, con
     MTGS_REQUIRE(row_of && rows && out, MTGS_EINVAL, "mtgs_rows_expand: null pointer");
     MTGS_REQUIRE(N * width < ((int64_t)1 << 39), MTGS_EINVAL, "mtgs_rows_expand: too many elements");
     if (width % 4 == 0 && row_stride % 4 == 0 && (((uintptr_t)rows | (uintptr_t)out) & 15) == 0)
-        rows_expand4_kernel<<<(unsigned)ceil_div64(N * (width / 4), 256), 256, 0, (hipStream_t)stream>>>(
+        rows_expand4_kernel<<<(unsigned)ceil_div64(N * (width / 4), 256 * RX_PER), 256, 0, (hipStream_t)stream>>>(
             N, width / 4, row_of, (const float4 *)rows, row_stride / 4, (float4 *)out);
     else
         rows_expand_kernel<<<(unsigned)ceil_div64(N * width, 256), 256, 0, (hipStream_t)stream>>>(N, width, row_of, rows, row_stride, out);

@@ -20,6 +20,36 @@ from .wrapper import (MAX_CHANNELS, SUPPORTED_CHANNELS, fused_rasterization, ise
                       spherical_harmonics)
 
 
+class _CameraPosition(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, viewmat):
+        from ._lib import call, ptr, require_gpu, stream_of
+        require_gpu(viewmat)
+        V = viewmat.detach().to(torch.float32).contiguous()
+        out = torch.empty(3, dtype=torch.float32, device=V.device)
+        call("mtgs_campos_fwd", ptr(V), ptr(out), stream_of(V))
+        ctx.save_for_backward(V)
+        ctx.dtype = viewmat.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, v_c):
+        from ._lib import call, ptr, stream_of
+        (V,) = ctx.saved_tensors
+        v = v_c.to(torch.float32).contiguous()
+        g = torch.empty((4, 4), dtype=torch.float32, device=V.device)
+        call("mtgs_campos_bwd", ptr(V), ptr(v), ptr(g), stream_of(V))
+        return g.to(ctx.dtype)
+
+
+def camera_position(viewmat: Tensor) -> Tensor:
+    """torch.inverse(viewmat)[:3, 3] of one [4,4] view matrix [A t; 0 1] -- the camera position gsplat's sh_degree path takes
+    its view directions from (gsplat/rendering.py) -- as -A^-1 t in one launch per direction (the LU route and its backward
+    are ~25 one-element launches).  Differentiable with respect to the view matrix."""
+    assert viewmat.shape == (4, 4), viewmat.shape
+    return _CameraPosition.apply(viewmat)
+
+
 def rasterization(
     means: Tensor,  # [N, 3]
     quats: Tensor,  # [N, 4]
@@ -149,7 +179,7 @@ def rasterization(
             and backgrounds is None and render_mode in ["RGB", "RGB+D", "RGB+ED"] and colors.dtype == torch.float32
             and (3 + int(with_depth)) in SUPPORTED_CHANNELS and N > 0):
         from .nodes import sh_coefficient_source
-        campos = torch.inverse(viewmats)[0, :3, 3]                 # differentiable: d dirs / d viewmat flows through it
+        campos = camera_position(viewmats[0])                      # = torch.inverse(viewmats)[0, :3, 3], differentiable, one launch
         cs = sh_coefficient_source(colors, sh_degree, campos)
         render_colors, render_alphas, m = fused_rasterization(
             means, quats, scales, opacities, None, viewmats, Ks, None, width, height, eps2d, near_plane, far_plane, radius_clip,

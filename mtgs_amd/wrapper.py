@@ -142,7 +142,7 @@ class _FullyFusedProjection(torch.autograd.Function):
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
-             None, 0, None, None, None, stream_of(means))
+             None, 0, None, None, None, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -800,7 +800,8 @@ class _FusedRasterization(torch.autograd.Function):
              host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs),
              None if d_col is None else G.data_ptr() + 4 * (8 + c0), DC - c0 if d_col is not None else 0,
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
-             ptr(totals) if ctx.graph else None, ptr(q_rows), st)
+             ptr(totals) if ctx.graph else None, ptr(q_rows),
+             ptr(dir_rows) if (cs is not None and cs.autograd and n_vis > 0) else None, st)   # (differentiable view directions: dirs = means - camera position)
         d_coeffs = d_campos = None
         if cs is not None and cs.autograd:
             if ctx.graph:
@@ -808,8 +809,7 @@ class _FusedRasterization(torch.autograd.Function):
             K3 = cs.width
             d_coeffs = torch.empty((N, K3 // 3, 3), dtype=torch.float32, device=dev)
             call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
-            if n_vis > 0:     # differentiable view directions: dirs = means - camera position
-                v_means.index_add_(0, vis_ids.long(), dir_rows[:n_vis])
+            if n_vis > 0:
                 d_campos = -dir_part.sum(0)
             else:
                 d_campos = torch.zeros(3, dtype=torch.float32, device=dev)

@@ -412,3 +412,26 @@ def test_hip_reproduces_gsplat_fixture(gs, name):
     assert_grad_close("v_viewmat", vm.grad, z["v_viewmat"], case=case)
     assert_grad_close("means2d.grad", info["means2d"].grad, z["v_means2d"], case=case)
     assert_grad_close("means2d.absgrad", info["means2d"].absgrad, z["v_means2d_abs"], case=case)
+
+
+def test_camera_position_equals_torch_inverse(hip_lib):
+    """mtgs_amd.rendering.camera_position = torch.inverse(viewmat)[:3, 3] (what gsplat's sh_degree path takes its view directions
+    from), value and gradient with respect to the view matrix, for rigid and for general (sheared / scaled) matrices."""
+    from mtgs_amd.rendering import camera_position
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(31)
+    for k in range(6):
+        A = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        if k >= 3:
+            A = A @ torch.diag(torch.tensor([1.5, 0.7, 1.1])) + 0.1 * torch.randn(3, 3, generator=g)
+        V = torch.eye(4)
+        V[:3, :3], V[:3, 3] = A, torch.randn(3, generator=g) * 5
+        cot = torch.randn(3, generator=g).to(dev)
+        Vd = V.to(dev).double().requires_grad_(True)
+        ref = torch.inverse(Vd)[:3, 3]
+        (ref * cot.double()).sum().backward()
+        Vf = V.to(dev).requires_grad_(True)
+        got = camera_position(Vf)
+        (got * cot).sum().backward()
+        assert torch.allclose(got.double(), ref.detach(), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(Vf.grad.double(), Vd.grad, rtol=1e-4, atol=1e-4), k      # (all 16 entries, as torch.inverse reports them)
