@@ -171,6 +171,32 @@ def make_step(args, dev, world):
     return step, step_fwd, all_params, info_box
 
 
+def sh_degree_cell(args, dev):
+    """ms per forward + backward of gsplat's OWN call style at the headline size -- rasterization(colors=coefficients, sh_degree=3):
+    SH evaluated for the visible Gaussians inside the call, view directions differentiable -- same Gaussians, camera and
+    cotangents as the headline step (which is MTGS's composition spherical_harmonics() + clamp + rasterization()).  Not part
+    of the headline figure."""
+    from mtgs_amd import rasterization
+    P = {k: dev[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "coeffs")}
+    vm = dev["viewmat"].detach().clone().requires_grad_(True)
+    K, Gc, Ga = dev["K"], dev["Gc"], dev["Ga"]
+
+    def fb():
+        for q in list(P.values()) + [vm]:
+            q.grad = None
+        r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["coeffs"], vm, K, args.width, args.height,
+                                   sh_degree=3, packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+        torch.autograd.backward([r, a], [Gc, Ga])
+    for _ in range(3):
+        fb()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        fb()
+    torch.cuda.synchronize()
+    return {"sh_degree_call_style_ms": round((time.perf_counter() - t0) / 10 * 1e3, 3)}
+
+
 def shipped_cells(args, dev):
     """ms per rasterization() forward + backward with the option set of the shipped config/MTGS.py (6 colour channels +
     expected depth, antialiased, absgrad, viewmat gradient; colours given), same Gaussians: 1920x1080 and 960x540, and the
@@ -500,6 +526,7 @@ def main():
             # what the SHIPPED config/MTGS.py drives (outside the timed region): RGB + camera-space normals + expected depth
             # = 7 blended channels, antialiased, absgrad -- at the headline size and at MTGS's training size 960x540
             out["also"].update(shipped_cells(args, dev))
+            out["also"].update(sh_degree_cell(args, dev))
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)
     if rank == 0:
