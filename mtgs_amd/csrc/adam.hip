@@ -297,7 +297,7 @@ __device__ __forceinline__ void adam_rows_list(const mtgs_adam_group &d, const H
 
 // Scheduling of the LIST groups (they are the LAST groups of a table), one workgroup before the row kernel: for every LIST group
 // the ranks of its tensor's items -- rank_start = first rank whose Gaussian index is >= item_start, rank_count = ranks below
-// item_start + n (row_ids is increasing; two 64-ary searches by one wave, three dependent loads each for 300k rows) -- and, from
+// item_start + n (row_ids is increasing; a 64-ary search by one wave each, three or four dependent loads for 300k rows) -- and, from
 // the counts, the workgroups each group really needs: first_block of the LIST groups is REWRITTEN here (the host launches an
 // upper bound; surplus workgroups leave after one descriptor load).
 __device__ __forceinline__ int64_t wave_lower_bound(const int32_t *__restrict__ ids, int64_t count, int64_t key) {
@@ -316,17 +316,22 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int32_t *__restrict__ 
     }
     return lo;
 }
-__global__ void __launch_bounds__(ADAM_BLOCK) adam_list_schedule_kernel(mtgs_adam_group *__restrict__ table, float *__restrict__ hyper,
-                                                                        int n_groups) {
-    constexpr int MAXG = 2048;                     // groups whose counts are kept in LDS for the prefix (more: read back)
-    __shared__ int s_count[MAXG];                  // -1: not a LIST group
+#define ADAM_SCHED_THREADS 1024
+__global__ void __launch_bounds__(ADAM_SCHED_THREADS) adam_list_schedule_kernel(mtgs_adam_group *__restrict__ table,
+                                                                               float *__restrict__ hyper, int n_groups) {
+    constexpr int MAXG = 2048;                     // groups whose bounds are kept in LDS (more: the second pass reads them back)
+    __shared__ int s_lo[MAXG], s_hi[MAXG];         // rank_start and the first rank past the tensor; s_lo = -1: not a LIST group
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int g = threadIdx.x; g < n_groups && g < MAXG; g += ADAM_BLOCK) s_count[g] = -1;
+    constexpr int WAVES = ADAM_SCHED_THREADS / 64;
+    for (int g = threadIdx.x; g < n_groups && g < MAXG; g += ADAM_SCHED_THREADS) s_lo[g] = -1;
     __syncthreads();
-    for (int g = wave; g < n_groups; g += ADAM_BLOCK / 64) {
+    // one search per wave: task 2 g = the start of group g's ranks, 2 g + 1 = their end (sixteen searches in flight: the two
+    // of a group one after the other in ONE wave, four waves, measured 9.4 us for six groups)
+    for (int task = wave; task < 2 * n_groups; task += WAVES) {
+        const int g = task >> 1, which = task & 1;
         mtgs_adam_group &d = table[g];
         if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) continue;
-        if (d.mode == MTGS_ADAM_ROWS_STEP && lane == 0) {
+        if (which == 0 && d.mode == MTGS_ADAM_ROWS_STEP && lane == 0) {
             // the step's bookkeeping (row_ctx does it for SCAN groups): a LIST group may have no workgroup at all -- a node
             // none of whose Gaussians the frame saw -- and the step still counts
             float *hy = hyper + 4 * (int64_t)d.hyper_index;
@@ -337,26 +342,26 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_list_schedule_kernel(mtgs_ada
         }
         int64_t count = d.n_rows;
         if (d.row_count_dev) { const int64_t c = *d.row_count_dev >> 32; if (c < count) count = c; }
-        const int64_t a = wave_lower_bound(d.row_ids, count, d.item_start);
-        const int64_t b = wave_lower_bound(d.row_ids, count, d.item_start + d.n);
+        const int64_t r = wave_lower_bound(d.row_ids, count, which ? d.item_start + d.n : d.item_start);
         if (lane == 0) {
-            d.rank_start = (int32_t)a; d.rank_count = (int32_t)(b - a);
-            if (g < MAXG) s_count[g] = (int)(b - a);
+            if (which) { if (g < MAXG) s_hi[g] = (int)r; else d.rank_count = (int32_t)r; }        // (> MAXG: end parked in rank_count)
+            else { if (g < MAXG) s_lo[g] = (int)r; d.rank_start = (int32_t)r; }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {      // (counts from LDS: the loop is a chain of stores, not of dependent loads)
+    if (threadIdx.x == 0) {      // (bounds from LDS: the loop is a chain of stores, not of dependent loads)
         int64_t next = -1;
         for (int g = 0; g < n_groups; ++g) {
             int cnt;
             if (g < MAXG) {
-                cnt = s_count[g];
-                if (cnt < 0) continue;
+                if (s_lo[g] < 0) continue;
+                cnt = s_hi[g] - s_lo[g];
             } else {
                 const mtgs_adam_group &e = table[g];
                 if (e.mode < MTGS_ADAM_ROWS_CATCHUP || e.row_ids == nullptr) continue;
-                cnt = e.rank_count;
+                cnt = e.rank_count - e.rank_start;
             }
+            table[g].rank_count = cnt;
             if (next < 0) next = table[g].first_block;      // (the first LIST group keeps the host's value)
             table[g].first_block = next;
             next += ((int64_t)cnt + ADAM_LIST_ROWS - 1) / ADAM_LIST_ROWS;
@@ -528,7 +533,7 @@ extern "C" int mtgs_adam_step(int n_groups, mtgs_adam_group *table, float *hyper
             hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)rows_from_block), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
     }
     if (rows_from_block < total_blocks) {
-        if (flags & 2) hipLaunchKernelGGL(adam_list_schedule_kernel, dim3(1), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
+        if (flags & 2) hipLaunchKernelGGL(adam_list_schedule_kernel, dim3(1), dim3(ADAM_SCHED_THREADS), 0, st, table, hyper, n_groups);
         hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)(total_blocks - rows_from_block)), dim3(ADAM_BLOCK), 0, st, table, hyper,
                            n_groups, rows_from_block);
     }
