@@ -171,6 +171,27 @@ def make_step(args, dev, world):
     return step, step_fwd, all_params, info_box
 
 
+def mtgs_like_iteration_cells():
+    """ms per WHOLE MTGS-style training iteration (scripts/mtgs_like_train.py: multi-traversal background + road node, 2M
+    Gaussians, 960x540, the shipped option set, loss head, densification statistics, optimizer step) captured as ONE HIP graph:
+    visibility-first colours with the fused Adam stepping every row, and with the exact row-lazy optimizer.  Run as child
+    processes (own scene, own allocator); not part of the headline figure; None when a run fails."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for key, extra in (("mtgs_like_iteration_graph_ms", ["--visfirst", "--optimizer", "fused"]),
+                       ("mtgs_like_iteration_graph_rowlazy_ms", ["--visfirst", "--optimizer", "fused", "--row-lazy"])):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "mtgs_like_train.py"), "--shipped", "--graph", "--reps", "24"] + extra,
+                               capture_output=True, text=True, timeout=180, cwd=root)
+            m = re.search(r"one graph launch ([\d.]+) ms wall", r.stdout)
+            res[key] = float(m.group(1)) if (r.returncode == 0 and m) else None
+        except Exception:       # noqa: BLE001
+            res[key] = None
+    return res
+
+
 def sh_degree_cell(args, dev):
     """ms per forward + backward of gsplat's OWN call style at the headline size -- rasterization(colors=coefficients, sh_degree=3):
     SH evaluated for the visible Gaussians inside the call, view directions differentiable -- same Gaussians, camera and
@@ -527,6 +548,7 @@ def main():
             # = 7 blended channels, antialiased, absgrad -- at the headline size and at MTGS's training size 960x540
             out["also"].update(shipped_cells(args, dev))
             out["also"].update(sh_degree_cell(args, dev))
+            out["also"].update(mtgs_like_iteration_cells())
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)
     if rank == 0:
