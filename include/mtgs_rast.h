@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 18
+#define MTGS_RAST_ABI_VERSION 19
 
 enum {
     MTGS_OK = 0,
@@ -513,10 +513,12 @@ typedef struct mtgs_stats_desc {
     float *xys_grad_norm, *vis_counts, *max_2dsize;
 } mtgs_stats_desc;
 /* The same statistics from the compact gradient rows of the one-node rasterization (csrc/stats.hip): table sorted by
- * `start`; the 2-D gradient of visible Gaussian r = rows[r * row_stride + col .. col + 1], col 0 (grad) or 2 (absgrad). */
+ * `start`; the 2-D gradient of visible Gaussian r = rows[r * row_stride + col .. col + 1], col 0 (grad) or 2 (absgrad).
+ * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals -- the number of rows is then min(n_vis, *n_vis_dev >> 32)
+ * (graph mode: n_vis is the capacity of the row buffers). */
 int mtgs_densify_stats_rows(int64_t n_vis, const int32_t *vis_ids, const float *rows, int64_t row_stride, int col,
                             const int32_t *radii, int n_nodes, const mtgs_stats_desc *table, int width, int height,
-                            void *stream);
+                            const int64_t *n_vis_dev, void *stream);
 int mtgs_stats_desc_bytes(void);
 int mtgs_densify_stats_batch(int n_nodes, const mtgs_stats_desc *table, int64_t total_blocks, const int32_t *radii,
                              const float *grad2d, int width, int height, void *stream);

@@ -94,7 +94,7 @@ _SIGNATURES = {
     "mtgs_refine_rows": [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp],
     "mtgs_stats_desc_bytes": [],
     "mtgs_densify_stats_batch": [_i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp],
-    "mtgs_densify_stats_rows": [_i64, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    "mtgs_densify_stats_rows": [_i64, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "mtgs_ncc_patches": [_i32, _i32, _i32, _i32, _i64p],
     "mtgs_ncc_fwd": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_ncc_bwd": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -134,7 +134,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 

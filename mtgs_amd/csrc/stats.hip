@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void densify_stats_rows_kernel(int64_t n_vis, 
                                                                  const float *__restrict__ rows, int64_t row_stride, int col,
                                                                  const int32_t *__restrict__ radii,
                                                                  const mtgs_stats_desc *__restrict__ table, int n_nodes,
-                                                                 float half_w, float half_h) {
+                                                                 float half_w, float half_h, const int64_t *__restrict__ n_vis_dev) {
+    if (n_vis_dev) {       // the count lives on the device (mtgs_front_fwd's packed totals); n_vis is the capacity of the rows
+        const int64_t c = *n_vis_dev >> 32;
+        if (c < n_vis) n_vis = c;
+    }
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_vis) return;
     const int64_t id = vis_ids[r];
@@ -79,13 +83,13 @@ __global__ __launch_bounds__(256) void densify_stats_rows_kernel(int64_t n_vis, 
  * visible Gaussian r (flat index vis_ids[r]) in columns col, col + 1 (0: means2d.grad, 2: means2d.absgrad). */
 extern "C" int mtgs_densify_stats_rows(int64_t n_vis, const int32_t *vis_ids, const float *rows, int64_t row_stride, int col,
                                        const int32_t *radii, int n_nodes, const mtgs_stats_desc *table, int width, int height,
-                                       void *stream) {
+                                       const int64_t *n_vis_dev, void *stream) {
     MTGS_REQUIRE(n_vis >= 0 && n_nodes >= 0 && row_stride >= 4 && (col == 0 || col == 2) && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_densify_stats_rows: bad arguments");
     if (n_vis == 0 || n_nodes == 0) return MTGS_OK;
     MTGS_REQUIRE(vis_ids && rows && radii && table, MTGS_EINVAL, "mtgs_densify_stats_rows: null pointer");
     densify_stats_rows_kernel<<<(unsigned)ceil_div64(n_vis, 256), 256, 0, (hipStream_t)stream>>>(
-        n_vis, vis_ids, rows, row_stride, col, radii, table, n_nodes, 0.5f * (float)width, 0.5f * (float)height);
+        n_vis, vis_ids, rows, row_stride, col, radii, table, n_nodes, 0.5f * (float)width, 0.5f * (float)height, n_vis_dev);
     MTGS_CHECK_LAUNCH("mtgs_densify_stats_rows");
     return MTGS_OK;
 }

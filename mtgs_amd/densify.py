@@ -83,12 +83,13 @@ def update_statistics_all(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii:
 @torch.no_grad()
 def update_statistics_rows(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii: Tensor, grad_rows: Tensor, vis_ids: Tensor,
                            width: int, height: int, starts: Optional[Sequence[int]] = None, absgrad: bool = True,
-                           n_vis: Optional[int] = None) -> None:
+                           n_vis: Optional[int] = None, n_vis_dev: Optional[Tensor] = None) -> None:
     """`update_statistics_all` from the COMPACT gradient rows of the one-node rasterization instead of a dense
     means2d gradient: grad_rows[n_vis, 16] (columns 0-1 the 2-D gradient, 2-3 its absolute-value sum) and vis_ids[n_vis]
     (flat index of each row's Gaussian), as the data-parallel exchange keeps them after the backward
     (mtgs_amd.dist.SparseGradExchange.grad_rows / .vis_ids) -- in that mode no dense gradient exists.  Same update,
-    visible Gaussians only (mtgs_scene_graph.py:1157-1183, vanilla_gaussian_splatting.py:448-474)."""
+    visible Gaussians only (mtgs_scene_graph.py:1157-1183, vanilla_gaussian_splatting.py:448-474).  n_vis_dev (device int64,
+    mtgs_front_fwd's packed totals): the row count on the device (graph mode: the buffers are capacity-sized)."""
     from ._lib import load
     if not stats:
         return
@@ -114,7 +115,7 @@ def update_statistics_rows(stats: Sequence[Tuple[Tensor, Tensor, Tensor]], radii
     from .nodes import upload_table
     tab_dev = upload_table(tab, r.device)
     call("mtgs_densify_stats_rows", nv, ptr(vis_ids), ptr(grad_rows), int(grad_rows.shape[1]), 2 if absgrad else 0, ptr(r),
-         len(stats), ptr(tab_dev), int(width), int(height), stream_of(r))
+         len(stats), ptr(tab_dev), int(width), int(height), ptr(n_vis_dev), stream_of(r))
 
 
 # ------------------------------------------------------------------------------------------------ refinement on device

@@ -186,6 +186,9 @@ class ColorSource:
         self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
         self.camera_normals = None   # camera_to_world [3,4] (device): the rasterization adds MTGS's three camera-space normal channels
         #                              (mtgs_scene_graph.py:526-545, 636-638) after the colours, computed for the VISIBLE Gaussians only
+        self.want_grad_rows = False  # True: the backward leaves the compact gradient rows in .grad_rows / .grad_row_ids / .grad_row_count
+        #                              (columns 0-1 the 2-D gradient, 2-3 absgrad: densify.update_statistics_rows) and writes NO dense absgrad
+        self.grad_rows = self.grad_row_ids = self.grad_row_count = None
         self.optimizer = None   # a FusedAdam with row-lazy colour parameters: prepare() peeks the visible rows for the colour kernel
         self.caught = None
 

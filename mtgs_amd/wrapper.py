@@ -784,8 +784,11 @@ class _FusedRasterization(torch.autograd.Function):
         v_viewmats = torch.empty_like(viewmats) if need[5] else None
         m2d_out = ctx.means2d_ref() if getattr(ctx, "means2d_ref", None) is not None else None
         want_m2d = m2d_out is not None and m2d_out.retains_grad
+        rows_only = cs is not None and getattr(cs, "want_grad_rows", False)
+        if rows_only:   # the caller takes the 2-D gradients from the compact rows (densify.update_statistics_rows): no dense absgrad
+            cs.grad_rows, cs.grad_row_ids, cs.grad_row_count = G, vis_ids, (totals if ctx.graph else None)
         d_m2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if want_m2d else None
-        d_abs = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if (ctx.absgrad and m2d_out is not None) else None
+        d_abs = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if (ctx.absgrad and m2d_out is not None and not rows_only) else None
         c0 = 0 if cs is None else (6 if ctx.n2c is not None else 3)   # (the dense colour gradient covers the other channels only)
         q_rows = None
         if cs is not None and ctx.n2c is not None:   # the normals' gradient: quaternion rows of the visible Gaussians

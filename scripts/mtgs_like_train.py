@@ -196,6 +196,8 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     gs = gaussians_fused(P, c2w, t, n, deferred=vf) if fused else gaussians_chain(P, c2w, t, n)
     colors = gs["rgbs"]
     VISFIRST["cs"] = gs.get("color_source") if vf else None
+    if vf:      # the densification statistics from the compact gradient rows: no dense absgrad / means2d gradient is written
+        VISFIRST["cs"].want_grad_rows = True
     if shipped and vf and VISFIRST["normals"]:
         # the camera-space normals of the VISIBLE Gaussians only, inside the rasterization (channels 3..5 after the colours)
         VISFIRST["cs"].camera_normals = c2w.reshape(-1, 4)[:3].to(torch.float32).contiguous()
@@ -208,7 +210,8 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H,
                                         packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True,
                                         **({"color_source": VISFIRST["cs"]} if vf else {}))
-    info["means2d"].retain_grad()
+    if not vf:
+        info["means2d"].retain_grad()
     if shipped:
         E, bg = shipped["exposure"][t], shipped["bg"]
         rgb, app, depth, normal = output_head(render, alpha, bg, E, depth=True, normal_channel=3) if fused else \
@@ -241,7 +244,12 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     loss.backward()
     sizes = [p["means"].shape[0] for p in P.values()]
     with torch.no_grad():
-        if fused and len(stats) > 2:   # scene graph with object nodes: one launch for all of them
+        if vf:
+            from mtgs_amd.densify import update_statistics_rows
+            cs = VISFIRST["cs"]
+            update_statistics_rows([tuple(s) for s in stats], info["radii"], cs.grad_rows, cs.grad_row_ids, W, H,
+                                   n_vis_dev=cs.grad_row_count)
+        elif fused and len(stats) > 2:   # scene graph with object nodes: one launch for all of them
             update_statistics_all([tuple(s) for s in stats], info["radii"], info["means2d"].absgrad, W, H)
         elif fused:
             start = 0
