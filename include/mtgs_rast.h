@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 19
+#define MTGS_RAST_ABI_VERSION 20
 
 enum {
     MTGS_OK = 0,
@@ -96,6 +96,8 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced.
  * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals; the number of rows is then min(n_vis, *n_vis_dev >> 32)
  * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count).
+ * Rows only: with v_means = v_quats = v_scales = v_opacities = NULL (compact path, no dense by-products) the streaming pass is
+ * skipped and vis_ws[n_vis, 12] = [v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | pad] IS the result (mtgs_node_bwd_rows).
  * x_quat_rows[n_vis, 4] (nullable, compact path only, 16-byte aligned): quaternion gradients of the visible Gaussians that did
  * not come through the projection -- the camera-space normals' (mtgs_normals_bwd_qrows) -- added to v_quats; x_mean_rows[n_vis, 3]
  * (nullable, compact path only): likewise position gradients (the view directions of gsplat's sh_degree colours:
@@ -463,6 +465,13 @@ int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_
                         int64_t *model_id, void *stream);
 int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree, const float *cam_pos,
                         void *stream);
+/* The geometry half of the node backward for the VISIBLE Gaussians: ws_rows[cap_vis, 12] (mtgs_project_bwd, rows only) ->
+ * param_rows[cap_vis, 12] = [means 3 | scales 3 | quats 4 | opacities 1 | pad], the gradients with respect to the RAW parameters of
+ * Gaussian vis_ids[r] (exp / normalise / sigmoid VJPs through the descriptors' scales / quats_raw / opacities), r < min(cap_vis,
+ * *totals >> 32) (totals nullable).  Static nodes only (pose = NULL).  The rows go to mtgs_adam_step through a row map: the dense
+ * geometry gradients (zeros for ~85 % of the Gaussians) are neither written nor read. */
+int mtgs_node_bwd_rows(int n_nodes, const mtgs_node_desc *table, const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis,
+                       const float *ws_rows, float *param_rows, void *stream);
 
 /* ---- camera-space normals of the Gaussians (predict_normals, the shipped MTGS.py config: 3 more blended channels) ------
  * MTGSSceneModel._get_gaussian_camera_space_normals (mtgs_scene_graph.py:526-545), ~25 PyTorch launches per direction and a

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "mtgs_node_desc_bytes": [],
     "mtgs_node_fwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp, _vp],
     "mtgs_node_bwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp],
+    "mtgs_node_bwd_rows": [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_normals_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -134,7 +135,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 

@@ -275,6 +275,42 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_geom_batch_kernel(const m
     d.opacities[gl] = 1.f / (1.f + expf(-orw));
 }
 
+// The geometry half of the node backward for the VISIBLE Gaussians only: the projection backward's workspace rows
+// ws[r] = [v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | pad] (gradients with respect to the ACTIVATED Gaussian vis_ids[r])
+// -> rows of gradients with respect to the raw parameters, out[r] = [means 3 | scales 3 | quats 4 | opacities 1 | pad]: the
+// exp / normalise / sigmoid VJPs of node_bwd_wave, same expressions.  Static nodes (a rigid node reduces a pose gradient over
+// all of its Gaussians: refused by the caller).  The optimizer takes the rows through its row map (adam.hip): no dense
+// [N, .] gradient of the geometry is written or read.
+__global__ __launch_bounds__(NODE_BLOCK) void node_bwd_rows_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
+                                                                   const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
+                                                                   int64_t cap_vis, const float *__restrict__ ws, float *__restrict__ out) {
+    int64_t n_vis = totals ? *totals >> 32 : cap_vis;
+    if (n_vis > cap_vis) n_vis = cap_vis;
+    const int64_t r = (int64_t)blockIdx.x * NODE_BLOCK + threadIdx.x;
+    if (r >= n_vis) return;
+    const int64_t g = vis_ids[r];
+    int lo = 0, hi = n_nodes - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].start <= g) lo = mid; else hi = mid - 1;
+    }
+    const mtgs_node_desc &d = table[lo];
+    const int64_t gl = g - d.start;
+    const float4 *w = reinterpret_cast<const float4 *>(ws + r * 12);
+    const float4 w0 = w[0], w1 = w[1], w2 = w[2];       // (v_mean xyz, vq.w) (vq.xyz', vs.x) (vs.yz, v_opacity, -)
+    const F3 s = *reinterpret_cast<const F3 *>(d.scales + gl * 3);
+    const F4 q = *reinterpret_cast<const F4 *>(d.quats_raw + gl * 4);
+    const F4 vq = F4{w0.w, w1.x, w1.y, w1.z};
+    const float qinv = 1.0f / sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    const F4 qn = F4{q.x * qinv, q.y * qinv, q.z * qinv, q.w * qinv};
+    const float dot = ((vq.x * qn.x + vq.y * qn.y) + vq.z * qn.z) + vq.w * qn.w;                // d (q / |q|)
+    const float o = d.opacities[gl];
+    float4 *dst = reinterpret_cast<float4 *>(out + r * 12);
+    dst[0] = make_float4(w0.x, w0.y, w0.z, w1.w * s.x);                                          // means | d exp = exp
+    dst[1] = make_float4(w2.x * s.y, w2.y * s.z, (vq.x - dot * qn.x) * qinv, (vq.y - dot * qn.y) * qinv);
+    dst[2] = make_float4((vq.z - dot * qn.z) * qinv, (vq.w - dot * qn.w) * qinv, w2.z * o * (1.f - o), 0.f);   // d sigmoid
+}
+
 struct NodeGrads {   // cotangents of the activated Gaussians and the gradients of the raw parameters
     const float *v_scales, *v_quats, *v_opacities, *v_rgbs, *v_means;
     float *g_scales_raw, *g_quats_raw, *g_opac_raw, *g_dc, *g_rest, *g_dc_add, *g_means, *g_pose;
@@ -572,5 +608,18 @@ extern "C" int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int
     MTGS_NODE_DISPATCH(node_bwd_batch_kernel, table, n_nodes, cam_pos)
     node_pose_finalize_kernel<<<(unsigned)((n_nodes + 255) / 256), 256, 0, st>>>(table, n_nodes);
     MTGS_CHECK_LAUNCH("mtgs_node_bwd_batch");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_node_bwd_rows(int n_nodes, const mtgs_node_desc *table, const int32_t *vis_ids, const int64_t *totals,
+                                  int64_t cap_vis, const float *ws_rows, float *param_rows, void *stream) {
+    MTGS_REQUIRE(n_nodes > 0 && cap_vis >= 0, MTGS_EINVAL, "mtgs_node_bwd_rows: bad sizes");
+    if (cap_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(table && vis_ids && ws_rows && param_rows, MTGS_EINVAL, "mtgs_node_bwd_rows: null pointer");
+    MTGS_REQUIRE(((reinterpret_cast<uintptr_t>(ws_rows) | reinterpret_cast<uintptr_t>(param_rows)) & 15) == 0, MTGS_EINVAL,
+                 "mtgs_node_bwd_rows: rows must be 16-byte aligned");
+    node_bwd_rows_kernel<<<(unsigned)ceil_div64(cap_vis, NODE_BLOCK), NODE_BLOCK, 0, (hipStream_t)stream>>>(table, n_nodes, vis_ids, totals,
+                                                                                                       cap_vis, ws_rows, param_rows);
+    MTGS_CHECK_LAUNCH("mtgs_node_bwd_rows");
     return MTGS_OK;
 }

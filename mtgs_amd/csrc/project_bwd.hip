@@ -517,12 +517,14 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
         if (int rc = mtgs_zero_async(v_viewmats, sizeof(float) * 16 * (size_t)C, st)) return rc;
     }
     if (N == 0 || C == 0) return MTGS_OK;
+    const bool rows_only = !v_means && !v_quats && !v_scales && !v_opacities && vis_ids && vis_ws && grad_row_index && C == 1 &&
+                           !d_means2d && !d_means2d_abs && !d_colors;      // (the caller keeps the workspace rows: mtgs_node_bwd_rows)
     MTGS_REQUIRE(means && quats && scales && viewmats && Ks && radii && conics && v_means2d &&
-                     v_depths && v_conics && v_means && v_quats && v_scales,
+                     v_depths && v_conics && (rows_only || (v_means && v_quats && v_scales)),
                  MTGS_EINVAL, "mtgs_project_bwd: null pointer");
     MTGS_REQUIRE(!v_compensations || compensations, MTGS_EINVAL,
                  "mtgs_project_bwd: v_compensations given without compensations");
-    MTGS_REQUIRE(!v_opac_eff || (opacities && v_opacities), MTGS_EINVAL,
+    MTGS_REQUIRE(!v_opac_eff || (opacities && (v_opacities || rows_only)), MTGS_EINVAL,
                  "mtgs_project_bwd: v_opac_eff needs opacities and v_opacities");
     const int64_t dense[5] = {2, 1, 3, 1, 1};
     int64_t rs[5];
@@ -555,7 +557,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
                 v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows);
         }
-        project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
+        if (!rows_only) project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
             N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);
         MTGS_CHECK_LAUNCH("mtgs_project_bwd");
         return MTGS_OK;

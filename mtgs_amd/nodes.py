@@ -186,6 +186,11 @@ class ColorSource:
         self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
         self.camera_normals = None   # camera_to_world [3,4] (device): the rasterization adds MTGS's three camera-space normal channels
         #                              (mtgs_scene_graph.py:526-545, 636-638) after the colours, computed for the VISIBLE Gaussians only
+        self.node_geometry = None    # per node: (means, scales, quats, opacities leaves, is a rigid node)
+        self.geometry_rows = False   # True (static nodes only): the rasterization's backward returns NO gradient for means / quats /
+        #                              scales / opacities; the projection backward's per-visible rows go through mtgs_node_bwd_rows and
+        #                              apply_to() hands them to the optimizer as row gradients of the nodes' raw geometry parameters
+        self.geo_ws = None
         self.want_grad_rows = False  # True: the backward leaves the compact gradient rows in .grad_rows / .grad_row_ids / .grad_row_count
         #                              (columns 0-1 the 2-D gradient, 2-3 absgrad: densify.update_statistics_rows) and writes NO dense absgrad
         self.grad_rows = self.grad_row_ids = self.grad_row_count = None
@@ -221,6 +226,16 @@ class ColorSource:
     def apply_to(self, optimizer) -> None:
         """optimizer.set_row_gradient(...) for every colour parameter of every node (call between backward() and step())."""
         assert self.rows is not None, "backward() of the rasterization first"
+        if self.geometry_rows and self.geo_ws is not None:
+            # the geometry half: rows of raw-parameter gradients of the visible Gaussians (mtgs_node_bwd_rows), one launch
+            ws, ids, totals = self.geo_ws
+            prow = torch.empty_like(ws)
+            call("mtgs_node_bwd_rows", self.n_nodes, ptr(self.table), ptr(ids), ptr(totals), ws.shape[0], ptr(ws), ptr(prow), stream_of(ws))
+            for (start, n, *_), (mn, sc, qt, op, _rigid) in zip(self.node_params, self.node_geometry):
+                ro = self.row_of[start:start + n]
+                for p_, col in ((mn, 0), (sc, 3), (qt, 6), (op, 10)):
+                    if p_.requires_grad:
+                        optimizer.set_row_gradient(p_, prow, ro, col)
         c = getattr(self, "caught", None)
         if c is not None and (optimizer is not self.optimizer or c.shape[0] < self.rows.shape[0]):
             c = None     # (the peeked rows belong to the optimizer that made them, numbered like this frame's gradient rows)
@@ -383,12 +398,18 @@ class _CollectNodes(torch.autograd.Function):
         del keep   # (stream-ordered allocator: the launch above is already enqueued)
         ctx.tab, ctx.dims, ctx.blocks, ctx.degree, ctx.rigid, ctx.deferred = tab, dims, blk, int(degree), rigid, deferred
         ctx.framed = [(i, specs[i][3], flat[_NK * i + 7].shape[0]) for i in framed]
+        ctx.n_flat = len(flat)
+        ctx.set_materialize_grads(False)     # (no zero-filled cotangents: see backward)
         ctx.save_for_backward(cam, scales, opacities, rgbs, mask, pose_all, *saved, *pose_tabs)
         ctx.mark_non_differentiable(model_id)
         return means, scales, quats, opacities, rgbs, model_id
 
     @staticmethod
     def backward(ctx, v_means, v_scales, v_quats, v_opacities, v_rgbs, _v_id):
+        if all(g is None for g in (v_means, v_scales, v_quats, v_opacities, v_rgbs)):
+            # nothing arrived (ColorSource.geometry_rows: the rasterization keeps its geometry gradients as rows for the
+            # optimizer): no launch, and the parameters' .grad stay None
+            return (None, None) + (None,) * ctx.n_flat
         cam, scales, opacities, rgbs, mask, pose_all, *saved = ctx.saved_tensors
         dims, rigid, framed = ctx.dims, ctx.rigid, ctx.framed
         saved = saved[:2 * len(dims)]   # (the pose tables behind them are only kept alive: the table holds their addresses)
@@ -543,6 +564,8 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     if deferred_colors:
         out["rgbs"] = None
         cs, _CollectNodes.last_color_source = _CollectNodes.last_color_source, None
+        cs.node_geometry = [(nd["means"], nd["scales"], nd["quats"], nd["opacities"],
+                             nd.get("instance_quat") is not None or nd.get("instance_quats") is not None) for nd in nodes]
         cs.node_params = [(st, n, nd["features_dc"], nd.get("features_adapters"), nd["features_rest"], nd.get("traversal_index"))
                           for (st, n), nd in zip(cs.node_params, nodes)]
         out["color_source"] = cs

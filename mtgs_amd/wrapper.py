@@ -777,14 +777,19 @@ class _FusedRasterization(torch.autograd.Function):
         if comps is not None and g_comps is not None and n_vis > 0:
             r_cmp = g_comps.reshape(Cn * N)[vi].contiguous()
         need = ctx.needs_input_grad
-        v_means = torch.empty_like(means)
-        v_quats = torch.empty_like(quats)
-        v_scales = torch.empty_like(scales)
-        v_opacities = torch.empty_like(opacities)
+        geo_rows = bool(cs is not None and getattr(cs, "geometry_rows", False) and not direct and n_vis > 0)
+        if geo_rows and (any(g[4] for g in cs.node_geometry) or cs.autograd):
+            raise NotImplementedError("ColorSource.geometry_rows: static nodes only (a rigid node's pose gradient is a sum over its Gaussians)")
+        v_means = None if geo_rows else torch.empty_like(means)
+        v_quats = None if geo_rows else torch.empty_like(quats)
+        v_scales = None if geo_rows else torch.empty_like(scales)
+        v_opacities = None if geo_rows else torch.empty_like(opacities)
         v_viewmats = torch.empty_like(viewmats) if need[5] else None
         m2d_out = ctx.means2d_ref() if getattr(ctx, "means2d_ref", None) is not None else None
         want_m2d = m2d_out is not None and m2d_out.retains_grad
         rows_only = cs is not None and getattr(cs, "want_grad_rows", False)
+        if geo_rows and not rows_only:
+            raise NotImplementedError("ColorSource.geometry_rows needs want_grad_rows (no dense by-products of the projection backward)")
         if rows_only:   # the caller takes the 2-D gradients from the compact rows (densify.update_statistics_rows): no dense absgrad
             cs.grad_rows, cs.grad_row_ids, cs.grad_row_count = G, vis_ids, (totals if ctx.graph else None)
         d_m2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if want_m2d else None
@@ -796,6 +801,8 @@ class _FusedRasterization(torch.autograd.Function):
             call("mtgs_normals_bwd_qrows", n_vis, ptr(vis_ids), ptr(totals) if ctx.graph else None, ptr(quats), ptr(scales), ptr(means),
                  ptr(ctx.n2c), ptr(G), RS, 8 + 3, ptr(q_rows), st)
         d_col = torch.empty((Cn, N, DC - c0), dtype=torch.float32, device=dev) if (DC - c0 and need[4]) else None
+        if geo_rows and (d_col is not None or want_m2d):
+            raise NotImplementedError("ColorSource.geometry_rows: no extra colour channels with a gradient, no retain_grad() on means2d")
         vis_ws = torch.empty((max(n_vis, 1), 12), dtype=torch.float32, device=dev)  # scratch of the compact VJP
         call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
              eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities), ptr(r_xy), ptr(r_dep_total), ptr(r_con),
@@ -823,6 +830,9 @@ class _FusedRasterization(torch.autograd.Function):
         v_bg = None
         if bg is not None and need[7] and v_render is not None:
             v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
+        if geo_rows:      # the per-visible rows ARE the geometry gradient (ColorSource.apply_to -> mtgs_node_bwd_rows -> the optimizer)
+            cs.geo_ws = (vis_ws, vis_ids, totals if ctx.graph else None)
+            return (None, None, None, None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos)
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
                 v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos)
 

@@ -182,7 +182,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
         start += n
 
 
-VISFIRST = {"on": False, "cs": None, "normals": True}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
+VISFIRST = {"on": False, "cs": None, "normals": True, "geometry_rows": False}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
 ROWLAZY = {"on": False, "opt": None}     # --row-lazy: exact row-lazy Adam for the colour parameters (needs --visfirst --optimizer fused)
 LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
 
@@ -198,6 +198,7 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     VISFIRST["cs"] = gs.get("color_source") if vf else None
     if vf:      # the densification statistics from the compact gradient rows: no dense absgrad / means2d gradient is written
         VISFIRST["cs"].want_grad_rows = True
+        VISFIRST["cs"].geometry_rows = VISFIRST["geometry_rows"] and not any("instance_quats" in p for p in P.values())
     if shipped and vf and VISFIRST["normals"]:
         # the camera-space normals of the VISIBLE Gaussians only, inside the rasterization (channels 3..5 after the colours)
         VISFIRST["cs"].camera_normals = c2w.reshape(-1, 4)[:3].to(torch.float32).contiguous()
@@ -520,6 +521,9 @@ def main():
                     "slices are left untouched by a step and caught up (bit-identically) before their traversal is rendered again")
     ap.add_argument("--dense-normals", action="store_true", help="with --visfirst --shipped: the camera-space normals of EVERY Gaussian "
                     "as extra colour channels (mtgs_amd.nodes.camera_space_normals) instead of the visible ones inside the rasterization")
+    ap.add_argument("--geometry-rows", action="store_true", help="with --visfirst --optimizer fused (static nodes): the geometry gradients "
+                    "stay rows of the visible Gaussians all the way to the optimizer (mtgs_node_bwd_rows): no dense expansion, no dense "
+                    "node backward")
     ap.add_argument("--row-lazy", action="store_true", help="with --visfirst --optimizer fused: exact row-lazy Adam -- the colour "
                     "parameters are stepped for the VISIBLE rows of the rendered traversal only and a row is caught up (bit-identically) "
                     "right before the forward reads it (mtgs_amd.optim.FusedAdam.set_row_lazy)")
@@ -528,6 +532,9 @@ def main():
     args = ap.parse_args()
     VISFIRST["on"] = bool(args.visfirst)
     VISFIRST["normals"] = not args.dense_normals
+    VISFIRST["geometry_rows"] = bool(args.geometry_rows)
+    if args.geometry_rows and not (args.visfirst and args.optimizer in (None, "fused")):
+        raise SystemExit("--geometry-rows needs --visfirst and the fused optimizer")
     LAZY["on"] = bool(args.lazy_adam)
     ROWLAZY["on"] = bool(args.row_lazy)
     if ROWLAZY["on"] and not (args.visfirst and args.optimizer in (None, "fused")) or (ROWLAZY["on"] and LAZY["on"]):

@@ -324,3 +324,24 @@ def test_mtgs_like_training_visibility_first_equals_dense_colours():
     from tests.util import assert_same_training
     for other in outs[1:]:
         assert_same_training(other, outs[0], 2, 45, 20)
+
+
+def test_mtgs_like_training_geometry_rows_and_row_lazy_equal_the_autograd_path():
+    """scripts/mtgs_like_train.py --visfirst --row-lazy --geometry-rows (static nodes): the geometry gradients stay rows of the
+    visible Gaussians all the way to the optimizer (no dense expansion, no dense node backward), the colour tensors are stepped
+    row-lazily -- same refinements and loss curve as the run whose geometry gradients go through autograd and whose optimizer
+    steps every row."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "3", "--width", "320", "--height", "200",
+              "--steps", "45", "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped", "--optimizer", "fused", "--visfirst"]
+    outs = []
+    for extra in ([], ["--row-lazy", "--geometry-rows"]):
+        r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py")] + common + extra, capture_output=True,
+                           text=True, timeout=900, cwd=str(root))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        outs.append(r.stdout)
+    from tests.util import assert_same_training
+    assert_same_training(outs[1], outs[0], 2, 45, 20)

@@ -397,3 +397,79 @@ def test_visibility_first_colours_equal_the_dense_node_path(hip_lib, degree, ext
     n0 = raw[0]["means"].shape[0]
     assert torch.equal(Pv[0]["features_rest"][~vis[:n0]].detach().cpu(), raw[0]["features_rest"][~vis[:n0].cpu()])
     assert torch.equal(Pv[1]["features_rest"][:, 0].detach().cpu(), raw[1]["features_rest"][:, 0])
+
+
+def test_geometry_rows_equal_the_dense_geometry_gradients(hip_lib):
+    """ColorSource.geometry_rows: the rasterization returns no gradient for means / quats / scales / opacities; the projection
+    backward's per-visible rows go through mtgs_node_bwd_rows (exp / normalise / sigmoid VJPs) and reach the optimizer as row
+    gradients of the RAW parameters.  Against the autograd path (dense expansion + node_bwd_batch) on two static nodes: the rows,
+    expanded, equal the dense gradients; the parameters' .grad stay None; the camera-space normals inside; rigid nodes refused."""
+    from mtgs_amd import rasterization
+    from mtgs_amd.nodes import collect_gaussians
+    from mtgs_amd.optim import FusedAdam
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    W, H, T, t = 320, 200, 2, 1
+    g = torch.Generator().manual_seed(41)
+
+    def node(n, multi, seed):
+        gg = torch.Generator().manual_seed(seed)
+        P = {"means": (torch.rand(n, 3, generator=gg) * 2 - 1) * torch.tensor([8.0, 2.0, 8.0]) + torch.tensor([0.0, 0.0, 6.0]),
+             "scales": torch.log(torch.rand(n, 3, generator=gg) * 0.2 + 0.03), "quats": torch.randn(n, 4, generator=gg),
+             "opacities": torch.randn(n, 1, generator=gg), "features_dc": torch.randn(n, 3, generator=gg) * 0.7,
+             "features_rest": torch.randn(n, T, 15, 3, generator=gg) * 0.2 if multi else torch.randn(n, 15, 3, generator=gg) * 0.2}
+        if multi:
+            P["features_adapters"] = torch.randn(n, T, 3, generator=gg) * 0.1
+        return P
+    raw = [node(6000, False, 1), node(5003, True, 2)]
+    vm, K = make_camera(W, H)
+    vm, K = vm.to(dev), K.to(dev)
+    c2w = torch.inverse(vm)[:, :3, :]
+    Gc = torch.randn(1, H, W, 7, generator=g).to(dev)
+    Ga = torch.randn(1, H, W, 1, generator=g).to(dev)
+
+    def run(geo):
+        P = [{k: v.clone().to(dev).requires_grad_(True) for k, v in nd.items()} for nd in raw]
+        nodes = [dict(p, traversal_index=t) if "features_adapters" in p else p for p in P]
+        gs = collect_gaussians(nodes, c2w, 3, deferred_colors=True)
+        cs = gs["color_source"]
+        cs.camera_normals = c2w[0].contiguous()
+        cs.want_grad_rows = cs.geometry_rows = geo
+        r, a, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], None, vm, K, W, H, packed=False,
+                                   render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True, color_source=cs)
+        torch.autograd.backward([r, a], [Gc, Ga])
+        return P, cs, r.detach(), info
+
+    Pd, _, rd, info = run(False)
+    Pg, cs, rg, _ = run(True)
+    assert torch.equal(rd, rg)
+    geo_keys = ("means", "scales", "quats", "opacities")
+    for p in Pg:
+        assert all(p[k].grad is None for k in geo_keys)            # nothing dense was written
+    opt = FusedAdam([{"params": [p[k] for p in Pg for k in p], "lr": 1e-3}], eps=1e-15)
+    cs.apply_to(opt)
+    vis = info["radii"][0] > 0
+    start = 0
+    for pd, pg in zip(Pd, Pg):
+        n = pd["means"].shape[0]
+        for k in geo_keys:
+            rows, row_of, col, stride, width = opt._rows[id(pg[k])][:5]
+            dense = torch.zeros(n, width, device=dev)
+            sel = row_of >= 0
+            dense[sel] = rows[row_of[sel].long(), col:col + width]
+            ref = pd[k].grad.reshape(n, width)
+            assert torch.equal(sel, vis[start:start + n])
+            assert float((dense - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9, k      # (fp32 atomics order in the rows)
+        start += n
+    opt.step()                                                      # (the optimizer takes them: smoke)
+    # a rigid node is refused
+    rig = dict(node(500, False, 3))
+    Pr = {k: v.clone().to(dev).requires_grad_(True) for k, v in rig.items()}
+    Pr["instance_quat"], Pr["instance_trans"] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev), torch.zeros(3, device=dev)
+    gs = collect_gaussians([Pr], c2w, 3, deferred_colors=True)
+    cs2 = gs["color_source"]
+    cs2.want_grad_rows = cs2.geometry_rows = True
+    r, a, _ = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], None, vm, K, W, H, packed=False,
+                            render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True, color_source=cs2)
+    with pytest.raises(NotImplementedError):
+        torch.autograd.backward([r, a], [Gc[..., :4].contiguous(), Ga])
