@@ -174,14 +174,16 @@ def make_step(args, dev, world):
 def mtgs_like_iteration_cells():
     """ms per WHOLE MTGS-style training iteration (scripts/mtgs_like_train.py: multi-traversal background + road node, 2M
     Gaussians, 960x540, the shipped option set, loss head, densification statistics, optimizer step) captured as ONE HIP graph:
-    visibility-first colours with the fused Adam stepping every row, and with the exact row-lazy optimizer.  Run as child
+    visibility-first colours with the fused Adam stepping every row, with the exact row-lazy optimizer, and with the geometry
+    gradients kept as rows on top of it.  Run as child
     processes (own scene, own allocator); not part of the headline figure; None when a run fails."""
     import re
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     res = {}
     for key, extra in (("mtgs_like_iteration_graph_ms", ["--visfirst", "--optimizer", "fused"]),
-                       ("mtgs_like_iteration_graph_rowlazy_ms", ["--visfirst", "--optimizer", "fused", "--row-lazy"])):
+                       ("mtgs_like_iteration_graph_rowlazy_ms", ["--visfirst", "--optimizer", "fused", "--row-lazy"]),
+                       ("mtgs_like_iteration_graph_rowlazy_georows_ms", ["--visfirst", "--optimizer", "fused", "--row-lazy", "--geometry-rows"])):
         try:
             r = subprocess.run([sys.executable, os.path.join(root, "scripts", "mtgs_like_train.py"), "--shipped", "--graph", "--reps", "24"] + extra,
                                capture_output=True, text=True, timeout=180, cwd=root)
