@@ -239,12 +239,12 @@ class ColorSource:
         c = getattr(self, "caught", None)
         if c is not None and (optimizer is not self.optimizer or c.shape[0] < self.rows.shape[0]):
             c = None     # (the peeked rows belong to the optimizer that made them, numbered like this frame's gradient rows)
-        lazy = getattr(optimizer, "_rowlazy", {})
+        is_lazy = getattr(optimizer, "is_row_lazy", lambda p: False)
         ids = getattr(self, "row_ids", None)
 
         def ck(p, col, start):
             kw = {}
-            if id(p) in lazy:
+            if is_lazy(p):
                 if c is not None:
                     kw["caught"] = (c, col)
                 if ids is not None:

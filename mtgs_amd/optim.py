@@ -235,6 +235,10 @@ class FusedAdam(torch.optim.Optimizer):
                                     "last": torch.full((param.shape[0] * T,), s0, dtype=torch.int32, device=param.device),
                                     "hist": torch.zeros(2 * cap, dtype=torch.float32, device=param.device)}
 
+    def is_row_lazy(self, param: torch.Tensor) -> bool:
+        """True when set_row_lazy() was called for this parameter."""
+        return id(param) in self._rowlazy
+
     def _rows_target(self, p) -> int:
         """The step zero-gradient catch-up goes up to: the steps already TAKEN.  Known to the host in eager use; once a step
         has been captured in a HIP graph only the device knows (< 0: the kernel reads it next to the step's scalars)."""
