@@ -185,6 +185,26 @@ def mtgs_like_iteration_cells():
     res = {}
     budget_s = float(os.environ.get("MTGS_BENCH_EXTRA_BUDGET_S", "150"))    # (a fresh box spends a minute or two importing torch: the
     #   extras must not push the run past "a few minutes"; a cell that does not fit the budget is reported as None)
+    # the loop that TRAINS, through HIP graphs (train_loop(graph=True)): 600 steps from a perturbed subset of the true Gaussians
+    # with the reference's refinement rules, refinements at 300 / 400 / 500; wall clock per step with the re-captures and the
+    # refinements inside, the GPU time per step of a stretch without either, and the loss it reached
+    left = budget_s - (time.time() - _T0)
+    res["mtgs_like_training_ms_per_step"] = res["mtgs_like_training_steady_ms"] = res["mtgs_like_training_loss"] = None
+    if left >= 30:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "mtgs_like_train.py"), "--shipped", "--visfirst", "--optimizer",
+                                "fused", "--row-lazy", "--geometry-rows", "--only", "fused", "--reps", "1", "--converge", "--grad-thresh", "1e-3",
+                                "--clear-radius", "12", "--steps", "600", "--refine-every", "100", "--densify-from", "250", "--steady", "60",
+                                "260", "--train-graph"], capture_output=True, text=True, timeout=min(180.0, left), cwd=root)
+            m = re.search(r"timing: ([\d.]+) ms per step", r.stdout)
+            sm = re.search(r"steady: ([\d.]+) ms per step", r.stdout)
+            cm = re.search(r"converge: loss ([\d.]+) -> ([\d.]+) .* through (\d+) refinements", r.stdout)
+            if r.returncode == 0 and m:
+                res["mtgs_like_training_ms_per_step"] = float(m.group(1))
+                res["mtgs_like_training_steady_ms"] = float(sm.group(1)) if sm else None
+                res["mtgs_like_training_loss"] = [float(cm.group(1)), float(cm.group(2)), int(cm.group(3))] if cm else None
+        except Exception:       # noqa: BLE001
+            pass
     for key, extra in (("mtgs_like_iteration_graph_ms", ["--visfirst", "--optimizer", "fused"]),
                        ("mtgs_like_iteration_graph_rowlazy_ms", ["--visfirst", "--optimizer", "fused", "--row-lazy"]),
                        ("mtgs_like_iteration_graph_rowlazy_georows_ms", ["--visfirst", "--optimizer", "fused", "--row-lazy", "--geometry-rows"])):
@@ -199,6 +219,54 @@ def mtgs_like_iteration_cells():
             res[key] = float(m.group(1)) if (r.returncode == 0 and m) else None
         except Exception:       # noqa: BLE001
             res[key] = None
+    return res
+
+
+def c1_c2_cells(args, device):
+    """BASELINE configs[0] and configs[1] on the driver's box (untimed extras; parity for both is in tests/test_gpu_fullsize.py):
+    C1 = 100k Gaussians, 640x480, colours given (SH deg 0), RGB / classic, FORWARD only -- the HIP path beside the CPU oracle's
+    forward on the same inputs (the C1 CPU-vs-HIP forward timing); C2 = 500k Gaussians, 1920x1080, SH deg 3,
+    forward + backward with the MTGS option set.  Median of 20 (C1) / 10 (C2) after 3 warm-ups, HIP events."""
+    import copy
+    import numpy as np
+    res = {}
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    a1 = copy.copy(args)
+    a1.n_gaussians, a1.width, a1.height, a1.variant = 100_000, 640, 480, "lean"
+    host1, dev1 = build_inputs(a1, 0, device)
+    _, fwd1, _, _ = make_step(a1, dev1, 1)
+    with torch.no_grad():
+        res["c1_100k_640x480_fwd_ms"] = round(timed(fwd1, 20), 4)
+    try:
+        from oracle import oracle as orc
+        orc.build()
+        orc.select_native()
+        h = {k: v.numpy() for k, v in host1.items()}
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            orc.rasterization(h["means"], h["quats"], h["scales"], h["opacities"], h["colors"], h["viewmat"], h["K"], 640, 480)
+            ts.append(time.perf_counter() - t0)
+        res["cpu_c1_fwd_ms"] = round(sorted(ts)[2] * 1e3, 2)
+        res["cpu_c1_cores"] = orc.num_threads()
+    except Exception:       # noqa: BLE001
+        res["cpu_c1_fwd_ms"] = None
+    a2 = copy.copy(args)
+    a2.n_gaussians, a2.width, a2.height, a2.variant = 500_000, 1920, 1080, "mtgs"
+    _, dev2 = build_inputs(a2, 0, device)
+    step2, _, _, _ = make_step(a2, dev2, 1)
+    res["c2_500k_sh3_1080p_ms"] = round(timed(step2, 10), 4)
     return res
 
 
@@ -558,6 +626,7 @@ def main():
             # = 7 blended channels, antialiased, absgrad -- at the headline size and at MTGS's training size 960x540
             out["also"].update(shipped_cells(args, dev))
             out["also"].update(sh_degree_cell(args, dev))
+            out["also"].update(c1_c2_cells(args, device))
             out["also"].update(mtgs_like_iteration_cells())
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(args, host, args.cpu_steps)

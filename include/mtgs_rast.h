@@ -688,7 +688,7 @@ int mtgs_rows_expand(int64_t N, int width, const int32_t *row_of, const float *r
 typedef struct mtgs_adam_group {
     float *p, *m, *v;           /* parameter, exp_avg, exp_avg_sq: n floats each, updated in place */
     const float *g;             /* dense gradient or NULL */
-    const float *rows;          /* compact gradient rows or NULL */
+    const float *rows;          /* compact gradient rows or NULL; streaming groups (DENSE / SLICE) with BOTH take g + the row */
     const int32_t *row_of;      /* [n / width] row of every item, < 0: none */
     const float *catchup;       /* catchup_k > 0: {step_size, bc2_sqrt} of the catchup_k steps to apply, oldest first (DEVICE) */
     int32_t *last;              /* row-lazy groups: [n, T] step up to which slice (i, t) of item i is current */

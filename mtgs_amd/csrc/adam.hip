@@ -13,6 +13,9 @@
 //          sees ~15 % of a road block).  Culled Gaussians get the exact zero-gradient update (their moments decay, the
 //          parameter keeps moving along exp_avg) without a dense gradient tensor ever being written or read; for a
 //          per-traversal tensor [N, T, ...] only the slice of the frame's traversal takes the row (sub_width / sub_index).
+//   both   (streaming groups) g + the row: the loss terms that reach a parameter outside the rasterization (MTGS's scale /
+//          sharp-shape / out-of-box regularisers, mtgs_scene_graph.py:939-981) leave a dense param.grad while the
+//          rasterization's own gradient arrives as rows.
 //
 // Arithmetic = torch.optim.Adam (amsgrad = False, maximize = False), fp32, in torch's operation order:
 //   g += weight_decay * p;  m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g;
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
                     g[u] = 0.f;
                     if (d.catchup_k == 0) {
                         if (dense) g[u] = d.g[phys[u]];
-                        else if (rows) { const int32_t r = d.row_of[i]; g[u] = (r < 0 || r >= d.n_rows) ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c]; }
+                        if (rows) { const int32_t r = d.row_of[i]; g[u] += (r < 0 || r >= d.n_rows) ? 0.f : d.rows[(int64_t)r * d.row_stride + d.row_col + c]; }
                     }
                 }
             }
@@ -439,10 +442,10 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
             v[u] = ld4<NT>(V + e);
             if (dense) g[u] = ld4<NT>(d.g + e);
         }
-        if (!dense) {
+        if (!dense || rows) {      // (both sources: the dense gradient of the terms outside the rasterization + the rows)
 #pragma unroll
             for (int u = 0; u < ADAM_UNROLL; ++u) {
-                g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!dense) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rows) {
                     const int64_t e = base + ((int64_t)u * ADAM_BLOCK + threadIdx.x) * ADAM_VEC;
                     int64_t i = e / d.width;
@@ -453,7 +456,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
                         t[k] = row_grad(d, i, c);
                         if (++c == d.width) { c = 0; ++i; }
                     }
-                    g[u] = make_float4(t[0], t[1], t[2], t[3]);
+                    g[u] = make_float4(g[u].x + t[0], g[u].y + t[1], g[u].z + t[2], g[u].w + t[3]);
                 }
             }
         }
@@ -475,7 +478,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
     for (int64_t e = base + threadIdx.x; e < end; e += ADAM_BLOCK) {
         float g = 0.f;
         if (dense) g = d.g[e];
-        else if (rows) { const int64_t i = e / d.width; g = row_grad(d, i, (int)(e - i * d.width)); }
+        if (rows) { const int64_t i = e / d.width; g += row_grad(d, i, (int)(e - i * d.width)); }
         float p = P[e], m = M[e], v = V[e];
         adam_update(p, m, v, g, h);
         P[e] = p; M[e] = m; V[e] = v;

@@ -298,13 +298,16 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_rows_kernel(const mtgs_no
     const int64_t gl = g - d.start;
     const float4 *w = reinterpret_cast<const float4 *>(ws + r * 12);
     const float4 w0 = w[0], w1 = w[1], w2 = w[2];       // (v_mean xyz, vq.w) (vq.xyz', vs.x) (vs.yz, v_opacity, -)
-    const F3 s = *reinterpret_cast<const F3 *>(d.scales + gl * 3);
+    // exp / sigmoid recomputed from the RAW parameters (the expressions of the forward, so the same bits): the activated
+    // tensors are autograd outputs that are released when the backward has run, i.e. before this kernel is enqueued
+    const F3 sr = *reinterpret_cast<const F3 *>(d.scales_raw + gl * 3);
+    const F3 s = F3{expf(sr.x), expf(sr.y), expf(sr.z)};
     const F4 q = *reinterpret_cast<const F4 *>(d.quats_raw + gl * 4);
     const F4 vq = F4{w0.w, w1.x, w1.y, w1.z};
     const float qinv = 1.0f / sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
     const F4 qn = F4{q.x * qinv, q.y * qinv, q.z * qinv, q.w * qinv};
     const float dot = ((vq.x * qn.x + vq.y * qn.y) + vq.z * qn.z) + vq.w * qn.w;                // d (q / |q|)
-    const float o = d.opacities[gl];
+    const float o = 1.f / (1.f + expf(-d.opacities_raw[gl]));
     float4 *dst = reinterpret_cast<float4 *>(out + r * 12);
     dst[0] = make_float4(w0.x, w0.y, w0.z, w1.w * s.x);                                          // means | d exp = exp
     dst[1] = make_float4(w2.x * s.y, w2.y * s.z, (vq.x - dot * qn.x) * qinv, (vq.y - dot * qn.y) * qinv);

@@ -360,7 +360,7 @@ class _CollectNodes(torch.autograd.Function):
             dc_c, s_dc = _rows(dc, 3)
             add_c, s_add = _rows(add, 3)
             rest_c, s_rest = _rows(rest, Kr * 3)
-            keep += [sr_c, o_c, dc_c, add_c, rest_c]
+            keep += [sr_c, qr_c, o_c, dc_c, add_c, rest_c]   # (ColorSource: what the table's raw-parameter pointers refer to)
             saved += [m_c, qr_c]
             dims.append((n, Kr, orw.shape, add is not None, T, int(trav), start))
             for k, v in zip(col, (m_c.data_ptr(), sr_c.data_ptr(), qr_c.data_ptr(), o_c.data_ptr(), dc_c.data_ptr(),

@@ -14,6 +14,9 @@ Two gradient sources per parameter:
   * `set_row_gradient(p, rows, row_of, col)`: compact gradient rows of the VISIBLE Gaussians plus a map Gaussian -> row
     (< 0: not visible).  Gaussians without a row get the exact zero-gradient Adam update -- the moments decay, the
     parameter keeps moving along exp_avg -- without a dense gradient tensor ever being written or read.
+  * both: a parameter with a row gradient AND a `p.grad` (a loss term that reaches it outside the rasterization: MTGS's
+    scale / sharp-shape / out-of-box regularisers, mtgs_scene_graph.py:939-981) is stepped with their sum; for a ROW-LAZY
+    parameter a dense gradient is an error (every row would have to be stepped), raised by step().
 
 Exact lazy Adam for per-traversal tensors (`set_lazy_slices(param)` for `[N, T, ...]` parameters: MTGS's features_rest /
 features_adapters): a step renders ONE traversal; the other traversals' slices only decay.  A lazy parameter's step touches
@@ -117,7 +120,8 @@ class FusedAdam(torch.optim.Optimizer):
         """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
         Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
         int32 [N].  slice_index = t for a per-traversal tensor `param[N, T, ...]`: only `param[:, t]` takes the row (width =
-        elements of one slice), the other traversals get the zero gradient.  `param.grad` is ignored for this parameter.
+        elements of one slice), the other traversals get the zero gradient.  A `param.grad` present at step() is ADDED (terms
+        outside the rasterization); row-lazy parameters refuse one.
         caught: row-lazy parameters -- the up-to-date rows peek_rows() left for THIS frame (same row numbering); the step then
         takes the parameter from them and only replays the moments of the missed steps.
         row_ids = (ids int32 [R] increasing, start, count | None): row-lazy parameters -- the frame's list of visible Gaussians
@@ -234,6 +238,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._rowlazy[id(param)] = {"param": param, "T": T, "cap": cap,
                                     "last": torch.full((param.shape[0] * T,), s0, dtype=torch.int32, device=param.device),
                                     "hist": torch.zeros(2 * cap, dtype=torch.float32, device=param.device)}
+
+    def forget(self, param: torch.Tensor) -> None:
+        """Drop everything held for `param` (row-lazy / lazy records with their `last` / `hist` buffers, a pending row gradient,
+        its state): for parameters a refinement REPLACED when the optimizer itself lives on.  flush() first if the old values
+        are still to be read.  (The records hold their parameter, so an id is never reused while a record exists.)"""
+        for d in (self._rowlazy, self._lazy, self._rows, self._active_slice, self._hyper_index):
+            d.pop(id(param), None)
+        self.state.pop(param, None)
+        self._table_key = self._catch_key = None
 
     def is_row_lazy(self, param: torch.Tensor) -> bool:
         """True when set_row_lazy() was called for this parameter."""
@@ -403,7 +416,11 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 g = None
-                if src is None:
+                if p.grad is not None:
+                    if src is not None and id(p) in self._rowlazy:
+                        raise RuntimeError("FusedAdam: a row-lazy parameter has a dense .grad next to its row gradient (a loss term outside "
+                                           "the rasterization reaches it: every row would have to be stepped) -- detach that term or "
+                                           "do not make the parameter row-lazy")
                     g = p.grad
                     if g.is_sparse:
                         raise RuntimeError("FusedAdam: sparse gradients are passed with set_row_gradient()")
@@ -446,7 +463,7 @@ class FusedAdam(torch.optim.Optimizer):
                 r["g"] = g.data_ptr()
                 align |= g.data_ptr()
                 keep.append(g)
-            elif src is not None:
+            if src is not None:         # (with a dense gradient too: the kernel adds them)
                 rows, row_of, col, stride, width, sub_w, sub_i, caught, rid = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 r["n_rows"] = rows.shape[0]
@@ -503,6 +520,21 @@ class FusedAdam(torch.optim.Optimizer):
         self._blocks = fb
         self._keep = keep
         return self._table_dev
+
+    def inherit_layout(self, old: "FusedAdam") -> None:
+        """After a refinement replaced the parameters: `self` was built over the NEW parameters with the same groups in the same
+        order as `old`, and every stepped tensor has its moments already.  Takes over what an eager step() would otherwise have
+        to establish before a step() can be CAPTURED: the device scalars (one row per stepped tensor) and each tensor's row in
+        them, by position in the groups.  advance() fills the scalars in front of the first replay."""
+        if not old._active or old._hyper_dev is None:
+            return
+        if self._hyper_dev is None or self._hyper_dev.numel() != 4 * len(old._active):
+            self._hyper_dev = torch.zeros(4 * len(old._active), dtype=torch.float32, device=old._hyper_dev.device)
+        for g_new, g_old in zip(self.param_groups, old.param_groups):
+            for p_new, p_old in zip(g_new["params"], g_old["params"]):
+                hi = old._hyper_index.get(id(p_old))
+                if hi is not None:
+                    self._hyper_index[id(p_new)] = hi
 
     def advance(self, active_slice: Optional[int] = None) -> None:
         """In front of every replay of a HIP graph that captured step(): increments the step count of the tensors that
@@ -564,7 +596,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._active = act
         if not act:
             return loss
-        self._hyper_index = {id(a[1]): i for i, a in enumerate(act)}
+        index = {id(a[1]): i for i, a in enumerate(act)}
+        if torch.cuda.is_current_stream_capturing() and any(self._hyper_index.get(k, v) != v for k, v in index.items()):
+            # (the forward of this capture peeked with the rows inherit_layout() handed over)
+            raise RuntimeError("FusedAdam: the captured step orders its tensors differently from the optimizer whose layout was inherited")
+        self._hyper_index = index
         if not torch.cuda.is_current_stream_capturing():
             self._advance(act)
         elif self._hyper_dev is None or self._hyper_dev.numel() != 4 * len(act):

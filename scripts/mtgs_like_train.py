@@ -15,6 +15,7 @@ Prints the per-iteration GPU time of both and checks that they compute the same 
 import argparse
 import json
 import math
+import os
 import sys
 import time
 from pathlib import Path
@@ -33,10 +34,18 @@ from mtgs_amd.synthetic import make_camera  # noqa: E402
 FRAMES = 40   # frames of an object's pose parameters
 
 
-def make_nodes(n_bg, n_road, T, seed, dev, n_objects=0, object_size=3000):
+def make_nodes(n_bg, n_road, T, seed, dev, n_objects=0, object_size=3000, clear=0.0):
+    """clear > 0: nothing within that many metres (in the ground plane) of the cameras' position, the origin -- as on a road
+    block, where the cameras ride on a car and nothing is splatted a metre in front of the lens."""
     g = torch.Generator().manual_seed(seed)
+    def place(n, extent, y0):
+        m = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor(extent) + torch.tensor([0.0, y0, 0.0])
+        if clear > 0:
+            r = m[:, [0, 2]].norm(dim=-1, keepdim=True).clamp_min(1e-6)
+            m[:, [0, 2]] = m[:, [0, 2]] * torch.clamp(clear / r, min=1.0)
+        return m
     def base(n, extent, y0):
-        return {"means": (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor(extent) + torch.tensor([0.0, y0, 0.0]),
+        return {"means": place(n, extent, y0),
                 "scales": torch.log(torch.exp(torch.rand(n, 3, generator=g) * (math.log(0.25) - math.log(0.03)) + math.log(0.03))),
                 "quats": torch.randn(n, 4, generator=g), "opacities": torch.randn(n, 1, generator=g) + 1.0,
                 "features_dc": (torch.rand(n, 3, generator=g) - 0.5) / 0.2820947917738781}
@@ -185,6 +194,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
 VISFIRST = {"on": False, "cs": None, "normals": True, "geometry_rows": False}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
 ROWLAZY = {"on": False, "opt": None}     # --row-lazy: exact row-lazy Adam for the colour parameters (needs --visfirst --optimizer fused)
 LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
+LAST = {"info": {}}                      # the device scalars of the last rasterization's `info` (graph mode: overflow flag and counts)
 
 
 def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
@@ -211,6 +221,8 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H,
                                         packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True,
                                         **({"color_source": VISFIRST["cs"]} if vf else {}))
+    LAST["info"] = {k: info[k] for k in ("overflow", "n_visible", "n_intersections") if k in info}   # (not `info` itself: its
+    #   means2d would keep this iteration's autograd graph -- and its AccumulateGrad nodes -- alive into the next capture)
     if not vf:
         info["means2d"].retain_grad()
     if shipped:
@@ -232,6 +244,9 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)     # use_ssim_on_raw_rgb
         ncc = depth_ncc_loss(depth, gt_d, 32, 16, mask=dmask) if fused else ncc_chain(depth, gt_d, 32, 16, mask=dmask)   # :886-894
         # pixels nothing was splatted on have a 0/0 normal; MTGS adds the term only when it is finite (mtgs_scene_graph.py:939)
+        if os.environ.get("MTGS_LOSS_DEBUG"):
+            print("terms: l1 %.4f ssim %.4f depth %.4f normal %.4f ncc %.4f | n_vis %d alpha mean %.3f" % (
+                float(l1), float(ssim), float(loss_d), float(loss_n), float(ncc), int((info["radii"] > 0).sum()), float(alpha.mean())))
         if fused:      # 0.8 l1 + 0.2 (1 - ssim) + 0.5 depth + 0.1 normal (when finite) + 0.1 ncc, one launch
             loss = combine_losses([l1, ssim, loss_d, loss_n, ncc], [0.8, -0.2, 0.5, 0.1, 0.1], constant=0.2, drop_if_not_finite=(3,))
         else:
@@ -338,27 +353,35 @@ def iteration_nograd(P, cam, gt, mask, stats, win, W, H, shipped):
     return 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
 
 
-def refine_device(P, stats, opt_state_of, step, seed, growth=0.02):
+def refine_device(P, stats, opt_state_of, step, seed, growth=0.02, cfg=None):
     """Densification of every static node with mtgs_amd.densify.refine_gaussians (csrc/refine.hip): the reference's rules
     (vanilla_gaussian_splatting.py:476-699) on the device, Adam moments following their rows, samples from a generator keyed
     by (seed, step, Gaussian index) -- identical on every rank of a data-parallel run.  The gradient threshold is set per
     node to the (1 - growth) quantile of the average screen-space gradient so that the synthetic scene refines at a steady
     rate (the statistics are all-reduced before, so every rank computes the same threshold).
+    cfg (mtgs_amd.densify.RefineConfig): FIXED thresholds instead -- the reference's control values (config/MTGS.py:59-71),
+    with the screen-space gradient threshold scaled ONCE for the synthetic scene (--converge): what refines is then decided
+    by the training state, and fewer Gaussians qualify as the model converges; the opacity reset of refinement_after
+    (:555-572) runs on the reference's schedule.
     Returns (added, culled, {old parameter id: (new parameter, new moments | None)})."""
-    from mtgs_amd.densify import RefineConfig, refine_gaussians
+    from mtgs_amd.densify import RefineConfig, refine_gaussians, reset_opacities
     added = culled = 0
     swap = {}
+    fixed = cfg
     for (name, p), st in zip(list(P.items()), stats):
         if "instance_quats" in p:
             continue
-        avg = st[0] / st[1]
-        thr = float(torch.quantile(avg[:: max(1, avg.numel() // 1_000_000)], 1.0 - growth))
-        cfg = RefineConfig(densify_grad_thresh=max(thr, 1e-12), densify_size_thresh=0.12, cull_alpha_thresh=0.02, refine_every=20,
-                           reset_alpha_every=10 ** 6, split_screen_size=1e9, cull_screen_size=1e9, clone_sample_means=False)
+        if fixed is None:
+            avg = st[0] / st[1]
+            thr = float(torch.quantile(avg[:: max(1, avg.numel() // 1_000_000)], 1.0 - growth))
+            cfg = RefineConfig(densify_grad_thresh=max(thr, 1e-12), densify_size_thresh=0.12, cull_alpha_thresh=0.02, refine_every=20,
+                               reset_alpha_every=10 ** 6, split_screen_size=1e9, cull_screen_size=1e9, clone_sample_means=False)
         moments = {k: (opt_state_of(v)["exp_avg"], opt_state_of(v)["exp_avg_sq"]) for k, v in p.items()
                    if opt_state_of(v) and "exp_avg" in opt_state_of(v)}
         new, new_m, info = refine_gaussians({k: v.detach() for k, v in p.items()}, tuple(st), cfg, step, seed,
                                             moments=moments or None)
+        if fixed is not None and step % (cfg.reset_alpha_every * cfg.refine_every) == cfg.refine_every:
+            reset_opacities(new["opacities"], cfg, new_m.get("opacities") if new_m else None)
         n_new = info["n_after"]
         for k, v in p.items():
             q = new[k].requires_grad_(True)
@@ -372,14 +395,38 @@ def refine_device(P, stats, opt_state_of, step, seed, growth=0.02):
     return added, culled, swap
 
 
+LR_SETS = {
+    # the harness's own (rounds 1-3): one rate per kind of parameter
+    "harness": {"features_dc": 2e-2, "features_rest": 2e-2, "features_adapters": 2e-2, "opacities": 5e-2, "means": 1e-4, "scales": 1e-4,
+                "quats": 1e-4, "instance_quats": 1e-4, "instance_trans": 1e-4, "exposure": 1e-4},
+    # the groups of config/MTGS.py:121-181 (means 8e-4 -> 8e-6 exponentially, features_dc 2.5e-3, features_rest 2.5e-3 / 20,
+    # opacities 5e-2, scales 5e-3, quats 1e-3), scaled ONCE for a run of a few hundred steps instead of 30 000: the colour rates
+    # x 4 (the synthetic colours start 0.3 off), everything else as shipped
+    "reference": {"features_dc": 1e-2, "features_rest": 1e-2 / 20, "features_adapters": 1e-2, "opacities": 5e-2, "means": 8e-4,
+                  "scales": 5e-3, "quats": 1e-3, "instance_quats": 1e-3, "instance_trans": 8e-4, "exposure": 1e-3},
+}
+LR = {"set": "harness"}
+
+
 def make_optimizer(kind, P, shipped=None, capturable=False):
     """One optimizer over every parameter group.  kind = "fused": mtgs_amd.optim.FusedAdam (one launch per step, csrc/adam.hip);
-    "torch": torch.optim.Adam(foreach=True), what nerfstudio builds per group (custom_trainer.py:115-136)."""
-    extra = [shipped["exposure"]] if shipped else []
-    geo = [p[k] for p in P.values() for k in p if not k.startswith("features") and k != "opacities"]
-    groups = [{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
-              {"params": [p["opacities"] for p in P.values()], "lr": 5e-2},      # config/MTGS.py: opacities 0.05
-              {"params": geo + extra, "lr": 1e-4}]
+    "torch": torch.optim.Adam(foreach=True), what nerfstudio builds per group (custom_trainer.py:115-136).  One group per kind of
+    parameter, as the reference's `{node}.{type}.{param}` groups (learning rates: LR_SETS)."""
+    rates = LR_SETS[LR["set"]]
+    by_kind = {}
+    for p in P.values():
+        for k, v in p.items():
+            by_kind.setdefault(k, []).append(v)
+    if shipped:
+        by_kind["exposure"] = [shipped["exposure"]]
+    if LR["set"] == "harness":      # (the original three groups, in the original parameter order: same training as rounds 1-3)
+        extra = [shipped["exposure"]] if shipped else []
+        geo = [p[k] for p in P.values() for k in p if not k.startswith("features") and k != "opacities"]
+        groups = [{"params": [p[k] for p in P.values() for k in p if k.startswith("features")], "lr": 2e-2},
+                  {"params": [p["opacities"] for p in P.values()], "lr": 5e-2},      # config/MTGS.py: opacities 0.05
+                  {"params": geo + extra, "lr": 1e-4}]
+    else:
+        groups = [{"params": v, "lr": rates[k], "name": k} for k, v in by_kind.items()]
     if kind == "fused":
         from mtgs_amd.optim import FusedAdam
         opt = FusedAdam(groups, eps=1e-15)
@@ -410,14 +457,39 @@ def enable_row_lazy(opt, P):
 
 
 def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=None, world=1, rank=0, accumulate=1, seed=7,
-               log=print, sparse=False, optimizer="fused"):
-    """Adam on the fused iteration.  world > 1: view-parallel data parallelism (one process per rank, camera
+               log=print, sparse=False, optimizer="fused", graph=False, refine_cfg=None, poll_every=16, means_lr_final=None,
+               timing_from=None, densify_from=0, steady=None, first_cap_scale=1.0):
+    """Adam on the fused iteration (MTGSSceneModel.get_outputs -> get_loss_dict -> backward -> optimizers.step ->
+    update_submodel_statistics / after_train / refinement_after every refine_every steps: mtgs_scene_graph.py:547-708, 806-987,
+    1157-1183; vanilla_gaussian_splatting.py:448-577).  world > 1: view-parallel data parallelism (one process per rank, camera
     (step * world + rank) % T, ONE dense all-reduce of every gradient per step, statistics all-reduced before each
     refinement, refinement identical on every rank).  accumulate = K in ONE process: the K cameras of a step rendered one
     after the other with the gradients accumulated -- the single-process statement of the same training step
-    (parity for C4 is defined against it)."""
+    (parity for C4 is defined against it).
+
+    No step waits for the host: the losses go to a device-side history that is read at the refinements and at the end.
+
+    graph = True (single process, one camera per step): the loop TRAINS THROUGH HIP GRAPHS.  Between two refinements N is
+    fixed; the first time a traversal's camera comes up in such a stretch its iteration runs once eagerly under
+    mtgs_amd.graph_mode (that IS the training step) and is captured right after (torch.cuda.graph: nothing executes), every
+    later step of that traversal is FusedAdam.advance() + one graph launch.  Capacities: the first stretch renders every
+    traversal once without fixed capacities (the size plan learns n_vis / M of this scene), later stretches scale the largest
+    counts their predecessor saw on the device by the growth of N.  The graphs OR the frames' `info["overflow"]` flags into one
+    device word that the host polls every `poll_every` steps through a pinned copy and an event it only QUERIES; on overflow
+    the graphs are dropped, every traversal renders one frame the ordinary way (exact sizes, the size plan updated) and is
+    captured again with larger capacities.  A refinement ends the stretch: flush the row-lazy state, refine on the device (the
+    one host synchronisation: the new N), new optimizer with the moved moments, new graphs.
+    refine_cfg: RefineConfig with fixed thresholds (refine_device), None = the per-refinement quantile of rounds 1-3.
+    densify_from: GaussianSplattingControlConfig.densify_from_iter -- no refinement (and no statistics reset) up to that step.
+    means_lr_final: the reference's exponential decay of the position learning rate (config/MTGS.py:124-129) over `steps`.
+    Returns (loss curve, N after every refinement)."""
+    import mtgs_amd
     from mtgs_amd import dist as mdist
+    from mtgs_amd import wrapper
     T = len(cams)
+    dev = next(iter(P.values()))["means"].device
+    if graph and (world > 1 or accumulate > 1 or optimizer != "fused" or LAZY["on"]):
+        raise ValueError("graph training: one process, one camera per step, the fused optimizer, no --lazy-adam")
 
     def make_opt():
         return make_optimizer(optimizer, P, shipped)
@@ -426,49 +498,194 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     mk = lambda: [[torch.zeros(p["means"].shape[0], device=p["means"].device), torch.ones(p["means"].shape[0], device=p["means"].device),
                    torch.zeros(p["means"].shape[0], device=p["means"].device)] for p in P.values()]
     stats = mk()
-    curve, sizes = [], []
+    sizes = []
     group = max(world, accumulate)
     sparse = sparse and world > 1
     mk_ex = lambda: mdist.SparseGradExchange(sum(p["means"].shape[0] for p in P.values()), 16, next(iter(P.values()))["means"].device,
                                              traversals=T) if sparse else None
     ex = mk_ex()
-    t_start = None
-    for i in range(steps):
-        if i == min(3, steps - 1):       # wall clock per step after the first few (allocator, size plan, lazy init)
+    loss_hist = torch.zeros(max(steps, 1), dtype=torch.float32, device=dev)     # (no per-step host read of the loss)
+
+    def set_lrs(i):
+        if means_lr_final is None:
+            return
+        for g in opt.param_groups:
+            if g.get("name") == "means":     # ExponentialDecaySchedulerConfig(lr_final, max_steps): lr0 * (lr_final / lr0) ** (i / steps)
+                lr0 = LR_SETS[LR["set"]]["means"]
+                g["lr"] = lr0 * (means_lr_final / lr0) ** (i / max(steps, 1))
+
+    # ---- graph training state (one stretch between two refinements)
+    graphs, caps, eager_left = {}, None, T
+    seen_dev = torch.zeros(2, dtype=torch.int64, device=dev)        # largest n_visible / n_intersections of the graph frames
+    ovf_dev = torch.zeros((), dtype=torch.bool, device=dev)         # OR of the graph frames' overflow flags
+    ovf_host = torch.zeros((), dtype=torch.bool).pin_memory() if graph else None
+    ovf_ev = None
+    counts = {"captures": 0, "warmups": 0, "overflows": 0, "eager": 0, "replays": 0}
+    cap_scale = [float(first_cap_scale)]
+    staged, n_active = {}, [0]       # per traversal: the pinned staging buffers of its graphs; tensors the optimizer steps
+    # ONE memory pool for every graph of the run: a graph's private pool is hipMalloc'ed at capture and released with the graph --
+    # per traversal and per refinement that was most of the cost of re-capturing at 2M Gaussians.  Sharing is safe here: the
+    # graphs are replayed one at a time on one stream, each replay writes everything it reads (tables, activations, gradients),
+    # and the only output read afterwards -- the loss -- is copied out in stream order right behind its replay.  The pool outlives
+    # the refinements through `pool_keeper`, a trivial graph captured into it first.
+    pool = pool_keeper = None
+    if graph:
+        pool = torch.cuda.graph_pool_handle()
+        pool_keeper = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(pool_keeper, pool=pool):
+            _keep = torch.zeros(1, device=dev) + 1
+    debug = bool(os.environ.get("MTGS_TRAIN_DEBUG"))
+    phase_ms, tick_t = {}, [time.perf_counter()]
+
+    def tick(name):      # MTGS_TRAIN_DEBUG=1: where the wall time goes (synchronising: not for timing runs)
+        if debug:
             torch.cuda.synchronize()
-            t_start, i_start = time.perf_counter(), i
+            now = time.perf_counter()
+            phase_ms[name] = phase_ms.get(name, 0.0) + (now - tick_t[0]) * 1e3
+            tick_t[0] = now
+
+    def body(c):
         opt.zero_grad(set_to_none=True)
-        losses = []
-        for a in range(accumulate):
-            c = (i * group + (rank if world > 1 else a)) % T
-            if sparse:
-                losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex, shipped=shipped))
-            else:
-                if LAZY["on"]:
-                    opt.prepare(c)
-                losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
-        loss = torch.stack(losses).sum()
-        params = [q for g in opt.param_groups for q in g["params"]]
-        if world > 1:
-            if not sparse:
-                mdist.all_reduce_grads(params)
-            elif shipped:                       # the replicated non-Gaussian parameters (exposure): a few floats
-                mdist.all_reduce_grads([shipped["exposure"]])
-            torch.distributed.all_reduce(loss)
-        curve.append(float(loss) / group)
-        if VISFIRST["cs"] is not None and accumulate == 1 and not sparse:
+        loss = iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped)
+        if VISFIRST["cs"] is not None:
             VISFIRST["cs"].apply_to(opt)
         opt.step()
-        if refine_every and (i + 1) % refine_every == 0 and i + 1 < steps:
+        info = LAST["info"]
+        if "overflow" in info:       # (graph mode: the counts and the flag are device scalars)
+            ovf_dev.logical_or_(info["overflow"])
+            torch.maximum(seen_dev, torch.stack([info["n_visible"], info["n_intersections"]]), out=seen_dev)
+        return loss
+
+    def plan_caps():
+        n_all = sum(p["means"].shape[0] for p in P.values())
+        n_vis, M = wrapper._size_plan.seen[(1, n_all, W, H)]
+        k, cap_scale[0] = cap_scale[0], 1.0       # (tests: the FIRST set of capacities too small, to drive the overflow path)
+        return int(1.3 * k * n_vis) + 4096, int(1.3 * k * M) + 65536
+
+    def graph_step(c):
+        nonlocal caps, eager_left
+        if caps is None:                       # the size plan does not know this N yet: ordinary frames (exact sizes)
+            loss = body(c)
+            counts["eager"] += 1
+            eager_left -= 1
+            if eager_left <= 0:
+                caps = plan_caps()
+            return loss
+        if c not in graphs:
+            tick("other")
+            gm = mtgs_amd.graph_mode(*caps)
+            if c in staged and n_active[0]:
+                # a later stretch: capture at once and let the first replay BE the step.  What a warm-up would provide is there
+                # already: the pinned staging buffers of the traversal's previous graph (same sequence of table sizes -- a
+                # mismatch would allocate pinned memory while capturing and is caught below) and the optimizer's device
+                # scalars (FusedAdam.inherit_layout; every tensor inherited its moments from the refinement)
+                gm.keep = staged[c]
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with gm, torch.cuda.graph(g, pool=pool):
+                        static = body(c)
+                except Exception as e:      # noqa: BLE001  (fall back to the warm-up path, once, loudly)
+                    log(f"capture without warm-up failed ({type(e).__name__}: {e}); warming up")
+                    staged.pop(c, None)
+                    torch.cuda.synchronize()
+                    return graph_step(c)
+                graphs[c] = (g, gm, static)
+                counts["captures"] += 1
+                tick("capture")
+                opt.advance()
+                g.replay()
+                counts["replays"] += 1
+                tick("first replay")
+                return static
+            with gm:                           # THE step of this iteration, eagerly, with the graph's capacities (also fills the
+                loss = body(c)                 #   mode object's staging buffers: no pinned allocation while capturing).  On the
+            #                                      main stream: a side stream has its own allocator pool, every tensor of the step
+            #                                      was hipMalloc'ed afresh there (10 ms per warm-up at 2M Gaussians)
+            tick("warm")
+            g = torch.cuda.CUDAGraph()
+            with gm, torch.cuda.graph(g, pool=pool):      # nothing executes
+                static = body(c)
+            graphs[c] = (g, gm, static)
+            staged[c] = gm.keep
+            n_active[0] = len(opt._active)
+            counts["captures"] += 1
+            counts["warmups"] += 1
+            tick("capture")
+            return loss
+        g, _, static = graphs[c]
+        opt.advance()                          # this step's {lr / bc1, sqrt(bc2), t}: one small copy in front of the launch
+        g.replay()
+        counts["replays"] += 1
+        return static
+
+    def poll_overflow(i):
+        """Never blocks: queries the event of the previous poll's copy, then issues the next one."""
+        nonlocal ovf_ev, caps, eager_left
+        if ovf_ev is not None and ovf_ev.query():
+            ovf_ev = None
+            if bool(ovf_host):
+                counts["overflows"] += 1
+                log(f"step {i}: a graph frame exceeded its capacities {caps}; re-capturing")
+                graphs.clear()
+                caps, eager_left = None, T
+                ovf_dev.zero_()
+        if ovf_ev is None and graphs and i % poll_every == 0:
+            ovf_host.copy_(ovf_dev, non_blocking=True)
+            ovf_ev = torch.cuda.Event()
+            ovf_ev.record()
+
+    t_start = None
+    i_start = 0
+    steady_ev = []           # GPU time per step over a window without refinements (steady = (first step, last step))
+    t_from = min(3, steps - 1) if timing_from is None else min(timing_from, steps - 1)
+    for i in range(steps):
+        if i == t_from:       # wall clock per step after the first few (allocator, size plan, lazy init)
+            torch.cuda.synchronize()
+            t_start, i_start = time.perf_counter(), i
+        set_lrs(i)
+        if steady and i in steady:
+            steady_ev.append(torch.cuda.Event(enable_timing=True))
+            steady_ev[-1].record()
+        if graph:
+            loss_hist[i].copy_(graph_step(i % T))
+            poll_overflow(i)
+        else:
+            opt.zero_grad(set_to_none=True)
+            losses = []
+            for a in range(accumulate):
+                c = (i * group + (rank if world > 1 else a)) % T
+                if sparse:
+                    losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex, shipped=shipped))
+                else:
+                    if LAZY["on"]:
+                        opt.prepare(c)
+                    losses.append(iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped))
+            loss = torch.stack(losses).sum()
+            params = [q for g in opt.param_groups for q in g["params"]]
+            if world > 1:
+                if not sparse:
+                    mdist.all_reduce_grads(params)
+                elif shipped:                       # the replicated non-Gaussian parameters (exposure): a few floats
+                    mdist.all_reduce_grads([shipped["exposure"]])
+                torch.distributed.all_reduce(loss)
+            loss_hist[i].copy_(loss / group)
+            if VISFIRST["cs"] is not None and accumulate == 1 and world == 1:
+                VISFIRST["cs"].apply_to(opt)
+            opt.step()
+        if refine_every and (i + 1) % refine_every == 0 and densify_from < i + 1 < steps:     # (refinement_after: step <= densify_from_iter returns)
+            tick("other")
             if world > 1:   # every rank must see the same statistics (vis_counts starts at ONE: counted once)
                 mdist.all_reduce_stats([t for s in stats for t in s[:2]], [s[2] for s in stats],
                                        sum_init=[v for _ in stats for v in (0.0, 1.0)])
             before = sum(p["means"].shape[0] for p in P.values())
             if LAZY["on"] or ROWLAZY["on"]:
                 opt.flush()                   # every slice / row up to date before rows move
+            params = [q for g in opt.param_groups for q in g["params"]]
             state = {id(q): opt.state.get(q) for q in params}
-            added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed)
-            opt = make_opt()
+            tick("flush")
+            added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed, cfg=refine_cfg)
+            tick("refine_device")
+            old_opt, opt = opt, make_opt()
             for old_id, (old, new_p, mom) in swap.items():
                 st_o = state.get(old_id)
                 if st_o and mom is not None:
@@ -478,18 +695,40 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                     if q not in opt.state and state.get(id(q)):
                         opt.state[q] = state[id(q)]
             enable_row_lazy(opt, P)
+            if hasattr(opt, "inherit_layout"):
+                opt.inherit_layout(old_opt)
+            del old_opt
             sizes.append(sum(p["means"].shape[0] for p in P.values()))
             ex = mk_ex()                      # N changed: new send buffers and visibility maps
+            if graph:                         # new parameters: new graphs, capacities scaled by the growth of N
+                graphs.clear()
+                ovf_ev = None
+                seen = seen_dev.tolist()      # (the refinement has synchronised already)
+                ratio = sizes[-1] / max(before, 1)
+                caps = (int(1.3 * ratio * seen[0]) + 4096, int(1.3 * ratio * seen[1]) + 65536) if seen[0] > 0 else None
+                eager_left = 0 if caps is not None else T
+                seen_dev.zero_()
+                ovf_dev.zero_()
             log(f"step {i + 1}: refine {before} -> {sizes[-1]} Gaussians (+{added} -{culled})")
+            tick("new optimizer")
+    if debug:
+        tick("other")
+        log("debug phases ms:", json.dumps({k: round(v, 1) for k, v in phase_ms.items()}))
     if LAZY["on"] or ROWLAZY["on"]:
         opt.flush()
     torch.cuda.synchronize()
     if t_start is not None and steps > i_start:
         ms = (time.perf_counter() - t_start) / (steps - i_start) * 1e3
         ph = {k: round(v, 3) for k, v in ex.phases_ms().items()} if ex is not None else {}
-        log(f"timing: {ms:.2f} ms per step (wall, refinements included) world {world} accumulate {accumulate} "
-            f"exchange {'sparse' if sparse else ('dense' if world > 1 else 'none')} optimizer {optimizer} phases_ms {json.dumps(ph)}")
-    return curve, sizes
+        log(f"timing: {ms:.2f} ms per step (wall, refinements{' and graph captures' if graph else ''} included) world {world} "
+            f"accumulate {accumulate} exchange {'sparse' if sparse else ('dense' if world > 1 else 'none')} optimizer {optimizer} "
+            f"phases_ms {json.dumps(ph)}" + (f" graph {json.dumps(counts)}" if graph else ""))
+    if len(steady_ev) == 2:
+        log(f"steady: {steady_ev[0].elapsed_time(steady_ev[1]) / (steady[1] - steady[0]):.3f} ms per step between steps {steady[0]} and {steady[1]} (GPU events)")
+    if graph and bool(ovf_dev):
+        log("note: a graph frame overflowed its capacities after the last poll")
+    graphs.clear()
+    return loss_hist[:steps].tolist(), sizes
 
 
 def main():
@@ -529,7 +768,33 @@ def main():
                     "right before the forward reads it (mtgs_amd.optim.FusedAdam.set_row_lazy)")
     ap.add_argument("--graph", action="store_true", help="fused iteration captured as ONE HIP graph per traversal "
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
+    ap.add_argument("--train-graph", action="store_true", help="with --steps: TRAIN through HIP graphs (one per traversal, re-captured "
+                    "after every refinement, overflow polled without a host wait; train_loop(graph=True))")
+    ap.add_argument("--converge", action="store_true", help="with --steps: the training problem with something to learn and the "
+                    "reference's refinement rules -- the model starts from a SUBSET of the true Gaussians with perturbed positions, "
+                    "shapes, opacities and colours; fixed thresholds of config/MTGS.py:59-71 (screen-space gradient threshold scaled once, "
+                    "--grad-thresh), clone_sample_means, opacity culling at 0.005; the reference's learning-rate groups (LR_SETS)")
+    ap.add_argument("--grad-thresh", type=float, default=None, help="with --converge: densify_grad_thresh (the reference's 0.001 is for "
+                    "nuPlan images; default: scaled once for the synthetic scene)")
+    ap.add_argument("--drop", type=float, default=0.1, help="with --converge: fraction of the true Gaussians the model starts without")
+    ap.add_argument("--poll-every", type=int, default=16)
+    ap.add_argument("--first-cap-scale", type=float, default=1.0, help="with --train-graph (tests): scale of the first graphs' capacities; "
+                    "< 1 makes their frames overflow, which the loop must notice and repair")
+    ap.add_argument("--steady", type=int, nargs=2, default=None, help="with --steps: also report the time per step between these two steps")
+    ap.add_argument("--size-thresh", type=float, default=0.2, help="with --converge: RefineConfig.densify_size_thresh (config/MTGS.py:65)")
+    ap.add_argument("--cull-alpha", type=float, default=0.005, help="with --converge: RefineConfig.cull_alpha_thresh (config/MTGS.py:63)")
+    ap.add_argument("--clear-radius", type=float, default=None, help="no Gaussians within this many metres of the cameras (ground plane); "
+                    "default 6 with --converge (3 sigma of the largest Gaussian then stays below split_screen_size = 100 px), else 0")
+    ap.add_argument("--split-screen-size", type=float, default=100.0, help="with --converge: RefineConfig.split_screen_size (config/MTGS.py:70)")
+    ap.add_argument("--densify-from", type=int, default=None, help="densify_from_iter (config/MTGS.py:57: 5 x refine_every, the default "
+                    "with --converge; 0 otherwise)")
+    ap.add_argument("--trace-refinements", action="store_true", help="print the loss around every refinement")
     args = ap.parse_args()
+    if args.visfirst and (args.accumulate > 1 or args.dp):
+        raise SystemExit("--visfirst hands the gradients to the optimizer as rows of ONE frame: not with --accumulate > 1 or --dp "
+                         "(the sparse exchange has its own row path)")
+    if args.train_graph and not args.steps:
+        raise SystemExit("--train-graph needs --steps")
     VISFIRST["on"] = bool(args.visfirst)
     VISFIRST["normals"] = not args.dense_normals
     VISFIRST["geometry_rows"] = bool(args.geometry_rows)
@@ -545,7 +810,8 @@ def main():
         raise SystemExit("--visfirst hands the colour gradients over as rows: --optimizer fused (or none)")
     dev = torch.device("cuda")
     W, H, T = args.width, args.height, args.traversals
-    truth = make_nodes(args.n_background, args.n_road, T, 0, dev, args.objects, args.object_size)
+    truth = make_nodes(args.n_background, args.n_road, T, 0, dev, args.objects, args.object_size,
+                       clear=(6.0 if args.converge else 0.0) if args.clear_radius is None else args.clear_radius)
     cams = []
     for t in range(T):
         vm, K = make_camera(W, H, yaw_deg=20.0 * t)
@@ -576,8 +842,39 @@ def main():
         shipped = {"exposure": (torch.eye(3, 4, device=dev)[None].repeat(T, 1, 1) + 0.02 * torch.randn(T, 3, 4, generator=ge).to(dev)).requires_grad_(True),
                    "bg": bg, "gt_depth": gt_depth, "gt_normal": gt_normal}
     g = torch.Generator().manual_seed(5)
-    P = {name: {k: (v + (0.3 * torch.randn(v.shape, generator=g)).to(dev) * (k in ("features_dc", "features_rest", "features_adapters"))
-                    ).clone().requires_grad_(True) for k, v in p.items()} for name, p in truth.items()}
+    if args.converge:
+        # something to learn: a random subset of the true Gaussians (the holes are what densification has to fill), positions
+        # off by half a standard deviation of the Gaussian itself, shapes, opacities and colours perturbed
+        LR["set"] = "reference"
+        P = {}
+        for name, p in truth.items():
+            n = p["means"].shape[0]
+            keep = (torch.rand(n, generator=g) >= args.drop).to(dev) if "instance_quats" not in p else torch.ones(n, dtype=torch.bool, device=dev)
+            rn = lambda v, sd: (sd * torch.randn(v.shape, generator=g)).to(dev)
+            q = {}
+            for k, v in p.items():
+                if k in ("instance_quats", "instance_trans"):
+                    q[k] = v.clone()
+                    continue
+                w = v[keep]
+                if k == "means":
+                    w = w + rn(w, 0.5) * torch.exp(p["scales"][keep])
+                elif k == "scales":
+                    w = w + rn(w, 0.2)
+                elif k == "quats":
+                    w = w + rn(w, 0.1)
+                elif k == "opacities":
+                    w = w + rn(w, 0.5)
+                else:
+                    w = w + rn(w, 0.3)
+                q[k] = w.contiguous().clone().requires_grad_(True)
+            for k in ("instance_quats", "instance_trans"):
+                if k in q:
+                    q[k].requires_grad_(True)
+            P[name] = q
+    else:
+        P = {name: {k: (v + (0.3 * torch.randn(v.shape, generator=g)).to(dev) * (k in ("features_dc", "features_rest", "features_adapters"))
+                        ).clone().requires_grad_(True) for k, v in p.items()} for name, p in truth.items()}
     params = [v for p in P.values() for v in p.values()] + ([shipped["exposure"]] if shipped else [])
     mk_stats = lambda: [[torch.zeros(p["means"].shape[0], device=dev), torch.ones(p["means"].shape[0], device=dev),
                          torch.zeros(p["means"].shape[0], device=dev)] for p in P.values()]
@@ -708,9 +1005,25 @@ def main():
             from mtgs_amd import dist as mdist
             rank, _, world = mdist.init_from_env()
         log = print if rank == 0 else (lambda *a, **k: None)
+        refine_cfg = None
+        if args.converge:
+            from mtgs_amd.densify import RefineConfig
+            # config/MTGS.py:59-71 as shipped, but: the gradient threshold scaled once for this scene (nuPlan's 0.001 is for real
+            # images at 30 000 steps), refine_every from the command line
+            refine_cfg = RefineConfig(refine_every=max(args.refine_every, 1), densify_grad_thresh=args.grad_thresh or 4e-4,
+                                      split_screen_size=args.split_screen_size, cull_alpha_thresh=args.cull_alpha,
+                                      densify_size_thresh=args.size_thresh)
         curve, sizes = train_loop(P, cams, targets, mask, win, W, H, args.steps, args.refine_every, shipped=shipped, world=world,
                                   rank=rank, accumulate=args.accumulate, log=log, sparse=args.dp_exchange == "sparse",
-                                  optimizer=args.optimizer if args.optimizer in ("torch", "fused") else "fused")
+                                  optimizer=args.optimizer if args.optimizer in ("torch", "fused") else "fused",
+                                  graph=args.train_graph, refine_cfg=refine_cfg, poll_every=args.poll_every,
+                                  means_lr_final=8e-6 if args.converge else None,
+                                  steady=tuple(args.steady) if args.steady else None, first_cap_scale=args.first_cap_scale,
+                                  densify_from=(5 * args.refine_every if args.converge else 0) if args.densify_from is None else args.densify_from)
+        if args.trace_refinements and args.refine_every:
+            for r in range(args.refine_every, args.steps, args.refine_every):
+                pts = [r - 2 * T, r - T, r, r + T, r + 2 * T, r + 4 * T, r + 8 * T]
+                log(f"around step {r}: " + " ".join(f"{q}:{sum(curve[q:q + T]) / T:.4f}" for q in pts if 0 <= q and q + T <= len(curve)))
         k = max(1, args.steps // 8)
         log("loss:", " ".join(f"{sum(curve[j:j + k]) / len(curve[j:j + k]):.4f}" for j in range(0, args.steps, k)))
         n_now = sum(p["means"].shape[0] for p in P.values())
@@ -720,7 +1033,15 @@ def main():
             assert int(t[0]) == n_now and int(-t[1]) == n_now, "N differs between the ranks"
             log(f"{world} ranks: N = {n_now} on every rank after {len(sizes)} refinements")
             torch.distributed.destroy_process_group()
-        if args.refine_every:
+        if args.converge:
+            # training has to WORK here: the loss falls through the refinements (mean of the last tenth against the first tenth)
+            k10 = max(1, args.steps // 10)
+            first, last = sum(curve[:k10]) / k10, sum(curve[-k10:]) / k10
+            log(f"converge: loss {first:.4f} -> {last:.4f} ({last / first:.2f}x) through {len(sizes)} refinements, N {sizes}")
+            assert all(math.isfinite(c) for c in curve), curve[-5:]
+            if args.steps >= 100:
+                assert last < 0.7 * first, (first, last)
+        elif args.refine_every:
             # the synthetic scene starts from the TRUE geometry and the reference's duplication is not image-preserving (a
             # clone doubles its parent's contribution until the opacities adapt), so every refinement perturbs a correct
             # model: the run checks that N can change under the fused path (tables, statistics, optimizer state) and

@@ -447,7 +447,12 @@ def test_geometry_rows_equal_the_dense_geometry_gradients(hip_lib):
     for p in Pg:
         assert all(p[k].grad is None for k in geo_keys)            # nothing dense was written
     opt = FusedAdam([{"params": [p[k] for p in Pg for k in p], "lr": 1e-3}], eps=1e-15)
+    # the activated tensors of run(True) are released by now (autograd outputs, freed with the graph): their blocks are handed
+    # out again and overwritten before apply_to() enqueues mtgs_node_bwd_rows, which must read the RAW parameters only
+    n_all = sum(p["means"].shape[0] for p in Pg)
+    junk = [torch.full(shape, float("nan"), device=dev) for _ in range(6) for shape in ((n_all, 3), (n_all, 4), (n_all,))]
     cs.apply_to(opt)
+    del junk
     vis = info["radii"][0] > 0
     start = 0
     for pd, pg in zip(Pd, Pg):
