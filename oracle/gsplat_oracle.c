@@ -657,17 +657,99 @@ void orc_blend_fwd(int C, int64_t N, int D, const float *means2d, const float *c
  * per-pixel terms of {conic 3, opacity 1, colour D} (for xy that sum is v_means2d_abs itself).  |sum| << sum of |terms|
  * marks a row whose terms cancel: its fp32-summed device value cannot be expected within a relative bound of the sum,
  * only within (per-term relative error) x (sum of |terms|) -- tests/util.py::assert_grad_close. */
-void orc_blend_bwd_ex(int C, int64_t N, int D, const float *means2d, const float *conics,
-                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
-                      int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
-                      int64_t M, const float *alphas, const int32_t *last_ids, const float *v_render,
-                      const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
-                      float *v_colors, float *v_opacities, float *term_abs) {
+/* Test aid of orc_blend_bwd_ex2: ONE pixel's forward and backward (the loops of orc_blend_fwd_ex / orc_blend_bwd_ex2) with at
+ * most one discrete decision overridden -- ov_kind 1: the alpha >= 1/255 / sigma >= 0 decision of list position ov_pos
+ * inverted, 2: its T <= 1e-4 stop decision inverted, 0: none.  terms[(end - start)][6 + D]: the SIGNED per-pixel gradient
+ * terms {xy 2, conic 3, opacity 1, colour D} of every list position (zero where the Gaussian does not contribute). */
+static void pixel_pass(int D, const float *means2d, const float *conics, const float *colors, const float *opacities,
+                       const float *bg, float fxp, float fyp, int64_t start, int64_t end, const int32_t *flatten_ids,
+                       const float *vr, float va_out, int64_t ov_pos, int ov_kind, float *terms) {
+    int SM = 6 + D;
+    int64_t L = end - start;
+    memset(terms, 0, (size_t)L * SM * sizeof(float));
+    uint8_t *inc = (uint8_t *)calloc((size_t)L, 1);
+    float T = 1.f;
+    int64_t last = start - 1;
+    for (int64_t i = start; i < end; ++i) {
+        int32_t g = flatten_ids[i];
+        float dx = means2d[g * 2] - fxp, dy = means2d[g * 2 + 1] - fyp;
+        float a = conics[g * 3], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
+        float sigma = 0.5f * (a * dx * dx + cc * dy * dy) + b * dx * dy;
+        float alpha = fminf(ALPHA_MAX, opacities[g] * expf(-sigma));
+        int skip = sigma < 0.f || alpha < ALPHA_MIN;
+        if (i == ov_pos && ov_kind == 1) skip = !skip;
+        if (skip) continue;
+        float next_T = T * (1.f - alpha);
+        int stop = next_T <= T_MIN;
+        if (i == ov_pos && ov_kind == 2) stop = !stop;
+        if (stop) break;
+        inc[i - start] = 1;
+        last = i;
+        T = next_T;
+    }
+    float T_final = T;
+    float buffer[64];
+    for (int k = 0; k < D; ++k) buffer[k] = 0.f;
+    float bg_dot = 0.f;
+    if (bg)
+        for (int k = 0; k < D; ++k) bg_dot += bg[k] * vr[k];
+    for (int64_t i = last; i >= start; --i) {
+        if (!inc[i - start]) continue;
+        int32_t g = flatten_ids[i];
+        float dx = means2d[g * 2] - fxp, dy = means2d[g * 2 + 1] - fyp;
+        float a = conics[g * 3], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
+        float opac = opacities[g];
+        float sigma = 0.5f * (a * dx * dx + cc * dy * dy) + b * dx * dy;
+        float vis = expf(-sigma);
+        float alpha = fminf(ALPHA_MAX, opac * vis);
+        float ra = 1.0f / (1.0f - alpha);
+        T *= ra;
+        float fac = alpha * T;
+        const float *col = colors + (int64_t)g * D;
+        float v_alpha = 0.f;
+        for (int k = 0; k < D; ++k) v_alpha += (col[k] * T - buffer[k] * ra) * vr[k];
+        v_alpha += T_final * ra * va_out;
+        if (bg) v_alpha += -T_final * ra * bg_dot;
+        float *Q = terms + (i - start) * SM;
+        if (opac * vis <= ALPHA_MAX) {
+            float v_sigma = -opac * vis * v_alpha;
+            Q[0] = v_sigma * (a * dx + b * dy);
+            Q[1] = v_sigma * (b * dx + cc * dy);
+            Q[2] = 0.5f * v_sigma * dx * dx;
+            Q[3] = v_sigma * dx * dy;
+            Q[4] = 0.5f * v_sigma * dy * dy;
+            Q[5] = vis * v_alpha;
+        }
+        for (int k = 0; k < D; ++k) {
+            Q[6 + k] = fac * vr[k];
+            buffer[k] += col[k] * fac;
+        }
+    }
+    free(inc);
+}
+
+/* _ex2: plus pixel_mask[C,H,W] / mask_terms[C,N,6+D] (both nullable, test aid): the FLIP SENSITIVITY of every gradient row.
+ * For every pixel with pixel_mask != 0 (the threshold-critical pixels of orc_blend_fwd_ex) and every threshold-critical
+ * decision on its list (alpha within 1e-4 of 1/255, sigma at 0, T (1 - alpha) within 1e-4 of 1e-4) the pixel is composited and
+ * back-propagated ONCE MORE with that one decision inverted (pixel_pass), and per Gaussian of the list the absolute change of
+ * its per-pixel terms {xy 2, conic 3, opacity 1, colour D} is summed.  That is how far a row can move when the discrete
+ * decisions of its critical pixels fall the other way on another fp32 implementation (first order in the number of flips per
+ * pixel) -- NOT the size of the row's own terms there: a flipped Gaussian behind j changes j's v_alpha through the
+ * accumulated colour, whatever j's own term is.  The magnitude bound of the "flipped" / "self-critical" classes of
+ * tests/util.py::assert_grad_close. */
+void orc_blend_bwd_ex2(int C, int64_t N, int D, const float *means2d, const float *conics,
+                       const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                       int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
+                       int64_t M, const float *alphas, const int32_t *last_ids, const float *v_render,
+                       const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
+                       float *v_colors, float *v_opacities, float *term_abs, const uint8_t *pixel_mask, float *mask_terms) {
     int64_t CN = (int64_t)C * N;
     int S = 8 + D; /* xy(2) abs(2) conic(3) opac(1) colour(D) */
     int SA = 4 + D;
+    int SM = 6 + D;
     double *acc = (double *)calloc((size_t)CN * S, sizeof(double));
     double *aab = term_abs ? (double *)calloc((size_t)CN * SA, sizeof(double)) : NULL;
+    double *amk = (pixel_mask && mask_terms) ? (double *)calloc((size_t)CN * SM, sizeof(double)) : NULL;
     int64_t n_tiles = (int64_t)C * tw * th;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int64_t t = 0; t < n_tiles; ++t) {
@@ -759,6 +841,65 @@ void orc_blend_bwd_ex(int C, int64_t N, int D, const float *means2d, const float
                 }
             }
     }
+    if (amk) {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            int c = (int)(t / ((int64_t)tw * th));
+            int ty = (int)((t / tw) % th), tx = (int)(t % tw);
+            int64_t start = offsets[t], end = (t == n_tiles - 1) ? M : offsets[t + 1];
+            if (end <= start) continue;
+            int64_t L = end - start;
+            float *base = NULL, *alt = NULL;
+            for (int py = ty * tile_size; py < (ty + 1) * tile_size && py < H; ++py)
+                for (int px = tx * tile_size; px < (tx + 1) * tile_size && px < W; ++px) {
+                    int64_t pid = ((int64_t)c * H + py) * W + px;
+                    if (!pixel_mask[pid]) continue;
+                    if (!base) { base = (float *)malloc((size_t)L * SM * sizeof(float)); alt = (float *)malloc((size_t)L * SM * sizeof(float)); }
+                    const float *vr = v_render + pid * D;
+                    const float *bg = backgrounds ? backgrounds + (int64_t)c * D : NULL;
+                    pixel_pass(D, means2d, conics, colors, opacities, bg, (float)px + 0.5f, (float)py + 0.5f, start, end, flatten_ids,
+                               vr, v_alphas[pid], -1, 0, base);
+                    /* the threshold-critical decisions of this pixel, found the way orc_blend_fwd_ex flags them */
+                    float T = 1.f;
+                    for (int64_t i = start; i < end; ++i) {
+                        int32_t g = flatten_ids[i];
+                        float dx = means2d[g * 2] - ((float)px + 0.5f), dy = means2d[g * 2 + 1] - ((float)py + 0.5f);
+                        float a = conics[g * 3], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
+                        float sigma = 0.5f * (a * dx * dx + cc * dy * dy) + b * dx * dy;
+                        float alpha = fminf(ALPHA_MAX, opacities[g] * expf(-sigma));
+                        int crit_inc = (fabsf(alpha - ALPHA_MIN) <= 1e-4f * ALPHA_MIN && sigma >= -1e-6f) || (fabsf(sigma) <= 1e-6f && alpha >= ALPHA_MIN);
+                        int skip = sigma < 0.f || alpha < ALPHA_MIN;
+                        int crit_stop = 0, stop = 0;
+                        float next_T = T;
+                        if (!skip) {
+                            next_T = T * (1.f - alpha);
+                            crit_stop = fabsf(next_T - T_MIN) <= 1e-4f * T_MIN;
+                            stop = next_T <= T_MIN;
+                        }
+                        for (int kind = 1; kind <= 2; ++kind) {
+                            if (!(kind == 1 ? crit_inc : crit_stop)) continue;
+                            pixel_pass(D, means2d, conics, colors, opacities, bg, (float)px + 0.5f, (float)py + 0.5f, start, end,
+                                       flatten_ids, vr, v_alphas[pid], i, kind, alt);
+                            for (int64_t q = 0; q < L; ++q) {
+                                double *Q = amk + (int64_t)flatten_ids[start + q] * SM;
+                                for (int k = 0; k < SM; ++k) {
+                                    float d = fabsf(alt[q * SM + k] - base[q * SM + k]);
+                                    if (d != 0.f) {
+#pragma omp atomic
+                                        Q[k] += (double)d;
+                                    }
+                                }
+                            }
+                        }
+                        if (skip) continue;
+                        if (stop) break;
+                        T = next_T;
+                    }
+                }
+            free(base);
+            free(alt);
+        }
+    }
 #pragma omp parallel for schedule(static)
     for (int64_t g = 0; g < CN; ++g) {
         const double *A = acc + g * S;
@@ -769,9 +910,23 @@ void orc_blend_bwd_ex(int C, int64_t N, int D, const float *means2d, const float
         for (int k = 0; k < D; ++k) v_colors[g * D + k] = (float)A[8 + k];
         if (aab)
             for (int k = 0; k < SA; ++k) term_abs[g * SA + k] = (float)aab[g * SA + k];
+        if (amk)
+            for (int k = 0; k < SM; ++k) mask_terms[g * SM + k] = (float)amk[g * SM + k];
     }
     free(acc);
     free(aab);
+    free(amk);
+}
+
+void orc_blend_bwd_ex(int C, int64_t N, int D, const float *means2d, const float *conics,
+                      const float *colors, const float *opacities, const float *backgrounds, int W, int H,
+                      int tile_size, int tw, int th, const int32_t *offsets, const int32_t *flatten_ids,
+                      int64_t M, const float *alphas, const int32_t *last_ids, const float *v_render,
+                      const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
+                      float *v_colors, float *v_opacities, float *term_abs) {
+    orc_blend_bwd_ex2(C, N, D, means2d, conics, colors, opacities, backgrounds, W, H, tile_size, tw, th, offsets, flatten_ids,
+                      M, alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities,
+                      term_abs, NULL, NULL);
 }
 
 void orc_blend_bwd(int C, int64_t N, int D, const float *means2d, const float *conics,

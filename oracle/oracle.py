@@ -236,9 +236,13 @@ def blend_fwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, 
 
 
 def blend_bwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, offsets, flatten_ids,
-              alphas, last_ids, v_render, v_alphas, absgrad=True, want_term_abs=False):
+              alphas, last_ids, v_render, v_alphas, absgrad=True, want_term_abs=False, pixel_mask=None):
     """want_term_abs: also returns term_abs[C,N,4+D] = per Gaussian the sums of |per-pixel term| of {conic 3, opacity 1,
-    colour D} (test aid: the conditioning of each row's sum; for xy it is v_means2d_abs)."""
+    colour D} (test aid: the conditioning of each row's sum; for xy it is v_means2d_abs).
+    pixel_mask bool[C,H,W] (with want_term_abs): additionally returns flip_terms[C,N,6+D] = the FLIP SENSITIVITY of every row
+    {xy 2, conic 3, opacity 1, colour D}: every masked pixel (pass the threshold-critical ones) is composited and back-propagated
+    once more per critical decision of its list with that decision inverted, and the absolute change of every Gaussian's
+    per-pixel terms is summed -- how far a row can move when those decisions fall the other way (orc_blend_bwd_ex2)."""
     means2d, conics, colors, opacities, backgrounds = map(_f, (means2d, conics, colors, opacities, backgrounds))
     alphas, v_render, v_alphas = map(_f, (alphas, v_render, v_alphas))
     Cc, N, D = colors.shape
@@ -252,13 +256,20 @@ def blend_bwd(means2d, conics, colors, opacities, backgrounds, W, H, tile_size, 
     v_colors = np.empty((Cc, N, D), np.float32)
     v_opac = np.empty((Cc, N), np.float32)
     term_abs = np.empty((Cc, N, 4 + D), np.float32) if want_term_abs else None
-    lib().orc_blend_bwd_ex(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
+    mask_u8 = mask_terms = None
+    if pixel_mask is not None:
+        assert want_term_abs
+        mask_u8 = np.ascontiguousarray(np.asarray(pixel_mask).reshape(Cc, H, W), dtype=np.uint8)
+        mask_terms = np.empty((Cc, N, 6 + D), np.float32)
+    lib().orc_blend_bwd_ex2(Cc, C.c_int64(N), D, _p(means2d, C.c_float), _p(conics, C.c_float),
                            _p(colors, C.c_float), _p(opacities, C.c_float), _p(backgrounds, C.c_float),
                            W, H, tile_size, tw, th, _p(offsets, C.c_int32), _p(flatten_ids, C.c_int32),
                            C.c_int64(flatten_ids.shape[0]), _p(alphas, C.c_float), _p(last_ids, C.c_int32),
                            _p(v_render, C.c_float), _p(v_alphas, C.c_float), _p(v_means2d, C.c_float),
                            _p(v_abs, C.c_float), _p(v_conics, C.c_float), _p(v_colors, C.c_float),
-                           _p(v_opac, C.c_float), _p(term_abs, C.c_float))
+                           _p(v_opac, C.c_float), _p(term_abs, C.c_float), _p(mask_u8, C.c_uint8), _p(mask_terms, C.c_float))
+    if mask_terms is not None:
+        return v_means2d, v_abs, v_conics, v_colors, v_opac, term_abs, mask_terms
     if want_term_abs:
         return v_means2d, v_abs, v_conics, v_colors, v_opac, term_abs
     return v_means2d, v_abs, v_conics, v_colors, v_opac

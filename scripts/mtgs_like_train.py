@@ -194,6 +194,7 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
 VISFIRST = {"on": False, "cs": None, "normals": True, "geometry_rows": False}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
 ROWLAZY = {"on": False, "opt": None}     # --row-lazy: exact row-lazy Adam for the colour parameters (needs --visfirst --optimizer fused)
 LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
+REGS = {"on": False}                     # --regularizers: the 2D and sharp-shape terms on the collected scales
 LAST = {"info": {}}                      # the device scalars of the last rasterization's `info` (graph mode: overflow flag and counts)
 
 
@@ -257,6 +258,15 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         l1 = masked_l1(gt, rgb, mask) if fused else torch.abs(gt - rgb)[mask.squeeze(-1)].mean()
         ssim = masked_ssim(gt, rgb, mask) if fused else ssim_chain(gt, rgb, mask, win)
         loss = 0.8 * l1 + 0.2 * (1 - ssim)
+    if REGS["on"]:
+        # the terms of get_loss_dict that reach the Gaussians OUTSIDE the rasterization (mtgs_scene_graph.py:936-939, 969-981:
+        # two_d_gaussians and sharp_shape_reg_lambda = 1.0 in config/MTGS.py:114-118): a dense gradient on the collected scales --
+        # with --geometry-rows the optimizer steps scales with this .grad PLUS the rasterization's rows
+        sc = gs["scales"]
+        two_d = torch.min(sc, dim=1, keepdim=True)[0].mean()
+        srt, _ = torch.sort(sc, dim=-1, descending=True)
+        sharp = (torch.maximum(srt[..., 0] / srt[..., 1], torch.tensor(10.0, device=sc.device)) - 10.0).mean()
+        loss = loss + two_d + 1.0 * sharp
     loss.backward()
     sizes = [p["means"].shape[0] for p in P.values()]
     with torch.no_grad():
@@ -778,6 +788,8 @@ def main():
                     "nuPlan images; default: scaled once for the synthetic scene)")
     ap.add_argument("--drop", type=float, default=0.1, help="with --converge: fraction of the true Gaussians the model starts without")
     ap.add_argument("--poll-every", type=int, default=16)
+    ap.add_argument("--regularizers", action="store_true", help="add MTGS's '2D reg' and 'Sharp Shape Reg' terms on the collected scales "
+                    "(mtgs_scene_graph.py:936-939, 969-981): loss terms that reach the Gaussians outside the rasterization")
     ap.add_argument("--first-cap-scale", type=float, default=1.0, help="with --train-graph (tests): scale of the first graphs' capacities; "
                     "< 1 makes their frames overflow, which the loop must notice and repair")
     ap.add_argument("--steady", type=int, nargs=2, default=None, help="with --steps: also report the time per step between these two steps")
@@ -796,6 +808,7 @@ def main():
     if args.train_graph and not args.steps:
         raise SystemExit("--train-graph needs --steps")
     VISFIRST["on"] = bool(args.visfirst)
+    REGS["on"] = bool(args.regularizers)
     VISFIRST["normals"] = not args.dense_normals
     VISFIRST["geometry_rows"] = bool(args.geometry_rows)
     if args.geometry_rows and not (args.visfirst and args.optimizer in (None, "fused")):

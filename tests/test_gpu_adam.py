@@ -135,6 +135,53 @@ def test_fused_adam_row_gradients_equal_dense_gradients(hip_lib):
         rows = rows * 0.5
 
 
+def test_fused_adam_adds_a_dense_gradient_to_the_row_gradient(hip_lib):
+    """Both gradient sources on one parameter: `p.grad` (a loss term that reaches the parameter outside the rasterization:
+    MTGS's scale regularisers, mtgs_scene_graph.py:936-981) AND set_row_gradient() (the rasterization's own gradient) -- the step
+    uses their sum, bit-identical to one dense gradient holding `dense + scattered rows` (round 3 ignored p.grad silently);
+    widths 3 / 4 / 45 / 1 and an unaligned tensor; a row-lazy parameter refuses the combination."""
+    from mtgs_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    N = 9_973
+    g = torch.Generator().manual_seed(8)
+    vis = torch.rand(N, generator=g) < 0.2
+    n_vis = int(vis.sum())
+    row_of = torch.full((N,), -1, dtype=torch.int32)
+    row_of[vis] = torch.arange(n_vis, dtype=torch.int32)
+    rows = torch.randn(n_vis, 64, generator=g)
+    layout = [("scales", (3,), 0), ("quats", (4,), 3), ("opacities", (), 7), ("rest", (15, 3), 8)]
+    base = {k: torch.randn(N, *shp, generator=g) for k, shp, _ in layout}
+    reg = {k: 0.3 * torch.randn(N, *shp, generator=g) for k, shp, _ in layout}
+
+    def make():
+        P = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        return P, FusedAdam([{"params": [p], "lr": 1e-2 * (i + 1)} for i, p in enumerate(P.values())], eps=1e-15)
+
+    Pa, oa = make()
+    Pb, ob = make()
+    rows_d, row_of_d = rows.to(dev), row_of.to(dev)
+    for step in range(3):
+        for k, shp, col in layout:
+            width = int(np.prod(shp)) if shp else 1
+            scat = torch.zeros(N, width)
+            scat[vis] = rows[:, col:col + width]
+            Pa[k].grad = (reg[k].view(N, width) + scat).view(N, *shp).to(dev)           # dense + rows, added in fp32 on the host
+            Pb[k].grad = reg[k].clone().to(dev)
+            ob.set_row_gradient(Pb[k], rows_d, row_of_d, col)
+        oa.step()
+        ob.step()
+        for k in Pa:
+            assert torch.equal(Pa[k], Pb[k]), (step, k)
+            assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), (step, k)
+    p = base["rest"].clone().to(dev).requires_grad_(True)
+    ol = FusedAdam([{"params": [p], "lr": 1e-2}], eps=1e-15)
+    ol.set_row_lazy(p)
+    p.grad = torch.zeros_like(p)
+    ol.set_row_gradient(p, rows_d, row_of_d, 8)
+    with pytest.raises(RuntimeError, match="row-lazy"):
+        ol.step()
+
+
 def test_fused_adam_state_dict_round_trip_with_torch_adam(hip_lib):
     """state_dict() is torch.optim.Adam's: a run can switch optimizers in either direction (checkpoints of the reference
     keep `optimizers` per group, custom_trainer.py:148-157)."""

@@ -96,9 +96,10 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
     Gc_raw = Gc_n.copy()
     Gc_raw[..., -1:] = Gc_n[..., -1:] / alc
     Ga_tot = Ga_n - (m["render_raw"][..., -1:] / alc ** 2) * Gc_n[..., -1:] * (a_ref > 1e-10)
-    v2d, vabs, vcon, vcol, vop, tabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
-                                                        m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
-                                                        Ga_tot, want_term_abs=True)
+    # ctabs: the same sums of |terms| over the threshold-critical pixels only -- the magnitude bound of the flipped rows
+    v2d, vabs, vcon, vcol, vop, tabs, ctabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                               m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
+                                                               Ga_tot, want_term_abs=True, pixel_mask=m["critical"])
     r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3,
                                                  m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
                                                  vcon, vop * a["opacities"][None])
@@ -106,13 +107,15 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
     # TERM_REL of their sum of |terms|, or (b) Gaussians on the list of a pixel whose alpha >= 1/255 / T <= 1e-4 decision
     # demonstrably flipped (`flipped`: the critical pixels where the IMAGE differs); nothing else.
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
-    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"])
+    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs)
 
     def close(name, got, ref, **kw):
         return assert_grad_close(name, got, ref, case=case, **kw)
 
-    close("means2d.grad", info["means2d"].grad, v2d, term_abs=vabs, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
-    close("means2d.absgrad", info["means2d"].absgrad, vabs, term_abs=vabs, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
+    close("means2d.grad", info["means2d"].grad, v2d, term_abs=vabs, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
+          crit_abs=ctabs[0, :, 0:2])
+    close("means2d.absgrad", info["means2d"].absgrad, vabs, term_abs=vabs, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
+          crit_abs=ctabs[0, :, 0:2])
     assert bool((info["means2d"].absgrad >= info["means2d"].grad.abs() - 1e-5).all())
     # behind the projection backward: the VJP itself, applied to the device's own rows, is within 1e-3 on EVERY row
     projection_vjp_accounted(case, oracle, dbg, a, vm.numpy(), K.numpy(), W, H, m, {k: P[k].grad for k in ("means", "quats", "scales", "opacities")})
@@ -123,14 +126,16 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
     #  4e-4 at 500k, 1.4e-3 at 2M Gaussians, against <= 6e-4 for every other tensor: its percentile bar is relaxed, but every
     #  row over 1e-3 must be a cancelling sum within TERM_REL of its sum of |terms|, or a flipped row)
     close("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0), row_rel_p999=2.5e-3,
-          term_abs=(tabs[..., 3] * m["compensations"]).sum(0), flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
+          term_abs=(tabs[..., 3] * m["compensations"]).sum(0), flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
+          crit_abs=(ctabs[..., 5] * m["compensations"]).sum(0))
     close("v_viewmats", vmd.grad[0], r_vvm[0])
     if sh:
         mask = (rgb_ref > 0.0) & (rgb_ref < 1.0)
         ref_vc, _ = oracle.sh_bwd(3, dirs, a["coeffs"], vcol[0, :, :3] * mask)
         close("v_coeffs", P["coeffs"].grad, ref_vc)
     else:
-        close("v_colors", P["colors"].grad, vcol[0, :, :3], term_abs=tabs[0, :, 4:7], flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
+        close("v_colors", P["colors"].grad, vcol[0, :, :3], term_abs=tabs[0, :, 4:7], flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
+              crit_abs=ctabs[0, :, 6:9])
 
 
 @pytest.mark.parametrize("W,H", [(1280, 720), (960, 540), (333, 211)])
@@ -171,14 +176,16 @@ def test_midsize_images_use_more_waves_per_tile(gs, oracle, W, H):
     Gc_raw = Gc.numpy().copy()
     Gc_raw[..., -1:] = Gc.numpy()[..., -1:] / alc
     Ga_tot = Ga.numpy() - (m["render_raw"][..., -1:] / alc ** 2) * Gc.numpy()[..., -1:] * (a_ref > 1e-10)
-    v2d, vabs, vcon, vcol, vop, tabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
-                                                        m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
-                                                        Ga_tot, want_term_abs=True)
+    # ctabs: the same sums of |terms| over the threshold-critical pixels only -- the magnitude bound of the flipped rows
+    v2d, vabs, vcon, vcol, vop, tabs, ctabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                               m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
+                                                               Ga_tot, want_term_abs=True, pixel_mask=m["critical"])
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
-    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"])
-    for name, got, ref, ta in (("means2d.grad", info["means2d"].grad, v2d, vabs), ("absgrad", info["means2d"].absgrad, vabs, vabs),
-                               ("v_colors", P["colors"].grad, vcol[0, :, :3], tabs[0, :, 4:7])):
-        assert_grad_close(name, got, ref, case=case, term_abs=ta, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
+    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs)
+    for name, got, ref, ta, ca in (("means2d.grad", info["means2d"].grad, v2d, vabs, ctabs[0, :, 0:2]),
+                                   ("absgrad", info["means2d"].absgrad, vabs, vabs, ctabs[0, :, 0:2]),
+                                   ("v_colors", P["colors"].grad, vcol[0, :, :3], tabs[0, :, 4:7], ctabs[0, :, 6:9])):
+        assert_grad_close(name, got, ref, case=case, term_abs=ta, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"], crit_abs=ca)
 
 
 def test_fullsize_properties_linearity_and_determinism(gs):
@@ -246,22 +253,23 @@ def test_shipped_option_cell_7_channels_960x540(gs, oracle):
     Gc_raw = Gc.numpy().copy()
     Gc_raw[..., -1:] = Gc.numpy()[..., -1:] / alc
     Ga_tot = Ga.numpy() - (m["render_raw"][..., -1:] / alc ** 2) * Gc.numpy()[..., -1:] * (a_ref > 1e-10)
-    v2d, vabs, vcon, vcol, vop, tabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
-                                                        m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
-                                                        Ga_tot, want_term_abs=True)
+    # ctabs: the same sums of |terms| over the threshold-critical pixels only -- the magnitude bound of the flipped rows
+    v2d, vabs, vcon, vcol, vop, tabs, ctabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
+                                                               m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
+                                                               Ga_tot, want_term_abs=True, pixel_mask=m["critical"])
     r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3,
                                                  m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
                                                  vcon, vop * a["opacities"][None])
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
-    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"])
+    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs)
     projection_vjp_accounted(case, oracle, dbg, a, vm.numpy(), K.numpy(), W, H, m, {k: P[k].grad for k in ("means", "quats", "scales", "opacities")})
     fl = dict(flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
-    for name, got, ref, kw in (("means2d.grad", info["means2d"].grad, v2d, dict(term_abs=vabs, **fl)),
-                               ("means2d.absgrad", info["means2d"].absgrad, vabs, dict(term_abs=vabs, **fl)),
+    for name, got, ref, kw in (("means2d.grad", info["means2d"].grad, v2d, dict(term_abs=vabs, crit_abs=ctabs[0, :, 0:2], **fl)),
+                               ("means2d.absgrad", info["means2d"].absgrad, vabs, dict(term_abs=vabs, crit_abs=ctabs[0, :, 0:2], **fl)),
                                ("v_means", P["means"].grad, r_vm, {}), ("v_quats", P["quats"].grad, r_vq, {}),
                                ("v_scales", P["scales"].grad, r_vs, {}),
                                ("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0),
-                                dict(term_abs=(tabs[..., 3] * m["compensations"]).sum(0), **fl)),
+                                dict(term_abs=(tabs[..., 3] * m["compensations"]).sum(0), crit_abs=(ctabs[..., 5] * m["compensations"]).sum(0), **fl)),
                                ("v_viewmats", vmd.grad[0], r_vvm[0], {}),
-                               ("v_colors", P["colors"].grad, vcol[0, :, :D], dict(term_abs=tabs[0, :, 4:4 + D], **fl))):
+                               ("v_colors", P["colors"].grad, vcol[0, :, :D], dict(term_abs=tabs[0, :, 4:4 + D], crit_abs=ctabs[0, :, 6:6 + D], **fl))):
         assert_grad_close(name, got, ref, case=case, **kw)

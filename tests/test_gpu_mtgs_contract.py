@@ -400,3 +400,19 @@ def test_graph_training_notices_a_capacity_overflow_and_recaptures():
     assert "exceeded its capacities" in out
     conv = re.search(r"converge: loss ([\d.]+) -> ([\d.]+)", out)
     assert float(conv.group(2)) < 0.7 * float(conv.group(1))
+
+
+def test_regularizers_outside_the_rasterization_reach_row_gradient_parameters():
+    """A loss term that reaches a parameter OUTSIDE the rasterization (MTGS's 2D and sharp-shape regularisers on the collected
+    scales, mtgs_scene_graph.py:936-939, 969-981) leaves a dense .grad while --geometry-rows hands the rasterization's own
+    gradient to the optimizer as rows: FusedAdam steps with their SUM (csrc/adam.hip, both sources) -- same training as the
+    autograd path, where the two meet in one dense gradient.  (Round 3 dropped the dense part silently.)"""
+    from tests.util import assert_same_training
+    common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "3", "--width", "320", "--height", "200", "--steps", "45",
+              "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped", "--optimizer", "fused", "--visfirst", "--regularizers"]
+    dense = _run_train(common)
+    rows = _run_train(common + ["--row-lazy", "--geometry-rows"])
+    assert_same_training(rows, dense, 2, 45, 20)
+    without = _run_train([a for a in common if a != "--regularizers"])
+    curve = lambda out: [float(x) for x in __import__("re").search(r"loss: (.*)", out).group(1).split()]
+    assert abs(curve(without)[0] - curve(dense)[0]) > 1e-3          # (the terms are there and matter)

@@ -248,3 +248,50 @@ def test_absgrad_dominates_grad(impl):
         v2d, vabs = out[0], out[1]
     assert np.all(vabs >= np.abs(v2d) - 1e-6)
     assert np.all((al >= 0) & (al < 1))
+
+
+def test_flip_sensitivity_of_a_threshold_critical_pixel(oracle):
+    """orc_blend_bwd_ex2 (test infrastructure of the row accounting): at a threshold-critical pixel the oracle re-composites
+    with the critical decision inverted and reports per Gaussian how far its per-pixel terms move.  Hand case: ONE pixel, a front
+    Gaussian whose alpha sits 5e-5 above 1/255 (included by the oracle; excluding it is the flip) and an ordinary one behind:
+    the front one's colour term a0 |vr| disappears, the back one's a1 T1 |vr| loses the factor (1 - a0): a change of a1 a0 |vr|.
+    No mask -> zeros; the gradients do not depend on the mask; an uncritical scene has no sensitivity anywhere."""
+    W = H = 16
+    px, py = 8, 8
+    means2d = np.array([[[px + 0.5 + 1.0, py + 0.5 + 0.5], [px + 0.5 - 0.5, py + 0.5 + 0.25]]], np.float32)
+    conics = np.array([[[0.02, 0.0, 0.03], [0.05, 0.01, 0.04]]], np.float32)
+    d0 = means2d[0, 0] - np.array([px + 0.5, py + 0.5], np.float32)
+    sigma0 = 0.5 * (0.02 * d0[0] ** 2 + 0.03 * d0[1] ** 2)
+    a_min = 1.0 / 255.0
+    op0 = np.float32(a_min * (1 + 5e-5) * math.exp(sigma0))
+    opac = np.array([[op0, 0.5]], np.float32)
+    colors = np.array([[[0.9, 0.2, 0.4], [0.1, 0.8, 0.3]]], np.float32)
+    offsets = np.zeros((1, 1, 1), np.int32)
+    flat = np.array([0, 1], np.int32)
+    r, al, last, crit = oracle.blend_fwd(means2d, conics, colors, opac, None, W, H, 16, offsets, flat, want_critical=True)
+    assert crit[0, py, px] and oracle.blend_fwd.critical_gaussians[0, 0] and not oracle.blend_fwd.critical_gaussians[0, 1]
+    g = np.random.default_rng(1)
+    Gc, Ga = g.standard_normal(r.shape).astype(np.float32), np.zeros(al.shape, np.float32)
+    mask = np.zeros((1, H, W), bool)
+    mask[0, py, px] = True
+    args = (means2d, conics, colors, opac, None, W, H, 16, offsets, flat, al, last, Gc, Ga)
+    base = oracle.blend_bwd(*args, want_term_abs=True)
+    out = oracle.blend_bwd(*args, want_term_abs=True, pixel_mask=mask)
+    for x, y in zip(base, out[:6]):
+        np.testing.assert_array_equal(x, y)
+    flip = out[6]
+    vr = np.abs(Gc[0, py, px])
+    d1 = means2d[0, 1] - np.array([px + 0.5, py + 0.5], np.float32)
+    a0 = op0 * math.exp(-sigma0)
+    a1 = 0.5 * math.exp(-(0.5 * (0.05 * d1[0] ** 2 + 0.04 * d1[1] ** 2) + 0.01 * d1[0] * d1[1]))
+    np.testing.assert_allclose(flip[0, 0, 6:9], a0 * vr, rtol=1e-4)
+    np.testing.assert_allclose(flip[0, 1, 6:9], a1 * a0 * vr, rtol=1e-3)
+    assert float(flip[0, :, :6].max()) > 0.0                              # geometry terms move too
+    none = oracle.blend_bwd(*args, want_term_abs=True, pixel_mask=np.zeros_like(mask))
+    assert float(np.abs(none[6]).max()) == 0.0
+    opac2 = np.array([[0.7, 0.5]], np.float32)                            # nothing near a threshold: a masked pixel adds nothing
+    r2, al2, last2, crit2 = oracle.blend_fwd(means2d, conics, colors, opac2, None, W, H, 16, offsets, flat, want_critical=True)
+    assert not crit2.any()
+    out2 = oracle.blend_bwd(means2d, conics, colors, opac2, None, W, H, 16, offsets, flat, al2, last2, Gc, Ga, want_term_abs=True,
+                            pixel_mask=np.ones_like(mask))
+    assert float(np.abs(out2[6]).max()) == 0.0
