@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 20
+#define MTGS_RAST_ABI_VERSION 21
 
 enum {
     MTGS_OK = 0,
@@ -375,6 +375,28 @@ int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *mean
                           const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                           float *v_coeffs, int64_t g_begin, int64_t g_end, uint64_t coeff_mask, int write_geometry,
                           int64_t coeff_stride, void *stream);
+/* ROWS out of the exchange (ABI v21): the receiver's sums as compact rows of the UNION of the senders' visible sets instead of
+ * dense [N, .] tensors -- what lets the optimizer step the rows some camera of the step saw, and only those
+ * (mtgs_amd.dist.SparseGradExchange.finish(rows=True) -> FusedAdam.set_row_gradient; reference: the per-traversal tensors of
+ * multi_color_gaussian_splatting.py:53-80 under the data-parallel site custom_pipeline.py:87-89).
+ * mtgs_dp_union: P sender subsets (masks[p], bit r = sender r) -> union_words[P, ceil(N/64)], union_prefix[P, ceil(N/64)] (the
+ * map format of a sender: row(n) = prefix[n/64] + popcount(words[n/64] below bit n%64)), totals[p] = number of rows << 32 (the
+ * packing of mtgs_front_fwd's totals); block_counts[P * ceil(ceil(N/64) / 256)] is scratch.
+ * mtgs_dp_reduce_rows: the pass of mtgs_dp_reduce_slices over [g_begin, g_end) with row outputs, either half optional:
+ *   geometry (sum over ALL senders): geo_rows[geo_cap, 16] = {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, C0 * sum v_rgb 3 (the
+ *     gradient of SH coefficient 0: features_dc), 0, Gaussian index}, geo_row_of[N] (row or -1), geo_ids[geo_cap] (row -> Gaussian),
+ *     numbered by the union map (geo_words, geo_prefix) of the full subset;
+ *   colour (sum over the senders of coeff_mask): coef_rows[coef_cap, coef_stride >= 3 K], coefficient k channel c at 3 k + c,
+ *     coef_row_of[N], numbered by the union map of that subset.
+ * The sums are formed in the order of mtgs_dp_reduce: a row equals the dense entry bit for bit.  Rows beyond a capacity are
+ * dropped (their row_of entry still names them: mtgs_adam_step ignores rows >= n_rows). */
+int mtgs_dp_union(int W, int64_t N, const uint64_t *words, int64_t map_stride_bytes, int P, const uint64_t *masks,
+                  uint64_t *union_words, uint32_t *union_prefix, int64_t *totals, uint32_t *block_counts, void *stream);
+int mtgs_dp_reduce_rows(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words, const uint32_t *prefix,
+                        int64_t map_stride_bytes, const float *rows, int64_t row_stride, const float *cams, int64_t g_begin,
+                        int64_t g_end, uint64_t coeff_mask, float *geo_rows, const uint64_t *geo_words, const uint32_t *geo_prefix,
+                        int32_t *geo_row_of, int32_t *geo_ids, int64_t geo_cap, float *coef_rows, const uint64_t *coef_words,
+                        const uint32_t *coef_prefix, int32_t *coef_row_of, int64_t coef_cap, int64_t coef_stride, void *stream);
 /* Wire rows straight from the compositing backward's compact gradient rows (no dense tensor, no pack pass): the VJP of
  * the projection per VISIBLE Gaussian (vis_ids[n_vis], index order; C = 1) writes wire_rows[n_vis,16] =
  * {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, 0, Gaussian index (int bits)}.  grad_rows[n_vis,row_stride] as mtgs_blend_bwd_packed
@@ -465,13 +487,14 @@ int mtgs_node_fwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_
                         int64_t *model_id, void *stream);
 int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int64_t total_blocks, int degree, const float *cam_pos,
                         void *stream);
-/* The geometry half of the node backward for the VISIBLE Gaussians: ws_rows[cap_vis, 12] (mtgs_project_bwd, rows only) ->
+/* The geometry half of the node backward for the VISIBLE Gaussians: ws_rows[cap_vis, ws_stride >= 12] (mtgs_project_bwd, rows only: 12;
+ * mtgs_dp_reduce_rows' geometry rows: 16) -> 
  * param_rows[cap_vis, 12] = [means 3 | scales 3 | quats 4 | opacities 1 | pad], the gradients with respect to the RAW parameters of
  * Gaussian vis_ids[r] (exp / normalise / sigmoid VJPs through the descriptors' scales / quats_raw / opacities), r < min(cap_vis,
  * *totals >> 32) (totals nullable).  Static nodes only (pose = NULL).  The rows go to mtgs_adam_step through a row map: the dense
  * geometry gradients (zeros for ~85 % of the Gaussians) are neither written nor read. */
 int mtgs_node_bwd_rows(int n_nodes, const mtgs_node_desc *table, const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis,
-                       const float *ws_rows, float *param_rows, void *stream);
+                       const float *ws_rows, int ws_stride, float *param_rows, void *stream);
 
 /* ---- camera-space normals of the Gaussians (predict_normals, the shipped MTGS.py config: 3 more blended channels) ------
  * MTGSSceneModel._get_gaussian_camera_space_normals (mtgs_scene_graph.py:526-545), ~25 PyTorch launches per direction and a

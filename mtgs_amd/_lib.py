@@ -66,6 +66,9 @@ _SIGNATURES = {
     "mtgs_dp_pack": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "mtgs_dp_union": [_i32, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_dp_reduce_rows": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _i64,
+                            _vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "mtgs_dp_reduce": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "mtgs_dp_reduce_slices": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                               C.c_uint64, _i32, _i64, _vp],
@@ -78,7 +81,7 @@ _SIGNATURES = {
     "mtgs_node_desc_bytes": [],
     "mtgs_node_fwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp, _vp],
     "mtgs_node_bwd_batch": [_i32, _vp, _i64, _i32, _vp, _vp],
-    "mtgs_node_bwd_rows": [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "mtgs_node_bwd_rows": [_i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_normals_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -135,7 +138,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 

@@ -247,13 +247,26 @@ constexpr int DP_MAXSTEP = DP_TILE / 4;
 // Gaussian-centric loop with a predicate per (Gaussian, sender) pair ran 48 % of its steps with ~30 % of the lanes
 // useful: 512 us at 8 senders.)  The Gaussian range [g_begin, g_end) lets the caller reduce one CHUNK of the index
 // range while the next chunk's rows are still on the wire.
-template <int MAXDEG>
+// ROW outputs (mtgs_dp_reduce_rows): instead of dense [N, .] tensors the sums leave as compact rows of the UNION of the
+// senders' visible sets -- geometry over all senders, colour over the senders of coeff_mask -- numbered in index order by a
+// union map (words / prefix, mtgs_dp_union): row(n) = prefix[n / 64] + popcount(words[n / 64] below bit n % 64), exactly as a
+// sender numbers its own rows.  geo row (16 floats) = {v_mean 3, v_quat 4, v_scale 3, v_opacity 1 | C0 * sum v_rgb 3 (the
+// gradient of SH coefficient 0 over ALL senders: what MTGS's features_dc receives from every traversal) | 0 | index};
+// colour row = coeff_stride floats, coefficient k channel c at 3 k + c.  row_of[N] (int32, -1: no sender sees the Gaussian) is
+// the map mtgs_adam_step takes; ids[u] = the Gaussian of geo row u (mtgs_node_bwd_rows).  Rows beyond a capacity are dropped.
+struct DpRowOut {
+    float *geo_rows; const unsigned long long *geo_words; const uint32_t *geo_prefix; int32_t *geo_row_of, *geo_ids; int64_t geo_cap;
+    float *coef_rows; const unsigned long long *coef_words; const uint32_t *coef_prefix; int32_t *coef_row_of; int64_t coef_cap;
+};
+constexpr float kShC0 = 0.2820947917738781f;
+
+template <int MAXDEG, bool ROWS = false>
 __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t g_end, int K, int nb,
                                                         const float *__restrict__ means, const DpSenders S,
                                                         float *__restrict__ v_means, float *__restrict__ v_quats,
                                                         float *__restrict__ v_scales, float *__restrict__ v_opacities,
                                                         float *__restrict__ v_coeffs, unsigned long long coeff_mask, int geom,
-                                                        int64_t coeff_stride) {
+                                                        int64_t coeff_stride, const DpRowOut R = DpRowOut{}) {
     // coeff_mask: the senders whose colour factors go into v_coeffs (per-traversal appearance: one pass per traversal
     // writes that traversal's slice, Gaussian n at v_coeffs + n * coeff_stride); geom: this pass also sums and writes
     // the geometry gradients (over ALL senders).
@@ -273,7 +286,8 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
     // the tile's means in LDS: a global gather per row would put a dependent memory round trip into every step
     __shared__ float s_mean[4][DP_TILE * 3];
     float *tmean = s_mean[wave];
-    if (v_coeffs) {
+    const bool any_colour = v_coeffs != nullptr || (ROWS && R.coef_rows != nullptr);
+    if (any_colour) {
         for (int e = lane; e < DP_TILE * 3; e += 64) tmean[e] = g0 * 3 + e < N * 3 ? means[g0 * 3 + e] : 1.f;
     }
     // (first row, number of rows, tile bits) every sender has for this tile: one lane per sender, one memory round trip
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         for (int st = 0; st < DP_MAXSTEP; ++st) cur[st] = nxt[st];
         const int cnt = nxt_cnt;
         if (r + 1 < S.W) issue(r + 1, nxt, nxt_cnt);
-        const bool colour = v_coeffs && ((coeff_mask >> r) & 1ull);
+        const bool colour = any_colour && ((coeff_mask >> r) & 1ull);
         if (cnt == 0 || !(geom || colour)) continue;  // wave-uniform: none of the tile's Gaussians / nothing to take from it
         const float cx = S.cams[r * 3], cy = S.cams[r * 3 + 1], cz = S.cams[r * 3 + 2];
 #pragma unroll
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
             const int idx = __builtin_amdgcn_ds_bpermute(row_lane0 + 15 * 4, vi);   // the row's Gaussian index (last word)
             const int pos = on ? (int)(idx - (int)g0) : 0;
             float4 a = acc[pos][k];
-            a.x += (geom && k < 11) ? cur[st] : 0.f;
+            a.x += (geom && k < 14) ? cur[st] : 0.f;      // (lanes 11-13: the sum of v_rgb over ALL senders, used by the row outputs)
             if (colour) {
                 const float q0 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 11 * 4, vi));
                 const float q1 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 12 * 4, vi));
@@ -334,6 +348,39 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
             }
             if (on) acc[pos][k] = a;
         }
+    }
+    if constexpr (ROWS) {
+        const bool want_colour = R.coef_rows != nullptr;
+        const unsigned long long uwg = geom ? R.geo_words[wi] : 0ull, uwc = want_colour ? R.coef_words[wi] : 0ull;
+        const int64_t upg = geom ? (int64_t)R.geo_prefix[wi] : 0, upc = want_colour ? (int64_t)R.coef_prefix[wi] : 0;
+#pragma unroll
+        for (int it = 0; it < DP_MAXSTEP; ++it) {
+            const int64_t n = g0 + it * 4 + sub;
+            if (n >= N) continue;
+            const int bit = (int)(n & 63);
+            const unsigned long long below = (1ull << bit) - 1ull;
+            const float4 a = acc[it * 4 + sub][k];
+            if (geom) {
+                const bool present = (uwg >> bit) & 1ull;
+                const int64_t u = upg + __popcll(uwg & below);
+                if (k == 0) R.geo_row_of[n] = present ? (int32_t)u : -1;
+                if (present && u < R.geo_cap) {
+                    const float v = k < 11 ? a.x : (k < 14 ? kShC0 * a.x : (k == 15 ? __int_as_float((int)n) : 0.f));
+                    R.geo_rows[u * 16 + k] = v;
+                    if (k == 15) R.geo_ids[u] = (int32_t)n;
+                }
+            }
+            if (want_colour) {
+                const bool present = (uwc >> bit) & 1ull;
+                const int64_t u = upc + __popcll(uwc & below);
+                if (k == 0) R.coef_row_of[n] = present ? (int32_t)u : -1;
+                if (present && u < R.coef_cap && k < K) {
+                    float *dst = R.coef_rows + u * coeff_stride + k * 3;
+                    dst[0] = a.y; dst[1] = a.z; dst[2] = a.w;
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int it = 0; it < DP_MAXSTEP; ++it) {
@@ -353,7 +400,132 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
     }
 }
 
+// Union maps of sender subsets (mtgs_dp_union): launch 1 ORs the senders' visibility words per subset and counts the set bits
+// per 256-word block; launch 2 turns the counts into word prefixes (every block sums the few hundred counts in front of it, as
+// dp_pack_ordered_kernel does) and publishes the totals, packed like mtgs_front_fwd's totals (count << 32).
+constexpr int UNION_BLOCK = 256;
+__global__ __launch_bounds__(UNION_BLOCK) void dp_union_words_kernel(int64_t nw, int W, const unsigned long long *__restrict__ words,
+                                                                     int64_t map_stride_bytes, const unsigned long long *__restrict__ masks,
+                                                                     unsigned long long *__restrict__ uwords, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t s_c[UNION_BLOCK / 64];
+    const int p = blockIdx.y;
+    const int64_t wi = (int64_t)blockIdx.x * UNION_BLOCK + threadIdx.x;
+    const unsigned long long mask = masks[p];
+    unsigned long long u = 0;
+    if (wi < nw)
+        for (int r = 0; r < W; ++r)
+            if ((mask >> r) & 1ull) u |= reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(words) + r * map_stride_bytes)[wi];
+    if (wi < nw) uwords[(int64_t)p * nw + wi] = u;
+    uint32_t c = (uint32_t)__popcll(u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < UNION_BLOCK / 64; ++w) t += s_c[w];
+        block_counts[(int64_t)p * gridDim.x + blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(UNION_BLOCK) void dp_union_prefix_kernel(int64_t nw, const unsigned long long *__restrict__ uwords,
+                                                                      const uint32_t *__restrict__ block_counts,
+                                                                      uint32_t *__restrict__ uprefix, int64_t *__restrict__ totals) {
+    __shared__ uint32_t s_red[UNION_BLOCK / 64];
+    __shared__ uint32_t s_w[UNION_BLOCK / 64];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *bc = block_counts + (int64_t)p * gridDim.x;
+    uint32_t part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += UNION_BLOCK) part += bc[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) s_red[wave] = part;
+    const int64_t wi = (int64_t)blockIdx.x * UNION_BLOCK + tid;
+    const uint32_t c = wi < nw ? (uint32_t)__popcll(uwords[(int64_t)p * nw + wi]) : 0u;
+    uint32_t inc = c;                     // inclusive scan of the word counts inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < UNION_BLOCK / 64; ++w) base += s_red[w];
+    uint32_t before = base + inc - c, total = base;
+#pragma unroll
+    for (int w = 0; w < UNION_BLOCK / 64; ++w) {
+        if (w < wave) before += s_w[w];
+        total += s_w[w];
+    }
+    if (wi < nw) uprefix[(int64_t)p * nw + wi] = before;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) totals[p] = (int64_t)total << 32;
+}
+
 }  // namespace
+
+extern "C" int mtgs_dp_union(int W, int64_t N, const uint64_t *words, int64_t map_stride_bytes, int P, const uint64_t *masks,
+                             uint64_t *union_words, uint32_t *union_prefix, int64_t *totals, uint32_t *block_counts, void *stream) {
+    MTGS_REQUIRE(W >= 1 && W <= DP_MAX_SENDERS && N >= 0 && P >= 1 && map_stride_bytes >= 0, MTGS_EINVAL, "mtgs_dp_union: bad sizes");
+    MTGS_REQUIRE(words && masks && union_words && union_prefix && totals && block_counts, MTGS_EINVAL, "mtgs_dp_union: null pointer");
+    const int64_t nw = (N + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (nw == 0) {
+        hipError_t e = hipMemsetAsync(totals, 0, sizeof(int64_t) * P, st);
+        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_dp_union: memset failed");
+        return MTGS_OK;
+    }
+    const dim3 grid((unsigned)ceil_div64(nw, UNION_BLOCK), (unsigned)P);
+    dp_union_words_kernel<<<grid, UNION_BLOCK, 0, st>>>(nw, W, (const unsigned long long *)words, map_stride_bytes,
+                                                        (const unsigned long long *)masks, (unsigned long long *)union_words, block_counts);
+    dp_union_prefix_kernel<<<grid, UNION_BLOCK, 0, st>>>(nw, (const unsigned long long *)union_words, block_counts, union_prefix, totals);
+    MTGS_CHECK_LAUNCH("mtgs_dp_union");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_dp_reduce_rows(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                                   const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
+                                   const float *cams, int64_t g_begin, int64_t g_end, uint64_t coeff_mask,
+                                   float *geo_rows, const uint64_t *geo_words, const uint32_t *geo_prefix, int32_t *geo_row_of,
+                                   int32_t *geo_ids, int64_t geo_cap, float *coef_rows, const uint64_t *coef_words,
+                                   const uint32_t *coef_prefix, int32_t *coef_row_of, int64_t coef_cap, int64_t coef_stride,
+                                   void *stream) {
+    MTGS_REQUIRE(W >= 1 && N >= 0 && map_stride_bytes >= 0 && row_stride >= 0 && geo_cap >= 0 && coef_cap >= 0, MTGS_EINVAL,
+                 "mtgs_dp_reduce_rows: bad sizes");
+    MTGS_REQUIRE(W <= DP_MAX_SENDERS, MTGS_EUNSUPPORTED, "mtgs_dp_reduce_rows: %d senders (at most %d)", W, DP_MAX_SENDERS);
+    if (g_end < 0) g_end = N;
+    MTGS_REQUIRE(g_begin >= 0 && g_begin <= g_end && g_end <= N && (g_begin % 64) == 0, MTGS_EINVAL,
+                 "mtgs_dp_reduce_rows: range [%lld, %lld) of %lld (the start must be a multiple of 64)", (long long)g_begin,
+                 (long long)g_end, (long long)N);
+    if (g_end == g_begin) return MTGS_OK;
+    MTGS_REQUIRE(geo_rows || coef_rows, MTGS_EINVAL, "mtgs_dp_reduce_rows: nothing to write");
+    MTGS_REQUIRE(words && prefix && rows && means, MTGS_EINVAL, "mtgs_dp_reduce_rows: null pointer");
+    MTGS_REQUIRE(!geo_rows || (geo_words && geo_prefix && geo_row_of && geo_ids), MTGS_EINVAL, "mtgs_dp_reduce_rows: geometry outputs");
+    int nb = 0;
+    if (coef_rows) {
+        MTGS_REQUIRE(coef_words && coef_prefix && coef_row_of && cams, MTGS_EINVAL, "mtgs_dp_reduce_rows: colour outputs");
+        MTGS_REQUIRE(degree >= 0 && degree <= 3 && K <= 16 && (degree + 1) * (degree + 1) <= K && coef_stride >= (int64_t)K * 3,
+                     MTGS_EUNSUPPORTED, "mtgs_dp_reduce_rows: degree %d / K %d / stride %lld", degree, K, (long long)coef_stride);
+        nb = (degree + 1) * (degree + 1);
+    }
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
+    const DpRowOut R{geo_rows, (const unsigned long long *)geo_words, geo_prefix, geo_row_of, geo_ids, geo_cap,
+                     coef_rows, (const unsigned long long *)coef_words, coef_prefix, coef_row_of, coef_cap};
+    const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned long long cm = coeff_mask;
+    const int geom = geo_rows ? 1 : 0;
+    float *none = nullptr;
+    switch (coef_rows ? degree : 0) {
+        case 0: dp_reduce_kernel<0, true><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, none, none, none, none, none, cm, geom, coef_stride, R); break;
+        case 1: dp_reduce_kernel<1, true><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, none, none, none, none, none, cm, geom, coef_stride, R); break;
+        case 2: dp_reduce_kernel<2, true><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, none, none, none, none, none, cm, geom, coef_stride, R); break;
+        default: dp_reduce_kernel<3, true><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, none, none, none, none, none, cm, geom, coef_stride, R); break;
+    }
+    MTGS_CHECK_LAUNCH("mtgs_dp_reduce_rows");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_dp_pack(int64_t N, const int32_t *radii, const float *v_means, const float *v_quats,
                             const float *v_scales, const float *v_opacities, const float *v_rgb, float *rows,

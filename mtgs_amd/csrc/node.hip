@@ -283,7 +283,8 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_geom_batch_kernel(const m
 // [N, .] gradient of the geometry is written or read.
 __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_rows_kernel(const mtgs_node_desc *__restrict__ table, int n_nodes,
                                                                    const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
-                                                                   int64_t cap_vis, const float *__restrict__ ws, float *__restrict__ out) {
+                                                                   int64_t cap_vis, const float *__restrict__ ws, int ws_stride,
+                                                                   float *__restrict__ out) {
     int64_t n_vis = totals ? *totals >> 32 : cap_vis;
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r = (int64_t)blockIdx.x * NODE_BLOCK + threadIdx.x;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_rows_kernel(const mtgs_no
     }
     const mtgs_node_desc &d = table[lo];
     const int64_t gl = g - d.start;
-    const float4 *w = reinterpret_cast<const float4 *>(ws + r * 12);
+    const float4 *w = reinterpret_cast<const float4 *>(ws + r * ws_stride);
     const float4 w0 = w[0], w1 = w[1], w2 = w[2];       // (v_mean xyz, vq.w) (vq.xyz', vs.x) (vs.yz, v_opacity, -)
     // exp / sigmoid recomputed from the RAW parameters (the expressions of the forward, so the same bits): the activated
     // tensors are autograd outputs that are released when the backward has run, i.e. before this kernel is enqueued
@@ -615,14 +616,14 @@ extern "C" int mtgs_node_bwd_batch(int n_nodes, const mtgs_node_desc *table, int
 }
 
 extern "C" int mtgs_node_bwd_rows(int n_nodes, const mtgs_node_desc *table, const int32_t *vis_ids, const int64_t *totals,
-                                  int64_t cap_vis, const float *ws_rows, float *param_rows, void *stream) {
-    MTGS_REQUIRE(n_nodes > 0 && cap_vis >= 0, MTGS_EINVAL, "mtgs_node_bwd_rows: bad sizes");
+                                  int64_t cap_vis, const float *ws_rows, int ws_stride, float *param_rows, void *stream) {
+    MTGS_REQUIRE(n_nodes > 0 && cap_vis >= 0 && ws_stride >= 12 && (ws_stride & 3) == 0, MTGS_EINVAL, "mtgs_node_bwd_rows: bad sizes");
     if (cap_vis == 0) return MTGS_OK;
     MTGS_REQUIRE(table && vis_ids && ws_rows && param_rows, MTGS_EINVAL, "mtgs_node_bwd_rows: null pointer");
     MTGS_REQUIRE(((reinterpret_cast<uintptr_t>(ws_rows) | reinterpret_cast<uintptr_t>(param_rows)) & 15) == 0, MTGS_EINVAL,
                  "mtgs_node_bwd_rows: rows must be 16-byte aligned");
     node_bwd_rows_kernel<<<(unsigned)ceil_div64(cap_vis, NODE_BLOCK), NODE_BLOCK, 0, (hipStream_t)stream>>>(table, n_nodes, vis_ids, totals,
-                                                                                                       cap_vis, ws_rows, param_rows);
+                                                                                                       cap_vis, ws_rows, ws_stride, param_rows);
     MTGS_CHECK_LAUNCH("mtgs_node_bwd_rows");
     return MTGS_OK;
 }

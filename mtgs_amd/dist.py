@@ -15,6 +15,7 @@ from __future__ import annotations
 import os
 from typing import Iterable, List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -271,9 +272,21 @@ class SparseGradExchange:
         # gradient exists in this mode)
         self.grad_rows, self.vis_ids = grad_rows, vis_ids
 
-    def finish(self, means: torch.Tensor, sh_degree: int):
+    def finish(self, means: torch.Tensor, sh_degree: int, rows: bool = False, all_colour_ranges=()):
         """After backward(): exchange the wire rows and return (v_means, v_quats, v_scales, v_opacities, v_coeffs) --
-        the dense sums over all ranks of the gradients that flowed through `rasterization()`."""
+        the dense sums over all ranks of the gradients that flowed through `rasterization()`.
+
+        rows = True: the sums leave as compact ROWS of the union of the ranks' visible sets instead (mtgs_dp_union /
+        mtgs_dp_reduce_rows): no dense [N, .] tensor -- in particular no [N, T, K, 3] coefficient gradient, 472 MB x T of
+        mostly zeros per step at 2M Gaussians -- is written, and an optimizer that takes row gradients
+        (FusedAdam.set_row_gradient, row-lazy for the per-traversal tensors) steps what some camera of the step saw.  Returns a
+        dict: "geo_rows" [cap, 16] = {v_mean 3, v_quat 4, v_scale 3, v_opacity 1 (with respect to the ACTIVATED Gaussians, summed over
+        all ranks) | the gradient of SH coefficient 0 summed over all ranks 3 | 0 | index}, "geo_row_of" int32 [N] (row or -1),
+        "geo_ids" int32 [cap], "geo_totals" int64 device (count << 32: mtgs_node_bwd_rows' `totals`); "coef" {t: (rows [cap_t, 3 K],
+        row_of int32 [N])} for every traversal some rank rendered (coefficient k channel c at 3 k + c, summed over THAT traversal's
+        ranks); all_colour_ranges = [(begin, end)]: index ranges of nodes whose colour parameters are shared by the traversals
+        -> "coef_all" (rows, row_of): the sum over ALL ranks, valid inside those ranges.  Every row equals the dense entry
+        bit for bit (same summation order)."""
         from ._lib import call, ptr, stream_of
         P = self._pending
         assert P is not None and P["stage"] == "rows", "finish() follows rasterization() + backward()"
@@ -290,12 +303,36 @@ class SparseGradExchange:
         cams = metas[:, 1:4].contiguous().view(torch.float32)
         words_all, prefix_all = metas[:, 4:], metas[:, 4 + 2 * nw:]
         T = self.T
-        out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
-               torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
-               torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
         # per-traversal appearance: the senders of traversal t (a bit mask) write slice t of the coefficient gradient
         trav = [int(samples[r][len(self.bounds)]) for r in range(world)]
         masks = [sum(1 << r for r in range(world) if trav[r] == t) for t in range(T)]
+        R = None
+        if rows:
+            import ctypes as _C
+            counts = [int(samples[r][0]) for r in range(world)]
+            present = [t for t in range(T) if masks[t]]
+            subsets = [(1 << world) - 1] + [masks[t] for t in present]       # subset 0: all ranks (geometry, coef_all)
+            caps = [min(N, sum(c for r, c in enumerate(counts) if (m >> r) & 1)) for m in subsets]
+            n_sub = len(subsets)
+            masks_dev = torch.tensor(np.asarray(subsets, dtype=np.uint64).view(np.int64), dtype=torch.int64, device=dev)
+            uw = torch.empty((n_sub, max(nw, 1)), dtype=torch.int64, device=dev)
+            up = torch.empty((n_sub, max(nw, 1)), dtype=torch.int32, device=dev)
+            totals = torch.empty(n_sub, dtype=torch.int64, device=dev)
+            scratch = torch.empty(n_sub * (max(nw, 1) // 256 + 1), dtype=torch.int32, device=dev)
+            call("mtgs_dp_union", world, N, ptr(words_all), self.meta_len * 4, n_sub, ptr(masks_dev), ptr(uw), ptr(up), ptr(totals),
+                 ptr(scratch), st)
+            new = lambda *shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
+            R = {"geo_rows": new(max(caps[0], 1), 16), "geo_row_of": new(N, dt=torch.int32), "geo_ids": new(max(caps[0], 1), dt=torch.int32),
+                 "geo_totals": totals[0:1], "coef": {}, "coef_all": None, "caps": caps}
+            for j, t in enumerate(present):
+                R["coef"][t] = (new(max(caps[1 + j], 1), 3 * K), new(N, dt=torch.int32))
+            if all_colour_ranges:
+                R["coef_all"] = (new(max(caps[0], 1), 3 * K), new(N, dt=torch.int32))
+            out = R
+        if rows != True:      # noqa: E712  (False: dense only; "both": the dense tensors beside the rows, from the same wire data: tests)
+            out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
+                   torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+                   torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
         ev = lambda: torch.cuda.Event(enable_timing=True)
         w0, w1, red = ev(), ev(), []
         # every chunk's all-gather is issued up front (they queue on the collective stream); chunk c is reduced as soon as
@@ -327,7 +364,32 @@ class SparseGradExchange:
                 w1.record()
             e0, e1 = ev(), ev()
             e0.record()
-            if T == 1:
+            if rows:
+                rs = caps[c] * self.ROW if (world > 1 or self.world_collectives) else 0
+                gb, ge = self.bounds[c], self.bounds[c + 1]
+
+                def reduce_rows(mask, geo, coef, sub, b0=gb, b1=ge):
+                    z = lambda t: ptr(t) if t is not None else None
+                    call("mtgs_dp_reduce_rows", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all),
+                         self.meta_len * 4, ptr(recvs[c]), rs, ptr(cams), b0, b1, _C.c_uint64(mask),
+                         z(R["geo_rows"] if geo else None), ptr(uw[0]), ptr(up[0]), z(R["geo_row_of"] if geo else None),
+                         z(R["geo_ids"] if geo else None), R["geo_rows"].shape[0],
+                         z(coef[0] if coef else None), ptr(uw[sub]), ptr(up[sub]), z(coef[1] if coef else None),
+                         coef[0].shape[0] if coef else 0, 3 * K, st)
+                if not present:
+                    reduce_rows(0, True, None, 0)
+                for j, t in enumerate(present):      # the first traversal's pass also sums the geometry over all ranks
+                    reduce_rows(masks[t], j == 0, R["coef"][t], 1 + j)
+                if R["coef_all"] is not None:        # nodes whose colour parameters the traversals share: all ranks, their index range
+                    if c == 0:
+                        R["coef_all"][1].fill_(-1)
+                    # (whole chunks: a sender's received rows start at the CHUNK's first row; rows outside the ranges are
+                    #  computed and never read)
+                    if any(min(ge, int(e)) > max(gb, int(b)) for (b, e) in all_colour_ranges):
+                        reduce_rows(subsets[0], False, R["coef_all"], 0)
+            if rows == True:      # noqa: E712
+                pass
+            elif T == 1:
                 call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4,
                      ptr(recvs[c]), caps[c] * self.ROW if (world > 1 or self.world_collectives) else 0, ptr(cams), ptr(out[0]),
                      ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), self.bounds[c], self.bounds[c + 1], st)
@@ -342,7 +404,7 @@ class SparseGradExchange:
             red.append((e0, e1))
         self._events.update(wire=(w0, w1), reduce=red)
         self.phase = "idle"
-        return out
+        return (out, R) if rows == "both" else out
 
     def phases_ms(self) -> dict:
         """Durations of the last step's exchange phases (synchronises): meta = all-gather of the visibility maps (side

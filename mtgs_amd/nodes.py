@@ -230,7 +230,7 @@ class ColorSource:
             # the geometry half: rows of raw-parameter gradients of the visible Gaussians (mtgs_node_bwd_rows), one launch
             ws, ids, totals = self.geo_ws
             prow = torch.empty_like(ws)
-            call("mtgs_node_bwd_rows", self.n_nodes, ptr(self.table), ptr(ids), ptr(totals), ws.shape[0], ptr(ws), ptr(prow), stream_of(ws))
+            call("mtgs_node_bwd_rows", self.n_nodes, ptr(self.table), ptr(ids), ptr(totals), ws.shape[0], ptr(ws), 12, ptr(prow), stream_of(ws))
             for (start, n, *_), (mn, sc, qt, op, _rigid) in zip(self.node_params, self.node_geometry):
                 ro = self.row_of[start:start + n]
                 for p_, col in ((mn, 0), (sc, 3), (qt, 6), (op, 10)):
@@ -392,6 +392,9 @@ class _CollectNodes(torch.autograd.Function):
         call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, -1 if deferred else int(degree), ptr(cam), ptr(model_id),
              stream_of(means))
         ctx.color_source = None
+        # (the table and what its raw-parameter pointers refer to: mtgs_node_bwd_rows of a caller that keeps geometry gradients
+        #  as rows -- ColorSource.geometry_rows, the row form of the data-parallel exchange)
+        _CollectNodes.last_table = (tab_dev, n_nodes, list(keep))
         if deferred:   # the front end of the rasterizer reads the coefficients of the VISIBLE Gaussians through this table
             node_params = [(int(starts[i]), sizes[i]) for i in range(n_nodes)]   # (+ the leaf parameters: collect_gaussians)
             _CollectNodes.last_color_source = ColorSource(tab_dev, n_nodes, int(degree), cam, keep, node_params)
@@ -561,6 +564,7 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
     assert not (deferred_colors and raw_colors)
     means, scales, quats, opacities, rgbs, model_id = _CollectNodes.apply(cam_pos, tuple(specs), *flat)
     out = {"means": means, "scales": scales, "quats": quats, "opacities": opacities, "rgbs": rgbs, "model_id": model_id}
+    out["node_table"], _CollectNodes.last_table = getattr(_CollectNodes, "last_table", None), None
     if deferred_colors:
         out["rgbs"] = None
         cs, _CollectNodes.last_color_source = _CollectNodes.last_color_source, None

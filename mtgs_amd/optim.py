@@ -101,7 +101,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.nontemporal = bool(nontemporal)
         self.grad_scale = 1.0          # every gradient is multiplied by this inside the kernel (1 / world for a DDP-style mean)
-        self._rows = {}                # id(param) -> (rows, row_of, col, stride)
+        self._rows = {}                # id(param) -> (rows, row_of, col, stride, width, sub_width, sub_index, caught, row_ids)
+        self._rows_more = {}           # id(param) -> further slices' sources of the same step (row-lazy per-traversal tensors)
         self._lazy = {}                # id(param) -> {"param", "T", "last": [step up to which slice t is current], "hist": [(step_size, bc2_sqrt)]}
         self._active_slice = {}        # id(param) -> slice the coming step() updates (lazy parameters)
         self._rowlazy = {}             # id(param) -> {"param", "T", "last": int32 [N * T], "hist": float32 [2 * cap], "cap"}
@@ -144,10 +145,19 @@ class FusedAdam(torch.optim.Optimizer):
             if cb.dtype != torch.float32 or cb.dim() != 2 or cb.stride(1) != 1 or cb.shape[0] < rows.shape[0] or \
                     cc < 0 or cc + (sub_w or width) > cb.shape[1]:
                 raise ValueError("set_row_gradient: caught = (float32 [R' >= R, stride], column)")
-        self._rows[id(param)] = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids))
+        src = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids))
+        first = self._rows.get(id(param))
+        if first is not None and sub_w > 0 and first[5] > 0 and sub_i not in [first[6]] + [e[6] for e in self._rows_more.get(id(param), [])]:
+            # ANOTHER slice of the same per-traversal tensor in the same step (data-parallel steps render several traversals:
+            # every traversal's senders give that slice its own rows and row map) -- row-lazy parameters only (step())
+            self._rows_more.setdefault(id(param), []).append(src)
+        else:
+            self._rows[id(param)] = src
+            self._rows_more.pop(id(param), None)
 
     def zero_grad(self, set_to_none: bool = True):
         self._rows.clear()
+        self._rows_more.clear()
         return super().zero_grad(set_to_none=set_to_none)
 
     # ---- exact lazy Adam for per-traversal tensors ----------------------------------------------------------------------
@@ -243,7 +253,7 @@ class FusedAdam(torch.optim.Optimizer):
         """Drop everything held for `param` (row-lazy / lazy records with their `last` / `hist` buffers, a pending row gradient,
         its state): for parameters a refinement REPLACED when the optimizer itself lives on.  flush() first if the old values
         are still to be read.  (The records hold their parameter, so an id is never reused while a record exists.)"""
-        for d in (self._rowlazy, self._lazy, self._rows, self._active_slice, self._hyper_index):
+        for d in (self._rowlazy, self._lazy, self._rows, self._rows_more, self._active_slice, self._hyper_index):
             d.pop(id(param), None)
         self.state.pop(param, None)
         self._table_key = self._catch_key = None
@@ -436,20 +446,30 @@ class FusedAdam(torch.optim.Optimizer):
         training autograd allocates new gradient tensors every iteration; under a HIP graph everything is static)."""
         _check_layout()
         elems = load().mtgs_adam_block_elems()
-        tab = np.zeros(len(act), _GROUP)
+        # one table row per (tensor, gradient source): a per-traversal tensor that several traversals of the step gave rows
+        # (set_row_gradient called once per slice) has one row-lazy group per slice -- disjoint elements, the same device scalars
+        entries = []
+        for i, (gi, p, st, g, src) in enumerate(act):
+            entries.append((i, src))
+            for extra in self._rows_more.get(id(p), []):
+                if id(p) not in self._rowlazy:
+                    raise RuntimeError("FusedAdam: row gradients for several slices of one tensor in one step need a row-lazy "
+                                       "parameter (set_row_lazy(param, traversals=T))")
+                entries.append((i, extra))
+        tab = np.zeros(len(entries), _GROUP)
         fb = 0
         keep = []
         # table order: the row-lazy tensors last (they run as a second kernel, mtgs_adam_step's rows_from_block); the device
         # scalars stay indexed by the position in `act` (hyper_index)
-        def rank(i):      # streaming groups, then row groups found through the row map, then row groups with an id list
-            p, src = act[i][1], act[i][4]
+        def rank(e):      # streaming groups, then row groups found through the row map, then row groups with an id list
+            p, src = act[e[0]][1], e[1]
             return 0 if id(p) not in self._rowlazy else (2 if (src is not None and src[8] is not None) else 1)
-        order = sorted(range(len(act)), key=rank)
+        order = sorted(entries, key=rank)
         self._rows_from = None
         self._list_groups = False
         lists = []
-        for j, i in enumerate(order):
-            gi, p, st, g, src = act[i]
+        for j, (i, src) in enumerate(order):
+            gi, p, st, g, _ = act[i]
             grp = self.param_groups[gi]
             m, v = st["exp_avg"], st["exp_avg_sq"]
             if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous():
@@ -519,6 +539,7 @@ class FusedAdam(torch.optim.Optimizer):
         fb += _list_blocks(lists)
         self._blocks = fb
         self._keep = keep
+        self._n_table = len(entries)
         return self._table_dev
 
     def inherit_layout(self, old: "FusedAdam") -> None:
@@ -607,9 +628,10 @@ class FusedAdam(torch.optim.Optimizer):
             # (pinned allocation is not permitted while capturing, and the step count must not advance at capture time)
             raise RuntimeError("FusedAdam: run one eager step() before capturing one (state and device buffers are created there)")
         table = self._table(act)
-        call("mtgs_adam_step", len(act), ptr(table), ptr(self._hyper_dev), self._blocks, self._rows_from,
+        call("mtgs_adam_step", self._n_table, ptr(table), ptr(self._hyper_dev), self._blocks, self._rows_from,
              int(self.nontemporal) | (2 if self._list_groups else 0), stream_of(act[0][1]))
         self._rows.clear()
+        self._rows_more.clear()
         self._active_slice.clear()
         self._pending_host = False
         if torch.cuda.is_current_stream_capturing():

@@ -13,8 +13,19 @@ from mtgs_amd import _lib, dist as mdist, wrapper  # noqa: E402
 from mtgs_amd._lib import call, ptr  # noqa: E402
 from mtgs_amd.synthetic import make_camera, make_scene  # noqa: E402
 
+import argparse
+import ctypes as C
+
+import numpy as np
+
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--width", type=int, default=1920)
+_ap.add_argument("--height", type=int, default=1080)
+_ap.add_argument("--no-render-leg", action="store_true")
+_args = _ap.parse_args()
 dev = torch.device("cuda")
-N, K, W, H = 2_000_000, 16, 1920, 1080
+N, K, W, H = 2_000_000, 16, _args.width, _args.height
+print(f"== {N} Gaussians, {W}x{H}")
 sc = {k: v.to(dev) for k, v in make_scene(N, seed=0, sh_degree=None).items()}
 means = sc["means"]
 g = torch.Generator().manual_seed(0)
@@ -63,6 +74,43 @@ for world in (2, 4, 8):
                        ptr(recv), cap * 16, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, st)
     covered = sum(counts)
     print("world %d: one-pass reduce over %d rows (%d MB received): %.1f us" % (world, covered, world * cap * 64 >> 20, t(red)))
+    # ---- the same sums as ROWS of the union of the senders' visible sets (finish(rows=True)): one traversal (geometry + colour
+    # in one pass), and one traversal PER sender (MTGS's multi-traversal step: T passes, dense [N, T, K, 3] against T row sets)
+    for T in (1, world):
+        masks = [(1 << world) - 1] + ([(1 << world) - 1] if T == 1 else [1 << r for r in range(world)])
+        n_sub = len(masks)
+        masks_dev = torch.tensor(np.asarray(masks, dtype=np.uint64).view(np.int64), dtype=torch.int64, device=dev)
+        uw = torch.empty((n_sub, nw), dtype=torch.int64, device=dev)
+        up = torch.empty((n_sub, nw), dtype=torch.int32, device=dev)
+        totals = torch.empty(n_sub, dtype=torch.int64, device=dev)
+        scratch = torch.empty(n_sub * (nw // 256 + 1), dtype=torch.int32, device=dev)
+        union = lambda: call("mtgs_dp_union", world, N, ptr(metas[:, 4:]), L * 4, n_sub, ptr(masks_dev), ptr(uw), ptr(up), ptr(totals),
+                             ptr(scratch), st)
+        union()
+        tot = [int(v) >> 32 for v in totals.tolist()]
+        geo_rows = torch.empty(max(tot[0], 1), 16, device=dev)
+        geo_ro, geo_ids = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(max(tot[0], 1), dtype=torch.int32, device=dev)
+        coef = [(torch.empty(max(tot[1 + j], 1), 3 * K, device=dev), torch.empty(N, dtype=torch.int32, device=dev)) for j in range(n_sub - 1)]
+
+        def red_rows():
+            for j in range(n_sub - 1):
+                call("mtgs_dp_reduce_rows", world, N, K, 3, ptr(means), ptr(metas[:, 4:]), ptr(metas[:, 4 + 2 * nw:]), L * 4, ptr(recv),
+                     cap * 16, ptr(cams), 0, -1, C.c_uint64(masks[1 + j]), ptr(geo_rows) if j == 0 else None, ptr(uw[0]), ptr(up[0]),
+                     ptr(geo_ro) if j == 0 else None, ptr(geo_ids) if j == 0 else None, geo_rows.shape[0], ptr(coef[j][0]),
+                     ptr(uw[1 + j]), ptr(up[1 + j]), ptr(coef[j][1]), coef[j][0].shape[0], 3 * K, st)
+        line = "world %d, %d traversal(s): rows of the union (%d geometry rows, %d colour rows): union maps %.1f us + reduce %.1f us" % (
+            world, T, tot[0], sum(tot[1:]), t(union), t(red_rows))
+        if T > 1:
+            outT = torch.empty(N, T, K, 3, device=dev)
+
+            def red_slices():
+                for tt in range(T):
+                    call("mtgs_dp_reduce_slices", world, N, K, 3, ptr(means), ptr(metas[:, 4:]), ptr(metas[:, 4 + 2 * nw:]), L * 4, ptr(recv),
+                         cap * 16, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), outT.data_ptr() + tt * K * 3 * 4, 0, -1,
+                         C.c_uint64(1 << tt), int(tt == 0), T * K * 3, st)
+            line += "  | dense [N, %d, K, 3] in %d passes: %.1f us" % (T, T, t(red_slices, 5))
+            del outT
+        print(line)
 
 
 # ---- the render leg of a data-parallel step (integrated form, one process): forward + backward down to the wire rows,
@@ -103,4 +151,5 @@ def render_leg():
     print("   phases of the last step (ms):", {k: round(v, 3) for k, v in ex.phases_ms().items()})
 
 
-render_leg()
+if not _args.no_render_leg:
+    render_leg()

@@ -194,6 +194,8 @@ def stats_chain(stats, radii, absgrad, sizes, W, H):
 VISFIRST = {"on": False, "cs": None, "normals": True, "geometry_rows": False}     # --visfirst: colours of the visible Gaussians only; the last frame's ColorSource
 ROWLAZY = {"on": False, "opt": None}     # --row-lazy: exact row-lazy Adam for the colour parameters (needs --visfirst --optimizer fused)
 LAZY = {"on": False}                     # --lazy-adam: exact lazy Adam for the per-traversal tensors (needs --visfirst)
+ALL_ROWS = {}                            # n -> int32 zeros [n]: a row map that selects every row (catch_up_rows)
+DPROWS = {"on": False}                   # --dp-rows: the sparse exchange hands ROWS to the optimizer (no dense gradient on any rank)
 REGS = {"on": False}                     # --regularizers: the 2D and sharp-shape terms on the collected scales
 LAST = {"info": {}}                      # the device scalars of the last rasterization's `info` (graph mode: overflow flag and counts)
 
@@ -287,7 +289,7 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     return loss.detach()
 
 
-def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=None):
+def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=None, opt=None):
     """The fused iteration of one rank under view-parallel data parallelism with the SPARSE gradient exchange
     (mtgs_amd.dist.SparseGradExchange with per-traversal colour routing) instead of a dense all-reduce of every parameter
     gradient: the node kernels hand out the activated geometry and the RAW SH colours of every Gaussian; the exchange
@@ -297,11 +299,28 @@ def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=Non
     features_dc / features_adapters / features_rest.  Statistics from the compact rows.
     shipped: the option set of config/MTGS.py.  Its three normal channels are a function of THIS rank's camera, so their
     gradient is folded into the quaternion gradient of the wire rows on the sender (mtgs_normals_bwd_rows, via the
-    exchange's rows_hook) before the rows are exchanged; the exposure parameters are replicated and all-reduced densely."""
+    exchange's rows_hook) before the rows are exchanged; the exposure parameters are replicated and all-reduced densely.
+    opt (a FusedAdam; --dp-rows, static nodes): ROWS all the way -- finish(rows=True) returns the sums as rows of the union of the
+    ranks' visible sets, the geometry rows go through the node activations' VJP per row (mtgs_node_bwd_rows), and every
+    parameter takes its gradient through FusedAdam.set_row_gradient: features_adapters / features_rest one slice per traversal
+    some rank rendered (row-lazy: the step touches those rows only), features_dc the coefficient-0 sum over all ranks.  No
+    dense [N, .] gradient -- in particular no [N, T, K, 3] -- exists on any rank."""
     from mtgs_amd._lib import call, ptr, stream_of
     from mtgs_amd.densify import update_statistics_rows
     from mtgs_amd.nodes import collect_gaussians
     vm, K, c2w, t = cam
+    if opt is not None:
+        # the node kernels read slice t of the per-traversal tensors for EVERY Gaussian (the sender evaluates SH before it knows
+        # what its camera sees): slice t is brought up to date in place first -- the zero-gradient steps its rows missed, bit-
+        # identically; the other T - 1 slices stay lazy.  (Next: visibility-first colours under the exchange, as --visfirst.)
+        items = []
+        for p in P.values():
+            if "features_adapters" in p:
+                every = ALL_ROWS.get(p["means"].shape[0])
+                if every is None or every.device != p["means"].device:
+                    every = ALL_ROWS[p["means"].shape[0]] = torch.zeros(p["means"].shape[0], dtype=torch.int32, device=p["means"].device)
+                items += [(p["features_adapters"], every, t), (p["features_rest"], every, t)]
+        opt.catch_up_rows(items)
     det = lambda p: {k: (v.detach() if k.startswith("features") else v) for k, v in p.items()}   # no colour gradient through the nodes
     gs = collect_gaussians([dict(det(p), traversal_index=t) if "features_adapters" in p else
                             (dict(det(p), frame_idx=frame_of(t)) if "instance_quats" in p else det(p)) for p in P.values()], c2w, n, 3,
@@ -336,6 +355,30 @@ def iteration_sparse_dp(P, cam, gt, mask, stats, win, W, H, ex, n=3, shipped=Non
     loss.backward()
     with torch.no_grad():
         update_statistics_rows([tuple(s) for s in stats], info["radii"], ex.grad_rows, ex.vis_ids, W, H, n_vis=ex.n_vis)
+    if opt is not None:
+        if any("instance_quats" in p for p in P.values()):
+            raise NotImplementedError("--dp-rows: static nodes (a rigid node reduces a pose gradient over its Gaussians)")
+        sizes = [p["means"].shape[0] for p in P.values()]
+        starts = [sum(sizes[:i]) for i in range(len(sizes))]
+        shared = [(st, st + n_i) for st, n_i, p in zip(starts, sizes, P.values()) if "features_adapters" not in p]
+        R = ex.finish(leaves["means"], n, rows=True, all_colour_ranges=shared)
+        tab_dev, n_nodes, _keep = gs["node_table"]
+        prow = torch.empty((R["geo_rows"].shape[0], 12), dtype=torch.float32, device=R["geo_rows"].device)
+        call("mtgs_node_bwd_rows", n_nodes, ptr(tab_dev), ptr(R["geo_ids"]), ptr(R["geo_totals"]), R["geo_rows"].shape[0],
+             ptr(R["geo_rows"]), 16, ptr(prow), stream_of(prow))
+        for st, n_i, p in zip(starts, sizes, P.values()):
+            ro = R["geo_row_of"][st:st + n_i]
+            for k, col in (("means", 0), ("scales", 3), ("quats", 6), ("opacities", 10)):
+                opt.set_row_gradient(p[k], prow, ro, col)
+            opt.set_row_gradient(p["features_dc"], R["geo_rows"], ro, 11)
+            if "features_adapters" in p:
+                for t_, (rows_t, ro_t) in R["coef"].items():
+                    opt.set_row_gradient(p["features_adapters"], rows_t, ro_t[st:st + n_i], 0, slice_index=t_)
+                    opt.set_row_gradient(p["features_rest"], rows_t, ro_t[st:st + n_i], 3, slice_index=t_)
+            else:
+                rows_a, ro_a = R["coef_all"]
+                opt.set_row_gradient(p["features_rest"], rows_a, ro_a[st:st + n_i], 3)
+        return loss.detach()
     g_means, g_quats, g_scales, g_opac, g_coeffs = ex.finish(leaves["means"], n)          # sums over all ranks
     torch.autograd.backward([gs["means"], gs["quats"], gs["scales"], gs["opacities"]], [g_means, g_quats, g_scales, g_opac])
     start = 0
@@ -449,6 +492,19 @@ def make_optimizer(kind, P, shipped=None, capturable=False):
     return torch.optim.Adam(groups, eps=1e-15, foreach=True, capturable=capturable)
 
 
+def enable_dp_rows(opt, P):
+    """--dp-rows: the per-traversal colour tensors are row-lazy (a step touches the rows of the slices some rank rendered; the
+    other slices and rows decay lazily, bit-identically to stepping them).  Call on a new optimizer after its state is in place."""
+    if not DPROWS["on"]:
+        return opt
+    for p in P.values():
+        if "features_adapters" in p:
+            a, r = p["features_adapters"], p["features_rest"]
+            opt.set_row_lazy(a, traversals=a.shape[1])
+            opt.set_row_lazy(r, traversals=r.shape[1])
+    return opt
+
+
 def enable_row_lazy(opt, P):
     """--row-lazy: the colour parameters (read for the visible Gaussians only under --visfirst) are stepped for the visible
     rows of the rendered traversal alone.  Call on a new optimizer AFTER its state is in place (refinement)."""
@@ -504,7 +560,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     def make_opt():
         return make_optimizer(optimizer, P, shipped)
 
-    opt = enable_row_lazy(make_opt(), P)
+    opt = enable_dp_rows(enable_row_lazy(make_opt(), P), P)
     mk = lambda: [[torch.zeros(p["means"].shape[0], device=p["means"].device), torch.ones(p["means"].shape[0], device=p["means"].device),
                    torch.zeros(p["means"].shape[0], device=p["means"].device)] for p in P.values()]
     stats = mk()
@@ -665,7 +721,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             for a in range(accumulate):
                 c = (i * group + (rank if world > 1 else a)) % T
                 if sparse:
-                    losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex, shipped=shipped))
+                    losses.append(iteration_sparse_dp(P, cams[c], targets[c], mask, stats, win, W, H, ex, shipped=shipped,
+                                                      opt=opt if DPROWS["on"] else None))
                 else:
                     if LAZY["on"]:
                         opt.prepare(c)
@@ -688,7 +745,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 mdist.all_reduce_stats([t for s in stats for t in s[:2]], [s[2] for s in stats],
                                        sum_init=[v for _ in stats for v in (0.0, 1.0)])
             before = sum(p["means"].shape[0] for p in P.values())
-            if LAZY["on"] or ROWLAZY["on"]:
+            if LAZY["on"] or ROWLAZY["on"] or DPROWS["on"]:
                 opt.flush()                   # every slice / row up to date before rows move
             params = [q for g in opt.param_groups for q in g["params"]]
             state = {id(q): opt.state.get(q) for q in params}
@@ -705,6 +762,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                     if q not in opt.state and state.get(id(q)):
                         opt.state[q] = state[id(q)]
             enable_row_lazy(opt, P)
+            enable_dp_rows(opt, P)
             if hasattr(opt, "inherit_layout"):
                 opt.inherit_layout(old_opt)
             del old_opt
@@ -724,7 +782,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     if debug:
         tick("other")
         log("debug phases ms:", json.dumps({k: round(v, 1) for k, v in phase_ms.items()}))
-    if LAZY["on"] or ROWLAZY["on"]:
+    if LAZY["on"] or ROWLAZY["on"] or DPROWS["on"]:
         opt.flush()
     torch.cuda.synchronize()
     if t_start is not None and steps > i_start:
@@ -788,6 +846,9 @@ def main():
                     "nuPlan images; default: scaled once for the synthetic scene)")
     ap.add_argument("--drop", type=float, default=0.1, help="with --converge: fraction of the true Gaussians the model starts without")
     ap.add_argument("--poll-every", type=int, default=16)
+    ap.add_argument("--dp-rows", action="store_true", help="with --dp --dp-exchange sparse --optimizer fused: the exchange's sums stay "
+                    "ROWS of the union of the ranks' visible sets all the way into the optimizer (SparseGradExchange.finish(rows=True), "
+                    "mtgs_node_bwd_rows, FusedAdam.set_row_gradient with one slice per rendered traversal; the colour tensors row-lazy)")
     ap.add_argument("--regularizers", action="store_true", help="add MTGS's '2D reg' and 'Sharp Shape Reg' terms on the collected scales "
                     "(mtgs_scene_graph.py:936-939, 969-981): loss terms that reach the Gaussians outside the rasterization")
     ap.add_argument("--first-cap-scale", type=float, default=1.0, help="with --train-graph (tests): scale of the first graphs' capacities; "
@@ -809,6 +870,9 @@ def main():
         raise SystemExit("--train-graph needs --steps")
     VISFIRST["on"] = bool(args.visfirst)
     REGS["on"] = bool(args.regularizers)
+    DPROWS["on"] = bool(args.dp_rows)
+    if args.dp_rows and not (args.dp and args.dp_exchange == "sparse" and args.optimizer in (None, "fused")):
+        raise SystemExit("--dp-rows needs --dp --dp-exchange sparse and the fused optimizer")
     VISFIRST["normals"] = not args.dense_normals
     VISFIRST["geometry_rows"] = bool(args.geometry_rows)
     if args.geometry_rows and not (args.visfirst and args.optimizer in (None, "fused")):

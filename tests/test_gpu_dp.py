@@ -276,6 +276,105 @@ def test_sparse_exchange_routes_colour_gradients_to_the_senders_traversal(tmp_pa
             assert scale > 0 and err <= 3e-5 * scale + 1e-7, f"rank {r} {name}: {err} vs {scale}"
 
 
+def _worker_rows(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MTGS_DIST_BACKEND="gloo")
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from mtgs_amd import dist as mdist, spherical_harmonics
+    from mtgs_amd.optim import FusedAdam
+    from mtgs_amd.synthetic import make_camera, make_scene
+    mdist.init_from_env()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    N, W, H, K, T = 20_000, 320, 240, 16, 3
+    sc = make_scene(N, seed=9, sh_degree=3, extent=(12.0, 4.0, 12.0))
+    g = torch.Generator().manual_seed(100)
+    coeffs0 = torch.randn(N, T, K, 3, generator=g) * 0.2                  # one set of SH coefficients per traversal
+    geo = ("means", "quats", "scales", "opacities")
+
+    def make():      # the rasterizer's inputs as the optimizer's parameters (the exchange sums gradients with respect to them)
+        P = {k: sc[k].clone().to(dev).requires_grad_(True) for k in geo}
+        P["coeffs"] = coeffs0.clone().to(dev).requires_grad_(True)
+        return P, FusedAdam([{"params": [P[k]], "lr": lr} for k, lr in (("means", 1e-3), ("quats", 1e-3), ("scales", 1e-3),
+                                                                         ("opacities", 1e-2), ("coeffs", 5e-3))], eps=1e-15)
+    PA, oa = make()                      # dense gradients, every row stepped
+    PB, ob = make()                      # row gradients, the coefficient tensor row-lazy
+    ob.set_row_lazy(PB["coeffs"], traversals=T)
+    every = torch.zeros(N, dtype=torch.int32, device=dev)
+    ex = mdist.SparseGradExchange(N, K, dev, traversals=T, chunks=2)
+    stats = {"max_rows": 0, "union": 0}
+    for step in range(3):
+        t = (rank + step) % T                                            # ranks 0 and 3 share a traversal in every step
+        vm, Kmat = make_camera(W, H, yaw_deg=50.0 * rank + 7.0 * step)
+        vm, Kmat = vm.to(dev), Kmat.to(dev)
+        cam_pos = torch.inverse(vm)[0, :3, 3]
+        g2 = torch.Generator().manual_seed(10 * step + rank + 1)
+        Gc, Ga = torch.randn(1, H, W, 4, generator=g2).to(dev), torch.randn(1, H, W, 1, generator=g2).to(dev)
+        ob.catch_up_rows([(PB["coeffs"], every, t)])                     # the sender evaluates SH for every Gaussian of slice t
+        assert torch.equal(PB["coeffs"][:, t], PA["coeffs"][:, t]), (rank, step)
+        for k in geo:
+            assert torch.equal(PA[k], PB[k]), (rank, step, k)
+        sh = spherical_harmonics(3, PB["means"].detach() - cam_pos, PB["coeffs"][:, t].detach().contiguous())
+        leaves = {k: PB[k].detach().requires_grad_(True) for k in geo}
+        r, a, info = ex.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], sh, vm, Kmat, W, H,
+                                      cam_pos, traversal=t)
+        torch.autograd.backward([r, a], [Gc, Ga])
+        dense, R = ex.finish(leaves["means"], 3, rows="both")            # ONE set of wire rows, both forms of the sums
+        # (a) every row equals the dense entry bit for bit, and nothing else is non-zero
+        ro = R["geo_row_of"].long()
+        seen = ro >= 0
+        n_u = int(seen.sum())
+        stats["union"], stats["max_rows"] = n_u, max(stats["max_rows"], R["geo_rows"].shape[0])
+        assert int(R["geo_totals"][0] >> 32) == n_u and torch.equal(R["geo_ids"][:n_u].long(), torch.nonzero(seen).flatten())
+        for k, (c0, c1) in zip(geo, ((0, 3), (3, 7), (7, 10), (10, 11))):
+            d = dense[geo.index(k)].reshape(N, -1)
+            assert torch.equal(R["geo_rows"][ro[seen], c0:c1], d[seen]) and not bool(d[~seen].any()), (rank, step, k)
+        assert set(R["coef"]) == {(q + step) % T for q in range(world)}
+        for tt in range(T):
+            dt = dense[4][:, tt].reshape(N, -1)
+            if tt in R["coef"]:
+                rows_t, ro_t = R["coef"][tt]
+                s_t = ro_t >= 0
+                assert torch.equal(rows_t[ro_t.long()[s_t]], dt[s_t]) and not bool(dt[~s_t].any()), (rank, step, tt)
+            else:
+                assert not bool(dt.any())
+        # (b) dense -> optimizer == rows -> optimizer
+        for k, gk in zip(geo + ("coeffs",), dense):
+            PA[k].grad = gk
+        oa.step()
+        for k, c0 in zip(geo, (0, 3, 7, 10)):
+            ob.set_row_gradient(PB[k], R["geo_rows"], R["geo_row_of"], c0)
+        for tt, (rows_t, ro_t) in R["coef"].items():
+            ob.set_row_gradient(PB["coeffs"], rows_t, ro_t, 0, slice_index=tt)
+        ob.step()
+    ob.flush()
+    same = {k: bool(torch.equal(PA[k], PB[k])) for k in PA}
+    same.update({"m_" + k: bool(torch.equal(oa.state[PA[k]]["exp_avg"], ob.state[PB[k]]["exp_avg"])) for k in PA})
+    moved = float((PA["coeffs"].detach().cpu() - coeffs0).abs().max())
+    import json
+    json.dump({"same": same, "moved": moved, "union": stats["union"], "cap": stats["max_rows"]}, open(Path(out_dir) / f"rows{rank}.json", "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_exchange_rows_into_the_optimizer_are_bit_identical_to_dense(tmp_path, hip_lib):
+    """SparseGradExchange.finish(rows=True): the receiver's sums leave as compact rows of the UNION of the ranks' visible sets
+    (mtgs_dp_union / mtgs_dp_reduce_rows) -- geometry over all ranks, the SH coefficient gradient per traversal over that
+    traversal's ranks -- and go to FusedAdam as row gradients, one slice per rendered traversal, the [N, T, K, 3] tensor row-lazy.
+    Four ranks, three traversals (two ranks share one in every step), three steps with moving cameras, from ONE set of wire rows
+    per step: (a) every row equals the dense tensor's entry bit for bit and the dense tensors are zero elsewhere; (b) after three
+    steps the parameters and the moments of the row-fed optimizer equal those of the optimizer fed the dense gradients, bit for
+    bit (reference: the per-traversal tensors of multi_color_gaussian_splatting.py:53-80 under the DDP site custom_pipeline.py:87-89)."""
+    import json
+    import torch.multiprocessing as mp
+    world = 4
+    mp.spawn(_worker_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        out = json.load(open(tmp_path / f"rows{r}.json"))
+        assert all(out["same"].values()), (r, out)
+        assert out["moved"] > 1e-3 and 0 < out["union"] < 20_000, out
+
+
 def _worker_configs3(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), MTGS_DIST_BACKEND="gloo")

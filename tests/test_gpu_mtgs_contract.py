@@ -416,3 +416,57 @@ def test_regularizers_outside_the_rasterization_reach_row_gradient_parameters():
     without = _run_train([a for a in common if a != "--regularizers"])
     curve = lambda out: [float(x) for x in __import__("re").search(r"loss: (.*)", out).group(1).split()]
     assert abs(curve(without)[0] - curve(dense)[0]) > 1e-3          # (the terms are there and matter)
+
+
+def _torchrun(nproc, extra, timeout=2400):
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(root / "scripts" / "mtgs_like_train.py")] + extra,
+                       capture_output=True, text=True, timeout=timeout, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    return r.stdout
+
+
+def test_mtgs_like_training_dp_rows_all_the_way_equals_accumulation():
+    """--dp-rows: under the sparse exchange the sums stay ROWS of the union of the ranks' visible sets all the way into the
+    optimizer (SparseGradExchange.finish(rows=True) -> mtgs_node_bwd_rows -> FusedAdam.set_row_gradient, one slice per rendered
+    traversal, the per-traversal colour tensors row-lazy): no dense gradient tensor on any rank.  Two ranks, three traversals,
+    the shipped option set, two refinements: same N on both ranks, same refinements and loss curve as the single process that
+    accumulates the two cameras of every step (and as the dense form of the exchange)."""
+    from tests.util import assert_same_training
+    common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "3", "--width", "320", "--height", "200", "--steps", "45",
+              "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped"]
+    rows = _torchrun(2, ["--dp", "--dp-exchange", "sparse", "--dp-rows"] + common)
+    one = _run_train(["--accumulate", "2"] + common)
+    assert "2 ranks: N = " in rows
+    assert_same_training(rows, one, 2, 45, 20)
+
+
+def test_configs4_eight_traversals_eight_ranks_rows_all_the_way():
+    """BASELINE configs[4] with EIGHT traversals: 2M Gaussians, 960x540, the shipped option set, eight ranks (one camera and
+    one traversal per rank and step) sharing the test box's one GPU over gloo -- possible because no rank ever holds a dense
+    [N, 8, 15, 3] gradient (2.9 GB per tensor, and 32 GB per rank of coefficients + moments + gradients in the dense form): the
+    exchange hands rows to the optimizer (--dp-rows).  Two refinements: N identical on every rank, sizes and loss curve equal to
+    the single process that renders the eight cameras of every step one after the other and accumulates dense gradients."""
+    import json
+    import re
+    from tests.util import REPORT, assert_same_training, refinement_sizes as sizes
+    common = ["--traversals", "8", "--width", "960", "--height", "540", "--steps", "24", "--refine-every", "10", "--reps", "1",
+              "--only", "fused", "--shipped"]
+    sp = _torchrun(8, ["--dp", "--dp-exchange", "sparse", "--dp-rows"] + common)
+    one = _run_train(["--accumulate", "8"] + common, timeout=2400)
+    assert "8 ranks: N = " in sp, sp[-800:]
+    assert_same_training(sp, one, 2, 24, 10)
+    assert int(sizes(sp)[0][0]) == 2_000_000
+    curve = lambda out: [float(x) for x in re.search(r"loss: (.*)", out).group(1).split()]
+    m = re.search(r"timing: ([\d.]+) ms per step .* phases_ms (\{.*\})", sp)
+    REPORT.append({"kind": "dp", "name": "configs[4], 2M Gaussians, EIGHT traversals, 960x540, shipped options: 8 ranks on one GPU over gloo, "
+                                         "rows from the exchange into the optimizer", "ms_per_step": float(m.group(1)) if m else None,
+                   "phases_ms": json.loads(m.group(2)) if m else None, "sizes": sizes(sp), "loss_curve": curve(sp)})
