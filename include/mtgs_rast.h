@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 21
+#define MTGS_RAST_ABI_VERSION 22
 
 enum {
     MTGS_OK = 0,
@@ -101,7 +101,10 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * x_quat_rows[n_vis, 4] (nullable, compact path only, 16-byte aligned): quaternion gradients of the visible Gaussians that did
  * not come through the projection -- the camera-space normals' (mtgs_normals_bwd_qrows) -- added to v_quats; x_mean_rows[n_vis, 3]
  * (nullable, compact path only): likewise position gradients (the view directions of gsplat's sh_degree colours:
- * mtgs_vis_color_bwd's dir_rows), added to v_means. */
+ * mtgs_vis_color_bwd's dir_rows), added to v_means.
+ * raw_rows (nullable, compact path only; ABI v22): the base of the compact gradient rows v_means2d / v_conics / x_means2d_abs point
+ * into (row stride = grad_row_strides[0]) when they hold mtgs_blend_bwd_packed's RAW MOMENT rows: every visible row's first eight
+ * floats are converted IN PLACE to {v_xy 2, |v_xy| 2, v_conic 3, v_opacity_eff} before they are used (see mtgs_blend_bwd_packed). */
 int mtgs_project_fwd(int C, int64_t N, const float *means, const float *quats, const float *scales,
                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                      float near_plane, float far_plane, float radius_clip, const float *opacities,
@@ -118,7 +121,7 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *x_means2d_abs, const float *x_colors, int x_channels,
                      const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
                      const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
-                     const float *x_quat_rows, const float *x_mean_rows, void *stream);
+                     const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -325,6 +328,11 @@ int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,
                           const int32_t *tile_order, void *stream);
+/* mtgs_blend_bwd_packed (ABI v22): grad_rows[n_vis, row_stride] holds RAW MOMENT rows -- with h = vis * dL/dalpha per (pixel,
+ * Gaussian) pair (gsplat's v_sigma = -opacity h): {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 |
+ * sum h | colours D | depth}; u = a dx + b dy, w = b dx + c dy.  The conic map of the position gradient and the factor -opacity
+ * are applied once per Gaussian by the row's consumer (mtgs_project_bwd(raw_rows), mtgs_project_bwd_rows(raw_rows = 1)), which
+ * writes {v_xy, |v_xy|, v_conic, v_opacity_eff} back in place.  (mtgs_blend_bwd writes those directly.) */
 int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, const float *alphas, const int32_t *last_ids,
@@ -406,9 +414,9 @@ int mtgs_dp_reduce_rows(int W, int64_t N, int K, int degree, const float *means,
 int mtgs_project_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
                           const float *viewmats, const float *Ks, int width, int height, float eps2d,
                           const float *conics, const float *compensations, const float *opacities,
-                          const float *grad_rows, int64_t row_stride, int D, int with_depth, const float *colors_pre,
+                          float *grad_rows, int64_t row_stride, int D, int with_depth, const float *colors_pre,
                           int color_mode, const int32_t *vis_ids, int64_t n_vis, float *wire_rows, float *v_viewmats,
-                          void *stream);
+                          int raw_rows, void *stream);
 
 /* ---- caller side of the path: fused per-node activations ----------------------------
  * One kernel per direction for what VanillaGaussianSplattingModel.get_gaussians does per step with a dozen PyTorch

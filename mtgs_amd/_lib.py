@@ -34,7 +34,7 @@ _SIGNATURES = {
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp,
-                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_isect_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -73,7 +73,7 @@ _SIGNATURES = {
     "mtgs_dp_reduce_slices": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                               C.c_uint64, _i32, _i64, _vp],
     "mtgs_project_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32,
-                              _vp, _i64, _vp, _vp, _vp],
+                              _vp, _i64, _vp, _vp, _i32, _vp],
     "mtgs_node_fwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                       _vp, _vp],
     "mtgs_node_bwd": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -138,7 +138,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 

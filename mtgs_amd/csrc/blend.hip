@@ -35,16 +35,15 @@
 #include "wave_reduce.hpp"
 #include "raster_rec.hpp"
 
-#ifdef MTGS_COUNT   // development: scripts/build_variant.py count -DMTGS_COUNT; read with mtgs_blend_counters()
-__device__ unsigned long long g_blend_counters[8];
-#define MTGS_COUNT_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_blend_counters[i], (unsigned long long)(v)); } while (0)
-extern "C" int mtgs_blend_counters(unsigned long long *out, int reset) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_counters), sizeof(g_blend_counters));
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_blend_counters), z, sizeof(z)); }
-    return 0;
-}
+// Development hooks (candidate / slot counters of the backward, the MTGS_PPL override of kbench.py's sweeps) live in
+// dev/blend_dev.hpp and exist in VARIANT builds only (scripts/build_variant.py NAME -DMTGS_DEV [-DMTGS_COUNT]): the product
+// library compiles the three hook sites below to nothing.
+#ifdef MTGS_DEV
+#include "dev/blend_dev.hpp"
 #else
 #define MTGS_COUNT_ADD(i, v) do { } while (0)
+#define MTGS_COUNT_SLOTS(vmask) do { } while (0)
+#define MTGS_DEV_PPL_OVERRIDE() do { } while (0)
 #endif
 
 namespace {
@@ -631,15 +630,16 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
             MTGS_COUNT_ADD(0, 1);
             if (any == 0) return;
             MTGS_COUNT_ADD(1, 1);
-#ifdef MTGS_COUNT
-            { int ns = 0; for (int p = 0; p < PPL; ++p) ns += vmask[p] != 0; MTGS_COUNT_ADD(2, ns);
-              int nl = 0; for (int p = 0; p < PPL; ++p) nl += __popcll(vmask[p]); MTGS_COUNT_ADD(3, nl); }
-#endif
+            MTGS_COUNT_SLOTS(vmask);
             float gv[4 * NR];
 #pragma unroll
             for (int k = 0; k < 4 * NR; ++k) gv[k] = 0.f;
             // sums over this lane's pixels of v_sigma * {1, dy, dy^2}: dx is common to the lane's pixels
-            // (same column), so the conic and mean gradients are recovered from these three numbers
+            // (same column), so the conic and mean gradients are recovered from these three numbers.
+            // PK (raw rows): the sums are of h = vis * g instead -- v_sigma = -opacity * h -- and the factor -opacity, like
+            // the conic map of the position gradient, is applied ONCE per Gaussian by the consumer of the rows
+            // (project_bwd.hip, rows_to_gradients): the slot loses the v_opacity accumulation (it IS sum h), the epilogue
+            // forms three products instead of nine.
             float S0 = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
                     Bq[p] += fac * A;
                     // alpha clamped at 0.999: no gradient through sigma / opacity (invalid lanes: vis == 0)
                     const float g = (!CLAMP || alpha_raw <= kAlphaMax) ? v_alpha : 0.f;
-                    const float v_sigma = -alpha_raw * g;
+                    const float v_sigma = PK ? vis * g : -alpha_raw * g;      // (PK: h)
                     const float vsdy = v_sigma * dy[p];
                     S0 += v_sigma;
                     S1 += vsdy;
@@ -674,15 +674,25 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
                     // |v_sigma u|, u = a dx + b dy and |v_sigma w|, w = b dx + c dy  (|x| is a source modifier: 2 FMAs each)
                     gv[2] = fmaf(fabsf(v_sigma), fabsf(fmaf(r0.w, dy[p], adx)), gv[2]);
                     gv[3] = fmaf(fabsf(v_sigma), fabsf(fmaf(r1.x, dy[p], bdx)), gv[3]);
-                    gv[7] += vis * g;
+                    if (!PK) gv[7] += vis * g;
                 }
             }
-            // sum_p v_sigma u_p with u_p = a dx + b dy_p (and w_p = b dx + c dy_p); conic: 1/2 v_sigma d d^T
-            gv[0] = adx * S0 + r0.w * S1;
-            gv[1] = bdx * S0 + r1.x * S1;
-            gv[4] = 0.5f * dx * dx * S0;
-            gv[5] = dx * S1;
-            gv[6] = 0.5f * S2;
+            if (PK) {
+                // RAW MOMENTS of h over the tile: {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h}
+                gv[0] = dx * S0;
+                gv[1] = S1;
+                gv[4] = dx * gv[0];
+                gv[5] = dx * S1;
+                gv[6] = S2;
+                gv[7] = S0;
+            } else {
+                // sum_p v_sigma u_p with u_p = a dx + b dy_p (and w_p = b dx + c dy_p); conic: 1/2 v_sigma d d^T
+                gv[0] = adx * S0 + r0.w * S1;
+                gv[1] = bdx * S0 + r1.x * S1;
+                gv[4] = 0.5f * dx * dx * S0;
+                gv[5] = dx * S1;
+                gv[6] = 0.5f * S2;
+            }
             float val;
             if constexpr (PACKED) {
                 val = wave_reduce_x4_packed<NR>(gv);
@@ -696,13 +706,9 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
             if (BATCH_FLUSH) {
                 if (red_lane && j_red < 16) s_grad[((tid >> 6) * CAND + t) * 16 + j_red] = val;
             } else {
-#if defined(MTGS_EXP_NO_ATOMIC)
-                asm volatile("" ::"v"(val), "v"(gid));
-#elif defined(MTGS_EXP_STORE)
-                if (a_base) *row_address(a_base, (uint32_t)gid, a_stride_bytes) = val;
-#else
+                // (what the atomics cost was measured with two experimental builds, since removed: none at all 423 -> 411 us,
+                //  plain stores 424 us -- DESIGN.md section 4)
                 if (a_base) unsafeAtomicAdd(row_address(a_base, (uint32_t)gid, a_stride_bytes), val);
-#endif
             }
         };
         // Entries are consumed two per iteration from two alternating register sets (A, B): the record of the
@@ -817,9 +823,7 @@ bool supported_channels(int D) { return (D >= 1 && D <= 8) || D == 16 || D == 32
 // trains at 960x540 = 2040 tiles) get 2 or 4 waves per tile instead.  Thresholds from kbench.py.
 static int pick_ppl(int64_t total_tiles, int DT, bool backward) {
     if (DT > 8) return 1;
-#ifdef MTGS_DEV  // development builds only (scripts/build_variant.py NAME -DMTGS_DEV): kbench.py sweeps
-    if (const char *e = getenv("MTGS_PPL")) return atoi(e);
-#endif
+    MTGS_DEV_PPL_OVERRIDE();
     // measured on MI355X, N = 2M (us, pixels per lane 4 / 2 / 1):
     //   fwd, 4 channels: 1200 tiles 405/291/220   2040 tiles 282/202/159   3600 tiles 237/187/169   8160 tiles 230/-/-
     //   bwd, 4 channels: 1200 tiles 424/344/324   2040 tiles 319/277/408   2800 tiles 320/310/484   8160 tiles 430/-/-

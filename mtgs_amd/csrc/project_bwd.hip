@@ -297,6 +297,25 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
 //                                v_opacities and the by-products) is staged through LDS and leaves as fully
 //                                coalesced 16-byte stores, zeros for the culled Gaussians included.
 constexpr int VIS_ROW = 12;  // floats per workspace row: v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | pad
+// RAW rows of the packed compositing backward (blend.hip, mtgs_blend_bwd_packed): with h = vis * dL/dalpha (v_sigma = -opacity h)
+//   row = {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h = v_opacity | colours ...}
+// -> the gradients gsplat's rasterize_to_pixels_bwd sums per pixel: v_xy = -o conic (m1, m2), |v_xy| = o (A1, A2),
+// v_conic = -o (m3 / 2, m4, m5 / 2), applied ONCE per Gaussian here instead of once per (tile, Gaussian) in the compositing
+// kernel (9 -> 3 instructions per epilogue there, one fewer per slot).  o = the opacity that was blended (opacity x
+// compensation, formed as front.hip forms it).  The converted values are written back: everything behind this kernel
+// (dense by-products, densification statistics, the tests' row accounting) reads rows of the documented meaning.
+struct RowGrads { float2 v_xy; float v_conic[3]; };
+__device__ __forceinline__ RowGrads rows_to_gradients(float *__restrict__ row, const float ca, const float cb, const float cc,
+                                                      const float o) {
+    const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
+    const float no = -o;
+    RowGrads g;
+    g.v_xy = make_float2(no * (ca * a.x + cb * a.y), no * (cb * a.x + cc * a.y));
+    g.v_conic[0] = 0.5f * no * b.x; g.v_conic[1] = no * b.y; g.v_conic[2] = 0.5f * no * b.z;
+    reinterpret_cast<float4 *>(row)[0] = make_float4(g.v_xy.x, g.v_xy.y, o * a.z, o * a.w);
+    reinterpret_cast<float4 *>(row)[1] = make_float4(g.v_conic[0], g.v_conic[1], g.v_conic[2], b.w);
+    return g;
+}
 __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     int64_t n_vis, const int32_t *__restrict__ vis_ids, const float *__restrict__ means,
     const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ viewmats,
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     const float *__restrict__ v_means2d, const float *__restrict__ v_depths, const float *__restrict__ v_conics,
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff, const ProjGradStrides gs,
     float *__restrict__ ws, float *__restrict__ v_viewmats, const int64_t *__restrict__ n_vis_dev,
-    const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows) {
+    const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows, float *raw_rows, int64_t raw_stride) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
@@ -327,9 +346,16 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
             sc[0] = scales[n * 3]; sc[1] = scales[n * 3 + 1]; sc[2] = scales[n * 3 + 2];
             PairIn in;
             in.conic[0] = conics[n * 3]; in.conic[1] = conics[n * 3 + 1]; in.conic[2] = conics[n * 3 + 2];
-            const float *vcon = v_conics + r * gs.conics;
-            in.v_conic[0] = vcon[0]; in.v_conic[1] = vcon[1]; in.v_conic[2] = vcon[2];
-            in.v_mean2d = make_float2(v_means2d[r * gs.means2d], v_means2d[r * gs.means2d + 1]);
+            if (raw_rows) {   // (v_means2d / v_conics point into these rows: the converted values are used from registers)
+                const float o_eff = compensations ? opacities[n] * compensations[n] : opacities[n];
+                const RowGrads rg = rows_to_gradients(raw_rows + r * raw_stride, in.conic[0], in.conic[1], in.conic[2], o_eff);
+                in.v_mean2d = rg.v_xy;
+                in.v_conic[0] = rg.v_conic[0]; in.v_conic[1] = rg.v_conic[1]; in.v_conic[2] = rg.v_conic[2];
+            } else {
+                const float *vcon = v_conics + r * gs.conics;
+                in.v_conic[0] = vcon[0]; in.v_conic[1] = vcon[1]; in.v_conic[2] = vcon[2];
+                in.v_mean2d = make_float2(v_means2d[r * gs.means2d], v_means2d[r * gs.means2d + 1]);
+            }
             in.v_depth = v_depths[r * gs.depths];
             in.has_comp = compensations != nullptr; in.has_vcomp = v_compensations != nullptr; in.has_opac = v_opac_eff != nullptr;
             in.comp = in.has_comp ? compensations[n] : 1.f;
@@ -375,8 +401,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
     int64_t n_vis, const int32_t *__restrict__ vis_ids, const float *__restrict__ means, const float *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ viewmats, const float *__restrict__ Ks, int W, int H,
     float eps2d, const float *__restrict__ conics, const float *__restrict__ compensations,
-    const float *__restrict__ opacities, const float *__restrict__ G, int64_t gs, int DC, int with_depth,
-    const float *__restrict__ colors_pre, int color_mode, float *__restrict__ wire, float *__restrict__ v_viewmats) {
+    const float *__restrict__ opacities, float *G, int64_t gs, int DC, int with_depth,
+    const float *__restrict__ colors_pre, int color_mode, float *__restrict__ wire, float *__restrict__ v_viewmats, int raw_rows) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
@@ -392,10 +418,12 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
             m[0] = means[n * 3]; m[1] = means[n * 3 + 1]; m[2] = means[n * 3 + 2];
             const float4 q = reinterpret_cast<const float4 *>(quats)[n];
             sc[0] = scales[n * 3]; sc[1] = scales[n * 3 + 1]; sc[2] = scales[n * 3 + 2];
-            const float4 *g4 = reinterpret_cast<const float4 *>(G + r * gs);
-            const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2];
             PairIn in;
             in.conic[0] = conics[n * 3]; in.conic[1] = conics[n * 3 + 1]; in.conic[2] = conics[n * 3 + 2];
+            if (raw_rows)
+                rows_to_gradients(G + r * gs, in.conic[0], in.conic[1], in.conic[2], compensations ? opacities[n] * compensations[n] : opacities[n]);
+            const float4 *g4 = reinterpret_cast<const float4 *>(G + r * gs);
+            const float4 g0 = g4[0], g1 = g4[1], g2 = g4[2];
             in.v_mean2d = make_float2(g0.x, g0.y);
             in.v_conic[0] = g1.x; in.v_conic[1] = g1.y; in.v_conic[2] = g1.z;
             const float gc[4] = {g2.x, g2.y, g2.z, g2.w};
@@ -509,7 +537,8 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const float *x_means2d_abs, const float *x_colors, int x_channels,
                                 const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
                                 float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
-                                const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, void *stream) {
+                                const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
+                                void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -548,6 +577,9 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                  MTGS_EINVAL, "mtgs_project_bwd: x_quat_rows needs the compact path (vis_ids, vis_ws, grad_row_index, C == 1), 16-byte aligned");
     MTGS_REQUIRE(!x_mean_rows || (vis_ids && vis_ws && grad_row_index && C == 1), MTGS_EINVAL,
                  "mtgs_project_bwd: x_mean_rows needs the compact path (vis_ids, vis_ws, grad_row_index, C == 1)");
+    MTGS_REQUIRE(!raw_rows || (vis_ids && vis_ws && grad_row_index && C == 1 && opacities && rs[0] >= 8 &&
+                               (reinterpret_cast<uintptr_t>(raw_rows) & 15) == 0 && (rs[0] & 3) == 0),
+                 MTGS_EINVAL, "mtgs_project_bwd: raw_rows needs the compact path, opacities and 16-byte aligned rows of >= 8 floats");
     if (vis_ids && vis_ws && grad_row_index && C == 1) {
         // compact path: grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank)
         MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
@@ -555,7 +587,8 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
             const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
             project_bwd_vis_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
-                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows);
+                v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows,
+                raw_rows, rs[0]);
         }
         if (!rows_only) project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
             N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);
@@ -575,9 +608,9 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
 extern "C" int mtgs_project_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
                                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
                                      const float *conics, const float *compensations, const float *opacities,
-                                     const float *grad_rows, int64_t row_stride, int D, int with_depth,
+                                     float *grad_rows, int64_t row_stride, int D, int with_depth,
                                      const float *colors_pre, int color_mode, const int32_t *vis_ids, int64_t n_vis,
-                                     float *wire_rows, float *v_viewmats, void *stream) {
+                                     float *wire_rows, float *v_viewmats, int raw_rows, void *stream) {
     MTGS_REQUIRE(N >= 0 && n_vis >= 0 && n_vis <= N && width > 0 && height > 0, MTGS_EINVAL, "mtgs_project_bwd_rows: bad sizes");
     // (colour channels beyond the third -- camera-space normals ... -- are not this call's: their gradient is folded into
     //  the rows by their own VJP, e.g. mtgs_normals_bwd_rows)
@@ -596,7 +629,7 @@ extern "C" int mtgs_project_bwd_rows(int64_t N, const float *means, const float 
     const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
     project_bwd_rows_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
         n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities, grad_rows,
-        row_stride, D, with_depth ? 1 : 0, colors_pre, color_mode, wire_rows, v_viewmats);
+        row_stride, D, with_depth ? 1 : 0, colors_pre, color_mode, wire_rows, v_viewmats, raw_rows);
     MTGS_CHECK_LAUNCH("mtgs_project_bwd_rows");
     return MTGS_OK;
 }

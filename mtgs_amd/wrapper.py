@@ -142,7 +142,7 @@ class _FullyFusedProjection(torch.autograd.Function):
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
-             None, 0, None, None, None, None, stream_of(means))
+             None, 0, None, None, None, None, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -730,6 +730,9 @@ class _FusedRasterization(torch.autograd.Function):
                      ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas), ptr(r_xy),
                      ptr(r_abs) if ctx.absgrad else None, ptr(r_con), ptr(r_col), ptr(r_dep), ptr(r_opa),
                      host_i64([RS] * 6), ptr(vis_rank), ptr(order), st)
+        # the packed compositing backward leaves RAW MOMENT rows (blend.hip / include/mtgs_rast.h): their consumer -- the
+        # projection backward, per visible Gaussian -- converts them in place to {v_xy, |v_xy|, v_conic, v_opacity_eff}
+        raw = bool(ctx.packed and rank_ids.numel() > 0 and (v_render is not None or v_alphas is not None))
         if _debug_rows is not None:
             _debug_rows.update(G=G, vis_ids=vis_ids, DC=DC, with_depth=with_depth)
         cs = ctx.cs
@@ -750,7 +753,7 @@ class _FusedRasterization(torch.autograd.Function):
             v_viewmats = torch.empty_like(viewmats) if ctx.needs_input_grad[5] else None
             call("mtgs_project_bwd_rows", N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height, eps2d,
                  ptr(conics), ptr(comps), ptr(opacities), ptr(G), RS, DC, int(with_depth), ptr(col), 1, ptr(vis_ids), n_vis,
-                 ptr(ctx.dp.rows), ptr(v_viewmats), st)
+                 ptr(ctx.dp.rows), ptr(v_viewmats), int(raw), st)
             if ctx.dp.rows_hook is not None:    # camera-dependent extra channels (normals): their VJP goes into the rows here
                 ctx.dp.rows_hook(G, RS, vis_ids, n_vis)
             ctx.dp.after_backward(n_vis, G, vis_ids)
@@ -760,6 +763,17 @@ class _FusedRasterization(torch.autograd.Function):
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
         if direct and ctx.graph:
             raise NotImplementedError("graph_mode: gradients on info[...] tensors (the visible list is capacity-sized)")
+        if raw and n_vis > 0 and (direct or Cn != 1):
+            # (rare: a loss on info[...] tensors, or several cameras -- the generic projection backward: the rows are brought to
+            #  their documented meaning by a few tensor operations first)
+            o = recs[:n_vis, 5:6]
+            ca, cb, cc = recs[:n_vis, 2:3], recs[:n_vis, 3:4], recs[:n_vis, 4:5]
+            m1, m2 = G[:n_vis, 0:1].clone(), G[:n_vis, 1:2].clone()
+            G[:n_vis, 0:1] = -o * (ca * m1 + cb * m2)
+            G[:n_vis, 1:2] = -o * (cb * m1 + cc * m2)
+            G[:n_vis, 2:4] *= o
+            G[:n_vis, 4:7] *= -o * G.new_tensor([0.5, 1.0, 0.5])
+            raw = False
         if n_vis > 0 and direct:
             vi = vis_ids.long()
             if g_means2d is not None:
@@ -811,7 +825,8 @@ class _FusedRasterization(torch.autograd.Function):
              None if d_col is None else G.data_ptr() + 4 * (8 + c0), DC - c0 if d_col is not None else 0,
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
              ptr(totals) if ctx.graph else None, ptr(q_rows),
-             ptr(dir_rows) if (cs is not None and cs.autograd and n_vis > 0) else None, st)   # (differentiable view directions: dirs = means - camera position)
+             ptr(dir_rows) if (cs is not None and cs.autograd and n_vis > 0) else None,      # (differentiable view directions: dirs = means - camera position)
+             ptr(G) if raw else None, st)
         d_coeffs = d_campos = None
         if cs is not None and cs.autograd:
             if ctx.graph:

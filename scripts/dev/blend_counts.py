@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development: candidate / entry / slot counts of the compositing backward (library built with -DMTGS_COUNT)."""
+"""Development: candidate / entry / slot counts of the compositing backward (library built with scripts/build_variant.py count -DMTGS_DEV -DMTGS_COUNT)."""
 import ctypes as C
 import sys
 from pathlib import Path
