@@ -307,7 +307,14 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
     int nxt_cnt = 0;
     auto issue = [&](int r, float (&dst)[DP_MAXSTEP], int &cnt_out) {
         const int2 sp = s_span[wave][r];
-        const int start = __builtin_amdgcn_readfirstlane(sp.x), cnt = __builtin_amdgcn_readfirstlane(sp.y);
+        const int start = __builtin_amdgcn_readfirstlane(sp.x);
+        int cnt = __builtin_amdgcn_readfirstlane(sp.y);
+        // a sender's rows occupy [r * row_stride, (r + 1) * row_stride): rows beyond that capacity (finish_static: a rank with
+        // more rows than the fixed capacity of the all-gather; the caller is told through its overflow flag) are not read
+        if (S.row_stride > 0) {
+            const int64_t room = S.row_stride / 16 - (int64_t)start;
+            cnt = room <= 0 ? 0 : (cnt < room ? cnt : (int)room);
+        }
         cnt_out = cnt;
         const float *rows_r = S.rows + (int64_t)r * S.row_stride + (int64_t)start * 16;
 #pragma unroll

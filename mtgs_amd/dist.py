@@ -272,6 +272,57 @@ class SparseGradExchange:
         # gradient exists in this mode)
         self.grad_rows, self.vis_ids = grad_rows, vis_ids
 
+    def finish_static(self, means: torch.Tensor, sh_degree: int, cap_rows: int, traversal_of_rank: Sequence[int]):
+        """finish() WITHOUT any host read or host wait -- the form a HIP graph can capture (with RCCL; the dynamic form sizes
+        its all-gathers from the ranks' row counts, which it reads from a pinned buffer behind an event).  Every rank sends a
+        FIXED number of rows, `cap_rows` (its rows are in index order from row 0, so the first min(count, cap_rows) are sent;
+        take the capacity from the size plan as mtgs_amd.graph_mode does for the frame), in ONE all-gather; the counts stay
+        on the device: the reduction finds every Gaussian through the senders' maps and never indexes past a sender's
+        capacity, and `overflow` (device bool) says whether some rank had more rows than `cap_rows` -- the step is then
+        incomplete and is to be repeated through finish() (as a frame beyond its capacities is).  traversal_of_rank: the
+        traversal each rank's camera belongs to this step -- known to every rank from the schedule (camera (step * world +
+        rank) mod T in the harness), so no meta record has to reach the host.
+        Returns ((v_means, v_quats, v_scales, v_opacities, v_coeffs), overflow): the dense sums of finish()."""
+        from ._lib import call, ptr, stream_of
+        import ctypes as _C
+        P = self._pending
+        assert P is not None and P["stage"] == "rows", "finish_static() follows rasterization() + backward()"
+        self._pending = None
+        N, K, dev, world, nw, T = self.N, self.K, self.device, self.world, self.n_words, self.T
+        assert len(traversal_of_rank) == world and all(0 <= int(t) < T for t in traversal_of_rank)
+        cap = int(max(1, min(cap_rows, self.rows.shape[0])))
+        means = means.detach().contiguous()
+        st = stream_of(means)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(P["done"])            # stream order only: the meta all-gather of the side stream
+        metas = P["metas"]
+        cams = metas[:, 1:4].contiguous().view(torch.float32)
+        words_all, prefix_all = metas[:, 4:], metas[:, 4 + 2 * nw:]
+        overflow = (metas[:, 0] > cap).any()
+        self.phase = f"exchange (static): all-gather of {cap} rows per rank"
+        if world > 1 or self.world_collectives:
+            recv = torch.empty((world, cap, self.ROW), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(recv.view(world * cap, self.ROW), self.rows[:cap], group=self.group)
+            row_stride = cap * self.ROW
+            self.last_bytes = world * (cap * self.ROW * 4 + self.meta_len * 4)
+        else:
+            recv, row_stride, self.last_bytes = self.rows, 0, 0
+        out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
+               torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+               torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
+        self.phase = "exchange (static): reduction"
+        if T == 1:
+            call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4, ptr(recv),
+                 row_stride, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, st)
+        else:
+            masks = [sum(1 << r for r in range(world) if int(traversal_of_rank[r]) == t) for t in range(T)]
+            for t in range(T):
+                call("mtgs_dp_reduce_slices", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), self.meta_len * 4,
+                     ptr(recv), row_stride, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+                     out[4].data_ptr() + t * K * 3 * 4, 0, -1, _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
+        self.phase = "idle"
+        return out, overflow
+
     def finish(self, means: torch.Tensor, sh_degree: int, rows: bool = False, all_colour_ranges=()):
         """After backward(): exchange the wire rows and return (v_means, v_quats, v_scales, v_opacities, v_coeffs) --
         the dense sums over all ranks of the gradients that flowed through `rasterization()`.

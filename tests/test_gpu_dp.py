@@ -259,6 +259,22 @@ def _worker_traversals(rank, world, port, out_dir):
     for got, ref in zip((g_means, g_quats, g_scales, g_opac, g_coeffs), dense):
         errs.append([float((got - ref).abs().max()), float(ref.abs().max())])
     np.save(Path(out_dir) / f"t{rank}.npy", np.array(errs))
+    # finish_static(): the same sums without any host read or wait (fixed-capacity all-gather, traversals from the schedule) --
+    # from a second frame of the same inputs; equal to finish() up to the order of the compositing atomics.  Then with a
+    # capacity that is too small for every rank: the overflow flag, and nothing is read out of bounds.
+    counts = int(ex._samples_host[rank][0])
+    assert counts > 200
+    for cap, want_overflow in ((N, False), (200, True)):      # (the capacity is a constant of the job: the same on every rank)
+        r3, a3, _ = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm, Kmat, W, H, cam_pos, traversal=t)
+        torch.autograd.backward([r3, a3], [Gc, Ga])
+        out_s, ovf = ex.finish_static(P["means"], 3, cap, [q % T for q in range(world)])
+        torch.cuda.synchronize()
+        assert bool(ovf) == want_overflow, (rank, cap, counts)
+        if not want_overflow:
+            for got, ref in zip(out_s, (g_means, g_quats, g_scales, g_opac, g_coeffs)):
+                assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-7, rank
+        else:
+            assert all(bool(torch.isfinite(o).all()) for o in out_s)
     dist.barrier()
     dist.destroy_process_group()
 
