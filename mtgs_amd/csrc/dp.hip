@@ -324,15 +324,23 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         }
     };
     const int row_lane0 = (lane & ~15) << 2;  // byte address of lane 0 of this 16-lane row (ds_bpermute)
-    issue(0, nxt, nxt_cnt);
-    for (int r = 0; r < S.W; ++r) {
+    // (a colour-only pass -- one traversal's slice -- walks ITS senders only: the rows of the others are not even loaded.  With
+    //  one traversal per sender the T passes of a step then read every sender's rows twice in total instead of T times.)
+    auto next_needed = [&](int r) {
+        while (r < S.W && !(geom || (any_colour && ((coeff_mask >> r) & 1ull)))) ++r;
+        return r;
+    };
+    int r_next = next_needed(0);
+    if (r_next < S.W) issue(r_next, nxt, nxt_cnt);
+    for (int r = r_next; r < S.W; r = r_next) {
         float cur[DP_MAXSTEP];
 #pragma unroll
         for (int st = 0; st < DP_MAXSTEP; ++st) cur[st] = nxt[st];
         const int cnt = nxt_cnt;
-        if (r + 1 < S.W) issue(r + 1, nxt, nxt_cnt);
+        r_next = next_needed(r + 1);
+        if (r_next < S.W) issue(r_next, nxt, nxt_cnt);
         const bool colour = any_colour && ((coeff_mask >> r) & 1ull);
-        if (cnt == 0 || !(geom || colour)) continue;  // wave-uniform: none of the tile's Gaussians / nothing to take from it
+        if (cnt == 0) continue;  // wave-uniform: none of the tile's Gaussians
         const float cx = S.cams[r * 3], cy = S.cams[r * 3 + 1], cz = S.cams[r * 3 + 2];
 #pragma unroll
         for (int st = 0; st < DP_MAXSTEP; ++st) {

@@ -270,6 +270,10 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
         sharp = (torch.maximum(srt[..., 0] / srt[..., 1], torch.tensor(10.0, device=sc.device)) - 10.0).mean()
         loss = loss + two_d + 1.0 * sharp
     loss.backward()
+    if os.environ.get("MTGS_LOSS_DEBUG") and vf and VISFIRST["cs"].rows is not None:
+        rows_ = VISFIRST["cs"].rows
+        nv_ = int((info["radii"] > 0).sum())
+        print("touched: %d of %d visible rows have a non-zero colour gradient" % (int((rows_[:nv_] != 0).any(1).sum()), nv_))
     sizes = [p["means"].shape[0] for p in P.values()]
     with torch.no_grad():
         if vf:
