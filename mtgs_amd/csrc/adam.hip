@@ -122,6 +122,9 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
 // and a stamp: 112 ... 148 us peek-like, 222 ... 253 us step-like -- the 12-byte and 4-byte pieces cost a memory transaction
 // each.  Measured here, arithmetic included (MTGS-like iteration, 960x540): peek 155 ... 180 us (SCAN 175 ... 200), step 243 ... 297.
 #define ADAM_HWIN 64
+#ifndef ADAM_ZERO_SKIP_MAX
+#define ADAM_ZERO_SKIP_MAX 6     // zero_probe without a bound of its own: a zero-gradient row is committed once it is this many steps behind
+#endif
 #define ADAM_LIST_ROWS 128
 struct RowCtx {
     bool step, flush, peek, has_state;
@@ -160,6 +163,21 @@ __device__ __forceinline__ void row_work(const mtgs_adam_group &d, const Hyper &
     int32_t *lastp = x.has_state ? d.last + i * x.T + d.sub_index : nullptr;
     int L = L_in;
     if (LIST) L = x.has_state ? *lastp : x.target;
+    if (x.step && d.zero_probe > 0 && x.has_state && r >= 0 && r < d.n_rows &&
+        x.target - L < ((d.zero_probe >> 16) > 0 ? (d.zero_probe >> 16) : ADAM_ZERO_SKIP_MAX)) {
+        // A visible row nothing was composited from (occluded: 90 % and more of the frustum-visible Gaussians) has an all-zero
+        // gradient: it may stay lazy like an unseen one -- but the forward peeks every visible row, and a row that is visible in
+        // every frame of its traversal and never stepped would have an ever longer history replayed by every peek.  So it is
+        // left alone only while it is fewer than K steps behind (zero_probe >> 16; the caller scales it with the number of traversals:
+        // a slice is rendered every T-th step); then this step commits it like a row with a
+        // gradient.  One 12-byte probe of the compact gradient row (+ the stamp) decides, before any of the scattered
+        // parameter / moment pieces is requested.
+        const float *pr = d.rows + (int64_t)r * d.row_stride + ((d.zero_probe & 0xffff) - 1);
+        const bool nz = c0 < 3 && pr[c0] != 0.f;
+        const unsigned long long b = __ballot(nz);
+        const int g0 = ((int)(threadIdx.x & 63) / LPR) * LPR;
+        if (((b >> g0) & ((1ull << LPR) - 1ull)) == 0ull) return;
+    }
     const bool in_rows = r >= 0 && r < d.n_rows;
     // STEP with this frame's caught rows: p comes from them, the missed steps are replayed for the moments only
     const bool use_caught = x.step && d.caught != nullptr && in_rows && h.wd == 0.f;

@@ -188,6 +188,11 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
             v.x *= y[0] * (1.f - y[0]); v.y *= y[1] * (1.f - y[1]); v.z *= y[2] * (1.f - y[2]);
             b = k == 0 ? 1.f : 0.f;
         }
+        // colour gradients below 4 x the smallest normal float count as zero, so that "the coefficient-0 gradient b_0 v is zero"
+        // and "every coefficient's gradient is zero" are the SAME statement (b_0 = 0.282: its product with such a v would
+        // round to zero where a larger basis value's would not): mtgs_adam_step's zero_probe leaves exactly the rows lazy
+        // whose gradient is all zero
+        v.x = fabsf(v.x) < 4.8e-38f ? 0.f : v.x; v.y = fabsf(v.y) < 4.8e-38f ? 0.f : v.y; v.z = fabsf(v.z) < 4.8e-38f ? 0.f : v.z;
         *reinterpret_cast<F3 *>(feat_rows + r * 48 + k * 3) = F3{b * v.x, b * v.y, b * v.z};
     }
     if (!dir_rows) return;

@@ -194,6 +194,8 @@ class ColorSource:
         self.want_grad_rows = False  # True: the backward leaves the compact gradient rows in .grad_rows / .grad_row_ids / .grad_row_count
         #                              (columns 0-1 the 2-D gradient, 2-3 absgrad: densify.update_statistics_rows) and writes NO dense absgrad
         self.grad_rows = self.grad_row_ids = self.grad_row_count = None
+        self.skip_zero_rows = True   # row-lazy parameters: visible rows whose colour gradient is exactly zero (occluded Gaussians: most
+        #                              of the frustum-visible ones) are left lazy by the step instead of being stepped with zeros
         self.optimizer = None   # a FusedAdam with row-lazy colour parameters: prepare() peeks the visible rows for the colour kernel
         self.caught = None
 
@@ -244,6 +246,8 @@ class ColorSource:
 
         def ck(p, col, start):
             kw = {}
+            if is_lazy(p) and self.skip_zero_rows:
+                kw["zero_probe"] = 0      # rows[:, 0:3] = C0 * v_rgb (x clamp mask): zero iff the whole coefficient gradient is
             if is_lazy(p):
                 if c is not None:
                     kw["caught"] = (c, col)

@@ -54,7 +54,7 @@ _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("row
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("caught_stride", "<i8"), ("item_start", "<i8"), ("n_rows", "<i8"),
                    ("width", "<i4"), ("row_col", "<i4"),
                    ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
-                   ("hyper_index", "<i4"), ("caught_col", "<i4"), ("rank_start", "<i4"), ("rank_count", "<i4"), ("reserved", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
+                   ("hyper_index", "<i4"), ("caught_col", "<i4"), ("rank_start", "<i4"), ("rank_count", "<i4"), ("zero_probe", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
                    ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
 MODE_DENSE, MODE_SLICE, MODE_ROWS_CATCHUP, MODE_ROWS_STEP, MODE_ROWS_FLUSH, MODE_ROWS_PEEK = 0, 1, 2, 3, 4, 5   # MTGS_ADAM_*
 _checked = False
@@ -117,7 +117,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- gradient source 2 -------------------------------------------------------------------------------------------
     def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0,
-                         slice_index: Optional[int] = None, caught=None, row_ids=None) -> None:
+                         slice_index: Optional[int] = None, caught=None, row_ids=None, zero_probe: Optional[int] = None) -> None:
         """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
         Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
         int32 [N].  slice_index = t for a per-traversal tensor `param[N, T, ...]`: only `param[:, t]` takes the row (width =
@@ -128,7 +128,11 @@ class FusedAdam(torch.optim.Optimizer):
         row_ids = (ids int32 [R] increasing, start, count | None): row-lazy parameters -- the frame's list of visible Gaussians
         (global index of every rank; this parameter's items are start .. start + N - 1; count: device int64 whose upper half is
         the number of valid ranks, mtgs_front_fwd's totals).  With it the rows are taken straight from the list (2-3x faster
-        than scanning the row map).  Cleared by step() / zero_grad()."""
+        than scanning the row map).
+        zero_probe = c: row-lazy parameters -- a row whose floats rows[r, c : c + 3] are all zero has an all-zero gradient and is
+        left lazy by the step (the caller guarantees the implication: ColorSource's rows hold C0 * v_rgb there).  Most
+        frustum-visible Gaussians are occluded and get no gradient; skipping them is exact -- the zero-gradient update is what
+        the next catch-up replays.  Cleared by step() / zero_grad()."""
         width = param.numel() // max(param.shape[0], 1) if param.dim() else 1
         sub_w, sub_i = 0, 0
         if slice_index is not None:
@@ -145,7 +149,10 @@ class FusedAdam(torch.optim.Optimizer):
             if cb.dtype != torch.float32 or cb.dim() != 2 or cb.stride(1) != 1 or cb.shape[0] < rows.shape[0] or \
                     cc < 0 or cc + (sub_w or width) > cb.shape[1]:
                 raise ValueError("set_row_gradient: caught = (float32 [R' >= R, stride], column)")
-        src = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids))
+        if zero_probe is not None and not (0 <= int(zero_probe) and int(zero_probe) + 3 <= rows.shape[1]):
+            raise ValueError("set_row_gradient: zero_probe")
+        src = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids),
+               -1 if zero_probe is None else int(zero_probe))
         first = self._rows.get(id(param))
         if first is not None and sub_w > 0 and first[5] > 0 and sub_i not in [first[6]] + [e[6] for e in self._rows_more.get(id(param), [])]:
             # ANOTHER slice of the same per-traversal tensor in the same step (data-parallel steps render several traversals:
@@ -484,7 +491,7 @@ class FusedAdam(torch.optim.Optimizer):
                 align |= g.data_ptr()
                 keep.append(g)
             if src is not None:         # (with a dense gradient too: the kernel adds them)
-                rows, row_of, col, stride, width, sub_w, sub_i, caught, rid = src
+                rows, row_of, col, stride, width, sub_w, sub_i, caught, rid, probe = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 r["n_rows"] = rows.shape[0]
                 r["sub_width"], r["sub_index"] = sub_w, sub_i
@@ -498,6 +505,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if (RL["T"] > 1) != (src[5] > 0) or (src[5] > 0 and src[4] // src[5] != RL["T"]):
                     raise RuntimeError("FusedAdam: row-lazy parameter and the slice of its row gradient do not match")
                 r["mode"], r["last"], r["hist"], r["n"] = MODE_ROWS_STEP, RL["last"].data_ptr(), RL["hist"].data_ptr(), p.shape[0]
+                # (the bound on the staleness of a skipped row: four visits of its slice -- a slice is rendered every T-th step)
+                r["zero_probe"] = ((src[9] + 1) | (min(4 * RL["T"], 0x7fff) << 16)) if (src[9] >= 0 and grp["weight_decay"] == 0) else 0
                 if src[7] is not None and grp["weight_decay"] == 0:
                     r["caught"], r["caught_stride"], r["caught_col"] = src[7][0].data_ptr(), src[7][0].stride(0), int(src[7][1])
                     keep.append(src[7][0])

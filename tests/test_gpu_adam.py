@@ -396,6 +396,50 @@ def test_exact_row_lazy_adam_touches_only_the_visible_rows(hip_lib):
         ob.step()
 
 
+def test_row_lazy_step_leaves_zero_gradient_rows_lazy(hip_lib):
+    """set_row_gradient(zero_probe=c): a visible row whose gradient is exactly zero (an occluded Gaussian: most of the frustum-
+    visible ones get no gradient at all) is NOT stepped -- it stays lazy like a Gaussian the frame did not see.  Eighty percent of
+    the visible rows of every frame are given all-zero gradient rows: (1) those rows are really left alone by the step, (2) after
+    flush() every parameter and moment is bit-identical to the optimizer that steps every row with the same (mostly zero)
+    gradients; SCAN and LIST forms."""
+    dev = torch.device("cuda")
+    N, T = 3001, 3
+    g = torch.Generator().manual_seed(23)
+    base, make = _row_lazy_case(dev, N, T, g)
+    for use_list in (False, True):
+        Pa, oa = make(False)
+        Pb, ob = make(True)
+        skipped_any = False
+        for step, t in enumerate([0, 1, 1, 2, 0, 2, 1, 0, 0, 2]):
+            vis, row_of, rows = _frame(N, g, dev, frac=0.3)
+            dead = (torch.rand(rows.shape[0], generator=g) < 0.8).to(dev)
+            rows = rows.clone()
+            rows[dead] = 0.0                                           # occluded: no gradient at all
+            ids = torch.nonzero(vis).flatten().int().contiguous()
+            kw = {"row_ids": (ids, 0, None)} if use_list else {}
+            before = Pb["rest"].detach().clone()
+            ob.catch_up_rows([(Pb["dc"], row_of, None), (Pb["adapters"], row_of, t), (Pb["rest"], row_of, t)])
+            caught = Pb["rest"].detach().clone()
+            for P, o, z in ((Pa, oa, {}), (Pb, ob, dict(zero_probe=0, **kw))):
+                P["means"].grad = torch.zeros(N, 3, device=dev)
+                o.set_row_gradient(P["dc"], rows, row_of, 0, **z)
+                o.set_row_gradient(P["adapters"], rows, row_of, 0, slice_index=t, **z)
+                o.set_row_gradient(P["rest"], rows, row_of, 3, slice_index=t, **z)
+                o.step()
+            dead_items = torch.nonzero(vis).flatten()[dead]
+            live_items = torch.nonzero(vis).flatten()[~dead]
+            assert torch.equal(Pb["rest"][dead_items, t], caught[dead_items, t])            # not stepped (only caught up before)
+            if step > 0 and not torch.equal(Pa["rest"][dead_items, t], Pb["rest"][dead_items, t]):
+                skipped_any = True                                                           # (the every-row optimizer moved them)
+            assert torch.equal(Pa["rest"][live_items, t], Pb["rest"][live_items, t]), (use_list, step)
+        assert skipped_any
+        ob.flush()
+        for k in base:
+            assert torch.equal(Pa[k], Pb[k]), (use_list, k)
+            assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), (use_list, k)
+            assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), (use_list, k)
+
+
 def test_row_lazy_adam_in_a_hip_graph(hip_lib):
     """catch_up_rows + step captured in ONE HIP graph (static row buffers, advance() per replay): after flush() bit-identical
     to the eager optimizer that steps every row -- the captured forward reads `t - 1` as the steps already taken."""
