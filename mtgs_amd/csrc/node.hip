@@ -289,6 +289,15 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_rows_kernel(const mtgs_no
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r = (int64_t)blockIdx.x * NODE_BLOCK + threadIdx.x;
     if (r >= n_vis) return;
+    const float4 *w = reinterpret_cast<const float4 *>(ws + r * ws_stride);
+    const float4 w0 = w[0], w1 = w[1], w2 = w[2];       // (v_mean xyz, vq.w) (vq.xyz', vs.x) (vs.yz, v_opacity, -)
+    if (w0.x == 0.f && w0.y == 0.f && w0.z == 0.f && w0.w == 0.f && w1.x == 0.f && w1.y == 0.f && w1.z == 0.f && w1.w == 0.f &&
+        w2.x == 0.f && w2.y == 0.f && w2.z == 0.f) {
+        // an occluded Gaussian (no gradient reached it: most frustum-visible ones): zero row, no parameter gathers, no node search
+        float4 *dz = reinterpret_cast<float4 *>(out + r * 12);
+        dz[0] = dz[1] = dz[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int64_t g = vis_ids[r];
     int lo = 0, hi = n_nodes - 1;
     while (lo < hi) {
@@ -297,8 +306,6 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_bwd_rows_kernel(const mtgs_no
     }
     const mtgs_node_desc &d = table[lo];
     const int64_t gl = g - d.start;
-    const float4 *w = reinterpret_cast<const float4 *>(ws + r * ws_stride);
-    const float4 w0 = w[0], w1 = w[1], w2 = w[2];       // (v_mean xyz, vq.w) (vq.xyz', vs.x) (vs.yz, v_opacity, -)
     // exp / sigmoid recomputed from the RAW parameters (the expressions of the forward, so the same bits): the activated
     // tensors are autograd outputs that are released when the backward has run, i.e. before this kernel is enqueued
     const F3 sr = *reinterpret_cast<const F3 *>(d.scales_raw + gl * 3);

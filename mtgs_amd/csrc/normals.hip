@@ -160,12 +160,18 @@ __global__ __launch_bounds__(256) void normals_bwd_qrows_kernel(int64_t cap_vis,
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_vis) return;
+    const F3 v = F3{G[r * row_stride + col], G[r * row_stride + col + 1], G[r * row_stride + col + 2]};
+    if (v.x == 0.f && v.y == 0.f && v.z == 0.f) {
+        // nothing was composited from this Gaussian (occluded: most frustum-visible ones): the VJP of a zero cotangent is zero,
+        // and its quaternion / scale / mean are not even gathered
+        *reinterpret_cast<F4 *>(qrows + r * 4) = F4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int64_t i = vis_ids[r];
     const F4 q = *reinterpret_cast<const F4 *>(quats + i * 4);
     const F3 s = *reinterpret_cast<const F3 *>(scales + i * 3);
     const F3 m = *reinterpret_cast<const F3 *>(means + i * 3);
     const NormalGeom g = geometry(q, s, m, c2w);
-    const F3 v = F3{G[r * row_stride + col], G[r * row_stride + col + 1], G[r * row_stride + col + 2]};
     *reinterpret_cast<F4 *>(qrows + r * 4) = normal_vjp(q, g, v, c2w);
 }
 }  // namespace
