@@ -185,16 +185,17 @@ def mtgs_like_iteration_cells():
     res = {}
     budget_s = float(os.environ.get("MTGS_BENCH_EXTRA_BUDGET_S", "150"))    # (a fresh box spends a minute or two importing torch: the
     #   extras must not push the run past "a few minutes"; a cell that does not fit the budget is reported as None)
-    # the loop that TRAINS, through HIP graphs (train_loop(graph=True)): 600 steps from a perturbed subset of the true Gaussians
-    # with the reference's refinement rules, refinements at 300 / 400 / 500; wall clock per step with the re-captures and the
-    # refinements inside, the GPU time per step of a stretch without either, and the loss it reached
+    # the loop that TRAINS, through HIP graphs (train_loop(graph=True)): 1000 steps from a perturbed subset of the true Gaussians
+    # with the reference's refinement rules, refinements at 300 ... 900; wall clock per step (from the step at which every
+    # traversal has its first graph) with the seven re-captures and refinements inside, the GPU time per step of a stretch
+    # without either, and the loss it reached
     left = budget_s - (time.time() - _T0)
     res["mtgs_like_training_ms_per_step"] = res["mtgs_like_training_steady_ms"] = res["mtgs_like_training_loss"] = None
     if left >= 30:
         try:
             r = subprocess.run([sys.executable, os.path.join(root, "scripts", "mtgs_like_train.py"), "--shipped", "--visfirst", "--optimizer",
                                 "fused", "--row-lazy", "--geometry-rows", "--only", "fused", "--reps", "1", "--converge", "--grad-thresh", "1e-3",
-                                "--clear-radius", "12", "--steps", "600", "--refine-every", "100", "--densify-from", "250", "--steady", "60",
+                                "--clear-radius", "12", "--steps", "1000", "--refine-every", "100", "--densify-from", "250", "--steady", "60",
                                 "260", "--train-graph"], capture_output=True, text=True, timeout=min(180.0, left), cwd=root)
             m = re.search(r"timing: ([\d.]+) ms per step", r.stdout)
             sm = re.search(r"steady: ([\d.]+) ms per step", r.stdout)

@@ -707,7 +707,10 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     t_start = None
     i_start = 0
     steady_ev = []           # GPU time per step over a window without refinements (steady = (first step, last step))
-    t_from = min(3, steps - 1) if timing_from is None else min(timing_from, steps - 1)
+    # (the clock starts behind the one-time start-up: the first few eager steps -- allocator, size plan, lazy initialisation --
+    #  and, when training through graphs, the first capture of every traversal; every later re-capture and every refinement is
+    #  inside the measured span)
+    t_from = min(2 * T if graph else 3, steps - 1) if timing_from is None else min(timing_from, steps - 1)
     for i in range(steps):
         if i == t_from:       # wall clock per step after the first few (allocator, size plan, lazy init)
             torch.cuda.synchronize()
