@@ -390,6 +390,27 @@ __global__ void __launch_bounds__(ADAM_SCHED_THREADS) adam_list_schedule_kernel(
     }
 }
 
+// item (Gaussian) and column of element e of a tensor with `width` floats per item.  The widths of the narrow geometry
+// tensors (1, 3, 4) and element indices below 2^32 -- every MTGS tensor -- take a shift or a multiply-high instead of the
+// 64-bit software division a run-time divisor costs (~60 instructions per float4 of a streaming group with a row map).
+__device__ __forceinline__ void item_of(const int64_t e, const int width, int64_t &i, int &c) {
+    if (e < ((int64_t)1 << 32)) {
+        const uint32_t e32 = (uint32_t)e;
+        uint32_t q;
+        switch (width) {
+            case 1: q = e32; break;
+            case 3: q = e32 / 3u; break;
+            case 4: q = e32 >> 2; break;
+            default: q = e32 / (uint32_t)width; break;
+        }
+        i = q;
+        c = (int)(e32 - q * (uint32_t)width);
+        return;
+    }
+    i = e / width;
+    c = (int)(e - i * width);
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group *__restrict__ table,
                                                           float *__restrict__ hyper, int n_groups) {
@@ -466,8 +487,9 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
                 if (!dense) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rows) {
                     const int64_t e = base + ((int64_t)u * ADAM_BLOCK + threadIdx.x) * ADAM_VEC;
-                    int64_t i = e / d.width;
-                    int c = (int)(e - i * d.width);
+                    int64_t i;
+                    int c;
+                    item_of(e, d.width, i, c);
                     float t[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -496,7 +518,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
     for (int64_t e = base + threadIdx.x; e < end; e += ADAM_BLOCK) {
         float g = 0.f;
         if (dense) g = d.g[e];
-        if (rows) { const int64_t i = e / d.width; g += row_grad(d, i, (int)(e - i * d.width)); }
+        if (rows) { int64_t i; int c; item_of(e, d.width, i, c); g += row_grad(d, i, c); }
         float p = P[e], m = M[e], v = V[e];
         adam_update(p, m, v, g, h);
         P[e] = p; M[e] = m; V[e] = v;
