@@ -145,7 +145,8 @@ class RefineConfig:
 
 @torch.no_grad()
 def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Tensor], cfg: RefineConfig, step: int, seed: int,
-                     moments: Optional[Dict[str, Tuple[Tensor, Tensor]]] = None):
+                     moments: Optional[Dict[str, Tuple[Tensor, Tensor]]] = None, extras: Optional[Dict[str, Tensor]] = None,
+                     before_rows=None):
     """VanillaGaussianSplattingModel.refinement_after (densification branch, step < stop_split_at) for one node, on the
     device: split / duplicate / cull, every per-Gaussian tensor of `params` (means[N,3], scales[N,3] log, quats[N,4] wxyz,
     opacities[N,1] logit, + any other [N, ...] tensors: features_dc / features_rest / features_adapters ...) compacted and
@@ -157,7 +158,11 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
     bit-identical tensors, so N stays identical without a broadcast (the reference draws torch.randn per rank, :642, :687).
     ONE host synchronisation: the new N (tensor sizes).  Returns (new_params, new_moments | None, info) with
     info = {n_before, n_after, n_old_kept (old Gaussians kept), n_children (split children), n_dups, n_split (split parents; a device scalar),
-    src_index, kind}."""
+    src_index, kind}.
+    extras {name: [N, ...] tensor of a 4-byte dtype}: moved like a parameter (a child / duplicate takes its parent's row) and
+    returned in info["extras"] -- the row-lazy optimizer's `last` stamps.  before_rows(parents bool [N]): called after the
+    decisions are known and before any row is copied, with the Gaussians that get children or a duplicate -- a caller whose rows are
+    lazy brings THOSE rows up to date there (FusedAdam.catch_up_rows) instead of flushing every row."""
     from ._lib import call, ptr, stream_of
     means, scales, quats, opac = (params[k] for k in ("means", "scales", "quats", "opacities"))
     require_gpu(means, scales, quats, opac, *stats)
@@ -193,6 +198,9 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
     call("mtgs_refine_apply", N, n_out, ptr(flags), ptr(pos), ptr(bases), ptr(c["means"]), ptr(c["scales"]), ptr(c["quats"]), th, opt,
          _C.c_uint64(seed & (2 ** 64 - 1)), int(step), ptr(src_index), ptr(kind), ptr(new["means"]), ptr(new["scales"]), st)
 
+    if before_rows is not None and N > 0:
+        before_rows((flags[:N] & 0x7E) != 0)      # (bits 1 .. 1 + S: a child or the duplicate is kept)
+
     def rows(src, zero_new):
         w = src.numel() // max(N, 1)
         dst = torch.empty((n_out,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
@@ -205,11 +213,15 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
     new_moments = None
     if moments is not None:
         new_moments = {k: (rows(a.detach(), True), rows(b.detach(), True)) for k, (a, b) in moments.items()}
+    moved = {}
+    for k, t in (extras or {}).items():
+        assert t.shape[0] == N and t.element_size() == 4, "extras: [N, ...] tensors of a 4-byte dtype"
+        moved[k] = rows(t.contiguous().view(torch.float32), False).view(t.dtype)      # (a bit-for-bit row copy)
     # (n_split stays a DEVICE scalar: children can be culled one by one, so the number of split parents does not follow from
     #  the totals, and a second host synchronisation is not worth a log line -- int(info["n_split"]) reads it when wanted)
     info = {"n_before": N, "n_after": n_out, "n_old_kept": tot_h[0], "n_children": sum(tot_h[1:1 + S]), "n_dups": tot_h[1 + S],
             "n_split": (flags[:N] >> 7).sum() if N else torch.zeros((), dtype=torch.int64, device=dev),
-            "src_index": src_index[:n_out], "kind": kind[:n_out]}
+            "src_index": src_index[:n_out], "kind": kind[:n_out], "extras": moved}
     return new, new_moments, info
 
 

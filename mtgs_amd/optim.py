@@ -239,11 +239,20 @@ class FusedAdam(torch.optim.Optimizer):
         self._flush_rows()
 
     # ---- exact row-lazy Adam (visible rows only) ---------------------------------------------------------------------------
-    def set_row_lazy(self, param: torch.Tensor, traversals: Optional[int] = None, hist_capacity: int = 1 << 17) -> None:
+    def row_lazy_state(self, param: torch.Tensor):
+        """(last int32 [N * T], hist float32 [2 * capacity], capacity) of a row-lazy parameter, or None -- what a refinement that
+        moves rows WITHOUT flushing carries over to the next optimizer (set_row_lazy(..., last=, hist=))."""
+        RL = self._rowlazy.get(id(param))
+        return None if RL is None else (RL["last"], RL["hist"], RL["cap"])
+
+    def set_row_lazy(self, param: torch.Tensor, traversals: Optional[int] = None, hist_capacity: int = 1 << 17,
+                     last: Optional[torch.Tensor] = None, hist: Optional[torch.Tensor] = None) -> None:
         """`param[N, ...]` (traversals=None) or `param[N, T, ...]` (traversals=T: the step's set_row_gradient names the slice):
         from now on step() updates only the rows the step's row map marks visible, catch_up_rows() brings rows up to date
         before a forward reads them, flush() all of them.  The parameter's gradient must come through set_row_gradient().
-        hist_capacity: optimizer steps the per-step scalar history holds (8 bytes each; grown on demand outside HIP graphs)."""
+        hist_capacity: optimizer steps the per-step scalar history holds (8 bytes each; grown on demand outside HIP graphs).
+        last / hist: the stamps (int32 [N * T], moved with their rows) and the history of the optimizer this one continues (a
+        refinement that did not flush: rows stay as lazy as they were); default: every row current as of the step count."""
         if not param.is_contiguous() or param.dtype != torch.float32 or not param.is_cuda:
             raise RuntimeError("FusedAdam.set_row_lazy: contiguous float32 HIP parameter")
         T = 1 if traversals is None else int(traversals)
@@ -252,6 +261,12 @@ class FusedAdam(torch.optim.Optimizer):
         st = self.state.get(param, {})
         s0 = int(float(st["step"])) if "step" in st else 0
         cap = max(int(hist_capacity), s0 + 2)
+        if last is not None or hist is not None:
+            if last is None or hist is None or last.dtype != torch.int32 or last.numel() != param.shape[0] * T or \
+                    not last.is_contiguous() or hist.dtype != torch.float32 or hist.numel() < 2 * (s0 + 2):
+                raise ValueError("set_row_lazy: last int32 [N * T] contiguous and hist float32 [2 * capacity] go together")
+            self._rowlazy[id(param)] = {"param": param, "T": T, "cap": hist.numel() // 2, "last": last.reshape(-1), "hist": hist}
+            return
         self._rowlazy[id(param)] = {"param": param, "T": T, "cap": cap,
                                     "last": torch.full((param.shape[0] * T,), s0, dtype=torch.int32, device=param.device),
                                     "hist": torch.zeros(2 * cap, dtype=torch.float32, device=param.device)}

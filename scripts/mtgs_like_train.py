@@ -410,7 +410,7 @@ def iteration_nograd(P, cam, gt, mask, stats, win, W, H, shipped):
     return 0.8 * masked_l1(gt, rgb, mask) + 0.2 * (1 - masked_ssim(gt, rgb, mask))
 
 
-def refine_device(P, stats, opt_state_of, step, seed, growth=0.02, cfg=None):
+def refine_device(P, stats, opt_state_of, step, seed, growth=0.02, cfg=None, lazy_opt=None):
     """Densification of every static node with mtgs_amd.densify.refine_gaussians (csrc/refine.hip): the reference's rules
     (vanilla_gaussian_splatting.py:476-699) on the device, Adam moments following their rows, samples from a generator keyed
     by (seed, step, Gaussian index) -- identical on every rank of a data-parallel run.  The gradient threshold is set per
@@ -420,7 +420,11 @@ def refine_device(P, stats, opt_state_of, step, seed, growth=0.02, cfg=None):
     with the screen-space gradient threshold scaled ONCE for the synthetic scene (--converge): what refines is then decided
     by the training state, and fewer Gaussians qualify as the model converges; the opacity reset of refinement_after
     (:555-572) runs on the reference's schedule.
-    Returns (added, culled, {old parameter id: (new parameter, new moments | None)})."""
+    lazy_opt (a FusedAdam with row-lazy parameters): NO flush before the rows move -- the `last` stamps travel with their rows
+    like the moments do (refine_gaussians(extras=...)), and only the Gaussians that get children or a duplicate, whose current
+    values the new rows copy, are caught up first (before_rows -> FusedAdam.catch_up_rows).  swap[...] then carries
+    (last, hist) for the next optimizer's set_row_lazy.
+    Returns (added, culled, {old parameter id: (old, new parameter, new moments | None, (last, hist) | None)})."""
     from mtgs_amd.densify import RefineConfig, refine_gaussians, reset_opacities
     added = culled = 0
     swap = {}
@@ -435,14 +439,28 @@ def refine_device(P, stats, opt_state_of, step, seed, growth=0.02, cfg=None):
                                reset_alpha_every=10 ** 6, split_screen_size=1e9, cull_screen_size=1e9, clone_sample_means=False)
         moments = {k: (opt_state_of(v)["exp_avg"], opt_state_of(v)["exp_avg_sq"]) for k, v in p.items()
                    if opt_state_of(v) and "exp_avg" in opt_state_of(v)}
+        n_old = p["means"].shape[0]
+        lazy = {k: lazy_opt.row_lazy_state(v) for k, v in p.items()
+                if lazy_opt is not None and hasattr(lazy_opt, "row_lazy_state") and lazy_opt.row_lazy_state(v) is not None}
+        extras = {"last:" + k: stt[0].view(n_old, -1) for k, stt in lazy.items()}
+
+        def before_rows(parents, p=p, lazy=lazy, n_old=n_old):
+            m = torch.where(parents, 0, -1).to(torch.int32).contiguous()
+            items = []
+            for k, stt in lazy.items():
+                T_k = stt[0].numel() // max(n_old, 1)
+                items += [(p[k], m, (t_ if T_k > 1 else None)) for t_ in range(T_k)]
+            lazy_opt.catch_up_rows(items)
         new, new_m, info = refine_gaussians({k: v.detach() for k, v in p.items()}, tuple(st), cfg, step, seed,
-                                            moments=moments or None)
+                                            moments=moments or None, extras=extras or None,
+                                            before_rows=before_rows if lazy else None)
         if fixed is not None and step % (cfg.reset_alpha_every * cfg.refine_every) == cfg.refine_every:
             reset_opacities(new["opacities"], cfg, new_m.get("opacities") if new_m else None)
         n_new = info["n_after"]
         for k, v in p.items():
             q = new[k].requires_grad_(True)
-            swap[id(v)] = (v, q, new_m.get(k) if new_m else None)
+            carry = (info["extras"]["last:" + k].reshape(-1).contiguous(), lazy[k][1]) if k in lazy else None
+            swap[id(v)] = (v, q, new_m.get(k) if new_m else None, carry)
             new[k] = q
         P[name] = new
         added += info["n_children"] + info["n_dups"]
@@ -496,32 +514,35 @@ def make_optimizer(kind, P, shipped=None, capturable=False):
     return torch.optim.Adam(groups, eps=1e-15, foreach=True, capturable=capturable)
 
 
-def enable_dp_rows(opt, P):
+def enable_dp_rows(opt, P, carry=None):
     """--dp-rows: the per-traversal colour tensors are row-lazy (a step touches the rows of the slices some rank rendered; the
     other slices and rows decay lazily, bit-identically to stepping them).  Call on a new optimizer after its state is in place."""
     if not DPROWS["on"]:
         return opt
+    kw = lambda q: dict(zip(("last", "hist"), carry[id(q)])) if (carry and carry.get(id(q))) else {}
     for p in P.values():
         if "features_adapters" in p:
             a, r = p["features_adapters"], p["features_rest"]
-            opt.set_row_lazy(a, traversals=a.shape[1])
-            opt.set_row_lazy(r, traversals=r.shape[1])
+            opt.set_row_lazy(a, traversals=a.shape[1], **kw(a))
+            opt.set_row_lazy(r, traversals=r.shape[1], **kw(r))
     return opt
 
 
-def enable_row_lazy(opt, P):
+def enable_row_lazy(opt, P, carry=None):
     """--row-lazy: the colour parameters (read for the visible Gaussians only under --visfirst) are stepped for the visible
-    rows of the rendered traversal alone.  Call on a new optimizer AFTER its state is in place (refinement)."""
+    rows of the rendered traversal alone.  Call on a new optimizer AFTER its state is in place (refinement); carry {id(parameter):
+    (last, hist)}: the stamps a refinement moved with their rows and the history of the previous optimizer (no flush)."""
     if not ROWLAZY["on"] or not hasattr(opt, "set_row_lazy"):
         return opt
+    kw = lambda q: dict(zip(("last", "hist"), carry[id(q)])) if (carry and carry.get(id(q))) else {}
     for p in P.values():
-        opt.set_row_lazy(p["features_dc"])
+        opt.set_row_lazy(p["features_dc"], **kw(p["features_dc"]))
         if "features_adapters" in p:
             a = p["features_adapters"]
-            opt.set_row_lazy(a, traversals=a.shape[1] if a.dim() == 3 else None)
+            opt.set_row_lazy(a, traversals=a.shape[1] if a.dim() == 3 else None, **kw(a))
         r = p["features_rest"]
         if r.shape[-2] > 0:
-            opt.set_row_lazy(r, traversals=r.shape[1] if r.dim() == 4 else None)
+            opt.set_row_lazy(r, traversals=r.shape[1] if r.dim() == 4 else None, **kw(r))
     ROWLAZY["opt"] = opt
     return opt
 
@@ -752,24 +773,29 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 mdist.all_reduce_stats([t for s in stats for t in s[:2]], [s[2] for s in stats],
                                        sum_init=[v for _ in stats for v in (0.0, 1.0)])
             before = sum(p["means"].shape[0] for p in P.values())
-            if LAZY["on"] or ROWLAZY["on"] or DPROWS["on"]:
-                opt.flush()                   # every slice / row up to date before rows move
+            if LAZY["on"]:
+                opt.flush()                   # (slice-lazy tensors: every slice up to date before rows move)
+            # row-lazy tensors are NOT flushed: their `last` stamps move with the rows, only the parents of new rows are caught up
             params = [q for g in opt.param_groups for q in g["params"]]
             state = {id(q): opt.state.get(q) for q in params}
             tick("flush")
-            added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed, cfg=refine_cfg)
+            added, culled, swap = refine_device(P, stats, lambda q: state.get(id(q)), i + 1, seed, cfg=refine_cfg,
+                                                lazy_opt=opt if (ROWLAZY["on"] or DPROWS["on"]) else None)
             tick("refine_device")
             old_opt, opt = opt, make_opt()
-            for old_id, (old, new_p, mom) in swap.items():
+            carry = {}
+            for old_id, (old, new_p, mom, lz) in swap.items():
                 st_o = state.get(old_id)
                 if st_o and mom is not None:
                     opt.state[new_p] = {"step": st_o["step"], "exp_avg": mom[0], "exp_avg_sq": mom[1]}
+                if lz is not None and st_o:
+                    carry[id(new_p)] = lz
             for grp in opt.param_groups:      # untouched parameters (object nodes, exposure) keep their whole state
                 for q in grp["params"]:
                     if q not in opt.state and state.get(id(q)):
                         opt.state[q] = state[id(q)]
-            enable_row_lazy(opt, P)
-            enable_dp_rows(opt, P)
+            enable_row_lazy(opt, P, carry)
+            enable_dp_rows(opt, P, carry)
             if hasattr(opt, "inherit_layout"):
                 opt.inherit_layout(old_opt)
             del old_opt
