@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 23
+#define MTGS_RAST_ABI_VERSION 24
 
 enum {
     MTGS_OK = 0,
@@ -730,6 +730,9 @@ typedef struct mtgs_adam_group {
     const int64_t *row_count_dev; /* LIST: number of valid ranks = min(n_rows, *row_count_dev >> 32) (mtgs_front_fwd's totals; nullable) */
     float *caught;              /* ROWS_PEEK: destination, ROWS_STEP: source (nullable) -- the up-to-date parameter rows of the
                                  * frame, row r = row_of[i] at caught[r * caught_stride + caught_col ..] (n_rows rows) */
+    const int32_t *sub_index_dev; /* (ABI v24, nullable) the slice in DEVICE memory: read when the kernel runs, overrides sub_index -- ONE
+                                 * captured step / peek serves every traversal of a per-traversal tensor (the caller rewrites the
+                                 * word in front of a replay) */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
     int64_t caught_stride;      /* floats between rows of `caught` */

@@ -41,6 +41,10 @@ struct Hyper {
     float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, wd, gscale;
 };
 
+// the slice (traversal) a group works on: a host value in the descriptor, or -- sub_index_dev -- a DEVICE word that is read when
+// the kernel runs, so that ONE captured step serves every traversal (the caller rewrites the word in front of a replay)
+__device__ __forceinline__ int slice_of(const mtgs_adam_group &d) { return d.sub_index_dev ? *d.sub_index_dev : d.sub_index; }
+
 // The update in two halves with the operation sequence PINNED (no contraction beyond the fused multiply-adds written out): the
 // row-lazy groups replay the moment half alone where the parameter half has already been done (adam_rows), and all paths
 // -- streaming, slice, row catch-up, row step -- must produce the same bits.
@@ -97,7 +101,7 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
     if (r < 0 || r >= d.n_rows) return 0.f;
     if (d.sub_width > 0) {
         const int s = c / d.sub_width;
-        if (s != d.sub_index) return 0.f;
+        if (s != slice_of(d)) return 0.f;
         c -= s * d.sub_width;
     }
     return d.rows[(int64_t)r * d.row_stride + d.row_col + c];
@@ -128,7 +132,7 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
 #define ADAM_LIST_ROWS 128
 struct RowCtx {
     bool step, flush, peek, has_state;
-    int t_now, target, win0, sw, T;
+    int t_now, target, win0, sw, T, slice;
     int64_t off;
     const float *s_hist;
 };
@@ -136,7 +140,8 @@ __device__ __forceinline__ RowCtx row_ctx(const mtgs_adam_group &d, const Hyper 
     RowCtx x;
     x.sw = d.sub_width > 0 ? d.sub_width : d.width;          // floats of the slice this group works on
     x.T = d.sub_width > 0 ? d.width / d.sub_width : 1;
-    x.off = d.sub_width > 0 ? (int64_t)d.sub_index * x.sw : 0;
+    x.slice = d.sub_width > 0 ? slice_of(d) : 0;
+    x.off = (int64_t)x.slice * x.sw;
     x.t_now = reinterpret_cast<const int32_t *>(hy)[2];
     const int pending = reinterpret_cast<const int32_t *>(hy)[3];
     x.step = d.mode == MTGS_ADAM_ROWS_STEP; x.flush = d.mode == MTGS_ADAM_ROWS_FLUSH; x.peek = d.mode == MTGS_ADAM_ROWS_PEEK;
@@ -160,7 +165,7 @@ __device__ __forceinline__ RowCtx row_ctx(const mtgs_adam_group &d, const Hyper 
 template <bool LIST, int LPR>
 __device__ __forceinline__ void row_work(const mtgs_adam_group &d, const Hyper &h, const RowCtx &x, const int64_t i, const int r,
                                          const int L_in, const int c0) {
-    int32_t *lastp = x.has_state ? d.last + i * x.T + d.sub_index : nullptr;
+    int32_t *lastp = x.has_state ? d.last + i * x.T + x.slice : nullptr;
     int L = L_in;
     if (LIST) L = x.has_state ? *lastp : x.target;
     if (x.step && d.zero_probe > 0 && x.has_state && r >= 0 && r < d.n_rows &&
@@ -267,7 +272,7 @@ __device__ __forceinline__ void adam_rows_scan(const mtgs_adam_group &d, const H
         bool sel = false;
         int L = x.target, r = -1;
         if (i < d.n) {
-            if (x.has_state) L = d.last[i * x.T + d.sub_index];
+            if (x.has_state) L = d.last[i * x.T + x.slice];
             if (!x.flush) r = d.row_of[i];
             sel = x.flush ? L < x.target : (x.peek ? (r >= 0 && r < d.n_rows) : (r >= 0 && (x.step || L < x.target)));
         }
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(ADAM_BLOCK) adam_kernel(const mtgs_adam_group 
         // scheme's two passes over one slice cost more than one pass over three, it pays from T ~ 5.)
         const int64_t end = base + ADAM_ELEMS < d.n ? base + ADAM_ELEMS : d.n;
         const int sw = d.sub_width;
-        const int64_t off = (int64_t)d.sub_index * sw;
+        const int64_t off = (int64_t)slice_of(d) * sw;
         for (int64_t e0 = base + threadIdx.x; e0 < end; e0 += ADAM_BLOCK * ADAM_UNROLL) {
             float p[ADAM_UNROLL], m[ADAM_UNROLL], v[ADAM_UNROLL], g[ADAM_UNROLL];
             int64_t phys[ADAM_UNROLL];

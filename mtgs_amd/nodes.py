@@ -209,6 +209,8 @@ class ColorSource:
         Returns the buffer, or None (no optimizer: the colour kernel reads the parameters in place)."""
         self.caught = self.row_ids = None
         if self.optimizer is None:
+            if any(isinstance(np_[5], Tensor) for np_ in self.node_params):
+                raise RuntimeError("ColorSource: a device traversal_index needs the row-lazy optimizer's peek (ColorSource.optimizer)")
             return None
         out = torch.empty((max(int(cap_rows), 1), self.COEF_STRIDE), dtype=torch.float32, device=vis_rank.device)
         items = []
@@ -536,6 +538,13 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
             if nd[k].dtype != torch.float32:
                 raise TypeError(f"collect_gaussians: {k} must be float32, got {nd[k].dtype}")
         rest, add, trav = nd["features_rest"], nd.get("features_adapters"), nd.get("traversal_index")
+        trav_dev = isinstance(trav, Tensor)
+        if trav_dev:
+            # the traversal as an int32 DEVICE scalar (one captured iteration for every traversal): only the optimizer's peek /
+            # step read it (ColorSource.optimizer with row-lazy colour parameters) -- the node table carries slice 0 unread
+            if not deferred_colors or trav.dtype != torch.int32 or trav.numel() != 1 or not trav.is_cuda:
+                raise ValueError("collect_gaussians: a device 'traversal_index' is one int32 on the GPU and needs deferred_colors")
+            trav = 0
         if rest.dim() == 4:
             if trav is None:
                 raise ValueError("collect_gaussians: per-traversal features_rest [N,T,K-1,3] needs 'traversal_index'")

@@ -50,12 +50,25 @@ import torch
 from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
-                   ("last", "<u8"), ("hist", "<u8"), ("row_ids", "<u8"), ("row_count_dev", "<u8"), ("caught", "<u8"),
+                   ("last", "<u8"), ("hist", "<u8"), ("row_ids", "<u8"), ("row_count_dev", "<u8"), ("caught", "<u8"), ("sub_index_dev", "<u8"),
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("caught_stride", "<i8"), ("item_start", "<i8"), ("n_rows", "<i8"),
                    ("width", "<i4"), ("row_col", "<i4"),
                    ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
                    ("hyper_index", "<i4"), ("caught_col", "<i4"), ("rank_start", "<i4"), ("rank_count", "<i4"), ("zero_probe", "<i4"), ("one_minus_beta1", "<f4"), ("beta2", "<f4"), ("one_minus_beta2", "<f4"), ("eps", "<f4"),
                    ("weight_decay", "<f4"), ("grad_scale", "<f4")], align=True)
+
+
+def _put_slice(r, t) -> None:
+    """The slice of a per-traversal tensor in a table row: a host int, or an int32 DEVICE scalar that the kernel reads when it
+    runs (one captured step / peek for every traversal: the caller rewrites the word in front of a replay)."""
+    if isinstance(t, torch.Tensor):
+        if t.dtype != torch.int32 or t.numel() != 1 or not t.is_cuda:
+            raise ValueError("a device slice index is one int32 on the GPU")
+        r["sub_index"], r["sub_index_dev"] = 0, t.data_ptr()
+    else:
+        r["sub_index"], r["sub_index_dev"] = int(t), 0
+
+
 MODE_DENSE, MODE_SLICE, MODE_ROWS_CATCHUP, MODE_ROWS_STEP, MODE_ROWS_FLUSH, MODE_ROWS_PEEK = 0, 1, 2, 3, 4, 5   # MTGS_ADAM_*
 _checked = False
 
@@ -137,9 +150,14 @@ class FusedAdam(torch.optim.Optimizer):
         sub_w, sub_i = 0, 0
         if slice_index is not None:
             T = param.shape[1]
-            if not 0 <= int(slice_index) < T:
-                raise ValueError("set_row_gradient: slice_index")
-            sub_w, sub_i = width // T, int(slice_index)
+            if isinstance(slice_index, torch.Tensor):        # a device word (its value is the caller's promise: 0 <= t < T)
+                if slice_index.dtype != torch.int32 or slice_index.numel() != 1 or not slice_index.is_cuda:
+                    raise ValueError("set_row_gradient: a device slice_index is one int32 on the GPU")
+                sub_w, sub_i = width // T, slice_index
+            else:
+                if not 0 <= int(slice_index) < T:
+                    raise ValueError("set_row_gradient: slice_index")
+                sub_w, sub_i = width // T, int(slice_index)
         if rows.dtype != torch.float32 or row_of.dtype != torch.int32 or row_of.numel() != param.shape[0]:
             raise ValueError("set_row_gradient: rows float32 [R, stride], row_of int32 [N]")
         if rows.dim() != 2 or rows.stride(1) != 1 or col < 0 or col + (sub_w or width) > rows.shape[1] or not row_of.is_contiguous():
@@ -154,7 +172,8 @@ class FusedAdam(torch.optim.Optimizer):
         src = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids),
                -1 if zero_probe is None else int(zero_probe))
         first = self._rows.get(id(param))
-        if first is not None and sub_w > 0 and first[5] > 0 and sub_i not in [first[6]] + [e[6] for e in self._rows_more.get(id(param), [])]:
+        if first is not None and sub_w > 0 and first[5] > 0 and not isinstance(sub_i, torch.Tensor) and \
+                not isinstance(first[6], torch.Tensor) and sub_i not in [first[6]] + [e[6] for e in self._rows_more.get(id(param), [])]:
             # ANOTHER slice of the same per-traversal tensor in the same step (data-parallel steps render several traversals:
             # every traversal's senders give that slice its own rows and row map) -- row-lazy parameters only (step())
             self._rows_more.setdefault(id(param), []).append(src)
@@ -335,7 +354,8 @@ class FusedAdam(torch.optim.Optimizer):
                 r["last"], r["hist"] = RL["last"].data_ptr(), RL["hist"].data_ptr()
             if t is not None and p.dim() >= 2 and (RL["T"] > 1 if RL is not None else True):
                 T = RL["T"] if RL is not None else p.shape[1]
-                r["sub_width"], r["sub_index"] = width // T, int(t)
+                r["sub_width"] = width // T
+                _put_slice(r, t)
             if out is not None:
                 r["caught"], r["caught_stride"], r["caught_col"], r["n_rows"] = out.data_ptr(), out.stride(0), int(col), out.shape[0]
             if ro is not None:
@@ -509,7 +529,8 @@ class FusedAdam(torch.optim.Optimizer):
                 rows, row_of, col, stride, width, sub_w, sub_i, caught, rid, probe = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 r["n_rows"] = rows.shape[0]
-                r["sub_width"], r["sub_index"] = sub_w, sub_i
+                r["sub_width"] = sub_w
+                _put_slice(r, sub_i)
                 keep.append((rows, row_of))
             r["vec_ok"] = int(align % 16 == 0)
             r["hyper_index"] = i

@@ -200,6 +200,14 @@ REGS = {"on": False}                     # --regularizers: the 2D and sharp-shap
 LAST = {"info": {}}                      # the device scalars of the last rasterization's `info` (graph mode: overflow flag and counts)
 
 
+def at(x, t):
+    """x[t] for a host traversal index; for an int32 DEVICE scalar (one captured iteration for every traversal) the row is
+    gathered on the device: x is then a stacked tensor [T, ...]."""
+    if isinstance(t, torch.Tensor):
+        return x.index_select(0, t.view(1))[0]
+    return x[t]
+
+
 def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     """shipped = None: RGB only (the path + L1 + SSIM).  shipped = dict(exposure=[T,3,4] parameter, bg=[3], gt_depth, gt_normal
     per camera): the option set of config/MTGS.py -- predict_normals (7 blended channels), the exposure model, the lidar
@@ -229,10 +237,10 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
     if not vf:
         info["means2d"].retain_grad()
     if shipped:
-        E, bg = shipped["exposure"][t], shipped["bg"]
+        E, bg = at(shipped["exposure"], t), shipped["bg"]
         rgb, app, depth, normal = output_head(render, alpha, bg, E, depth=True, normal_channel=3) if fused else \
             head_chain(render, alpha, bg, E, True)
-        gt_d, gt_n = shipped["gt_depth"][t], shipped["gt_normal"][t]
+        gt_d, gt_n = at(shipped["gt_depth"], t), at(shipped["gt_normal"], t)
         if fused:
             l1 = masked_l1(gt, app, mask)
             loss_d, dmask = inverse_depth_l1(depth, gt_d, mask, 0.1, 80.0, 1e-5)     # :849-858, 875-879: the mask is a by-product
@@ -547,9 +555,12 @@ def enable_row_lazy(opt, P, carry=None):
     return opt
 
 
+ANY = "any traversal"      # key of the one graph that serves every traversal (train_loop(one_graph=True))
+
+
 def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=None, world=1, rank=0, accumulate=1, seed=7,
                log=print, sparse=False, optimizer="fused", graph=False, refine_cfg=None, poll_every=16, means_lr_final=None,
-               timing_from=None, densify_from=0, steady=None, first_cap_scale=1.0):
+               timing_from=None, densify_from=0, steady=None, first_cap_scale=1.0, one_graph=False):
     """Adam on the fused iteration (MTGSSceneModel.get_outputs -> get_loss_dict -> backward -> optimizers.step ->
     update_submodel_statistics / after_train / refinement_after every refine_every steps: mtgs_scene_graph.py:547-708, 806-987,
     1157-1183; vanilla_gaussian_splatting.py:448-577).  world > 1: view-parallel data parallelism (one process per rank, camera
@@ -570,6 +581,10 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     the graphs are dropped, every traversal renders one frame the ordinary way (exact sizes, the size plan updated) and is
     captured again with larger capacities.  A refinement ends the stretch: flush the row-lazy state, refine on the device (the
     one host synchronisation: the new N), new optimizer with the moved moments, new graphs.
+    one_graph = True (with graph; visibility-first colours and row-lazy colour parameters, static nodes): the traversal is an
+    int32 DEVICE scalar -- the camera, the targets and the exposure row are gathered from stacked tensors inside the graph, the
+    optimizer's peek / step read the slice from that word (mtgs_adam_group.sub_index_dev) -- so a stretch captures ONE graph
+    instead of one per traversal (MTGS trains with 8 traversals: 7 captures fewer behind every refinement).
     refine_cfg: RefineConfig with fixed thresholds (refine_device), None = the per-refinement quantile of rounds 1-3.
     densify_from: GaussianSplattingControlConfig.densify_from_iter -- no refinement (and no statistics reset) up to that step.
     means_lr_final: the reference's exponential decay of the position learning rate (config/MTGS.py:124-129) over `steps`.
@@ -581,6 +596,15 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     dev = next(iter(P.values()))["means"].device
     if graph and (world > 1 or accumulate > 1 or optimizer != "fused" or LAZY["on"]):
         raise ValueError("graph training: one process, one camera per step, the fused optimizer, no --lazy-adam")
+
+    if one_graph:
+        if not (graph and VISFIRST["on"] and ROWLAZY["on"]) or any("instance_quats" in p for p in P.values()):
+            raise ValueError("one_graph: graph training with --visfirst --row-lazy and static nodes")
+        t_dev = torch.zeros((), dtype=torch.int32, device=dev)
+        cam_all = [torch.stack([cm[j] for cm in cams]).contiguous() for j in range(3)]          # viewmats, Ks, camera_to_worlds
+        gt_all = torch.stack(list(targets)).contiguous()
+        shipped_all = None if shipped is None else dict(shipped, gt_depth=torch.stack(list(shipped["gt_depth"])).contiguous(),
+                                                        gt_normal=torch.stack(list(shipped["gt_normal"])).contiguous())
 
     def make_opt():
         return make_optimizer(optimizer, P, shipped)
@@ -637,7 +661,11 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
 
     def body(c):
         opt.zero_grad(set_to_none=True)
-        loss = iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped)
+        if c is ANY:       # the traversal of the device word: everything that depends on it is gathered on the device
+            cam = tuple(at(x, t_dev) for x in cam_all) + (t_dev,)
+            loss = iteration(P, cam, at(gt_all, t_dev), mask, True, stats, win, W, H, shipped=shipped_all)
+        else:
+            loss = iteration(P, cams[c], targets[c], mask, True, stats, win, W, H, shipped=shipped)
         if VISFIRST["cs"] is not None:
             VISFIRST["cs"].apply_to(opt)
         opt.step()
@@ -662,6 +690,9 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             if eager_left <= 0:
                 caps = plan_caps()
             return loss
+        if one_graph:          # one graph for every traversal: the traversal goes in through the device word
+            t_dev.fill_(c)
+            c = ANY
         if c not in graphs:
             tick("other")
             gm = mtgs_amd.graph_mode(*caps)
@@ -871,6 +902,8 @@ def main():
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     ap.add_argument("--train-graph", action="store_true", help="with --steps: TRAIN through HIP graphs (one per traversal, re-captured "
                     "after every refinement, overflow polled without a host wait; train_loop(graph=True))")
+    ap.add_argument("--one-graph", action="store_true", help="with --train-graph --visfirst --row-lazy: the traversal is a DEVICE word, "
+                    "one graph per stretch serves every traversal (train_loop(one_graph=True))")
     ap.add_argument("--converge", action="store_true", help="with --steps: the training problem with something to learn and the "
                     "reference's refinement rules -- the model starts from a SUBSET of the true Gaussians with perturbed positions, "
                     "shapes, opacities and colours; fixed thresholds of config/MTGS.py:59-71 (screen-space gradient threshold scaled once, "
@@ -1126,7 +1159,7 @@ def main():
         curve, sizes = train_loop(P, cams, targets, mask, win, W, H, args.steps, args.refine_every, shipped=shipped, world=world,
                                   rank=rank, accumulate=args.accumulate, log=log, sparse=args.dp_exchange == "sparse",
                                   optimizer=args.optimizer if args.optimizer in ("torch", "fused") else "fused",
-                                  graph=args.train_graph, refine_cfg=refine_cfg, poll_every=args.poll_every,
+                                  graph=args.train_graph, one_graph=args.one_graph, refine_cfg=refine_cfg, poll_every=args.poll_every,
                                   means_lr_final=8e-6 if args.converge else None,
                                   steady=tuple(args.steady) if args.steady else None, first_cap_scale=args.first_cap_scale,
                                   densify_from=(5 * args.refine_every if args.converge else 0) if args.densify_from is None else args.densify_from)

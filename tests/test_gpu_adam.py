@@ -506,6 +506,79 @@ def test_row_lazy_adam_in_a_hip_graph(hip_lib):
         assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
 
 
+def test_row_lazy_one_graph_for_every_traversal_through_a_device_slice(hip_lib):
+    """The slice of a per-traversal tensor as an int32 DEVICE word (mtgs_adam_group.sub_index_dev): peek_rows + step captured
+    ONCE serve every traversal -- the word is rewritten in front of each replay.  Bit-identical (after flush) to the eager
+    optimizer that steps every row with the host slice index; the peeked rows are the every-row optimizer's parameters."""
+    dev = torch.device("cuda")
+    N, T = 3001, 3
+    g = torch.Generator().manual_seed(23)
+    base, make = _row_lazy_case(dev, N, T, g)
+    Pa, oa = make(False)
+    Pb, ob = make(True)
+    frames = [_frame(N, g, dev, frac=0.25) for _ in range(12)]
+    cap = max(f[2].shape[0] for f in frames)
+    row_of_s = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    rows_s = torch.zeros(cap, 48, device=dev)
+    gm_s = torch.zeros(N, 3, device=dev)
+    Pb["means"].grad = gm_s
+    t_dev = torch.zeros((), dtype=torch.int32, device=dev)
+    C = torch.zeros(cap, 56, device=dev)
+
+    def load(i, t):
+        vis, row_of, rows = frames[i]
+        row_of_s.copy_(row_of)
+        rows_s.zero_()
+        rows_s[:rows.shape[0]].copy_(rows)
+        gm_s.copy_(torch.full((N, 3), 0.01 * (i + 1), device=dev))
+        t_dev.fill_(t)
+
+    def body_dev():
+        ob.peek_rows([(Pb["dc"], row_of_s, None, 0), (Pb["adapters"], row_of_s, t_dev, 3), (Pb["rest"], row_of_s, t_dev, 6)], C)
+        ob.set_row_gradient(Pb["dc"], rows_s, row_of_s, 0, caught=(C, 0))
+        ob.set_row_gradient(Pb["adapters"], rows_s, row_of_s, 0, slice_index=t_dev, caught=(C, 3))
+        ob.set_row_gradient(Pb["rest"], rows_s, row_of_s, 3, slice_index=t_dev, caught=(C, 6))
+        ob.step()
+
+    def ref(i, t):
+        vis, row_of, rows = frames[i]
+        Pa["means"].grad = torch.full((N, 3), 0.01 * (i + 1), device=dev)
+        oa.set_row_gradient(Pa["dc"], rows, row_of, 0)
+        oa.set_row_gradient(Pa["adapters"], rows, row_of, 0, slice_index=t)
+        oa.set_row_gradient(Pa["rest"], rows, row_of, 3, slice_index=t)
+        oa.step()
+
+    import mtgs_amd
+    seq = [0, 1, 2, 2, 0, 1, 1, 1, 2, 0, 2, 0]
+    gm = mtgs_amd.graph_mode(1, 1)
+    for i in range(2):                        # eager steps with the device word: state and device scalars exist from here on
+        load(i, seq[i])
+        ref(i, seq[i])
+        with gm:
+            body_dev()
+    gr = torch.cuda.CUDAGraph()
+    with gm, torch.cuda.graph(gr):
+        body_dev()
+    for i in range(2, len(seq)):
+        t = seq[i]
+        vis, row_of, rows = frames[i]
+        load(i, t)
+        ob.advance()
+        gr.replay()
+        r = row_of[vis].long()
+        assert torch.equal(C[r, 3:6], Pa["adapters"][vis, t]) and torch.equal(C[r, 6:51], Pa["rest"][vis, t].reshape(-1, 45)), i
+        ref(i, t)
+        assert torch.equal(Pa["rest"][vis, t], Pb["rest"][vis, t]), i
+    ob.flush()
+    torch.cuda.synchronize()
+    for k in base:
+        assert torch.equal(Pa[k], Pb[k]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
+    with pytest.raises(ValueError):
+        ob.set_row_gradient(Pb["rest"], rows_s, row_of_s, 3, slice_index=torch.zeros((), dtype=torch.int64, device=dev))
+
+
 def test_row_lazy_adam_long_gaps_settle_without_changing_a_bit(hip_lib):
     """Rows unseen for thousands of steps: exp_avg reaches a fixed point of the zero-gradient recurrence and the catch-up
     switches to its one-multiplication step (csrc/adam.hip) -- the result must still be bit-identical to stepping every row

@@ -387,6 +387,21 @@ def test_mtgs_like_training_through_graphs_equals_eager_and_converges():
                    "loss_first_tenth": float(conv.group(1)), "loss_last_tenth": float(conv.group(2)), "graph_counts": counts})
 
 
+def test_one_graph_per_stretch_with_the_traversal_on_the_device_equals_eager():
+    """train_loop(one_graph=True): the traversal is an int32 device word -- camera, targets and exposure row are gathered on the
+    device, the optimizer's peek / step take the slice from the word -- so ONE graph per stretch serves all three traversals
+    (3 captures for 3 stretches instead of 9).  Same training as the eager loop."""
+    import json
+    import re
+    from tests.util import assert_same_training
+    common = ["--n-background", "400000", "--n-road", "100000", "--steps", "400", "--refine-every", "50", "--densify-from", "250"] + _CONVERGE
+    eager = _run_train(common)
+    graph = _run_train(common + ["--train-graph", "--one-graph"])
+    assert_same_training(graph, eager, 2, 400, 50, later_sizes=1e-3)
+    counts = json.loads(re.search(r'graph (\{.*\})', graph).group(1))
+    assert counts["overflows"] == 0 and counts["warmups"] == 1 and counts["captures"] == 3 and counts["replays"] == 400 - 3 - 1, counts
+
+
 def test_graph_training_notices_a_capacity_overflow_and_recaptures():
     """The first graphs get capacities that are too small (--first-cap-scale 0.3): their frames are truncated, the OR of the
     frames' overflow flags reaches the host through the polled pinned copy, the loop drops the graphs, renders every traversal
