@@ -46,7 +46,7 @@ DOMINANT = ("mtgs_blend_bwd_packed", "mtgs_blend_bwd")   # the compositing backw
 ENTRY_POINTS = {
     "mtgs_sh_fwd": ["sh_fwd_k16_kernel<3>"],
     "mtgs_front_fwd": ["front_project_kernel", "front_compact_kernel"],
-    "mtgs_bin3_build": ["bin3_rows_count_kernel", "bin3_rows_place_kernel", "bin3_tiles_count_kernel", "bin3_tiles_place_kernel",
+    "mtgs_bin3_build": ["bin3_rows_count_kernel<true>", "bin3_rows_place_kernel<true>", "bin3_tiles_count_kernel", "bin3_tiles_place_kernel",
                         "bin3_sort_small_kernel", "bin3_sort_large_kernel", "zero"],
     "mtgs_blend_fwd_packed": ["blend_fwd_kernel<4, 4, true>"],
     "mtgs_blend_bwd_packed": ["blend_bwd_kernel<4, 4, true>"],
@@ -486,7 +486,10 @@ def main():
     _th = -(-args.height // 16)
     _rows = (torch.ceil((_y + _r) / 16).clamp(0, _th) - torch.floor((_y - _r) / 16).clamp(0, _th))[_r > 0]
     n_items = int(_rows.sum().item())
-    M = int(info["flatten_ids"].numel())
+    M = int(info["flatten_ids"].numel())       # gsplat's intersection count (3-sigma squares): SURVEY.md section 8(d)'s unit
+    # the (tile, Gaussian) pairs the tile lists hold (tight lists, include/mtgs_rast.h mtgs_bin3_build): what the sort and the
+    # compositing kernels actually gather -- their algorithmic bytes below are priced on THIS count, not on gsplat's
+    M_l = int(info["n_listed"]) if info.get("n_listed") is not None else M
     P = args.width * args.height
     ms_per_step = elapsed / args.steps * 1e3
     value = world * P / (elapsed / args.steps) / 1e6
@@ -494,7 +497,7 @@ def main():
     # algorithmic HBM bytes of one compositing-backward launch
     D = 4 if args.variant == "mtgs" else 3
     A = 1 if args.variant == "mtgs" else 0
-    bytes_bwd = P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A)
+    bytes_bwd = P * (4 * D + 12) + M_l * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A)
     # whole-step algorithmic HBM bytes, SURVEY.md section 8(d): B_F + B_B (K = 16 SH bases when the step includes SH)
     N, T = args.n_gaussians, -(-args.width // 16) * -(-args.height // 16)
     Ksh = 16 if args.variant == "mtgs" else 0
@@ -514,12 +517,12 @@ def main():
         "front_compact_kernel": N * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
         "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
         "project_bwd_expand_kernel": N * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
-        "bin3_rows_count_kernel": n_vis * 64,
-        "bin3_rows_place_kernel": n_vis * 64 + n_items * 8,
+        "bin3_rows_count_kernel<true>": n_vis * 64,
+        "bin3_rows_place_kernel<true>": n_vis * 64 + n_items * 8,
         "bin3_tiles_count_kernel": n_items * 8,
-        "bin3_tiles_place_kernel": n_items * (8 + 4) + M * 8,
-        "bin3_sort_small_kernel": M * (8 + 4 + 4 + 4 + 8),
-        "blend_fwd_kernel<4, 4, true>": M * (4 + 64) + P * (4 * D + 8),
+        "bin3_tiles_place_kernel": n_items * (8 + 4) + M_l * 8,
+        "bin3_sort_small_kernel": M_l * (8 + 4 + 4 + 4 + 8),
+        "blend_fwd_kernel<4, 4, true>": M_l * (4 + 64) + P * (4 * D + 8),
         "blend_bwd_kernel<4, 4, true>": bytes_bwd,
     }
     # (1) measured in THIS run: HIP events around every C-ABI entry point of the step (second, untimed pass)
@@ -572,7 +575,7 @@ def main():
                         + (" (SH deg 3 K=16 -> RGB+ED, antialiased, absgrad, viewmat grad)" if args.variant == "mtgs"
                            else " (colours given, RGB, classic)"),
             "n_gaussians": args.n_gaussians, "width": args.width, "height": args.height,
-            "n_visible": n_vis, "n_intersections": M,
+            "n_visible": n_vis, "n_intersections": M, "n_listed": M_l,
             "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange, "
                            f"{info_box['grad_bytes']} bytes received per rank per step",
         },

@@ -299,6 +299,13 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  * isect_tiles(sort=True) + isect_offset_encode.  Sizes come from `totals` on the device, clamped to (cap_vis, cap_M):
  * the caller sizes buffers and this call sizes grids for the capacities; if the true totals exceed them the outputs are
  * truncated (never out of bounds) and the caller repeats with larger ones.  Seven launches.
+ * tight (ABI v24) != 0: TIGHT lists -- a (tile, Gaussian) pair of gsplat's 3-sigma square is listed only if the Gaussian's
+ * {alpha >= 1/255} ellipse reaches a pixel centre of the tile (the exact ellipse / rectangle test, with a margin, that
+ * mtgs_blend_*_packed apply when they stage a tile's candidates: 32 % of gsplat's pairs at the headline workload).  The
+ * lists are sublists of gsplat's in the same order; every pair left out would be skipped pixel by pixel (gsplat's
+ * `alpha < 1/255: continue`), so render, alphas and all gradients are those of the full lists, but the pair is never counted,
+ * placed, sorted or gathered.  offsets[last] = the number of pairs listed (<= M of `totals`); tiles_per_gauss of
+ * mtgs_front_fwd and M stay gsplat's.  tight = 0: gsplat's lists, bit-identical.
  * Supported when mtgs_bin3_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 32768 (3840x2160 has 32400 tiles), C*tile_h <= 4096, tile_w <= 4096,
  * cap_M < 2^30), else use mtgs_bin_build.  ws: mtgs_bin3_workspace_bytes, 256-byte aligned.
  *
@@ -323,7 +330,7 @@ int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, in
 int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
                     int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                     const int64_t *vis_keys, int32_t *rank_ids, int32_t *flatten_ids, int64_t *isect_ids,
-                    int32_t *offsets, int32_t *tile_order, void *ws, size_t ws_bytes, void *stream);
+                    int32_t *offsets, int32_t *tile_order, int tight, void *ws, size_t ws_bytes, void *stream);
 int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,

@@ -53,18 +53,61 @@ struct Item { uint32_t rank, span; };
 constexpr int SPAN_BITS = 12;   // row widths up to 2^12 tiles, tile ids below 2^20 (MAX_BINS)
 constexpr int MAX_ROWS = 4096;  // (camera, tile row) bins of the row kernels' LDS histogram (60 cameras at 1080p)
 
-struct RowGeom { int row0, h, tile0, w; };   // first (camera, row) bin, rows, first tile id of the first row, tiles per row
+struct RowGeom {
+    int row0, h, tile0, w;   // first (camera, row) bin, rows, first tile id of the first row, tiles per row
+    int y0, x0;              // first tile row / column inside the camera's grid
+    float mx, my, ca, cb, cc, s2max;   // TIGHT lists: the {alpha >= 1/255} ellipse of the Gaussian (raster_rec.hpp)
+};
+template <bool TIGHT>
 __device__ __forceinline__ RowGeom row_geom(const float *__restrict__ recs, const int32_t *__restrict__ vis_ids, int64_t rank,
                                             int64_t N, int C, float ts, int tw, int th) {
-    const float *rec = recs + rank * REC_FLOATS;
-    const float2 m = *reinterpret_cast<const float2 *>(rec);
-    const Rect q = tile_rect(m.x, m.y, __float_as_int(rec[7]), ts, tw, th);
+    const float4 *rec = reinterpret_cast<const float4 *>(recs + rank * REC_FLOATS);
+    const float4 r0 = rec[0], r1 = rec[1];
+    const Rect q = tile_rect(r0.x, r0.y, __float_as_int(r1.w), ts, tw, th);
     const int cam = C == 1 ? 0 : (int)((uint32_t)vis_ids[rank] / (uint32_t)N);
     RowGeom g;
     g.row0 = cam * th + q.y0; g.h = q.y1 - q.y0; g.w = q.x1 - q.x0;
     g.tile0 = g.row0 * tw + q.x0;
+    g.y0 = q.y0; g.x0 = q.x0;
+    g.mx = r0.x; g.my = r0.y; g.ca = r0.z; g.cb = r0.w; g.cc = r1.x; g.s2max = r1.z;
     if (g.w <= 0) g.h = 0;
+    if (TIGHT && !(g.s2max >= 0.f)) g.h = 0;   // opacity < 1/255 (or NaN): no pixel anywhere (the staging of blend.hip drops it too)
     return g;
+}
+// The tiles of row y (0 .. h-1 of the Gaussian's 3-sigma square) that belong to the lists: gsplat's -- all w of them -- or,
+// TIGHT, those whose pixel centres the {alpha >= 1/255} ellipse reaches.  The ellipse is convex, so these are an interval of the
+// row (closed form below, with the margin of the exact test the compositing kernels apply when they stage a tile's candidates,
+// rec_reaches_rect): no pair with a pixel that could pass the per-pixel test is left out, so pixel for pixel nothing changes,
+// but the other pairs are never counted, placed, sorted or gathered.
+// first = tile id, returns the number of tiles (<= 0: none).
+template <bool TIGHT>
+__device__ __forceinline__ int row_span(const RowGeom &g, int y, int tw, int &first) {
+    first = g.tile0 + y * tw;
+    if (!TIGHT) return g.w;
+    const float a = g.ca, b = g.cb, c = g.cc, det = a * c - b * b;
+    if (!(det > 0.f && a > 0.f && c > 0.f)) return g.w;          // (rec_reaches_rect keeps every tile of such a conic)
+    const float ty = (float)((g.y0 + y) * MTGS_TILE_SIZE);
+    const float Y0 = ty + 0.5f - g.my, Y1 = ty + 15.5f - g.my;   // the band of this row's pixel centres, relative to the mean
+    // The x-extent of {q <= s} inside the band, in closed form.  For a fixed dy the ellipse is dx in (-b dy -+ sqrt(a s - det dy^2)) / a;
+    // the left end is convex in dy with its minimum at dy = b X / c (the ellipse's leftmost point, X = sqrt(s c / det)), so over
+    // the band it is attained at that dy clamped into the band (and into the ellipse's own y range); the right end mirrors it.
+    const float sm = g.s2max * 1.001f + 1e-2f;                    // (the margin of rec_reaches_rect)
+    const float rdet = 1.0f / det, ymax = sqrtf(a * sm * rdet), X = sqrtf(sm * c * rdet);
+    const float yb0 = fmaxf(Y0, -ymax), yb1 = fminf(Y1, ymax);
+    if (!(yb0 <= yb1)) return 0;
+    const float ra = 1.0f / a, tilt = b * X / c;
+    const float dyl = fminf(fmaxf(tilt, yb0), yb1), dyr = fminf(fmaxf(-tilt, yb0), yb1);
+    const float xl = (-b * dyl - sqrtf(fmaxf(a * sm - det * dyl * dyl, 0.f))) * ra - 2e-3f;
+    const float xr = (-b * dyr + sqrtf(fmaxf(a * sm - det * dyr * dyr, 0.f))) * ra + 2e-3f;
+    // tile column t holds the centres 16 t + 0.5 .. 16 t + 15.5: it meets [mx + xl, mx + xr] iff
+    //   t >= (mx + xl - 15.5) / 16  and  t <= (mx + xr - 0.5) / 16
+    const float inv = 1.0f / (float)MTGS_TILE_SIZE;
+    const int lo = (int)fmaxf(ceilf((g.mx + xl - 15.5f) * inv), (float)g.x0) - g.x0;
+    const int hi = (int)fminf(floorf((g.mx + xr - 0.5f) * inv), (float)(g.x0 + g.w - 1)) - g.x0 + 1;
+    // (the closed form errs on the wide side by its margins; any superset of the exact set is fine -- blend.hip's staging
+    //  applies rec_reaches_rect to what is listed)
+    first += lo;
+    return hi - lo;
 }
 
 // Last-block hand-off of the two counting kernels: true in every thread of the workgroup that arrives last among the
@@ -86,7 +129,59 @@ constexpr int R_BLOCK = 1024;
 // lanes of a wave.  (With a low threshold the queue costs more than it saves -- 8: 49 us against 38 us for the tile
 // placement -- because every queued item is re-read from global memory by the wave that expands it.)
 constexpr int SERIAL_MAX = 48;
+
+// TIGHT lists: a row costs ~40 instructions (row_span) instead of one LDS atomic, and a wave would wait for its Gaussian with the
+// most rows (3.6 on average, up to SERIAL_MAX): the rows of a workgroup's 1024 Gaussians are numbered by a prefix sum and shared
+// out evenly over its threads -- thread i takes rows i, i + 1024, ... and finds the owner by bisection in LDS.
+struct RowShare {
+    float mx[R_BLOCK], my[R_BLOCK], ca[R_BLOCK], cb[R_BLOCK], cc[R_BLOCK], s2[R_BLOCK];
+    uint32_t xy[R_BLOCK];        // x0 | y0 << 16: first tile column / row inside the camera's grid
+    uint32_t wr[R_BLOCK];        // (w - 1) | row0 << 16: tiles per row of the 3-sigma square, first (camera, row) bin
+    uint32_t off[R_BLOCK + 1];   // exclusive prefix sum of the row counts
+    uint32_t ws[R_BLOCK / 64];
+};
+// emit(owner thread, (camera, row) bin, first tile id, number of tiles > 0); h = this thread's rows (0: none, or shared elsewhere)
+template <class F>
+__device__ __forceinline__ void tight_rows_walk(RowShare &S, const RowGeom &g, int h, int tw, F &&emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    S.mx[tid] = g.mx; S.my[tid] = g.my; S.ca[tid] = g.ca; S.cb[tid] = g.cb; S.cc[tid] = g.cc; S.s2[tid] = g.s2max;
+    S.xy[tid] = (uint32_t)g.x0 | ((uint32_t)g.y0 << 16);
+    S.wr[tid] = (uint32_t)max(g.w - 1, 0) | ((uint32_t)g.row0 << 16);
+    uint32_t inc = (uint32_t)h;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) S.ws[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += S.ws[w];
+    S.off[tid] = base + inc - (uint32_t)h;
+    if (tid == R_BLOCK - 1) S.off[R_BLOCK] = base + inc;
+    __syncthreads();
+    const uint32_t total = S.off[R_BLOCK];
+    static_assert(R_BLOCK == 1 << 10, "ten bisection steps");
+    for (uint32_t idx = tid; idx < total; idx += R_BLOCK) {
+        int lo = 0, hi = R_BLOCK;    // the last owner whose offset is <= idx (owners without rows share their successor's offset)
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            const int mid = (lo + hi) >> 1;
+            if (S.off[mid] <= idx) lo = mid; else hi = mid;
+        }
+        const int y = (int)(idx - S.off[lo]);
+        RowGeom q;
+        q.mx = S.mx[lo]; q.my = S.my[lo]; q.ca = S.ca[lo]; q.cb = S.cb[lo]; q.cc = S.cc[lo]; q.s2max = S.s2[lo];
+        const uint32_t xy = S.xy[lo], wr = S.wr[lo];
+        q.x0 = (int)(xy & 0xffffu); q.y0 = (int)(xy >> 16); q.w = (int)(wr & 0xffffu) + 1; q.row0 = (int)(wr >> 16);
+        q.tile0 = q.row0 * tw + q.x0; q.h = 0;
+        int first;
+        const int w = row_span<true>(q, y, tw, first);
+        if (w > 0) emit(lo, q.row0 + y, first, w);
+    }
+}
 // counts per (workgroup, row); every pair gets its base inside the row's segment from ONE returning atomic
+template <bool TIGHT>
 __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef n_vis_ref, const float *__restrict__ recs,
                                                                  const int32_t *__restrict__ vis_ids, int64_t N, int C, float ts,
                                                                  int tw, int th, int n_rows, uint32_t *__restrict__ row_count,
@@ -108,18 +203,28 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef 
     for (int b = tid; b < n_rows; b += R_BLOCK) s_row[b] = 0;
     if (tid == 0) s_ntall = 0;
     __syncthreads();
+    RowGeom g = {};
+    int my_rows = 0;   // rows this thread's Gaussian contributes to the shared walk
     if (r < n_vis) {
-        const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
+        g = row_geom<TIGHT>(recs, vis_ids, r, N, C, ts, tw, th);
         if (g.h <= SERIAL_MAX) {
-            for (int y = 0; y < g.h; ++y) atomicAdd(&s_row[g.row0 + y], 1u);
+            my_rows = g.h;
+            if (!TIGHT)
+                for (int y = 0; y < g.h; ++y) atomicAdd(&s_row[g.row0 + y], 1u);
         } else {
             s_tall[atomicAdd(&s_ntall, 1u)] = (uint16_t)tid;   // a wave shares its rows (below)
         }
     }
+    if constexpr (TIGHT) {
+        __shared__ RowShare s_share;
+        tight_rows_walk(s_share, g, my_rows, tw, [&](int, int bin, int, int) { atomicAdd(&s_row[bin], 1u); });
+    }
     __syncthreads();
     for (uint32_t q = wave; q < s_ntall; q += R_BLOCK / 64) {
-        const RowGeom g = row_geom(recs, vis_ids, (int64_t)blockIdx.x * R_BLOCK + s_tall[q], N, C, ts, tw, th);
-        for (int y = lane; y < g.h; y += 64) atomicAdd(&s_row[g.row0 + y], 1u);
+        const RowGeom g = row_geom<TIGHT>(recs, vis_ids, (int64_t)blockIdx.x * R_BLOCK + s_tall[q], N, C, ts, tw, th);
+        int first;
+        for (int y = lane; y < g.h; y += 64)
+            if (row_span<TIGHT>(g, y, tw, first) > 0) atomicAdd(&s_row[g.row0 + y], 1u);
     }
     __syncthreads();
     for (int b = tid; b < n_rows; b += R_BLOCK) {
@@ -156,6 +261,7 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_count_kernel(const SizeRef 
     }
 }
 
+template <bool TIGHT>
 __global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef n_vis_ref, const float *__restrict__ recs,
                                                                  const int32_t *__restrict__ vis_ids, int64_t N, int C, float ts,
                                                                  int tw, int th, int n_rows, const uint32_t *__restrict__ row_start,
@@ -172,24 +278,39 @@ __global__ __launch_bounds__(R_BLOCK) void bin3_rows_place_kernel(const SizeRef 
     if (tid == 0) s_ntall = 0;
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * R_BLOCK + tid;
+    RowGeom g = {};
+    int my_rows = 0;
     if (r < n_vis) {
-        const RowGeom g = row_geom(recs, vis_ids, r, N, C, ts, tw, th);
+        g = row_geom<TIGHT>(recs, vis_ids, r, N, C, ts, tw, th);
         if (g.h <= SERIAL_MAX) {
-            for (int y = 0; y < g.h; ++y) {
-                const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
-                if (pos < cap_items) items[pos] = Item{(uint32_t)r, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
-            }
+            my_rows = g.h;
+            if (!TIGHT)
+                for (int y = 0; y < g.h; ++y) {
+                    const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
+                    if (pos < cap_items) items[pos] = Item{(uint32_t)r, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
+                }
         } else {
             s_tall[atomicAdd(&s_ntall, 1u)] = (uint16_t)tid;
         }
     }
+    if constexpr (TIGHT) {
+        __shared__ RowShare s_share;
+        const int64_t r0 = (int64_t)blockIdx.x * R_BLOCK;
+        tight_rows_walk(s_share, g, my_rows, tw, [&](int owner, int bin, int first, int w) {
+            const int64_t pos = atomicAdd(&s_row[bin], 1u);
+            if (pos < cap_items) items[pos] = Item{(uint32_t)(r0 + owner), ((uint32_t)first << SPAN_BITS) | (uint32_t)(w - 1)};
+        });
+    }
     __syncthreads();
     for (uint32_t q = wave; q < s_ntall; q += R_BLOCK / 64) {
         const int64_t rq = (int64_t)blockIdx.x * R_BLOCK + s_tall[q];
-        const RowGeom g = row_geom(recs, vis_ids, rq, N, C, ts, tw, th);
+        const RowGeom g = row_geom<TIGHT>(recs, vis_ids, rq, N, C, ts, tw, th);
         for (int y = lane; y < g.h; y += 64) {
+            int first;
+            const int w = row_span<TIGHT>(g, y, tw, first);
+            if (w <= 0) continue;
             const int64_t pos = atomicAdd(&s_row[g.row0 + y], 1u);
-            if (pos < cap_items) items[pos] = Item{(uint32_t)rq, ((uint32_t)(g.tile0 + y * tw) << SPAN_BITS) | (uint32_t)(g.w - 1)};
+            if (pos < cap_items) items[pos] = Item{(uint32_t)rq, ((uint32_t)first << SPAN_BITS) | (uint32_t)(w - 1)};
         }
     }
 }
@@ -756,7 +877,7 @@ extern "C" int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t 
 extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
                                int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                                const int64_t *vis_keys, int32_t *rank_ids,
-                               int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order,
+                               int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, int tight,
                                void *ws, size_t ws_bytes, void *stream) {
     MTGS_REQUIRE(C > 0 && N >= 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0, MTGS_EINVAL, "mtgs_bin3_build: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_bin3_build: tile_size=%d (only 16 is implemented)", tile_size);
@@ -776,10 +897,17 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
     const unsigned r_grid = (unsigned)ceil_div64(cap_vis > 0 ? cap_vis : 1, R_BLOCK);
     const unsigned t_grid = (unsigned)min((int64_t)512, ceil_div64(cap_M > 0 ? cap_M : 1, T_TILE));
     const float ts = (float)tile_size;
-    bin3_rows_count_kernel<<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_count,
-                                                      w.rbase, w.done_rows, w.row_start);
-    bin3_rows_place_kernel<<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_start,
-                                                      w.rbase, cap_M, w.items);
+    if (tight) {
+        bin3_rows_count_kernel<true><<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_count,
+                                                                w.rbase, w.done_rows, w.row_start);
+        bin3_rows_place_kernel<true><<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_start,
+                                                                w.rbase, cap_M, w.items);
+    } else {
+        bin3_rows_count_kernel<false><<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_count,
+                                                                 w.rbase, w.done_rows, w.row_start);
+        bin3_rows_place_kernel<false><<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_start,
+                                                                 w.rbase, cap_M, w.items);
+    }
     bin3_tiles_count_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
                                                                             cap_M, w.bins, w.done_tiles, offsets, order, w.n_long);
     bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,

@@ -128,29 +128,9 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
             // opacity < 1/255 (or NaN): alpha >= 1/255 is unreachable.  Dropped here unconditionally -- the
             // per-pixel range test compares bit patterns and relies on s2max >= 0.
             keep = s2max >= 0.f;
-            if (CULL && keep) {
-                // Exact test: does the ellipse {q(d) = a dx^2 + 2 b dx dy + c dy^2 <= s2max} reach the rectangle
-                // of this tile's pixel centres?  q is convex, so its minimum over the rectangle is 0 if the mean
-                // lies inside, otherwise it is attained on one of the four edges (a clamped 1-D parabola each).
-                const float det = ca * cc - cb * cb;
-                if (det > 0.f && ca > 0.f && cc > 0.f) {
-                    const float X0 = tile_x0 + 0.5f - xy.x, X1 = tile_x0 + 15.5f - xy.x;
-                    const float Y0 = tile_y0 + 0.5f - xy.y, Y1 = tile_y0 + 15.5f - xy.y;
-                    const bool inside = X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f;
-                    const float rcc = __builtin_amdgcn_rcpf(cc), rca = __builtin_amdgcn_rcpf(ca);
-                    auto edge_x = [&](float xe) {  // vertical edge x = xe
-                        const float dy = fminf(fmaxf(-cb * xe * rcc, Y0), Y1);
-                        return ca * xe * xe + 2.f * cb * xe * dy + cc * dy * dy;
-                    };
-                    auto edge_y = [&](float ye) {  // horizontal edge y = ye
-                        const float dx = fminf(fmaxf(-cb * ye * rca, X0), X1);
-                        return ca * dx * dx + 2.f * cb * dx * ye + cc * ye * ye;
-                    };
-                    const float qmin = inside ? 0.f : fminf(fminf(edge_x(X0), edge_x(X1)), fminf(edge_y(Y0), edge_y(Y1)));
-                    // margin: never drop a candidate the per-pixel test (s2 <= s2max) could still accept
-                    keep = qmin <= s2max * 1.001f + 1e-2f;
-                }
-            }
+            if (CULL && keep)   // the exact ellipse / rectangle test (raster_rec.hpp)
+                keep = rec_reaches_rect(ca, cb, cc, s2max, tile_x0 + 0.5f - xy.x, tile_x0 + 15.5f - xy.x, tile_y0 + 0.5f - xy.y,
+                                        tile_y0 + 15.5f - xy.y);
         }
         clamp_any |= __ballot(keep && op > kNoClampOpacity);
         int slot = k;

@@ -127,7 +127,7 @@ def rasterization(
                      "tile_height": math.ceil(height / 16.0), "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
                      "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width, "height": height,
                      "tile_size": tile_size, "n_cameras": C})
-        for k in ("n_visible", "n_intersections", "overflow"):
+        for k in ("n_visible", "n_intersections", "overflow", "n_listed"):
             if k in m:
                 meta[k] = m[k]
         return render_colors, render_alphas, meta
@@ -167,7 +167,7 @@ def rasterization(
                          "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
                          "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width,
                          "height": height, "tile_size": tile_size, "n_cameras": C})
-            for k in ("n_visible", "n_intersections", "overflow"):   # only inside mtgs_amd.graph_mode
+            for k in ("n_visible", "n_intersections", "overflow", "n_listed"):   # only inside mtgs_amd.graph_mode
                 if k in m:
                     meta[k] = m[k]
             return render_colors, render_alphas, meta
@@ -189,6 +189,9 @@ def rasterization(
                      "tile_height": tile_height, "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
                      "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width, "height": height,
                      "tile_size": tile_size, "n_cameras": C})
+        for k in ("n_visible", "n_intersections", "overflow", "n_listed"):
+            if k in m:
+                meta[k] = m[k]
         return render_colors, render_alphas, meta
 
     # (1) projection, fused with `opacities.repeat(C, 1) [* compensations]`

@@ -12,6 +12,7 @@ a HIP kernel launched through the C ABI (include/mtgs_rast.h).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import time
 from typing import Optional, Tuple
@@ -411,6 +412,10 @@ class _RasterizeToPixels(torch.autograd.Function):
 # ------------------------------------------------------------------------------------- fused path
 RECORD_CHANNELS = 8      # blended channels a packed record holds (csrc/raster_rec.hpp)
 speculative_sizing = True  # enqueue binning + compositing before the host knows (n_vis, M); see _SizePlan
+tight_lists = os.environ.get("MTGS_EXACT_LISTS", "0") != "1"   # rasterization(): the tile lists hold only the (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse reaches a
+#                            pixel centre of the tile (mtgs_bin3_build(tight=1)): render / alphas / gradients are unchanged, the meta
+#                            tensors isect_ids / flatten_ids / isect_offsets are ORDERED SUBLISTS of gsplat's (valid length =
+#                            isect_offsets-derived, info["n_listed"]); False (or exact_lists()): gsplat's lists, bit-identical
 _force_caps = None       # tests: (cap_vis, cap_M) used for the speculative attempt, to exercise the overflow path
 _debug_rows = None       # tests: a dict that the fused backward fills with its compact gradient rows {"G", "vis_ids", "DC"}
 
@@ -443,6 +448,25 @@ class _SizePlan(threading.local):
 
 
 _size_plan = _SizePlan()
+
+
+class exact_lists:
+    """`with mtgs_amd.exact_lists(): ...` -- rasterization() builds gsplat's tile lists (every tile of the 3-sigma square of
+    every visible Gaussian: isect_ids / flatten_ids / isect_offsets bit-identical to gsplat 1.4.0 isect_tiles +
+    isect_offset_encode) instead of the tight ones (module switch `wrapper.tight_lists`)."""
+
+    def __init__(self, on: bool = True):
+        self.on, self.prev = bool(on), None
+
+    def __enter__(self):
+        global tight_lists
+        self.prev, tight_lists = tight_lists, not self.on
+        return self
+
+    def __exit__(self, *exc):
+        global tight_lists
+        tight_lists = self.prev
+        return False
 
 
 class _GraphState:
@@ -636,7 +660,8 @@ class _FusedRasterization(torch.autograd.Function):
                 off = (-ws.data_ptr()) % 256
                 call("mtgs_bin3_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
                      ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
-                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), ws.data_ptr() + off,
+                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), int(bool(tight_lists)),
+                     ws.data_ptr() + off,
                      nbytes.value, st)
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
                      ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), st)
@@ -675,6 +700,7 @@ class _FusedRasterization(torch.autograd.Function):
             rank_ids, flatten_ids, isect_ids = out["rank_ids"][:M], out["flatten_ids"][:M], out["isect_ids"][:M]
             offsets = offsets_buf[:Cn * th * tw].view(Cn, th, tw)
             offsets._mtgs_tile_order = order
+            offsets._mtgs_n_listed = offsets_buf[Cn * th * tw]     # (device scalar: the number of pairs in the lists)
             isect_ids._mtgs_offsets = offsets
         if not packed:
             totals = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -874,6 +900,8 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
     meta = {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
             "compensations": comps if calc_compensations else None, "opacities": opac_eff,
             "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": offsets}
+    if getattr(offsets, "_mtgs_n_listed", None) is not None:
+        meta["n_listed"] = offsets._mtgs_n_listed    # int32 device scalar: valid prefix of isect_ids / flatten_ids (tight lists)
     if _graph.caps is not None:   # graph mode: the counts live on the device (see graph_mode)
         n_v, n_m = totals[0] >> 32, totals[0] & 0xFFFFFFFF
         meta.update({"n_visible": n_v, "n_intersections": n_m,

@@ -36,6 +36,14 @@ def hip_lib():
     return _lib.load()
 
 
+@pytest.fixture(params=["tight", "gsplat"])
+def lists_mode(request):
+    """Both forms of the fused path's tile lists: the tight ones (default) and gsplat's own (mtgs_amd.exact_lists())."""
+    import mtgs_amd
+    with mtgs_amd.exact_lists(request.param == "gsplat"):
+        yield request.param
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Parity report: the measured errors of every image / gradient comparison of this session (tests/util.py REPORT)."""
     try:

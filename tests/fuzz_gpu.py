@@ -19,6 +19,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mtgs_amd import rasterization, wrapper  # noqa: E402
+from tests.util import assert_tile_lists  # noqa: E402
 from mtgs_amd.densify import update_statistics  # noqa: E402
 from mtgs_amd.loss import masked_l1, masked_ssim  # noqa: E402
 from mtgs_amd.nodes import node_gaussians  # noqa: E402
@@ -73,7 +74,7 @@ def compose(P, vm, K, cfg, bg):
     else:
         r, a = wrapper.rasterize_to_pixels_with_depth(m2d, con, cols, opac, dep, cfg["mode"] == "RGB+ED", W, H, 16, off, flat,
                                                       backgrounds=bg, absgrad=cfg["absgrad"])
-    return r, a, {"means2d": m2d, "radii": radii, "flatten_ids": flat}
+    return r, a, {"means2d": m2d, "radii": radii, "flatten_ids": flat, "isect_ids": ids, "isect_offsets": off}
 
 
 def run_paths(cfg, P0, vm0, K0, Gc, Ga, bg0):
@@ -109,7 +110,8 @@ def check_raster(cfg, with_oracle):
     bg0 = torch.rand(C, D, generator=g) if cfg["bg"] else None
     (r1, a1, i1, g1), (r0, a0, i0, g0) = run_paths(cfg, P0, vm0, K0, Gc, Ga, bg0)
     assert torch.equal(r1, r0) and torch.equal(a1, a0), "forward differs"
-    assert torch.equal(i1["radii"], i0["radii"]) and torch.equal(i1["flatten_ids"], i0["flatten_ids"]), "binning differs"
+    assert torch.equal(i1["radii"], i0["radii"]) and torch.equal(i1["radii"], i0["radii"]), "binning differs"
+    assert_tile_lists(i1, i0)
     noise = None
     for k in g0:
         if g0[k] is None and g1[k] is None:
@@ -137,7 +139,7 @@ def check_raster(cfg, with_oracle):
                                       render_mode=cfg["mode"], rasterize_mode="antialiased" if cfg["aa"] else "classic",
                                       backgrounds=None if bg0 is None else bg0.numpy())
         assert np.array_equal(i1["radii"].cpu().numpy(), m["radii"]), "radii vs oracle"
-        assert np.array_equal(i1["flatten_ids"].cpu().numpy(), m["flatten_ids"]), "flatten_ids vs oracle"
+        assert_tile_lists(i1, m)
         ok = ~m["critical"] if "critical" in m else np.ones(rr.shape[:3], bool)
         d = np.abs(r1.cpu().numpy() - rr).max(-1)
         tol = 1e-4 * max(1.0, float(np.abs(rr).max()))

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import assert_tile_lists, listed
+
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
@@ -78,7 +80,7 @@ def _worker(rank, world, port, out_dir):
         ex2 = mdist.SparseGradExchange(N, K, dev, chunks=chunks)
         r2, a2, info2 = ex2.rasterization(P2["means"], P2["quats"], P2["scales"], P2["opacities"], sh3, vm2, Kmat.to(dev), W, H,
                                           cam_pos)
-        assert torch.equal(r2, render) and torch.equal(a2, alpha) and torch.equal(info2["flatten_ids"], info["flatten_ids"])
+        assert torch.equal(r2, render) and torch.equal(a2, alpha) and torch.equal(listed(info2), listed(info))
         torch.autograd.backward([r2, a2], [Gc, Ga])
         assert all(P2[k].grad is None for k in ("means", "quats", "scales", "opacities")) and vm2.grad is not None
         o3 = ex2.finish(P2["means"], 3)
@@ -103,7 +105,7 @@ def _worker(rank, world, port, out_dir):
                                               cam_pos)
         finally:
             wrapper._force_caps, wrapper.speculative_sizing = old
-        assert n_vis > 500 and torch.equal(r3, render) and torch.equal(info3["flatten_ids"], info["flatten_ids"])
+        assert n_vis > 500 and torch.equal(r3, render) and torch.equal(listed(info3), listed(info))
         torch.autograd.backward([r3, a3], [Gc, Ga])
         o4 = ex3.finish(P2["means"], 3)
         for k, t in zip(("means", "quats", "scales", "opacities", "coeffs"), o4):
@@ -461,7 +463,7 @@ def _worker_configs3(rank, world, port, out_dir):
             r_ref, a_ref, m = orc.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], rgb, vm_r.numpy(), K_r.numpy(),
                                                 W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
             if r == 0:   # this rank's own frame: the exchange renders what rasterization() renders
-                assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
+                assert_tile_lists(info, m)
             Gc_r, Ga_r = (t.numpy() for t in cotangents(r))
             alc = np.maximum(a_ref, 1e-10)
             Gc_raw = Gc_r.copy()

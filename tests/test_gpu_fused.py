@@ -7,6 +7,8 @@ import math
 import pytest
 import torch
 
+from tests.util import assert_tile_lists, listed
+
 pytestmark = pytest.mark.gpu
 
 
@@ -27,7 +29,7 @@ def _compose(P, vm, K, W, H, render_mode, rasterize_mode, absgrad, backgrounds=N
         render, alpha = w.rasterize_to_pixels_with_depth(means2d, conics, cols, opac, depths, render_mode == "RGB+ED",
                                                          W, H, 16, off, flat, backgrounds=backgrounds, absgrad=absgrad)
     return render, alpha, {"means2d": means2d, "depths": depths, "conics": conics, "opacities": opac, "radii": radii,
-                           "flatten_ids": flat}
+                           "flatten_ids": flat, "isect_ids": isect_ids, "isect_offsets": off}
 
 
 def _scene(N, D, seed, dev):
@@ -88,7 +90,8 @@ def test_fused_equals_composition(hip_lib, cams, D, render_mode, rasterize_mode,
         results.append((render.detach(), alpha.detach(), info, grads))
     (r1, a1, i1, g1), (r0, a0, i0, g0) = results
     assert torch.equal(r1, r0) and torch.equal(a1, a0)                      # same kernels, same inputs
-    assert torch.equal(i1["radii"], i0["radii"]) and torch.equal(i1["flatten_ids"], i0["flatten_ids"])
+    assert torch.equal(i1["radii"], i0["radii"])
+    assert_tile_lists(i1, i0)                     # (the fused path's lists: ordered sublists of the operator path's = gsplat's)
     assert torch.equal(i1["means2d"].detach(), i0["means2d"].detach())
     assert set(g1) == set(g0)
     for k in g0:
@@ -155,12 +158,14 @@ def test_speculative_sizing_overflow_repeats_the_frame_exactly(hip_lib):
         return r.detach(), a.detach(), info, {k: p.grad for k, p in P.items()}
 
     r0, a0, i0, g0 = run(None)
-    n_vis, M = int((i0["radii"] > 0).sum()), i0["flatten_ids"].numel()
+    n_vis, M = int((i0["radii"] > 0).sum()), i0["flatten_ids"].numel()      # (M: gsplat's count -- what the capacities are about)
     assert n_vis > 500 and M > 2000
     for caps in [(n_vis // 2, 1 << 16), (n_vis + 10, M // 3), (64, 64), (n_vis, M)]:
         r1, a1, i1, g1 = run(caps)
-        for k in ("flatten_ids", "isect_ids", "isect_offsets", "radii", "tiles_per_gauss"):
+        for k in ("isect_offsets", "radii", "tiles_per_gauss"):
             assert torch.equal(i0[k], i1[k]), (caps, k)
+        for k in ("flatten_ids", "isect_ids"):
+            assert torch.equal(listed(i0, k), listed(i1, k)), (caps, k)
         assert torch.equal(r0, r1) and torch.equal(a0, a1), caps
         for k in g0:
             # (fp32 atomics accumulate in a different order from run to run)
@@ -197,10 +202,10 @@ def test_graph_mode_capture_replay_equals_eager(hip_lib):
         r, a, info = run()
         torch.cuda.synchronize()
         return (r.detach().clone(), a.detach().clone(), {k: p.grad.clone() for k, p in P.items()}, info["means2d"].absgrad.clone(),
-                int((info["radii"] > 0).sum()), info["flatten_ids"].clone())
+                int((info["radii"] > 0).sum()), listed(info).clone(), info["flatten_ids"].numel())
 
     ref0 = eager()
-    n_vis, M = ref0[4], ref0[5].numel()
+    n_vis, M = ref0[4], ref0[6]          # (gsplat's intersection count: the totals of the front end, the capacity's unit)
     for p in P.values():
         p.grad = torch.zeros_like(p)
     grads = [p.grad for p in P.values()]
@@ -225,7 +230,8 @@ def test_graph_mode_capture_replay_equals_eager(hip_lib):
     def check(ref):
         graph.replay()
         torch.cuda.synchronize()
-        assert int(info["n_visible"]) == ref[4] and int(info["n_intersections"]) == ref[5].numel() and not bool(info["overflow"])
+        assert int(info["n_visible"]) == ref[4] and int(info["n_intersections"]) == ref[6] and not bool(info["overflow"])
+        assert int(info["n_listed"]) == ref[5].numel()
         assert torch.equal(info["flatten_ids"][:ref[5].numel()], ref[5])
         assert torch.equal(r, ref[0]) and torch.equal(a, ref[1])
         for k, p in P.items():
@@ -256,7 +262,7 @@ def test_graph_mode_capture_replay_equals_eager(hip_lib):
 
 
 @pytest.mark.parametrize("n,equal_depths", [(300, False), (1500, True), (3000, False), (4200, True), (6000, False), (40_000, True)])
-def test_long_tile_lists_every_sort_path(hip_lib, n, equal_depths):
+def test_long_tile_lists_every_sort_path(hip_lib, lists_mode, n, equal_depths):
     """Binning without a global sort (csrc/bin3.hip): the per-tile sort has a one-wave path (< 1020 keys), a workgroup
     path (<= 4096; around 4200 Gaussians the nine lists straddle that limit inside the dispatch order's first length
     bucket), a 1024-thread path (<= 16384 keys in LDS) and a chunked path that merges through global memory.
@@ -293,9 +299,9 @@ def test_long_tile_lists_every_sort_path(hip_lib, n, equal_depths):
     if equal_depths:
         d = depths[0][radii[0] > 0]
         assert d.unique().numel() < d.numel(), "expected Gaussians with bit-identical depths"
-    assert torch.equal(info["isect_offsets"], off)
-    assert torch.equal(info["flatten_ids"], flat)
-    assert torch.equal(info["isect_ids"], isect_ids)
+    assert_tile_lists(info, {"isect_offsets": off, "flatten_ids": flat, "isect_ids": isect_ids})
+    if lists_mode == "tight":     # (opacities 0.02 .. 0.22: the tight lists are shorter, but every sort path must still be reached)
+        assert int(info["n_listed"]) > 0.5 * isect_ids.numel()
     r2, a2 = w.rasterize_to_pixels_with_depth(means2d, conics, cols.unsqueeze(0), oe, depths, True, W, H, 16, off, flat)
     assert torch.allclose(render, r2, atol=1e-5) and torch.allclose(alpha, a2, atol=1e-5)
 
@@ -324,13 +330,13 @@ def test_more_tile_rows_than_the_packed_path_takes(hip_lib):
     radii, means2d, depths, conics, comps, oe = w.projection_with_opacities(means.detach(), quats, scales, vm, K, opac, W, H,
                                                                             calc_compensations=True)
     _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 2, 4125)
-    assert isect_ids.numel() > n and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
+    assert isect_ids.numel() > n and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)   # (gather path: gsplat's lists)
     (render.sum() + alpha.sum()).backward()
     assert means.grad is not None and float(means.grad.abs().sum()) > 0
 
 
 @pytest.mark.parametrize("W,H", [(2560, 1440), (3840, 2160)])
-def test_high_resolution_frames_take_the_packed_path(hip_lib, W, H):
+def test_high_resolution_frames_take_the_packed_path(hip_lib, lists_mode, W, H):
     """14400 and 32400 tiles (one LDS histogram entry per tile: up to 32768): same ids and image as the operator path."""
     from mtgs_amd import _lib, rasterization
     from mtgs_amd import wrapper as w
@@ -352,12 +358,12 @@ def test_high_resolution_frames_take_the_packed_path(hip_lib, W, H):
     _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, tw, th)
     off = w.isect_offset_encode(isect_ids, 1, tw, th)
     assert isect_ids.numel() > 100_000
-    assert torch.equal(info["isect_offsets"], off) and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
+    assert_tile_lists(info, {"isect_offsets": off, "flatten_ids": flat, "isect_ids": isect_ids})
     r2, a2 = w.rasterize_to_pixels_with_depth(means2d, conics, cols.unsqueeze(0), oe, depths, True, W, H, 16, off, flat)
     assert torch.allclose(render, r2, atol=1e-5) and torch.allclose(alpha, a2, atol=1e-5)
 
 
-def test_many_cameras_in_one_call_take_the_packed_path(hip_lib):
+def test_many_cameras_in_one_call_take_the_packed_path(hip_lib, lists_mode):
     """24 cameras of 640x480: 24 x 30 = 720 (camera, tile row) bins, 28800 (camera, tile) bins -- one call, same ids as the
     operator path."""
     from mtgs_amd import _lib, rasterization
@@ -378,4 +384,46 @@ def test_many_cameras_in_one_call_take_the_packed_path(hip_lib):
                                                                             W, H, calc_compensations=True)
     _, isect_ids, flat = w.isect_tiles(means2d, radii, depths, 16, 40, 30)
     off = w.isect_offset_encode(isect_ids, C, 40, 30)
-    assert torch.equal(info["isect_offsets"], off) and torch.equal(info["flatten_ids"], flat) and torch.equal(info["isect_ids"], isect_ids)
+    assert_tile_lists(info, {"isect_offsets": off, "flatten_ids": flat, "isect_ids": isect_ids})
+
+
+@pytest.mark.parametrize("N,W,H,C,D", [(60_000, 320, 200, 1, 3), (200_000, 640, 480, 1, 3), (120_000, 640, 360, 3, 3),
+                                       (500_000, 960, 540, 1, 6)])
+def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D):
+    """The default tile lists hold only the (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse reaches a pixel centre of the
+    tile (mtgs_bin3_build(tight=1)).  Against gsplat's lists (mtgs_amd.exact_lists(): every tile of the 3-sigma square): render and
+    alphas are BIT-identical -- every pair left out is skipped pixel by pixel by gsplat's own `alpha < 1/255` rule -- the
+    gradients agree to the order of the fp32 atomics, the lists are ordered sublists, and they are much shorter."""
+    import mtgs_amd
+    from mtgs_amd import rasterization
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda")
+    sc = {k: v.to(dev) for k, v in make_scene(N, seed=5, sh_degree=None).items()}
+    g = torch.Generator().manual_seed(2)
+    cols = torch.rand(N, D, generator=g).to(dev)
+    sc["opacities"] = (torch.rand(N, generator=g) ** 2).to(dev)          # (many faint Gaussians: small alpha >= 1/255 ellipses)
+    vms, Ks = zip(*[make_camera(W, H, yaw_deg=25.0 * c) for c in range(C)])
+    vm, K = torch.cat(vms).to(dev), torch.cat(Ks).to(dev)
+    Gc, Ga = torch.randn(C, H, W, D + 1, generator=g).to(dev), torch.randn(C, H, W, 1, generator=g).to(dev)
+    out = {}
+    for mode in ("gsplat", "tight"):
+        P = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
+        c = cols.clone().requires_grad_(True)
+        v = vm.clone().requires_grad_(True)
+        with mtgs_amd.exact_lists(mode == "gsplat"):
+            r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], c, v, K, W, H, packed=False,
+                                       render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+            info["means2d"].retain_grad()
+            torch.autograd.backward([r, a], [Gc, Ga])
+        grads = {k: p.grad for k, p in P.items()}
+        grads.update(colors=c.grad, viewmat=v.grad, means2d=info["means2d"].grad, absgrad=info["means2d"].absgrad)
+        out[mode] = (r.detach(), a.detach(), info, grads)
+    (r0, a0, i0, g0), (r1, a1, i1, g1) = out["gsplat"], out["tight"]
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max() <= 2e-4 * g0[k].abs().max() + 1e-7, k
+    for k in ("radii", "tiles_per_gauss"):
+        assert torch.equal(i0[k], i1[k])
+    assert int(i0["n_listed"]) == i0["flatten_ids"].numel() == i1["flatten_ids"].numel()
+    assert_tile_lists(i1, {k: listed(i0, k) if k != "isect_offsets" else i0[k] for k in ("isect_offsets", "flatten_ids", "isect_ids")})
+    assert int(i1["n_listed"]) < 0.8 * int(i0["n_listed"]), (int(i1["n_listed"]), int(i0["n_listed"]))

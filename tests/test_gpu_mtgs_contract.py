@@ -445,7 +445,9 @@ def _torchrun(nproc, extra, timeout=2400):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(root / "scripts" / "mtgs_like_train.py")] + extra,
                        capture_output=True, text=True, timeout=timeout, env=env, cwd=str(root))
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    if r.returncode != 0:      # (the launcher's summary names the first rank that failed; its own traceback is further up)
+        first = r.stderr.find("Traceback")
+        raise AssertionError(r.stdout[-1500:] + r.stderr[max(first, 0):][:4000] + "\n...\n" + r.stderr[-1500:])
     return r.stdout
 
 

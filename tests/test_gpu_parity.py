@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_grad_close, assert_image_close, small_scene, to_np
+from tests.util import assert_grad_close, assert_image_close, assert_tile_lists, listed, small_scene, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -176,9 +176,11 @@ def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad
                                            absgrad=absgrad, backgrounds=None if bg is None else dev(bg))
     info["means2d"].retain_grad()
     assert np.array_equal(info["radii"].cpu().numpy(), m["radii"])
-    assert np.array_equal(info["isect_ids"].cpu().numpy(), m["isect_ids"])
-    assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
-    assert np.array_equal(info["isect_offsets"].cpu().numpy(), m["isect_offsets"])
+    # the tile lists: ordered sublists of gsplat's in the default (tight) mode, gsplat's own bit for bit under exact_lists()
+    assert_tile_lists(info, m, rerun=lambda: gs.rasterization(
+        P["means"].detach(), P["quats"].detach(), P["scales"].detach(), P["opacities"].detach(), P["colors"].detach(), vmd.detach(),
+        dev(K), W, H, packed=False, render_mode=render_mode, rasterize_mode=rmode, absgrad=absgrad,
+        backgrounds=None if bg is None else dev(bg))[2])
     case = f"small {render_mode}/{rmode} D={D} {W}x{H}"
     assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render", case=case,
                        depth_channel=None if render_mode == "RGB" else -1, alpha=r_alpha)
@@ -248,7 +250,7 @@ def test_rasterization_sh_path_backward(gs, oracle, N, W, H, deg, mode):
     vmd = dev(vm).requires_grad_(True)
     render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["coeffs"], vmd, dev(K), W, H,
                                            sh_degree=deg, packed=False, render_mode=mode, rasterize_mode=rmode, absgrad=True)
-    assert np.array_equal(info["flatten_ids"].cpu().numpy(), m["flatten_ids"])
+    assert_tile_lists(info, m)
     assert_image_close(render.detach().cpu().numpy(), r_render, m["critical"], RENDER_TOL, name="render", case=f"sh_degree path N={N}",
                        depth_channel=-1 if aa else None, alpha=r_alpha)
     assert_image_close(alpha.detach().cpu().numpy(), r_alpha, m["critical"], RENDER_TOL, name="alpha", case=f"sh_degree path N={N}")
@@ -288,7 +290,7 @@ def test_empty_and_degenerate_inputs(gs):
     quats = torch.tensor([[1.0, 0, 0, 0]] * 2).cuda(); scales = torch.full((2, 3), 0.1).cuda()
     opac = torch.full((2,), 0.5).cuda(); cols = torch.rand(2, 3).cuda()
     render, alpha, info = gs.rasterization(means, quats, scales, opac, cols, vm, K, W, H, packed=False, render_mode="RGB+ED")
-    assert info["flatten_ids"].numel() == 0 and (info["radii"] == 0).all()
+    assert listed(info).numel() == 0 and (info["radii"] == 0).all()
     assert render.abs().max() == 0 and alpha.abs().max() == 0
     (render.sum() + alpha.sum()).backward()
     assert means.grad.abs().max() == 0
@@ -355,8 +357,12 @@ def test_hip_reproduces_golden_fixture(gs, name):
     render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm,
                                            dev(z["K"]), W, H, packed=False, render_mode=str(z["render_mode"]),
                                            rasterize_mode=str(z["rasterize_mode"]), backgrounds=bg, absgrad=True)
-    for key in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+    for key in ("radii", "tiles_per_gauss"):
         assert np.array_equal(info[key].cpu().numpy(), z[key]), key
+    assert_tile_lists(info, z, rerun=lambda: gs.rasterization(
+        P["means"].detach(), P["quats"].detach(), P["scales"].detach(), P["opacities"].detach(), P["colors"].detach(), vm.detach(),
+        dev(z["K"]), W, H, packed=False, render_mode=str(z["render_mode"]), rasterize_mode=str(z["rasterize_mode"]), backgrounds=bg,
+        absgrad=True)[2])
     for key in ("means2d", "depths", "conics"):
         assert np.array_equal(info[key].detach().cpu().numpy(), z[key]), key
     has_depth = str(z["render_mode"]) != "RGB"
@@ -398,8 +404,11 @@ def test_hip_reproduces_gsplat_fixture(gs, name):
     for key in ("means2d", "depths", "conics", "opacities"):
         ref = z["opacities_eff" if key == "opacities" else key]
         np.testing.assert_allclose(info[key].detach().cpu().numpy()[vis], ref[vis], rtol=2e-5, atol=1e-6, err_msg=key)
-    for key in ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
-        assert np.array_equal(info[key].cpu().numpy(), z[key]), key
+    assert np.array_equal(info["tiles_per_gauss"].cpu().numpy(), z["tiles_per_gauss"])
+    assert_tile_lists(info, z, rerun=lambda: gs.rasterization(
+        P["means"].detach(), P["quats"].detach(), P["scales"].detach(), P["opacities"].detach(), P["colors"].detach(), vm.detach(),
+        dev(z["K"]), W, H, packed=False, render_mode=str(z["render_mode"]), rasterize_mode=str(z["rasterize_mode"]), backgrounds=bg,
+        absgrad=True)[2])
     case = f"gsplat fixture {name}"
     nocrit = np.zeros(z["alpha"].shape[:3], bool)
     assert_image_close(render.detach().cpu().numpy(), z["render"], nocrit, RENDER_TOL, name="render", case=case,

@@ -41,6 +41,57 @@ REPORT = []
 MAX_CRITICAL_RATE = 1e-2
 
 
+def listed(info, key="flatten_ids"):
+    """The valid prefix of a tile-list tensor of rasterization()'s meta: all of it with gsplat's lists, the first
+    info["n_listed"] entries with the tight ones (buffers are sized for gsplat's count)."""
+    n = info.get("n_listed")
+    return info[key] if n is None else info[key][:int(n)]
+
+
+def assert_tile_lists(info, ref, rerun=None):
+    """The tile lists of a fused rasterization() against gsplat's (`ref`: the oracle's meta or the operator path's tensors:
+    isect_offsets, flatten_ids, optionally isect_ids).
+    * gsplat's lists requested (mtgs_amd.exact_lists()): bit-identical.
+    * tight lists (the default): ORDERED SUBLISTS -- every listed (tile, Gaussian) pair is one of gsplat's, tile by tile in
+      gsplat's order, with gsplat's isect_ids; the offsets are the prefix sums of the lists' own lengths.  (That no pair with a
+      contributing pixel is left out is what the image comparisons establish: tests/test_gpu_fused.py compares the two modes
+      bit for bit.)
+    rerun: a callable that repeats the forward and returns its info -- run under exact_lists() and compared bit for bit."""
+    import mtgs_amd
+    from mtgs_amd import wrapper
+    a = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+    off_ref, flat_ref = a(ref["isect_offsets"]).reshape(-1).astype(np.int64), a(ref["flatten_ids"]).astype(np.int64)
+    n = int(info["n_listed"]) if info.get("n_listed") is not None else int(info["flatten_ids"].numel())
+    off, flat = a(info["isect_offsets"]).reshape(-1).astype(np.int64), a(info["flatten_ids"])[:n].astype(np.int64)
+    assert off.shape == off_ref.shape
+    if not wrapper.tight_lists:
+        assert n == flat_ref.size and np.array_equal(flat, flat_ref) and np.array_equal(off, off_ref)
+        if "isect_ids" in ref:
+            assert np.array_equal(a(info["isect_ids"])[:n], a(ref["isect_ids"]))
+    else:
+        assert n <= flat_ref.size and (n == 0 or (off[0] == 0 and np.all(np.diff(off) >= 0) and off[-1] <= n))
+        tile_ref = np.repeat(np.arange(off_ref.size), np.diff(np.append(off_ref, flat_ref.size)))
+        tile = np.repeat(np.arange(off.size), np.diff(np.append(off, n)))
+        assert tile.size == n
+        big = int(max(flat_ref.max(initial=0), flat.max(initial=0))) + 1
+        key_ref, key = tile_ref * big + flat_ref, tile * big + flat
+        order = np.argsort(key_ref, kind="stable")
+        pos = np.searchsorted(key_ref[order], key)
+        assert np.all(pos < key_ref.size) and np.array_equal(key_ref[order][np.minimum(pos, max(key_ref.size - 1, 0))], key), \
+            "a listed (tile, Gaussian) pair is not one of gsplat's"
+        at = order[pos]                       # index of every listed pair in gsplat's list
+        assert np.all(np.diff(at) > 0), "listed pairs are not in gsplat's order"
+        if "isect_ids" in ref and n:
+            assert np.array_equal(a(info["isect_ids"])[:n], a(ref["isect_ids"])[at])
+    if rerun is not None:
+        with mtgs_amd.exact_lists():
+            ex = rerun()
+        assert ex.get("n_listed") is None or int(ex["n_listed"]) == flat_ref.size
+        assert np.array_equal(a(ex["flatten_ids"]), flat_ref) and np.array_equal(a(ex["isect_offsets"]).reshape(-1), off_ref)
+        if "isect_ids" in ref:
+            assert np.array_equal(a(ex["isect_ids"]), a(ref["isect_ids"]))
+
+
 def assert_image_close(got, ref, critical, tol=1e-4, flip_bound=1.0 / 255.0, name="render", scale=None, case="",
                        depth_channel=None, alpha=None):
     """The north star's bar, per channel GROUP (an RGB regression must not hide behind a depth channel's metres):
