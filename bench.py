@@ -199,7 +199,7 @@ def mtgs_like_iteration_cells():
             r = subprocess.run([sys.executable, os.path.join(root, "scripts", "mtgs_like_train.py"), "--shipped", "--visfirst", "--optimizer",
                                 "fused", "--row-lazy", "--geometry-rows", "--only", "fused", "--reps", "1", "--converge", "--grad-thresh", "1e-3",
                                 "--clear-radius", "12", "--steps", "1000", "--refine-every", "100", "--densify-from", "250", "--steady", "60",
-                                "260", "--train-graph"], capture_output=True, text=True, timeout=min(180.0, left), cwd=root)
+                                "260", "--train-graph", "--one-graph"], capture_output=True, text=True, timeout=min(180.0, left), cwd=root)
             m = re.search(r"timing: ([\d.]+) ms per step", r.stdout)
             sm = re.search(r"steady: ([\d.]+) ms per step", r.stdout)
             cm = re.search(r"converge: loss ([\d.]+) -> ([\d.]+) .* through (\d+) refinements", r.stdout)
