@@ -335,6 +335,15 @@ int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,
                           const int32_t *tile_order, void *stream);
+/* mtgs_blend_touch_packed (ABI v24): the forward's per-pixel DECISIONS without its colours -- touched[cap_vis] (uint8, cleared by the
+ * call) gets 1 for every visible Gaussian (rank) that the frame composites FROM, i.e. that has a non-zero weight at some pixel: same
+ * staging, validity test, alpha / T expressions and termination as mtgs_blend_fwd_packed, reading the geometry half (32 bytes) of the
+ * records only (the colour channels may still be open).  Exactly those Gaussians receive a gradient in mtgs_blend_bwd_packed; in an
+ * opaque scene they are a few percent of the frustum-visible ones.  What is per visible Gaussian behind the front end takes the flags
+ * (row_flags of mtgs_vis_color_fwd / mtgs_normals_fwd_rows / mtgs_adam_group) and leaves the others alone -- their colour never
+ * reaches a pixel (weight 0 wherever they are met), their gradient is zero. */
+int mtgs_blend_touch_packed(int C, const float *recs, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
+                            const int32_t *rank_ids, const int32_t *tile_order, uint8_t *touched, int64_t cap_vis, void *stream);
 /* mtgs_blend_bwd_packed (ABI v22): grad_rows[n_vis, row_stride] holds RAW MOMENT rows -- with h = vis * dL/dalpha per (pixel,
  * Gaussian) pair (gsplat's v_sigma = -opacity h): {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 |
  * sum h | colours D | depth}; u = a dx + b dy, w = b dx + c dy.  The conic map of the position gradient and the factor -opacity
@@ -537,8 +546,10 @@ int mtgs_normals_bwd_rows(int64_t n_vis, const int32_t *vis_ids, const float *qu
  * vis_ids[r] goes into channels `channel` .. + 2 of its record (mtgs_front_fwd color_mode 3 left them open), r < min(cap_vis,
  * *totals >> 32) (totals nullable: cap_vis rows).  bwd_qrows: quat_rows[r, 4] = the quaternion gradient from v_normal =
  * grad_rows[r, col .. col + 2], handed to mtgs_project_bwd as x_quat_rows.  No [N, 3] normal tensor and no dense gradient of it. */
+/* row_flags (ABI v24, nullable): rows with row_flags[r] == 0 (nothing is composited from them: mtgs_blend_touch_packed) get zeros and
+ * nothing of theirs is gathered */
 int mtgs_normals_fwd_rows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats, const float *scales,
-                          const float *means, const float *c2w, float *recs, int channel, void *stream);
+                          const float *means, const float *c2w, float *recs, int channel, const uint8_t *row_flags, void *stream);
 int mtgs_normals_bwd_qrows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats, const float *scales,
                            const float *means, const float *c2w, const float *grad_rows, int64_t row_stride, int col,
                            float *quat_rows, void *stream);
@@ -694,7 +705,7 @@ int mtgs_loss_combine_bwd(int n, const float *v_out, const uint32_t *kept, const
  * what mtgs_adam_step's MTGS_ADAM_ROWS_PEEK groups leave (row-lazy optimizer: up-to-date values without touching the parameters). */
 int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
-                       const float *coef_rows, int64_t coef_stride, void *stream);
+                       const float *coef_rows, int64_t coef_stride, const uint8_t *row_flags, void *stream);
 int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                        int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
@@ -740,6 +751,9 @@ typedef struct mtgs_adam_group {
     const int32_t *sub_index_dev; /* (ABI v24, nullable) the slice in DEVICE memory: read when the kernel runs, overrides sub_index -- ONE
                                  * captured step / peek serves every traversal of a per-traversal tensor (the caller rewrites the
                                  * word in front of a replay) */
+    const uint8_t *row_flags;   /* (ABI v24, nullable) LIST groups, ROWS_PEEK / ROWS_STEP: row r (rank) is worked on only if row_flags[r] != 0 --
+                                 * the Gaussians the frame composites FROM (mtgs_blend_touch_packed); the others have a zero gradient
+                                 * and nobody reads their peeked row: they are skipped before anything of theirs is requested */
     int64_t n, first_block;
     int64_t row_stride;         /* floats between rows */
     int64_t caught_stride;      /* floats between rows of `caught` */

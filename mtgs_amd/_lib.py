@@ -60,6 +60,7 @@ _SIGNATURES = {
     "mtgs_bin3_build": [_i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                         _vp, _sz, _vp],
     "mtgs_blend_fwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_blend_touch_packed": [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_blend_bwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _i64, _i32, _vp, _vp],
     "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -85,7 +86,7 @@ _SIGNATURES = {
     "mtgs_normals_fwd": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_normals_bwd": [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_normals_bwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
-    "mtgs_normals_fwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "mtgs_normals_fwd_rows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mtgs_normals_bwd_qrows": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "mtgs_densify_stats": [_i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "mtgs_deform_embed": [_i64, _vp, _f32, _f32, _vp, _i32, _i32, _i32, _vp, _i64, _vp],
@@ -123,7 +124,7 @@ _SIGNATURES = {
     "mtgs_campos_bwd": [_vp, _vp, _vp, _vp],
     "mtgs_loss_combine_fwd": [_i32, _vp, C.POINTER(C.c_float), C.c_uint, _f32, _vp, _vp, _vp],
     "mtgs_loss_combine_bwd": [_i32, _vp, _vp, C.POINTER(C.c_float), _vp, _vp],
-    "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp],
+    "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_rows_expand": [_i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "mtgs_adam_group_bytes": [],

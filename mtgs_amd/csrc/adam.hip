@@ -125,7 +125,7 @@ __device__ __forceinline__ float row_grad(const mtgs_adam_group &d, int64_t i, i
 // (4.2 TB/s), 111 us read + write; MTGS's three colour tensors (dc [N, 3], adapter [N, T, 3], rest [N, T, 45]) each with p, m, v
 // and a stamp: 112 ... 148 us peek-like, 222 ... 253 us step-like -- the 12-byte and 4-byte pieces cost a memory transaction
 // each.  Measured here, arithmetic included (MTGS-like iteration, 960x540): peek 155 ... 180 us (SCAN 175 ... 200), step 243 ... 297.
-#define ADAM_HWIN 64
+#define ADAM_HWIN 64     // steps of history in LDS; older steps: one load per LPR / 2 steps, shared by the row's lanes (row_work)
 #ifndef ADAM_ZERO_SKIP_MAX
 #define ADAM_ZERO_SKIP_MAX 6     // zero_probe without a bound of its own: a zero-gradient row is committed once it is this many steps behind
 #endif
@@ -165,6 +165,13 @@ __device__ __forceinline__ RowCtx row_ctx(const mtgs_adam_group &d, const Hyper 
 template <bool LIST, int LPR>
 __device__ __forceinline__ void row_work(const mtgs_adam_group &d, const Hyper &h, const RowCtx &x, const int64_t i, const int r,
                                          const int L_in, const int c0) {
+    // row_flags (LIST): the rows the frame composites FROM (mtgs_blend_touch_packed).  PEEK: nobody reads the colour of the others,
+    // so nothing of theirs is requested (the stamp, the parameter and moment pieces are a memory transaction each) and their
+    // `caught` row is not written.  STEP: the others have a zero gradient and NO caught row -- they follow the zero_probe rule
+    // (left lazy while fewer than K steps behind, then committed, so that no row the frames keep seeing falls far behind and the
+    // replay of a row that becomes visible from behind an occluder stays short), taking p from the parameter itself.
+    const bool flagged = !(LIST && d.row_flags && r >= 0 && r < d.n_rows) || d.row_flags[r] != 0;
+    if (x.peek && !flagged) return;
     int32_t *lastp = x.has_state ? d.last + i * x.T + x.slice : nullptr;
     int L = L_in;
     if (LIST) L = x.has_state ? *lastp : x.target;
@@ -185,7 +192,7 @@ __device__ __forceinline__ void row_work(const mtgs_adam_group &d, const Hyper &
     }
     const bool in_rows = r >= 0 && r < d.n_rows;
     // STEP with this frame's caught rows: p comes from them, the missed steps are replayed for the moments only
-    const bool use_caught = x.step && d.caught != nullptr && in_rows && h.wd == 0.f;
+    const bool use_caught = x.step && d.caught != nullptr && in_rows && h.wd == 0.f && flagged;
     const bool need_state = LIST ? x.has_state : (x.has_state && (x.step || L < x.target));
 #pragma unroll 1
     for (int cb = 0; cb < x.sw; cb += LPR * ADAM_SEG) {
@@ -217,10 +224,20 @@ __device__ __forceinline__ void row_work(const mtgs_adam_group &d, const Hyper &
                 // for the step's scalar (checked per step: learning rates move), so a gap costs ~40 instructions per element
                 // for its first ~900 steps and 2 for the rest -- still the same bits as stepping every time.
                 bool settled = false;
-                float m_max = 0.f, lim_min = 0.f;
+                float m_max = 0.f, lim_min = 0.f, h_cache = 0.f;
+                int h_base = -1;
                 for (int j = L + 1; j <= x.target; ++j) {      // the zero-gradient steps this row missed, oldest first
                     if (j >= x.win0) { hj.step_size = x.s_hist[2 * (j - x.win0)]; hj.bc2_sqrt = x.s_hist[2 * (j - x.win0) + 1]; }
-                    else { hj.step_size = d.hist[2 * (int64_t)j]; hj.bc2_sqrt = d.hist[2 * (int64_t)j + 1]; }
+                    else {
+                        // older than the LDS window: the scalars of LPR / 2 steps per load, one float per lane of the row's group
+                        // (all lanes of a group walk the same j), handed round with a group-wide shuffle -- a long replay waits for
+                        // memory once per LPR / 2 steps instead of once per step
+                        constexpr int CH = LPR / 2;
+                        const int jb = j - (j % CH);
+                        if (jb != h_base) { h_cache = d.hist[2 * (int64_t)jb + c0]; h_base = jb; }
+                        hj.step_size = __shfl(h_cache, 2 * (j - jb), LPR);
+                        hj.bc2_sqrt = __shfl(h_cache, 2 * (j - jb) + 1, LPR);
+                    }
                     if (settled && hj.step_size * m_max < lim_min) {
 #pragma unroll
                         for (int u = 0; u < ADAM_SEG; ++u) adam_moments(0.f, m[u], v[u], 0.f, h);   // m stays, v *= beta2

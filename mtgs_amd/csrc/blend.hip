@@ -433,6 +433,99 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The forward's per-pixel DECISIONS without its colours: which Gaussians does the frame composite FROM?  Same staging, same
+// validity test, same alpha / T expressions and the same termination as blend_fwd_kernel (so exactly the entries the forward
+// gives a non-zero weight -- and the backward a gradient -- are found), but no colour row is read and nothing is accumulated:
+// an entry with at least one updating pixel sets touched[rank] = 1.  In an opaque scene most frustum-visible Gaussians are
+// never reached (91-98 % in MTGS-like scenes): everything that is per VISIBLE Gaussian behind the front end -- the optimizer's
+// peek of the coefficient rows, the SH evaluation, the normals, the optimizer step -- can then run over the touched ones alone.
+// Records are staged without their colour half (32 of 64 bytes gathered).
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_touch_kernel(int C, const float *__restrict__ recs, int W, int H, int tw, int th,
+                                                                const int32_t *__restrict__ offsets,
+                                                                const int32_t *__restrict__ rank_ids,
+                                                                const int32_t *__restrict__ order, uint8_t *__restrict__ touched) {
+    constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<0>::N;
+    constexpr int CAND = NT == 64 ? 128 : 256, NR = CAND / NT;
+    static_assert(REC == 8, "geometry half of the record");
+    __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
+    __shared__ int32_t s_id[CAND];
+    __shared__ int s_wc[NT / 64];
+    const int64_t n_tiles = (int64_t)tw * th;
+    const int64_t tile = block_to_tile(order);
+    const int cam = (int)(tile / n_tiles);
+    const int t_in = (int)(tile - (int64_t)cam * n_tiles);
+    const int ty = t_in / tw, tx = t_in - ty * tw;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ix = tx * 16 + lx;
+    const float px = (float)ix + 0.5f;
+    float py[PPL], T[PPL];
+    unsigned long long done[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+        const int iy = ty * 16 + ly + p * ROWS;
+        py[p] = (float)iy + 0.5f;
+        done[p] = __ballot(!(ix < W && iy < H));
+        T[p] = 1.f;
+    }
+    const int64_t start = offsets[tile], end = offsets[tile + 1];
+    for (int64_t b0 = start; b0 < end; b0 += CAND) {
+        bool all_done = true;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) all_done = all_done && done[p] == ~0ull;
+        if (__syncthreads_and(all_done)) break;
+        int32_t g_cur[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) g_cur[r] = (b0 + r * NT + tid < end) ? rank_ids[b0 + r * NT + tid] : 0;
+        const int n_cand = (int)min((int64_t)CAND, end - b0);
+        const int bsz = stage_batch<0, NT, CAND, false, true, true>(s_rec, s_id, s_wc, recs, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                                                    nullptr, g_cur, b0, n_cand, (float)(tx * 16), (float)(ty * 16));
+        __syncthreads();
+        bool fin = false;
+        for (int t = 0; t < bsz && !fin; ++t) {
+            const float4 r0 = *reinterpret_cast<const float4 *>(s_rec + t * REC);
+            const float4 r1 = *reinterpret_cast<const float4 *>(s_rec + t * REC + 4);
+            const float dx = r0.x - px;
+            const float adx = r0.z * dx, bdx = r0.w * dx;
+            const float q0 = adx * dx, b2dx = bdx + bdx;
+            float s2[PPL];
+            unsigned long long vmask[PPL], any = 0;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                s2[p] = eval_s2(q0, b2dx, r1.x, r0.y - py[p]);
+                vmask[p] = in_range_mask(s2[p], r1.z) & ~done[p];
+                any |= vmask[p];
+            }
+            if (any == 0) continue;
+            unsigned long long stopped = 0, hit = 0;
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                if (vmask[p] != 0) {
+                    const float e = __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]);
+                    const float alpha = fminf(kAlphaMax, alpha_rounded(r1.y, e));
+                    const float next_T = T[p] * (1.f - alpha);
+                    const unsigned long long sm = __builtin_amdgcn_fcmpf(next_T, kTMin, 5 /* FCMP_OLE */) & vmask[p];
+                    done[p] |= sm;
+                    stopped |= sm;
+                    const unsigned long long um = vmask[p] & ~sm;
+                    hit |= um;
+                    const bool upd = __builtin_amdgcn_inverse_ballot_w64(um);
+                    T[p] = upd ? next_T : T[p];
+                }
+            }
+            if (hit != 0 && (tid & 63) == 0) touched[s_id[t]] = 1;     // (several waves / tiles may store the same 1)
+            if (stopped) {
+                unsigned long long ad = done[0];
+#pragma unroll
+                for (int p = 1; p < PPL; ++p) ad &= done[p];
+                fin = ad == ~0ull;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row strides (bytes) of the six gradient outputs.  Dense gsplat arrays by default; the Python layer passes
 // views of ONE interleaved [C,N,16] buffer instead (xy, |xy|, conic, opacity, colour.. in reduction order), so
 // that the 12 lanes of an entry's atomic instruction fall into a single 64-byte line: measured 0.06 ns per
@@ -939,6 +1032,27 @@ extern "C" int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *
     MTGS_DISPATCH_PK(launch_fwd, C, recs, nullptr, nullptr, nullptr, nullptr, backgrounds, nullptr, D, ed_normalize, width, height,
                      tile_w, tile_h, offsets, rank_ids, (int64_t)-1, render, alphas, last_ids, tile_order, st);
     MTGS_CHECK_LAUNCH("mtgs_blend_fwd_packed");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_blend_touch_packed(int C, const float *recs, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
+                                       const int32_t *rank_ids, const int32_t *tile_order, uint8_t *touched, int64_t cap_vis,
+                                       void *stream) {
+    MTGS_REQUIRE(C >= 0 && width > 0 && height > 0 && cap_vis >= 0, MTGS_EINVAL, "mtgs_blend_touch_packed: bad sizes");
+    MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
+                 "mtgs_blend_touch_packed: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
+    if (C == 0 || cap_vis == 0) return MTGS_OK;
+    MTGS_REQUIRE(recs && offsets && rank_ids && touched, MTGS_EINVAL, "mtgs_blend_touch_packed: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(touched, 0, (size_t)cap_vis, st);
+    MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_blend_touch_packed: memset failed");
+    const int64_t total_tiles = (int64_t)C * tile_w * tile_h;
+    const int ppl = pick_ppl(total_tiles, 4, false);
+    const unsigned grid = (unsigned)total_tiles;
+    if (ppl == 4) blend_touch_kernel<4><<<grid, 64, 0, st>>>(C, recs, width, height, tile_w, tile_h, offsets, rank_ids, tile_order, touched);
+    else if (ppl == 2) blend_touch_kernel<2><<<grid, 128, 0, st>>>(C, recs, width, height, tile_w, tile_h, offsets, rank_ids, tile_order, touched);
+    else blend_touch_kernel<1><<<grid, 256, 0, st>>>(C, recs, width, height, tile_w, tile_h, offsets, rank_ids, tile_order, touched);
+    MTGS_CHECK_LAUNCH("mtgs_blend_touch_packed");
     return MTGS_OK;
 }
 

@@ -135,11 +135,17 @@ __global__ __launch_bounds__(256) void normals_bwd_rows_kernel(int64_t n_vis, co
 __global__ __launch_bounds__(256) void normals_fwd_rows_kernel(int64_t cap_vis, const int32_t *__restrict__ vis_ids,
                                                                const int64_t *__restrict__ totals, const float *__restrict__ quats,
                                                                const float *__restrict__ scales, const float *__restrict__ means,
-                                                               const float *__restrict__ c2w, float *__restrict__ recs, int channel) {
+                                                               const float *__restrict__ c2w, float *__restrict__ recs, int channel,
+                                                               const uint8_t *__restrict__ row_flags) {
     int64_t n_vis = totals ? *totals >> 32 : cap_vis;
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_vis) return;
+    if (row_flags && !row_flags[r]) {   // nothing is composited from this Gaussian: any finite value will do, nothing is gathered
+        float *dst = recs + r * REC_FLOATS + 8 + channel;
+        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;
+        return;
+    }
     const int64_t i = vis_ids[r];
     const F4 q = *reinterpret_cast<const F4 *>(quats + i * 4);
     const F3 s = *reinterpret_cast<const F3 *>(scales + i * 3);
@@ -178,13 +184,14 @@ __global__ __launch_bounds__(256) void normals_bwd_qrows_kernel(int64_t cap_vis,
 
 extern "C" int mtgs_normals_fwd_rows(int64_t cap_vis, const int32_t *vis_ids, const int64_t *totals, const float *quats,
                                      const float *scales, const float *means, const float *c2w, float *recs, int channel,
+                                     const uint8_t *row_flags,
                                      void *stream) {
     MTGS_REQUIRE(cap_vis >= 0 && channel >= 0 && channel + 3 <= REC_MAX_CHANNELS, MTGS_EINVAL, "mtgs_normals_fwd_rows: bad sizes");
     if (cap_vis == 0) return MTGS_OK;
     MTGS_REQUIRE(vis_ids && quats && scales && means && c2w && recs, MTGS_EINVAL, "mtgs_normals_fwd_rows: null pointer");
     MTGS_REQUIRE((reinterpret_cast<uintptr_t>(quats) & 15) == 0, MTGS_EINVAL, "mtgs_normals_fwd_rows: quats must be 16-byte aligned");
     normals_fwd_rows_kernel<<<(unsigned)ceil_div64(cap_vis, 256), 256, 0, (hipStream_t)stream>>>(cap_vis, vis_ids, totals, quats, scales,
-                                                                                                 means, c2w, recs, channel);
+                                                                                                 means, c2w, recs, channel, row_flags);
     MTGS_CHECK_LAUNCH("mtgs_normals_fwd_rows");
     return MTGS_OK;
 }

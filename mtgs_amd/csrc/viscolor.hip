@@ -50,7 +50,8 @@ struct RowInfo {
 __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ table, int n_nodes, const float *__restrict__ cam_pos,
                                              const float *__restrict__ means, const int32_t *__restrict__ vis_ids, int64_t r0,
                                              int64_t n_vis, RowInfo *s_row, int64_t *s_start,
-                                             const float *__restrict__ coef_rows = nullptr, int64_t coef_stride = 0) {
+                                             const float *__restrict__ coef_rows = nullptr, int64_t coef_stride = 0,
+                                             const uint8_t *__restrict__ row_flags = nullptr) {
     const int tid = threadIdx.x;
     const bool small = n_nodes <= VC_LDS_NODES;
     if (small) {
@@ -61,7 +62,9 @@ __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ 
         const int64_t r = r0 + tid;
         RowInfo ri;
         ri.dc = nullptr; ri.dc_add = nullptr; ri.rest = nullptr; ri.dx = 0.f; ri.dy = 0.f; ri.dz = 1.f; ri.inorm = 0.f; ri.k_rest = 0; ri.use_sh = 1;
-        if (r < n_vis) {
+        // row_flags: a Gaussian the frame composites nothing from gets a constant colour (whatever a zero SH sum activates to:
+        // finite, and multiplied by a zero weight wherever the compositing meets it) -- nothing of it is read
+        if (r < n_vis && (!row_flags || row_flags[r])) {
             const int64_t g = vis_ids[r];
             int lo = 0, hi = n_nodes - 1;
             while (lo < hi) {
@@ -95,7 +98,8 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
                                                                  const float *__restrict__ cam_pos, const float *__restrict__ means,
                                                                  const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
                                                                  int64_t cap_vis, float *__restrict__ recs, uint8_t *__restrict__ vis_mask,
-                                                                 const float *__restrict__ coef_rows, int64_t coef_stride) {
+                                                                 const float *__restrict__ coef_rows, int64_t coef_stride,
+                                                                 const uint8_t *__restrict__ row_flags) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     __shared__ RowInfo s_row[VC_ROWS];
     __shared__ int64_t s_start[VC_LDS_NODES];
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r0 = (int64_t)blockIdx.x * VC_ROWS;
     if (r0 >= n_vis) return;
-    resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, coef_rows, coef_stride);
+    resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, coef_rows, coef_stride, row_flags);
     const int k = threadIdx.x & 15, sub = threadIdx.x >> 4;
     const ShLaneConst lc = sh_lane_const(k);
     F3 c[VC_STEPS];
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void rows_expand4_kernel(int64_t N, int width4
 
 extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                                   const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
-                                  const float *coef_rows, int64_t coef_stride, void *stream) {
+                                  const float *coef_rows, int64_t coef_stride, const uint8_t *row_flags, void *stream) {
     MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0, MTGS_EINVAL, "mtgs_vis_color_fwd: bad sizes (degree <= 3)");
     MTGS_REQUIRE(!coef_rows || coef_stride >= 51, MTGS_EINVAL, "mtgs_vis_color_fwd: coef_stride=%lld (a row is dc 3 | dc_add 3 | rest 45)",
                  (long long)coef_stride);
@@ -311,7 +315,7 @@ extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int 
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
     MTGS_VC_DISPATCH(vis_color_fwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, recs, vis_mask, coef_rows,
-                     coef_stride)
+                     coef_stride, row_flags)
     MTGS_CHECK_LAUNCH("mtgs_vis_color_fwd");
     return MTGS_OK;
 }

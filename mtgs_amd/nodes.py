@@ -198,16 +198,24 @@ class ColorSource:
         #                              of the frustum-visible ones) are left lazy by the step instead of being stepped with zeros
         self.optimizer = None   # a FusedAdam with row-lazy colour parameters: prepare() peeks the visible rows for the colour kernel
         self.caught = None
+        self.touch_first = False  # True (opt-in): the rasterization bins first and flags the Gaussians the frame composites FROM (one
+        #                           pass of the compositing DECISIONS, mtgs_blend_touch_packed: costs about one forward); the
+        #                           optimizer's peek, the SH evaluation and the normals then leave the others -- 90 % of the visible
+        #                           ones in an opaque scene -- alone.  Exact (tests/test_gpu_nodes.py).  Pays when the peek of every
+        #                           visible row costs more than a forward pass (a wash at 960x540 / 2M)
+        self.row_flags = None     # the flags of the last frame (uint8 [cap_vis]) or None
 
     COEF_STRIDE = 52            # floats of a compact coefficient row: dc 3 | dc_add (adapter) 3 | rest 45 | pad
 
-    def prepare(self, vis_rank: Tensor, cap_rows: int, vis_ids: Optional[Tensor] = None, totals: Optional[Tensor] = None) -> Optional[Tensor]:
+    def prepare(self, vis_rank: Tensor, cap_rows: int, vis_ids: Optional[Tensor] = None, totals: Optional[Tensor] = None,
+                row_flags: Optional[Tensor] = None) -> Optional[Tensor]:
         """Called by the rasterization between its front end and the colour kernel.  With a row-lazy optimizer attached
         (`self.optimizer`, FusedAdam.set_row_lazy): the UP-TO-DATE coefficient rows of the Gaussians the frame sees, as one
         compact buffer [cap_rows, COEF_STRIDE] that the colour kernel reads instead of the parameters (FusedAdam.peek_rows:
         nothing in the optimizer changes) and that apply_to() hands back to the step.  vis_rank int32 [N]: row or -1.
         Returns the buffer, or None (no optimizer: the colour kernel reads the parameters in place)."""
         self.caught = self.row_ids = None
+        self.row_flags = row_flags
         if self.optimizer is None:
             if any(isinstance(np_[5], Tensor) for np_ in self.node_params):
                 raise RuntimeError("ColorSource: a device traversal_index needs the row-lazy optimizer's peek (ColorSource.optimizer)")
@@ -222,7 +230,7 @@ class ColorSource:
                 items.append((adapters, ro, trav if adapters.dim() == 3 else None, 3, rid))
             if rest.shape[-2] > 0:
                 items.append((rest, ro, trav if rest.dim() == 4 else None, 6, rid))
-        self.optimizer.peek_rows(items, out)
+        self.optimizer.peek_rows(items, out, row_flags=row_flags if vis_ids is not None else None)
         self.row_ids = None if vis_ids is None else (vis_ids, totals)
         self.caught = out
         return out
@@ -255,6 +263,8 @@ class ColorSource:
                     kw["caught"] = (c, col)
                 if ids is not None:
                     kw["row_ids"] = (ids[0], start, ids[1])
+                    if self.row_flags is not None and optimizer is self.optimizer:
+                        kw["row_flags"] = self.row_flags
             return kw
         for start, n, dc, adapters, rest, trav in self.node_params:
             ro = self.row_of[start:start + n]

@@ -50,7 +50,7 @@ import torch
 from ._lib import call, load, ptr, stream_of
 
 _GROUP = np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("g", "<u8"), ("rows", "<u8"), ("row_of", "<u8"), ("catchup", "<u8"),
-                   ("last", "<u8"), ("hist", "<u8"), ("row_ids", "<u8"), ("row_count_dev", "<u8"), ("caught", "<u8"), ("sub_index_dev", "<u8"),
+                   ("last", "<u8"), ("hist", "<u8"), ("row_ids", "<u8"), ("row_count_dev", "<u8"), ("caught", "<u8"), ("sub_index_dev", "<u8"), ("row_flags", "<u8"),
                    ("n", "<i8"), ("first_block", "<i8"), ("row_stride", "<i8"), ("caught_stride", "<i8"), ("item_start", "<i8"), ("n_rows", "<i8"),
                    ("width", "<i4"), ("row_col", "<i4"),
                    ("vec_ok", "<i4"), ("sub_width", "<i4"), ("sub_index", "<i4"), ("mode", "<i4"), ("catchup_k", "<i4"),
@@ -130,7 +130,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- gradient source 2 -------------------------------------------------------------------------------------------
     def set_row_gradient(self, param: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor, col: int = 0,
-                         slice_index: Optional[int] = None, caught=None, row_ids=None, zero_probe: Optional[int] = None) -> None:
+                         slice_index: Optional[int] = None, caught=None, row_ids=None, zero_probe: Optional[int] = None,
+                         row_flags: Optional[torch.Tensor] = None) -> None:
         """For the NEXT step, `param[N, ...]`'s gradient is `rows[row_of[n], col : col + width]` (width = elements per
         Gaussian of param) where row_of[n] >= 0 and zero elsewhere; `rows` float32 [R, stride] (row-contiguous), `row_of`
         int32 [N].  slice_index = t for a per-traversal tensor `param[N, T, ...]`: only `param[:, t]` takes the row (width =
@@ -145,7 +146,11 @@ class FusedAdam(torch.optim.Optimizer):
         zero_probe = c: row-lazy parameters -- a row whose floats rows[r, c : c + 3] are all zero has an all-zero gradient and is
         left lazy by the step (the caller guarantees the implication: ColorSource's rows hold C0 * v_rgb there).  Most
         frustum-visible Gaussians are occluded and get no gradient; skipping them is exact -- the zero-gradient update is what
-        the next catch-up replays.  Cleared by step() / zero_grad()."""
+        the next catch-up replays.
+        row_flags (uint8 [>= R]; row-lazy parameters in the LIST form): rows with a zero flag have a zero gradient BY CONSTRUCTION
+        (the frame composites nothing from them: mtgs_blend_touch_packed) and are left lazy without anything of theirs being
+        read -- unlike zero_probe without a bound on how far behind they fall: the forward that passes the same flags to
+        peek_rows() does not peek them either.  Cleared by step() / zero_grad()."""
         width = param.numel() // max(param.shape[0], 1) if param.dim() else 1
         sub_w, sub_i = 0, 0
         if slice_index is not None:
@@ -169,8 +174,11 @@ class FusedAdam(torch.optim.Optimizer):
                 raise ValueError("set_row_gradient: caught = (float32 [R' >= R, stride], column)")
         if zero_probe is not None and not (0 <= int(zero_probe) and int(zero_probe) + 3 <= rows.shape[1]):
             raise ValueError("set_row_gradient: zero_probe")
+        if row_flags is not None and (row_flags.dtype != torch.uint8 or row_flags.numel() < rows.shape[0] or not row_flags.is_contiguous()
+                                      or row_ids is None):
+            raise ValueError("set_row_gradient: row_flags uint8 [>= R], with row_ids (the LIST form)")
         src = (rows, row_of, int(col), int(rows.stride(0)), int(width), sub_w, sub_i, caught, _check_row_ids(row_ids),
-               -1 if zero_probe is None else int(zero_probe))
+               -1 if zero_probe is None else int(zero_probe), row_flags)
         first = self._rows.get(id(param))
         if first is not None and sub_w > 0 and first[5] > 0 and not isinstance(sub_i, torch.Tensor) and \
                 not isinstance(first[6], torch.Tensor) and sub_i not in [first[6]] + [e[6] for e in self._rows_more.get(id(param), [])]:
@@ -399,15 +407,19 @@ class FusedAdam(torch.optim.Optimizer):
         call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(self._hyper_dev), blocks, 0, 2 if any_list else 0,
              stream_of(todo[0][0]["param"]))
 
-    def peek_rows(self, items, out: torch.Tensor) -> None:
+    def peek_rows(self, items, out: torch.Tensor, row_flags: Optional[torch.Tensor] = None) -> None:
         """items: [(param, row_of int32 [N], slice | None, column[, row_ids])] (row_ids as in set_row_gradient: the fast LIST form)
         -- for every Gaussian with row_of[n] = r >= 0 the UP-TO-DATE row
         of the parameter (its slice) is written to out[r, column : column + width]: row-lazy parameters are caught up in
         registers (nothing in the optimizer changes: a forward stays free of side effects), other tensors are copied.  `out`
         float32 [R, stride]; ranks >= R are skipped.  One launch.  Hand `out` back through set_row_gradient(caught=...) and
-        the step reuses the caught-up parameter values instead of recomputing them."""
+        the step reuses the caught-up parameter values instead of recomputing them.
+        row_flags (uint8 [>= R], LIST-form items only): rows with a zero flag are left alone -- out[r] is NOT written (the caller
+        does not read it: mtgs_blend_touch_packed's flags of the Gaussians the frame composites from)."""
         if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
             raise ValueError("peek_rows: out float32 [R, stride]")
+        if row_flags is not None and (row_flags.dtype != torch.uint8 or row_flags.numel() < out.shape[0] or not row_flags.is_contiguous()):
+            raise ValueError("peek_rows: row_flags uint8 [>= rows of out]")
         todo = []
         for it in items:
             p, ro, t, col = it[0], it[1], it[2], it[3]
@@ -419,13 +431,15 @@ class FusedAdam(torch.optim.Optimizer):
         if built is None:
             return
         tab, blocks, any_list = built
+        if row_flags is not None:
+            tab["row_flags"][tab["row_ids"] != 0] = row_flags.data_ptr()
         dev = out.device
         hyper = self._hyper_dev if self._hyper_dev is not None else torch.zeros(4, dtype=torch.float32, device=dev)
         key = tab.tobytes()
         if key != self._catch_key or torch.cuda.is_current_stream_capturing():
             from .nodes import upload_table
             self._catch_table, self._catch_key = upload_table(tab, dev), key
-        self._peek_keep = (out, hyper)
+        self._peek_keep = (out, hyper, row_flags)
         call("mtgs_adam_step", len(tab), ptr(self._catch_table), ptr(hyper), blocks, 0, 2 if any_list else 0, stream_of(out))
 
     def _flush_rows(self) -> None:
@@ -526,7 +540,7 @@ class FusedAdam(torch.optim.Optimizer):
                 align |= g.data_ptr()
                 keep.append(g)
             if src is not None:         # (with a dense gradient too: the kernel adds them)
-                rows, row_of, col, stride, width, sub_w, sub_i, caught, rid, probe = src
+                rows, row_of, col, stride, width, sub_w, sub_i, caught, rid, probe, rflags = src
                 r["rows"], r["row_of"], r["row_col"], r["row_stride"], r["width"] = rows.data_ptr(), row_of.data_ptr(), col, stride, width
                 r["n_rows"] = rows.shape[0]
                 r["sub_width"] = sub_w
@@ -552,6 +566,9 @@ class FusedAdam(torch.optim.Optimizer):
                     r["row_count_dev"] = 0 if count is None else count.data_ptr()
                     lists.append((start, min(int(rows.shape[0]), int(ids.numel()))))     # (workgroups: assigned on the device)
                     keep.append((ids, count))
+                    if src[10] is not None:
+                        r["row_flags"] = src[10].data_ptr()
+                        keep.append(src[10])
                     self._list_groups = True
                 else:
                     fb += -(-int(p.shape[0]) // load().mtgs_adam_block_rows())

@@ -619,6 +619,21 @@ class _FusedRasterization(torch.autograd.Function):
                 raise RuntimeError("rasterization(): mtgs_amd.graph_mode is active on another thread (fixed capacities, no host "
                                    "read-back); serialise the two callers or leave graph_mode first")
 
+            # TOUCH FIRST (ColorSource.touch_first, opt-in): the binning needs the records' geometry only, so it runs in front of the
+            # colours, and one pass of the compositing DECISIONS (mtgs_blend_touch_packed) flags the Gaussians the frame composites
+            # from -- a few percent of the visible ones in an opaque scene.  Peek, SH evaluation and normals work on those alone.
+            touch_first = cs is not None and bool(cs.touch_first)
+
+            def colours(b, flags):   # colours of the visible Gaussians, straight into their records
+                cap_vis = b["cap_vis"]
+                coef = cs.prepare(vis_rank, cap_vis, b["vis_ids"], totals, row_flags=flags)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
+                call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
+                     ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), ptr(coef), 0 if coef is None else coef.stride(0),
+                     ptr(flags), st)
+                if n2c is not None:  # ... and their camera-space normals (channels 3..5)
+                    call("mtgs_normals_fwd_rows", cap_vis, ptr(b["vis_ids"]), ptr(totals), ptr(quats), ptr(scales), ptr(means),
+                         ptr(n2c), ptr(b["recs"]), 3, ptr(flags), st)
+
             def front(cap_vis, repeat=False):
                 # repeat=True: the capacity-overflow repeat of a frame.  The visibility map / row count of the exchange do not
                 # depend on cap_vis and are already on their way: they are neither rewritten nor gathered a second time
@@ -637,13 +652,8 @@ class _FusedRasterization(torch.autograd.Function):
                      (1 if dp is not None else 0) if cs is None else (3 if c_open == 6 else 2), ptr(totals),
                      None if mailbox is None else mailbox.data_ptr(), tag,
                      ptr(front_ws), front_bytes, st)
-                if cs is not None:   # colours of the visible Gaussians, straight into their records
-                    coef = cs.prepare(vis_rank, cap_vis, b["vis_ids"], totals)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
-                    call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
-                         ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), ptr(coef), 0 if coef is None else coef.stride(0), st)
-                    if n2c is not None:  # ... and their camera-space normals (channels 3..5)
-                        call("mtgs_normals_fwd_rows", cap_vis, ptr(b["vis_ids"]), ptr(totals), ptr(quats), ptr(scales), ptr(means),
-                             ptr(n2c), ptr(b["recs"]), 3, st)
+                if cs is not None and not touch_first:
+                    colours(b, None)
                 b["mailbox"], b["tag"] = mailbox, tag
                 if dpf is not None:
                     dpf.after_front()      # the visibility maps travel while this frame is composited
@@ -663,6 +673,11 @@ class _FusedRasterization(torch.autograd.Function):
                      ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), int(bool(tight_lists)),
                      ws.data_ptr() + off,
                      nbytes.value, st)
+                if touch_first:
+                    flags = torch.empty(max(b["cap_vis"], 1), dtype=torch.uint8, device=dev)
+                    call("mtgs_blend_touch_packed", Cn, ptr(b["recs"]), width, height, tw, th, ptr(offsets_buf), ptr(out["rank_ids"]),
+                         ptr(order), ptr(flags), b["cap_vis"], st)
+                    colours(b, flags)
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
                      ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), st)
                 return out

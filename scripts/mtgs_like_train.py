@@ -229,6 +229,7 @@ def iteration(P, cam, gt, mask, fused, stats, win, W, H, n=3, shipped=None):
             torch.cat([colors, normals_chain(gs, c2w)], dim=-1)       # (visibility first: rgbs = None -> the normals alone)
     if VISFIRST["cs"] is not None and ROWLAZY["on"]:
         VISFIRST["cs"].optimizer = ROWLAZY["opt"]      # the coefficient rows this frame sees are caught up before they are read
+        VISFIRST["cs"].touch_first = bool(TOUCH["on"])         # (--touch-first on / auto: train_loop's policy per stretch)
     render, alpha, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], colors, vm, K, W, H,
                                         packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True,
                                         **({"color_source": VISFIRST["cs"]} if vf else {}))
@@ -555,6 +556,7 @@ def enable_row_lazy(opt, P, carry=None):
     return opt
 
 
+TOUCH = {"on": False, "mode": "off"}   # ColorSource.touch_first for the frames to come (--touch-first; auto: decided per stretch)
 ANY = "any traversal"      # key of the one graph that serves every traversal (train_loop(one_graph=True))
 
 
@@ -608,6 +610,20 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
 
     def make_opt():
         return make_optimizer(optimizer, P, shipped)
+
+    def touch_policy(after_reset=False):
+        """ColorSource.touch_first for the next stretch: one more pass of the compositing decisions (about one forward) finds the
+        Gaussians a frame composites FROM, and the optimizer's peek / step, the SH evaluation and the normals leave the others
+        alone -- worth it when most visible Gaussians are hidden (an opaque scene: 2-9 % carry a gradient), not while the model is
+        translucent (right after an opacity reset; a perturbed start).  Measured on the last frame's gradient rows."""
+        cs = VISFIRST["cs"]
+        if not (ROWLAZY["on"] and cs is not None and cs.rows is not None) or TOUCH["mode"] != "auto":
+            return
+        n_vis = int((cs.row_of >= 0).sum())
+        frac = float((cs.rows[:n_vis, 0:3] != 0).any(1).sum()) / max(n_vis, 1)
+        TOUCH["on"] = (frac < 0.35) and not after_reset
+        log(f"touch-first {'on' if TOUCH['on'] else 'off'}: {100 * frac:.1f} % of the {n_vis} visible Gaussians carry a gradient"
+            + (" (opacity reset: off for this stretch)" if after_reset else ""))
 
     opt = enable_dp_rows(enable_row_lazy(make_opt(), P), P)
     mk = lambda: [[torch.zeros(p["means"].shape[0], device=p["means"].device), torch.ones(p["means"].shape[0], device=p["means"].device),
@@ -689,6 +705,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             eager_left -= 1
             if eager_left <= 0:
                 caps = plan_caps()
+                touch_policy()
             return loss
         if one_graph:          # one graph for every traversal: the traversal goes in through the device word
             t_dev.fill_(c)
@@ -775,6 +792,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             loss_hist[i].copy_(graph_step(i % T))
             poll_overflow(i)
         else:
+            if i == T and world == 1 and accumulate == 1:
+                touch_policy()
             opt.zero_grad(set_to_none=True)
             losses = []
             for a in range(accumulate):
@@ -832,6 +851,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             del old_opt
             sizes.append(sum(p["means"].shape[0] for p in P.values()))
             ex = mk_ex()                      # N changed: new send buffers and visibility maps
+            touch_policy(after_reset=refine_cfg is not None and
+                         (i + 1) % (refine_cfg.reset_alpha_every * refine_cfg.refine_every) == refine_cfg.refine_every)
             if graph:                         # new parameters: new graphs, capacities scaled by the growth of N
                 graphs.clear()
                 ovf_ev = None
@@ -902,6 +923,10 @@ def main():
                     "(torch.cuda.graph + mtgs_amd.graph_mode): wall time per iteration vs its GPU time")
     ap.add_argument("--train-graph", action="store_true", help="with --steps: TRAIN through HIP graphs (one per traversal, re-captured "
                     "after every refinement, overflow polled without a host wait; train_loop(graph=True))")
+    ap.add_argument("--touch-first", choices=("off", "on", "auto"), default="off", help="with --visfirst --row-lazy: ColorSource.touch_first "
+                    "(one more pass of the compositing decisions flags the Gaussians a frame composites from; peek / SH / normals for those "
+                    "alone); auto: per stretch, on while fewer than 35 %% of the visible Gaussians carry a gradient and no opacity reset "
+                    "has just happened")
     ap.add_argument("--one-graph", action="store_true", help="with --train-graph --visfirst --row-lazy: the traversal is a DEVICE word, "
                     "one graph per stretch serves every traversal (train_loop(one_graph=True))")
     ap.add_argument("--converge", action="store_true", help="with --steps: the training problem with something to learn and the "
@@ -935,6 +960,7 @@ def main():
     if args.train_graph and not args.steps:
         raise SystemExit("--train-graph needs --steps")
     VISFIRST["on"] = bool(args.visfirst)
+    TOUCH["mode"], TOUCH["on"] = args.touch_first, args.touch_first == "on"
     REGS["on"] = bool(args.regularizers)
     DPROWS["on"] = bool(args.dp_rows)
     if args.dp_rows and not (args.dp and args.dp_exchange == "sparse" and args.optimizer in (None, "fused")):

@@ -70,7 +70,7 @@ def test_descriptor_tables_match_the_c_structs(hip_lib):
     from mtgs_amd import loss
     assert hip_lib.mtgs_oob_desc_bytes() == loss._OOB_DESC.itemsize == 64
     from mtgs_amd import optim
-    assert hip_lib.mtgs_adam_group_bytes() == optim._GROUP.itemsize == 224
+    assert hip_lib.mtgs_adam_group_bytes() == optim._GROUP.itemsize == 232
     header = (ROOT / "include" / "mtgs_rast.h").read_text()
 
     def c_fields(name):
@@ -101,7 +101,7 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
     src = tmp_path / "h.c"
     src.write_text('#include "mtgs_rast.h"\n'
                    'int main(void) { return sizeof(mtgs_node_desc) == 312 && sizeof(mtgs_stats_desc) == 48 && '
-                   'sizeof(mtgs_oob_desc) == 64 && sizeof(mtgs_adam_group) == 224 ? 0 : 1; }\n')
+                   'sizeof(mtgs_oob_desc) == 64 && sizeof(mtgs_adam_group) == 232 ? 0 : 1; }\n')
     exe = tmp_path / "h"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0

@@ -579,6 +579,62 @@ def test_row_lazy_one_graph_for_every_traversal_through_a_device_slice(hip_lib):
         ob.set_row_gradient(Pb["rest"], rows_s, row_of_s, 3, slice_index=torch.zeros((), dtype=torch.int64, device=dev))
 
 
+def test_row_flags_leave_the_rows_nothing_is_composited_from_alone(hip_lib):
+    """row_flags (the flags of mtgs_blend_touch_packed: the Gaussians a frame composites FROM): peek_rows() requests nothing of
+    the rows with a zero flag and does not write their rows of the buffer; step() takes the parameter of a flagged row from the
+    buffer and treats the others by the zero_probe rule (zero gradient: left lazy while fewer than 4 T steps behind, then committed
+    from the parameter itself).  Over a random sequence with 15 % of the visible rows flagged: (1) the peeked rows of the FLAGGED
+    Gaussians are the every-row optimizer's parameters, (2) unflagged rows of the peek buffer stay untouched, (3) after flush()
+    parameters and moments are bit-identical, (4) the lazy optimizer really left unflagged rows behind."""
+    dev = torch.device("cuda")
+    N, T = 4001, 3
+    g = torch.Generator().manual_seed(31)
+    base, make = _row_lazy_case(dev, N, T, g)
+    Pa, oa = make(False)
+    Pb, ob = make(True, hist_capacity=8)
+    seq = [0, 1, 2, 2, 0, 1, 1, 2, 0, 0, 1, 2, 2, 0, 1, 0]
+    ids_all = torch.arange(N, dtype=torch.int32, device=dev)
+    skipped_some = False
+    for step, t in enumerate(seq):
+        vis, row_of, rows = _frame(N, g, dev, frac=0.3)
+        R = rows.shape[0]
+        flags = (torch.rand(R, generator=g) < 0.15).to(torch.uint8).to(dev)
+        rows = rows * flags[:, None].float()                     # an unflagged row has a zero gradient
+        vis_ids = ids_all[vis].contiguous()                      # the frame's visible Gaussians in increasing order
+        count = torch.tensor([R << 32], dtype=torch.int64, device=dev)
+        rid = (vis_ids, 0, count)
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-2 * 0.93 ** step
+        C = torch.full((R, 56), float("nan"), device=dev)
+        ob.peek_rows([(Pb["dc"], row_of, None, 0, rid), (Pb["adapters"], row_of, t, 3, rid), (Pb["rest"], row_of, t, 6, rid)], C,
+                     row_flags=flags)
+        on = flags.bool()
+        sel = vis_ids[on].long()
+        assert torch.equal(C[on, 0:3], Pa["dc"][sel]) and torch.equal(C[on, 3:6], Pa["adapters"][sel, t]), step            # (1)
+        assert torch.equal(C[on, 6:51], Pa["rest"][sel, t].reshape(-1, 45)), step
+        assert torch.isnan(C[~on, :51]).all(), step                                                                        # (2)
+        grad_means = (torch.randn(N, 3, generator=g) * 0.1).to(dev)
+        Pa["means"].grad, Pb["means"].grad = grad_means.clone(), grad_means.clone()
+        oa.set_row_gradient(Pa["dc"], rows, row_of, 0)
+        oa.set_row_gradient(Pa["adapters"], rows, row_of, 0, slice_index=t)
+        oa.set_row_gradient(Pa["rest"], rows, row_of, 3, slice_index=t)
+        oa.step()
+        kw = lambda col: {"caught": (C, col), "row_ids": rid, "row_flags": flags, "zero_probe": 0}
+        ob.set_row_gradient(Pb["dc"], rows, row_of, 0, **kw(0))
+        ob.set_row_gradient(Pb["adapters"], rows, row_of, 0, slice_index=t, **kw(3))
+        ob.set_row_gradient(Pb["rest"], rows, row_of, 3, slice_index=t, **kw(6))
+        ob.step()
+        assert torch.equal(Pa["rest"][sel, t], Pb["rest"][sel, t]) and torch.equal(Pa["dc"][sel], Pb["dc"][sel]), step
+        off = vis_ids[~on].long()
+        skipped_some = skipped_some or not torch.equal(Pa["rest"][off, t], Pb["rest"][off, t])                             # (4)
+    assert skipped_some
+    ob.flush()
+    for k in base:
+        assert torch.equal(Pa[k], Pb[k]), k                                                                                # (3)
+        assert torch.equal(oa.state[Pa[k]]["exp_avg"], ob.state[Pb[k]]["exp_avg"]), k
+        assert torch.equal(oa.state[Pa[k]]["exp_avg_sq"], ob.state[Pb[k]]["exp_avg_sq"]), k
+
+
 def test_row_lazy_adam_long_gaps_settle_without_changing_a_bit(hip_lib):
     """Rows unseen for thousands of steps: exp_avg reaches a fixed point of the zero-gradient recurrence and the catch-up
     switches to its one-multiplication step (csrc/adam.hip) -- the result must still be bit-identical to stepping every row

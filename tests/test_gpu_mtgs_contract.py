@@ -351,10 +351,22 @@ _CONVERGE = ["--shipped", "--visfirst", "--optimizer", "fused", "--row-lazy", "-
              "--converge", "--grad-thresh", "1e-3", "--clear-radius", "12"]
 
 
+def _release_cached_gpu_memory():
+    """The child processes share this box's one GPU with the pytest process, whose caching allocator still holds what earlier
+    tests used (tens of GB behind tests/test_gpu_large.py): eight ranks of configs[4] then run out of memory."""
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
 def _run_train(extra, timeout=900):
     import subprocess
     import sys
     from pathlib import Path
+    _release_cached_gpu_memory()
     root = Path(__file__).resolve().parents[1]
     r = subprocess.run([sys.executable, str(root / "scripts" / "mtgs_like_train.py")] + extra, capture_output=True, text=True,
                        timeout=timeout, cwd=str(root))
@@ -439,6 +451,7 @@ def _torchrun(nproc, extra, timeout=2400):
     import subprocess
     import sys
     from pathlib import Path
+    _release_cached_gpu_memory()
     root = Path(__file__).resolve().parents[1]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -401,6 +401,64 @@ def test_visibility_first_colours_equal_the_dense_node_path(hip_lib, degree, ext
     assert torch.equal(Pv[1]["features_rest"][:, 0].detach().cpu(), raw[1]["features_rest"][:, 0])
 
 
+@pytest.mark.parametrize("inside,dense_scene", [(False, False), (True, True)])
+def test_touch_first_changes_no_pixel_and_finds_exactly_the_rows_with_a_gradient(hip_lib, inside, dense_scene):
+    """ColorSource.touch_first: the rasterization bins first, one pass of the compositing DECISIONS (mtgs_blend_touch_packed) flags
+    the Gaussians the frame composites from, and the SH evaluation / normals run for those alone (the others get a constant: their
+    weight is zero wherever the compositing meets them).  Against the same call without the pass: render and alphas BIT-identical,
+    the same gradient rows; a Gaussian without the flag has an all-zero gradient row, and (random cotangents) every flagged one a
+    non-zero one -- the flags ARE the set of rows that receive a gradient."""
+    from mtgs_amd import rasterization, wrapper
+    from mtgs_amd.nodes import collect_gaussians
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    W, H, T, t = 320, 200, 3, 2
+    g = torch.Generator().manual_seed(77)
+    n = 60_000 if dense_scene else 12_000
+    raw = {"means": (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([8.0, 2.0, 8.0]) + torch.tensor([0.0, 0.0, 6.0]),
+           "scales": torch.log(torch.rand(n, 3, generator=g) * (0.5 if dense_scene else 0.2) + 0.03), "quats": torch.randn(n, 4, generator=g),
+           "opacities": torch.randn(n, 1, generator=g) + (2.0 if dense_scene else 0.0), "features_dc": torch.randn(n, 3, generator=g) * 0.7,
+           "features_rest": torch.randn(n, T, 15, 3, generator=g) * 0.2, "features_adapters": torch.randn(n, T, 3, generator=g) * 0.1}
+    vm, K = make_camera(W, H)
+    vm, K = vm.to(dev), K.to(dev)
+    c2w = torch.inverse(vm)[:, :3, :]
+    D = 7 if inside else 4
+    Gc, Ga = torch.randn(1, H, W, D, generator=g).to(dev), torch.randn(1, H, W, 1, generator=g).to(dev)
+
+    def run(touch):
+        P = {k: v.clone().to(dev).requires_grad_(True) for k, v in raw.items()}
+        gs = collect_gaussians([dict(P, traversal_index=t)], c2w, 3, deferred_colors=True)
+        cs = gs["color_source"]
+        cs.touch_first = touch
+        if inside:
+            cs.camera_normals = c2w[0].contiguous()
+        dbg = {}
+        wrapper._debug_rows = dbg
+        try:
+            r, a, info = rasterization(gs["means"], gs["quats"], gs["scales"], gs["opacities"], None, vm, K, W, H, packed=False,
+                                       render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True, color_source=cs)
+            torch.autograd.backward([r, a], [Gc, Ga])
+        finally:
+            wrapper._debug_rows = None
+        return P, r.detach(), a.detach(), info, cs, dbg["G"]
+
+    P0, r0, a0, i0, cs0, G0 = run(False)
+    P1, r1, a1, i1, cs1, G1 = run(True)
+    assert cs0.row_flags is None and cs1.row_flags is not None
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)
+    n_vis = int((i0["radii"] > 0).sum())
+    flags = cs1.row_flags[:n_vis].bool()
+    assert 0 < int(flags.sum()) < n_vis
+    if dense_scene:
+        assert int(flags.sum()) < 0.6 * n_vis, (int(flags.sum()), n_vis)       # an opaque scene hides most of what is in the frustum
+    nz0, nz1 = (G0[:n_vis] != 0).any(1), (G1[:n_vis] != 0).any(1)
+    assert not bool(nz1[~flags].any()) and not bool(nz0[~flags].any())          # no flag: no gradient, with or without the pass
+    assert int((flags & ~nz1).sum()) <= max(2, n_vis // 2000)                   # a flag: a gradient (random cotangents)
+    assert float((cs0.rows[:n_vis] - cs1.rows[:n_vis]).abs().max()) <= 2e-4 * float(cs0.rows[:n_vis].abs().max())
+    for k in ("means", "scales", "quats", "opacities"):
+        assert float((P0[k].grad - P1[k].grad).abs().max()) <= 2e-4 * float(P0[k].grad.abs().max()) + 1e-9, k
+
+
 def test_geometry_rows_equal_the_dense_geometry_gradients(hip_lib):
     """ColorSource.geometry_rows: the rasterization returns no gradient for means / quats / scales / opacities; the projection
     backward's per-visible rows go through mtgs_node_bwd_rows (exp / normalise / sigmoid VJPs) and reach the optimizer as row
