@@ -415,6 +415,157 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
     }
 }
 
+// ---- every colour group of a step in ONE pass (mtgs_dp_reduce_rows_groups) ----------------------------------------------
+// A data-parallel step of MTGS renders several traversals: the senders of traversal t sum into slice t of the per-traversal colour
+// tensors, all senders into the geometry.  One launch of dp_reduce_kernel<.., true> per traversal walks all N / 32 tiles each time
+// (clearing accumulators, loading the tile's means and every sender's span, writing a row map over all N) -- at eight traversals
+// the fixed part is paid eight times (968 us at 2M Gaussians against 323 us for one).  Here a wave walks its tile ONCE: first the
+// geometry of ALL senders in rank order (the order of the dense reduction: the sums are bit-identical to it), then the groups
+// (sender sets, one per rendered traversal) take turns on the colour accumulators, each summing its senders in rank order as its
+// own pass would.  A sender's rows are read twice in total, as with one pass per group.
+template <int MAXDEG>
+__global__ __launch_bounds__(256) void dp_reduce_groups_kernel(int64_t g_begin, int64_t g_end, int K, int nb,
+                                                               const float *__restrict__ means, const DpSenders S, int n_groups,
+                                                               const mtgs_dp_group *__restrict__ groups, int64_t coeff_stride,
+                                                               const DpRowOut R) {
+    __shared__ float4 s_acc[4][DP_TILE][16];
+    __shared__ float s_mean[4][DP_TILE * 3];
+    __shared__ int2 s_span[4][DP_MAX_SENDERS];
+    const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4, wave = threadIdx.x >> 6;
+    const int64_t tile = g_begin / DP_TILE + (int64_t)blockIdx.x * 4 + wave;
+    const int64_t g0 = tile * DP_TILE;
+    if (g0 >= g_end) return;
+    const int64_t N = g_end;
+    const int64_t wi = g0 >> 6;
+    const int half = (int)(tile & 1);
+    ShLaneConst lc = sh_lane_const(k);
+    if (k >= nb) { lc.a0 = 0.f; lc.a1 = 0.f; lc.a2 = 0.f; lc.a3 = 0.f; }
+    float4(*acc)[16] = s_acc[wave];
+#pragma unroll
+    for (int it = 0; it < DP_MAXSTEP; ++it) acc[it * 4 + sub][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *tmean = s_mean[wave];
+    for (int e = lane; e < DP_TILE * 3; e += 64) tmean[e] = g0 * 3 + e < N * 3 ? means[g0 * 3 + e] : 1.f;
+    if (lane < S.W) {
+        const char *wp = reinterpret_cast<const char *>(S.words) + lane * S.map_stride_bytes;
+        const char *pp = reinterpret_cast<const char *>(S.prefix) + lane * S.map_stride_bytes;
+        const unsigned long long wv = reinterpret_cast<const unsigned long long *>(wp)[wi];
+        const unsigned lo = (unsigned)wv, hi = (unsigned)(wv >> 32);
+        const uint32_t p_w = reinterpret_cast<const uint32_t *>(pp)[wi], p_0 = reinterpret_cast<const uint32_t *>(pp)[S.word0];
+        const int start = (int)(p_w - p_0) + (half ? __builtin_popcount(lo) : 0);
+        s_span[wave][lane] = make_int2(start, __builtin_popcount(half ? hi : lo));
+    }
+    const int row_lane0 = (lane & ~15) << 2;
+    auto issue = [&](int r, float (&dst)[DP_MAXSTEP], int &cnt_out) {
+        const int2 sp = s_span[wave][r];
+        const int start = __builtin_amdgcn_readfirstlane(sp.x);
+        int cnt = __builtin_amdgcn_readfirstlane(sp.y);
+        if (S.row_stride > 0) {
+            const int64_t room = S.row_stride / 16 - (int64_t)start;
+            cnt = room <= 0 ? 0 : (cnt < room ? cnt : (int)room);
+        }
+        cnt_out = cnt;
+        const float *rows_r = S.rows + (int64_t)r * S.row_stride + (int64_t)start * 16;
+#pragma unroll
+        for (int st = 0; st < DP_MAXSTEP; ++st) {
+            const int j = st * 4 + sub;
+            dst[st] = j < cnt ? rows_r[j * 16 + k] : 0.f;
+        }
+    };
+    // the senders of `mask`, in rank order, software-pipelined as in dp_reduce_kernel.  (ONE pipeline over the whole schedule --
+    // geometry, then group after group, the next pair's rows in flight across the phase boundaries -- measured SLOWER: 930 against
+    // 780 us at eight groups; its bookkeeping costs more registers and branches than the eight pipeline refills.)
+    auto walk = [&](unsigned long long mask, bool geom, bool colour) {
+        auto next_in = [&](int r) {
+            while (r < S.W && !((mask >> r) & 1ull)) ++r;
+            return r;
+        };
+        float nxt[DP_MAXSTEP];
+        int nxt_cnt = 0;
+        int r_next = next_in(0);
+        if (r_next < S.W) issue(r_next, nxt, nxt_cnt);
+        for (int r = r_next; r < S.W; r = r_next) {
+            float cur[DP_MAXSTEP];
+#pragma unroll
+            for (int st = 0; st < DP_MAXSTEP; ++st) cur[st] = nxt[st];
+            const int cnt = nxt_cnt;
+            r_next = next_in(r + 1);
+            if (r_next < S.W) issue(r_next, nxt, nxt_cnt);
+            if (cnt == 0) continue;
+            const float cx = S.cams[r * 3], cy = S.cams[r * 3 + 1], cz = S.cams[r * 3 + 2];
+#pragma unroll
+            for (int st = 0; st < DP_MAXSTEP; ++st) {
+                if (st * 4 >= cnt) break;
+                const bool on = st * 4 + sub < cnt;
+                const int vi = __float_as_int(cur[st]);
+                const int idx = __builtin_amdgcn_ds_bpermute(row_lane0 + 15 * 4, vi);
+                const int pos = on ? (int)(idx - (int)g0) : 0;
+                float4 a = acc[pos][k];
+                a.x += (geom && k < 14) ? cur[st] : 0.f;
+                if (colour) {
+                    const float q0 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 11 * 4, vi));
+                    const float q1 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 12 * 4, vi));
+                    const float q2 = __int_as_float(__builtin_amdgcn_ds_bpermute(row_lane0 + 13 * 4, vi));
+                    float x = tmean[pos * 3] - cx, y = tmean[pos * 3 + 1] - cy, z = tmean[pos * 3 + 2] - cz;
+                    const float inorm = __builtin_amdgcn_rsqf((x * x + y * y) + z * z);
+                    x *= inorm; y *= inorm; z *= inorm;
+                    const float bk = sh_lane_basis<MAXDEG>(lc, x, y, z);
+                    a.y += bk * q0; a.z += bk * q1; a.w += bk * q2;
+                }
+                if (on) acc[pos][k] = a;
+            }
+        }
+    };
+    const unsigned long long all = S.W >= 64 ? ~0ull : ((1ull << S.W) - 1ull);
+    if (R.geo_rows) walk(all, true, false);
+    for (int j = 0; j < n_groups; ++j) {
+        const mtgs_dp_group G = groups[j];
+        if (j > 0) {       // the colour accumulators start from zero for every group; the geometry sums stay
+#pragma unroll
+            for (int it = 0; it < DP_MAXSTEP; ++it) {
+                float4 a = acc[it * 4 + sub][k];
+                a.y = 0.f; a.z = 0.f; a.w = 0.f;
+                acc[it * 4 + sub][k] = a;
+            }
+        }
+        walk(G.mask & all, false, true);
+        const unsigned long long uwc = G.coef_words[wi];
+        const int64_t upc = (int64_t)G.coef_prefix[wi];
+#pragma unroll
+        for (int it = 0; it < DP_MAXSTEP; ++it) {
+            const int64_t n = g0 + it * 4 + sub;
+            if (n >= N) continue;
+            const int bit = (int)(n & 63);
+            const bool present = (uwc >> bit) & 1ull;
+            const int64_t u = upc + __popcll(uwc & ((1ull << bit) - 1ull));
+            if (k == 0) G.coef_row_of[n] = present ? (int32_t)u : -1;
+            if (present && u < G.coef_cap && k < K) {
+                const float4 a = acc[it * 4 + sub][k];
+                float *dst = G.coef_rows + u * coeff_stride + k * 3;
+                dst[0] = a.y; dst[1] = a.z; dst[2] = a.w;
+            }
+        }
+    }
+    if (R.geo_rows) {
+        const unsigned long long uwg = R.geo_words[wi];
+        const int64_t upg = (int64_t)R.geo_prefix[wi];
+#pragma unroll
+        for (int it = 0; it < DP_MAXSTEP; ++it) {
+            const int64_t n = g0 + it * 4 + sub;
+            if (n >= N) continue;
+            const int bit = (int)(n & 63);
+            const bool present = (uwg >> bit) & 1ull;
+            const int64_t u = upg + __popcll(uwg & ((1ull << bit) - 1ull));
+            const float4 a = acc[it * 4 + sub][k];
+            if (k == 0) R.geo_row_of[n] = present ? (int32_t)u : -1;
+            if (present && u < R.geo_cap) {
+                const float v = k < 11 ? a.x : (k < 14 ? kShC0 * a.x : (k == 15 ? __int_as_float((int)n) : 0.f));
+                R.geo_rows[u * 16 + k] = v;
+                if (k == 15) R.geo_ids[u] = (int32_t)n;
+            }
+        }
+    }
+}
+
 // Union maps of sender subsets (mtgs_dp_union): launch 1 ORs the senders' visibility words per subset and counts the set bits
 // per 256-word block; launch 2 turns the counts into word prefixes (every block sums the few hundred counts in front of it, as
 // dp_pack_ordered_kernel does) and publishes the totals, packed like mtgs_front_fwd's totals (count << 32).
@@ -601,6 +752,39 @@ extern "C" int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float
     dp_pack_ordered_kernel<<<grid, VIS_BLOCK, 0, st>>>(N, (const unsigned long long *)words, block_counts, prefix, count,
                                                       v_means, v_quats, v_scales, v_opacities, v_rgb, rows, capacity);
     MTGS_CHECK_LAUNCH("mtgs_dp_pack_ordered");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_dp_reduce_rows_groups(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                                          const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
+                                          const float *cams, int64_t g_begin, int64_t g_end, int n_groups, const mtgs_dp_group *groups,
+                                          float *geo_rows, const uint64_t *geo_words, const uint32_t *geo_prefix, int32_t *geo_row_of,
+                                          int32_t *geo_ids, int64_t geo_cap, int64_t coef_stride, void *stream) {
+    MTGS_REQUIRE(W >= 1 && N >= 0 && map_stride_bytes >= 0 && row_stride >= 0 && geo_cap >= 0 && n_groups >= 1, MTGS_EINVAL,
+                 "mtgs_dp_reduce_rows_groups: bad sizes");
+    MTGS_REQUIRE(W <= DP_MAX_SENDERS, MTGS_EUNSUPPORTED, "mtgs_dp_reduce_rows_groups: %d senders (at most %d)", W, DP_MAX_SENDERS);
+    if (g_end < 0) g_end = N;
+    MTGS_REQUIRE(g_begin >= 0 && g_begin <= g_end && g_end <= N && (g_begin % 64) == 0, MTGS_EINVAL,
+                 "mtgs_dp_reduce_rows_groups: range [%lld, %lld) of %lld (the start must be a multiple of 64)", (long long)g_begin,
+                 (long long)g_end, (long long)N);
+    if (g_end == g_begin) return MTGS_OK;
+    MTGS_REQUIRE(words && prefix && rows && means && cams && groups, MTGS_EINVAL, "mtgs_dp_reduce_rows_groups: null pointer");
+    MTGS_REQUIRE(!geo_rows || (geo_words && geo_prefix && geo_row_of && geo_ids), MTGS_EINVAL, "mtgs_dp_reduce_rows_groups: geometry outputs");
+    MTGS_REQUIRE(degree >= 0 && degree <= 3 && K <= 16 && (degree + 1) * (degree + 1) <= K && coef_stride >= (int64_t)K * 3,
+                 MTGS_EUNSUPPORTED, "mtgs_dp_reduce_rows_groups: degree %d / K %d / stride %lld", degree, K, (long long)coef_stride);
+    const int nb = (degree + 1) * (degree + 1);
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
+    const DpRowOut R{geo_rows, (const unsigned long long *)geo_words, geo_prefix, geo_row_of, geo_ids, geo_cap, nullptr, nullptr, nullptr,
+                     nullptr, 0};
+    const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+        case 0: dp_reduce_groups_kernel<0><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, n_groups, groups, coef_stride, R); break;
+        case 1: dp_reduce_groups_kernel<1><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, n_groups, groups, coef_stride, R); break;
+        case 2: dp_reduce_groups_kernel<2><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, n_groups, groups, coef_stride, R); break;
+        default: dp_reduce_groups_kernel<3><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, n_groups, groups, coef_stride, R); break;
+    }
+    MTGS_CHECK_LAUNCH("mtgs_dp_reduce_rows_groups");
     return MTGS_OK;
 }
 

@@ -130,6 +130,10 @@ def all_reduce_grads(params: Sequence[torch.Tensor], average: bool = False, grou
     return nbytes
 
 
+_DP_GROUP = np.dtype([("mask", "<u8"), ("coef_rows", "<u8"), ("coef_words", "<u8"), ("coef_prefix", "<u8"), ("coef_row_of", "<u8"),
+                      ("coef_cap", "<i8")])       # include/mtgs_rast.h: mtgs_dp_group
+
+
 class SparseGradExchange:
     """Sparse, factored replacement for the dense gradient all-reduce of view-parallel DP.
 
@@ -168,6 +172,7 @@ class SparseGradExchange:
         # tests: issue the collectives also in a one-rank group (normally short-cut), so that the RCCL code path of the
         # integrated form executes on a single-GPU box
         self.world_collectives = False
+        self.grouped_receiver = True     # finish(rows=True): all colour groups + the geometry in one launch per chunk
         N = self.N
         # chunk boundaries of the index range (multiples of 2048, so that they are visibility-word and tile aligned)
         per = -(-max(N, 1) // max(int(chunks), 1))
@@ -380,6 +385,14 @@ class SparseGradExchange:
             if all_colour_ranges:
                 R["coef_all"] = (new(max(caps[0], 1), 3 * K), new(N, dt=torch.int32))
             out = R
+            group_tab = None
+            if present:      # every rendered traversal's colour group + the geometry in ONE launch per chunk (mtgs_dp_reduce_rows_groups)
+                from .nodes import upload_table
+                gt = np.zeros(len(present), dtype=_DP_GROUP)
+                for j, t in enumerate(present):
+                    gt[j] = (masks[t], R["coef"][t][0].data_ptr(), uw[1 + j].data_ptr(), up[1 + j].data_ptr(), R["coef"][t][1].data_ptr(),
+                             R["coef"][t][0].shape[0])
+                group_tab = upload_table(gt, dev)
         if rows != True:      # noqa: E712  (False: dense only; "both": the dense tensors beside the rows, from the same wire data: tests)
             out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
                    torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
@@ -429,8 +442,13 @@ class SparseGradExchange:
                          coef[0].shape[0] if coef else 0, 3 * K, st)
                 if not present:
                     reduce_rows(0, True, None, 0)
-                for j, t in enumerate(present):      # the first traversal's pass also sums the geometry over all ranks
-                    reduce_rows(masks[t], j == 0, R["coef"][t], 1 + j)
+                elif self.grouped_receiver and len(present) > 1:
+                    call("mtgs_dp_reduce_rows_groups", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all),
+                         self.meta_len * 4, ptr(recvs[c]), rs, ptr(cams), gb, ge, len(present), ptr(group_tab), ptr(R["geo_rows"]),
+                         ptr(uw[0]), ptr(up[0]), ptr(R["geo_row_of"]), ptr(R["geo_ids"]), R["geo_rows"].shape[0], 3 * K, st)
+                else:
+                    for j, t in enumerate(present):      # the first traversal's pass also sums the geometry over all ranks
+                        reduce_rows(masks[t], j == 0, R["coef"][t], 1 + j)
                 if R["coef_all"] is not None:        # nodes whose colour parameters the traversals share: all ranks, their index range
                     if c == 0:
                         R["coef_all"][1].fill_(-1)

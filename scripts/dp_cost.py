@@ -98,8 +98,20 @@ for world in (2, 4, 8):
                      cap * 16, ptr(cams), 0, -1, C.c_uint64(masks[1 + j]), ptr(geo_rows) if j == 0 else None, ptr(uw[0]), ptr(up[0]),
                      ptr(geo_ro) if j == 0 else None, ptr(geo_ids) if j == 0 else None, geo_rows.shape[0], ptr(coef[j][0]),
                      ptr(uw[1 + j]), ptr(up[1 + j]), ptr(coef[j][1]), coef[j][0].shape[0], 3 * K, st)
-        line = "world %d, %d traversal(s): rows of the union (%d geometry rows, %d colour rows): union maps %.1f us + reduce %.1f us" % (
-            world, T, tot[0], sum(tot[1:]), t(union), t(red_rows))
+        # the same in ONE launch (mtgs_dp_reduce_rows_groups: a tile is walked once for the geometry and every colour group)
+        from mtgs_amd.nodes import upload_table
+        gt = np.zeros(n_sub - 1, dtype=mdist._DP_GROUP)
+        for j in range(n_sub - 1):
+            gt[j] = (masks[1 + j], coef[j][0].data_ptr(), uw[1 + j].data_ptr(), up[1 + j].data_ptr(), coef[j][1].data_ptr(), coef[j][0].shape[0])
+        gtab = upload_table(gt, dev)
+        red_groups = lambda: call("mtgs_dp_reduce_rows_groups", world, N, K, 3, ptr(means), ptr(metas[:, 4:]), ptr(metas[:, 4 + 2 * nw:]),
+                                  L * 4, ptr(recv), cap * 16, ptr(cams), 0, -1, n_sub - 1, ptr(gtab), ptr(geo_rows), ptr(uw[0]), ptr(up[0]),
+                                  ptr(geo_ro), ptr(geo_ids), geo_rows.shape[0], 3 * K, st)
+        red_rows(); ref = [c[0].clone() for c in coef] + [geo_rows.clone()]
+        red_groups(); torch.cuda.synchronize()
+        same = all(torch.equal(a, b) for a, b in zip(ref, [c[0] for c in coef] + [geo_rows]))
+        line = "world %d, %d traversal(s): rows of the union (%d geometry rows, %d colour rows): union maps %.1f us + reduce %.1f us (one launch for all groups: %.1f us, bit-identical %s)" % (
+            world, T, tot[0], sum(tot[1:]), t(union), t(red_rows), t(red_groups), same)
         if T > 1:
             outT = torch.empty(N, T, K, 3, device=dev)
 
