@@ -1,6 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_dp.py -x -q -m gpu 2>&1 | tail -3
-timeout 2400 python -m pytest tests/test_gpu_mtgs_contract.py -x -q -m gpu -k "dp_rows or configs4 or data_parallel or sparse" 2>&1 | tail -3
-(timeout 900 python scripts/dp_cost.py --no-render-leg; timeout 900 python scripts/dp_cost.py --no-render-leg --width 960 --height 540) 2>&1 | grep -v amdgpu.ids > gpurun_out/dp_cost_r04.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+/usr/bin/time -v timeout 900 python bench.py 2> gpurun_out/bench_time.txt | tail -1 > gpurun_out/bench_r04_final.json
+grep -E "Elapsed|Maximum resident" gpurun_out/bench_time.txt
+cut -c1-300 gpurun_out/bench_r04_final.json
