@@ -16,6 +16,12 @@ One "step" = one pass of the hot path over one camera per rank, inputs resident 
 Each rank renders a different camera (yaw = rank * 45 deg) of the same replicated 2M-Gaussian
 WB-v1 scene, so per-GPU work is fixed as N grows: "scaling": "weak".
 
+Launch modes (N = 1): the W + K steps run twice -- launched eagerly from Python (every kernel and library call of the step: the
+HIP events around the dominant kernel live in this loop) and as ONE HIP GRAPH LAUNCH per step (the same step captured once under
+mtgs_amd.graph_mode + torch.cuda.graph and replayed: same kernels, same inputs, nothing from the host but the launch).  The eager loop
+follows the box's CPU load (1.00 ... 1.22 ms measured on one box within minutes, next to 0.94 ms of GPU work); the line carries the
+faster of the two and names it in config.launch, both are in ms_per_step_eager / ms_per_step_graph.
+
 Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` describes the
 dominant kernel (compositing backward) with its duration measured live by HIP events on the
 launch stream; `cpu_baseline` times oracle/gsplat_oracle.c (the CPU restatement, "port") on the
@@ -74,6 +80,10 @@ def parse_args():
                          "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
                          "dense = plain all-reduce of every gradient tensor")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="N = 1: graph (default): the K steps are timed twice -- "
+                    "launched eagerly (~40 kernel launches and ~15 library calls per step from Python) and as ONE HIP graph launch each "
+                    "(the step captured once under mtgs_amd.graph_mode) -- and the line carries the faster, named in config.launch; "
+                    "eager: the eager loop only")
     ap.add_argument("--no-also", action="store_true", help="skip the untimed extras (forward-only rate, shipped 7-channel cells): "
                                                             "profiling runs, so that the trace holds the headline step only")
     return ap.parse_args()
@@ -113,7 +123,9 @@ def make_step(args, dev, world):
     def step():
         for p in all_params:
             p.grad = None
-        ev["start"].record()
+        capturing = info_box.get("capture", False)     # (timing events cannot be recorded into a HIP graph)
+        if not capturing:
+            ev["start"].record()
         if sparse:
             # ONE exchange per step: the sum of the Gaussian gradients over the ranks (cameras).  The exchange renders
             # (MTGS's colour activation fused), its backward leaves 64-byte wire rows of the visible Gaussians, and
@@ -150,10 +162,12 @@ def make_step(args, dev, world):
                 rasterize_mode="classic")
         info["means2d"].retain_grad()
         torch.autograd.backward([render, alpha], [Gc, Ga])
-        ev["rows"].record()
+        if not capturing:
+            ev["rows"].record()
         if world > 1:   # dense exchange: every Gaussian gradient tensor (the camera's own viewmat gradient stays local)
             info_box["grad_bytes"] = all_reduce_grads(list(params.values()))
-        ev["end"].record()
+        if not capturing:
+            ev["end"].record()
         info_box["info"] = info
         return render, alpha
 
@@ -441,6 +455,54 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [t for name in DOMINANT for t in _lib.timed_ms().get(name, [])]
     _lib.time_calls(())
+    # (detached: the info of a step holds means2d and with it the step's autograd graph, whose AccumulateGrad nodes would be reused
+    #  by the capture on another stream)
+    eager_info = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in info_box["info"].items()}
+    info_box["info"] = None
+    # ---- the same K steps as ONE HIP GRAPH LAUNCH each (N = 1): the step is captured once under mtgs_amd.graph_mode (fixed capacities,
+    # counts on the device, nothing waits for the host) and replayed.  Same kernels on the same inputs; what goes is the host's share
+    # -- ~40 kernel launches, ~15 library calls and one mailbox wait per step next to ~1 ms of GPU work, which made the eager figure
+    # follow the box's CPU load (1.00 ... 1.22 ms on the same box within minutes).  The eager loop above still runs (its HIP events
+    # give the dominant kernel's launch time) and is reported as also.headline_eager_ms.
+    elapsed_eager, elapsed_graph, launch, graph_error = elapsed, None, "eager", None
+    if world == 1 and args.launch == "graph":
+        try:
+            import mtgs_amd
+            nv_e, m_e = int((eager_info["radii"] > 0).sum().item()), int(eager_info["flatten_ids"].numel())
+            gm = mtgs_amd.graph_mode(int(1.1 * nv_e) + 4096, int(1.1 * m_e) + 65536)
+            info_box["capture"] = True
+            for p_ in all_params:
+                p_.grad = None
+            import gc
+            gc.collect()
+            with gm:
+                step()                  # (under the mode once: its staging buffers exist before the capture)
+            info_box["info"] = None     # (its means2d holds that step's autograd graph: see above)
+            gc.collect()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with gm, torch.cuda.graph(g):
+                step()
+            overflow = info_box["info"]["overflow"]
+            for _ in range(args.warmup):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if bool(overflow):
+                raise RuntimeError("the captured frame exceeded its capacities")
+            elapsed_graph = t1 - t0
+            if elapsed_graph < elapsed:      # the line carries the faster of the two launch modes and names it; the other is beside it
+                elapsed, launch = elapsed_graph, "graph"
+        except Exception as e:      # noqa: BLE001  (the eager figure stands)
+            graph_error = f"{type(e).__name__}: {e}"[:300]
+            print(f"[bench] graph launch failed, reporting the eager loop: {graph_error}", file=sys.stderr)
+        finally:
+            info_box["capture"] = False
+    info_box["info"] = eager_info
     # per-rank phase breakdown of the last timed step (N > 1), read before anything else touches the events
     rank_phases = None
     if world > 1:
@@ -567,7 +629,9 @@ def main():
     out = {
         "metric": "rendered Mpix/s (fwd+bwd) @ 2M Gaussians 1920x1080",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_eager": round(elapsed_eager / args.steps * 1e3, 3),
+        "ms_per_step_graph": None if elapsed_graph is None else round(elapsed_graph / args.steps * 1e3, 3),
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[2]: {args.n_gaussians} Gaussians (WB-v1 seed {args.seed}), "
@@ -576,6 +640,13 @@ def main():
                            else " (colours given, RGB, classic)"),
             "n_gaussians": args.n_gaussians, "width": args.width, "height": args.height,
             "n_visible": n_vis, "n_intersections": M, "n_listed": M_l,
+            "launch": ("one HIP graph launch per step: the step captured once under mtgs_amd.graph_mode + torch.cuda.graph and replayed "
+                       "(the K steps were timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)")
+                      if launch == "graph" else
+                      "eager: every kernel of the step launched from Python" +
+                      (f" (graph launch failed: {graph_error})" if graph_error else
+                       (" (timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)"
+                        if elapsed_graph is not None else "")),
             "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange, "
                            f"{info_box['grad_bytes']} bytes received per rank per step",
         },
@@ -589,7 +660,8 @@ def main():
                      "algorithmic_bytes_on_gsplat_lists": P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A),
                      "frac_on_gsplat_lists": round((P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A))
                                                    / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else 0.0,
-                     "note": "algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) -- the (tile, Gaussian) pairs the tight lists "
+                     "note": "avg_launch_ms: HIP events on the launch stream around every mtgs_blend_bwd_packed call of the K EAGER steps run "
+                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) -- the (tile, Gaussian) pairs the tight lists "
                              "hold (config.n_listed), not gsplat's count (config.n_intersections); "
                              "kernel is VALU bound, not HBM bound (DESIGN.md section 4); avg_launch_ms is measured in this run; traffic and "
                              "valu_busy_frac (SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8) come from the committed rocprofv3 "
@@ -634,7 +706,7 @@ def main():
         out["dp_env"] = {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_P2P_LEVEL", "NCCL_MIN_NCHANNELS",
                                                        "HSA_ENABLE_IPC_MODE_LEGACY", "MTGS_DIST_BACKEND")}
     if fwd_ms is not None:
-        out["also"] = {"fwd_only_ms": round(fwd_ms, 3), "fwd_only_mpix_s": round(P / fwd_ms / 1e3, 1),
+        out["also"] = {"headline_eager_ms": round(elapsed_eager / args.steps * 1e3, 3), "fwd_only_ms": round(fwd_ms, 3), "fwd_only_mpix_s": round(P / fwd_ms / 1e3, 1),
                        "gaussians_per_s_fwd_bwd": round(world * args.n_gaussians / (ms_per_step * 1e-3), 0)}
         if args.variant == "mtgs":
             # what the SHIPPED config/MTGS.py drives (outside the timed region): RGB + camera-space normals + expected depth

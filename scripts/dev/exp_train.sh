@@ -1,7 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-/usr/bin/time -v timeout 900 python bench.py 2> gpurun_out/bench_time.txt | tail -1 > gpurun_out/bench_r04_final.json
-grep -E "Elapsed|Maximum resident" gpurun_out/bench_time.txt
-cut -c1-300 gpurun_out/bench_r04_final.json
+show='import json,sys
+d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["ms_per_step_eager"], d["ms_per_step_graph"], d["config"]["launch"][:30], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"])'
+for i in 1 2 3; do timeout 600 python bench.py --cpu-steps 0 --no-also 2>/dev/null | tail -1 | python -c "$show"; done
+S=$(date +%s); timeout 900 python bench.py 2>gpurun_out/bench_err.txt | tail -1 > gpurun_out/bench_r04_final.json; echo "wall $(( $(date +%s) - S )) s"; python -c "$show" < gpurun_out/bench_r04_final.json
