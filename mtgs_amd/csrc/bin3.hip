@@ -102,8 +102,11 @@ __device__ __forceinline__ int row_span(const RowGeom &g, int y, int tw, int &fi
     // tile column t holds the centres 16 t + 0.5 .. 16 t + 15.5: it meets [mx + xl, mx + xr] iff
     //   t >= (mx + xl - 15.5) / 16  and  t <= (mx + xr - 0.5) / 16
     const float inv = 1.0f / (float)MTGS_TILE_SIZE;
-    const int lo = (int)fmaxf(ceilf((g.mx + xl - 15.5f) * inv), (float)g.x0) - g.x0;
-    const int hi = (int)fminf(floorf((g.mx + xr - 0.5f) * inv), (float)(g.x0 + g.w - 1)) - g.x0 + 1;
+    // (clamped on both sides BEFORE the conversion: an ellipse far larger than the image -- or a NaN, which fmaxf / fminf turn into
+    //  the bound, i.e. the full span -- must not reach an out-of-range float-to-int conversion)
+    const float fx0 = (float)g.x0, fx1 = (float)(g.x0 + g.w);
+    const int lo = (int)fminf(fmaxf(ceilf((g.mx + xl - 15.5f) * inv), fx0), fx1) - g.x0;
+    const int hi = (int)fmaxf(fminf(floorf((g.mx + xr - 0.5f) * inv), fx1 - 1.f), fx0 - 1.f) - g.x0 + 1;
     // (the closed form errs on the wide side by its margins; any superset of the exact set is fine -- blend.hip's staging
     //  applies rec_reaches_rect to what is listed)
     first += lo;

@@ -387,9 +387,9 @@ def test_many_cameras_in_one_call_take_the_packed_path(hip_lib, lists_mode):
     assert_tile_lists(info, {"isect_offsets": off, "flatten_ids": flat, "isect_ids": isect_ids})
 
 
-@pytest.mark.parametrize("N,W,H,C,D", [(60_000, 320, 200, 1, 3), (200_000, 640, 480, 1, 3), (120_000, 640, 360, 3, 3),
-                                       (500_000, 960, 540, 1, 6)])
-def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D):
+@pytest.mark.parametrize("N,W,H,C,D,needles", [(60_000, 320, 200, 1, 3, False), (200_000, 640, 480, 1, 3, False), (120_000, 640, 360, 3, 3, False),
+                                               (500_000, 960, 540, 1, 6, False), (80_000, 640, 360, 2, 3, True)])
+def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D, needles):
     """The default tile lists hold only the (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse reaches a pixel centre of the
     tile (mtgs_bin3_build(tight=1)).  Against gsplat's lists (mtgs_amd.exact_lists(): every tile of the 3-sigma square): render and
     alphas are BIT-identical -- every pair left out is skipped pixel by pixel by gsplat's own `alpha < 1/255` rule -- the
@@ -402,15 +402,19 @@ def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D
     g = torch.Generator().manual_seed(2)
     cols = torch.rand(N, D, generator=g).to(dev)
     sc["opacities"] = (torch.rand(N, generator=g) ** 2).to(dev)          # (many faint Gaussians: small alpha >= 1/255 ellipses)
+    if needles:      # long thin splats at every orientation (conics with a large off-diagonal term: the closed-form row spans'
+        #              clamped tangent points), some of them crossing the whole image
+        sc["scales"] = (torch.tensor([2.5, 0.02, 0.02]) * (0.2 + torch.rand(N, 1, generator=g))).to(dev)
+        sc["quats"] = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=1).to(dev)
     vms, Ks = zip(*[make_camera(W, H, yaw_deg=25.0 * c) for c in range(C)])
     vm, K = torch.cat(vms).to(dev), torch.cat(Ks).to(dev)
     Gc, Ga = torch.randn(C, H, W, D + 1, generator=g).to(dev), torch.randn(C, H, W, 1, generator=g).to(dev)
     out = {}
-    for mode in ("gsplat", "tight"):
+    for mode in ("gsplat", "tight", "gsplat again"):
         P = {k: sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")}
         c = cols.clone().requires_grad_(True)
         v = vm.clone().requires_grad_(True)
-        with mtgs_amd.exact_lists(mode == "gsplat"):
+        with mtgs_amd.exact_lists(mode != "tight"):
             r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], c, v, K, W, H, packed=False,
                                        render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
             info["means2d"].retain_grad()
@@ -420,8 +424,13 @@ def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D
         out[mode] = (r.detach(), a.detach(), info, grads)
     (r0, a0, i0, g0), (r1, a1, i1, g1) = out["gsplat"], out["tight"]
     assert torch.equal(r0, r1) and torch.equal(a0, a1)
+    g2 = out["gsplat again"][3]
     for k in g0:
-        assert (g0[k] - g1[k]).abs().max() <= 2e-4 * g0[k].abs().max() + 1e-7, k
+        # the order of the fp32 atomics is all that can differ.  Splats that cross hundreds of tiles sum ~10^4 contributions of both
+        # signs per Gaussian: there two runs of the SAME lists differ by more than 2e-4 of the largest gradient, so the bound is
+        # calibrated on that run-to-run difference (as tests/fuzz_gpu.py does)
+        noise = float((g0[k] - g2[k]).abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 4.0 * noise + 2e-4 * float(g0[k].abs().max()) + 1e-7, (k, noise)
     for k in ("radii", "tiles_per_gauss"):
         assert torch.equal(i0[k], i1[k])
     assert int(i0["n_listed"]) == i0["flatten_ids"].numel() == i1["flatten_ids"].numel()
