@@ -347,6 +347,22 @@ def test_mtgs_like_training_geometry_rows_and_row_lazy_equal_the_autograd_path()
     assert_same_training(outs[1], outs[0], 2, 45, 20)
 
 
+def test_mtgs_like_training_touch_first_is_the_same_training():
+    """--touch-first on (ColorSource.touch_first: one pass of the compositing decisions flags the Gaussians a frame composites from;
+    the optimizer's peek, the SH evaluation and the normals leave the others alone) and auto (the harness decides per stretch from
+    the share of visible Gaussians that carry a gradient): the same refinements and loss curve as without the pass."""
+    from tests.util import assert_same_training
+    common = ["--n-background", "60000", "--n-road", "20000", "--traversals", "3", "--width", "320", "--height", "200",
+              "--steps", "45", "--refine-every", "20", "--reps", "1", "--only", "fused", "--shipped", "--optimizer", "fused", "--visfirst",
+              "--row-lazy", "--geometry-rows"]
+    off = _run_train(common)
+    on = _run_train(common + ["--touch-first", "on"])
+    auto = _run_train(common + ["--touch-first", "auto"])
+    assert_same_training(on, off, 2, 45, 20)
+    assert_same_training(auto, off, 2, 45, 20)
+    assert "touch-first o" in auto and "touch-first o" not in on
+
+
 _CONVERGE = ["--shipped", "--visfirst", "--optimizer", "fused", "--row-lazy", "--geometry-rows", "--only", "fused", "--reps", "1",
              "--converge", "--grad-thresh", "1e-3", "--clear-radius", "12"]
 
