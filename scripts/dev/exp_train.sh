@@ -1,3 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_mtgs_contract.py -x -q -m gpu -k "touch_first" 2>&1 | grep -E "^E  |passed|failed" | head -8
+show='import json,sys
+d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step_eager"], d["ms_per_step_graph"], [ (e["entry_point"][5:], e["avg_us_live"]) for e in d["roofline"]["entry_points"] if "blend" in e["entry_point"]])'
+for i in 1 2; do timeout 600 python bench.py --cpu-steps 0 --no-also 2>/dev/null | tail -1 | python -c "$show"; done
