@@ -1,5 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-show='import json,sys
-d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step_eager"], [ (e["entry_point"][5:], e["avg_us_live"]) for e in d["roofline"]["entry_points"] if "blend" in e["entry_point"]])'
-for k in 0 128 256 512 1024; do echo "K=$k"; MTGS_SPLIT_K=$k timeout 600 python bench.py --cpu-steps 0 --no-also --launch eager 2>/dev/null | tail -1 | python -c "$show"; done
+mkdir -p gpurun_out
+timeout 3000 python -m pytest tests -q -m gpu > gpurun_out/pytest_full.log 2>&1
+echo rc=$?
+grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/pytest_full.log | head -20
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
