@@ -1,7 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 3000 python -m pytest tests -q -m gpu > gpurun_out/pytest_full.log 2>&1
-echo rc=$?
-grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/pytest_full.log | head -20
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+C="--shipped --visfirst --optimizer fused --row-lazy --geometry-rows --only fused --reps 1 --converge --grad-thresh 1e-3 --clear-radius 12"
+MTGS_REFINE_DEBUG=1 MTGS_TRAIN_DEBUG=1 timeout 900 python scripts/mtgs_like_train.py $C --steps 520 --refine-every 100 --densify-from 250 --train-graph --one-graph 2>&1 | grep -E "refine |step |debug phases|timing" | tail -40
