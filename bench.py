@@ -54,7 +54,7 @@ ENTRY_POINTS = {
     "mtgs_front_fwd": ["front_project_kernel", "front_compact_kernel"],
     "mtgs_bin3_build": ["bin3_rows_count_kernel<true>", "bin3_rows_place_kernel<true>", "bin3_tiles_count_kernel", "bin3_tiles_place_kernel",
                         "bin3_sort_small_kernel", "bin3_sort_large_kernel", "zero"],
-    "mtgs_blend_fwd_packed": ["blend_fwd_kernel<4, 4, true>"],
+    "mtgs_blend_fwd_packed": ["blend_fwd_kernel<4, 2, true>"],
     "mtgs_blend_bwd_packed": ["blend_bwd_kernel<4, 4, true>"],
     "mtgs_project_bwd": ["project_bwd_vis_kernel", "project_bwd_expand_kernel"],
     "mtgs_project_bwd_rows": ["project_bwd_rows_kernel"],
@@ -584,7 +584,7 @@ def main():
         "bin3_tiles_count_kernel": n_items * 8,
         "bin3_tiles_place_kernel": n_items * (8 + 4) + M_l * 8,
         "bin3_sort_small_kernel": M_l * (8 + 4 + 4 + 4 + 8),
-        "blend_fwd_kernel<4, 4, true>": M_l * (4 + 64) + P * (4 * D + 8),
+        "blend_fwd_kernel<4, 2, true>": M_l * (4 + 64) + P * (4 * D + 8),
         "blend_bwd_kernel<4, 4, true>": bytes_bwd,
     }
     # (1) measured in THIS run: HIP events around every C-ABI entry point of the step (second, untimed pass)

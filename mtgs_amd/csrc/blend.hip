@@ -902,11 +902,16 @@ static int pick_ppl(int64_t total_tiles, int DT, bool backward) {
     //   bwd, 4 channels: 1200 tiles 424/344/324   2040 tiles 319/277/408   2800 tiles 320/310/484   8160 tiles 430/-/-
     //   bwd, 7 channels: 1200 tiles  - /389/600   2040 tiles 362/323/804   3600 tiles 349/383/ -    8160 tiles 505/591/-
     // (re-measured after the compact gradient rows and the packed reduction: two waves per tile now win the middle range)
+    // round 4, tight tile lists (half the pairs per tile; us, pixels per lane 1 / 2 / 4, packed kernels, median of 12-30):
+    //   fwd, 4 channels: 2040 tiles 109/132/193   3600 tiles 124/119/162   8160 tiles 179/152-157/156-158
+    //   fwd, 7 channels: 2040 tiles 126/140/193   3600 tiles 142/130/158   8160 tiles 204/197/200
+    //   bwd, 4 channels: 2040 tiles 336/230/294   3600 tiles 464/256/263   8160 tiles 795/382/330
+    //   bwd, 7 channels: 2040 tiles 691/261/329   3600 tiles 948/298/304   8160 tiles 1640/480/392
     if (backward) {
-        if (total_tiles >= 3200) return 4;
+        if (total_tiles >= 6000) return 4;
         return (DT <= 4 && total_tiles < 1536) ? 1 : 2;
     }
-    return total_tiles >= 6144 ? 4 : (total_tiles >= 4608 ? 2 : 1);
+    return total_tiles >= 16000 ? 4 : (total_tiles >= 3000 ? 2 : 1);
 }
 
 #define MTGS_DISPATCH_ONE(FN, DD, ...)                                         \
