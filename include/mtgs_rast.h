@@ -519,6 +519,9 @@ typedef struct mtgs_node_desc {
         *g_pose;               /* g_pose[7]: zeroed accumulator (atomics), gradient of (normalised quaternion | translation) */
     float *g_pose_quat_row, *g_pose_trans_row;   /* pose_normalize: rows [4] / [3] of the gradients of the per-frame parameters,
                                                   * written after the launch from g_pose (nullable) */
+    const int32_t *frame_dev;  /* (ABI v24, nullable) the frame of this step in DEVICE memory: pose / pose_trans / g_pose_*_row then name
+                                * row 0 of the node's per-frame tables and the kernels add the frame when they run (one captured
+                                * iteration for every frame) */
 } mtgs_node_desc;
 int mtgs_node_desc_bytes(void);   /* sizeof(mtgs_node_desc): bindings check their layout against it */
 /* total_blocks = sum over nodes of ceil(n / 256); `degree` = sh_degree_to_use of the step (all nodes), or -1 for

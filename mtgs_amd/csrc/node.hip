@@ -219,9 +219,14 @@ __device__ __forceinline__ int node_of_block(const mtgs_node_desc *__restrict__ 
     }
     return __builtin_amdgcn_readfirstlane(lo);
 }
+// frame_dev (nullable): `pose` / `pose_trans` / the gradient rows are the FIRST rows of the node's per-frame tables and the frame of
+// this step is read from device memory when the kernel runs (one captured iteration for every frame: the caller rewrites the word)
+__device__ __forceinline__ int64_t frame_of(const mtgs_node_desc &d) { return d.frame_dev ? (int64_t)*d.frame_dev : 0; }
+__device__ __forceinline__ const float *pose_q(const mtgs_node_desc &d) { return d.pose ? d.pose + 4 * frame_of(d) : nullptr; }
+__device__ __forceinline__ const float *pose_t(const mtgs_node_desc &d) { return d.pose_trans ? d.pose_trans + 3 * frame_of(d) : nullptr; }
 __device__ __forceinline__ NodeParams params_of(const mtgs_node_desc &d, const float *cam_pos) {
     return NodeParams{d.means, d.scales_raw, d.quats_raw, d.opacities_raw, d.features_dc, d.features_dc_add, d.features_rest,
-                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, d.pose, d.pose_trans, d.pose_normalize,
+                      d.dc_stride, d.dc_add_stride, d.rest_stride, cam_pos, d.k_rest, d.use_sh, pose_q(d), pose_t(d), d.pose_normalize,
                       d.skip_colors};
 }
 
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(NODE_BLOCK) void node_fwd_geom_batch_kernel(const m
     if (model_id) model_id[d.start + gl] = i;
     Pose ps;
     if (d.pose) {
-        ps = load_pose(d.pose, d.pose_trans, d.pose_normalize);
+        ps = load_pose(pose_q(d), pose_t(d), d.pose_normalize);
         mn = F3{(ps.R[0] * mn.x + ps.R[1] * mn.y) + ps.R[2] * mn.z + ps.tx, (ps.R[3] * mn.x + ps.R[4] * mn.y) + ps.R[5] * mn.z + ps.ty,
                 (ps.R[6] * mn.x + ps.R[7] * mn.y) + ps.R[8] * mn.z + ps.tz};
     }
@@ -511,14 +516,16 @@ __global__ void node_pose_finalize_kernel(const mtgs_node_desc *__restrict__ tab
     if (i >= n_nodes) return;
     const mtgs_node_desc &d = table[i];
     if (!d.pose || !d.pose_normalize || !d.g_pose) return;
-    const float w = d.pose[0], x = d.pose[1], y = d.pose[2], z = d.pose[3];
+    const float *pq = pose_q(d);
+    const int64_t f = frame_of(d);
+    const float w = pq[0], x = pq[1], y = pq[2], z = pq[3];
     const float inv = 1.0f / sqrtf(((w * w + x * x) + y * y) + z * z);
     const float qn[4] = {w * inv, x * inv, y * inv, z * inv};
     const float dot = ((d.g_pose[0] * qn[0] + d.g_pose[1] * qn[1]) + d.g_pose[2] * qn[2]) + d.g_pose[3] * qn[3];
     if (d.g_pose_quat_row)
-        for (int k = 0; k < 4; ++k) d.g_pose_quat_row[k] = (d.g_pose[k] - dot * qn[k]) * inv;
+        for (int k = 0; k < 4; ++k) d.g_pose_quat_row[4 * f + k] = (d.g_pose[k] - dot * qn[k]) * inv;
     if (d.g_pose_trans_row)
-        for (int k = 0; k < 3; ++k) d.g_pose_trans_row[k] = d.g_pose[4 + k];
+        for (int k = 0; k < 3; ++k) d.g_pose_trans_row[3 * f + k] = d.g_pose[4 + k];
 }
 
 }  // namespace

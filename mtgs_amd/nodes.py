@@ -143,7 +143,7 @@ _DESC = np.dtype([(k, "<i8") for k in ("n", "first_block", "start")]
                  + [(k, "<u8") for k in ("scales", "quats", "opacities", "rgbs", "clamp_mask", "means_out", "v_scales", "v_quats",
                                          "v_opacities", "v_rgbs", "v_means", "g_scales_raw", "g_quats_raw", "g_opacities_raw",
                                          "g_features_dc", "g_features_rest", "g_features_dc_add", "g_means", "g_pose", "g_pose_quat_row",
-                                         "g_pose_trans_row")], align=True)
+                                         "g_pose_trans_row", "frame_dev")], align=True)
 _desc_checked = False
 
 
@@ -404,6 +404,10 @@ class _CollectNodes(torch.autograd.Function):
             tab["pose"][framed] = [q.data_ptr() + 16 * f for q, f in zip(pose_tabs[0::2], fr)]
             tab["pose_trans"][framed] = [t.data_ptr() + 12 * f for t, f in zip(pose_tabs[1::2], fr)]
             tab["pose_normalize"][framed] = 1
+            for i in framed:      # (a device frame index: spec frame 0 = row 0 of the tables, the kernels add the word's value)
+                if len(specs[i]) > 5 and specs[i][5] is not None:
+                    tab["frame_dev"][i] = specs[i][5].data_ptr()
+                    keep.append(specs[i][5])
         tab_dev = _upload(tab, dev)
         call("mtgs_node_fwd_batch", n_nodes, ptr(tab_dev), blk, -1 if deferred else int(degree), ptr(cam), ptr(model_id),
              stream_of(means))
@@ -571,16 +575,23 @@ def collect_gaussians(nodes, camera_to_worlds: Tensor, sh_degree_to_use: int, mo
         if use_sh:
             assert (sh_degree_to_use + 1) ** 2 <= Kr + 1, (sh_degree_to_use, rest.shape)
         assert nd["scales"].shape == (N, 3) and nd["quats"].shape == (N, 4) and nd["opacities"].numel() == N
-        iq, it, frame = nd.get("instance_quat"), nd.get("instance_trans"), -1
+        iq, it, frame, frame_dev = nd.get("instance_quat"), nd.get("instance_trans"), -1, None
         if nd.get("instance_quats") is not None:   # per-frame pose parameters [F,4] / [F,3] + the frame of this step
             assert iq is None, "pass either instance_quat (the pose) or instance_quats + frame_idx (the parameters)"
-            iq, frame = nd["instance_quats"], int(nd["frame_idx"])
+            iq, frame = nd["instance_quats"], nd["frame_idx"]
             assert iq.dim() == 2 and iq.shape[1] == 4 and it is not None and it.shape == (iq.shape[0], 3), (iq.shape, None if it is None else it.shape)
-            assert 0 <= frame < iq.shape[0], (frame, iq.shape)
+            if isinstance(frame, Tensor):    # the frame as an int32 DEVICE scalar (one captured iteration for every frame; its value --
+                #                              0 <= frame < F -- is the caller's promise): the kernels add it to the tables' row 0
+                if frame.dtype != torch.int32 or frame.numel() != 1 or not frame.is_cuda:
+                    raise ValueError("collect_gaussians: a device 'frame_idx' is one int32 on the GPU")
+                frame_dev, frame = frame, 0
+            else:
+                frame = int(frame)
+                assert 0 <= frame < iq.shape[0], (frame, iq.shape)
         else:
             assert (iq is None) == (it is None) and (iq is None or (iq.numel() == 4 and it.numel() == 3)), "rigid pose: quat[4] + trans[3]"
         specs.append((int(sh_degree_to_use), 2 if raw_colors else int(use_sh), -1 if trav is None else int(trav), frame,
-                      bool(deferred_colors)))
+                      bool(deferred_colors), frame_dev))
         flat += [nd["means"], nd["scales"], nd["quats"], nd["opacities"], nd["features_dc"], add, rest, iq, it]
         sizes.append(N)
     cam_pos = camera_to_worlds[..., :3, 3].reshape(-1)[:3]

@@ -83,6 +83,8 @@ def quat_mult(a, b):     # mtgs utils.quat_mult
 
 
 def frame_of(t):
+    if isinstance(t, torch.Tensor):      # the traversal as a device word (one graph for every traversal): the frame on the device too
+        return ((7 * t + 3) % FRAMES).to(torch.int32)
     return (7 * t + 3) % FRAMES
 
 
@@ -585,8 +587,9 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
     one host synchronisation: the new N), new optimizer with the moved moments, new graphs.
     one_graph = True (with graph; visibility-first colours and row-lazy colour parameters, static nodes): the traversal is an
     int32 DEVICE scalar -- the camera, the targets and the exposure row are gathered from stacked tensors inside the graph, the
-    optimizer's peek / step read the slice from that word (mtgs_adam_group.sub_index_dev) -- so a stretch captures ONE graph
-    instead of one per traversal (MTGS trains with 8 traversals: 7 captures fewer behind every refinement).
+    optimizer's peek / step read the slice from that word (mtgs_adam_group.sub_index_dev), the rigid nodes' frame of the step is a
+    device word too (mtgs_node_desc.frame_dev) -- so a stretch captures ONE graph instead of one per traversal (MTGS trains with 8
+    traversals: 7 captures fewer behind every refinement).
     refine_cfg: RefineConfig with fixed thresholds (refine_device), None = the per-refinement quantile of rounds 1-3.
     densify_from: GaussianSplattingControlConfig.densify_from_iter -- no refinement (and no statistics reset) up to that step.
     means_lr_final: the reference's exponential decay of the position learning rate (config/MTGS.py:124-129) over `steps`.
@@ -600,8 +603,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
         raise ValueError("graph training: one process, one camera per step, the fused optimizer, no --lazy-adam")
 
     if one_graph:
-        if not (graph and VISFIRST["on"] and ROWLAZY["on"]) or any("instance_quats" in p for p in P.values()):
-            raise ValueError("one_graph: graph training with --visfirst --row-lazy and static nodes")
+        if not (graph and VISFIRST["on"] and ROWLAZY["on"]):
+            raise ValueError("one_graph: graph training with --visfirst --row-lazy")
         t_dev = torch.zeros((), dtype=torch.int32, device=dev)
         cam_all = [torch.stack([cm[j] for cm in cams]).contiguous() for j in range(3)]          # viewmats, Ks, camera_to_worlds
         gt_all = torch.stack(list(targets)).contiguous()

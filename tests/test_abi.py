@@ -65,7 +65,7 @@ def test_descriptor_tables_match_the_c_structs(hip_lib):
     follow the declaration order with natural alignment."""
     import re
     from mtgs_amd import densify, nodes
-    assert hip_lib.mtgs_node_desc_bytes() == nodes._DESC.itemsize == 312
+    assert hip_lib.mtgs_node_desc_bytes() == nodes._DESC.itemsize == 320
     assert hip_lib.mtgs_stats_desc_bytes() == densify._STATS_DESC.itemsize == 48
     from mtgs_amd import loss
     assert hip_lib.mtgs_oob_desc_bytes() == loss._OOB_DESC.itemsize == 64
@@ -100,7 +100,7 @@ def test_header_is_plain_c_and_struct_sizes_match(tmp_path):
         pytest.skip("gcc not installed")
     src = tmp_path / "h.c"
     src.write_text('#include "mtgs_rast.h"\n'
-                   'int main(void) { return sizeof(mtgs_node_desc) == 312 && sizeof(mtgs_stats_desc) == 48 && '
+                   'int main(void) { return sizeof(mtgs_node_desc) == 320 && sizeof(mtgs_stats_desc) == 48 && '
                    'sizeof(mtgs_oob_desc) == 64 && sizeof(mtgs_adam_group) == 232 ? 0 : 1; }\n')
     exe = tmp_path / "h"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])

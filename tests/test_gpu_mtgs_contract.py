@@ -430,6 +430,22 @@ def test_one_graph_per_stretch_with_the_traversal_on_the_device_equals_eager():
     assert counts["overflows"] == 0 and counts["warmups"] == 1 and counts["captures"] == 3 and counts["replays"] == 400 - 3 - 1, counts
 
 
+def test_one_graph_training_with_rigid_object_nodes_equals_eager():
+    """A scene graph with rigid object nodes (per-frame pose PARAMETERS, mtgs/scene_model/gaussian_model/rigid_node.py:139-216) under
+    train_loop(one_graph=True): the frame of the step is a device word too (mtgs_node_desc.frame_dev: the node kernels add it to
+    row 0 of the pose tables and of their gradient rows), so one captured iteration serves every traversal AND its frame.  Same
+    training as the eager loop, which launches per-object work from Python every step."""
+    import json
+    import re
+    from tests.util import assert_same_training
+    common = ["--n-background", "300000", "--n-road", "80000", "--objects", "12", "--steps", "160", "--refine-every", "40", "--densify-from", "70"] + _CONVERGE
+    eager = _run_train(common)
+    graph = _run_train(common + ["--train-graph", "--one-graph"])
+    assert_same_training(graph, eager, 2, 160, 40, later_sizes=1e-3)
+    counts = json.loads(re.search(r'graph (\{.*\})', graph).group(1))
+    assert counts["overflows"] == 0 and counts["captures"] == 3, counts
+
+
 def test_graph_training_notices_a_capacity_overflow_and_recaptures():
     """The first graphs get capacities that are too small (--first-cap-scale 0.3): their frames are truncated, the OR of the
     frames' overflow flags reaches the host through the polled pinned copy, the loop drops the graphs, renders every traversal

@@ -280,12 +280,14 @@ def test_collect_rigid_nodes_with_per_frame_pose_parameters(hip_lib):
     total = sum(sizes)
     cot = {k: torch.randn(total, w, generator=g).squeeze(-1) for k, w in (("means", 3), ("scales", 3), ("quats", 4), ("opacities", 1), ("rgbs", 3))}
     res = []
-    for in_kernel in (True, False):
+    for in_kernel in (True, False, "device word"):
         P = [{k: v.to(dev).requires_grad_(True) for k, v in p.items()} for p in base]
         nodes = []
         for p, f in zip(P, fidx):
             if f is None:
                 nodes.append(p)
+            elif in_kernel == "device word":   # the frame as an int32 DEVICE scalar (one captured iteration for every frame)
+                nodes.append(dict(p, frame_idx=torch.tensor(f, dtype=torch.int32, device=dev)))
             elif in_kernel:
                 nodes.append(dict(p, frame_idx=f))
             else:
@@ -297,6 +299,10 @@ def test_collect_rigid_nodes_with_per_frame_pose_parameters(hip_lib):
         res.append(({k: out[k].detach() for k in cot}, [{k: v.grad for k, v in p.items()} for p in P]))
     for k in cot:
         assert torch.allclose(res[0][0][k], res[1][0][k], rtol=1e-5, atol=1e-5), k
+        assert torch.equal(res[0][0][k], res[2][0][k]), k                      # the device word: the same kernels on the same rows
+    for ga, gc in zip(res[0][1], res[2][1]):
+        for k in ga:
+            assert float((ga[k] - gc[k]).abs().max()) <= 2e-5 * (float(ga[k].abs().max()) + 1e-12), k      # (atomics order)
     for i, (ga, gb) in enumerate(zip(res[0][1], res[1][1])):
         for k in ga:
             assert ga[k] is not None and gb[k] is not None, (i, k)
