@@ -1,3 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_mtgs_contract.py -x -q -m gpu -k "rigid_object or one_graph" 2>&1 | grep -E "^E  |passed|failed|Error" | head -8
+mkdir -p gpurun_out
+C="--shipped --visfirst --optimizer fused --row-lazy --only fused --reps 1 --converge --grad-thresh 1e-3 --clear-radius 12 --objects 100 --traversals 8"
+( echo "--- 2M Gaussians + 100 rigid objects, eight traversals, one graph per stretch"
+timeout 1200 python scripts/mtgs_like_train.py $C --steps 700 --refine-every 100 --densify-from 300 --steady 100 280 --train-graph --one-graph 2>&1 | grep -E "timing|steady|converge|refine|Error|error|Traceback" | tail -8
+echo "--- the same, eager loop (200 steps)"
+timeout 1200 python scripts/mtgs_like_train.py $C --steps 200 --refine-every 100 --densify-from 300 --steady 60 180 2>&1 | grep -E "timing|steady|converge|Error|error|Traceback" | tail -4 ) | tee gpurun_out/training_objects.txt
