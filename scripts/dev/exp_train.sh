@@ -1,8 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-C="--shipped --visfirst --optimizer fused --row-lazy --only fused --reps 1 --converge --grad-thresh 1e-3 --clear-radius 12 --objects 100 --traversals 8"
-( echo "--- 2M Gaussians + 100 rigid objects, eight traversals, one graph per stretch"
-timeout 1200 python scripts/mtgs_like_train.py $C --steps 700 --refine-every 100 --densify-from 300 --steady 100 280 --train-graph --one-graph 2>&1 | grep -E "timing|steady|converge|refine|Error|error|Traceback" | tail -8
-echo "--- the same, eager loop (200 steps)"
-timeout 1200 python scripts/mtgs_like_train.py $C --steps 200 --refine-every 100 --densify-from 300 --steady 60 180 2>&1 | grep -E "timing|steady|converge|Error|error|Traceback" | tail -4 ) | tee gpurun_out/training_objects.txt
+timeout 3000 python -m pytest tests -q -m gpu > gpurun_out/pytest_full.log 2>&1
+echo rc=$?
+grep -E "^FAILED|^ERROR|passed|failed" gpurun_out/pytest_full.log | head -20
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
