@@ -332,7 +332,7 @@ __device__ __forceinline__ void adam_rows_list_t(const mtgs_adam_group &d, const
 }
 __device__ __forceinline__ void adam_rows_list(const mtgs_adam_group &d, const Hyper &h, float *hy, int64_t block_in_group) {
     __shared__ float s_hist[2 * ADAM_HWIN];
-    const RowCtx x = row_ctx(d, h, hy, false, s_hist);      // (the step's bookkeeping: adam_list_schedule_kernel)
+    const RowCtx x = row_ctx(d, h, hy, false, s_hist);      // (the step's bookkeeping: adam_list_search_kernel)
     __syncthreads();      // s_hist
     if (x.sw <= 4) adam_rows_list_t<4>(d, h, x, block_in_group);
     else adam_rows_list_t<16>(d, h, x, block_in_group);
@@ -360,53 +360,104 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int32_t *__restrict__ 
     return lo;
 }
 #define ADAM_SCHED_THREADS 1024
-__global__ void __launch_bounds__(ADAM_SCHED_THREADS) adam_list_schedule_kernel(mtgs_adam_group *__restrict__ table,
-                                                                               float *__restrict__ hyper, int n_groups) {
-    constexpr int MAXG = 2048;                     // groups whose bounds are kept in LDS (more: the second pass reads them back)
-    __shared__ int s_lo[MAXG], s_hi[MAXG];         // rank_start and the first rank past the tensor; s_lo = -1: not a LIST group
+#define ADAM_SEARCH_THREADS 256
+// 1. the searches, one per wave, spread over as many workgroups as there are tasks (a scene graph with a hundred object nodes has
+//    ~300 LIST groups = 600 searches of three or four dependent loads each: in ONE workgroup they took 172 us per launch):
+//    task 2 g = the start of group g's ranks, 2 g + 1 = their end (parked in rank_count until the assignment below)
+__global__ void __launch_bounds__(ADAM_SEARCH_THREADS) adam_list_search_kernel(mtgs_adam_group *__restrict__ table,
+                                                                              float *__restrict__ hyper, int n_groups) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int WAVES = ADAM_SCHED_THREADS / 64;
-    for (int g = threadIdx.x; g < n_groups && g < MAXG; g += ADAM_SCHED_THREADS) s_lo[g] = -1;
-    __syncthreads();
-    // one search per wave: task 2 g = the start of group g's ranks, 2 g + 1 = their end (sixteen searches in flight: the two
-    // of a group one after the other in ONE wave, four waves, measured 9.4 us for six groups)
-    for (int task = wave; task < 2 * n_groups; task += WAVES) {
-        const int g = task >> 1, which = task & 1;
-        mtgs_adam_group &d = table[g];
-        if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) continue;
-        if (which == 0 && d.mode == MTGS_ADAM_ROWS_STEP && lane == 0) {
-            // the step's bookkeeping (row_ctx does it for SCAN groups): a LIST group may have no workgroup at all -- a node
-            // none of whose Gaussians the frame saw -- and the step still counts
-            float *hy = hyper + 4 * (int64_t)d.hyper_index;
-            const int t_now = reinterpret_cast<const int32_t *>(hy)[2];
-            d.hist[2 * (int64_t)t_now] = hy[0];
-            d.hist[2 * (int64_t)t_now + 1] = hy[1];
-            reinterpret_cast<int32_t *>(hy)[3] = 0;
-        }
-        int64_t count = d.n_rows;
-        if (d.row_count_dev) { const int64_t c = *d.row_count_dev >> 32; if (c < count) count = c; }
-        const int64_t r = wave_lower_bound(d.row_ids, count, which ? d.item_start + d.n : d.item_start);
-        if (lane == 0) {
-            if (which) { if (g < MAXG) s_hi[g] = (int)r; else d.rank_count = (int32_t)r; }        // (> MAXG: end parked in rank_count)
-            else { if (g < MAXG) s_lo[g] = (int)r; d.rank_start = (int32_t)r; }
-        }
+    const int task = blockIdx.x * (ADAM_SEARCH_THREADS / 64) + wave;
+    if (task >= 2 * n_groups) return;
+    const int g = task >> 1, which = task & 1;
+    mtgs_adam_group &d = table[g];
+    if (d.mode < MTGS_ADAM_ROWS_CATCHUP || d.row_ids == nullptr) return;
+    if (which == 0 && d.mode == MTGS_ADAM_ROWS_STEP && lane == 0) {
+        // the step's bookkeeping (row_ctx does it for SCAN groups): a LIST group may have no workgroup at all -- a node
+        // none of whose Gaussians the frame saw -- and the step still counts
+        float *hy = hyper + 4 * (int64_t)d.hyper_index;
+        const int t_now = reinterpret_cast<const int32_t *>(hy)[2];
+        d.hist[2 * (int64_t)t_now] = hy[0];
+        d.hist[2 * (int64_t)t_now + 1] = hy[1];
+        reinterpret_cast<int32_t *>(hy)[3] = 0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {      // (bounds from LDS: the loop is a chain of stores, not of dependent loads)
+    int64_t count = d.n_rows;
+    if (d.row_count_dev) { const int64_t c = *d.row_count_dev >> 32; if (c < count) count = c; }
+    const int64_t r = wave_lower_bound(d.row_ids, count, which ? d.item_start + d.n : d.item_start);
+    if (lane == 0) {
+        if (which) d.rank_count = (int32_t)r; else d.rank_start = (int32_t)r;
+    }
+}
+// 2. the workgroups every LIST group really needs: first_block of the LIST groups is REWRITTEN (the host launches an upper bound;
+//    surplus workgroups leave after one descriptor load).  One workgroup: the bounds are gathered into LDS by all threads, the prefix
+//    itself is a chain of stores by one thread, not of dependent loads.
+__global__ void __launch_bounds__(ADAM_SCHED_THREADS) adam_list_assign_kernel(mtgs_adam_group *__restrict__ table, int n_groups) {
+    constexpr int MAXG = 2 * ADAM_SCHED_THREADS;   // groups handled by the parallel prefix (two per thread); more: one thread walks them
+    __shared__ int64_t s_ws[ADAM_SCHED_THREADS / 64];
+    __shared__ int64_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n_groups <= MAXG) {
+        // exclusive prefix of the LIST groups' workgroup counts, two consecutive groups per thread; the first LIST group keeps the
+        // host's first_block, the others follow it
+        int cnt[2];
+        int64_t blocks[2], first[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int g = 2 * tid + e;
+            cnt[e] = -1; blocks[e] = 0; first[e] = 0;
+            if (g < n_groups) {
+                const mtgs_adam_group &d = table[g];
+                if (d.mode >= MTGS_ADAM_ROWS_CATCHUP && d.row_ids != nullptr) {
+                    cnt[e] = d.rank_count - d.rank_start;
+                    blocks[e] = ((int64_t)cnt[e] + ADAM_LIST_ROWS - 1) / ADAM_LIST_ROWS;
+                    first[e] = d.first_block;
+                }
+            }
+        }
+        // the first LIST group: smallest index with cnt >= 0
+        if (tid == 0) s_base = -1;
+        __syncthreads();
+        const int mine = cnt[0] >= 0 ? 2 * tid : (cnt[1] >= 0 ? 2 * tid + 1 : 0x7fffffff);
+        int best = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+        __shared__ int s_first_idx[ADAM_SCHED_THREADS / 64];
+        if (lane == 0) s_first_idx[wave] = best;
+        const int64_t sum = blocks[0] + blocks[1];
+        int64_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) s_ws[wave] = inc;
+        __syncthreads();
+        int first_idx = 0x7fffffff;
+        for (int w = 0; w < ADAM_SCHED_THREADS / 64; ++w) first_idx = min(first_idx, s_first_idx[w]);
+        if (first_idx == 0x7fffffff) return;                      // no LIST group
+        if (2 * tid == (first_idx & ~1)) s_base = first[first_idx & 1];
+        __syncthreads();
+        int64_t run = s_base + inc - sum;
+        for (int w = 0; w < wave; ++w) run += s_ws[w];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (cnt[e] >= 0) {
+                table[2 * tid + e].rank_count = cnt[e];
+                table[2 * tid + e].first_block = run;
+            }
+            run += blocks[e];
+        }
+        return;
+    }
+    if (tid == 0) {
         int64_t next = -1;
         for (int g = 0; g < n_groups; ++g) {
-            int cnt;
-            if (g < MAXG) {
-                if (s_lo[g] < 0) continue;
-                cnt = s_hi[g] - s_lo[g];
-            } else {
-                const mtgs_adam_group &e = table[g];
-                if (e.mode < MTGS_ADAM_ROWS_CATCHUP || e.row_ids == nullptr) continue;
-                cnt = e.rank_count - e.rank_start;
-            }
-            table[g].rank_count = cnt;
-            if (next < 0) next = table[g].first_block;      // (the first LIST group keeps the host's value)
-            table[g].first_block = next;
+            mtgs_adam_group &e = table[g];
+            if (e.mode < MTGS_ADAM_ROWS_CATCHUP || e.row_ids == nullptr) continue;
+            const int cnt = e.rank_count - e.rank_start;
+            e.rank_count = cnt;
+            if (next < 0) next = e.first_block;      // (the first LIST group keeps the host's value)
+            e.first_block = next;
             next += ((int64_t)cnt + ADAM_LIST_ROWS - 1) / ADAM_LIST_ROWS;
         }
     }
@@ -598,7 +649,11 @@ extern "C" int mtgs_adam_step(int n_groups, mtgs_adam_group *table, float *hyper
             hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)rows_from_block), dim3(ADAM_BLOCK), 0, st, table, hyper, n_groups);
     }
     if (rows_from_block < total_blocks) {
-        if (flags & 2) hipLaunchKernelGGL(adam_list_schedule_kernel, dim3(1), dim3(ADAM_SCHED_THREADS), 0, st, table, hyper, n_groups);
+        if (flags & 2) {
+            const unsigned sb = (unsigned)((2 * (int64_t)n_groups + ADAM_SEARCH_THREADS / 64 - 1) / (ADAM_SEARCH_THREADS / 64));
+            hipLaunchKernelGGL(adam_list_search_kernel, dim3(sb), dim3(ADAM_SEARCH_THREADS), 0, st, table, hyper, n_groups);
+            hipLaunchKernelGGL(adam_list_assign_kernel, dim3(1), dim3(ADAM_SCHED_THREADS), 0, st, table, n_groups);
+        }
         hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)(total_blocks - rows_from_block)), dim3(ADAM_BLOCK), 0, st, table, hyper,
                            n_groups, rows_from_block);
     }

@@ -1111,6 +1111,14 @@ def main():
             prep(t)
             eager_loss.append(float(body(t)))
         torch.cuda.synchronize()
+        if os.environ.get("MTGS_TORCH_PROFILE"):      # development: which operators the iteration launches, by count
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                for i in range(4):
+                    prep(i % T)
+                    body(i % T)
+                torch.cuda.synchronize()
+            print(prof.key_averages().table(sort_by="count", row_limit=45, max_name_column_width=60))
         t0 = time.perf_counter()
         for i in range(args.reps):
             prep(i % T)
