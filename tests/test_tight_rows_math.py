@@ -1,0 +1,79 @@
+"""The closed form behind the tight tile lists (mtgs_amd/csrc/bin3.hip::row_span) restated in numpy float32 and checked against
+the exact ellipse / rectangle test the compositing kernels apply (raster_rec.hpp::rec_reaches_rect), also restated: for random
+conics, opacities and positions, every tile of a tile row that the exact test keeps -- a superset of the tiles with a pixel that
+can pass gsplat's alpha >= 1/255 test -- lies inside the closed-form interval, and the interval is not much wider than that."""
+import numpy as np
+
+f32 = np.float32
+
+
+def reaches_rect(a, b, c, s2max, X0, X1, Y0, Y1):
+    det = a * c - b * b
+    if not (det > 0 and a > 0 and c > 0):
+        return True
+    inside = X0 <= 0 <= X1 and Y0 <= 0 <= Y1
+
+    def edge_x(xe):
+        dy = min(max(-b * xe / c, Y0), Y1)
+        return a * xe * xe + 2 * b * xe * dy + c * dy * dy
+
+    def edge_y(ye):
+        dx = min(max(-b * ye / a, X0), X1)
+        return a * dx * dx + 2 * b * dx * ye + c * ye * ye
+    qmin = 0.0 if inside else min(edge_x(X0), edge_x(X1), edge_y(Y0), edge_y(Y1))
+    return qmin <= s2max * 1.001 + 1e-2
+
+
+def row_span(mx, my, a, b, c, s2max, x0, w, row):
+    """(first tile column, number of tiles) of tile row `row`, float32 arithmetic as in the kernel."""
+    a, b, c, s2max, mx, my = map(f32, (a, b, c, s2max, mx, my))
+    det = a * c - b * b
+    if not (det > 0 and a > 0 and c > 0):
+        return x0, w
+    ty = f32(row * 16)
+    Y0, Y1 = ty + f32(0.5) - my, ty + f32(15.5) - my
+    sm = s2max * f32(1.001) + f32(1e-2)
+    rdet = f32(1) / det
+    ymax, X = np.sqrt(a * sm * rdet), np.sqrt(sm * c * rdet)
+    yb0, yb1 = max(Y0, -ymax), min(Y1, ymax)
+    if not (yb0 <= yb1):
+        return x0, 0
+    ra, tilt = f32(1) / a, b * X / c
+    dyl, dyr = min(max(tilt, yb0), yb1), min(max(-tilt, yb0), yb1)
+    xl = (-b * dyl - np.sqrt(max(a * sm - det * dyl * dyl, f32(0)))) * ra - f32(2e-3)
+    xr = (-b * dyr + np.sqrt(max(a * sm - det * dyr * dyr, f32(0)))) * ra + f32(2e-3)
+    inv = f32(1.0 / 16.0)
+    lo = int(min(max(np.ceil((mx + xl - f32(15.5)) * inv), f32(x0)), f32(x0 + w))) - x0
+    hi = int(max(min(np.floor((mx + xr - f32(0.5)) * inv), f32(x0 + w - 1)), f32(x0 - 1))) - x0 + 1
+    return x0 + lo, hi - lo
+
+
+def test_closed_form_row_spans_contain_what_the_exact_test_keeps():
+    rng = np.random.default_rng(5)
+    tw = 40
+    widened = kept_total = 0
+    for case in range(8000):
+        # a covariance from a rotation and two standard deviations (needles, blobs, image-filling splats), plus the 0.3 blur
+        ang = rng.uniform(0, np.pi)
+        s1, s2 = np.exp(rng.uniform(np.log(0.3), np.log(300.0))), np.exp(rng.uniform(np.log(0.3), np.log(30.0)))
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        cov = R @ np.diag([s1 * s1, s2 * s2]) @ R.T + 0.3 * np.eye(2)
+        con = np.linalg.inv(cov)
+        a, b, c = con[0, 0], con[0, 1], con[1, 1]
+        opacity = np.exp(rng.uniform(np.log(1.0 / 255.0), 0.0)) * 0.999
+        s2max = 2.0 * np.log(255.0 * opacity)
+        mx, my = rng.uniform(-50, tw * 16 + 50), rng.uniform(-50, 400)
+        radius = np.ceil(3.0 * np.sqrt(max(np.linalg.eigvalsh(cov))))
+        x0 = int(min(max(np.floor((mx - radius) / 16), 0), tw)); x1 = int(min(max(np.ceil((mx + radius) / 16), 0), tw))
+        if x1 <= x0:
+            continue
+        row = int(rng.integers(max(int((my - radius) // 16), 0), max(int((my + radius) // 16), 0) + 1))
+        first, n = row_span(mx, my, a, b, c, s2max, x0, x1 - x0, row)
+        Y0, Y1 = row * 16 + 0.5 - my, row * 16 + 15.5 - my
+        kept = [t for t in range(x0, x1) if reaches_rect(a, b, c, s2max, t * 16 + 0.5 - mx, t * 16 + 15.5 - mx, Y0, Y1)]
+        if kept:
+            assert n > 0 and first <= kept[0] and kept[-1] < first + n, (case, first, n, kept[0], kept[-1])
+            assert kept == list(range(kept[0], kept[-1] + 1)), "the kept tiles of a row are an interval"
+        kept_total += len(kept)
+        widened += max(n, 0) - len(kept)
+    assert kept_total > 5000 and widened <= 0.02 * kept_total, (kept_total, widened)
