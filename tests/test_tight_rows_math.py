@@ -77,3 +77,28 @@ def test_closed_form_row_spans_contain_what_the_exact_test_keeps():
         kept_total += len(kept)
         widened += max(n, 0) - len(kept)
     assert kept_total > 5000 and widened <= 0.02 * kept_total, (kept_total, widened)
+
+
+def test_the_exact_test_never_drops_a_tile_with_a_contributing_pixel():
+    """rec_reaches_rect against brute force: whenever one of a tile's 256 pixel centres satisfies gsplat's alpha >= 1/255 condition
+    (a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 opacity)), the test keeps the tile -- and it keeps few tiles without such a pixel."""
+    rng = np.random.default_rng(9)
+    px = np.arange(16) + 0.5
+    with_pixel = kept_without = 0
+    for case in range(20000):
+        ang = rng.uniform(0, np.pi)
+        s1, s2 = np.exp(rng.uniform(np.log(0.3), np.log(60.0))), np.exp(rng.uniform(np.log(0.3), np.log(10.0)))
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        con = np.linalg.inv(R @ np.diag([s1 * s1, s2 * s2]) @ R.T + 0.3 * np.eye(2))
+        a, b, c = con[0, 0], con[0, 1], con[1, 1]
+        s2max = 2.0 * np.log(255.0 * np.exp(rng.uniform(np.log(1.0 / 255.0), 0.0)) * 0.999)
+        mx, my = rng.uniform(-40, 56), rng.uniform(-40, 56)            # the tile is [0, 16) x [0, 16)
+        dx, dy = px[None, :] - mx, px[:, None] - my
+        any_pixel = bool(((a * dx * dx + 2 * b * dx * dy + c * dy * dy) <= s2max).any())
+        keep = reaches_rect(a, b, c, s2max, 0.5 - mx, 15.5 - mx, 0.5 - my, 15.5 - my)
+        if any_pixel:
+            with_pixel += 1
+            assert keep, (case, a, b, c, s2max, mx, my)
+        elif keep:
+            kept_without += 1
+    assert with_pixel > 3000 and kept_without < 0.15 * with_pixel, (with_pixel, kept_without)
