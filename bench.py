@@ -469,7 +469,7 @@ def main():
         try:
             import mtgs_amd
             nv_e, m_e = int((eager_info["radii"] > 0).sum().item()), int(eager_info["flatten_ids"].numel())
-            gm = mtgs_amd.graph_mode(int(1.1 * nv_e) + 4096, int(1.1 * m_e) + 65536)
+            gm = mtgs_amd.graph_mode(int(1.02 * nv_e) + 1024, int(1.02 * m_e) + 8192)      # (a static scene: the counts of the eager steps, a small margin)
             info_box["capture"] = True
             for p_ in all_params:
                 p_.grad = None
