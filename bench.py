@@ -52,7 +52,7 @@ DOMINANT = ("mtgs_blend_bwd_packed", "mtgs_blend_bwd")   # the compositing backw
 ENTRY_POINTS = {
     "mtgs_sh_fwd": ["sh_fwd_k16_kernel<3>"],
     "mtgs_front_fwd": ["front_project_kernel", "front_compact_kernel"],
-    "mtgs_bin3_build": ["bin3_rows_count_kernel<true>", "bin3_rows_place_kernel<true>", "bin3_tiles_count_kernel", "bin3_tiles_place_kernel",
+    "mtgs_bin3_build": ["bin3_rows_count_kernel", "bin3_rows_place_kernel", "bin3_tiles_count_kernel", "bin3_tiles_place_kernel",
                         "bin3_sort_small_kernel", "bin3_sort_large_kernel", "zero"],
     "mtgs_blend_fwd_packed": ["blend_fwd_kernel<4, 2, true>"],
     "mtgs_blend_bwd_packed": ["blend_bwd_kernel<4, 4, true>"],
@@ -465,25 +465,30 @@ def main():
     # follow the box's CPU load (1.00 ... 1.22 ms on the same box within minutes).  The eager loop above still runs (its HIP events
     # give the dominant kernel's launch time) and is reported as also.headline_eager_ms.
     elapsed_eager, elapsed_graph, launch, graph_error = elapsed, None, "eager", None
-    if world == 1 and args.launch == "graph":
+    elapsed_graph_tight, n_listed_tight = None, None
+
+    def graph_time(tight):
+        """K replays of the step captured once under mtgs_amd.graph_mode (+ the opt-in tight tile lists when `tight`)."""
+        import gc
+        import mtgs_amd
+        nv_e, m_e = int((eager_info["radii"] > 0).sum().item()), int(eager_info["flatten_ids"].numel())
+        gm = mtgs_amd.graph_mode(int(1.02 * nv_e) + 1024, int(1.02 * m_e) + 8192)      # (a static scene: the counts of the eager steps, a small margin)
+        info_box["capture"] = True
         try:
-            import mtgs_amd
-            nv_e, m_e = int((eager_info["radii"] > 0).sum().item()), int(eager_info["flatten_ids"].numel())
-            gm = mtgs_amd.graph_mode(int(1.02 * nv_e) + 1024, int(1.02 * m_e) + 8192)      # (a static scene: the counts of the eager steps, a small margin)
-            info_box["capture"] = True
-            for p_ in all_params:
-                p_.grad = None
-            import gc
-            gc.collect()
-            with gm:
-                step()                  # (under the mode once: its staging buffers exist before the capture)
-            info_box["info"] = None     # (its means2d holds that step's autograd graph: see above)
-            gc.collect()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with gm, torch.cuda.graph(g):
-                step()
-            overflow = info_box["info"]["overflow"]
+            with mtgs_amd.tight_lists(tight):
+                for p_ in all_params:
+                    p_.grad = None
+                gc.collect()
+                with gm:
+                    step()                  # (under the mode once: its staging buffers exist before the capture)
+                info_box["info"] = None     # (its means2d holds that step's autograd graph: see above)
+                gc.collect()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with gm, torch.cuda.graph(g):
+                    step()
+            overflow, n_l = info_box["info"]["overflow"], info_box["info"]["n_listed"]
+            info_box["info"] = None
             for _ in range(args.warmup):
                 g.replay()
             torch.cuda.synchronize()
@@ -494,14 +499,22 @@ def main():
             t1 = time.perf_counter()
             if bool(overflow):
                 raise RuntimeError("the captured frame exceeded its capacities")
-            elapsed_graph = t1 - t0
+            return t1 - t0, int(n_l)
+        finally:
+            info_box["capture"] = False
+
+    if world == 1 and args.launch == "graph":
+        try:
+            elapsed_graph, _ = graph_time(False)
             if elapsed_graph < elapsed:      # the line carries the faster of the two launch modes and names it; the other is beside it
                 elapsed, launch = elapsed_graph, "graph"
         except Exception as e:      # noqa: BLE001  (the eager figure stands)
             graph_error = f"{type(e).__name__}: {e}"[:300]
             print(f"[bench] graph launch failed, reporting the eager loop: {graph_error}", file=sys.stderr)
-        finally:
-            info_box["capture"] = False
+        try:        # beside the headline, never the headline: the same step on the opt-in tight tile lists
+            elapsed_graph_tight, n_listed_tight = graph_time(True)
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] tight-lists graph failed: {type(e).__name__}: {e}"[:300], file=sys.stderr)
     info_box["info"] = eager_info
     # per-rank phase breakdown of the last timed step (N > 1), read before anything else touches the events
     rank_phases = None
@@ -549,9 +562,10 @@ def main():
     _rows = (torch.ceil((_y + _r) / 16).clamp(0, _th) - torch.floor((_y - _r) / 16).clamp(0, _th))[_r > 0]
     n_items = int(_rows.sum().item())
     M = int(info["flatten_ids"].numel())       # gsplat's intersection count (3-sigma squares): SURVEY.md section 8(d)'s unit
-    # the (tile, Gaussian) pairs the tile lists hold (tight lists, include/mtgs_rast.h mtgs_bin3_build): what the sort and the
-    # compositing kernels actually gather -- their algorithmic bytes below are priced on THIS count, not on gsplat's
+    # the (tile, Gaussian) pairs the tile lists of the TIMED steps hold: the headline is the default call = gsplat's lists, so this
+    # is M -- every byte figure of the line (kernels, entry points, whole step) is priced on the one unit SURVEY.md section 8(d) names
     M_l = int(info["n_listed"]) if info.get("n_listed") is not None else M
+    tight_headline = M_l != M      # (only when the run was started with MTGS_TIGHT_LISTS=1)
     P = args.width * args.height
     ms_per_step = elapsed / args.steps * 1e3
     value = world * P / (elapsed / args.steps) / 1e6
@@ -579,8 +593,8 @@ def main():
         "front_compact_kernel": N * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
         "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
         "project_bwd_expand_kernel": N * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
-        "bin3_rows_count_kernel<true>": n_vis * 64,
-        "bin3_rows_place_kernel<true>": n_vis * 64 + n_items * 8,
+        "bin3_rows_count_kernel": n_vis * 64,
+        "bin3_rows_place_kernel": n_vis * 64 + n_items * 8,
         "bin3_tiles_count_kernel": n_items * 8,
         "bin3_tiles_place_kernel": n_items * (8 + 4) + M_l * 8,
         "bin3_sort_small_kernel": M_l * (8 + 4 + 4 + 4 + 8),
@@ -601,7 +615,8 @@ def main():
     # (2) counter-based traffic and VALU-busy fraction per kernel: COMMITTED rocprofv3 --pmc passes of this command on the
     # headline workload (scripts/pmc_step.sh -> profiles/rNN_pmc_step.json, FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated there).
     # They are builder-held numbers echoed into this line, labelled as such, and dropped when the file was made with
-    # another ABI version of the library than the one running.
+    # another HOT-PATH ABI version of the library than the one running (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION: bumps of the
+    # optimizer / loss entry points do not invalidate them) or in the other tile-list mode.
     traffic = valu_busy = None
     kernels, counters_from = [], None
     headline = (args.n_gaussians, args.width, args.height, args.variant) == (2_000_000, 1920, 1080, "mtgs")
@@ -610,11 +625,11 @@ def main():
             break
         try:
             doc = json.loads(pmc.read_text())
-            if doc.get("abi_version") != _lib.ABI_VERSION:
+            if doc.get("hot_abi_version") != _lib.HOT_ABI_VERSION or doc.get("lists", "gsplat") != ("tight" if tight_headline else "gsplat"):
                 continue
             rec = doc["kernels"]
             for name, a_bytes in alg.items():
-                r = rec.get(name)
+                r = rec.get(name) or next((v for k, v in rec.items() if k.startswith(name + "<")), None)   # (template instances of the list mode)
                 if r and r.get("hbm_bytes"):
                     kernels.append({"kernel": name, "algorithmic_bytes": int(a_bytes), "counter_bytes_committed": r["hbm_bytes"],
                                     "avg_us_committed": r.get("avg_us"), "valu_busy_frac_committed": r.get("valu_busy_frac")})
@@ -631,6 +646,8 @@ def main():
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_eager": round(elapsed_eager / args.steps * 1e3, 3),
         "ms_per_step_graph": None if elapsed_graph is None else round(elapsed_graph / args.steps * 1e3, 3),
+        "ms_per_step_exact_lists": round(ms_per_step, 3) if not tight_headline else None,
+        "ms_per_step_tight_lists": None if elapsed_graph_tight is None else round(elapsed_graph_tight / args.steps * 1e3, 3),
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -640,6 +657,10 @@ def main():
                            else " (colours given, RGB, classic)"),
             "n_gaussians": args.n_gaussians, "width": args.width, "height": args.height,
             "n_visible": n_vis, "n_intersections": M, "n_listed": M_l,
+            "lists": ("tight (MTGS_TIGHT_LISTS=1): ordered sublists of gsplat's lists, same pixels and gradients" if tight_headline else
+                      "gsplat (the default call): isect_ids / flatten_ids / isect_offsets bit-identical to gsplat 1.4.0 isect_tiles + "
+                      "isect_offset_encode; the opt-in tight lists (mtgs_amd.tight_lists(): same pixels and gradients, "
+                      f"{n_listed_tight} listed pairs) are timed beside it as ms_per_step_tight_lists, never as `value`"),
             "launch": ("one HIP graph launch per step: the step captured once under mtgs_amd.graph_mode + torch.cuda.graph and replayed "
                        "(the K steps were timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)")
                       if launch == "graph" else
@@ -655,14 +676,14 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
                      "launches_timed": len(kernel_ms),
-                     # rounds 1-3 priced the kernel on gsplat's intersection count (every tile of the 3-sigma squares); the tight
-                     # lists gather fewer records: `achieved` follows what the kernel has to read NOW, the old figure stays beside it
+                     # the dominant kernel priced on gsplat's intersection count M (the lists of the default call): the same
+                     # unit as whole_step below and as SURVEY.md section 8(d)
                      "algorithmic_bytes_on_gsplat_lists": P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A),
                      "frac_on_gsplat_lists": round((P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A))
                                                    / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else 0.0,
                      "note": "avg_launch_ms: HIP events on the launch stream around every mtgs_blend_bwd_packed call of the K EAGER steps run "
-                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) -- the (tile, Gaussian) pairs the tight lists "
-                             "hold (config.n_listed), not gsplat's count (config.n_intersections); "
+                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) with n_listed = the (tile, Gaussian) pairs "
+                             "of the timed steps' lists (config.n_listed; = gsplat's count config.n_intersections for the default call); "
                              "kernel is VALU bound, not HBM bound (DESIGN.md section 4); avg_launch_ms is measured in this run; traffic and "
                              "valu_busy_frac (SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8) come from the committed rocprofv3 "
                              "--pmc passes named in counters_from (null when none matches this library's ABI version)",

@@ -37,7 +37,14 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 24
+#define MTGS_RAST_ABI_VERSION 25
+/* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
+ * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
+ * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
+#define MTGS_RAST_HOT_ABI_VERSION 1
+#define MTGS_BIN3_TIGHT 1
+#define MTGS_BIN3_FILL_TO_M 2
+#define MTGS_BIN3_FILL_TO_CAP 4
 
 enum {
     MTGS_OK = 0,
@@ -56,6 +63,7 @@ enum {
 #define MTGS_MAX_CHANNELS 32 /* blended colour channels per launch (gsplat channel_chunk default) */
 
 int mtgs_rast_version(void);
+int mtgs_rast_hot_version(void);   /* MTGS_RAST_HOT_ABI_VERSION of the built library */
 const char *mtgs_rast_last_error(void);
 
 /* ---- spherical harmonics: gsplat compute_sh_fwd / compute_sh_bwd ------------------------------
@@ -299,13 +307,18 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  * isect_tiles(sort=True) + isect_offset_encode.  Sizes come from `totals` on the device, clamped to (cap_vis, cap_M):
  * the caller sizes buffers and this call sizes grids for the capacities; if the true totals exceed them the outputs are
  * truncated (never out of bounds) and the caller repeats with larger ones.  Seven launches.
- * tight (ABI v24) != 0: TIGHT lists -- a (tile, Gaussian) pair of gsplat's 3-sigma square is listed only if the Gaussian's
+ * flags (ABI v25; was `tight`): MTGS_BIN3_TIGHT (1) -- TIGHT lists -- a (tile, Gaussian) pair of gsplat's 3-sigma square is listed only if the Gaussian's
  * {alpha >= 1/255} ellipse reaches a pixel centre of the tile (the exact ellipse / rectangle test, with a margin, that
  * mtgs_blend_*_packed apply when they stage a tile's candidates: 32 % of gsplat's pairs at the headline workload).  The
  * lists are sublists of gsplat's in the same order; every pair left out would be skipped pixel by pixel (gsplat's
  * `alpha < 1/255: continue`), so render, alphas and all gradients are those of the full lists, but the pair is never counted,
  * placed, sorted or gathered.  offsets[last] = the number of pairs listed (<= M of `totals`); tiles_per_gauss of
- * mtgs_front_fwd and M stay gsplat's.  tight = 0: gsplat's lists, bit-identical.
+ * mtgs_front_fwd and M stay gsplat's.  Without the flag: gsplat's lists, bit-identical (the default of rasterization()).
+ * MTGS_BIN3_FILL_TO_M (2) / MTGS_BIN3_FILL_TO_CAP (4): the entries of flatten_ids / isect_ids behind the listed pairs -- up to
+ * min(cap_M, M of `totals`) / up to cap_M -- are filled with sentinels (flatten_ids -1; isect_ids = last camera | last tile |
+ * +inf depth bits): a caller that slices the tensors to gsplat's M (tight lists) or hands out capacity-sized tensors (graph
+ * capture) never exposes uninitialised entries, and gsplat's "last range ends at numel" convention stays safe
+ * (mtgs_blend_fwd stops at the first negative id; mtgs_isect_offsets of the padded ids puts the tail into the last tile).
  * Supported when mtgs_bin3_supported(C, tile_w, tile_h, cap_M) (C*tile_w*tile_h <= 32768 (3840x2160 has 32400 tiles), C*tile_h <= 4096, tile_w <= 4096,
  * cap_M < 2^30), else use mtgs_bin_build.  ws: mtgs_bin3_workspace_bytes, 256-byte aligned.
  *
@@ -330,7 +343,7 @@ int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, in
 int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
                     int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                     const int64_t *vis_keys, int32_t *rank_ids, int32_t *flatten_ids, int64_t *isect_ids,
-                    int32_t *offsets, int32_t *tile_order, int tight, void *ws, size_t ws_bytes, void *stream);
+                    int32_t *offsets, int32_t *tile_order, int flags, void *ws, size_t ws_bytes, void *stream);
 int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,

@@ -7,9 +7,9 @@ Importing this package does not load the HIP library or touch the GPU; the first
 does, and raises if libmtgs_rast.so has not been built (python -m mtgs_amd.build).
 """
 from .rendering import rasterization
-from .wrapper import (exact_lists, fully_fused_projection, graph_mode, isect_offset_encode, isect_tiles, rasterize_to_pixels,
-                      spherical_harmonics)
+from .wrapper import (exact_lists, fully_fused_projection, graph_mode, isect_offset_encode, isect_tiles, lists_are_tight,
+                      rasterize_to_pixels, spherical_harmonics, tight_lists)
 
 __version__ = "0.1.0"
 __all__ = ["rasterization", "spherical_harmonics", "fully_fused_projection", "isect_tiles",
-           "isect_offset_encode", "rasterize_to_pixels", "graph_mode", "exact_lists"]
+           "isect_offset_encode", "rasterize_to_pixels", "graph_mode", "exact_lists", "tight_lists", "lists_are_tight"]

@@ -140,8 +140,9 @@ _SIGNATURES = {
     "mtgs_blend_bwd": [_i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
-EXPORTS = ["mtgs_rast_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 24
+EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
+ABI_VERSION = 25
+HOT_ABI_VERSION = 1      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None
 
@@ -157,6 +158,7 @@ def load() -> C.CDLL:
             "mtgs_amd has no CPU or PyTorch fallback for the rasterizer.")
     lib = C.CDLL(str(LIB_PATH))
     lib.mtgs_rast_version.restype = C.c_int
+    lib.mtgs_rast_hot_version.restype = C.c_int
     lib.mtgs_rast_last_error.restype = C.c_char_p
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
@@ -165,6 +167,8 @@ def load() -> C.CDLL:
     v = lib.mtgs_rast_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libmtgs_rast.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+    if lib.mtgs_rast_hot_version() != HOT_ABI_VERSION:
+        raise RuntimeError(f"libmtgs_rast.so hot-path ABI version {lib.mtgs_rast_hot_version()} != expected {HOT_ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

@@ -14,4 +14,5 @@ void mtgs_set_error(const char *fmt, ...) {
 }
 
 extern "C" int mtgs_rast_version(void) { return MTGS_RAST_ABI_VERSION; }
+extern "C" int mtgs_rast_hot_version(void) { return MTGS_RAST_HOT_ABI_VERSION; }
 extern "C" const char *mtgs_rast_last_error(void) { return g_last_error; }

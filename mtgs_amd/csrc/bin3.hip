@@ -444,6 +444,14 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
     for (int t = tid; t < n_bins; t += T_THREADS) order[atomicAdd(&s_aux[bucket_of(t)], 1u)] = t;
 }
 
+struct TailFill {
+    int mode;                // 0: none; 2: up to min(cap, M of `totals`); 4: up to the capacity
+    const int64_t *totals;   // device: n_vis << 32 | M
+    int32_t *flatten_ids;
+    int64_t *isect_ids;      // nullable
+    int64_t sentinel_key;
+};
+
 // ---- 3. every intersection into its tile's segment --------------------------------------------------------------
 // A workgroup's intersections of one tile take CONSECUTIVE slots of the tile's segment: one returning global atomic per
 // (workgroup, tile) reserves them, LDS atomics hand them out -- ~130k global atomics per frame instead of one per
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_count_kernel(
 __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
     const uint32_t *__restrict__ n_items_ptr, int64_t cap_items, const Item *__restrict__ items, int tw, int n_bins,
     const int32_t *__restrict__ offsets, uint32_t *__restrict__ cursor /* [n_bins], zero */,
-    const uint64_t *__restrict__ vis_keys, uint32_t cap_keys, uint64_t *__restrict__ keys64) {
+    const uint64_t *__restrict__ vis_keys, uint32_t cap_keys, uint64_t *__restrict__ keys64, const TailFill tail) {
     // (In a frame beyond its capacities the offsets are clamped and a tile's keys may spill into its neighbour's slots or
     // past cap_keys: the stores stay inside the buffer, slots may stay unwritten, and the sort's epilogue clamps the
     // rank it reads from them -- the caller repeats such a frame.)
@@ -515,6 +523,20 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
             }
         }
         __syncthreads();
+    }
+    // The caller-visible tail of flatten_ids / isect_ids behind the listed pairs (tight lists: [n_listed, M); graph mode:
+    // up to the capacity) is filled with SENTINELS -- flatten_ids -1, isect_ids = last camera | last tile | +inf depth -- so that
+    // gsplat's convention "the last tile's range ends at flatten_ids.numel()" never walks uninitialised entries: the
+    // gather-based compositing forward stops at the first negative id, isect_offset_encode of the padded isect_ids puts the
+    // tail into the last tile.  offsets[n_bins] is final here (bin3_tiles_count_kernel); the sort kernels behind write [0, n_listed).
+    if (tail.mode) {
+        const int64_t from = offsets[n_bins];
+        int64_t to = (int64_t)cap_keys;
+        if (tail.mode == 2) to = min(to, (int64_t)(*tail.totals & 0xFFFFFFFFll));
+        for (int64_t i = from + (int64_t)blockIdx.x * T_THREADS + tid; i < to; i += (int64_t)gridDim.x * T_THREADS) {
+            tail.flatten_ids[i] = -1;
+            if (tail.isect_ids) tail.isect_ids[i] = tail.sentinel_key;
+        }
     }
 }
 
@@ -880,8 +902,10 @@ extern "C" int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t 
 extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
                                int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                                const int64_t *vis_keys, int32_t *rank_ids,
-                               int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, int tight,
+                               int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, int flags,
                                void *ws, size_t ws_bytes, void *stream) {
+    const int tight = flags & MTGS_BIN3_TIGHT;
+    MTGS_REQUIRE((flags & ~(MTGS_BIN3_TIGHT | MTGS_BIN3_FILL_TO_M | MTGS_BIN3_FILL_TO_CAP)) == 0, MTGS_EINVAL, "mtgs_bin3_build: unknown flags %d", flags);
     MTGS_REQUIRE(C > 0 && N >= 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0, MTGS_EINVAL, "mtgs_bin3_build: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_bin3_build: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(mtgs_bin3_supported(C, tile_w, tile_h, cap_M), MTGS_EUNSUPPORTED,
@@ -911,10 +935,13 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
         bin3_rows_place_kernel<false><<<r_grid, R_BLOCK, 0, st>>>(n_vis_ref, recs, vis_ids, N, C, ts, tile_w, tile_h, n_rows, w.row_start,
                                                                  w.rbase, cap_M, w.items);
     }
+    const int tile_bits_ = bit_length_u32((uint32_t)(tile_w * tile_h));
+    const TailFill tail{cap_M > 0 ? ((flags & MTGS_BIN3_FILL_TO_CAP) ? 4 : ((flags & MTGS_BIN3_FILL_TO_M) ? 2 : 0)) : 0, totals, flatten_ids, isect_ids,
+                        ((int64_t)(C - 1) << (32 + tile_bits_)) | ((int64_t)(tile_w * tile_h - 1) << 32) | (int64_t)0x7f800000};
     bin3_tiles_count_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
                                                                             cap_M, w.bins, w.done_tiles, offsets, order, w.n_long);
     bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
-                                                                            offsets, w.cursor, (const uint64_t *)vis_keys, (uint32_t)(cap_M > 0 ? cap_M : 1), w.keys64);
+                                                                            offsets, w.cursor, (const uint64_t *)vis_keys, (uint32_t)(cap_M > 0 ? cap_M : 1), w.keys64, tail);
     const SortEpilogue epi{rank_ids, flatten_ids, isect_ids, vis_ids, (uint32_t)(tile_w * tile_h),
                            bit_length_u32((uint32_t)(tile_w * tile_h)), C == 1, (uint32_t)(cap_vis > 0 ? cap_vis - 1 : 0)};
     static const bool big_lds = [] {

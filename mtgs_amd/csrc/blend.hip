@@ -106,7 +106,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
 #pragma unroll
     for (int r = 0; r < CAND / NT; ++r) {
         const int k = r * NT + tid;
-        const bool in_range = k < n_cand;
+        const bool in_range = k < n_cand && (PK || g[r] >= 0);   // (gather form: a sentinel behind the listed pairs)
         bool keep = in_range;
         float2 xy = make_float2(0.f, 0.f);
         float ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f, s2max = 0.f;
@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 
 #pragma unroll
         for (int p = 0; p < PPL; ++p) all_done = all_done && done[p] == ~0ull;
         if (__syncthreads_and(all_done)) break;
+        // gather form: a negative id is the SENTINEL behind the listed pairs of tight lists / capacity-sized tensors
+        // (mtgs_bin3_build, MTGS_BIN3_FILL_*): gsplat ends the last tile's range at flatten_ids.numel(), the list ends here
+        if (!PK && flatten_ids[b0] < 0) break;
         int32_t g_cur[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) g_cur[r] = g_next[r];

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
             const int64_t r = r0 + threadIdx.x;
             bool nz = false;
             if (r < n_vis) {
-                RowIn ri;
+                RowIn ri = {};      // (a raw row of zeros leaves v_xy / v_conic unassigned below: they must then BE zero when the depth /
+                //                      compensation / normal cotangents alone make the row non-zero)
                 // (everything that is read from the gradient rows is read BEFORE the raw rows are rewritten in place: the
                 //  pointers alias, and a load behind the store would wait for it)
                 ri.v_depth = v_depths[r * gs.depths];

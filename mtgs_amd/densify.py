@@ -162,7 +162,10 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
     extras {name: [N, ...] tensor of a 4-byte dtype}: moved like a parameter (a child / duplicate takes its parent's row) and
     returned in info["extras"] -- the row-lazy optimizer's `last` stamps.  before_rows(parents bool [N]): called after the
     decisions are known and before any row is copied, with the Gaussians that get children or a duplicate -- a caller whose rows are
-    lazy brings THOSE rows up to date there (FusedAdam.catch_up_rows) instead of flushing every row."""
+    lazy brings THOSE rows up to date there (FusedAdam.catch_up_rows) instead of flushing every row.
+    The four GEOMETRY tensors (means, scales, quats, opacities) must be CURRENT when this function is called: the split / cull
+    decisions and the children's positions are computed from them before the hook runs, so the hook is only good for tensors that
+    are copied afterwards (colours, extras).  A caller whose geometry rows are lazy flushes them first."""
     from ._lib import call, ptr, stream_of
     means, scales, quats, opac = (params[k] for k in ("means", "scales", "quats", "opacities"))
     require_gpu(means, scales, quats, opac, *stats)
@@ -199,7 +202,8 @@ def refine_gaussians(params: Dict[str, Tensor], stats: Tuple[Tensor, Tensor, Ten
          _C.c_uint64(seed & (2 ** 64 - 1)), int(step), ptr(src_index), ptr(kind), ptr(new["means"]), ptr(new["scales"]), st)
 
     if before_rows is not None and N > 0:
-        before_rows((flags[:N] & 0x7E) != 0)      # (bits 1 .. 1 + S: a child or the duplicate is kept)
+        assert 1 <= S <= 5, S                      # (flag byte: bit 0 old row kept, bits 1..S children, bit 1+S duplicate, bit 7 split parent)
+        before_rows((flags[:N] & (((1 << (S + 1)) - 1) << 1)) != 0)      # (bits 1 .. 1 + S: a child or the duplicate is kept)
 
     def rows(src, zero_new):
         w = src.numel() // max(N, 1)

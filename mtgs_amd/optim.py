@@ -583,7 +583,8 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: a lazy per-traversal parameter needs its slice (set_active_slice / slice_index)")
                 width = p.numel() // p.shape[0]
                 sw = width // L["T"]
-                r["width"], r["sub_width"], r["sub_index"], r["mode"], r["n"] = width, sw, int(t), MODE_SLICE, p.shape[0] * sw
+                r["width"], r["sub_width"], r["mode"], r["n"] = width, sw, MODE_SLICE, p.shape[0] * sw
+                _put_slice(r, t)      # (a host int or an int32 device scalar: the kernel's slice_of() reads either)
             b1, b2 = grp["betas"]
             r["one_minus_beta1"], r["beta2"], r["one_minus_beta2"] = 1.0 - b1, b2, 1.0 - b2   # (differences taken in double)
             r["eps"], r["weight_decay"], r["grad_scale"] = grp["eps"], grp["weight_decay"], self.grad_scale

@@ -412,10 +412,6 @@ class _RasterizeToPixels(torch.autograd.Function):
 # ------------------------------------------------------------------------------------- fused path
 RECORD_CHANNELS = 8      # blended channels a packed record holds (csrc/raster_rec.hpp)
 speculative_sizing = True  # enqueue binning + compositing before the host knows (n_vis, M); see _SizePlan
-tight_lists = os.environ.get("MTGS_EXACT_LISTS", "0") != "1"   # rasterization(): the tile lists hold only the (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse reaches a
-#                            pixel centre of the tile (mtgs_bin3_build(tight=1)): render / alphas / gradients are unchanged, the meta
-#                            tensors isect_ids / flatten_ids / isect_offsets are ORDERED SUBLISTS of gsplat's (valid length =
-#                            isect_offsets-derived, info["n_listed"]); False (or exact_lists()): gsplat's lists, bit-identical
 _force_caps = None       # tests: (cap_vis, cap_M) used for the speculative attempt, to exercise the overflow path
 _debug_rows = None       # tests: a dict that the fused backward fills with its compact gradient rows {"G", "vis_ids", "DC"}
 
@@ -450,23 +446,53 @@ class _SizePlan(threading.local):
 _size_plan = _SizePlan()
 
 
-class exact_lists:
-    """`with mtgs_amd.exact_lists(): ...` -- rasterization() builds gsplat's tile lists (every tile of the 3-sigma square of
-    every visible Gaussian: isect_ids / flatten_ids / isect_offsets bit-identical to gsplat 1.4.0 isect_tiles +
-    isect_offset_encode) instead of the tight ones (module switch `wrapper.tight_lists`)."""
+class _ListMode(threading.local):
+    """Per thread: which tile lists rasterization() builds (the train thread and the viewer thread of
+    render_state_machine.py:142 each have their own; a context manager entered on one never changes the other's frame)."""
+
+    def __init__(self):
+        self.tight = os.environ.get("MTGS_TIGHT_LISTS", "0") == "1"
+
+
+_list_mode = _ListMode()
+
+
+def lists_are_tight() -> bool:
+    """True while the calling thread builds tight tile lists (inside `with mtgs_amd.tight_lists():`)."""
+    return bool(_list_mode.tight)
+
+
+class tight_lists:
+    """`with mtgs_amd.tight_lists(): ...` -- OPT-IN extension (trainers; never the default): the tile lists hold only the
+    (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse reaches a pixel centre of the tile (mtgs_bin3_build, flag 1).  render /
+    alphas / gradients are bit-identical to the default mode (those pairs are skipped pixel by pixel anyway); the meta tensors
+    isect_ids / flatten_ids / isect_offsets are ORDERED SUBLISTS of gsplat's: `info["n_listed"]` (int32 device scalar) is the number
+    of listed pairs, the offsets are the prefix sums of the tight lists' own lengths, and the tensors keep gsplat's length M with
+    the tail [n_listed, M) filled with SENTINELS (flatten_ids -1; isect_ids = last camera | last tile | +inf depth), so that
+    gsplat's "the last tile's range ends at flatten_ids.numel()" convention stays safe: this package's rasterize_to_pixels stops
+    at the first sentinel, isect_offset_encode of the padded isect_ids attributes the tail to the last tile.
+    Thread-local, like exact_lists()."""
 
     def __init__(self, on: bool = True):
         self.on, self.prev = bool(on), None
 
     def __enter__(self):
-        global tight_lists
-        self.prev, tight_lists = tight_lists, not self.on
+        self.prev, _list_mode.tight = _list_mode.tight, self.on
         return self
 
     def __exit__(self, *exc):
-        global tight_lists
-        tight_lists = self.prev
+        _list_mode.tight = self.prev
         return False
+
+
+class exact_lists(tight_lists):
+    """`with mtgs_amd.exact_lists(): ...` -- gsplat's tile lists (every tile of the 3-sigma square of every visible Gaussian:
+    isect_ids / flatten_ids / isect_offsets bit-identical to gsplat 1.4.0 isect_tiles + isect_offset_encode).  This is the DEFAULT
+    of rasterization(); the context manager pins it inside code that runs under tight_lists() (or MTGS_TIGHT_LISTS=1).
+    Thread-local."""
+
+    def __init__(self, on: bool = True):
+        super().__init__(not on)
 
 
 class _GraphState:
@@ -623,6 +649,11 @@ class _FusedRasterization(torch.autograd.Function):
             # colours, and one pass of the compositing DECISIONS (mtgs_blend_touch_packed) flags the Gaussians the frame composites
             # from -- a few percent of the visible ones in an opaque scene.  Peek, SH evaluation and normals work on those alone.
             touch_first = cs is not None and bool(cs.touch_first)
+            # tile lists of this frame (thread-local mode, read once): gsplat's by default; mtgs_bin3_build flags: 1 = tight lists,
+            # 2 = sentinel-fill the tail [n_listed, M) of flatten_ids / isect_ids (tight lists, tensors sliced to gsplat's M),
+            # 4 = sentinel-fill up to the capacity (graph mode: the tensors are capacity-sized in both list modes)
+            tight = lists_are_tight()
+            list_flags = (1 if tight else 0) | (4 if graph_caps is not None else (2 if tight else 0))
 
             def colours(b, flags):   # colours of the visible Gaussians, straight into their records
                 cap_vis = b["cap_vis"]
@@ -670,7 +701,7 @@ class _FusedRasterization(torch.autograd.Function):
                 off = (-ws.data_ptr()) % 256
                 call("mtgs_bin3_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
                      ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
-                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), int(bool(tight_lists)),
+                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), list_flags,
                      ws.data_ptr() + off,
                      nbytes.value, st)
                 if touch_first:
@@ -715,7 +746,8 @@ class _FusedRasterization(torch.autograd.Function):
             rank_ids, flatten_ids, isect_ids = out["rank_ids"][:M], out["flatten_ids"][:M], out["isect_ids"][:M]
             offsets = offsets_buf[:Cn * th * tw].view(Cn, th, tw)
             offsets._mtgs_tile_order = order
-            offsets._mtgs_n_listed = offsets_buf[Cn * th * tw]     # (device scalar: the number of pairs in the lists)
+            if tight or graph_caps is not None:
+                offsets._mtgs_n_listed = offsets_buf[Cn * th * tw]     # (device scalar: the number of pairs in the lists)
             isect_ids._mtgs_offsets = offsets
         if not packed:
             totals = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -38,7 +38,8 @@ shutil.copy(stats, os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
 avg_us = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(stats))}
 sys.path.insert(0, ROOT)
 from mtgs_amd import _lib  # noqa: E402  (only for the ABI version the profiles were taken with)
-out = {"abi_version": _lib.ABI_VERSION, "_about": "scripts/pmc_step.sh on the MI355X box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ counters in SEPARATE passes "
+out = {"abi_version": _lib.ABI_VERSION, "hot_abi_version": _lib.HOT_ABI_VERSION,
+       "lists": "tight" if os.environ.get("MTGS_TIGHT_LISTS", "0") == "1" else "gsplat", "_about": "scripts/pmc_step.sh on the MI355X box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ counters in SEPARATE passes "
                  "over `bench.py --steps 6 --warmup 2 --cpu-steps 0` (headline workload), per-kernel averages over the launches of "
                  "the run; avg_us from the rocprofv3 --kernel-trace --stats run of scripts/prof_bench.sh.  Counters are KB: bytes = "
                  "value x 1024 x correction.",

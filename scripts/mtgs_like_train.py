@@ -20,6 +20,11 @@ import sys
 import time
 from pathlib import Path
 
+# A TRAINER opts into the tight tile lists (mtgs_amd.tight_lists: same pixels and gradients, shorter lists): rasterization()'s own
+# default is gsplat's lists.  Process-wide here (every thread of this script, the `--dp` ranks are processes); MTGS_TIGHT_LISTS=0
+# runs the script on gsplat's lists.
+os.environ.setdefault("MTGS_TIGHT_LISTS", "1")
+
 import torch
 import torch.nn.functional as F
 

@@ -38,9 +38,9 @@ def hip_lib():
 
 @pytest.fixture(params=["tight", "gsplat"])
 def lists_mode(request):
-    """Both forms of the fused path's tile lists: the tight ones (default) and gsplat's own (mtgs_amd.exact_lists())."""
+    """Both forms of the fused path's tile lists: gsplat's own (the default) and the tight ones (`with mtgs_amd.tight_lists():`)."""
     import mtgs_amd
-    with mtgs_amd.exact_lists(request.param == "gsplat"):
+    with mtgs_amd.tight_lists(request.param == "tight"):
         yield request.param
 
 

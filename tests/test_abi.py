@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol(hip_lib):
     raw = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
         assert hasattr(raw, s), f"{s} not exported by libmtgs_rast.so"
-    assert hip_lib.mtgs_rast_version() == _lib.ABI_VERSION == 24
+    assert hip_lib.mtgs_rast_version() == _lib.ABI_VERSION == 25
+    assert hip_lib.mtgs_rast_hot_version() == _lib.HOT_ABI_VERSION
 
 
 def test_host_side_argument_validation(hip_lib):

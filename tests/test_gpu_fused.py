@@ -390,8 +390,8 @@ def test_many_cameras_in_one_call_take_the_packed_path(hip_lib, lists_mode):
 @pytest.mark.parametrize("N,W,H,C,D,needles", [(60_000, 320, 200, 1, 3, False), (200_000, 640, 480, 1, 3, False), (120_000, 640, 360, 3, 3, False),
                                                (500_000, 960, 540, 1, 6, False), (80_000, 640, 360, 2, 3, True)])
 def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D, needles):
-    """The default tile lists hold only the (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse reaches a pixel centre of the
-    tile (mtgs_bin3_build(tight=1)).  Against gsplat's lists (mtgs_amd.exact_lists(): every tile of the 3-sigma square): render and
+    """The opt-in tight tile lists (`with mtgs_amd.tight_lists():`) hold only the (tile, Gaussian) pairs whose {alpha >= 1/255} ellipse
+    reaches a pixel centre of the tile (mtgs_bin3_build, MTGS_BIN3_TIGHT).  Against gsplat's lists (the default: every tile of the 3-sigma square): render and
     alphas are BIT-identical -- every pair left out is skipped pixel by pixel by gsplat's own `alpha < 1/255` rule -- the
     gradients agree to the order of the fp32 atomics, the lists are ordered sublists, and they are much shorter."""
     import mtgs_amd
@@ -433,6 +433,67 @@ def test_tight_tile_lists_change_no_pixel_and_no_gradient(hip_lib, N, W, H, C, D
         assert float((g0[k] - g1[k]).abs().max()) <= 4.0 * noise + 2e-4 * float(g0[k].abs().max()) + 1e-7, (k, noise)
     for k in ("radii", "tiles_per_gauss"):
         assert torch.equal(i0[k], i1[k])
-    assert int(i0["n_listed"]) == i0["flatten_ids"].numel() == i1["flatten_ids"].numel()
-    assert_tile_lists(i1, {k: listed(i0, k) if k != "isect_offsets" else i0[k] for k in ("isect_offsets", "flatten_ids", "isect_ids")})
-    assert int(i1["n_listed"]) < 0.8 * int(i0["n_listed"]), (int(i1["n_listed"]), int(i0["n_listed"]))
+    assert i0.get("n_listed") is None and i0["flatten_ids"].numel() == i1["flatten_ids"].numel()     # (gsplat's M in both modes)
+    assert_tile_lists(i1, {k: i0[k] for k in ("isect_offsets", "flatten_ids", "isect_ids")}, tight=True)
+    assert int(i1["n_listed"]) < 0.8 * i0["flatten_ids"].numel(), (int(i1["n_listed"]), i0["flatten_ids"].numel())
+
+
+@pytest.mark.parametrize("mode", ["gsplat", "tight"])
+@pytest.mark.parametrize("N,W,H,C,rmode", [(60_000, 320, 200, 1, "classic"), (150_000, 640, 360, 2, "antialiased")])
+def test_meta_lists_feed_rasterize_to_pixels(hip_lib, mode, N, W, H, C, rmode):
+    """gsplat's pattern: the tensors of rasterization()'s `meta` go back into the operators --
+        rasterize_to_pixels(info["means2d"], info["conics"], colors, info["opacities"], W, H, 16, info["isect_offsets"], info["flatten_ids"])
+    -- and reproduce `render` / `alphas` BIT FOR BIT, with the lists passed as CLONES (nothing rides on the tensor objects) and
+    gsplat's convention that the last tile's range ends at flatten_ids.numel().  Default call: gsplat's lists, numel == M.
+    Under tight_lists(): the tensors keep gsplat's length and hold sentinels behind n_listed, which the operator stops at; the
+    offsets re-encoded from the (padded) isect_ids are the tight lists' own.  Backward through the re-fed lists works too."""
+    import mtgs_amd
+    from mtgs_amd import rasterization, wrapper as w
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    P = _scene(N, 3, 11, dev)
+    vms, Ks = zip(*[make_camera(W, H, yaw_deg=20.0 * c) for c in range(C)])
+    vm, K = torch.cat(vms).to(dev), torch.cat(Ks).to(dev)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    with mtgs_amd.tight_lists(mode == "tight"), torch.no_grad():
+        render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K, W, H, packed=False,
+                                            rasterize_mode=rmode)
+    M = int(info["tiles_per_gauss"].sum())
+    assert info["flatten_ids"].numel() == M == info["isect_ids"].numel()          # gsplat's length in both modes
+    if mode == "gsplat":
+        assert "n_listed" not in info
+    else:
+        n = int(info["n_listed"])
+        assert 0 < n < M and bool((info["flatten_ids"][n:] == -1).all()) and bool((info["flatten_ids"][:n] >= 0).all())
+    flat, ids, off = info["flatten_ids"].clone(), info["isect_ids"].clone(), info["isect_offsets"].clone()
+    assert torch.equal(w.isect_offset_encode(ids, C, tw, th), off)
+    cols = P["colors"].detach().unsqueeze(0).expand(C, -1, -1).contiguous().requires_grad_(True)
+    m2d = info["means2d"].clone().requires_grad_(True)
+    r2, a2 = w.rasterize_to_pixels(m2d, info["conics"].clone(), cols, info["opacities"].clone(), W, H, 16, off, flat)
+    assert torch.equal(r2, render) and torch.equal(a2, alpha)
+    (r2.sum() + a2.sum()).backward()
+    assert torch.isfinite(cols.grad).all() and torch.isfinite(m2d.grad).all() and float(cols.grad.abs().max()) > 0
+
+
+def test_graph_mode_tensors_end_in_sentinels(hip_lib):
+    """Inside graph_mode the list tensors are capacity-sized in BOTH list modes: the entries behind the listed pairs are sentinels
+    (never uninitialised), info["n_listed"] is the device count of listed pairs."""
+    import mtgs_amd
+    from mtgs_amd import rasterization
+    from mtgs_amd.synthetic import make_camera
+    dev = torch.device("cuda")
+    N, W, H = 50_000, 320, 200
+    P = _scene(N, 3, 12, dev)
+    vm, K = (t.to(dev) for t in make_camera(W, H))
+    with torch.no_grad():
+        _, _, eager = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K, W, H, packed=False)
+    M, n_vis = eager["flatten_ids"].numel(), int((eager["radii"] > 0).sum())
+    for tight in (False, True):
+        with mtgs_amd.tight_lists(tight), mtgs_amd.graph_mode(n_vis + 100, M + 777), torch.no_grad():
+            _, _, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vm, K, W, H, packed=False)
+        torch.cuda.synchronize()
+        n = int(info["n_listed"])
+        assert info["flatten_ids"].numel() == M + 777 and (n == M if not tight else 0 < n < M)
+        assert bool((info["flatten_ids"][n:] == -1).all()) and bool((info["isect_ids"][n:] == info["isect_ids"][-1]).all())
+        if not tight:
+            assert torch.equal(info["flatten_ids"][:M], eager["flatten_ids"]) and torch.equal(info["isect_ids"][:M], eager["isect_ids"])

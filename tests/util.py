@@ -48,23 +48,33 @@ def listed(info, key="flatten_ids"):
     return info[key] if n is None else info[key][:int(n)]
 
 
-def assert_tile_lists(info, ref, rerun=None):
+def n_listed(info) -> int:
+    """Number of (tile, Gaussian) pairs in the lists of a rasterization() meta (info["n_listed"] exists under tight_lists() and
+    in graph_mode; otherwise the tensors hold exactly gsplat's pairs)."""
+    n = info.get("n_listed")
+    return int(info["flatten_ids"].numel()) if n is None else int(n)
+
+
+def assert_tile_lists(info, ref, rerun=None, tight=None):
     """The tile lists of a fused rasterization() against gsplat's (`ref`: the oracle's meta or the operator path's tensors:
     isect_offsets, flatten_ids, optionally isect_ids).
-    * gsplat's lists requested (mtgs_amd.exact_lists()): bit-identical.
-    * tight lists (the default): ORDERED SUBLISTS -- every listed (tile, Gaussian) pair is one of gsplat's, tile by tile in
-      gsplat's order, with gsplat's isect_ids; the offsets are the prefix sums of the lists' own lengths.  (That no pair with a
-      contributing pixel is left out is what the image comparisons establish: tests/test_gpu_fused.py compares the two modes
-      bit for bit.)
-    rerun: a callable that repeats the forward and returns its info -- run under exact_lists() and compared bit for bit."""
+    * gsplat's lists (the DEFAULT of rasterization(); mtgs_amd.exact_lists()): bit-identical.
+    * tight lists (opt-in, `with mtgs_amd.tight_lists():`): ORDERED SUBLISTS -- every listed (tile, Gaussian) pair is one of
+      gsplat's, tile by tile in gsplat's order, with gsplat's isect_ids; the offsets are the prefix sums of the lists' own
+      lengths; the tail [n_listed, numel) holds the sentinels (flatten_ids -1, isect_ids = last camera | last tile | +inf).
+      (That no pair with a contributing pixel is left out is what the image comparisons establish: tests/test_gpu_fused.py
+      compares the two modes bit for bit.)
+    tight: which of the two `info` was made under (default: the calling thread's current mode).
+    rerun: a callable that repeats the forward and returns its info -- run under the OTHER mode and checked as that mode."""
     import mtgs_amd
-    from mtgs_amd import wrapper
     a = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+    if tight is None:
+        tight = mtgs_amd.lists_are_tight()
     off_ref, flat_ref = a(ref["isect_offsets"]).reshape(-1).astype(np.int64), a(ref["flatten_ids"]).astype(np.int64)
     n = int(info["n_listed"]) if info.get("n_listed") is not None else int(info["flatten_ids"].numel())
     off, flat = a(info["isect_offsets"]).reshape(-1).astype(np.int64), a(info["flatten_ids"])[:n].astype(np.int64)
     assert off.shape == off_ref.shape
-    if not wrapper.tight_lists:
+    if not tight:
         assert n == flat_ref.size and np.array_equal(flat, flat_ref) and np.array_equal(off, off_ref)
         if "isect_ids" in ref:
             assert np.array_equal(a(info["isect_ids"])[:n], a(ref["isect_ids"]))
@@ -83,13 +93,18 @@ def assert_tile_lists(info, ref, rerun=None):
         assert np.all(np.diff(at) > 0), "listed pairs are not in gsplat's order"
         if "isect_ids" in ref and n:
             assert np.array_equal(a(info["isect_ids"])[:n], a(ref["isect_ids"])[at])
+        # the tail behind the listed pairs: sentinels, never uninitialised memory (device tensors only: hand-made lists of
+        # tests/test_tile_list_checker.py carry their own padding)
+        tail = a(info["flatten_ids"])[n:]
+        if tail.size and hasattr(info["flatten_ids"], "is_cuda") and info["flatten_ids"].is_cuda:
+            assert np.all(tail == -1), "flatten_ids behind n_listed must be -1"
+            if "isect_ids" in info and info["isect_ids"] is not None:
+                ids_tail = a(info["isect_ids"])[n:]
+                assert np.all((ids_tail & 0xFFFFFFFF) == 0x7f800000) and np.all(ids_tail == ids_tail[0])
     if rerun is not None:
-        with mtgs_amd.exact_lists():
-            ex = rerun()
-        assert ex.get("n_listed") is None or int(ex["n_listed"]) == flat_ref.size
-        assert np.array_equal(a(ex["flatten_ids"]), flat_ref) and np.array_equal(a(ex["isect_offsets"]).reshape(-1), off_ref)
-        if "isect_ids" in ref:
-            assert np.array_equal(a(ex["isect_ids"]), a(ref["isect_ids"]))
+        with mtgs_amd.tight_lists(not tight):
+            other = rerun()
+        assert_tile_lists(other, ref, rerun=None, tight=not tight)
 
 
 def assert_image_close(got, ref, critical, tol=1e-4, flip_bound=1.0 / 255.0, name="render", scale=None, case="",
