@@ -79,6 +79,11 @@ def parse_args():
                     help="N > 1: sparse = all-gather of 64-byte rows of the visible Gaussians, SH-coefficient "
                          "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
                          "dense = plain all-reduce of every gradient tensor")
+    ap.add_argument("--dp-finish", choices=["static", "dynamic"], default="static",
+                    help="N > 1, sparse exchange: static = SparseGradExchange.finish_static (ONE fixed-capacity all-gather of the wire "
+                         "rows, capacity = the ranks' largest warm-up row count + 5 %%, no host read between render and reduce: the form a "
+                         "HIP graph can capture); dynamic = finish() (row counts read on the host, chunked all-gathers pipelined with "
+                         "the reduction)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="N = 1: graph (default): the K steps are timed twice -- "
                     "launched eagerly (~40 kernel launches and ~15 library calls per step from Python) and as ONE HIP graph launch each "
@@ -138,7 +143,12 @@ def make_step(args, dev, world):
                                                          render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
             torch.autograd.backward([render, alpha], [Gc, Ga])
             ev["rows"].record()
-            g = exchange.finish(params["means"], 3)
+            cap = info_box.get("static_cap")
+            if cap:      # no host read, no host wait: one fixed-capacity all-gather, counts stay on the device
+                g, ovf = exchange.finish_static(params["means"], 3, cap, [0] * world)
+                info_box["overflow"] = ovf if info_box.get("overflow") is None else (info_box["overflow"] | ovf)
+            else:
+                g = exchange.finish(params["means"], 3)
             for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
                 params[name].grad = t
             ev["end"].record()
@@ -407,12 +417,62 @@ def cpu_baseline(args, host, steps):
                       f"fwd+bwd, variant {args.variant}) by oracle/gsplat_oracle.c with OpenMP; median"}
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this process has not touched
+    the GPU: it never calls torch.cuda.is_available() / any HIP function -- torch.cuda.device_count() does not initialise it),
+    one per GPU, rendezvous on 127.0.0.1, and exit with the worst of their exit codes.  Rank 0 prints the JSON line on the
+    inherited stdout.  Fewer GPUs than ranks is refused unless MTGS_DIST_BACKEND=gloo says the ranks are MEANT to share GPUs
+    (a functional run of the N > 1 path on a one-GPU box, not a scaling measurement)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    n_dev = torch.cuda.device_count()
+    if n_dev < n and os.environ.get("MTGS_DIST_BACKEND") != "gloo":
+        print(json.dumps({"bench_error": f"--gpus {n} but {n_dev} GPU(s) visible: refusing to run {n} ranks on fewer GPUs "
+                                         "(set MTGS_DIST_BACKEND=gloo for a functional run with ranks sharing a GPU)"}), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p_ in list(pending):
+                rc = p_.poll()
+                if rc is None:
+                    continue
+                pending.remove(p_)
+                if rc != 0:
+                    worst = max(worst, abs(rc) or 1)
+                    for q in pending:       # a rank died: the others would wait for it until the collective timeout
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return worst
+
+
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(args))          # (before anything touches the GPU)
+    if int(env_world or "1") != args.gpus:
+        # never a silent N = 1 (or N = something else) number under an `--gpus N` label
+        print(json.dumps({"bench_error": f"--gpus {args.gpus} but WORLD_SIZE={env_world or 1}: launch with "
+                                         f"`python bench.py --gpus {args.gpus}` (spawns its ranks) or torchrun --nproc-per-node {args.gpus}"}),
+              file=sys.stderr)
+        sys.exit(2)
     from mtgs_amd import _lib, dist as mdist
     rank, local_rank, world = mdist.init_from_env(timeout_s=300.0)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -439,6 +499,17 @@ def main():
             step()
         torch.cuda.synchronize()
         barrier()
+        ex_ = info_box.get("exchange")
+        if world > 1 and ex_ is not None and args.dp_finish == "static":
+            # the static exchange's row capacity: the largest row count any rank saw in the warm-up (dynamic) steps + 5 %, agreed
+            # on by ONE setup collective; from here on the step never reads a count on the host
+            t_cap = torch.tensor([float(ex_.n_vis)], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
+            info_box["static_cap"] = int(float(t_cap.item()) * 1.05) + 1024
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            barrier()
     except Exception as e:      # noqa: BLE001
         fail("warm-up", e)
     _lib.time_calls(DOMINANT)
@@ -453,6 +524,8 @@ def main():
     except Exception as e:      # noqa: BLE001
         fail("timed steps", e)
     elapsed = time.perf_counter() - t0
+    if info_box.get("overflow") is not None and bool(info_box["overflow"]):
+        fail("timed steps", RuntimeError(f"static exchange: a rank had more wire rows than the capacity {info_box['static_cap']}"))
     kernel_ms = [t for name in DOMINANT for t in _lib.timed_ms().get(name, [])]
     _lib.time_calls(())
     # (detached: the info of a step holds means2d and with it the step's autograd graph, whose AccumulateGrad nodes would be reused
@@ -668,8 +741,10 @@ def main():
                       (f" (graph launch failed: {graph_error})" if graph_error else
                        (" (timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)"
                         if elapsed_graph is not None else "")),
-            "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange, "
-                           f"{info_box['grad_bytes']} bytes received per rank per step",
+            "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange"
+                           + (f" ({'finish_static: one all-gather of ' + str(info_box['static_cap']) + ' rows per rank, no host read' if info_box.get('static_cap') else 'finish: chunked all-gathers sized on the host'})"
+                              if (world > 1 and info_box.get("exchange") is not None) else "")
+                           + f", {info_box['grad_bytes']} bytes received per rank per step",
         },
         "roofline": {"kernel": "blend_bwd_kernel<4,4,packed> (mtgs_blend_bwd_packed)", "bound": "hbm",
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
