@@ -250,6 +250,17 @@ class SparseGradExchange:
     def after_front(self):
         """Called right after the front kernels are enqueued: all-gather the meta records on the side stream and bring
         the row counts / chunk starts of every rank to pinned host memory -- overlaps the binning and the compositing."""
+        if self.comm_stream is None:
+            # CPU tensors (tests/test_dist_gloo.py: the host-side bookkeeping of the exchange over gloo): the same collective and
+            # the same samples, no streams or events
+            if self.world > 1 or self.world_collectives:
+                metas = torch.empty((self.world, self.meta_len), dtype=torch.int32, device=self.device)
+                dist.all_gather_into_tensor(metas, self.meta[None].contiguous(), group=self.group)
+            else:
+                metas = self.meta[None]
+            self._samples_host.copy_(metas[:, self._sample_idx])
+            self._pending = {"stage": "meta", "metas": metas, "done": None}
+            return
         ev = torch.cuda.Event()
         ev.record()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -328,6 +339,52 @@ class SparseGradExchange:
         self.phase = "idle"
         return out, overflow
 
+    # ---- host-side bookkeeping of finish(): pure functions of the samples every rank holds after the meta all-gather ----------
+    def plan(self, samples) -> dict:
+        """What finish() derives on the host from `samples[world, n_chunks + 2]` (row count | row index at every chunk boundary
+        | traversal of the rank's camera -- the words _sample_idx picks out of every rank's meta record):
+          counts[r]; starts[r][c] = first row of index chunk c in rank r's rows (+ the count as the last entry);
+          caps[c] = rows per rank in the all-gather of chunk c (the largest chunk of any rank, at least 1: equal sizes for all);
+          trav[r]; masks[t] = bit mask of the ranks that rendered traversal t; present = traversals some rank rendered;
+          subsets = [all ranks] + [masks[t] for t in present] (subset 0: geometry / coef_all; 1 + j: colour group of present[j]);
+          union_caps[i] = upper bound of the rows of subset i's union (sum of its ranks' counts, at most N).
+        Identical on every rank (it is a function of the all-gathered samples only), so the ranks issue identical collectives."""
+        world, T, nch = self.world, self.T, self.n_chunks
+        counts = [int(samples[r][0]) for r in range(world)]
+        starts = [[int(samples[r][1 + c]) for c in range(nch)] + [counts[r]] for r in range(world)]
+        caps = [max(max(starts[r][c + 1] - starts[r][c] for r in range(world)), 1) for c in range(nch)]
+        trav = [int(samples[r][len(self.bounds)]) for r in range(world)]
+        masks = [sum(1 << r for r in range(world) if trav[r] == t) for t in range(T)]
+        present = [t for t in range(T) if masks[t]]
+        subsets = [(1 << world) - 1] + [masks[t] for t in present]
+        union_caps = [min(self.N, sum(c for r, c in enumerate(counts) if (m >> r) & 1)) for m in subsets]
+        return {"counts": counts, "starts": starts, "caps": caps, "trav": trav, "masks": masks, "present": present,
+                "subsets": subsets, "union_caps": union_caps}
+
+    def gather_rows(self, plan: dict):
+        """Every chunk's all-gather, issued up front (they queue on the collective stream): chunk c of rank r's rows is
+        rows[starts[r][c] : starts[r][c] + caps[c]] -- a FIXED count per rank, so the tail of a short chunk carries rows of the
+        next chunk (or slack), which the receiver never reads: it finds a Gaussian's row through the sender's map
+        (prefix - starts[r][c]).  Returns (works, recvs[c] [world, caps[c], ROW])."""
+        world, dev = self.world, self.device
+        works, recvs = [], []
+        self.last_bytes = 0
+        for c in range(self.n_chunks):
+            cap = plan["caps"][c]
+            self.phase = f"exchange: issuing the row all-gather of chunk {c} of {self.n_chunks} ({cap} rows per rank)"
+            if world > 1 or self.world_collectives:
+                recv = torch.empty((world, cap, self.ROW), dtype=torch.float32, device=dev)
+                s0 = plan["starts"][self.rank][c]
+                works.append(dist.all_gather_into_tensor(recv.view(world * cap, self.ROW), self.rows[s0:s0 + cap],
+                                                         group=self.group, async_op=True))
+                self.last_bytes += world * cap * self.ROW * 4
+            else:
+                recv = self.rows[plan["starts"][0][c]:]
+                works.append(None)
+            recvs.append(recv)
+        self.last_bytes += world * self.meta_len * 4 if world > 1 else 0
+        return works, recvs
+
     def finish(self, means: torch.Tensor, sh_degree: int, rows: bool = False, all_colour_ranges=()):
         """After backward(): exchange the wire rows and return (v_means, v_quats, v_scales, v_opacities, v_coeffs) --
         the dense sums over all ranks of the gradients that flowed through `rasterization()`.
@@ -351,7 +408,8 @@ class SparseGradExchange:
         means = means.detach().contiguous()
         st = stream_of(means)
         self.phase = "exchange: waiting for the meta all-gather (visibility maps)"
-        P["done"].synchronize()          # side stream only: finished while the frame was composited
+        if P["done"] is not None:
+            P["done"].synchronize()      # side stream only: finished while the frame was composited
         samples = self._samples_host.numpy()
         metas = P["metas"]
         if self.comm_stream is not None:
@@ -360,15 +418,12 @@ class SparseGradExchange:
         words_all, prefix_all = metas[:, 4:], metas[:, 4 + 2 * nw:]
         T = self.T
         # per-traversal appearance: the senders of traversal t (a bit mask) write slice t of the coefficient gradient
-        trav = [int(samples[r][len(self.bounds)]) for r in range(world)]
-        masks = [sum(1 << r for r in range(world) if trav[r] == t) for t in range(T)]
+        pl = self.plan(samples)
+        masks, present, subsets = pl["masks"], pl["present"], pl["subsets"]
         R = None
         if rows:
             import ctypes as _C
-            counts = [int(samples[r][0]) for r in range(world)]
-            present = [t for t in range(T) if masks[t]]
-            subsets = [(1 << world) - 1] + [masks[t] for t in present]       # subset 0: all ranks (geometry, coef_all)
-            caps = [min(N, sum(c for r, c in enumerate(counts) if (m >> r) & 1)) for m in subsets]
+            caps = pl["union_caps"]
             n_sub = len(subsets)
             masks_dev = torch.tensor(np.asarray(subsets, dtype=np.uint64).view(np.int64), dtype=torch.int64, device=dev)
             uw = torch.empty((n_sub, max(nw, 1)), dtype=torch.int64, device=dev)
@@ -401,25 +456,9 @@ class SparseGradExchange:
         w0, w1, red = ev(), ev(), []
         # every chunk's all-gather is issued up front (they queue on the collective stream); chunk c is reduced as soon as
         # it has arrived, while the later chunks are still on the wire
-        starts = [[int(samples[r][1 + c]) for c in range(self.n_chunks)] + [int(samples[r][0])] for r in range(world)]
-        works, recvs, caps = [], [], []
         w0.record()
-        self.last_bytes = 0
-        for c in range(self.n_chunks):
-            cap = max(max(starts[r][c + 1] - starts[r][c] for r in range(world)), 1)
-            self.phase = f"exchange: issuing the row all-gather of chunk {c} of {self.n_chunks} ({cap} rows per rank)"
-            if world > 1 or self.world_collectives:
-                recv = torch.empty((world, cap, self.ROW), dtype=torch.float32, device=dev)
-                s0 = starts[self.rank][c]
-                works.append(dist.all_gather_into_tensor(recv.view(world * cap, self.ROW), self.rows[s0:s0 + cap],
-                                                         group=self.group, async_op=True))
-                self.last_bytes += world * cap * self.ROW * 4
-            else:
-                recv, s0 = self.rows[starts[0][c]:], 0
-                works.append(None)
-            recvs.append(recv)
-            caps.append(cap)
-        self.last_bytes += world * self.meta_len * 4 if world > 1 else 0
+        works, recvs = self.gather_rows(pl)
+        caps = pl["caps"]
         for c in range(self.n_chunks):
             self.phase = f"exchange: wire + reduction of chunk {c} of {self.n_chunks}"
             if works[c] is not None:

@@ -112,3 +112,110 @@ def test_camera_sharding_covers_all_cameras():
     for step in range(3):
         assert sorted(camera_for_rank(step, r, world, n_cam) for r in range(world)) == list(range(8))
     assert [camera_for_rank(s, 0, 2, 5) for s in range(5)] == [0, 2, 4, 1, 3]
+
+
+# ---- the default exchange (SparseGradExchange): its HOST-SIDE bookkeeping over gloo, CPU tensors, no kernels ---------------------
+def _sparse_inputs(rank, N, T):
+    """A rank's frame as the front / projection-backward kernels would leave it: visibility mask, meta record
+    [count, cam xyz | words u64 | prefix u32 | traversal, spare] and the wire rows of its visible Gaussians in index order."""
+    g = np.random.default_rng(100 + rank)
+    vis = g.random(N) < (0.15 + 0.1 * rank)
+    vis[N // 2: N // 2 + 300] = rank == 0            # a stretch only rank 0 sees (an index chunk where the other ranks' share is short)
+    idx = np.nonzero(vis)[0]
+    rows = g.standard_normal((idx.size, 16)).astype(np.float32)
+    rows[:, 15] = idx.astype(np.int32).view(np.float32)
+    nw = (N + 63) // 64
+    bits = np.zeros(nw * 64, dtype=np.uint8)
+    bits[:N] = vis
+    words = np.packbits(bits.reshape(nw, 64), axis=1, bitorder="little").view(np.uint64).reshape(nw)
+    prefix = np.concatenate([[0], np.cumsum(bits.reshape(nw, 64).sum(1))[:-1]]).astype(np.uint32)
+    cam = np.array([1.0 + rank, -2.0, 0.5 * rank], dtype=np.float32)
+    trav = (rank + 1) % T
+    return vis, idx, rows, words, prefix, cam, trav
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, str(ROOT))
+    from mtgs_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    N, T, K = 5000, 2, 16
+    ex = mdist.SparseGradExchange(N, K, "cpu", chunks=3, traversals=T)
+    assert ex.bounds == [0, 2048, 4096, 5000] and ex.n_chunks == 3 and (ex.world, ex.rank) == (world, rank)
+    vis, idx, rows, words, prefix, cam, trav = _sparse_inputs(rank, N, T)
+    nw = ex.n_words
+    # what mtgs_front_fwd / SparseGradExchange.rasterization() write into the meta record, and mtgs_project_bwd_rows into the rows
+    meta = np.zeros(ex.meta_len, dtype=np.int32)
+    meta[0] = idx.size
+    meta[1:4] = cam.view(np.int32)
+    meta[4:4 + 2 * nw] = words.view(np.int32)
+    meta[4 + 2 * nw:4 + 3 * nw] = prefix.view(np.int32)
+    meta[ex.meta_len - 2] = trav
+    ex.meta.copy_(torch.from_numpy(meta))
+    ex.rows[:idx.size] = torch.from_numpy(rows)
+    ex.rows[idx.size:] = float("nan")                 # slack behind the rows: may travel, must never be read
+    ex._pending = {"stage": "forward"}
+    ex.after_front()                                   # the meta all-gather + the samples every rank's plan is a function of
+    pl = ex.plan(ex._samples_host.numpy())
+    works, recvs = ex.gather_rows(pl)
+    for w in works:
+        w.wait()
+    # ---- the plan against an independent count from every rank's mask (regenerated from its seed)
+    others = [_sparse_inputs(r, N, T) for r in range(world)]
+    for r, (vis_r, idx_r, _, _, _, _, trav_r) in enumerate(others):
+        assert pl["counts"][r] == idx_r.size and pl["trav"][r] == trav_r
+        assert pl["starts"][r] == [int(vis_r[:b].sum()) for b in ex.bounds[:-1]] + [idx_r.size]
+    for c in range(ex.n_chunks):
+        assert pl["caps"][c] == max(max(int(o[0][ex.bounds[c]:ex.bounds[c + 1]].sum()) for o in others), 1)
+    assert pl["masks"] == [sum(1 << r for r in range(world) if others[r][6] == t) for t in range(T)]
+    assert pl["present"] == [t for t in range(T) if pl["masks"][t]] and pl["subsets"][0] == (1 << world) - 1
+    assert pl["subsets"][1:] == [pl["masks"][t] for t in pl["present"]]
+    assert pl["union_caps"][0] == min(N, sum(o[1].size for o in others))
+    assert ex.last_bytes == sum(world * cap * 64 for cap in pl["caps"]) + world * ex.meta_len * 4
+    # ---- every sender's row of every Gaussian is where the receiver's kernel looks for it: block c, row prefix(n) - starts[r][c]
+    metas = ex._pending["metas"].numpy()
+    dense = np.zeros((N, 15), dtype=np.float64)        # what the reduction sums: all ranks, index by index
+    per_trav = {t: np.zeros((N, 3), dtype=np.float64) for t in range(T)}       # the colour part goes to the SENDER's traversal
+    for r in range(world):
+        w64 = metas[r, 4:4 + 2 * nw].copy().view(np.uint64)
+        pre = metas[r, 4 + 2 * nw:4 + 3 * nw].copy().view(np.uint32)
+        assert np.array_equal(metas[r, 1:4].view(np.float32), others[r][5])
+        for c in range(ex.n_chunks):
+            b0, b1 = ex.bounds[c], ex.bounds[c + 1]
+            for n in np.nonzero(others[r][0][b0:b1])[0] + b0:
+                word, bit = int(w64[n >> 6]), int(n & 63)
+                assert (word >> bit) & 1
+                row_abs = int(pre[n >> 6]) + bin(word & ((1 << bit) - 1)).count("1")
+                k = row_abs - pl["starts"][r][c]
+                assert 0 <= k < pl["caps"][c]
+                row = recvs[c][r, k].numpy()
+                assert int(row[15:16].view(np.int32)[0]) == n and not np.isnan(row[:15]).any()
+                dense[n] += row[:15]
+                per_trav[others[r][6]][n] += row[11:14]
+    ref = np.zeros((N, 15), dtype=np.float64)
+    for (_, idx_r, rows_r, *_rest) in others:
+        ref[idx_r] += rows_r[:, :15]
+    assert np.array_equal(dense, ref)                   # ranks == accumulation over the cameras, through the wire layout
+    for t in range(T):
+        sel = np.zeros((N, 3))
+        for (_, idx_r, rows_r, _, _, _, trav_r) in others:
+            if trav_r == t:
+                sel[idx_r] += rows_r[:, 11:14]
+        assert np.array_equal(per_trav[t], sel)
+    np.save(Path(out_dir) / f"sparse{rank}.npy", dense)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparse_exchange_bookkeeping_over_gloo(tmp_path, world):
+    """SparseGradExchange's host logic with `world` ranks over gloo on CPU tensors: meta all-gather -> samples -> plan (counts, chunk
+    starts, equal per-chunk capacities, traversal masks / subsets, union capacities) -> chunked row all-gathers.  Every rank
+    finds every sender's row of every visible Gaussian at block c, row prefix(n) - starts[r][c] (the receiver kernels' address
+    rule), the sums equal the accumulation over all cameras, the colour part is routed to the sender's traversal, and the
+    ranks agree bit for bit.  (The kernels that consume this layout are covered on the GPU: tests/test_gpu_dp.py.)"""
+    port = _free_port()
+    mp.spawn(_sparse_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"sparse{r}.npy") for r in range(world)]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
