@@ -41,7 +41,7 @@ extern "C" {
 /* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
-#define MTGS_RAST_HOT_ABI_VERSION 1
+#define MTGS_RAST_HOT_ABI_VERSION 2
 #define MTGS_BIN3_TIGHT 1
 #define MTGS_BIN3_FILL_TO_M 2
 #define MTGS_BIN3_FILL_TO_CAP 4
@@ -57,6 +57,9 @@ enum {
 /* Fixed algorithm constants (gsplat 1.4.0 semantics; see oracle/gsplat_oracle.c for citations) */
 #define MTGS_TILE_SIZE 16
 #define MTGS_ALPHA_MAX 0.999f
+/* exp(-sigma) is evaluated as exp2(-s2 * log2(e)/2); the compositing kernels fold the factor into the staged conic (blend.hip) */
+#define MTGS_HALF_LOG2E 0.72134752044448170368f
+#define MTGS_HALF_LOG2E_INV 1.38629436111989061883f
 #define MTGS_ALPHA_MIN (1.0f / 255.0f)
 #define MTGS_T_MIN 1e-4f
 #define MTGS_MAX_SH_DEGREE 4
@@ -358,8 +361,9 @@ int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const
 int mtgs_blend_touch_packed(int C, const float *recs, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                             const int32_t *rank_ids, const int32_t *tile_order, uint8_t *touched, int64_t cap_vis, void *stream);
 /* mtgs_blend_bwd_packed (ABI v22): grad_rows[n_vis, row_stride] holds RAW MOMENT rows -- with h = vis * dL/dalpha per (pixel,
- * Gaussian) pair (gsplat's v_sigma = -opacity h): {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 |
- * sum h | colours D | depth}; u = a dx + b dy, w = b dx + c dy.  The conic map of the position gradient and the factor -opacity
+ * Gaussian) pair (gsplat's v_sigma = -opacity h): {sum h dx, sum h dy | k sum |h u|, k sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 |
+ * sum h | colours D | depth}; u = a dx + b dy, w = b dx + c dy, k = MTGS_HALF_LOG2E (hot ABI v2: the kernels stage the conic with
+ * that factor folded in, so that alpha = opacity * exp2(-s2) costs no multiply per pixel).  The conic map of the position gradient and the factor -opacity
  * are applied once per Gaussian by the row's consumer (mtgs_project_bwd(raw_rows), mtgs_project_bwd_rows(raw_rows = 1)), which
  * writes {v_xy, |v_xy|, v_conic, v_opacity_eff} back in place.  (mtgs_blend_bwd writes those directly.) */
 int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,

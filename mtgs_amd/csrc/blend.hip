@@ -53,9 +53,10 @@ constexpr float kTMin = MTGS_T_MIN;
 // alpha = opacity * exp(-sigma) <= opacity (sigma >= 0): below this opacity the min(0.999, .) of the reference can never bind,
 // and a batch of candidates without such a Gaussian runs the loop without the clamp and its gradient mask
 constexpr float kNoClampOpacity = 0.9989f;
+constexpr float kHalfLog2e = MTGS_HALF_LOG2E;   // exp(-s2/2) = exp2(-s2 * log2(e)/2)
 
 // LDS record per staged Gaussian, in floats:  x y a b | c opac s2max idx | col[D] (padded to x4)
-//   a b c   = conic,  s2max = 2 ln(255 opac)  (alpha >= 1/255  <=>  dx u + dy w <= s2max),
+//   a b c   = conic x log2(e)/2,  s2max = 2 ln(255 opac) x log2(e)/2  (alpha >= 1/255  <=>  s2 <= s2max; alpha = opac exp2(-s2)),
 //   idx     = position in the sorted intersection list (int bits).
 template <int D>
 struct Rec {
@@ -132,6 +133,10 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
                 keep = rec_reaches_rect(ca, cb, cc, s2max, tile_x0 + 0.5f - xy.x, tile_x0 + 15.5f - xy.x, tile_y0 + 0.5f - xy.y,
                                         tile_y0 + 15.5f - xy.y);
         }
+        // exp(-sigma) = exp2(-s2 log2(e) / 2): the factor is folded into the STAGED conic and threshold (4 multiplies per
+        // candidate and tile here instead of one per pixel slot in every loop below); forward, decision pass and backward
+        // stage through this one function, so they evaluate the same expression and take identical per-pixel decisions
+        ca *= kHalfLog2e; cb *= kHalfLog2e; cc *= kHalfLog2e; s2max *= kHalfLog2e;
         clamp_any |= __ballot(keep && op > kNoClampOpacity);
         int slot = k;
         if (CULL) {
@@ -159,6 +164,7 @@ __device__ __forceinline__ int stage_batch(float *__restrict__ s_rec, int32_t *_
             float4 *dst = reinterpret_cast<float4 *>(s_rec + slot * REC);
             const float idxf = __int_as_float((int32_t)(BWD ? base - k : base + k));
             if (PK) {
+                pk[0].z = ca; pk[0].w = cb; pk[1].x = cc; pk[1].z = s2max;   // (scaled, see above)
                 pk[1].w = idxf;   // (the radius is not needed any more)
 #pragma unroll
                 for (int c = 0; c < REC / 4; ++c) dst[c] = pk[c];
@@ -255,7 +261,6 @@ __device__ __forceinline__ float *row_address(float *base, uint32_t row, uint32_
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(addr), "=s"(carry) : "v"(row), "v"(stride_bytes), "v"((uint64_t)base));
     return reinterpret_cast<float *>(addr);
 }
-constexpr float kHalfLog2e = 0.5f * 1.4426950408889634f;  // exp(-s2/2) = exp2(-s2 * log2(e)/2)
 // alpha = opacity * exp(-sigma) as a ROUNDED product: the reference rounds alpha before it forms 1 - alpha; left to the
 // compiler the product is contracted into 1 - opacity * e (one fma), which moves T by an ulp per Gaussian and doubles the
 // number of pixels whose T <= 1e-4 / alpha >= 1/255 decisions differ from the oracle's (measured at the headline size).
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 
                 if (vmask[p] != 0) {  // wave-uniform: skip the strips of the tile this Gaussian does not reach
                     // every lane computes (an invalid lane's s2 is anything from a large number to NaN: its alpha is 0,
                     // tiny or NaN and never used); the masks stay wave-uniform values in SGPRs
-                    const float e = __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]);
+                    const float e = __builtin_amdgcn_exp2f(-s2[p]);
                     const float alpha = CLAMP ? fminf(kAlphaMax, alpha_rounded(r1.y, e)) : alpha_rounded(r1.y, e);
                     const float w = alpha * T[p];
                     const float next_T = T[p] * (1.f - alpha);     // (the reference's expression: the T <= 1e-4 decision hangs on it)
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_touch_kernel(int C, const flo
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 if (vmask[p] != 0) {
-                    const float e = __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]);
+                    const float e = __builtin_amdgcn_exp2f(-s2[p]);
                     const float alpha = fminf(kAlphaMax, alpha_rounded(r1.y, e));
                     const float next_T = T[p] * (1.f - alpha);
                     const unsigned long long sm = __builtin_amdgcn_fcmpf(next_T, kTMin, 5 /* FCMP_OLE */) & vmask[p];
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
                 // saves the select but costs the explicit zeroing of ten accumulators per entry: measured worse).
                 if (vmask[p] != 0) {
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask[p]);
-                    const float vis = valid ? __builtin_amdgcn_exp2f(-kHalfLog2e * s2[p]) : 0.f;
+                    const float vis = valid ? __builtin_amdgcn_exp2f(-s2[p]) : 0.f;
                     const float alpha_raw = alpha_rounded(opac, vis);
                     const float alpha = CLAMP ? fminf(kAlphaMax, alpha_raw) : alpha_raw;
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -754,7 +759,8 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
                 }
             }
             if (PK) {
-                // RAW MOMENTS of h over the tile: {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h}
+                // RAW MOMENTS of h over the tile: {sum h dx, sum h dy | k sum |h u|, k sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h}
+                // (k = log2(e)/2 rides on the staged conic: the consumer of the rows divides it out, rows_to_gradients)
                 gv[0] = dx * S0;
                 gv[1] = S1;
                 gv[4] = dx * gv[0];
@@ -763,8 +769,11 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
                 gv[7] = S0;
             } else {
                 // sum_p v_sigma u_p with u_p = a dx + b dy_p (and w_p = b dx + c dy_p); conic: 1/2 v_sigma d d^T
-                gv[0] = adx * S0 + r0.w * S1;
-                gv[1] = bdx * S0 + r1.x * S1;
+                // (the staged conic carries the factor log2(e)/2: taken out of the four sums it appears in)
+                gv[0] = (adx * S0 + r0.w * S1) * MTGS_HALF_LOG2E_INV;
+                gv[1] = (bdx * S0 + r1.x * S1) * MTGS_HALF_LOG2E_INV;
+                gv[2] *= MTGS_HALF_LOG2E_INV;
+                gv[3] *= MTGS_HALF_LOG2E_INV;
                 gv[4] = 0.5f * dx * dx * S0;
                 gv[5] = dx * S1;
                 gv[6] = 0.5f * S2;

@@ -298,8 +298,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_kernel(
 //                                coalesced 16-byte stores, zeros for the culled Gaussians included.
 constexpr int VIS_ROW = 12;  // floats per workspace row: v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | pad
 // RAW rows of the packed compositing backward (blend.hip, mtgs_blend_bwd_packed): with h = vis * dL/dalpha (v_sigma = -opacity h)
-//   row = {sum h dx, sum h dy | sum |h u|, sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h = v_opacity | colours ...}
-// -> the gradients gsplat's rasterize_to_pixels_bwd sums per pixel: v_xy = -o conic (m1, m2), |v_xy| = o (A1, A2),
+//   row = {sum h dx, sum h dy | k sum |h u|, k sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h = v_opacity | colours ...},  k = log2(e)/2
+// -> the gradients gsplat's rasterize_to_pixels_bwd sums per pixel: v_xy = -o conic (m1, m2), |v_xy| = o / k (A1, A2),
 // v_conic = -o (m3 / 2, m4, m5 / 2), applied ONCE per Gaussian here instead of once per (tile, Gaussian) in the compositing
 // kernel (9 -> 3 instructions per epilogue there, one fewer per slot).  o = the opacity that was blended (opacity x
 // compensation, formed as front.hip forms it).  The converted values are written back: everything behind this kernel
@@ -312,7 +312,8 @@ __device__ __forceinline__ RowGrads rows_to_gradients(float *__restrict__ row, c
     RowGrads g;
     g.v_xy = make_float2(no * (ca * a.x + cb * a.y), no * (cb * a.x + cc * a.y));
     g.v_conic[0] = 0.5f * no * b.x; g.v_conic[1] = no * b.y; g.v_conic[2] = 0.5f * no * b.z;
-    reinterpret_cast<float4 *>(row)[0] = make_float4(g.v_xy.x, g.v_xy.y, o * a.z, o * a.w);
+    const float ok = o * MTGS_HALF_LOG2E_INV;     // (the absgrad sums carry the factor log2(e)/2 of the staged conic, blend.hip)
+    reinterpret_cast<float4 *>(row)[0] = make_float4(g.v_xy.x, g.v_xy.y, ok * a.z, ok * a.w);
     reinterpret_cast<float4 *>(row)[1] = make_float4(g.v_conic[0], g.v_conic[1], g.v_conic[2], b.w);
     return g;
 }

@@ -844,7 +844,7 @@ class _FusedRasterization(torch.autograd.Function):
             m1, m2 = G[:n_vis, 0:1].clone(), G[:n_vis, 1:2].clone()
             G[:n_vis, 0:1] = -o * (ca * m1 + cb * m2)
             G[:n_vis, 1:2] = -o * (cb * m1 + cc * m2)
-            G[:n_vis, 2:4] *= o
+            G[:n_vis, 2:4] *= o * 1.38629436111989061883      # (1 / (log2(e)/2): the factor the staged conic carries, include/mtgs_rast.h)
             G[:n_vis, 4:7] *= -o * G.new_tensor([0.5, 1.0, 0.5])
             raw = False
         if n_vis > 0 and direct:

@@ -481,7 +481,9 @@ def _worker_configs3(rank, world, port, out_dir):
                          ("coeffs", vc_)):
                 acc[k] += v
             op = a["opacities"][None]
-            push_abs(vm_r, K_r, m, (vabs, tabs[..., 7], tabs[..., 0:3], tabs[..., 3] * op), ta)          # (channel 3 of D = 4: depth)
+            # (the xy terms in the form the packed backward sums them: a h dx and b h dy per pixel, tests/util.py::moment_xy_terms)
+            push_abs(vm_r, K_r, m, (util.moment_xy_terms(vabs, tabs, m["conics"], m["opacities"]), tabs[..., 7], tabs[..., 0:3],
+                                    tabs[..., 3] * op), ta)          # (channel 3 of D = 4: depth)
             push_abs(vm_r, K_r, m, (ctabs[..., 0:2], ctabs[..., 9], ctabs[..., 2:5], ctabs[..., 5] * op), ca)
             ta["opacities"] += (tabs[..., 3] * m["compensations"]).sum(0)
             ca["opacities"] += (ctabs[..., 5] * m["compensations"]).sum(0)

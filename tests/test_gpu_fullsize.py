@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from mtgs_amd.synthetic import make_camera, make_scene
-from tests.util import (assert_grad_close, assert_image_close, assert_tile_lists, blend_rows_accounted, listed,
+from tests.util import (assert_grad_close, assert_image_close, assert_tile_lists, blend_rows_accounted, listed, moment_xy_terms,
                         projection_vjp_accounted)
 
 pytestmark = pytest.mark.gpu
@@ -118,12 +118,14 @@ def test_config2_config3_1080p_forward_backward(gs, oracle, N, sh):
     # TERM_REL of their sum of |terms|, or (b) Gaussians on the list of a pixel whose alpha >= 1/255 / T <= 1e-4 decision
     # demonstrably flipped (`flipped`: the critical pixels where the IMAGE differs); nothing else.
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
-    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs)
+    xy_terms = moment_xy_terms(vabs, tabs, m["conics"], m["opacities"])
+    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs,
+                         xy_terms=xy_terms)
 
     def close(name, got, ref, **kw):
         return assert_grad_close(name, got, ref, case=case, **kw)
 
-    close("means2d.grad", info["means2d"].grad, v2d, term_abs=vabs, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
+    close("means2d.grad", info["means2d"].grad, v2d, term_abs=xy_terms, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
           crit_abs=ctabs[0, :, 0:2])
     close("means2d.absgrad", info["means2d"].absgrad, vabs, term_abs=vabs, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"],
           crit_abs=ctabs[0, :, 0:2])
@@ -197,8 +199,10 @@ def test_midsize_images_use_more_waves_per_tile(gs, oracle, W, H):
                                                                m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
                                                                Ga_tot, want_term_abs=True, pixel_mask=m["critical"])
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
-    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs)
-    for name, got, ref, ta, ca in (("means2d.grad", info["means2d"].grad, v2d, vabs, ctabs[0, :, 0:2]),
+    xy_terms = moment_xy_terms(vabs, tabs, m["conics"], m["opacities"])
+    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs,
+                         xy_terms=xy_terms)
+    for name, got, ref, ta, ca in (("means2d.grad", info["means2d"].grad, v2d, xy_terms, ctabs[0, :, 0:2]),
                                    ("absgrad", info["means2d"].absgrad, vabs, vabs, ctabs[0, :, 0:2]),
                                    ("v_colors", P["colors"].grad, vcol[0, :, :3], tabs[0, :, 4:7], ctabs[0, :, 6:9])):
         assert_grad_close(name, got, ref, case=case, term_abs=ta, flipped_rows=flipped_rows, self_critical=m["critical_gaussians"], crit_abs=ca)
@@ -283,10 +287,12 @@ def test_shipped_option_cell_7_channels_960x540(gs, oracle):
                                                  m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
                                                  vcon, vop * a["opacities"][None])
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
-    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs)
+    xy_terms = moment_xy_terms(vabs, tabs, m["conics"], m["opacities"])
+    blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs,
+                         xy_terms=xy_terms)
     projection_vjp_accounted(case, oracle, dbg, a, vm.numpy(), K.numpy(), W, H, m, {k: P[k].grad for k in ("means", "quats", "scales", "opacities")})
     fl = dict(flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
-    for name, got, ref, kw in (("means2d.grad", info["means2d"].grad, v2d, dict(term_abs=vabs, crit_abs=ctabs[0, :, 0:2], **fl)),
+    for name, got, ref, kw in (("means2d.grad", info["means2d"].grad, v2d, dict(term_abs=xy_terms, crit_abs=ctabs[0, :, 0:2], **fl)),
                                ("means2d.absgrad", info["means2d"].absgrad, vabs, dict(term_abs=vabs, crit_abs=ctabs[0, :, 0:2], **fl)),
                                ("v_means", P["means"].grad, r_vm, {}), ("v_quats", P["quats"].grad, r_vq, {}),
                                ("v_scales", P["scales"].grad, r_vs, {}),

@@ -289,8 +289,29 @@ def assert_grad_close(name, got, ref, case="", rel_to_max=1e-3, row_rel_p999=1e-
     return st
 
 
+def moment_xy_terms(vabs, term_abs, conics, opacities):
+    """Sum of |terms| of the position gradient IN THE FORM THE PACKED BACKWARD EVALUATES IT (blend.hip raw-moment rows, ABI v22):
+        v_x = -o (a sum h dx + b sum h dy),   v_y = -o (b sum h dx + c sum h dy),       h = vis dL/dalpha,
+    whose terms are a h dx and b h dy per pixel -- not gsplat's h (a dx + b dy): for an elongated splat the two partial sums
+    cancel where the per-pixel form does not (the relative precision drops by the conic's condition number; DESIGN.md section 4,
+    profiles/r04_blend_isa_budget.md).  A sum of TERM_REL-accurate terms is TERM_REL x sum |terms| accurate, so THIS is the
+    quantity the cancellation class of assert_grad_close has to be measured against for the xy rows.  The oracle reports
+    sum |h| (opacity column) and sum |h| dx^2 / 2, sum |h| dy^2 / 2 (conic columns, x o); by Cauchy-Schwarz
+        sum |h dx| <= sqrt(sum |h| . sum |h| dx^2),
+    which bounds the moment form's sum of |terms| from the oracle's own sums.  Never below gsplat's per-pixel sum `vabs`.
+    vabs [C,N,2], term_abs [C,N,4+D] (conic 3 | opacity | colours), conics [C,N,3], opacities [C,N] -> [C,N,2]."""
+    o = np.maximum(np.asarray(opacities, np.float64), 1e-30)
+    ta = np.asarray(term_abs, np.float64)
+    sh = ta[..., 3]
+    X = np.sqrt(sh * 2.0 * ta[..., 0] / o)          # >= sum |h dx|
+    Y = np.sqrt(sh * 2.0 * ta[..., 2] / o)          # >= sum |h dy|
+    a, b, c = (np.abs(np.asarray(conics, np.float64)[..., k]) for k in range(3))
+    mt = np.stack([o * (a * X + b * Y), o * (b * X + c * Y)], axis=-1)
+    return np.maximum(mt, np.asarray(vabs, np.float64))
+
+
 def blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, term_abs, flipped_rows, max_unexplained=0, self_critical=None,
-                         crit_terms=None):
+                         crit_terms=None, xy_terms=None):
     """The compositing backward's own output -- the compact gradient rows the fused path keeps per visible Gaussian
     (mtgs_amd.wrapper._debug_rows: [xy 2 | |xy| 2 | conic 3 | opacity 1 | colours | depth]) -- against the oracle's
     fp64-summed rows, one camera, with EVERY row accounted for (assert_grad_close: within 1e-3, or a cancelling sum, or on
@@ -308,7 +329,8 @@ def blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, term_abs, flippe
     ct = None if crit_terms is None else crit_terms[0][vis]
     cpart = lambda sl: None if ct is None else ct[:, sl]
     out = np.zeros(N, bool)
-    parts = (("rows.xy", G[:, 0:2], v2d[0][vis], vabs[0][vis], cpart(slice(0, 2))),
+    # (xy_terms: moment_xy_terms(...) -- the sum of |terms| of the form the packed backward evaluates the position gradient in)
+    parts = (("rows.xy", G[:, 0:2], v2d[0][vis], (vabs if xy_terms is None else xy_terms)[0][vis], cpart(slice(0, 2))),
              ("rows.|xy|", G[:, 2:4], vabs[0][vis], vabs[0][vis], cpart(slice(0, 2))),
              ("rows.conic", G[:, 4:7], vcon[0][vis], ta[:, 0:3], cpart(slice(2, 5))),
              ("rows.opacity", G[:, 7], vop[0][vis], ta[:, 3], cpart(5)),
