@@ -732,8 +732,9 @@ def main():
             "n_visible": n_vis, "n_intersections": M, "n_listed": M_l,
             "lists": ("tight (MTGS_TIGHT_LISTS=1): ordered sublists of gsplat's lists, same pixels and gradients" if tight_headline else
                       "gsplat (the default call): isect_ids / flatten_ids / isect_offsets bit-identical to gsplat 1.4.0 isect_tiles + "
-                      "isect_offset_encode; the opt-in tight lists (mtgs_amd.tight_lists(): same pixels and gradients, "
-                      f"{n_listed_tight} listed pairs) are timed beside it as ms_per_step_tight_lists, never as `value`"),
+                      "isect_offset_encode" + ("" if n_listed_tight is None else
+                                               "; the opt-in tight lists (mtgs_amd.tight_lists(): same pixels and gradients, "
+                                               f"{n_listed_tight} listed pairs) are timed beside it as ms_per_step_tight_lists, never as `value`")),
             "launch": ("one HIP graph launch per step: the step captured once under mtgs_amd.graph_mode + torch.cuda.graph and replayed "
                        "(the K steps were timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)")
                       if launch == "graph" else

@@ -5,6 +5,10 @@ the hot path of OpenDriveLab/MTGS (rasterization() + spherical_harmonics()).
 
 Importing this package does not load the HIP library or touch the GPU; the first operator call
 does, and raises if libmtgs_rast.so has not been built (python -m mtgs_amd.build).
+
+Beyond gsplat's surface: `mtgs_amd.graph_mode` / `mtgs_amd.graphs.GraphedIteration` (an iteration as one HIP graph launch),
+`mtgs_amd.tight_lists` (opt-in shorter tile lists), `mtgs_amd.dist` (view-parallel data parallelism), `mtgs_amd.nodes` / `.loss`
+/ `.densify` / `.optim` (the fused neighbours of the path).
 """
 from .rendering import rasterization
 from .wrapper import (exact_lists, fully_fused_projection, graph_mode, isect_offset_encode, isect_tiles, lists_are_tight,

@@ -653,26 +653,10 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 lr0 = LR_SETS[LR["set"]]["means"]
                 g["lr"] = lr0 * (means_lr_final / lr0) ** (i / max(steps, 1))
 
-    # ---- graph training state (one stretch between two refinements)
-    graphs, caps, eager_left = {}, None, T
-    seen_dev = torch.zeros(2, dtype=torch.int64, device=dev)        # largest n_visible / n_intersections of the graph frames
-    ovf_dev = torch.zeros((), dtype=torch.bool, device=dev)         # OR of the graph frames' overflow flags
-    ovf_host = torch.zeros((), dtype=torch.bool).pin_memory() if graph else None
-    ovf_ev = None
-    counts = {"captures": 0, "warmups": 0, "overflows": 0, "eager": 0, "replays": 0}
-    cap_scale = [float(first_cap_scale)]
-    staged, n_active = {}, [0]       # per traversal: the pinned staging buffers of its graphs; tensors the optimizer steps
-    # ONE memory pool for every graph of the run: a graph's private pool is hipMalloc'ed at capture and released with the graph --
-    # per traversal and per refinement that was most of the cost of re-capturing at 2M Gaussians.  Sharing is safe here: the
-    # graphs are replayed one at a time on one stream, each replay writes everything it reads (tables, activations, gradients),
-    # and the only output read afterwards -- the loss -- is copied out in stream order right behind its replay.  The pool outlives
-    # the refinements through `pool_keeper`, a trivial graph captured into it first.
-    pool = pool_keeper = None
-    if graph:
-        pool = torch.cuda.graph_pool_handle()
-        pool_keeper = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(pool_keeper, pool=pool):
-            _keep = torch.zeros(1, device=dev) + 1
+    # ---- graph training: the capture / replay / overflow / re-capture manager is mtgs_amd.graphs.GraphedIteration (one stretch
+    # between two refinements per set of graphs, one memory pool for the run); this loop supplies the iteration body and the hooks
+    n_active = [0]       # tensors the optimizer steps (known once an optimizer has run a step: capture without warm-up needs it)
+    GI = None
     debug = bool(os.environ.get("MTGS_TRAIN_DEBUG"))
     phase_ms, tick_t = {}, [time.perf_counter()]
 
@@ -693,93 +677,26 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
         if VISFIRST["cs"] is not None:
             VISFIRST["cs"].apply_to(opt)
         opt.step()
-        info = LAST["info"]
-        if "overflow" in info:       # (graph mode: the counts and the flag are device scalars)
-            ovf_dev.logical_or_(info["overflow"])
-            torch.maximum(seen_dev, torch.stack([info["n_visible"], info["n_intersections"]]), out=seen_dev)
         return loss
 
-    def plan_caps():
-        n_all = sum(p["means"].shape[0] for p in P.values())
-        n_vis, M = wrapper._size_plan.seen[(1, n_all, W, H)]
-        k, cap_scale[0] = cap_scale[0], 1.0       # (tests: the FIRST set of capacities too small, to drive the overflow path)
-        return int(1.3 * k * n_vis) + 4096, int(1.3 * k * M) + 65536
+    if graph:
+        from mtgs_amd.graphs import GraphedIteration
+        GI = GraphedIteration(lambda c: (body(c), LAST["info"]), n_keys=T,
+                              size_key=lambda: (1, sum(p["means"].shape[0] for p in P.values()), W, H), device=dev,
+                              before_replay=lambda: opt.advance(),      # this step's {lr / bc1, sqrt(bc2), t}: one small copy in front of the launch
+                              on_capacities=lambda: touch_policy(), can_skip_warmup=lambda: n_active[0] > 0, poll_every=poll_every,
+                              first_cap_scale=first_cap_scale, tight_lists=None, log=log, tick=tick)
 
     def graph_step(c):
-        nonlocal caps, eager_left
-        if caps is None:                       # the size plan does not know this N yet: ordinary frames (exact sizes)
-            loss = body(c)
-            counts["eager"] += 1
-            eager_left -= 1
-            if eager_left <= 0:
-                caps = plan_caps()
-                touch_policy()
-            return loss
-        if one_graph:          # one graph for every traversal: the traversal goes in through the device word
+        key = c
+        if one_graph and GI.caps is not None:      # one graph for every traversal: the traversal goes in through the device word
             t_dev.fill_(c)
-            c = ANY
-        if c not in graphs:
-            tick("other")
-            gm = mtgs_amd.graph_mode(*caps)
-            if c in staged and n_active[0]:
-                # a later stretch: capture at once and let the first replay BE the step.  What a warm-up would provide is there
-                # already: the pinned staging buffers of the traversal's previous graph (same sequence of table sizes -- a
-                # mismatch would allocate pinned memory while capturing and is caught below) and the optimizer's device
-                # scalars (FusedAdam.inherit_layout; every tensor inherited its moments from the refinement)
-                gm.keep = staged[c]
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with gm, torch.cuda.graph(g, pool=pool):
-                        static = body(c)
-                except Exception as e:      # noqa: BLE001  (fall back to the warm-up path, once, loudly)
-                    log(f"capture without warm-up failed ({type(e).__name__}: {e}); warming up")
-                    staged.pop(c, None)
-                    torch.cuda.synchronize()
-                    return graph_step(c)
-                graphs[c] = (g, gm, static)
-                counts["captures"] += 1
-                tick("capture")
-                opt.advance()
-                g.replay()
-                counts["replays"] += 1
-                tick("first replay")
-                return static
-            with gm:                           # THE step of this iteration, eagerly, with the graph's capacities (also fills the
-                loss = body(c)                 #   mode object's staging buffers: no pinned allocation while capturing).  On the
-            #                                      main stream: a side stream has its own allocator pool, every tensor of the step
-            #                                      was hipMalloc'ed afresh there (10 ms per warm-up at 2M Gaussians)
-            tick("warm")
-            g = torch.cuda.CUDAGraph()
-            with gm, torch.cuda.graph(g, pool=pool):      # nothing executes
-                static = body(c)
-            graphs[c] = (g, gm, static)
-            staged[c] = gm.keep
+            key = ANY
+        warm = GI.counts["warmups"]
+        loss = GI.step(key)
+        if GI.counts["warmups"] > warm:
             n_active[0] = len(opt._active)
-            counts["captures"] += 1
-            counts["warmups"] += 1
-            tick("capture")
-            return loss
-        g, _, static = graphs[c]
-        opt.advance()                          # this step's {lr / bc1, sqrt(bc2), t}: one small copy in front of the launch
-        g.replay()
-        counts["replays"] += 1
-        return static
-
-    def poll_overflow(i):
-        """Never blocks: queries the event of the previous poll's copy, then issues the next one."""
-        nonlocal ovf_ev, caps, eager_left
-        if ovf_ev is not None and ovf_ev.query():
-            ovf_ev = None
-            if bool(ovf_host):
-                counts["overflows"] += 1
-                log(f"step {i}: a graph frame exceeded its capacities {caps}; re-capturing")
-                graphs.clear()
-                caps, eager_left = None, T
-                ovf_dev.zero_()
-        if ovf_ev is None and graphs and i % poll_every == 0:
-            ovf_host.copy_(ovf_dev, non_blocking=True)
-            ovf_ev = torch.cuda.Event()
-            ovf_ev.record()
+        return loss
 
     t_start = None
     i_start = 0
@@ -798,7 +715,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             steady_ev[-1].record()
         if graph:
             loss_hist[i].copy_(graph_step(i % T))
-            poll_overflow(i)
+            GI.poll(i)
         else:
             if i == T and world == 1 and accumulate == 1:
                 touch_policy()
@@ -862,14 +779,7 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
             touch_policy(after_reset=refine_cfg is not None and
                          (i + 1) % (refine_cfg.reset_alpha_every * refine_cfg.refine_every) == refine_cfg.refine_every)
             if graph:                         # new parameters: new graphs, capacities scaled by the growth of N
-                graphs.clear()
-                ovf_ev = None
-                seen = seen_dev.tolist()      # (the refinement has synchronised already)
-                ratio = sizes[-1] / max(before, 1)
-                caps = (int(1.3 * ratio * seen[0]) + 4096, int(1.3 * ratio * seen[1]) + 65536) if seen[0] > 0 else None
-                eager_left = 0 if caps is not None else T
-                seen_dev.zero_()
-                ovf_dev.zero_()
+                GI.after_refinement(before, sizes[-1])
             log(f"step {i + 1}: refine {before} -> {sizes[-1]} Gaussians (+{added} -{culled})")
             tick("new optimizer")
     if debug:
@@ -883,12 +793,13 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
         ph = {k: round(v, 3) for k, v in ex.phases_ms().items()} if ex is not None else {}
         log(f"timing: {ms:.2f} ms per step (wall, refinements{' and graph captures' if graph else ''} included) world {world} "
             f"accumulate {accumulate} exchange {'sparse' if sparse else ('dense' if world > 1 else 'none')} optimizer {optimizer} "
-            f"phases_ms {json.dumps(ph)}" + (f" graph {json.dumps(counts)}" if graph else ""))
+            f"phases_ms {json.dumps(ph)}" + (f" graph {json.dumps(GI.counts)}" if graph else ""))
     if len(steady_ev) == 2:
         log(f"steady: {steady_ev[0].elapsed_time(steady_ev[1]) / (steady[1] - steady[0]):.3f} ms per step between steps {steady[0]} and {steady[1]} (GPU events)")
-    if graph and bool(ovf_dev):
+    if graph and GI.overflowed():
         log("note: a graph frame overflowed its capacities after the last poll")
-    graphs.clear()
+    if graph:
+        GI.close()
     return loss_hist[:steps].tolist(), sizes
 
 
