@@ -775,6 +775,8 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                 opt.inherit_layout(old_opt)
             del old_opt
             sizes.append(sum(p["means"].shape[0] for p in P.values()))
+            if world > 1 and os.environ.get("MTGS_DIST_BACKEND") == "gloo":
+                torch.cuda.empty_cache()      # (the ranks of a gloo run SHARE one GPU: hand the old tensors' blocks back to the other ranks)
             ex = mk_ex()                      # N changed: new send buffers and visibility maps
             touch_policy(after_reset=refine_cfg is not None and
                          (i + 1) % (refine_cfg.reset_alpha_every * refine_cfg.refine_every) == refine_cfg.refine_every)
