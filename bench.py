@@ -79,16 +79,20 @@ def parse_args():
                     help="N > 1: sparse = all-gather of 64-byte rows of the visible Gaussians, SH-coefficient "
                          "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
                          "dense = plain all-reduce of every gradient tensor")
-    ap.add_argument("--dp-finish", choices=["static", "dynamic"], default="static",
-                    help="N > 1, sparse exchange: static = SparseGradExchange.finish_static (ONE fixed-capacity all-gather of the wire "
-                         "rows, capacity = the ranks' largest warm-up row count + 5 %%, no host read between render and reduce: the form a "
-                         "HIP graph can capture); dynamic = finish() (row counts read on the host, chunked all-gathers pipelined with "
-                         "the reduction)")
+    ap.add_argument("--dp-finish", choices=["touched", "static", "dynamic"], default="touched",
+                    help="N > 1, sparse exchange: touched (default) = SparseGradExchange.finish_touched: only the wire rows that CARRY a "
+                         "gradient travel (40 %% of the visible ones at this scene), with their own map, in ONE fixed-capacity all-gather "
+                         "per step -- no visibility-map exchange, no host read between render and reduce; static = finish_static (ONE "
+                         "fixed-capacity all-gather of every visible row, capacity = the ranks' largest warm-up row count + 5 %%, "
+                         "visibility maps all-gathered during the frame); dynamic = finish() (row counts read on the host, chunked "
+                         "all-gathers pipelined with the reduction)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="N = 1: graph (default): the K steps are timed twice -- "
                     "launched eagerly (~40 kernel launches and ~15 library calls per step from Python) and as ONE HIP graph launch each "
                     "(the step captured once under mtgs_amd.graph_mode) -- and the line carries the faster, named in config.launch; "
                     "eager: the eager loop only")
+    ap.add_argument("--no-tight", action="store_true", help="skip the second graph timing pass on the opt-in tight tile lists (profiling runs: "
+                                                             "the kernel trace then holds the default call's kernels only)")
     ap.add_argument("--no-also", action="store_true", help="skip the untimed extras (forward-only rate, shipped 7-channel cells): "
                                                             "profiling runs, so that the trace holds the headline step only")
     return ap.parse_args()
@@ -145,7 +149,8 @@ def make_step(args, dev, world):
             ev["rows"].record()
             cap = info_box.get("static_cap")
             if cap:      # no host read, no host wait: one fixed-capacity all-gather, counts stay on the device
-                g, ovf = exchange.finish_static(params["means"], 3, cap, [0] * world)
+                fin = exchange.finish_touched if info_box.get("touched") else exchange.finish_static
+                g, ovf = fin(params["means"], 3, cap, [0] * world)
                 info_box["overflow"] = ovf if info_box.get("overflow") is None else (info_box["overflow"] | ovf)
             else:
                 g = exchange.finish(params["means"], 3)
@@ -500,12 +505,21 @@ def main():
         torch.cuda.synchronize()
         barrier()
         ex_ = info_box.get("exchange")
-        if world > 1 and ex_ is not None and args.dp_finish == "static":
+        if world > 1 and ex_ is not None and args.dp_finish in ("static", "touched"):
             # the static exchange's row capacity: the largest row count any rank saw in the warm-up (dynamic) steps + 5 %, agreed
             # on by ONE setup collective; from here on the step never reads a count on the host
             t_cap = torch.tensor([float(ex_.n_vis)], dtype=torch.float64, device=device)
             torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
             info_box["static_cap"] = int(float(t_cap.item()) * 1.05) + 1024
+            if args.dp_finish == "touched":
+                # ... and of the rows that carry a gradient: one step with the visible-row capacity, then the ranks' largest count + 10 %
+                info_box["touched"] = True
+                ex_.defer_maps = True
+                step()
+                t_cap = ex_.touched_count.to(torch.float64).reshape(1)
+                torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
+                info_box["static_cap"] = int(float(t_cap.item()) * 1.10) + 1024
+                info_box["overflow"] = None
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
@@ -585,7 +599,8 @@ def main():
             graph_error = f"{type(e).__name__}: {e}"[:300]
             print(f"[bench] graph launch failed, reporting the eager loop: {graph_error}", file=sys.stderr)
         try:        # beside the headline, never the headline: the same step on the opt-in tight tile lists
-            elapsed_graph_tight, n_listed_tight = graph_time(True)
+            if not args.no_tight:
+                elapsed_graph_tight, n_listed_tight = graph_time(True)
         except Exception as e:      # noqa: BLE001
             print(f"[bench] tight-lists graph failed: {type(e).__name__}: {e}"[:300], file=sys.stderr)
     info_box["info"] = eager_info
@@ -743,7 +758,7 @@ def main():
                        (" (timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)"
                         if elapsed_graph is not None else "")),
             "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange"
-                           + (f" ({'finish_static: one all-gather of ' + str(info_box['static_cap']) + ' rows per rank, no host read' if info_box.get('static_cap') else 'finish: chunked all-gathers sized on the host'})"
+                           + (f" ({('finish_touched: one all-gather of the ' if info_box.get('touched') else 'finish_static: one all-gather of ') + str(info_box['static_cap']) + (' rows that carry a gradient + their map' if info_box.get('touched') else ' visible rows') + ' per rank, no host read' if info_box.get('static_cap') else 'finish: chunked all-gathers sized on the host'})"
                               if (world > 1 and info_box.get("exchange") is not None) else "")
                            + f", {info_box['grad_bytes']} bytes received per rank per step",
         },

@@ -402,6 +402,15 @@ int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float *v_means, 
                          const float *v_scales, const float *v_opacities, const float *v_rgb, uint64_t *words,
                          uint32_t *prefix, int32_t *count, uint32_t *block_counts, float *rows, int64_t capacity,
                          void *stream);
+/* mtgs_dp_touched_pack (ABI v25): a sender's wire rows[n_rows,16] (index order, one per VISIBLE Gaussian, mtgs_project_bwd_rows) ->
+ * only the rows that carry a gradient (any of the 14 gradient floats non-zero), compacted in the same order into
+ * out_rows[capacity,16], with THEIR map in the format of a visibility map: out_words[ceil(N/64)] (bit n = Gaussian n has a row),
+ * out_prefix[ceil(N/64)] (rows in front of the word), out_count[1] i32 and totals[1] i64 (count << 32).  The receivers' reduction
+ * (mtgs_dp_reduce*) runs unchanged on the shorter rows.  scratch_words[ceil(N/64)] u64 and block_counts[ceil(ceil(N/64)/256)] are
+ * scratch; rows beyond `capacity` are dropped (out_count tells: the caller falls back to the untruncated exchange). */
+int mtgs_dp_touched_pack(int64_t n_rows, const float *rows, int64_t N, uint64_t *scratch_words, uint64_t *out_words,
+                         uint32_t *out_prefix, int32_t *out_count, int64_t *totals, uint32_t *block_counts, float *out_rows,
+                         int64_t capacity, void *stream);
 int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
                    const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
                    const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,

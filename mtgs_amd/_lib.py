@@ -67,6 +67,7 @@ _SIGNATURES = {
     "mtgs_dp_pack": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "mtgs_dp_touched_pack": [_i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_dp_union": [_i32, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_reduce_rows_groups": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _i64, _i64, _vp],

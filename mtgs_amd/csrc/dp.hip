@@ -629,7 +629,93 @@ __global__ __launch_bounds__(UNION_BLOCK) void dp_union_prefix_kernel(int64_t nw
     if (blockIdx.x == gridDim.x - 1 && tid == 0) totals[p] = (int64_t)total << 32;
 }
 
+// ---- sender: only the rows that CARRY a gradient travel (mtgs_dp_touched_pack) ---------------------------------------------------
+// A rank's wire rows cover the Gaussians its camera SEES (the projection backward writes one per visible Gaussian, index order);
+// in an opaque scene most of them are hidden behind others -- the compositing terminates before it reaches them -- and their
+// rows are exactly zero: 60 % at the headline scene, 91-98 % in MTGS-like scenes.  Three small launches compact the non-zero
+// rows (same order) and build THEIR map in the format of a visibility map (words + per-word prefix), so that the receivers'
+// reduction runs unchanged on 2.5x .. 50x fewer rows and the wire carries as many fewer bytes.
+constexpr int TOUCH_BLOCK = 256;
+__device__ __forceinline__ bool wire_row_nonzero(const float *__restrict__ row) {
+    const float4 *q = reinterpret_cast<const float4 *>(row);
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    return a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
+           c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f || d.x != 0.f || d.y != 0.f;      // (d.z: pad, d.w: the index)
+}
+__global__ __launch_bounds__(TOUCH_BLOCK) void dp_touched_words_kernel(int64_t n_rows, const float *__restrict__ rows,
+                                                                       unsigned long long *__restrict__ words /* zero */) {
+    const int64_t r = (int64_t)blockIdx.x * TOUCH_BLOCK + threadIdx.x;
+    if (r >= n_rows) return;
+    const float *row = rows + r * 16;
+    if (!wire_row_nonzero(row)) return;
+    const uint32_t n = (uint32_t)__float_as_int(row[15]);
+    atomicOr(words + (n >> 6), 1ull << (n & 63u));
+}
+__global__ __launch_bounds__(UNION_BLOCK) void dp_touched_count_kernel(int64_t nw, const unsigned long long *__restrict__ words,
+                                                                       unsigned long long *__restrict__ out_words,
+                                                                       uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t s_c[UNION_BLOCK / 64];
+    const int64_t wi = (int64_t)blockIdx.x * UNION_BLOCK + threadIdx.x;
+    const unsigned long long u = wi < nw ? words[wi] : 0ull;
+    if (wi < nw) out_words[wi] = u;
+    uint32_t c = (uint32_t)__popcll(u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < UNION_BLOCK / 64; ++w) t += s_c[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(TOUCH_BLOCK) void dp_touched_rows_kernel(int64_t n_rows, const float *__restrict__ rows,
+                                                                      const unsigned long long *__restrict__ words,
+                                                                      const uint32_t *__restrict__ prefix, const int64_t *__restrict__ totals,
+                                                                      float *__restrict__ out_rows, int64_t capacity,
+                                                                      int32_t *__restrict__ out_count) {
+    const int64_t r = (int64_t)blockIdx.x * TOUCH_BLOCK + threadIdx.x;
+    if (r == 0) *out_count = (int32_t)(*totals >> 32);
+    if (r >= n_rows) return;
+    const float4 *src = reinterpret_cast<const float4 *>(rows + r * 16);
+    if (!wire_row_nonzero(rows + r * 16)) return;
+    const uint32_t n = (uint32_t)__float_as_int(rows[r * 16 + 15]);
+    const unsigned long long w = words[n >> 6];
+    const int64_t dst = (int64_t)prefix[n >> 6] + __popcll(w & ((1ull << (n & 63u)) - 1ull));
+    if (dst >= capacity) return;      // (the count says so: the caller repeats the exchange with the untruncated form)
+    float4 *out = reinterpret_cast<float4 *>(out_rows + dst * 16);
+    out[0] = src[0]; out[1] = src[1]; out[2] = src[2]; out[3] = src[3];
+}
+
 }  // namespace
+
+extern "C" int mtgs_dp_touched_pack(int64_t n_rows, const float *rows, int64_t N, uint64_t *scratch_words, uint64_t *out_words,
+                                    uint32_t *out_prefix, int32_t *out_count, int64_t *totals, uint32_t *block_counts,
+                                    float *out_rows, int64_t capacity, void *stream) {
+    MTGS_REQUIRE(n_rows >= 0 && N >= 0 && N < ((int64_t)1 << 31) && capacity >= 0, MTGS_EINVAL, "mtgs_dp_touched_pack: bad sizes");
+    MTGS_REQUIRE(scratch_words && out_words && out_prefix && out_count && totals && block_counts && (n_rows == 0 || (rows && out_rows)),
+                 MTGS_EINVAL, "mtgs_dp_touched_pack: null pointer");
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_rows) & 15) == 0, MTGS_EINVAL,
+                 "mtgs_dp_touched_pack: rows must be 16-byte aligned");
+    const int64_t nw = (N + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (nw == 0) {
+        hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int32_t), st);
+        MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_dp_touched_pack: memset failed");
+        return MTGS_OK;
+    }
+    if (int rc = mtgs_zero_async(scratch_words, (size_t)nw * 8, st)) return rc;
+    if (n_rows > 0)
+        dp_touched_words_kernel<<<(unsigned)ceil_div64(n_rows, TOUCH_BLOCK), TOUCH_BLOCK, 0, st>>>(n_rows, rows, (unsigned long long *)scratch_words);
+    const unsigned grid = (unsigned)ceil_div64(nw, UNION_BLOCK);
+    dp_touched_count_kernel<<<grid, UNION_BLOCK, 0, st>>>(nw, (const unsigned long long *)scratch_words, (unsigned long long *)out_words, block_counts);
+    dp_union_prefix_kernel<<<dim3(grid, 1), UNION_BLOCK, 0, st>>>(nw, (const unsigned long long *)out_words, block_counts, out_prefix, totals);
+    dp_touched_rows_kernel<<<(unsigned)ceil_div64(n_rows > 0 ? n_rows : 1, TOUCH_BLOCK), TOUCH_BLOCK, 0, st>>>(
+        n_rows, rows, (const unsigned long long *)out_words, out_prefix, totals, out_rows, capacity, out_count);
+    MTGS_CHECK_LAUNCH("mtgs_dp_touched_pack");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_dp_union(int W, int64_t N, const uint64_t *words, int64_t map_stride_bytes, int P, const uint64_t *masks,
                              uint64_t *union_words, uint32_t *union_prefix, int64_t *totals, uint32_t *block_counts, void *stream) {

@@ -8,8 +8,8 @@ rm -rf $OUT && mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $OUT/read_bench $R/scripts/dev/read_bench.hip > $OUT/build.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -- $OUT/read_bench --calibrate > $OUT/cal_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-steps 0 --no-also > $OUT/$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-steps 0 --no-also --no-tight > $OUT/$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-steps 0 --no-also > $OUT/sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-steps 0 --no-also --no-tight > $OUT/sq.log 2>&1
 rm -f $OUT/read_bench
 find $OUT -name "*counter_collection.csv" | head -8

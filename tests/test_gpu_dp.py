@@ -277,6 +277,34 @@ def _worker_traversals(rank, world, port, out_dir):
                 assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-7, rank
         else:
             assert all(bool(torch.isfinite(o).all()) for o in out_s)
+    # finish_touched(): only the rows that carry a gradient travel, with their own map, in ONE all-gather -- the front end's
+    # visibility maps are not exchanged at all (defer_maps).  From the same wire rows the sums are those of finish_static()
+    # BIT FOR BIT (zero rows add exact zeros, the order of the others is unchanged); then a capacity that is too small.
+    ex.defer_maps = True
+    for cap, want_overflow in ((N, False), (64, True)):
+        r4, a4, _ = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm, Kmat, W, H, cam_pos, traversal=t)
+        torch.autograd.backward([r4, a4], [Gc, Ga])
+        rows_before = ex.rows[:ex.n_vis].clone()
+        out_t, ovf = ex.finish_touched(P["means"], 3, cap, [q % T for q in range(world)])
+        torch.cuda.synchronize()
+        n_touched = int(ex.touched_count)
+        assert bool(ovf) == want_overflow and 64 < n_touched < ex.n_vis, (rank, cap, n_touched, ex.n_vis)
+        assert n_touched == int((rows_before[:, :14] != 0).any(1).sum())
+        assert ex.last_bytes == world * 4 * (cap * 16 + -(-ex.meta_len // 16) * 16)
+        if not want_overflow:
+            # the reference from the SAME rows: the visibility-map form needs the maps after all -- gather them now
+            ex.defer_maps = False
+            ex._pending = {"stage": "forward"}
+            ex.after_front()
+            ex._pending.update(stage="rows", n_vis=ex.n_vis)
+            out_v, ovf_v = ex.finish_static(P["means"], 3, N, [q % T for q in range(world)])
+            ex.defer_maps = True
+            torch.cuda.synchronize()
+            assert not bool(ovf_v)
+            for got, ref in zip(out_t, out_v):
+                assert torch.equal(got, ref), rank
+        else:
+            assert all(bool(torch.isfinite(o).all()) for o in out_t)
     dist.barrier()
     dist.destroy_process_group()
 
