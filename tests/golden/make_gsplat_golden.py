@@ -11,6 +11,11 @@ image / alpha / meta tensors, torch autograd through gsplat's own backward kerne
   tests/test_gpu_parity.py::test_hip_reproduces_gsplat_fixture               (GPU: pins the HIP path directly)
 stop skipping, and the "PARITY UNPINNED" notes (oracle/gsplat_oracle.c) can go.
 
+Tile lists: the real gsplat has ONE list form, and since round 5 it is what this package's default call returns -- the fixture's
+isect_ids / flatten_ids / isect_offsets are compared bit for bit with the default `rasterization()`, and the opt-in tight lists
+(`with mtgs_amd.tight_lists():`) are then checked as ordered sublists of the fixture's with a sentinel tail
+(tests/util.py::assert_tile_lists(..., rerun=...)); `lists` / `n_intersections` in the file say so.
+
 Neither gsplat nor CUDA exists in the build container of this repository (no network), so the files are NOT in the
 tree yet; this script is the committed recipe.  It imports nothing of the HIP library (mtgs_amd.synthetic / tests.util
 are plain torch)."""
@@ -61,6 +66,7 @@ def main():
         n = lambda t: t.detach().cpu().numpy()
         np.savez_compressed(
             OUT / f"{name}.npz", W=W, H=H, render_mode=render_mode, rasterize_mode=rmode, source=f"gsplat {gsplat.__version__}",
+            lists="gsplat", n_intersections=int(info["flatten_ids"].numel()),
             means=n(sc["means"]), quats=n(sc["quats"]), scales=n(sc["scales"]), opacities=n(sc["opacities"]),
             colors=n(sc["colors"]), viewmat=n(vm), K=n(K), backgrounds=np.zeros((0,), np.float32) if bg is None else n(bg),
             Gc=n(Gc), Ga=n(Ga), render=n(render), alpha=n(alpha), radii=n(radii).astype(np.int32), means2d=n(info["means2d"]),

@@ -405,6 +405,10 @@ def test_hip_reproduces_gsplat_fixture(gs, name):
         ref = z["opacities_eff" if key == "opacities" else key]
         np.testing.assert_allclose(info[key].detach().cpu().numpy()[vis], ref[vis], rtol=2e-5, atol=1e-6, err_msg=key)
     assert np.array_equal(info["tiles_per_gauss"].cpu().numpy(), z["tiles_per_gauss"])
+    # (the default call returns gsplat's lists: bit for bit against the fixture; the rerun checks the opt-in tight lists as ordered
+    #  sublists of the fixture's)
+    assert "lists" not in z.files or str(z["lists"]) == "gsplat"
+    assert info.get("n_listed") is None and info["flatten_ids"].numel() == z["flatten_ids"].shape[0]
     assert_tile_lists(info, z, rerun=lambda: gs.rasterization(
         P["means"].detach(), P["quats"].detach(), P["scales"].detach(), P["opacities"].detach(), P["colors"].detach(), vm.detach(),
         dev(z["K"]), W, H, packed=False, render_mode=str(z["render_mode"]), rasterize_mode=str(z["rasterize_mode"]), backgrounds=bg,

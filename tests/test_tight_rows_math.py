@@ -102,3 +102,44 @@ def test_the_exact_test_never_drops_a_tile_with_a_contributing_pixel():
         elif keep:
             kept_without += 1
     assert with_pixel > 3000 and kept_without < 0.15 * with_pixel, (with_pixel, kept_without)
+
+
+def test_row_spans_of_image_crossing_needles_against_brute_force_pixels():
+    """The margin of the tight lists at its hardest: needles that cross the whole image (major axis up to 3000 px, minor axis down
+    to the eps2d floor, any orientation, so b is close to sqrt(a c) and det = a c - b^2 cancels in fp32), their conic INVERTED IN
+    FP32 as the projection does.  row_span (fp32, as the kernel) is compared DIRECTLY with brute force over the pixel centres of the
+    tile row, evaluated in fp64 on that same fp32 conic with the kernels' per-pixel condition s2 <= s2max: every tile column that
+    holds a passing pixel must lie inside the span.  (Round-4 advisor: the suite covered sigma_major <= 300 px and only against
+    rec_reaches_rect.)"""
+    rng = np.random.default_rng(17)
+    tw = 120                                     # 1920 px
+    px = np.arange(tw * 16) + 0.5
+    checked = misses = 0
+    for case in range(6000):
+        ang = rng.uniform(0, np.pi)
+        if case % 3 == 0:                        # nearly axis-aligned and nearly diagonal needles too
+            ang = rng.choice([0.0, np.pi / 2, np.pi / 4, 3 * np.pi / 4]) + rng.normal(0, 1e-3)
+        s1 = np.exp(rng.uniform(np.log(100.0), np.log(3000.0)))
+        s2 = np.exp(rng.uniform(np.log(0.01), np.log(1.0)))
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        cov = (R @ np.diag([s1 * s1, s2 * s2]) @ R.T + 0.3 * np.eye(2)).astype(f32)
+        # the projection's fp32 inverse of the blurred covariance (project_fwd_body.hpp: det, then the three quotients)
+        det = f32(cov[0, 0] * cov[1, 1] - cov[0, 1] * cov[0, 1])
+        if not det > 0:
+            continue
+        a, b, c = f32(cov[1, 1] / det), f32(-cov[0, 1] / det), f32(cov[0, 0] / det)
+        opacity = np.exp(rng.uniform(np.log(2.0 / 255.0), 0.0)) * 0.999
+        s2max = f32(2.0 * np.log(255.0 * opacity))
+        mx, my = rng.uniform(-200, tw * 16 + 200), rng.uniform(-200, 1300)
+        row = int(rng.integers(0, 68))
+        first, n = row_span(mx, my, a, b, c, s2max, 0, tw, row)
+        ys = row * 16 + np.arange(16) + 0.5
+        dx, dy = (px[None, :] - f32(mx)).astype(np.float64), (ys[:, None] - f32(my)).astype(np.float64)
+        q = float(a) * dx * dx + 2.0 * float(b) * dx * dy + float(c) * dy * dy
+        cols = np.nonzero((q <= float(s2max)).any(axis=0))[0] // 16          # tile columns with a passing pixel
+        if cols.size == 0:
+            continue
+        checked += 1
+        if not (n > 0 and first <= cols.min() and cols.max() < first + n):
+            misses += 1
+    assert checked > 1500 and misses == 0, (checked, misses)
