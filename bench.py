@@ -125,6 +125,8 @@ def make_step(args, dev, world):
     info_box = {"grad_bytes": 0}
     sparse = world > 1 and args.dp_exchange == "sparse" and args.variant == "mtgs"
     exchange = SparseGradExchange(args.n_gaussians, 16, dev["means"].device) if sparse else None
+    if sparse and args.dp_finish == "touched":
+        exchange.defer_maps = True       # the touched rows' map travels with the rows: no visibility-map exchange during the frame
 
     ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rows", "end")}
     info_box["events"] = ev
@@ -147,13 +149,27 @@ def make_step(args, dev, world):
                                                          render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
             torch.autograd.backward([render, alpha], [Gc, Ga])
             ev["rows"].record()
-            cap = info_box.get("static_cap")
-            if cap:      # no host read, no host wait: one fixed-capacity all-gather, counts stay on the device
-                fin = exchange.finish_touched if info_box.get("touched") else exchange.finish_static
-                g, ovf = fin(params["means"], 3, cap, [0] * world)
-                info_box["overflow"] = ovf if info_box.get("overflow") is None else (info_box["overflow"] | ovf)
-            else:
+            if args.dp_finish == "dynamic":
                 g = exchange.finish(params["means"], 3)
+            else:
+                # no host read, no host wait: ONE fixed-capacity all-gather per step, counts stay on the device.  The capacity is
+                # agreed on ONCE, in the first (warm-up) step, from that step's own counts (a tiny MAX all-reduce: setup, not part
+                # of a timed step) -- the dynamic finish() is never run in these modes, so the first multi-GPU execution
+                # exercises exactly the collectives of the timed steps
+                touched = args.dp_finish == "touched"
+                cap = info_box.get("static_cap")
+                if cap is None:
+                    t_cap = torch.tensor([float(exchange.n_vis)], dtype=torch.float64, device=dev["means"].device)
+                    torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
+                    cap = info_box["static_cap"] = int(float(t_cap.item()) * 1.05) + 1024      # (rows of the VISIBLE Gaussians)
+                fin = exchange.finish_touched if touched else exchange.finish_static
+                g, ovf = fin(params["means"], 3, cap, [0] * world)
+                if touched and not info_box.get("touched"):
+                    # ... and, for the touched form, on the rows that carry a gradient: this step's largest count + 10 %
+                    t_cap = exchange.touched_count.to(torch.float64).reshape(1)
+                    torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
+                    info_box["static_cap"], info_box["touched"] = int(float(t_cap.item()) * 1.10) + 1024, True
+                info_box["overflow"] = ovf if info_box.get("overflow") is None else (info_box["overflow"] | ovf)
             for name, t in zip(("means", "quats", "scales", "opacities", "coeffs"), g):
                 params[name].grad = t
             ev["end"].record()
@@ -504,26 +520,7 @@ def main():
             step()
         torch.cuda.synchronize()
         barrier()
-        ex_ = info_box.get("exchange")
-        if world > 1 and ex_ is not None and args.dp_finish in ("static", "touched"):
-            # the static exchange's row capacity: the largest row count any rank saw in the warm-up (dynamic) steps + 5 %, agreed
-            # on by ONE setup collective; from here on the step never reads a count on the host
-            t_cap = torch.tensor([float(ex_.n_vis)], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
-            info_box["static_cap"] = int(float(t_cap.item()) * 1.05) + 1024
-            if args.dp_finish == "touched":
-                # ... and of the rows that carry a gradient: one step with the visible-row capacity, then the ranks' largest count + 10 %
-                info_box["touched"] = True
-                ex_.defer_maps = True
-                step()
-                t_cap = ex_.touched_count.to(torch.float64).reshape(1)
-                torch.distributed.all_reduce(t_cap, op=torch.distributed.ReduceOp.MAX)
-                info_box["static_cap"] = int(float(t_cap.item()) * 1.10) + 1024
-                info_box["overflow"] = None
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            barrier()
+        info_box["overflow"] = None       # (the capacities were set inside the first warm-up step)
     except Exception as e:      # noqa: BLE001
         fail("warm-up", e)
     _lib.time_calls(DOMINANT)
