@@ -163,7 +163,7 @@ def test_sparse_exchange_single_process(hip_lib, K, degree):
         assert torch.allclose(got, r, atol=2e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("exchange", ["sparse", "dense"])
+@pytest.mark.parametrize("exchange", ["sparse", "sparse/static", "sparse/dynamic", "dense"])
 def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
     rank), with both ranks on the test box's single GPU and gloo in place of RCCL: the whole N > 1 code path
@@ -173,7 +173,11 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     env = dict(os.environ, MTGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--n-gaussians", "50000", "--width", "640", "--height", "480", "--dp-exchange", exchange]
+           "--warmup", "1", "--n-gaussians", "50000", "--width", "640", "--height", "480", "--dp-exchange", exchange.split("/")[0]]
+    finish = exchange.split("/")[1] if "/" in exchange else "touched"        # (the default of --gpus N > 1)
+    if "/" in exchange:
+        cmd += ["--dp-finish", finish]
+    exchange = exchange.split("/")[0]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -185,7 +189,12 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     # the N > 1 line carries the phase breakdown that makes a scaling run diagnostic
     ph = out["dp_phases_ms"]
     assert out["dp_world_size"] == 2 and out["dp_backend"] == "gloo"
-    want = {"render", "exchange"} | ({"meta", "wire", "reduce"} if exchange == "sparse" else set())
+    # (touched / static: ONE all-gather inside `exchange`; static also all-gathers the visibility maps during the frame: `meta`;
+    #  dynamic: chunked all-gathers pipelined with the reduction, timed as `wire` / `reduce`)
+    want = {"render", "exchange"}
+    if exchange == "sparse":
+        want |= {"touched": set(), "static": {"meta"}, "dynamic": {"meta", "wire", "reduce"}}[finish]
+        assert {"touched": "finish_touched", "static": "finish_static", "dynamic": "finish:"}[finish] in out["config"]["parallelism"]
     assert want <= set(ph) and all(ph[k] >= 0 for k in want), ph
 
 
@@ -208,7 +217,9 @@ def test_bench_configs3_workload_eight_ranks_on_one_gpu(hip_lib):
     assert out["n_gpus"] == 8 and out["dp_world_size"] == 8 and out["scaling"] == "weak"
     assert out["config"]["n_gaussians"] == 2_000_000 and out["config"]["width"] == 1920
     ph = out["dp_phases_ms"]
-    assert {"render", "exchange", "meta", "wire", "reduce"} <= set(ph)
+    assert {"render", "exchange"} <= set(ph) and "finish_touched" in out["config"]["parallelism"]      # (the default exchange form)
+    # every rank receives the rows that carry a gradient of all eight cameras: ~8 x 130k x 64 B + eight 0.37 MB maps
+    assert 8 * 100_000 * 64 < out["dp_bytes_received_per_rank"][0] < 8 * 200_000 * 64 + 8 * 400_000
     # every rank receives the visible rows of all eight cameras: ~8 x 300k x 64 B, an order of magnitude below the
     # 8 x 472 MB a dense all-reduce moves
     assert "sparse" in out["config"]["parallelism"]
