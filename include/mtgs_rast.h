@@ -41,7 +41,7 @@ extern "C" {
 /* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
-#define MTGS_RAST_HOT_ABI_VERSION 2
+#define MTGS_RAST_HOT_ABI_VERSION 3
 #define MTGS_BIN3_TIGHT 1
 #define MTGS_BIN3_FILL_TO_M 2
 #define MTGS_BIN3_FILL_TO_CAP 4

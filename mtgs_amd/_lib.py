@@ -143,7 +143,7 @@ _SIGNATURES = {
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
 ABI_VERSION = 25
-HOT_ABI_VERSION = 2      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
+HOT_ABI_VERSION = 3      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None
 

@@ -8,15 +8,16 @@
 //      oracle) and the tile count of its 3-sigma square; all dense gsplat `meta` outputs; per 256-pair chunk (and, by
 //      one atomic per block, per 64-chunk group) the number of visible pairs and intersections;
 //   2. front_compact_kernel: every visible pair gets its RANK in index order (group counts + chunk counts in front +
-//      an in-block scan: no inter-block dependency) and, indexed by rank: the 64-byte record (raster_rec.hpp), the flat
+//      an in-block scan: no inter-block dependency) and, indexed by rank: the 64-byte record (raster_rec.hpp; its geometry
+//      half copied from the chunk-local compact rows kernel 1 left, round 5 -- not gathered from the dense arrays), the flat
 //      index (vis_ids) and the depth key (tile count << 40 | camera << 32 | depth bits); vis_rank[flat index] =
 //      rank for the backward's expansion pass; the totals (n_vis, M) go to device memory AND to a pinned host mailbox,
 //      so that the host learns them without synchronising the stream;
 //      optionally the visibility bitmap + per-word rank prefix that the data-parallel gradient exchange
 //      (mtgs_amd.dist, csrc/dp.hip) all-gathers -- available at the START of the frame, so that exchange overlaps
 //      the compositing.
-// Roofline: HBM (streaming): kernel 1 per pair 40 B in + 32..36 B out; kernel 2 per pair 8 B in, per visible pair
-// 36 B (+ colours) gathered + 64 + 20 B out.
+// Roofline: HBM (streaming): kernel 1 per pair 40 B in + 32..36 B out (+ 48 B per visible pair into chunk-local compact rows);
+// kernel 2 per pair 4 B in + 4 B out (radii, vis_rank), per visible pair 48 B (staged row) + colours in, 64 + 12 B out.
 // Compiled with -ffp-contract=off (mtgs_amd/build.py) like project.hip.
 #include "project_fwd_body.hpp"
 #include "tile_rect.hpp"
@@ -28,6 +29,8 @@ namespace {
 // pairs, a group 64 chunks; intersections of a group < 2^14 * 2^19 = 2^33).
 constexpr int CHUNKS_PER_GROUP = 64;
 constexpr int COMPACT_THREADS = 256, COMPACT_ROWS = 8, COMPACT_TILE = COMPACT_THREADS * COMPACT_ROWS;  // 8 chunks
+constexpr int STAGE_FLOATS = 12;   // chunk-local compact row of a visible pair: x y a b | c opacity depth radius | tile count - - -
+static_assert(COMPACT_THREADS == PROJ_BLOCK, "a row of the compaction kernel = one chunk of the projection kernel");
 __device__ __forceinline__ uint64_t pk_vis(uint64_t w) { return w >> 40; }
 __device__ __forceinline__ uint64_t pk_m(uint64_t w) { return w & ((1ull << 40) - 1ull); }
 
@@ -39,10 +42,13 @@ __global__ __launch_bounds__(PROJ_BLOCK) void front_project_kernel(
     float eps2d, float near_plane, float far_plane, float radius_clip, const float *__restrict__ opacities,
     int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics,
     float *__restrict__ compensations, float *__restrict__ opac_eff, float tile_size, int tile_w, int tile_h,
-    int32_t *__restrict__ tiles_per_gauss, uint64_t *__restrict__ chunk_counts, unsigned long long *__restrict__ group_counts) {
+    int32_t *__restrict__ tiles_per_gauss, uint64_t *__restrict__ chunk_counts, unsigned long long *__restrict__ group_counts,
+    float *__restrict__ staged) {
     __shared__ uint64_t s_w[PROJ_BLOCK / 64];
     const int64_t idx = (int64_t)blockIdx.x * PROJ_BLOCK + threadIdx.x;
     uint64_t v = 0;
+    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0;      // the geometry half of this pair's record, if it is visible
+    int32_t st_cnt = 0;
     if (idx < (int64_t)C * N) {
         const int c = C == 1 ? 0 : (int)(idx / N);
         const int64_t n = idx - (int64_t)c * N;
@@ -60,14 +66,37 @@ __global__ __launch_bounds__(PROJ_BLOCK) void front_project_kernel(
             const Rect q = tile_rect(o.mx, o.my, o.radius, tile_size, tile_w, tile_h);
             cnt = (q.x1 - q.x0) * (q.y1 - q.y0);
             v = (1ull << 40) | (uint64_t)(uint32_t)cnt;
+            st0 = make_float4(o.mx, o.my, o.ca, o.cb);
+            st1 = make_float4(o.cc, op, o.depth, __int_as_float(o.radius));
+            st_cnt = cnt;
         }
         opac_eff[idx] = op;
         tiles_per_gauss[idx] = cnt;
     }
+    const uint64_t mine = v;
+    // inclusive scan inside the wave (visible << 40 | tiles), the wave totals through LDS
+    uint64_t inc = v;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(inc, d, 64);
+        if ((threadIdx.x & 63) >= d) inc += up;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
     __syncthreads();
+    // The visible pairs of the chunk leave their record geometry in CHUNK-LOCAL compact rows (staged[chunk * 256 + j], 48 bytes,
+    // j = number of visible pairs in front inside the chunk): front_compact_kernel copies those ~38 contiguous rows per chunk to
+    // their global ranks instead of gathering 28 bytes from five dense arrays per visible pair (its traffic was 2.1x its
+    // algorithmic bytes that way: every 64-byte line of the dense arrays holds a visible pair somewhere)
+    if (mine) {
+        uint64_t before = inc - mine;
+#pragma unroll
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w)
+            if (w < (int)(threadIdx.x >> 6)) before += s_w[w];
+        float4 *dst = reinterpret_cast<float4 *>(staged + ((int64_t)blockIdx.x * PROJ_BLOCK + (int64_t)pk_vis(before)) * STAGE_FLOATS);
+        dst[0] = st0;
+        dst[1] = st1;
+        dst[2] = make_float4(__int_as_float(st_cnt), 0.f, 0.f, 0.f);
+    }
     if (threadIdx.x == 0) {
         uint64_t t = 0;
 #pragma unroll
@@ -80,8 +109,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void front_project_kernel(
 struct CompactArgs {
     int C;
     int64_t N;
-    const int32_t *radii, *tiles_per_gauss;
-    const float *means2d, *depths, *conics, *opac_eff;
+    const int32_t *radii;
+    const float *staged;  // chunk-local compact rows of front_project_kernel
     const float *colors;  // [C*N, DC] (nullable when DC == 0)
     int DC, with_depth, color_mode;
     const uint64_t *chunk_counts, *group_counts;
@@ -105,7 +134,7 @@ struct CompactArgs {
 // chained scan inside ONE fused kernel measured 75 us against 40 + 20 us for these two: its ticket, look-back and
 // low occupancy behind the ~700-instruction projection cost more than a second pass over 8 bytes per pair).
 __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const CompactArgs a) {
-    __shared__ uint64_t s_red[2][COMPACT_THREADS / 64];
+    __shared__ uint64_t s_red[3][COMPACT_THREADS / 64];
     __shared__ uint64_t s_wave[COMPACT_ROWS][COMPACT_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t total = (int64_t)a.C * a.N;
@@ -115,20 +144,22 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
     uint64_t pv = 0, pm = 0;
     for (int64_t g = tid; g < group0; g += COMPACT_THREADS) { const uint64_t w = a.group_counts[g]; pv += pk_vis(w); pm += pk_m(w); }
     for (int64_t c = group0 * CHUNKS_PER_GROUP + tid; c < chunk0; c += COMPACT_THREADS) { const uint64_t w = a.chunk_counts[c]; pv += pk_vis(w); pm += pk_m(w); }
-    int32_t rad[COMPACT_ROWS], cnt[COMPACT_ROWS];
+    int32_t rad[COMPACT_ROWS];
 #pragma unroll
     for (int r = 0; r < COMPACT_ROWS; ++r) {
         const int64_t idx = base + r * COMPACT_THREADS + tid;
         rad[r] = idx < total ? a.radii[idx] : 0;
-        cnt[r] = idx < total ? a.tiles_per_gauss[idx] : 0;
     }
+    // (the intersections of this block's own chunks, for the totals: the per-pair prefix of the tile counts is not needed)
+    uint64_t own_m = 0;
+    if (tid < COMPACT_ROWS && chunk0 + tid < ceil_div64(total, PROJ_BLOCK)) own_m = pk_m(a.chunk_counts[chunk0 + tid]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { pv += __shfl_xor(pv, o, 64); pm += __shfl_xor(pm, o, 64); }
-    if (lane == 0) { s_red[0][wave] = pv; s_red[1][wave] = pm; }
+    for (int o = 32; o > 0; o >>= 1) { pv += __shfl_xor(pv, o, 64); pm += __shfl_xor(pm, o, 64); own_m += __shfl_xor(own_m, o, 64); }
+    if (lane == 0) { s_red[0][wave] = pv; s_red[1][wave] = pm; s_red[2][wave] = own_m; }
     uint64_t incl_w[COMPACT_ROWS];
 #pragma unroll
     for (int r = 0; r < COMPACT_ROWS; ++r) {
-        uint64_t inc = rad[r] > 0 ? ((1ull << 40) | (uint64_t)(uint32_t)cnt[r]) : 0ull;
+        uint64_t inc = rad[r] > 0 ? (1ull << 40) : 0ull;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t up = __shfl_up(inc, d, 64);
@@ -138,12 +169,13 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
         if (lane == 63) s_wave[r][wave] = inc;
     }
     __syncthreads();
-    uint64_t excl_vis = 0, excl_m = 0;
+    uint64_t excl_vis = 0, excl_m = 0, block_m = 0;
 #pragma unroll
-    for (int w = 0; w < COMPACT_THREADS / 64; ++w) { excl_vis += s_red[0][w]; excl_m += s_red[1][w]; }
-    uint64_t block_tot = 0, pre[COMPACT_ROWS];
+    for (int w = 0; w < COMPACT_THREADS / 64; ++w) { excl_vis += s_red[0][w]; excl_m += s_red[1][w]; block_m += s_red[2][w]; }
+    uint64_t block_tot = 0, pre[COMPACT_ROWS], row0[COMPACT_ROWS];
 #pragma unroll
     for (int r = 0; r < COMPACT_ROWS; ++r) {
+        row0[r] = block_tot;        // visible pairs of this block in front of row (= chunk) r
 #pragma unroll
         for (int w = 0; w < COMPACT_THREADS / 64; ++w) {
             if (w == wave) pre[r] = block_tot;
@@ -166,9 +198,14 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
         if (idx < total) a.vis_rank[idx] = vis ? (int32_t)rank : -1;
         if (vis) {
             if (rank < a.cap_vis) {
-                const float2 xy = reinterpret_cast<const float2 *>(a.means2d)[idx];
-                const F3 con = *reinterpret_cast<const F3 *>(a.conics + idx * 3);
-                const float dep = a.depths[idx], op = a.opac_eff[idx];
+                // this pair's staged row: chunk r of the block, position = visible pairs of the chunk in front of it
+                const int64_t local = (int64_t)(pk_vis(pre[r]) - pk_vis(row0[r]) + pk_vis(incl_w[r])) - 1;
+                const float4 *sp = reinterpret_cast<const float4 *>(a.staged + ((chunk0 + r) * PROJ_BLOCK + local) * STAGE_FLOATS);
+                const float4 g0 = sp[0], g1 = sp[1];
+                const int32_t cnt_r = __float_as_int(sp[2].x);
+                const float2 xy = make_float2(g0.x, g0.y);
+                const F3 con = F3{g0.z, g0.w, g1.x};
+                const float dep = g1.z, op = g1.y;
                 float ch[REC_MAX_CHANNELS];
 #pragma unroll
                 for (int k = 0; k < REC_MAX_CHANNELS; ++k) ch[k] = 0.f;
@@ -194,7 +231,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                 a.vis_ids[rank] = (int32_t)idx;
                 // depth key: tile count | camera | depth bits (bin3.hip reads the depth bits: the high word of its
                 // per-tile sort keys)
-                a.vis_keys[rank] = ((uint64_t)(uint32_t)cnt[r] << 40) | ((uint64_t)(a.C == 1 ? 0 : idx / a.N) << 32) |
+                a.vis_keys[rank] = ((uint64_t)(uint32_t)cnt_r << 40) | ((uint64_t)(a.C == 1 ? 0 : idx / a.N) << 32) |
                                    (uint64_t)__float_as_uint(dep);
                 float4 *dst = reinterpret_cast<float4 *>(a.recs + rank * REC_FLOATS);
                 dst[0] = make_float4(xy.x, xy.y, con.x, con.y);
@@ -205,7 +242,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
         }
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
-        uint64_t n_vis = excl_vis + pk_vis(block_tot), M = excl_m + pk_m(block_tot);
+        uint64_t n_vis = excl_vis + pk_vis(block_tot), M = excl_m + block_m;
         // more than 2^31 - 2 intersections: published as M = 2^31 - 1, which the host refuses (flatten_ids /
         // isect_offsets are int32, so such a frame cannot be rendered anyway)
         if (M > 0x7fffffffull) M = 0x7fffffffull;
@@ -219,13 +256,17 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
     }
 }
 
-// workspace: group counts (zeroed by the call) | chunk counts
+// workspace: group counts (zeroed by the call) | chunk counts | staged rows
 inline size_t front_group_bytes(int64_t total) {
     const int64_t chunks = ceil_div64(total > 0 ? total : 1, PROJ_BLOCK);
     return ((size_t)ceil_div64(chunks, CHUNKS_PER_GROUP) * 8 + 255) & ~(size_t)255;
 }
+inline size_t front_counts_bytes(int64_t total) {
+    return (front_group_bytes(total) + (size_t)ceil_div64(total > 0 ? total : 1, PROJ_BLOCK) * 8 + 255) & ~(size_t)255;
+}
+// ... | chunk-local compact rows of the visible pairs (capacity: every pair; only the visible ones' rows are ever touched)
 inline size_t front_ws_bytes(int64_t total) {
-    return front_group_bytes(total) + (size_t)ceil_div64(total > 0 ? total : 1, PROJ_BLOCK) * 8;
+    return front_counts_bytes(total) + (size_t)ceil_div64(total > 0 ? total : 1, PROJ_BLOCK) * PROJ_BLOCK * STAGE_FLOATS * 4;
 }
 
 }  // namespace
@@ -284,13 +325,13 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
     if (int rc = mtgs_zero_async(ws, front_group_bytes(total), st)) return rc;
     unsigned long long *group_counts = (unsigned long long *)ws;
     uint64_t *chunk_counts = (uint64_t *)((char *)ws + front_group_bytes(total));
+    float *staged = (float *)((char *)ws + front_counts_bytes(total));
     front_project_kernel<<<(unsigned)ceil_div64(total, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
         C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, opacities, radii,
         means2d, depths, conics, compensations, opac_eff, (float)tile_size, tile_w, tile_h, tiles_per_gauss, chunk_counts,
-        group_counts);
+        group_counts, staged);
     CompactArgs a;
-    a.C = C; a.N = N; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss; a.means2d = means2d; a.depths = depths;
-    a.conics = conics; a.opac_eff = opac_eff; a.colors = colors; a.DC = D; a.with_depth = with_depth ? 1 : 0;
+    a.C = C; a.N = N; a.radii = radii; a.staged = staged; a.colors = colors; a.DC = D; a.with_depth = with_depth ? 1 : 0;
     a.chunk_counts = chunk_counts; a.group_counts = (const uint64_t *)group_counts;
     a.recs = recs; a.vis_ids = vis_ids; a.vis_keys = (uint64_t *)vis_keys; a.vis_rank = vis_rank; a.cap_vis = cap_vis;
     a.dp_words = (unsigned long long *)dp_words; a.dp_prefix = dp_prefix; a.dp_count = dp_count; a.color_mode = color_mode;
