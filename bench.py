@@ -674,8 +674,8 @@ def main():
     alg = {
         "sh_fwd_k16_kernel<3>": N * (12 + 12 * Ksh_ + 12),
         "sh_bwd_kernel<3>": N * (24 + 12 * Ksh_),
-        "front_project_kernel": N * (40 + 4 + 40),
-        "front_compact_kernel": N * 8 + n_vis * (36 + 16 + 64 + 4 + 8 + 4),
+        "front_project_kernel": N * (40 + 4 + 40) + n_vis * 48,                  # (+ the chunk-local compact rows of the visible pairs)
+        "front_compact_kernel": N * (4 + 4) + n_vis * (48 + 12 + 64 + 4 + 8),   # radii in, vis_rank out | staged row + colours in, record + id + key out
         "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
         "project_bwd_expand_kernel": N * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
         "bin3_rows_count_kernel": n_vis * 64,
