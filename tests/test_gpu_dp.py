@@ -589,8 +589,15 @@ def _worker_nccl_world1(out_path):
     sums = ex.finish(P["means"], 3)
     t = torch.ones(1024, device=dev)
     dist.all_reduce(t)                      # and a plain RCCL all-reduce (the dense exchange's collective)
+    # the default exchange of bench.py --gpus N: one RCCL all-gather of [rows that carry a gradient | their map]
+    ex.defer_maps = True
+    r2, a2, _ = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm.to(dev), Kmat.to(dev), W, H, cam_pos)
+    torch.autograd.backward([r2, a2], [Gc, Ga])
+    sums_t, ovf = ex.finish_touched(P["means"], 3, N, [0])
     torch.cuda.synchronize()
-    ok = bool(torch.isfinite(sums[0]).all()) and float(t.sum()) == 1024.0 and float(sums[0].abs().max()) > 0
+    same = all(float((x - y).abs().max()) <= 3e-5 * float(y.abs().max()) + 1e-7 for x, y in zip(sums_t, sums))
+    ok = bool(torch.isfinite(sums[0]).all()) and float(t.sum()) == 1024.0 and float(sums[0].abs().max()) > 0 and same and not bool(ovf) \
+        and ex.last_bytes > 0
     ver = ".".join(str(v) for v in torch.cuda.nccl.version())
     with open(out_path, "w") as f:
         f.write(f"{int(ok)} {ver} {dist.get_backend()}")
