@@ -41,10 +41,11 @@ extern "C" {
 /* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
-#define MTGS_RAST_HOT_ABI_VERSION 3
+#define MTGS_RAST_HOT_ABI_VERSION 4
 #define MTGS_BIN3_TIGHT 1
 #define MTGS_BIN3_FILL_TO_M 2
 #define MTGS_BIN3_FILL_TO_CAP 4
+#define MTGS_BIN3_PREZEROED 8
 
 enum {
     MTGS_OK = 0,
@@ -317,6 +318,7 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  * `alpha < 1/255: continue`), so render, alphas and all gradients are those of the full lists, but the pair is never counted,
  * placed, sorted or gathered.  offsets[last] = the number of pairs listed (<= M of `totals`); tiles_per_gauss of
  * mtgs_front_fwd and M stay gsplat's.  Without the flag: gsplat's lists, bit-identical (the default of rasterization()).
+ * MTGS_BIN3_PREZEROED (8): the workspace's control words are zero already (mtgs_front_fwd(also_zero)).
  * MTGS_BIN3_FILL_TO_M (2) / MTGS_BIN3_FILL_TO_CAP (4): the entries of flatten_ids / isect_ids behind the listed pairs -- up to
  * min(cap_M, M of `totals`) / up to cap_M -- are filled with sentinels (flatten_ids -1; isect_ids = last camera | last tile |
  * +inf depth bits): a caller that slices the tensors to gsplat's M (tight lists) or hands out capacity-sized tensors (graph
@@ -339,8 +341,12 @@ int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, con
                    float *compensations, float *opac_eff, int tile_size, int tile_w, int tile_h,
                    int32_t *tiles_per_gauss, float *recs, int32_t *vis_ids, int64_t *vis_keys,
                    int32_t *vis_rank, int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
-                   int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws, size_t ws_bytes,
-                   void *stream);
+                   int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *also_zero,
+                   size_t also_zero_bytes, void *ws, size_t ws_bytes, void *stream);
+/* also_zero (nullable; hot ABI v4): a region of whole 4-byte words that mtgs_front_fwd's compaction kernel clears for the caller --
+ * the control words at the start of mtgs_bin3_build's workspace (mtgs_bin3_control_bytes), so that the binning, called with
+ * MTGS_BIN3_PREZEROED behind it on the same stream, needs no launch of its own for them. */
+int mtgs_bin3_control_bytes(int C, int tile_w, int tile_h, size_t *bytes);
 int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M);
 int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
 int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,

@@ -54,8 +54,9 @@ _SIGNATURES = {
     "mtgs_front_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_front_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32,
                        _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32,
-                       _vp, _vp, _i64, _vp, _sz, _vp],
+                       _vp, _vp, _i64, _vp, _sz, _vp, _sz, _vp],
     "mtgs_bin3_supported": [_i32, _i32, _i32, _i64],
+    "mtgs_bin3_control_bytes": [_i32, _i32, _i32, C.POINTER(_sz)],
     "mtgs_bin3_workspace_bytes": [_i32, _i32, _i32, _i64, _i64, C.POINTER(_sz)],
     "mtgs_bin3_build": [_i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                         _vp, _sz, _vp],
@@ -143,7 +144,7 @@ _SIGNATURES = {
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
 ABI_VERSION = 25
-HOT_ABI_VERSION = 3      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
+HOT_ABI_VERSION = 4      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None
 

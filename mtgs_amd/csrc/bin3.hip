@@ -892,6 +892,12 @@ extern "C" int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M)
                ? 1 : 0;
 }
 
+extern "C" int mtgs_bin3_control_bytes(int C, int tile_w, int tile_h, size_t *bytes) {
+    MTGS_REQUIRE(C > 0 && tile_w > 0 && tile_h > 0 && bytes, MTGS_EINVAL, "mtgs_bin3_control_bytes: bad arguments");
+    *bytes = carve3(nullptr, 1, 1, C * tile_h, C * tile_w * tile_h).control_bytes;
+    return MTGS_OK;
+}
+
 extern "C" int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes) {
     MTGS_REQUIRE(C > 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0 && bytes, MTGS_EINVAL,
                  "mtgs_bin3_workspace_bytes: bad arguments");
@@ -905,7 +911,8 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
                                int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, int flags,
                                void *ws, size_t ws_bytes, void *stream) {
     const int tight = flags & MTGS_BIN3_TIGHT;
-    MTGS_REQUIRE((flags & ~(MTGS_BIN3_TIGHT | MTGS_BIN3_FILL_TO_M | MTGS_BIN3_FILL_TO_CAP)) == 0, MTGS_EINVAL, "mtgs_bin3_build: unknown flags %d", flags);
+    MTGS_REQUIRE((flags & ~(MTGS_BIN3_TIGHT | MTGS_BIN3_FILL_TO_M | MTGS_BIN3_FILL_TO_CAP | MTGS_BIN3_PREZEROED)) == 0, MTGS_EINVAL,
+                 "mtgs_bin3_build: unknown flags %d", flags);
     MTGS_REQUIRE(C > 0 && N >= 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0, MTGS_EINVAL, "mtgs_bin3_build: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_bin3_build: tile_size=%d (only 16 is implemented)", tile_size);
     MTGS_REQUIRE(mtgs_bin3_supported(C, tile_w, tile_h, cap_M), MTGS_EUNSUPPORTED,
@@ -918,7 +925,10 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
     Bin3Workspace w = carve3((char *)ws, cap_vis, cap_M, n_rows, n_bins);
     MTGS_REQUIRE(ws_bytes >= w.total, MTGS_EWORKSPACE, "mtgs_bin3_build: workspace %zu < %zu bytes", ws_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = mtgs_zero_async(w.control, w.control_bytes, st)) return rc;
+    // (MTGS_BIN3_PREZEROED: the first mtgs_bin3_control_bytes() of the workspace were cleared by a kernel in front of this call on
+    //  the same stream -- mtgs_front_fwd(also_zero) -- one launch fewer per frame)
+    if (!(flags & MTGS_BIN3_PREZEROED))
+        if (int rc = mtgs_zero_async(w.control, w.control_bytes, st)) return rc;
     const SizeRef n_vis_ref{totals, 1, cap_vis};
     int32_t *order = tile_order ? tile_order : w.order;
     const unsigned r_grid = (unsigned)ceil_div64(cap_vis > 0 ? cap_vis : 1, R_BLOCK);

@@ -126,6 +126,8 @@ struct CompactArgs {
     int64_t *totals;       // device: n_vis << 32 | M
     int64_t *host_totals;  // pinned host mailbox {totals, tag}; nullable
     int64_t host_tag;
+    uint32_t *also_zero;   // nullable: words this kernel clears for the caller (the binning's control words: one launch fewer per frame)
+    int64_t also_zero_words;
 };
 
 // ---- kernel 2: rank of every visible pair (index order) and its packed record.  A block owns 8 chunks; the number of
@@ -139,6 +141,9 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t total = (int64_t)a.C * a.N;
     const int64_t base = (int64_t)blockIdx.x * COMPACT_TILE;
+    if (a.also_zero)
+        for (int64_t i = (int64_t)blockIdx.x * COMPACT_THREADS + tid; i < a.also_zero_words; i += (int64_t)gridDim.x * COMPACT_THREADS)
+            a.also_zero[i] = 0u;
     const int64_t chunk0 = (int64_t)blockIdx.x * COMPACT_ROWS, group0 = chunk0 / CHUNKS_PER_GROUP;
     // prefix: groups in front, then the chunks of this group in front of the block
     uint64_t pv = 0, pm = 0;
@@ -285,8 +290,10 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
                               int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss, float *recs,
                               int32_t *vis_ids, int64_t *vis_keys, int32_t *vis_rank,
                               int64_t cap_vis, uint64_t *dp_words, uint32_t *dp_prefix, int32_t *dp_count,
-                              int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *ws,
-                              size_t ws_bytes, void *stream) {
+                              int color_mode, int64_t *totals, int64_t *host_totals, int64_t host_tag, void *also_zero,
+                              size_t also_zero_bytes, void *ws, size_t ws_bytes, void *stream) {
+    MTGS_REQUIRE(!also_zero || ((reinterpret_cast<uintptr_t>(also_zero) | also_zero_bytes) & 3) == 0, MTGS_EINVAL,
+                 "mtgs_front_fwd: also_zero must be a 4-byte aligned region of whole words");
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0 && D >= 0 && cap_vis >= 0, MTGS_EINVAL,
                  "mtgs_front_fwd: bad sizes C=%d N=%lld W=%d H=%d D=%d", C, (long long)N, width, height, D);
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_front_fwd: tile_size=%d (only 16 is implemented)", tile_size);
@@ -303,6 +310,8 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
     if (total == 0) {
         hipError_t e = hipMemsetAsync(totals, 0, sizeof(int64_t), st);
         MTGS_REQUIRE(e == hipSuccess, MTGS_ELAUNCH, "mtgs_front_fwd: memset failed");
+        if (also_zero && also_zero_bytes)
+            if (int rc = mtgs_zero_async(also_zero, also_zero_bytes, st)) return rc;
         if (host_totals) {  // host memory: nothing to wait for
             host_totals[0] = 0;
             __atomic_store_n(host_totals + 1, host_tag, __ATOMIC_RELEASE);
@@ -336,6 +345,7 @@ extern "C" int mtgs_front_fwd(int C, int64_t N, const float *means, const float 
     a.recs = recs; a.vis_ids = vis_ids; a.vis_keys = (uint64_t *)vis_keys; a.vis_rank = vis_rank; a.cap_vis = cap_vis;
     a.dp_words = (unsigned long long *)dp_words; a.dp_prefix = dp_prefix; a.dp_count = dp_count; a.color_mode = color_mode;
     a.totals = totals; a.host_totals = host_totals; a.host_tag = host_tag;
+    a.also_zero = (uint32_t *)also_zero; a.also_zero_words = also_zero ? (int64_t)(also_zero_bytes / 4) : 0;
     front_compact_kernel<<<(unsigned)ceil_div64(total, COMPACT_TILE), COMPACT_THREADS, 0, st>>>(a);
     MTGS_CHECK_LAUNCH("mtgs_front_fwd");
     return MTGS_OK;

@@ -665,7 +665,15 @@ class _FusedRasterization(torch.autograd.Function):
                     call("mtgs_normals_fwd_rows", cap_vis, ptr(b["vis_ids"]), ptr(totals), ptr(quats), ptr(scales), ptr(means),
                          ptr(n2c), ptr(b["recs"]), 3, ptr(flags), st)
 
-            def front(cap_vis, repeat=False):
+            def bin_ws(cap_vis, cap_M):      # the binning's workspace, 256-byte aligned: (tensor, pointer, bytes, bytes of its control words)
+                nbytes, cbytes = C.c_size_t(0), C.c_size_t(0)
+                call("mtgs_bin3_workspace_bytes", Cn, tw, th, cap_vis, cap_M, C.byref(nbytes))
+                call("mtgs_bin3_control_bytes", Cn, tw, th, C.byref(cbytes))
+                ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+                return ws, ws.data_ptr() + (-ws.data_ptr()) % 256, nbytes.value, cbytes.value
+
+            def front(cap_vis, repeat=False, prezero=None):
+                # prezero = bin_ws(...) of the binning that follows: its control words are cleared by the compaction kernel here
                 # repeat=True: the capacity-overflow repeat of a frame.  The visibility map / row count of the exchange do not
                 # depend on cap_vis and are already on their way: they are neither rewritten nor gathered a second time
                 # (a second meta all-gather on ONE rank would desynchronise the ranks' collectives).
@@ -682,6 +690,7 @@ class _FusedRasterization(torch.autograd.Function):
                      ptr(vis_rank), cap_vis, *(dpf.front_pointers() if dpf is not None else (None, None, None)),
                      (1 if dp is not None else 0) if cs is None else (3 if c_open == 6 else 2), ptr(totals),
                      None if mailbox is None else mailbox.data_ptr(), tag,
+                     None if prezero is None else prezero[1], 0 if prezero is None else prezero[3],
                      ptr(front_ws), front_bytes, st)
                 if cs is not None and not touch_first:
                     colours(b, None)
@@ -690,20 +699,16 @@ class _FusedRasterization(torch.autograd.Function):
                     dpf.after_front()      # the visibility maps travel while this frame is composited
                 return b
 
-            def rest(b, cap_M):
+            def rest(b, cap_M, prezeroed=None):
                 cap_alloc = max(cap_M, 1)
                 out = {"rank_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
                        "flatten_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
                        "isect_ids": torch.empty(cap_alloc, dtype=torch.int64, device=dev)}
-                nbytes = C.c_size_t(0)
-                call("mtgs_bin3_workspace_bytes", Cn, tw, th, b["cap_vis"], cap_M, C.byref(nbytes))
-                ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
-                off = (-ws.data_ptr()) % 256
+                ws, ws_ptr, ws_bytes, _ = prezeroed if prezeroed is not None else bin_ws(b["cap_vis"], cap_M)
                 call("mtgs_bin3_build", Cn, N, tile_size, tw, th, ptr(totals), b["cap_vis"], cap_M, ptr(b["recs"]),
                      ptr(b["vis_ids"]), ptr(b["vis_keys"]), ptr(out["rank_ids"]),
-                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order), list_flags,
-                     ws.data_ptr() + off,
-                     nbytes.value, st)
+                     ptr(out["flatten_ids"]), ptr(out["isect_ids"]), ptr(offsets_buf), ptr(order),
+                     list_flags | (8 if prezeroed is not None else 0), ws_ptr, ws_bytes, st)
                 if touch_first:
                     flags = torch.empty(max(b["cap_vis"], 1), dtype=torch.uint8, device=dev)
                     call("mtgs_blend_touch_packed", Cn, ptr(b["recs"]), width, height, tw, th, ptr(offsets_buf), ptr(out["rank_ids"]),
@@ -720,12 +725,14 @@ class _FusedRasterization(torch.autograd.Function):
                 # graph mode: fixed capacities, nothing waits for the host; the counts stay on the device
                 if dp is not None or not _bin3_ok(Cn, tw, th, graph_caps[1]):
                     raise NotImplementedError("graph_mode: unsupported configuration (data-parallel exchange / capacity >= 2^30)")
-                b = front(min(graph_caps[0], total))
-                out = rest(b, graph_caps[1])
+                pz = bin_ws(min(graph_caps[0], total), graph_caps[1])
+                b = front(min(graph_caps[0], total), prezero=pz)
+                out = rest(b, graph_caps[1], prezeroed=pz)
                 n_vis, M = b["cap_vis"], graph_caps[1]
             elif caps is not None:
-                b = front(min(caps[0], total))
-                out = rest(b, caps[1])                    # enqueued before the totals are known
+                pz = bin_ws(min(caps[0], total), caps[1])
+                b = front(min(caps[0], total), prezero=pz)
+                out = rest(b, caps[1], prezeroed=pz)      # enqueued before the totals are known
                 n_vis, M = _wait_mailbox(b["mailbox"], b["tag"], totals, total)
                 if n_vis > b["cap_vis"] or M > caps[1]:   # capacities too small: repeat with exact sizes
                     if not _bin3_ok(Cn, tw, th, M):
