@@ -25,6 +25,59 @@ template <int MODE> __global__ __launch_bounds__(256) void w_rows192(float *__re
     const f4 v = {1.f, 2.f, 3.f, 4.f};
     for (size_t i = threadIdx.x; i < n4; i += 256) { if (MODE) __builtin_nontemporal_store(v, dst + i); else dst[i] = v; }
 }
+// sh_bwd-like: per block 128 rows: each thread reads 2 x 12 bytes of its row's inputs, stages 48 floats in LDS, barrier, block writes 24.5 KB coalesced
+template <int BLOCK, int WORK> __global__ __launch_bounds__(BLOCK) void w_shlike(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ p, size_t rows) {
+    __shared__ float lds[BLOCK * 49];
+    const size_t g0 = (size_t)blockIdx.x * BLOCK;
+    const int cnt = (int)(rows - g0 < BLOCK ? rows - g0 : BLOCK), tid = threadIdx.x;
+    if (tid < cnt) {
+        const size_t g = g0 + tid;
+        float x = a[g * 3], y = a[g * 3 + 1], z = a[g * 3 + 2], v0 = b[g * 3], v1 = b[g * 3 + 1], v2 = b[g * 3 + 2];
+        float acc = x;
+#pragma unroll
+        for (int w = 0; w < WORK; ++w) acc = acc * y + z;      // stand-in for the basis evaluation
+        float *row = lds + tid * 49;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { row[3 * k] = acc * v0 + k; row[3 * k + 1] = acc * v1; row[3 * k + 2] = acc * v2; }
+    }
+    __syncthreads();
+    f4 *dst = (f4 *)(p + g0 * 48);
+    const int n4 = cnt * 12;
+    for (int i4 = tid; i4 < n4; i4 += BLOCK) {
+        const int g = i4 / 12, j = (i4 % 12) * 4;
+        const float *s = lds + g * 49;
+        f4 v = {s[j], s[j + 1], s[j + 2], s[j + 3]};
+        dst[i4] = v;
+    }
+}
+// the same with 16-byte LDS accesses: 12 ds_write_b128 + 12 ds_read_b128 per thread instead of 48 + 48 four-byte ones (row stride 52 floats)
+template <int BLOCK, int WORK, int RS> __global__ __launch_bounds__(BLOCK) void w_shlike128(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ p, size_t rows) {
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * RS];
+    const size_t g0 = (size_t)blockIdx.x * BLOCK;
+    const int cnt = (int)(rows - g0 < BLOCK ? rows - g0 : BLOCK), tid = threadIdx.x;
+    if (tid < cnt) {
+        const size_t g = g0 + tid;
+        float x = a[g * 3], y = a[g * 3 + 1], z = a[g * 3 + 2], v[3] = {b[g * 3], b[g * 3 + 1], b[g * 3 + 2]};
+        float acc = x;
+#pragma unroll
+        for (int w = 0; w < WORK; ++w) acc = acc * y + z;
+        f4 *row = (f4 *)(lds + tid * RS);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            f4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = 4 * q + i; o[i] = (acc + (float)(e / 3)) * v[e % 3]; }
+            row[q] = o;
+        }
+    }
+    __syncthreads();
+    f4 *dst = (f4 *)(p + g0 * 48);
+    const int n4 = cnt * 12;
+    for (int i4 = tid; i4 < n4; i4 += BLOCK) {
+        const int g = i4 / 12, q = i4 % 12;
+        dst[i4] = *(const f4 *)(lds + g * RS + q * 4);
+    }
+}
 template <class F> void timeit(const char *name, size_t bytes, F &&launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
@@ -50,5 +103,15 @@ int main() {
     const size_t rows = bytes / 192;
     timeit("rows of 192 B, 256/block", bytes, [&] { w_rows192<0><<<(unsigned)((rows + 255) / 256), 256>>>((float *)p, rows); });
     timeit("rows of 192 B, 256/block nt", bytes, [&] { w_rows192<1><<<(unsigned)((rows + 255) / 256), 256>>>((float *)p, rows); });
+    float *a, *b; hipMalloc(&a, rows * 12); hipMalloc(&b, rows * 12); hipMemset(a, 0, rows * 12); hipMemset(b, 0, rows * 12);
+    const size_t tot = bytes + rows * 24;
+    timeit("sh_bwd-like 128/block, work 0", tot, [&] { w_shlike<128, 0><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like 128/block, work 40", tot, [&] { w_shlike<128, 40><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like 256/block, work 40", tot, [&] { w_shlike<256, 40><<<(unsigned)((rows + 255) / 256), 256>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like b128 128/blk rs52 w0", tot, [&] { w_shlike128<128, 0, 52><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like b128 128/blk rs52 w40", tot, [&] { w_shlike128<128, 40, 52><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like b128 256/blk rs52 w40", tot, [&] { w_shlike128<256, 40, 52><<<(unsigned)((rows + 255) / 256), 256>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like b128 128/blk rs48 w40", tot, [&] { w_shlike128<128, 40, 48><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sh_bwd-like 64/block, work 40", tot, [&] { w_shlike<64, 40><<<(unsigned)((rows + 63) / 64), 64>>>(a, b, (float *)p, rows); });
     return 0;
 }
