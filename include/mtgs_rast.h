@@ -37,15 +37,16 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 25
+#define MTGS_RAST_ABI_VERSION 26
 /* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
-#define MTGS_RAST_HOT_ABI_VERSION 4
+#define MTGS_RAST_HOT_ABI_VERSION 5
 #define MTGS_BIN3_TIGHT 1
 #define MTGS_BIN3_FILL_TO_M 2
 #define MTGS_BIN3_FILL_TO_CAP 4
 #define MTGS_BIN3_PREZEROED 8
+#define MTGS_BIN3_STATUS 16
 
 enum {
     MTGS_OK = 0,
@@ -106,6 +107,8 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * vis_ids[n_vis] i32 + vis_ws[n_vis*12] f32 scratch (both nullable): the visible Gaussians in increasing order
  * with grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank).  With them (and C == 1) the
  * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced.
+ * recs (nullable; hot ABI v5; compact path): mtgs_front_fwd's 64-byte records, indexed like the rows -- conic and blended opacity of a
+ * visible Gaussian are then read from its record (contiguous) instead of being gathered from conics / opacities / compensations.
  * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals; the number of rows is then min(n_vis, *n_vis_dev >> 32)
  * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count).
  * Rows only: with v_means = v_quats = v_scales = v_opacities = NULL (compact path, no dense by-products) the streaming pass is
@@ -133,7 +136,7 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *x_means2d_abs, const float *x_colors, int x_channels,
                      const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
                      const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
-                     const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, void *stream);
+                     const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, const float *recs, void *stream);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.
@@ -319,6 +322,9 @@ int mtgs_refine_rows(int64_t n_out, int64_t width, const float *src, const int32
  * placed, sorted or gathered.  offsets[last] = the number of pairs listed (<= M of `totals`); tiles_per_gauss of
  * mtgs_front_fwd and M stay gsplat's.  Without the flag: gsplat's lists, bit-identical (the default of rasterization()).
  * MTGS_BIN3_PREZEROED (8): the workspace's control words are zero already (mtgs_front_fwd(also_zero)).
+ * MTGS_BIN3_STATUS (16; hot ABI v5): `totals` points at FOUR words and the call writes words 1..3 = {n_vis, M, 1 if n_vis > cap_vis
+ * or M > cap_M (the frame was truncated: repeat it with larger capacities) else 0} -- the device scalars a graph-captured caller
+ * hands out as info["n_visible"] / ["n_intersections"] / ["overflow"] without launching anything to unpack word 0.
  * MTGS_BIN3_FILL_TO_M (2) / MTGS_BIN3_FILL_TO_CAP (4): the entries of flatten_ids / isect_ids behind the listed pairs -- up to
  * min(cap_M, M of `totals`) / up to cap_M -- are filled with sentinels (flatten_ids -1; isect_ids = last camera | last tile |
  * +inf depth bits): a caller that slices the tensors to gsplat's M (tight lists) or hands out capacity-sized tensors (graph
@@ -349,7 +355,7 @@ int mtgs_front_fwd(int C, int64_t N, const float *means, const float *quats, con
 int mtgs_bin3_control_bytes(int C, int tile_w, int tile_h, size_t *bytes);
 int mtgs_bin3_supported(int C, int tile_w, int tile_h, int64_t cap_M);
 int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t cap_vis, int64_t cap_M, size_t *bytes);
-int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
+int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, int64_t *totals,
                     int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                     const int64_t *vis_keys, int32_t *rank_ids, int32_t *flatten_ids, int64_t *isect_ids,
                     int32_t *offsets, int32_t *tile_order, int flags, void *ws, size_t ws_bytes, void *stream);

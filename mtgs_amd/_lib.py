@@ -34,7 +34,7 @@ _SIGNATURES = {
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp,
-                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+                         _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],
     "mtgs_isect_scan": [_i64, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -143,8 +143,8 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 25
-HOT_ABI_VERSION = 4      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
+ABI_VERSION = 26
+HOT_ABI_VERSION = 5      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None
 

@@ -450,6 +450,8 @@ struct TailFill {
     int32_t *flatten_ids;
     int64_t *isect_ids;      // nullable
     int64_t sentinel_key;
+    int64_t *status;         // nullable (MTGS_BIN3_STATUS): {n_vis, M, frame beyond its capacities} for the caller, behind `totals`
+    int64_t cap_vis, cap_M;
 };
 
 // ---- 3. every intersection into its tile's segment --------------------------------------------------------------
@@ -529,6 +531,12 @@ __global__ __launch_bounds__(T_THREADS) void bin3_tiles_place_kernel(
     // gsplat's convention "the last tile's range ends at flatten_ids.numel()" never walks uninitialised entries: the
     // gather-based compositing forward stops at the first negative id, isect_offset_encode of the padded isect_ids puts the
     // tail into the last tile.  offsets[n_bins] is final here (bin3_tiles_count_kernel); the sort kernels behind write [0, n_listed).
+    if (tail.status && blockIdx.x == 0 && tid == 0) {
+        const int64_t packed = *tail.totals, nv = packed >> 32, m = packed & 0xFFFFFFFFll;
+        tail.status[0] = nv;
+        tail.status[1] = m;
+        tail.status[2] = (nv > tail.cap_vis || m > tail.cap_M) ? 1 : 0;
+    }
     if (tail.mode) {
         const int64_t from = offsets[n_bins];
         int64_t to = (int64_t)cap_keys;
@@ -905,13 +913,13 @@ extern "C" int mtgs_bin3_workspace_bytes(int C, int tile_w, int tile_h, int64_t 
     return MTGS_OK;
 }
 
-extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, const int64_t *totals,
+extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, int64_t *totals,
                                int64_t cap_vis, int64_t cap_M, const float *recs, const int32_t *vis_ids,
                                const int64_t *vis_keys, int32_t *rank_ids,
                                int32_t *flatten_ids, int64_t *isect_ids, int32_t *offsets, int32_t *tile_order, int flags,
                                void *ws, size_t ws_bytes, void *stream) {
     const int tight = flags & MTGS_BIN3_TIGHT;
-    MTGS_REQUIRE((flags & ~(MTGS_BIN3_TIGHT | MTGS_BIN3_FILL_TO_M | MTGS_BIN3_FILL_TO_CAP | MTGS_BIN3_PREZEROED)) == 0, MTGS_EINVAL,
+    MTGS_REQUIRE((flags & ~(MTGS_BIN3_TIGHT | MTGS_BIN3_FILL_TO_M | MTGS_BIN3_FILL_TO_CAP | MTGS_BIN3_PREZEROED | MTGS_BIN3_STATUS)) == 0, MTGS_EINVAL,
                  "mtgs_bin3_build: unknown flags %d", flags);
     MTGS_REQUIRE(C > 0 && N >= 0 && tile_w > 0 && tile_h > 0 && cap_vis >= 0 && cap_M >= 0, MTGS_EINVAL, "mtgs_bin3_build: bad sizes");
     MTGS_REQUIRE(tile_size == MTGS_TILE_SIZE, MTGS_EUNSUPPORTED, "mtgs_bin3_build: tile_size=%d (only 16 is implemented)", tile_size);
@@ -947,7 +955,8 @@ extern "C" int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int 
     }
     const int tile_bits_ = bit_length_u32((uint32_t)(tile_w * tile_h));
     const TailFill tail{cap_M > 0 ? ((flags & MTGS_BIN3_FILL_TO_CAP) ? 4 : ((flags & MTGS_BIN3_FILL_TO_M) ? 2 : 0)) : 0, totals, flatten_ids, isect_ids,
-                        ((int64_t)(C - 1) << (32 + tile_bits_)) | ((int64_t)(tile_w * tile_h - 1) << 32) | (int64_t)0x7f800000};
+                        ((int64_t)(C - 1) << (32 + tile_bits_)) | ((int64_t)(tile_w * tile_h - 1) << 32) | (int64_t)0x7f800000,
+                        (flags & MTGS_BIN3_STATUS) ? totals + 1 : nullptr, cap_vis, cap_M};
     bin3_tiles_count_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,
                                                                             cap_M, w.bins, w.done_tiles, offsets, order, w.n_long);
     bin3_tiles_place_kernel<<<t_grid, T_THREADS, (size_t)n_bins * 4, st>>>(w.row_start + n_rows, cap_M, w.items, tile_w, n_bins,

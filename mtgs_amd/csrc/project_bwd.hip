@@ -7,6 +7,7 @@
 // Roofline: HBM for the dense part (radii read, 44 B of gradients written per Gaussian, zeros for the
 // invisible ones) + ~1500 flops per VISIBLE Gaussian.
 #include "project_common.hpp"
+#include "raster_rec.hpp"
 
 namespace {
 
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     const float *__restrict__ v_means2d, const float *__restrict__ v_depths, const float *__restrict__ v_conics,
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff, const ProjGradStrides gs,
     float *__restrict__ ws, float *__restrict__ v_viewmats, const int64_t *__restrict__ n_vis_dev,
-    const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows, float *raw_rows, int64_t raw_stride) {
+    const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows, float *raw_rows, int64_t raw_stride,
+    const float *__restrict__ recs /* nullable: mtgs_front_fwd's records, indexed like the rows */) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
@@ -362,8 +364,17 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
                     nz = a4.x != 0.f || a4.y != 0.f || a4.z != 0.f || a4.w != 0.f || b4.x != 0.f || b4.y != 0.f || b4.z != 0.f || b4.w != 0.f;
                     if (nz) {
                         const int64_t n = vis_ids[r];
-                        const float o_eff = compensations ? opacities[n] * compensations[n] : opacities[n];
-                        const RowGrads rg = rows_to_gradients(raw_rows + r * raw_stride, conics[n * 3], conics[n * 3 + 1], conics[n * 3 + 2], o_eff);
+                        float o_eff, ca, cb, cc;
+                        if (recs) {      // the forward's 64-byte record of this Gaussian (raster_rec.hpp) holds the conic and the blended
+                            //                  opacity: one contiguous read instead of gathers from conics / opacities / compensations
+                            const float4 g0 = *reinterpret_cast<const float4 *>(recs + r * REC_FLOATS);
+                            const float2 g1 = *reinterpret_cast<const float2 *>(recs + r * REC_FLOATS + 4);
+                            ca = g0.z; cb = g0.w; cc = g1.x; o_eff = g1.y;
+                        } else {
+                            o_eff = compensations ? opacities[n] * compensations[n] : opacities[n];
+                            ca = conics[n * 3]; cb = conics[n * 3 + 1]; cc = conics[n * 3 + 2];
+                        }
+                        const RowGrads rg = rows_to_gradients(raw_rows + r * raw_stride, ca, cb, cc, o_eff);
                         ri.v_xy = rg.v_xy;
                         ri.v_conic[0] = rg.v_conic[0]; ri.v_conic[1] = rg.v_conic[1]; ri.v_conic[2] = rg.v_conic[2];
                     }
@@ -409,18 +420,24 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
             const RowIn ri = s_in[src];
             const int64_t n = vis_ids[r];
             float m[3], sc[3], am[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f}, ao = 0.f;
-            m[0] = means[n * 3]; m[1] = means[n * 3 + 1]; m[2] = means[n * 3 + 2];
-            const float4 q = reinterpret_cast<const float4 *>(quats)[n];
-            sc[0] = scales[n * 3]; sc[1] = scales[n * 3 + 1]; sc[2] = scales[n * 3 + 2];
+            float4 q;
             PairIn in;
-            in.conic[0] = conics[n * 3]; in.conic[1] = conics[n * 3 + 1]; in.conic[2] = conics[n * 3 + 2];
+            in.has_comp = compensations != nullptr; in.has_vcomp = v_compensations != nullptr; in.has_opac = v_opac_eff != nullptr;
+            m[0] = means[n * 3]; m[1] = means[n * 3 + 1]; m[2] = means[n * 3 + 2];
+            q = reinterpret_cast<const float4 *>(quats)[n];
+            sc[0] = scales[n * 3]; sc[1] = scales[n * 3 + 1]; sc[2] = scales[n * 3 + 2];
+            if (recs) {
+                const float4 g0 = *reinterpret_cast<const float4 *>(recs + r * REC_FLOATS);
+                in.conic[0] = g0.z; in.conic[1] = g0.w; in.conic[2] = recs[r * REC_FLOATS + 4];
+            } else {
+                in.conic[0] = conics[n * 3]; in.conic[1] = conics[n * 3 + 1]; in.conic[2] = conics[n * 3 + 2];
+            }
+            in.comp = in.has_comp ? compensations[n] : 1.f;
+            in.opac = in.has_opac ? opacities[n] : 0.f;
             in.v_mean2d = ri.v_xy;
             in.v_conic[0] = ri.v_conic[0]; in.v_conic[1] = ri.v_conic[1]; in.v_conic[2] = ri.v_conic[2];
             in.v_depth = ri.v_depth;
-            in.has_comp = compensations != nullptr; in.has_vcomp = v_compensations != nullptr; in.has_opac = v_opac_eff != nullptr;
-            in.comp = in.has_comp ? compensations[n] : 1.f;
             in.v_comp = ri.v_comp;
-            in.opac = in.has_opac ? opacities[n] : 0.f;
             in.v_opac_eff = ri.v_opac_eff;
             project_vjp_pair(m, q, sc, cam, W, H, eps2d, in, am, aq, as, ao, vRt);
             if (x_quat_rows) {   // quaternion gradients that reached the Gaussian beside the projection (camera-space normals)
@@ -605,7 +622,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
                                 float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
                                 const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
-                                void *stream) {
+                                const float *recs, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -647,6 +664,8 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
     MTGS_REQUIRE(!raw_rows || (vis_ids && vis_ws && grad_row_index && C == 1 && opacities && rs[0] >= 8 &&
                                (reinterpret_cast<uintptr_t>(raw_rows) & 15) == 0 && (rs[0] & 3) == 0),
                  MTGS_EINVAL, "mtgs_project_bwd: raw_rows needs the compact path, opacities and 16-byte aligned rows of >= 8 floats");
+    MTGS_REQUIRE(!recs || (vis_ids && vis_ws && grad_row_index && C == 1 && (reinterpret_cast<uintptr_t>(recs) & 15) == 0), MTGS_EINVAL,
+                 "mtgs_project_bwd: recs needs the compact path (vis_ids, vis_ws, grad_row_index, C == 1), 16-byte aligned");
     if (vis_ids && vis_ws && grad_row_index && C == 1) {
         // compact path: grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank)
         MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
@@ -655,7 +674,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
             project_bwd_vis_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
                 v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows,
-                raw_rows, rs[0]);
+                raw_rows, rs[0], recs);
         }
         if (!rows_only) project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
             N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);

@@ -143,7 +143,7 @@ class _FullyFusedProjection(torch.autograd.Function):
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
-             None, 0, None, None, None, None, None, stream_of(means))
+             None, 0, None, None, None, None, None, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -635,7 +635,8 @@ class _FusedRasterization(torch.autograd.Function):
             # ---- packed records
             key = (Cn, N, width, height)
             front_ws, front_bytes = _ws("mtgs_front_workspace_bytes", total, dev)
-            totals = torch.empty(1, dtype=torch.int64, device=dev)
+            # (graph mode: {packed, n_vis, M, overflow} -- words 1..3 are written by the binning, MTGS_BIN3_STATUS)
+            totals = torch.empty(4 if _graph.caps is not None else 1, dtype=torch.int64, device=dev)
             vis_rank = torch.empty(total, dtype=torch.int32, device=dev)
             offsets_buf = torch.empty(Cn * th * tw + 1, dtype=torch.int32, device=dev)
             order = torch.empty(Cn * th * tw, dtype=torch.int32, device=dev)
@@ -651,9 +652,10 @@ class _FusedRasterization(torch.autograd.Function):
             touch_first = cs is not None and bool(cs.touch_first)
             # tile lists of this frame (thread-local mode, read once): gsplat's by default; mtgs_bin3_build flags: 1 = tight lists,
             # 2 = sentinel-fill the tail [n_listed, M) of flatten_ids / isect_ids (tight lists, tensors sliced to gsplat's M),
-            # 4 = sentinel-fill up to the capacity (graph mode: the tensors are capacity-sized in both list modes)
+            # 4 = sentinel-fill up to the capacity (graph mode: the tensors are capacity-sized in both list modes), 16 = the frame's
+            # counts and its overflow flag as device words behind `totals` (graph mode)
             tight = lists_are_tight()
-            list_flags = (1 if tight else 0) | (4 if graph_caps is not None else (2 if tight else 0))
+            list_flags = (1 if tight else 0) | (4 | 16 if graph_caps is not None else (2 if tight else 0))
 
             def colours(b, flags):   # colours of the visible Gaussians, straight into their records
                 cap_vis = b["cap_vis"]
@@ -906,7 +908,7 @@ class _FusedRasterization(torch.autograd.Function):
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
              ptr(totals) if ctx.graph else None, ptr(q_rows),
              ptr(dir_rows) if (cs is not None and cs.autograd and n_vis > 0) else None,      # (differentiable view directions: dirs = means - camera position)
-             ptr(G) if raw else None, st)
+             ptr(G) if raw else None, ptr(recs) if (raw and Cn == 1) else None, st)
         d_coeffs = d_campos = None
         if cs is not None and cs.autograd:
             if ctx.graph:
@@ -956,10 +958,9 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
             "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": offsets}
     if getattr(offsets, "_mtgs_n_listed", None) is not None:
         meta["n_listed"] = offsets._mtgs_n_listed    # int32 device scalar: valid prefix of isect_ids / flatten_ids (tight lists)
-    if _graph.caps is not None:   # graph mode: the counts live on the device (see graph_mode)
-        n_v, n_m = totals[0] >> 32, totals[0] & 0xFFFFFFFF
-        meta.update({"n_visible": n_v, "n_intersections": n_m,
-                     "overflow": (n_v > min(_graph.caps[0], radii.numel())) | (n_m > _graph.caps[1])})
+    if _graph.caps is not None and totals.numel() == 4:   # graph mode: the counts live on the device (see graph_mode) -- views of words the binning wrote,
+        # no launch (five tiny torch kernels unpacked totals[0] here until round 5)
+        meta.update({"n_visible": totals[1], "n_intersections": totals[2], "overflow": totals[3:4].view(torch.bool)[0]})
     return render, alphas, meta
 
 
