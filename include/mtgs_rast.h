@@ -79,6 +79,14 @@ int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, const float *co
 int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
                 const uint8_t *masks, const float *v_colors, float *v_coeffs, float *v_dirs,
                 void *stream);
+/* The same v_coeffs for a cotangent that is zero for most Gaussians (the colours feed the rasterizer: only composited Gaussians
+ * have one) -- v_coeffs[n,K,3] must be ZERO on entry (mtgs_fill_zero, which a caller can overlap with other work: it depends on
+ * nothing -- mtgs_blend_bwd_packed(also_zero) writes it beside its own work); the call reads v_colors and writes the rows of the Gaussians whose cotangent is non-zero (and whose mask is set).
+ * Same values as mtgs_sh_bwd (a zero cotangent gives a zero row there too).  No v_dirs. */
+int mtgs_sh_bwd_rows(int64_t n, int K, int degree, const float *dirs, const uint8_t *masks, const float *v_colors,
+                     float *v_coeffs, void *stream);
+/* bytes of zeros at p (4-byte aligned, a whole number of words), stream-ordered: 16-byte stores, the chip's fastest pure write. */
+int mtgs_fill_zero(void *p, size_t bytes, void *stream);
 
 /* ---- projection: gsplat fully_fused_projection_fwd / _bwd (pinhole, packed=False) -------------
  * means[N,3] quats[N,4] (wxyz, any norm) scales[N,3] viewmats[C,4,4] (world->cam) Ks[C,3,3].
@@ -382,7 +390,12 @@ int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *recs, const
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, const float *alphas, const int32_t *last_ids,
                           const float *render, const float *v_render, const float *v_alphas, float *grad_rows,
-                          int64_t row_stride, int absgrad, const int32_t *tile_order, void *stream);
+                          int64_t row_stride, int absgrad, const int32_t *tile_order, void *also_zero, size_t also_zero_bytes,
+                          void *stream);
+/* also_zero (nullable; hot ABI v5): a 16-byte aligned region of whole 16-byte words that the kernel CLEARS for the caller while it
+ * runs -- it is VALU-bound and leaves HBM ~85 % idle; every wave writes one slice of zeros when its tile is done.  The Python layer
+ * passes the dL/dcoeffs buffers of the spherical_harmonics() backwards that follow in the same backward pass (384 MB at the headline
+ * workload, 94 % of it zeros: mtgs_sh_bwd_rows then writes the other rows). */
 
 /* ---- view-parallel data parallelism: sparse, factored gradient exchange (mtgs_amd/csrc/dp.hip) ------
  * No gsplat counterpart.  Rows are 16 floats: v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, spare,

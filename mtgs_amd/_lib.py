@@ -30,6 +30,8 @@ _i64p = C.POINTER(C.c_int64)  # HOST array (row strides), nullable
 _SIGNATURES = {
     "mtgs_sh_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "mtgs_sh_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_sh_bwd_rows": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_fill_zero": [_vp, _sz, _vp],
     "mtgs_project_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
@@ -63,7 +65,7 @@ _SIGNATURES = {
     "mtgs_blend_fwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_blend_touch_packed": [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_blend_bwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _i64, _i32, _vp, _vp],
+                              _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp],
     "mtgs_isect_offsets": [_i64, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_dp_pack": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -542,6 +542,17 @@ __global__ __launch_bounds__(256 / PPL) void blend_touch_kernel(int C, const flo
 struct GradRowBytes { uint32_t means2d, means2d_abs, conics, colors, depths, opacities; };
 
 // Gradient components per Gaussian, in reduction order: xy(2) |xy|(2) conic(3) opacity(1) colour(D)
+// A region the compositing BACKWARD clears for the caller while it runs (mtgs_blend_bwd_packed(also_zero)): the kernel is
+// VALU-bound and leaves HBM ~85 % idle, so every wave writes one slice of zeros when its tile is done -- the tiles finish at very
+// different times, which spreads the stores over the kernel's duration.  (The SH backward's dL/dcoeffs, 384 MB of which 94 % are
+// zeros at the headline workload: written here it costs the compositing ~15 us, on its own 58 us; a fill on a second stream
+// beside the kernel cost more -- queue switches inside a captured graph, and a burst that starved the kernel's own loads.)
+struct ZeroFill {
+    uint4 *p;
+    unsigned long long n16;   // 16-byte words
+    uint32_t per_wave;        // 16-byte words per wave (n16 <= per_wave * waves of the launch)
+};
+
 template <int D>
 struct GradLayout {
     static constexpr int NV = 8 + D;
@@ -564,11 +575,17 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
     const float *__restrict__ v_render, const float *__restrict__ v_alphas,
     float *__restrict__ v_means2d, float *__restrict__ v_means2d_abs, float *__restrict__ v_conics,
     float *__restrict__ v_colors, float *__restrict__ v_depths, float *__restrict__ v_opacities,
-    const GradRowBytes gs, const int32_t *__restrict__ row_index, const int32_t *__restrict__ order) {
+    const GradRowBytes gs, const int32_t *__restrict__ row_index, const int32_t *__restrict__ order, const ZeroFill zf) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     constexpr bool CULL = true;
     constexpr int CAND = NT == 64 ? 128 : 256, NRD = CAND / NT;
     constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
+    auto zero_slice = [&]() {      // this wave's slice of the caller's region (see ZeroFill)
+        if (zf.p == nullptr) return;
+        const unsigned long long w0 = ((unsigned long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * zf.per_wave;
+        for (uint32_t i = threadIdx.x & 63; i < zf.per_wave; i += 64)
+            if (w0 + i < zf.n16) zf.p[w0 + i] = make_uint4(0u, 0u, 0u, 0u);
+    };
     __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
     __shared__ int32_t s_id[CAND];
     __shared__ int32_t s_max[NT / 64];
@@ -577,7 +594,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
     const int64_t tile = block_to_tile(order);
     const int64_t start = offsets[tile];
     const int64_t end = (!PK && tile == total_tiles - 1) ? M : (int64_t)offsets[tile + 1];
-    if (end <= start) return;
+    if (end <= start) { zero_slice(); return; }
     const int cam = (int)(tile / n_tiles);
     const int t_in = (int)(tile - (int64_t)cam * n_tiles);
     const int ty = t_in / tw, tx = t_in - ty * tw;
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
         for (int w = 0; w < NT / 64; ++w) wmax = max(wmax, s_max[w]);
     }
     const int64_t top = wmax;  // sorted index of the last Gaussian any pixel of the tile used
-    if (top < start) return;
+    if (top < start) { zero_slice(); return; }
 
     // After the transposed reduction component jr = 4*col + row lives in row `row` of register `col`.
     // One wave (or two) per tile: lane 16*row + col issues the atomic for its component right away.
@@ -832,6 +849,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
             }
         }
     }
+    zero_slice();
 }
 
 template <int D, int PPL, bool PK = false>
@@ -855,13 +873,18 @@ int launch_bwd(int C, const float *recs, const float *means2d, const float *coni
                const float *alphas, const int32_t *last_ids, const float *render, const float *v_render,
                const float *v_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics, float *v_colors,
                float *v_depths, float *v_opacities, const GradRowBytes gs, const int32_t *row_index, const int32_t *order,
-               hipStream_t st) {
+               hipStream_t st, void *also_zero = nullptr, size_t also_zero_bytes = 0) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
+    ZeroFill zf{nullptr, 0ull, 0u};
+    if (also_zero && also_zero_bytes) {
+        const unsigned long long n16 = also_zero_bytes / 16, waves = (unsigned long long)grid * (256 / PPL / 64);
+        zf = ZeroFill{(uint4 *)also_zero, n16, (uint32_t)((n16 + waves - 1) / waves)};
+    }
     blend_bwd_kernel<D, PPL, PK><<<grid, 256 / PPL, 0, st>>>(
         C, recs, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
         alphas, last_ids, render, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_depths,
-        v_opacities, gs, row_index, order);
+        v_opacities, gs, row_index, order, zf);
     return 0;
 }
 
@@ -1078,8 +1101,11 @@ extern "C" int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *
                                      const int32_t *offsets, const int32_t *rank_ids, const float *alphas,
                                      const int32_t *last_ids, const float *render, const float *v_render,
                                      const float *v_alphas, float *grad_rows, int64_t row_stride, int absgrad,
-                                     const int32_t *tile_order, void *stream) {
+                                     const int32_t *tile_order, void *also_zero, size_t also_zero_bytes, void *stream) {
     MTGS_REQUIRE(C >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_bwd_packed: bad sizes");
+    MTGS_REQUIRE(!also_zero || ((reinterpret_cast<uintptr_t>(also_zero) | also_zero_bytes) & 15) == 0, MTGS_EINVAL,
+                 "mtgs_blend_bwd_packed: also_zero must be a 16-byte aligned region of whole 16-byte words");
+    MTGS_REQUIRE(also_zero_bytes / 16 < ((size_t)1 << 32) * 64, MTGS_EINVAL, "mtgs_blend_bwd_packed: also_zero too large");
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
                  "mtgs_blend_bwd_packed: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
     const int DT = D + (with_depth ? 1 : 0);
@@ -1088,7 +1114,7 @@ extern "C" int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *
     MTGS_REQUIRE(!ed_normalize || (with_depth && render), MTGS_EINVAL, "mtgs_blend_bwd_packed: ed_normalize needs depth and render");
     MTGS_REQUIRE(row_stride >= 8 + DT && row_stride < ((int64_t)1 << 28), MTGS_EINVAL, "mtgs_blend_bwd_packed: row_stride=%lld",
                  (long long)row_stride);
-    if (C == 0) return MTGS_OK;
+    if (C == 0) return also_zero ? mtgs_zero_async(also_zero, also_zero_bytes, (hipStream_t)stream) : MTGS_OK;
     MTGS_REQUIRE(recs && offsets && rank_ids && alphas && last_ids && v_render && v_alphas && grad_rows, MTGS_EINVAL,
                  "mtgs_blend_bwd_packed: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -1099,7 +1125,7 @@ extern "C" int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *
     MTGS_DISPATCH_PK(launch_bwd, C, recs, nullptr, nullptr, nullptr, nullptr, backgrounds, nullptr, D, ed_normalize, width, height,
                      tile_w, tile_h, offsets, rank_ids, (int64_t)-1, alphas, last_ids, render, v_render, v_alphas, grad_rows,
                      absgrad ? grad_rows + 2 : nullptr, grad_rows + 4, grad_rows + 8, grad_rows + 8 + D, grad_rows + 7, gs, nullptr,
-                     tile_order, st);
+                     tile_order, st, also_zero, also_zero_bytes);
     MTGS_CHECK_LAUNCH("mtgs_blend_bwd_packed");
     return MTGS_OK;
 }

@@ -336,6 +336,44 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
     }
 }
 
+
+// ---- sparse backward: only the rows whose cotangent is non-zero --------------------------------------------------------------
+// The colours feed the rasterizer, so dL/dcolour is zero for every Gaussian nothing was composited from -- ~94 % of them at the
+// headline workload -- and 12 K bytes of dL/dcoeffs per Gaussian are then zeros, which need neither the directions nor a kernel
+// that waits for its loads before it stores (sh_bwd_kernel: 5.3 TB/s against 6.8 TB/s of a pure fill).  With v_coeffs ZERO ALREADY
+// (mtgs_fill_zero -- the Python layer issues it on a second stream while the compute-bound compositing backward runs,
+// mtgs_amd/wrapper.py::_prefill) this kernel reads the 12-byte cotangents and writes the 12 K-byte rows of the others: one thread
+// per Gaussian, its row as 16-byte stores (few lanes of a wave are active, the pieces of a line merge in L2).  Cost grows
+// linearly with the density of the cotangent; at 100 % it is the partial-line pattern that measured 195 us at 2M rows.
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_bwd_rows_kernel(int64_t n, int K, const float *__restrict__ dirs, const uint8_t *__restrict__ masks,
+                                                          const float *__restrict__ v_colors, float *__restrict__ v_coeffs) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const float v[3] = {v_colors[g * 3], v_colors[g * 3 + 1], v_colors[g * 3 + 2]};
+    if ((v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) || (masks && !masks[g])) return;
+    float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+    const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
+    x *= inorm; y *= inorm; z *= inorm;
+    float b[NB];
+    sh_bases_dev(DEG, x, y, z, b);
+    const int K3 = K * 3;
+    float *dst = v_coeffs + g * K3;
+    if (K3 % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < (NB3 + 3) / 4; ++q) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = 4 * q + i; o[i] = e < NB3 ? b[e / 3] * v[e % 3] : 0.f; }
+            reinterpret_cast<float4 *>(dst)[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NB3; ++e) dst[e] = b[e / 3] * v[e % 3];
+    }
+}
+
 }  // namespace
 
 extern "C" int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
@@ -390,5 +428,28 @@ extern "C" int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, cons
     }
 #undef MTGS_SH_BWD
     MTGS_CHECK_LAUNCH("mtgs_sh_bwd");
+    return MTGS_OK;
+}
+
+extern "C" int mtgs_sh_bwd_rows(int64_t n, int K, int degree, const float *dirs, const uint8_t *masks, const float *v_colors,
+                                float *v_coeffs, void *stream) {
+    MTGS_REQUIRE(n >= 0 && K > 0, MTGS_EINVAL, "mtgs_sh_bwd_rows: bad sizes n=%lld K=%d", (long long)n, K);
+    MTGS_REQUIRE(degree >= 0 && degree <= MTGS_MAX_SH_DEGREE && (degree + 1) * (degree + 1) <= K, MTGS_EINVAL,
+                 "mtgs_sh_bwd_rows: degree %d needs (degree+1)^2 <= K=%d and degree <= 4", degree, K);
+    if (n == 0) return MTGS_OK;
+    MTGS_REQUIRE(dirs && v_colors && v_coeffs, MTGS_EINVAL, "mtgs_sh_bwd_rows: null pointer");
+    MTGS_REQUIRE((K * 3) % 4 != 0 || (reinterpret_cast<uintptr_t>(v_coeffs) & 15) == 0, MTGS_EINVAL, "mtgs_sh_bwd_rows: v_coeffs must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div64(n, 256);
+#define MTGS_SH_ROWS(DG) sh_bwd_rows_kernel<DG><<<grid, 256, 0, st>>>(n, K, dirs, masks, v_colors, v_coeffs)
+    switch (degree) {
+        case 0: MTGS_SH_ROWS(0); break;
+        case 1: MTGS_SH_ROWS(1); break;
+        case 2: MTGS_SH_ROWS(2); break;
+        case 3: MTGS_SH_ROWS(3); break;
+        default: MTGS_SH_ROWS(4); break;
+    }
+#undef MTGS_SH_ROWS
+    MTGS_CHECK_LAUNCH("mtgs_sh_bwd_rows");
     return MTGS_OK;
 }

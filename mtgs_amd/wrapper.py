@@ -15,6 +15,7 @@ import ctypes as C
 import os
 import threading
 import time
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -52,6 +53,59 @@ def _strided_rows(t: Optional[Tensor], width: int):
 
 
 # ------------------------------------------------------------------------------------- SH
+class _ZeroRequest:
+    """A [n, K, 3] buffer of zeros that a spherical_harmonics() backward will want (see _Prefill)."""
+    __slots__ = ("shape", "device", "buffer", "__weakref__")
+
+    def __init__(self, shape, device):
+        self.shape, self.device, self.buffer = tuple(shape), device, None
+
+
+class _Prefill:
+    """THE SH BACKWARD'S ZEROS, WRITTEN BY THE COMPOSITING BACKWARD (round 5).  dL/dcoeffs is [N, K, 3] -- 384 MB at the headline
+    workload -- of which the rows of the ~6 % composited Gaussians are non-zero; writing it is what the SH backward costs (81 us,
+    HBM-bound), and the zeros depend on nothing.  The compositing backward, two autograd nodes earlier in the same backward pass,
+    is VALU-bound and leaves HBM ~85 % idle for 0.3 ms.  So: a spherical_harmonics() forward whose coefficients need a gradient
+    leaves a request here; the next rasterization() backward on that device allocates the buffers (one allocation) and hands them
+    to mtgs_blend_bwd_packed(also_zero), whose waves clear a slice each when their tile is done; the SH backward then only writes
+    the non-zero rows (mtgs_sh_bwd_rows).  One stream, nothing to join, nothing special inside a graph capture.  A request nobody
+    serves -- spherical_harmonics() used without the rasterizer -- falls back to the one-kernel dense backward.  Process-wide
+    (autograd runs backward nodes on its own threads), weakly referenced (a graph that is never differentiated leaves nothing)."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.pending = weakref.WeakSet()
+        self.enabled = os.environ.get("MTGS_SH_PREFILL", "1") == "1"
+
+    def request(self, shape, device) -> Optional[_ZeroRequest]:
+        if not self.enabled:
+            return None
+        req = _ZeroRequest(shape, device)
+        with self.lock:
+            self.pending.add(req)
+        return req
+
+    def take(self, device):
+        """Called by a rasterization backward in front of its compositing kernel: (pointer, bytes) of ONE region holding the
+        buffers of every pending request of the device (16-byte aligned pieces), or (None, 0)."""
+        with self.lock:
+            mine = [r for r in self.pending if r.device == device and r.buffer is None]
+            for r in mine:
+                self.pending.discard(r)
+        if not mine:
+            return None, 0
+        sizes = [-(-int(torch.Size(r.shape).numel()) // 4) * 4 for r in mine]      # floats, padded to 16 bytes
+        region = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        at = 0
+        for r, n in zip(mine, sizes):
+            r.buffer = region[at:at + int(torch.Size(r.shape).numel())].view(r.shape)
+            at += n
+        return region.data_ptr(), region.numel() * 4
+
+
+_prefill = _Prefill()
+
+
 class _SphericalHarmonics(torch.autograd.Function):
     @staticmethod
     def forward(ctx, degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor]):
@@ -65,6 +119,9 @@ class _SphericalHarmonics(torch.autograd.Function):
              stream_of(dirs_c))
         ctx.save_for_backward(dirs_c, coeffs_c, masks_c)
         ctx.degree, ctx.K, ctx.n = degree, K, n
+        # (see _Prefill: zeros for dL/dcoeffs, filled while the rasterizer's backward runs)
+        ctx.zeros = _prefill.request(coeffs_c.shape, coeffs_c.device) if (ctx.needs_input_grad[2] and not ctx.needs_input_grad[1]
+                                                                          and n * K * 12 >= (1 << 22)) else None
         return colors
 
     @staticmethod
@@ -72,6 +129,11 @@ class _SphericalHarmonics(torch.autograd.Function):
         dirs, coeffs, masks = ctx.saved_tensors
         v_colors = _f32c(v_colors)
         need_dirs = ctx.needs_input_grad[1]
+        req = ctx.zeros
+        if req is not None and req.buffer is not None and not need_dirs:
+            v_coeffs, req.buffer = req.buffer, None
+            call("mtgs_sh_bwd_rows", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(masks), ptr(v_colors), ptr(v_coeffs), stream_of(dirs))
+            return None, None, v_coeffs, None
         v_coeffs = torch.empty_like(coeffs)
         v_dirs = torch.empty_like(dirs) if need_dirs else None
         call("mtgs_sh_bwd", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(coeffs), ptr(masks),
@@ -803,9 +865,11 @@ class _FusedRasterization(torch.autograd.Function):
             v_render, v_alphas = _f32c(v_render), _f32c(v_alphas)
             if ctx.packed:
                 if rank_ids.numel() > 0:
+                    # (the zeros the spherical_harmonics() backwards of this pass want are written by this kernel: _Prefill)
+                    z_ptr, z_bytes = _prefill.take(dev)
                     call("mtgs_blend_bwd_packed", Cn, DC, int(with_depth), ptr(recs), ptr(bg), int(ed), width, height, tw, th,
                          ptr(offsets), ptr(rank_ids), ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas),
-                         ptr(G), RS, int(ctx.absgrad), ptr(order), st)
+                         ptr(G), RS, int(ctx.absgrad), ptr(order), z_ptr, z_bytes, st)
             else:
                 call("mtgs_blend_bwd", Cn, N, DC, ptr(means2d), ptr(conics), ptr(col), ptr(opac_eff), ptr(bg), ptr(dep), int(ed),
                      width, height, tile_size, tw, th, ptr(offsets), ptr(flatten_ids), flatten_ids.numel(), ptr(alphas),

@@ -78,6 +78,44 @@ template <int BLOCK, int WORK, int RS> __global__ __launch_bounds__(BLOCK) void 
         dst[i4] = *(const f4 *)(lds + g * RS + q * 4);
     }
 }
+// sparse cotangents (the real frame: ~6 % of the Gaussians carry a gradient): only those rows are computed and staged; the block's
+// coalesced write takes zeros from registers for the others (flag per row in LDS)
+template <int BLOCK, int WORK, int RS> __global__ __launch_bounds__(BLOCK) void w_shsparse(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ p, size_t rows) {
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * RS];
+    __shared__ unsigned char s_nz[BLOCK];
+    const size_t g0 = (size_t)blockIdx.x * BLOCK;
+    const int cnt = (int)(rows - g0 < BLOCK ? rows - g0 : BLOCK), tid = threadIdx.x;
+    bool nz = false;
+    if (tid < cnt) {
+        const size_t g = g0 + tid;
+        float v[3] = {b[g * 3], b[g * 3 + 1], b[g * 3 + 2]};
+        nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f;
+        if (nz) {
+            float x = a[g * 3], y = a[g * 3 + 1], z = a[g * 3 + 2];
+            float acc = x;
+#pragma unroll
+            for (int w = 0; w < WORK; ++w) acc = acc * y + z;
+            f4 *row = (f4 *)(lds + tid * RS);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                f4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int e = 4 * q + i; o[i] = (acc + (float)(e / 3)) * v[e % 3]; }
+                row[q] = o;
+            }
+        }
+    }
+    s_nz[tid] = nz;
+    __syncthreads();
+    f4 *dst = (f4 *)(p + g0 * 48);
+    const int n4 = cnt * 12;
+    for (int i4 = tid; i4 < n4; i4 += BLOCK) {
+        const int g = i4 / 12, q = i4 % 12;
+        f4 o = {0.f, 0.f, 0.f, 0.f};
+        if (s_nz[g]) o = *(const f4 *)(lds + g * RS + q * 4);
+        dst[i4] = o;
+    }
+}
 template <class F> void timeit(const char *name, size_t bytes, F &&launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
@@ -112,6 +150,15 @@ int main() {
     timeit("sh_bwd-like b128 128/blk rs52 w40", tot, [&] { w_shlike128<128, 40, 52><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
     timeit("sh_bwd-like b128 256/blk rs52 w40", tot, [&] { w_shlike128<256, 40, 52><<<(unsigned)((rows + 255) / 256), 256>>>(a, b, (float *)p, rows); });
     timeit("sh_bwd-like b128 128/blk rs48 w40", tot, [&] { w_shlike128<128, 40, 48><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    {   // 6 % of the rows carry a cotangent
+        float *hb = (float *)malloc(rows * 12); for (size_t r = 0; r < rows; ++r) { const bool on = (r * 2654435761u) % 100 < 6; hb[3 * r] = hb[3 * r + 1] = hb[3 * r + 2] = on ? 1.f : 0.f; }
+        hipMemcpy(b, hb, rows * 12, hipMemcpyHostToDevice); free(hb);
+    }
+    timeit("sh_bwd-like 128/blk, 6% rows", tot, [&] { w_shlike128<128, 40, 52><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sparse-staged 128/blk, 6% rows", tot, [&] { w_shsparse<128, 40, 52><<<(unsigned)((rows + 127) / 128), 128>>>(a, b, (float *)p, rows); });
+    timeit("sparse-staged 256/blk, 6% rows", tot, [&] { w_shsparse<256, 40, 52><<<(unsigned)((rows + 255) / 256), 256>>>(a, b, (float *)p, rows); });
+    timeit("sparse-staged 64/blk, 6% rows", tot, [&] { w_shsparse<64, 40, 52><<<(unsigned)((rows + 63) / 64), 64>>>(a, b, (float *)p, rows); });
+    timeit("rows of 192 B again", bytes, [&] { w_rows192<0><<<(unsigned)((rows + 255) / 256), 256>>>((float *)p, rows); });
     timeit("sh_bwd-like 64/block, work 40", tot, [&] { w_shlike<64, 40><<<(unsigned)((rows + 63) / 64), 64>>>(a, b, (float *)p, rows); });
     return 0;
 }
