@@ -345,32 +345,70 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
 // mtgs_amd/wrapper.py::_prefill) this kernel reads the 12-byte cotangents and writes the 12 K-byte rows of the others: one thread
 // per Gaussian, its row as 16-byte stores (few lanes of a wave are active, the pieces of a line merge in L2).  Cost grows
 // linearly with the density of the cotangent; at 100 % it is the partial-line pattern that measured 195 us at 2M rows.
+// One thread per Gaussian finds the rows; a row is then WRITTEN by K3/4 lanes, one 16-byte piece each, so that one store
+// instruction of the wave carries 64 / (K3/4) whole rows (5 at K = 16): the products go through a per-wave LDS buffer (in-order DS
+// instructions of one wave: no barrier).  With each lane storing its own row, a wave issued 12 store instructions for ~4 active
+// lanes -- 20 us of the 36 us this kernel took on 2M rows, 6 % of them with a cotangent (cold; scripts/dev/shrows_bench.py).
 template <int DEG>
 __global__ __launch_bounds__(256) void sh_bwd_rows_kernel(int64_t n, int K, const float *__restrict__ dirs, const uint8_t *__restrict__ masks,
                                                           const float *__restrict__ v_colors, float *__restrict__ v_coeffs) {
     constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n) return;
-    const float v[3] = {v_colors[g * 3], v_colors[g * 3 + 1], v_colors[g * 3 + 2]};
-    if ((v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) || (masks && !masks[g])) return;
-    float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
-    const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
-    x *= inorm; y *= inorm; z *= inorm;
-    float b[NB];
-    sh_bases_dev(DEG, x, y, z, b);
+    __shared__ __attribute__((aligned(16))) float s_p[4][256];
+    __shared__ int s_row[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * 256 + wave * 64;      // first Gaussian of the wave
+    const int64_t g = base + lane;
+    float v[3] = {0.f, 0.f, 0.f};
+    bool nz = false;
+    if (g < n) {
+        v[0] = v_colors[g * 3]; v[1] = v_colors[g * 3 + 1]; v[2] = v_colors[g * 3 + 2];
+        nz = !(v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) && !(masks && !masks[g]);
+    }
+    unsigned long long m = __ballot(nz);
+    if (m == 0ull) return;
     const int K3 = K * 3;
-    float *dst = v_coeffs + g * K3;
-    if (K3 % 4 == 0) {
+    const bool coop = K3 % 4 == 0 && K3 <= 256;
+    const int pieces = coop ? K3 / 4 : 1, rows_per = coop ? 64 / pieces : 0;
+    float b[NB];
+    if (nz) {
+        float x = dirs[g * 3], y = dirs[g * 3 + 1], z = dirs[g * 3 + 2];
+        const float inorm = 1.0f / sqrtf((x * x + y * y) + z * z);
+        x *= inorm; y *= inorm; z *= inorm;
+        sh_bases_dev(DEG, x, y, z, b);
+    }
+    if (!coop) {
+        if (nz) {
+            float *dst = v_coeffs + g * K3;
 #pragma unroll
-        for (int q = 0; q < (NB3 + 3) / 4; ++q) {
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const int e = 4 * q + i; o[i] = e < NB3 ? b[e / 3] * v[e % 3] : 0.f; }
-            reinterpret_cast<float4 *>(dst)[q] = make_float4(o[0], o[1], o[2], o[3]);
+            for (int e = 0; e < NB3; ++e) dst[e] = b[e / 3] * v[e % 3];
         }
-    } else {
+        return;
+    }
+    int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // rows with work in front
+    int left = __popcll(m);
+    while (left > 0) {
+        const int cnt = min(left, rows_per);
+        if (nz && rank >= 0 && rank < cnt) {
+            float *row = &s_p[wave][rank * K3];
 #pragma unroll
-        for (int e = 0; e < NB3; ++e) dst[e] = b[e / 3] * v[e % 3];
+            for (int q = 0; q < (NB3 + 3) / 4; ++q) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int e = 4 * q + i; o[i] = e < NB3 ? b[e / 3] * v[e % 3] : 0.f; }
+                *reinterpret_cast<float4 *>(row + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            for (int q = (NB3 + 3) / 4; q < pieces; ++q) *reinterpret_cast<float4 *>(row + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_row[wave][rank] = lane;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int slot = lane / pieces, piece = lane - slot * pieces;
+        if (slot < cnt) {
+            const int64_t gr = base + s_row[wave][slot];
+            reinterpret_cast<float4 *>(v_coeffs + gr * K3)[piece] = *reinterpret_cast<const float4 *>(&s_p[wave][slot * K3 + 4 * piece]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        rank -= cnt;
+        left -= cnt;
     }
 }
 
