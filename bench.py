@@ -59,6 +59,7 @@ ENTRY_POINTS = {
     "mtgs_project_bwd": ["project_bwd_vis_kernel", "project_bwd_expand_kernel"],
     "mtgs_project_bwd_rows": ["project_bwd_rows_kernel"],
     "mtgs_sh_bwd": ["sh_bwd_kernel<3>"],
+    "mtgs_sh_bwd_rows": ["sh_bwd_rows_kernel<3>"],
     "mtgs_dp_reduce": ["dp_reduce_kernel"],
 }
 
@@ -659,6 +660,18 @@ def main():
     D = 4 if args.variant == "mtgs" else 3
     A = 1 if args.variant == "mtgs" else 0
     bytes_bwd = P * (4 * D + 12) + M_l * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A)
+    # ... plus, round 5, the zeros of dL/dcoeffs [N, 16, 3] that the kernel writes for the spherical_harmonics() backward behind it
+    # (mtgs_blend_bwd_packed(also_zero), mtgs_amd/wrapper.py::_Prefill): bytes the step has to write, moved into the kernel that
+    # leaves HBM idle; n_coeff_rows = the Gaussians whose coefficient gradient is non-zero (mtgs_sh_bwd_rows writes those rows)
+    from mtgs_amd import wrapper as _wr
+    sparse_dp = world > 1 and args.dp_exchange == "sparse" and args.variant == "mtgs"      # (its colours are detached: no SH autograd node)
+    sh_zeros_in_bwd = bool(args.variant == "mtgs" and _wr._prefill.enabled and not sparse_dp)
+    n_coeff_rows = 0
+    _cg = dev["coeffs"].grad if (args.variant == "mtgs" and "coeffs" in dev) else None
+    if _cg is not None:
+        n_coeff_rows = int((_cg.abs().amax(dim=(1, 2)) > 0).sum().item())
+    if sh_zeros_in_bwd:
+        bytes_bwd += args.n_gaussians * 12 * 16
     # whole-step algorithmic HBM bytes, SURVEY.md section 8(d): B_F + B_B (K = 16 SH bases when the step includes SH)
     N, T = args.n_gaussians, -(-args.width // 16) * -(-args.height // 16)
     Ksh = 16 if args.variant == "mtgs" else 0
@@ -674,6 +687,7 @@ def main():
     alg = {
         "sh_fwd_k16_kernel<3>": N * (12 + 12 * Ksh_ + 12),
         "sh_bwd_kernel<3>": N * (24 + 12 * Ksh_),
+        "sh_bwd_rows_kernel<3>": N * 12 + n_coeff_rows * (12 + 12 * Ksh_),      # cotangents in; direction in + row out where there is one
         "front_project_kernel": N * (40 + 4 + 40) + n_vis * 48,                  # (+ the chunk-local compact rows of the visible pairs)
         "front_compact_kernel": N * (4 + 4) + n_vis * (48 + 12 + 64 + 4 + 8),   # radii in, vis_rank out | staged row + colours in, record + id + key out
         "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
@@ -764,13 +778,16 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
                      "launches_timed": len(kernel_ms),
+                     # (round 5) of which the zeros of dL/dcoeffs [N,16,3] the kernel writes for the SH backward behind it
+                     "sh_gradient_zeros_in_this_launch": args.n_gaussians * 12 * 16 if sh_zeros_in_bwd else 0,
+                     "sh_coefficient_rows_with_gradient": n_coeff_rows,
                      # the dominant kernel priced on gsplat's intersection count M (the lists of the default call): the same
                      # unit as whole_step below and as SURVEY.md section 8(d)
                      "algorithmic_bytes_on_gsplat_lists": P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A),
                      "frac_on_gsplat_lists": round((P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A))
                                                    / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else 0.0,
                      "note": "avg_launch_ms: HIP events on the launch stream around every mtgs_blend_bwd_packed call of the K EAGER steps run "
-                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) with n_listed = the (tile, Gaussian) pairs "
+                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) [+ N*192: the zeros of the SH coefficient gradient, written by this kernel beside its own work since round 5 -- sh_gradient_zeros_in_this_launch] with n_listed = the (tile, Gaussian) pairs "
                              "of the timed steps' lists (config.n_listed; = gsplat's count config.n_intersections for the default call); "
                              "kernel is VALU bound, not HBM bound (DESIGN.md section 4); avg_launch_ms is measured in this run; traffic and "
                              "valu_busy_frac (SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8) come from the committed rocprofv3 "

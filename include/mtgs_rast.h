@@ -370,7 +370,9 @@ int mtgs_bin3_build(int C, int64_t N, int tile_size, int tile_w, int tile_h, int
 int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
                           int ed_normalize, int width, int height, int tile_w, int tile_h, const int32_t *offsets,
                           const int32_t *rank_ids, float *render, float *alphas, int32_t *last_ids,
-                          const int32_t *tile_order, void *stream);
+                          const int32_t *tile_order, void *also_zero, size_t also_zero_bytes, void *stream);
+/* also_zero: as for mtgs_blend_bwd_packed below (a training forward clears what its backward pass will want zeroed: the gradient
+ * rows of the compositing backward, the dL/dcoeffs of the spherical_harmonics() backwards). */
 /* mtgs_blend_touch_packed (ABI v24): the forward's per-pixel DECISIONS without its colours -- touched[cap_vis] (uint8, cleared by the
  * call) gets 1 for every visible Gaussian (rank) that the frame composites FROM, i.e. that has a non-zero weight at some pixel: same
  * staging, validity test, alpha / T expressions and termination as mtgs_blend_fwd_packed, reading the geometry half (32 bytes) of the

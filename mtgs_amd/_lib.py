@@ -62,7 +62,7 @@ _SIGNATURES = {
     "mtgs_bin3_workspace_bytes": [_i32, _i32, _i32, _i64, _i64, C.POINTER(_sz)],
     "mtgs_bin3_build": [_i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                         _vp, _sz, _vp],
-    "mtgs_blend_fwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_blend_fwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "mtgs_blend_touch_packed": [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_blend_bwd_packed": [_i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp],

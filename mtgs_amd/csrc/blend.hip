@@ -273,6 +273,33 @@ __device__ __forceinline__ float alpha_rounded(float opac, float e) {
 #ifndef MTGS_FWD_WAVES
 #define MTGS_FWD_WAVES 6
 #endif
+// A region a compositing kernel clears for the caller while it runs (mtgs_blend_{fwd,bwd}_packed(also_zero)): the kernels are
+// VALU-bound and leave HBM ~85 % idle, so every wave writes one slice of zeros when its tile is done -- the tiles finish at very
+// different times, which spreads the stores over the kernel's duration.  (The SH backward's dL/dcoeffs, 384 MB of which 94 % are
+// zeros at the headline workload: written here it costs the compositing ~15 us, on its own 58 us; a fill on a second stream
+// beside the kernel cost more -- queue switches inside a captured graph, and a burst that starved the kernel's own loads.)
+struct ZeroFill {
+    uint4 *p;
+    unsigned long long n16;   // 16-byte words
+    uint32_t per_wave;        // 16-byte words per wave (n16 <= per_wave * waves of the launch)
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_fill_slice(const ZeroFill &zf) {
+    if (zf.p == nullptr) return;
+    const unsigned long long w0 = ((unsigned long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * zf.per_wave;
+    for (uint32_t i = threadIdx.x & 63; i < zf.per_wave; i += 64)
+        if (w0 + i < zf.n16) zf.p[w0 + i] = make_uint4(0u, 0u, 0u, 0u);
+}
+inline ZeroFill make_zero_fill(void *also_zero, size_t also_zero_bytes, unsigned grid, int waves_per_block) {
+    ZeroFill zf{nullptr, 0ull, 0u};
+    if (also_zero && also_zero_bytes) {
+        const unsigned long long n16 = also_zero_bytes / 16, waves = (unsigned long long)grid * waves_per_block;
+        zf = ZeroFill{(uint4 *)also_zero, n16, (uint32_t)((n16 + waves - 1) / waves)};
+    }
+    return zf;
+}
+
 template <int D, int PPL, bool PK>
 __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 1) void blend_fwd_kernel(
     int C, const float *__restrict__ recs, const float *__restrict__ means2d, const float *__restrict__ conics,
@@ -280,7 +307,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
     int tw, int th, const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int64_t M,
     float *__restrict__ render, float *__restrict__ alphas, int32_t *__restrict__ last_ids,
-    const int32_t *__restrict__ order) {
+    const int32_t *__restrict__ order, const ZeroFill zf) {
     constexpr int NT = 256 / PPL, ROWS = NT / 16, REC = Rec<D>::N;
     constexpr bool CULL = true;
     constexpr int CAND = NT == 64 ? 128 : 256, NR = CAND / NT;
@@ -438,6 +465,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_FWD_WAVES : 
             }
         }
     }
+    zero_fill_slice<NT>(zf);      // (see ZeroFill)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,17 +570,6 @@ __global__ __launch_bounds__(256 / PPL) void blend_touch_kernel(int C, const flo
 struct GradRowBytes { uint32_t means2d, means2d_abs, conics, colors, depths, opacities; };
 
 // Gradient components per Gaussian, in reduction order: xy(2) |xy|(2) conic(3) opacity(1) colour(D)
-// A region the compositing BACKWARD clears for the caller while it runs (mtgs_blend_bwd_packed(also_zero)): the kernel is
-// VALU-bound and leaves HBM ~85 % idle, so every wave writes one slice of zeros when its tile is done -- the tiles finish at very
-// different times, which spreads the stores over the kernel's duration.  (The SH backward's dL/dcoeffs, 384 MB of which 94 % are
-// zeros at the headline workload: written here it costs the compositing ~15 us, on its own 58 us; a fill on a second stream
-// beside the kernel cost more -- queue switches inside a captured graph, and a burst that starved the kernel's own loads.)
-struct ZeroFill {
-    uint4 *p;
-    unsigned long long n16;   // 16-byte words
-    uint32_t per_wave;        // 16-byte words per wave (n16 <= per_wave * waves of the launch)
-};
-
 template <int D>
 struct GradLayout {
     static constexpr int NV = 8 + D;
@@ -580,12 +597,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 
     constexpr bool CULL = true;
     constexpr int CAND = NT == 64 ? 128 : 256, NRD = CAND / NT;
     constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
-    auto zero_slice = [&]() {      // this wave's slice of the caller's region (see ZeroFill)
-        if (zf.p == nullptr) return;
-        const unsigned long long w0 = ((unsigned long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * zf.per_wave;
-        for (uint32_t i = threadIdx.x & 63; i < zf.per_wave; i += 64)
-            if (w0 + i < zf.n16) zf.p[w0 + i] = make_uint4(0u, 0u, 0u, 0u);
-    };
+    auto zero_slice = [&]() { zero_fill_slice<NT>(zf); };      // this wave's slice of the caller's region (see ZeroFill)
     __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
     __shared__ int32_t s_id[CAND];
     __shared__ int32_t s_max[NT / 64];
@@ -857,12 +869,14 @@ int launch_fwd(int C, const float *recs, const float *means2d, const float *coni
                const float *opacities, const float *backgrounds, const float *depths, int DC, int ed, int W,
                int H, int tw, int th,
                const int32_t *offsets, const int32_t *flatten_ids, int64_t M, float *render,
-               float *alphas, int32_t *last_ids, const int32_t *order, hipStream_t st) {
+               float *alphas, int32_t *last_ids, const int32_t *order, hipStream_t st, void *also_zero = nullptr,
+               size_t also_zero_bytes = 0) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
     blend_fwd_kernel<D, PPL, PK><<<grid, 256 / PPL, 0, st>>>(C, recs, means2d, conics, colors, opacities,
                                                          backgrounds, depths, DC, ed, W, H, tw, th, offsets,
-                                                         flatten_ids, M, render, alphas, last_ids, order);
+                                                         flatten_ids, M, render, alphas, last_ids, order,
+                                                         make_zero_fill(also_zero, also_zero_bytes, grid, 256 / PPL / 64));
     return 0;
 }
 
@@ -876,11 +890,7 @@ int launch_bwd(int C, const float *recs, const float *means2d, const float *coni
                hipStream_t st, void *also_zero = nullptr, size_t also_zero_bytes = 0) {
     const int64_t total = (int64_t)C * tw * th;
     const unsigned grid = (unsigned)total;
-    ZeroFill zf{nullptr, 0ull, 0u};
-    if (also_zero && also_zero_bytes) {
-        const unsigned long long n16 = also_zero_bytes / 16, waves = (unsigned long long)grid * (256 / PPL / 64);
-        zf = ZeroFill{(uint4 *)also_zero, n16, (uint32_t)((n16 + waves - 1) / waves)};
-    }
+    const ZeroFill zf = make_zero_fill(also_zero, also_zero_bytes, grid, 256 / PPL / 64);
     blend_bwd_kernel<D, PPL, PK><<<grid, 256 / PPL, 0, st>>>(
         C, recs, means2d, conics, colors, opacities, backgrounds, depths, DC, ed, W, H, tw, th, offsets, flatten_ids, M,
         alphas, last_ids, render, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_depths,
@@ -1057,20 +1067,23 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
 extern "C" int mtgs_blend_fwd_packed(int C, int D, int with_depth, const float *recs, const float *backgrounds,
                                      int ed_normalize, int width, int height, int tile_w, int tile_h,
                                      const int32_t *offsets, const int32_t *rank_ids, float *render, float *alphas,
-                                     int32_t *last_ids, const int32_t *tile_order, void *stream) {
+                                     int32_t *last_ids, const int32_t *tile_order, void *also_zero, size_t also_zero_bytes,
+                                     void *stream) {
     MTGS_REQUIRE(C >= 0 && D >= 0 && width > 0 && height > 0, MTGS_EINVAL, "mtgs_blend_fwd_packed: bad sizes");
+    MTGS_REQUIRE(!also_zero || ((reinterpret_cast<uintptr_t>(also_zero) | also_zero_bytes) & 15) == 0, MTGS_EINVAL,
+                 "mtgs_blend_fwd_packed: also_zero must be a 16-byte aligned region of whole 16-byte words");
     MTGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16, MTGS_EINVAL,
                  "mtgs_blend_fwd_packed: tile grid %dx%d does not match image %dx%d", tile_w, tile_h, width, height);
     const int DT = D + (with_depth ? 1 : 0);
     MTGS_REQUIRE(DT >= 1 && DT <= REC_MAX_CHANNELS, MTGS_EUNSUPPORTED, "mtgs_blend_fwd_packed: %d blended channels (1..%d)", DT,
                  REC_MAX_CHANNELS);
     MTGS_REQUIRE(!ed_normalize || with_depth, MTGS_EINVAL, "mtgs_blend_fwd_packed: ed_normalize needs the depth channel");
-    if (C == 0) return MTGS_OK;
+    if (C == 0) return also_zero ? mtgs_zero_async(also_zero, also_zero_bytes, (hipStream_t)stream) : MTGS_OK;
     MTGS_REQUIRE(recs && offsets && rank_ids && render && alphas && last_ids, MTGS_EINVAL, "mtgs_blend_fwd_packed: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, false);
     MTGS_DISPATCH_PK(launch_fwd, C, recs, nullptr, nullptr, nullptr, nullptr, backgrounds, nullptr, D, ed_normalize, width, height,
-                     tile_w, tile_h, offsets, rank_ids, (int64_t)-1, render, alphas, last_ids, tile_order, st);
+                     tile_w, tile_h, offsets, rank_ids, (int64_t)-1, render, alphas, last_ids, tile_order, st, also_zero, also_zero_bytes);
     MTGS_CHECK_LAUNCH("mtgs_blend_fwd_packed");
     return MTGS_OK;
 }

@@ -62,20 +62,23 @@ class _ZeroRequest:
 
 
 class _Prefill:
-    """THE SH BACKWARD'S ZEROS, WRITTEN BY THE COMPOSITING BACKWARD (round 5).  dL/dcoeffs is [N, K, 3] -- 384 MB at the headline
-    workload -- of which the rows of the ~6 % composited Gaussians are non-zero; writing it is what the SH backward costs (81 us,
-    HBM-bound), and the zeros depend on nothing.  The compositing backward, two autograd nodes earlier in the same backward pass,
-    is VALU-bound and leaves HBM ~85 % idle for 0.3 ms.  So: a spherical_harmonics() forward whose coefficients need a gradient
-    leaves a request here; the next rasterization() backward on that device allocates the buffers (one allocation) and hands them
-    to mtgs_blend_bwd_packed(also_zero), whose waves clear a slice each when their tile is done; the SH backward then only writes
-    the non-zero rows (mtgs_sh_bwd_rows).  One stream, nothing to join, nothing special inside a graph capture.  A request nobody
-    serves -- spherical_harmonics() used without the rasterizer -- falls back to the one-kernel dense backward.  Process-wide
-    (autograd runs backward nodes on its own threads), weakly referenced (a graph that is never differentiated leaves nothing)."""
+    """ZEROS THE BACKWARD PASS WANTS, WRITTEN BY THE COMPOSITING KERNELS (round 5).  dL/dcoeffs of spherical_harmonics() is
+    [N, K, 3] -- 384 MB at the headline workload -- of which the rows of the ~6 % composited Gaussians are non-zero; writing it is
+    what the SH backward costs (81 us, HBM-bound), and the zeros depend on nothing.  The compositing kernels of the rasterizer are
+    VALU-bound and leave HBM ~85 % idle for 0.16 + 0.33 ms.  So: a spherical_harmonics() forward whose coefficients need a
+    gradient leaves a request here; the rasterization() forward that follows (when something needs a gradient) allocates the
+    buffers -- one region, plus the gradient rows its own compositing backward accumulates into -- and hands it to
+    mtgs_blend_fwd_packed(also_zero), whose waves clear a slice each when their tile is done; requests that only turn up later are
+    served the same way by the compositing backward.  The SH backward then only writes the non-zero rows (mtgs_sh_bwd_rows).  One
+    stream, nothing to join, nothing special inside a graph capture.  A request nobody serves -- spherical_harmonics() without the
+    rasterizer -- falls back to the one-kernel dense backward; a forward that is never differentiated has written zeros nobody
+    reads (~10 us).  Process-wide (autograd runs backward nodes on its own threads), weakly referenced."""
 
     def __init__(self):
         self.lock = threading.Lock()
         self.pending = weakref.WeakSet()
         self.enabled = os.environ.get("MTGS_SH_PREFILL", "1") == "1"
+        self.in_forward = os.environ.get("MTGS_PREFILL_IN_FORWARD", "1") == "1"
 
     def request(self, shape, device) -> Optional[_ZeroRequest]:
         if not self.enabled:
@@ -85,22 +88,24 @@ class _Prefill:
             self.pending.add(req)
         return req
 
-    def take(self, device):
-        """Called by a rasterization backward in front of its compositing kernel: (pointer, bytes) of ONE region holding the
-        buffers of every pending request of the device (16-byte aligned pieces), or (None, 0)."""
+    def take(self, device, extra_floats: int = 0):
+        """Called by a rasterization forward / backward in front of its compositing kernel: (pointer, bytes, extra) of ONE region
+        holding the buffers of every pending request of the device (16-byte aligned pieces) and `extra_floats` more for the caller
+        (`extra`: a flat view), or (None, 0, None)."""
         with self.lock:
             mine = [r for r in self.pending if r.device == device and r.buffer is None]
             for r in mine:
                 self.pending.discard(r)
-        if not mine:
-            return None, 0
+        if not mine and not extra_floats:
+            return None, 0, None
         sizes = [-(-int(torch.Size(r.shape).numel()) // 4) * 4 for r in mine]      # floats, padded to 16 bytes
-        region = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        at = 0
+        own = -(-int(extra_floats) // 4) * 4
+        region = torch.empty(sum(sizes) + own, dtype=torch.float32, device=device)
+        at = own
         for r, n in zip(mine, sizes):
             r.buffer = region[at:at + int(torch.Size(r.shape).numel())].view(r.shape)
             at += n
-        return region.data_ptr(), region.numel() * 4
+        return region.data_ptr(), region.numel() * 4, (region[:int(extra_floats)] if extra_floats else None)
 
 
 _prefill = _Prefill()
@@ -763,6 +768,8 @@ class _FusedRasterization(torch.autograd.Function):
                     dpf.after_front()      # the visibility maps travel while this frame is composited
                 return b
 
+            ctx_box = {}
+
             def rest(b, cap_M, prezeroed=None):
                 cap_alloc = max(cap_M, 1)
                 out = {"rank_ids": torch.empty(cap_alloc, dtype=torch.int32, device=dev),
@@ -778,8 +785,15 @@ class _FusedRasterization(torch.autograd.Function):
                     call("mtgs_blend_touch_packed", Cn, ptr(b["recs"]), width, height, tw, th, ptr(offsets_buf), ptr(out["rank_ids"]),
                          ptr(order), ptr(flags), b["cap_vis"], st)
                     colours(b, flags)
+                # a training forward: its compositing kernel (VALU-bound, HBM mostly idle) clears what the backward pass will want
+                # zeroed -- the gradient rows of the compositing backward, the dL/dcoeffs of the SH backwards (_Prefill)
+                z_ptr, z_bytes = None, 0
+                if _prefill.enabled and _prefill.in_forward and any(ctx.needs_input_grad) and dp is None and ctx_box.get("rows") is None:
+                    RS_ = -(-(8 + DC + int(with_depth)) // 16) * 16
+                    z_ptr, z_bytes, rows_ = _prefill.take(dev, max(b["cap_vis"], 1) * RS_)
+                    ctx_box["rows"] = rows_.view(max(b["cap_vis"], 1), RS_)
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
-                     ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), st)
+                     ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), z_ptr, z_bytes, st)
                 return out
 
             caps = _force_caps or (_size_plan.caps(key, total) if speculative_sizing else None)
@@ -826,6 +840,7 @@ class _FusedRasterization(torch.autograd.Function):
                               comps, opac_eff, offsets if not packed else offsets_buf, flatten_ids, alphas, last_ids, order,
                               vis_ids, vis_rank, render if ed else None, recs, rank_ids, totals)
         ctx.cs, ctx.vis_mask, ctx.cap_vis = cs, (b["vis_mask"] if cs is not None else None), (b["cap_vis"] if packed else 0)
+        ctx.zero_rows = ctx_box.get("rows") if packed else None      # gradient rows the forward's compositing kernel cleared
         ctx.n2c = n2c
         ctx.graph = packed and _graph.caps is not None
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
@@ -853,7 +868,12 @@ class _FusedRasterization(torch.autograd.Function):
         # compact gradient rows, one per VISIBLE (camera, Gaussian) pair:
         #   [xy 2 | |xy| 2 | conic 3 | opacity 1 | colour DC | depth 1 | pad]
         RS = -(-(8 + DT) // 16) * 16
-        G = torch.zeros((max(n_vis, 1), RS), dtype=torch.float32, device=dev)
+        G = getattr(ctx, "zero_rows", None)
+        if G is not None and G.shape[1] == RS and G.shape[0] >= max(n_vis, 1):
+            ctx.zero_rows = None            # (cleared by the forward's compositing kernel; a second backward of the node takes the else)
+            G = G[:max(n_vis, 1)]
+        else:
+            G = torch.zeros((max(n_vis, 1), RS), dtype=torch.float32, device=dev)
         r_xy, r_abs, r_con, r_opa = G[:, 0:2], G[:, 2:4], G[:, 4:7], G[:, 7]
         r_col = G[:, 8:8 + DC] if DC else None
         r_dep = G[:, 8 + DC] if with_depth else None
@@ -866,7 +886,7 @@ class _FusedRasterization(torch.autograd.Function):
             if ctx.packed:
                 if rank_ids.numel() > 0:
                     # (the zeros the spherical_harmonics() backwards of this pass want are written by this kernel: _Prefill)
-                    z_ptr, z_bytes = _prefill.take(dev)
+                    z_ptr, z_bytes, _ = _prefill.take(dev)
                     call("mtgs_blend_bwd_packed", Cn, DC, int(with_depth), ptr(recs), ptr(bg), int(ed), width, height, tw, th,
                          ptr(offsets), ptr(rank_ids), ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas),
                          ptr(G), RS, int(ctx.absgrad), ptr(order), z_ptr, z_bytes, st)

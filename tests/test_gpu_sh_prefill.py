@@ -1,5 +1,5 @@
-"""The SH backward's zeros written by the rasterizer's compositing backward (mtgs_amd/wrapper.py::_Prefill,
-csrc/blend.hip::ZeroFill -- mtgs_blend_bwd_packed(also_zero) --, csrc/sh.hip::sh_bwd_rows_kernel): dL/dcoeffs of `spherical_harmonics() -> clamp(. + 0.5) -> rasterization()` -- the call sequence of
+"""The SH backward's zeros written by the rasterizer's compositing kernels (mtgs_amd/wrapper.py::_Prefill,
+csrc/blend.hip::ZeroFill -- mtgs_blend_{fwd,bwd}_packed(also_zero) --, csrc/sh.hip::sh_bwd_rows_kernel): dL/dcoeffs of `spherical_harmonics() -> clamp(. + 0.5) -> rasterization()` -- the call sequence of
 /root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:309-318 + mtgs_scene_graph.py:641-662 -- must be the
 dense one-kernel backward's, bit for bit, whether the cotangent is sparse (only composited Gaussians) or dense (an extra loss on the
 colours), with masks, inside a HIP graph capture, and when the request is never served (no rasterizer in the graph)."""
@@ -37,7 +37,7 @@ def _step(P, vm, K, Gc, Ga, WH, degree=3, dense_extra=False, masks=None):
 
 @pytest.mark.parametrize("degree", [0, 1, 2, 3])
 @pytest.mark.parametrize("dense_extra", [False, True])
-def test_zeros_from_the_compositing_backward_plus_rows_equal_the_dense_backward(hip_lib, degree, dense_extra):
+def test_zeros_from_the_compositing_kernels_plus_rows_equal_the_dense_backward(hip_lib, degree, dense_extra):
     from mtgs_amd import wrapper
     dev = torch.device("cuda")
     args = _scene(dev)
@@ -147,3 +147,43 @@ def test_inside_a_graph_capture(hip_lib):
     assert not bool(box["overflow"])
     torch.testing.assert_close(P["coeffs"].grad, eager["coeffs"], rtol=1e-3, atol=1e-5 * float(eager["coeffs"].abs().max()))
     torch.testing.assert_close(P["means"].grad, eager["means"], rtol=1e-3, atol=1e-5 * float(eager["means"].abs().max()))
+
+
+@pytest.mark.parametrize("in_forward", [True, False])
+def test_served_by_the_forward_or_by_the_backward_and_backward_twice(hip_lib, in_forward):
+    """The region is cleared by the compositing FORWARD (default) or, for requests that only turn up later, by the compositing
+    BACKWARD; a second backward through the same graph (retain_graph) finds its rows used and takes the plain paths."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    dev = torch.device("cuda")
+    P, vm, K, Gc, Ga, WH = _scene(dev, N=150_000)
+    want = _step(P, vm, K, Gc, Ga, WH)
+    was = wrapper._prefill.in_forward
+    wrapper._prefill.in_forward = in_forward
+    calls = []
+    real = wrapper.call
+    try:
+        wrapper.call = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        for p in P.values():
+            p.grad = None
+        dirs = P["means"].detach() - torch.inverse(vm)[0, :3, 3]
+        rgb = torch.clamp(spherical_harmonics(3, dirs, P["coeffs"]) + 0.5, 0.0, 1.0)
+        render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, WH[0], WH[1], packed=False,
+                                            render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+        loss = (render * Gc).sum() + (alpha * Ga).sum()
+        loss.backward(retain_graph=True)
+        first = {k: v.grad.clone() for k, v in P.items()}
+        for p in P.values():
+            p.grad = None
+        loss.backward()
+        second = {k: v.grad.clone() for k, v in P.items()}
+    finally:
+        wrapper.call, wrapper._prefill.in_forward = real, was
+    fwd_zero = [a[-2] for n, a in calls if n == "mtgs_blend_fwd_packed"]
+    bwd_zero = [a[-2] for n, a in calls if n == "mtgs_blend_bwd_packed"]
+    n_coeff_bytes = P["coeffs"].numel() * 4
+    assert (fwd_zero[0] >= n_coeff_bytes and bwd_zero == [0, 0]) if in_forward else (fwd_zero == [0] and bwd_zero[0] == n_coeff_bytes and bwd_zero[1] == 0), (fwd_zero, bwd_zero)
+    names = [n for n, _ in calls]
+    assert names.count("mtgs_sh_bwd_rows") == 1 and names.count("mtgs_sh_bwd") == 1      # (second backward: the dense kernel)
+    for got in (first, second):
+        for k in got:
+            torch.testing.assert_close(got[k], want[k], rtol=1e-3, atol=1e-5 * float(want[k].abs().max()))
