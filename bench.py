@@ -660,18 +660,23 @@ def main():
     D = 4 if args.variant == "mtgs" else 3
     A = 1 if args.variant == "mtgs" else 0
     bytes_bwd = P * (4 * D + 12) + M_l * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A)
-    # ... plus, round 5, the zeros of dL/dcoeffs [N, 16, 3] that the kernel writes for the spherical_harmonics() backward behind it
-    # (mtgs_blend_bwd_packed(also_zero), mtgs_amd/wrapper.py::_Prefill): bytes the step has to write, moved into the kernel that
-    # leaves HBM idle; n_coeff_rows = the Gaussians whose coefficient gradient is non-zero (mtgs_sh_bwd_rows writes those rows)
+    # Round 5: the zeros of dL/dcoeffs [N, 16, 3] that the spherical_harmonics() backward behind the rasterizer used to write are
+    # written by a COMPOSITING kernel beside its own work (mtgs_blend_{fwd,bwd}_packed(also_zero), mtgs_amd/wrapper.py::_Prefill:
+    # the forward's by default, together with the 64-byte gradient rows of the compositing backward) -- bytes the step has to
+    # write, moved into kernels that leave HBM idle; n_coeff_rows = the Gaussians whose coefficient gradient is non-zero
+    # (mtgs_sh_bwd_rows writes those rows)
     from mtgs_amd import wrapper as _wr
     sparse_dp = world > 1 and args.dp_exchange == "sparse" and args.variant == "mtgs"      # (its colours are detached: no SH autograd node)
-    sh_zeros_in_bwd = bool(args.variant == "mtgs" and _wr._prefill.enabled and not sparse_dp)
+    sh_zeros = bool(args.variant == "mtgs" and _wr._prefill.enabled and not sparse_dp)
+    zeros_in_fwd = bool(_wr._prefill.enabled and _wr._prefill.in_forward and not sparse_dp)
     n_coeff_rows = 0
     _cg = dev["coeffs"].grad if (args.variant == "mtgs" and "coeffs" in dev) else None
     if _cg is not None:
         n_coeff_rows = int((_cg.abs().amax(dim=(1, 2)) > 0).sum().item())
-    if sh_zeros_in_bwd:
-        bytes_bwd += args.n_gaussians * 12 * 16
+    sh_zero_bytes = args.n_gaussians * 12 * 16 if sh_zeros else 0
+    bytes_fwd_zeros = (sh_zero_bytes + n_vis * 64) if zeros_in_fwd else 0
+    if sh_zeros and not zeros_in_fwd:
+        bytes_bwd += sh_zero_bytes
     # whole-step algorithmic HBM bytes, SURVEY.md section 8(d): B_F + B_B (K = 16 SH bases when the step includes SH)
     N, T = args.n_gaussians, -(-args.width // 16) * -(-args.height // 16)
     Ksh = 16 if args.variant == "mtgs" else 0
@@ -697,7 +702,7 @@ def main():
         "bin3_tiles_count_kernel": n_items * 8,
         "bin3_tiles_place_kernel": n_items * (8 + 4) + M_l * 8,
         "bin3_sort_small_kernel": M_l * (8 + 4 + 4 + 4 + 8),
-        "blend_fwd_kernel<4, 2, true>": M_l * (4 + 64) + P * (4 * D + 8),
+        "blend_fwd_kernel<4, 2, true>": M_l * (4 + 64) + P * (4 * D + 8) + bytes_fwd_zeros,
         "blend_bwd_kernel<4, 4, true>": bytes_bwd,
     }
     # (1) measured in THIS run: HIP events around every C-ABI entry point of the step (second, untimed pass)
@@ -778,16 +783,18 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
                      "launches_timed": len(kernel_ms),
-                     # (round 5) of which the zeros of dL/dcoeffs [N,16,3] the kernel writes for the SH backward behind it
-                     "sh_gradient_zeros_in_this_launch": args.n_gaussians * 12 * 16 if sh_zeros_in_bwd else 0,
-                     "sh_coefficient_rows_with_gradient": n_coeff_rows,
+                     # (round 5) zeros the backward pass wants -- dL/dcoeffs [N,16,3] of the SH backward, the compositing backward's own
+                     # gradient rows -- are written by a compositing kernel beside its work: which one, and how many bytes
+                     "zeros_for_the_backward_pass": {"written_by": ("mtgs_blend_fwd_packed" if zeros_in_fwd else "mtgs_blend_bwd_packed") if sh_zeros else None,
+                                                     "bytes": bytes_fwd_zeros if zeros_in_fwd else sh_zero_bytes,
+                                                     "sh_coefficient_rows_with_gradient": n_coeff_rows},
                      # the dominant kernel priced on gsplat's intersection count M (the lists of the default call): the same
                      # unit as whole_step below and as SURVEY.md section 8(d)
                      "algorithmic_bytes_on_gsplat_lists": P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A),
                      "frac_on_gsplat_lists": round((P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A))
                                                    / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else 0.0,
                      "note": "avg_launch_ms: HIP events on the launch stream around every mtgs_blend_bwd_packed call of the K EAGER steps run "
-                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) [+ N*192: the zeros of the SH coefficient gradient, written by this kernel beside its own work since round 5 -- sh_gradient_zeros_in_this_launch] with n_listed = the (tile, Gaussian) pairs "
+                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) [+ N*192 when zeros_for_the_backward_pass.written_by names this kernel] with n_listed = the (tile, Gaussian) pairs "
                              "of the timed steps' lists (config.n_listed; = gsplat's count config.n_intersections for the default call); "
                              "kernel is VALU bound, not HBM bound (DESIGN.md section 4); avg_launch_ms is measured in this run; traffic and "
                              "valu_busy_frac (SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8) come from the committed rocprofv3 "
