@@ -117,6 +117,9 @@ int mtgs_fill_zero(void *p, size_t bytes, void *stream);
  * VJP runs one thread per VISIBLE Gaussian and a streaming pass writes every dense output coalesced.
  * recs (nullable; hot ABI v5; compact path): mtgs_front_fwd's 64-byte records, indexed like the rows -- conic and blended opacity of a
  * visible Gaussian are then read from its record (contiguous) instead of being gathered from conics / opacities / compensations.
+ * vm_partials (nullable; hot ABI v5; compact path, with v_viewmats): scratch of 12 * blocks floats (mtgs_project_bwd_blocks) -- every
+ * workgroup of the per-visible pass leaves its 12 sums of the camera gradient there and the pass behind adds them in a fixed order into
+ * v_viewmats (written in full): no launch to zero it, no same-address atomics (5 us at the headline workload), a deterministic sum.
  * n_vis_dev (nullable, device): mtgs_front_fwd's packed totals; the number of rows is then min(n_vis, *n_vis_dev >> 32)
  * and n_vis is only the capacity of the row buffers (graph mode: the host never learns the count).
  * Rows only: with v_means = v_quats = v_scales = v_opacities = NULL (compact path, no dense by-products) the streaming pass is
@@ -144,7 +147,10 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const float *x_means2d_abs, const float *x_colors, int x_channels,
                      const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
                      const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
-                     const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, const float *recs, void *stream);
+                     const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, const float *recs, float *vm_partials,
+                     void *stream);
+/* workgroups of the compact path's per-visible pass for n_vis rows: vm_partials holds 12 floats for each */
+int mtgs_project_bwd_blocks(int64_t n_vis, int64_t *blocks);
 
 /* ---- tile intersection: gsplat isect_tiles (count pass / cumsum / emit pass) -------------------
  * mtgs_isect_count : tiles_per_gauss[C,N] i32 = #tiles of the clamped bounding square.

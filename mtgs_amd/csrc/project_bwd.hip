@@ -327,7 +327,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     const float *__restrict__ v_compensations, const float *__restrict__ v_opac_eff, const ProjGradStrides gs,
     float *__restrict__ ws, float *__restrict__ v_viewmats, const int64_t *__restrict__ n_vis_dev,
     const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows, float *raw_rows, int64_t raw_stride,
-    const float *__restrict__ recs /* nullable: mtgs_front_fwd's records, indexed like the rows */) {
+    const float *__restrict__ recs /* nullable: mtgs_front_fwd's records, indexed like the rows */,
+    float *__restrict__ vm_partials /* nullable: [gridDim.x, 12] -- the blocks' viewmat sums, added up by viewmat_from_partials */) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
@@ -462,8 +463,40 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     if (v_viewmats && threadIdx.x < 12) {
         const int k = threadIdx.x;
         const float v = s_acc[k];
-        if (v != 0.f) atomicAdd(v_viewmats + (k < 9 ? (k / 3) * 4 + (k % 3) : (k - 9) * 4 + 3), v);
+        // (1180 blocks x 12 atomics on ONE 64-byte line serialise: 5 us of this kernel's 41 at the headline workload, plus the launch
+        //  that zeroed the target.  With vm_partials every block leaves its 12 sums and the pass behind adds them in a fixed order)
+        if (vm_partials) vm_partials[blockIdx.x * 12 + k] = v;
+        else if (v != 0.f) atomicAdd(v_viewmats + (k < 9 ? (k / 3) * 4 + (k % 3) : (k - 9) * 4 + 3), v);
     }
+}
+
+// v_viewmats[4][4] = sum over the blocks' partial sums (v_R[i][j] -> [i][j], v_t[i] -> [i][3], last row 0), in a fixed order: 12
+// components x 16 threads each, then an LDS tree.  Called by the first block of the pass behind project_bwd_vis_kernel.
+__device__ __forceinline__ void viewmat_from_partials(const float *__restrict__ partials, int n_blocks, float *__restrict__ v_viewmats,
+                                                      float *lds /* [192] */) {
+    const int t = threadIdx.x;
+    if (t < 192) {
+        const int k = t % 12, j = t / 12;
+        float v = 0.f;
+        for (int b = j; b < n_blocks; b += 16) v += partials[b * 12 + k];
+        lds[t] = v;
+    }
+    __syncthreads();
+    if (t < 16) {
+        float v = 0.f;
+        const int i = t >> 2, jj = t & 3;
+        if (i < 3) {
+            const int k = jj < 3 ? i * 3 + jj : 9 + i;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v += lds[j * 12 + k];
+        }
+        v_viewmats[t] = v;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(PROJ_BLOCK) void viewmat_reduce_kernel(const float *__restrict__ partials, int n_blocks, float *__restrict__ v_viewmats) {
+    __shared__ float lds[192];
+    viewmat_from_partials(partials, n_blocks, v_viewmats, lds);
 }
 
 // ---- wire rows (view-parallel data parallelism, mtgs_amd.dist / csrc/dp.hip) ----------------------------------------
@@ -565,8 +598,9 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
     int64_t N, int64_t n_rows, const int32_t *__restrict__ radii, const int32_t *__restrict__ row_index,
     const float *__restrict__ ws, const float *__restrict__ v_means2d, int64_t m2d_stride,
     float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
-    float *__restrict__ v_opacities, const ProjExpand ex) {
+    float *__restrict__ v_opacities, const ProjExpand ex, const float *__restrict__ vm_partials, int vm_blocks, float *__restrict__ v_viewmats) {
     __shared__ __attribute__((aligned(16))) float s_vm[PROJ_BLOCK * 3], s_vq[PROJ_BLOCK * 4], s_vs[PROJ_BLOCK * 3], s_vo[PROJ_BLOCK];
+    if (vm_partials && blockIdx.x == 0) viewmat_from_partials(vm_partials, vm_blocks, v_viewmats, s_vm);   // (the vis kernel's block sums)
     __shared__ __attribute__((aligned(16))) float s_m2d[PROJ_BLOCK * 2], s_abs[PROJ_BLOCK * 2], s_col[PROJ_BLOCK * EXP_STAGE_COL];
     const int t = threadIdx.x;
     const int64_t chunk = (int64_t)blockIdx.x * PROJ_BLOCK;
@@ -610,6 +644,19 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
 
 }  // namespace
 
+namespace {
+inline int64_t vis_blocks(int64_t n_vis) {
+    const int64_t blocks = ceil_div64(n_vis > 0 ? n_vis : 1, PROJ_BLOCK);
+    return blocks < 8192 ? blocks : 8192;
+}
+}  // namespace
+
+extern "C" int mtgs_project_bwd_blocks(int64_t n_vis, int64_t *blocks) {
+    MTGS_REQUIRE(n_vis >= 0 && blocks, MTGS_EINVAL, "mtgs_project_bwd_blocks: bad arguments");
+    *blocks = vis_blocks(n_vis);
+    return MTGS_OK;
+}
+
 extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats,
                                 const float *scales, const float *viewmats, const float *Ks,
                                 int width, int height, float eps2d, const int32_t *radii,
@@ -622,11 +669,13 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
                                 float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
                                 const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
-                                const float *recs, void *stream) {
+                                const float *recs, float *vm_partials, void *stream) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
-    if (v_viewmats && C > 0) {
+    // (vm_partials: the compact path writes v_viewmats in full from the blocks' partial sums -- no zero launch, no atomics)
+    const bool partial_sums = vm_partials && v_viewmats && vis_ids && vis_ws && grad_row_index && C == 1 && N > 0 && n_vis > 0;
+    if (v_viewmats && C > 0 && !partial_sums) {
         if (int rc = mtgs_zero_async(v_viewmats, sizeof(float) * 16 * (size_t)C, st)) return rc;
     }
     if (N == 0 || C == 0) return MTGS_OK;
@@ -670,14 +719,16 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
         // compact path: grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank)
         MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
         if (n_vis > 0) {
-            const int64_t blocks = ceil_div64(n_vis, PROJ_BLOCK);
-            project_bwd_vis_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), PROJ_BLOCK, 0, st>>>(
+            project_bwd_vis_kernel<<<(unsigned)vis_blocks(n_vis), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
                 v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows,
-                raw_rows, rs[0], recs);
+                raw_rows, rs[0], recs, partial_sums ? vm_partials : nullptr);
         }
+        const int vm_blocks = (int)vis_blocks(n_vis);
         if (!rows_only) project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
-            N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex);
+            N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex,
+            partial_sums ? vm_partials : nullptr, vm_blocks, v_viewmats);
+        else if (partial_sums) viewmat_reduce_kernel<<<1, PROJ_BLOCK, 0, st>>>(vm_partials, vm_blocks, v_viewmats);
         MTGS_CHECK_LAUNCH("mtgs_project_bwd");
         return MTGS_OK;
     }

@@ -210,7 +210,7 @@ class _FullyFusedProjection(torch.autograd.Function):
              ptr(v_means2d), ptr(v_depths), ptr(v_conics), ptr(v_comps), ptr(v_opac_eff), ptr(v_means),
              ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([s_m2d, s_dep, s_con, s_cmp, s_opa]), None, None, None, 0, None, None, None, None,
-             None, 0, None, None, None, None, None, None, stream_of(means))
+             None, 0, None, None, None, None, None, None, None, stream_of(means))
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
                 v_viewmats, None, v_opacities if g[5] else None, None, None, None, None, None, None, None)
@@ -984,6 +984,11 @@ class _FusedRasterization(torch.autograd.Function):
         if geo_rows and (d_col is not None or want_m2d):
             raise NotImplementedError("ColorSource.geometry_rows: no extra colour channels with a gradient, no retain_grad() on means2d")
         vis_ws = torch.empty((max(n_vis, 1), 12), dtype=torch.float32, device=dev)  # scratch of the compact VJP
+        vm_part = None      # ... and of the camera gradient: the workgroups' partial sums (added up in a fixed order, no atomics)
+        if v_viewmats is not None and Cn == 1 and n_vis > 0:
+            nb = C.c_int64(0)
+            call("mtgs_project_bwd_blocks", n_vis, C.byref(nb))
+            vm_part = torch.empty(nb.value * 12, dtype=torch.float32, device=dev)
         call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
              eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities), ptr(r_xy), ptr(r_dep_total), ptr(r_con),
              ptr(r_cmp), ptr(r_opa), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
@@ -992,7 +997,7 @@ class _FusedRasterization(torch.autograd.Function):
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
              ptr(totals) if ctx.graph else None, ptr(q_rows),
              ptr(dir_rows) if (cs is not None and cs.autograd and n_vis > 0) else None,      # (differentiable view directions: dirs = means - camera position)
-             ptr(G) if raw else None, ptr(recs) if (raw and Cn == 1) else None, st)
+             ptr(G) if raw else None, ptr(recs) if (raw and Cn == 1) else None, ptr(vm_part), st)
         d_coeffs = d_campos = None
         if cs is not None and cs.autograd:
             if ctx.graph:

@@ -148,7 +148,7 @@ def main():
     res["project_bwd"] = timeit(lambda: call("mtgs_project_bwd", 1, N, ptr(d["means"]), ptr(d["quats"]), ptr(d["scales"]), ptr(vm), ptr(K), W, H, 0.3,
                                               ptr(radii), ptr(conics), ptr(comps), ptr(d["opacities"]), ptr(v2d), ptr(vdep), ptr(vcon), None,
                                               ptr(vop), ptr(vm_), ptr(vq), ptr(vs), ptr(vvm), ptr(vopn), pstr, ptr(rank), ptr(vab), ptr(vcl), DC,
-                                              host_i64([RS, RS]) if dense_out else None, ptr(d2), ptr(dab), ptr(dcl), ptr(vids), n_vis_k, ptr(vws), None, None, None, None, None, st), args.reps)
+                                              host_i64([RS, RS]) if dense_out else None, ptr(d2), ptr(dab), ptr(dcl), ptr(vids), n_vis_k, ptr(vws), None, None, None, None, None, None, st), args.reps)
     n_vis = int((radii > 0).sum())
     print(f"N={N} {W}x{H} variant={args.variant} n_vis={n_vis} M={M} D={D}")
     tot = 0.0
