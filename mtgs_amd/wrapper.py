@@ -55,10 +55,10 @@ def _strided_rows(t: Optional[Tensor], width: int):
 # ------------------------------------------------------------------------------------- SH
 class _ZeroRequest:
     """A [n, K, 3] buffer of zeros that a spherical_harmonics() backward will want (see _Prefill)."""
-    __slots__ = ("shape", "device", "buffer", "__weakref__")
+    __slots__ = ("shape", "device", "buffer", "stream", "__weakref__")
 
     def __init__(self, shape, device):
-        self.shape, self.device, self.buffer = tuple(shape), device, None
+        self.shape, self.device, self.buffer, self.stream = tuple(shape), device, None, None
 
 
 class _Prefill:
@@ -102,8 +102,9 @@ class _Prefill:
         own = -(-int(extra_floats) // 4) * 4
         region = torch.empty(sum(sizes) + own, dtype=torch.float32, device=device)
         at = own
+        stream = torch.cuda.current_stream(device).cuda_stream      # (the kernel that clears the region is enqueued there)
         for r, n in zip(mine, sizes):
-            r.buffer = region[at:at + int(torch.Size(r.shape).numel())].view(r.shape)
+            r.buffer, r.stream = region[at:at + int(torch.Size(r.shape).numel())].view(r.shape), stream
             at += n
         return region.data_ptr(), region.numel() * 4, (region[:int(extra_floats)] if extra_floats else None)
 
@@ -135,7 +136,9 @@ class _SphericalHarmonics(torch.autograd.Function):
         v_colors = _f32c(v_colors)
         need_dirs = ctx.needs_input_grad[1]
         req = ctx.zeros
-        if req is not None and req.buffer is not None and not need_dirs:
+        # (the zeros were written on the stream of the rasterization that served the request: only a backward ordered behind it,
+        #  i.e. on the same stream, may take them)
+        if req is not None and req.buffer is not None and not need_dirs and req.stream == stream_of(dirs):
             v_coeffs, req.buffer = req.buffer, None
             call("mtgs_sh_bwd_rows", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(masks), ptr(v_colors), ptr(v_coeffs), stream_of(dirs))
             return None, None, v_coeffs, None

@@ -187,3 +187,67 @@ def test_served_by_the_forward_or_by_the_backward_and_backward_twice(hip_lib, in
     for got in (first, second):
         for k in got:
             torch.testing.assert_close(got[k], want[k], rtol=1e-3, atol=1e-5 * float(want[k].abs().max()))
+
+
+def test_two_nodes_one_rasterization_and_a_backward_on_another_stream(hip_lib):
+    """A scene graph evaluates spherical_harmonics() once per node and rasterizes the concatenation (mtgs_scene_graph.py:408-461 +
+    641-662): both requests are served by the one rasterization, in one region.  A spherical_harmonics() whose backward runs on
+    ANOTHER stream than the rasterization that cleared its buffer must not take it (nothing orders the two): it falls back."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    dev = torch.device("cuda")
+    P, vm, K, Gc, Ga, WH = _scene(dev, N=200_000)
+    cam = torch.inverse(vm)[0, :3, 3]
+    half = 120_000
+
+    def run():
+        for p in P.values():
+            p.grad = None
+        cA = P["coeffs"][:half].detach().clone().requires_grad_(True)
+        cB = P["coeffs"][half:].detach().clone().requires_grad_(True)
+        dirs = P["means"].detach() - cam
+        shA, shB = spherical_harmonics(3, dirs[:half], cA), spherical_harmonics(2, dirs[half:], cB)
+        rgb = torch.clamp(torch.cat([shA, shB]) + 0.5, 0.0, 1.0)
+        render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, WH[0], WH[1], packed=False,
+                                            render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+        torch.autograd.backward([render, alpha], [Gc, Ga])
+        return cA.grad.clone(), cB.grad.clone()
+
+    calls = []
+    real = wrapper.call
+    try:
+        wrapper.call = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        gA, gB = run()
+    finally:
+        wrapper.call = real
+    names = [n for n, _ in calls]
+    assert names.count("mtgs_sh_bwd_rows") == 2 and "mtgs_sh_bwd" not in names
+    zeroed = [a[-2] for n, a in calls if n == "mtgs_blend_fwd_packed"][0]
+    assert zeroed >= (half + (200_000 - half)) * 16 * 3 * 4
+    wrapper._prefill.enabled = False
+    try:
+        wA, wB = run()
+    finally:
+        wrapper._prefill.enabled = True
+    for got, want in ((gA, wA), (gB, wB)):
+        assert torch.equal(got != 0, want != 0)
+        torch.testing.assert_close(got, want, rtol=1e-3, atol=1e-5 * float(want.abs().max()))
+    assert float(gB[:, 9:].abs().max()) == 0.0      # (degree 2 of K = 16: the rows kernel leaves the higher bands zero)
+    # ... a request served on one stream, its backward on another: the dense kernel
+    side = torch.cuda.Stream()
+    c = P["coeffs"].detach().clone().requires_grad_(True)
+    sh = spherical_harmonics(3, P["means"].detach() - cam, c)
+    rgb = torch.clamp(sh + 0.5, 0.0, 1.0)
+    render, alpha, info = rasterization(P["means"].detach(), P["quats"].detach(), P["scales"].detach(), P["opacities"].detach(), rgb, vm, K,
+                                        WH[0], WH[1], packed=False, render_mode="RGB+ED", rasterize_mode="antialiased")
+    req = sh.grad_fn.zeros
+    assert req is not None and req.buffer is not None
+    req.stream = side.cuda_stream                     # (as if the rasterization had run over there)
+    calls.clear()
+    try:
+        wrapper.call = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        torch.autograd.backward([render, alpha], [Gc, Ga])
+    finally:
+        wrapper.call = real
+    names = [n for n, _ in calls]
+    assert "mtgs_sh_bwd" in names and "mtgs_sh_bwd_rows" not in names
+    assert torch.isfinite(c.grad).all() and float(c.grad.abs().sum()) > 0
