@@ -788,7 +788,10 @@ int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, con
 int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                        int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
-                       float *dir_rows, float *dir_part, void *stream);
+                       float *dir_rows, float *dir_part, float *dense_rows, void *stream);
+/* dense_rows (nullable; ABI v26; one node): a ZEROED [N, 16, 3] coefficient gradient -- the rows of the visible Gaussians whose colour
+ * cotangent is not zero are written straight into it (row = vis_ids[r]) and feat_rows may be NULL: gsplat's `sh_degree` call style
+ * without the [n_vis, 48] intermediate and the dense expansion pass behind it. */
 /* use_sh = 4 in a descriptor: gsplat's own sh_degree path -- clamp_min(SH + 0.5, 0) (gsplat/rendering.py), and dir_rows
  * (nullable [cap_vis, 3]) receives d L / d (means - camera position) of the visible rows (gsplat's view directions are
  * differentiable; MTGS detaches them) and dir_part[ceil(cap_vis / 128), 3] (zeroed by the caller) their per-workgroup sums

@@ -132,7 +132,7 @@ _SIGNATURES = {
     "mtgs_loss_combine_fwd": [_i32, _vp, C.POINTER(C.c_float), C.c_uint, _f32, _vp, _vp, _vp],
     "mtgs_loss_combine_bwd": [_i32, _vp, _vp, C.POINTER(C.c_float), _vp, _vp],
     "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
-    "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_rows_expand": [_i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "mtgs_adam_group_bytes": [],
     "mtgs_adam_block_elems": [],

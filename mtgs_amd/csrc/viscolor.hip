@@ -163,7 +163,8 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
                                                                  int64_t cap_vis, const float *__restrict__ grad_rows, int64_t row_stride,
                                                                  int col, const float *__restrict__ recs,
                                                                  const uint8_t *__restrict__ vis_mask, float *__restrict__ feat_rows,
-                                                                 float *__restrict__ dir_rows, float *__restrict__ dir_part) {
+                                                                 float *__restrict__ dir_rows, float *__restrict__ dir_part,
+                                                                 float *__restrict__ dense_rows) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     __shared__ RowInfo s_row[VC_ROWS];
     __shared__ int64_t s_start[VC_LDS_NODES];
@@ -197,7 +198,13 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
         // round to zero where a larger basis value's would not): mtgs_adam_step's zero_probe leaves exactly the rows lazy
         // whose gradient is all zero
         v.x = fabsf(v.x) < 4.8e-38f ? 0.f : v.x; v.y = fabsf(v.y) < 4.8e-38f ? 0.f : v.y; v.z = fabsf(v.z) < 4.8e-38f ? 0.f : v.z;
-        *reinterpret_cast<F3 *>(feat_rows + r * 48 + k * 3) = F3{b * v.x, b * v.y, b * v.z};
+        if (dense_rows) {      // a ZEROED [N, 16, 3] gradient: the row of this Gaussian, if its cotangent is not zero (the zeros were
+            //                    written beside a compositing kernel's work: mtgs_blend_fwd_packed(also_zero))
+            if (v.x != 0.f || v.y != 0.f || v.z != 0.f)
+                *reinterpret_cast<F3 *>(dense_rows + (int64_t)vis_ids[r] * 48 + k * 3) = F3{b * v.x, b * v.y, b * v.z};
+        } else {
+            *reinterpret_cast<F3 *>(feat_rows + r * 48 + k * 3) = F3{b * v.x, b * v.y, b * v.z};
+        }
     }
     if (!dir_rows) return;
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -323,16 +330,18 @@ extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int 
 extern "C" int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                                   const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                                   int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
-                                  float *dir_rows, float *dir_part, void *stream) {
+                                  float *dir_rows, float *dir_part, float *dense_rows, void *stream) {
     MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0 && row_stride >= col + 3 && col >= 0, MTGS_EINVAL,
                  "mtgs_vis_color_bwd: bad sizes");
     if (cap_vis == 0) return MTGS_OK;
-    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && grad_rows && recs && vis_mask && feat_rows && (!dir_rows == !dir_part),
-                 MTGS_EINVAL, "mtgs_vis_color_bwd: null pointer (dir_rows and dir_part go together)");
+    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && grad_rows && recs && vis_mask && (feat_rows || dense_rows) &&
+                     (!dir_rows == !dir_part),
+                 MTGS_EINVAL, "mtgs_vis_color_bwd: null pointer (dir_rows and dir_part go together; feat_rows or dense_rows)");
+    MTGS_REQUIRE(!dense_rows || n_nodes == 1, MTGS_EINVAL, "mtgs_vis_color_bwd: dense_rows is the gradient of ONE [N, 16, 3] coefficient tensor");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
     MTGS_VC_DISPATCH(vis_color_bwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, grad_rows, row_stride, col, recs,
-                     vis_mask, feat_rows, dir_rows, dir_part)
+                     vis_mask, feat_rows, dir_rows, dir_part, dense_rows)
     MTGS_CHECK_LAUNCH("mtgs_vis_color_bwd");
     return MTGS_OK;
 }

@@ -793,8 +793,14 @@ class _FusedRasterization(torch.autograd.Function):
                 z_ptr, z_bytes = None, 0
                 if _prefill.enabled and _prefill.in_forward and any(ctx.needs_input_grad) and dp is None and ctx_box.get("rows") is None:
                     RS_ = -(-(8 + DC + int(with_depth)) // 16) * 16
-                    z_ptr, z_bytes, rows_ = _prefill.take(dev, max(b["cap_vis"], 1) * RS_)
-                    ctx_box["rows"] = rows_.view(max(b["cap_vis"], 1), RS_)
+                    n_rows_ = max(b["cap_vis"], 1) * RS_
+                    # (gsplat's sh_degree call style: the dense [N, 16, 3] coefficient gradient too -- the backward then writes the
+                    #  rows of the Gaussians with a cotangent straight into it, mtgs_vis_color_bwd(dense_rows))
+                    n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and cs.n_nodes == 1 and graph_caps is None) else 0
+                    z_ptr, z_bytes, own_ = _prefill.take(dev, n_rows_ + n_coef_)
+                    ctx_box["rows"] = own_[:n_rows_].view(max(b["cap_vis"], 1), RS_)
+                    if n_coef_:
+                        ctx_box["coeffs"] = own_[n_rows_:].view(N, 16, 3)
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
                      ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), z_ptr, z_bytes, st)
                 return out
@@ -844,6 +850,7 @@ class _FusedRasterization(torch.autograd.Function):
                               vis_ids, vis_rank, render if ed else None, recs, rank_ids, totals)
         ctx.cs, ctx.vis_mask, ctx.cap_vis = cs, (b["vis_mask"] if cs is not None else None), (b["cap_vis"] if packed else 0)
         ctx.zero_rows = ctx_box.get("rows") if packed else None      # gradient rows the forward's compositing kernel cleared
+        ctx.zero_coeffs = ctx_box.get("coeffs") if packed else None
         ctx.n2c = n2c
         ctx.graph = packed and _graph.caps is not None
         ctx.dims = (width, height, tile_size, tw, th, DC, bool(with_depth), ed, float(eps2d))
@@ -908,11 +915,13 @@ class _FusedRasterization(torch.autograd.Function):
         if cs is not None:
             # visibility-first colours: d L / d (SH coefficients) of the VISIBLE Gaussians as 192-byte rows; the optimizer takes
             # them through the row map (vis_rank: rank or -1) -- no dense [N, (T,) K, 3] gradient is written
-            feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev)
+            dense_coeffs = getattr(ctx, "zero_coeffs", None) if cs.autograd else None      # (zeroed by the forward's compositing kernel)
+            ctx.zero_coeffs = None
+            feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev) if dense_coeffs is None else None
             dir_rows = torch.empty((max(n_vis, 1), 3), dtype=torch.float32, device=dev) if cs.autograd else None
             dir_part = torch.zeros((-(-max(n_vis, 1) // 128), 3), dtype=torch.float32, device=dev) if cs.autograd else None
             call("mtgs_vis_color_bwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(vis_ids), ptr(totals),
-                 n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), ptr(dir_rows), ptr(dir_part), st)
+                 n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), ptr(dir_rows), ptr(dir_part), ptr(dense_coeffs), st)
             cs.rows, cs.row_of = feat, vis_rank
         if ctx.dp is not None:
             # data-parallel mode: the per-visible VJP writes this rank's wire rows (index order) into the exchange's send
@@ -1006,8 +1015,11 @@ class _FusedRasterization(torch.autograd.Function):
             if ctx.graph:
                 raise NotImplementedError("graph_mode: rasterization(sh_degree=...) (dense coefficient gradient)")
             K3 = cs.width
-            d_coeffs = torch.empty((N, K3 // 3, 3), dtype=torch.float32, device=dev)
-            call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
+            if dense_coeffs is not None:
+                d_coeffs = dense_coeffs
+            else:
+                d_coeffs = torch.empty((N, K3 // 3, 3), dtype=torch.float32, device=dev)
+                call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
             if n_vis > 0:
                 d_campos = -dir_part.sum(0)
             else:

@@ -251,3 +251,37 @@ def test_two_nodes_one_rasterization_and_a_backward_on_another_stream(hip_lib):
     names = [n for n, _ in calls]
     assert "mtgs_sh_bwd" in names and "mtgs_sh_bwd_rows" not in names
     assert torch.isfinite(c.grad).all() and float(c.grad.abs().sum()) > 0
+
+
+def test_gsplats_sh_degree_call_style_writes_the_coefficient_gradient_in_place(hip_lib):
+    """rasterization(colors=coeffs[N,16,3], sh_degree=3): the dense coefficient gradient is a buffer the compositing forward cleared,
+    the backward writes the rows with a cotangent straight into it (mtgs_vis_color_bwd(dense_rows)) -- no [n_vis, 48] intermediate, no
+    dense expansion pass -- and equals the expansion path."""
+    from mtgs_amd import rasterization, wrapper
+    dev = torch.device("cuda")
+    P, vm, K, Gc, Ga, WH = _scene(dev, N=150_000)
+
+    def run():
+        for p in P.values():
+            p.grad = None
+        render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["coeffs"], vm, K, WH[0], WH[1],
+                                            sh_degree=3, packed=False, render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+        torch.autograd.backward([render, alpha], [Gc, Ga])
+        return {k: v.grad.clone() for k, v in P.items()}
+
+    calls = []
+    real = wrapper.call
+    try:
+        wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        got = run()
+    finally:
+        wrapper.call = real
+    assert "mtgs_vis_color_bwd" in calls and "mtgs_rows_expand" not in calls, calls
+    wrapper._prefill.enabled = False
+    try:
+        want = run()
+    finally:
+        wrapper._prefill.enabled = True
+    assert torch.equal(got["coeffs"] != 0, want["coeffs"] != 0) and float(want["coeffs"].abs().sum()) > 0
+    for k in got:
+        torch.testing.assert_close(got[k], want[k], rtol=1e-3, atol=1e-5 * float(want[k].abs().max()))
