@@ -516,14 +516,50 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
     const float *__restrict__ colors_pre, int color_mode, float *__restrict__ wire, float *__restrict__ v_viewmats, int raw_rows) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
+    __shared__ int s_list[PROJ_BLOCK];
+    __shared__ int s_wcnt[PROJ_BLOCK / 64];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
     const Cam cam = load_cam(viewmats, Ks);
     for (int64_t r0 = (int64_t)blockIdx.x * PROJ_BLOCK; r0 < n_vis; r0 += (int64_t)gridDim.x * PROJ_BLOCK) {
-        const int64_t r = r0 + threadIdx.x;
+        // As in project_bwd_vis_kernel: most frustum-visible rows carry no gradient (nothing was composited from them).  Their wire
+        // row is zeros + the index -- no gathers, no VJP; the rows that have one are compacted (ballot + LDS list) and the ~2000
+        // instructions run on dense waves (round 5: the data-parallel render leg ran the VJP for every visible row).
+        __syncthreads();      // s_list reuse
+        {
+            const int64_t r = r0 + threadIdx.x;
+            bool nz = false;
+            if (r < n_vis) {
+                const float4 *g4 = reinterpret_cast<const float4 *>(G + r * gs);      // (the WHOLE row: extra channels -- normals -- too)
+                for (int64_t q4 = 0; q4 < gs / 4; ++q4) {
+                    const float4 a4 = g4[q4];
+                    nz = nz || a4.x != 0.f || a4.y != 0.f || a4.z != 0.f || a4.w != 0.f;
+                }
+                if (!nz) {
+                    float4 *out = reinterpret_cast<float4 *>(wire + r * WIRE_ROW);
+                    out[0] = out[1] = out[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    out[3] = make_float4(0.f, 0.f, 0.f, __int_as_float((int)vis_ids[r]));
+                }
+            }
+            const unsigned long long m = __ballot(nz);
+            const int wave_id = threadIdx.x >> 6;
+            if (lane_id() == 0) s_wcnt[wave_id] = __popcll(m);
+            __syncthreads();
+            int wbase = 0;
+#pragma unroll
+            for (int w = 0; w < PROJ_BLOCK / 64; ++w)
+                if (w < wave_id) wbase += s_wcnt[w];
+            if (nz) s_list[wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = threadIdx.x;
+            __syncthreads();
+        }
+        int count = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_BLOCK / 64; ++w) count += s_wcnt[w];
+        if (count == 0) continue;      // (uniform over the block)
         float vRt[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) vRt[k] = 0.f;
-        if (r < n_vis) {
+        if ((int)threadIdx.x < count) {
+            const int64_t r = r0 + s_list[threadIdx.x];
             const int64_t n = vis_ids[r];
             float m[3], sc[3], am[3] = {0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, as[3] = {0.f, 0.f, 0.f}, ao = 0.f;
             m[0] = means[n * 3]; m[1] = means[n * 3 + 1]; m[2] = means[n * 3 + 2];
