@@ -618,7 +618,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
     }
 }
 
-constexpr int EXP_STAGE_COL = 8;  // colour channels staged through LDS (more: per-lane stores)
+constexpr int EXP_STAGE_COL = 8;  // colour channels staged through LDS at most (more: per-lane stores)
 // `count` floats from LDS to consecutive global addresses, whole block, 16-byte stores when aligned
 __device__ __forceinline__ void block_store(float *__restrict__ dst, const float *lds, int count) {
     if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
@@ -630,6 +630,9 @@ __device__ __forceinline__ void block_store(float *__restrict__ dst, const float
         for (int k = threadIdx.x; k < count; k += PROJ_BLOCK) dst[k] = lds[k];
     }
 }
+// SC = colour channels the LDS staging is sized for (1 / 4 / 8: 14 / 17 / 21 KB per workgroup -- with 8 for every call the kernel
+// ran 6 workgroups per CU instead of the 8 its wave slots allow, 2 us of 44 at the headline workload)
+template <int SC>
 __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
     int64_t N, int64_t n_rows, const int32_t *__restrict__ radii, const int32_t *__restrict__ row_index,
     const float *__restrict__ ws, const float *__restrict__ v_means2d, int64_t m2d_stride,
@@ -637,12 +640,12 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_expand_kernel(
     float *__restrict__ v_opacities, const ProjExpand ex, const float *__restrict__ vm_partials, int vm_blocks, float *__restrict__ v_viewmats) {
     __shared__ __attribute__((aligned(16))) float s_vm[PROJ_BLOCK * 3], s_vq[PROJ_BLOCK * 4], s_vs[PROJ_BLOCK * 3], s_vo[PROJ_BLOCK];
     if (vm_partials && blockIdx.x == 0) viewmat_from_partials(vm_partials, vm_blocks, v_viewmats, s_vm);   // (the vis kernel's block sums)
-    __shared__ __attribute__((aligned(16))) float s_m2d[PROJ_BLOCK * 2], s_abs[PROJ_BLOCK * 2], s_col[PROJ_BLOCK * EXP_STAGE_COL];
+    __shared__ __attribute__((aligned(16))) float s_m2d[PROJ_BLOCK * 2], s_abs[PROJ_BLOCK * 2], s_col[PROJ_BLOCK * SC];
     const int t = threadIdx.x;
     const int64_t chunk = (int64_t)blockIdx.x * PROJ_BLOCK;
     const int n_chunk = (int)min((int64_t)PROJ_BLOCK, N - chunk);
     const int64_t n = chunk + t;
-    const bool stage_col = ex.colors && ex.channels <= EXP_STAGE_COL;
+    const bool stage_col = ex.colors && ex.channels <= SC;
     bool vis = n < N && radii[n] > 0;
     float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0;
     float2 xy = make_float2(0.f, 0.f), ab = xy;
@@ -761,9 +764,16 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                 raw_rows, rs[0], recs, partial_sums ? vm_partials : nullptr);
         }
         const int vm_blocks = (int)vis_blocks(n_vis);
-        if (!rows_only) project_bwd_expand_kernel<<<(unsigned)ceil_div64(N, PROJ_BLOCK), PROJ_BLOCK, 0, st>>>(
-            N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, v_means, v_quats, v_scales, v_opacities, ex,
-            partial_sums ? vm_partials : nullptr, vm_blocks, v_viewmats);
+        if (!rows_only) {
+            const unsigned eg = (unsigned)ceil_div64(N, PROJ_BLOCK);
+            const float *vp = partial_sums ? vm_partials : nullptr;
+#define MTGS_EXPAND(SC) project_bwd_expand_kernel<SC><<<eg, PROJ_BLOCK, 0, st>>>(N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, \
+                                                                                 v_means, v_quats, v_scales, v_opacities, ex, vp, vm_blocks, v_viewmats)
+            if (!ex.colors || ex.channels > EXP_STAGE_COL) MTGS_EXPAND(1);      // (nothing staged: per-lane stores or no colours)
+            else if (ex.channels <= 4) MTGS_EXPAND(4);
+            else MTGS_EXPAND(EXP_STAGE_COL);
+#undef MTGS_EXPAND
+        }
         else if (partial_sums) viewmat_reduce_kernel<<<1, PROJ_BLOCK, 0, st>>>(vm_partials, vm_blocks, v_viewmats);
         MTGS_CHECK_LAUNCH("mtgs_project_bwd");
         return MTGS_OK;
