@@ -560,10 +560,12 @@ struct SortEpilogue {
     __device__ __forceinline__ void store(int64_t dst, uint32_t bin, uint64_t key) const {
         const int32_t rank = (int32_t)min((uint32_t)key, rank_max);
         rank_ids[dst] = rank;
-        flatten_ids[dst] = vis_ids[rank];
+        // (NON-TEMPORAL: gsplat's two index tensors are outputs nobody in the frame reads -- the compositing kernels walk rank_ids --
+        //  and 48 MB of them would evict the keys and records the kernels behind re-read)
+        __builtin_nontemporal_store(vis_ids[rank], flatten_ids + dst);
         if (isect_ids) {
             const int64_t cam = single_cam ? 0 : bin / n_tiles, tile = single_cam ? bin : bin % n_tiles;
-            isect_ids[dst] = (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)(key >> 32);
+            __builtin_nontemporal_store((long long)((cam << (32 + tile_bits)) | (tile << 32) | (int64_t)(key >> 32)), reinterpret_cast<long long *>(isect_ids) + dst);
         }
     }
 };

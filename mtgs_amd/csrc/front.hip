@@ -55,10 +55,12 @@ __global__ __launch_bounds__(PROJ_BLOCK) void front_project_kernel(
         const Cam cam = load_cam(viewmats + c * 16, Ks + c * 9);
         const ProjOut o = project_pair(means, quats, scales, cam, n, W, H, eps2d, near_plane, far_plane, radius_clip);
         radii[idx] = o.radius;
-        reinterpret_cast<float2 *>(means2d)[idx] = make_float2(o.mx, o.my);
-        depths[idx] = o.depth;
-        *reinterpret_cast<F3 *>(conics + idx * 3) = F3{o.ca, o.cb, o.cc};
-        if (compensations) compensations[idx] = o.comp;
+        // (NON-TEMPORAL: the dense meta outputs are not read again inside the frame; the compaction kernel behind re-reads radii and the
+        //  chunk-local rows)
+        __builtin_nontemporal_store(o.mx, means2d + idx * 2); __builtin_nontemporal_store(o.my, means2d + idx * 2 + 1);
+        __builtin_nontemporal_store(o.depth, depths + idx);
+        __builtin_nontemporal_store(o.ca, conics + idx * 3); __builtin_nontemporal_store(o.cb, conics + idx * 3 + 1); __builtin_nontemporal_store(o.cc, conics + idx * 3 + 2);
+        if (compensations) __builtin_nontemporal_store(o.comp, compensations + idx);
         int32_t cnt = 0;
         float op = 0.f;
         if (o.radius > 0) {
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void front_project_kernel(
             st1 = make_float4(o.cc, op, o.depth, __int_as_float(o.radius));
             st_cnt = cnt;
         }
-        opac_eff[idx] = op;
-        tiles_per_gauss[idx] = cnt;
+        __builtin_nontemporal_store(op, opac_eff + idx);
+        __builtin_nontemporal_store(cnt, tiles_per_gauss + idx);
     }
     const uint64_t mine = v;
     // inclusive scan inside the wave (visible << 40 | tiles), the wave totals through LDS
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void front_compact_kernel(const Co
                 a.dp_prefix[idx >> 6] = (uint32_t)rank;   // lane 0: number of visible pairs in front of this word
             }
         }
-        if (idx < total) a.vis_rank[idx] = vis ? (int32_t)rank : -1;
+        if (idx < total) __builtin_nontemporal_store(vis ? (int32_t)rank : -1, a.vis_rank + idx);
         if (vis) {
             if (rank < a.cap_vis) {
                 // this pair's staged row: chunk r of the block, position = visible pairs of the chunk in front of it
