@@ -285,3 +285,25 @@ def test_gsplats_sh_degree_call_style_writes_the_coefficient_gradient_in_place(h
     assert torch.equal(got["coeffs"] != 0, want["coeffs"] != 0) and float(want["coeffs"].abs().sum()) > 0
     for k in got:
         torch.testing.assert_close(got[k], want[k], rtol=1e-3, atol=1e-5 * float(want[k].abs().max()))
+
+
+def test_a_thumbnail_frame_clears_the_region_with_the_fill_kernel(hip_lib):
+    """Two tiles under a 58 MB coefficient gradient: mtgs_blend_fwd_packed hands the region to the fill kernel instead of making two
+    waves write it (blend.hip::zero_fill_fallback); same gradients."""
+    from mtgs_amd import wrapper
+    dev = torch.device("cuda")
+    P, vm, K, Gc, Ga, _ = _scene(dev, N=300_000)
+    WH = (32, 16)
+    g = torch.Generator().manual_seed(5)
+    Gc, Ga = torch.randn(1, 16, 32, 4, generator=g).to(dev), torch.randn(1, 16, 32, 1, generator=g).to(dev)
+    vm2, K2 = vm.clone(), K.clone()
+    K2[0, 0, 0] = K2[0, 1, 1] = 25.0; K2[0, 0, 2] = 16.0; K2[0, 1, 2] = 8.0
+    got = _step(P, vm2, K2, Gc, Ga, WH)
+    wrapper._prefill.enabled = False
+    try:
+        want = _step(P, vm2, K2, Gc, Ga, WH)
+    finally:
+        wrapper._prefill.enabled = True
+    assert float(want["coeffs"].abs().sum()) > 0 and torch.equal(got["coeffs"] != 0, want["coeffs"] != 0)
+    for k in got:
+        torch.testing.assert_close(got[k], want[k], rtol=2e-3, atol=1e-5 * float(want[k].abs().max()))
