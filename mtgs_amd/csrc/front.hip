@@ -28,7 +28,9 @@ namespace {
 // Packed {visible pairs, tile intersections} of a chunk / group: visible << 40 | intersections (a chunk holds 256
 // pairs, a group 64 chunks; intersections of a group < 2^14 * 2^19 = 2^33).
 constexpr int CHUNKS_PER_GROUP = 64;
-constexpr int COMPACT_THREADS = 256, COMPACT_ROWS = 8, COMPACT_TILE = COMPACT_THREADS * COMPACT_ROWS;  // 8 chunks
+// (2 chunks per workgroup: with 8 the grid was 977 workgroups -- under four per CU for a chain of dependent loads; 16 / 8 / 4 / 2 / 1
+//  chunks measured 85.1 / 81.7 / 79.9 / 79.0 / 80.2 us for the entry point)
+constexpr int COMPACT_THREADS = 256, COMPACT_ROWS = 2, COMPACT_TILE = COMPACT_THREADS * COMPACT_ROWS;
 constexpr int STAGE_FLOATS = 12;   // chunk-local compact row of a visible pair: x y a b | c opacity depth radius | tile count - - -
 static_assert(COMPACT_THREADS == PROJ_BLOCK, "a row of the compaction kernel = one chunk of the projection kernel");
 __device__ __forceinline__ uint64_t pk_vis(uint64_t w) { return w >> 40; }
@@ -132,7 +134,7 @@ struct CompactArgs {
     int64_t also_zero_words;
 };
 
-// ---- kernel 2: rank of every visible pair (index order) and its packed record.  A block owns 8 chunks; the number of
+// ---- kernel 2: rank of every visible pair (index order) and its packed record.  A block owns COMPACT_ROWS chunks; the number of
 // visible pairs / intersections in front of it is the sum of the group counts in front of its group plus the chunk
 // counts in front of it inside the group: independent loads of values kernel 1 wrote, no inter-block waiting (a
 // chained scan inside ONE fused kernel measured 75 us against 40 + 20 us for these two: its ticket, look-back and
