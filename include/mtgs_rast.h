@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 26
+#define MTGS_RAST_ABI_VERSION 27
 /* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
@@ -444,6 +444,22 @@ int mtgs_dp_pack_ordered(int64_t N, const int32_t *radii, const float *v_means, 
 int mtgs_dp_touched_pack(int64_t n_rows, const float *rows, int64_t N, uint64_t *scratch_words, uint64_t *out_words,
                          uint32_t *out_prefix, int32_t *out_count, int64_t *totals, uint32_t *block_counts, float *out_rows,
                          int64_t capacity, void *stream);
+/* mtgs_dp_touched_pack_chunks (ABI v27): the same compaction into CHUNKS of the Gaussian index range -- the rows of the Gaussians
+ * in [begin[c], begin[c + 1]) go to rows[c] (at most cap[c] of them, same order), so that every chunk is its own all-gather message
+ * and a receiver reduces chunk c (mtgs_dp_reduce_slices_cap over [begin[c], begin[c + 1]), rows = the gathered chunk) while chunk
+ * c + 1 is on the wire.  begin[0] = 0, begin[n] = N, the others multiples of 64.  The map (out_words / out_prefix / out_count /
+ * totals) is the WHOLE range's, as mtgs_dp_touched_pack writes it; overflow[1] i32 (device) is set to 1 when a chunk held more rows
+ * than its capacity (they are dropped), 0 otherwise.  `chunks` is read on the host during the call. */
+#define MTGS_DP_MAX_CHUNKS 16
+typedef struct mtgs_dp_chunks {
+    int n;
+    int64_t begin[MTGS_DP_MAX_CHUNKS + 1];
+    float *rows[MTGS_DP_MAX_CHUNKS];
+    int64_t cap[MTGS_DP_MAX_CHUNKS];
+} mtgs_dp_chunks;
+int mtgs_dp_touched_pack_chunks(int64_t n_rows, const float *rows, int64_t N, uint64_t *scratch_words, uint64_t *out_words,
+                                uint32_t *out_prefix, int32_t *out_count, int64_t *totals, uint32_t *block_counts,
+                                const mtgs_dp_chunks *chunks, int32_t *overflow, void *stream);
 int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
                    const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride,
                    const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
@@ -458,6 +474,14 @@ int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *mean
                           const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                           float *v_coeffs, int64_t g_begin, int64_t g_end, uint64_t coeff_mask, int write_geometry,
                           int64_t coeff_stride, void *stream);
+/* mtgs_dp_reduce_slices_cap (ABI v27): mtgs_dp_reduce_slices with the number of ROWS a sender's block holds given apart from the
+ * block stride: a block may carry more than rows (finish_touched: [rows | the sender's map]), and a sender that had more rows than
+ * the agreed capacity must not have the words behind its rows summed as floats.  row_cap = 0: row_stride / 16 (the whole block). */
+int mtgs_dp_reduce_slices_cap(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                              const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride, int64_t row_cap,
+                              const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                              float *v_coeffs, int64_t g_begin, int64_t g_end, uint64_t coeff_mask, int write_geometry,
+                              int64_t coeff_stride, void *stream);
 /* ROWS out of the exchange (ABI v21): the receiver's sums as compact rows of the UNION of the senders' visible sets instead of
  * dense [N, .] tensors -- what lets the optimizer step the rows some camera of the step saw, and only those
  * (mtgs_amd.dist.SparseGradExchange.finish(rows=True) -> FusedAdam.set_row_gradient; reference: the per-traversal tensors of

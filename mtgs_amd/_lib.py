@@ -72,6 +72,9 @@ _SIGNATURES = {
     "mtgs_dp_accumulate": [_i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_pack_ordered": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "mtgs_dp_touched_pack": [_i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "mtgs_dp_touched_pack_chunks": [_i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_dp_reduce_slices_cap": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                  C.c_uint64, _i32, _i64, _vp],
     "mtgs_dp_union": [_i32, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_dp_reduce_rows_groups": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _i64, _i64, _vp],
@@ -146,7 +149,7 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 26
+ABI_VERSION = 27
 HOT_ABI_VERSION = 5      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None

@@ -232,6 +232,7 @@ struct DpSenders {
     const float *cams;                // [W,3]
     int W;
     int64_t word0;                    // first visibility word of the Gaussian range the rows cover
+    int64_t row_cap;                  // rows a sender's block HOLDS (0: row_stride / 16, the whole block is rows)
 };
 constexpr int DP_MAX_SENDERS = 64;  // one lane per sender computes its row span of a tile
 constexpr int DP_TILE = 32;    // Gaussians per wave (half a visibility word)
@@ -311,8 +312,10 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         int cnt = __builtin_amdgcn_readfirstlane(sp.y);
         // a sender's rows occupy [r * row_stride, (r + 1) * row_stride): rows beyond that capacity (finish_static: a rank with
         // more rows than the fixed capacity of the all-gather; the caller is told through its overflow flag) are not read
-        if (S.row_stride > 0) {
-            const int64_t room = S.row_stride / 16 - (int64_t)start;
+        // (row_cap: a block [rows | meta record] -- finish_touched -- must not be read past its rows: the words behind them are map
+        //  bits, and a sender that overflowed its capacity would otherwise hand them to the sum as floats)
+        if (S.row_stride > 0 || S.row_cap > 0) {
+            const int64_t room = (S.row_cap > 0 ? S.row_cap : S.row_stride / 16) - (int64_t)start;
             cnt = room <= 0 ? 0 : (cnt < room ? cnt : (int)room);
         }
         cnt_out = cnt;
@@ -459,8 +462,10 @@ __global__ __launch_bounds__(256) void dp_reduce_groups_kernel(int64_t g_begin, 
         const int2 sp = s_span[wave][r];
         const int start = __builtin_amdgcn_readfirstlane(sp.x);
         int cnt = __builtin_amdgcn_readfirstlane(sp.y);
-        if (S.row_stride > 0) {
-            const int64_t room = S.row_stride / 16 - (int64_t)start;
+        // (row_cap: a block [rows | meta record] -- finish_touched -- must not be read past its rows: the words behind them are map
+        //  bits, and a sender that overflowed its capacity would otherwise hand them to the sum as floats)
+        if (S.row_stride > 0 || S.row_cap > 0) {
+            const int64_t room = (S.row_cap > 0 ? S.row_cap : S.row_stride / 16) - (int64_t)start;
             cnt = room <= 0 ? 0 : (cnt < room ? cnt : (int)room);
         }
         cnt_out = cnt;
@@ -688,7 +693,80 @@ __global__ __launch_bounds__(TOUCH_BLOCK) void dp_touched_rows_kernel(int64_t n_
     out[0] = src[0]; out[1] = src[1]; out[2] = src[2]; out[3] = src[3];
 }
 
+// The same compaction into CHUNKS of the Gaussian index range (mtgs_dp_touched_pack_chunks): chunk c's rows go to their own block
+// (a separate all-gather message each, so that a receiver reduces chunk c while chunk c + 1 is on the wire), at most cap[c] of
+// them; *overflow = 1 when some chunk had more.
+struct DpChunkTab {
+    int n;
+    int64_t begin[MTGS_DP_MAX_CHUNKS + 1];
+    float *rows[MTGS_DP_MAX_CHUNKS];
+    int64_t cap[MTGS_DP_MAX_CHUNKS];
+};
+__global__ __launch_bounds__(TOUCH_BLOCK) void dp_touched_rows_chunks_kernel(int64_t n_rows, const float *__restrict__ rows,
+                                                                             const unsigned long long *__restrict__ words,
+                                                                             const uint32_t *__restrict__ prefix,
+                                                                             const int64_t *__restrict__ totals, const DpChunkTab tab,
+                                                                             int32_t *__restrict__ out_count, int32_t *__restrict__ overflow) {
+    const int64_t r = (int64_t)blockIdx.x * TOUCH_BLOCK + threadIdx.x;
+    if (r == 0) *out_count = (int32_t)(*totals >> 32);
+    if (r >= n_rows) return;
+    const float4 *src = reinterpret_cast<const float4 *>(rows + r * 16);
+    if (!wire_row_nonzero(rows + r * 16)) return;
+    const uint32_t n = (uint32_t)__float_as_int(rows[r * 16 + 15]);
+    const unsigned long long w = words[n >> 6];
+    const int64_t dst = (int64_t)prefix[n >> 6] + __popcll(w & ((1ull << (n & 63u)) - 1ull));
+    int c = 0;
+#pragma unroll 1
+    while (c + 1 < tab.n && (int64_t)n >= tab.begin[c + 1]) ++c;
+    const int64_t local = dst - (int64_t)prefix[tab.begin[c] >> 6];      // (chunks begin on word boundaries)
+    if (local >= tab.cap[c]) { *overflow = 1; return; }
+    float4 *out = reinterpret_cast<float4 *>(tab.rows[c] + local * 16);
+    out[0] = src[0]; out[1] = src[1]; out[2] = src[2]; out[3] = src[3];
+}
+
 }  // namespace
+
+extern "C" int mtgs_dp_touched_pack_chunks(int64_t n_rows, const float *rows, int64_t N, uint64_t *scratch_words, uint64_t *out_words,
+                                           uint32_t *out_prefix, int32_t *out_count, int64_t *totals, uint32_t *block_counts,
+                                           const mtgs_dp_chunks *chunks, int32_t *overflow, void *stream) {
+    MTGS_REQUIRE(n_rows >= 0 && N >= 0 && N < ((int64_t)1 << 31), MTGS_EINVAL, "mtgs_dp_touched_pack_chunks: bad sizes");
+    MTGS_REQUIRE(scratch_words && out_words && out_prefix && out_count && totals && block_counts && chunks && overflow &&
+                     (n_rows == 0 || rows), MTGS_EINVAL, "mtgs_dp_touched_pack_chunks: null pointer");
+    MTGS_REQUIRE(chunks->n >= 1 && chunks->n <= MTGS_DP_MAX_CHUNKS, MTGS_EINVAL, "mtgs_dp_touched_pack_chunks: %d chunks (1..%d)", chunks->n,
+                 MTGS_DP_MAX_CHUNKS);
+    DpChunkTab tab;
+    tab.n = chunks->n;
+    for (int c = 0; c <= chunks->n; ++c) {
+        const int64_t b = chunks->begin[c];
+        MTGS_REQUIRE(b >= 0 && b <= N && (c == 0 ? b == 0 : b >= chunks->begin[c - 1]) && (c == chunks->n ? b == N : (b % 64) == 0), MTGS_EINVAL,
+                     "mtgs_dp_touched_pack_chunks: chunk boundary %d = %lld (ascending multiples of 64 from 0 to N = %lld)", c, (long long)b,
+                     (long long)N);
+        tab.begin[c] = b;
+    }
+    for (int c = 0; c < chunks->n; ++c) {
+        MTGS_REQUIRE(chunks->cap[c] >= 0 && (chunks->cap[c] == 0 || chunks->rows[c]) &&
+                         (reinterpret_cast<uintptr_t>(chunks->rows[c]) & 15) == 0, MTGS_EINVAL,
+                     "mtgs_dp_touched_pack_chunks: chunk %d: capacity %lld, rows %p (16-byte aligned)", c, (long long)chunks->cap[c],
+                     (void *)chunks->rows[c]);
+        tab.rows[c] = chunks->rows[c];
+        tab.cap[c] = chunks->cap[c];
+    }
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(rows) & 15) == 0, MTGS_EINVAL, "mtgs_dp_touched_pack_chunks: rows must be 16-byte aligned");
+    const int64_t nw = (N + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = mtgs_zero_async(overflow, sizeof(int32_t), st)) return rc;
+    if (nw == 0) return mtgs_zero_async(out_count, sizeof(int32_t), st);
+    if (int rc = mtgs_zero_async(scratch_words, (size_t)nw * 8, st)) return rc;
+    if (n_rows > 0)
+        dp_touched_words_kernel<<<(unsigned)ceil_div64(n_rows, TOUCH_BLOCK), TOUCH_BLOCK, 0, st>>>(n_rows, rows, (unsigned long long *)scratch_words);
+    const unsigned grid = (unsigned)ceil_div64(nw, UNION_BLOCK);
+    dp_touched_count_kernel<<<grid, UNION_BLOCK, 0, st>>>(nw, (const unsigned long long *)scratch_words, (unsigned long long *)out_words, block_counts);
+    dp_union_prefix_kernel<<<dim3(grid, 1), UNION_BLOCK, 0, st>>>(nw, (const unsigned long long *)out_words, block_counts, out_prefix, totals);
+    dp_touched_rows_chunks_kernel<<<(unsigned)ceil_div64(n_rows > 0 ? n_rows : 1, TOUCH_BLOCK), TOUCH_BLOCK, 0, st>>>(
+        n_rows, rows, (const unsigned long long *)out_words, out_prefix, totals, tab, out_count, overflow);
+    MTGS_CHECK_LAUNCH("mtgs_dp_touched_pack_chunks");
+    return MTGS_OK;
+}
 
 extern "C" int mtgs_dp_touched_pack(int64_t n_rows, const float *rows, int64_t N, uint64_t *scratch_words, uint64_t *out_words,
                                     uint32_t *out_prefix, int32_t *out_count, int64_t *totals, uint32_t *block_counts,
@@ -761,7 +839,7 @@ extern "C" int mtgs_dp_reduce_rows(int W, int64_t N, int K, int degree, const fl
                      MTGS_EUNSUPPORTED, "mtgs_dp_reduce_rows: degree %d / K %d / stride %lld", degree, K, (long long)coef_stride);
         nb = (degree + 1) * (degree + 1);
     }
-    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64, 0};
     const DpRowOut R{geo_rows, (const unsigned long long *)geo_words, geo_prefix, geo_row_of, geo_ids, geo_cap,
                      coef_rows, (const unsigned long long *)coef_words, coef_prefix, coef_row_of, coef_cap};
     const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);
@@ -859,7 +937,7 @@ extern "C" int mtgs_dp_reduce_rows_groups(int W, int64_t N, int K, int degree, c
     MTGS_REQUIRE(degree >= 0 && degree <= 3 && K <= 16 && (degree + 1) * (degree + 1) <= K && coef_stride >= (int64_t)K * 3,
                  MTGS_EUNSUPPORTED, "mtgs_dp_reduce_rows_groups: degree %d / K %d / stride %lld", degree, K, (long long)coef_stride);
     const int nb = (degree + 1) * (degree + 1);
-    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64, 0};
     const DpRowOut R{geo_rows, (const unsigned long long *)geo_words, geo_prefix, geo_row_of, geo_ids, geo_cap, nullptr, nullptr, nullptr,
                      nullptr, 0};
     const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);
@@ -874,12 +952,14 @@ extern "C" int mtgs_dp_reduce_rows_groups(int W, int64_t N, int K, int degree, c
     return MTGS_OK;
 }
 
-extern "C" int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
-                                     const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
-                                     int64_t row_stride, const float *cams, float *v_means, float *v_quats,
-                                     float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
-                                     uint64_t coeff_mask, int write_geometry, int64_t coeff_stride, void *stream) {
+extern "C" int mtgs_dp_reduce_slices_cap(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                                         const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
+                                         int64_t row_stride, int64_t row_cap, const float *cams, float *v_means, float *v_quats,
+                                         float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
+                                         uint64_t coeff_mask, int write_geometry, int64_t coeff_stride, void *stream) {
     MTGS_REQUIRE(W >= 1 && N >= 0 && map_stride_bytes >= 0 && row_stride >= 0, MTGS_EINVAL, "mtgs_dp_reduce: bad sizes");
+    MTGS_REQUIRE(row_cap >= 0 && (row_cap == 0 || row_stride == 0 || row_cap <= row_stride / 16), MTGS_EINVAL,
+                 "mtgs_dp_reduce: row_cap %lld rows do not fit a block of %lld floats", (long long)row_cap, (long long)row_stride);
     MTGS_REQUIRE(W <= DP_MAX_SENDERS, MTGS_EUNSUPPORTED, "mtgs_dp_reduce: %d senders (at most %d; use mtgs_dp_accumulate)", W,
                  DP_MAX_SENDERS);
     if (g_end < 0) g_end = N;
@@ -901,7 +981,7 @@ extern "C" int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const 
         nb = (degree + 1) * (degree + 1);
     }
     MTGS_REQUIRE(means, MTGS_EINVAL, "mtgs_dp_reduce: null pointer");
-    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64};
+    const DpSenders S{(const unsigned long long *)words, prefix, map_stride_bytes, rows, row_stride, cams, W, g_begin / 64, row_cap};
     const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);  // one wave per 32-Gaussian tile
     hipStream_t st = (hipStream_t)stream;
     const unsigned long long cm = coeff_mask;
@@ -915,6 +995,15 @@ extern "C" int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const 
     }
     MTGS_CHECK_LAUNCH("mtgs_dp_reduce");
     return MTGS_OK;
+}
+
+extern "C" int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
+                                     const uint32_t *prefix, int64_t map_stride_bytes, const float *rows,
+                                     int64_t row_stride, const float *cams, float *v_means, float *v_quats,
+                                     float *v_scales, float *v_opacities, float *v_coeffs, int64_t g_begin, int64_t g_end,
+                                     uint64_t coeff_mask, int write_geometry, int64_t coeff_stride, void *stream) {
+    return mtgs_dp_reduce_slices_cap(W, N, K, degree, means, words, prefix, map_stride_bytes, rows, row_stride, 0, cams, v_means, v_quats,
+                                     v_scales, v_opacities, v_coeffs, g_begin, g_end, coeff_mask, write_geometry, coeff_stride, stream);
 }
 
 extern "C" int mtgs_dp_reduce(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,

@@ -134,6 +134,9 @@ _DP_GROUP = np.dtype([("mask", "<u8"), ("coef_rows", "<u8"), ("coef_words", "<u8
                       ("coef_cap", "<i8")])       # include/mtgs_rast.h: mtgs_dp_group
 
 
+_DP_CHUNKS = np.dtype([("n", "<i4"), ("_pad", "<i4"), ("begin", "<i8", (17,)), ("rows", "<u8", (16,)), ("cap", "<i8", (16,))])   # mtgs_dp_chunks
+
+
 class SparseGradExchange:
     """Sparse, factored replacement for the dense gradient all-reduce of view-parallel DP.
 
@@ -211,6 +214,10 @@ class SparseGradExchange:
         # only ever finishes that way sets defer_maps = True, and the front end's visibility maps are not all-gathered at all
         self.defer_maps = False
         self._touched = None
+        self._touched_chunks = None
+        self._chunk_words = None
+        self._recover = None     # the last frame finished through a truncating form: finish_recover() repeats it untruncated
+        self._keep = None
 
     # ---- integrated form -----------------------------------------------------------------------------------------
     def rasterization(self, means, quats, scales, opacities, sh_out, viewmats, Ks, width, height, cam_pos, near_plane=0.01,
@@ -242,7 +249,7 @@ class SparseGradExchange:
         """Drops a frame whose exchange was started (rasterization()) but never finished: waits -- on the side stream only --
         until the all-gather of its meta record no longer reads `self.meta`, which the next frame rewrites.  Forward-only
         callers (evaluation) call this instead of backward() + finish()."""
-        P, self._pending = self._pending, None
+        P, self._pending, self._recover = self._pending, None, None
         if P is not None and P.get("done") is not None:
             torch.cuda.current_stream().wait_event(P["done"])
 
@@ -312,7 +319,7 @@ class SparseGradExchange:
         import ctypes as _C
         P = self._pending
         assert P is not None and P["stage"] == "rows", "finish_touched() follows rasterization() + backward()"
-        self._pending = None
+        self._pending, self._recover = None, P       # (the frame stays recoverable -- finish_recover() -- until the next one starts)
         N, K, dev, world, nw, T = self.N, self.K, self.device, self.world, self.n_words, self.T
         assert len(traversal_of_rank) == world and all(0 <= int(t) < T for t in traversal_of_rank)
         cap = int(max(1, min(cap_rows, self.rows.shape[0])))
@@ -321,8 +328,8 @@ class SparseGradExchange:
         if P.get("done") is not None:
             torch.cuda.current_stream().wait_event(P["done"])      # (a frame that did all-gather its visibility maps: stream order only)
         pad = -(-self.meta_len // 16) * 16           # (every sender's block is a whole number of 64-byte rows)
-        L = cap * self.ROW + pad                     # [rows | meta]: the reduction's capacity guard (row_stride / 16 rows per sender)
-        #                                              then ends inside the sender's OWN block, never in the next sender's or past the buffer
+        L = cap * self.ROW + pad                     # [rows | meta]; the reduction reads at most `cap` rows of a block (row_cap): a sender
+        #                                              that overflowed never has its map words summed as floats
         m0 = cap * self.ROW                          # first int32 of the meta record inside a block
         tb = self._touched
         if tb is None or tb["send"].numel() != L:
@@ -357,17 +364,147 @@ class SparseGradExchange:
                torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
         self.phase = "exchange (touched): reduction"
         stride_b, stride_f = L * 4, L
-        if T == 1:
-            call("mtgs_dp_reduce", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), stride_b, ptr(rows_all),
-                 stride_f, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, st)
-        else:
-            masks = [sum(1 << r for r in range(world) if int(traversal_of_rank[r]) == t) for t in range(T)]
-            for t in range(T):
-                call("mtgs_dp_reduce_slices", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), stride_b,
-                     ptr(rows_all), stride_f, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
-                     out[4].data_ptr() + t * K * 3 * 4, 0, -1, _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
+        masks = [sum(1 << r for r in range(world) if int(traversal_of_rank[r]) == t) for t in range(T)]
+        for t in range(T):      # (T == 1: one pass, every sender)
+            call("mtgs_dp_reduce_slices_cap", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), stride_b,
+                 ptr(rows_all), stride_f, cap, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+                 out[4].data_ptr() + t * K * 3 * 4, 0, -1, _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
         self.phase = "idle"
         return out, overflow
+
+    # ---- the same exchange in CHUNKS of the index range: wire and reduction overlap, still no host read -------------------------
+    def touched_chunk_counts(self) -> torch.Tensor:
+        """Rows that carried a gradient in every index chunk of the LAST finish_touched_chunked() step (int64 [n_chunks], device):
+        what the per-chunk capacities are agreed from in a warm-up step (MAX over the ranks + a margin)."""
+        tb = self._touched_chunks
+        assert tb is not None, "finish_touched_chunked() first"
+        pre = tb["send0"].view(torch.int32)[4 + 2 * self.n_words:4 + 3 * self.n_words].to(torch.int64)
+        total = tb["send0"].view(torch.int32)[0:1].to(torch.int64)
+        starts = torch.cat([pre[self._chunk_words[:-1]], total])
+        return starts[1:] - starts[:-1]
+
+    def finish_touched_chunked(self, means: torch.Tensor, sh_degree: int, cap_rows: Sequence[int], traversal_of_rank: Sequence[int]):
+        """finish_touched() with the rows in `n_chunks` pieces of the Gaussian index range (the constructor's `chunks`), each its own
+        all-gather: the K collectives are issued back to back (they queue on the collective stream) and chunk c is reduced on the
+        main stream as soon as it has arrived, while chunks c + 1 .. are still on the wire -- the overlap finish() has, without its
+        host reads: capacities are static (cap_rows[c] rows of chunk c per rank, agreed in a warm-up step from
+        touched_chunk_counts()), counts and the overflow flag stay on the device, stream order is all that joins the collectives
+        and the reductions (async_op work handles: a stream wait under RCCL), so a HIP graph can hold the whole step.
+        The first message carries the sender's meta record (camera, traversal, the touched rows' map for the WHOLE range: 0.37 MB
+        at 2M Gaussians) in front of chunk 0's rows.  Rows are compacted in index order, so chunk c is a contiguous range of a
+        sender's touched rows; a chunk with more rows than its capacity sets `overflow` (device bool; finish_recover() repeats
+        the exchange untruncated).
+        Returns ((v_means, v_quats, v_scales, v_opacities, v_coeffs), overflow): bit-identical to finish_touched() (the same rows
+        meet every Gaussian in the same sender order)."""
+        from ._lib import call, ptr, stream_of
+        import ctypes as _C
+        P = self._pending
+        assert P is not None and P["stage"] == "rows", "finish_touched_chunked() follows rasterization() + backward()"
+        self._pending, self._recover = None, P
+        N, K, dev, world, nw, T, nch = self.N, self.K, self.device, self.world, self.n_words, self.T, self.n_chunks
+        assert len(traversal_of_rank) == world and all(0 <= int(t) < T for t in traversal_of_rank)
+        assert len(cap_rows) == nch and nch <= 16, (len(cap_rows), nch)
+        caps = [int(max(1, min(int(c), self.rows.shape[0]))) for c in cap_rows]
+        means = means.detach().contiguous()
+        st = stream_of(means)
+        if P.get("done") is not None:
+            torch.cuda.current_stream().wait_event(P["done"])
+        lay = self.chunk_layout(caps)
+        pad = lay["pad"]                              # the meta record, padded to whole 64-byte rows, leads message 0
+        tb = self._touched_chunks
+        if tb is None or tb["caps"] != caps:
+            sends = [torch.zeros(n, dtype=torch.float32, device=dev) for n in lay["floats"]]
+            tab = np.zeros(1, dtype=_DP_CHUNKS)
+            tab["n"] = nch
+            tab["begin"][0, :nch + 1] = self.bounds
+            for c in range(nch):
+                tab["rows"][0, c] = sends[c].data_ptr() + (pad * 4 if c == 0 else 0)
+                tab["cap"][0, c] = caps[c]
+            tb = self._touched_chunks = {"caps": caps, "sends": sends, "send0": sends[0], "tab": tab,
+                                         "scratch": torch.empty(max(nw, 1), dtype=torch.int64, device=dev),
+                                         "blocks": torch.empty(max(nw, 1) // 256 + 2, dtype=torch.int32, device=dev),
+                                         "totals": torch.zeros(1, dtype=torch.int64, device=dev)}
+            self._chunk_words = torch.tensor([min(b // 64, max(nw - 1, 0)) for b in self.bounds], dtype=torch.int64, device=dev)
+        sends, send0 = tb["sends"], tb["send0"]
+        s0i = send0.view(torch.int32)
+        self.phase = "exchange (touched, chunked): compaction of the rows that carry a gradient"
+        s0i[1:4].copy_(self.meta[1:4])                                                        # camera position
+        s0i[self.meta_len - 2:self.meta_len - 1].copy_(self.meta[self.meta_len - 2:self.meta_len - 1])      # traversal
+        mb = send0.data_ptr()
+        call("mtgs_dp_touched_pack_chunks", int(self.n_vis), ptr(self.rows), N, ptr(tb["scratch"]), mb + 16, mb + 16 + 8 * nw, mb,
+             ptr(tb["totals"]), ptr(tb["blocks"]), tb["tab"].ctypes.data, mb + 4 * (self.meta_len - 1), st)
+        self.touched_count = s0i[0]
+        collectives = world > 1 or self.world_collectives
+        works, recvs = self.gather_chunk_messages(sends)
+        out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
+               torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+               torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
+        masks = [sum(1 << r for r in range(world) if int(traversal_of_rank[r]) == t) for t in range(T)]
+        r0 = recvs[0]
+        r0i = r0.view(torch.int32)
+        stride0_b = r0.shape[1] * 4
+        cams = None
+        for c in range(nch):
+            self.phase = f"exchange (touched, chunked): wire + reduction of chunk {c} of {nch}"
+            if works[c] is not None:
+                works[c].wait()
+            if c == 0:
+                cams = r0[:, 1:4].contiguous()
+            rows_c = recvs[c][:, pad:] if c == 0 else recvs[c]
+            for t in range(T):
+                call("mtgs_dp_reduce_slices_cap", world, N, K, int(sh_degree), ptr(means), r0i.data_ptr() + 16, r0i.data_ptr() + 16 + 8 * nw,
+                     stride0_b, rows_c.data_ptr(), recvs[c].shape[1] if collectives else 0, caps[c], ptr(cams), ptr(out[0]), ptr(out[1]),
+                     ptr(out[2]), ptr(out[3]), out[4].data_ptr() + t * K * 3 * 4, self.bounds[c], self.bounds[c + 1],
+                     _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
+        overflow = (r0i[:, self.meta_len - 1] != 0).any()
+        self._keep = (recvs, works)      # (the receive buffers stay referenced until the next step: the collective stream may still own them)
+        self.phase = "idle"
+        return out, overflow
+
+    def chunk_layout(self, caps: Sequence[int]) -> dict:
+        """Messages of finish_touched_chunked(): message 0 = [meta record padded to `pad` floats | caps[0] rows], message c = caps[c]
+        rows; "floats"[c] = length of message c, "row0"[c] = first float of its rows.  A pure function of the capacities (identical
+        on every rank once they are agreed), which is what makes the ranks' collectives match without a host exchange per step."""
+        pad = -(-self.meta_len // 16) * 16
+        caps = [int(c) for c in caps]
+        return {"pad": pad, "floats": [pad + caps[0] * self.ROW] + [c * self.ROW for c in caps[1:]], "row0": [pad] + [0] * (len(caps) - 1)}
+
+    def gather_chunk_messages(self, sends: Sequence[torch.Tensor]):
+        """Every chunk message's all-gather, issued back to back (async: they queue on the collective stream / the gloo thread).
+        Returns (works, recvs[c] [world, len(message c)]); a single rank without `world_collectives` short-cuts to views."""
+        works, recvs = [], []
+        self.last_bytes = 0
+        for c, s in enumerate(sends):
+            self.phase = f"exchange (touched, chunked): issuing the all-gather of chunk {c} of {len(sends)} ({s.numel() * 4} bytes per rank)"
+            if self.world > 1 or self.world_collectives:
+                recv = torch.empty((self.world, s.numel()), dtype=s.dtype, device=s.device)
+                works.append(dist.all_gather_into_tensor(recv.view(-1), s, group=self.group, async_op=True))
+                self.last_bytes += recv.numel() * 4
+            else:
+                recv = s[None]
+                works.append(None)
+            recvs.append(recv)
+        return works, recvs
+
+    def finish_recover(self, means: torch.Tensor, sh_degree: int, rows: bool = False, all_colour_ranges=()):
+        """After finish_touched() / finish_touched_chunked() / finish_static() reported `overflow` (the caller read the device flag):
+        repeat the step's exchange UNTRUNCATED through finish(), from the rows buffer those forms leave untouched.  A frame whose
+        visibility maps were never exchanged (defer_maps) all-gathers them now (blocking: this is the rare path).  Collective:
+        every rank calls it (the overflow flag is the same on every rank -- it is computed from all-gathered counts)."""
+        P = self._recover
+        assert P is not None and P.get("stage") == "rows", "finish_recover() follows a finish_*() of the same frame"
+        if P.get("metas") is None:
+            if self.world > 1 or self.world_collectives:
+                metas = torch.empty((self.world, self.meta_len), dtype=torch.int32, device=self.device)
+                dist.all_gather_into_tensor(metas, self.meta[None].contiguous(), group=self.group)
+            else:
+                metas = self.meta[None]
+            self._samples_host.copy_(metas[:, self._sample_idx])      # (blocking copy to pinned memory)
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().synchronize()
+            P.update(metas=metas, done=None)
+        self._pending, self._recover = P, None
+        return self.finish(means, sh_degree, rows=rows, all_colour_ranges=all_colour_ranges)
 
     def finish_static(self, means: torch.Tensor, sh_degree: int, cap_rows: int, traversal_of_rank: Sequence[int]):
         """finish() WITHOUT any host read or host wait -- the form a HIP graph can capture (with RCCL; the dynamic form sizes
@@ -384,7 +521,7 @@ class SparseGradExchange:
         import ctypes as _C
         P = self._pending
         assert P is not None and P["stage"] == "rows", "finish_static() follows rasterization() + backward()"
-        self._pending = None
+        self._pending, self._recover = None, P
         N, K, dev, world, nw, T = self.N, self.K, self.device, self.world, self.n_words, self.T
         assert len(traversal_of_rank) == world and all(0 <= int(t) < T for t in traversal_of_rank)
         cap = int(max(1, min(cap_rows, self.rows.shape[0])))

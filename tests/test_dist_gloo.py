@@ -219,3 +219,103 @@ def test_sparse_exchange_bookkeeping_over_gloo(tmp_path, world):
     outs = [np.load(tmp_path / f"sparse{r}.npy") for r in range(world)]
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
+
+
+# ---- the chunked, overlapped touched exchange (SparseGradExchange.finish_touched_chunked): its wire layout over gloo, CPU tensors ------
+def _touched_inputs(rank, N, T):
+    """_sparse_inputs with ~60 % of the visible rows exactly zero (hidden behind others: no gradient), the touched rows' map
+    (mtgs_dp_touched_pack_chunks' output format = a visibility map of the rows that carry a gradient)."""
+    vis, idx, rows, _, _, cam, trav = _sparse_inputs(rank, N, T)
+    g = np.random.default_rng(500 + rank)
+    zero = g.random(idx.size) < 0.6
+    zero[idx >= 4096] = rank == 1                    # the last index chunk: rank 1 has nothing there, the others everything
+    rows[zero, :15] = 0.0
+    t_idx = idx[~zero]
+    nw = (N + 63) // 64
+    bits = np.zeros(nw * 64, dtype=np.uint8)
+    bits[t_idx] = 1
+    words = np.packbits(bits.reshape(nw, 64), axis=1, bitorder="little").view(np.uint64).reshape(nw)
+    prefix = np.concatenate([[0], np.cumsum(bits.reshape(nw, 64).sum(1))[:-1]]).astype(np.uint32)
+    return t_idx, rows[~zero], words, prefix, cam, trav
+
+
+def _chunked_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, str(ROOT))
+    from mtgs_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    N, T, K = 5000, 2, 16
+    ex = mdist.SparseGradExchange(N, K, "cpu", chunks=3, traversals=T)
+    nw, nch, bounds = ex.n_words, ex.n_chunks, ex.bounds
+    t_idx, t_rows, words, prefix, cam, trav = _touched_inputs(rank, N, T)
+    # warm-up agreement: per-chunk counts -> MAX over the ranks + a margin (what bench.py does with touched_chunk_counts())
+    counts = np.array([int(((t_idx >= bounds[c]) & (t_idx < bounds[c + 1])).sum()) for c in range(nch)], dtype=np.float64)
+    starts = [int(prefix[bounds[c] // 64]) for c in range(nch)] + [t_idx.size]
+    assert [starts[c + 1] - starts[c] for c in range(nch)] == counts.astype(int).tolist()      # the device formula of touched_chunk_counts()
+    agreed = torch.from_numpy(counts.copy())
+    dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+    caps = [int(c) + 4 for c in agreed.tolist()]
+    lay = ex.chunk_layout(caps)
+    assert lay["pad"] % 16 == 0 and lay["pad"] >= ex.meta_len and lay["floats"][0] == lay["pad"] + caps[0] * 16
+    assert lay["floats"][1:] == [c * 16 for c in caps[1:]] and lay["row0"] == [lay["pad"], 0, 0]
+    # the sender's messages as mtgs_dp_touched_pack_chunks leaves them: meta record in front of chunk 0's rows, NaN slack behind the rows
+    sends = [np.full(n, np.nan, dtype=np.float32) for n in lay["floats"]]
+    meta = sends[0][:lay["pad"]].view(np.int32)
+    meta[:] = 0
+    meta[0] = t_idx.size
+    meta[1:4] = cam.view(np.int32)
+    meta[4:4 + 2 * nw] = words.view(np.int32)
+    meta[4 + 2 * nw:4 + 3 * nw] = prefix.view(np.int32)
+    meta[ex.meta_len - 2] = trav
+    for c in range(nch):
+        blk = sends[c][lay["row0"][c]:].reshape(caps[c], 16)
+        blk[:starts[c + 1] - starts[c]] = t_rows[starts[c]:starts[c + 1]]
+    works, recvs = ex.gather_chunk_messages([torch.from_numpy(s) for s in sends])
+    assert ex.last_bytes == world * 4 * sum(lay["floats"])
+    # a receiver reduces chunk c as soon as ITS message is there: wait in order, read only that chunk
+    others = [_touched_inputs(r, N, T) for r in range(world)]
+    dense = np.zeros((N, 15), dtype=np.float64)
+    metas = None
+    for c in range(nch):
+        works[c].wait()
+        got = recvs[c].numpy()
+        if c == 0:
+            metas = got[:, :lay["pad"]].copy().view(np.int32)
+        for r in range(world):
+            w64 = metas[r, 4:4 + 2 * nw].copy().view(np.uint64)
+            pre = metas[r, 4 + 2 * nw:4 + 3 * nw].copy().view(np.uint32)
+            assert metas[r, 0] == others[r][0].size and metas[r, ex.meta_len - 2] == others[r][5]
+            assert np.array_equal(metas[r, 1:4].view(np.float32), others[r][4])
+            rows_rc = got[r, lay["row0"][c]:].reshape(caps[c], 16)
+            start_rc = int(pre[bounds[c] // 64])                        # dp_reduce_kernel: prefix[word0]
+            ids = others[r][0]
+            for n in ids[(ids >= bounds[c]) & (ids < bounds[c + 1])]:
+                word, bit = int(w64[n >> 6]), int(n & 63)
+                assert (word >> bit) & 1
+                k = int(pre[n >> 6]) + bin(word & ((1 << bit) - 1)).count("1") - start_rc
+                assert 0 <= k < caps[c]                                   # (row_cap: never past the chunk's rows)
+                row = rows_rc[k]
+                assert int(row[15:16].view(np.int32)[0]) == n and not np.isnan(row[:15]).any()
+                dense[n] += row[:15]
+    ref = np.zeros((N, 15), dtype=np.float64)
+    for (ids, rws, *_r) in others:
+        ref[ids] += rws[:, :15]
+    assert np.array_equal(dense, ref)
+    np.save(Path(out_dir) / f"chunked{rank}.npy", dense)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_touched_chunked_exchange_layout_over_gloo(tmp_path, world):
+    """finish_touched_chunked()'s wire protocol with `world` ranks over gloo on CPU tensors: per-chunk capacities agreed from the
+    ranks' counts (MAX + margin), chunk_layout() -> one message per index chunk (the meta record with the touched rows' map leads
+    message 0), gather_chunk_messages() issues them back to back, and a receiver that waits for message c alone finds every
+    sender's row of every touched Gaussian of chunk c at row prefix(n) - prefix(first word of the chunk) of that message -- the
+    address rule of mtgs_dp_reduce_slices_cap; sums equal the accumulation over all cameras, ranks agree bit for bit.  (The
+    kernels on both sides run on the GPU: tests/test_gpu_dp.py.)"""
+    port = _free_port()
+    mp.spawn(_chunked_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"chunked{r}.npy") for r in range(world)]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)

@@ -316,6 +316,66 @@ def _worker_traversals(rank, world, port, out_dir):
                 assert torch.equal(got, ref), rank
         else:
             assert all(bool(torch.isfinite(o).all()) for o in out_t)
+            # the overflow's recovery through the PUBLIC API: the frame is still there, finish_recover() gathers the
+            # visibility maps this frame never exchanged (defer_maps) and repeats the exchange untruncated: finish()'s sums
+            out_r = ex.finish_recover(P["means"], 3)
+            torch.cuda.synchronize()
+            for got, ref in zip(out_r, (g_means, g_quats, g_scales, g_opac, g_coeffs)):
+                assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-7, rank
+    # A sender that overflows must not have the words BEHIND its rows summed as floats (the block is [rows | map], and a
+    # map word of all-one bits is a NaN): every Gaussian visible AND touched makes the map dense, the capacity is far too small.
+    r5, a5, _ = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm, Kmat, W, H, cam_pos, traversal=t)
+    torch.autograd.backward([r5, a5], [Gc, Ga])
+    ex.rows[:N, :14] = 1.0                                  # every row "carries a gradient" ...
+    ex.rows[:N, 15] = torch.arange(N, device=dev, dtype=torch.int32).view(torch.float32)     # ... of Gaussian n: dense all-ones map words
+    ex.n_vis = N
+    out_p, ovf = ex.finish_touched(P["means"], 3, 64, [q % T for q in range(world)])
+    torch.cuda.synchronize()
+    assert bool(ovf) and all(bool(torch.isfinite(o).all()) for o in out_p), rank
+    assert float(out_p[0].abs().max()) <= world, rank       # (sums of the 1.0 rows: nothing else was read)
+    # finish_touched_chunked(): the same rows in index chunks, one all-gather per chunk issued back to back, chunk c reduced while
+    # c + 1 is on the wire; bit-identical to finish_touched(); per-chunk capacities from a warm-up step's counts (MAX over ranks);
+    # then one chunk too small: the overflow flag, finite sums, and the recovery
+    exc = mdist.SparseGradExchange(N, K, dev, traversals=T, chunks=3)
+    exc.defer_maps = True
+    trav = [q % T for q in range(world)]
+
+    def frame(e):
+        rr, aa, _ = e.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm, Kmat, W, H, cam_pos, traversal=t)
+        torch.autograd.backward([rr, aa], [Gc, Ga])
+    frame(exc)
+    _, ovf0 = exc.finish_touched_chunked(P["means"], 3, [N] * exc.n_chunks, trav)      # warm-up: generous capacities
+    cnt = exc.touched_chunk_counts().to(torch.float64)
+    assert not bool(ovf0) and int(cnt.sum()) == int(exc.touched_count) and exc.n_chunks == 3
+    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+    caps = [int(c) + 8 for c in cnt.tolist()]
+    frame(exc)
+    out_c, ovf_c = exc.finish_touched_chunked(P["means"], 3, caps, trav)
+    lay = exc.chunk_layout(caps)
+    assert exc.last_bytes == world * 4 * sum(lay["floats"])
+    frame(exc)
+    out_1, ovf_1 = exc.finish_touched(P["means"], 3, N, trav)
+    torch.cuda.synchronize()
+    assert not bool(ovf_c) and not bool(ovf_1)
+    for got, ref in zip(out_c, out_1):
+        # (two frames: the compositing atomics may sum in another order -- the exchange itself adds nothing to that)
+        assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-7, rank
+    # same frame, both forms: BIT identity (the chunked form re-reads the rows buffer the unchunked one left untouched)
+    exc._pending = dict(exc._recover)
+    out_c2, _ = exc.finish_touched_chunked(P["means"], 3, caps, trav)
+    torch.cuda.synchronize()
+    for got, ref in zip(out_c2, out_1):
+        assert torch.equal(got, ref), rank
+    small = list(caps)
+    small[1] = 4
+    frame(exc)
+    out_o, ovf_o = exc.finish_touched_chunked(P["means"], 3, small, trav)
+    torch.cuda.synchronize()
+    assert bool(ovf_o) and all(bool(torch.isfinite(o).all()) for o in out_o), rank
+    out_r = exc.finish_recover(P["means"], 3)
+    torch.cuda.synchronize()
+    for got, ref in zip(out_r, out_1):
+        assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-7, rank
     dist.barrier()
     dist.destroy_process_group()
 
@@ -596,6 +656,12 @@ def _worker_nccl_world1(out_path):
     sums_t, ovf = ex.finish_touched(P["means"], 3, N, [0])
     torch.cuda.synchronize()
     same = all(float((x - y).abs().max()) <= 3e-5 * float(y.abs().max()) + 1e-7 for x, y in zip(sums_t, sums))
+    # ... and its chunked, overlapped form: two RCCL all-gathers issued back to back, the reductions joined by stream order alone
+    r3, a3, _ = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm.to(dev), Kmat.to(dev), W, H, cam_pos)
+    torch.autograd.backward([r3, a3], [Gc, Ga])
+    sums_c, ovf_c = ex.finish_touched_chunked(P["means"], 3, [N] * ex.n_chunks, [0])
+    torch.cuda.synchronize()
+    same = same and all(float((x - y).abs().max()) <= 3e-5 * float(y.abs().max()) + 1e-7 for x, y in zip(sums_c, sums)) and not bool(ovf_c)
     ok = bool(torch.isfinite(sums[0]).all()) and float(t.sum()) == 1024.0 and float(sums[0].abs().max()) > 0 and same and not bool(ovf) \
         and ex.last_bytes > 0
     ver = ".".join(str(v) for v in torch.cuda.nccl.version())
