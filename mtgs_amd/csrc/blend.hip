@@ -35,9 +35,10 @@
 #include "wave_reduce.hpp"
 #include "raster_rec.hpp"
 
-// Development hooks (candidate / slot counters of the backward, the MTGS_PPL override of kbench.py's sweeps) live in
-// dev/blend_dev.hpp and exist in VARIANT builds only (scripts/build_variant.py NAME -DMTGS_DEV [-DMTGS_COUNT]): the product
-// library compiles the three hook sites below to nothing.
+// Development hooks (candidate / slot counters of the backward, the MTGS_PPL override of kbench.py's sweeps, the per-tile timeline
+// of round 6 and its ablation switches) live in dev/blend_dev.hpp and exist in VARIANT builds only
+// (scripts/build_variant.py NAME -DMTGS_DEV [-DMTGS_COUNT | -DMTGS_TIMELINE | -DMTGS_ABL_NOREDUCE ...]): the product library
+// compiles the hook sites below to nothing.
 #ifdef MTGS_DEV
 #include "dev/blend_dev.hpp"
 #else
@@ -595,8 +596,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_touch_kernel(int C, const flo
 // that the 12 lanes of an entry's atomic instruction fall into a single 64-byte line: measured 0.06 ns per
 // (instruction x line) chip-wide, i.e. 638 us for this kernel's ~2M instructions on six dense arrays against
 // 126 us on one line (scripts/dev/atomic_bench.hip) -- the atomics, not VALU, bounded the dense layout.
-struct GradRowBytes { uint32_t means2d, means2d_abs, conics, colors, depths, opacities;
-                      uint32_t pk_shift; };   // packed rows: log2 of the row stride in bytes when it is a power of two, else 0
+struct GradRowBytes { uint32_t means2d, means2d_abs, conics, colors, depths, opacities; };
 
 // Gradient components per Gaussian, in reduction order: xy(2) |xy|(2) conic(3) opacity(1) colour(D)
 template <int D>
@@ -610,16 +610,9 @@ struct GradLayout {
 #ifndef MTGS_BWD_WAVES
 #define MTGS_BWD_WAVES 4
 #endif
-// Round 6: the packed one-wave-per-tile backward (the headline's kernel) in its LEAN form -- one record register set refilled
-// behind the pixel slots, the gradient row's index fetched in the epilogue, the atomic addressed as (uniform base) + 32-bit lane
-// offset -- needs <= 96 VGPRs: FIVE waves per SIMD instead of four (107 VGPRs).  profiles/r06_valu_ceiling.md: the kernel's
-// cycles per VALU instruction follow the resident waves (one wave issues at most every ~5.4 cycles, whatever it issues).
-#ifndef MTGS_BWD_LEAN_WAVES
-#define MTGS_BWD_LEAN_WAVES 5
-#endif
 
 template <int D, int PPL, bool PK>
-__global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LEAN_WAVES : MTGS_BWD_WAVES) : 1) void blend_bwd_kernel(
+__global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? MTGS_BWD_WAVES : 1) void blend_bwd_kernel(
     int C, const float *__restrict__ recs, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ backgrounds, const float *__restrict__ depths, int DC, int ed, int W, int H,
@@ -633,11 +626,9 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
     constexpr bool CULL = true;
     constexpr int CAND = NT == 64 ? 128 : 256, NRD = CAND / NT;
     constexpr int NV = GradLayout<D>::NV, NR = GradLayout<D>::NR;
-    // LEAN (packed records, one wave per tile): see MTGS_BWD_LEAN_WAVES
-    constexpr bool LEAN = PK && NT == 64;
     MTGS_TL_DECL();
     auto zero_slice = [&]() { zero_fill_slice<NT>(zf); MTGS_TL_END(1); };      // this wave's slice of the caller's region (see ZeroFill)
-    __shared__ __attribute__((aligned(16))) float s_rec[(CAND + (LEAN ? 1 : 0)) * REC];   // (LEAN: the refill behind the last entry reads one record on)
+    __shared__ __attribute__((aligned(16))) float s_rec[CAND * REC];
     __shared__ int32_t s_id[CAND];
     __shared__ int32_t s_max[NT / 64];
     __shared__ int s_wc[NT / 64];
@@ -715,10 +706,7 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
     const int j = BATCH_FLUSH ? (tid & 15) : j_red;
     float *a_base = nullptr;
     uint32_t a_stride_bytes = 0;
-    int32_t a_off = -1;     // LEAN: byte offset of this lane's component inside a gradient row (component j at float j), -1: none
-    if (LEAN) {
-        if (red_lane && j < NV && (v_means2d_abs != nullptr || j < 2 || j >= 4)) a_off = 4 * j;
-    } else if ((BATCH_FLUSH || red_lane) && j < NV) {
+    if ((BATCH_FLUSH || red_lane) && j < NV) {
         if (j < 2) { a_base = v_means2d + j; a_stride_bytes = gs.means2d; }
         else if (j < 4) { a_base = v_means2d_abs ? v_means2d_abs + (j - 2) : nullptr; a_stride_bytes = gs.means2d_abs; }
         else if (j < 7) { a_base = v_conics + (j - 4); a_stride_bytes = gs.conics; }
@@ -753,15 +741,6 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
         // (a VGPR shared by the two entries of an iteration: every LDS read of the loop is `va` / `vi` + an immediate),
         // CLAMP = false: no candidate of the batch can reach alpha = 0.999 (stage_batch), so the clamp and the mask of
         // its gradient are compiled out.
-        // LEAN: ONE record register set.  The next entry's record is read into it behind the current entry's pixel slots (its
-        // last readers), so that the LDS latency runs under the epilogue's reduction; the A / B double set of the other forms
-        // keeps eight more registers live through the slots.
-        f32x4 lean_q0, lean_q1;
-        auto lean_refill = [&lean_q0, &lean_q1](const uint32_t va, auto off_tag) {
-            constexpr int OFFB = decltype(off_tag)::value;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lean_q0) : "v"(va), "n"(OFFB));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lean_q1) : "v"(va), "n"(OFFB + 16));
-        };
         auto entry = [&](const float4 &r0, const float4 &r1, const int t, const uint32_t va, const uint32_t vi, auto off_tag,
                          auto clamp_tag) {
             constexpr int OFF = decltype(off_tag)::value;
@@ -770,8 +749,8 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
             // (the anchor of the hand-issued loads is the lane's first pixel y: the validity test below depends on it, so
             //  the scheduler cannot sink the loads under the test, and no copy of a record register is needed)
             col.template load_at<OFF * REC * 4>(va, py[0]);
-            int32_t gid;  // Gaussian row for the atomics at the end of the entry, fetched the same way (LEAN: in the epilogue)
-            if constexpr (!LEAN) asm volatile("ds_read_b32 %0, %2 offset:%3" : "=v"(gid), "+v"(py[0]) : "v"(vi), "n"(OFF * 4));
+            int32_t gid;  // Gaussian row for the atomics at the end of the entry, fetched the same way
+            asm volatile("ds_read_b32 %0, %2 offset:%3" : "=v"(gid), "+v"(py[0]) : "v"(vi), "n"(OFF * 4));
             const int32_t idx = __float_as_int(r1.w);
             const float opac = r1.y;
             const float dx = r0.x - px;
@@ -788,12 +767,9 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
                 any |= vmask[p];
             }
             col.wait();
-            if constexpr (!LEAN) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gid));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gid));
             MTGS_COUNT_ADD(0, 1);
-            if (any == 0) {
-                if constexpr (LEAN) lean_refill(va, std::integral_constant<int, REC * 4>{});
-                return;
-            }
+            if (any == 0) return;
             MTGS_COUNT_ADD(1, 1);
             MTGS_COUNT_SLOTS(vmask);
             MTGS_TL_ACTIVE();
@@ -815,10 +791,18 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
                 // saves the select but costs the explicit zeroing of ten accumulators per entry: measured worse).
                 if (vmask[p] != 0) {
                     const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmask[p]);
+#if defined(MTGS_DEV) && defined(MTGS_ABL_NOTRANS)       // (ablation: the two transcendentals of a slot replaced by plain VALU)
+                    const float vis = valid ? (0.25f - 1e-3f * s2[p]) : 0.f;
+#else
                     const float vis = valid ? __builtin_amdgcn_exp2f(-s2[p]) : 0.f;
+#endif
                     const float alpha_raw = alpha_rounded(opac, vis);
                     const float alpha = CLAMP ? fminf(kAlphaMax, alpha_raw) : alpha_raw;
+#if defined(MTGS_DEV) && defined(MTGS_ABL_NOTRANS)
+                    const float ra = 1.0f + alpha;
+#else
                     const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+#endif
                     T[p] *= ra;
                     const float fac = alpha * T[p];
                     float A = 0.f;  // <colour of this Gaussian, vr>
@@ -843,14 +827,6 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
                     if (!PK) gv[7] += vis * g;
                 }
             }
-            if constexpr (LEAN) {
-                // the slots were the last readers of this entry's record: refill the register set with the next one, then fetch
-                // the gradient row's index -- both land while the reduction below runs
-                lean_refill(va, std::integral_constant<int, REC * 4>{});
-                uint32_t vt;
-                asm volatile("v_mov_b32 %0, %1" : "=v"(vt) : "s"(lds_offset(s_id) + (uint32_t)t * 4u));
-                asm volatile("ds_read_b32 %0, %1" : "=v"(gid) : "v"(vt));
-            }
             if (PK) {
                 // RAW MOMENTS of h over the tile: {sum h dx, sum h dy | k sum |h u|, k sum |h w| | sum h dx^2, sum h dx dy, sum h dy^2 | sum h}
                 // (k = log2(e)/2 rides on the staged conic: the consumer of the rows divides it out, rows_to_gradients)
@@ -872,6 +848,12 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
                 gv[6] = 0.5f * S2;
             }
             float val;
+#if defined(MTGS_DEV) && defined(MTGS_ABL_NOREDUCE)      // (round-6 ablation: what the cross-lane reduction costs -- profiles/r06_valu_ceiling.md)
+            val = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4 * NR; ++k) val += gv[k];
+            if (false)
+#endif
             if constexpr (PACKED) {
                 val = wave_reduce_x4_packed<NR>(gv);
             } else {
@@ -881,25 +863,16 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
 #pragma unroll
                 for (int i = 1; i < NR; ++i) val = (a_col == i) ? red[i] : val;
             }
-            if constexpr (LEAN) {
-                // ONE atomic instruction per (tile, Gaussian): uniform base + 32-bit lane offset (row << shift | component)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gid));
-                if (a_off >= 0) {
-                    char *rows = reinterpret_cast<char *>(v_means2d);
-                    if (gs.pk_shift) {
-                        const uint32_t off = ((uint32_t)gid << gs.pk_shift) + (uint32_t)a_off;
-                        unsafeAtomicAdd(reinterpret_cast<float *>(rows + off), val);
-                    } else {
-                        const uint32_t off = (uint32_t)gid * gs.means2d + (uint32_t)a_off;
-                        unsafeAtomicAdd(reinterpret_cast<float *>(rows + off), val);
-                    }
-                }
-            } else if (BATCH_FLUSH) {
+            if (BATCH_FLUSH) {
                 if (red_lane && j_red < 16) s_grad[((tid >> 6) * CAND + t) * 16 + j_red] = val;
             } else {
                 // (what the atomics cost was measured with two experimental builds, since removed: none at all 423 -> 411 us,
                 //  plain stores 424 us -- DESIGN.md section 4)
+#if defined(MTGS_DEV) && defined(MTGS_ABL_NOATOMIC)
+                if (a_base && val == 1.2345e-30f) unsafeAtomicAdd(row_address(a_base, (uint32_t)gid, a_stride_bytes), val);
+#else
                 if (a_base) unsafeAtomicAdd(row_address(a_base, (uint32_t)gid, a_stride_bytes), val);
+#endif
             }
         };
         // Entries are consumed two per iteration from two alternating register sets (A, B): the record of the
@@ -915,17 +888,6 @@ __global__ __launch_bounds__(256 / PPL, (PPL == 4 && D <= 4) ? (PK ? MTGS_BWD_LE
             };
             uint32_t va, vi;
             asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0));
-            if constexpr (LEAN) {
-                lean_refill(va, Z{});
-                for (int t = 0; t < bsz; ++t) {
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0 + (uint32_t)t * (REC * 4)));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lean_q0), "+v"(lean_q1));
-                    const float4 r0 = make_float4(lean_q0.x, lean_q0.y, lean_q0.z, lean_q0.w);
-                    const float4 r1 = make_float4(lean_q1.x, lean_q1.y, lean_q1.z, lean_q1.w);
-                    entry(r0, r1, t, va, 0u, Z{}, clamp_tag);
-                }
-                return;
-            }
             float4 ra0 = rec_at(va, 0), ra1 = rec_at(va, 1), rb0 = ra0, rb1 = ra1;
             for (int t = 0; t < bsz; t += 2) {
                 asm volatile("v_mov_b32 %0, %1" : "=v"(va) : "s"(rec0 + (uint32_t)t * (REC * 4)));
@@ -1124,7 +1086,7 @@ extern "C" int mtgs_blend_bwd(int C, int64_t N, int D, const float *means2d, con
                      "mtgs_blend_bwd: grad_row_strides[%d]=%lld (row width %lld)", i, (long long)rs, (long long)min_w[i]);
         sb[i] = (uint32_t)(rs * 4);
     }
-    const GradRowBytes gs{sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], 0u};
+    const GradRowBytes gs{sb[0], sb[1], sb[2], sb[3], sb[4], sb[5]};
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
     MTGS_DISPATCH_D(launch_bwd, C, nullptr, means2d, conics, colors, opacities, backgrounds, depths, D, ed_normalize, width,
                     height, tile_w, tile_h, offsets, flatten_ids, M, alphas, last_ids, render, v_render, v_alphas,
@@ -1222,8 +1184,7 @@ extern "C" int mtgs_blend_bwd_packed(int C, int D, int with_depth, const float *
     hipStream_t st = (hipStream_t)stream;
     // rows: [xy 2 | |xy| 2 | conic 3 | opacity 1 | colour D | depth 1 | pad]
     const uint32_t sb = (uint32_t)(row_stride * 4);
-    const uint32_t shift = (sb & (sb - 1)) == 0 ? (uint32_t)__builtin_ctz(sb) : 0u;   // (rows of 16 floats: 6)
-    const GradRowBytes gs{sb, sb, sb, sb, sb, sb, shift};
+    const GradRowBytes gs{sb, sb, sb, sb, sb, sb};
     if (int rc = zero_fill_fallback(also_zero, also_zero_bytes, (int64_t)C * tile_w * tile_h, st)) return rc;
     const int ppl = pick_ppl((int64_t)C * tile_w * tile_h, DT, true);
     MTGS_DISPATCH_PK(launch_bwd, C, recs, nullptr, nullptr, nullptr, nullptr, backgrounds, nullptr, D, ed_normalize, width, height,

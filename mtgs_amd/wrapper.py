@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import contextlib
 import threading
 import time
 import weakref
@@ -55,10 +56,13 @@ def _strided_rows(t: Optional[Tensor], width: int):
 # ------------------------------------------------------------------------------------- SH
 class _ZeroRequest:
     """A [n, K, 3] buffer of zeros that a spherical_harmonics() backward will want (see _Prefill)."""
-    __slots__ = ("shape", "device", "buffer", "stream", "__weakref__")
+    __slots__ = ("shape", "device", "buffer", "stream", "thread", "fwd_stream", "__weakref__")
 
     def __init__(self, shape, device):
         self.shape, self.device, self.buffer, self.stream = tuple(shape), device, None, None
+        # where the spherical_harmonics() forward ran: only a rasterization on the same (thread, stream) serves the request
+        self.thread = threading.get_ident()
+        self.fwd_stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
 
 
 class _Prefill:
@@ -66,43 +70,81 @@ class _Prefill:
     [N, K, 3] -- 384 MB at the headline workload -- of which the rows of the ~6 % composited Gaussians are non-zero; writing it is
     what the SH backward costs (81 us, HBM-bound), and the zeros depend on nothing.  The compositing kernels of the rasterizer are
     VALU-bound and leave HBM ~85 % idle for 0.16 + 0.33 ms.  So: a spherical_harmonics() forward whose coefficients need a
-    gradient leaves a request here; the rasterization() forward that follows (when something needs a gradient) allocates the
-    buffers -- one region, plus the gradient rows its own compositing backward accumulates into -- and hands it to
-    mtgs_blend_fwd_packed(also_zero), whose waves clear a slice each when their tile is done; requests that only turn up later are
-    served the same way by the compositing backward.  The SH backward then only writes the non-zero rows (mtgs_sh_bwd_rows).  One
-    stream, nothing to join, nothing special inside a graph capture.  A request nobody serves -- spherical_harmonics() without the
-    rasterizer -- falls back to the one-kernel dense backward; a forward that is never differentiated has written zeros nobody
-    reads (~10 us).  Process-wide (autograd runs backward nodes on its own threads), weakly referenced."""
+    gradient leaves a request on its autograd node; the rasterization() forward whose `colors` DESCEND from that node (when something
+    needs a gradient) allocates the buffers -- one region, plus the gradient rows its own compositing backward accumulates into --
+    and hands it to mtgs_blend_fwd_packed(also_zero), whose waves clear a slice each when their tile is done; the SH backward then
+    only writes the non-zero rows (mtgs_sh_bwd_rows).  One stream, nothing to join, nothing special inside a graph capture.
+
+    SCOPE (round 6).  A request is served only by a rasterization
+      * whose colours are computed from that spherical_harmonics() output (found on the autograd graph behind `colors`:
+        clamp / add / cat / expand ... up to 64 nodes), and
+      * that runs on the thread and stream the SH forward ran on;
+    a second model on the device, an evaluation pass with gradients, a viewer thread never pay allocations or HBM writes for someone
+    else's backward.  A request nobody serves -- spherical_harmonics() without the rasterizer -- falls back to the one-kernel dense
+    backward and EXPIRES at the next spherical_harmonics() forward of the same shape on its thread; a forward that is never
+    differentiated has written zeros nobody reads (~10 us).
+    LIFETIME: every buffer served by one take() is a view of ONE region (the kernel clears one address range): the region stays
+    allocated while any of those dL/dcoeffs (a parameter's .grad) is alive -- with one model per rasterization that is the gradient
+    itself plus 64 bytes per visible Gaussian.  `max_region_bytes` bounds a region (larger requests take the dense backward).
+    Switches: `mtgs_amd.sh_prefill(enabled=..., in_forward=...)` (context manager); the environment variables MTGS_SH_PREFILL /
+    MTGS_PREFILL_IN_FORWARD only set the defaults at import."""
 
     def __init__(self):
         self.lock = threading.Lock()
         self.pending = weakref.WeakSet()
         self.enabled = os.environ.get("MTGS_SH_PREFILL", "1") == "1"
         self.in_forward = os.environ.get("MTGS_PREFILL_IN_FORWARD", "1") == "1"
+        self.max_region_bytes = int(os.environ.get("MTGS_PREFILL_MAX_BYTES", str(8 << 30)))
+        self.regions = 0          # regions allocated so far / bytes of the last one (tests, diagnostics)
+        self.last_region_bytes = 0
 
     def request(self, shape, device) -> Optional[_ZeroRequest]:
         if not self.enabled:
             return None
         req = _ZeroRequest(shape, device)
         with self.lock:
+            for old in [r for r in self.pending if r.buffer is None and r.thread == req.thread and r.device == req.device
+                        and r.shape == req.shape]:
+                self.pending.discard(old)          # an unserved request of an earlier forward of this shape: expired
             self.pending.add(req)
         return req
 
-    def take(self, device, extra_floats: int = 0):
+    @staticmethod
+    def behind(t, max_nodes: int = 64):
+        """The requests of the spherical_harmonics() forwards tensor `t` is computed from (breadth first over its autograd graph)."""
+        found, seen = [], set()
+        queue = [t.grad_fn] if (t is not None and t.grad_fn is not None) else []
+        while queue and len(seen) < max_nodes:
+            node = queue.pop(0)
+            if node is None or node in seen:
+                continue
+            seen.add(node)
+            req = getattr(node, "zeros", None)
+            if isinstance(req, _ZeroRequest):
+                found.append(req)
+                continue                           # (nothing of interest behind an SH node)
+            queue.extend(fn for fn, _ in node.next_functions)
+        return found
+
+    def take(self, device, extra_floats: int = 0, only=()):
         """Called by a rasterization forward / backward in front of its compositing kernel: (pointer, bytes, extra) of ONE region
-        holding the buffers of every pending request of the device (16-byte aligned pieces) and `extra_floats` more for the caller
-        (`extra`: a flat view), or (None, 0, None)."""
+        holding the buffers of the still unserved requests among `only` (the requests behind this rasterization's colours; same
+        device, same stream -- and, in a forward, same thread) and `extra_floats` more for the caller (`extra`: a flat view), or
+        (None, 0, None)."""
+        stream = torch.cuda.current_stream(device).cuda_stream      # (the kernel that clears the region is enqueued there)
         with self.lock:
-            mine = [r for r in self.pending if r.device == device and r.buffer is None]
+            mine = [r for r in only if r in self.pending and r.device == device and r.buffer is None and r.fwd_stream == stream]
+            sizes = [-(-int(torch.Size(r.shape).numel()) // 4) * 4 for r in mine]      # floats, padded to 16 bytes
+            own = -(-int(extra_floats) // 4) * 4
+            while mine and (sum(sizes) + own) * 4 > self.max_region_bytes:
+                mine.pop(), sizes.pop()            # (beyond the budget: that request takes the dense backward)
             for r in mine:
                 self.pending.discard(r)
         if not mine and not extra_floats:
             return None, 0, None
-        sizes = [-(-int(torch.Size(r.shape).numel()) // 4) * 4 for r in mine]      # floats, padded to 16 bytes
-        own = -(-int(extra_floats) // 4) * 4
         region = torch.empty(sum(sizes) + own, dtype=torch.float32, device=device)
+        self.regions, self.last_region_bytes = self.regions + 1, region.numel() * 4
         at = own
-        stream = torch.cuda.current_stream(device).cuda_stream      # (the kernel that clears the region is enqueued there)
         for r, n in zip(mine, sizes):
             r.buffer, r.stream = region[at:at + int(torch.Size(r.shape).numel())].view(r.shape), stream
             at += n
@@ -110,6 +152,20 @@ class _Prefill:
 
 
 _prefill = _Prefill()
+_sh_scope = threading.local()      # .reqs: the requests behind the colours of the rasterization being recorded (fused_rasterization)
+
+
+@contextlib.contextmanager
+def sh_prefill(enabled: bool = True, in_forward: bool = True):
+    """Switches of the zero prefill of dL/dcoeffs (see _Prefill) for the enclosed calls: enabled = False -> every
+    spherical_harmonics() backward is the one-kernel dense one; in_forward = False -> the zeros ride on the compositing BACKWARD
+    instead of the forward.  Process-wide while active (autograd runs backward nodes on its own threads)."""
+    old = (_prefill.enabled, _prefill.in_forward)
+    _prefill.enabled, _prefill.in_forward = bool(enabled), bool(in_forward)
+    try:
+        yield
+    finally:
+        _prefill.enabled, _prefill.in_forward = old
 
 
 class _SphericalHarmonics(torch.autograd.Function):
@@ -797,7 +853,7 @@ class _FusedRasterization(torch.autograd.Function):
                     # (gsplat's sh_degree call style: the dense [N, 16, 3] coefficient gradient too -- the backward then writes the
                     #  rows of the Gaussians with a cotangent straight into it, mtgs_vis_color_bwd(dense_rows))
                     n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and cs.n_nodes == 1 and graph_caps is None) else 0
-                    z_ptr, z_bytes, own_ = _prefill.take(dev, n_rows_ + n_coef_)
+                    z_ptr, z_bytes, own_ = _prefill.take(dev, n_rows_ + n_coef_, only=getattr(_sh_scope, "reqs", ()))
                     ctx_box["rows"] = own_[:n_rows_].view(max(b["cap_vis"], 1), RS_)
                     if n_coef_:
                         ctx_box["coeffs"] = own_[n_rows_:].view(N, 16, 3)
@@ -850,6 +906,7 @@ class _FusedRasterization(torch.autograd.Function):
                               vis_ids, vis_rank, render if ed else None, recs, rank_ids, totals)
         ctx.cs, ctx.vis_mask, ctx.cap_vis = cs, (b["vis_mask"] if cs is not None else None), (b["cap_vis"] if packed else 0)
         ctx.zero_rows = ctx_box.get("rows") if packed else None      # gradient rows the forward's compositing kernel cleared
+        ctx.sh_reqs = [weakref.ref(r) for r in getattr(_sh_scope, "reqs", ())]      # (what the forward did not serve, the backward may)
         ctx.zero_coeffs = ctx_box.get("coeffs") if packed else None
         ctx.n2c = n2c
         ctx.graph = packed and _graph.caps is not None
@@ -896,7 +953,7 @@ class _FusedRasterization(torch.autograd.Function):
             if ctx.packed:
                 if rank_ids.numel() > 0:
                     # (the zeros the spherical_harmonics() backwards of this pass want are written by this kernel: _Prefill)
-                    z_ptr, z_bytes, _ = _prefill.take(dev)
+                    z_ptr, z_bytes, _ = _prefill.take(dev, only=[r for r in (w() for w in getattr(ctx, "sh_reqs", ())) if r is not None])
                     call("mtgs_blend_bwd_packed", Cn, DC, int(with_depth), ptr(recs), ptr(bg), int(ed), width, height, tw, th,
                          ptr(offsets), ptr(rank_ids), ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas),
                          ptr(G), RS, int(ctx.absgrad), ptr(order), z_ptr, z_bytes, st)
@@ -1049,10 +1106,15 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
         total = (0 if colors is None else colors.shape[-1]) + opened + int(with_depth)
         if total not in SUPPORTED_CHANNELS:
             raise ValueError(f"fused_rasterization: {total} blended channels (supported: {SUPPORTED_CHANNELS})")
-    out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
-                                    int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-                                    bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp,
-                                    color_source, *(sh_source or (None, None)))
+    # the spherical_harmonics() forwards these colours come from: only THEIR backward's zeros ride on this rasterization (_Prefill)
+    _sh_scope.reqs = _prefill.behind(colors) if (_prefill.enabled and colors is not None and colors.requires_grad) else ()
+    try:
+        out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
+                                        int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+                                        bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp,
+                                        color_source, *(sh_source or (None, None)))
+    finally:
+        _sh_scope.reqs = ()
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
      offsets, totals) = out
     if render.grad_fn is not None:  # the backward sets .grad / .absgrad on this very tensor (weak: no cycle)

@@ -307,3 +307,62 @@ def test_a_thumbnail_frame_clears_the_region_with_the_fill_kernel(hip_lib):
     assert float(want["coeffs"].abs().sum()) > 0 and torch.equal(got["coeffs"] != 0, want["coeffs"] != 0)
     for k in got:
         torch.testing.assert_close(got[k], want[k], rtol=2e-3, atol=1e-5 * float(want[k].abs().max()))
+
+
+def test_a_second_models_rasterization_does_not_serve_the_first_models_request(hip_lib):
+    """SCOPE of the prefill (round 6): two models on one device.  Model A's spherical_harmonics() forward leaves a request; model B's
+    rasterization -- whose colours do NOT descend from A's SH output -- must neither allocate nor zero A's dL/dcoeffs (its region holds
+    its own gradient rows only), and A's request is still served by A's own rasterization afterwards; a rasterization on ANOTHER stream
+    does not serve it either; an unserved request expires at the next SH forward of the same shape."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    dev = torch.device("cuda")
+    PA, vm, K, Gc, Ga, (W, H) = _scene(dev, N=200_000)
+    PB, *_ = _scene(dev, N=200_000)
+    pf = wrapper._prefill
+    cam = torch.inverse(vm)[0, :3, 3]
+
+    def raster(P, rgb):
+        return rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False, render_mode="RGB+ED",
+                             absgrad=True, rasterize_mode="antialiased")
+
+    sh_a = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
+    req_a = sh_a.grad_fn.zeros
+    assert req_a is not None and req_a in pf.pending and wrapper._Prefill.behind(torch.clamp(sh_a + 0.5, 0.0, 1.0)[None]) == [req_a]
+    # model B: plain colours that need a gradient (no SH behind them)
+    col_b = torch.rand(200_000, 3, device=dev, requires_grad=True)
+    assert wrapper._Prefill.behind(col_b) == []
+    n0 = pf.regions
+    rb, ab, info_b = raster(PB, col_b)
+    n_vis_b = int((info_b["radii"] > 0).sum())
+    assert pf.regions == n0 + 1 and req_a.buffer is None and req_a in pf.pending           # B's region: its own gradient rows only
+    assert pf.last_region_bytes <= 4 * 16 * int(1.6 * n_vis_b + 4096), (pf.last_region_bytes, n_vis_b)
+    # the same on another stream, with colours that DO descend from A's SH output: not served (the zeros would not be ordered)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        raster(PA, torch.clamp(sh_a + 0.5, 0.0, 1.0))
+    torch.cuda.current_stream().wait_stream(side)
+    assert req_a.buffer is None and req_a in pf.pending
+    # A's own rasterization on A's stream serves it
+    ra, aa, _ = raster(PA, torch.clamp(sh_a + 0.5, 0.0, 1.0))
+    assert req_a.buffer is not None and req_a not in pf.pending and req_a.buffer.shape == PA["coeffs"].shape
+    assert pf.last_region_bytes >= PA["coeffs"].numel() * 4
+    ((ra * Gc).sum() + (aa * Ga).sum() + (rb * Gc).sum()).backward()
+    got = PA["coeffs"].grad.clone()
+    with wrapper.sh_prefill(enabled=False):
+        for p in PA.values():
+            p.grad = None
+        sh2 = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
+        assert sh2.grad_fn.zeros is None
+        r2, a2, _ = raster(PA, torch.clamp(sh2 + 0.5, 0.0, 1.0))
+        ((r2 * Gc).sum() + (a2 * Ga).sum()).backward()
+    assert pf.enabled
+    assert torch.equal(got != 0, PA["coeffs"].grad != 0)
+    torch.testing.assert_close(got, PA["coeffs"].grad, rtol=1e-3, atol=1e-5 * float(got.abs().max()))
+    # expiry: a request nobody served is dropped by the next forward of the same shape
+    s1 = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
+    r1 = s1.grad_fn.zeros
+    s2 = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
+    assert r1 not in pf.pending and s2.grad_fn.zeros in pf.pending
+    (s1.sum() + s2.sum()).backward()            # both take the dense backward
+    assert bool(torch.isfinite(PA["coeffs"].grad).all())
