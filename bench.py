@@ -47,6 +47,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# Issue cost per wave64 instruction per SIMD on gfx950, shader cycles, measured (profiles/r06_valu_ceiling.md)
+VALU_COST = {"plain": 2.7, "dpp": 3.9, "swap": 7.5, "trans": 8.3}
+
+
+def valu_ceiling(active_over_insts, kernel=""):
+    """Cost-weighted issue ceiling (cycles per VALU instruction per SIMD) of a kernel's own mix: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU - 1 is
+    the share of the 2-weight opcodes (transcendentals, permlane swaps: ~8 cycles), the compositing backward adds 7 DPP adds per 152."""
+    if not active_over_insts:
+        return None
+    heavy = max(0.0, float(active_over_insts) - 1.0)
+    dpp = 7.0 / 152.0 if kernel.startswith("blend_bwd") else 0.0
+    heavy_cost = 0.5 * (VALU_COST["swap"] + VALU_COST["trans"])
+    return round((1.0 - heavy - dpp) * VALU_COST["plain"] + heavy * heavy_cost + dpp * VALU_COST["dpp"], 2)
+
+
 DOMINANT = ("mtgs_blend_bwd_packed", "mtgs_blend_bwd")   # the compositing backward (packed-record / gather form)
 # every C-ABI entry point the step calls, with the kernels behind it (timed live in a second, untimed pass)
 ENTRY_POINTS = {
@@ -80,8 +95,12 @@ def parse_args():
                     help="N > 1: sparse = all-gather of 64-byte rows of the visible Gaussians, SH-coefficient "
                          "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
                          "dense = plain all-reduce of every gradient tensor")
-    ap.add_argument("--dp-finish", choices=["touched", "static", "dynamic"], default="touched",
-                    help="N > 1, sparse exchange: touched (default) = SparseGradExchange.finish_touched: only the wire rows that CARRY a "
+    ap.add_argument("--dp-chunks", type=int, default=4, help="N > 1, --dp-finish touched-chunked / dynamic: index chunks of the exchange "
+                    "(one all-gather each; the reduction of chunk c overlaps the wire time of chunks c + 1 ..)")
+    ap.add_argument("--dp-finish", choices=["touched-chunked", "touched", "static", "dynamic"], default="touched-chunked",
+                    help="N > 1, sparse exchange: touched-chunked (default since round 6) = SparseGradExchange.finish_touched_chunked: the rows "
+                         "that carry a gradient in --dp-chunks index chunks, one fixed-capacity all-gather each issued back to back, chunk c "
+                         "reduced while c + 1 .. are on the wire, no host read (profiles/r06_dp_budget.md); touched = SparseGradExchange.finish_touched: only the wire rows that CARRY a "
                          "gradient travel (40 %% of the visible ones at this scene), with their own map, in ONE fixed-capacity all-gather "
                          "per step -- no visibility-map exchange, no host read between render and reduce; static = finish_static (ONE "
                          "fixed-capacity all-gather of every visible row, capacity = the ranks' largest warm-up row count + 5 %%, "
@@ -125,8 +144,8 @@ def make_step(args, dev, world):
     all_params = list(params.values()) + [viewmat]
     info_box = {"grad_bytes": 0}
     sparse = world > 1 and args.dp_exchange == "sparse" and args.variant == "mtgs"
-    exchange = SparseGradExchange(args.n_gaussians, 16, dev["means"].device) if sparse else None
-    if sparse and args.dp_finish == "touched":
+    exchange = SparseGradExchange(args.n_gaussians, 16, dev["means"].device, chunks=max(1, min(16, args.dp_chunks))) if sparse else None
+    if sparse and args.dp_finish in ("touched", "touched-chunked"):
         exchange.defer_maps = True       # the touched rows' map travels with the rows: no visibility-map exchange during the frame
 
     ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rows", "end")}
@@ -152,6 +171,21 @@ def make_step(args, dev, world):
             ev["rows"].record()
             if args.dp_finish == "dynamic":
                 g = exchange.finish(params["means"], 3)
+            elif args.dp_finish == "touched-chunked":
+                # per-chunk capacities agreed ONCE, in the first (warm-up) step, from that step's own per-chunk counts (one tiny MAX
+                # all-reduce: setup, not part of a timed step); afterwards nothing of the exchange reaches the host
+                caps = info_box.get("chunk_caps")
+                first = caps is None
+                if first:
+                    caps = [args.n_gaussians] * exchange.n_chunks         # (generous: the warm-up step's messages are not the timed ones)
+                g, ovf = exchange.finish_touched_chunked(params["means"], 3, caps, [0] * world)
+                if first:
+                    cnt = exchange.touched_chunk_counts().to(torch.float64)
+                    torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MAX)
+                    info_box["chunk_caps"] = [int(c * 1.10) + 256 for c in cnt.tolist()]
+                    info_box["static_cap"], info_box["touched"] = sum(info_box["chunk_caps"]), True
+                else:
+                    info_box["overflow"] = ovf if info_box.get("overflow") is None else (info_box["overflow"] | ovf)
             else:
                 # no host read, no host wait: ONE fixed-capacity all-gather per step, counts stay on the device.  The capacity is
                 # agreed on ONCE, in the first (warm-up) step, from that step's own counts (a tiny MAX all-reduce: setup, not part
@@ -713,15 +747,21 @@ def main():
             continue
         a_bytes = sum(alg.get(k, 0) for k in kerns)
         us = sum(v) / len(v) * 1e3
-        entry_points.append({"entry_point": name, "kernels": kerns, "avg_us_live": round(us, 2), "launches_timed": len(v),
-                             "algorithmic_bytes": int(a_bytes) if a_bytes else None,
-                             "frac_of_peak_algorithmic": round(a_bytes / us / 1e3 / HBM_PEAK_GBS, 4) if a_bytes else None})
+        ep = {"entry_point": name, "kernels": kerns, "avg_us_live": round(us, 2), "launches_timed": len(v),
+              "algorithmic_bytes": int(a_bytes) if a_bytes else None,
+              "frac_of_peak_algorithmic": round(a_bytes / us / 1e3 / HBM_PEAK_GBS, 4) if a_bytes else None}
+        if name == "mtgs_blend_fwd_packed" and bytes_fwd_zeros:
+            # the compositing's own bytes (SURVEY.md section 8(d)'s unit) apart from the zeros that ride on the kernel for the backward pass
+            own = a_bytes - bytes_fwd_zeros
+            ep["algorithmic_bytes_split"] = {"compositing": int(own), "riding_zeros": int(bytes_fwd_zeros)}
+            ep["frac_of_peak_compositing_only"] = round(own / us / 1e3 / HBM_PEAK_GBS, 4)
+        entry_points.append(ep)
     # (2) counter-based traffic and VALU-busy fraction per kernel: COMMITTED rocprofv3 --pmc passes of this command on the
     # headline workload (scripts/pmc_step.sh -> profiles/rNN_pmc_step.json, FETCH_SIZE x2 / WRITE_SIZE x1 as calibrated there).
     # They are builder-held numbers echoed into this line, labelled as such, and dropped when the file was made with
     # another HOT-PATH ABI version of the library than the one running (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION: bumps of the
     # optimizer / loss entry points do not invalidate them) or in the other tile-list mode.
-    traffic = valu_busy = None
+    traffic = valu = None
     kernels, counters_from = [], None
     headline = (args.n_gaussians, args.width, args.height, args.variant) == (2_000_000, 1920, 1080, "mtgs")
     for pmc in sorted((ROOT / "profiles").glob("r*_pmc_step.json"), reverse=True):
@@ -735,14 +775,32 @@ def main():
             for name, a_bytes in alg.items():
                 r = rec.get(name) or next((v for k, v in rec.items() if k.startswith(name + "<")), None)   # (template instances of the list mode)
                 if r and r.get("hbm_bytes"):
+                    cpi, ceil_ = r.get("cycles_per_valu_inst_per_simd"), valu_ceiling(r.get("active_over_insts_valu"), name)
+                    frac_hbm = (r["hbm_bytes"] / r["avg_us"] / 1e3 / HBM_PEAK_GBS) if r.get("avg_us") else None
+                    frac_valu = (ceil_ / cpi) if (cpi and ceil_) else None
                     kernels.append({"kernel": name, "algorithmic_bytes": int(a_bytes), "counter_bytes_committed": r["hbm_bytes"],
-                                    "avg_us_committed": r.get("avg_us"), "valu_busy_frac_committed": r.get("valu_busy_frac")})
+                                    "avg_us_committed": r.get("avg_us"), "cycles_per_valu_inst_committed": cpi,
+                                    "valu_ceiling_cycles_per_inst": ceil_, "frac_of_valu_ceiling": None if frac_valu is None else round(frac_valu, 3),
+                                    "frac_of_hbm_peak_counter": None if frac_hbm is None else round(frac_hbm, 3),
+                                    "mean_resident_waves_per_simd": r.get("mean_resident_waves_per_simd"),
+                                    # what binds, from the counters: the larger of the two fractions (a latency-bound kernel is far below both)
+                                    "bound": None if (frac_hbm is None or frac_valu is None) else
+                                             ("latency" if max(frac_hbm, frac_valu) < 0.35 else ("valu-issue" if frac_valu > frac_hbm else "hbm"))})
             dom = rec.get("blend_bwd_kernel<4, 4, true>", {})
-            traffic, valu_busy = dom.get("hbm_bytes"), dom.get("valu_busy_frac")
+            traffic = dom.get("hbm_bytes")
+            if dom.get("cycles_per_valu_inst_per_simd"):
+                ceil_ = valu_ceiling(dom.get("active_over_insts_valu"), "blend_bwd_kernel<4, 4, true>")
+                valu = {"insts": dom.get("SQ_INSTS_VALU"), "cycles_per_inst": dom["cycles_per_valu_inst_per_simd"],
+                        "ceiling_cycles_per_inst": ceil_, "frac": round(ceil_ / dom["cycles_per_valu_inst_per_simd"], 3),
+                        "plain_valu_cycles_per_inst": VALU_COST["plain"], "mean_resident_waves_per_simd": dom.get("mean_resident_waves_per_simd"),
+                        "note": "wave64 VALU instructions per launch and shader cycles per instruction per SIMD (GRBM_GUI_ACTIVE / 8 x 1024 / "
+                                "SQ_INSTS_VALU) from the committed counter pass named in counters_from; ceiling = the cost-weighted mean over the "
+                                "kernel's own instruction mix with the per-class issue costs measured in profiles/r06_valu_ceiling.md (plain 2.7, "
+                                "DPP 3.9, permlane swap 7.5, transcendental 8.3 cycles); frac = ceiling / measured"}
             counters_from = pmc.name
             break
         except Exception:
-            traffic = valu_busy = None
+            traffic = valu = None
             kernels = []
 
     out = {
@@ -774,11 +832,15 @@ def main():
                        (" (timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)"
                         if elapsed_graph is not None else "")),
             "parallelism": f"view-parallel dp{world}, {args.dp_exchange if world > 1 else 'no'} gradient exchange"
-                           + (f" ({('finish_touched: one all-gather of the ' if info_box.get('touched') else 'finish_static: one all-gather of ') + str(info_box['static_cap']) + (' rows that carry a gradient + their map' if info_box.get('touched') else ' visible rows') + ' per rank, no host read' if info_box.get('static_cap') else 'finish: chunked all-gathers sized on the host'})"
+                           + (f" ({(('finish_touched_chunked: ' + str(len(info_box['chunk_caps'])) + ' all-gathers (index chunks, reduction overlapped) of together ') if info_box.get('chunk_caps') else 'finish_touched: one all-gather of the ' if info_box.get('touched') else 'finish_static: one all-gather of ') + str(info_box['static_cap']) + (' rows that carry a gradient + their map' if info_box.get('touched') else ' visible rows') + ' per rank, no host read' if info_box.get('static_cap') else 'finish: chunked all-gathers sized on the host'})"
                               if (world > 1 and info_box.get("exchange") is not None) else "")
                            + f", {info_box['grad_bytes']} bytes received per rank per step",
         },
-        "roofline": {"kernel": "blend_bwd_kernel<4,4,packed> (mtgs_blend_bwd_packed)", "bound": "hbm",
+        "roofline": {"kernel": "blend_bwd_kernel<4,4,packed> (mtgs_blend_bwd_packed)", "bound": "hbm", "binds": "valu-issue",
+                     "binds_note": "`bound` names the roofline `achieved` / `peak` are quoted on (the contract's hbm | mfma: MFMA is unused); what "
+                                   "BINDS the kernel is VALU issue: see `valu` (fraction of the issue ceiling of its own instruction mix) "
+                                   "against `frac` (fraction of the HBM peak)",
+                     "valu": valu,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_ms": round(k_ms, 4),
@@ -796,12 +858,10 @@ def main():
                      "note": "avg_launch_ms: HIP events on the launch stream around every mtgs_blend_bwd_packed call of the K EAGER steps run "
                              "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) [+ N*192 when zeros_for_the_backward_pass.written_by names this kernel] with n_listed = the (tile, Gaussian) pairs "
                              "of the timed steps' lists (config.n_listed; = gsplat's count config.n_intersections for the default call); "
-                             "kernel is VALU bound, not HBM bound (DESIGN.md section 4); avg_launch_ms is measured in this run; traffic and "
-                             "valu_busy_frac (SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8) come from the committed rocprofv3 "
-                             "--pmc passes named in counters_from (null when none matches this library's ABI version)",
+                             "kernel is VALU-issue bound, not HBM bound (profiles/r06_valu_ceiling.md); avg_launch_ms is measured in this run; traffic "
+                             "and the `valu` block come from the committed rocprofv3 --pmc passes named in counters_from (null when none "
+                             "matches this library's hot-path ABI version)",
                      "counters_from": counters_from,
-                     # (the two counters come from different blocks of the chip: a ratio a percent above 1 is "busy throughout")
-                     "valu_busy_frac": None if valu_busy is None else min(1.0, valu_busy), "valu_busy_raw": valu_busy,
                      "entry_points": entry_points,
                      "entry_points_note": "measured in THIS run: HIP events on the launch stream around every C-ABI entry point of the "
                                           "step, in a second untimed pass; algorithmic bytes from this run's (N, n_vis, M)",
@@ -830,6 +890,17 @@ def main():
         out["dp_phases_ms_min"] = {k: round(float(table[:, i].min()), 3) for i, k in enumerate(keys)}
         out["dp_n_visible_per_rank"] = [int(v) for v in table[:, len(keys)]]
         out["dp_bytes_received_per_rank"] = [int(v) for v in table[:, len(keys) + 1]]
+        # self-diagnosis of the exchange (first multi-GPU run: which assumption of profiles/r06_dp_budget.md holds?)
+        ex_ms = [float(table[r, keys.index("exchange")]) for r in range(world)]
+        recv = [float(v) for v in table[:, len(keys) + 1]]
+        out["dp_finish"] = args.dp_finish if info_box.get("exchange") is not None else "dense all-reduce"
+        out["dp_chunk_caps_rows"] = info_box.get("chunk_caps")
+        out["dp_overflow"] = None if info_box.get("overflow") is None else bool(info_box["overflow"])
+        # bytes a rank RECEIVES from the other ranks per step / the exchange phase: a LOWER bound of what the wire sustained (the phase
+        # holds the pack and the reductions too); per link = / (world - 1) peers on a fully connected xGMI node
+        out["dp_exchange_GBs_per_rank"] = [round(recv[r] * (world - 1) / world / max(ex_ms[r], 1e-6) / 1e6, 2) for r in range(world)]
+        out["dp_exchange_GBs_per_link"] = [round(v / max(world - 1, 1), 2) for v in out["dp_exchange_GBs_per_rank"]]
+        out["dp_rank_phases_ms"] = [{k: round(float(table[r, i]), 3) for i, k in enumerate(keys)} for r in range(world)]
         out["dp_world_size"] = torch.distributed.get_world_size()
         out["dp_backend"] = torch.distributed.get_backend()
         try:

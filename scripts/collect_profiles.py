@@ -2,7 +2,8 @@
 """Copies the rocprofv3 outputs merged into gpurun_out/ (scripts/prof_bench.sh, scripts/pmc_step.sh) into profiles/ and
 derives profiles/<round>_pmc_step.json: per kernel of the benchmark step the counter-based HBM traffic (FETCH_SIZE and
 WRITE_SIZE from SEPARATE --pmc passes, corrected by the factors measured on kernels with a known byte count), the
-VALU-busy fraction, and the average duration from the kernel trace of the same command.  Run in the build container after
+cycles per VALU instruction per SIMD with the resident waves and wait fractions, and the average duration from the kernel trace
+of the same command.  Run in the build container after
 the gpurun calls:   python scripts/collect_profiles.py r02"""
 import collections
 import csv
@@ -80,10 +81,20 @@ for k in F:
         rec["counter_GBs"] = round((fb + wb) / rec["avg_us"] / 1e3, 1)
         rec["frac_of_8TBs"] = round((fb + wb) / rec["avg_us"] / 1e3 / 8000.0, 4)
     s = S.get(k)
-    if s and s.get("GRBM_GUI_ACTIVE"):
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over 8 XCDs
-        rec["valu_busy_frac"] = round(s["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), 3)
+    if s and s.get("GRBM_GUI_ACTIVE") and s.get("SQ_INSTS_VALU"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* over the chip's 1024 SIMDs.  SQ_ACTIVE_INST_VALU is an instruction count
+        # weighted per opcode class (1: plain / DPP, 2: transcendentals, permlane swaps), NOT busy cycles (profiles/r06_valu_ceiling.md)
+        cyc = s["GRBM_GUI_ACTIVE"] / 8
         rec["SQ_INSTS_VALU"] = int(s["SQ_INSTS_VALU"])
+        rec["gpu_cycles"] = int(cyc)
+        rec["cycles_per_valu_inst_per_simd"] = round(cyc * 1024 / s["SQ_INSTS_VALU"], 3)
+        rec["active_over_insts_valu"] = round(s["SQ_ACTIVE_INST_VALU"] / s["SQ_INSTS_VALU"], 3)
+        if s.get("SQ_WAVE_CYCLES"):
+            rec["mean_resident_waves_per_simd"] = round(s["SQ_WAVE_CYCLES"] * 4 / cyc / 1024, 2)
+            rec["wait_any_frac"] = round(s.get("SQ_WAIT_ANY", 0.0) / s["SQ_WAVE_CYCLES"], 3)
+            rec["wait_inst_any_frac"] = round(s.get("SQ_WAIT_INST_ANY", 0.0) / s["SQ_WAVE_CYCLES"], 3)
+        if s.get("SQ_INSTS_SALU") is not None:
+            rec["salu_per_valu"] = round(s["SQ_INSTS_SALU"] / s["SQ_INSTS_VALU"], 3)
     kernels[short(k)] = rec
 out["kernels"] = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes"]))
 json.dump(out, open(os.path.join(P, f"{tag}_pmc_step.json"), "w"), indent=1)

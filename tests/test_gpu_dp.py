@@ -163,7 +163,7 @@ def test_sparse_exchange_single_process(hip_lib, K, degree):
         assert torch.allclose(got, r, atol=2e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("exchange", ["sparse", "sparse/static", "sparse/dynamic", "dense"])
+@pytest.mark.parametrize("exchange", ["sparse", "sparse/touched", "sparse/static", "sparse/dynamic", "dense"])
 def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
     rank), with both ranks on the test box's single GPU and gloo in place of RCCL: the whole N > 1 code path
@@ -174,7 +174,7 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--n-gaussians", "50000", "--width", "640", "--height", "480", "--dp-exchange", exchange.split("/")[0]]
-    finish = exchange.split("/")[1] if "/" in exchange else "touched"        # (the default of --gpus N > 1)
+    finish = exchange.split("/")[1] if "/" in exchange else "touched-chunked"        # (the default of --gpus N > 1)
     if "/" in exchange:
         cmd += ["--dp-finish", finish]
     exchange = exchange.split("/")[0]
@@ -193,8 +193,15 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     #  dynamic: chunked all-gathers pipelined with the reduction, timed as `wire` / `reduce`)
     want = {"render", "exchange"}
     if exchange == "sparse":
-        want |= {"touched": set(), "static": {"meta"}, "dynamic": {"meta", "wire", "reduce"}}[finish]
-        assert {"touched": "finish_touched", "static": "finish_static", "dynamic": "finish:"}[finish] in out["config"]["parallelism"]
+        want |= {"touched-chunked": set(), "touched": set(), "static": {"meta"}, "dynamic": {"meta", "wire", "reduce"}}[finish]
+        assert {"touched-chunked": "finish_touched_chunked: 4 all-gathers", "touched": "finish_touched: one", "static": "finish_static",
+                "dynamic": "finish:"}[finish] in out["config"]["parallelism"]
+        # the self-diagnosis of the N > 1 line (round 6): exchange form, overflow flag, per-rank phases, achieved GB/s per rank and link
+        assert out["dp_finish"] == finish and len(out["dp_rank_phases_ms"]) == 2 and len(out["dp_exchange_GBs_per_link"]) == 2
+        if finish in ("touched-chunked", "touched", "static"):
+            assert out["dp_overflow"] is False
+        if finish == "touched-chunked":
+            assert len(out["dp_chunk_caps_rows"]) == 4 and all(c > 0 for c in out["dp_chunk_caps_rows"])
     assert want <= set(ph) and all(ph[k] >= 0 for k in want), ph
 
 
