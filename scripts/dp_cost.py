@@ -74,6 +74,40 @@ for world in (2, 4, 8):
                        ptr(recv), cap * 16, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, st)
     covered = sum(counts)
     print("world %d: one-pass reduce over %d rows (%d MB received): %.1f us" % (world, covered, world * cap * 64 >> 20, t(red)))
+    # ---- the TOUCHED form (finish_touched / finish_touched_chunked): 40 % of every sender's rows carry a gradient (the headline
+    # scene's share), compacted with their own map by mtgs_dp_touched_pack; the reduction over them, in one pass and in index chunks
+    tb = {"scratch": torch.empty(nw, dtype=torch.int64, device=dev), "blocks": torch.empty(nw // 256 + 2, dtype=torch.int32, device=dev),
+          "totals": torch.zeros(1, dtype=torch.int64, device=dev)}
+    gz = torch.Generator().manual_seed(5)
+    pad = -(-L // 16) * 16
+    tcap = int(0.45 * cap) + 1024
+    Lt = tcap * 16 + pad
+    recv_t = torch.zeros(world, Lt, device=dev)
+    t_counts, t_pack = [], None
+    for r in range(world):
+        rr = rows[r].clone()
+        rr[(torch.rand(rr.shape[0], generator=gz) < 0.6).to(dev), :15] = 0.0
+        blk = recv_t[r]
+        mb = blk.data_ptr() + 4 * tcap * 16
+        pk = lambda rr=rr, blk=blk, mb=mb: call("mtgs_dp_touched_pack", rr.shape[0], ptr(rr), N, ptr(tb["scratch"]), mb + 16, mb + 16 + 8 * nw, mb,
+                                                ptr(tb["totals"]), ptr(tb["blocks"]), blk.data_ptr(), tcap, st)
+        if r == 0:
+            t_pack = t(pk)
+        pk()
+        blk.view(torch.int32)[tcap * 16 + 1:tcap * 16 + 4].copy_(metas[r, 1:4])
+        t_counts.append(int(blk.view(torch.int32)[tcap * 16].item()))
+    ri = recv_t.view(torch.int32)
+    m0 = tcap * 16
+    red_t = lambda b0=0, b1=-1: call("mtgs_dp_reduce_slices_cap", world, N, K, 3, ptr(means), ri.data_ptr() + 4 * (m0 + 4),
+                                     ri.data_ptr() + 4 * (m0 + 4 + 2 * nw), Lt * 4, ptr(recv_t), Lt, tcap, ptr(cams), ptr(out[0]), ptr(out[1]),
+                                     ptr(out[2]), ptr(out[3]), ptr(out[4]), b0, b1, C.c_uint64((1 << world) - 1), 1, K * 3, st)
+    line_t = "world %d, touched rows only (%d of %d rows, %d MB received; pack %.1f us): one-pass reduce %.1f us" % (
+        world, sum(t_counts), covered, world * Lt * 4 >> 20, t_pack, t(red_t))
+    for nch in (2, 4):
+        per = -(-(-(-N // nch)) // 2048) * 2048
+        bounds = list(range(0, N, per)) + [N]
+        line_t += "; in %d index chunks %.1f us" % (nch, t(lambda: [red_t(bounds[c], bounds[c + 1]) for c in range(len(bounds) - 1)]))
+    print(line_t)
     # ---- the same sums as ROWS of the union of the senders' visible sets (finish(rows=True)): one traversal (geometry + colour
     # in one pass), and one traversal PER sender (MTGS's multi-traversal step: T passes, dense [N, T, K, 3] against T row sets)
     for T in (1, world):

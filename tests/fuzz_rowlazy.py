@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised stress of the exact row-lazy Adam (not collected by pytest; run on a GPU box):
+"""Randomised stress of the exact row-lazy Adam (run on a GPU box; collected through tests/test_gpu_fuzz.py):
     python tests/fuzz_rowlazy.py --cases 200 --seed 1
 Every case draws sizes, tensor shapes ([N, w] / [N, T, w], w in 1 .. 70), hyper-parameters (incl. weight decay, where the
 caught rows must be ignored) and a random sequence of frames -- peek + step with the caught rows, peek without a step (an

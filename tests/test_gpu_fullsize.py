@@ -238,34 +238,40 @@ def test_fullsize_properties_linearity_and_determinism(gs):
     assert float(g1["means"][culled].abs().max()) == 0.0 and float(g1["colors"][culled].abs().max()) == 0.0
 
 
-def test_shipped_option_cell_7_channels_960x540(gs, oracle):
-    """The cell the shipped config/MTGS.py drives: RGB + camera-space normals = 6 colour channels
-    + expected depth = 7 blended channels, antialiased, absgrad, viewmat gradient, at MTGS's training size 960x540
-    (camera_res_scale_factor 0.5), 500k Gaussians -- forward and backward against the oracle."""
-    N, W, H, D = 500_000, 960, 540, 6
+@pytest.mark.parametrize("cell", ["MTGS.py", "3DGS.py"])
+def test_shipped_option_cell_7_channels_960x540(gs, oracle, cell):
+    """The cells the shipped configs drive, at MTGS's training size 960x540 (camera_res_scale_factor 0.5),
+    500k Gaussians -- forward and backward against the oracle.
+    MTGS.py: RGB + camera-space normals = 6 colour channels + expected depth = 7 blended channels, antialiased, absgrad, viewmat gradient.
+    3DGS.py (/root/reference/mtgs/config/3DGS.py:83-95): RGB + expected depth, CLASSIC, absgrad off, camera optimizer off = the pose
+    carries no gradient."""
+    mtgs = cell == "MTGS.py"
+    N, W, H, D = 500_000, 960, 540, (6 if mtgs else 3)
+    rmode, absgrad = ("antialiased", True) if mtgs else ("classic", False)
     sc = make_scene(N, seed=5)
     g = torch.Generator().manual_seed(9)
-    sc["colors"] = torch.cat([sc["colors"], torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)], -1)
+    if mtgs:
+        sc["colors"] = torch.cat([sc["colors"], torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)], -1)
     vm, K = make_camera(W, H, yaw_deg=15.0)
     a = {k: v.numpy() for k, v in sc.items()}
     Gc, Ga = torch.randn(1, H, W, D + 1, generator=g), torch.randn(1, H, W, 1, generator=g)
     r_ref, a_ref, m = oracle.rasterization(a["means"], a["quats"], a["scales"], a["opacities"], a["colors"], vm.numpy(),
-                                           K.numpy(), W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+                                           K.numpy(), W, H, render_mode="RGB+ED", rasterize_mode=rmode)
     P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
-    vmd = dev(vm).requires_grad_(True)
+    vmd = dev(vm).requires_grad_(mtgs)
     render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vmd, dev(K), W, H,
-                                           packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+                                           packed=False, render_mode="RGB+ED", rasterize_mode=rmode, absgrad=absgrad)
     info["means2d"].retain_grad()
-    case = "shipped cell 7ch 500k 960x540"
+    case = "shipped cell 7ch 500k 960x540" if mtgs else "3DGS.py cell RGB+ED classic 500k 960x540"
     for key in ("radii", "tiles_per_gauss"):
         assert np.array_equal(info[key].cpu().numpy(), m[key]), key
 
     def again():
         with torch.no_grad():
             return gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vmd, dev(K), W, H, packed=False,
-                                    render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)[2]
+                                    render_mode="RGB+ED", rasterize_mode=rmode, absgrad=absgrad)[2]
     assert_tile_lists(info, m, rerun=again)
-    assert render.shape == (1, H, W, 7)
+    assert render.shape == (1, H, W, D + 1)
     flipped = assert_image_close(render.detach().cpu().numpy(), r_ref, m["critical"], name="render", case=case, depth_channel=-1,
                                  alpha=a_ref)
     flipped |= assert_image_close(alpha.detach().cpu().numpy(), a_ref, m["critical"], name="alpha", case=case)
@@ -283,21 +289,26 @@ def test_shipped_option_cell_7_channels_960x540(gs, oracle):
     v2d, vabs, vcon, vcol, vop, tabs, ctabs = oracle.blend_bwd(m["means2d"], m["conics"], m["colors"], m["opacities"], None, W, H, 16,
                                                                m["isect_offsets"], m["flatten_ids"], a_ref, m["last_ids"], Gc_raw,
                                                                Ga_tot, want_term_abs=True, pixel_mask=m["critical"])
+    comp = m["compensations"] if mtgs else np.ones_like(vop)       # (classic: no compensation factor on the opacity)
     r_vm, r_vq, r_vs, r_vvm = oracle.project_bwd(a["means"], a["quats"], a["scales"], vm.numpy(), K.numpy(), W, H, 0.3,
                                                  m["radii"], m["conics"], m["compensations"], v2d, vcol[..., -1].copy(),
-                                                 vcon, vop * a["opacities"][None])
+                                                 vcon, vop * a["opacities"][None] if mtgs else None)
     flipped_rows = oracle.gaussians_on_pixels(flipped, m["last_ids"], m["isect_offsets"], m["flatten_ids"], N)
     xy_terms = moment_xy_terms(vabs, tabs, m["conics"], m["opacities"])
     blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, tabs, flipped_rows, self_critical=m["critical_gaussians"], crit_terms=ctabs,
-                         xy_terms=xy_terms)
+                         xy_terms=xy_terms, absgrad=absgrad)
     projection_vjp_accounted(case, oracle, dbg, a, vm.numpy(), K.numpy(), W, H, m, {k: P[k].grad for k in ("means", "quats", "scales", "opacities")})
     fl = dict(flipped_rows=flipped_rows, self_critical=m["critical_gaussians"])
-    for name, got, ref, kw in (("means2d.grad", info["means2d"].grad, v2d, dict(term_abs=xy_terms, crit_abs=ctabs[0, :, 0:2], **fl)),
-                               ("means2d.absgrad", info["means2d"].absgrad, vabs, dict(term_abs=vabs, crit_abs=ctabs[0, :, 0:2], **fl)),
-                               ("v_means", P["means"].grad, r_vm, {}), ("v_quats", P["quats"].grad, r_vq, {}),
-                               ("v_scales", P["scales"].grad, r_vs, {}),
-                               ("v_opacities", P["opacities"].grad, (vop * m["compensations"]).sum(0),
-                                dict(term_abs=(tabs[..., 3] * m["compensations"]).sum(0), crit_abs=(ctabs[..., 5] * m["compensations"]).sum(0), **fl)),
-                               ("v_viewmats", vmd.grad[0], r_vvm[0], {}),
-                               ("v_colors", P["colors"].grad, vcol[0, :, :D], dict(term_abs=tabs[0, :, 4:4 + D], crit_abs=ctabs[0, :, 6:6 + D], **fl))):
+    checks = [("means2d.grad", info["means2d"].grad, v2d, dict(term_abs=xy_terms, crit_abs=ctabs[0, :, 0:2], **fl)),
+              ("v_means", P["means"].grad, r_vm, {}), ("v_quats", P["quats"].grad, r_vq, {}),
+              ("v_scales", P["scales"].grad, r_vs, {}),
+              ("v_opacities", P["opacities"].grad, (vop * comp).sum(0),
+               dict(term_abs=(tabs[..., 3] * comp).sum(0), crit_abs=(ctabs[..., 5] * comp).sum(0), **fl)),
+              ("v_colors", P["colors"].grad, vcol[0, :, :D], dict(term_abs=tabs[0, :, 4:4 + D], crit_abs=ctabs[0, :, 6:6 + D], **fl))]
+    if mtgs:
+        checks += [("means2d.absgrad", info["means2d"].absgrad, vabs, dict(term_abs=vabs, crit_abs=ctabs[0, :, 0:2], **fl)),
+                   ("v_viewmats", vmd.grad[0], r_vvm[0], {})]
+    else:
+        assert vmd.grad is None and not hasattr(info["means2d"], "absgrad")
+    for name, got, ref, kw in checks:
         assert_grad_close(name, got, ref, case=case, **kw)

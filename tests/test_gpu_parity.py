@@ -144,8 +144,11 @@ def test_sort_pairs_all_digit_plans(gs, M, key_bits):
 
 
 CONFIGS = [
-    # (render_mode, rasterize_mode, absgrad, D, backgrounds, W, H)
+    # (render_mode, rasterize_mode, absgrad, D, backgrounds, W, H); W < 0: the camera pose carries NO gradient (|W| is the width)
     ("RGB", "classic", False, 3, False, 100, 70),
+    # the 3DGS.py option cell itself (/root/reference/mtgs/config/3DGS.py:83-95: rasterize_mode classic, output_depth_during_training
+    # -> RGB+ED, camera_optimizer off -> viewmats without a gradient; use_abs_grad off): classic / no absgrad / RGB+ED / D = 3
+    ("RGB+ED", "classic", False, 3, False, -100, 70),
     ("RGB+ED", "antialiased", True, 3, False, 100, 70),   # 3DGS.py-like + MTGS flags
     ("RGB+ED", "antialiased", True, 6, False, 97, 61),    # MTGS.py: RGB + normals + depth = 7 channels
     ("RGB+D", "classic", True, 3, True, 64, 48),
@@ -157,6 +160,7 @@ CONFIGS = [
 
 @pytest.mark.parametrize("render_mode,rmode,absgrad,D,use_bg,W,H", CONFIGS)
 def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad, D, use_bg, W, H):
+    vm_grad, W = W > 0, abs(W)
     sc, vm, K = small_scene(N=400, W=W, H=H, D=D)
     a = to_np(sc)
     g = torch.Generator().manual_seed(11)
@@ -170,7 +174,7 @@ def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad
                                                 rasterize_mode=rmode, backgrounds=None if bg is None else bg.numpy())
     # ---- device forward
     P = {k: dev(v).requires_grad_(True) for k, v in sc.items()}
-    vmd = dev(vm).requires_grad_(True)
+    vmd = dev(vm).requires_grad_(vm_grad)
     render, alpha, info = gs.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], P["colors"], vmd, dev(K),
                                            W, H, packed=False, render_mode=render_mode, rasterize_mode=rmode,
                                            absgrad=absgrad, backgrounds=None if bg is None else dev(bg))
@@ -215,7 +219,10 @@ def test_rasterization_fwd_bwd_vs_oracle(gs, oracle, render_mode, rmode, absgrad
     close("v_quats", P["quats"].grad, r_vq)
     close("v_scales", P["scales"].grad, r_vs)
     close("v_opacities", P["opacities"].grad, r_vo)
-    close("v_viewmats", vmd.grad[0], r_vvm[0])
+    if vm_grad:
+        close("v_viewmats", vmd.grad[0], r_vvm[0])
+    else:
+        assert vmd.grad is None and not hasattr(info["means2d"], "absgrad")     # (3DGS.py: no pose gradient, no absgrad attribute)
     if render_mode not in ("ED", "D"):
         close("v_colors", P["colors"].grad, vcol[..., :D].sum(0))
 

@@ -39,6 +39,7 @@ REPORT = []
 # scenes of the suite (4.5e-3 at 2M Gaussians / 1920x1080; profiles/r02_parity_report.json); the bound is about twice
 # the largest measured rate.  How many of them actually differ from the oracle is reported too (`flipped`).
 MAX_CRITICAL_RATE = 1e-2
+MAX_FLIPPED_RATE = 2e-5      # threshold pixels whose alpha >= 1/255 / T <= 1e-4 decision demonstrably differs from the oracle's
 
 
 def listed(info, key="flatten_ids"):
@@ -166,8 +167,13 @@ def assert_image_close(got, ref, critical, tol=1e-4, flip_bound=1.0 / 255.0, nam
     if dch is not None:
         flipped |= critical & (rel > 4.0 * max(rec["depth_max_rel_err"], 1e-7))
     rec["flipped_pixels"] = int(flipped.sum())
+    rec["flipped_rate"] = rec["flipped_pixels"] / max(n_pix, 1)
     REPORT.append(rec)
     assert not msgs, "; ".join(msgs)
+    # the flipped decisions are the ONLY pixels outside the north star's flat 1e-4 (1 / 6 / 22 of 0.3 / 2.07 / 2.07 M pixels at
+    # C1 / C2 / C3 in round 5): their RATE is bounded, so that a reformulation of the alpha / T expressions cannot quietly multiply it
+    assert rec["flipped_pixels"] <= max(MAX_FLIPPED_RATE * n_pix, 2), \
+        f"{name} ({case}): {rec['flipped_pixels']} flipped threshold pixels of {n_pix} (rate {rec['flipped_rate']:.2e} > {MAX_FLIPPED_RATE:.0e})"
     return flipped
 
 
@@ -311,7 +317,7 @@ def moment_xy_terms(vabs, term_abs, conics, opacities):
 
 
 def blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, term_abs, flipped_rows, max_unexplained=0, self_critical=None,
-                         crit_terms=None, xy_terms=None):
+                         crit_terms=None, xy_terms=None, absgrad=True):
     """The compositing backward's own output -- the compact gradient rows the fused path keeps per visible Gaussian
     (mtgs_amd.wrapper._debug_rows: [xy 2 | |xy| 2 | conic 3 | opacity 1 | colours | depth]) -- against the oracle's
     fp64-summed rows, one camera, with EVERY row accounted for (assert_grad_close: within 1e-3, or a cancelling sum, or on
@@ -336,6 +342,9 @@ def blend_rows_accounted(case, dbg, v2d, vabs, vcon, vcol, vop, term_abs, flippe
              ("rows.opacity", G[:, 7], vop[0][vis], ta[:, 3], cpart(5)),
              ("rows.colour+depth", G[:, 8:8 + DT], vcol[0][vis], ta[:, 4:4 + DT], cpart(slice(6, 6 + DT))))
     for name, got, ref, tabs, cabs in parts:
+        if name == "rows.|xy|" and not absgrad:      # (absgrad off -- the 3DGS.py cell: the kernel leaves those two sums alone)
+            assert not got.any(), "|xy| sums written although absgrad is off"
+            continue
         st = assert_grad_close(name, got, ref, case=case, term_abs=tabs, flipped_rows=fl, max_unexplained=max_unexplained,
                                self_critical=sc, row_rel_p999=1.0, crit_abs=cabs)     # (the percentile bar applies to what leaves the rasterizer)
         out[vis[st["_outlier_rows"]]] = True
