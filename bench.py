@@ -95,7 +95,9 @@ def parse_args():
                     help="N > 1: sparse = all-gather of 64-byte rows of the visible Gaussians, SH-coefficient "
                          "gradients rebuilt from their rank-1 factors (mtgs_amd.dist.SparseGradExchange); "
                          "dense = plain all-reduce of every gradient tensor")
-    ap.add_argument("--dp-chunks", type=int, default=4, help="N > 1, --dp-finish touched-chunked / dynamic: index chunks of the exchange "
+    ap.add_argument("--dp-no-prezero", action="store_true", help="N > 1, touched forms: the reduction writes every dense gradient completely "
+                    "(round 5) instead of only the touched Gaussians into tensors the frame's compositing forward cleared (round 6)")
+    ap.add_argument("--dp-chunks", type=int, default=2, help="N > 1, --dp-finish touched-chunked / dynamic: index chunks of the exchange "
                     "(one all-gather each; the reduction of chunk c overlaps the wire time of chunks c + 1 ..)")
     ap.add_argument("--dp-finish", choices=["touched-chunked", "touched", "static", "dynamic"], default="touched-chunked",
                     help="N > 1, sparse exchange: touched-chunked (default since round 6) = SparseGradExchange.finish_touched_chunked: the rows "
@@ -147,6 +149,7 @@ def make_step(args, dev, world):
     exchange = SparseGradExchange(args.n_gaussians, 16, dev["means"].device, chunks=max(1, min(16, args.dp_chunks))) if sparse else None
     if sparse and args.dp_finish in ("touched", "touched-chunked"):
         exchange.defer_maps = True       # the touched rows' map travels with the rows: no visibility-map exchange during the frame
+        exchange.prezero = not args.dp_no_prezero      # the dense sums' zeros ride on the compositing forward; the reduction writes touched Gaussians only
 
     ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "rows", "end")}
     info_box["events"] = ev

@@ -476,7 +476,10 @@ int mtgs_dp_reduce_slices(int W, int64_t N, int K, int degree, const float *mean
                           int64_t coeff_stride, void *stream);
 /* mtgs_dp_reduce_slices_cap (ABI v27): mtgs_dp_reduce_slices with the number of ROWS a sender's block holds given apart from the
  * block stride: a block may carry more than rows (finish_touched: [rows | the sender's map]), and a sender that had more rows than
- * the agreed capacity must not have the words behind its rows summed as floats.  row_cap = 0: row_stride / 16 (the whole block). */
+ * the agreed capacity must not have the words behind its rows summed as floats.  row_cap = 0: row_stride / 16 (the whole block).
+ * write_geometry: bit 0 = this pass writes the four geometry gradients; bit 1 (ABI v27) = SPARSE write: the outputs were zeroed by the
+ * caller (mtgs_blend_fwd_packed(also_zero) does it beside the compositing), so only the Gaussians some sender has a row for are
+ * written and 32-Gaussian tiles without any are skipped -- same values as the dense write. */
 int mtgs_dp_reduce_slices_cap(int W, int64_t N, int K, int degree, const float *means, const uint64_t *words,
                               const uint32_t *prefix, int64_t map_stride_bytes, const float *rows, int64_t row_stride, int64_t row_cap,
                               const float *cams, float *v_means, float *v_quats, float *v_scales, float *v_opacities,

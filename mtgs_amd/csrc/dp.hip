@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
     }
     // (first row, number of rows, tile bits) every sender has for this tile: one lane per sender, one memory round trip
     __shared__ int2 s_span[4][DP_MAX_SENDERS];
+    unsigned my_bits = 0u;      // this sender's (lane's) Gaussians of the tile
     if (lane < S.W) {
         const char *wp = reinterpret_cast<const char *>(S.words) + lane * S.map_stride_bytes;
         const char *pp = reinterpret_cast<const char *>(S.prefix) + lane * S.map_stride_bytes;
@@ -300,8 +301,20 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         const unsigned lo = (unsigned)wv, hi = (unsigned)(wv >> 32);
         const uint32_t p_w = reinterpret_cast<const uint32_t *>(pp)[wi], p_0 = reinterpret_cast<const uint32_t *>(pp)[S.word0];
         const int start = (int)(p_w - p_0) + (half ? __builtin_popcount(lo) : 0);
-        s_span[wave][lane] = make_int2(start, __builtin_popcount(half ? hi : lo));
+        my_bits = half ? hi : lo;
+        s_span[wave][lane] = make_int2(start, __builtin_popcount(my_bits));
     }
+    // SPARSE WRITE (geom bit 1; the dense outputs were zeroed by the caller -- the compositing forward's riding zeros, dist.py):
+    // only the Gaussians some sender has a row for are written, and a tile none has a row for is left alone altogether
+    const bool sparse = !ROWS && (geom & 2) != 0;
+    unsigned ubits = 0xffffffffu;
+    if (sparse) {
+        ubits = my_bits;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ubits |= (unsigned)__shfl_xor((int)ubits, o, 64);
+        if (ubits == 0u) return;
+    }
+    geom &= 1;
     // Software pipeline over the senders: the rows of sender r + 1 are in flight while sender r is accumulated
     // (all of a sender's row loads are issued before any is used: one memory round trip per sender, overlapped).
     float nxt[DP_MAXSTEP];
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
 #pragma unroll
     for (int it = 0; it < DP_MAXSTEP; ++it) {
         const int64_t n = g0 + it * 4 + sub;
-        if (n >= N) continue;
+        if (n >= N || !((ubits >> (it * 4 + sub)) & 1u)) continue;
         const float4 a = acc[it * 4 + sub][k];
         if (geom) {
             if (k < 3) v_means[n * 3 + k] = a.x;
@@ -967,9 +980,9 @@ extern "C" int mtgs_dp_reduce_slices_cap(int W, int64_t N, int K, int degree, co
                  "mtgs_dp_reduce: range [%lld, %lld) of %lld (the start must be a multiple of 64)", (long long)g_begin,
                  (long long)g_end, (long long)N);
     if (g_end == g_begin) return MTGS_OK;
-    MTGS_REQUIRE(words && prefix && rows && (!write_geometry || (v_means && v_quats && v_scales && v_opacities)), MTGS_EINVAL,
+    MTGS_REQUIRE(words && prefix && rows && (!(write_geometry & 1) || (v_means && v_quats && v_scales && v_opacities)), MTGS_EINVAL,
                  "mtgs_dp_reduce: null pointer");
-    MTGS_REQUIRE(write_geometry || v_coeffs, MTGS_EINVAL, "mtgs_dp_reduce: nothing to write");
+    MTGS_REQUIRE((write_geometry & 1) || v_coeffs, MTGS_EINVAL, "mtgs_dp_reduce: nothing to write");
     int nb = 0;
     if (v_coeffs) {
         MTGS_REQUIRE(means && cams && degree >= 0 && (degree + 1) * (degree + 1) <= K, MTGS_EINVAL,
@@ -985,7 +998,7 @@ extern "C" int mtgs_dp_reduce_slices_cap(int W, int64_t N, int K, int degree, co
     const unsigned grid = (unsigned)ceil_div64(ceil_div64(g_end - g_begin, DP_TILE), 4);  // one wave per 32-Gaussian tile
     hipStream_t st = (hipStream_t)stream;
     const unsigned long long cm = coeff_mask;
-    const int geom = write_geometry ? 1 : 0;
+    const int geom = write_geometry & 3;      // bit 0: write the geometry gradients; bit 1: SPARSE write into pre-zeroed outputs
     // (the kernel bounds its writes by g_end: the last range ends at N)
     switch (degree) {
         case 0: dp_reduce_kernel<0><<<grid, 256, 0, st>>>(g_begin, g_end, K, nb, means, S, v_means, v_quats, v_scales, v_opacities, v_coeffs, cm, geom, coeff_stride); break;

@@ -218,6 +218,12 @@ class SparseGradExchange:
         self._chunk_words = None
         self._recover = None     # the last frame finished through a truncating form: finish_recover() repeats it untruncated
         self._keep = None
+        # prezero = True: the dense sums of finish_touched() / finish_touched_chunked() are allocated when the frame STARTS, as one
+        # region the frame's compositing forward clears beside its own work (mtgs_blend_fwd_packed(also_zero): VALU-bound, HBM ~85 %
+        # idle -- what the single-GPU step does with the SH backward's zeros), and the reduction writes the touched Gaussians only
+        self.prezero = False
+        self.zero_region = None      # (pointer, bytes) for the rasterization's forward; _zero_out: the five views
+        self._zero_out = None
 
     # ---- integrated form -----------------------------------------------------------------------------------------
     def rasterization(self, means, quats, scales, opacities, sh_out, viewmats, Ks, width, height, cam_pos, near_plane=0.01,
@@ -237,6 +243,15 @@ class SparseGradExchange:
         self.abandon()      # a previous frame that never reached finish() (forward-only / eval call, an exception in between)
         self.meta[1:4].copy_(cam_pos.reshape(3).to(torch.float32).contiguous().view(torch.int32))
         self.meta[self.meta_len - 2:self.meta_len - 1].fill_(int(traversal))
+        self.zero_region = self._zero_out = None
+        if self.prezero and torch.is_grad_enabled():
+            N, K, T = self.N, self.K, self.T
+            sizes = [N * 3, N * 4, N * 3, N, N * T * K * 3]
+            offs = np.cumsum([0] + [-(-s // 4) * 4 for s in sizes])
+            region = torch.empty(int(offs[-1]), dtype=torch.float32, device=self.device)
+            shapes = [(N, 3), (N, 4), (N, 3), (N,), (N, K, 3) if T == 1 else (N, T, K, 3)]
+            self._zero_out = tuple(region[int(o):int(o) + s].view(sh) for o, s, sh in zip(offs[:-1], sizes, shapes))
+            self.zero_region = (region.data_ptr(), region.numel() * 4)
         self._pending = {"stage": "forward"}
         self.phase = "render (forward; meta all-gather on the side stream)"
         render, alphas, m = fused_rasterization(
@@ -359,16 +374,14 @@ class SparseGradExchange:
         words_all, prefix_all = recv_i[:, m0 + 4:], recv_i[:, m0 + 4 + 2 * nw:]
         rows_all = recv
         overflow = (recv_i[:, m0] > cap).any()
-        out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
-               torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
-               torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
+        out, sparse = self._dense_outputs()
         self.phase = "exchange (touched): reduction"
         stride_b, stride_f = L * 4, L
         masks = [sum(1 << r for r in range(world) if int(traversal_of_rank[r]) == t) for t in range(T)]
         for t in range(T):      # (T == 1: one pass, every sender)
             call("mtgs_dp_reduce_slices_cap", world, N, K, int(sh_degree), ptr(means), ptr(words_all), ptr(prefix_all), stride_b,
                  ptr(rows_all), stride_f, cap, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
-                 out[4].data_ptr() + t * K * 3 * 4, 0, -1, _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
+                 out[4].data_ptr() + t * K * 3 * 4, 0, -1, _C.c_uint64(masks[t]), int(t == 0) | sparse, T * K * 3, st)
         self.phase = "idle"
         return out, overflow
 
@@ -436,9 +449,7 @@ class SparseGradExchange:
         self.touched_count = s0i[0]
         collectives = world > 1 or self.world_collectives
         works, recvs = self.gather_chunk_messages(sends)
-        out = (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
-               torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
-               torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev))
+        out, sparse = self._dense_outputs()
         masks = [sum(1 << r for r in range(world) if int(traversal_of_rank[r]) == t) for t in range(T)]
         r0 = recvs[0]
         r0i = r0.view(torch.int32)
@@ -455,11 +466,22 @@ class SparseGradExchange:
                 call("mtgs_dp_reduce_slices_cap", world, N, K, int(sh_degree), ptr(means), r0i.data_ptr() + 16, r0i.data_ptr() + 16 + 8 * nw,
                      stride0_b, rows_c.data_ptr(), recvs[c].shape[1] if collectives else 0, caps[c], ptr(cams), ptr(out[0]), ptr(out[1]),
                      ptr(out[2]), ptr(out[3]), out[4].data_ptr() + t * K * 3 * 4, self.bounds[c], self.bounds[c + 1],
-                     _C.c_uint64(masks[t]), int(t == 0), T * K * 3, st)
+                     _C.c_uint64(masks[t]), int(t == 0) | sparse, T * K * 3, st)
         overflow = (r0i[:, self.meta_len - 1] != 0).any()
         self._keep = (recvs, works)      # (the receive buffers stay referenced until the next step: the collective stream may still own them)
         self.phase = "idle"
         return out, overflow
+
+    def _dense_outputs(self):
+        """(the five dense sums, flag): the views of the region this frame's compositing forward cleared (prezero; flag 2 = the
+        reduction writes the touched Gaussians only) or fresh uninitialised tensors the reduction writes completely (flag 0)."""
+        N, K, T, dev = self.N, self.K, self.T, self.device
+        if self._zero_out is not None:
+            out, self._zero_out, self.zero_region = self._zero_out, None, None
+            return out, 2
+        return (torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty((N, 4), dtype=torch.float32, device=dev),
+                torch.empty((N, 3), dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev),
+                torch.empty((N, K, 3) if T == 1 else (N, T, K, 3), dtype=torch.float32, device=dev)), 0
 
     def chunk_layout(self, caps: Sequence[int]) -> dict:
         """Messages of finish_touched_chunked(): message 0 = [meta record padded to `pad` floats | caps[0] rows], message c = caps[c]

@@ -857,6 +857,9 @@ class _FusedRasterization(torch.autograd.Function):
                     ctx_box["rows"] = own_[:n_rows_].view(max(b["cap_vis"], 1), RS_)
                     if n_coef_:
                         ctx_box["coeffs"] = own_[n_rows_:].view(N, 16, 3)
+                elif dp is not None and getattr(dp, "zero_region", None) is not None and any(ctx.needs_input_grad):
+                    # data-parallel frame: the dense sums the exchange will return (SparseGradExchange.prezero) are cleared here too
+                    z_ptr, z_bytes = dp.zero_region
                 call("mtgs_blend_fwd_packed", Cn, DC, int(with_depth), ptr(b["recs"]), ptr(bg), int(ed), width, height, tw, th,
                      ptr(offsets_buf), ptr(out["rank_ids"]), ptr(render), ptr(alphas), ptr(last_ids), ptr(order), z_ptr, z_bytes, st)
                 return out

@@ -107,6 +107,13 @@ for world in (2, 4, 8):
         per = -(-(-(-N // nch)) // 2048) * 2048
         bounds = list(range(0, N, per)) + [N]
         line_t += "; in %d index chunks %.1f us" % (nch, t(lambda: [red_t(bounds[c], bounds[c + 1]) for c in range(len(bounds) - 1)]))
+    # ... into PRE-ZEROED outputs (the zeros ride on the frame's compositing forward): touched Gaussians only, untouched tiles skipped
+    for o in out:
+        o.zero_()
+    red_s = lambda: call("mtgs_dp_reduce_slices_cap", world, N, K, 3, ptr(means), ri.data_ptr() + 4 * (m0 + 4),
+                         ri.data_ptr() + 4 * (m0 + 4 + 2 * nw), Lt * 4, ptr(recv_t), Lt, tcap, ptr(cams), ptr(out[0]), ptr(out[1]),
+                         ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, C.c_uint64((1 << world) - 1), 1 | 2, K * 3, st)
+    line_t += "; SPARSE write into pre-zeroed outputs %.1f us" % t(red_s)
     print(line_t)
     # ---- the same sums as ROWS of the union of the senders' visible sets (finish(rows=True)): one traversal (geometry + colour
     # in one pass), and one traversal PER sender (MTGS's multi-traversal step: T passes, dense [N, T, K, 3] against T row sets)

@@ -194,14 +194,14 @@ def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     want = {"render", "exchange"}
     if exchange == "sparse":
         want |= {"touched-chunked": set(), "touched": set(), "static": {"meta"}, "dynamic": {"meta", "wire", "reduce"}}[finish]
-        assert {"touched-chunked": "finish_touched_chunked: 4 all-gathers", "touched": "finish_touched: one", "static": "finish_static",
+        assert {"touched-chunked": "finish_touched_chunked: 2 all-gathers", "touched": "finish_touched: one", "static": "finish_static",
                 "dynamic": "finish:"}[finish] in out["config"]["parallelism"]
         # the self-diagnosis of the N > 1 line (round 6): exchange form, overflow flag, per-rank phases, achieved GB/s per rank and link
         assert out["dp_finish"] == finish and len(out["dp_rank_phases_ms"]) == 2 and len(out["dp_exchange_GBs_per_link"]) == 2
         if finish in ("touched-chunked", "touched", "static"):
             assert out["dp_overflow"] is False
         if finish == "touched-chunked":
-            assert len(out["dp_chunk_caps_rows"]) == 4 and all(c > 0 for c in out["dp_chunk_caps_rows"])
+            assert len(out["dp_chunk_caps_rows"]) == 2 and all(c > 0 for c in out["dp_chunk_caps_rows"])
     assert want <= set(ph) and all(ph[k] >= 0 for k in want), ph
 
 
@@ -373,6 +373,27 @@ def _worker_traversals(rank, world, port, out_dir):
     torch.cuda.synchronize()
     for got, ref in zip(out_c2, out_1):
         assert torch.equal(got, ref), rank
+    # prezero: the dense sums allocated when the frame starts, cleared by the frame's compositing forward, and the reduction writes
+    # the touched Gaussians only -- bit-identical to the dense write of the same frame's rows, in both forms
+    exc.prezero = True
+    frame(exc)
+    assert exc.zero_region is not None and exc.zero_region[1] >= 4 * N * (11 + T * K * 3)
+    out_z, ovf_z = exc.finish_touched_chunked(P["means"], 3, caps, trav)
+    assert exc.zero_region is None
+    exc._pending = dict(exc._recover)
+    out_d, _ = exc.finish_touched_chunked(P["means"], 3, caps, trav)        # (no region left: the dense write)
+    torch.cuda.synchronize()
+    assert not bool(ovf_z)
+    for got, ref in zip(out_z, out_d):
+        assert torch.equal(got, ref), rank
+    frame(exc)
+    out_z1, _ = exc.finish_touched(P["means"], 3, N, trav)
+    exc._pending = dict(exc._recover)
+    out_d1, _ = exc.finish_touched(P["means"], 3, N, trav)
+    torch.cuda.synchronize()
+    for got, ref in zip(out_z1, out_d1):
+        assert torch.equal(got, ref), rank
+    exc.prezero = False
     small = list(caps)
     small[1] = 4
     frame(exc)
