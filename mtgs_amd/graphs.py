@@ -58,6 +58,8 @@ class GraphedIteration:
         one small copy enqueued in front of the launch).
     on_capacities(): called when a stretch's capacities have just been planned from eager frames (a policy hook).
     can_skip_warmup(): True when a capture without a warm-up pass is valid (the optimizer's device scalars exist already).
+    snapshot_host_state() / restore_host_state(s): the body's HOST side effects (optimizer step counters) around a capture without
+        warm-up that fails: rolled back before the step is repeated (`FusedAdam.host_state` / `set_host_state`).
     margin: capacities = margin x the counts seen + a constant; first_cap_scale < 1 makes the FIRST capacities too small (tests).
     tight_lists: True = build the opt-in tight tile lists inside the iterations (a trainer's choice: same pixels and gradients,
         shorter lists); False = gsplat's lists; None = whatever mode the calling thread is in."""
@@ -66,11 +68,16 @@ class GraphedIteration:
                  device, before_replay: Optional[Callable[[], None]] = None, on_capacities: Optional[Callable[[], None]] = None,
                  can_skip_warmup: Optional[Callable[[], bool]] = None, poll_every: int = 16, margin: float = 1.3,
                  first_cap_scale: float = 1.0, tight_lists: Optional[bool] = True, log: Callable[..., None] = print,
-                 tick: Optional[Callable[[str], None]] = None):
+                 tick: Optional[Callable[[str], None]] = None, snapshot_host_state: Optional[Callable[[], object]] = None,
+                 restore_host_state: Optional[Callable[[object], None]] = None):
         self.body, self.n_keys, self.size_key, self.device = body, int(n_keys), size_key, torch.device(device)
         self.before_replay, self.on_capacities, self.can_skip_warmup = before_replay, on_capacities, can_skip_warmup
         self.poll_every, self.margin, self.tight, self.log = int(poll_every), float(margin), tight_lists, log
         self.tick = tick or (lambda name: None)
+        # host state the body advances per call (the optimizer's Python step counters): snapshot() in front of a capture without
+        # warm-up, restore(snapshot) when that capture fails and the step is run again (FusedAdam.host_state / set_host_state)
+        self.snapshot_host_state, self.restore_host_state = snapshot_host_state, restore_host_state
+        assert (snapshot_host_state is None) == (restore_host_state is None)
         self._cap_scale = float(first_cap_scale)
         self.graphs: Dict[Hashable, tuple] = {}
         self.caps: Optional[Tuple[int, int]] = None
@@ -121,14 +128,26 @@ class GraphedIteration:
                 # already: the pinned staging buffers of the key's previous graph (same sequence of table sizes -- a mismatch would
                 # allocate pinned memory while capturing and is caught below)
                 gm.keep = self.staged[key]
+                snap = self.snapshot_host_state() if self.snapshot_host_state is not None else None
                 try:
                     g = torch.cuda.CUDAGraph()
                     with gm, torch.cuda.graph(g, pool=self.pool):
                         static = self._run(key)
-                except Exception as e:      # noqa: BLE001  (fall back to the warm-up path, once, loudly)
+                except RuntimeError as e:
+                    # The EXPECTED failure only: something allocated or synchronised while capturing (a staging buffer of another size
+                    # than the previous graph's: "operation not permitted when stream is capturing" and its relatives).  Nothing has
+                    # executed on the device, but the body's HOST side effects have happened: the caller's hook rolls them back
+                    # (FusedAdam: the step counters its bias corrections are computed from) before the step is run again the
+                    # warm-up way.  Anything else -- a failed launch, a HIP error, a bug in the body -- propagates.
+                    msg = str(e).lower()
+                    if not any(s in msg for s in ("captur", "not permitted", "pinned", "cudamallochost", "hipmallochost", "hiphostmalloc")):
+                        raise
                     self.log(f"capture without warm-up failed ({type(e).__name__}: {e}); warming up")
+                    self.counts["capture_fallbacks"] = self.counts.get("capture_fallbacks", 0) + 1
                     self.staged.pop(key, None)
                     torch.cuda.synchronize()
+                    if snap is not None:
+                        self.restore_host_state(snap)
                     return self.step(key)
                 self.graphs[key] = (g, gm, static)
                 self.counts["captures"] += 1
@@ -186,6 +205,15 @@ class GraphedIteration:
         refinement has synchronised already: the read of the two counts costs nothing)."""
         self.graphs.clear()
         self._ovf_ev = None
+        # an overflow behind the last poll must not vanish with the flag: the read costs nothing here (seen_dev.tolist() below
+        # synchronises anyway).  The stretch is over, so there is nothing to re-capture -- but the steps since the overflow trained
+        # on truncated tile lists, and the counts the new capacities are scaled from are the TRUE ones (the binning reports a
+        # frame's counts whether or not they fitted), so they stay valid.
+        if bool(self.ovf_dev):
+            self.counts["overflows"] += 1
+            self.counts["overflows_found_at_refinement"] = self.counts.get("overflows_found_at_refinement", 0) + 1
+            self.log(f"refinement: a graph frame of the last stretch had exceeded its capacities {self.caps} after the last poll "
+                     "(its steps used truncated tile lists); the new capacities follow the counts it reported")
         seen = self.seen_dev.tolist()
         ratio = n_after / max(n_before, 1)
         self.caps = ((int(self.margin * ratio * seen[0]) + 4096, int(self.margin * ratio * seen[1]) + 65536) if seen[0] > 0 else None)

@@ -620,6 +620,28 @@ class FusedAdam(torch.optim.Optimizer):
                 if hi is not None:
                     self._hyper_index[id(p_new)] = hi
 
+    def host_state(self):
+        """The optimizer's HOST-side per-step state (the step counters the bias corrections are computed from, the lazy slices'
+        bookkeeping): what a body that failed half way -- GraphedIteration's capture without warm-up -- has to get back before the
+        step is run again (set_host_state)."""
+        import copy
+        steps = {id(p): (st["step"].clone() if torch.is_tensor(st.get("step")) else st.get("step"))
+                 for g in self.param_groups for p in g["params"] for st in [self.state.get(p, {})] if "step" in st}
+        lazy = {k: {"last": list(v["last"]), "hist": dict(v["hist"])} for k, v in self._lazy.items() if "last" in v and "hist" in v}
+        return {"steps": steps, "lazy": lazy, "pending": self._pending_host, "active_slice": copy.copy(self._active_slice)}
+
+    def set_host_state(self, s) -> None:
+        for g in self.param_groups:
+            for p in g["params"]:
+                if id(p) in s["steps"] and p in self.state:
+                    v = s["steps"][id(p)]
+                    self.state[p]["step"] = v.clone() if torch.is_tensor(v) else v
+        for k, v in s["lazy"].items():
+            if k in self._lazy:
+                self._lazy[k]["last"], self._lazy[k]["hist"] = list(v["last"]), dict(v["hist"])
+        self._pending_host = s["pending"]
+        self._active_slice = dict(s["active_slice"])
+
     def advance(self, active_slice: Optional[int] = None) -> None:
         """In front of every replay of a HIP graph that captured step(): increments the step count of the tensors that
         step updates and copies this step's {lr / (1 - beta1^t), sqrt(1 - beta2^t)} per tensor to the device

@@ -685,7 +685,9 @@ def train_loop(P, cams, targets, mask, win, W, H, steps, refine_every, shipped=N
                               size_key=lambda: (1, sum(p["means"].shape[0] for p in P.values()), W, H), device=dev,
                               before_replay=lambda: opt.advance(),      # this step's {lr / bc1, sqrt(bc2), t}: one small copy in front of the launch
                               on_capacities=lambda: touch_policy(), can_skip_warmup=lambda: n_active[0] > 0, poll_every=poll_every,
-                              first_cap_scale=first_cap_scale, tight_lists=None, log=log, tick=tick)
+                              first_cap_scale=first_cap_scale, tight_lists=None, log=log, tick=tick,
+                              snapshot_host_state=(lambda: opt.host_state()) if hasattr(opt, "host_state") else None,
+                              restore_host_state=(lambda s: opt.set_host_state(s)) if hasattr(opt, "host_state") else None)
 
     def graph_step(c):
         key = c
