@@ -75,6 +75,11 @@ ENTRY_POINTS = {
     "mtgs_project_bwd_rows": ["project_bwd_rows_kernel"],
     "mtgs_sh_bwd": ["sh_bwd_kernel<3>"],
     "mtgs_sh_bwd_rows": ["sh_bwd_rows_kernel<3>"],
+    # (round 6: the step's `torch.clamp(sh + 0.5, 0, 1)` is fused into the SH kernels -- mtgs_amd/wrapper.py::_LazySH -- so these are
+    #  the entry points the step calls; MTGS_SH_LAZY=0 gives the plain ones above and PyTorch's six elementwise kernels)
+    "mtgs_sh_fwd_act": ["sh_fwd_k16_kernel<3>"],
+    "mtgs_sh_bwd_act": ["sh_bwd_kernel<3>"],
+    "mtgs_sh_bwd_rows_act": ["sh_bwd_rows_kernel<3>"],
     "mtgs_dp_reduce": ["dp_reduce_kernel"],
 }
 
@@ -588,11 +593,17 @@ def main():
     # give the dominant kernel's launch time) and is reported as also.headline_eager_ms.
     elapsed_eager, elapsed_graph, launch, graph_error = elapsed, None, "eager", None
     elapsed_graph_tight, n_listed_tight = None, None
+    elapsed_graph_torch_act = None
 
-    def graph_time(tight):
-        """K replays of the step captured once under mtgs_amd.graph_mode (+ the opt-in tight tile lists when `tight`)."""
+    def graph_time(tight, lazy_sh=True):
+        """K replays of the step captured once under mtgs_amd.graph_mode (+ the opt-in tight tile lists when `tight`; lazy_sh = False:
+        spherical_harmonics() evaluated at once, the step's clamp(sh + 0.5) as PyTorch's own kernels -- the round-5 form)."""
         import gc
         import mtgs_amd
+        with mtgs_amd.sh_lazy(lazy_sh):
+            return _graph_time(tight, gc, mtgs_amd)
+
+    def _graph_time(tight, gc, mtgs_amd):
         nv_e, m_e = int((eager_info["radii"] > 0).sum().item()), int(eager_info["flatten_ids"].numel())
         gm = mtgs_amd.graph_mode(int(1.02 * nv_e) + 1024, int(1.02 * m_e) + 8192)      # (a static scene: the counts of the eager steps, a small margin)
         info_box["capture"] = True
@@ -638,6 +649,11 @@ def main():
                 elapsed_graph_tight, n_listed_tight = graph_time(True)
         except Exception as e:      # noqa: BLE001
             print(f"[bench] tight-lists graph failed: {type(e).__name__}: {e}"[:300], file=sys.stderr)
+        try:        # ... and with the colour activation left to PyTorch (what round 5's line measured)
+            if not args.no_tight and args.variant == "mtgs":
+                elapsed_graph_torch_act, _ = graph_time(False, lazy_sh=False)
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] torch-activation graph failed: {type(e).__name__}: {e}"[:300], file=sys.stderr)
     info_box["info"] = eager_info
     # per-rank phase breakdown of the last timed step (N > 1), read before anything else touches the events
     rank_phases = None
@@ -813,6 +829,7 @@ def main():
         "ms_per_step_graph": None if elapsed_graph is None else round(elapsed_graph / args.steps * 1e3, 3),
         "ms_per_step_exact_lists": round(ms_per_step, 3) if not tight_headline else None,
         "ms_per_step_tight_lists": None if elapsed_graph_tight is None else round(elapsed_graph_tight / args.steps * 1e3, 3),
+        "ms_per_step_torch_activation": None if elapsed_graph_torch_act is None else round(elapsed_graph_torch_act / args.steps * 1e3, 3),
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -827,6 +844,10 @@ def main():
                       "isect_offset_encode" + ("" if n_listed_tight is None else
                                                "; the opt-in tight lists (mtgs_amd.tight_lists(): same pixels and gradients, "
                                                f"{n_listed_tight} listed pairs) are timed beside it as ms_per_step_tight_lists, never as `value`")),
+            "colour_activation": ("fused: spherical_harmonics() returns a deferred tensor and the step's own `torch.clamp(sh + 0.5, 0.0, 1.0)` "
+                                  "(vanilla_gaussian_splatting.py:318) runs inside the SH kernels, bit-identical values and gradients "
+                                  "(mtgs_amd/wrapper.py::_LazySH, tests/test_gpu_sh_lazy.py)" if getattr(__import__("mtgs_amd").wrapper, "_lazy_sh_enabled", False)
+                                  else "PyTorch elementwise kernels (MTGS_SH_LAZY=0)"),
             "launch": ("one HIP graph launch per step: the step captured once under mtgs_amd.graph_mode + torch.cuda.graph and replayed "
                        "(the K steps were timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)")
                       if launch == "graph" else

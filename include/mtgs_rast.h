@@ -41,7 +41,7 @@ extern "C" {
 /* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
-#define MTGS_RAST_HOT_ABI_VERSION 5
+#define MTGS_RAST_HOT_ABI_VERSION 6
 #define MTGS_BIN3_TIGHT 1
 #define MTGS_BIN3_FILL_TO_M 2
 #define MTGS_BIN3_FILL_TO_CAP 4
@@ -85,6 +85,20 @@ int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *co
  * Same values as mtgs_sh_bwd (a zero cotangent gives a zero row there too).  No v_dirs. */
 int mtgs_sh_bwd_rows(int64_t n, int K, int degree, const float *dirs, const uint8_t *masks, const float *v_colors,
                      float *v_coeffs, void *stream);
+/* Round 6 (hot-path ABI v6): the caller's colour activation fused into the SH kernels.  MTGS writes `torch.clamp(rgbs + 0.5, 0.0, 1.0)`
+ * behind every spherical_harmonics() call (vanilla_gaussian_splatting.py:318; multi_color / rigid / deformable nodes alike), gsplat's
+ * own sh_degree path `clamp_min(colors + 0.5, 0)`: two elementwise passes forward and four backward over [n, 3].
+ * mtgs_sh_fwd_act: colors = clamp(x + add, lo, hi) with x the SH output (has_add = 0: clamp(x); hi = +inf: clamp_min), the same fp32
+ * operations in the same order as the torch expression, NaN propagating; pass[n] u8 (required) receives per Gaussian the bits of the
+ * channels with lo <= x + add <= hi -- torch's clamp backward mask.  pass = NULL: mtgs_sh_fwd.
+ * mtgs_sh_bwd_act / mtgs_sh_bwd_rows_act: v_colors is the cotangent of the ACTIVATED colours; channels whose bit is clear pass nothing.
+ * The Python layer uses them when the caller's expression is exactly that one (mtgs_amd/wrapper.py::_LazySH). */
+int mtgs_sh_fwd_act(int64_t n, int K, int degree, const float *dirs, const float *coeffs, const uint8_t *masks, float *colors,
+                    int has_add, float add, float lo, float hi, uint8_t *pass, void *stream);
+int mtgs_sh_bwd_act(int64_t n, int K, int degree, const float *dirs, const float *coeffs, const uint8_t *masks, const float *v_colors,
+                    float *v_coeffs, float *v_dirs, const uint8_t *pass, void *stream);
+int mtgs_sh_bwd_rows_act(int64_t n, int K, int degree, const float *dirs, const uint8_t *masks, const float *v_colors, float *v_coeffs,
+                         const uint8_t *pass, void *stream);
 /* bytes of zeros at p (4-byte aligned, a whole number of words), stream-ordered: 16-byte stores, the chip's fastest pure write. */
 int mtgs_fill_zero(void *p, size_t bytes, void *stream);
 

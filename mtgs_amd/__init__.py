@@ -12,8 +12,8 @@ Beyond gsplat's surface: `mtgs_amd.graph_mode` / `mtgs_amd.graphs.GraphedIterati
 """
 from .rendering import rasterization
 from .wrapper import (exact_lists, fully_fused_projection, graph_mode, isect_offset_encode, isect_tiles, lists_are_tight,
-                      rasterize_to_pixels, sh_prefill, spherical_harmonics, tight_lists)
+                      rasterize_to_pixels, sh_lazy, sh_prefill, spherical_harmonics, tight_lists)
 
 __version__ = "0.1.0"
 __all__ = ["rasterization", "spherical_harmonics", "fully_fused_projection", "isect_tiles",
-           "isect_offset_encode", "rasterize_to_pixels", "graph_mode", "exact_lists", "tight_lists", "lists_are_tight", "sh_prefill"]
+           "isect_offset_encode", "rasterize_to_pixels", "graph_mode", "exact_lists", "tight_lists", "lists_are_tight", "sh_prefill", "sh_lazy"]

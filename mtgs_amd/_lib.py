@@ -31,6 +31,9 @@ _SIGNATURES = {
     "mtgs_sh_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "mtgs_sh_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_sh_bwd_rows": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_sh_fwd_act": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp, _vp],
+    "mtgs_sh_bwd_act": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_sh_bwd_rows_act": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_fill_zero": [_vp, _sz, _vp],
     "mtgs_project_fwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -150,7 +153,7 @@ _SIGNATURES = {
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
 ABI_VERSION = 27
-HOT_ABI_VERSION = 5      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
+HOT_ABI_VERSION = 6      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None
 

@@ -143,12 +143,32 @@ __device__ __forceinline__ void stage_coeffs(float *lds, const float *__restrict
     }
 }
 
+// ---- the colour activation of the callers, fused (round 6) --------------------------------------------------------------------
+// MTGS turns the SH output into a colour with `torch.clamp(rgbs + 0.5, 0.0, 1.0)` (vanilla_gaussian_splatting.py:318, and the same
+// line in the multi-colour / rigid / deformable nodes), gsplat's own sh_degree path with `clamp_min(colors + 0.5, 0)`
+// (rendering.py): two more passes over [N, 3] forward and four backward, all launch-bound (67 us of a 0.93 ms step).  With `act.pass`
+// given the forward kernels write y = clamp(x + add, lo, hi) -- the same two fp32 operations in the same order, NaN propagating as
+// torch.clamp does -- and one byte per Gaussian whose bit c says "channel c passes its cotangent" (lo <= x + add <= hi: torch's
+// clamp backward); the backward kernels mask the incoming cotangent with it.  The Python layer decides when the caller's
+// expression is exactly this one (mtgs_amd/wrapper.py::_LazySH).
+struct ShAct {
+    uint8_t *pass;     // nullable: no activation
+    float add, lo, hi;
+    int has_add;       // 0: y = clamp(x) (no `+ 0.0`: the sign of a zero would change)
+};
+__device__ __forceinline__ float sh_act_apply(const ShAct &a, float x, int c, unsigned &bits) {
+#pragma clang fp contract(off)
+    const float v = a.has_add ? x + a.add : x;
+    if (v >= a.lo && v <= a.hi) bits |= 1u << c;
+    return v < a.lo ? a.lo : (v > a.hi ? a.hi : v);       // (a NaN fails both compares and stays a NaN, as in torch.clamp)
+}
+
 template <int DEG>
 __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(int64_t n, int K,
                                                          const float *__restrict__ dirs,
                                                          const float *__restrict__ coeffs,
                                                          const uint8_t *__restrict__ masks,
-                                                         float *__restrict__ colors) {
+                                                         float *__restrict__ colors, const ShAct act) {
     constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3, STRIDE = NB3 | 1;
     __shared__ float lds[SH_BLOCK * STRIDE];
     const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
@@ -172,6 +192,11 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(int64_t n, int K,
             gg += b[k] * c[k * 3 + 1];
             bb += b[k] * c[k * 3 + 2];
         }
+    }
+    if (act.pass) {
+        unsigned bits = 0u;
+        r = sh_act_apply(act, r, 0, bits); gg = sh_act_apply(act, gg, 1, bits); bb = sh_act_apply(act, bb, 2, bits);
+        act.pass[g] = (uint8_t)bits;
     }
     colors[g * 3] = r; colors[g * 3 + 1] = gg; colors[g * 3 + 2] = bb;
 }
@@ -209,7 +234,7 @@ template <int DEG>
 __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const float *__restrict__ dirs,
                                                                 const float *__restrict__ coeffs,
                                                                 const uint8_t *__restrict__ masks,
-                                                                float *__restrict__ colors) {
+                                                                float *__restrict__ colors, const ShAct act) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
     const ShLaneConst lc = sh_lane_const(k);
@@ -259,7 +284,15 @@ __global__ __launch_bounds__(SH16_BLOCK) void sh_fwd_k16_kernel(int64_t n, const
     myr = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(myr)));
     myg = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(myg)));
     myb = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(myb)));
-    if (gl < n) *reinterpret_cast<F3 *>(colors + gl * 3) = onl ? F3{myr, myg, myb} : F3{0.f, 0.f, 0.f};
+    if (gl < n) {
+        F3 o = onl ? F3{myr, myg, myb} : F3{0.f, 0.f, 0.f};
+        if (act.pass) {
+            unsigned bits = 0u;
+            o.x = sh_act_apply(act, o.x, 0, bits); o.y = sh_act_apply(act, o.y, 1, bits); o.z = sh_act_apply(act, o.z, 2, bits);
+            act.pass[gl] = (uint8_t)bits;
+        }
+        *reinterpret_cast<F3 *>(colors + gl * 3) = o;
+    }
 }
 
 template <int DEG>
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
                                                          const uint8_t *__restrict__ masks,
                                                          const float *__restrict__ v_colors,
                                                          float *__restrict__ v_coeffs,
-                                                         float *__restrict__ v_dirs) {
+                                                         float *__restrict__ v_dirs, const uint8_t *__restrict__ pass) {
     constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3, STRIDE = NB3 | 1;
     __shared__ float lds[SH_BLOCK * STRIDE];
     const int64_t g0 = (int64_t)blockIdx.x * SH_BLOCK;
@@ -290,7 +323,11 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
             x *= inorm; y *= inorm; z *= inorm;
             float b[NB];
             sh_bases_dev(DEG, x, y, z, b);
-            const float v0 = v_colors[g * 3], v1 = v_colors[g * 3 + 1], v2 = v_colors[g * 3 + 2];
+            float v0 = v_colors[g * 3], v1 = v_colors[g * 3 + 1], v2 = v_colors[g * 3 + 2];
+            if (pass) {      // the fused activation's backward: a clamped channel passes no cotangent
+                const unsigned pb = pass[g];
+                v0 = (pb & 1u) ? v0 : 0.f; v1 = (pb & 2u) ? v1 : 0.f; v2 = (pb & 4u) ? v2 : 0.f;
+            }
             if (v_dirs) {
                 float s[NB];
 #pragma unroll
@@ -351,7 +388,8 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(int64_t n, int K,
 // lanes -- 20 us of the 36 us this kernel took on 2M rows, 6 % of them with a cotangent (cold; scripts/dev/shrows_bench.py).
 template <int DEG>
 __global__ __launch_bounds__(256) void sh_bwd_rows_kernel(int64_t n, int K, const float *__restrict__ dirs, const uint8_t *__restrict__ masks,
-                                                          const float *__restrict__ v_colors, float *__restrict__ v_coeffs) {
+                                                          const float *__restrict__ v_colors, float *__restrict__ v_coeffs,
+                                                          const uint8_t *__restrict__ pass) {
     constexpr int NB = (DEG + 1) * (DEG + 1), NB3 = NB * 3;
     __shared__ __attribute__((aligned(16))) float s_p[4][256];
     __shared__ int s_row[4][64];
@@ -362,6 +400,10 @@ __global__ __launch_bounds__(256) void sh_bwd_rows_kernel(int64_t n, int K, cons
     bool nz = false;
     if (g < n) {
         v[0] = v_colors[g * 3]; v[1] = v_colors[g * 3 + 1]; v[2] = v_colors[g * 3 + 2];
+        if (pass && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f)) {      // (the byte is only fetched for a Gaussian with a cotangent)
+            const unsigned pb = pass[g];
+            v[0] = (pb & 1u) ? v[0] : 0.f; v[1] = (pb & 2u) ? v[1] : 0.f; v[2] = (pb & 4u) ? v[2] : 0.f;
+        }
         nz = !(v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) && !(masks && !masks[g]);
     }
     unsigned long long m = __ballot(nz);
@@ -416,7 +458,14 @@ __global__ __launch_bounds__(256) void sh_bwd_rows_kernel(int64_t n, int K, cons
 
 extern "C" int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
                            const uint8_t *masks, float *colors, void *stream) {
+    return mtgs_sh_fwd_act(n, K, degree, dirs, coeffs, masks, colors, 0, 0.f, 0.f, 0.f, nullptr, stream);
+}
+
+extern "C" int mtgs_sh_fwd_act(int64_t n, int K, int degree, const float *dirs, const float *coeffs, const uint8_t *masks, float *colors,
+                               int has_add, float add, float lo, float hi, uint8_t *pass, void *stream) {
     MTGS_REQUIRE(n >= 0 && K > 0, MTGS_EINVAL, "mtgs_sh_fwd: bad sizes n=%lld K=%d", (long long)n, K);
+    MTGS_REQUIRE(!pass || lo <= hi, MTGS_EINVAL, "mtgs_sh_fwd_act: lo %g > hi %g", (double)lo, (double)hi);
+    const ShAct act{pass, add, lo, hi, has_add ? 1 : 0};
     MTGS_REQUIRE(degree >= 0 && degree <= MTGS_MAX_SH_DEGREE && (degree + 1) * (degree + 1) <= K,
                  MTGS_EINVAL, "mtgs_sh_fwd: degree %d needs (degree+1)^2 <= K=%d and degree <= 4", degree, K);
     if (n == 0) return MTGS_OK;
@@ -425,21 +474,21 @@ extern "C" int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, cons
     if (K == 16 && degree <= 3) {
         const unsigned g16 = (unsigned)ceil_div64(n, SH16_PER_WAVE * (SH16_BLOCK / 64));
         switch (degree) {
-            case 0: sh_fwd_k16_kernel<0><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
-            case 1: sh_fwd_k16_kernel<1><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
-            case 2: sh_fwd_k16_kernel<2><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
-            default: sh_fwd_k16_kernel<3><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors); break;
+            case 0: sh_fwd_k16_kernel<0><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors, act); break;
+            case 1: sh_fwd_k16_kernel<1><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors, act); break;
+            case 2: sh_fwd_k16_kernel<2><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors, act); break;
+            default: sh_fwd_k16_kernel<3><<<g16, SH16_BLOCK, 0, st>>>(n, dirs, coeffs, masks, colors, act); break;
         }
         MTGS_CHECK_LAUNCH("mtgs_sh_fwd");
         return MTGS_OK;
     }
     const unsigned grid = (unsigned)ceil_div64(n, SH_BLOCK);
     switch (degree) {
-        case 0: sh_fwd_kernel<0><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
-        case 1: sh_fwd_kernel<1><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
-        case 2: sh_fwd_kernel<2><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
-        case 3: sh_fwd_kernel<3><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
-        default: sh_fwd_kernel<4><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors); break;
+        case 0: sh_fwd_kernel<0><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors, act); break;
+        case 1: sh_fwd_kernel<1><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors, act); break;
+        case 2: sh_fwd_kernel<2><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors, act); break;
+        case 3: sh_fwd_kernel<3><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors, act); break;
+        default: sh_fwd_kernel<4><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, colors, act); break;
     }
     MTGS_CHECK_LAUNCH("mtgs_sh_fwd");
     return MTGS_OK;
@@ -448,6 +497,11 @@ extern "C" int mtgs_sh_fwd(int64_t n, int K, int degree, const float *dirs, cons
 extern "C" int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, const float *coeffs,
                            const uint8_t *masks, const float *v_colors, float *v_coeffs,
                            float *v_dirs, void *stream) {
+    return mtgs_sh_bwd_act(n, K, degree, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, nullptr, stream);
+}
+
+extern "C" int mtgs_sh_bwd_act(int64_t n, int K, int degree, const float *dirs, const float *coeffs, const uint8_t *masks,
+                               const float *v_colors, float *v_coeffs, float *v_dirs, const uint8_t *pass, void *stream) {
     MTGS_REQUIRE(n >= 0 && K > 0, MTGS_EINVAL, "mtgs_sh_bwd: bad sizes n=%lld K=%d", (long long)n, K);
     MTGS_REQUIRE(degree >= 0 && degree <= MTGS_MAX_SH_DEGREE && (degree + 1) * (degree + 1) <= K,
                  MTGS_EINVAL, "mtgs_sh_bwd: degree %d needs (degree+1)^2 <= K=%d and degree <= 4", degree, K);
@@ -456,7 +510,7 @@ extern "C" int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, cons
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(n, SH_BLOCK);
 #define MTGS_SH_BWD(DG) \
-    sh_bwd_kernel<DG><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs)
+    sh_bwd_kernel<DG><<<grid, SH_BLOCK, 0, st>>>(n, K, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs, pass)
     switch (degree) {
         case 0: MTGS_SH_BWD(0); break;
         case 1: MTGS_SH_BWD(1); break;
@@ -471,6 +525,11 @@ extern "C" int mtgs_sh_bwd(int64_t n, int K, int degree, const float *dirs, cons
 
 extern "C" int mtgs_sh_bwd_rows(int64_t n, int K, int degree, const float *dirs, const uint8_t *masks, const float *v_colors,
                                 float *v_coeffs, void *stream) {
+    return mtgs_sh_bwd_rows_act(n, K, degree, dirs, masks, v_colors, v_coeffs, nullptr, stream);
+}
+
+extern "C" int mtgs_sh_bwd_rows_act(int64_t n, int K, int degree, const float *dirs, const uint8_t *masks, const float *v_colors,
+                                    float *v_coeffs, const uint8_t *pass, void *stream) {
     MTGS_REQUIRE(n >= 0 && K > 0, MTGS_EINVAL, "mtgs_sh_bwd_rows: bad sizes n=%lld K=%d", (long long)n, K);
     MTGS_REQUIRE(degree >= 0 && degree <= MTGS_MAX_SH_DEGREE && (degree + 1) * (degree + 1) <= K, MTGS_EINVAL,
                  "mtgs_sh_bwd_rows: degree %d needs (degree+1)^2 <= K=%d and degree <= 4", degree, K);
@@ -479,7 +538,7 @@ extern "C" int mtgs_sh_bwd_rows(int64_t n, int K, int degree, const float *dirs,
     MTGS_REQUIRE((K * 3) % 4 != 0 || (reinterpret_cast<uintptr_t>(v_coeffs) & 15) == 0, MTGS_EINVAL, "mtgs_sh_bwd_rows: v_coeffs must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(n, 256);
-#define MTGS_SH_ROWS(DG) sh_bwd_rows_kernel<DG><<<grid, 256, 0, st>>>(n, K, dirs, masks, v_colors, v_coeffs)
+#define MTGS_SH_ROWS(DG) sh_bwd_rows_kernel<DG><<<grid, 256, 0, st>>>(n, K, dirs, masks, v_colors, v_coeffs, pass)
     switch (degree) {
         case 0: MTGS_SH_ROWS(0); break;
         case 1: MTGS_SH_ROWS(1); break;

@@ -169,17 +169,27 @@ def sh_prefill(enabled: bool = True, in_forward: bool = True):
 
 
 class _SphericalHarmonics(torch.autograd.Function):
+    """spherical_harmonics(), optionally with the caller's colour activation fused: act = None, or (has_add, add, lo, hi) for
+    colors = clamp(SH + add, lo, hi) (csrc/sh.hip, ShAct; the decision is _LazySH's)."""
+
     @staticmethod
-    def forward(ctx, degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor]):
+    def forward(ctx, degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor], act=None):
         require_gpu(dirs, coeffs, masks)
         dirs_c, coeffs_c = _f32c(dirs), _f32c(coeffs)
         K = coeffs_c.shape[-2]
         n = dirs_c.numel() // 3
         masks_c = None if masks is None else masks.contiguous().to(torch.uint8)
         colors = torch.empty(dirs_c.shape, dtype=torch.float32, device=dirs_c.device)
-        call("mtgs_sh_fwd", n, K, degree, ptr(dirs_c), ptr(coeffs_c), ptr(masks_c), ptr(colors),
-             stream_of(dirs_c))
-        ctx.save_for_backward(dirs_c, coeffs_c, masks_c)
+        passed = None
+        if act is None:
+            call("mtgs_sh_fwd", n, K, degree, ptr(dirs_c), ptr(coeffs_c), ptr(masks_c), ptr(colors),
+                 stream_of(dirs_c))
+        else:
+            has_add, add, lo, hi = act
+            passed = torch.empty(max(n, 1), dtype=torch.uint8, device=dirs_c.device)      # bit c: channel c passes its cotangent
+            call("mtgs_sh_fwd_act", n, K, degree, ptr(dirs_c), ptr(coeffs_c), ptr(masks_c), ptr(colors), int(has_add), float(add),
+                 float(lo), float(hi), ptr(passed), stream_of(dirs_c))
+        ctx.save_for_backward(dirs_c, coeffs_c, masks_c, passed)
         ctx.degree, ctx.K, ctx.n = degree, K, n
         # (see _Prefill: zeros for dL/dcoeffs, filled while the rasterizer's backward runs)
         ctx.zeros = _prefill.request(coeffs_c.shape, coeffs_c.device) if (ctx.needs_input_grad[2] and not ctx.needs_input_grad[1]
@@ -188,7 +198,7 @@ class _SphericalHarmonics(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_colors: Tensor):
-        dirs, coeffs, masks = ctx.saved_tensors
+        dirs, coeffs, masks, passed = ctx.saved_tensors
         v_colors = _f32c(v_colors)
         need_dirs = ctx.needs_input_grad[1]
         req = ctx.zeros
@@ -196,15 +206,132 @@ class _SphericalHarmonics(torch.autograd.Function):
         #  i.e. on the same stream, may take them)
         if req is not None and req.buffer is not None and not need_dirs and req.stream == stream_of(dirs):
             v_coeffs, req.buffer = req.buffer, None
-            call("mtgs_sh_bwd_rows", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(masks), ptr(v_colors), ptr(v_coeffs), stream_of(dirs))
-            return None, None, v_coeffs, None
+            if passed is None:
+                call("mtgs_sh_bwd_rows", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(masks), ptr(v_colors), ptr(v_coeffs), stream_of(dirs))
+            else:
+                call("mtgs_sh_bwd_rows_act", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(masks), ptr(v_colors), ptr(v_coeffs), ptr(passed),
+                     stream_of(dirs))
+            return None, None, v_coeffs, None, None
         v_coeffs = torch.empty_like(coeffs)
         v_dirs = torch.empty_like(dirs) if need_dirs else None
-        call("mtgs_sh_bwd", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(coeffs), ptr(masks),
-             ptr(v_colors), ptr(v_coeffs), ptr(v_dirs), stream_of(dirs))
+        if passed is None:
+            call("mtgs_sh_bwd", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(coeffs), ptr(masks),
+                 ptr(v_colors), ptr(v_coeffs), ptr(v_dirs), stream_of(dirs))
+        else:
+            call("mtgs_sh_bwd_act", ctx.n, ctx.K, ctx.degree, ptr(dirs), ptr(coeffs), ptr(masks), ptr(v_colors), ptr(v_coeffs),
+                 ptr(v_dirs), ptr(passed), stream_of(dirs))
         if not ctx.needs_input_grad[2]:
             v_coeffs = None
-        return None, v_dirs, v_coeffs, None
+        return None, v_dirs, v_coeffs, None, None
+
+
+# ---- the caller's colour activation, fused without touching the caller ------------------------------------------------------------
+# MTGS writes, behind every spherical_harmonics() call,
+#     rgbs = spherical_harmonics(n, viewdirs, colors);  rgbs = torch.clamp(rgbs + 0.5, 0.0, 1.0)
+# (vanilla_gaussian_splatting.py:317-318, multi_color_gaussian_splatting.py:96, rigid_node.py:248, deformable_node.py:125), gsplat's own
+# sh_degree path `clamp_min(colors + 0.5, 0.0)`.  Those two elementwise expressions are six launch-bound kernels per step (forward:
+# add, clamp; backward: two compares, and, where -- 67 us of the 0.93 ms headline step, profiles/r05_bench_kernel_stats.csv).
+# spherical_harmonics() therefore returns a DEFERRED tensor: nothing has run yet.  `x + c` (a Python scalar) stays deferred; `clamp` /
+# `clip` / `clamp_min` / `clamp_max` with scalar bounds on it runs ONE kernel that evaluates SH, adds and clamps (the same fp32
+# operations in the same order: bit-identical values) and records torch's clamp-backward mask, and the SH backward applies that mask
+# -- one autograd node for the three.  ANY other use (arithmetic, indexing, .sum(), .grad_fn, passing it to a kernel ...)
+# materialises the plain SH output once and carries on with an ordinary tensor, so every other program behaves exactly as before.
+# `mtgs_amd.sh_lazy(False)` (or MTGS_SH_LAZY=0) switches the deferral off.
+def _is_number(v) -> bool:
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
+
+
+class _LazySH(Tensor):
+    @staticmethod
+    def __new__(cls, degree, dirs, coeffs, masks, base=None, add=None):
+        rg = torch.is_grad_enabled() and (coeffs.requires_grad or dirs.requires_grad)
+        r = Tensor._make_wrapper_subclass(cls, dirs.shape, dtype=torch.float32, device=dirs.device, requires_grad=rg)
+        r._lz_sh = (degree, dirs, coeffs, masks)
+        r._lz_base, r._lz_add, r._lz_plain = base, add, None
+        return r
+
+    def _materialize(self) -> Tensor:
+        """The ordinary tensor this object stands for (computed once)."""
+        if self._lz_plain is None:
+            with torch._C.DisableTorchFunctionSubclass():
+                if self._lz_base is not None:
+                    self._lz_plain = self._lz_base._materialize() + self._lz_add
+                else:
+                    self._lz_plain = _SphericalHarmonics.apply(*self._lz_sh)
+        return self._lz_plain
+
+    def _fused(self, lo: float, hi: float) -> Tensor:
+        has_add = self._lz_add is not None
+        with torch._C.DisableTorchFunctionSubclass():
+            return _SphericalHarmonics.apply(*self._lz_sh, (has_add, self._lz_add if has_add else 0.0, lo, hi))
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        me = args[0] if args and isinstance(args[0], _LazySH) else None
+        name = getattr(func, "__name__", "")
+        if me is not None and me._lz_plain is None:
+            if func in _LAZY_META or (name == "__get__" and getattr(func, "__self__", None) in _LAZY_META_PROPS):
+                with torch._C.DisableTorchFunctionSubclass():
+                    return func(*args, **kwargs)
+            # x + c, c + x with a Python scalar: stays deferred (one pending add at most)
+            if func in _LAZY_ADD and me._lz_base is None and len(args) == 2 and _is_number(args[1]) and kwargs.get("alpha", 1) == 1 \
+                    and not (set(kwargs) - {"alpha"}):
+                return _LazySH(*me._lz_sh, base=me, add=float(args[1]))
+            # clamp(x, lo, hi) / clip / clamp_min / clamp_max with scalar bounds: the fused kernel
+            if func in _LAZY_CLAMP:
+                a = list(args[1:])
+                lo = kwargs.get("min", a[0] if len(a) > 0 else None)
+                hi = kwargs.get("max", a[1] if len(a) > 1 else None)
+                if func in _LAZY_CLAMP_MAX:
+                    lo, hi = None, kwargs.get("max", a[0] if a else None)
+                ok = not (set(kwargs) - {"min", "max"}) and len(a) <= 2 and (lo is None or _is_number(lo)) and (hi is None or _is_number(hi)) \
+                    and not (lo is None and hi is None) and not (lo is not None and hi is not None and lo > hi)
+                if ok:
+                    root = me._lz_base if me._lz_base is not None else me
+                    if root._lz_plain is None:
+                        return me._fused(float("-inf") if lo is None else float(lo), float("inf") if hi is None else float(hi))
+        # everything else: ordinary tensors from here on
+        args, kwargs = _lazy_plain(args), _lazy_plain(kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # (a path that went around __torch_function__ -- C++ callers: the same rule, ordinary tensors from here on)
+        return func(*_lazy_plain(args), **_lazy_plain(kwargs or {}))
+
+
+def _lazy_plain(v):
+    if isinstance(v, _LazySH):
+        return v._materialize()
+    if isinstance(v, (list, tuple)):
+        return type(v)(_lazy_plain(e) for e in v)
+    if isinstance(v, dict):
+        return {k: _lazy_plain(e) for k, e in v.items()}
+    return v
+
+
+_LAZY_META = {Tensor.size, Tensor.dim, Tensor.numel, Tensor.nelement, Tensor.ndimension, Tensor.is_floating_point, Tensor.is_complex,
+              Tensor.element_size, Tensor.get_device}
+_LAZY_META_PROPS = {Tensor.shape, Tensor.dtype, Tensor.device, Tensor.ndim, Tensor.is_cuda, Tensor.layout, Tensor.requires_grad,
+                    Tensor.is_sparse, Tensor.is_quantized, Tensor.is_meta}
+_LAZY_ADD = {torch.add, Tensor.add, Tensor.__add__, Tensor.__radd__}
+_LAZY_CLAMP_MAX = {torch.clamp_max, Tensor.clamp_max}
+_LAZY_CLAMP = {torch.clamp, Tensor.clamp, torch.clip, Tensor.clip, torch.clamp_min, Tensor.clamp_min} | _LAZY_CLAMP_MAX
+_lazy_sh_enabled = os.environ.get("MTGS_SH_LAZY", "1") == "1"
+
+
+@contextlib.contextmanager
+def sh_lazy(enabled: bool = True):
+    """Switches the deferred evaluation of spherical_harmonics() (see _LazySH) for the enclosed calls: False = the function runs its
+    kernel at once and returns an ordinary tensor, the caller's `clamp(x + 0.5, ...)` stays PyTorch's."""
+    global _lazy_sh_enabled
+    old, _lazy_sh_enabled = _lazy_sh_enabled, bool(enabled)
+    try:
+        yield
+    finally:
+        _lazy_sh_enabled = old
 
 
 def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
@@ -218,6 +345,9 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
         assert masks.shape == dirs.shape[:-1], masks.shape
     if degrees_to_use > 4:
         raise NotImplementedError("spherical_harmonics: degrees_to_use > 4")
+    if _lazy_sh_enabled and type(dirs) is Tensor and type(coeffs) is Tensor and dirs.is_cuda and coeffs.is_cuda \
+            and dirs.dtype == torch.float32 and coeffs.dtype == torch.float32 and (masks is None or masks.is_cuda):
+        return _LazySH(degrees_to_use, dirs, coeffs, masks)
     return _SphericalHarmonics.apply(degrees_to_use, dirs, coeffs, masks)
 
 

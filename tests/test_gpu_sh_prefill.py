@@ -45,7 +45,7 @@ def test_zeros_from_the_compositing_kernels_plus_rows_equal_the_dense_backward(h
     calls = []
     real = wrapper.call
     try:
-        wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        wrapper.call = lambda name, *a: (calls.append(name.replace("_act", "")), real(name, *a))[1]      # (the fused-activation forms count as their plain ones)
         got = _step(*args, degree=degree, dense_extra=dense_extra)
     finally:
         wrapper.call = real
@@ -162,7 +162,7 @@ def test_served_by_the_forward_or_by_the_backward_and_backward_twice(hip_lib, in
     calls = []
     real = wrapper.call
     try:
-        wrapper.call = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        wrapper.call = lambda name, *a: (calls.append((name.replace("_act", ""), a)), real(name, *a))[1]
         for p in P.values():
             p.grad = None
         dirs = P["means"].detach() - torch.inverse(vm)[0, :3, 3]
@@ -215,7 +215,7 @@ def test_two_nodes_one_rasterization_and_a_backward_on_another_stream(hip_lib):
     calls = []
     real = wrapper.call
     try:
-        wrapper.call = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        wrapper.call = lambda name, *a: (calls.append((name.replace("_act", ""), a)), real(name, *a))[1]
         gA, gB = run()
     finally:
         wrapper.call = real
@@ -239,12 +239,12 @@ def test_two_nodes_one_rasterization_and_a_backward_on_another_stream(hip_lib):
     rgb = torch.clamp(sh + 0.5, 0.0, 1.0)
     render, alpha, info = rasterization(P["means"].detach(), P["quats"].detach(), P["scales"].detach(), P["opacities"].detach(), rgb, vm, K,
                                         WH[0], WH[1], packed=False, render_mode="RGB+ED", rasterize_mode="antialiased")
-    req = sh.grad_fn.zeros
+    req = wrapper._Prefill.behind(rgb)[0]            # (the request on the SH node behind these colours -- fused activation or not)
     assert req is not None and req.buffer is not None
     req.stream = side.cuda_stream                     # (as if the rasterization had run over there)
     calls.clear()
     try:
-        wrapper.call = lambda name, *a: (calls.append((name, a)), real(name, *a))[1]
+        wrapper.call = lambda name, *a: (calls.append((name.replace("_act", ""), a)), real(name, *a))[1]
         torch.autograd.backward([render, alpha], [Gc, Ga])
     finally:
         wrapper.call = real
@@ -272,7 +272,7 @@ def test_gsplats_sh_degree_call_style_writes_the_coefficient_gradient_in_place(h
     calls = []
     real = wrapper.call
     try:
-        wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        wrapper.call = lambda name, *a: (calls.append(name.replace("_act", "")), real(name, *a))[1]      # (the fused-activation forms count as their plain ones)
         got = run()
     finally:
         wrapper.call = real
@@ -326,8 +326,9 @@ def test_a_second_models_rasterization_does_not_serve_the_first_models_request(h
                              absgrad=True, rasterize_mode="antialiased")
 
     sh_a = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
-    req_a = sh_a.grad_fn.zeros
-    assert req_a is not None and req_a in pf.pending and wrapper._Prefill.behind(torch.clamp(sh_a + 0.5, 0.0, 1.0)[None]) == [req_a]
+    rgb_a = torch.clamp(sh_a + 0.5, 0.0, 1.0)          # (with the deferred SH this IS the spherical_harmonics() node: one kernel)
+    (req_a,) = wrapper._Prefill.behind(rgb_a[None])
+    assert req_a is not None and req_a in pf.pending
     # model B: plain colours that need a gradient (no SH behind them)
     col_b = torch.rand(200_000, 3, device=dev, requires_grad=True)
     assert wrapper._Prefill.behind(col_b) == []
@@ -340,11 +341,11 @@ def test_a_second_models_rasterization_does_not_serve_the_first_models_request(h
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        raster(PA, torch.clamp(sh_a + 0.5, 0.0, 1.0))
+        raster(PA, rgb_a)
     torch.cuda.current_stream().wait_stream(side)
     assert req_a.buffer is None and req_a in pf.pending
     # A's own rasterization on A's stream serves it
-    ra, aa, _ = raster(PA, torch.clamp(sh_a + 0.5, 0.0, 1.0))
+    ra, aa, _ = raster(PA, rgb_a)
     assert req_a.buffer is not None and req_a not in pf.pending and req_a.buffer.shape == PA["coeffs"].shape
     assert pf.last_region_bytes >= PA["coeffs"].numel() * 4
     ((ra * Gc).sum() + (aa * Ga).sum() + (rb * Gc).sum()).backward()
@@ -352,17 +353,17 @@ def test_a_second_models_rasterization_does_not_serve_the_first_models_request(h
     with wrapper.sh_prefill(enabled=False):
         for p in PA.values():
             p.grad = None
-        sh2 = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
-        assert sh2.grad_fn.zeros is None
-        r2, a2, _ = raster(PA, torch.clamp(sh2 + 0.5, 0.0, 1.0))
+        rgb2 = torch.clamp(spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"]) + 0.5, 0.0, 1.0)
+        assert wrapper._Prefill.behind(rgb2) == []
+        r2, a2, _ = raster(PA, rgb2)
         ((r2 * Gc).sum() + (a2 * Ga).sum()).backward()
     assert pf.enabled
     assert torch.equal(got != 0, PA["coeffs"].grad != 0)
     torch.testing.assert_close(got, PA["coeffs"].grad, rtol=1e-3, atol=1e-5 * float(got.abs().max()))
     # expiry: a request nobody served is dropped by the next forward of the same shape
-    s1 = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
-    r1 = s1.grad_fn.zeros
-    s2 = spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"])
-    assert r1 not in pf.pending and s2.grad_fn.zeros in pf.pending
+    s1 = torch.clamp(spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"]) + 0.5, 0.0, 1.0)
+    (r1,) = wrapper._Prefill.behind(s1)
+    s2 = torch.clamp(spherical_harmonics(3, PA["means"].detach() - cam, PA["coeffs"]) + 0.5, 0.0, 1.0)
+    assert r1 not in pf.pending and wrapper._Prefill.behind(s2)[0] in pf.pending
     (s1.sum() + s2.sum()).backward()            # both take the dense backward
     assert bool(torch.isfinite(PA["coeffs"].grad).all())

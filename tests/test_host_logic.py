@@ -214,3 +214,47 @@ def test_round3_host_logic_without_a_gpu():
     cs = nodes.ColorSource(None, 1, 3, None, [], [])
     with pytest.raises(AssertionError):
         cs.apply_to(o)
+
+
+def test_deferred_sh_dispatch_rules_on_cpu(monkeypatch):
+    """mtgs_amd.wrapper._LazySH's decisions without a GPU: which expressions stay deferred, which take the fused kernel (with which
+    activation), which materialise -- the SH autograd function replaced by a torch stand-in (a linear map of the coefficients)."""
+    import torch
+    from mtgs_amd import wrapper
+    seen = []
+
+    class Fake:
+        @staticmethod
+        def apply(degree, dirs, coeffs, masks, act=None):
+            seen.append(act)
+            x = coeffs[..., 0, :] * 2.0 + dirs
+            if act is None:
+                return x
+            has_add, add, lo, hi = act
+            return torch.clamp(x + add if has_add else x, lo, hi)
+
+    monkeypatch.setattr(wrapper, "_SphericalHarmonics", Fake)
+    d, c = torch.randn(7, 3), torch.randn(7, 16, 3, requires_grad=True)
+    ref = c[..., 0, :] * 2.0 + d
+    new = lambda: wrapper._LazySH(3, d, c, None)
+    x = new()
+    assert (x.shape, x.dtype, x.dim(), x.numel(), x.requires_grad, x.device.type) == (d.shape, torch.float32, 2, 21, True, "cpu") and not seen
+    y = torch.clamp(x + 0.5, 0.0, 1.0)
+    assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor and torch.equal(y, torch.clamp(ref + 0.5, 0.0, 1.0))
+    seen.clear()
+    assert torch.equal(torch.clamp_min(0.5 + new(), 0.0), torch.clamp_min(ref + 0.5, 0.0)) and seen == [(True, 0.5, 0.0, float("inf"))]
+    seen.clear()
+    assert torch.equal(new().clamp(max=0.25), ref.clamp(max=0.25)) and seen == [(False, 0.0, float("-inf"), 0.25)]
+    seen.clear()
+    # not the pattern: a tensor addend, alpha, a second add, tensor bounds, min > max, an `out=` -> ordinary tensors (act None)
+    for expr, want in ((lambda z: z + torch.ones(7, 3), ref + 1), (lambda z: torch.add(z, 1.0, alpha=3), ref + 3.0),
+                       (lambda z: (z + 0.5) + 0.25, ref + 0.5 + 0.25), (lambda z: torch.clamp(z, torch.zeros(7, 3), torch.ones(7, 3)), ref.clamp(0, 1)),
+                       (lambda z: torch.clamp(z + 0.5, 1.0, 0.0), torch.clamp(ref + 0.5, 1.0, 0.0)), (lambda z: z * 2, ref * 2), (lambda z: z[2:4], ref[2:4])):
+        seen.clear()
+        got = expr(new())
+        assert seen == [None] and torch.equal(got, want)
+    # used twice: materialised ONCE
+    seen.clear()
+    z = new()
+    a, b = z + 0.5, z.sum()
+    assert torch.equal(a * 1, ref + 0.5) and seen == [None]
