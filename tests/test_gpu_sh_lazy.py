@@ -58,8 +58,9 @@ def test_fused_activation_is_the_three_torch_operations_bit_for_bit(hip_lib, for
             y2 = FORMS[form](x2)
             (y2 * v).sum().backward()
         assert torch.equal(y, y2) and torch.equal(c1.grad, c2.grad), (form, K, degree, m is not None)
-        frac = float(((y2 == y2.min()) | (y2 == y2.max())).float().mean())
-        assert 0.02 < frac < 0.98, frac      # (the clamp binds on a real share of the channels: the mask is exercised)
+        if form == "mtgs" and degree > 0:      # (the clamp binds on a real share of the channels: the mask is exercised)
+            frac = float(((y2 == 0.0) | (y2 == 1.0)).float().mean())
+            assert 0.02 < frac < 0.98, frac
 
 
 def test_bounds_are_inclusive_and_nan_propagates_like_torch(hip_lib):
