@@ -236,6 +236,8 @@ class _SphericalHarmonics(torch.autograd.Function):
 # operations in the same order: bit-identical values) and records torch's clamp-backward mask, and the SH backward applies that mask
 # -- one autograd node for the three.  ANY other use (arithmetic, indexing, .sum(), .grad_fn, passing it to a kernel ...)
 # materialises the plain SH output once and carries on with an ordinary tensor, so every other program behaves exactly as before.
+# The one cost: a program that uses the RAW output a second time besides clamping it (`clamp(x + 0.5, 0, 1)` AND, say, a regulariser on
+# `x`) evaluates SH twice -- the fused kernel and a plain one, each with its own backward; MTGS never does (get_rgbs clamps at once).
 # `mtgs_amd.sh_lazy(False)` (or MTGS_SH_LAZY=0) switches the deferral off.
 def _is_number(v) -> bool:
     return isinstance(v, (int, float)) and not isinstance(v, bool)
