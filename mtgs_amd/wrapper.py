@@ -347,7 +347,8 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
         assert masks.shape == dirs.shape[:-1], masks.shape
     if degrees_to_use > 4:
         raise NotImplementedError("spherical_harmonics: degrees_to_use > 4")
-    if _lazy_sh_enabled and type(dirs) is Tensor and type(coeffs) is Tensor and dirs.is_cuda and coeffs.is_cuda \
+    plain_types = (Tensor, torch.nn.Parameter)      # (not other tensor subclasses: their __torch_function__ has its own plans)
+    if _lazy_sh_enabled and type(dirs) in plain_types and type(coeffs) in plain_types and dirs.is_cuda and coeffs.is_cuda \
             and dirs.dtype == torch.float32 and coeffs.dtype == torch.float32 and (masks is None or masks.is_cuda):
         return _LazySH(degrees_to_use, dirs, coeffs, masks)
     return _SphericalHarmonics.apply(degrees_to_use, dirs, coeffs, masks)
