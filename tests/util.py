@@ -411,7 +411,7 @@ def assert_same_curve(a, b, rel=2e-3, floor=1e-3):
     assert not bad, (f"{len(bad)} of {len(a)} points differ by more than {rel:g}; worst at {worst}: {a[worst]!r} vs {b[worst]!r}", a, b)
 
 
-def assert_same_training(out_a, out_b, n_refinements, steps, refine_every, rel=2e-3, loose=0.15, later_sizes=None, first_sizes=1e-4):
+def assert_same_training(out_a, out_b, n_refinements, steps, refine_every, rel=2e-3, loose=0.15, later_sizes=None, first_sizes=1e-4, mid=1e-2):
     """Two runs of scripts/mtgs_like_train.py that are the same job up to the order of floating-point sums (ranks vs
     accumulation, compact vs dense gradients; the compositing atomics have no fixed order even between two runs of ONE
     configuration): same refinements (same_refinements) and the same loss curve -- to `rel` up to the first refinement at which
@@ -428,5 +428,9 @@ def assert_same_training(out_a, out_b, n_refinements, steps, refine_every, rel=2
     cut = (differ[0] + 1) * refine_every if differ else steps          # steps before `cut` saw identical Gaussian sets
     k = max(1, steps // 8)                                             # (one curve point = the mean over k steps)
     for j, (x, y) in enumerate(zip(a, b)):
-        tol = rel if (j + 1) * k <= cut else loose
+        # `rel` while no refinement has happened (identical Gaussian sets for sure); `mid` behind a refinement that produced EQUAL
+        # SIZES (equal counts are not identical sets: the selection near the thresholds may already differ, and the atomics-order
+        # noise of ~100 steps feeds back through it -- observed 0.0525 vs 0.0528 on the last point of one run in three, round 6);
+        # `loose` once the sizes themselves differ
+        tol = (rel if (j + 1) * k <= refine_every else mid) if (j + 1) * k <= cut else loose
         assert abs(x - y) <= tol * max(abs(y), 1e-3), (j, x, y, tol, sa, sb, a, b)
