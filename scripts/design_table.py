@@ -25,6 +25,10 @@ for k in line["roofline"]["kernels"]:
     rows.append((us or 0.0, f"| `{name}` (`{f}`) | {k['algorithmic_bytes'] / 1e6:.0f} MB | {us:.1f} | "
                  f"{k.get('frac_of_hbm_peak_counter', 0) or 0:.2f} ({k['counter_bytes_committed'] / 1e6:.0f} MB) | "
                  + (f"{cpi:.2f} ({(ceil_ / cpi):.2f} of {ceil_:.2f})" if cpi and ceil_ else "-") + f" | {k.get('bound') or '-'} |"))
+split = next((e.get("algorithmic_bytes_split") for e in line["roofline"]["entry_points"] if e["entry_point"] == "mtgs_blend_fwd_packed"), None)
+if split:      # the zeros that ride on the compositing forward are not compositing bytes (SURVEY 8(d)'s unit)
+    rows = [(u, r.replace(" MB | ", f" MB ({split['compositing'] / 1e6:.0f} compositing + {split['riding_zeros'] / 1e6:.0f} riding zeros) | ", 1)
+             if "`blend_fwd_kernel" in r else r) for u, r in rows]
 rows.sort(key=lambda r: -r[0])
 head = ("| kernel (file) | algorithmic HBM bytes | avg µs | of HBM peak (counter bytes) | cycles / VALU inst (of its ceiling) | bound |\n"
         "|---|---|---|---|---|---|\n")
