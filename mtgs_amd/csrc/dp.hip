@@ -237,7 +237,6 @@ struct DpSenders {
 constexpr int DP_MAX_SENDERS = 64;  // one lane per sender computes its row span of a tile
 constexpr int DP_TILE = 32;    // Gaussians per wave (half a visibility word)
 constexpr int DP_MAXSTEP = DP_TILE / 4;
-constexpr int DP_DEPTH = 4;      // senders whose rows are in flight together (dp_reduce_kernel)
 // ROW-centric inside a Gaussian tile: a wave owns 32 consecutive Gaussians and keeps their 16 x 4 accumulators
 // (lane k: geometry component k | coefficient k x rgb) in LDS.  Rows are packed in index order, so the rows a sender
 // has for the tile are CONTIGUOUS: [prefix + popcount(bits below the tile), + popcount(tile bits)).  The wave walks
@@ -316,10 +315,10 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         if (ubits == 0u) return;
     }
     geom &= 1;
-    // The senders are walked in GROUPS of DP_DEPTH: the row loads of every sender of a group are issued before any is used, so a tile
-    // pays one memory round trip per group, not per sender (round 6: one sender ahead was one exposed round trip EACH -- at eight
-    // senders with ~2 rows per (tile, sender) the kernel was the latency of eight dependent gathers: 196 us for 85 MB of rows).  The
-    // accumulation stays in sender order: the sums are bit-identical to the one-sender-at-a-time walk.
+    // Software pipeline over the senders: the rows of sender r + 1 are in flight while sender r is accumulated
+    // (all of a sender's row loads are issued before any is used: one memory round trip per sender, overlapped).
+    float nxt[DP_MAXSTEP];
+    int nxt_cnt = 0;
     auto issue = [&](int r, float (&dst)[DP_MAXSTEP], int &cnt_out) {
         const int2 sp = s_span[wave][r];
         const int start = __builtin_amdgcn_readfirstlane(sp.x);
@@ -347,9 +346,17 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
         while (r < S.W && !(geom || (any_colour && ((coeff_mask >> r) & 1ull)))) ++r;
         return r;
     };
-    auto accumulate = [&](const int r, const float (&cur)[DP_MAXSTEP], const int cnt) {
+    int r_next = next_needed(0);
+    if (r_next < S.W) issue(r_next, nxt, nxt_cnt);
+    for (int r = r_next; r < S.W; r = r_next) {
+        float cur[DP_MAXSTEP];
+#pragma unroll
+        for (int st = 0; st < DP_MAXSTEP; ++st) cur[st] = nxt[st];
+        const int cnt = nxt_cnt;
+        r_next = next_needed(r + 1);
+        if (r_next < S.W) issue(r_next, nxt, nxt_cnt);
         const bool colour = any_colour && ((coeff_mask >> r) & 1ull);
-        if (cnt == 0) return;  // wave-uniform: none of the tile's Gaussians
+        if (cnt == 0) continue;  // wave-uniform: none of the tile's Gaussians
         const float cx = S.cams[r * 3], cy = S.cams[r * 3 + 1], cz = S.cams[r * 3 + 2];
 #pragma unroll
         for (int st = 0; st < DP_MAXSTEP; ++st) {
@@ -372,24 +379,6 @@ __global__ __launch_bounds__(256) void dp_reduce_kernel(int64_t g_begin, int64_t
             }
             if (on) acc[pos][k] = a;
         }
-    };
-    int r_next = next_needed(0);
-    while (r_next < S.W) {
-        float buf[DP_DEPTH][DP_MAXSTEP];
-        int cnt[DP_DEPTH], who[DP_DEPTH];
-#pragma unroll
-        for (int d = 0; d < DP_DEPTH; ++d) {
-            who[d] = -1;
-            cnt[d] = 0;
-            if (r_next < S.W) {
-                who[d] = r_next;
-                issue(r_next, buf[d], cnt[d]);
-                r_next = next_needed(r_next + 1);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < DP_DEPTH; ++d)
-            if (who[d] >= 0) accumulate(who[d], buf[d], cnt[d]);
     }
     if constexpr (ROWS) {
         const bool want_colour = R.coef_rows != nullptr;
