@@ -37,11 +37,12 @@
 extern "C" {
 #endif
 
-#define MTGS_RAST_ABI_VERSION 27
-/* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
+#define MTGS_RAST_ABI_VERSION 28
+/* Version of the HOT-PATH subset (mtgs_sh_*, mtgs_vis_color_*_dirs, mtgs_front_fwd, mtgs_bin3_build, mtgs_blend_*_packed, mtgs_project_bwd*): bumped only
  * when one of THOSE kernels or signatures changes, so that committed per-kernel counter files (profiles/rNN_pmc_step.json, keyed
  * on it) survive bumps of the optimizer / loss / node entry points.  mtgs_rast_hot_version() returns it. */
-#define MTGS_RAST_HOT_ABI_VERSION 6
+#define MTGS_RAST_HOT_ABI_VERSION 7
+#define MTGS_VIS_COLOR_ROWS 64   /* visible Gaussians per workgroup of mtgs_vis_color_*: the granularity of dir_part */
 #define MTGS_BIN3_TIGHT 1
 #define MTGS_BIN3_FILL_TO_M 2
 #define MTGS_BIN3_FILL_TO_CAP 4
@@ -830,12 +831,27 @@ int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, con
                        const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                        int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
                        float *dir_rows, float *dir_part, float *dense_rows, void *stream);
+/* mtgs_vis_color_fwd_dirs / mtgs_vis_color_bwd_dirs (ABI v28, hot ABI v7): the same with the view directions GIVEN -- dirs[N, 3]
+ * (nullable: then as above), indexed by the Gaussian like `means`, normalised by the kernel exactly as mtgs_sh_fwd does -- instead of
+ * means[g] - cam_pos (which may then be NULL).  This is MTGS's own call style, gsplat.cuda._wrapper.spherical_harmonics(n, viewdirs,
+ * colors) followed by torch.clamp(. + 0.5, 0, 1) (vanilla_gaussian_splatting.py:313-318), evaluated for the Gaussians the projection
+ * found visible when the caller hands the result to rasterization() (mtgs_amd/wrapper.py, _LazySH): bit-identical colours to
+ * mtgs_sh_fwd_act with K = 16 for those Gaussians, no [N, 3] colour tensor, no read of the other ~85 % of the coefficient rows.
+ * With dirs the directions are not differentiated: dir_rows / dir_part must be NULL. */
+int mtgs_vis_color_fwd_dirs(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                            const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
+                            const float *coef_rows, int64_t coef_stride, const uint8_t *row_flags, const float *dirs, void *stream);
+int mtgs_vis_color_bwd_dirs(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                            const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
+                            int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
+                            float *dir_rows, float *dir_part, float *dense_rows, const float *dirs, void *stream);
 /* dense_rows (nullable; ABI v26; one node): a ZEROED [N, 16, 3] coefficient gradient -- the rows of the visible Gaussians whose colour
  * cotangent is not zero are written straight into it (row = vis_ids[r]) and feat_rows may be NULL: gsplat's `sh_degree` call style
  * without the [n_vis, 48] intermediate and the dense expansion pass behind it. */
 /* use_sh = 4 in a descriptor: gsplat's own sh_degree path -- clamp_min(SH + 0.5, 0) (gsplat/rendering.py), and dir_rows
  * (nullable [cap_vis, 3]) receives d L / d (means - camera position) of the visible rows (gsplat's view directions are
- * differentiable; MTGS detaches them) and dir_part[ceil(cap_vis / 128), 3] (zeroed by the caller) their per-workgroup sums
+ * differentiable; MTGS detaches them) and dir_part[ceil(cap_vis / MTGS_VIS_COLOR_ROWS), 3] (zeroed by the caller; 64 rows per workgroup
+ * since ABI v28, 128 before) their per-workgroup sums
  * (minus their total is the camera position's gradient).  mtgs_rows_expand: dense expansion of gradient rows for autograd callers:
  * out[n, c] = row_of[n] >= 0 ? rows[row_of[n] * row_stride + c] : 0 for c < width. */
 int mtgs_rows_expand(int64_t N, int width, const int32_t *row_of, const float *rows, int64_t row_stride, float *out,

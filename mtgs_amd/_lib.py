@@ -139,6 +139,8 @@ _SIGNATURES = {
     "mtgs_loss_combine_bwd": [_i32, _vp, _vp, C.POINTER(C.c_float), _vp, _vp],
     "mtgs_vis_color_fwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "mtgs_vis_color_bwd": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_vis_color_fwd_dirs": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "mtgs_vis_color_bwd_dirs": [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_rows_expand": [_i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "mtgs_adam_group_bytes": [],
     "mtgs_adam_block_elems": [],
@@ -152,8 +154,8 @@ _SIGNATURES = {
                        _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp],
 }
 EXPORTS = ["mtgs_rast_version", "mtgs_rast_hot_version", "mtgs_rast_last_error"] + list(_SIGNATURES)
-ABI_VERSION = 27
-HOT_ABI_VERSION = 6      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
+ABI_VERSION = 28
+HOT_ABI_VERSION = 7      # hot-path subset (include/mtgs_rast.h MTGS_RAST_HOT_ABI_VERSION): what profiles/rNN_pmc_step.json is keyed on
 
 _lib = None
 

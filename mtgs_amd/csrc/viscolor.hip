@@ -31,13 +31,30 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 struct F3 { float x, y, z; };
+// (non-temporal, as sh_fwd_k16_kernel's: the coefficient rows are read once per frame and would only push the records and gradient
+//  rows of this frame out of the Infinity Cache -- 46.7 -> 41.6 us for the call at the headline workload, with 64 instead of 128
+//  Gaussians per workgroup 37.6: profiles/r06_viscolor_ab.txt)
+__device__ __forceinline__ F3 vc_load3(const float *p) {
+#ifndef MTGS_VC_PLAIN_LOADS
+    typedef float f3v __attribute__((ext_vector_type(3)));
+    const f3v v = __builtin_nontemporal_load(reinterpret_cast<const f3v *>(p));
+    return F3{v.x, v.y, v.z};
+#else
+    return *reinterpret_cast<const F3 *>(p);
+#endif
+}
 
-// A workgroup owns VC_ROWS = 128 consecutive visible Gaussians.  Phase 1: thread i < 128 resolves row i -- Gaussian index,
+// A workgroup owns VC_ROWS = 64 consecutive visible Gaussians.  Phase 1: thread i < 64 resolves row i -- Gaussian index,
 // node (binary search over the table's `start`, in LDS when the table is small), the three coefficient row addresses --
-// into LDS; phase 2: every 16-lane DPP row walks VC_STEPS = 8 of them with all coefficient loads issued before the first
-// use.  (One row per 16 lanes and four dependent global round trips per wave measured 77 us for 465k visible Gaussians:
+// into LDS and ISSUES the load of its direction; phase 2: every 16-lane DPP row walks VC_STEPS = 4 of them with all coefficient
+// loads issued before the first use, and only then the directions are normalised and published (publish_dirs): index -> {direction,
+// coefficients} are two dependent round trips, not three.  (One row per 16 lanes and four dependent global round trips per wave measured 77 us for 465k visible Gaussians:
 // latency, not bandwidth.)
-constexpr int VC_STEPS = 8, VC_ROWS = VC_ROWS_PER_BLOCK * VC_STEPS, VC_LDS_NODES = 128;
+#ifndef MTGS_VC_STEPS
+#define MTGS_VC_STEPS 4
+#endif
+constexpr int VC_STEPS = MTGS_VC_STEPS, VC_ROWS = VC_ROWS_PER_BLOCK * VC_STEPS, VC_LDS_NODES = 128;
+static_assert(VC_ROWS == MTGS_VIS_COLOR_ROWS || MTGS_VC_STEPS != 4, "include/mtgs_rast.h: MTGS_VIS_COLOR_ROWS");
 struct RowInfo {
     const float *dc, *dc_add, *rest;   // addresses of this Gaussian's coefficient rows (dc_add nullable)
     float dx, dy, dz;                  // unit view direction
@@ -47,17 +64,20 @@ struct RowInfo {
 
 // coef_rows (nullable): the coefficients of visible Gaussian r as ONE compact row [dc 3 | dc_add 3 | rest 3 k_rest] at
 // coef_rows + r * coef_stride (the optimizer's peek: mtgs_adam_step, MTGS_ADAM_ROWS_PEEK) instead of the nodes' tensors.
-__device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ table, int n_nodes, const float *__restrict__ cam_pos,
-                                             const float *__restrict__ means, const int32_t *__restrict__ vis_ids, int64_t r0,
-                                             int64_t n_vis, RowInfo *s_row, int64_t *s_start,
-                                             const float *__restrict__ coef_rows = nullptr, int64_t coef_stride = 0,
-                                             const uint8_t *__restrict__ row_flags = nullptr) {
+struct RawDir { float x, y, z; bool on; };
+__device__ __forceinline__ RawDir resolve_rows(const mtgs_node_desc *__restrict__ table, int n_nodes, const float *__restrict__ cam_pos,
+                                               const float *__restrict__ means, const int32_t *__restrict__ vis_ids, int64_t r0,
+                                               int64_t n_vis, RowInfo *s_row, int64_t *s_start,
+                                               const float *__restrict__ coef_rows = nullptr, int64_t coef_stride = 0,
+                                               const uint8_t *__restrict__ row_flags = nullptr,
+                                               const float *__restrict__ dirs = nullptr) {
     const int tid = threadIdx.x;
     const bool small = n_nodes <= VC_LDS_NODES;
-    if (small) {
+    if (small && n_nodes > 1) {
         for (int i = tid; i < n_nodes; i += VC_BLOCK) s_start[i] = table[i].start;
         __syncthreads();
     }
+    RawDir rd{0.f, 0.f, 1.f, false};
     if (tid < VC_ROWS) {
         const int64_t r = r0 + tid;
         RowInfo ri;
@@ -83,12 +103,28 @@ __device__ __forceinline__ void resolve_rows(const mtgs_node_desc *__restrict__ 
                 ri.rest = ri.dc + 6;
             }
             ri.k_rest = d.k_rest; ri.use_sh = d.use_sh;
-            const F3 m = *reinterpret_cast<const F3 *>(means + g * 3);
-            float dx = m.x - cam_pos[0], dy = m.y - cam_pos[1], dz = m.z - cam_pos[2];
-            const float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-            ri.dx = dx * inorm; ri.dy = dy * inorm; ri.dz = dz * inorm; ri.inorm = inorm;
+            // dirs (mtgs_vis_color_fwd_dirs): the caller's own view directions [N, 3] (MTGS: spherical_harmonics(n, viewdirs, colors) with
+            // viewdirs computed in PyTorch) instead of mean - camera position; normalised as sh_fwd_k16_kernel does (sh.hip)
+            rd.on = true;
+            if (dirs) {
+                const F3 dv = *reinterpret_cast<const F3 *>(dirs + g * 3);
+                rd.x = dv.x; rd.y = dv.y; rd.z = dv.z;
+            } else {
+                const F3 m = *reinterpret_cast<const F3 *>(means + g * 3);
+                rd.x = m.x - cam_pos[0]; rd.y = m.y - cam_pos[1]; rd.z = m.z - cam_pos[2];
+            }
         }
         s_row[tid] = ri;
+    }
+    __syncthreads();
+    return rd;
+}
+// ... the second half of phase 1: the resolving threads normalise the direction they loaded and publish it
+__device__ __forceinline__ void publish_dirs(RowInfo *s_row, const RawDir rd) {
+    if (threadIdx.x < VC_ROWS && rd.on) {
+        const float inorm = 1.0f / sqrtf((rd.x * rd.x + rd.y * rd.y) + rd.z * rd.z);
+        RowInfo &ri = s_row[threadIdx.x];
+        ri.dx = rd.x * inorm; ri.dy = rd.y * inorm; ri.dz = rd.z * inorm; ri.inorm = inorm;
     }
     __syncthreads();
 }
@@ -99,7 +135,7 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
                                                                  const int32_t *__restrict__ vis_ids, const int64_t *__restrict__ totals,
                                                                  int64_t cap_vis, float *__restrict__ recs, uint8_t *__restrict__ vis_mask,
                                                                  const float *__restrict__ coef_rows, int64_t coef_stride,
-                                                                 const uint8_t *__restrict__ row_flags) {
+                                                                 const uint8_t *__restrict__ row_flags, const float *__restrict__ dirs) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     __shared__ RowInfo s_row[VC_ROWS];
     __shared__ int64_t s_start[VC_LDS_NODES];
@@ -107,7 +143,7 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r0 = (int64_t)blockIdx.x * VC_ROWS;
     if (r0 >= n_vis) return;
-    resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, coef_rows, coef_stride, row_flags);
+    const RawDir rd = resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, coef_rows, coef_stride, row_flags, dirs);
     const int k = threadIdx.x & 15, sub = threadIdx.x >> 4;
     const ShLaneConst lc = sh_lane_const(k);
     F3 c[VC_STEPS];
@@ -118,16 +154,17 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
         const bool active = ri.dc && (ri.use_sh ? (k < NB && k - 1 < ri.k_rest) : (k == 0));
         if (active) {
             if (k == 0) {
-                c[it] = *reinterpret_cast<const F3 *>(ri.dc);
+                c[it] = vc_load3(ri.dc);
                 if (ri.dc_add) {
-                    const F3 a = *reinterpret_cast<const F3 *>(ri.dc_add);
+                    const F3 a = vc_load3(ri.dc_add);
                     c[it].x += a.x; c[it].y += a.y; c[it].z += a.z;
                 }
             } else {
-                c[it] = *reinterpret_cast<const F3 *>(ri.rest + (k - 1) * 3);
+                c[it] = vc_load3(ri.rest + (k - 1) * 3);
             }
         }
     }
+    publish_dirs(s_row, rd);
 #pragma unroll
     for (int it = 0; it < VC_STEPS; ++it) {
         const int row = it * VC_ROWS_PER_BLOCK + sub;
@@ -140,11 +177,11 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_fwd_kernel(const mtgs_node
         uint8_t mk = 7;
         if (ri.use_sh == 4) {   // gsplat's own sh_degree path (rendering.py): clamp_min(SH + 0.5, 0), no upper clamp
             const float x = sr + 0.5f, y = sg + 0.5f, z = sb + 0.5f;
-            rgb = F3{fmaxf(x, 0.f), fmaxf(y, 0.f), fmaxf(z, 0.f)};
+            rgb = F3{x < 0.f ? 0.f : x, y < 0.f ? 0.f : y, z < 0.f ? 0.f : z};      // (a NaN stays a NaN, as in torch.clamp_min)
             mk = (uint8_t)((x >= 0.f) | ((y >= 0.f) << 1) | ((z >= 0.f) << 2));
         } else if (ri.use_sh) {
             const float x = sr + 0.5f, y = sg + 0.5f, z = sb + 0.5f;
-            rgb = F3{fminf(fmaxf(x, 0.f), 1.f), fminf(fmaxf(y, 0.f), 1.f), fminf(fmaxf(z, 0.f), 1.f)};
+            rgb = F3{x < 0.f ? 0.f : (x > 1.f ? 1.f : x), y < 0.f ? 0.f : (y > 1.f ? 1.f : y), z < 0.f ? 0.f : (z > 1.f ? 1.f : z)};
             // torch.clamp passes the gradient where min <= x <= max (inclusive): one bit per channel
             mk = (uint8_t)((x >= 0.f && x <= 1.f) | ((y >= 0.f && y <= 1.f) << 1) | ((z >= 0.f && z <= 1.f) << 2));
         } else {
@@ -164,7 +201,7 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
                                                                  int col, const float *__restrict__ recs,
                                                                  const uint8_t *__restrict__ vis_mask, float *__restrict__ feat_rows,
                                                                  float *__restrict__ dir_rows, float *__restrict__ dir_part,
-                                                                 float *__restrict__ dense_rows) {
+                                                                 float *__restrict__ dense_rows, const float *__restrict__ dirs) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
     __shared__ RowInfo s_row[VC_ROWS];
     __shared__ int64_t s_start[VC_LDS_NODES];
@@ -172,8 +209,22 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
     if (n_vis > cap_vis) n_vis = cap_vis;
     const int64_t r0 = (int64_t)blockIdx.x * VC_ROWS;
     if (r0 >= n_vis) return;
-    resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start);
     const int k = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    // the cotangents and masks of the workgroup's rows do not depend on the Gaussian index: in flight beside the index -> direction chain
+    F3 vin[VC_STEPS];
+    unsigned mkin[VC_STEPS];
+#pragma unroll
+    for (int it = 0; it < VC_STEPS; ++it) {
+        const int64_t r = r0 + it * VC_ROWS_PER_BLOCK + sub;
+        vin[it] = F3{0.f, 0.f, 0.f}; mkin[it] = 0u;
+        if (r < n_vis) {
+            const float *gr = grad_rows + r * row_stride + col;
+            vin[it] = F3{gr[0], gr[1], gr[2]};
+            mkin[it] = vis_mask[r];
+        }
+    }
+    const RawDir rd = resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, nullptr, 0, nullptr, dirs);
+    publish_dirs(s_row, rd);
     const ShLaneConst lc = sh_lane_const(k);
 #pragma unroll
     for (int it = 0; it < VC_STEPS; ++it) {
@@ -181,11 +232,10 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
         const int64_t r = r0 + row;
         if (r >= n_vis) continue;
         const RowInfo &ri = s_row[row];
-        const float *gr = grad_rows + r * row_stride + col;
-        F3 v = F3{gr[0], gr[1], gr[2]};
+        F3 v = vin[it];
         float b;
         if (ri.use_sh) {
-            const unsigned mk = vis_mask[r];   // torch.clamp passes the gradient where min <= x <= max
+            const unsigned mk = mkin[it];   // torch.clamp passes the gradient where min <= x <= max
             v.x = (mk & 1u) ? v.x : 0.f; v.y = (mk & 2u) ? v.y : 0.f; v.z = (mk & 4u) ? v.z : 0.f;
             b = (k < NB && k - 1 < ri.k_rest) ? sh_lane_basis<DEG>(lc, ri.dx, ri.dy, ri.dz) : 0.f;
         } else {
@@ -314,15 +364,24 @@ __global__ __launch_bounds__(256) void rows_expand4_kernel(int64_t N, int width4
 extern "C" int mtgs_vis_color_fwd(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                                   const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
                                   const float *coef_rows, int64_t coef_stride, const uint8_t *row_flags, void *stream) {
+    return mtgs_vis_color_fwd_dirs(n_nodes, table, degree, cam_pos, means, vis_ids, totals, cap_vis, recs, vis_mask, coef_rows, coef_stride,
+                                   row_flags, nullptr, stream);
+}
+
+extern "C" int mtgs_vis_color_fwd_dirs(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                                       const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
+                                       const float *coef_rows, int64_t coef_stride, const uint8_t *row_flags, const float *dirs,
+                                       void *stream) {
     MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0, MTGS_EINVAL, "mtgs_vis_color_fwd: bad sizes (degree <= 3)");
     MTGS_REQUIRE(!coef_rows || coef_stride >= 51, MTGS_EINVAL, "mtgs_vis_color_fwd: coef_stride=%lld (a row is dc 3 | dc_add 3 | rest 45)",
                  (long long)coef_stride);
     if (cap_vis == 0) return MTGS_OK;
-    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && recs && vis_mask, MTGS_EINVAL, "mtgs_vis_color_fwd: null pointer");
+    MTGS_REQUIRE(table && (dirs || (cam_pos && means)) && vis_ids && totals && recs && vis_mask, MTGS_EINVAL,
+                 "mtgs_vis_color_fwd: null pointer (directions: dirs, or means and cam_pos)");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
     MTGS_VC_DISPATCH(vis_color_fwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, recs, vis_mask, coef_rows,
-                     coef_stride, row_flags)
+                     coef_stride, row_flags, dirs)
     MTGS_CHECK_LAUNCH("mtgs_vis_color_fwd");
     return MTGS_OK;
 }
@@ -331,17 +390,26 @@ extern "C" int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int 
                                   const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                                   int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
                                   float *dir_rows, float *dir_part, float *dense_rows, void *stream) {
+    return mtgs_vis_color_bwd_dirs(n_nodes, table, degree, cam_pos, means, vis_ids, totals, cap_vis, grad_rows, row_stride, col, recs,
+                                   vis_mask, feat_rows, dir_rows, dir_part, dense_rows, nullptr, stream);
+}
+
+extern "C" int mtgs_vis_color_bwd_dirs(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
+                                       const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
+                                       int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
+                                       float *dir_rows, float *dir_part, float *dense_rows, const float *dirs, void *stream) {
     MTGS_REQUIRE(n_nodes > 0 && degree >= 0 && degree <= 3 && cap_vis >= 0 && row_stride >= col + 3 && col >= 0, MTGS_EINVAL,
                  "mtgs_vis_color_bwd: bad sizes");
     if (cap_vis == 0) return MTGS_OK;
-    MTGS_REQUIRE(table && cam_pos && means && vis_ids && totals && grad_rows && recs && vis_mask && (feat_rows || dense_rows) &&
+    MTGS_REQUIRE(table && (dirs || (cam_pos && means)) && vis_ids && totals && grad_rows && recs && vis_mask && (feat_rows || dense_rows) &&
                      (!dir_rows == !dir_part),
                  MTGS_EINVAL, "mtgs_vis_color_bwd: null pointer (dir_rows and dir_part go together; feat_rows or dense_rows)");
+    MTGS_REQUIRE(!dirs || !dir_rows, MTGS_EINVAL, "mtgs_vis_color_bwd: dir_rows is the gradient of directions mean - cam_pos (not of `dirs`)");
     MTGS_REQUIRE(!dense_rows || n_nodes == 1, MTGS_EINVAL, "mtgs_vis_color_bwd: dense_rows is the gradient of ONE [N, 16, 3] coefficient tensor");
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
     MTGS_VC_DISPATCH(vis_color_bwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, grad_rows, row_stride, col, recs,
-                     vis_mask, feat_rows, dir_rows, dir_part, dense_rows)
+                     vis_mask, feat_rows, dir_rows, dir_part, dense_rows, dirs)
     MTGS_CHECK_LAUNCH("mtgs_vis_color_bwd");
     return MTGS_OK;
 }

@@ -184,6 +184,7 @@ class ColorSource:
         self.node_params = node_params     # per node: (start, n, features_dc, features_adapters | None, features_rest, traversal | None)
         self.rows = self.row_of = None
         self.autograd, self.width = False, 48   # (sh_coefficient_source: dense coefficient gradient + differentiable directions)
+        self.dirs = None             # (sh_direction_source: the caller's own view directions [N, 3], no gradient, instead of means - cam)
         self.camera_normals = None   # camera_to_world [3,4] (device): the rasterization adds MTGS's three camera-space normal channels
         #                              (mtgs_scene_graph.py:526-545, 636-638) after the colours, computed for the VISIBLE Gaussians only
         self.node_geometry = None    # per node: (means, scales, quats, opacities leaves, is a rigid node)
@@ -318,6 +319,39 @@ def sh_coefficient_source(coeffs: Tensor, sh_degree: int, campos: Tensor) -> Col
     cam = campos.detach().reshape(3).to(torch.float32).contiguous()
     cs = ColorSource(_upload(tab, c.device), 1, int(sh_degree), cam, [c], [(0, N, coeffs, None, coeffs, None)])
     cs.autograd, cs.width = True, K * 3
+    return cs
+
+
+_dir_tables: dict = {}      # (coefficient pointer, N, K, activation, device, stream) -> uploaded descriptor (its content is a function of the key)
+
+
+def sh_direction_source(coeffs: Tensor, sh_degree: int, dirs: Tensor, use_sh: int) -> ColorSource:
+    """ColorSource for MTGS's own call style -- rgbs = spherical_harmonics(n, viewdirs, colors); torch.clamp(rgbs + 0.5, 0, 1)
+    (vanilla_gaussian_splatting.py:313-318; use_sh = 1) or clamp_min (use_sh = 4) -- whose deferred result reached rasterization()
+    (wrapper._LazySH.raster_source): ONE descriptor over the [N, 16, 3] coefficient tensor, the caller's directions as they are."""
+    from . import wrapper
+    N, K = coeffs.shape[0], coeffs.shape[1]
+    assert coeffs.dim() == 3 and coeffs.shape[2] == 3 and coeffs.dtype == torch.float32 and K == 16 and sh_degree <= 3
+    c = coeffs.detach().contiguous()
+    d = dirs.detach().contiguous()
+    dev = c.device
+    in_graph = wrapper._graph.caps is not None or torch.cuda.is_current_stream_capturing()
+    key = (c.data_ptr(), N, K, int(use_sh), dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    table = None if in_graph else _dir_tables.get(key)
+    if table is None:
+        tab = np.zeros(1, dtype=_DESC)
+        tab["n"], tab["start"], tab["first_block"] = N, 0, 0
+        tab["features_dc"], tab["features_rest"] = c.data_ptr(), c.data_ptr() + 12
+        tab["dc_stride"] = tab["rest_stride"] = K * 3
+        tab["dc_add_stride"] = 3
+        tab["k_rest"], tab["use_sh"] = K - 1, int(use_sh)
+        table = _upload(tab, dev)
+        if not in_graph:      # (a table uploaded inside a capture has no content before the first replay)
+            if len(_dir_tables) >= 16:
+                _dir_tables.clear()
+            _dir_tables[key] = table
+    cs = ColorSource(table, 1, int(sh_degree), None, [c, d], [(0, N, coeffs, None, coeffs, None)])
+    cs.autograd, cs.width, cs.dirs = True, K * 3, d
     return cs
 
 

@@ -15,7 +15,7 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
-from .wrapper import (MAX_CHANNELS, SUPPORTED_CHANNELS, fused_rasterization, isect_offset_encode, isect_tiles,
+from .wrapper import (MAX_CHANNELS, SUPPORTED_CHANNELS, _LazySH, fused_rasterization, isect_offset_encode, isect_tiles,
                       projection_with_opacities, rasterize_to_pixels, rasterize_to_pixels_with_depth,
                       spherical_harmonics)
 
@@ -114,6 +114,30 @@ def rasterization(
     assert quats.shape == (N, 4), quats.shape
     assert scales.shape == (N, 3), scales.shape
 
+    # MTGS's colours -- clamp(spherical_harmonics(...) + 0.5, 0, 1) -- still deferred (wrapper._LazySH): evaluated for the Gaussians the
+    # projection finds visible, by the rasterization itself; whatever this call cannot take over is evaluated now, for all of them
+    if type(colors) is _LazySH:
+        src = None
+        if (color_source is None and sh_degree is None and C == 1 and backgrounds is None and colors.dim() == 2
+                and render_mode in ["RGB", "RGB+D", "RGB+ED"] and (3 + int(render_mode != "RGB")) in SUPPORTED_CHANNELS):
+            src = colors.raster_source(N, width, height)
+        if src is None:
+            colors = colors._materialize()
+        else:
+            with_depth = render_mode != "RGB"
+            render_colors, render_alphas, m = fused_rasterization(
+                means, quats, scales, opacities, None, viewmats, Ks, None, width, height, eps2d, near_plane, far_plane, radius_clip,
+                rasterize_mode == "antialiased", with_depth, render_mode == "RGB+ED", absgrad, color_source=src[0],
+                sh_source=(src[1], None))
+            meta.update({"camera_ids": None, "gaussian_ids": None, "radii": m["radii"], "means2d": m["means2d"], "depths": m["depths"],
+                         "conics": m["conics"], "opacities": m["opacities"], "tile_width": math.ceil(width / 16.0),
+                         "tile_height": math.ceil(height / 16.0), "tiles_per_gauss": m["tiles_per_gauss"], "isect_ids": m["isect_ids"],
+                         "flatten_ids": m["flatten_ids"], "isect_offsets": m["isect_offsets"], "width": width, "height": height,
+                         "tile_size": tile_size, "n_cameras": C})
+            for k in ("n_visible", "n_intersections", "overflow", "n_listed"):
+                if k in m:
+                    meta[k] = m[k]
+            return render_colors, render_alphas, meta
     if color_source is not None:
         if sh_degree is not None or C != 1 or render_mode in ["D", "ED"] or backgrounds is not None:
             raise NotImplementedError("rasterization(color_source=...): one camera, an RGB render mode, no sh_degree / backgrounds")

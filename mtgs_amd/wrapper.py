@@ -244,23 +244,46 @@ def _is_number(v) -> bool:
 
 
 class _LazySH(Tensor):
+    # three states: the raw SH output (base None), `raw + c` (add), `clamp(raw [+ c], lo, hi)` (act = (lo, hi); base = the state clamped)
     @staticmethod
-    def __new__(cls, degree, dirs, coeffs, masks, base=None, add=None):
+    def __new__(cls, degree, dirs, coeffs, masks, base=None, add=None, act=None):
         rg = torch.is_grad_enabled() and (coeffs.requires_grad or dirs.requires_grad)
         r = Tensor._make_wrapper_subclass(cls, dirs.shape, dtype=torch.float32, device=dirs.device, requires_grad=rg)
         r._lz_sh = (degree, dirs, coeffs, masks)
-        r._lz_base, r._lz_add, r._lz_plain = base, add, None
+        r._lz_base, r._lz_add, r._lz_act, r._lz_plain = base, add, act, None
         return r
 
     def _materialize(self) -> Tensor:
         """The ordinary tensor this object stands for (computed once)."""
         if self._lz_plain is None:
             with torch._C.DisableTorchFunctionSubclass():
-                if self._lz_base is not None:
+                if self._lz_act is not None:
+                    self._lz_plain = self._lz_base._fused(*self._lz_act)
+                elif self._lz_base is not None:
                     self._lz_plain = self._lz_base._materialize() + self._lz_add
                 else:
                     self._lz_plain = _SphericalHarmonics.apply(*self._lz_sh)
         return self._lz_plain
+
+    def _raster_form(self, lo: float, hi: float) -> bool:
+        """clamp(self, lo, hi) is a colour activation rasterization() can evaluate for the VISIBLE Gaussians by itself
+        (csrc/viscolor.hip: MTGS's clamp(x + 0.5, 0, 1), gsplat's clamp_min(x + 0.5, 0); K = 16 coefficient rows, given directions
+        without a gradient): the clamp then stays deferred too, see raster_source()."""
+        degree, dirs, coeffs, masks = self._lz_sh
+        return (_lazy_raster_enabled and self._lz_add == 0.5 and lo == 0.0 and hi in (1.0, float("inf")) and masks is None
+                and degree <= 3 and dirs.dim() == 2 and coeffs.dim() == 3 and coeffs.shape[1] == 16 and not dirs.requires_grad)
+
+    def raster_source(self, n: int, width: int, height: int):
+        """(ColorSource, coefficients) for rasterization() when this object is a deferred activation it can take over -- the colours are
+        then evaluated for the visible Gaussians only, straight into their records, and d L / d coefficients leaves the rasterization's
+        backward (rows of the Gaussians with a cotangent, written into zeros that rode on the compositing forward) -- else None."""
+        if self._lz_act is None or self._lz_plain is not None:
+            return None
+        degree, dirs, coeffs, _ = self._lz_sh
+        if dirs.shape != (n, 3) or n == 0 or not _bin3_ok(1, -(-width // 16), -(-height // 16), 0):
+            return None
+        from .nodes import sh_direction_source
+        return sh_direction_source(coeffs, degree, dirs, 1 if self._lz_act[1] == 1.0 else 4), coeffs
 
     def _fused(self, lo: float, hi: float) -> Tensor:
         has_add = self._lz_add is not None
@@ -277,11 +300,11 @@ class _LazySH(Tensor):
                 with torch._C.DisableTorchFunctionSubclass():
                     return func(*args, **kwargs)
             # x + c, c + x with a Python scalar: stays deferred (one pending add at most)
-            if func in _LAZY_ADD and me._lz_base is None and len(args) == 2 and _is_number(args[1]) and kwargs.get("alpha", 1) == 1 \
+            if func in _LAZY_ADD and me._lz_base is None and me._lz_act is None and len(args) == 2 and _is_number(args[1]) and kwargs.get("alpha", 1) == 1 \
                     and not (set(kwargs) - {"alpha"}):
                 return _LazySH(*me._lz_sh, base=me, add=float(args[1]))
             # clamp(x, lo, hi) / clip / clamp_min / clamp_max with scalar bounds: the fused kernel
-            if func in _LAZY_CLAMP:
+            if func in _LAZY_CLAMP and me._lz_act is None:
                 a = list(args[1:])
                 lo = kwargs.get("min", a[0] if len(a) > 0 else None)
                 hi = kwargs.get("max", a[1] if len(a) > 1 else None)
@@ -292,7 +315,10 @@ class _LazySH(Tensor):
                 if ok:
                     root = me._lz_base if me._lz_base is not None else me
                     if root._lz_plain is None:
-                        return me._fused(float("-inf") if lo is None else float(lo), float("inf") if hi is None else float(hi))
+                        lo_f, hi_f = float("-inf") if lo is None else float(lo), float("inf") if hi is None else float(hi)
+                        if me._raster_form(lo_f, hi_f):      # still nothing runs: rasterization() may want the visible Gaussians only
+                            return _LazySH(*me._lz_sh, base=me, act=(lo_f, hi_f))
+                        return me._fused(lo_f, hi_f)
         # everything else: ordinary tensors from here on
         args, kwargs = _lazy_plain(args), _lazy_plain(kwargs)
         with torch._C.DisableTorchFunctionSubclass():
@@ -322,18 +348,21 @@ _LAZY_ADD = {torch.add, Tensor.add, Tensor.__add__, Tensor.__radd__}
 _LAZY_CLAMP_MAX = {torch.clamp_max, Tensor.clamp_max}
 _LAZY_CLAMP = {torch.clamp, Tensor.clamp, torch.clip, Tensor.clip, torch.clamp_min, Tensor.clamp_min} | _LAZY_CLAMP_MAX
 _lazy_sh_enabled = os.environ.get("MTGS_SH_LAZY", "1") == "1"
+_lazy_raster_enabled = os.environ.get("MTGS_SH_LAZY_RASTER", "1") == "1"      # ... through the clamp into rasterization() (raster_source)
 
 
 @contextlib.contextmanager
-def sh_lazy(enabled: bool = True):
+def sh_lazy(enabled: bool = True, raster: Optional[bool] = None):
     """Switches the deferred evaluation of spherical_harmonics() (see _LazySH) for the enclosed calls: False = the function runs its
-    kernel at once and returns an ordinary tensor, the caller's `clamp(x + 0.5, ...)` stays PyTorch's."""
-    global _lazy_sh_enabled
-    old, _lazy_sh_enabled = _lazy_sh_enabled, bool(enabled)
+    kernel at once and returns an ordinary tensor, the caller's `clamp(x + 0.5, ...)` stays PyTorch's.  raster = False: the clamp
+    runs the fused SH + activation kernel over ALL Gaussians at once instead of staying deferred for rasterization() (None: as it is)."""
+    global _lazy_sh_enabled, _lazy_raster_enabled
+    old = (_lazy_sh_enabled, _lazy_raster_enabled)
+    _lazy_sh_enabled, _lazy_raster_enabled = bool(enabled), (_lazy_raster_enabled if raster is None else bool(raster))
     try:
         yield
     finally:
-        _lazy_sh_enabled = old
+        _lazy_sh_enabled, _lazy_raster_enabled = old
 
 
 def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
@@ -919,9 +948,9 @@ class _FusedRasterization(torch.autograd.Function):
             def colours(b, flags):   # colours of the visible Gaussians, straight into their records
                 cap_vis = b["cap_vis"]
                 coef = cs.prepare(vis_rank, cap_vis, b["vis_ids"], totals, row_flags=flags)    # (row-lazy optimizer: up-to-date coefficient rows, compact)
-                call("mtgs_vis_color_fwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
+                call("mtgs_vis_color_fwd_dirs", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(b["vis_ids"]),
                      ptr(totals), cap_vis, ptr(b["recs"]), ptr(b["vis_mask"]), ptr(coef), 0 if coef is None else coef.stride(0),
-                     ptr(flags), st)
+                     ptr(flags), ptr(cs.dirs), st)
                 if n2c is not None:  # ... and their camera-space normals (channels 3..5)
                     call("mtgs_normals_fwd_rows", cap_vis, ptr(b["vis_ids"]), ptr(totals), ptr(quats), ptr(scales), ptr(means),
                          ptr(n2c), ptr(b["recs"]), 3, ptr(flags), st)
@@ -985,7 +1014,8 @@ class _FusedRasterization(torch.autograd.Function):
                     n_rows_ = max(b["cap_vis"], 1) * RS_
                     # (gsplat's sh_degree call style: the dense [N, 16, 3] coefficient gradient too -- the backward then writes the
                     #  rows of the Gaussians with a cotangent straight into it, mtgs_vis_color_bwd(dense_rows))
-                    n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and cs.n_nodes == 1 and graph_caps is None) else 0
+                    n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and cs.n_nodes == 1
+                                         and (graph_caps is None or cs.dirs is not None) and ctx.needs_input_grad[20]) else 0
                     z_ptr, z_bytes, own_ = _prefill.take(dev, n_rows_ + n_coef_, only=getattr(_sh_scope, "reqs", ()))
                     ctx_box["rows"] = own_[:n_rows_].view(max(b["cap_vis"], 1), RS_)
                     if n_coef_:
@@ -1110,11 +1140,15 @@ class _FusedRasterization(torch.autograd.Function):
             # them through the row map (vis_rank: rank or -1) -- no dense [N, (T,) K, 3] gradient is written
             dense_coeffs = getattr(ctx, "zero_coeffs", None) if cs.autograd else None      # (zeroed by the forward's compositing kernel)
             ctx.zero_coeffs = None
-            feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev) if dense_coeffs is None else None
-            dir_rows = torch.empty((max(n_vis, 1), 3), dtype=torch.float32, device=dev) if cs.autograd else None
-            dir_part = torch.zeros((-(-max(n_vis, 1) // 128), 3), dtype=torch.float32, device=dev) if cs.autograd else None
-            call("mtgs_vis_color_bwd", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(vis_ids), ptr(totals),
-                 n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), ptr(dir_rows), ptr(dir_part), ptr(dense_coeffs), st)
+            want_dirs = cs.autograd and cs.dirs is None      # (given directions -- MTGS's call style -- carry no gradient)
+            feat = dir_rows = dir_part = None
+            if not (cs.autograd and cs.dirs is not None and not ctx.needs_input_grad[20]):      # (frozen coefficients: nothing to do)
+                feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev) if dense_coeffs is None else None
+                dir_rows = torch.empty((max(n_vis, 1), 3), dtype=torch.float32, device=dev) if want_dirs else None
+                dir_part = torch.zeros((-(-max(n_vis, 1) // 64), 3), dtype=torch.float32, device=dev) if want_dirs else None      # (MTGS_VIS_COLOR_ROWS)
+                call("mtgs_vis_color_bwd_dirs", cs.n_nodes, ptr(cs.table), cs.degree, ptr(cs.cam), ptr(means), ptr(vis_ids), ptr(totals),
+                     n_vis, ptr(G), RS, 8, ptr(recs), ptr(ctx.vis_mask), ptr(feat), ptr(dir_rows), ptr(dir_part), ptr(dense_coeffs),
+                     ptr(cs.dirs), st)
             cs.rows, cs.row_of = feat, vis_rank
         if ctx.dp is not None:
             # data-parallel mode: the per-visible VJP writes this rank's wire rows (index order) into the exchange's send
@@ -1201,19 +1235,21 @@ class _FusedRasterization(torch.autograd.Function):
              None if d_col is None else G.data_ptr() + 4 * (8 + c0), DC - c0 if d_col is not None else 0,
              host_i64([RS, RS]), ptr(d_m2d), ptr(d_abs), ptr(d_col), ptr(vis_ids), n_vis, ptr(vis_ws),
              ptr(totals) if ctx.graph else None, ptr(q_rows),
-             ptr(dir_rows) if (cs is not None and cs.autograd and n_vis > 0) else None,      # (differentiable view directions: dirs = means - camera position)
+             ptr(dir_rows) if (cs is not None and cs.autograd and cs.dirs is None and n_vis > 0) else None,      # (differentiable view directions: dirs = means - camera position)
              ptr(G) if raw else None, ptr(recs) if (raw and Cn == 1) else None, ptr(vm_part), st)
         d_coeffs = d_campos = None
         if cs is not None and cs.autograd:
-            if ctx.graph:
+            if ctx.graph and cs.dirs is None:
                 raise NotImplementedError("graph_mode: rasterization(sh_degree=...) (dense coefficient gradient)")
             K3 = cs.width
             if dense_coeffs is not None:
                 d_coeffs = dense_coeffs
-            else:
+            elif feat is not None:
                 d_coeffs = torch.empty((N, K3 // 3, 3), dtype=torch.float32, device=dev)
                 call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
-            if n_vis > 0:
+            if cs.dirs is not None:
+                d_campos = None
+            elif n_vis > 0:
                 d_campos = -dir_part.sum(0)
             else:
                 d_campos = torch.zeros(3, dtype=torch.float32, device=dev)

@@ -22,6 +22,8 @@ _ap = argparse.ArgumentParser()
 _ap.add_argument("--width", type=int, default=1920)
 _ap.add_argument("--height", type=int, default=1080)
 _ap.add_argument("--no-render-leg", action="store_true")
+_ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
+_ap.add_argument("--pmc", action="store_true", help="counter run: per world only 3 one-pass touched reductions, then 3 sparse-write ones")
 _args = _ap.parse_args()
 dev = torch.device("cuda")
 N, K, W, H = 2_000_000, 16, _args.width, _args.height
@@ -43,7 +45,7 @@ def t(fn, reps=10):
     return s.elapsed_time(e) / reps * 1e3
 
 
-for world in (2, 4, 8):
+for world in _args.worlds:
     ex = mdist.SparseGradExchange(N, K, dev)
     nw, L = ex.n_words, ex.meta_len
     metas = torch.zeros(world, L, dtype=torch.int32, device=dev)
@@ -73,7 +75,8 @@ for world in (2, 4, 8):
     red = lambda: call("mtgs_dp_reduce", world, N, K, 3, ptr(means), ptr(metas[:, 4:]), ptr(metas[:, 4 + 2 * nw:]), L * 4,
                        ptr(recv), cap * 16, ptr(cams), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, st)
     covered = sum(counts)
-    print("world %d: one-pass reduce over %d rows (%d MB received): %.1f us" % (world, covered, world * cap * 64 >> 20, t(red)))
+    if not _args.pmc:
+        print("world %d: one-pass reduce over %d rows (%d MB received): %.1f us" % (world, covered, world * cap * 64 >> 20, t(red)))
     # ---- the TOUCHED form (finish_touched / finish_touched_chunked): 40 % of every sender's rows carry a gradient (the headline
     # scene's share), compacted with their own map by mtgs_dp_touched_pack; the reduction over them, in one pass and in index chunks
     tb = {"scratch": torch.empty(nw, dtype=torch.int64, device=dev), "blocks": torch.empty(nw // 256 + 2, dtype=torch.int32, device=dev),
@@ -101,6 +104,19 @@ for world in (2, 4, 8):
     red_t = lambda b0=0, b1=-1: call("mtgs_dp_reduce_slices_cap", world, N, K, 3, ptr(means), ri.data_ptr() + 4 * (m0 + 4),
                                      ri.data_ptr() + 4 * (m0 + 4 + 2 * nw), Lt * 4, ptr(recv_t), Lt, tcap, ptr(cams), ptr(out[0]), ptr(out[1]),
                                      ptr(out[2]), ptr(out[3]), ptr(out[4]), b0, b1, C.c_uint64((1 << world) - 1), 1, K * 3, st)
+    if _args.pmc:
+        for o in out:
+            o.zero_()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            red_t()
+        for _ in range(3):
+            call("mtgs_dp_reduce_slices_cap", world, N, K, 3, ptr(means), ri.data_ptr() + 4 * (m0 + 4),
+                 ri.data_ptr() + 4 * (m0 + 4 + 2 * nw), Lt * 4, ptr(recv_t), Lt, tcap, ptr(cams), ptr(out[0]), ptr(out[1]),
+                 ptr(out[2]), ptr(out[3]), ptr(out[4]), 0, -1, C.c_uint64((1 << world) - 1), 1 | 2, K * 3, st)
+        torch.cuda.synchronize()
+        print("pmc: world %d: touched rows %d, received %d MB" % (world, sum(t_counts), world * Lt * 4 >> 20))
+        continue
     line_t = "world %d, touched rows only (%d of %d rows, %d MB received; pack %.1f us): one-pass reduce %.1f us" % (
         world, sum(t_counts), covered, world * Lt * 4 >> 20, t_pack, t(red_t))
     for nch in (2, 4):

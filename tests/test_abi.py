@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     raw = C.CDLL(str(_lib.LIB_PATH))
     for s in syms:
         assert hasattr(raw, s), f"{s} not exported by libmtgs_rast.so"
-    assert hip_lib.mtgs_rast_version() == _lib.ABI_VERSION == 27
+    assert hip_lib.mtgs_rast_version() == _lib.ABI_VERSION == 28
     assert hip_lib.mtgs_rast_hot_version() == _lib.HOT_ABI_VERSION
 
 

@@ -46,6 +46,11 @@ def test_fused_activation_is_the_three_torch_operations_bit_for_bit(hip_lib, for
             x = spherical_harmonics(degree, dirs, c1, masks=m)
             assert type(x).__name__ == "_LazySH" and not calls and x.shape == dirs.shape and x.requires_grad and x.device == dirs.device
             y = FORMS[form](x)
+            if form in ("mtgs", "gsplat", "kwargs", "method") and K == 16 and m is None:
+                # the activations rasterization() can evaluate by itself stay deferred through the clamp (tests/test_gpu_sh_raster.py);
+                # any other consumer gets the fused kernel's result, here
+                assert type(y).__name__ == "_LazySH" and not calls and y.requires_grad and y.shape == dirs.shape
+                y = y.contiguous()
             assert type(y) is torch.Tensor and calls == ["mtgs_sh_fwd_act"], calls
             (y * v).sum().backward()
         finally:
@@ -150,7 +155,7 @@ def test_the_training_step_with_the_deferred_sh_equals_the_plain_one(hip_lib):
         real = wrapper.call
         try:
             wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
-            with wrapper.sh_lazy(lazy):
+            with wrapper.sh_lazy(lazy, raster=False):
                 rgb = torch.clamp(spherical_harmonics(3, P["means"].detach() - cam, P["coeffs"]) + 0.5, 0.0, 1.0)
                 render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
                                                     render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")

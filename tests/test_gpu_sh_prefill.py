@@ -9,6 +9,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _sh_evaluated_by_its_own_kernels():
+    """These tests are about the spherical_harmonics() autograd node and the zeros of ITS backward.  MTGS's plain step no longer has
+    such a node -- the colours stay deferred into the rasterization (tests/test_gpu_sh_raster.py) -- but every composition the
+    rasterization cannot take over still has (masks, several nodes concatenated, K != 16, a second use of the colours ...): the
+    deferral into the rasterization is switched off here so that the plain step exercises it."""
+    from mtgs_amd import wrapper
+    with wrapper.sh_lazy(wrapper._lazy_sh_enabled, raster=False):
+        yield
+
+
 def _scene(dev, N=300_000, W=640, H=368):
     from mtgs_amd.synthetic import make_camera, make_scene
     sc = make_scene(N, seed=3, sh_degree=3)
@@ -286,7 +297,7 @@ def test_gsplats_sh_degree_call_style_writes_the_coefficient_gradient_in_place(h
         got = run()
     finally:
         wrapper.call = real
-    assert "mtgs_vis_color_bwd" in calls and "mtgs_rows_expand" not in calls, calls
+    assert "mtgs_vis_color_bwd_dirs" in calls and "mtgs_rows_expand" not in calls, calls      # (the _dirs entry points, dirs = NULL here)
     wrapper._prefill.enabled = False
     try:
         want = run()

@@ -1,0 +1,200 @@
+"""MTGS's colours deferred THROUGH the clamp into rasterization() (mtgs_amd/wrapper.py::_LazySH.raster_source, csrc/viscolor.hip
+mtgs_vis_color_*_dirs): `rgbs = torch.clamp(spherical_harmonics(n, viewdirs, colors) + 0.5, 0.0, 1.0)`
+(/root/reference/mtgs/scene_model/gaussian_model/vanilla_gaussian_splatting.py:313-318) handed to `rasterization(colors=rgbs, ...)`
+(mtgs_scene_graph.py:641-660) is evaluated for the Gaussians the projection finds VISIBLE only -- no [N, 3] colour tensor, no read of
+the other coefficient rows -- and must give the render of the plain composition bit for bit, its gradients up to the order of the
+compositing atomics, and fall back to the full evaluation wherever the rasterization cannot take the colours over."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(N, W, H, seed=3):
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda")
+    sc = make_scene(N, seed=seed, sh_degree=3)
+    vm, K = make_camera(W, H)
+    vm, K = vm.to(dev), K.to(dev)
+    g = torch.Generator().manual_seed(2)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=g).to(dev), torch.randn(1, H, W, 1, generator=g).to(dev)
+    cam = torch.inverse(vm)[0, :3, 3]
+    return sc, vm, K, Gc, Ga, cam, dev
+
+
+def _step(sc, vm, K, W, H, Gc, Ga, cam, dev, mode, form="mtgs", render_mode="RGB+ED", frozen=(), no_grad=False, normalise=False):
+    """mode: 'raster' (deferred into the rasterization), 'fused' (SH + activation over all Gaussians), 'torch' (three torch operations)."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    P = {k: v.to(dev).requires_grad_(k not in frozen) for k, v in sc.items()}
+    calls = []
+    real = wrapper.call
+    act = (lambda x: torch.clamp(x + 0.5, 0.0, 1.0)) if form == "mtgs" else (lambda x: torch.clamp_min(x + 0.5, 0.0))
+    ctx = torch.no_grad() if no_grad else torch.enable_grad()
+    try:
+        wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        with wrapper.sh_lazy(mode != "torch", raster=mode == "raster"), ctx:
+            dirs = P["means"].detach() - cam
+            if normalise:      # (MTGS normalises in PyTorch first: vanilla_gaussian_splatting.py:314)
+                dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+            rgb = act(spherical_harmonics(3, dirs, P["coeffs"]))
+            render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
+                                                render_mode=render_mode, absgrad=True, rasterize_mode="antialiased")
+            if not no_grad:
+                info["means2d"].retain_grad()
+                nc = render.shape[-1]
+                ((render * Gc[..., :nc]).sum() + (alpha * Ga).sum()).backward()
+    finally:
+        wrapper.call = real
+    grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in P.items()}
+    if not no_grad:
+        grads["means2d"], grads["absgrad"] = info["means2d"].grad.clone(), info["means2d"].absgrad.clone()
+    return render.detach(), alpha.detach(), grads, calls, info
+
+
+@pytest.mark.parametrize("form", ["mtgs", "gsplat"])
+@pytest.mark.parametrize("render_mode", ["RGB+ED", "RGB"])
+def test_deferred_colours_render_bit_for_bit_and_train_alike(hip_lib, form, render_mode):
+    N, W, H = 300_000, 640, 368
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H)
+    r1, a1, g1, c1, i1 = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "raster", form, render_mode)
+    r2, a2, g2, c2, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "fused", form, render_mode)
+    r0, a0, g0, c0, i0 = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "torch", form, render_mode)
+    # the visible Gaussians only, inside the rasterization: no SH launch of its own, no dense expansion, no torch clamp
+    assert "mtgs_vis_color_fwd_dirs" in c1 and "mtgs_vis_color_bwd_dirs" in c1, c1
+    assert not [n for n in c1 if n.startswith("mtgs_sh_")] and "mtgs_rows_expand" not in c1, c1
+    assert "mtgs_sh_fwd_act" in c2 and "mtgs_sh_bwd_rows_act" in c2 and "mtgs_vis_color_fwd_dirs" not in c2
+    assert "mtgs_sh_fwd" in c0 and "mtgs_vis_color_fwd_dirs" not in c0
+    assert torch.equal(r1, r0) and torch.equal(a1, a0) and torch.equal(r2, r0)
+    for k in ("radii", "means2d", "depths", "conics", "opacities", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert torch.equal(i1[k], i0[k]), k
+    n_vis = int((i0["radii"] > 0).sum())
+    assert 0 < n_vis < N // 2
+    # d L / d coefficients: rows of the Gaussians with a cotangent -- the same Gaussians, the same values (the compositing atomics' order
+    # aside); every other row is exactly zero
+    assert torch.equal(g1["coeffs"] != 0, g0["coeffs"] != 0) and torch.equal(g2["coeffs"] != 0, g0["coeffs"] != 0)
+    assert int((g1["coeffs"] != 0).any(dim=(1, 2)).sum()) <= n_vis
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-3, atol=1e-5 * scale)
+        torch.testing.assert_close(g2[k], g0[k], rtol=1e-3, atol=1e-5 * scale)
+
+
+def test_normalised_directions_frozen_coefficients_and_inference(hip_lib):
+    N, W, H = 120_000, 400, 240
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=5)
+    # MTGS's own order: directions normalised in PyTorch, then spherical_harmonics
+    r1, _, g1, c1, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "raster", normalise=True)
+    r0, _, g0, _, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "torch", normalise=True)
+    assert torch.equal(r1, r0) and "mtgs_vis_color_fwd_dirs" in c1
+    torch.testing.assert_close(g1["coeffs"], g0["coeffs"], rtol=1e-3, atol=1e-5 * float(g0["coeffs"].abs().max()))
+    # frozen coefficients: no colour backward at all, the geometry still trains
+    r1, _, g1, c1, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "raster", frozen=("coeffs",))
+    r0, _, g0, _, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "torch", frozen=("coeffs",))
+    assert torch.equal(r1, r0) and g1["coeffs"] is None and "mtgs_vis_color_bwd_dirs" not in c1 and "mtgs_vis_color_fwd_dirs" in c1
+    torch.testing.assert_close(g1["means"], g0["means"], rtol=1e-3, atol=1e-5 * float(g0["means"].abs().max()))
+    # only the coefficients train
+    r1, _, g1, c1, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "raster", frozen=("means", "quats", "scales", "opacities"))
+    r0, _, g0, _, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "torch", frozen=("means", "quats", "scales", "opacities"))
+    assert torch.equal(r1, r0) and g1["means"] is None
+    torch.testing.assert_close(g1["coeffs"], g0["coeffs"], rtol=1e-3, atol=1e-5 * float(g0["coeffs"].abs().max()))
+    # inference
+    r1, a1, _, c1, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "raster", no_grad=True)
+    r0, a0, _, _, _ = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "torch", no_grad=True)
+    assert torch.equal(r1, r0) and torch.equal(a1, a0) and "mtgs_vis_color_fwd_dirs" in c1 and not r1.requires_grad
+
+
+def test_what_the_rasterization_cannot_take_over_is_evaluated_in_full(hip_lib):
+    """Several cameras, a background, extra channels behind the colours (MTGS's predict_normals: torch.cat), the colours used a second
+    time, directions with a gradient: the deferred object turns into the fused kernel's ordinary tensor -- same results as PyTorch's."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    from mtgs_amd.synthetic import make_camera
+    N, W, H = 60_000, 320, 200
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=7)
+    vm2 = torch.cat([vm, make_camera(W, H, yaw_deg=20.0)[0].to(dev)])
+    K2 = torch.cat([K, K])
+    bg = torch.tensor([[0.1, 0.2, 0.3]], device=dev)
+    extra = torch.rand(N, 2, device=dev)
+
+    def run(lazy, case):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+        calls = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(lazy):
+                dirs = P["means"] - cam if case == "dirs_grad" else P["means"].detach() - cam
+                rgb = torch.clamp(spherical_harmonics(3, dirs, P["coeffs"]) + 0.5, 0.0, 1.0)
+                kw = dict(packed=False, render_mode="RGB", rasterize_mode="antialiased")
+                reg = 0.0
+                if case == "two_cameras":
+                    out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm2, K2, W, H, **kw)
+                elif case == "background":
+                    out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, backgrounds=bg, **kw)
+                elif case == "extra_channels":
+                    out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], torch.cat([rgb, extra], dim=-1), vm, K, W, H, **kw)
+                elif case == "used_twice":
+                    out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, **kw)
+                    reg = (rgb * rgb).sum() * 1e-3
+                else:
+                    out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, **kw)
+                (out[0].sum() + reg).backward()
+        finally:
+            wrapper.call = real
+        return out[0].detach(), {k: v.grad.clone() for k, v in P.items()}, calls
+
+    for case in ("two_cameras", "background", "extra_channels", "used_twice", "dirs_grad"):
+        r1, g1, c1 = run(True, case)
+        r0, g0, c0 = run(False, case)
+        assert torch.equal(r1, r0), case
+        if case == "used_twice":      # the rasterization took the colours over; the second use evaluated them in full once more
+            assert "mtgs_vis_color_fwd_dirs" in c1 and "mtgs_sh_fwd_act" in c1, c1
+        else:
+            assert "mtgs_vis_color_fwd_dirs" not in c1 and "mtgs_sh_fwd_act" in c1, (case, c1)
+        for k in g0:
+            torch.testing.assert_close(g1[k], g0[k], rtol=2e-3, atol=2e-5 * float(g0[k].abs().max()), msg=lambda m: f"{case} {k}: {m}")
+
+
+def test_deferred_colours_in_one_captured_graph(hip_lib):
+    """The headline step -- spherical_harmonics, clamp, rasterization, backward -- captured in ONE HIP graph (mtgs_amd.graph_mode: fixed
+    capacities, counts on the device) with the colours deferred into the rasterization: replays give the eager step's render bit for bit and
+    its gradients; the dense coefficient gradient is the zeros that rode on the compositing forward plus the touched rows."""
+    from mtgs_amd import graph_mode, rasterization, spherical_harmonics, wrapper
+    N, W, H = 200_000, 640, 368
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=9)
+    r0, a0, g0, _, i0 = _step(sc, vm, K, W, H, Gc, Ga, cam, dev, "torch")
+    n_vis, M = int((i0["radii"] > 0).sum()), int(i0["flatten_ids"].numel())
+    P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    dirs = (P["means"].detach() - cam).contiguous()
+    calls = []
+    real = wrapper.call
+
+    def body():
+        rgb = torch.clamp(spherical_harmonics(3, dirs, P["coeffs"]) + 0.5, 0.0, 1.0)
+        render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
+                                            render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+        ((render * Gc).sum() + (alpha * Ga).sum()).backward()
+        return render, alpha, info
+
+    gm = graph_mode(int(n_vis * 1.2) + 1024, int(M * 1.2) + 4096)
+    with gm:
+        body()                                  # under the mode once: its staging buffers exist before the capture
+    for p in P.values():
+        p.grad = None
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    try:
+        wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        with gm, torch.cuda.graph(graph):
+            render, alpha, info = body()
+    finally:
+        wrapper.call = real
+    assert "mtgs_vis_color_fwd_dirs" in calls and "mtgs_vis_color_bwd_dirs" in calls and "mtgs_rows_expand" not in calls, calls
+    assert not [n for n in calls if n.startswith("mtgs_sh_")], calls
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert not bool(info["overflow"]) and int(info["n_visible"]) == n_vis
+    assert torch.equal(render, r0) and torch.equal(alpha, a0)
+    for k in P:
+        torch.testing.assert_close(P[k].grad, g0[k], rtol=1e-3, atol=1e-5 * float(g0[k].abs().max()))
+    assert torch.equal(P["coeffs"].grad != 0, g0["coeffs"] != 0)

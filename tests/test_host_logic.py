@@ -239,10 +239,32 @@ def test_deferred_sh_dispatch_rules_on_cpu(monkeypatch):
     new = lambda: wrapper._LazySH(3, d, c, None)
     x = new()
     assert (x.shape, x.dtype, x.dim(), x.numel(), x.requires_grad, x.device.type) == (d.shape, torch.float32, 2, 21, True, "cpu") and not seen
+    # MTGS's and gsplat's activations on K = 16 rows stay deferred THROUGH the clamp (rasterization() may take them over: visible
+    # Gaussians only); any other use runs the fused kernel with that activation, once
     y = torch.clamp(x + 0.5, 0.0, 1.0)
-    assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor and torch.equal(y, torch.clamp(ref + 0.5, 0.0, 1.0))
+    assert not seen and type(y) is wrapper._LazySH and y._lz_act == (0.0, 1.0) and y.shape == d.shape and y.requires_grad
+    assert y.raster_source(8, 64, 64) is None      # (not this tensor's Gaussian count: the caller falls back to the full evaluation)
+    assert torch.equal(y, torch.clamp(ref + 0.5, 0.0, 1.0)) and torch.equal(y * 2, torch.clamp(ref + 0.5, 0.0, 1.0) * 2)
+    assert seen == [(True, 0.5, 0.0, 1.0)] and y.raster_source(7, 64, 64) is None      # (already evaluated)
     seen.clear()
-    assert torch.equal(torch.clamp_min(0.5 + new(), 0.0), torch.clamp_min(ref + 0.5, 0.0)) and seen == [(True, 0.5, 0.0, float("inf"))]
+    y = torch.clamp_min(0.5 + new(), 0.0)
+    assert not seen and type(y) is wrapper._LazySH
+    assert torch.equal(y, torch.clamp_min(ref + 0.5, 0.0)) and seen == [(True, 0.5, 0.0, float("inf"))]
+    seen.clear()
+    assert type(torch.clamp(y, 0.0, 0.5)) is torch.Tensor and not seen      # (a second clamp: ordinary tensors, no second evaluation)
+    with wrapper.sh_lazy(True, raster=False):      # ... switched off: the clamp runs the fused kernel over all Gaussians at once
+        y = torch.clamp(new() + 0.5, 0.0, 1.0)
+        assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor and torch.equal(y, torch.clamp(ref + 0.5, 0.0, 1.0))
+    seen.clear()
+    for expr, want, act in ((lambda z: torch.clamp(z + 0.25, 0.0, 1.0), torch.clamp(ref + 0.25, 0.0, 1.0), (True, 0.25, 0.0, 1.0)),
+                            (lambda z: torch.clamp(z + 0.5, 0.0, 2.0), torch.clamp(ref + 0.5, 0.0, 2.0), (True, 0.5, 0.0, 2.0)),
+                            (lambda z: torch.clamp(z, 0.0, 1.0), torch.clamp(ref, 0.0, 1.0), (False, 0.0, 0.0, 1.0))):
+        got = expr(new())      # other activations: the fused kernel at once
+        assert seen == [act] and type(got) is torch.Tensor and torch.equal(got, want)
+        seen.clear()
+    c8 = torch.randn(7, 9, 3)
+    y = torch.clamp(wrapper._LazySH(2, d, c8, None) + 0.5, 0.0, 1.0)      # K != 16: at once
+    assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor
     seen.clear()
     assert torch.equal(new().clamp(max=0.25), ref.clamp(max=0.25)) and seen == [(False, 0.0, float("-inf"), 0.25)]
     seen.clear()
