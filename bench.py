@@ -80,9 +80,29 @@ ENTRY_POINTS = {
     "mtgs_sh_fwd_act": ["sh_fwd_k16_kernel<3>"],
     "mtgs_sh_bwd_act": ["sh_bwd_kernel<3>"],
     "mtgs_sh_bwd_rows_act": ["sh_bwd_rows_kernel<3>"],
+    # (... and since the clamp stays deferred too, the rasterization evaluates SH + activation for the VISIBLE Gaussians by itself:
+    #  these two replace the three above in the default step; mtgs_amd.sh_lazy(True, raster=False) gives those back)
+    "mtgs_vis_color_fwd_dirs": ["vis_color_fwd_kernel<3>"],
+    "mtgs_vis_color_bwd_dirs": ["vis_color_bwd_kernel<3>"],
     "mtgs_dp_reduce": ["dp_reduce_kernel"],
 }
 
+
+
+def _colour_activation_note():
+    import mtgs_amd.wrapper as w
+    if not getattr(w, "_lazy_sh_enabled", False):
+        return "PyTorch elementwise kernels (MTGS_SH_LAZY=0)"
+    if getattr(w, "_lazy_raster_enabled", False):
+        return ("deferred into the rasterization: spherical_harmonics() and the step's own `torch.clamp(sh + 0.5, 0.0, 1.0)` "
+                "(vanilla_gaussian_splatting.py:313-318) return a deferred tensor, and rasterization(colors=that) evaluates SH + clamp "
+                "for the Gaussians its projection finds VISIBLE only, straight into their records -- the same render bit for bit "
+                "(mtgs_amd/wrapper.py::_LazySH.raster_source, csrc/viscolor.hip, tests/test_gpu_sh_raster.py); "
+                "ms_per_step_sh_over_all_gaussians = the same step with SH + clamp as one kernel over all N, "
+                "ms_per_step_torch_activation = with the clamp as PyTorch's kernels")
+    return ("fused: spherical_harmonics() returns a deferred tensor and the step's own `torch.clamp(sh + 0.5, 0.0, 1.0)` "
+            "(vanilla_gaussian_splatting.py:318) runs inside the SH kernels, bit-identical values and gradients "
+            "(mtgs_amd/wrapper.py::_LazySH, tests/test_gpu_sh_lazy.py)")
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -593,14 +613,15 @@ def main():
     # give the dominant kernel's launch time) and is reported as also.headline_eager_ms.
     elapsed_eager, elapsed_graph, launch, graph_error = elapsed, None, "eager", None
     elapsed_graph_tight, n_listed_tight = None, None
-    elapsed_graph_torch_act = None
+    elapsed_graph_torch_act = elapsed_graph_all_sh = None
 
-    def graph_time(tight, lazy_sh=True):
+    def graph_time(tight, lazy_sh=True, raster=None):
         """K replays of the step captured once under mtgs_amd.graph_mode (+ the opt-in tight tile lists when `tight`; lazy_sh = False:
-        spherical_harmonics() evaluated at once, the step's clamp(sh + 0.5) as PyTorch's own kernels -- the round-5 form)."""
+        spherical_harmonics() evaluated at once, the step's clamp(sh + 0.5) as PyTorch's own kernels -- the round-5 form; raster = False:
+        SH + activation in one kernel over ALL Gaussians, not deferred into the rasterization -- the first round-6 form)."""
         import gc
         import mtgs_amd
-        with mtgs_amd.sh_lazy(lazy_sh):
+        with mtgs_amd.sh_lazy(lazy_sh, raster=raster):
             return _graph_time(tight, gc, mtgs_amd)
 
     def _graph_time(tight, gc, mtgs_amd):
@@ -652,6 +673,7 @@ def main():
         try:        # ... and with the colour activation left to PyTorch (what round 5's line measured)
             if not args.no_tight and args.variant == "mtgs":
                 elapsed_graph_torch_act, _ = graph_time(False, lazy_sh=False)
+                elapsed_graph_all_sh, _ = graph_time(False, raster=False)
         except Exception as e:      # noqa: BLE001
             print(f"[bench] torch-activation graph failed: {type(e).__name__}: {e}"[:300], file=sys.stderr)
     info_box["info"] = eager_info
@@ -746,6 +768,8 @@ def main():
         "sh_fwd_k16_kernel<3>": N * (12 + 12 * Ksh_ + 12),
         "sh_bwd_kernel<3>": N * (24 + 12 * Ksh_),
         "sh_bwd_rows_kernel<3>": N * 12 + n_coeff_rows * (12 + 12 * Ksh_),      # cotangents in; direction in + row out where there is one
+        "vis_color_fwd_kernel<3>": n_vis * (4 + 12 + 12 * Ksh_ + 12 + 1),          # id, direction, coefficient row in; colour into the record, clamp bits out
+        "vis_color_bwd_kernel<3>": n_vis * (4 + 12 + 12 + 1) + n_coeff_rows * 12 * Ksh_,   # id, direction, cotangent, clamp bits in; row out where there is one
         "front_project_kernel": N * (40 + 4 + 40) + n_vis * 48,                  # (+ the chunk-local compact rows of the visible pairs)
         "front_compact_kernel": N * (4 + 4) + n_vis * (48 + 12 + 64 + 4 + 8),   # radii in, vis_rank out | staged row + colours in, record + id + key out
         "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
@@ -830,6 +854,7 @@ def main():
         "ms_per_step_exact_lists": round(ms_per_step, 3) if not tight_headline else None,
         "ms_per_step_tight_lists": None if elapsed_graph_tight is None else round(elapsed_graph_tight / args.steps * 1e3, 3),
         "ms_per_step_torch_activation": None if elapsed_graph_torch_act is None else round(elapsed_graph_torch_act / args.steps * 1e3, 3),
+        "ms_per_step_sh_over_all_gaussians": None if elapsed_graph_all_sh is None else round(elapsed_graph_all_sh / args.steps * 1e3, 3),
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -844,10 +869,7 @@ def main():
                       "isect_offset_encode" + ("" if n_listed_tight is None else
                                                "; the opt-in tight lists (mtgs_amd.tight_lists(): same pixels and gradients, "
                                                f"{n_listed_tight} listed pairs) are timed beside it as ms_per_step_tight_lists, never as `value`")),
-            "colour_activation": ("fused: spherical_harmonics() returns a deferred tensor and the step's own `torch.clamp(sh + 0.5, 0.0, 1.0)` "
-                                  "(vanilla_gaussian_splatting.py:318) runs inside the SH kernels, bit-identical values and gradients "
-                                  "(mtgs_amd/wrapper.py::_LazySH, tests/test_gpu_sh_lazy.py)" if getattr(__import__("mtgs_amd").wrapper, "_lazy_sh_enabled", False)
-                                  else "PyTorch elementwise kernels (MTGS_SH_LAZY=0)"),
+            "colour_activation": _colour_activation_note(),
             "launch": ("one HIP graph launch per step: the step captured once under mtgs_amd.graph_mode + torch.cuda.graph and replayed "
                        "(the K steps were timed in both launch modes, the line carries the faster: ms_per_step_eager / ms_per_step_graph)")
                       if launch == "graph" else

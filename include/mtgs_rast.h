@@ -544,7 +544,9 @@ int mtgs_dp_reduce_rows_groups(int W, int64_t N, int K, int degree, const float 
  * {v_mean 3, v_quat 4, v_scale 3, v_opacity 1, v_rgb 3, 0, Gaussian index (int bits)}.  grad_rows[n_vis,row_stride] as mtgs_blend_bwd_packed
  * leaves them (the first three of D <= 7 colour channels; further channels are folded into the rows by their own VJP,
  * e.g. mtgs_normals_bwd_rows).  color_mode 1: colours were clamp(colors_pre + 0.5, 0, 1) (mtgs_front_fwd),
- * v_rgb is the gradient with respect to colors_pre[N,3].  v_viewmats[1,4,4] nullable, overwritten. */
+ * v_rgb is the gradient with respect to colors_pre[N,3].  color_mode 2 (hot ABI v7): the colours were written into the records by
+ * mtgs_vis_color_fwd(_dirs) (use_sh = 1) and `colors_pre` points at its vis_mask -- uint8[n_vis], bit c = channel c passes its
+ * cotangent -- instead of a dense [N,3] tensor.  v_viewmats[1,4,4] nullable, overwritten. */
 int mtgs_project_bwd_rows(int64_t N, const float *means, const float *quats, const float *scales,
                           const float *viewmats, const float *Ks, int width, int height, float eps2d,
                           const float *conics, const float *compensations, const float *opacities,
@@ -845,7 +847,8 @@ int mtgs_vis_color_bwd_dirs(int n_nodes, const mtgs_node_desc *table, int degree
                             const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, const float *grad_rows,
                             int64_t row_stride, int col, const float *recs, const uint8_t *vis_mask, float *feat_rows,
                             float *dir_rows, float *dir_part, float *dense_rows, const float *dirs, void *stream);
-/* dense_rows (nullable; ABI v26; one node): a ZEROED [N, 16, 3] coefficient gradient -- the rows of the visible Gaussians whose colour
+/* dense_rows (nullable; ABI v26; since v28 any number of nodes whose coefficient tensors are plain [n_i, 16, 3] rows: node i's gradient
+ * is the slice [start_i, start_i + n_i) of the buffer): a ZEROED [N, 16, 3] coefficient gradient -- the rows of the visible Gaussians whose colour
  * cotangent is not zero are written straight into it (row = vis_ids[r]) and feat_rows may be NULL: gsplat's `sh_degree` call style
  * without the [n_vis, 48] intermediate and the dense expansion pass behind it. */
 /* use_sh = 4 in a descriptor: gsplat's own sh_degree path -- clamp_min(SH + 0.5, 0) (gsplat/rendering.py), and dir_rows

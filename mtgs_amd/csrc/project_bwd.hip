@@ -505,7 +505,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void viewmat_reduce_kernel(const float 
 // and writing, per visible Gaussian in index order, the 64-byte row the gradient exchange puts on the wire:
 //   [v_mean 3 | v_quat 4 | v_scale 3 | v_opacity 1 | v_rgb 3 | 0 | Gaussian index (int bits)]
 // v_rgb is the gradient with respect to the SH OUTPUT x: with color_mode 1 the colour was clamp(x + 0.5, 0, 1)
-// (front.hip), whose VJP passes the gradient where 0 <= x + 0.5 <= 1 (torch.clamp's rule).  No dense tensor is
+// (front.hip), whose VJP passes the gradient where 0 <= x + 0.5 <= 1 (torch.clamp's rule); color_mode 2: the colours were evaluated for
+// the visible Gaussians by mtgs_vis_color_fwd and `colors_pre` points at ITS clamp bits (uint8 per visible row, bit c = channel c passes).  No dense tensor is
 // written: the receivers' reduction (mtgs_dp_reduce) rebuilds every dense gradient, this rank's included.
 constexpr int WIRE_ROW = 16;
 __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
@@ -595,6 +596,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_rows_kernel(
                     if (color_mode == 1) {
                         const float x = colors_pre[n * DC + k] + 0.5f;
                         v = (x >= 0.f && x <= 1.f) ? v : 0.f;
+                    } else if (color_mode == 2) {      // the clamp bits of mtgs_vis_color_fwd, one byte per visible row
+                        v = ((reinterpret_cast<const uint8_t *>(colors_pre)[r] >> k) & 1u) ? v : 0.f;
                     }
                     vrgb[k] = v;
                 }
@@ -808,7 +811,8 @@ extern "C" int mtgs_project_bwd_rows(int64_t N, const float *means, const float 
     //  the rows by their own VJP, e.g. mtgs_normals_bwd_rows)
     MTGS_REQUIRE(D >= 0 && D <= 7 && row_stride >= 8 + D + (with_depth ? 1 : 0) && (row_stride % 4) == 0, MTGS_EINVAL,
                  "mtgs_project_bwd_rows: D=%d (0..7 colour channels) row_stride=%lld", D, (long long)row_stride);
-    MTGS_REQUIRE(color_mode == 0 || (color_mode == 1 && D >= 3 && colors_pre), MTGS_EINVAL, "mtgs_project_bwd_rows: color_mode");
+    MTGS_REQUIRE(color_mode == 0 || ((color_mode == 1 || color_mode == 2) && D >= 3 && colors_pre), MTGS_EINVAL,
+                 "mtgs_project_bwd_rows: color_mode");
     hipStream_t st = (hipStream_t)stream;
     if (v_viewmats) {
         if (int rc = mtgs_zero_async(v_viewmats, sizeof(float) * 16, st)) return rc;

@@ -70,7 +70,11 @@ __device__ __forceinline__ RawDir resolve_rows(const mtgs_node_desc *__restrict_
                                                int64_t n_vis, RowInfo *s_row, int64_t *s_start,
                                                const float *__restrict__ coef_rows = nullptr, int64_t coef_stride = 0,
                                                const uint8_t *__restrict__ row_flags = nullptr,
-                                               const float *__restrict__ dirs = nullptr) {
+                                               const float *__restrict__ dirs = nullptr,
+                                               const float *__restrict__ cotangents = nullptr, int64_t cot_stride = 0) {
+    // cotangents (backward): d L / d rgb of row r at cotangents + r * cot_stride -- a row whose three values are zero (a visible
+    // Gaussian the frame composited nothing from: ~60 % of them in an opaque scene) has an all-zero gradient whatever its direction,
+    // so its direction is not fetched (a scattered 12-byte read each)
     const int tid = threadIdx.x;
     const bool small = n_nodes <= VC_LDS_NODES;
     if (small && n_nodes > 1) {
@@ -103,10 +107,16 @@ __device__ __forceinline__ RawDir resolve_rows(const mtgs_node_desc *__restrict_
                 ri.rest = ri.dc + 6;
             }
             ri.k_rest = d.k_rest; ri.use_sh = d.use_sh;
+            bool want_dir = true;
+            if (cotangents) {
+                const float *cg = cotangents + r * cot_stride;
+                want_dir = cg[0] != 0.f || cg[1] != 0.f || cg[2] != 0.f;
+            }
             // dirs (mtgs_vis_color_fwd_dirs): the caller's own view directions [N, 3] (MTGS: spherical_harmonics(n, viewdirs, colors) with
             // viewdirs computed in PyTorch) instead of mean - camera position; normalised as sh_fwd_k16_kernel does (sh.hip)
-            rd.on = true;
-            if (dirs) {
+            rd.on = want_dir;
+            if (!want_dir) {
+            } else if (dirs) {
                 const F3 dv = *reinterpret_cast<const F3 *>(dirs + g * 3);
                 rd.x = dv.x; rd.y = dv.y; rd.z = dv.z;
             } else {
@@ -223,7 +233,8 @@ __global__ __launch_bounds__(VC_BLOCK) void vis_color_bwd_kernel(const mtgs_node
             mkin[it] = vis_mask[r];
         }
     }
-    const RawDir rd = resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, nullptr, 0, nullptr, dirs);
+    const RawDir rd = resolve_rows(table, n_nodes, cam_pos, means, vis_ids, r0, n_vis, s_row, s_start, nullptr, 0, nullptr, dirs,
+                                   grad_rows + col, row_stride);
     publish_dirs(s_row, rd);
     const ShLaneConst lc = sh_lane_const(k);
 #pragma unroll
@@ -405,7 +416,8 @@ extern "C" int mtgs_vis_color_bwd_dirs(int n_nodes, const mtgs_node_desc *table,
                      (!dir_rows == !dir_part),
                  MTGS_EINVAL, "mtgs_vis_color_bwd: null pointer (dir_rows and dir_part go together; feat_rows or dense_rows)");
     MTGS_REQUIRE(!dirs || !dir_rows, MTGS_EINVAL, "mtgs_vis_color_bwd: dir_rows is the gradient of directions mean - cam_pos (not of `dirs`)");
-    MTGS_REQUIRE(!dense_rows || n_nodes == 1, MTGS_EINVAL, "mtgs_vis_color_bwd: dense_rows is the gradient of ONE [N, 16, 3] coefficient tensor");
+    // (dense_rows: ONE zeroed [N, 16, 3] buffer in collected order -- with several nodes, each node's gradient is its slice
+    //  [start, start + n) of it, which takes plain K = 16 coefficient rows in every node: sh_direction_source / sh_coefficient_source)
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div64(cap_vis, VC_ROWS);
     MTGS_VC_DISPATCH(vis_color_bwd_kernel, table, n_nodes, cam_pos, means, vis_ids, totals, cap_vis, grad_rows, row_stride, col, recs,

@@ -236,7 +236,7 @@ class SparseGradExchange:
         traversal this rank's camera belongs to -- MTGS's multi-colour nodes have one set of SH coefficients per traversal
         (multi_color_gaussian_splatting.py:77-101), and finish() then returns the coefficient gradient as [N, T, K, 3]
         with every sender's contribution in ITS traversal's slice."""
-        from .wrapper import fused_rasterization
+        from .wrapper import _LazySH, fused_rasterization
         assert viewmats.shape[0] == 1 and sh_out.dim() == 2 and sh_out.shape[0] == self.N and sh_out.shape[1] >= 3 and means.shape == (self.N, 3)
         assert render_mode in ("RGB", "RGB+D", "RGB+ED") and rasterize_mode in ("classic", "antialiased")
         assert 0 <= int(traversal) < self.T, (traversal, self.T)
@@ -254,10 +254,14 @@ class SparseGradExchange:
             self.zero_region = (region.data_ptr(), region.numel() * 4)
         self._pending = {"stage": "forward"}
         self.phase = "render (forward; meta all-gather on the side stream)"
+        # `sh_out` still deferred (spherical_harmonics() returns a deferred tensor, wrapper._LazySH): SH + clamp are evaluated for the
+        # Gaussians this camera sees only, by the rasterization (csrc/viscolor.hip) -- no [N, 3] tensor, 85 % of the coefficient rows unread
+        cs = sh_out.exchange_source(self.N) if (type(sh_out) is _LazySH and sh_out.shape[1] == 3) else None
+        cols = None if cs is not None else sh_out.detach().unsqueeze(0)
         render, alphas, m = fused_rasterization(
-            means, quats, scales, opacities, sh_out.detach().unsqueeze(0), viewmats, Ks, None, width, height, eps2d,
+            means, quats, scales, opacities, cols, viewmats, Ks, None, width, height, eps2d,
             near_plane, far_plane, radius_clip, rasterize_mode == "antialiased", render_mode != "RGB",
-            render_mode == "RGB+ED", absgrad, dp=self)
+            render_mode == "RGB+ED", absgrad, dp=self, color_source=cs)
         return render, alphas, m
 
     def abandon(self):

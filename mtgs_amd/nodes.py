@@ -325,32 +325,42 @@ def sh_coefficient_source(coeffs: Tensor, sh_degree: int, campos: Tensor) -> Col
 _dir_tables: dict = {}      # (coefficient pointer, N, K, activation, device, stream) -> uploaded descriptor (its content is a function of the key)
 
 
-def sh_direction_source(coeffs: Tensor, sh_degree: int, dirs: Tensor, use_sh: int) -> ColorSource:
+def sh_direction_source(coeffs, sh_degree: int, dirs, use_sh: int) -> ColorSource:
     """ColorSource for MTGS's own call style -- rgbs = spherical_harmonics(n, viewdirs, colors); torch.clamp(rgbs + 0.5, 0, 1)
     (vanilla_gaussian_splatting.py:313-318; use_sh = 1) or clamp_min (use_sh = 4) -- whose deferred result reached rasterization()
-    (wrapper._LazySH.raster_source): ONE descriptor over the [N, 16, 3] coefficient tensor, the caller's directions as they are."""
+    (wrapper._LazySH.raster_source): one descriptor per [n_i, 16, 3] coefficient tensor (`coeffs` / `dirs`: a tensor each, or equally long
+    lists of them -- the nodes of a scene graph whose colours were concatenated, mtgs_scene_graph.py:451-452 -- in that order), the
+    caller's directions as they are."""
     from . import wrapper
-    N, K = coeffs.shape[0], coeffs.shape[1]
-    assert coeffs.dim() == 3 and coeffs.shape[2] == 3 and coeffs.dtype == torch.float32 and K == 16 and sh_degree <= 3
-    c = coeffs.detach().contiguous()
-    d = dirs.detach().contiguous()
-    dev = c.device
+    cl = list(coeffs) if isinstance(coeffs, (list, tuple)) else [coeffs]
+    dl = list(dirs) if isinstance(dirs, (list, tuple)) else [dirs]
+    assert len(cl) == len(dl) >= 1 and sh_degree <= 3
+    for c_, d_ in zip(cl, dl):
+        assert c_.dim() == 3 and c_.shape[1:] == (16, 3) and c_.dtype == torch.float32 and d_.shape == (c_.shape[0], 3)
+    K = 16
+    cc = [c_.detach().contiguous() for c_ in cl]
+    d = dl[0].detach().contiguous() if len(dl) == 1 else torch.cat([d_.detach() for d_ in dl], dim=0)      # (collected order, like `means`)
+    dev = cc[0].device
     in_graph = wrapper._graph.caps is not None or torch.cuda.is_current_stream_capturing()
-    key = (c.data_ptr(), N, K, int(use_sh), dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (tuple((c_.data_ptr(), c_.shape[0]) for c_ in cc), int(use_sh), dev.index, torch.cuda.current_stream(dev).cuda_stream)
     table = None if in_graph else _dir_tables.get(key)
+    starts = np.concatenate([[0], np.cumsum([c_.shape[0] for c_ in cc])]).astype(np.int64)
     if table is None:
-        tab = np.zeros(1, dtype=_DESC)
-        tab["n"], tab["start"], tab["first_block"] = N, 0, 0
-        tab["features_dc"], tab["features_rest"] = c.data_ptr(), c.data_ptr() + 12
-        tab["dc_stride"] = tab["rest_stride"] = K * 3
-        tab["dc_add_stride"] = 3
-        tab["k_rest"], tab["use_sh"] = K - 1, int(use_sh)
+        tab = np.zeros(len(cc), dtype=_DESC)
+        for i, c_ in enumerate(cc):
+            tab["n"][i], tab["start"][i] = c_.shape[0], starts[i]
+            tab["features_dc"][i], tab["features_rest"][i] = c_.data_ptr(), c_.data_ptr() + 12
+            tab["dc_stride"][i] = tab["rest_stride"][i] = K * 3
+            tab["dc_add_stride"][i] = 3
+            tab["k_rest"][i], tab["use_sh"][i] = K - 1, int(use_sh)
+        tab["first_block"] = np.concatenate([[0], np.cumsum([-(-c_.shape[0] // 256) for c_ in cc])[:-1]])
         table = _upload(tab, dev)
         if not in_graph:      # (a table uploaded inside a capture has no content before the first replay)
             if len(_dir_tables) >= 16:
                 _dir_tables.clear()
             _dir_tables[key] = table
-    cs = ColorSource(table, 1, int(sh_degree), None, [c, d], [(0, N, coeffs, None, coeffs, None)])
+    cs = ColorSource(table, len(cc), int(sh_degree), None, cc + [d],
+                     [(int(starts[i]), c_.shape[0], cl[i], None, cl[i], None) for i, c_ in enumerate(cc)])
     cs.autograd, cs.width, cs.dirs = True, K * 3, d
     return cs
 

@@ -244,20 +244,39 @@ def _is_number(v) -> bool:
 
 
 class _LazySH(Tensor):
-    # three states: the raw SH output (base None), `raw + c` (add), `clamp(raw [+ c], lo, hi)` (act = (lo, hi); base = the state clamped)
+    # four states: the raw SH output (base None), `raw + c` (add), `clamp(raw [+ c], lo, hi)` (act = (lo, hi); base = the state clamped),
+    # and torch.cat(dim 0) of clamped states of ONE activation and degree (parts: the nodes of a scene graph, mtgs_scene_graph.py:451-452)
     @staticmethod
     def __new__(cls, degree, dirs, coeffs, masks, base=None, add=None, act=None):
         rg = torch.is_grad_enabled() and (coeffs.requires_grad or dirs.requires_grad)
         r = Tensor._make_wrapper_subclass(cls, dirs.shape, dtype=torch.float32, device=dirs.device, requires_grad=rg)
         r._lz_sh = (degree, dirs, coeffs, masks)
-        r._lz_base, r._lz_add, r._lz_act, r._lz_plain = base, add, act, None
+        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts = base, add, act, None, None
+        return r
+
+    @classmethod
+    def _cat(cls, parts):
+        """torch.cat(parts, dim=0) of deferred activations, still deferred -- or None when the parts are not ONE composition
+        rasterization() could take over (then every part is evaluated by the fused kernel and PyTorch concatenates)."""
+        first = parts[0]
+        for q in parts:
+            if not (type(q) is cls and q._lz_act is not None and q._lz_parts is None and q._lz_plain is None and q._lz_act == first._lz_act
+                    and q._lz_sh[0] == first._lz_sh[0] and q.device == first.device):
+                return None
+        n = sum(int(q.shape[0]) for q in parts)
+        r = Tensor._make_wrapper_subclass(cls, (n, 3), dtype=torch.float32, device=first.device,
+                                          requires_grad=any(q.requires_grad for q in parts))
+        r._lz_sh = (first._lz_sh[0], None, None, None)
+        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts = None, None, first._lz_act, None, list(parts)
         return r
 
     def _materialize(self) -> Tensor:
         """The ordinary tensor this object stands for (computed once)."""
         if self._lz_plain is None:
             with torch._C.DisableTorchFunctionSubclass():
-                if self._lz_act is not None:
+                if self._lz_parts is not None:
+                    self._lz_plain = torch.cat([q._materialize() for q in self._lz_parts], dim=0)
+                elif self._lz_act is not None:
                     self._lz_plain = self._lz_base._fused(*self._lz_act)
                 elif self._lz_base is not None:
                     self._lz_plain = self._lz_base._materialize() + self._lz_add
@@ -273,17 +292,33 @@ class _LazySH(Tensor):
         return (_lazy_raster_enabled and self._lz_add == 0.5 and lo == 0.0 and hi in (1.0, float("inf")) and masks is None
                 and degree <= 3 and dirs.dim() == 2 and coeffs.dim() == 3 and coeffs.shape[1] == 16 and not dirs.requires_grad)
 
+    def exchange_source(self, n: int):
+        """ColorSource for a data-parallel frame (dist.SparseGradExchange.rasterization: `sh_out` = the RAW SH output of this rank's
+        camera, blended as clamp(x + 0.5, 0, 1), its gradient rebuilt by the receivers from v_rgb) when this object is that raw output,
+        still deferred: SH + clamp for the visible Gaussians only, no backward of its own -- else None."""
+        degree, dirs, coeffs, masks = self._lz_sh
+        if not (_lazy_raster_enabled and self._lz_base is None and self._lz_act is None and self._lz_plain is None and masks is None
+                and degree <= 3 and dirs.dim() == 2 and dirs.shape == (n, 3) and n > 0 and coeffs.dim() == 3 and coeffs.shape[1] == 16):
+            return None
+        from .nodes import sh_direction_source
+        cs = sh_direction_source(coeffs, degree, dirs, 1)
+        cs.autograd, cs.exchange = False, True
+        return cs
+
     def raster_source(self, n: int, width: int, height: int):
         """(ColorSource, coefficients) for rasterization() when this object is a deferred activation it can take over -- the colours are
         then evaluated for the visible Gaussians only, straight into their records, and d L / d coefficients leaves the rasterization's
         backward (rows of the Gaussians with a cotangent, written into zeros that rode on the compositing forward) -- else None."""
         if self._lz_act is None or self._lz_plain is not None:
             return None
-        degree, dirs, coeffs, _ = self._lz_sh
-        if dirs.shape != (n, 3) or n == 0 or not _bin3_ok(1, -(-width // 16), -(-height // 16), 0):
+        parts = self._lz_parts if self._lz_parts is not None else [self]
+        if any(q._lz_plain is not None for q in parts):      # (a node's colours were used elsewhere meanwhile: they exist, concatenate them)
+            return None
+        if tuple(self.shape) != (n, 3) or n == 0 or not _bin3_ok(1, -(-width // 16), -(-height // 16), 0):
             return None
         from .nodes import sh_direction_source
-        return sh_direction_source(coeffs, degree, dirs, 1 if self._lz_act[1] == 1.0 else 4), coeffs
+        coeffs, dirs = [q._lz_sh[2] for q in parts], [q._lz_sh[1] for q in parts]
+        return sh_direction_source(coeffs, self._lz_sh[0], dirs, 1 if self._lz_act[1] == 1.0 else 4), coeffs
 
     def _fused(self, lo: float, hi: float) -> Tensor:
         has_add = self._lz_add is not None
@@ -295,6 +330,12 @@ class _LazySH(Tensor):
         kwargs = kwargs or {}
         me = args[0] if args and isinstance(args[0], _LazySH) else None
         name = getattr(func, "__name__", "")
+        if func in _LAZY_CAT and args and isinstance(args[0], (list, tuple)) and len(args[0]) >= 1 and not (set(kwargs) - {"dim"}) \
+                and (kwargs.get("dim", args[1] if len(args) > 1 else 0) in (0, -2)) and len(args) <= 2 \
+                and all(type(q) is _LazySH for q in args[0]):
+            got = _LazySH._cat(list(args[0]))
+            if got is not None:
+                return got
         if me is not None and me._lz_plain is None:
             if func in _LAZY_META or (name == "__get__" and getattr(func, "__self__", None) in _LAZY_META_PROPS):
                 with torch._C.DisableTorchFunctionSubclass():
@@ -345,6 +386,7 @@ _LAZY_META = {Tensor.size, Tensor.dim, Tensor.numel, Tensor.nelement, Tensor.ndi
 _LAZY_META_PROPS = {Tensor.shape, Tensor.dtype, Tensor.device, Tensor.ndim, Tensor.is_cuda, Tensor.layout, Tensor.requires_grad,
                     Tensor.is_sparse, Tensor.is_quantized, Tensor.is_meta}
 _LAZY_ADD = {torch.add, Tensor.add, Tensor.__add__, Tensor.__radd__}
+_LAZY_CAT = {torch.cat, torch.concat, torch.concatenate}
 _LAZY_CLAMP_MAX = {torch.clamp_max, Tensor.clamp_max}
 _LAZY_CLAMP = {torch.clamp, Tensor.clamp, torch.clip, Tensor.clip, torch.clamp_min, Tensor.clamp_min} | _LAZY_CLAMP_MAX
 _lazy_sh_enabled = os.environ.get("MTGS_SH_LAZY", "1") == "1"
@@ -866,7 +908,7 @@ class _FusedRasterization(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
                 near_plane, far_plane, radius_clip, calc_compensations, with_depth, expected_depth, absgrad, dp=None, cs=None,
-                sh_coeffs=None, campos=None):
+                sh_coeffs=None, campos=None, *sh_more):
         """dp (mtgs_amd.dist.SparseGradExchange | None): data-parallel mode -- `colors` is the SH output x[1,N,3], blended
         as clamp(x + 0.5, 0, 1); the front kernel writes the visibility map of the exchange, and the backward leaves
         the gradients as wire rows in the exchange's send buffer instead of dense tensors (see dist.py).
@@ -874,7 +916,9 @@ class _FusedRasterization(torch.autograd.Function):
         from the nodes' SH coefficients for the VISIBLE Gaussians only (csrc/viscolor.hip), `colors` holds the remaining
         channels ([C,N,DX] or None); the backward leaves the coefficient gradient as compact rows in `cs` (rows, row_of).
         sh_coeffs [N,K,3], campos [3] (with cs.autograd): gsplat's own `sh_degree` call style -- the coefficient gradient is
-        expanded to a dense tensor for autograd, and the view directions are differentiable (means, camera position)."""
+        expanded to a dense tensor for autograd, and the view directions are differentiable (means, camera position).
+        sh_more (with cs.dirs, sh_direction_source): the coefficient tensors of the further nodes, in collected order -- node i's
+        gradient is the slice [start_i, start_i + n_i) of the dense one."""
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
         means, quats, scales, opacities, col, viewmats, Ks, bg = map(
             _f32c, (means, quats, scales, opacities, colors, viewmats, Ks, backgrounds))
@@ -903,7 +947,7 @@ class _FusedRasterization(torch.autograd.Function):
             raise NotImplementedError("data-parallel rasterization: one camera, the SH output in the first 3 colour channels (further "
                                       "channels need SparseGradExchange.rows_hook to fold their gradient into the wire rows), no "
                                       "backgrounds")
-        if cs is not None and not (packed and Cn == 1 and dp is None and bg is None):
+        if cs is not None and not (packed and Cn == 1 and (dp is None or getattr(cs, "exchange", False)) and bg is None):
             raise NotImplementedError("rasterization(color_source=...): one camera, at most 8 blended channels, no backgrounds")
         if not packed:
             # ---- gather-based kernels (csrc/project.hip, bin.hip, blend.hip with dense attribute arrays)
@@ -1014,8 +1058,9 @@ class _FusedRasterization(torch.autograd.Function):
                     n_rows_ = max(b["cap_vis"], 1) * RS_
                     # (gsplat's sh_degree call style: the dense [N, 16, 3] coefficient gradient too -- the backward then writes the
                     #  rows of the Gaussians with a cotangent straight into it, mtgs_vis_color_bwd(dense_rows))
-                    n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and cs.n_nodes == 1
-                                         and (graph_caps is None or cs.dirs is not None) and ctx.needs_input_grad[20]) else 0
+                    n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and (cs.n_nodes == 1 or cs.dirs is not None)
+                                         and (graph_caps is None or cs.dirs is not None)
+                                         and (ctx.needs_input_grad[20] or any(ctx.needs_input_grad[22:]))) else 0
                     z_ptr, z_bytes, own_ = _prefill.take(dev, n_rows_ + n_coef_, only=getattr(_sh_scope, "reqs", ()))
                     ctx_box["rows"] = own_[:n_rows_].view(max(b["cap_vis"], 1), RS_)
                     if n_coef_:
@@ -1135,14 +1180,14 @@ class _FusedRasterization(torch.autograd.Function):
         if _debug_rows is not None:
             _debug_rows.update(G=G, vis_ids=vis_ids, DC=DC, with_depth=with_depth)
         cs = ctx.cs
-        if cs is not None:
+        if cs is not None and not getattr(cs, "exchange", False):      # (data-parallel frames: the colour gradient travels as v_rgb in the wire rows)
             # visibility-first colours: d L / d (SH coefficients) of the VISIBLE Gaussians as 192-byte rows; the optimizer takes
             # them through the row map (vis_rank: rank or -1) -- no dense [N, (T,) K, 3] gradient is written
             dense_coeffs = getattr(ctx, "zero_coeffs", None) if cs.autograd else None      # (zeroed by the forward's compositing kernel)
             ctx.zero_coeffs = None
             want_dirs = cs.autograd and cs.dirs is None      # (given directions -- MTGS's call style -- carry no gradient)
             feat = dir_rows = dir_part = None
-            if not (cs.autograd and cs.dirs is not None and not ctx.needs_input_grad[20]):      # (frozen coefficients: nothing to do)
+            if not (cs.autograd and cs.dirs is not None and not (ctx.needs_input_grad[20] or any(ctx.needs_input_grad[22:]))):      # (frozen coefficients: nothing to do)
                 feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev) if dense_coeffs is None else None
                 dir_rows = torch.empty((max(n_vis, 1), 3), dtype=torch.float32, device=dev) if want_dirs else None
                 dir_part = torch.zeros((-(-max(n_vis, 1) // 64), 3), dtype=torch.float32, device=dev) if want_dirs else None      # (MTGS_VIS_COLOR_ROWS)
@@ -1157,12 +1202,13 @@ class _FusedRasterization(torch.autograd.Function):
                 raise NotImplementedError("data-parallel rasterization: gradients on info[...] tensors")
             v_viewmats = torch.empty_like(viewmats) if ctx.needs_input_grad[5] else None
             call("mtgs_project_bwd_rows", N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height, eps2d,
-                 ptr(conics), ptr(comps), ptr(opacities), ptr(G), RS, DC, int(with_depth), ptr(col), 1, ptr(vis_ids), n_vis,
-                 ptr(ctx.dp.rows), ptr(v_viewmats), int(raw), st)
+                 ptr(conics), ptr(comps), ptr(opacities), ptr(G), RS, DC, int(with_depth),
+                 *((ptr(col), 1) if cs is None else (ptr(ctx.vis_mask), 2)),      # (the clamp's pass-through rule: from x, or from the colour kernel's bits)
+                 ptr(vis_ids), n_vis, ptr(ctx.dp.rows), ptr(v_viewmats), int(raw), st)
             if ctx.dp.rows_hook is not None:    # camera-dependent extra channels (normals): their VJP goes into the rows here
                 ctx.dp.rows_hook(G, RS, vis_ids, n_vis)
             ctx.dp.after_backward(n_vis, G, vis_ids)
-            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * 14
+            return (None, None, None, None, None, v_viewmats, None, None) + (None,) * (len(ctx.needs_input_grad) - 8)
         # gradients that reached the projection outputs directly (losses on info["means2d"] / ["depths"] / ...):
         # added to the visible rows (culled pairs have no gradient path in gsplat either)
         direct = [g for g in (g_means2d, g_conics, g_opac, g_depths, g_comps) if g is not None]
@@ -1238,6 +1284,7 @@ class _FusedRasterization(torch.autograd.Function):
              ptr(dir_rows) if (cs is not None and cs.autograd and cs.dirs is None and n_vis > 0) else None,      # (differentiable view directions: dirs = means - camera position)
              ptr(G) if raw else None, ptr(recs) if (raw and Cn == 1) else None, ptr(vm_part), st)
         d_coeffs = d_campos = None
+        d_more = (None,) * max(len(ctx.needs_input_grad) - 22, 0)
         if cs is not None and cs.autograd:
             if ctx.graph and cs.dirs is None:
                 raise NotImplementedError("graph_mode: rasterization(sh_degree=...) (dense coefficient gradient)")
@@ -1249,6 +1296,10 @@ class _FusedRasterization(torch.autograd.Function):
                 call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
             if cs.dirs is not None:
                 d_campos = None
+                if cs.n_nodes > 1 and d_coeffs is not None:      # one dense buffer in collected order: every node's gradient is its slice
+                    need_c = [ctx.needs_input_grad[20]] + list(ctx.needs_input_grad[22:])
+                    parts = [d_coeffs[s:s + n_] if nd else None for (s, n_, *_), nd in zip(cs.node_params, need_c)]
+                    d_coeffs, d_more = parts[0], tuple(parts[1:])
             elif n_vis > 0:
                 d_campos = -dir_part.sum(0)
             else:
@@ -1262,9 +1313,20 @@ class _FusedRasterization(torch.autograd.Function):
             v_bg = (v_render[..., :DC] * (1.0 - alphas)).sum(dim=(1, 2))
         if geo_rows:      # the per-visible rows ARE the geometry gradient (ColorSource.apply_to -> mtgs_node_bwd_rows -> the optimizer)
             cs.geo_ws = (vis_ws, vis_ids, totals if ctx.graph else None)
-            return (None, None, None, None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos)
+            return (None, None, None, None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos) + d_more
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
-                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos)
+                v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos) + d_more
+
+
+def _sh_inputs(sh_source):
+    """(sh_coeffs, campos, *further coefficient tensors) of _FusedRasterization from fused_rasterization's sh_source =
+    (coefficient tensor | list of them, campos | None) | None."""
+    if sh_source is None:
+        return (None, None)
+    coeffs, campos = sh_source
+    if isinstance(coeffs, (list, tuple)):
+        return (coeffs[0], campos) + tuple(coeffs[1:])
+    return (coeffs, campos)
 
 
 def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height, eps2d,
@@ -1284,7 +1346,7 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
         out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
                                         int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                         bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp,
-                                        color_source, *(sh_source or (None, None)))
+                                        color_source, *_sh_inputs(sh_source))
     finally:
         _sh_scope.reqs = ()
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,

@@ -163,6 +163,49 @@ def test_sparse_exchange_single_process(hip_lib, K, degree):
         assert torch.allclose(got, r, atol=2e-6, rtol=1e-5)
 
 
+def test_a_data_parallel_frame_evaluates_its_colours_for_the_visible_gaussians_only(hip_lib):
+    """SparseGradExchange.rasterization(sh_out=spherical_harmonics(...)): the SH output arrives still deferred (wrapper._LazySH) and
+    the frame evaluates SH + clamp for the Gaussians its camera sees only (mtgs_vis_color_fwd_dirs; the wire rows' v_rgb takes the
+    clamp's pass-through rule from that kernel's bits, mtgs_project_bwd_rows color_mode 2): the render of the dense-colour frame
+    bit for bit, its wire rows up to the order of the compositing atomics, and the same dense sums out of finish()."""
+    from mtgs_amd import dist as mdist, spherical_harmonics, wrapper
+    from mtgs_amd.synthetic import make_camera, make_scene
+    dev = torch.device("cuda")
+    N, W, H, K = 60_000, 480, 272, 16
+    sc = make_scene(N, seed=11, sh_degree=3)
+    vm, Kmat = make_camera(W, H, yaw_deg=10.0)
+    vm, Kmat = vm.to(dev), Kmat.to(dev)
+    P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+    cam_pos = torch.inverse(vm)[0, :3, 3]
+    g = torch.Generator().manual_seed(3)
+    Gc, Ga = torch.randn(1, H, W, 4, generator=g).to(dev), torch.randn(1, H, W, 1, generator=g).to(dev)
+    real = wrapper.call
+    out = {}
+    for lazy in (True, False):
+        ex = mdist.SparseGradExchange(N, K, dev)
+        calls = []
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(lazy):
+                sh = spherical_harmonics(3, P["means"].detach() - cam_pos, P["coeffs"].detach())
+                r, a, info = ex.rasterization(P["means"], P["quats"], P["scales"], P["opacities"], sh, vm, Kmat, W, H, cam_pos)
+                torch.autograd.backward([r, a], [Gc, Ga])
+        finally:
+            wrapper.call = real
+        rows = ex.rows[:ex.n_vis].clone()
+        sums = [o.clone() for o in ex.finish(P["means"], 3)]
+        out[lazy] = (r.detach().clone(), a.detach().clone(), rows, sums, calls, int(ex.n_vis))
+    (r1, a1, rows1, s1, c1, n1), (r0, a0, rows0, s0, c0, n0) = out[True], out[False]
+    assert "mtgs_vis_color_fwd_dirs" in c1 and not [n for n in c1 if n.startswith("mtgs_sh_") or n.startswith("mtgs_vis_color_bwd")], c1
+    assert "mtgs_sh_fwd" in c0 and "mtgs_vis_color_fwd_dirs" not in c0
+    assert n1 == n0 and 0 < n1 < N // 2 and torch.equal(r1, r0) and torch.equal(a1, a0)
+    assert torch.equal(rows1[:, 15].view(torch.int32), rows0[:, 15].view(torch.int32))      # the same Gaussians, in index order
+    assert torch.equal(rows1[:, :14] != 0, rows0[:, :14] != 0) and float(rows0[:, 11:14].abs().sum()) > 0
+    torch.testing.assert_close(rows1[:, :14], rows0[:, :14], rtol=1e-3, atol=1e-5 * float(rows0[:, :14].abs().max()))
+    for got, ref in zip(s1, s0):
+        torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("exchange", ["sparse", "sparse/touched", "sparse/static", "sparse/dynamic", "dense"])
 def test_bench_two_ranks_driver_launch(exchange, hip_lib):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per

@@ -198,3 +198,66 @@ def test_deferred_colours_in_one_captured_graph(hip_lib):
     for k in P:
         torch.testing.assert_close(P[k].grad, g0[k], rtol=1e-3, atol=1e-5 * float(g0[k].abs().max()))
     assert torch.equal(P["coeffs"].grad != 0, g0["coeffs"] != 0)
+
+
+def test_the_nodes_of_a_scene_graph_concatenated_stay_deferred(hip_lib):
+    """MTGS evaluates get_rgbs() per node and concatenates (mtgs_scene_graph.py:440-452: `torch.cat(value, dim=0)`, for a single node
+    too): torch.cat(dim 0) of deferred activations of one degree stays deferred, rasterization() evaluates the visible Gaussians of ALL
+    nodes in one launch (one descriptor per node) and every node's coefficient tensor receives ITS slice of the dense gradient.  Nodes
+    of different degrees (or a plain tensor among them) are evaluated in full and concatenated by PyTorch."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    N, W, H = 150_000, 512, 288
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=13)
+    cuts = [0, 70_000, 70_001, 120_000, N]          # four nodes, one of a single Gaussian
+
+    def run(mode, degrees=(3, 3, 3, 3), plain_part=False):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items() if k != "coeffs"}
+        Cs = [sc["coeffs"][a:b].to(dev).clone().requires_grad_(True) for a, b in zip(cuts[:-1], cuts[1:])]
+        calls = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(mode != "torch", raster=mode == "raster"):
+                parts = []
+                for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                    dirs = P["means"][a:b].detach() - cam
+                    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+                    rgbs = torch.clamp(spherical_harmonics(degrees[i], dirs, Cs[i]) + 0.5, 0.0, 1.0)
+                    parts.append(rgbs * 1.0 if (plain_part and i == 1) else rgbs)
+                rgb = torch.cat(parts, dim=0)
+                deferred = type(rgb).__name__ == "_LazySH"
+                render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
+                                                    render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+                ((render * Gc).sum() + (alpha * Ga).sum()).backward()
+        finally:
+            wrapper.call = real
+        return render.detach(), [c.grad.clone() for c in Cs], {k: v.grad.clone() for k, v in P.items()}, calls, deferred
+
+    r0, c0, g0, _, d0 = run("torch")
+    r1, c1, g1, calls, d1 = run("raster")
+    assert d1 and not d0 and calls.count("mtgs_vis_color_fwd_dirs") == 1 and calls.count("mtgs_vis_color_bwd_dirs") == 1
+    assert not [n for n in calls if n.startswith("mtgs_sh_")] and "mtgs_rows_expand" not in calls, calls
+    assert torch.equal(r1, r0)
+    for a, b in zip(c1, c0):
+        assert a.shape == b.shape and torch.equal(a != 0, b != 0)
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5 * float(max(b.abs().max(), 1e-20)))
+    assert sum(int((c != 0).any()) for c in c0) >= 3      # (several nodes are seen by the camera)
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-3, atol=1e-5 * float(g0[k].abs().max()))
+    # a single node, concatenated alone (what MTGS does for a scene without objects)
+    cuts_all, cuts[:] = list(cuts), [0, N]
+    try:
+        r2, c2, _, calls2, d2 = run("raster", degrees=(3,))
+        r3, c3, _, _, _ = run("torch", degrees=(3,))
+    finally:
+        cuts[:] = cuts_all
+    assert d2 and "mtgs_vis_color_fwd_dirs" in calls2 and torch.equal(r2, r3)
+    torch.testing.assert_close(c2[0], c3[0], rtol=1e-3, atol=1e-5 * float(c3[0].abs().max()))
+    # different degrees / a plain tensor among the parts: evaluated in full per node (fused kernel), concatenated by PyTorch
+    for kw in (dict(degrees=(3, 2, 3, 3)), dict(plain_part=True)):
+        r4, c4, _, calls4, d4 = run("raster", **kw)
+        r5, c5, _, _, _ = run("torch", **kw)
+        assert not d4 and "mtgs_vis_color_fwd_dirs" not in calls4 and calls4.count("mtgs_sh_fwd_act") == 4, (kw, calls4)
+        assert torch.equal(r4, r5)
+        for a, b in zip(c4, c5):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5 * float(max(b.abs().max(), 1e-20)))

@@ -262,6 +262,19 @@ def test_deferred_sh_dispatch_rules_on_cpu(monkeypatch):
         got = expr(new())      # other activations: the fused kernel at once
         assert seen == [act] and type(got) is torch.Tensor and torch.equal(got, want)
         seen.clear()
+    # torch.cat(dim 0) of deferred activations of one degree and form stays deferred; anything else concatenates ordinary tensors
+    mk = lambda deg=3: torch.clamp(wrapper._LazySH(deg, d, c, None) + 0.5, 0.0, 1.0)
+    z = torch.cat([mk(), mk()], dim=0)
+    assert not seen and type(z) is wrapper._LazySH and z.shape == (14, 3) and z.requires_grad and len(z._lz_parts) == 2
+    want = torch.clamp(ref + 0.5, 0.0, 1.0)
+    assert torch.equal(z, torch.cat([want, want])) and seen == [(True, 0.5, 0.0, 1.0)] * 2
+    seen.clear()
+    assert type(torch.cat([mk()])) is wrapper._LazySH and type(torch.concat((mk(), mk()), 0)) is wrapper._LazySH and not seen
+    for parts in ([mk(), mk(2)], [mk(), want], [mk(), torch.clamp_min(wrapper._LazySH(3, d, c, None) + 0.5, 0.0)]):
+        z = torch.cat(parts)
+        assert type(z) is torch.Tensor and z.shape == (14, 3)
+    assert type(torch.cat([mk(), mk()], dim=1)) is torch.Tensor
+    seen.clear()
     c8 = torch.randn(7, 9, 3)
     y = torch.clamp(wrapper._LazySH(2, d, c8, None) + 0.5, 0.0, 1.0)      # K != 16: at once
     assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor
