@@ -15,7 +15,7 @@ stats = {}
 for r in csv.DictReader(open(ROOT / "profiles" / f"{tag}_bench_kernel_stats.csv")):
     name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     stats[name] = float(r["AverageNs"]) / 1e3
-files = {"sh_": "sh.hip", "front_": "front.hip", "project_bwd": "project_bwd.hip", "bin3_": "bin3.hip", "blend_": "blend.hip"}
+files = {"sh_": "sh.hip", "vis_color": "viscolor.hip", "front_": "front.hip", "project_bwd": "project_bwd.hip", "bin3_": "bin3.hip", "blend_": "blend.hip"}
 rows = []
 for k in line["roofline"]["kernels"]:
     name = k["kernel"]

@@ -22,7 +22,7 @@ _ap = argparse.ArgumentParser()
 _ap.add_argument("--width", type=int, default=1920)
 _ap.add_argument("--height", type=int, default=1080)
 _ap.add_argument("--no-render-leg", action="store_true")
-_ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
+_ap.add_argument("--worlds", type=int, nargs="*", default=[2, 4, 8])
 _ap.add_argument("--pmc", action="store_true", help="counter run: per world only 3 one-pass touched reductions, then 3 sparse-write ones")
 _args = _ap.parse_args()
 dev = torch.device("cuda")
