@@ -72,6 +72,9 @@ ENTRY_POINTS = {
     "mtgs_blend_fwd_packed": ["blend_fwd_kernel<4, 2, true>"],
     "mtgs_blend_bwd_packed": ["blend_bwd_kernel<4, 4, true>"],
     "mtgs_project_bwd": ["project_bwd_vis_kernel", "project_bwd_expand_kernel"],
+    # (round 6: the dense gradients are cleared beside the compositing backward's work and the per-visible pass writes the rows with a
+    #  gradient to their places: no streaming pass; MTGS_ZEROED_OUTPUTS=0 gives the entry point above back)
+    "mtgs_project_bwd_zeroed": ["project_bwd_vis_kernel", "viewmat_reduce_kernel"],
     "mtgs_project_bwd_rows": ["project_bwd_rows_kernel"],
     "mtgs_sh_bwd": ["sh_bwd_kernel<3>"],
     "mtgs_sh_bwd_rows": ["sh_bwd_rows_kernel<3>"],
@@ -749,6 +752,12 @@ def main():
     if _cg is not None:
         n_coeff_rows = int((_cg.abs().amax(dim=(1, 2)) > 0).sum().item())
     sh_zero_bytes = args.n_gaussians * 12 * 16 if sh_zeros else 0
+    # Round 6: the DENSE gradients the rasterization returns (v_means 12 + v_quats 16 + v_scales 12 + v_opacities 4 + means2d.grad 8 +
+    # absgrad 8 [+ colours] bytes per Gaussian, ~94 % zeros) are cleared by the compositing BACKWARD beside its own work; the projection
+    # backward writes the rows with a gradient in place and its streaming pass over all N is gone (mtgs_project_bwd_zeroed)
+    dense_zeroed = bool(world == 1 and _wr._prefill.enabled and getattr(_wr, "_zeroed_outputs", False))
+    dense_zero_bytes = args.n_gaussians * (44 + 8 + 8 * A + (0 if args.variant == "mtgs" else 12)) if dense_zeroed else 0
+    bytes_bwd += dense_zero_bytes
     bytes_fwd_zeros = (sh_zero_bytes + n_vis * 64) if zeros_in_fwd else 0
     if sh_zeros and not zeros_in_fwd:
         bytes_bwd += sh_zero_bytes
@@ -772,7 +781,8 @@ def main():
         "vis_color_bwd_kernel<3>": n_vis * (4 + 12 + 12 + 1) + n_coeff_rows * 12 * Ksh_,   # id, direction, cotangent, clamp bits in; row out where there is one
         "front_project_kernel": N * (40 + 4 + 40) + n_vis * 48,                  # (+ the chunk-local compact rows of the visible pairs)
         "front_compact_kernel": N * (4 + 4) + n_vis * (48 + 12 + 64 + 4 + 8),   # radii in, vis_rank out | staged row + colours in, record + id + key out
-        "project_bwd_vis_kernel": n_vis * (40 + 16 + 4 + 64 + 48),
+        # (zeroed outputs: id + row in; parameters in, 60 bytes out where there is a gradient)
+        "project_bwd_vis_kernel": (n_vis * (40 + 16 + 4 + 64 + 48)) if not dense_zeroed else (n_vis * (4 + 64) + n_coeff_rows * (40 + 60)),
         "project_bwd_expand_kernel": N * (4 + 44 + 28) + n_vis * (4 + 48 + 28),
         "bin3_rows_count_kernel": n_vis * 64,
         "bin3_rows_place_kernel": n_vis * 64 + n_items * 8,
@@ -895,14 +905,16 @@ def main():
                      # gradient rows -- are written by a compositing kernel beside its work: which one, and how many bytes
                      "zeros_for_the_backward_pass": {"written_by": ("mtgs_blend_fwd_packed" if zeros_in_fwd else "mtgs_blend_bwd_packed") if sh_zeros else None,
                                                      "bytes": bytes_fwd_zeros if zeros_in_fwd else sh_zero_bytes,
-                                                     "sh_coefficient_rows_with_gradient": n_coeff_rows},
+                                                     "sh_coefficient_rows_with_gradient": n_coeff_rows,
+                                                     # (round 6) the dense gradients the node returns, cleared by the compositing BACKWARD
+                                                     "dense_gradient_bytes_in_mtgs_blend_bwd_packed": dense_zero_bytes},
                      # the dominant kernel priced on gsplat's intersection count M (the lists of the default call): the same
                      # unit as whole_step below and as SURVEY.md section 8(d)
                      "algorithmic_bytes_on_gsplat_lists": P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A),
                      "frac_on_gsplat_lists": round((P * (4 * D + 12) + M * (4 + 24 + 4 * D) + n_vis * (24 + 4 * D + 8 * A))
                                                    / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else 0.0,
                      "note": "avg_launch_ms: HIP events on the launch stream around every mtgs_blend_bwd_packed call of the K EAGER steps run "
-                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) [+ N*192 when zeros_for_the_backward_pass.written_by names this kernel] with n_listed = the (tile, Gaussian) pairs "
+                             "in front of the timed graph replays (events cannot be recorded into a graph); algorithmic bytes: P*(4D+12) + n_listed*(28+4D) + n_vis*(24+4D+8A) [+ N*192 when zeros_for_the_backward_pass.written_by names this kernel] [+ zeros_for_the_backward_pass.dense_gradient_bytes_in_mtgs_blend_bwd_packed] with n_listed = the (tile, Gaussian) pairs "
                              "of the timed steps' lists (config.n_listed; = gsplat's count config.n_intersections for the default call); "
                              "kernel is VALU-issue bound, not HBM bound (profiles/r06_valu_ceiling.md); avg_launch_ms is measured in this run; traffic "
                              "and the `valu` block come from the committed rocprofv3 --pmc passes named in counters_from (null when none "

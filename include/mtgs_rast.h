@@ -164,6 +164,25 @@ int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats, c
                      const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
                      const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, const float *recs, float *vm_partials,
                      void *stream);
+/* mtgs_project_bwd_zeroed (ABI v28, hot ABI v7): the compact path of mtgs_project_bwd (C == 1, vis_ids, vis_ws, grad_row_index) for
+ * dense outputs the CALLER ZEROED -- v_means, v_quats (16-byte aligned), v_scales, v_opacities, d_means2d, d_means2d_abs (8-byte
+ * aligned), d_colors: typically as one region cleared beside the compositing backward's own work (mtgs_blend_bwd_packed(also_zero):
+ * that kernel is VALU-bound, the bandwidth is idle).  The per-visible pass then writes the values of the Gaussians that HAVE a gradient
+ * straight to their places (6 % of all Gaussians at the headline scene) and the streaming pass over all N -- every byte of every dense
+ * output, 85 % of them zeros -- does not run; vis_ws is not written.  Same values as mtgs_project_bwd (a zero gradient is +0.0 here
+ * where the VJP of an all-zero row may produce -0.0).  Same parameters. */
+int mtgs_project_bwd_zeroed(int C, int64_t N, const float *means, const float *quats, const float *scales,
+                     const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                     const int32_t *radii, const float *conics, const float *compensations,
+                     const float *opacities, const float *v_means2d, const float *v_depths,
+                     const float *v_conics, const float *v_compensations, const float *v_opac_eff,
+                     float *v_means, float *v_quats, float *v_scales, float *v_viewmats,
+                     float *v_opacities, const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                     const float *x_means2d_abs, const float *x_colors, int x_channels,
+                     const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs, float *d_colors,
+                     const int32_t *vis_ids, int64_t n_vis, float *vis_ws, const int64_t *n_vis_dev,
+                     const float *x_quat_rows, const float *x_mean_rows, float *raw_rows, const float *recs, float *vm_partials,
+                     void *stream);
 /* workgroups of the compact path's per-visible pass for n_vis rows: vm_partials holds 12 floats for each */
 int mtgs_project_bwd_blocks(int64_t n_vis, int64_t *blocks);
 

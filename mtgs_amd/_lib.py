@@ -40,6 +40,9 @@ _SIGNATURES = {
     "mtgs_project_bwd": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp,
                          _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mtgs_project_bwd_zeroed": [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p, _vp,
+                                _vp, _vp, _i32, _i64p, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mtgs_project_bwd_blocks": [_i64, _i64p],
     "mtgs_isect_count": [_i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "mtgs_scan_workspace_bytes": [_i64, C.POINTER(_sz)],

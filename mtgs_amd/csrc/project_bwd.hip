@@ -305,7 +305,7 @@ constexpr int VIS_ROW = 12;  // floats per workspace row: v_mean 3 | v_quat 4 | 
 // kernel (9 -> 3 instructions per epilogue there, one fewer per slot).  o = the opacity that was blended (opacity x
 // compensation, formed as front.hip forms it).  The converted values are written back: everything behind this kernel
 // (dense by-products, densification statistics, the tests' row accounting) reads rows of the documented meaning.
-struct RowGrads { float2 v_xy; float v_conic[3]; };
+struct RowGrads { float2 v_xy; float v_conic[3]; float2 v_abs; };
 __device__ __forceinline__ RowGrads rows_to_gradients(float *__restrict__ row, const float ca, const float cb, const float cc,
                                                       const float o) {
     const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
@@ -314,10 +314,21 @@ __device__ __forceinline__ RowGrads rows_to_gradients(float *__restrict__ row, c
     g.v_xy = make_float2(no * (ca * a.x + cb * a.y), no * (cb * a.x + cc * a.y));
     g.v_conic[0] = 0.5f * no * b.x; g.v_conic[1] = no * b.y; g.v_conic[2] = 0.5f * no * b.z;
     const float ok = o * MTGS_HALF_LOG2E_INV;     // (the absgrad sums carry the factor log2(e)/2 of the staged conic, blend.hip)
-    reinterpret_cast<float4 *>(row)[0] = make_float4(g.v_xy.x, g.v_xy.y, ok * a.z, ok * a.w);
+    g.v_abs = make_float2(ok * a.z, ok * a.w);
+    reinterpret_cast<float4 *>(row)[0] = make_float4(g.v_xy.x, g.v_xy.y, g.v_abs.x, g.v_abs.y);
     reinterpret_cast<float4 *>(row)[1] = make_float4(g.v_conic[0], g.v_conic[1], g.v_conic[2], b.w);
     return g;
 }
+// ZEROED outputs (mtgs_project_bwd_zeroed): the dense gradients were cleared by the caller -- beside the compositing backward's own
+// work, mtgs_blend_bwd_packed(also_zero): that kernel is VALU-bound and leaves 88 % of the HBM bandwidth idle -- and this kernel
+// writes the values of the visible Gaussians that HAVE a gradient straight to their places (15 floats in six arrays, 6 % of the
+// Gaussians at the headline scene); the streaming pass behind it (project_bwd_expand_kernel: every byte of every dense output, 85 %
+// of them zeros) does not run.
+struct ProjSparse {
+    int on;
+    float *v_means, *v_quats, *v_scales, *v_opacities;     // v_opacities nullable
+    ProjExpand ex;                                          // dense by-products (nullable members) and their row sources
+};
 __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     int64_t n_vis, const int32_t *__restrict__ vis_ids, const float *__restrict__ means,
     const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ viewmats,
@@ -328,7 +339,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
     float *__restrict__ ws, float *__restrict__ v_viewmats, const int64_t *__restrict__ n_vis_dev,
     const float *__restrict__ x_quat_rows, const float *__restrict__ x_mean_rows, float *raw_rows, int64_t raw_stride,
     const float *__restrict__ recs /* nullable: mtgs_front_fwd's records, indexed like the rows */,
-    float *__restrict__ vm_partials /* nullable: [gridDim.x, 12] -- the blocks' viewmat sums, added up by viewmat_from_partials */) {
+    float *__restrict__ vm_partials /* nullable: [gridDim.x, 12] -- the blocks' viewmat sums, added up by viewmat_from_partials */,
+    const ProjSparse sp) {
     __shared__ float red[(PROJ_BLOCK / 64) * 12];
     __shared__ float s_acc[12];
     if (threadIdx.x < 12) s_acc[threadIdx.x] = 0.f;
@@ -359,6 +371,8 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
                 ri.v_depth = v_depths[r * gs.depths];
                 ri.v_comp = v_compensations ? v_compensations[r * gs.compensations] : 0.f;
                 ri.v_opac_eff = v_opac_eff ? v_opac_eff[r * gs.opac_eff] : 0.f;
+                float2 by_abs = make_float2(0.f, 0.f);      // (zeroed outputs: the absgrad pair of this row, from whichever form the rows have)
+                if (sp.on && sp.ex.means2d_abs && !raw_rows) by_abs = make_float2(sp.ex.abs_src[r * sp.ex.abs_stride], sp.ex.abs_src[r * sp.ex.abs_stride + 1]);
                 if (raw_rows) {
                     const float4 *row = reinterpret_cast<const float4 *>(raw_rows + r * raw_stride);
                     const float4 a4 = row[0], b4 = row[1];
@@ -378,6 +392,7 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
                         const RowGrads rg = rows_to_gradients(raw_rows + r * raw_stride, ca, cb, cc, o_eff);
                         ri.v_xy = rg.v_xy;
                         ri.v_conic[0] = rg.v_conic[0]; ri.v_conic[1] = rg.v_conic[1]; ri.v_conic[2] = rg.v_conic[2];
+                        by_abs = rg.v_abs;
                     }
                 } else {
                     const float *vcon = v_conics + r * gs.conics;
@@ -391,9 +406,24 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
                     nz = nz || xq.x != 0.f || xq.y != 0.f || xq.z != 0.f || xq.w != 0.f;
                 }
                 if (x_mean_rows) nz = nz || x_mean_rows[r * 3] != 0.f || x_mean_rows[r * 3 + 1] != 0.f || x_mean_rows[r * 3 + 2] != 0.f;
+                if (sp.on) {
+                    // the dense by-products of this row -- 2-D gradient (retain_grad), absgrad, extra colour channels --, where not zero
+                    const bool nxy = sp.ex.means2d && (ri.v_xy.x != 0.f || ri.v_xy.y != 0.f);
+                    const bool nab = sp.ex.means2d_abs && (by_abs.x != 0.f || by_abs.y != 0.f);
+                    bool ncol = false;
+                    if (sp.ex.colors)
+                        for (int k = 0; k < sp.ex.channels; ++k) ncol = ncol || sp.ex.col_src[r * sp.ex.col_stride + k] != 0.f;
+                    if (nxy || nab || ncol) {
+                        const int64_t n = vis_ids[r];
+                        if (nxy) reinterpret_cast<float2 *>(sp.ex.means2d)[n] = ri.v_xy;
+                        if (nab) reinterpret_cast<float2 *>(sp.ex.means2d_abs)[n] = by_abs;
+                        if (ncol)
+                            for (int k = 0; k < sp.ex.channels; ++k) sp.ex.colors[n * sp.ex.channels + k] = sp.ex.col_src[r * sp.ex.col_stride + k];
+                    }
+                }
                 if (nz) {
                     s_in[threadIdx.x] = ri;
-                } else {
+                } else if (!sp.on) {
                     float4 *out = reinterpret_cast<float4 *>(ws + r * VIS_ROW);
                     out[0] = out[1] = out[2] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -448,10 +478,17 @@ __global__ __launch_bounds__(PROJ_BLOCK) void project_bwd_vis_kernel(
             if (x_mean_rows) {   // ... and position gradients (gsplat's differentiable view directions of the SH colours)
                 am[0] += x_mean_rows[r * 3]; am[1] += x_mean_rows[r * 3 + 1]; am[2] += x_mean_rows[r * 3 + 2];
             }
-            float4 *out = reinterpret_cast<float4 *>(ws + r * VIS_ROW);
-            out[0] = make_float4(am[0], am[1], am[2], aq[0]);
-            out[1] = make_float4(aq[1], aq[2], aq[3], as[0]);
-            out[2] = make_float4(as[1], as[2], ao, 0.f);
+            if (sp.on) {
+                sp.v_means[n * 3] = am[0]; sp.v_means[n * 3 + 1] = am[1]; sp.v_means[n * 3 + 2] = am[2];
+                reinterpret_cast<float4 *>(sp.v_quats)[n] = make_float4(aq[0], aq[1], aq[2], aq[3]);
+                sp.v_scales[n * 3] = as[0]; sp.v_scales[n * 3 + 1] = as[1]; sp.v_scales[n * 3 + 2] = as[2];
+                if (sp.v_opacities) sp.v_opacities[n] = ao;
+            } else {
+                float4 *out = reinterpret_cast<float4 *>(ws + r * VIS_ROW);
+                out[0] = make_float4(am[0], am[1], am[2], aq[0]);
+                out[1] = make_float4(aq[1], aq[2], aq[3], as[0]);
+                out[2] = make_float4(as[1], as[2], ao, 0.f);
+            }
         }
         if (count == 0) continue;      // (uniform over the block)
         if (v_viewmats) {
@@ -494,9 +531,34 @@ __device__ __forceinline__ void viewmat_from_partials(const float *__restrict__ 
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(PROJ_BLOCK) void viewmat_reduce_kernel(const float *__restrict__ partials, int n_blocks, float *__restrict__ v_viewmats) {
-    __shared__ float lds[192];
-    viewmat_from_partials(partials, n_blocks, v_viewmats, lds);
+// The same sum as a kernel of its own (no streaming pass behind the per-visible pass: rows only, zeroed outputs): ONE workgroup of 1024
+// threads -- 12 components x 85 slices, ~14 independent loads per thread, then the slices from LDS.  (The 16-slice form above inside a
+// 256-thread launch measured 19 us for 1180 blocks: 74 dependent global loads per thread.)  A fixed order: deterministic.
+constexpr int VM_SLICES = 85;
+__global__ __launch_bounds__(1024) void viewmat_reduce_kernel(const float *__restrict__ partials, int n_blocks, float *__restrict__ v_viewmats) {
+    __shared__ float lds[VM_SLICES * 12];
+    const int t = threadIdx.x;
+    if (t < VM_SLICES * 12) {
+        const int k = t % 12, j = t / 12;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int b = j;
+        for (; b + 3 * VM_SLICES < n_blocks; b += 4 * VM_SLICES) {
+            v0 += partials[b * 12 + k]; v1 += partials[(b + VM_SLICES) * 12 + k];
+            v2 += partials[(b + 2 * VM_SLICES) * 12 + k]; v3 += partials[(b + 3 * VM_SLICES) * 12 + k];
+        }
+        for (; b < n_blocks; b += VM_SLICES) v0 += partials[b * 12 + k];
+        lds[t] = (v0 + v1) + (v2 + v3);
+    }
+    __syncthreads();
+    if (t < 16) {
+        float v = 0.f;
+        const int i = t >> 2, jj = t & 3;
+        if (i < 3) {
+            const int k = jj < 3 ? i * 3 + jj : 9 + i;
+            for (int j = 0; j < VM_SLICES; ++j) v += lds[j * 12 + k];
+        }
+        v_viewmats[t] = v;
+    }
 }
 
 // ---- wire rows (view-parallel data parallelism, mtgs_amd.dist / csrc/dp.hip) ----------------------------------------
@@ -708,6 +770,20 @@ extern "C" int mtgs_project_bwd_blocks(int64_t n_vis, int64_t *blocks) {
     return MTGS_OK;
 }
 
+static int project_bwd_impl(int C, int64_t N, const float *means, const float *quats,
+                                const float *scales, const float *viewmats, const float *Ks,
+                                int width, int height, float eps2d, const int32_t *radii,
+                                const float *conics, const float *compensations, const float *opacities,
+                                const float *v_means2d, const float *v_depths, const float *v_conics,
+                                const float *v_compensations, const float *v_opac_eff, float *v_means,
+                                float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities,
+                                const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                                const float *x_means2d_abs, const float *x_colors, int x_channels,
+                                const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
+                                float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
+                                const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
+                                const float *recs, float *vm_partials, void *stream, bool zeroed);
+
 extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const float *quats,
                                 const float *scales, const float *viewmats, const float *Ks,
                                 int width, int height, float eps2d, const int32_t *radii,
@@ -721,6 +797,50 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
                                 float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
                                 const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
                                 const float *recs, float *vm_partials, void *stream) {
+    return project_bwd_impl(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics, compensations, opacities,
+                            v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, v_means, v_quats, v_scales, v_viewmats,
+                            v_opacities, grad_row_strides, grad_row_index, x_means2d_abs, x_colors, x_channels, x_row_strides, d_means2d,
+                            d_means2d_abs, d_colors, vis_ids, n_vis, vis_ws, n_vis_dev, x_quat_rows, x_mean_rows, raw_rows, recs,
+                            vm_partials, stream, false);
+}
+
+extern "C" int mtgs_project_bwd_zeroed(int C, int64_t N, const float *means, const float *quats,
+                                       const float *scales, const float *viewmats, const float *Ks,
+                                       int width, int height, float eps2d, const int32_t *radii,
+                                       const float *conics, const float *compensations, const float *opacities,
+                                       const float *v_means2d, const float *v_depths, const float *v_conics,
+                                       const float *v_compensations, const float *v_opac_eff, float *v_means,
+                                       float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities,
+                                       const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                                       const float *x_means2d_abs, const float *x_colors, int x_channels,
+                                       const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
+                                       float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
+                                       const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
+                                       const float *recs, float *vm_partials, void *stream) {
+    MTGS_REQUIRE(C == 1 && vis_ids && vis_ws && grad_row_index && v_means && v_quats && v_scales,
+                 MTGS_EINVAL, "mtgs_project_bwd_zeroed: the compact path (C == 1, vis_ids, grad_row_index) with dense outputs");
+    MTGS_REQUIRE((reinterpret_cast<uintptr_t>(v_quats) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_means2d) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(d_means2d_abs) & 7) == 0, MTGS_EINVAL, "mtgs_project_bwd_zeroed: v_quats 16-byte, d_means2d(_abs) 8-byte aligned");
+    return project_bwd_impl(C, N, means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics, compensations, opacities,
+                            v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, v_means, v_quats, v_scales, v_viewmats,
+                            v_opacities, grad_row_strides, grad_row_index, x_means2d_abs, x_colors, x_channels, x_row_strides, d_means2d,
+                            d_means2d_abs, d_colors, vis_ids, n_vis, vis_ws, n_vis_dev, x_quat_rows, x_mean_rows, raw_rows, recs,
+                            vm_partials, stream, true);
+}
+
+static int project_bwd_impl(int C, int64_t N, const float *means, const float *quats,
+                                const float *scales, const float *viewmats, const float *Ks,
+                                int width, int height, float eps2d, const int32_t *radii,
+                                const float *conics, const float *compensations, const float *opacities,
+                                const float *v_means2d, const float *v_depths, const float *v_conics,
+                                const float *v_compensations, const float *v_opac_eff, float *v_means,
+                                float *v_quats, float *v_scales, float *v_viewmats, float *v_opacities,
+                                const int64_t *grad_row_strides, const int32_t *grad_row_index,
+                                const float *x_means2d_abs, const float *x_colors, int x_channels,
+                                const int64_t *x_row_strides, float *d_means2d, float *d_means2d_abs,
+                                float *d_colors, const int32_t *vis_ids, int64_t n_vis, float *vis_ws,
+                                const int64_t *n_vis_dev, const float *x_quat_rows, const float *x_mean_rows, float *raw_rows,
+                                const float *recs, float *vm_partials, void *stream, bool zeroed) {
     MTGS_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, MTGS_EINVAL,
                  "mtgs_project_bwd: bad sizes C=%d N=%lld W=%d H=%d", C, (long long)N, width, height);
     hipStream_t st = (hipStream_t)stream;
@@ -770,13 +890,18 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
         // compact path: grad_row_index[vis_ids[r]] == r (mtgs_bin_compact's vis_ids / vis_rank)
         MTGS_REQUIRE(n_vis >= 0 && n_vis <= N, MTGS_EINVAL, "mtgs_project_bwd: n_vis=%lld", (long long)n_vis);
         if (n_vis > 0) {
+            ProjSparse sp;
+            sp.on = zeroed ? 1 : 0;
+            sp.v_means = v_means; sp.v_quats = v_quats; sp.v_scales = v_scales; sp.v_opacities = v_opacities; sp.ex = ex;
             project_bwd_vis_kernel<<<(unsigned)vis_blocks(n_vis), PROJ_BLOCK, 0, st>>>(
                 n_vis, vis_ids, means, quats, scales, viewmats, Ks, width, height, eps2d, conics, compensations, opacities,
                 v_means2d, v_depths, v_conics, v_compensations, v_opac_eff, gs, vis_ws, v_viewmats, n_vis_dev, x_quat_rows, x_mean_rows,
-                raw_rows, rs[0], recs, partial_sums ? vm_partials : nullptr);
+                raw_rows, rs[0], recs, partial_sums ? vm_partials : nullptr, sp);
         }
         const int vm_blocks = (int)vis_blocks(n_vis);
-        if (!rows_only) {
+        if (zeroed) {      // no streaming pass: the outputs were zeroed by the caller, the rows with a gradient are in place
+            if (partial_sums) viewmat_reduce_kernel<<<1, 1024, 0, st>>>(vm_partials, vm_blocks, v_viewmats);
+        } else if (!rows_only) {
             const unsigned eg = (unsigned)ceil_div64(N, PROJ_BLOCK);
             const float *vp = partial_sums ? vm_partials : nullptr;
 #define MTGS_EXPAND(SC) project_bwd_expand_kernel<SC><<<eg, PROJ_BLOCK, 0, st>>>(N, n_vis, radii, grad_row_index, vis_ws, v_means2d, gs.means2d, \
@@ -786,7 +911,7 @@ extern "C" int mtgs_project_bwd(int C, int64_t N, const float *means, const floa
             else MTGS_EXPAND(EXP_STAGE_COL);
 #undef MTGS_EXPAND
         }
-        else if (partial_sums) viewmat_reduce_kernel<<<1, PROJ_BLOCK, 0, st>>>(vm_partials, vm_blocks, v_viewmats);
+        else if (partial_sums) viewmat_reduce_kernel<<<1, 1024, 0, st>>>(vm_partials, vm_blocks, v_viewmats);
         MTGS_CHECK_LAUNCH("mtgs_project_bwd");
         return MTGS_OK;
     }

@@ -1155,6 +1155,7 @@ class _FusedRasterization(torch.autograd.Function):
         r_xy, r_abs, r_con, r_opa = G[:, 0:2], G[:, 2:4], G[:, 4:7], G[:, 7]
         r_col = G[:, 8:8 + DC] if DC else None
         r_dep = G[:, 8 + DC] if with_depth else None
+        zeroed_out = None
         if v_render is not None or v_alphas is not None:
             if v_render is None:
                 v_render = torch.zeros((Cn, height, width, DT), dtype=torch.float32, device=dev)
@@ -1164,7 +1165,15 @@ class _FusedRasterization(torch.autograd.Function):
             if ctx.packed:
                 if rank_ids.numel() > 0:
                     # (the zeros the spherical_harmonics() backwards of this pass want are written by this kernel: _Prefill)
-                    z_ptr, z_bytes, _ = _prefill.take(dev, only=[r for r in (w() for w in getattr(ctx, "sh_reqs", ())) if r is not None])
+                    # ... and the DENSE gradients this node returns (v_means, v_quats, v_scales, v_opacities, means2d.grad, .absgrad,
+                    # extra colour channels: zeros for the ~94 % of the Gaussians without a gradient): the compositing backward is
+                    # VALU-bound and clears them beside its own work, the projection backward then writes the rows that have a gradient
+                    # to their places and its streaming pass over all N does not run (mtgs_project_bwd_zeroed)
+                    zplan = _zeroed_outputs_plan(ctx, Cn, N, n_vis, DC, g_means2d, g_depths, g_conics, g_comps, g_opac)
+                    z_ptr, z_bytes, z_own = _prefill.take(dev, 0 if zplan is None else zplan["floats"],
+                                                          only=[r for r in (w() for w in getattr(ctx, "sh_reqs", ())) if r is not None])
+                    if zplan is not None:
+                        zeroed_out = {k: z_own[o:o + n_].view(shape) for k, (o, n_, shape) in zplan["views"].items()}
                     call("mtgs_blend_bwd_packed", Cn, DC, int(with_depth), ptr(recs), ptr(bg), int(ed), width, height, tw, th,
                          ptr(offsets), ptr(rank_ids), ptr(alphas), ptr(last_ids), ptr(render), ptr(v_render), ptr(v_alphas),
                          ptr(G), RS, int(ctx.absgrad), ptr(order), z_ptr, z_bytes, st)
@@ -1245,10 +1254,13 @@ class _FusedRasterization(torch.autograd.Function):
         geo_rows = bool(cs is not None and getattr(cs, "geometry_rows", False) and not direct and n_vis > 0)
         if geo_rows and (any(g[4] for g in cs.node_geometry) or cs.autograd):
             raise NotImplementedError("ColorSource.geometry_rows: static nodes only (a rigid node's pose gradient is a sum over its Gaussians)")
-        v_means = None if geo_rows else torch.empty_like(means)
-        v_quats = None if geo_rows else torch.empty_like(quats)
-        v_scales = None if geo_rows else torch.empty_like(scales)
-        v_opacities = None if geo_rows else torch.empty_like(opacities)
+        if zeroed_out is not None and (geo_rows or direct or not raw):
+            zeroed_out = None      # (cannot happen: _zeroed_outputs_plan tests the same conditions)
+        Z = zeroed_out or {}
+        v_means = None if geo_rows else Z.get("means", None) if Z else torch.empty_like(means)
+        v_quats = None if geo_rows else Z.get("quats", None) if Z else torch.empty_like(quats)
+        v_scales = None if geo_rows else Z.get("scales", None) if Z else torch.empty_like(scales)
+        v_opacities = None if geo_rows else Z.get("opacities", None) if Z else torch.empty_like(opacities)
         v_viewmats = torch.empty_like(viewmats) if need[5] else None
         m2d_out = ctx.means2d_ref() if getattr(ctx, "means2d_ref", None) is not None else None
         want_m2d = m2d_out is not None and m2d_out.retains_grad
@@ -1257,15 +1269,15 @@ class _FusedRasterization(torch.autograd.Function):
             raise NotImplementedError("ColorSource.geometry_rows needs want_grad_rows (no dense by-products of the projection backward)")
         if rows_only:   # the caller takes the 2-D gradients from the compact rows (densify.update_statistics_rows): no dense absgrad
             cs.grad_rows, cs.grad_row_ids, cs.grad_row_count = G, vis_ids, (totals if ctx.graph else None)
-        d_m2d = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if want_m2d else None
-        d_abs = torch.empty((Cn, N, 2), dtype=torch.float32, device=dev) if (ctx.absgrad and m2d_out is not None and not rows_only) else None
+        d_m2d = (Z["m2d"] if Z else torch.empty((Cn, N, 2), dtype=torch.float32, device=dev)) if want_m2d else None
+        d_abs = (Z["abs"] if Z else torch.empty((Cn, N, 2), dtype=torch.float32, device=dev)) if (ctx.absgrad and m2d_out is not None and not rows_only) else None
         c0 = 0 if cs is None else (6 if ctx.n2c is not None else 3)   # (the dense colour gradient covers the other channels only)
         q_rows = None
         if cs is not None and ctx.n2c is not None:   # the normals' gradient: quaternion rows of the visible Gaussians
             q_rows = torch.empty((max(n_vis, 1), 4), dtype=torch.float32, device=dev)
             call("mtgs_normals_bwd_qrows", n_vis, ptr(vis_ids), ptr(totals) if ctx.graph else None, ptr(quats), ptr(scales), ptr(means),
                  ptr(ctx.n2c), ptr(G), RS, 8 + 3, ptr(q_rows), st)
-        d_col = torch.empty((Cn, N, DC - c0), dtype=torch.float32, device=dev) if (DC - c0 and need[4]) else None
+        d_col = (Z["col"] if Z else torch.empty((Cn, N, DC - c0), dtype=torch.float32, device=dev)) if (DC - c0 and need[4]) else None
         if geo_rows and (d_col is not None or want_m2d):
             raise NotImplementedError("ColorSource.geometry_rows: no extra colour channels with a gradient, no retain_grad() on means2d")
         vis_ws = torch.empty((max(n_vis, 1), 12), dtype=torch.float32, device=dev)  # scratch of the compact VJP
@@ -1274,7 +1286,7 @@ class _FusedRasterization(torch.autograd.Function):
             nb = C.c_int64(0)
             call("mtgs_project_bwd_blocks", n_vis, C.byref(nb))
             vm_part = torch.empty(nb.value * 12, dtype=torch.float32, device=dev)
-        call("mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
+        call("mtgs_project_bwd_zeroed" if Z else "mtgs_project_bwd", Cn, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height,
              eps2d, ptr(radii), ptr(conics), ptr(comps), ptr(opacities), ptr(r_xy), ptr(r_dep_total), ptr(r_con),
              ptr(r_cmp), ptr(r_opa), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_viewmats), ptr(v_opacities),
              host_i64([RS, r_dep_total.stride(0), RS, 1, RS]), ptr(vis_rank), ptr(r_abs),
@@ -1316,6 +1328,40 @@ class _FusedRasterization(torch.autograd.Function):
             return (None, None, None, None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos) + d_more
         return (v_means if need[0] else None, v_quats if need[1] else None, v_scales if need[2] else None,
                 v_opacities if need[3] else None, d_col, v_viewmats, None, v_bg) + (None,) * 12 + (d_coeffs, d_campos) + d_more
+
+
+def _zeroed_outputs_plan(ctx, Cn, N, n_vis, DC, g_means2d, g_depths, g_conics, g_comps, g_opac):
+    """Layout of the dense gradients of a _FusedRasterization backward inside ONE region that its compositing backward clears
+    (see the call site), or None when this backward does not take that form: {"floats": total, "views": {name: (offset, count, shape)}},
+    every view 16-byte aligned.  Mirrors the decisions the backward takes further down (which by-products it returns)."""
+    if not (_prefill.enabled and _zeroed_outputs and ctx.packed and Cn == 1 and ctx.dp is None and n_vis > 0 and N > 0):
+        return None
+    if any(g is not None for g in (g_means2d, g_depths, g_conics, g_comps, g_opac)):      # (a loss on info[...]: the generic path)
+        return None
+    cs = ctx.cs
+    if cs is not None and getattr(cs, "geometry_rows", False):
+        return None
+    m2d_out = ctx.means2d_ref() if getattr(ctx, "means2d_ref", None) is not None else None
+    want_m2d = m2d_out is not None and m2d_out.retains_grad
+    rows_only = cs is not None and getattr(cs, "want_grad_rows", False)
+    want_abs = bool(ctx.absgrad and m2d_out is not None and not rows_only)
+    c0 = 0 if cs is None else (6 if ctx.n2c is not None else 3)
+    want_col = bool(DC - c0 and ctx.needs_input_grad[4])
+    items = [("means", N * 3, (N, 3)), ("quats", N * 4, (N, 4)), ("scales", N * 3, (N, 3)), ("opacities", N, (N,))]
+    if want_m2d:
+        items.append(("m2d", N * 2, (1, N, 2)))
+    if want_abs:
+        items.append(("abs", N * 2, (1, N, 2)))
+    if want_col:
+        items.append(("col", N * (DC - c0), (1, N, DC - c0)))
+    views, at = {}, 0
+    for name, n_, shape in items:
+        views[name] = (at, n_, shape)
+        at += -(-n_ // 4) * 4
+    return {"floats": at, "views": views}
+
+
+_zeroed_outputs = os.environ.get("MTGS_ZEROED_OUTPUTS", "1") == "1"      # (development switch: 0 = the streaming expansion pass of rounds 1-5)
 
 
 def _sh_inputs(sh_source):

@@ -34,10 +34,10 @@ vm, K = vm.to(dev).requires_grad_(True), K.to(dev)
 g = torch.Generator().manual_seed(1)
 D = (3 if args.sh else P["colors"].shape[-1]) + 1
 Gc, Ga = torch.randn(1, args.height, args.width, D, generator=g).to(dev), torch.randn(1, args.height, args.width, 1, generator=g).to(dev)
-names = ["mtgs_front_fwd", "mtgs_bin3_build", "mtgs_blend_fwd_packed", "mtgs_blend_bwd_packed", "mtgs_project_bwd"]
+names = ["mtgs_front_fwd", "mtgs_bin3_build", "mtgs_blend_fwd_packed", "mtgs_blend_bwd_packed", "mtgs_project_bwd", "mtgs_project_bwd_zeroed"]
 if args.sh:
     names[1:1] = ["mtgs_vis_color_fwd_dirs"]
-    names[-1:-1] = ["mtgs_vis_color_bwd_dirs"]
+    names[-2:-2] = ["mtgs_vis_color_bwd_dirs"]
     cam = torch.inverse(vm.detach())[0, :3, 3]
     dirs = (P["means"].detach().to(dev) - cam).contiguous()
 
@@ -63,6 +63,6 @@ torch.cuda.synchronize()
 ms = _lib.timed_ms()
 print(f"lib={args.lib or 'in-tree'} N={args.n} {args.width}x{args.height} D={D} n_vis={int((info['radii'] > 0).sum())} M={info['flatten_ids'].numel()}")
 for n in names:
-    v = sorted(ms.get(n, [0.0]))
+    v = sorted(ms.get(n) or [0.0])
     print(f"  {n:26s} median {v[len(v) // 2] * 1e3:8.1f} us   min {v[0] * 1e3:8.1f} us")
 print(f"  whole step (raster only)   {t0.elapsed_time(t1) / args.reps * 1e3:8.1f} us")
