@@ -202,7 +202,11 @@ def test_served_by_the_forward_or_by_the_backward_and_backward_twice(hip_lib, in
     fwd_zero = [a[-2] for n, a in calls if n == "mtgs_blend_fwd_packed"]
     bwd_zero = [a[-2] for n, a in calls if n == "mtgs_blend_bwd_packed"]
     n_coeff_bytes = P["coeffs"].numel() * 4
-    assert (fwd_zero[0] >= n_coeff_bytes and bwd_zero == [0, 0]) if in_forward else (fwd_zero == [0] and bwd_zero[0] == n_coeff_bytes and bwd_zero[1] == 0), (fwd_zero, bwd_zero)
+    # (the compositing backward also clears the DENSE gradients this node returns -- tests/test_gpu_zeroed_outputs.py --: D bytes in
+    #  both backwards; the SH request's bytes come on top of them in the first one when the forward did not serve it)
+    D = bwd_zero[1]
+    assert 0 < D < n_coeff_bytes, (fwd_zero, bwd_zero)
+    assert (fwd_zero[0] >= n_coeff_bytes and bwd_zero == [D, D]) if in_forward else (fwd_zero == [0] and bwd_zero[0] == n_coeff_bytes + D), (fwd_zero, bwd_zero)
     names = [n for n, _ in calls]
     assert names.count("mtgs_sh_bwd_rows") == 1 and names.count("mtgs_sh_bwd") == 1      # (second backward: the dense kernel)
     for got in (first, second):

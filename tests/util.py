@@ -399,7 +399,10 @@ def same_refinements(x, y, count, later=None, first=1e-4):
         tol = [max(2, int(q * first)) if not (diverged and later) else max(2, int(q * later)) for q in b]
         if any(abs(p - q) > t for p, q, t in zip(a, b, tol)):
             return False
-        diverged = diverged or a != b
+        # (equal sizes are not identical sets: a refinement that split / culled thousands may have picked a few other Gaussians in the
+        #  two runs and still arrive at the same N -- observed: 82186 = 82186, then 94417 vs 94373.  With `later` given, everything
+        #  behind the first refinement is compared to it)
+        diverged = diverged or a != b or later is not None
     return True
 
 
