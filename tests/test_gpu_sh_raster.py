@@ -261,3 +261,62 @@ def test_the_nodes_of_a_scene_graph_concatenated_stay_deferred(hip_lib):
         assert torch.equal(r4, r5)
         for a, b in zip(c4, c5):
             torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5 * float(max(b.abs().max(), 1e-20)))
+
+
+def test_concatenated_nodes_with_a_frozen_node_and_in_inference(hip_lib):
+    """One node's coefficients frozen (requires_grad False: MTGS freezes nodes it does not optimise): that node gets no gradient, the
+    others theirs; the whole concatenation without grad mode renders the same image."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    N, W, H = 90_000, 400, 240
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=19)
+    cuts = [0, 30_000, 65_000, N]
+
+    def run(mode, frozen=1, no_grad=False):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items() if k != "coeffs"}
+        Cs = [sc["coeffs"][a:b].to(dev).clone().requires_grad_(i != frozen) for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+        calls = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(mode != "torch", raster=mode == "raster"), (torch.no_grad() if no_grad else torch.enable_grad()):
+                rgb = torch.cat([torch.clamp(spherical_harmonics(3, P["means"][a:b].detach() - cam, Cs[i]) + 0.5, 0.0, 1.0)
+                                 for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))], dim=0)
+                render, alpha, _ = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
+                                                 render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+                if not no_grad:
+                    ((render * Gc).sum() + (alpha * Ga).sum()).backward()
+        finally:
+            wrapper.call = real
+        return render.detach(), [c.grad for c in Cs], P["means"].grad, calls
+
+    r1, c1, m1, calls = run("raster")
+    r0, c0, m0, _ = run("torch")
+    assert "mtgs_vis_color_fwd_dirs" in calls and torch.equal(r1, r0)
+    assert c1[1] is None and c0[1] is None
+    for i in (0, 2):
+        assert torch.equal(c1[i] != 0, c0[i] != 0) and float(c0[i].abs().sum()) > 0
+        torch.testing.assert_close(c1[i], c0[i], rtol=1e-3, atol=1e-5 * float(c0[i].abs().max()))
+    torch.testing.assert_close(m1, m0, rtol=1e-3, atol=1e-5 * float(m0.abs().max()))
+    r2, _, _, calls2 = run("raster", no_grad=True)
+    assert torch.equal(r2, r0) and "mtgs_vis_color_fwd_dirs" in calls2 and not r2.requires_grad
+    # every node frozen, the geometry trains: no colour backward at all
+    r3, c3, m3, calls3 = run("raster", frozen=None)      # (reference run with all nodes training, for the geometry gradient)
+
+    def run_all_frozen():
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items() if k != "coeffs"}
+        calls_ = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls_.append(name), real(name, *a))[1]
+            rgb = torch.cat([torch.clamp(spherical_harmonics(3, P["means"][a:b].detach() - cam, sc["coeffs"][a:b].to(dev)) + 0.5, 0.0, 1.0)
+                             for a, b in zip(cuts[:-1], cuts[1:])], dim=0)
+            render, alpha, _ = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
+                                             render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+            ((render * Gc).sum() + (alpha * Ga).sum()).backward()
+        finally:
+            wrapper.call = real
+        return render.detach(), P["means"].grad, calls_
+
+    r4, m4, calls4 = run_all_frozen()
+    assert torch.equal(r4, r0) and "mtgs_vis_color_fwd_dirs" in calls4 and "mtgs_vis_color_bwd_dirs" not in calls4
+    torch.testing.assert_close(m4, m3, rtol=1e-3, atol=1e-5 * float(m3.abs().max()))
