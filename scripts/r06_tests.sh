@@ -1,7 +1,8 @@
 #!/bin/bash
+# Round 6: the whole -m gpu suite (writes gpurun_out/parity_report.json) + the smoke entry
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r06_tests
-rm -rf $OUT && mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py -x -q -m gpu > $OUT/pytest.txt 2>&1
-tail -8 $OUT/pytest.txt
-python scripts/dp_cost.py --no-render-leg > $OUT/dp_cost.txt 2>&1; grep "touched" $OUT/dp_cost.txt
+mkdir -p gpurun_out/r06_tests
+timeout 1700 python -m pytest tests -m gpu -q > gpurun_out/r06_tests/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/r06_tests/pytest_gpu.log
+tail -4 gpurun_out/r06_tests/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
