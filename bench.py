@@ -450,6 +450,28 @@ def shipped_cells(args, dev):
             return round((time.perf_counter() - t0) / reps * 1e3, 3)
 
         res[key] = timed(fb)
+        if (W, H) == (args.width, args.height) and "coeffs" in dev:
+            # ... and config/MTGS.py's own composition of those seven channels: rgbs = clamp(spherical_harmonics(...) + 0.5, 0, 1),
+            # torch.cat([rgbs, normals], dim=-1) (mtgs_scene_graph.py:636-638) -- the colours stay deferred through the clamp AND the
+            # concatenation and are evaluated for the visible Gaussians by the rasterization; beside it, SH + clamp over all N
+            import mtgs_amd
+            from mtgs_amd import spherical_harmonics
+            coeffs = dev["coeffs"].detach().clone().requires_grad_(True)
+            cam = torch.inverse(vm.detach())[0, :3, 3]
+            normals = P["colors"].detach()[:, 3:].clone().requires_grad_(True)
+
+            def fb_sh():
+                for q in list(P.values()) + [vm, coeffs, normals]:
+                    q.grad = None
+                rgbs = torch.clamp(spherical_harmonics(3, P["means"].detach() - cam, coeffs) + 0.5, 0.0, 1.0)
+                r, a, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], torch.cat([rgbs, normals], dim=-1), vm, K, W, H,
+                                           packed=False, render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+                info["means2d"].retain_grad()
+                torch.autograd.backward([r, a], [Gc, Ga])
+
+            res[f"mtgs_py_sh_plus_normals_{W}x{H}_ms"] = timed(fb_sh)
+            with mtgs_amd.sh_lazy(True, raster=False):
+                res[f"mtgs_py_sh_plus_normals_{W}x{H}_sh_over_all_gaussians_ms"] = timed(fb_sh)
         if (W, H) == (960, 540):
             with torch.no_grad():
                 res["fwd_only_7ch_960x540_ms"] = timed(lambda: fb(False))

@@ -119,14 +119,16 @@ def rasterization(
     if type(colors) is _LazySH:
         src = None
         if (color_source is None and sh_degree is None and C == 1 and backgrounds is None and colors.dim() == 2
-                and render_mode in ["RGB", "RGB+D", "RGB+ED"] and (3 + int(render_mode != "RGB")) in SUPPORTED_CHANNELS):
+                and render_mode in ["RGB", "RGB+D", "RGB+ED"] and (colors.shape[1] + int(render_mode != "RGB")) in SUPPORTED_CHANNELS
+                and colors.shape[1] + int(render_mode != "RGB") <= 8):
             src = colors.raster_source(N, width, height)
         if src is None:
             colors = colors._materialize()
         else:
             with_depth = render_mode != "RGB"
+            extra = src[2].unsqueeze(0) if len(src) > 2 else None      # (channels behind the colours -- MTGS's normals --, as they are)
             render_colors, render_alphas, m = fused_rasterization(
-                means, quats, scales, opacities, None, viewmats, Ks, None, width, height, eps2d, near_plane, far_plane, radius_clip,
+                means, quats, scales, opacities, extra, viewmats, Ks, None, width, height, eps2d, near_plane, far_plane, radius_clip,
                 rasterize_mode == "antialiased", with_depth, render_mode == "RGB+ED", absgrad, color_source=src[0],
                 sh_source=(src[1], None))
             meta.update({"camera_ids": None, "gaussian_ids": None, "radii": m["radii"], "means2d": m["means2d"], "depths": m["depths"],

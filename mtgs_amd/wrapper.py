@@ -251,7 +251,7 @@ class _LazySH(Tensor):
         rg = torch.is_grad_enabled() and (coeffs.requires_grad or dirs.requires_grad)
         r = Tensor._make_wrapper_subclass(cls, dirs.shape, dtype=torch.float32, device=dirs.device, requires_grad=rg)
         r._lz_sh = (degree, dirs, coeffs, masks)
-        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts = base, add, act, None, None
+        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts, r._lz_extra = base, add, act, None, None, None
         return r
 
     @classmethod
@@ -260,21 +260,46 @@ class _LazySH(Tensor):
         rasterization() could take over (then every part is evaluated by the fused kernel and PyTorch concatenates)."""
         first = parts[0]
         for q in parts:
-            if not (type(q) is cls and q._lz_act is not None and q._lz_parts is None and q._lz_plain is None and q._lz_act == first._lz_act
+            if not (type(q) is cls and q._lz_act is not None and q._lz_parts is None and q._lz_extra is None and q._lz_plain is None
+                    and q._lz_act == first._lz_act
                     and q._lz_sh[0] == first._lz_sh[0] and q.device == first.device):
                 return None
         n = sum(int(q.shape[0]) for q in parts)
         r = Tensor._make_wrapper_subclass(cls, (n, 3), dtype=torch.float32, device=first.device,
                                           requires_grad=any(q.requires_grad for q in parts))
         r._lz_sh = (first._lz_sh[0], None, None, None)
-        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts = None, None, first._lz_act, None, list(parts)
+        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts, r._lz_extra = None, None, first._lz_act, None, list(parts), None
+        return r
+
+    @classmethod
+    def _with_extra(cls, inner, extras):
+        """torch.cat([deferred colours, further channels ...], dim=-1) -- MTGS's `predict_normals` appends three camera-space normal
+        channels behind the colours (mtgs_scene_graph.py:636-638) --, still deferred: rasterization() evaluates the colours for the
+        visible Gaussians and takes the further channels as they are; or None (then the colours are evaluated in full and PyTorch
+        concatenates)."""
+        n = int(inner.shape[0])
+        if not (type(inner) is cls and inner._lz_act is not None and inner._lz_plain is None and inner._lz_extra is None and extras):
+            return None
+        for e in extras:
+            if not (type(e) in (Tensor, torch.nn.Parameter) and e.dim() == 2 and e.shape[0] == n and e.dtype == torch.float32
+                    and e.device == inner.device and e.shape[1] >= 1):
+                return None
+        if 3 + sum(int(e.shape[1]) for e in extras) > RECORD_CHANNELS:      # (what a record holds; with a depth channel one fewer: rendering.py)
+            return None
+        extra = extras[0] if len(extras) == 1 else torch.cat(list(extras), dim=-1)
+        r = Tensor._make_wrapper_subclass(cls, (n, 3 + int(extra.shape[1])), dtype=torch.float32, device=inner.device,
+                                          requires_grad=bool(inner.requires_grad or (torch.is_grad_enabled() and extra.requires_grad)))
+        r._lz_sh = inner._lz_sh
+        r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts, r._lz_extra = inner, None, inner._lz_act, None, None, extra
         return r
 
     def _materialize(self) -> Tensor:
         """The ordinary tensor this object stands for (computed once)."""
         if self._lz_plain is None:
             with torch._C.DisableTorchFunctionSubclass():
-                if self._lz_parts is not None:
+                if self._lz_extra is not None:
+                    self._lz_plain = torch.cat([self._lz_base._materialize(), self._lz_extra], dim=-1)
+                elif self._lz_parts is not None:
                     self._lz_plain = torch.cat([q._materialize() for q in self._lz_parts], dim=0)
                 elif self._lz_act is not None:
                     self._lz_plain = self._lz_base._fused(*self._lz_act)
@@ -311,6 +336,9 @@ class _LazySH(Tensor):
         backward (rows of the Gaussians with a cotangent, written into zeros that rode on the compositing forward) -- else None."""
         if self._lz_act is None or self._lz_plain is not None:
             return None
+        if self._lz_extra is not None:      # colours + further channels: (source, coefficients, the further channels [N, DX])
+            inner = self._lz_base.raster_source(n, width, height) if tuple(self.shape) == (n, 3 + self._lz_extra.shape[1]) else None
+            return None if inner is None else (inner[0], inner[1], self._lz_extra)
         parts = self._lz_parts if self._lz_parts is not None else [self]
         if any(q._lz_plain is not None for q in parts):      # (a node's colours were used elsewhere meanwhile: they exist, concatenate them)
             return None
@@ -334,6 +362,12 @@ class _LazySH(Tensor):
                 and (kwargs.get("dim", args[1] if len(args) > 1 else 0) in (0, -2)) and len(args) <= 2 \
                 and all(type(q) is _LazySH for q in args[0]):
             got = _LazySH._cat(list(args[0]))
+            if got is not None:
+                return got
+        if func in _LAZY_CAT and args and isinstance(args[0], (list, tuple)) and len(args[0]) >= 2 and not (set(kwargs) - {"dim"}) \
+                and (kwargs.get("dim", args[1] if len(args) > 1 else 0) in (1, -1)) and len(args) <= 2 \
+                and type(args[0][0]) is _LazySH and not any(isinstance(q, _LazySH) for q in args[0][1:]):
+            got = _LazySH._with_extra(args[0][0], list(args[0][1:]))
             if got is not None:
                 return got
         if me is not None and me._lz_plain is None:

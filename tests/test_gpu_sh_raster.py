@@ -104,8 +104,9 @@ def test_normalised_directions_frozen_coefficients_and_inference(hip_lib):
 
 
 def test_what_the_rasterization_cannot_take_over_is_evaluated_in_full(hip_lib):
-    """Several cameras, a background, extra channels behind the colours (MTGS's predict_normals: torch.cat), the colours used a second
-    time, directions with a gradient: the deferred object turns into the fused kernel's ordinary tensor -- same results as PyTorch's."""
+    """Several cameras, a background, channels in FRONT of the colours, the colours used a second time, directions with a gradient: the
+    deferred object turns into the fused kernel's ordinary tensor -- same results as PyTorch's.  (Channels BEHIND the colours --
+    MTGS's predict_normals -- are taken over with them.)"""
     from mtgs_amd import rasterization, spherical_harmonics, wrapper
     from mtgs_amd.synthetic import make_camera
     N, W, H = 60_000, 320, 200
@@ -132,6 +133,8 @@ def test_what_the_rasterization_cannot_take_over_is_evaluated_in_full(hip_lib):
                     out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, backgrounds=bg, **kw)
                 elif case == "extra_channels":
                     out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], torch.cat([rgb, extra], dim=-1), vm, K, W, H, **kw)
+                elif case == "extra_in_front":
+                    out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], torch.cat([extra, rgb], dim=-1), vm, K, W, H, **kw)
                 elif case == "used_twice":
                     out = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, **kw)
                     reg = (rgb * rgb).sum() * 1e-3
@@ -142,12 +145,14 @@ def test_what_the_rasterization_cannot_take_over_is_evaluated_in_full(hip_lib):
             wrapper.call = real
         return out[0].detach(), {k: v.grad.clone() for k, v in P.items()}, calls
 
-    for case in ("two_cameras", "background", "extra_channels", "used_twice", "dirs_grad"):
+    for case in ("two_cameras", "background", "extra_channels", "extra_in_front", "used_twice", "dirs_grad"):
         r1, g1, c1 = run(True, case)
         r0, g0, c0 = run(False, case)
         assert torch.equal(r1, r0), case
         if case == "used_twice":      # the rasterization took the colours over; the second use evaluated them in full once more
             assert "mtgs_vis_color_fwd_dirs" in c1 and "mtgs_sh_fwd_act" in c1, c1
+        elif case == "extra_channels":      # channels BEHIND the colours (MTGS's normals) stay deferred with them
+            assert "mtgs_vis_color_fwd_dirs" in c1 and "mtgs_sh_fwd_act" not in c1, c1
         else:
             assert "mtgs_vis_color_fwd_dirs" not in c1 and "mtgs_sh_fwd_act" in c1, (case, c1)
         for k in g0:
@@ -320,3 +325,49 @@ def test_concatenated_nodes_with_a_frozen_node_and_in_inference(hip_lib):
     r4, m4, calls4 = run_all_frozen()
     assert torch.equal(r4, r0) and "mtgs_vis_color_fwd_dirs" in calls4 and "mtgs_vis_color_bwd_dirs" not in calls4
     torch.testing.assert_close(m4, m3, rtol=1e-3, atol=1e-5 * float(m3.abs().max()))
+
+
+@pytest.mark.parametrize("render_mode,dx", [("RGB+ED", 3), ("RGB", 3), ("RGB+ED", 1), ("RGB", 5)])
+def test_channels_concatenated_behind_the_colours_stay_deferred(hip_lib, render_mode, dx):
+    """config/MTGS.py renders `torch.cat([rgbs, normals], dim=-1)` (predict_normals, mtgs_scene_graph.py:636-638; RGB+ED: seven
+    blended channels): the colours stay deferred through that concatenation too -- the rasterization evaluates them for the visible
+    Gaussians and takes the further channels as they are; same render bit for bit, the further channels receive their dense gradient."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    N, W, H = 150_000, 512, 288
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=23)
+    g = torch.Generator().manual_seed(5)
+    extra0 = torch.randn(N, dx, generator=g).to(dev)
+    cuts = [0, 90_000, N]
+
+    def run(mode):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items() if k != "coeffs"}
+        Cs = [sc["coeffs"][a:b].to(dev).clone().requires_grad_(True) for a, b in zip(cuts[:-1], cuts[1:])]
+        extra = extra0.clone().requires_grad_(True)
+        calls = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(mode != "torch", raster=mode == "raster"):
+                rgbs = torch.cat([torch.clamp(spherical_harmonics(3, P["means"][a:b].detach() - cam, Cs[i]) + 0.5, 0.0, 1.0)
+                                  for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))], dim=0)
+                colors = torch.cat([rgbs, extra * 0.5], dim=-1)      # (the further channels come out of the caller's own autograd graph)
+                deferred = type(colors).__name__ == "_LazySH"
+                render, alpha, info = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], colors, vm, K, W, H, packed=False,
+                                                    render_mode=render_mode, absgrad=True, rasterize_mode="antialiased")
+                info["means2d"].retain_grad()
+                Gr = torch.randn(render.shape, generator=torch.Generator().manual_seed(9)).to(dev)
+                ((render * Gr).sum() + (alpha * Ga).sum()).backward()
+        finally:
+            wrapper.call = real
+        grads = {k: v.grad.clone() for k, v in P.items()}
+        grads.update(extra=extra.grad.clone(), c0=Cs[0].grad.clone(), c1=Cs[1].grad.clone(), m2d=info["means2d"].grad.clone())
+        return render.detach(), alpha.detach(), grads, calls, deferred
+
+    r1, a1, g1, calls, d1 = run("raster")
+    r0, a0, g0, _, d0 = run("torch")
+    assert d1 and not d0 and "mtgs_vis_color_fwd_dirs" in calls and not [n for n in calls if n.startswith("mtgs_sh_")], calls
+    assert r1.shape[-1] == 3 + dx + int(render_mode != "RGB") and torch.equal(r1, r0) and torch.equal(a1, a0)
+    for k in g0:
+        assert torch.equal(g1[k] != 0, g0[k] != 0), k
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-3, atol=1e-5 * float(g0[k].abs().max()), msg=lambda m: f"{k}: {m}")
+    assert float(g0["extra"].abs().sum()) > 0 and float(g0["c1"].abs().sum()) > 0

@@ -275,6 +275,19 @@ def test_deferred_sh_dispatch_rules_on_cpu(monkeypatch):
         assert type(z) is torch.Tensor and z.shape == (14, 3)
     assert type(torch.cat([mk(), mk()], dim=1)) is torch.Tensor
     seen.clear()
+    # further channels behind the colours (MTGS's predict_normals: torch.cat([rgbs, normals], dim=-1)) stay deferred too
+    nrm = torch.randn(7, 3, requires_grad=True)
+    z = torch.cat([mk(), nrm], dim=-1)
+    assert not seen and type(z) is wrapper._LazySH and z.shape == (7, 6) and z.requires_grad and z._lz_extra is nrm
+    assert torch.equal(z, torch.cat([want, nrm], dim=-1)) and seen == [(True, 0.5, 0.0, 1.0)]
+    seen.clear()
+    z = torch.cat([torch.cat([mk(), mk()]), torch.cat([nrm, nrm]).detach(), torch.ones(14, 1)], dim=1)      # nodes, then two tensors behind
+    assert not seen and type(z) is wrapper._LazySH and z.shape == (14, 7) and z._lz_extra.shape == (14, 4)
+    assert type(torch.cat([z, z])) is torch.Tensor      # (not a part of a node concatenation any more)
+    seen.clear()
+    for parts in ([nrm, mk()], [mk(), torch.randn(7, 6)], [mk(), torch.randn(6, 3)], [mk(), nrm.double()]):      # colours not first / > 8 channels / other N / other dtype
+        assert type(torch.cat(parts, dim=-1) if parts[1].shape[0] == 7 else torch.cat([parts[0][:6], parts[1]], dim=-1)) is torch.Tensor
+    seen.clear()
     c8 = torch.randn(7, 9, 3)
     y = torch.clamp(wrapper._LazySH(2, d, c8, None) + 0.5, 0.0, 1.0)      # K != 16: at once
     assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor
