@@ -858,7 +858,8 @@ int mtgs_vis_color_bwd(int n_nodes, const mtgs_node_desc *table, int degree, con
  * colors) followed by torch.clamp(. + 0.5, 0, 1) (vanilla_gaussian_splatting.py:313-318), evaluated for the Gaussians the projection
  * found visible when the caller hands the result to rasterization() (mtgs_amd/wrapper.py, _LazySH): bit-identical colours to
  * mtgs_sh_fwd_act with K = 16 for those Gaussians, no [N, 3] colour tensor, no read of the other ~85 % of the coefficient rows.
- * With dirs the directions are not differentiated: dir_rows / dir_part must be NULL. */
+ * dir_rows / dir_part with dirs: d L / d dirs[vis_ids[r]] of the visible rows (through the kernel's normalisation), for callers whose
+ * directions carry a gradient (MTGS with its camera optimizer: viewdirs = means.detach() - camera_to_worlds[..., :3, 3]). */
 int mtgs_vis_color_fwd_dirs(int n_nodes, const mtgs_node_desc *table, int degree, const float *cam_pos, const float *means,
                             const int32_t *vis_ids, const int64_t *totals, int64_t cap_vis, float *recs, uint8_t *vis_mask,
                             const float *coef_rows, int64_t coef_stride, const uint8_t *row_flags, const float *dirs, void *stream);

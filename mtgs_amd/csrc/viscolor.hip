@@ -415,7 +415,6 @@ extern "C" int mtgs_vis_color_bwd_dirs(int n_nodes, const mtgs_node_desc *table,
     MTGS_REQUIRE(table && (dirs || (cam_pos && means)) && vis_ids && totals && grad_rows && recs && vis_mask && (feat_rows || dense_rows) &&
                      (!dir_rows == !dir_part),
                  MTGS_EINVAL, "mtgs_vis_color_bwd: null pointer (dir_rows and dir_part go together; feat_rows or dense_rows)");
-    MTGS_REQUIRE(!dirs || !dir_rows, MTGS_EINVAL, "mtgs_vis_color_bwd: dir_rows is the gradient of directions mean - cam_pos (not of `dirs`)");
     // (dense_rows: ONE zeroed [N, 16, 3] buffer in collected order -- with several nodes, each node's gradient is its slice
     //  [start, start + n) of it, which takes plain K = 16 coefficient rows in every node: sh_direction_source / sh_coefficient_source)
     hipStream_t st = (hipStream_t)stream;

@@ -311,11 +311,10 @@ class _LazySH(Tensor):
 
     def _raster_form(self, lo: float, hi: float) -> bool:
         """clamp(self, lo, hi) is a colour activation rasterization() can evaluate for the VISIBLE Gaussians by itself
-        (csrc/viscolor.hip: MTGS's clamp(x + 0.5, 0, 1), gsplat's clamp_min(x + 0.5, 0); K = 16 coefficient rows, given directions
-        without a gradient): the clamp then stays deferred too, see raster_source()."""
+        (csrc/viscolor.hip: MTGS's clamp(x + 0.5, 0, 1), gsplat's clamp_min(x + 0.5, 0); K = 16 coefficient rows, given directions): the clamp then stays deferred too, see raster_source()."""
         degree, dirs, coeffs, masks = self._lz_sh
         return (_lazy_raster_enabled and self._lz_add == 0.5 and lo == 0.0 and hi in (1.0, float("inf")) and masks is None
-                and degree <= 3 and dirs.dim() == 2 and coeffs.dim() == 3 and coeffs.shape[1] == 16 and not dirs.requires_grad)
+                and degree <= 3 and dirs.dim() == 2 and coeffs.dim() == 3 and coeffs.shape[1] == 16)
 
     def exchange_source(self, n: int):
         """ColorSource for a data-parallel frame (dist.SparseGradExchange.rasterization: `sh_out` = the RAW SH output of this rank's
@@ -346,7 +345,12 @@ class _LazySH(Tensor):
             return None
         from .nodes import sh_direction_source
         coeffs, dirs = [q._lz_sh[2] for q in parts], [q._lz_sh[1] for q in parts]
-        return sh_direction_source(coeffs, self._lz_sh[0], dirs, 1 if self._lz_act[1] == 1.0 else 4), coeffs
+        dirs_grad = torch.is_grad_enabled() and any(d.requires_grad for d in dirs)      # (MTGS with a camera optimizer: viewdirs carry one)
+        if dirs_grad and _graph.caps is not None:
+            return None      # (graph mode: the visible list is capacity-sized; the scatter of the direction gradient is not)
+        cs = sh_direction_source(coeffs, self._lz_sh[0], dirs, 1 if self._lz_act[1] == 1.0 else 4)
+        cs.dirs_inputs = dirs if dirs_grad else None
+        return cs, coeffs
 
     def _fused(self, lo: float, hi: float) -> Tensor:
         has_add = self._lz_add is not None
@@ -952,7 +956,8 @@ class _FusedRasterization(torch.autograd.Function):
         sh_coeffs [N,K,3], campos [3] (with cs.autograd): gsplat's own `sh_degree` call style -- the coefficient gradient is
         expanded to a dense tensor for autograd, and the view directions are differentiable (means, camera position).
         sh_more (with cs.dirs, sh_direction_source): the coefficient tensors of the further nodes, in collected order -- node i's
-        gradient is the slice [start_i, start_i + n_i) of the dense one."""
+        gradient is the slice [start_i, start_i + n_i) of the dense one --, then (cs.dirs_inputs) every node's direction tensor when
+        the directions carry a gradient: theirs is the slice of a dense [N, 3] one."""
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
         means, quats, scales, opacities, col, viewmats, Ks, bg = map(
             _f32c, (means, quats, scales, opacities, colors, viewmats, Ks, backgrounds))
@@ -1094,7 +1099,7 @@ class _FusedRasterization(torch.autograd.Function):
                     #  rows of the Gaussians with a cotangent straight into it, mtgs_vis_color_bwd(dense_rows))
                     n_coef_ = N * 48 if (cs is not None and cs.autograd and cs.width == 48 and (cs.n_nodes == 1 or cs.dirs is not None)
                                          and (graph_caps is None or cs.dirs is not None)
-                                         and (ctx.needs_input_grad[20] or any(ctx.needs_input_grad[22:]))) else 0
+                                         and (ctx.needs_input_grad[20] or any(ctx.needs_input_grad[22:22 + cs.n_nodes - 1]))) else 0
                     z_ptr, z_bytes, own_ = _prefill.take(dev, n_rows_ + n_coef_, only=getattr(_sh_scope, "reqs", ()))
                     ctx_box["rows"] = own_[:n_rows_].view(max(b["cap_vis"], 1), RS_)
                     if n_coef_:
@@ -1228,9 +1233,12 @@ class _FusedRasterization(torch.autograd.Function):
             # them through the row map (vis_rank: rank or -1) -- no dense [N, (T,) K, 3] gradient is written
             dense_coeffs = getattr(ctx, "zero_coeffs", None) if cs.autograd else None      # (zeroed by the forward's compositing kernel)
             ctx.zero_coeffs = None
-            want_dirs = cs.autograd and cs.dirs is None      # (given directions -- MTGS's call style -- carry no gradient)
+            n_c = 22 + cs.n_nodes - 1      # (inputs 20, 22 .. n_c - 1: the nodes' coefficient tensors; n_c ..: their direction tensors, if given)
+            need_coef = bool(ctx.needs_input_grad[20] or any(ctx.needs_input_grad[22:n_c]))
+            need_dirs = bool(getattr(cs, "dirs_inputs", None)) and any(ctx.needs_input_grad[n_c:])
+            want_dirs = cs.autograd and (cs.dirs is None or need_dirs)      # (given directions carry a gradient only with a camera optimizer)
             feat = dir_rows = dir_part = None
-            if not (cs.autograd and cs.dirs is not None and not (ctx.needs_input_grad[20] or any(ctx.needs_input_grad[22:]))):      # (frozen coefficients: nothing to do)
+            if not (cs.autograd and cs.dirs is not None and not (need_coef or need_dirs)):      # (frozen coefficients: nothing to do)
                 feat = torch.empty((max(n_vis, 1), 48), dtype=torch.float32, device=dev) if dense_coeffs is None else None
                 dir_rows = torch.empty((max(n_vis, 1), 3), dtype=torch.float32, device=dev) if want_dirs else None
                 dir_part = torch.zeros((-(-max(n_vis, 1) // 64), 3), dtype=torch.float32, device=dev) if want_dirs else None      # (MTGS_VIS_COLOR_ROWS)
@@ -1337,15 +1345,27 @@ class _FusedRasterization(torch.autograd.Function):
             K3 = cs.width
             if dense_coeffs is not None:
                 d_coeffs = dense_coeffs
-            elif feat is not None:
+            elif feat is not None and (cs.dirs is None or need_coef):
                 d_coeffs = torch.empty((N, K3 // 3, 3), dtype=torch.float32, device=dev)
                 call("mtgs_rows_expand", N, K3, ptr(vis_rank), ptr(feat), 48, ptr(d_coeffs), st)
             if cs.dirs is not None:
                 d_campos = None
+                n_c = 22 + cs.n_nodes - 1
+                need_c = [ctx.needs_input_grad[20]] + list(ctx.needs_input_grad[22:n_c])
+                d_dirs = ()
+                if len(ctx.needs_input_grad) > n_c:      # directions with a gradient: the visible rows scattered into a dense [N, 3]
+                    v_dirs = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+                    if dir_rows is not None and n_vis > 0:
+                        v_dirs.index_copy_(0, vis_ids[:n_vis].long(), dir_rows[:n_vis])
+                    d_dirs = tuple(v_dirs[s:s + n_] if nd else None for (s, n_, *_), nd in zip(cs.node_params, ctx.needs_input_grad[n_c:]))
+                if d_coeffs is not None and not any(need_c):
+                    d_coeffs = None
                 if cs.n_nodes > 1 and d_coeffs is not None:      # one dense buffer in collected order: every node's gradient is its slice
-                    need_c = [ctx.needs_input_grad[20]] + list(ctx.needs_input_grad[22:])
                     parts = [d_coeffs[s:s + n_] if nd else None for (s, n_, *_), nd in zip(cs.node_params, need_c)]
                     d_coeffs, d_more = parts[0], tuple(parts[1:])
+                else:
+                    d_more = (None,) * (cs.n_nodes - 1)
+                d_more = d_more + d_dirs
             elif n_vis > 0:
                 d_campos = -dir_part.sum(0)
             else:
@@ -1426,7 +1446,8 @@ def fused_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, b
         out = _FusedRasterization.apply(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, int(width),
                                         int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                         bool(calc_compensations), bool(with_depth), bool(expected_depth), bool(absgrad), dp,
-                                        color_source, *_sh_inputs(sh_source))
+                                        color_source, *_sh_inputs(sh_source),
+                                        *(getattr(color_source, "dirs_inputs", None) or ()))
     finally:
         _sh_scope.reqs = ()
     (render, alphas, radii, means2d, depths, conics, comps, opac_eff, tiles_per_gauss, isect_ids, flatten_ids,
