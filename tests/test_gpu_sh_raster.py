@@ -420,3 +420,35 @@ def test_directions_with_a_gradient_stay_deferred(hip_lib):
     r3, cam3, _, _, _, _ = run("torch", frozen_coeffs=True)
     assert torch.equal(r2, r3) and c2[0] is None and "mtgs_rows_expand" not in calls2
     torch.testing.assert_close(cam2, cam3, rtol=2e-3, atol=2e-5 * float(cam3.abs().max()))
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2])
+def test_lower_degrees_of_the_sh_schedule(hip_lib, degree):
+    """MTGS raises the SH degree with the step count (n = min(step // sh_degree_interval, sh_degree), vanilla_gaussian_splatting.py:315)
+    on coefficient tensors that hold all 16 rows from the start: degrees 0 .. 2 on K = 16 through the rasterization, bit for bit."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    N, W, H = 100_000, 400, 240
+    sc, vm, K, Gc, Ga, cam, dev = _scene(N, W, H, seed=31)
+
+    def run(mode):
+        P = {k: v.to(dev).requires_grad_(True) for k, v in sc.items()}
+        calls = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(mode != "torch", raster=mode == "raster"):
+                rgb = torch.clamp(spherical_harmonics(degree, P["means"].detach() - cam, P["coeffs"]) + 0.5, 0.0, 1.0)
+                render, alpha, _ = rasterization(P["means"], P["quats"], P["scales"], P["opacities"], rgb, vm, K, W, H, packed=False,
+                                                 render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+                ((render * Gc).sum() + (alpha * Ga).sum()).backward()
+        finally:
+            wrapper.call = real
+        return render.detach(), P["coeffs"].grad.clone(), calls
+
+    r1, c1, calls = run("raster")
+    r0, c0, _ = run("torch")
+    assert "mtgs_vis_color_fwd_dirs" in calls and torch.equal(r1, r0)
+    nb = (degree + 1) ** 2
+    assert float(c1[:, nb:].abs().max()) == 0.0 and float(c0[:, nb:].abs().max()) == 0.0      # (the bands above the degree in use)
+    assert torch.equal(c1 != 0, c0 != 0) and float(c0.abs().sum()) > 0
+    torch.testing.assert_close(c1, c0, rtol=1e-3, atol=1e-5 * float(c0.abs().max()))
