@@ -452,3 +452,68 @@ def test_lower_degrees_of_the_sh_schedule(hip_lib, degree):
     assert float(c1[:, nb:].abs().max()) == 0.0 and float(c0[:, nb:].abs().max()) == 0.0      # (the bands above the degree in use)
     assert torch.equal(c1 != 0, c0 != 0) and float(c0.abs().sum()) > 0
     torch.testing.assert_close(c1, c0, rtol=1e-3, atol=1e-5 * float(c0.abs().max()))
+
+
+def test_the_colour_path_of_config_mtgs_py_end_to_end(hip_lib):
+    """Everything config/MTGS.py does between its parameters and rasterization(), at once: per-node get_rgbs() on
+    `torch.cat((features_dc[:, None, :], features_rest), dim=1)` with view directions from the OPTIMISED camera, normalised in PyTorch
+    (vanilla_gaussian_splatting.py:309-322), the scene graph's `torch.cat(value, dim=0)` of every collected tensor
+    (mtgs_scene_graph.py:451-452), camera-space normals concatenated behind the colours (:636-638), RGB+ED / antialiased / absgrad
+    (:641-659), `retain_grad()` on means2d (:666-668).  Deferred all the way against PyTorch's evaluation: the same render bit for bit,
+    the same gradients of every leaf (features_dc, features_rest, geometry, camera position)."""
+    from mtgs_amd import rasterization, spherical_harmonics, wrapper
+    N, W, H = 160_000, 640, 368
+    sc, vm, K, _, Ga, cam0, dev = _scene(N, W, H, seed=37)
+    cuts = [0, 100_000, 100_300, N]      # a background node, a small object node, another node
+    Gr = torch.randn(1, H, W, 7, generator=torch.Generator().manual_seed(6)).to(dev)
+
+    def run(mode):
+        leaves = {}
+        nodes = []
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            nd = {"means": sc["means"][a:b].to(dev).clone().requires_grad_(True), "quats": sc["quats"][a:b].to(dev).clone().requires_grad_(True),
+                  "scales": sc["scales"][a:b].to(dev).clone().requires_grad_(True), "opacities": sc["opacities"][a:b].to(dev).clone().requires_grad_(True),
+                  "features_dc": sc["coeffs"][a:b, 0].to(dev).clone().requires_grad_(True),
+                  "features_rest": sc["coeffs"][a:b, 1:].to(dev).clone().requires_grad_(True)}
+            nodes.append(nd)
+            leaves.update({f"{k}{i}": v for k, v in nd.items()})
+        campos = cam0.clone().requires_grad_(True)
+        leaves["campos"] = campos
+        calls = []
+        real = wrapper.call
+        try:
+            wrapper.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            with wrapper.sh_lazy(mode != "torch", raster=mode == "raster"):
+                gs = {"means": [], "quats": [], "scales": [], "opacities": [], "rgbs": []}
+                for nd in nodes:
+                    colors = torch.cat((nd["features_dc"][:, None, :], nd["features_rest"]), dim=1)
+                    viewdirs = nd["means"].detach() - campos
+                    viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+                    rgbs = torch.clamp(spherical_harmonics(3, viewdirs, colors) + 0.5, 0.0, 1.0)
+                    for k in ("means", "quats", "scales", "opacities"):
+                        gs[k].append(nd[k])
+                    gs["rgbs"].append(rgbs)
+                col = {k: torch.cat(v, dim=0) for k, v in gs.items()}
+                normals = torch.nn.functional.normalize(col["quats"][:, 1:] * col["scales"], dim=1)      # (a stand-in with the real one's graph shape)
+                render_colors = torch.cat([col["rgbs"], normals], dim=-1)
+                deferred = type(render_colors).__name__ == "_LazySH"
+                render, alpha, info = rasterization(means=col["means"], quats=col["quats"], scales=col["scales"], opacities=col["opacities"],
+                                                    colors=render_colors, viewmats=vm, Ks=K, width=W, height=H, tile_size=16, packed=False,
+                                                    near_plane=0.01, far_plane=1e10, render_mode="RGB+ED", sparse_grad=False, absgrad=True,
+                                                    rasterize_mode="antialiased")
+                info["means2d"].retain_grad()
+                ((render * Gr).sum() + (alpha * Ga).sum()).backward()
+        finally:
+            wrapper.call = real
+        grads = {k: v.grad.clone() for k, v in leaves.items()}
+        grads["absgrad"] = info["means2d"].absgrad.clone()
+        return render.detach(), grads, calls, deferred
+
+    r1, g1, calls, d1 = run("raster")
+    r0, g0, _, d0 = run("torch")
+    assert d1 and not d0 and calls.count("mtgs_vis_color_fwd_dirs") == 1 and not [n for n in calls if n.startswith("mtgs_sh_")], calls
+    assert r1.shape[-1] == 7 and torch.equal(r1, r0)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert scale > 0 or k.startswith(("features", "means", "quats", "scales", "opacities")), k
+        torch.testing.assert_close(g1[k], g0[k], rtol=2e-3, atol=2e-5 * max(scale, 1e-20), msg=lambda m: f"{k}: {m}")
