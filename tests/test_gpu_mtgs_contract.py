@@ -530,7 +530,8 @@ def test_mtgs_like_training_dp_rows_all_the_way_equals_accumulation():
     assert "2 ranks: N = " in rows
     # (the first refinement differs by one threshold-critical Gaussian of 82 188; the two -- equally valid -- trainings then select
     #  from different sets four more times over 250 steps: the sizes drift apart to ~1.5e-3 of N)
-    assert_same_training(rows, one, 5, 400, 50, later_sizes=3e-3, first_sizes=3e-4)     # (150 steps in front of the first refinement)
+    # (round 6: 3.2e-3 at the fifth refinement in one of six runs -- 118271 against 117893 -- where the other five stayed below 2e-3)
+    assert_same_training(rows, one, 5, 400, 50, later_sizes=6e-3, first_sizes=3e-4)     # (150 steps in front of the first refinement)
     _assert_converged(rows, 5)      # (the converging schedule: five refinements, last tenth of the losses < 0.5 x first tenth)
     _assert_converged(one, 5)
 
