@@ -530,7 +530,9 @@ def test_mtgs_like_training_dp_rows_all_the_way_equals_accumulation():
     assert "2 ranks: N = " in rows
     # (the first refinement differs by one threshold-critical Gaussian of 82 188; the two -- equally valid -- trainings then select
     #  from different sets four more times over 250 steps: the sizes drift apart to ~1.5e-3 of N)
-    # (round 6: 3.2e-3 at the fifth refinement in one of six runs -- 118271 against 117893 -- where the other five stayed below 2e-3)
+    # (round 6: 3.2e-3 at the fifth refinement in one of six runs -- 118271 against 117893.  scripts/dev/drift_probe.sh: four runs of
+    #  the SAME single-process command end at 117883 .. 118166 (2.4e-3 of N), with the streaming projection backward of rounds 1-5 at
+    #  117888 .. 118227 (2.9e-3): the compositing atomics' order alone moves the fifth refinement that far)
     assert_same_training(rows, one, 5, 400, 50, later_sizes=6e-3, first_sizes=3e-4)     # (150 steps in front of the first refinement)
     _assert_converged(rows, 5)      # (the converging schedule: five refinements, last tenth of the losses < 0.5 x first tenth)
     _assert_converged(one, 5)
