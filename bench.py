@@ -22,6 +22,12 @@ mtgs_amd.graph_mode + torch.cuda.graph and replayed: same kernels, same inputs, 
 follows the box's CPU load (1.00 ... 1.22 ms measured on one box within minutes, next to 0.94 ms of GPU work); the line carries the
 faster of the two and names it in config.launch, both are in ms_per_step_eager / ms_per_step_graph.
 
+The step is the caller's code as MTGS writes it; what the library makes of it is the library's business and is named in
+config.colour_activation: spherical_harmonics() and the clamp return a DEFERRED tensor and rasterization() evaluates SH + clamp for
+the Gaussians its projection finds visible (same render bit for bit).  Beside `ms_per_step` the line carries the same step with SH +
+clamp as one kernel over all N (`ms_per_step_sh_over_all_gaussians`), with the clamp as PyTorch's kernels
+(`ms_per_step_torch_activation`: what rounds 1-5 measured) and on the opt-in tight tile lists (`ms_per_step_tight_lists`).
+
 Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline` describes the
 dominant kernel (compositing backward) with its duration measured live by HIP events on the
 launch stream; `cpu_baseline` times oracle/gsplat_oracle.c (the CPU restatement, "port") on the
