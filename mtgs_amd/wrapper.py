@@ -252,7 +252,18 @@ class _LazySH(Tensor):
         r = Tensor._make_wrapper_subclass(cls, dirs.shape, dtype=torch.float32, device=dirs.device, requires_grad=rg)
         r._lz_sh = (degree, dirs, coeffs, masks)
         r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts, r._lz_extra = base, add, act, None, None, None
+        # (the evaluation is deferred, its inputs must not be: an in-place change of the directions or coefficients between the call
+        #  and the first use would be seen by the deferred kernel and not by PyTorch's evaluation -- caught like autograd catches it)
+        r._lz_ver = base._lz_ver if base is not None else (dirs._version, coeffs._version)
         return r
+
+    def _check_inputs(self):
+        if self._lz_extra is not None and self._lz_extra._version != self._lz_extra_ver:
+            raise RuntimeError("torch.cat([colours, channels], dim=-1) on deferred spherical_harmonics() colours: the channels were modified in "
+                               "place before the result was used; clone them, or evaluate at once with mtgs_amd.sh_lazy(False)")
+        if self._lz_sh[1] is not None and (self._lz_sh[1]._version, self._lz_sh[2]._version) != self._lz_ver:
+            raise RuntimeError("spherical_harmonics(): `dirs` or `coeffs` was modified in place between the call and the first use of its "
+                               "(deferred) result; clone the tensor, or evaluate at once with mtgs_amd.sh_lazy(False) / MTGS_SH_LAZY=0")
 
     @classmethod
     def _cat(cls, parts):
@@ -269,6 +280,7 @@ class _LazySH(Tensor):
                                           requires_grad=any(q.requires_grad for q in parts))
         r._lz_sh = (first._lz_sh[0], None, None, None)
         r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts, r._lz_extra = None, None, first._lz_act, None, list(parts), None
+        r._lz_ver = None
         return r
 
     @classmethod
@@ -291,6 +303,8 @@ class _LazySH(Tensor):
                                           requires_grad=bool(inner.requires_grad or (torch.is_grad_enabled() and extra.requires_grad)))
         r._lz_sh = inner._lz_sh
         r._lz_base, r._lz_add, r._lz_act, r._lz_plain, r._lz_parts, r._lz_extra = inner, None, inner._lz_act, None, None, extra
+        r._lz_ver = inner._lz_ver
+        r._lz_extra_ver = extra._version
         return r
 
     def _materialize(self) -> Tensor:
@@ -298,6 +312,7 @@ class _LazySH(Tensor):
         if self._lz_plain is None:
             with torch._C.DisableTorchFunctionSubclass():
                 if self._lz_extra is not None:
+                    self._check_inputs()
                     self._lz_plain = torch.cat([self._lz_base._materialize(), self._lz_extra], dim=-1)
                 elif self._lz_parts is not None:
                     self._lz_plain = torch.cat([q._materialize() for q in self._lz_parts], dim=0)
@@ -306,6 +321,7 @@ class _LazySH(Tensor):
                 elif self._lz_base is not None:
                     self._lz_plain = self._lz_base._materialize() + self._lz_add
                 else:
+                    self._check_inputs()
                     self._lz_plain = _SphericalHarmonics.apply(*self._lz_sh)
         return self._lz_plain
 
@@ -325,6 +341,7 @@ class _LazySH(Tensor):
                 and degree <= 3 and dirs.dim() == 2 and dirs.shape == (n, 3) and n > 0 and coeffs.dim() == 3 and coeffs.shape[1] == 16):
             return None
         from .nodes import sh_direction_source
+        self._check_inputs()
         cs = sh_direction_source(coeffs, degree, dirs, 1)
         cs.autograd, cs.exchange = False, True
         return cs
@@ -336,6 +353,7 @@ class _LazySH(Tensor):
         if self._lz_act is None or self._lz_plain is not None:
             return None
         if self._lz_extra is not None:      # colours + further channels: (source, coefficients, the further channels [N, DX])
+            self._check_inputs()
             inner = self._lz_base.raster_source(n, width, height) if tuple(self.shape) == (n, 3 + self._lz_extra.shape[1]) else None
             return None if inner is None else (inner[0], inner[1], self._lz_extra)
         parts = self._lz_parts if self._lz_parts is not None else [self]
@@ -344,6 +362,8 @@ class _LazySH(Tensor):
         if tuple(self.shape) != (n, 3) or n == 0 or not _bin3_ok(1, -(-width // 16), -(-height // 16), 0):
             return None
         from .nodes import sh_direction_source
+        for q in parts:
+            q._check_inputs()
         coeffs, dirs = [q._lz_sh[2] for q in parts], [q._lz_sh[1] for q in parts]
         dirs_grad = torch.is_grad_enabled() and any(d.requires_grad for d in dirs)      # (MTGS with a camera optimizer: viewdirs carry one)
         if dirs_grad and _graph.caps is not None:
@@ -353,6 +373,7 @@ class _LazySH(Tensor):
         return cs, coeffs
 
     def _fused(self, lo: float, hi: float) -> Tensor:
+        self._check_inputs()
         has_add = self._lz_add is not None
         with torch._C.DisableTorchFunctionSubclass():
             return _SphericalHarmonics.apply(*self._lz_sh, (has_add, self._lz_add if has_add else 0.0, lo, hi))

@@ -288,6 +288,18 @@ def test_deferred_sh_dispatch_rules_on_cpu(monkeypatch):
     for parts in ([nrm, mk()], [mk(), torch.randn(7, 6)], [mk(), torch.randn(6, 3)], [mk(), nrm.double()]):      # colours not first / > 8 channels / other N / other dtype
         assert type(torch.cat(parts, dim=-1) if parts[1].shape[0] == 7 else torch.cat([parts[0][:6], parts[1]], dim=-1)) is torch.Tensor
     seen.clear()
+    # the evaluation is deferred, the inputs are not: an in-place change between the call and the first use is an error, as in autograd
+    cc = torch.randn(7, 16, 3)
+    z = torch.clamp(wrapper._LazySH(3, d, cc, None) + 0.5, 0.0, 1.0)
+    cc.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        z * 1.0
+    e2 = torch.randn(7, 3)
+    z = torch.cat([mk(), e2], dim=-1)
+    e2.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in\n? ?place|modified in place"):
+        z * 1.0
+    seen.clear()
     c8 = torch.randn(7, 9, 3)
     y = torch.clamp(wrapper._LazySH(2, d, c8, None) + 0.5, 0.0, 1.0)      # K != 16: at once
     assert seen == [(True, 0.5, 0.0, 1.0)] and type(y) is torch.Tensor
